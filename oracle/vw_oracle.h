@@ -1,0 +1,64 @@
+/* vw_oracle.h — C interface of the CPU parity oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a dependency-free restatement of the
+ * Vision Workbench reference algorithms on the dense block-matching hot path.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * it; the product (visionworkbench_amd, libvwgpu.so) never does.
+ *
+ * The reference itself cannot be compiled here (every VW header needs Boost,
+ * first failure src/vw/Core/FundamentalTypes.h:32), so each function below
+ * cites the reference file:line it restates and is pinned by the reference's
+ * own known-answer tests re-typed in tests/test_oracle_golden.py.
+ *
+ * Image layout everywhere: row-major, contiguous, `cols` fastest
+ * (vw::ImageView, src/vw/Image/ImageView.h:209-239).
+ * Disparity layout: 3 x int32 per pixel {dx, dy, valid}, valid = INT32_MAX or 0
+ * (vw::PixelMask<Vector2i>, src/vw/Image/PixelMask.h:48-120).
+ */
+#ifndef VW_ORACLE_H
+#define VW_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* CostFunctionType, src/vw/Stereo/CostFunctions.h:143-149 */
+enum { VWO_ABSOLUTE_DIFFERENCE = 0, VWO_SQUARED_DIFFERENCE = 1, VWO_CROSS_CORRELATION = 2 };
+
+/* fast_box_sum<double>, src/vw/Stereo/Algorithms.h:43-129.
+ * in: w x h (float or double), out: (w-kx+1) x (h-ky+1) double. returns 0, or -1 on even kernel. */
+int vwo_fast_box_sum_f32(const float* in, int w, int h, int kx, int ky, double* out);
+int vwo_fast_box_sum_f64(const double* in, int w, int h, int kx, int ky, double* out);
+
+/* Per-pixel cost images (the lazy BinaryPerPixelView of CostFunctions.h:153-236 rasterised to double).
+ * NCC returns the raw float product (no normalisation), as NCCCost::operator() does. */
+int vwo_cost_image(int cost_type, const float* a, const float* b, int w, int h, double* out);
+
+/* best_of_search_convolution, src/vw/Stereo/Correlation.cc:33-137, on already-cropped rasters
+ * (what calc_disparity, Correlation.cc:330-375, hands it):
+ *   left  lw x lh, right rw x rh with rw >= lw+sx-1, rh >= lh+sy-1 (row strides in elements).
+ *   out   (lw-kx+1) x (lh-ky+1) x {dx,dy,valid}. */
+int vwo_calc_disparity(int cost_type,
+                       const float* left, int lw, int lh, int64_t lstride,
+                       const float* right, int rw, int rh, int64_t rstride,
+                       int kx, int ky, int sx, int sy, int32_t* out);
+
+/* The reference's real execution model for a big image: output split into tile x tile blocks,
+ * `threads` workers pull tiles from a queue, each tile calls single-threaded calc_disparity on its
+ * padded crop (src/vw/Image/ImageIO.h:228-251, src/vw/tools/correlate.cc:266).
+ * max_tiles > 0 bounds the number of tiles processed (bench sample); returns #output pixels done
+ * through *pixels_done. */
+int vwo_calc_disparity_tiled(int cost_type,
+                             const float* left, int lw, int lh,
+                             const float* right, int rw, int rh,
+                             int kx, int ky, int sx, int sy, int32_t* out,
+                             int tile, int threads, int max_tiles, int64_t* pixels_done);
+
+/* cross_corr_consistency_check, src/vw/Stereo/Correlate.cc:1441-1502 (in place on l2r). */
+int vwo_cross_corr_consistency_check(int32_t* l2r, int lw, int lh,
+                                     const int32_t* r2l, int rw, int rh, float thr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,159 @@
+"""Pins the CPU oracle against the reference's own known-answer tests.
+
+Each test is the re-typed body of a reference gtest; the citation is in the docstring.
+CPU only (no GPU needed).
+"""
+import numpy as np
+import pytest
+
+from visionworkbench_amd import synth
+
+
+def test_fast_box_float_ramp(oracle):
+    """src/vw/Stereo/tests/TestAlgorithms.cxx:46-72 (FastBoxFloat): 7x5 ramp 1..35, kernels (5,3) and (3,3)."""
+    img = np.arange(1, 36, dtype=np.float32).reshape(5, 7)
+    o53 = oracle.fast_box_sum(img, (5, 3))
+    assert o53.shape == (3, 3)
+    assert oracle.fast_box_sum(img, (3, 3)).shape == (3, 5)
+    # output(col,row) in VW == o[row, col] here
+    assert o53[0, 0] == 150 and o53[0, 1] == 165 and o53[0, 2] == 180
+    assert o53[2, 0] == 360 and o53[2, 1] == 375 and o53[2, 2] == 390
+
+
+def test_fast_box_double(oracle):
+    """TestAlgorithms.cxx:100-126 (FastBoxDouble): ones, first row = 2, input(6,0) = 3; kernel (3,3)."""
+    img = np.ones((5, 7), np.float64)
+    img[0, :] = 2
+    img[0, 6] = 3
+    o = oracle.fast_box_sum(img, (3, 3))
+    assert o.shape == (3, 5)
+    assert o[0, 0] == 12 and o[1, 0] == 9 and o[2, 0] == 9
+    assert o[0, 1] == 12 and o[0, 2] == 12 and o[0, 3] == 12 and o[0, 4] == 13
+
+
+def test_fast_box_char_values(oracle):
+    """TestAlgorithms.cxx:128-152 (FastBoxChar): 30-filled, first row 40, (6,0)=50; (5,3) kernel; 255 fill (5,5)."""
+    img = np.full((5, 7), 30, np.float32)
+    img[0, :] = 40
+    img[0, 6] = 50
+    o = oracle.fast_box_sum(img, (5, 3))
+    assert o[2, 0] == 450 and o[2, 2] == 450 and o[0, 0] == 500 and o[0, 2] == 510 and o[1, 1] == 450
+    assert oracle.fast_box_sum(np.full((5, 7), 255, np.float32), (5, 5))[0, 0] == 6375
+
+
+def test_fast_box_pixel_u8_values(oracle):
+    """TestAlgorithms.cxx:154-174 (FastBoxPixelU8): 27-filled, first row 40, kernel (5,3)."""
+    img = np.full((5, 7), 27, np.float32)
+    img[0, :] = 40
+    o = oracle.fast_box_sum(img, (5, 3))
+    assert (o[0, :] == 470).all() and (o[1, :] == 405).all() and o[2, 0] == 405 and o[2, 2] == 405
+
+
+def test_fast_box_even_kernel_rejected(oracle):
+    """Always-on VW_ASSERT, src/vw/Stereo/Algorithms.h:45-46."""
+    with pytest.raises(ValueError):
+        oracle.fast_box_sum(np.zeros((5, 7), np.float32), (4, 3))
+
+
+def _cost_fixture():
+    """SetUp of TestCostFunctions.cxx:40-50 for PixelGray<float> (ChannelRange max = 1.0)."""
+    a = np.zeros((2, 2), np.float32)
+    b = np.zeros((2, 2), np.float32)
+    a[0, 0] = b[0, 0] = 128          # input(0,0)
+    a[0, 1] = b[1, 0] = 10           # input1(1,0) = input2(0,1) = 10   [row, col] = (y, x)
+    b[0, 1] = a[1, 0] = 100          # input2(1,0) = input1(0,1) = 100
+    a[1, 1] = 0
+    b[1, 1] = 1.0
+    return a, b
+
+
+def test_cost_functions_per_pixel(oracle):
+    """TestCostFunctions.cxx:54-84: AbsDiff 0,90,90,max; SquaredDiff 0,8100,8100,max^2; CrossCorr 16384,1000,1000,0."""
+    a, b = _cost_fixture()
+    r = oracle.cost_image(oracle.ABSOLUTE_DIFFERENCE, a, b)
+    assert r[0, 0] == 0 and r[1, 0] == 90 and r[0, 1] == 90 and r[1, 1] == 1.0
+    r = oracle.cost_image(oracle.SQUARED_DIFFERENCE, a, b)
+    assert r[0, 0] == 0 and r[1, 0] == 8100 and r[0, 1] == 8100 and r[1, 1] == 1.0
+    r = oracle.cost_image(oracle.CROSS_CORRELATION, a, b)
+    assert r[0, 0] == 16384 and r[1, 0] == 1000 and r[0, 1] == 1000 and r[1, 1] == 0
+
+
+def _correlation_fixture(dtype_scale):
+    """SetUp of TestCorrelation.cxx:45-53: 25x25 noise; right = crop(edge_extend(left, Constant), -3, -8, 31, 46),
+    i.e. R(x, y) = L_clamped(x-3, y-8); kernel (7,5); search (7,12); solution (3,8).  Any PRNG will do."""
+    u = (synth.splitmix64(10, 25 * 25) >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+    left = (u.reshape(25, 25) * dtype_scale)
+    if dtype_scale > 1:
+        left = np.floor(left)
+    left = left.astype(np.float32)
+    ys = np.clip(np.arange(46) - 8, 0, 24)
+    xs = np.clip(np.arange(31) - 3, 0, 24)
+    right = left[np.ix_(ys, xs)]
+    return left, right
+
+
+@pytest.mark.parametrize("cost", [0, 1, 2])
+@pytest.mark.parametrize("scale", [255.0, 32767.0, 1.0])   # u8-, i16- and float-like fixtures
+def test_calc_disparity_recovers_shift(oracle, cost, scale):
+    """TestCorrelation.cxx:73-214: output 19x21, every pixel valid and == (3,8), for ABS/SQ/NCC."""
+    left, right = _correlation_fixture(scale)
+    d = oracle.calc_disparity(cost, left, right, (7, 5), (7, 12))
+    assert d.shape == (21, 19, 3)
+    assert (d[..., 2] == oracle.VALID).all()
+    assert (d[..., 0] == 3).all() and (d[..., 1] == 8).all()
+
+
+def test_search_volume_one_is_always_invalid(oracle):
+    """best == worst for a single disparity (Correlation.cc:110-117,121-133)."""
+    left, right = _correlation_fixture(255.0)
+    d = oracle.calc_disparity(0, left, right, (7, 5), (1, 1))
+    assert (d[..., 2] == 0).all() and (d[..., :2] == 0).all()
+
+
+def test_cross_corr_consistency(oracle):
+    """TestCorrelate.cxx:29-55 (CrossCorrConsistency), thresholds 0 and 2."""
+    V = oracle.VALID
+    l2r = np.zeros((3, 3, 3), np.int32)
+    r2l = np.zeros((3, 3, 3), np.int32)
+    l2r[..., 2] = V
+    r2l[..., 2] = V
+    l2r[:, 2, 0:2] = 2            # crop(l2r,2,0,1,3) = (2,2)
+    l2r[0, 0, 0:2] = 1            # l2r(0,0) = (1,1)
+    r2l[1, 1, 0:2] = -1           # r2l(1,1) = (-1,-1)
+    l2r[0, 1, 0:2] = 1            # l2r(1,0) = (1,1)
+
+    o = oracle.cross_corr_consistency_check(l2r, r2l, 0)
+    assert o[0, 2, 2] == 0 and o[1, 2, 2] == 0 and o[2, 2, 2] == 0
+    assert o[0, 0, 2] == V and o[0, 1, 2] == 0
+
+    o = oracle.cross_corr_consistency_check(l2r, r2l, 2)
+    assert o[0, 2, 2] == 0 and o[1, 2, 2] == 0 and o[2, 2, 2] == 0
+    assert o[0, 0, 2] == V and o[0, 1, 2] == V
+
+
+def test_tiled_equals_whole(oracle):
+    """Tile-threaded execution (ImageIO.h:228-251) must equal the single call — the same property
+    src/vw/Image/tests/TestBlockRasterize.cxx:26-47 checks for block rasterisation."""
+    left, right, _ = synth.stereo_pair(150, 90, 9, 2, block=32)
+    whole = oracle.calc_disparity(0, left, right, (5, 5), (9, 2))
+    tiled, done = oracle.calc_disparity_tiled(0, left, right, (5, 5), (9, 2), tile=64, threads=3)
+    assert done == whole.shape[0] * whole.shape[1]
+    assert np.array_equal(whole, tiled)
+
+
+def test_synthetic_pair_truth(oracle):
+    """The benchmark generator: interior pixels of each pasted block must recover centre + s_b."""
+    left, right, truth = synth.stereo_pair(128, 64, 33, 1, block=32)
+    d = oracle.calc_disparity(0, left, right, (5, 5), (33, 1))
+    oh, ow = d.shape[:2]
+    t = truth[:oh, :ow]
+    # pixels whose 5x5 window at the true disparity survived later pastes (zero SAD there)
+    yy, xx = np.mgrid[0:oh, 0:ow]
+    zero = np.ones((oh, ow), bool)
+    for j in range(5):
+        for i in range(5):
+            zero &= left[yy + j, xx + i] == right[yy + j, xx + i + t]
+    assert zero.mean() > 0.5
+    assert (d[..., 0][zero] <= t[zero]).all()          # first zero-cost disparity wins
+    assert (d[..., 2][zero] == oracle.VALID).all()
+    assert (d[..., 0][zero] == t[zero]).mean() > 0.99
