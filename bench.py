@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — disparity Mpix/s of the block-matching hot path on MI355X (BASELINE.json metric).
+
+Workload (BASELINE config 2): 4096x4096 synthetic stereo pair, 7x7 SAD, +-64 px search
+(search_volume 129x1), one call of vw::stereo::calc_disparity per step, inputs (float32 PixelGray images)
+already resident in HBM, output (PixelMask<Vector2i>, 12 B/px) left in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N > 1: launched by torch.distributed.run, one rank per GPU.  The pair is split into N row strips
+  (output rows [g*oh/N, (g+1)*oh/N) on rank g, input strip + ky-1 halo rows resident on that GPU);
+  block matching needs no exchange step, so there is no data-path collective.  Total work is fixed:
+  scaling = "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     HBM roofline of the hot path's kernels: algorithmic bytes / HIP-event time
+  cpu_baseline the CPU oracle (restated reference, tile-threaded like the reference) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W = H = 4096
+KERNEL = (7, 7)
+SEARCH = (129, 1)
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FCLK_HZ = 2.4e9                # max shader clock
+LANES = 256 * 4 * 32           # CUs x SIMDs x lanes issued per clock
+
+
+def algorithmic_bytes(lw, lh, kx, ky, sx, sy):
+    """read L once (f32), read R once (f32), write the VW-layout disparity once."""
+    return 4 * lw * lh + 4 * (lw + sx - 1) * (lh + sy - 1) + 12 * (lw - kx + 1) * (lh - ky + 1)
+
+
+def cpu_baseline(left, right, budget_tiles=None):
+    """The restated reference timed the way the reference runs: 1024^2 output tiles on a pool of T threads
+    (src/vw/tools/correlate.cc:266, src/vw/Image/ImageIO.h:228-251), bounded to ~T tiles of the same workload."""
+    import oracle
+    cores = os.cpu_count() or 1
+    tiles = budget_tiles or max(1, min(16, cores))
+    t0 = time.perf_counter()
+    _, done = oracle.calc_disparity_tiled(0, left, right, KERNEL, SEARCH, tile=1024, threads=cores, max_tiles=tiles)
+    dt = time.perf_counter() - t0
+    return {"value": done / dt / 1e6, "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": "%d of 16 1024x1024 output tiles of the same 4096^2/7x7/129x1 pair, %d threads, %.1f s"
+                      % (tiles, cores, dt),
+            "ns_per_pixel_disparity_per_thread": dt * cores / (done * SEARCH[0] * SEARCH[1]) * 1e9 if tiles >= cores
+            else dt / (done / tiles * SEARCH[0] * SEARCH[1]) * 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import visionworkbench_amd as vwa
+    from visionworkbench_amd import core, stereo, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    kx, ky = KERNEL
+    sx, sy = SEARCH
+    left, right, _ = synth.stereo_pair(W, H, sx, sy)
+    ow, oh = W - kx + 1, H - ky + 1
+    # row strip of this rank (output rows), plus the halo rows its windows read
+    r0, r1 = rank * oh // world, (rank + 1) * oh // world
+    l_strip = torch.from_numpy(left[r0:r1 + ky - 1]).to(dev)
+    r_strip = torch.from_numpy(right[r0:r1 + ky - 1 + sy - 1]).to(dev)
+    region = vwa.BBox2i(0, 0, W, r1 - r0 + ky - 1)
+    ctx = vwa.Context(local)
+
+    def step():
+        return stereo.calc_disparity(core.ABSOLUTE_DIFFERENCE, l_strip, r_strip, region, SEARCH, KERNEL, ctx=ctx)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    out = None
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    path = ctx.last_path()
+
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    recs = ctx.profile_read(16 * args.steps + 16)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # sanity: the result of the timed work is a real disparity map
+    got = out[:8, :64].cpu().numpy()
+    assert got.shape == (8, 64, 3) and (got[..., 0] >= 0).all() and (got[..., 0] < sx).all()
+
+    if rank == 0:
+        per_kernel = {}
+        for name, ms in recs:
+            per_kernel.setdefault(name, []).append(ms)
+        kavg_us = {k: 1e3 * float(np.mean(v)) for k, v in per_kernel.items()}
+        hot = ["pack_u8_left", "pack_u8_right", "bm_sad_u8"] if path == core.PATH_SAD_U8 else ["bm_generic"]
+        t_hot_us = sum(kavg_us.get(k, 0.0) for k in hot)
+        strip_bytes = algorithmic_bytes(W, r1 - r0 + ky - 1, kx, ky, sx, sy)
+        achieved = strip_bytes / (t_hot_us * 1e-6) / 1e9 if t_hot_us > 0 else 0.0
+        evals = (r1 - r0) * ow * sx * sy
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "disparity Mpix/s, 4096x4096 pair, 7x7 SAD, +-64-px search",
+            "value": ow * oh * args.steps / dt / 1e6,
+            "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u8" if path == core.PATH_SAD_U8 else "f64",
+            "data": "synthetic (SplitMix64 integer-valued float32 noise pair, 256-px blocks shifted by 64+-48)",
+            "config": {"workload": "BASELINE configs[1]: 4096x4096 pair, 7x7 SAD, search_volume 129x1, calc_disparity",
+                       "kernel": list(KERNEL), "search_volume": list(SEARCH),
+                       "partition": "%d row strip(s), no collective" % world,
+                       "path": {core.PATH_SAD_U8: "packed-u8 qsad", core.PATH_GENERIC_F64: "generic f64"}.get(path, "?")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "+".join(hot), "algorithmic_bytes_per_launch": strip_bytes,
+                         "avg_us_per_launch": {k: kavg_us.get(k) for k in kavg_us},
+                         "issue_bound_frac": (evals / (t_hot_us * 1e-6)) / (LANES * FCLK_HZ) if t_hot_us > 0 else None,
+                         "note": "rank-0 strip; issue_bound_frac = (pixel*disparity evaluations per second) / "
+                                 "(256 CU x 128 lanes x 2.4 GHz) — the kernel is VALU-issue bound, see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(left, right)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

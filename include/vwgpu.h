@@ -1,0 +1,135 @@
+/* vwgpu.h — C ABI of the MI355X-native stereo-correlation engine (libvwgpu.so).
+ *
+ * This is the drop-in boundary for Vision Workbench's dense block-matching hot path.  The reference has no
+ * FFI/plugin interface (the path is ordinary C++ linked into libVwStereo.so), so each entry
+ * point below is what the body of the cited reference function would call once its inputs are rasterised.
+ * The C++ surface that keeps the reference's own signatures (vw::stereo::calc_disparity, ...) lives in
+ * visionworkbench_amd/vwlite/ and is a thin wrapper over these calls; INTEGRATION.md shows the binding a
+ * Vision Workbench maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types.  Images are row-major, `stride` in ELEMENTS per row.
+ *   - `*_dev` entry points take DEVICE pointers and are asynchronous on the context's stream;
+ *     the un-suffixed ones take HOST pointers, stage through HBM and return when the result is in host memory.
+ *   - every call returns VWGPU_OK (0) or a negative vwgpu_status; nothing throws.  One context per
+ *     (host thread x GPU), mirroring the reference's one-thread-per-tile model
+ *     (src/vw/Image/ImageIO.h:228-251); a context is not thread-safe, different contexts are independent.
+ *   - disparity images use the vw::PixelMask<Vector2i> memory layout: 3 x int32 per pixel {dx, dy, valid},
+ *     valid = INT32_MAX or 0 (src/vw/Image/PixelMask.h:48-120, src/vw/Image/PixelTypeInfo.h:95-102);
+ *     float disparities use vw::PixelMask<Vector2f>: 3 x float {dx, dy, valid in {0.f, 1.f}}.
+ */
+#ifndef VWGPU_H
+#define VWGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VWGPU_ABI_VERSION 1
+
+typedef struct vwgpu_ctx vwgpu_ctx;
+
+/* Status codes; the C++ wrappers map them to the reference's exception types
+ * (src/vw/Core/Exception.h:225-253): ARGUMENT -> vw::ArgumentErr, NOIMPL -> vw::NoImplErr,
+ * LOGIC/HIP/NOMEM -> vw::LogicErr. */
+typedef enum vwgpu_status {
+  VWGPU_OK = 0,
+  VWGPU_ERR_ARGUMENT = -1,
+  VWGPU_ERR_NOIMPL = -2,
+  VWGPU_ERR_HIP = -3,
+  VWGPU_ERR_NOMEM = -4,
+  VWGPU_ERR_LOGIC = -5
+} vwgpu_status;
+
+/* vw::stereo::CostFunctionType, src/vw/Stereo/CostFunctions.h:143-149 (same numeric values). */
+typedef enum vwgpu_cost_type {
+  VWGPU_ABSOLUTE_DIFFERENCE = 0,
+  VWGPU_SQUARED_DIFFERENCE = 1,
+  VWGPU_CROSS_CORRELATION = 2
+} vwgpu_cost_type;
+
+/* Which kernel family served the last calc_disparity call (vwgpu_last_path). */
+typedef enum vwgpu_path {
+  VWGPU_PATH_NONE = 0,
+  VWGPU_PATH_GENERIC_F64 = 1,  /* any float input, float64 accumulators (reference arithmetic)          */
+  VWGPU_PATH_SAD_U8 = 2        /* integer-valued inputs in [0,255]: packed u8 SAD (v_qsad_pk_u16_u8)      */
+} vwgpu_path;
+
+/* ---- context ------------------------------------------------------------------------------------- */
+
+int vwgpu_abi_version(void);
+
+/* Creates a context on HIP device `device` with its own stream. Fails with VWGPU_ERR_HIP if no GPU. */
+int vwgpu_create(vwgpu_ctx** ctx, int device);
+void vwgpu_destroy(vwgpu_ctx* ctx);
+
+/* Use an externally owned hipStream_t (passed as void*; NULL = back to the context's own stream). */
+int vwgpu_set_stream(vwgpu_ctx* ctx, void* hip_stream);
+/* Blocks until everything queued on the context's stream is done. */
+int vwgpu_synchronize(vwgpu_ctx* ctx);
+
+const char* vwgpu_strerror(int status);
+/* Detail text of the last failing call on this context ("" if none). */
+const char* vwgpu_last_error(const vwgpu_ctx* ctx);
+
+/* Forces a kernel family (testing / benchmarking): VWGPU_PATH_NONE = automatic dispatch (default). */
+int vwgpu_force_path(vwgpu_ctx* ctx, int path);
+int vwgpu_last_path(const vwgpu_ctx* ctx);
+
+/* Per-kernel timing with HIP events on the context's stream (bench.py roofline leg).
+ * enable=1 records an event pair around every kernel launch of subsequent calls; vwgpu_profile_read
+ * synchronises and returns up to `cap` (name, milliseconds) records since the last reset. */
+int vwgpu_profile_enable(vwgpu_ctx* ctx, int enable);
+int vwgpu_profile_reset(vwgpu_ctx* ctx);
+int vwgpu_profile_read(vwgpu_ctx* ctx, const char** names, float* ms, int cap);
+
+/* ---- block matching: calc_disparity -------------------------------------------------------------- */
+
+/* Replaces vw::stereo::calc_disparity (decl src/vw/Stereo/Correlation.h:50-57, impl
+ * src/vw/Stereo/Correlation.cc:330-375) from the point where it has rasterised its two crops (:356-359)
+ * and calls best_of_search_convolution (:33-137) with fast_box_sum (src/vw/Stereo/Algorithms.h:43-129)
+ * and the cost functors of src/vw/Stereo/CostFunctions.h:153-236.
+ *
+ *   left   lw x lh  : crop(left_in, left_region)
+ *   right  rw x rh  : crop(right_in, left_region grown by search_volume-1 on the max side);
+ *                     rw >= lw+sx-1 and rh >= lh+sy-1 (larger is allowed, the excess is ignored)
+ *   kx,ky  kernel_size (odd; <= lw, lh),  sx,sy search_volume (>= 1)
+ *   out    (lw-kx+1) x (lh-ky+1) pixels x {dx,dy,valid}; ostride in PIXELS (0 = dense).
+ *          dx in [0,sx), dy in [0,sy): offsets into the right crop, exactly as the reference returns them.
+ *
+ * Semantics kept from the reference: raster order dy-outer/dx-inner, strict comparison, first wins;
+ * a pixel is invalid iff its best and worst cost are equal (so search_volume (1,1) is all-invalid).
+ * Bit-exact against the reference when pixel values are integer-valued floats. */
+int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
+                             const float* d_left, int lw, int lh, ptrdiff_t lstride,
+                             const float* d_right, int rw, int rh, ptrdiff_t rstride,
+                             int kx, int ky, int sx, int sy,
+                             int32_t* d_out, ptrdiff_t ostride);
+
+int vwgpu_calc_disparity(vwgpu_ctx* ctx, int cost_type,
+                         const float* left, int lw, int lh, ptrdiff_t lstride,
+                         const float* right, int rw, int rh, ptrdiff_t rstride,
+                         int kx, int ky, int sx, int sy,
+                         int32_t* out, ptrdiff_t ostride);
+
+/* ---- left/right consistency check --------------------------------------------------------------- */
+
+/* Replaces vw::stereo::cross_corr_consistency_check (src/vw/Stereo/Correlate.cc:1441-1502; decl
+ * src/vw/Stereo/Correlate.h:52-58): invalidates l2r(c,r) when the r2l pixel at (c+dx, r+dy) is out of
+ * bounds or invalid, or when max(|dx+dx'|, |dy+dy'|) > threshold.  In place on l2r. Strides in pixels. */
+int vwgpu_cross_corr_consistency_check_dev(vwgpu_ctx* ctx,
+                                           int32_t* d_l2r, int lw, int lh, ptrdiff_t lstride,
+                                           const int32_t* d_r2l, int rw, int rh, ptrdiff_t rstride,
+                                           float threshold);
+int vwgpu_cross_corr_consistency_check(vwgpu_ctx* ctx,
+                                       int32_t* l2r, int lw, int lh, ptrdiff_t lstride,
+                                       const int32_t* r2l, int rw, int rh, ptrdiff_t rstride,
+                                       float threshold);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VWGPU_H */

@@ -1,0 +1,71 @@
+"""CPU-only: the C-ABI library builds, loads and exports every symbol include/vwgpu.h declares.
+No compute calls are made here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import visionworkbench_amd as vwa
+from visionworkbench_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vwgpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vwgpu_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    _lib.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), "libvwgpu.so does not export %s" % s
+
+
+def test_python_binding_covers_header():
+    assert sorted(_lib.SYMBOLS) == _declared_symbols()
+    lib = _lib.load()
+    assert lib.vwgpu_abi_version() == 1
+    assert lib.vwgpu_strerror(-1) == b"invalid argument"
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(vwa.LogicErr):
+        vwa.Context(0)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under visionworkbench_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "visionworkbench_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "vw_oracle" not in src and "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_bbox2i_semantics():
+    """src/vw/Math/BBox.tcc:156-174: half-open boxes; empty boxes report zero width/height."""
+    b = vwa.BBox2i(2, 3, 10, 5)
+    assert b.min == [2, 3] and b.max == [12, 8] and b.width() == 10 and b.height() == 5 and not b.empty()
+    z = vwa.BBox2i(0, 0, 129, 0)
+    assert z.empty() and z.width() == 0
+
+
+def test_synth_is_deterministic():
+    a = vwa.synth.stereo_pair(64, 48, 17)
+    b = vwa.synth.stereo_pair(64, 48, 17)
+    for x, y in zip(a, b):
+        assert (x == y).all()
+    l, r, t = a
+    assert l.dtype.name == "float32" and l.min() >= 0 and l.max() <= 255 and (l == l.round()).all()
+    assert r.shape == (48, 64 + 16)

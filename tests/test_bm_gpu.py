@@ -1,0 +1,251 @@
+"""GPU parity tests of the block-matching hot path, through the C ABI (libvwgpu.so), against the CPU oracle.
+
+Integer disparities and validity must be BIT-EXACT on integer-valued inputs; the golden cases
+are the reference's own (src/vw/Stereo/tests/TestCorrelation.cxx, TestCorrelate.cxx)."""
+import numpy as np
+import pytest
+
+import visionworkbench_amd as vwa
+from visionworkbench_amd import core, synth
+
+pytestmark = pytest.mark.gpu
+
+ABS, SQ, NCC = 0, 1, 2
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def ctx(torch_cuda):
+    c = vwa.Context(0)
+    yield c
+    c.close()
+
+
+def _gpu(ctx, cost, left, right, kernel, search, path=core.PATH_NONE, device=True):
+    from visionworkbench_amd import stereo
+    import torch
+    ctx.force_path(path)
+    try:
+        if device:
+            l = torch.from_numpy(left).cuda()
+            r = torch.from_numpy(right).cuda()
+            out = stereo.calc_disparity(cost, l, r, vwa.bounding_box(left), search, kernel, ctx=ctx)
+            torch.cuda.synchronize()
+            ctx.synchronize()
+            return out.cpu().numpy(), ctx.last_path()
+        out = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), search, kernel, ctx=ctx)
+        return out, ctx.last_path()
+    finally:
+        ctx.force_path(core.PATH_NONE)
+
+
+def _correlation_fixture(scale):
+    """SetUp of TestCorrelation.cxx:45-53 (see tests/test_oracle_golden.py)."""
+    u = (synth.splitmix64(10, 25 * 25) >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+    left = u.reshape(25, 25) * scale
+    if scale > 1:
+        left = np.floor(left)
+    left = left.astype(np.float32)
+    ys = np.clip(np.arange(46) - 8, 0, 24)
+    xs = np.clip(np.arange(31) - 3, 0, 24)
+    return left, np.ascontiguousarray(left[np.ix_(ys, xs)])
+
+
+@pytest.mark.parametrize("cost", [ABS, SQ, NCC])
+@pytest.mark.parametrize("scale", [255.0, 32767.0, 1.0])
+@pytest.mark.parametrize("device", [True, False])
+def test_golden_test_correlation(ctx, oracle, cost, scale, device):
+    """TestCorrelation.cxx:73-214: 19x21 output, all valid, all == (3,8)."""
+    left, right = _correlation_fixture(scale)
+    d, _ = _gpu(ctx, cost, left, right, (7, 5), (7, 12), device=device)
+    assert d.shape == (21, 19, 3)
+    assert (d[..., 2] == core.VALID_I32).all()
+    assert (d[..., 0] == 3).all() and (d[..., 1] == 8).all()
+    if scale > 1:   # integer-valued: bit-exact vs the oracle as well
+        assert np.array_equal(d, oracle.calc_disparity(cost, left, right, (7, 5), (7, 12)))
+
+
+CASES = [
+    # (w, h, kernel, search)
+    (96, 40, (7, 7), (33, 1)),
+    (300, 70, (5, 5), (33, 1)),
+    (257, 33, (7, 7), (129, 1)),
+    (130, 50, (3, 3), (7, 5)),
+    (200, 45, (9, 9), (18, 3)),
+    (190, 37, (11, 11), (21, 2)),
+    (64, 30, (7, 5), (1, 4)),
+    (33, 21, (13, 15), (6, 2)),      # no packed path -> generic
+    (1100, 20, (7, 7), (10, 1)),     # wider than one workgroup tile
+]
+
+
+@pytest.mark.parametrize("w,h,kernel,search", CASES)
+@pytest.mark.parametrize("cost", [ABS, SQ, NCC])
+def test_parity_vs_oracle_integer_inputs(ctx, oracle, w, h, kernel, search, cost):
+    left, right, _ = synth.stereo_pair(w, h, search[0], search[1], block=32, seeds=(21, 22, 23))
+    want = oracle.calc_disparity(cost, left, right, kernel, search)
+    got, _ = _gpu(ctx, cost, left, right, kernel, search)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), "mismatching pixels: %d" % int((got != want).any(-1).sum())
+
+
+@pytest.mark.parametrize("w,h,kernel,search", [c for c in CASES if c[2] != (13, 15)])
+def test_packed_u8_path_is_used_and_equals_generic(ctx, oracle, w, h, kernel, search):
+    left, right, _ = synth.stereo_pair(w, h, search[0], search[1], block=32, seeds=(31, 32, 33), smooth=True)
+    fast, p_fast = _gpu(ctx, ABS, left, right, kernel, search, path=core.PATH_SAD_U8)
+    gen, p_gen = _gpu(ctx, ABS, left, right, kernel, search, path=core.PATH_GENERIC_F64)
+    assert p_fast == core.PATH_SAD_U8 and p_gen == core.PATH_GENERIC_F64
+    want = oracle.calc_disparity(ABS, left, right, kernel, search)
+    assert np.array_equal(gen, want)
+    assert np.array_equal(fast, want), "mismatching pixels: %d" % int((fast != want).any(-1).sum())
+
+
+def test_ties_and_flat_regions(ctx, oracle):
+    """Many exact ties and constant areas: first-wins tie-breaking and best==worst invalidation."""
+    rng = np.random.RandomState(5)
+    left = (rng.randint(0, 3, (60, 140)) * 100).astype(np.float32)
+    right = (rng.randint(0, 3, (62, 172)) * 100).astype(np.float32)
+    left[10:40, 20:90] = 50.0
+    right[5:50, 10:150] = 50.0
+    left[45:, :] = 255.0
+    right[45:, :] = 0.0
+    for kernel, search in [((7, 7), (33, 3)), ((5, 5), (16, 1)), ((3, 3), (33, 2))]:
+        want = oracle.calc_disparity(ABS, left, right, kernel, search)
+        assert (want[..., 2] == 0).any() and (want[..., 2] != 0).any()
+        got, path = _gpu(ctx, ABS, left, right, kernel, search)
+        assert path == core.PATH_SAD_U8
+        assert np.array_equal(got, want)
+        for cost in (SQ, NCC):
+            assert np.array_equal(_gpu(ctx, cost, left, right, kernel, search)[0],
+                                  oracle.calc_disparity(cost, left, right, kernel, search))
+
+
+def test_search_volume_one_all_invalid(ctx, oracle):
+    left, right, _ = synth.stereo_pair(80, 30, 1, 1)
+    for cost in (ABS, SQ, NCC):
+        got, _ = _gpu(ctx, cost, left, right, (7, 7), (1, 1))
+        assert (got[..., 2] == 0).all() and (got[..., :2] == 0).all()
+        assert np.array_equal(got, oracle.calc_disparity(cost, left, right, (7, 7), (1, 1)))
+
+
+def test_minimum_size_image(ctx, oracle):
+    """Kernel as large as the region: a single output pixel."""
+    left, right, _ = synth.stereo_pair(7, 7, 9, 2)
+    for cost in (ABS, SQ, NCC):
+        got, _ = _gpu(ctx, cost, left, right, (7, 7), (9, 2))
+        assert got.shape == (1, 1, 3)
+        assert np.array_equal(got, oracle.calc_disparity(cost, left, right, (7, 7), (9, 2)))
+
+
+def test_non_integer_input_falls_back_to_generic(ctx, oracle):
+    """Float textures are outside the bit-exact domain: the packed path must refuse them (device flag) and the
+    float64 kernel must take over; the mismatch rate against the reference's serial sums is reported, not zero."""
+    left = synth.noise_f32(41, 48, 120, 0.0, 1.0)
+    right = np.concatenate([synth.noise_f32(42, 48, 8), left, synth.noise_f32(43, 48, 8)], axis=1)
+    got, path = _gpu(ctx, ABS, left, right, (7, 7), (17, 1))
+    assert path == core.PATH_GENERIC_F64
+    want = oracle.calc_disparity(ABS, left, right, (7, 7), (17, 1))
+    assert (got[..., 0] == 8).mean() > 0.99
+    assert (got != want).any(-1).mean() < 0.01
+    # 255.5 / negative / NaN also force the fallback
+    for bad in (255.5, -1.0, float("nan"), 256.0):
+        l2, r2, _ = synth.stereo_pair(64, 24, 9)
+        l2[3, 5] = bad
+        _, p = _gpu(ctx, ABS, l2, r2, (5, 5), (9, 1))
+        assert p == core.PATH_GENERIC_F64
+
+
+def test_strided_region_crop(ctx, oracle):
+    """calc_disparity with a left_region inside a larger image (Correlation.cc:356-359 crops)."""
+    import torch
+    from visionworkbench_amd import stereo
+    left, right, _ = synth.stereo_pair(200, 80, 20, 2, block=32)
+    region = vwa.BBox2i(13, 9, 150, 50)
+    want = oracle.calc_disparity(ABS, left[9:59, 13:163], right[9:59 + 1, 13:163 + 19], (7, 7), (20, 2))
+    got = stereo.calc_disparity(ABS, torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda(), region,
+                                (20, 2), (7, 7), ctx=ctx)
+    assert np.array_equal(got.cpu().numpy(), want)
+    got_h = stereo.calc_disparity(ABS, left, right, region, (20, 2), (7, 7), ctx=ctx)
+    assert np.array_equal(got_h, want)
+
+
+def test_argument_errors(ctx):
+    """Reference checks (Correlation.cc:341-351, Algorithms.h:45-46) surface as ArgumentErr."""
+    from visionworkbench_amd import stereo
+    left, right, _ = synth.stereo_pair(40, 30, 9)
+    bb = vwa.bounding_box(left)
+    with pytest.raises(vwa.ArgumentErr):
+        stereo.calc_disparity(ABS, left, right, bb, (9, 1), (4, 5), ctx=ctx)       # even kernel
+    with pytest.raises(vwa.ArgumentErr):
+        stereo.calc_disparity(ABS, left, right, bb, (0, 1), (5, 5), ctx=ctx)       # empty search
+    with pytest.raises(vwa.ArgumentErr):
+        stereo.calc_disparity(ABS, left, right, bb, (9, 1), (41, 5), ctx=ctx)      # kernel > region
+    with pytest.raises(vwa.ArgumentErr):
+        stereo.calc_disparity(ABS, left, right, vwa.BBox2i(0, 0, 41, 30), (9, 1), (5, 5), ctx=ctx)
+    with pytest.raises(vwa.NoImplErr):
+        stereo.calc_disparity(3, left, right, bb, (9, 1), (5, 5), ctx=ctx)         # census is not a BM cost
+
+
+def test_lr_check_golden_and_random(ctx, oracle):
+    """TestCorrelate.cxx:29-55 + random parity, host and device entry."""
+    import torch
+    from visionworkbench_amd import stereo
+    V = core.VALID_I32
+    l2r = np.zeros((3, 3, 3), np.int32)
+    r2l = np.zeros((3, 3, 3), np.int32)
+    l2r[..., 2] = V
+    r2l[..., 2] = V
+    l2r[:, 2, 0:2] = 2
+    l2r[0, 0, 0:2] = 1
+    r2l[1, 1, 0:2] = -1
+    l2r[0, 1, 0:2] = 1
+    for thr in (0, 2):
+        want = oracle.cross_corr_consistency_check(l2r, r2l, thr)
+        got = stereo.cross_corr_consistency_check(l2r.copy(), r2l, thr, ctx=ctx)
+        assert np.array_equal(got, want)
+    rng = np.random.RandomState(9)
+    a = rng.randint(-6, 7, (70, 90, 3)).astype(np.int32)
+    b = rng.randint(-6, 7, (64, 95, 3)).astype(np.int32)
+    a[..., 2] = np.where(rng.rand(70, 90) < 0.8, V, 0)
+    b[..., 2] = np.where(rng.rand(64, 95) < 0.8, V, 0)
+    for thr in (0.0, 1.0, 2.5):
+        want = oracle.cross_corr_consistency_check(a, b, thr)
+        got = stereo.cross_corr_consistency_check(torch.from_numpy(a.copy()).cuda(), torch.from_numpy(b).cuda(), thr, ctx=ctx)
+        assert np.array_equal(got.cpu().numpy(), want)
+    with pytest.raises(vwa.ArgumentErr):
+        stereo.cross_corr_consistency_check(a.copy(), b, -1.0, ctx=ctx)
+
+
+def test_full_size_config2_sampled_parity(ctx, oracle):
+    """BASELINE config 2 (4096^2, 7x7 SAD, 129x1) at full size: output tiles are independent units
+    (SURVEY §8e), so the oracle is run on sampled padded crops and compared bit-for-bit; plus the
+    size-independent property that pixels whose true-shift window survived must reach zero SAD there."""
+    import torch
+    from visionworkbench_amd import stereo
+    W = H = 4096
+    left, right, truth = synth.stereo_pair(W, H, 129, 1)
+    lt, rt = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    got = stereo.calc_disparity(ABS, lt, rt, vwa.bounding_box(left), (129, 1), (7, 7), ctx=ctx)
+    torch.cuda.synchronize()
+    assert ctx.last_path() == core.PATH_SAD_U8
+    got = got.cpu().numpy()
+    assert got.shape == (4090, 4090, 3)
+    rng = np.random.RandomState(3)
+    spots = [(0, 0), (4090 - 96, 4090 - 48), (1000, 4090 - 48), (4090 - 96, 7)] + \
+            [(int(rng.randint(0, 4090 - 96)), int(rng.randint(0, 4090 - 48))) for _ in range(6)]
+    for (x, y) in spots:
+        tw, th = 96, 48
+        want = oracle.calc_disparity(ABS, left[y:y + th + 6, x:x + tw + 6], right[y:y + th + 6, x:x + tw + 6 + 128],
+                                     (7, 7), (129, 1))
+        assert np.array_equal(got[y:y + th, x:x + tw], want), (x, y)
+    # property: where the whole 7x7 window (and its copy in the right image) lies inside one 256-block that was
+    # not overwritten, cost(truth) == 0 so the winner is at or before the true shift and valid.
+    t = truth[:4090, :4090]
+    assert (got[..., 2] == core.VALID_I32).mean() > 0.999
+    assert (got[..., 0] == t).mean() > 0.9

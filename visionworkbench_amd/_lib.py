@@ -1,0 +1,62 @@
+"""ctypes loader of libvwgpu.so (include/vwgpu.h).  Fails loudly: there is no CPU fallback in the product."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvwgpu.so")
+_LIB = None
+
+SYMBOLS = [
+    "vwgpu_abi_version", "vwgpu_create", "vwgpu_destroy", "vwgpu_set_stream", "vwgpu_synchronize",
+    "vwgpu_strerror", "vwgpu_last_error", "vwgpu_force_path", "vwgpu_last_path",
+    "vwgpu_profile_enable", "vwgpu_profile_reset", "vwgpu_profile_read",
+    "vwgpu_calc_disparity_dev", "vwgpu_calc_disparity",
+    "vwgpu_cross_corr_consistency_check_dev", "vwgpu_cross_corr_consistency_check",
+]
+
+
+def build(force=False):
+    """Compile every HIP translation unit for gfx950 into lib/libvwgpu.so (hipcc cross-compiles on CPU)."""
+    args = ["make", "-s", "-j8", "-C", os.path.join(_HERE, "csrc")]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "visionworkbench_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    P, I, F, PD = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_ssize_t
+    lib.vwgpu_abi_version.restype = I
+    lib.vwgpu_create.argtypes = [ctypes.POINTER(P), I]
+    lib.vwgpu_destroy.argtypes = [P]
+    lib.vwgpu_destroy.restype = None
+    lib.vwgpu_set_stream.argtypes = [P, P]
+    lib.vwgpu_synchronize.argtypes = [P]
+    lib.vwgpu_strerror.argtypes = [I]
+    lib.vwgpu_strerror.restype = ctypes.c_char_p
+    lib.vwgpu_last_error.argtypes = [P]
+    lib.vwgpu_last_error.restype = ctypes.c_char_p
+    lib.vwgpu_force_path.argtypes = [P, I]
+    lib.vwgpu_last_path.argtypes = [P]
+    lib.vwgpu_profile_enable.argtypes = [P, I]
+    lib.vwgpu_profile_reset.argtypes = [P]
+    lib.vwgpu_profile_read.argtypes = [P, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(F), I]
+    bm = [P, I, P, I, I, PD, P, I, I, PD, I, I, I, I, P, PD]
+    lib.vwgpu_calc_disparity_dev.argtypes = bm
+    lib.vwgpu_calc_disparity.argtypes = bm
+    lr = [P, P, I, I, PD, P, I, I, PD, F]
+    lib.vwgpu_cross_corr_consistency_check_dev.argtypes = lr
+    lib.vwgpu_cross_corr_consistency_check.argtypes = lr
+    for name in SYMBOLS:
+        getattr(lib, name)  # AttributeError if the ABI and the header drifted apart
+    _LIB = lib
+    return lib

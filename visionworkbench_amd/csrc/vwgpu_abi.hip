@@ -1,0 +1,283 @@
+// vwgpu_abi.hip — extern "C" entry points of libvwgpu.so (declared in include/vwgpu.h).
+// Argument validation, path dispatch, host staging, error text.  No kernels here.
+#include <cstring>
+
+#include "vwgpu_internal.h"
+
+// ---- helpers ----------------------------------------------------------------------------------------
+
+int vwgpu_fail(vwgpu_ctx* ctx, int status, const char* fmt, ...) {
+  if (ctx) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    ctx->err = buf;
+  }
+  return status;
+}
+
+int vwgpu_arena_reserve(vwgpu_ctx* ctx, vwgpu_arena* a, size_t bytes) {
+  if (bytes <= a->cap) return VWGPU_OK;
+  // Kernels already queued may still use the old block: drain before freeing it.
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (a->base) { (void)hipFree(a->base); a->base = nullptr; a->cap = 0; }
+  const size_t want = vwgpu_align_up(bytes + bytes / 4, 1 << 20);
+  VWGPU_HIP(ctx, hipMalloc(&a->base, want));
+  a->cap = want;
+  return VWGPU_OK;
+}
+
+vwgpu_prof_scope::vwgpu_prof_scope(vwgpu_ctx* c, const char* name) : ctx(c) {
+  if (!ctx->profiling) return;
+  hipEvent_t a = nullptr;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { b = nullptr; return; }
+  (void)hipEventRecord(a, ctx->stream);
+  ctx->prof.push_back({name, a, b});
+}
+vwgpu_prof_scope::~vwgpu_prof_scope() {
+  if (b) (void)hipEventRecord(b, ctx->stream);
+}
+
+static void prof_clear(vwgpu_ctx* ctx) {
+  for (auto& r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  ctx->prof.clear();
+}
+
+// ---- context ------------------------------------------------------------------------------------------
+
+extern "C" {
+
+int vwgpu_abi_version(void) { return VWGPU_ABI_VERSION; }
+
+const char* vwgpu_strerror(int status) {
+  switch (status) {
+    case VWGPU_OK: return "ok";
+    case VWGPU_ERR_ARGUMENT: return "invalid argument";
+    case VWGPU_ERR_NOIMPL: return "not implemented for this configuration";
+    case VWGPU_ERR_HIP: return "HIP runtime error";
+    case VWGPU_ERR_NOMEM: return "out of device memory";
+    case VWGPU_ERR_LOGIC: return "internal logic error";
+    default: return "unknown status";
+  }
+}
+
+int vwgpu_create(vwgpu_ctx** out, int device) {
+  if (!out) return VWGPU_ERR_ARGUMENT;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VWGPU_ERR_HIP;   // no silent CPU fallback
+  if (device < 0 || device >= n) return VWGPU_ERR_ARGUMENT;
+  if (hipSetDevice(device) != hipSuccess) return VWGPU_ERR_HIP;
+  vwgpu_ctx* ctx = new vwgpu_ctx();
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return VWGPU_ERR_HIP; }
+  ctx->stream = ctx->own_stream;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+  *out = ctx;
+  return VWGPU_OK;
+}
+
+void vwgpu_destroy(vwgpu_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  prof_clear(ctx);
+  if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
+  if (ctx->staging.base) (void)hipFree(ctx->staging.base);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int vwgpu_set_stream(vwgpu_ctx* ctx, void* hip_stream) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return VWGPU_OK;
+}
+
+int vwgpu_synchronize(vwgpu_ctx* ctx) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VWGPU_OK;
+}
+
+const char* vwgpu_last_error(const vwgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int vwgpu_force_path(vwgpu_ctx* ctx, int path) {
+  if (!ctx || path < VWGPU_PATH_NONE || path > VWGPU_PATH_SAD_U8) return VWGPU_ERR_ARGUMENT;
+  ctx->forced_path = path;
+  return VWGPU_OK;
+}
+
+int vwgpu_last_path(const vwgpu_ctx* cctx) {
+  vwgpu_ctx* ctx = const_cast<vwgpu_ctx*>(cctx);
+  if (!ctx) return VWGPU_PATH_NONE;
+  if (ctx->last_path == VWGPU_PATH_SAD_U8 && ctx->scratch.base) {
+    // The fast path reports non-representable input through a device flag; the generic kernel then ran.
+    int flag = 0;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return VWGPU_PATH_NONE;
+    if (hipMemcpy(&flag, ctx->scratch.base, sizeof flag, hipMemcpyDeviceToHost) != hipSuccess) return VWGPU_PATH_NONE;
+    return flag ? VWGPU_PATH_GENERIC_F64 : VWGPU_PATH_SAD_U8;
+  }
+  return ctx->last_path;
+}
+
+int vwgpu_profile_enable(vwgpu_ctx* ctx, int enable) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  ctx->profiling = enable != 0;
+  return VWGPU_OK;
+}
+
+int vwgpu_profile_reset(vwgpu_ctx* ctx) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  (void)hipStreamSynchronize(ctx->stream);
+  prof_clear(ctx);
+  return VWGPU_OK;
+}
+
+int vwgpu_profile_read(vwgpu_ctx* ctx, const char** names, float* ms, int cap) {
+  if (!ctx || cap < 0) return VWGPU_ERR_ARGUMENT;
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int n = 0;
+  for (auto& r : ctx->prof) {
+    if (n >= cap) break;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) t = -1.f;
+    if (names) names[n] = r.name;
+    if (ms) ms[n] = t;
+    ++n;
+  }
+  return n;
+}
+
+// ---- calc_disparity -----------------------------------------------------------------------------------
+
+static int check_bm_args(vwgpu_ctx* ctx, int cost_type, const void* l, int lw, int lh, ptrdiff_t ls,
+                         const void* r, int rw, int rh, ptrdiff_t rs, int kx, int ky, int sx, int sy,
+                         const void* out, ptrdiff_t os) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  ctx->err.clear();
+  if (!l || !r || !out) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity: null image pointer");
+  if (cost_type < VWGPU_ABSOLUTE_DIFFERENCE || cost_type > VWGPU_CROSS_CORRELATION)
+    return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: cost type %d is not a block-matching cost", cost_type);
+  // The reference's checks (src/vw/Stereo/Correlation.cc:341-351, Algorithms.h:45-46), always on here.
+  if (kx < 1 || ky < 1 || kx % 2 != 1 || ky % 2 != 1)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity: Kernel input not sized with odd values.");
+  if (kx > lw || ky > lh)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity: Kernel size too large of active region.");
+  if (sx < 1 || sy < 1)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity: Search volume must be greater than 0.");
+  if (rw < lw + sx - 1 || rh < lh + sy - 1)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity: right raster %dx%d smaller than %dx%d", rw, rh,
+                      lw + sx - 1, lh + sy - 1);
+  if (ls < lw || rs < rw || (os != 0 && os < lw - kx + 1))
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity: row stride smaller than row width");
+  if ((long long)sx * sy > 65535)
+    return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: search volume %dx%d exceeds 65535 disparities", sx, sy);
+  return VWGPU_OK;
+}
+
+int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
+                             const float* d_left, int lw, int lh, ptrdiff_t ls,
+                             const float* d_right, int rw, int rh, ptrdiff_t rs,
+                             int kx, int ky, int sx, int sy, int32_t* d_out, ptrdiff_t os) {
+  int rc = check_bm_args(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os);
+  if (rc) return rc;
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  if (os == 0) os = lw - kx + 1;
+
+  const bool fast_ok = vwgpu_bm_sad_u8_supported(cost_type, kx, ky, sx, sy);
+  if (ctx->forced_path == VWGPU_PATH_SAD_U8 && !fast_ok)
+    return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: no packed-u8 path for cost %d kernel %dx%d search %dx%d",
+                      cost_type, kx, ky, sx, sy);
+  if (fast_ok && ctx->forced_path != VWGPU_PATH_GENERIC_F64) {
+    int* d_flag = nullptr;
+    rc = vwgpu_launch_bm_sad_u8(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
+    if (rc) return rc;
+    ctx->last_path = VWGPU_PATH_SAD_U8;
+    if (ctx->forced_path == VWGPU_PATH_SAD_U8) return VWGPU_OK;   // caller inspects vwgpu_last_path()
+    // Inputs that are not integer-valued in [0,255] raise the device flag; the generic kernel then
+    // recomputes the whole image (its blocks return at once when the flag is clear).
+    return vwgpu_launch_bm_generic_flag(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs,
+                                        kx, ky, sx, sy, d_out, os, d_flag);
+  }
+  ctx->last_path = VWGPU_PATH_GENERIC_F64;
+  return vwgpu_launch_bm_generic(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os);
+}
+
+int vwgpu_calc_disparity(vwgpu_ctx* ctx, int cost_type,
+                         const float* left, int lw, int lh, ptrdiff_t ls,
+                         const float* right, int rw, int rh, ptrdiff_t rs,
+                         int kx, int ky, int sx, int sy, int32_t* out, ptrdiff_t os) {
+  int rc = check_bm_args(ctx, cost_type, left, lw, lh, ls, right, rw, rh, rs, kx, ky, sx, sy, out, os);
+  if (rc) return rc;
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  const int ow = lw - kx + 1, oh = lh - ky + 1;
+  if (os == 0) os = ow;
+  // Only the part of the right raster the search can reach is staged (Correlation.cc:356-359).
+  const int rcw = lw + sx - 1, rch = lh + sy - 1;
+  const size_t lb = vwgpu_align_up((size_t)lw * lh * sizeof(float), 256);
+  const size_t rb = vwgpu_align_up((size_t)rcw * rch * sizeof(float), 256);
+  const size_t ob = vwgpu_align_up((size_t)ow * oh * 3 * sizeof(int32_t), 256);
+  rc = vwgpu_arena_reserve(ctx, &ctx->staging, lb + rb + ob);
+  if (rc) return rc;
+  char* base = static_cast<char*>(ctx->staging.base);
+  float* d_l = reinterpret_cast<float*>(base);
+  float* d_r = reinterpret_cast<float*>(base + lb);
+  int32_t* d_o = reinterpret_cast<int32_t*>(base + lb + rb);
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_l, (size_t)lw * 4, left, (size_t)ls * 4, (size_t)lw * 4, lh, hipMemcpyHostToDevice, ctx->stream));
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_r, (size_t)rcw * 4, right, (size_t)rs * 4, (size_t)rcw * 4, rch, hipMemcpyHostToDevice, ctx->stream));
+  rc = vwgpu_calc_disparity_dev(ctx, cost_type, d_l, lw, lh, lw, d_r, rcw, rch, rcw, kx, ky, sx, sy, d_o, ow);
+  if (rc) return rc;
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(out, (size_t)os * 12, d_o, (size_t)ow * 12, (size_t)ow * 12, oh, hipMemcpyDeviceToHost, ctx->stream));
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VWGPU_OK;
+}
+
+// ---- left/right consistency check -----------------------------------------------------------------------
+
+int vwgpu_cross_corr_consistency_check_dev(vwgpu_ctx* ctx, int32_t* d_l2r, int lw, int lh, ptrdiff_t ls,
+                                           const int32_t* d_r2l, int rw, int rh, ptrdiff_t rs, float thr) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  ctx->err.clear();
+  if (!d_l2r || !d_r2l || lw < 0 || lh < 0 || rw < 0 || rh < 0)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "cross_corr_consistency_check: bad image");
+  // VW_DEBUG_ASSERT in the reference (Correlate.cc:1457-1460); always on here.
+  if (!(thr >= 0.0f))
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "cross_corr_consistency_check: the threshold is less than 0.");
+  if (ls == 0) ls = lw;
+  if (rs == 0) rs = rw;
+  if (lw == 0 || lh == 0) return VWGPU_OK;
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  return vwgpu_launch_lr_check(ctx, d_l2r, lw, lh, ls, d_r2l, rw, rh, rs, thr);
+}
+
+int vwgpu_cross_corr_consistency_check(vwgpu_ctx* ctx, int32_t* l2r, int lw, int lh, ptrdiff_t ls,
+                                       const int32_t* r2l, int rw, int rh, ptrdiff_t rs, float thr) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  if (!l2r || !r2l || lw < 0 || lh < 0 || rw < 0 || rh < 0)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "cross_corr_consistency_check: bad image");
+  if (ls == 0) ls = lw;
+  if (rs == 0) rs = rw;
+  if (lw == 0 || lh == 0) return VWGPU_OK;
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t lb = vwgpu_align_up((size_t)lw * lh * 12, 256), rb = vwgpu_align_up((size_t)rw * rh * 12, 256);
+  int rc = vwgpu_arena_reserve(ctx, &ctx->staging, lb + rb);
+  if (rc) return rc;
+  char* base = static_cast<char*>(ctx->staging.base);
+  int32_t* d_l = reinterpret_cast<int32_t*>(base);
+  int32_t* d_r = reinterpret_cast<int32_t*>(base + lb);
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_l, (size_t)lw * 12, l2r, (size_t)ls * 12, (size_t)lw * 12, lh, hipMemcpyHostToDevice, ctx->stream));
+  if (rw > 0 && rh > 0)
+    VWGPU_HIP(ctx, hipMemcpy2DAsync(d_r, (size_t)rw * 12, r2l, (size_t)rs * 12, (size_t)rw * 12, rh, hipMemcpyHostToDevice, ctx->stream));
+  rc = vwgpu_cross_corr_consistency_check_dev(ctx, d_l, lw, lh, lw, d_r, rw, rh, rw, thr);
+  if (rc) return rc;
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(l2r, (size_t)ls * 12, d_l, (size_t)lw * 12, (size_t)lw * 12, lh, hipMemcpyDeviceToHost, ctx->stream));
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VWGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// vwgpu_internal.h — context object and launch helpers shared by the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "vwgpu.h"
+
+struct vwgpu_prof_rec {
+  const char* name;
+  hipEvent_t a, b;
+};
+
+// Grow-only device scratch arena: one allocation reused across calls so that steady-state calls do no
+// hipMalloc/hipFree (they would serialise the stream).
+struct vwgpu_arena {
+  void* base = nullptr;
+  size_t cap = 0;
+};
+
+struct vwgpu_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int forced_path = VWGPU_PATH_NONE;
+  int last_path = VWGPU_PATH_NONE;
+  bool profiling = false;
+  std::vector<vwgpu_prof_rec> prof;
+  std::vector<hipEvent_t> event_pool;
+  vwgpu_arena scratch;   // kernel scratch (packed u8 planes, NCC precision images, flags)
+  vwgpu_arena staging;   // device copies of host images for the host-pointer entry points
+  int num_cu = 256;
+};
+
+int vwgpu_fail(vwgpu_ctx* ctx, int status, const char* fmt, ...);
+int vwgpu_arena_reserve(vwgpu_ctx* ctx, vwgpu_arena* a, size_t bytes);
+
+#define VWGPU_HIP(ctx, call)                                                                     \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return vwgpu_fail((ctx), e_ == hipErrorOutOfMemory ? VWGPU_ERR_NOMEM : VWGPU_ERR_HIP,      \
+                        "%s failed: %s", #call, hipGetErrorString(e_));                          \
+  } while (0)
+
+// RAII event bracket around one kernel launch when profiling is on.
+struct vwgpu_prof_scope {
+  vwgpu_ctx* ctx;
+  hipEvent_t b = nullptr;
+  vwgpu_prof_scope(vwgpu_ctx* c, const char* name);
+  ~vwgpu_prof_scope();
+};
+
+static inline size_t vwgpu_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- kernel-family launchers (each in its own .hip) ------------------------------------------------
+// All pointers are device pointers; every launcher enqueues on ctx->stream and returns a vwgpu_status.
+
+int vwgpu_launch_bm_generic(vwgpu_ctx* ctx, int cost_type,
+                            const float* left, int lw, int lh, ptrdiff_t ls,
+                            const float* right, int rw, int rh, ptrdiff_t rs,
+                            int kx, int ky, int sx, int sy, int32_t* out, ptrdiff_t os);
+
+// Same, but the kernel returns immediately when run_flag != NULL and *run_flag == 0 (device memory).
+int vwgpu_launch_bm_generic_flag(vwgpu_ctx* ctx, int cost_type,
+                                 const float* left, int lw, int lh, ptrdiff_t ls,
+                                 const float* right, int rw, int rh, ptrdiff_t rs,
+                                 int kx, int ky, int sx, int sy, int32_t* out, ptrdiff_t os,
+                                 const int* run_flag);
+
+// Returns VWGPU_ERR_NOIMPL (without touching `out`) if this configuration has no u8 fast path;
+// otherwise enqueues pack + match.  *d_fallback_flag (device int) is nonzero afterwards if the inputs were
+// not integer-valued in [0,255] — the caller must then run the generic path.
+bool vwgpu_bm_sad_u8_supported(int cost_type, int kx, int ky, int sx, int sy);
+int vwgpu_launch_bm_sad_u8(vwgpu_ctx* ctx,
+                           const float* left, int lw, int lh, ptrdiff_t ls,
+                           const float* right, int rw, int rh, ptrdiff_t rs,
+                           int kx, int ky, int sx, int sy, int32_t* out, ptrdiff_t os,
+                           int** d_fallback_flag);
+
+int vwgpu_launch_lr_check(vwgpu_ctx* ctx, int32_t* l2r, int lw, int lh, ptrdiff_t ls,
+                          const int32_t* r2l, int rw, int rh, ptrdiff_t rs, float thr);
