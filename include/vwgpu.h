@@ -66,8 +66,11 @@ int vwgpu_abi_version(void);
 int vwgpu_create(vwgpu_ctx** ctx, int device);
 void vwgpu_destroy(vwgpu_ctx* ctx);
 
-/* Use an externally owned hipStream_t (passed as void*; NULL = back to the context's own stream). */
+/* Enqueue on an externally owned hipStream_t (passed as void*).  NULL means the legacy default stream
+ * (that is what torch's default stream is), NOT the context's own stream — see vwgpu_reset_stream. */
 int vwgpu_set_stream(vwgpu_ctx* ctx, void* hip_stream);
+/* Back to the context's own (non-blocking) stream. */
+int vwgpu_reset_stream(vwgpu_ctx* ctx);
 /* Blocks until everything queued on the context's stream is done. */
 int vwgpu_synchronize(vwgpu_ctx* ctx);
 

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvwgpu.so")
 _LIB = None
 
 SYMBOLS = [
-    "vwgpu_abi_version", "vwgpu_create", "vwgpu_destroy", "vwgpu_set_stream", "vwgpu_synchronize",
+    "vwgpu_abi_version", "vwgpu_create", "vwgpu_destroy", "vwgpu_set_stream", "vwgpu_reset_stream", "vwgpu_synchronize",
     "vwgpu_strerror", "vwgpu_last_error", "vwgpu_force_path", "vwgpu_last_path",
     "vwgpu_profile_enable", "vwgpu_profile_reset", "vwgpu_profile_read",
     "vwgpu_calc_disparity_dev", "vwgpu_calc_disparity",
@@ -33,6 +33,13 @@ def load():
         raise RuntimeError(
             "visionworkbench_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback)" % LIB_PATH)
+    # torch bundles its own libamdhip64.so.7; libvwgpu.so names the same SONAME (RUNPATH /opt/rocm).  Whichever
+    # is loaded first serves both, and a process that ends up with two half-initialised HIP runtimes fails in
+    # hipGetDeviceCount.  Import torch first so that torch tensors and our kernels share one runtime.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     P, I, F, PD = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_ssize_t
     lib.vwgpu_abi_version.restype = I
@@ -40,6 +47,7 @@ def load():
     lib.vwgpu_destroy.argtypes = [P]
     lib.vwgpu_destroy.restype = None
     lib.vwgpu_set_stream.argtypes = [P, P]
+    lib.vwgpu_reset_stream.argtypes = [P]
     lib.vwgpu_synchronize.argtypes = [P]
     lib.vwgpu_strerror.argtypes = [I]
     lib.vwgpu_strerror.restype = ctypes.c_char_p

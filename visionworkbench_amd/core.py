@@ -114,7 +114,11 @@ class Context:
             raise exc(detail or self._lib.vwgpu_strerror(rc).decode())
 
     def set_stream(self, stream_ptr):
+        """Enqueue on the given hipStream_t (int handle); 0/None = the legacy default stream (torch's default)."""
         self.check(self._lib.vwgpu_set_stream(self._h, ctypes.c_void_p(stream_ptr or None)))
+
+    def reset_stream(self):
+        self.check(self._lib.vwgpu_reset_stream(self._h))
 
     def synchronize(self):
         self.check(self._lib.vwgpu_synchronize(self._h))

@@ -93,8 +93,21 @@ void vwgpu_destroy(vwgpu_ctx* ctx) {
 
 int vwgpu_set_stream(vwgpu_ctx* ctx, void* hip_stream) {
   if (!ctx) return VWGPU_ERR_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  if (s == ctx->stream && !ctx->stream_is_own) return VWGPU_OK;
+  // The scratch arenas are shared by consecutive calls: work queued on the old stream must finish first.
   (void)hipStreamSynchronize(ctx->stream);
-  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  ctx->stream = s;
+  ctx->stream_is_own = false;
+  return VWGPU_OK;
+}
+
+int vwgpu_reset_stream(vwgpu_ctx* ctx) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  if (ctx->stream_is_own) return VWGPU_OK;
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->stream = ctx->own_stream;
+  ctx->stream_is_own = true;
   return VWGPU_OK;
 }
 

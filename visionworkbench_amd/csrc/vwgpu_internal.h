@@ -25,6 +25,7 @@ struct vwgpu_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  bool stream_is_own = true;
   std::string err;
   int forced_path = VWGPU_PATH_NONE;
   int last_path = VWGPU_PATH_NONE;
