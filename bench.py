@@ -130,7 +130,9 @@ def main():
         for name, ms in recs:
             per_kernel.setdefault(name, []).append(ms)
         kavg_us = {k: 1e3 * float(np.mean(v)) for k, v in per_kernel.items()}
-        hot = ["pack_u8_left", "pack_u8_right", "bm_sad_u8"] if path == core.PATH_SAD_U8 else ["bm_generic"]
+        # dominant kernel of the path: the single matcher launch reads both float images and writes the disparity
+        # image, i.e. it moves exactly the algorithmic bytes of SURVEY.md §8(d)
+        hot = ["bm_sad_u8"] if path == core.PATH_SAD_U8 else ["bm_generic"]
         t_hot_us = sum(kavg_us.get(k, 0.0) for k in hot)
         strip_bytes = algorithmic_bytes(W, r1 - r0 + ky - 1, kx, ky, sx, sy)
         achieved = strip_bytes / (t_hot_us * 1e-6) / 1e9 if t_hot_us > 0 else 0.0

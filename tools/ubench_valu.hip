@@ -42,6 +42,27 @@ __global__ void __launch_bounds__(256) bench(u32* out, u32 seed) {
       if (OP == 17) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
       if (OP == 18) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
       if (OP == 19) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(q[i]) : "v"(w));
+      if (OP == 21) asm volatile("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(a[i]) : "v"(b), "v"(c));
+      if (OP == 22) asm volatile("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(a[i]) : "v"(b), "v"(c));
+      if (OP == 23) asm volatile("v_sub_u16 %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+      if (OP == 30) asm volatile("v_min_u32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == 31) asm volatile("v_max_u32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == 32) asm volatile("v_and_b32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == 33) asm volatile("v_xor_b32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == 34) asm volatile("v_lshlrev_b32_e32 %0, 1, %0" : "+v"(a[i]));
+      if (OP == 35) asm volatile("v_sub_u32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == 36) asm volatile("v_add_u16_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == 37) asm volatile("v_min_u16_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == 38) asm volatile("v_max_u16_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == 39) asm volatile("v_mov_b32_e32 %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == 40) asm volatile("v_add_u32_e64 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == 41) asm volatile("v_sub_u16_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == 42) asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == 43) asm volatile("v_mul_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == 44) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+      if (OP == 45) asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == 46) asm volatile("v_min_u32_e64 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == 47) asm volatile("v_sub_u16_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(a[i]) : "v"(c));
       if (OP == 20) asm volatile("v_add_f64 %0, %0, %1" : "+v"(q[i]) : "v"(w));
     }
   }
@@ -72,6 +93,13 @@ int main() {
   run<1>("v_pk_sub_u16", d); run<13>("v_pk_add_u16", d); run<2>("v_pk_max_u16", d); run<11>("v_pk_min_u16", d);
   run<12>("v_pk_minimum3_f16", d); run<16>("v_pk_mad_u16", d);
   run<3>("v_min3_u32", d); run<17>("v_min_u32", d); run<4>("v_lshl_or_b32", d); run<5>("v_bfi_b32", d);
+  run<21>("v_sub_u16_sdwa W0->W1", d); run<22>("v_sub_u16_sdwa W1->W1", d); run<23>("v_sub_u16", d);
+  run<45>("v_add_u32_e32", d); run<40>("v_add_u32_e64", d); run<35>("v_sub_u32_e32", d);
+  run<30>("v_min_u32_e32", d); run<46>("v_min_u32_e64", d); run<31>("v_max_u32_e32", d); run<32>("v_and_b32_e32", d); run<33>("v_xor_b32_e32", d);
+  run<34>("v_lshlrev_b32_e32", d); run<39>("v_mov_b32_e32", d);
+  run<36>("v_add_u16_e32", d); run<41>("v_sub_u16_e32(dep)", d); run<37>("v_min_u16_e32", d); run<38>("v_max_u16_e32", d);
+  run<47>("v_sub_u16_sdwa(dword dst)", d);
+  run<42>("v_add_f32_e32", d); run<43>("v_mul_f32_e32", d); run<44>("v_fmac_f32_e32", d);
   run<15>("v_and_or_b32", d); run<14>("v_perm_b32", d); run<10>("v_alignbyte_b32", d);
   return 0;
 }

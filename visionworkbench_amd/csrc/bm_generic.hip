@@ -156,11 +156,9 @@ int vwgpu_launch_bm_generic_flag(vwgpu_ctx* ctx, int cost_type,
     const int rph = rch - ky + 1;
     const size_t lbytes = vwgpu_align_up((size_t)ow * oh * sizeof(double), 256);
     const size_t rbytes = vwgpu_align_up((size_t)rpw * rph * sizeof(double), 256);
-    // NCC precision images live at the END of the scratch arena's first region; the u8 planes of the
-    // fast path (SAD only) never coexist with them.
-    int rc = vwgpu_arena_reserve(ctx, &ctx->scratch, lbytes + rbytes + 256);
+    int rc = vwgpu_arena_reserve(ctx, &ctx->scratch, lbytes + rbytes);
     if (rc) return rc;
-    lprec = reinterpret_cast<double*>(static_cast<char*>(ctx->scratch.base) + 256);
+    lprec = reinterpret_cast<double*>(ctx->scratch.base);
     rprec = reinterpret_cast<double*>(reinterpret_cast<char*>(lprec) + lbytes);
     dim3 blk(64, 4);
     {

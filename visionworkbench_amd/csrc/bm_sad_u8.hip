@@ -1,37 +1,44 @@
 // bm_sad_u8.hip — packed-u8 SAD block matching + winner-take-all for integer-valued imagery.
 //
-// The headline kernel (BASELINE.json config 2: 4096^2, 7x7 SAD, 129x1 search).  It replaces the whole
+// The headline kernel (BASELINE.json config 2: 4096^2, 7x7 SAD, 129x1 search).  ONE launch replaces the whole
 // per-disparity pipeline of best_of_search_convolution (src/vw/Stereo/Correlation.cc:64-133: crop copy ->
 // AbsoluteCost image -> fast_box_sum -> compare loop -> validity pass) for inputs on which the reference's
 // float/double arithmetic is exact: pixel values that are integers in [0,255].  On that
 // domain |a-b| in float, the float64 box sums and the strict `<` compares are all exact, so the result only
 // depends on (cost, dy, dx) lexicographic order ("strict compare, first wins" == smallest (cost, dy, dx)),
-// which is what this kernel tracks.  Anything else raises a device flag and the generic float64 kernel
-// (bm_generic.hip) recomputes the image.
+// which is what this kernel tracks.  It reads the float32 images directly (4 B/px, once per tile), checks
+// the domain on the fly and raises a device flag otherwise; the generic float64 kernel (bm_generic.hip)
+// then recomputes the image.
 //
-// Why not the float formulation: 4096^2 x 129 disparities = 2.16 G (pixel, disparity) evaluations against
-// 337 MB of compulsory HBM traffic (42 us) — the kernel is VALU-issue bound, not HBM bound.
-// v_qsad_pk_u16_u8 does 16 abs-diffs + 4 accumulates per lane per issue, so the design is built around it:
+// Issue-bound, not HBM-bound: 4096^2 x 129 disparities = 2.16 G (pixel, disparity) evaluations against
+// 337 MB of compulsory HBM traffic (42 us).  Measured on MI355X (profiles/r01_ubench_valu.txt): an ordinary
+// VALU op issues 16 lanes/clk/SIMD (64 lane-ops/clk/CU), v_qsad_pk_u16_u8 is quarter rate (16 abs-diffs
+// in 16 clk/wave = the same 4 abs-diffs per lane-slot as v_sad_u8), so the floor of this formulation is
+// ~17 lane-slots per 4 evaluations (11 qsad incl. the ky-1 halo rows + 4 key + 2 min3).
 //
 //   mapping   lane <-> 4 consecutive output pixels (q..q+3) x TY output rows; wave <-> 256 x TY pixels;
 //             workgroup = 4 (or 2) waves side by side.
-//   qsad      src0 (64 bit) = 8 LEFT bytes L[q+4n .. q+4n+7] held in registers for all TY+ky-1 rows,
+//   qsad      src0 (64 bit) = 8 LEFT bytes L[q+4n .. q+4n+7], in registers for all TY+ky-1 rows,
 //             src1 (32 bit) = 4 RIGHT bytes R[q+j+4n .. +3] read from LDS, j = "step" = 4a+t.
 //             Result slot i (u16) = sum_b |L[q+i+4n+b] - R[q+j+4n+b]|  -> pixel q+i at disparity d = j-i.
-//             Putting RIGHT in the 32-bit operand makes a partial last word (kx % 4 != 0) harmless: its
-//             missing bytes are zeroed in LDS, which adds sum L[...] to every disparity of that pixel —
+//             RIGHT sits in the 32-bit operand so that a partial last word (kx % 4 != 0) is harmless: its
+//             missing bytes are zeroed in LDS, which adds sum L[...] to EVERY disparity of that pixel —
 //             a per-pixel constant that changes neither the argmin nor the best==worst validity test.
 //   vertical  one accumulator chain per step runs down the rows (the adds are free inside qsad); the
-//             ky-row window cost is P[r] - P[r-ky] (v_pk_sub_u16, modulo 2^16, exact because the true
-//             window sum is < 2^16).
-//   LDS       RIGHT words at byte phase t = j mod 4 are unaligned in memory, so the step loop runs t-outer:
-//             for each t the workgroup rebuilds one LDS array of pre-shifted, pre-masked word groups
-//             (v_alignbyte once per word), then walks a = 0..A with one 8/16-byte LDS read per row.
-//   WTA       key = cost << 16 | (dy*sx + dx); K = v_min3_u32(K, key_a, key_a+1).  Order independent, so
-//             the t-outer loop order is fine.  Worst cost is tracked with v_pk_max_u16 for the validity test.
+//             ky-row window cost is P[r] - P[r-ky] modulo 2^16 (exact: the true window sum is < 2^16).
+//   WTA       key = cost << 16 | (dy*sx + dx).  v_sub_u16_sdwa writes P[r]-P[r-ky] straight into the high
+//             half of a register whose low half holds the disparity index, so one op does the vertical
+//             difference AND builds the key; K = v_min3_u32(K, key_a, key_a+1).  Order independent.
+//   LDS       RIGHT words at byte phase t = j mod 4 are unaligned, so the step loop runs t-outer: the
+//             float tile is converted to a u8 base tile in LDS once, and for each t the workgroup derives
+//             one array of pre-shifted, pre-masked word groups (v_alignbyte_b32), then walks a = 0..A with
+//             one 8/16-byte LDS read per row.
+//   validity  invalid <=> all sx*sy costs equal.  Instead of tracking the worst cost everywhere, four costs
+//             per pixel are compared during the first sweep; only if some pixel of the workgroup has all four
+//             equal (never on textured data, always on flat data) a second launch (FIX = true) recomputes packed best/worst.
 //
-// Limits (else VWGPU_ERR_NOIMPL -> generic path): SAD only; kx <= 15; 4*ceil(kx/4)*ky*255 < 65536;
-// sx*sy <= 65535; LDS footprint <= 64 KiB.
+// Limits (else the generic path): SAD only; kernel sizes in kLaunch; 4*ceil(kx/4)*ky*255 < 65536;
+// sx*sy <= 65535; LDS footprint <= 80 KiB.
 #include <type_traits>
 
 #include "vwgpu_internal.h"
@@ -48,35 +55,34 @@ __device__ __forceinline__ u32 pk_sub_u16(u32 a, u32 b) {
 __device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) {
   return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
-__device__ __forceinline__ u32 umin3(u32 a, u32 b, u32 c) { return min(min(a, b), c); }
-
-// ---- float -> u8 planes --------------------------------------------------------------------------------
-// Writes the whole padded plane (pad = 0) and raises *flag if any pixel is not an integer in [0,255].
-__global__ void pack_u8_kernel(const float* __restrict__ src, ptrdiff_t stride, int w, int h,
-                               u32* __restrict__ dst, int pitch_dw, int rows, int* __restrict__ flag) {
-  const int xd = blockIdx.x * blockDim.x + threadIdx.x;   // dword column
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (xd >= pitch_dw || y >= rows) return;
-  u32 packed = 0;
-  bool bad = false;
-  if (y < h) {
-    const float* p = src + (ptrdiff_t)y * stride;
-    const int x = xd * 4;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      if (x + b < w) {
-        const float v = p[x + b];
-        const float r = rintf(v);
-        bad |= !(r == v && v >= 0.0f && v <= 255.0f);
-        packed |= ((u32)(int)fminf(fmaxf(r, 0.0f), 255.0f)) << (8 * b);
-      }
-    }
-  }
-  dst[(size_t)y * pitch_dw + xd] = packed;
-  if (bad) atomicOr(flag, 1);
+__device__ __forceinline__ u32 pk_min_u16(u32 a, u32 b) {
+  return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+// K = min(K, a, b).  `volatile` keeps the SDWA key writes and the min3 reads in program order: the key registers
+// are rewritten in place every row, and letting the scheduler overlap consecutive rows costs a v_mov per key.
+__device__ __forceinline__ void umin3_acc(u32& k, u32 a, u32 b) {
+  asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(k) : "v"(a), "v"(b));
 }
 
-// ---- the matcher -----------------------------------------------------------------------------------------
+// key.hi16 = a.WORD_w - b.WORD_w (mod 2^16), IN PLACE; key.lo16 (the disparity index) is preserved, so the
+// same register serves every row of a step without being re-initialised.
+template <int W>
+__device__ __forceinline__ void key_sub(u32& key, u32 a, u32 b) {
+  if (W == 0)
+    asm volatile("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0"
+                 : "+v"(key) : "v"(a), "v"(b));
+  else
+    asm volatile("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1"
+                 : "+v"(key) : "v"(a), "v"(b));
+}
+
+// float -> u8 with the exactness test of the fast path: integer-valued and inside [0,255].
+__device__ __forceinline__ u32 to_u8(float v, bool& bad) {
+  const float r = rintf(v);
+  bad |= !(r == v && v >= 0.0f && v <= 255.0f);
+  return (u32)(int)fminf(fmaxf(r, 0.0f), 255.0f);
+}
+
 template <int KX, int KY, int TY>
 struct Cfg {
   static constexpr int NW = (KX + 3) / 4;          // qsads per row
@@ -85,176 +91,297 @@ struct Cfg {
   static constexpr int THREADS = WAVES * 64;
   static constexpr int TWB = WAVES * 256;          // output columns per workgroup
   static constexpr int NR = TY + KY - 1;           // input rows per tile
+  static constexpr int LBW = TWB / 4 + NW + 1;     // dwords per row of the LEFT u8 tile
   static constexpr u32 LAST_MASK = (KX % 4 == 0) ? 0xffffffffu : ((1u << (8 * (KX % 4))) - 1u);
 };
 
-template <int KX, int KY, int TY>
+// Loads a row-segment of a float image as packed u8 dwords into LDS: dst[g] = bytes (x0+4g .. x0+4g+3),
+// zero outside [0,w) x [0,h).  `vec4` (workgroup-uniform) = every in-range group of 4 floats is 16-byte aligned.
+__device__ __forceinline__ u32 pack4(float v0, float v1, float v2, float v3, bool& bad) {
+  return to_u8(v0, bad) | (to_u8(v1, bad) << 8) | (to_u8(v2, bad) << 16) | (to_u8(v3, bad) << 24);
+}
+
+__device__ __forceinline__ void stage_u8_rows(const float* __restrict__ img, ptrdiff_t stride, int w, int h,
+                                              int x0, int y0, int nrows, int ndw, int dst_pitch_dw,
+                                              u32* __restrict__ dst, int tid, int nthreads, bool& bad) {
+  const bool vec4 = ((reinterpret_cast<uintptr_t>(img) & 15) == 0) && ((stride & 3) == 0);
+  for (int g = tid; g < ndw; g += nthreads) {
+    const int x = x0 + 4 * g;
+    if (vec4 && x + 3 < w) {
+#pragma unroll 4
+      for (int r = 0; r < nrows; ++r) {
+        const int y = y0 + r;
+        u32 p = 0;
+        if (y < h) {
+          const float4 v = *reinterpret_cast<const float4*>(img + (ptrdiff_t)y * stride + x);
+          p = pack4(v.x, v.y, v.z, v.w, bad);
+        }
+        dst[(size_t)r * dst_pitch_dw + g] = p;
+      }
+    } else {
+#pragma unroll 2
+      for (int r = 0; r < nrows; ++r) {
+        const int y = y0 + r;
+        const float* row = img + (ptrdiff_t)y * stride;
+        u32 p = 0;
+        if (y < h) {
+          if (x + 3 < w) {
+            p = pack4(row[x], row[x + 1], row[x + 2], row[x + 3], bad);
+          } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+              if (x + b < w) p |= to_u8(row[x + b], bad) << (8 * b);
+          }
+        }
+        dst[(size_t)r * dst_pitch_dw + g] = p;
+      }
+    }
+  }
+}
+
+// FIX = false: the matcher (first sweep: keys + equality probe; raises need_fix[workgroup] if some pixel may be
+//               invalid).  FIX = true: the validity fix-up launched right after it; workgroups whose need_fix
+//               entry is clear return at once, the others recompute packed best/worst costs and invalidate
+//               pixels with best == worst (Correlation.cc:121-133).
+template <int KX, int KY, int TY, bool FIX>
 __global__ void __launch_bounds__((KX <= 8 ? 256 : 128), 2)
-bm_sad_u8_kernel(const uint8_t* __restrict__ L8, int pitch_l, const uint8_t* __restrict__ R8, int pitch_r,
-                 int sx, int sy, int ne, int32_t* __restrict__ out, ptrdiff_t os, int ow, int oh) {
+bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
+                 const float* __restrict__ R, ptrdiff_t rs, int rcw, int rch,
+                 int sx, int sy, int ne, int32_t* __restrict__ out, ptrdiff_t os, int ow, int oh,
+                 int* __restrict__ flag_set, int* __restrict__ flag_clear, int* __restrict__ need_fix) {
   typedef Cfg<KX, KY, TY> C;
   constexpr int NW = C::NW, EW = C::EW, NR = C::NR;
-  extern __shared__ __attribute__((aligned(16))) u32 lds[];   // [NR][ne][EW]
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  u32* ent = lds;                                   // [NR][ne][EW]   word groups of the current byte phase
+  const int bpitch = ne + NW + 1;                   // dwords per row of the RIGHT u8 base tile
+  u32* base = lds + (size_t)NR * ne * EW;           // [NR][bpitch]
 
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * C::TWB;
   const int y0 = blockIdx.y * TY;
-  const int lqb = tid;                    // entry index of this lane's pixel group inside the tile
-  const int q = x0 + 4 * tid;             // first of the lane's 4 output pixels
+  const int q = x0 + 4 * tid;                       // first of the lane's 4 output pixels
+  bool bad = false;
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  if (FIX) {
+    if (need_fix[wg] == 0) return;                  // workgroup-uniform
+  } else if (wg == 0 && tid == 0) {
+    *flag_clear = 0;                                // the NEXT call's flag
+  }
 
-  // LEFT windows for all rows: win[r][n] = bytes L[q+4n .. q+4n+7]
-  u64 win[NR][NW];
+  // ---- LEFT: float tile -> u8 in LDS (borrowing the entry array) -> per-lane register windows ----
+  stage_u8_rows(L, ls, lw, lh, x0, y0, NR, C::LBW, C::LBW, ent, tid, C::THREADS, bad);
+  __syncthreads();
+  u64 win[NR][NW];                                  // win[r][n] = bytes L[q+4n .. q+4n+7]
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    const u32* lp = reinterpret_cast<const u32*>(L8 + (size_t)(y0 + r) * pitch_l + q);
     u32 a[NW + 1];
 #pragma unroll
-    for (int n = 0; n <= NW; ++n) a[n] = lp[n];
+    for (int n = 0; n <= NW; ++n) a[n] = ent[r * C::LBW + tid + n];
 #pragma unroll
     for (int n = 0; n < NW; ++n) win[r][n] = (u64)a[n] | ((u64)a[n + 1] << 32);
   }
 
-  u32 K[TY][4];       // best key per pixel: cost << 16 | disparity index
-  u32 MX[TY][2];      // worst cost, packed u16 x 2
+  u32 K[TY][4];                                     // best key per pixel: cost << 16 | disparity index
+  u32 MN[TY][2], MX[TY][2];                         // packed best / worst cost (fix-up kernel only)
 #pragma unroll
   for (int y = 0; y < TY; ++y) {
     K[y][0] = K[y][1] = K[y][2] = K[y][3] = 0xffffffffu;
+    MN[y][0] = MN[y][1] = 0xffffffffu;
     MX[y][0] = MX[y][1] = 0u;
   }
-  const u32 HI = 0xffff0000u;
+  u32 eq_lo = 0xffffffffu, eq_hi = 0xffffffffu;     // bit y*4+s: "all compared costs of pixel (y,s) were equal"
+  int eq_checks = 0;
+  // Probed step pairs: a pixel stays a candidate only if all NPROBE compared cost pairs were equal.  On noise one
+  // pair is equal with p ~ 7e-4, so 4 pairs leave ~2e-13 per pixel; a flat (truly invalid) pixel always passes.
+  constexpr int NPROBE = 4;
+  const u32 zero = 0;
 
-  for (int dy = 0; dy < sy; ++dy) {
-    for (int t = 0; t < 4; ++t) {
-      const int a_last = (sx + 2 - t) >> 2;            // last step with any valid slot (floor; sx+2-t >= 0)
-      // ---- rebuild the LDS array of RIGHT word groups at byte phase t ----
-      __syncthreads();                                   // previous pass done reading
-      for (int r = 0; r < NR; ++r) {
-        const uint8_t* rrow = R8 + (size_t)(y0 + r + dy) * pitch_r + x0;
+  typedef std::true_type T;
+  typedef std::false_type F;
+
+  {
+    constexpr bool MAXSWEEP = FIX;
+    for (int dy = 0; dy < sy; ++dy) {
+      __syncthreads();                              // everyone is done with the previous base tile / windows
+      stage_u8_rows(R, rs, rcw, rch, x0, y0 + dy, NR, bpitch, bpitch, base, tid, C::THREADS, bad);
+      for (int t = 0; t < 4; ++t) {
+        const int a_last = (sx + 2 - t) >> 2;       // last step with any valid slot
+        __syncthreads();                            // base staged / previous phase's readers done
         for (int m = tid; m < ne; m += C::THREADS) {
-          const u32* bp = reinterpret_cast<const u32*>(rrow + 4 * m);
-          u32 b[NW + 1];
+#pragma unroll 2
+          for (int r = 0; r < NR; ++r) {
+            const u32* bp = base + (size_t)r * bpitch + m;
+            u32 b[NW + 1];
 #pragma unroll
-          for (int n = 0; n <= NW; ++n) b[n] = bp[n];
-          u32 w[EW];
+            for (int n = 0; n <= NW; ++n) b[n] = bp[n];
+            u32 w[EW];
 #pragma unroll
-          for (int n = 0; n < EW; ++n) w[n] = 0;
+            for (int n = 0; n < EW; ++n) w[n] = 0;
 #pragma unroll
-          for (int n = 0; n < NW; ++n) w[n] = __builtin_amdgcn_alignbyte(b[n + 1], b[n], t);
-          w[NW - 1] &= C::LAST_MASK;
-          u32* e = lds + ((size_t)r * ne + m) * EW;
-          if (EW == 2) *reinterpret_cast<uint2*>(e) = make_uint2(w[0], w[1]);
-          else *reinterpret_cast<uint4*>(e) = make_uint4(w[0], w[1], w[2 % EW], w[3 % EW]);
+            for (int n = 0; n < NW; ++n) w[n] = __builtin_amdgcn_alignbyte(b[n + 1], b[n], t);
+            w[NW - 1] &= C::LAST_MASK;
+            u32* e = ent + ((size_t)r * ne + m) * EW;
+            if (EW == 2) *reinterpret_cast<uint2*>(e) = make_uint2(w[0], w[1]);
+            else *reinterpret_cast<uint4*>(e) = make_uint4(w[0], w[1], w[2 % EW], w[3 % EW]);
+          }
         }
-      }
-      __syncthreads();
+        __syncthreads();
 
-      // One step = one accumulator chain down the NR rows.  MASKED handles range ends (some slots outside
-      // [0,sx)); PAIR processes steps a and a+1 together so the WTA is one v_min3_u32 per pixel.
-      auto step = [&](int a, auto masked_tag, auto pair_tag) __attribute__((always_inline)) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
-        constexpr bool PAIR = decltype(pair_tag)::value;
-        const int jbase = 4 * a + t;                     // d for slot i is jbase - i
-        const int ibase = dy * sx + jbase;
-        u32 idxA[4], idxB[4];
-        u32 orA[2] = {0u, 0u};
+        // One step = one accumulator chain down the NR rows.  MASKED handles the range ends (some slots outside
+        // [0,sx)); PAIR processes steps a and a+1 together so the WTA is one v_min3_u32 per pixel; PROBE adds the
+        // equality probe of the validity pre-filter (two iterations per workgroup).
+        auto step = [&](int a, auto masked_tag, auto pair_tag, auto probe_tag) __attribute__((always_inline)) {
+          constexpr bool MASKED = decltype(masked_tag)::value;
+          constexpr bool PAIR = decltype(pair_tag)::value;
+          constexpr bool PROBE = decltype(probe_tag)::value;
+          const int jbase = 4 * a + t;              // d for slot i is jbase - i
+          const int ibase = dy * sx + jbase;
+          u32 kinA[4], kinB[4];                     // key registers: low half = disparity index
+          u32 orA[2] = {0u, 0u};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          idxA[i] = (u32)(ibase - i) & 0xffffu;
-          idxB[i] = (u32)(ibase + 4 - i) & 0xffffu;
-          if (MASKED) {
-            const int d = jbase - i;
-            if (d < 0 || d >= sx) orA[i >> 1] |= (i & 1) ? 0xffff0000u : 0x0000ffffu;
-          }
-        }
-        const u32* ep = lds + (size_t)(lqb + a) * EW;
-        u64 accA = 0, accB = 0;
-        u64 PA[NR], PB[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          const u32* e = ep + (size_t)r * ne * EW;
-          u32 wa[EW], wb[EW];
-          if (EW == 2) {
-            const uint2 v = *reinterpret_cast<const uint2*>(e);
-            wa[0] = v.x; wa[1] = v.y;
-            if (PAIR) { const uint2 u = *reinterpret_cast<const uint2*>(e + EW); wb[0] = u.x; wb[1] = u.y; }
-          } else {
-            const uint4 v = *reinterpret_cast<const uint4*>(e);
-            wa[0] = v.x; wa[1] = v.y; wa[2 % EW] = v.z; wa[3 % EW] = v.w;
-            if (PAIR) { const uint4 u = *reinterpret_cast<const uint4*>(e + EW); wb[0] = u.x; wb[1] = u.y; wb[2 % EW] = u.z; wb[3 % EW] = u.w; }
-          }
-#pragma unroll
-          for (int n = 0; n < NW; ++n) {
-            accA = __builtin_amdgcn_qsad_pk_u16_u8(win[r][n], wa[n], accA);
-            if (PAIR) accB = __builtin_amdgcn_qsad_pk_u16_u8(win[r][n], wb[n], accB);
-          }
-          PA[r] = accA;
-          if (PAIR) PB[r] = accB;
-          if (r >= KY - 1) {
-            const int y = r - (KY - 1);
-            u32 sA0 = (u32)PA[r], sA1 = (u32)(PA[r] >> 32);
-            if (r >= KY) { sA0 = pk_sub_u16(sA0, (u32)PA[r - KY]); sA1 = pk_sub_u16(sA1, (u32)(PA[r - KY] >> 32)); }
+          for (int i = 0; i < 4; ++i) {
+            kinA[i] = (u32)(ibase - i) & 0xffffu;
+            kinB[i] = (u32)(ibase + 4 - i) & 0xffffu;
             if (MASKED) {
-              MX[y][0] = pk_max_u16(MX[y][0], sA0 & ~orA[0]);
-              MX[y][1] = pk_max_u16(MX[y][1], sA1 & ~orA[1]);
-              sA0 |= orA[0]; sA1 |= orA[1];
-            } else {
-              MX[y][0] = pk_max_u16(MX[y][0], sA0);
-              MX[y][1] = pk_max_u16(MX[y][1], sA1);
-            }
-            const u32 kA0 = (sA0 << 16) | idxA[0], kA1 = (sA0 & HI) | idxA[1];
-            const u32 kA2 = (sA1 << 16) | idxA[2], kA3 = (sA1 & HI) | idxA[3];
-            if (PAIR) {
-              u32 sB0 = (u32)PB[r], sB1 = (u32)(PB[r] >> 32);
-              if (r >= KY) { sB0 = pk_sub_u16(sB0, (u32)PB[r - KY]); sB1 = pk_sub_u16(sB1, (u32)(PB[r - KY] >> 32)); }
-              MX[y][0] = pk_max_u16(MX[y][0], sB0);
-              MX[y][1] = pk_max_u16(MX[y][1], sB1);
-              const u32 kB0 = (sB0 << 16) | idxB[0], kB1 = (sB0 & HI) | idxB[1];
-              const u32 kB2 = (sB1 << 16) | idxB[2], kB3 = (sB1 & HI) | idxB[3];
-              K[y][0] = umin3(K[y][0], kA0, kB0);
-              K[y][1] = umin3(K[y][1], kA1, kB1);
-              K[y][2] = umin3(K[y][2], kA2, kB2);
-              K[y][3] = umin3(K[y][3], kA3, kB3);
-            } else {
-              K[y][0] = min(K[y][0], kA0);
-              K[y][1] = min(K[y][1], kA1);
-              K[y][2] = min(K[y][2], kA2);
-              K[y][3] = min(K[y][3], kA3);
+              const int d = jbase - i;
+              if (d < 0 || d >= sx) orA[i >> 1] |= (i & 1) ? 0xffff0000u : 0x0000ffffu;
             }
           }
-        }
-      };
-      typedef std::true_type T;
-      typedef std::false_type F;
+          const u32* ep = ent + (size_t)(tid + a) * EW;
+          u64 accA = 0, accB = 0;
+          u64 PA[NR], PB[NR];
+          // LDS reads are issued PF rows ahead by hand: the volatile asm statements below are scheduling barriers
+          // for memory operations, so the compiler will not hoist them itself.
+          constexpr int PF = 4;
+          u32 wa[NR][EW], wb[NR][EW];
+          auto fetch = [&](int r) __attribute__((always_inline)) {
+            const u32* e = ep + (size_t)r * ne * EW;
+            if (EW == 2) {
+              const uint2 v = *reinterpret_cast<const uint2*>(e);
+              wa[r][0] = v.x; wa[r][1] = v.y;
+              if (PAIR) { const uint2 u = *reinterpret_cast<const uint2*>(e + EW); wb[r][0] = u.x; wb[r][1] = u.y; }
+            } else {
+              const uint4 v = *reinterpret_cast<const uint4*>(e);
+              wa[r][0] = v.x; wa[r][1] = v.y; wa[r][2 % EW] = v.z; wa[r][3 % EW] = v.w;
+              if (PAIR) { const uint4 u = *reinterpret_cast<const uint4*>(e + EW); wb[r][0] = u.x; wb[r][1] = u.y; wb[r][2 % EW] = u.z; wb[r][3 % EW] = u.w; }
+            }
+          };
+#pragma unroll
+          for (int r = 0; r < PF && r < NR; ++r) fetch(r);
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            if (r + PF < NR) fetch(r + PF);
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+              accA = __builtin_amdgcn_qsad_pk_u16_u8(win[r][n], wa[r][n], accA);
+              if (PAIR) accB = __builtin_amdgcn_qsad_pk_u16_u8(win[r][n], wb[r][n], accB);
+            }
+            PA[r] = accA;
+            if (PAIR) PB[r] = accB;
+            if (r >= KY - 1) {
+              const int y = r - (KY - 1);
+              const int ro = (r >= KY) ? r - KY : 0;
+              const u32 nA0 = (u32)PA[r], nA1 = (u32)(PA[r] >> 32);
+              const u32 oA0 = (r >= KY) ? (u32)PA[ro] : zero;
+              const u32 oA1 = (r >= KY) ? (u32)(PA[ro] >> 32) : zero;
+              if (MAXSWEEP) {
+                const u32 sA0 = pk_sub_u16(nA0, oA0), sA1 = pk_sub_u16(nA1, oA1);
+                MN[y][0] = pk_min_u16(MN[y][0], MASKED ? (sA0 | orA[0]) : sA0);
+                MN[y][1] = pk_min_u16(MN[y][1], MASKED ? (sA1 | orA[1]) : sA1);
+                MX[y][0] = pk_max_u16(MX[y][0], MASKED ? (sA0 & ~orA[0]) : sA0);
+                MX[y][1] = pk_max_u16(MX[y][1], MASKED ? (sA1 & ~orA[1]) : sA1);
+                if (PAIR) {
+                  const u32 nB0 = (u32)PB[r], nB1 = (u32)(PB[r] >> 32);
+                  const u32 oB0 = (r >= KY) ? (u32)PB[ro] : zero;
+                  const u32 oB1 = (r >= KY) ? (u32)(PB[ro] >> 32) : zero;
+                  const u32 sB0 = pk_sub_u16(nB0, oB0), sB1 = pk_sub_u16(nB1, oB1);
+                  MN[y][0] = pk_min_u16(MN[y][0], sB0);
+                  MN[y][1] = pk_min_u16(MN[y][1], sB1);
+                  MX[y][0] = pk_max_u16(MX[y][0], sB0);
+                  MX[y][1] = pk_max_u16(MX[y][1], sB1);
+                }
+              } else {
+                key_sub<0>(kinA[0], nA0, oA0); key_sub<1>(kinA[1], nA0, oA0);
+                key_sub<0>(kinA[2], nA1, oA1); key_sub<1>(kinA[3], nA1, oA1);
+                if (PAIR) {
+                  const u32 nB0 = (u32)PB[r], nB1 = (u32)(PB[r] >> 32);
+                  const u32 oB0 = (r >= KY) ? (u32)PB[ro] : zero;
+                  const u32 oB1 = (r >= KY) ? (u32)(PB[ro] >> 32) : zero;
+                  key_sub<0>(kinB[0], nB0, oB0); key_sub<1>(kinB[1], nB0, oB0);
+                  key_sub<0>(kinB[2], nB1, oB1); key_sub<1>(kinB[3], nB1, oB1);
+                  if (PROBE) {
+                    u32 ne_bits = 0;
+                    if ((kinA[0] ^ kinB[0]) >> 16) ne_bits |= 1u << ((y * 4 + 0) & 31);
+                    if ((kinA[1] ^ kinB[1]) >> 16) ne_bits |= 1u << ((y * 4 + 1) & 31);
+                    if ((kinA[2] ^ kinB[2]) >> 16) ne_bits |= 1u << ((y * 4 + 2) & 31);
+                    if ((kinA[3] ^ kinB[3]) >> 16) ne_bits |= 1u << ((y * 4 + 3) & 31);
+                    if (y * 4 < 32) eq_lo &= ~ne_bits; else eq_hi &= ~ne_bits;
+                  }
+                  umin3_acc(K[y][0], kinA[0], kinB[0]);
+                  umin3_acc(K[y][1], kinA[1], kinB[1]);
+                  umin3_acc(K[y][2], kinA[2], kinB[2]);
+                  umin3_acc(K[y][3], kinA[3], kinB[3]);
+                } else {
+                  // range ends: slots outside [0,sx) must never win
+                  const u32 kA0 = (MASKED && (orA[0] & 0x0000ffffu)) ? 0xffffffffu : kinA[0];
+                  const u32 kA1 = (MASKED && (orA[0] & 0xffff0000u)) ? 0xffffffffu : kinA[1];
+                  const u32 kA2 = (MASKED && (orA[1] & 0x0000ffffu)) ? 0xffffffffu : kinA[2];
+                  const u32 kA3 = (MASKED && (orA[1] & 0xffff0000u)) ? 0xffffffffu : kinA[3];
+                  umin3_acc(K[y][0], kA0, kA0);
+                  umin3_acc(K[y][1], kA1, kA1);
+                  umin3_acc(K[y][2], kA2, kA2);
+                  umin3_acc(K[y][3], kA3, kA3);
+                }
+              }
+            }
+          }
+        };
 
-      // clean range: every slot valid  <=>  jbase-3 >= 0 and jbase <= sx-1
-      int a_lo = (t >= 3) ? 0 : 1;
-      int a_hi = (sx - 1 - t >= 0) ? ((sx - 1 - t) >> 2) + 1 : 0;   // exclusive
-      if (a_hi > a_last + 1) a_hi = a_last + 1;
-      if (a_lo > a_hi) a_lo = a_hi;
-      int a = 0;
-      for (; a < a_lo && a <= a_last; ++a) step(a, T{}, F{});
-      for (; a + 1 < a_hi; a += 2) step(a, F{}, T{});
-      for (; a <= a_last; ++a) step(a, T{}, F{});
+        // clean range: every slot valid  <=>  jbase-3 >= 0 and jbase <= sx-1
+        int a_lo = (t >= 3) ? 0 : 1;
+        int a_hi = (sx - 1 - t >= 0) ? ((sx - 1 - t) >> 2) + 1 : 0;   // exclusive
+        if (a_hi > a_last + 1) a_hi = a_last + 1;
+        if (a_lo > a_hi) a_lo = a_hi;
+        int a = 0;
+        for (; a < a_lo && a <= a_last; ++a) step(a, T{}, F{}, F{});
+        if (!MAXSWEEP && dy == 0 && t == 0) {
+          for (; a + 1 < a_hi && eq_checks < NPROBE; a += 2, ++eq_checks) step(a, F{}, T{}, T{});
+        }
+        for (; a + 1 < a_hi; a += 2) step(a, F{}, T{}, F{});
+        for (; a <= a_last; ++a) step(a, T{}, F{}, F{});
+      }
     }
   }
 
-  // ---- epilogue: decode keys, validity, store in the PixelMask<Vector2i> layout --------------------------
+  if (FIX) {
+#pragma unroll
+    for (int y = 0; y < TY; ++y) {
+      const u32 same0 = MN[y][0] ^ MX[y][0], same1 = MN[y][1] ^ MX[y][1];
+      const bool inv[4] = {(same0 & 0xffffu) == 0, (same0 >> 16) == 0, (same1 & 0xffffu) == 0, (same1 >> 16) == 0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        if (inv[s] && y0 + y < oh && q + s < ow)
+          out[((ptrdiff_t)(y0 + y) * os + q + s) * 3 + 2] = 0;   // best == worst (Correlation.cc:121-133)
+    }
+    return;
+  }
+  if (bad) atomicOr(flag_set, 1);
+
+  // ---- epilogue 1: decode keys, store {dx, dy, VALID} in the PixelMask<Vector2i> layout -------------------
 #pragma unroll
   for (int y = 0; y < TY; ++y) {
     const int oy = y0 + y;
     if (oy >= oh) continue;
     int32_t* orow = out + ((ptrdiff_t)oy * os + q) * 3;
-    u32 mx[4] = {MX[y][0] & 0xffffu, MX[y][0] >> 16, MX[y][1] & 0xffffu, MX[y][1] >> 16};
     int32_t v[12];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const u32 k = K[y][s];
-      const u32 di = k & 0xffffu;
+      const u32 di = K[y][s] & 0xffffu;
       int dx, dy;
       if (sy == 1) { dx = (int)di; dy = 0; } else { dy = (int)(di / (u32)sx); dx = (int)(di - (u32)dy * (u32)sx); }
       v[3 * s] = dx;
       v[3 * s + 1] = dy;
-      v[3 * s + 2] = ((k >> 16) == mx[s]) ? 0 : 0x7fffffff;
+      v[3 * s + 2] = 0x7fffffff;
     }
     if (q + 3 < ow) {
 #pragma unroll
@@ -265,18 +392,38 @@ bm_sad_u8_kernel(const uint8_t* __restrict__ L8, int pitch_l, const uint8_t* __r
         if (q + s < ow) { orow[3 * s] = v[3 * s]; orow[3 * s + 1] = v[3 * s + 1]; orow[3 * s + 2] = v[3 * s + 2]; }
     }
   }
+
+  // ---- validity: only pixels whose probed costs were all equal can be invalid ---------------------------------
+  static_assert(TY * 4 <= 64, "equality bitmap holds 64 pixels per lane");
+  u32 cand_lo = eq_lo, cand_hi = eq_hi;
+  if (eq_checks < NPROBE) { cand_lo = 0xffffffffu; cand_hi = 0xffffffffu; }   // small search range: nothing is known
+  // pixels outside the output image (zero padding: every cost equal) must not trigger the second sweep
+#pragma unroll
+  for (int y = 0; y < TY; ++y) {
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      if (y0 + y >= oh || q + s2 >= ow) {
+        if (y * 4 + s2 < 32) cand_lo &= ~(1u << ((y * 4 + s2) & 31)); else cand_hi &= ~(1u << ((y * 4 + s2) & 31));
+      }
+    }
+  }
+  const int any = __syncthreads_or((cand_lo | cand_hi) != 0u);   // never set on textured imagery
+  if (tid == 0) need_fix[wg] = any;
 }
 
+typedef void (*KernelFn)(const float*, ptrdiff_t, int, int, const float*, ptrdiff_t, int, int, int, int, int,
+                         int32_t*, ptrdiff_t, int, int, int*, int*, int*);
 struct Launch {
   int kx, ky, ty;
-  int threads, twb, nr, ew;
-  void (*fn)(const uint8_t*, int, const uint8_t*, int, int, int, int, int32_t*, ptrdiff_t, int, int);
+  int threads, twb, nr, ew, nw;
+  KernelFn fn, fix_fn;
 };
 
 template <int KX, int KY, int TY>
 constexpr Launch make_launch() {
   typedef Cfg<KX, KY, TY> C;
-  return Launch{KX, KY, TY, C::THREADS, C::TWB, C::NR, C::EW, bm_sad_u8_kernel<KX, KY, TY>};
+  return Launch{KX, KY, TY, C::THREADS, C::TWB, C::NR, C::EW, C::NW,
+                bm_sad_u8_kernel<KX, KY, TY, false>, bm_sad_u8_kernel<KX, KY, TY, true>};
 }
 
 // Instantiated kernel sizes.  Others fall back to the generic path.
@@ -291,11 +438,16 @@ const Launch* find_launch(int kx, int ky) {
   return nullptr;
 }
 
-constexpr size_t kMaxLds = 64 * 1024;
+constexpr size_t kMaxLds = 80 * 1024;   // two workgroups per CU
+
+int entries_per_row(const Launch& l, int sx) { return l.twb / 4 + ((sx + 2) >> 2) + 1; }
 
 size_t lds_bytes(const Launch& l, int sx) {
-  const int ne = l.twb / 4 + ((sx + 2) >> 2) + 1;
-  return (size_t)l.nr * ne * l.ew * sizeof(u32);
+  const int ne = entries_per_row(l, sx);
+  const size_t ent = (size_t)l.nr * ne * l.ew;
+  const size_t left = (size_t)l.nr * (l.twb / 4 + l.nw + 1);        // borrowed from the entry array
+  const size_t base = (size_t)l.nr * (ne + l.nw + 1);
+  return ((ent > left ? ent : left) + base) * sizeof(u32);
 }
 
 }  // namespace
@@ -318,42 +470,42 @@ int vwgpu_launch_bm_sad_u8(vwgpu_ctx* ctx,
   if (!l) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "no packed-u8 kernel for %dx%d", kx, ky);
   const int ow = lw - kx + 1, oh = lh - ky + 1;
   const int rcw = lw + sx - 1, rch = lh + sy - 1;
-
   const int gx = (ow + l->twb - 1) / l->twb, gy = (oh + l->ty - 1) / l->ty;
-  const int ne = l->twb / 4 + ((sx + 2) >> 2) + 1;
-  // Padded planes so that every tile read stays inside the allocation (pad bytes are zero).
-  const int pitch_l = (int)vwgpu_align_up((size_t)gx * l->twb + 64, 64);
-  const int pitch_r = (int)vwgpu_align_up((size_t)(gx - 1) * l->twb + 4 * (size_t)(ne + 4) + 64, 64);
-  const int rows_l = gy * l->ty + ky;
-  const int rows_r = gy * l->ty + ky + sy;
-  const size_t lbytes = vwgpu_align_up((size_t)pitch_l * rows_l, 256);
-  const size_t rbytes = vwgpu_align_up((size_t)pitch_r * rows_r, 256);
-  int rc = vwgpu_arena_reserve(ctx, &ctx->scratch, 256 + lbytes + rbytes);
-  if (rc) return rc;
-  char* base = static_cast<char*>(ctx->scratch.base);
-  int* flag = reinterpret_cast<int*>(base);
-  uint8_t* l8 = reinterpret_cast<uint8_t*>(base + 256);
-  uint8_t* r8 = l8 + lbytes;
-  *d_fallback_flag = flag;
+  const int ne = entries_per_row(*l, sx);
 
-  VWGPU_HIP(ctx, hipMemsetAsync(flag, 0, 256, ctx->stream));
-  {
-    vwgpu_prof_scope ps(ctx, "pack_u8_left");
-    dim3 blk(64, 4), grd((pitch_l / 4 + 63) / 64, (rows_l + 3) / 4);
-    hipLaunchKernelGGL(pack_u8_kernel, grd, blk, 0, ctx->stream, left, ls, lw, lh,
-                       reinterpret_cast<u32*>(l8), pitch_l / 4, rows_l, flag);
+  // Two alternating device flags: call n raises flags[n&1] on unsuitable input and clears flags[(n+1)&1]
+  // for the next call, so no memset launch is needed (stream order makes this race free).
+  int rc = vwgpu_arena_reserve(ctx, &ctx->flags, 256 + (size_t)gx * gy * sizeof(int));
+  if (rc) return rc;
+  int* flags = static_cast<int*>(ctx->flags.base);
+  if (ctx->flags_base_seen != ctx->flags.base) { ctx->flags_init = false; ctx->flags_base_seen = ctx->flags.base; }
+  if (!ctx->flags_init) {
+    VWGPU_HIP(ctx, hipMemsetAsync(flags, 0, 256, ctx->stream));
+    ctx->flags_init = true;
   }
-  {
-    vwgpu_prof_scope ps(ctx, "pack_u8_right");
-    dim3 blk(64, 4), grd((pitch_r / 4 + 63) / 64, (rows_r + 3) / 4);
-    hipLaunchKernelGGL(pack_u8_kernel, grd, blk, 0, ctx->stream, right, rs, rcw, rch,
-                       reinterpret_cast<u32*>(r8), pitch_r / 4, rows_r, flag);
+  int* flag_set = flags + (ctx->flag_parity & 1);
+  int* flag_clear = flags + ((ctx->flag_parity + 1) & 1);
+  ctx->flag_parity ^= 1;
+  int* need_fix = flags + 64;                       // one int per workgroup, written by every matcher launch
+  *d_fallback_flag = flag_set;
+  const size_t shmem = lds_bytes(*l, sx);
+  if (shmem > 64 * 1024) {
+    VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(l->fn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(l->fix_fn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   }
   {
     vwgpu_prof_scope ps(ctx, "bm_sad_u8");
-    const size_t shmem = lds_bytes(*l, sx);
     hipLaunchKernelGGL(l->fn, dim3(gx, gy), dim3(l->threads), shmem, ctx->stream,
-                       l8, pitch_l, r8, pitch_r, sx, sy, ne, out, os, ow, oh);
+                       left, ls, lw, lh, right, rs, rcw, rch, sx, sy, ne, out, os, ow, oh,
+                       flag_set, flag_clear, need_fix);
+  }
+  {
+    vwgpu_prof_scope ps(ctx, "bm_sad_u8_validity_fix");
+    hipLaunchKernelGGL(l->fix_fn, dim3(gx, gy), dim3(l->threads), shmem, ctx->stream,
+                       left, ls, lw, lh, right, rs, rcw, rch, sx, sy, ne, out, os, ow, oh,
+                       flag_set, flag_clear, need_fix);
   }
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;

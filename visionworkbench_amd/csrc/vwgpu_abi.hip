@@ -86,6 +86,7 @@ void vwgpu_destroy(vwgpu_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   prof_clear(ctx);
   if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
+  if (ctx->flags.base) (void)hipFree(ctx->flags.base);
   if (ctx->staging.base) (void)hipFree(ctx->staging.base);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -128,11 +129,11 @@ int vwgpu_force_path(vwgpu_ctx* ctx, int path) {
 int vwgpu_last_path(const vwgpu_ctx* cctx) {
   vwgpu_ctx* ctx = const_cast<vwgpu_ctx*>(cctx);
   if (!ctx) return VWGPU_PATH_NONE;
-  if (ctx->last_path == VWGPU_PATH_SAD_U8 && ctx->scratch.base) {
+  if (ctx->last_path == VWGPU_PATH_SAD_U8 && ctx->last_flag) {
     // The fast path reports non-representable input through a device flag; the generic kernel then ran.
     int flag = 0;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return VWGPU_PATH_NONE;
-    if (hipMemcpy(&flag, ctx->scratch.base, sizeof flag, hipMemcpyDeviceToHost) != hipSuccess) return VWGPU_PATH_NONE;
+    if (hipMemcpy(&flag, ctx->last_flag, sizeof flag, hipMemcpyDeviceToHost) != hipSuccess) return VWGPU_PATH_NONE;
     return flag ? VWGPU_PATH_GENERIC_F64 : VWGPU_PATH_SAD_U8;
   }
   return ctx->last_path;
@@ -211,6 +212,7 @@ int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
     rc = vwgpu_launch_bm_sad_u8(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
     if (rc) return rc;
     ctx->last_path = VWGPU_PATH_SAD_U8;
+    ctx->last_flag = d_flag;
     if (ctx->forced_path == VWGPU_PATH_SAD_U8) return VWGPU_OK;   // caller inspects vwgpu_last_path()
     // Inputs that are not integer-valued in [0,255] raise the device flag; the generic kernel then
     // recomputes the whole image (its blocks return at once when the flag is clear).

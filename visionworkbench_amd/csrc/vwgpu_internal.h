@@ -32,7 +32,12 @@ struct vwgpu_ctx {
   bool profiling = false;
   std::vector<vwgpu_prof_rec> prof;
   std::vector<hipEvent_t> event_pool;
-  vwgpu_arena scratch;   // kernel scratch (packed u8 planes, NCC precision images, flags)
+  vwgpu_arena scratch;   // kernel scratch (NCC precision images)
+  vwgpu_arena flags;     // two alternating "input not representable" flags of the packed-u8 path
+  bool flags_init = false;
+  void* flags_base_seen = nullptr;
+  int flag_parity = 0;
+  int* last_flag = nullptr;
   vwgpu_arena staging;   // device copies of host images for the host-pointer entry points
   int num_cu = 256;
 };
