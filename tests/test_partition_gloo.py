@@ -1,0 +1,67 @@
+"""N > 1 path of the benchmark / engine on CPU: world_size-2 `gloo` processes each take one row strip (with its
+halo rows), compute it with the oracle standing in for the GPU kernel, and rank 0 reassembles the image, which must
+equal the single-call result bit for bit.  This is the partition + halo arithmetic bench.py uses (no collective is
+needed on the data path; the gather here only serves the check)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from visionworkbench_amd import partition, synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, kernel, search, w, h, q):
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    left, right, _ = synth.stereo_pair(w, h, search[0], search[1], block=32)
+    (la, lb), (ra, rb) = partition.strip_inputs(rank, world, h, kernel[1], search[1])
+    part = oracle.calc_disparity(0, left[la:lb], right[ra:rb], kernel, search)
+    r0, r1 = partition.row_strip(rank, world, h - kernel[1] + 1)
+    assert part.shape[0] == r1 - r0
+    parts = [None] * world
+    dist.all_gather_object(parts, part)
+    dist.barrier()
+    if rank == 0:
+        q.put(np.concatenate(parts, axis=0))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_strips_reassemble_exactly(oracle, world):
+    kernel, search, w, h = (7, 7), (17, 2), 96, 61
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kernel, search, w, h, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    left, right, _ = synth.stereo_pair(w, h, search[0], search[1], block=32)
+    want = oracle.calc_disparity(0, left, right, kernel, search)
+    assert np.array_equal(got, want)
+
+
+def test_strip_ranges_cover_everything():
+    for world in (1, 2, 4, 8):
+        rows = [partition.row_strip(r, world, 4090) for r in range(world)]
+        assert rows[0][0] == 0 and rows[-1][1] == 4090
+        assert all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+        (la, lb), (ra, rb) = partition.strip_inputs(world - 1, world, 4096, 7, 1)
+        assert lb == 4096 and rb == 4096
