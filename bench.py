@@ -55,10 +55,13 @@ def cpu_baseline(left, right, budget_s=12.0):
     t1 = time.perf_counter() - t0
     ns_per_op = t1 / (done1 * SEARCH[0] * SEARCH[1]) * 1e9
     tiles = int(min(ntiles_total, max(cores, budget_s / t1 * cores * 0.7)))
-    est = t1 * tiles / cores
-    reps = int(max(1, min(50, round(3.0 / max(est, 1e-3)))))       # many-core hosts finish one pass in ~0.1 s
-    done, t0 = 0, time.perf_counter()
-    for _ in range(reps):
+    # one threaded pass to see how the host really scales (many-core hosts are memory bound here), then repeat
+    # it until ~budget_s seconds of wall time have been spent
+    t0 = time.perf_counter()
+    _, done = oracle.calc_disparity_tiled(0, left, right, KERNEL, SEARCH, tile=tile, threads=cores, max_tiles=tiles)
+    first = time.perf_counter() - t0
+    reps = 1 + int(max(0, min(40, (budget_s - first) / max(first, 1e-3))))
+    for _ in range(reps - 1):
         _, d = oracle.calc_disparity_tiled(0, left, right, KERNEL, SEARCH, tile=tile, threads=cores, max_tiles=tiles)
         done += d
     dt = time.perf_counter() - t0

@@ -5,8 +5,9 @@ import sys
 
 
 def short_name(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     head = name[:name.index(">(") + 1] if ">(" in name else name.split("(")[0]
-    return head.replace("void ", "").replace("(anonymous namespace)::", "")[:90]
+    return head[:90]
 
 
 def main(path, out=None):
