@@ -4,7 +4,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvwgpu.so")
+LIB_PATH = os.environ.get("VWGPU_LIBRARY") or os.path.join(_HERE, "lib", "libvwgpu.so")  # override: experiments only
 _LIB = None
 
 SYMBOLS = [

@@ -101,42 +101,113 @@ __device__ __forceinline__ u32 pack4(float v0, float v1, float v2, float v3, boo
   return to_u8(v0, bad) | (to_u8(v1, bad) << 8) | (to_u8(v2, bad) << 16) | (to_u8(v3, bad) << 24);
 }
 
+// float4 -> 4 packed u8 (v_cvt_pk_u8_f32 saturates) and the exactness test of the fast path: a pixel is
+// representable iff converting the byte back gives the same float; the differences are OR-ed into `acc`
+// (non-zero bits => some pixel was not an integer in [0,255]; NaN/Inf/-0.0 also land there).
+__device__ __forceinline__ u32 pack4_check(float4 v, u32& acc) {
+  u32 p = 0;
+  p = __builtin_amdgcn_cvt_pk_u8_f32(v.x, 0, p);
+  p = __builtin_amdgcn_cvt_pk_u8_f32(v.y, 1, p);
+  p = __builtin_amdgcn_cvt_pk_u8_f32(v.z, 2, p);
+  p = __builtin_amdgcn_cvt_pk_u8_f32(v.w, 3, p);
+  acc |= __builtin_bit_cast(u32, v.x - (float)(p & 0xffu));
+  acc |= __builtin_bit_cast(u32, v.y - (float)((p >> 8) & 0xffu));
+  acc |= __builtin_bit_cast(u32, v.z - (float)((p >> 16) & 0xffu));
+  acc |= __builtin_bit_cast(u32, v.w - (float)(p >> 24));
+  return p;
+}
+
+// Loads NROWS rows of a float image as packed u8 dwords into LDS: dst[r][g] = bytes (x0+4g .. x0+4g+3), zero
+// outside [0,w) x [0,h).  Row base pointers are workgroup-uniform (scalar), the per-lane part of the address is one
+// offset shared by all rows, and all NROWS loads of a thread are unconditional (out-of-range groups read offset 0 of
+// a valid row and are zeroed afterwards), so they are in flight together: staging a tile costs about one memory
+// latency.  Columns beyond the first `nthreads` groups (the search margin) are spread evenly over the workgroup.
+// Groups straddling the right image edge (at most one per row) are patched by a scalar tail loop.
+template <int NROWS>
 __device__ __forceinline__ void stage_u8_rows(const float* __restrict__ img, ptrdiff_t stride, int w, int h,
-                                              int x0, int y0, int nrows, int ndw, int dst_pitch_dw,
-                                              u32* __restrict__ dst, int tid, int nthreads, bool& bad) {
+                                              int x0, int y0, int ndw, int dst_pitch_dw,
+                                              u32* __restrict__ dst, int tid, int nthreads, u32& acc) {
   const bool vec4 = ((reinterpret_cast<uintptr_t>(img) & 15) == 0) && ((stride & 3) == 0);
-  for (int g = tid; g < ndw; g += nthreads) {
-    const int x = x0 + 4 * g;
-    if (vec4 && x + 3 < w) {
-#pragma unroll 4
-      for (int r = 0; r < nrows; ++r) {
-        const int y = y0 + r;
-        u32 p = 0;
-        if (y < h) {
-          const float4 v = *reinterpret_cast<const float4*>(img + (ptrdiff_t)y * stride + x);
-          p = pack4(v.x, v.y, v.z, v.w, bad);
-        }
-        dst[(size_t)r * dst_pitch_dw + g] = p;
-      }
-    } else {
-#pragma unroll 2
-      for (int r = 0; r < nrows; ++r) {
-        const int y = y0 + r;
-        const float* row = img + (ptrdiff_t)y * stride;
-        u32 p = 0;
-        if (y < h) {
-          if (x + 3 < w) {
-            p = pack4(row[x], row[x + 1], row[x + 2], row[x + 3], bad);
-          } else {
+  auto load4 = [&](const float* rowp, int off, bool full) __attribute__((always_inline)) -> float4 {
+    if (vec4) return *reinterpret_cast<const float4*>(rowp + off);
+    return make_float4(rowp[off], rowp[off + (full ? 1 : 0)], rowp[off + (full ? 2 : 0)], rowp[off + (full ? 3 : 0)]);
+  };
+  // main part: group g = tid, every row
+  if (tid < ndw) {
+    const int g = tid, x = x0 + 4 * g;
+    const bool colin = x + 3 < w;
+    const int off = colin ? x : 0;
+    float4 v[NROWS];
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-              if (x + b < w) p |= to_u8(row[x + b], bad) << (8 * b);
-          }
-        }
-        dst[(size_t)r * dst_pitch_dw + g] = p;
+    for (int r = 0; r < NROWS; ++r) {
+      const float* rowp = (y0 + r < h) ? img + (ptrdiff_t)(y0 + r) * stride : img;   // uniform
+      v[r] = load4(rowp, off, colin);
+    }
+#pragma unroll
+    for (int r = 0; r < NROWS; ++r) {
+      u32 a = 0;
+      const u32 p = pack4_check(v[r], a);
+      const bool inb = colin && (y0 + r < h);
+      if (inb) acc |= a;
+      dst[r * dst_pitch_dw + g] = inb ? p : 0u;
+    }
+  }
+  // remainder columns [nthreads, ndw): NROWS * rem items spread over all threads, 4 in flight per thread
+  const int rem = ndw - nthreads;
+  if (rem > 0) {
+    const int total = NROWS * rem;
+    const float inv = 1.0f / (float)rem;
+    for (int i0 = 0; i0 < total; i0 += 4 * nthreads) {
+      float4 v[4]; int di[4]; bool inb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int idx = i0 + k * nthreads + tid;
+        int r = (int)(((float)(idx < total ? idx : 0) + 0.5f) * inv);
+        int c = (idx < total ? idx : 0) - r * rem;
+        if (c < 0) { --r; c += rem; }
+        if (c >= rem) { ++r; c -= rem; }
+        const int g = nthreads + c, x = x0 + 4 * g;
+        inb[k] = (idx < total) && (x + 3 < w) && (y0 + r < h);
+        di[k] = (idx < total) ? r * dst_pitch_dw + g : -1;
+        const float* src = inb[k] ? img + (ptrdiff_t)(y0 + r) * stride + x : img;
+        v[k] = load4(src, 0, inb[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        u32 a = 0;
+        const u32 p = pack4_check(v[k], a);
+        if (inb[k]) acc |= a;
+        if (di[k] >= 0) dst[di[k]] = inb[k] ? p : 0u;
       }
     }
   }
+  // right-edge groups: x < w <= x+3
+  const int ge = (w - x0) >> 2;
+  if (ge >= 0 && ge < ndw && ((w - x0) & 3) != 0) {
+    for (int r = tid; r < NROWS; r += nthreads) {
+      const int y = y0 + r;
+      u32 p = 0;
+      if (y < h) {
+        const float* row = img + (ptrdiff_t)y * stride;
+        const int x = x0 + 4 * ge;
+        bool bad = false;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (x + b < w) p |= to_u8(row[x + b], bad) << (8 * b);
+        if (bad) acc |= 1u;
+      }
+      dst[r * dst_pitch_dw + ge] = p;
+    }
+  }
+}
+
+// idx / d and idx % d for 0 <= idx < 2^20 without an integer division (d is workgroup-uniform, inv = 1.0f / d).
+__device__ __forceinline__ void divmod_small(int idx, int d, float inv, int& quo, int& rem) {
+  int qq = (int)(((float)idx + 0.5f) * inv);
+  int rr = idx - qq * d;
+  if (rr < 0) { --qq; rr += d; }
+  if (rr >= d) { ++qq; rr -= d; }
+  quo = qq; rem = rr;
 }
 
 // FIX = false: the matcher (first sweep: keys + equality probe; raises need_fix[workgroup] if some pixel may be
@@ -160,8 +231,27 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   const int x0 = blockIdx.x * C::TWB;
   const int y0 = blockIdx.y * TY;
   const int q = x0 + 4 * tid;                       // first of the lane's 4 output pixels
-  bool bad = false;
+  u32 bad_acc = 0;                                  // non-zero: some input pixel is not an integer in [0,255]
   const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+#if defined(VWGPU_EXP) && VWGPU_EXP == 2
+  long long ts_[24]; int nts_ = 0; const long long wc0_ = wall_clock64();
+#define STAMP() do { if (tid == 0 && nts_ < 24) ts_[nts_++] = clock64(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+  STAMP();
+#if defined(VWGPU_EXP) && (VWGPU_EXP == 3 || VWGPU_EXP == 4 || VWGPU_EXP == 5)
+  {
+    bool dly = false;
+    if (VWGPU_EXP == 3) dly = (wg & 1) != 0;
+    if (VWGPU_EXP == 4) dly = ((wg >> 8) & 1) != 0;
+    if (VWGPU_EXP == 5) dly = ((wg >> 3) & 1) != 0;
+    if (!FIX && dly && wg < 512) {
+      const long long t0 = clock64();
+      while (clock64() - t0 < 40000) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+#endif
   if (FIX) {
     if (need_fix[wg] == 0) return;                  // workgroup-uniform
   } else if (wg == 0 && tid == 0) {
@@ -169,8 +259,11 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   }
 
   // ---- LEFT: float tile -> u8 in LDS (borrowing the entry array) -> per-lane register windows ----
-  stage_u8_rows(L, ls, lw, lh, x0, y0, NR, C::LBW, C::LBW, ent, tid, C::THREADS, bad);
+  // Both tiles are staged before anything else is live in registers (the LEFT tile borrows the entry array).
+  stage_u8_rows<NR>(L, ls, lw, lh, x0, y0, C::LBW, C::LBW, ent, tid, C::THREADS, bad_acc);
+  stage_u8_rows<NR>(R, rs, rcw, rch, x0, y0, bpitch, bpitch, base, tid, C::THREADS, bad_acc);
   __syncthreads();
+  STAMP();
   u64 win[NR][NW];                                  // win[r][n] = bytes L[q+4n .. q+4n+7]
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -203,13 +296,19 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
     constexpr bool MAXSWEEP = FIX;
     for (int dy = 0; dy < sy; ++dy) {
       __syncthreads();                              // everyone is done with the previous base tile / windows
-      stage_u8_rows(R, rs, rcw, rch, x0, y0 + dy, NR, bpitch, bpitch, base, tid, C::THREADS, bad);
+      STAMP();
+      if (dy > 0) stage_u8_rows<NR>(R, rs, rcw, rch, x0, y0 + dy, bpitch, bpitch, base, tid, C::THREADS, bad_acc);
       for (int t = 0; t < 4; ++t) {
         const int a_last = (sx + 2 - t) >> 2;       // last step with any valid slot
         __syncthreads();                            // base staged / previous phase's readers done
-        for (int m = tid; m < ne; m += C::THREADS) {
-#pragma unroll 2
-          for (int r = 0; r < NR; ++r) {
+        STAMP();
+        {
+          const int total = NR * ne;
+          const float inv = 1.0f / (float)ne;
+#pragma unroll 4
+          for (int idx = tid; idx < total; idx += C::THREADS) {
+            int r, m;
+            divmod_small(idx, ne, inv, r, m);
             const u32* bp = base + (size_t)r * bpitch + m;
             u32 b[NW + 1];
 #pragma unroll
@@ -220,12 +319,13 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
 #pragma unroll
             for (int n = 0; n < NW; ++n) w[n] = __builtin_amdgcn_alignbyte(b[n + 1], b[n], t);
             w[NW - 1] &= C::LAST_MASK;
-            u32* e = ent + ((size_t)r * ne + m) * EW;
+            u32* e = ent + (size_t)idx * EW;
             if (EW == 2) *reinterpret_cast<uint2*>(e) = make_uint2(w[0], w[1]);
             else *reinterpret_cast<uint4*>(e) = make_uint4(w[0], w[1], w[2 % EW], w[3 % EW]);
           }
         }
         __syncthreads();
+        STAMP();
 
         // One step = one accumulator chain down the NR rows.  MASKED handles the range ends (some slots outside
         // [0,sx)); PAIR processes steps a and a+1 together so the WTA is one v_min3_u32 per pixel; PROBE adds the
@@ -343,6 +443,9 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
         if (a_hi > a_last + 1) a_hi = a_last + 1;
         if (a_lo > a_hi) a_lo = a_hi;
         int a = 0;
+#if defined(VWGPU_EXP) && VWGPU_EXP == 1
+        a = a_last + 1;   // experiment: no sweeps at all (staging + LDS builds + barriers + epilogue only)
+#endif
         for (; a < a_lo && a <= a_last; ++a) step(a, T{}, F{}, F{});
         if (!MAXSWEEP && dy == 0 && t == 0) {
           for (; a + 1 < a_hi && eq_checks < NPROBE; a += 2, ++eq_checks) step(a, F{}, T{}, T{});
@@ -365,8 +468,9 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
     }
     return;
   }
-  if (bad) atomicOr(flag_set, 1);
+  if (bad_acc != 0u) atomicOr(flag_set, 1);
 
+  STAMP();
   // ---- epilogue 1: decode keys, store {dx, dy, VALID} in the PixelMask<Vector2i> layout -------------------
 #pragma unroll
   for (int y = 0; y < TY; ++y) {
@@ -409,6 +513,17 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   }
   const int any = __syncthreads_or((cand_lo | cand_hi) != 0u);   // never set on textured imagery
   if (tid == 0) need_fix[wg] = any;
+  STAMP();
+#if defined(VWGPU_EXP) && VWGPU_EXP == 2
+  if (tid == 0 && wg == 0) {
+    printf("wg %d stamps:", wg);
+    for (int i = 1; i < nts_; ++i) printf(" %.1f", (double)(ts_[i] - ts_[0]) / 2400.0);
+    printf("\n");
+  }
+  if (tid == 0 && ((wg & 255) == 0 || (wg & 255) == 37)) {
+    printf("wg %d start %.1f us end %.1f us (wall clock, 100 MHz)\n", wg, (double)(wc0_ % 100000000ll) / 100.0, (double)(wall_clock64() % 100000000ll) / 100.0);
+  }
+#endif
 }
 
 typedef void (*KernelFn)(const float*, ptrdiff_t, int, int, const float*, ptrdiff_t, int, int, int, int, int,
