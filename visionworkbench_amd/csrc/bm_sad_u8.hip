@@ -215,7 +215,7 @@ __device__ __forceinline__ void divmod_small(int idx, int d, float inv, int& quo
 //               entry is clear return at once, the others recompute packed best/worst costs and invalidate
 //               pixels with best == worst (Correlation.cc:121-133).
 template <int KX, int KY, int TY, bool FIX>
-__global__ void __launch_bounds__((KX <= 8 ? 256 : 128), 2)
+__global__ void __launch_bounds__((KX <= 8 ? 256 : 128), (TY <= 8 && KX <= 8 ? 3 : 2))
 bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
                  const float* __restrict__ R, ptrdiff_t rs, int rcw, int rch,
                  int sx, int sy, int ne, int32_t* __restrict__ out, ptrdiff_t os, int ow, int oh,
@@ -282,7 +282,9 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
     MN[y][0] = MN[y][1] = 0xffffffffu;
     MX[y][0] = MX[y][1] = 0u;
   }
-  u32 eq_lo = 0xffffffffu, eq_hi = 0xffffffffu;     // bit y*4+s: "all compared costs of pixel (y,s) were equal"
+  // bit y*4+s: "all compared costs of pixel (y,s) were equal"; only the TY*4 bits of real pixels start set
+  u32 eq_lo = (TY * 4 >= 32) ? 0xffffffffu : ((1u << ((TY * 4) & 31)) - 1u);
+  u32 eq_hi = (TY * 4 >= 64) ? 0xffffffffu : ((TY * 4 > 32) ? ((1u << ((TY * 4 - 32) & 31)) - 1u) : 0u);
   int eq_checks = 0;
   // Probed step pairs: a pixel stays a candidate only if all NPROBE compared cost pairs were equal.  On noise one
   // pair is equal with p ~ 7e-4, so 4 pairs leave ~2e-13 per pixel; a flat (truly invalid) pixel always passes.
@@ -500,7 +502,10 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   // ---- validity: only pixels whose probed costs were all equal can be invalid ---------------------------------
   static_assert(TY * 4 <= 64, "equality bitmap holds 64 pixels per lane");
   u32 cand_lo = eq_lo, cand_hi = eq_hi;
-  if (eq_checks < NPROBE) { cand_lo = 0xffffffffu; cand_hi = 0xffffffffu; }   // small search range: nothing is known
+  if (eq_checks < NPROBE) {                         // small search range: nothing is known -> every real pixel
+    cand_lo = (TY * 4 >= 32) ? 0xffffffffu : ((1u << ((TY * 4) & 31)) - 1u);
+    cand_hi = (TY * 4 >= 64) ? 0xffffffffu : ((TY * 4 > 32) ? ((1u << ((TY * 4 - 32) & 31)) - 1u) : 0u);
+  }
   // pixels outside the output image (zero padding: every cost equal) must not trigger the second sweep
 #pragma unroll
   for (int y = 0; y < TY; ++y) {
