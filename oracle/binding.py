@@ -11,9 +11,14 @@ _LIB = None
 ABSOLUTE_DIFFERENCE, SQUARED_DIFFERENCE, CROSS_CORRELATION = 0, 1, 2
 VALID = np.iinfo(np.int32).max
 
+EDGE_CONSTANT, EDGE_ZERO = 0, 1
+PREFILTER_NONE, PREFILTER_MEANSUB, PREFILTER_LOG = 0, 1, 2
+
 __all__ = ["build", "lib", "fast_box_sum", "cost_image", "calc_disparity", "calc_disparity_tiled",
            "cross_corr_consistency_check", "ABSOLUTE_DIFFERENCE", "SQUARED_DIFFERENCE",
-           "CROSS_CORRELATION", "VALID"]
+           "CROSS_CORRELATION", "VALID", "generate_gaussian_kernel", "separable_convolution", "convolution_2d",
+           "subsample_mask_by_two", "prefilter_image", "pyramid_smoothing_kernel",
+           "EDGE_CONSTANT", "EDGE_ZERO", "PREFILTER_NONE", "PREFILTER_MEANSUB", "PREFILTER_LOG"]
 
 
 def build(force=False):
@@ -35,6 +40,15 @@ def lib():
         _LIB.vwo_calc_disparity.argtypes = [I, P, I, I, L, P, I, I, L, I, I, I, I, P]
         _LIB.vwo_calc_disparity_tiled.argtypes = [I, P, I, I, P, I, I, I, I, I, I, P, I, I, I, P]
         _LIB.vwo_cross_corr_consistency_check.argtypes = [P, I, I, P, I, I, ctypes.c_float]
+        D, F = ctypes.c_double, ctypes.c_float
+        _LIB.vwo_generate_gaussian_kernel_f32.argtypes = [D, I, P, I]
+        _LIB.vwo_generate_gaussian_kernel_f64.argtypes = [D, I, P, I]
+        _LIB.vwo_separable_convolution_f32.argtypes = [P, I, I, P, I, I, P, I, I, I, I, P]
+        _LIB.vwo_separable_convolution_f64.argtypes = [P, I, I, P, I, I, P, I, I, I, I, P]
+        _LIB.vwo_convolution_2d_f32.argtypes = [P, I, I, P, I, I, I, I, I, P]
+        _LIB.vwo_convolution_2d_f64.argtypes = [P, I, I, P, I, I, I, I, I, P]
+        _LIB.vwo_subsample_mask_by_two.argtypes = [P, I, I, P]
+        _LIB.vwo_prefilter_image.argtypes = [P, I, I, I, F, P]
     return _LIB
 
 
@@ -106,3 +120,68 @@ def cross_corr_consistency_check(l2r, r2l, thr):
                                                 _p(r2l), r2l.shape[1], r2l.shape[0], thr)
     assert rc == 0
     return l2r
+
+
+def generate_gaussian_kernel(sigma, size=0, dtype=np.float32):
+    """generate_gaussian_kernel<KernelT>(kernel, sigma, size), src/vw/Image/Filter.tcc:37-78."""
+    out = np.zeros(4096, dtype)
+    fn = lib().vwo_generate_gaussian_kernel_f32 if dtype == np.float32 else lib().vwo_generate_gaussian_kernel_f64
+    n = fn(float(sigma), int(size), _p(out), out.size)
+    assert n >= 0
+    return out[:n].copy()
+
+
+def pyramid_smoothing_kernel():
+    """generate_pyramid_smoothing_kernel(), src/vw/Image/Filter.h:89-99: float {1,4,6,4,1}/16."""
+    return np.array([1.0 / 16.0, 4.0 / 16.0, 6.0 / 16.0, 4.0 / 16.0, 1.0 / 16.0], np.float32)
+
+
+def separable_convolution(img, xk, yk, cx=None, cy=None, edge=EDGE_CONSTANT, subsample=1):
+    """separable_convolution_filter(img, xk, yk[, cx, cy], edge) rasterised, then subsample(., s)."""
+    dt = np.float64 if img.dtype == np.float64 else np.float32
+    a = np.ascontiguousarray(img, dt)
+    xk = np.ascontiguousarray(xk, dt)
+    yk = np.ascontiguousarray(yk, dt)
+    if cx is None:
+        cx = (len(xk) - 1) // 2 if len(xk) else 0
+    if cy is None:
+        cy = (len(yk) - 1) // 2 if len(yk) else 0
+    h, w = a.shape
+    out = np.empty((1 + (h - 1) // subsample, 1 + (w - 1) // subsample), dt)
+    fn = lib().vwo_separable_convolution_f64 if dt == np.float64 else lib().vwo_separable_convolution_f32
+    rc = fn(_p(a), w, h, _p(xk), len(xk), cx, _p(yk), len(yk), cy, edge, subsample, _p(out))
+    assert rc == 0
+    return out
+
+
+def convolution_2d(img, kernel, ci=None, cj=None, edge=EDGE_CONSTANT):
+    """convolution_filter(img, kernel[, ci, cj], edge), src/vw/Image/Convolution.h:105-170."""
+    dt = np.float64 if img.dtype == np.float64 else np.float32
+    a = np.ascontiguousarray(img, dt)
+    k = np.ascontiguousarray(kernel, dt)
+    kh, kw = k.shape
+    if ci is None:
+        ci = (kw - 1) // 2
+    if cj is None:
+        cj = (kh - 1) // 2
+    h, w = a.shape
+    out = np.empty((h, w), dt)
+    fn = lib().vwo_convolution_2d_f64 if dt == np.float64 else lib().vwo_convolution_2d_f32
+    rc = fn(_p(a), w, h, _p(k), kw, kh, ci, cj, edge, _p(out))
+    assert rc == 0
+    return out
+
+
+def subsample_mask_by_two(mask):
+    m = np.ascontiguousarray(mask, np.uint8)
+    h, w = m.shape
+    out = np.empty((1 + (h - 1) // 2, 1 + (w - 1) // 2), np.uint8)
+    assert lib().vwo_subsample_mask_by_two(_p(m), w, h, _p(out)) == 0
+    return out
+
+
+def prefilter_image(img, mode, width):
+    a = np.ascontiguousarray(img, np.float32)
+    out = np.empty_like(a)
+    assert lib().vwo_prefilter_image(_p(a), a.shape[1], a.shape[0], int(mode), float(width), _p(out)) == 0
+    return out

@@ -252,3 +252,168 @@ int vwo_cross_corr_consistency_check(int32_t* l2r, int lw, int lh,
 }
 
 }  // extern "C"
+
+// ---- image filters on the path ---------------------------------------------------------------------------
+
+namespace {
+
+// Edge extension of src/vw/Image/EdgeExtension.h: Constant = clamp coordinates, Zero = 0 outside.
+template <class T>
+inline T ext_at(const T* src, int w, int h, int x, int y, int edge) {
+  if (edge == VWO_EDGE_ZERO) {
+    if (x < 0 || y < 0 || x >= w || y >= h) return T(0);
+    return src[(size_t)y * w + x];
+  }
+  x = x < 0 ? 0 : (x >= w ? w - 1 : x);
+  y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+  return src[(size_t)y * w + x];
+}
+
+// generate_gaussian_kernel<KernelT>, src/vw/Image/Filter.tcc:37-78.
+template <class K>
+int gaussian_kernel(double sigma, int size, K* out, int cap) {
+  if (sigma == 0) return 0;
+  if (size == 0) {                                  // compute_kernel_size, Filter.cc:32-37
+    size = (int)(7 * sigma);
+    if (size < 3) size = 3;
+    else if (size % 2 == 0) size -= 1;
+  }
+  if (size > cap) return -1;
+  const int center = size / 2;
+  double sum = 0.0, tap;
+  const double z = 1 / (std::sqrt(2.0) * sigma);
+  if (size % 2 == 0) {
+    for (int i = 0; i < center; ++i) {
+      tap = std::erf((i + 1.0) * z) - std::erf(i * z);
+      sum += tap;
+      out[center + i] = out[center - i - 1] = (K)tap;
+    }
+    sum *= 2.0;
+  } else {
+    for (int i = 1; i <= center; ++i) {
+      tap = std::erf((i + 0.5) * z) - std::erf((i - 0.5) * z);
+      sum += tap;
+      out[center + i] = out[center - i] = (K)tap;
+    }
+    sum *= 2.0;
+    tap = std::erf(0.5 * z) - std::erf(-0.5 * z);
+    sum += tap;
+    out[center] = (K)tap;
+  }
+  const double norm = 1.0 / sum;
+  for (int i = 0; i < size; ++i) out[i] *= norm;   // KernelT *= double, as in the reference (:76-77)
+  return size;
+}
+
+// SeparableConvolutionView::rasterize over the whole image + SubsampleView  (Convolution.h:275-328).
+// correlate_1d_at_point(src, kernel.rbegin(), n): result = 0; result += k[n-1-i] * s[i], i = 0..n-1  (:53-65).
+template <class T>
+int sepconv(const T* src, int w, int h, const T* xk, int nx, int cx, const T* yk, int ny, int cy,
+            int edge, int step, T* dst) {
+  if (w <= 0 || h <= 0 || step < 1 || nx < 0 || ny < 0) return -1;
+  const int x_lo = nx ? nx - cx - 1 : 0, y_lo = ny ? ny - cy - 1 : 0;   // child_bbox.min() -= ...  (:282)
+  const int y_hi = ny ? cy : 0;
+  const int ch = h + y_lo + y_hi;                                      // child_bbox.height()
+  std::vector<T> work((size_t)w * ch);
+  for (int yy = 0; yy < ch; ++yy) {
+    const int sy = yy - y_lo;
+    for (int x = 0; x < w; ++x) {
+      if (nx) {
+        T result = T(0);
+        for (int i = 0; i < nx; ++i) result += xk[nx - 1 - i] * ext_at(src, w, h, x - x_lo + i, sy, edge);
+        work[(size_t)yy * w + x] = result;
+      } else {
+        work[(size_t)yy * w + x] = ext_at(src, w, h, x, sy, edge);
+      }
+    }
+  }
+  const int ow = 1 + (w - 1) / step, oh = 1 + (h - 1) / step;            // SubsampleView sizes (Manipulation.h:238-243)
+  for (int oy = 0; oy < oh; ++oy) {
+    const int y = oy * step;
+    for (int ox = 0; ox < ow; ++ox) {
+      const int x = ox * step;
+      if (ny) {
+        T result = T(0);
+        for (int j = 0; j < ny; ++j) result += yk[ny - 1 - j] * work[(size_t)(y + j) * w + x];
+        dst[(size_t)oy * ow + ox] = result;
+      } else {
+        dst[(size_t)oy * ow + ox] = work[(size_t)(y + y_lo) * w + x];
+      }
+    }
+  }
+  return 0;
+}
+
+// ConvolutionView with the kernel rotated by 180 degrees (Convolution.h:105-170), correlate_2d_at_point (:66-88).
+template <class T>
+int conv2d(const T* src, int w, int h, const T* k, int kw, int kh, int mci, int mcj, int edge, T* dst) {
+  if (w <= 0 || h <= 0 || kw <= 0 || kh <= 0) return -1;
+  const int ci = kw - 1 - mci, cj = kh - 1 - mcj;
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      T result = T(0);
+      for (int j = 0; j < kh; ++j)
+        for (int i = 0; i < kw; ++i)
+          result += k[(size_t)(kh - 1 - j) * kw + (kw - 1 - i)] * ext_at(src, w, h, x - ci + i, y - cj + j, edge);
+      dst[(size_t)y * w + x] = result;
+    }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vwo_generate_gaussian_kernel_f32(double sigma, int size, float* out, int cap) { return gaussian_kernel(sigma, size, out, cap); }
+int vwo_generate_gaussian_kernel_f64(double sigma, int size, double* out, int cap) { return gaussian_kernel(sigma, size, out, cap); }
+
+int vwo_separable_convolution_f32(const float* src, int w, int h, const float* xk, int nx, int cx,
+                                  const float* yk, int ny, int cy, int edge, int subsample, float* dst) {
+  return sepconv(src, w, h, xk, nx, cx, yk, ny, cy, edge, subsample, dst);
+}
+int vwo_separable_convolution_f64(const double* src, int w, int h, const double* xk, int nx, int cx,
+                                  const double* yk, int ny, int cy, int edge, int subsample, double* dst) {
+  return sepconv(src, w, h, xk, nx, cx, yk, ny, cy, edge, subsample, dst);
+}
+int vwo_convolution_2d_f32(const float* src, int w, int h, const float* k, int kw, int kh, int ci, int cj, int edge, float* dst) {
+  return conv2d(src, w, h, k, kw, kh, ci, cj, edge, dst);
+}
+int vwo_convolution_2d_f64(const double* src, int w, int h, const double* k, int kw, int kh, int ci, int cj, int edge, double* dst) {
+  return conv2d(src, w, h, k, kw, kh, ci, cj, edge, dst);
+}
+
+int vwo_subsample_mask_by_two(const uint8_t* src, int w, int h, uint8_t* dst) {
+  // SubsampleMaskByTwoFunc over a ZeroEdgeExtension'd image (Filter.h:133-136), then subsample(...,2)
+  if (w <= 0 || h <= 0) return -1;
+  const int ow = 1 + (w - 1) / 2, oh = 1 + (h - 1) / 2;
+  for (int oy = 0; oy < oh; ++oy)
+    for (int ox = 0; ox < ow; ++ox) {
+      const int x = 2 * ox, y = 2 * oy;
+      int count = 0;
+      if (ext_at(src, w, h, x, y, VWO_EDGE_ZERO)) count++;
+      if (ext_at(src, w, h, x + 1, y, VWO_EDGE_ZERO)) count++;
+      if (ext_at(src, w, h, x, y + 1, VWO_EDGE_ZERO)) count++;
+      if (ext_at(src, w, h, x + 1, y + 1, VWO_EDGE_ZERO)) count++;
+      dst[(size_t)oy * ow + ox] = count > 1 ? 255 : 0;
+    }
+  return 0;
+}
+
+int vwo_prefilter_image(const float* src, int w, int h, int mode, float width, float* dst) {
+  const size_t n = (size_t)w * h;
+  if (mode == VWO_PREFILTER_NONE) { std::memcpy(dst, src, n * sizeof(float)); return 0; }   // NullOperation
+  float taps[1024];
+  const int nt = gaussian_kernel<float>((double)width, 0, taps, 1024);                       // gaussian_filter(image, width)
+  if (nt < 0) return -1;
+  std::vector<float> g(n);
+  int rc = sepconv<float>(src, w, h, taps, nt, (nt - 1) / 2, taps, nt, (nt - 1) / 2, VWO_EDGE_CONSTANT, 1, g.data());
+  if (rc) return rc;
+  if (mode == VWO_PREFILTER_MEANSUB) {                                                        // I - gaussian (PreFilter.h:73)
+    for (size_t i = 0; i < n; ++i) dst[i] = src[i] - g[i];
+    return 0;
+  }
+  const float lap[9] = {0, 1, 0, 1, -4, 1, 0, 1, 0};                                          // laplacian_filter (Filter.h:320-335)
+  return conv2d<float>(g.data(), w, h, lap, 3, 3, 1, 1, VWO_EDGE_CONSTANT, dst);
+}
+
+}  // extern "C"

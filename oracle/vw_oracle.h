@@ -58,6 +58,39 @@ int vwo_calc_disparity_tiled(int cost_type,
 int vwo_cross_corr_consistency_check(int32_t* l2r, int lw, int lh,
                                      const int32_t* r2l, int rw, int rh, float thr);
 
+/* ---- image filters on the path (pyramid + prefilters) ---------------------------------------------------- */
+
+enum { VWO_EDGE_CONSTANT = 0, VWO_EDGE_ZERO = 1 };
+enum { VWO_PREFILTER_NONE = 0, VWO_PREFILTER_MEANSUB = 1, VWO_PREFILTER_LOG = 2 };
+
+/* generate_gaussian_kernel<float>, src/vw/Image/Filter.tcc:37-78 + compute_kernel_size, Filter.cc:32-37.
+ * size == 0 -> default size.  Returns the number of taps (0 for sigma == 0), writes them to out (cap >= result). */
+int vwo_generate_gaussian_kernel_f32(double sigma, int size, float* out, int cap);
+int vwo_generate_gaussian_kernel_f64(double sigma, int size, double* out, int cap);
+
+/* SeparableConvolutionView<ImageView<float>, float, Edge>::rasterize over the whole image
+ * (src/vw/Image/Convolution.h:275-328, correlate_1d_at_point :53-65), followed by SubsampleView
+ * (src/vw/Image/Manipulation.h:214-293) with step `subsample` (1 = none).  nx or ny may be 0 (axis inactive).
+ * cx, cy = kernel origins ((n-1)/2 for the reference's default constructor).  dst is
+ * (1+(w-1)/s) x (1+(h-1)/s). */
+int vwo_separable_convolution_f32(const float* src, int w, int h, const float* xk, int nx, int cx,
+                                  const float* yk, int ny, int cy, int edge, int subsample, float* dst);
+int vwo_separable_convolution_f64(const double* src, int w, int h, const double* xk, int nx, int cx,
+                                  const double* yk, int ny, int cy, int edge, int subsample, double* dst);
+
+/* ConvolutionView (general 2-D kernel, kw x kh, origin (ci,cj)): src/vw/Image/Convolution.h:105-170,
+ * correlate_2d_at_point :66-88 with the kernel rotated by 180 degrees. */
+int vwo_convolution_2d_f32(const float* src, int w, int h, const float* k, int kw, int kh, int ci, int cj,
+                           int edge, float* dst);
+int vwo_convolution_2d_f64(const double* src, int w, int h, const double* k, int kw, int kh, int ci, int cj,
+                           int edge, double* dst);
+
+/* subsample_mask_by_two, src/vw/Stereo/CorrelationView.cc:38-63. dst is (1+(w-1)/2) x (1+(h-1)/2). */
+int vwo_subsample_mask_by_two(const uint8_t* src, int w, int h, uint8_t* dst);
+
+/* prefilter_image, src/vw/Stereo/PreFilter.h:41-95 (LoG = laplacian(gaussian(width)); MEANSUB = I - gaussian(width)). */
+int vwo_prefilter_image(const float* src, int w, int h, int mode, float width, float* dst);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,3 +157,96 @@ def test_synthetic_pair_truth(oracle):
     assert (d[..., 0][zero] <= t[zero]).all()          # first zero-cost disparity wins
     assert (d[..., 2][zero] == oracle.VALID).all()
     assert (d[..., 0][zero] == t[zero]).mean() > 0.99
+
+
+# ---- image filters on the path (pyramid, prefilters) ------------------------------------------------------------
+
+def test_gaussian_kernel_golden(oracle):
+    """src/vw/Image/tests/TestFilter.cxx:45-74 (GaussianKernel)."""
+    k = oracle.generate_gaussian_kernel(1.0, 5, np.float64)
+    assert len(k) == 5
+    np.testing.assert_allclose(k, [0.06135958087, 0.2447702197, 0.3877403988, 0.2447702197, 0.06135958087], atol=1e-7)
+    k = oracle.generate_gaussian_kernel(1.0, 4, np.float64)
+    np.testing.assert_allclose(k, [0.1423836140, 0.3576163860, 0.3576163860, 0.1423836140], atol=1e-7)
+    k = oracle.generate_gaussian_kernel(1.5, 0, np.float64)
+    assert len(k) == 9
+    np.testing.assert_allclose(k, [0.008488347404, 0.03807782601, 0.1111650246, 0.2113567063, 0.2618241916,
+                                   0.2113567063, 0.1111650246, 0.03807782601, 0.008488347404], atol=1e-7)
+    assert len(oracle.generate_gaussian_kernel(0, 0, np.float64)) == 0
+
+
+def _src22():
+    # src(0,0)=1; src(1,0)=2; src(0,1)=3; src(1,1)=4   ->  [row, col]
+    return np.array([[1.0, 2.0], [3.0, 4.0]])
+
+
+def test_separable_convolution_golden(oracle):
+    """src/vw/Image/tests/TestConvolution.cxx:110-215: SeparableView, _0x2, _2x0 with ZeroEdgeExtension."""
+    krn = np.array([1.0, -1.0])
+    d = oracle.separable_convolution(_src22(), krn, krn, edge=oracle.EDGE_ZERO)
+    assert d[0, 0] == 1 and d[1, 0] == 2 and d[0, 1] == 1 and d[1, 1] == 0          # dst(col,row) == d[row,col]
+    src = np.array([[1.0, 2.0], [4.0, 6.0]])
+    d = oracle.separable_convolution(src, np.array([]), krn, edge=oracle.EDGE_ZERO)  # SeparableView_0x2
+    assert d[0, 0] == 1 and d[1, 0] == 3 and d[0, 1] == 2 and d[1, 1] == 4
+    d = oracle.separable_convolution(_src22(), krn, np.array([]), edge=oracle.EDGE_ZERO)  # SeparableView_2x0
+    assert d[0, 0] == 1 and d[0, 1] == 1 and d[1, 0] == 3 and d[1, 1] == 1
+
+
+def test_convolution_2d_golden(oracle):
+    """TestConvolution.cxx:80-108 (View) and TestFilter.cxx:141-150 (Laplacian), ZeroEdgeExtension."""
+    krn = np.array([[2.0, -1.0], [0.0, 3.0]])      # krn(0,0)=2; krn(1,0)=-1; krn(0,1)=0; krn(1,1)=3
+    d = oracle.convolution_2d(_src22(), krn, edge=oracle.EDGE_ZERO)
+    assert d[0, 0] == 2 and d[0, 1] == 3 and d[1, 0] == 6 and d[1, 1] == 8
+    lap = np.array([[0.0, 1, 0], [1, -4, 1], [0, 1, 0]])
+    d = oracle.convolution_2d(_src22(), lap, 1, 1, edge=oracle.EDGE_ZERO)
+    assert d[0, 0] == 1 and d[0, 1] == -3 and d[1, 0] == -7 and d[1, 1] == -11
+
+
+def test_gaussian_filter_golden(oracle):
+    """TestFilter.cxx:132-139 (Gaussian): gaussian_filter(src, 1.0, 0, 5, 0, ZeroEdgeExtension) — x only."""
+    k = oracle.generate_gaussian_kernel(1.0, 5, np.float64)
+    d = oracle.separable_convolution(_src22(), k, np.array([]), edge=oracle.EDGE_ZERO)
+    np.testing.assert_allclose(d, [[0.3877403988 * 1 + 0.2447702197 * 2, 0.3877403988 * 2 + 0.2447702197 * 1],
+                                   [0.3877403988 * 3 + 0.2447702197 * 4, 0.3877403988 * 4 + 0.2447702197 * 3]], atol=1e-7)
+
+
+def test_prerasterize_fixture(oracle):
+    """TestConvolution.cxx:203-215 (Prerasterize): gaussian(1.5) of a constant-1 image stays 1 inside (float taps
+    sum to ~1), zero-extended outside."""
+    img = np.ones((40, 60), np.float32)
+    k = oracle.generate_gaussian_kernel(1.5)
+    d = oracle.separable_convolution(img, k, k)
+    assert abs(d[20, 30] - 1.0) < 1e-6 and abs(d[0, 0] - 1.0) < 1e-6
+
+
+def test_prefilters_are_the_compositions(oracle):
+    """src/vw/Stereo/tests/TestPreFilter.cxx:47-112: the prefilter structs equal the explicit compositions."""
+    rng = np.random.RandomState(1)
+    img = rng.randint(0, 256, (37, 53)).astype(np.float32)
+    # the prefilter structs hold the width as float (PreFilter.h:53,68): sigma = (double)1.4f
+    k = oracle.generate_gaussian_kernel(float(np.float32(1.4)))
+    assert len(k) == 9
+    g = oracle.separable_convolution(img, k, k)
+    lap = np.array([[0.0, 1, 0], [1, -4, 1], [0, 1, 0]], np.float32)
+    assert np.array_equal(oracle.prefilter_image(img, oracle.PREFILTER_LOG, 1.4), oracle.convolution_2d(g, lap, 1, 1))
+    k5 = oracle.generate_gaussian_kernel(5.0)
+    assert len(k5) == 35
+    assert np.array_equal(oracle.prefilter_image(img, oracle.PREFILTER_MEANSUB, 5.0),
+                          img - oracle.separable_convolution(img, k5, k5))
+    assert np.array_equal(oracle.prefilter_image(img, oracle.PREFILTER_NONE, 0.0), img)
+
+
+def test_pyramid_level_and_mask(oracle):
+    """subsample(separable_convolution_filter(level, k, k), 2) and subsample_mask_by_two
+    (src/vw/Stereo/CorrelationView.cc:38-63,210-216): sizes 1+(N-1)/2; constant images stay constant."""
+    k = oracle.pyramid_smoothing_kernel()
+    img = np.full((9, 14), 100.0, np.float32)
+    lvl = oracle.separable_convolution(img, k, k, subsample=2)
+    assert lvl.shape == (5, 7) and (lvl == 100.0).all()
+    mask = np.zeros((5, 7), np.uint8)
+    mask[0, 0] = 255                # one of four -> off
+    mask[2, 2] = mask[2, 3] = 9     # two of four -> on
+    mask[4, 6] = 1                  # corner block partly outside (zero extension): one -> off
+    m2 = oracle.subsample_mask_by_two(mask)
+    assert m2.shape == (3, 4)
+    assert m2[0, 0] == 0 and m2[1, 1] == 255 and m2[2, 3] == 0

@@ -526,7 +526,11 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
     printf("\n");
   }
   if (tid == 0 && ((wg & 255) == 0 || (wg & 255) == 37)) {
-    printf("wg %d start %.1f us end %.1f us (wall clock, 100 MHz)\n", wg, (double)(wc0_ % 100000000ll) / 100.0, (double)(wall_clock64() % 100000000ll) / 100.0);
+    const long long wc1_ = wall_clock64();
+    printf("wg %d start %.1f us end %.1f us (wall clock, 100 MHz); %lld shader ticks in %.1f us = %.2f GHz\n", wg,
+           (double)(wc0_ % 100000000ll) / 100.0, (double)(wc1_ % 100000000ll) / 100.0,
+           (long long)(clock64() - ts_[0]), (double)(wc1_ - wc0_) / 100.0,
+           (double)(clock64() - ts_[0]) / ((double)(wc1_ - wc0_) * 10.0));
   }
 #endif
 }
