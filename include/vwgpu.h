@@ -132,6 +132,57 @@ int vwgpu_cross_corr_consistency_check(vwgpu_ctx* ctx,
                                        const int32_t* r2l, int rw, int rh, ptrdiff_t rstride,
                                        float threshold);
 
+/* ---- image filters on the path: Gaussian pyramid and prefilters ------------------------------------- */
+
+/* vw::ConstantEdgeExtension / vw::ZeroEdgeExtension (src/vw/Image/EdgeExtension.h). */
+typedef enum vwgpu_edge { VWGPU_EDGE_CONSTANT = 0, VWGPU_EDGE_ZERO = 1 } vwgpu_edge;
+/* vw::stereo::PrefilterModeType, src/vw/Stereo/PrefilterEnum.h:24-28 (same numeric values). */
+typedef enum vwgpu_prefilter { VWGPU_PREFILTER_NONE = 0, VWGPU_PREFILTER_MEANSUB = 1, VWGPU_PREFILTER_LOG = 2 } vwgpu_prefilter;
+
+/* Replaces vw::generate_gaussian_kernel<float> (src/vw/Image/Filter.tcc:37-78; default size
+ * vw::compute_kernel_size, src/vw/Image/Filter.cc:32-37).  Host-side math (erf in double), no context needed.
+ * size == 0 selects the default size.  Returns the number of taps written (0 for sigma == 0) or a negative
+ * vwgpu_status if cap is too small. */
+int vwgpu_generate_gaussian_kernel(double sigma, int size, float* taps, int cap);
+
+/* Replaces rasterising vw::separable_convolution_filter(src, x_kernel, y_kernel, cx, cy, edge)
+ * (src/vw/Image/Filter.h:156-191 -> SeparableConvolutionView::rasterize, src/vw/Image/Convolution.h:275-328) over the
+ * whole image, optionally followed by vw::subsample(., subsample) (src/vw/Image/Manipulation.h:214-311) — the
+ * pyramid-level operation of build_image_pyramids (src/vw/Stereo/CorrelationView.cc:210-214).
+ *   nx / ny may be 0 (axis not filtered); cx, cy = kernel origins ((n-1)/2 is the reference's default).
+ *   dst is (1+(w-1)/subsample) x (1+(h-1)/subsample).  x_kernel / y_kernel are HOST pointers in both variants.
+ * Accumulation order and float arithmetic are the reference's; results are bit-identical for any float input. */
+int vwgpu_separable_convolution_dev(vwgpu_ctx* ctx, const float* d_src, int w, int h, ptrdiff_t stride,
+                                    const float* x_kernel, int nx, int cx, const float* y_kernel, int ny, int cy,
+                                    int edge, int subsample, float* d_dst, ptrdiff_t dstride);
+int vwgpu_separable_convolution(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
+                                const float* x_kernel, int nx, int cx, const float* y_kernel, int ny, int cy,
+                                int edge, int subsample, float* dst, ptrdiff_t dstride);
+
+/* Replaces rasterising vw::convolution_filter(src, kernel, ci, cj, edge) for small 2-D kernels (<= 49 taps)
+ * (ConvolutionView, src/vw/Image/Convolution.h:105-170); kernel is row-major kw x kh, HOST pointer.
+ * vw::laplacian_filter (src/vw/Image/Filter.h:320-335) is this call with {0,1,0,1,-4,1,0,1,0}, origin (1,1). */
+int vwgpu_convolution_2d_dev(vwgpu_ctx* ctx, const float* d_src, int w, int h, ptrdiff_t stride,
+                             const float* kernel, int kw, int kh, int ci, int cj, int edge,
+                             float* d_dst, ptrdiff_t dstride);
+int vwgpu_convolution_2d(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
+                         const float* kernel, int kw, int kh, int ci, int cj, int edge,
+                         float* dst, ptrdiff_t dstride);
+
+/* Replaces vw::stereo::subsample_mask_by_two (src/vw/Stereo/CorrelationView.cc:38-63): a 2x2 block with at least
+ * two non-zero pixels gives 255, else 0; dst is (1+(w-1)/2) x (1+(h-1)/2). */
+int vwgpu_subsample_mask_by_two_dev(vwgpu_ctx* ctx, const uint8_t* d_src, int w, int h, ptrdiff_t stride,
+                                    uint8_t* d_dst, ptrdiff_t dstride);
+int vwgpu_subsample_mask_by_two(vwgpu_ctx* ctx, const uint8_t* src, int w, int h, ptrdiff_t stride,
+                                uint8_t* dst, ptrdiff_t dstride);
+
+/* Replaces vw::stereo::prefilter_image (src/vw/Stereo/PreFilter.h:76-95): NONE = copy, MEANSUB = image -
+ * gaussian_filter(image, width), LOG = laplacian_filter(gaussian_filter(image, width)); constant edge extension. */
+int vwgpu_prefilter_image_dev(vwgpu_ctx* ctx, const float* d_src, int w, int h, ptrdiff_t stride,
+                              int mode, float width, float* d_dst, ptrdiff_t dstride);
+int vwgpu_prefilter_image(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
+                          int mode, float width, float* dst, ptrdiff_t dstride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,11 @@ SYMBOLS = [
     "vwgpu_profile_enable", "vwgpu_profile_reset", "vwgpu_profile_read",
     "vwgpu_calc_disparity_dev", "vwgpu_calc_disparity",
     "vwgpu_cross_corr_consistency_check_dev", "vwgpu_cross_corr_consistency_check",
+    "vwgpu_generate_gaussian_kernel",
+    "vwgpu_separable_convolution_dev", "vwgpu_separable_convolution",
+    "vwgpu_convolution_2d_dev", "vwgpu_convolution_2d",
+    "vwgpu_subsample_mask_by_two_dev", "vwgpu_subsample_mask_by_two",
+    "vwgpu_prefilter_image_dev", "vwgpu_prefilter_image",
 ]
 
 
@@ -64,6 +69,19 @@ def load():
     lr = [P, P, I, I, PD, P, I, I, PD, F]
     lib.vwgpu_cross_corr_consistency_check_dev.argtypes = lr
     lib.vwgpu_cross_corr_consistency_check.argtypes = lr
+    lib.vwgpu_generate_gaussian_kernel.argtypes = [ctypes.c_double, I, P, I]
+    sc = [P, P, I, I, PD, P, I, I, P, I, I, I, I, P, PD]
+    lib.vwgpu_separable_convolution_dev.argtypes = sc
+    lib.vwgpu_separable_convolution.argtypes = sc
+    c2 = [P, P, I, I, PD, P, I, I, I, I, I, P, PD]
+    lib.vwgpu_convolution_2d_dev.argtypes = c2
+    lib.vwgpu_convolution_2d.argtypes = c2
+    mk = [P, P, I, I, PD, P, PD]
+    lib.vwgpu_subsample_mask_by_two_dev.argtypes = mk
+    lib.vwgpu_subsample_mask_by_two.argtypes = mk
+    pf = [P, P, I, I, PD, I, F, P, PD]
+    lib.vwgpu_prefilter_image_dev.argtypes = pf
+    lib.vwgpu_prefilter_image.argtypes = pf
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the ABI and the header drifted apart
     _LIB = lib

@@ -1,0 +1,193 @@
+// vwgpu_filters_abi.hip — extern "C" entry points of the pyramid / prefilter family (include/vwgpu.h).
+#include <cmath>
+#include <vector>
+
+#include "vwgpu_internal.h"
+
+namespace {
+
+int check_image(vwgpu_ctx* ctx, const char* what, const void* src, int w, int h, ptrdiff_t& stride, const void* dst) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  ctx->err.clear();
+  if (!src || !dst || w <= 0 || h <= 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "%s: empty image or null pointer", what);
+  if (stride == 0) stride = w;
+  if (stride < w) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "%s: row stride smaller than row width", what);
+  return VWGPU_OK;
+}
+
+// Host-pointer variants: stage src, run `body(d_src, d_dst)`, copy back.
+template <class T, class Body>
+int staged(vwgpu_ctx* ctx, const T* src, int w, int h, ptrdiff_t stride, T* dst, int ow, int oh, ptrdiff_t dstride, Body body) {
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t sb = vwgpu_align_up((size_t)w * h * sizeof(T), 256), db = vwgpu_align_up((size_t)ow * oh * sizeof(T), 256);
+  int rc = vwgpu_arena_reserve(ctx, &ctx->staging, sb + db);
+  if (rc) return rc;
+  T* d_s = reinterpret_cast<T*>(ctx->staging.base);
+  T* d_d = reinterpret_cast<T*>(static_cast<char*>(ctx->staging.base) + sb);
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_s, (size_t)w * sizeof(T), src, (size_t)stride * sizeof(T), (size_t)w * sizeof(T), h,
+                                  hipMemcpyHostToDevice, ctx->stream));
+  rc = body(d_s, d_d);
+  if (rc) return rc;
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(dst, (size_t)dstride * sizeof(T), d_d, (size_t)ow * sizeof(T), (size_t)ow * sizeof(T), oh,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VWGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vwgpu_generate_gaussian_kernel(double sigma, int size, float* taps, int cap) {
+  // vw::generate_gaussian_kernel<float>, src/vw/Image/Filter.tcc:37-78 (vw::erf is ::erf on Linux,
+  // src/vw/Math/Functions.h:197).
+  if (sigma == 0) return 0;
+  if (size == 0) {                                 // vw::compute_kernel_size, src/vw/Image/Filter.cc:32-37
+    size = (int)(7 * sigma);
+    if (size < 3) size = 3;
+    else if (size % 2 == 0) size -= 1;
+  }
+  if (size < 0 || size > cap || !taps) return VWGPU_ERR_ARGUMENT;
+  const int center = size / 2;
+  double sum = 0.0, tap;
+  const double z = 1 / (std::sqrt(2.0) * sigma);
+  if (size % 2 == 0) {
+    for (int i = 0; i < center; ++i) {
+      tap = std::erf((i + 1.0) * z) - std::erf(i * z);
+      sum += tap;
+      taps[center + i] = taps[center - i - 1] = (float)tap;
+    }
+    sum *= 2.0;
+  } else {
+    for (int i = 1; i <= center; ++i) {
+      tap = std::erf((i + 0.5) * z) - std::erf((i - 0.5) * z);
+      sum += tap;
+      taps[center + i] = taps[center - i] = (float)tap;
+    }
+    sum *= 2.0;
+    tap = std::erf(0.5 * z) - std::erf(-0.5 * z);
+    sum += tap;
+    taps[center] = (float)tap;
+  }
+  const double norm = 1.0 / sum;
+  for (int i = 0; i < size; ++i) taps[i] *= norm;  // float *= double, as the reference does
+  return size;
+}
+
+int vwgpu_separable_convolution_dev(vwgpu_ctx* ctx, const float* d_src, int w, int h, ptrdiff_t stride,
+                                    const float* xk, int nx, int cx, const float* yk, int ny, int cy,
+                                    int edge, int subsample, float* d_dst, ptrdiff_t dstride) {
+  int rc = check_image(ctx, "separable_convolution_filter", d_src, w, h, stride, d_dst);
+  if (rc) return rc;
+  if (nx < 0 || ny < 0 || (nx && !xk) || (ny && !yk) || subsample < 1 || (edge != 0 && edge != 1) ||
+      (nx && (cx < 0 || cx >= nx)) || (ny && (cy < 0 || cy >= ny)))
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "separable_convolution_filter: bad kernel / origin / edge / subsample argument");
+  const int ow = 1 + (w - 1) / subsample;
+  if (dstride == 0) dstride = ow;
+  if (dstride < ow) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "separable_convolution_filter: destination stride too small");
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  return vwgpu_launch_sepconv(ctx, d_src, w, h, stride, xk, nx, cx, yk, ny, cy, edge, subsample, d_dst, dstride);
+}
+
+int vwgpu_separable_convolution(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
+                                const float* xk, int nx, int cx, const float* yk, int ny, int cy,
+                                int edge, int subsample, float* dst, ptrdiff_t dstride) {
+  int rc = check_image(ctx, "separable_convolution_filter", src, w, h, stride, dst);
+  if (rc) return rc;
+  if (subsample < 1) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "separable_convolution_filter: subsample < 1");
+  const int ow = 1 + (w - 1) / subsample, oh = 1 + (h - 1) / subsample;
+  if (dstride == 0) dstride = ow;
+  return staged<float>(ctx, src, w, h, stride, dst, ow, oh, dstride, [&](float* ds, float* dd) {
+    return vwgpu_separable_convolution_dev(ctx, ds, w, h, w, xk, nx, cx, yk, ny, cy, edge, subsample, dd, ow);
+  });
+}
+
+int vwgpu_convolution_2d_dev(vwgpu_ctx* ctx, const float* d_src, int w, int h, ptrdiff_t stride,
+                             const float* kernel, int kw, int kh, int ci, int cj, int edge,
+                             float* d_dst, ptrdiff_t dstride) {
+  int rc = check_image(ctx, "convolution_filter", d_src, w, h, stride, d_dst);
+  if (rc) return rc;
+  if (!kernel || kw <= 0 || kh <= 0 || ci < 0 || ci >= kw || cj < 0 || cj >= kh || (edge != 0 && edge != 1))
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "convolution_filter: bad kernel / origin / edge argument");
+  if (dstride == 0) dstride = w;
+  if (dstride < w) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "convolution_filter: destination stride too small");
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  return vwgpu_launch_conv2d(ctx, d_src, w, h, stride, kernel, kw, kh, ci, cj, edge, d_dst, dstride);
+}
+
+int vwgpu_convolution_2d(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
+                         const float* kernel, int kw, int kh, int ci, int cj, int edge, float* dst, ptrdiff_t dstride) {
+  int rc = check_image(ctx, "convolution_filter", src, w, h, stride, dst);
+  if (rc) return rc;
+  if (dstride == 0) dstride = w;
+  return staged<float>(ctx, src, w, h, stride, dst, w, h, dstride, [&](float* ds, float* dd) {
+    return vwgpu_convolution_2d_dev(ctx, ds, w, h, w, kernel, kw, kh, ci, cj, edge, dd, w);
+  });
+}
+
+int vwgpu_subsample_mask_by_two_dev(vwgpu_ctx* ctx, const uint8_t* d_src, int w, int h, ptrdiff_t stride,
+                                    uint8_t* d_dst, ptrdiff_t dstride) {
+  int rc = check_image(ctx, "subsample_mask_by_two", d_src, w, h, stride, d_dst);
+  if (rc) return rc;
+  const int ow = 1 + (w - 1) / 2;
+  if (dstride == 0) dstride = ow;
+  if (dstride < ow) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "subsample_mask_by_two: destination stride too small");
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  return vwgpu_launch_mask_by_two(ctx, d_src, w, h, stride, d_dst, dstride);
+}
+
+int vwgpu_subsample_mask_by_two(vwgpu_ctx* ctx, const uint8_t* src, int w, int h, ptrdiff_t stride,
+                                uint8_t* dst, ptrdiff_t dstride) {
+  int rc = check_image(ctx, "subsample_mask_by_two", src, w, h, stride, dst);
+  if (rc) return rc;
+  const int ow = 1 + (w - 1) / 2, oh = 1 + (h - 1) / 2;
+  if (dstride == 0) dstride = ow;
+  return staged<uint8_t>(ctx, src, w, h, stride, dst, ow, oh, dstride, [&](uint8_t* ds, uint8_t* dd) {
+    return vwgpu_subsample_mask_by_two_dev(ctx, ds, w, h, w, dd, ow);
+  });
+}
+
+int vwgpu_prefilter_image_dev(vwgpu_ctx* ctx, const float* d_src, int w, int h, ptrdiff_t stride,
+                              int mode, float width, float* d_dst, ptrdiff_t dstride) {
+  int rc = check_image(ctx, "prefilter_image", d_src, w, h, stride, d_dst);
+  if (rc) return rc;
+  if (dstride == 0) dstride = w;
+  if (dstride < w) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "prefilter_image: destination stride too small");
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  if (mode != VWGPU_PREFILTER_LOG && mode != VWGPU_PREFILTER_MEANSUB) {
+    // NullOperation: edge_extend(image) rasterised = a copy (src/vw/Stereo/PreFilter.h:41-47, default :91-93)
+    if (d_src != d_dst)
+      VWGPU_HIP(ctx, hipMemcpy2DAsync(d_dst, (size_t)dstride * 4, d_src, (size_t)stride * 4, (size_t)w * 4, h,
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+    return VWGPU_OK;
+  }
+  float taps[1024];
+  const int nt = vwgpu_generate_gaussian_kernel((double)width, 0, taps, 1024);   // gaussian_filter(image, kernel_width)
+  if (nt < 0) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "prefilter_image: prefilter width %g too large", (double)width);
+  if (nt == 0) {   // sigma == 0: empty kernels, gaussian_filter is the identity
+    if (mode == VWGPU_PREFILTER_MEANSUB) return vwgpu_launch_subtract(ctx, d_src, stride, d_src, stride, w, h, d_dst, dstride);
+    const float lap0[9] = {0, 1, 0, 1, -4, 1, 0, 1, 0};
+    return vwgpu_launch_conv2d(ctx, d_src, w, h, stride, lap0, 3, 3, 1, 1, 0, d_dst, dstride);
+  }
+  rc = vwgpu_arena_reserve(ctx, &ctx->filt, (size_t)w * h * sizeof(float));
+  if (rc) return rc;
+  float* g = static_cast<float*>(ctx->filt.base);
+  rc = vwgpu_launch_sepconv(ctx, d_src, w, h, stride, taps, nt, (nt - 1) / 2, taps, nt, (nt - 1) / 2, 0, 1, g, w);
+  if (rc) return rc;
+  if (mode == VWGPU_PREFILTER_MEANSUB)                                            // PreFilter.h:73
+    return vwgpu_launch_subtract(ctx, d_src, stride, g, w, w, h, d_dst, dstride);
+  const float lap[9] = {0, 1, 0, 1, -4, 1, 0, 1, 0};                               // Filter.h:320-335
+  return vwgpu_launch_conv2d(ctx, g, w, h, w, lap, 3, 3, 1, 1, 0, d_dst, dstride);
+}
+
+int vwgpu_prefilter_image(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
+                          int mode, float width, float* dst, ptrdiff_t dstride) {
+  int rc = check_image(ctx, "prefilter_image", src, w, h, stride, dst);
+  if (rc) return rc;
+  if (dstride == 0) dstride = w;
+  return staged<float>(ctx, src, w, h, stride, dst, w, h, dstride, [&](float* ds, float* dd) {
+    return vwgpu_prefilter_image_dev(ctx, ds, w, h, w, mode, width, dd, w);
+  });
+}
+
+}  // extern "C"

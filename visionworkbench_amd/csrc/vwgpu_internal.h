@@ -39,6 +39,7 @@ struct vwgpu_ctx {
   int flag_parity = 0;
   int* last_flag = nullptr;
   vwgpu_arena staging;   // device copies of host images for the host-pointer entry points
+  vwgpu_arena filt;      // intermediate image of composite filters (prefilter_image)
   int num_cu = 256;
 };
 
@@ -90,3 +91,14 @@ int vwgpu_launch_bm_sad_u8(vwgpu_ctx* ctx,
 
 int vwgpu_launch_lr_check(vwgpu_ctx* ctx, int32_t* l2r, int lw, int lh, ptrdiff_t ls,
                           const int32_t* r2l, int rw, int rh, ptrdiff_t rs, float thr);
+
+// filters.hip
+int vwgpu_launch_sepconv(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
+                         const float* xk, int nx, int cx, const float* yk, int ny, int cy,
+                         int edge, int step, float* dst, ptrdiff_t dstride);
+int vwgpu_launch_conv2d(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
+                        const float* k, int kw, int kh, int ci, int cj, int edge, float* dst, ptrdiff_t dstride);
+int vwgpu_launch_mask_by_two(vwgpu_ctx* ctx, const uint8_t* src, int w, int h, ptrdiff_t stride,
+                             uint8_t* dst, ptrdiff_t dstride);
+int vwgpu_launch_subtract(vwgpu_ctx* ctx, const float* a, ptrdiff_t as, const float* b, ptrdiff_t bs, int w, int h,
+                          float* dst, ptrdiff_t ds);
