@@ -183,6 +183,29 @@ int vwgpu_prefilter_image_dev(vwgpu_ctx* ctx, const float* d_src, int w, int h, 
 int vwgpu_prefilter_image(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
                           int mode, float width, float* dst, ptrdiff_t dstride);
 
+/* ---- parabola sub-pixel refinement ------------------------------------------------------------------- */
+
+/* Replaces rasterising vw::stereo::parabola_subpixel(disparity, left, right, prefilter_mode, prefilter_width,
+ * kernel_size) (src/vw/Stereo/ParabolaSubpixelView.h:112-117; ParabolaSubpixelView::prerasterize + evaluate,
+ * src/vw/Stereo/ParabolaSubpixelView.cc:31-330) over the whole image.
+ *   disp  w x h x {dx, dy, valid in {0.f,1.f}} float (PixelMask<Vector2f>; truncated to int like the reference),
+ *         same size as the left image (the reference VW_ASSERTs this); strides of disp / out in PIXELS.
+ *   left  w x h float, right rw x rh float; both are prefiltered internally (mode / width as in prefilter_image),
+ *         with the reference's constant edge extension wherever a window leaves an image.
+ *   out   w x h x {dx, dy, valid}: integer disparity + parabola offset (if |offset| < 5 and the nine costs differ),
+ *         invalid pixels -> {0,0,0}.
+ * Bit-exact on integer-valued imagery with PREFILTER_NONE; otherwise to float rounding. */
+int vwgpu_parabola_subpixel_dev(vwgpu_ctx* ctx, const float* d_disp, int w, int h, ptrdiff_t dstride,
+                                const float* d_left, ptrdiff_t lstride,
+                                const float* d_right, int rw, int rh, ptrdiff_t rstride,
+                                int prefilter_mode, float prefilter_width, int kx, int ky,
+                                float* d_out, ptrdiff_t ostride);
+int vwgpu_parabola_subpixel(vwgpu_ctx* ctx, const float* disp, int w, int h, ptrdiff_t dstride,
+                            const float* left, ptrdiff_t lstride,
+                            const float* right, int rw, int rh, ptrdiff_t rstride,
+                            int prefilter_mode, float prefilter_width, int kx, int ky,
+                            float* out, ptrdiff_t ostride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,7 +18,8 @@ __all__ = ["build", "lib", "fast_box_sum", "cost_image", "calc_disparity", "calc
            "cross_corr_consistency_check", "ABSOLUTE_DIFFERENCE", "SQUARED_DIFFERENCE",
            "CROSS_CORRELATION", "VALID", "generate_gaussian_kernel", "separable_convolution", "convolution_2d",
            "subsample_mask_by_two", "prefilter_image", "pyramid_smoothing_kernel",
-           "EDGE_CONSTANT", "EDGE_ZERO", "PREFILTER_NONE", "PREFILTER_MEANSUB", "PREFILTER_LOG"]
+           "EDGE_CONSTANT", "EDGE_ZERO", "PREFILTER_NONE", "PREFILTER_MEANSUB", "PREFILTER_LOG",
+           "subdivide_regions", "prefilter_region", "parabola_subpixel"]
 
 
 def build(force=False):
@@ -49,6 +50,9 @@ def lib():
         _LIB.vwo_convolution_2d_f64.argtypes = [P, I, I, P, I, I, I, I, I, P]
         _LIB.vwo_subsample_mask_by_two.argtypes = [P, I, I, P]
         _LIB.vwo_prefilter_image.argtypes = [P, I, I, I, F, P]
+        _LIB.vwo_subdivide_regions.argtypes = [P, I, I, I, I, P, I]
+        _LIB.vwo_prefilter_region.argtypes = [P, I, I, I, F, I, I, I, I, P]
+        _LIB.vwo_parabola_subpixel.argtypes = [P, I, I, P, P, I, I, I, F, I, I, P]
     return _LIB
 
 
@@ -184,4 +188,37 @@ def prefilter_image(img, mode, width):
     a = np.ascontiguousarray(img, np.float32)
     out = np.empty_like(a)
     assert lib().vwo_prefilter_image(_p(a), a.shape[1], a.shape[0], int(mode), float(width), _p(out)) == 0
+    return out
+
+
+def subdivide_regions(disp, kernel):
+    """subdivide_regions(disparity, bounding_box(disparity), list, kernel_size); returns an (n, 8) int32 array of
+    {region.min.x, region.min.y, region.max.x, region.max.y, range.min.x, range.min.y, range.max.x, range.max.y}."""
+    d = np.ascontiguousarray(disp, np.int32)
+    h, w = d.shape[:2]
+    cap = 1 << 16
+    z = np.zeros((cap, 8), np.int32)
+    n = lib().vwo_subdivide_regions(_p(d), w, h, kernel[0], kernel[1], _p(z), cap)
+    assert 0 <= n <= cap
+    return z[:n].copy()
+
+
+def prefilter_region(img, mode, width, x0, y0, bw, bh):
+    a = np.ascontiguousarray(img, np.float32)
+    out = np.empty((bh, bw), np.float32)
+    assert lib().vwo_prefilter_region(_p(a), a.shape[1], a.shape[0], int(mode), float(width), x0, y0, bw, bh, _p(out)) == 0
+    return out
+
+
+def parabola_subpixel(disparity, left, right, prefilter_mode, prefilter_width, kernel):
+    """parabola_subpixel(...) rasterised over the whole image. disparity: (h, w, 3) float32 PixelMask<Vector2f>."""
+    d = np.ascontiguousarray(disparity, np.float32)
+    l = np.ascontiguousarray(left, np.float32)
+    r = np.ascontiguousarray(right, np.float32)
+    h, w = l.shape
+    assert d.shape == (h, w, 3)
+    out = np.empty((h, w, 3), np.float32)
+    rc = lib().vwo_parabola_subpixel(_p(d), w, h, _p(l), _p(r), r.shape[1], r.shape[0], int(prefilter_mode),
+                                     float(prefilter_width), kernel[0], kernel[1], _p(out))
+    assert rc == 0
     return out

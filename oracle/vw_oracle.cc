@@ -417,3 +417,295 @@ int vwo_prefilter_image(const float* src, int w, int h, int mode, float width, f
 }
 
 }  // extern "C"
+
+// ---- zone subdivision and parabola sub-pixel refinement ---------------------------------------------------------
+
+namespace {
+
+// vw::BBox2i with the exact semantics of src/vw/Math/BBox.tcc (default box :40-45, grow :82-108, crop :110-121,
+// empty/width/height/area :156-197).
+struct Box {
+  int minx, miny, maxx, maxy;
+  Box() { const int big = std::numeric_limits<int32_t>::max() - 1; minx = miny = big; maxx = maxy = -big; }
+  Box(int x0, int y0, int x1, int y1) : minx(x0), miny(y0), maxx(x1), maxy(y1) {}
+  static Box xywh(int x, int y, int w, int h) { return Box(x, y, x + w, y + h); }
+  bool empty() const { return minx >= maxx || miny >= maxy; }
+  int width() const { return empty() ? 0 : maxx - minx; }
+  int height() const { return empty() ? 0 : maxy - miny; }
+  int area() const { return empty() ? 0 : (maxx - minx) * (maxy - miny); }
+  int sizex() const { return maxx - minx; }
+  int sizey() const { return maxy - miny; }
+  void grow_pt(int x, int y) { if (x > maxx) maxx = x; if (x < minx) minx = x; if (y > maxy) maxy = y; if (y < miny) miny = y; }
+  void grow(Box const& b) { if (b.empty()) return; grow_pt(b.minx, b.miny); grow_pt(b.maxx, b.maxy); }
+  void crop(Box const& b) { if (minx < b.minx) minx = b.minx; if (maxx > b.maxx) maxx = b.maxx; if (miny < b.miny) miny = b.miny; if (maxy > b.maxy) maxy = b.maxy; }
+  void expand(int n) { minx -= n; miny -= n; maxx += n; maxy += n; }   // BBox::expand (no empty() guard in the reference)
+  bool operator==(Box const& o) const { return minx == o.minx && miny == o.miny && maxx == o.maxx && maxy == o.maxy; }
+  bool operator!=(Box const& o) const { return !(*this == o); }
+};
+
+struct Zone { Box region, range; };
+
+// PixelAccumulator<EWMinMaxAccumulator<Vector2i>> over crop(disparity, box): element-wise min/max of the VALID pixels.
+struct MinMax {
+  bool valid = false; int mnx = 0, mny = 0, mxx = 0, mxy = 0;
+  void add(int x, int y) {
+    if (!valid) { mnx = mxx = x; mny = mxy = y; valid = true; return; }
+    if (x < mnx) mnx = x;
+    if (x > mxx) mxx = x;
+    if (y < mny) mny = y;
+    if (y > mxy) mxy = y;
+  }
+};
+MinMax minmax_in(const int32_t* d, int w, Box const& b) {
+  MinMax a;
+  for (int y = b.miny; y < b.maxy; ++y)
+    for (int x = b.minx; x < b.maxx; ++x) {
+      const int32_t* p = d + ((size_t)y * w + x) * 3;
+      if (p[2]) a.add(p[0], p[1]);
+    }
+  return a;
+}
+
+// subdivide_regions, src/vw/Stereo/Correlation.cc:139-328 (statement by statement).
+bool subdivide(const int32_t* d, int w, int h, Box const& cur, std::vector<Zone>& list, int kx, int ky, int fail_count = 0) {
+  const int MIN_REGION_SIZE = 16;
+  if (cur.sizex() * cur.sizey() <= 200 || cur.width() < MIN_REGION_SIZE || cur.height() < MIN_REGION_SIZE) {   // :149-162
+    Box expanded = cur;
+    expanded.expand(1);
+    expanded.crop(Box(0, 0, w, h));
+    MinMax a = minmax_in(d, w, expanded);
+    if (!a.valid) return true;
+    list.push_back(Zone{cur, Box(a.mnx, a.mny, a.mxx + 1, a.mxy + 1)});
+    return true;
+  }
+  const int sx = cur.sizex() / 2, sy = cur.sizey() / 2;                                                         // :165-171
+  Box q1(cur.minx, cur.miny, cur.minx + sx, cur.miny + sy);
+  Box q4(cur.minx + sx, cur.miny + sy, cur.maxx, cur.maxy);
+  Box q2(cur.minx + sx, cur.miny, cur.maxx, cur.miny + sy);
+  Box q3(cur.minx, cur.miny + sy, cur.minx + sx, cur.maxy);
+  Box qs[4] = {q1, q2, q3, q4};
+  Box search[4];
+  int32_t split_search = 0;
+  for (int i = 0; i < 4; ++i) {                                                                                 // :179-218
+    MinMax a = minmax_in(d, w, qs[i]);
+    if (a.valid) {
+      search[i] = Box(a.mnx, a.mny, a.mxx + 1, a.mxy + 1);
+      split_search += search[i].area() * ((qs[i].sizex() + kx) * (qs[i].sizey() + ky));
+    }
+  }
+  Box cs;                                                                                                      // :225-239
+  if (search[0] != Box()) cs = search[0];
+  for (int i = 1; i < 4; ++i) {
+    if (search[i] != Box() && cs == Box()) cs = search[i];
+    else cs.grow(search[i]);
+  }
+  const int32_t current_search = cs.area() * ((cur.sizex() + kx) * (cur.sizey() + ky));                         // :241
+  const double IMPROVEMENT_RATIO = 0.8;
+  if (split_search > current_search * IMPROVEMENT_RATIO && fail_count == 0) {                                   // :245
+    std::vector<Zone> failed;
+    for (int i = 0; i < 4; ++i)
+      if (!subdivide(d, w, h, qs[i], list, kx, ky, fail_count + 1)) failed.push_back(Zone{qs[i], search[i]});
+    auto adjacent_same = [](Zone const& a, Zone const& b) {
+      return (a.region.minx == b.region.minx || a.region.miny == b.region.miny) && a.range == b.range;
+    };
+    if (failed.size() == 4) {
+      list.push_back(Zone{cur, cs});
+      return true;
+    } else if (failed.size() == 3) {                                                                            // :264-299
+      if (adjacent_same(failed[0], failed[1])) {
+        Box m = failed[0].region; m.grow(failed[1].region);
+        list.push_back(Zone{m, failed[0].range}); list.push_back(failed[2]); return true;
+      }
+      if (adjacent_same(failed[1], failed[2])) {
+        Box m = failed[1].region; m.grow(failed[2].region);
+        list.push_back(Zone{m, failed[1].range}); list.push_back(failed[0]); return true;
+      }
+      if (adjacent_same(failed[0], failed[2])) {
+        Box m = failed[0].region; m.grow(failed[2].region);
+        list.push_back(Zone{m, failed[0].range}); list.push_back(failed[1]); return true;
+      }
+      list.insert(list.end(), failed.begin(), failed.end());
+    } else if (failed.size() == 2) {                                                                            // :300-313
+      if (adjacent_same(failed[0], failed[1])) {
+        Box m = failed[0].region; m.grow(failed[1].region);
+        list.push_back(Zone{m, failed[0].range});
+        return true;
+      }
+      list.insert(list.end(), failed.begin(), failed.end());
+    } else if (failed.size() == 1) {
+      list.push_back(failed[0]);
+    }
+    return true;
+  } else if (split_search > current_search * IMPROVEMENT_RATIO && fail_count > 0) {                           // :319
+    return false;
+  } else {                                                                                                      // :322-327
+    for (int i = 0; i < 4; ++i) subdivide(d, w, h, qs[i], list, kx, ky);
+  }
+  return true;
+}
+
+// prefilter.filter(image) rasterised over a region that may leave the image (see vwo_prefilter_region).
+int prefilter_region(const float* src, int w, int h, int mode, float width, int x0, int y0, int bw, int bh, float* dst) {
+  if (mode != VWO_PREFILTER_LOG && mode != VWO_PREFILTER_MEANSUB) {      // NullOperation: edge_extend(image, Constant)
+    for (int y = 0; y < bh; ++y) for (int x = 0; x < bw; ++x) dst[(size_t)y * bw + x] = ext_at(src, w, h, x0 + x, y0 + y, VWO_EDGE_CONSTANT);
+    return 0;
+  }
+  float taps[1024];
+  const int nt = gaussian_kernel<float>((double)width, 0, taps, 1024);
+  if (nt < 0) return -1;
+  const int c = nt ? (nt - 1) / 2 : 0, lo = nt ? nt - c - 1 : 0;
+  // gaussian view evaluated at (x,y), any integer coordinates: filter of the constant-extended source
+  auto gauss_at = [&](int x, int y) -> float {
+    if (nt == 0) return ext_at(src, w, h, x, y, VWO_EDGE_CONSTANT);
+    float result = 0.0f;
+    for (int j = 0; j < nt; ++j) {
+      float hrow = 0.0f;                                                  // the float `work` pixel of the H pass
+      for (int i = 0; i < nt; ++i) hrow += taps[nt - 1 - i] * ext_at(src, w, h, x - lo + i, y - lo + j, VWO_EDGE_CONSTANT);
+      result += taps[nt - 1 - j] * hrow;
+    }
+    return result;
+  };
+  if (mode == VWO_PREFILTER_MEANSUB) {                                     // edge_extend(image) - gaussian_filter(image)
+    for (int y = 0; y < bh; ++y) for (int x = 0; x < bw; ++x)
+      dst[(size_t)y * bw + x] = ext_at(src, w, h, x0 + x, y0 + y, VWO_EDGE_CONSTANT) - gauss_at(x0 + x, y0 + y);
+    return 0;
+  }
+  // LoG: laplacian_filter(gaussian view) with ConstantEdgeExtension of the gaussian VIEW (its domain is the image)
+  std::vector<float> g((size_t)w * h);
+  for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) g[(size_t)y * w + x] = gauss_at(x, y);
+  const float lap[9] = {0, 1, 0, 1, -4, 1, 0, 1, 0};
+  for (int y = 0; y < bh; ++y) for (int x = 0; x < bw; ++x) {
+    float result = 0.0f;
+    for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i)
+      result += lap[(2 - j) * 3 + (2 - i)] * ext_at(g.data(), w, h, x0 + x - 1 + i, y0 + y - 1 + j, VWO_EDGE_CONSTANT);
+    dst[(size_t)y * bw + x] = result;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vwo_subdivide_regions(const int32_t* disp3, int w, int h, int kx, int ky, int32_t* zones, int cap) {
+  std::vector<Zone> list;
+  subdivide(disp3, w, h, Box(0, 0, w, h), list, kx, ky);
+  int n = 0;
+  for (auto const& z : list) {
+    if (n < cap) {
+      int32_t* o = zones + (size_t)n * 8;
+      o[0] = z.region.minx; o[1] = z.region.miny; o[2] = z.region.maxx; o[3] = z.region.maxy;
+      o[4] = z.range.minx; o[5] = z.range.miny; o[6] = z.range.maxx; o[7] = z.range.maxy;
+    }
+    ++n;
+  }
+  return n;
+}
+
+int vwo_prefilter_region(const float* src, int w, int h, int mode, float width, int x0, int y0, int bw, int bh, float* dst) {
+  return prefilter_region(src, w, h, mode, width, x0, y0, bw, bh, dst);
+}
+
+int vwo_parabola_subpixel(const float* disp3f, int w, int h, const float* left, const float* right, int rw, int rh,
+                          int prefilter_mode, float prefilter_width, int kx, int ky, float* out3f) {
+  if (kx % 2 != 1 || ky % 2 != 1 || w <= 0 || h <= 0) return -1;
+  const size_t n = (size_t)w * h;
+  // prerasterize(bbox = whole image), ParabolaSubpixelView.cc:277-298
+  std::vector<int32_t> idisp(n * 3);                                       // crop(m_disparity, bbox) as PixelMask<Vector2i>
+  for (size_t i = 0; i < n; ++i) {
+    idisp[3*i] = (int32_t)disp3f[3*i]; idisp[3*i+1] = (int32_t)disp3f[3*i+1];  // float -> int32 conversion truncates
+    idisp[3*i+2] = disp3f[3*i+2] != 0.0f ? std::numeric_limits<int32_t>::max() : 0;
+  }
+  // get_disparity_range does NOT skip invalid pixels (src/vw/Stereo/DisparityMap.h:52-66)
+  int mnx = idisp[0], mxx = idisp[0], mny = idisp[1], mxy = idisp[1];
+  for (size_t i = 0; i < n; ++i) {
+    mnx = std::min(mnx, idisp[3*i]); mxx = std::max(mxx, idisp[3*i]);
+    mny = std::min(mny, idisp[3*i+1]); mxy = std::max(mxy, idisp[3*i+1]);
+  }
+  Box range(mnx, mny, mxx + 1, mxy + 1);                                  // entire_search_range, max += (1,1)
+  range.expand(1);
+  const int hx = kx / 2, hy = ky / 2;
+  Box left_region(-hx, -hy, w + hx, h + hy);
+  Box right_region(left_region.minx + range.minx, left_region.miny + range.miny,
+                   left_region.maxx + range.minx + range.sizex(), left_region.maxy + range.miny + range.sizey());
+  const int lrw = left_region.sizex(), lrh = left_region.sizey(), rrw = right_region.sizex(), rrh = right_region.sizey();
+  std::vector<float> lras((size_t)lrw * lrh), rras((size_t)rrw * rrh);
+  if (prefilter_region(left, w, h, prefilter_mode, prefilter_width, left_region.minx, left_region.miny, lrw, lrh, lras.data())) return -1;
+  if (prefilter_region(right, rw, rh, prefilter_mode, prefilter_width, right_region.minx, right_region.miny, rrw, rrh, rras.data())) return -1;
+
+  // evaluate(), ParabolaSubpixelView.cc:31-274
+  std::vector<float> patch(n * 9, 0.0f);                                   // ImageView<Vector<float,9>> zero-initialised
+  std::vector<Zone> big, zones;
+  subdivide(idisp.data(), w, h, Box(0, 0, w, h), big, kx, ky);
+  const double ratio = 1.0;
+  for (auto const& z : big) {                                              // :76-101
+    const double len1 = z.region.area(), len2 = z.range.area();
+    if (len2 / len1 < ratio) { zones.push_back(z); continue; }
+    for (int dx = z.region.minx; dx < z.region.maxx; ++dx)
+      for (int dy = z.region.miny; dy < z.region.maxy; ++dy) {
+        const int32_t* p = &idisp[((size_t)dy * w + dx) * 3];
+        if (!p[2]) continue;
+        zones.push_back(Zone{Box(dx, dy, dx + 1, dy + 1), Box(p[0], p[1], p[0] + 1, p[1] + 1)});
+      }
+  }
+  std::vector<double> cost_applied, cost_metric;
+  for (auto zone : zones) {                                                // :104-218
+    zone.range.expand(1);
+    const int zw = zone.region.width(), zh = zone.region.height();
+    const int cw = zw + kx - 1, chh = zh + ky - 1;                          // left_zone = region, max += kernel-1
+    cost_applied.resize((size_t)cw * chh);
+    cost_metric.resize((size_t)zw * zh);
+    for (int dx = 0; dx < zone.range.width(); ++dx)
+      for (int dy = 0; dy < zone.range.height(); ++dy) {
+        const int ax = dx + zone.range.minx, ay = dy + zone.range.miny;    // disparity_abs
+        // crops of left_raster / right_raster; zone coordinates are relative to the rasters' origins
+        const int rx0 = zone.region.minx + ax - range.minx, ry0 = zone.region.miny + ay - range.miny;
+        for (int y = 0; y < chh; ++y)
+          for (int x = 0; x < cw; ++x)
+            cost_applied[(size_t)y * cw + x] =
+                cost_abs(lras[(size_t)(zone.region.miny + y) * lrw + zone.region.minx + x], rras[(size_t)(ry0 + y) * rrw + rx0 + x]);
+        box_sum(cost_applied.data(), cw, cw, chh, kx, ky, cost_metric.data());
+        for (int j = 0; j < zh; ++j)
+          for (int i = 0; i < zw; ++i) {
+            const size_t pi = (size_t)(zone.region.miny + j) * w + zone.region.minx + i;
+            const int ddx = ax - idisp[3*pi], ddy = ay - idisp[3*pi+1];
+            if (ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1)
+              patch[pi * 9 + (ddy + 1) * 3 + (ddx + 1)] = (float)cost_metric[(size_t)j * zw + i];   // :187-205
+          }
+      }
+  }
+  // pinvA rows a..f, ParabolaSubpixelView.h:83-88 (static float array initialised from double literals)
+  static const float A[6][9] = {
+    { (float)(1.0/6), (float)(-1.0/3), (float)(1.0/6), (float)(1.0/6), (float)(-1.0/3), (float)(1.0/6), (float)(1.0/6), (float)(-1.0/3), (float)(1.0/6) },
+    { (float)(1.0/6), (float)(1.0/6), (float)(1.0/6), (float)(-1.0/3), (float)(-1.0/3), (float)(-1.0/3), (float)(1.0/6), (float)(1.0/6), (float)(1.0/6) },
+    { (float)(1.0/4), 0.0f, (float)(-1.0/4), 0.0f, 0.0f, 0.0f, (float)(-1.0/4), 0.0f, (float)(1.0/4) },
+    { (float)(-1.0/6), 0.0f, (float)(1.0/6), (float)(-1.0/6), 0.0f, (float)(1.0/6), (float)(-1.0/6), 0.0f, (float)(1.0/6) },
+    { (float)(-1.0/6), (float)(-1.0/6), (float)(-1.0/6), 0.0f, 0.0f, 0.0f, (float)(1.0/6), (float)(1.0/6), (float)(1.0/6) },
+    { (float)(-1.0/9), (float)(2.0/9), (float)(-1.0/9), (float)(2.0/9), (float)(5.0/9), (float)(2.0/9), (float)(-1.0/9), (float)(2.0/9), (float)(-1.0/9) } };
+  for (size_t i = 0; i < n; ++i) {                                         // :221-271
+    float* o = out3f + 3 * i;
+    if (!idisp[3*i+2]) { o[0] = o[1] = o[2] = 0.0f; continue; }
+    const float* pc = &patch[i * 9];
+    bool all_equal = true;
+    for (int c = 1; c < 9; ++c) if (pc[c] != pc[c - 1]) { all_equal = false; break; }
+    o[0] = (float)idisp[3*i]; o[1] = (float)idisp[3*i+1]; o[2] = 1.0f;
+    if (all_equal) continue;
+    float x[6];
+    for (int r = 0; r < 6; ++r) {                                          // Matrix<float,6,9> * Vector<float,9>: sequential dot product
+      float acc = 0.0f;
+      for (int c = 0; c < 9; ++c) acc += A[r][c] * pc[c];
+      x[r] = acc;
+    }
+    const float denom = 4 * x[0] * x[1] - (x[2] * x[2]);
+    const float ox = (x[2] * x[4] - 2 * x[1] * x[3]) / denom;
+    const float oy = (x[2] * x[3] - 2 * x[0] * x[4]) / denom;
+    const float MAX_SUBPIXEL_SHIFT = 5.0;
+    // norm_2 = sqrt(norm_2_sqr) in double, norm_2_sqr accumulates float products in double and returns them cast to
+    // the vector's value type (src/vw/Math/Vector.h:1591-1604)
+    double n2 = 0.0; n2 += ox * ox; n2 += oy * oy;
+    if (std::sqrt((double)(float)n2) < MAX_SUBPIXEL_SHIFT) { o[0] = (float)idisp[3*i] + ox; o[1] = (float)idisp[3*i+1] + oy; }
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -91,6 +91,26 @@ int vwo_subsample_mask_by_two(const uint8_t* src, int w, int h, uint8_t* dst);
 /* prefilter_image, src/vw/Stereo/PreFilter.h:41-95 (LoG = laplacian(gaussian(width)); MEANSUB = I - gaussian(width)). */
 int vwo_prefilter_image(const float* src, int w, int h, int mode, float width, float* dst);
 
+/* ---- zone subdivision and parabola sub-pixel refinement ------------------------------------------------------- */
+
+/* subdivide_regions(disparity, bounding_box(disparity), list, kernel_size), src/vw/Stereo/Correlation.cc:139-328.
+ * disp3: w x h x {dx,dy,valid} int32.  Each zone is written as 8 ints
+ * {region.min.x, region.min.y, region.max.x, region.max.y, range.min.x, range.min.y, range.max.x, range.max.y}.
+ * Returns the number of zones (may exceed cap; only cap are written). */
+int vwo_subdivide_regions(const int32_t* disp3, int w, int h, int kx, int ky, int32_t* zones, int cap);
+
+/* Rasterises prefilter.filter(image) (src/vw/Stereo/PreFilter.h:41-74) over an arbitrary region [x0,x0+bw) x
+ * [y0,y0+bh), which may extend beyond the image: the lazy views evaluate the filter of the edge-extended source
+ * there (this is what ParabolaSubpixelView::prerasterize crops, ParabolaSubpixelView.cc:302-327). */
+int vwo_prefilter_region(const float* src, int w, int h, int mode, float width,
+                         int x0, int y0, int bw, int bh, float* dst);
+
+/* parabola_subpixel(disparity, left, right, prefilter_mode, prefilter_width, kernel) rasterised over the whole
+ * image in one block: ParabolaSubpixelView::prerasterize + evaluate, src/vw/Stereo/ParabolaSubpixelView.cc:31-330.
+ * disp3f / out3f: w x h x {dx, dy, valid in {0.f,1.f}} float (PixelMask<Vector2f>); left is w x h. */
+int vwo_parabola_subpixel(const float* disp3f, int w, int h, const float* left, const float* right, int rw, int rh,
+                          int prefilter_mode, float prefilter_width, int kx, int ky, float* out3f);
+
 #ifdef __cplusplus
 }
 #endif

@@ -250,3 +250,62 @@ def test_pyramid_level_and_mask(oracle):
     m2 = oracle.subsample_mask_by_two(mask)
     assert m2.shape == (3, 4)
     assert m2[0, 0] == 0 and m2[1, 1] == 255 and m2[2, 3] == 0
+
+
+# ---- zone subdivision and parabola sub-pixel ----------------------------------------------------------------------
+
+def _pm2f(dx, dy, h, w, valid=1.0):
+    d = np.zeros((h, w, 3), np.float32)
+    d[..., 0], d[..., 1], d[..., 2] = dx, dy, valid
+    return d
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_parabola_null_test(oracle, mode):
+    """src/vw/Stereo/tests/TestSubPixel.cxx:93-124 (NullTest): constant images 0.5 / 0.6, disparity (1,1), 3x3 kernel,
+    PREFILTER_NONE and PREFILTER_LOG(1.4): every pixel valid and within 0.1 of (1,1)."""
+    left = np.full((5, 5), 0.5, np.float32)
+    right = np.full((5, 5), 0.6, np.float32)
+    out = oracle.parabola_subpixel(_pm2f(1, 1, 5, 5), left, right, mode, 1.4, (3, 3))
+    assert out.shape == (5, 5, 3)
+    assert (out[..., 2] == 1.0).all()
+    assert np.abs(out[..., :2] - 1.0).max() < 0.1
+
+
+def test_parabola_recovers_fractional_shift(oracle):
+    """In the spirit of TestSubPixel.cxx:130-140 (stretched copy, mean error < 0.6, nothing invalid): a smooth texture
+    shifted by a fraction of a pixel; starting from the truncated disparity the refined one must be much closer."""
+    yy, xx = np.mgrid[0:80, 0:120].astype(np.float64)
+
+    def tex(x, y):
+        return 120 + 50 * np.sin(x / 3.1) * np.cos(y / 4.3) + 40 * np.sin((x + 2 * y) / 5.7) + 20 * np.cos(x / 1.9 + y / 2.3)
+    left = tex(xx, yy).astype(np.float32)
+    right = tex(xx - 2.35, yy - 0.6).astype(np.float32)              # right(x + 2.35, y + 0.6) == left(x, y)
+    out = oracle.parabola_subpixel(_pm2f(2, 1, 80, 120), left, right, 0, 0.0, (7, 7))   # nearest integer start
+    core = out[10:-10, 10:-10]
+    assert (core[..., 2] == 1.0).all()
+    err = np.abs(core[..., 0] - 2.35) + np.abs(core[..., 1] - 0.6)
+    assert err.mean() < 0.4                                          # the integer start has error 0.35 + 0.4 = 0.75
+
+
+def test_subdivide_regions_basic(oracle):
+    """subdivide_regions (Correlation.cc:139-328): zones tile the image, each zone's range contains its pixels'
+    disparities, a uniform image stays one zone, a two-valued image splits."""
+    V = oracle.VALID
+    d = np.zeros((64, 96, 3), np.int32)
+    d[..., 0], d[..., 1], d[..., 2] = 3, 1, V
+    z = oracle.subdivide_regions(d, (7, 7))
+    assert len(z) == 1 and list(z[0]) == [0, 0, 96, 64, 3, 1, 4, 2]
+    d[:, 48:, 0] = 40                                                  # right half far away
+    z = oracle.subdivide_regions(d, (7, 7))
+    assert len(z) >= 2
+    cover = np.zeros((64, 96), np.int32)
+    for x0, y0, x1, y1, rx0, ry0, rx1, ry1 in z:
+        cover[y0:y1, x0:x1] += 1
+        blk = d[y0:y1, x0:x1]
+        assert (blk[..., 0] >= rx0).all() and (blk[..., 0] < rx1).all()
+        assert (blk[..., 1] >= ry0).all() and (blk[..., 1] < ry1).all()
+    assert (cover == 1).all()
+    # invalid areas produce no zone
+    d[..., 2] = 0
+    assert len(oracle.subdivide_regions(d, (7, 7))) == 0

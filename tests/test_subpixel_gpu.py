@@ -1,0 +1,111 @@
+"""GPU parity of parabola_subpixel through the C ABI against the oracle (the literal zone-based restatement of
+ParabolaSubpixelView::evaluate).  Integer-valued imagery + PREFILTER_NONE: bit-exact.  Prefiltered / float imagery:
+1e-5 absolute (BASELINE.json's tolerance for sub-pixel results) — the reference's running box sums are position
+dependent there."""
+import numpy as np
+import pytest
+
+import visionworkbench_amd as vwa
+from visionworkbench_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available()
+    c = vwa.Context(0)
+    yield c
+    c.close()
+
+
+def _disp_from_bm(oracle, left, right, kernel, search):
+    """Integer disparity of the block matcher, centred like ParabolaSubpixelView expects (same size as left)."""
+    kx, ky = kernel
+    hx, hy = kx // 2, ky // 2
+    lp = np.pad(left, ((hy, hy), (hx, hx)), mode="edge")
+    rp = np.pad(right, ((hy, hy + search[1] - 1), (hx, hx + search[0] - 1)), mode="edge")[:lp.shape[0] + search[1] - 1, :lp.shape[1] + search[0] - 1]
+    d = oracle.calc_disparity(0, lp, rp, kernel, search)
+    out = np.zeros(left.shape + (3,), np.float32)
+    out[..., 0] = d[..., 0]
+    out[..., 1] = d[..., 1]
+    out[..., 2] = (d[..., 2] != 0)
+    return out
+
+
+def _run(ctx, disp, left, right, mode, width, kernel):
+    import torch
+    from visionworkbench_amd import stereo
+    got_h = stereo.parabola_subpixel(disp, left, right, mode, width, kernel, ctx=ctx)
+    got_d = stereo.parabola_subpixel(torch.from_numpy(disp).cuda(), torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda(),
+                                     mode, width, kernel, ctx=ctx)
+    torch.cuda.synchronize()
+    assert np.array_equal(got_h, got_d.cpu().numpy())
+    return got_h
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_null_test_golden(ctx, oracle, mode):
+    """TestSubPixel.cxx:93-124 through the engine."""
+    left = np.full((5, 5), 0.5, np.float32)
+    right = np.full((5, 5), 0.6, np.float32)
+    d = np.zeros((5, 5, 3), np.float32)
+    d[..., 0] = d[..., 1] = d[..., 2] = 1
+    out = _run(ctx, d, left, right, mode, 1.4, (3, 3))
+    assert (out[..., 2] == 1.0).all() and np.abs(out[..., :2] - 1.0).max() < 0.1
+
+
+@pytest.mark.parametrize("kernel", [(7, 7), (11, 11), (5, 3)])
+def test_integer_imagery_is_bit_exact(ctx, oracle, kernel):
+    left, right, _ = synth.stereo_pair(160, 70, 17, 3, block=32, seeds=(41, 42, 43), smooth=True)
+    right = np.ascontiguousarray(right[:70 + 2, :160 + 16])
+    disp = _disp_from_bm(oracle, left, right, kernel, (17, 3))
+    disp[5:9, 20:40, 2] = 0                                       # some invalid pixels
+    want = oracle.parabola_subpixel(disp, left, right, 0, 0.0, kernel)
+    got = _run(ctx, disp, left, right, 0, 0.0, kernel)
+    assert np.array_equal(got, want), "max abs diff %g" % np.abs(got - want).max()
+    assert (got[5:9, 20:40] == 0).all()
+
+
+@pytest.mark.parametrize("mode,width", [(2, 1.4), (1, 3.0), (0, 0.0)])
+def test_prefiltered_and_float_imagery_within_tolerance(ctx, oracle, mode, width):
+    yy, xx = np.mgrid[0:60, 0:110].astype(np.float64)
+
+    def tex(x, y):
+        return 120 + 50 * np.sin(x / 3.1) * np.cos(y / 4.3) + 40 * np.sin((x + 2 * y) / 5.7) + 20 * np.cos(x / 1.9 + y / 2.3)
+    left = tex(xx, yy).astype(np.float32)
+    right = tex(xx - 3.4, yy - 0.7).astype(np.float32)
+    disp = np.zeros((60, 110, 3), np.float32)
+    disp[..., 0], disp[..., 1], disp[..., 2] = 3, 1, 1
+    disp[:, 60:, 0] = 4                                           # two disparity zones
+    want = oracle.parabola_subpixel(disp, left, right, mode, width, (7, 7))
+    got = _run(ctx, disp, left, right, mode, width, (7, 7))
+    assert np.array_equal(got[..., 2], want[..., 2])
+    assert np.abs(got - want).max() <= 1e-5, np.abs(got - want).max()
+
+
+def test_disparities_pointing_outside_the_right_image(ctx, oracle):
+    """Windows that leave the images use the constant edge extension of the (prefiltered) views."""
+    left, right, _ = synth.stereo_pair(64, 40, 9, 1, block=16)
+    right = np.ascontiguousarray(right[:, :64])                    # right as small as left
+    disp = np.zeros((40, 64, 3), np.float32)
+    disp[..., 0], disp[..., 1], disp[..., 2] = 6, -2, 1
+    disp[10:20, :, 0] = -5
+    for mode, width in [(0, 0.0), (2, 1.4)]:
+        want = oracle.parabola_subpixel(disp, left, right, mode, width, (5, 5))
+        got = _run(ctx, disp, left, right, mode, width, (5, 5))
+        if mode == 0:
+            assert np.array_equal(got, want)
+        else:
+            assert np.abs(got - want).max() <= 1e-5
+
+
+def test_argument_errors(ctx):
+    from visionworkbench_amd import stereo
+    d = np.zeros((10, 12, 3), np.float32)
+    img = np.zeros((10, 12), np.float32)
+    with pytest.raises(vwa.ArgumentErr):
+        stereo.parabola_subpixel(d, img, img, 0, 0.0, (4, 3), ctx=ctx)
+    with pytest.raises(vwa.ArgumentErr):
+        stereo.parabola_subpixel(d[:9], img, img, 0, 0.0, (3, 3), ctx=ctx)

@@ -18,6 +18,7 @@ SYMBOLS = [
     "vwgpu_convolution_2d_dev", "vwgpu_convolution_2d",
     "vwgpu_subsample_mask_by_two_dev", "vwgpu_subsample_mask_by_two",
     "vwgpu_prefilter_image_dev", "vwgpu_prefilter_image",
+    "vwgpu_parabola_subpixel_dev", "vwgpu_parabola_subpixel",
 ]
 
 
@@ -82,6 +83,9 @@ def load():
     pf = [P, P, I, I, PD, I, F, P, PD]
     lib.vwgpu_prefilter_image_dev.argtypes = pf
     lib.vwgpu_prefilter_image.argtypes = pf
+    ps = [P, P, I, I, PD, P, PD, P, I, I, PD, I, F, I, I, P, PD]
+    lib.vwgpu_parabola_subpixel_dev.argtypes = ps
+    lib.vwgpu_parabola_subpixel.argtypes = ps
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the ABI and the header drifted apart
     _LIB = lib

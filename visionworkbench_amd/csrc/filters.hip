@@ -42,14 +42,16 @@ __device__ __forceinline__ float ext_load(const float* __restrict__ src, ptrdiff
 template <int EDGE>
 __global__ void __launch_bounds__(256)
 sepconv_kernel(const float* __restrict__ src, ptrdiff_t stride, int w, int h, Taps t, int step,
-               float* __restrict__ dst, ptrdiff_t dstride, int ow, int oh, int sw, int sh) {
+               float* __restrict__ dst, ptrdiff_t dstride, int ow, int oh, int sw, int sh, int offx, int offy) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tile = smem;                       // [sh][sw]   edge-extended source
   float* work = smem + (size_t)sh * sw;     // [sh][TW]   horizontal pass (float, like the reference's `work`)
   const int tid = threadIdx.x;
   const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
   const int x_lo = t.nx ? t.nx - t.cx - 1 : 0, y_lo = t.ny ? t.ny - t.cy - 1 : 0;
-  const int X0 = ox0 * step - x_lo, Y0 = oy0 * step - y_lo;
+  // output (ox, oy) sits at source position (ox*step + offx, oy*step + offy); the offsets let a caller rasterise the
+  // view over a region that leaves the image (filter of the edge-extended source, as the reference's lazy views do)
+  const int X0 = ox0 * step + offx - x_lo, Y0 = oy0 * step + offy - y_lo;
 
   for (int i = tid; i < sh * sw; i += 256) {
     const int yy = i / sw, xx = i - yy * sw;
@@ -91,15 +93,25 @@ struct Kernel2D {
 
 template <int EDGE>
 __global__ void conv2d_kernel(const float* __restrict__ src, ptrdiff_t stride, int w, int h, Kernel2D kk,
-                              float* __restrict__ dst, ptrdiff_t dstride) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= w || y >= h) return;
+                              float* __restrict__ dst, ptrdiff_t dstride, int ow, int oh, int offx, int offy) {
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y * blockDim.y + threadIdx.y;
+  if (ox >= ow || oy >= oh) return;
+  const int x = ox + offx, y = oy + offy;          // source position of this output (may be outside the image)
   const int ci = kk.kw - 1 - kk.ci, cj = kk.kh - 1 - kk.cj;
   float result = 0.0f;
   for (int j = 0; j < kk.kh; ++j)
     for (int i = 0; i < kk.kw; ++i)
       result += kk.k[(kk.kh - 1 - j) * kk.kw + (kk.kw - 1 - i)] * ext_load<EDGE>(src, stride, w, h, x - ci + i, y - cj + j);
-  dst[(ptrdiff_t)y * dstride + x] = result;
+  dst[(ptrdiff_t)oy * dstride + ox] = result;
+}
+
+// dst(ox,oy) = a(clamp(ox+offx), clamp(oy+offy)) - (b ? b(ox,oy) : 0): NullOperation / SubtractedMean over a region
+__global__ void ext_sub_kernel(const float* __restrict__ a, ptrdiff_t as, int w, int h, const float* __restrict__ b, ptrdiff_t bs,
+                               float* __restrict__ dst, ptrdiff_t ds, int ow, int oh, int offx, int offy) {
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y * blockDim.y + threadIdx.y;
+  if (ox >= ow || oy >= oh) return;
+  const float v = ext_load<0>(a, as, w, h, ox + offx, oy + offy);
+  dst[(ptrdiff_t)oy * ds + ox] = b ? v - b[(ptrdiff_t)oy * bs + ox] : v;
 }
 
 __global__ void mask_by_two_kernel(const uint8_t* __restrict__ src, ptrdiff_t stride, int w, int h,
@@ -121,38 +133,54 @@ __global__ void subtract_kernel(const float* __restrict__ a, ptrdiff_t as, const
 
 }  // namespace
 
+int vwgpu_launch_sepconv_region(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
+                                const float* xk, int nx, int cx, const float* yk, int ny, int cy,
+                                int edge, int step, float* dst, ptrdiff_t dstride, int ow, int oh, int offx, int offy);
+
 int vwgpu_launch_sepconv(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
                          const float* xk, int nx, int cx, const float* yk, int ny, int cy,
                          int edge, int step, float* dst, ptrdiff_t dstride) {
+  return vwgpu_launch_sepconv_region(ctx, src, w, h, stride, xk, nx, cx, yk, ny, cy, edge, step, dst, dstride,
+                                     1 + (w - 1) / step, 1 + (h - 1) / step, 0, 0);
+}
+
+int vwgpu_launch_sepconv_region(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
+                                const float* xk, int nx, int cx, const float* yk, int ny, int cy,
+                                int edge, int step, float* dst, ptrdiff_t dstride, int ow, int oh, int offx, int offy) {
   if (nx > MAXT || ny > MAXT) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "separable convolution: more than %d taps", MAXT);
   Taps t;
   t.nx = nx; t.ny = ny; t.cx = cx; t.cy = cy;
   for (int i = 0; i < nx; ++i) t.x[i] = xk[i];
   for (int i = 0; i < ny; ++i) t.y[i] = yk[i];
-  const int ow = 1 + (w - 1) / step, oh = 1 + (h - 1) / step;
   const int sw = (TW - 1) * step + 1 + (nx ? nx - 1 : 0), sh = (TH - 1) * step + 1 + (ny ? ny - 1 : 0);
   const size_t shmem = ((size_t)sh * sw + (size_t)sh * TW) * sizeof(float);
   if (shmem > 64 * 1024) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "separable convolution: kernel %dx%d step %d needs %zu B of LDS", nx, ny, step, shmem);
   dim3 grd((ow + TW - 1) / TW, (oh + TH - 1) / TH), blk(256);
   vwgpu_prof_scope ps(ctx, step > 1 ? "sepconv_decimate" : "sepconv");
   if (edge == 1)
-    hipLaunchKernelGGL(sepconv_kernel<1>, grd, blk, shmem, ctx->stream, src, stride, w, h, t, step, dst, dstride, ow, oh, sw, sh);
+    hipLaunchKernelGGL(sepconv_kernel<1>, grd, blk, shmem, ctx->stream, src, stride, w, h, t, step, dst, dstride, ow, oh, sw, sh, offx, offy);
   else
-    hipLaunchKernelGGL(sepconv_kernel<0>, grd, blk, shmem, ctx->stream, src, stride, w, h, t, step, dst, dstride, ow, oh, sw, sh);
+    hipLaunchKernelGGL(sepconv_kernel<0>, grd, blk, shmem, ctx->stream, src, stride, w, h, t, step, dst, dstride, ow, oh, sw, sh, offx, offy);
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }
 
 int vwgpu_launch_conv2d(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
                         const float* k, int kw, int kh, int ci, int cj, int edge, float* dst, ptrdiff_t dstride) {
+  return vwgpu_launch_conv2d_region(ctx, src, w, h, stride, k, kw, kh, ci, cj, edge, dst, dstride, w, h, 0, 0);
+}
+
+int vwgpu_launch_conv2d_region(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
+                               const float* k, int kw, int kh, int ci, int cj, int edge, float* dst, ptrdiff_t dstride,
+                               int ow, int oh, int offx, int offy) {
   if (kw * kh > 49) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "2-D convolution: kernel %dx%d larger than 49 taps", kw, kh);
   Kernel2D kk;
   kk.kw = kw; kk.kh = kh; kk.ci = ci; kk.cj = cj;
   for (int i = 0; i < kw * kh; ++i) kk.k[i] = k[i];
-  dim3 blk(64, 4), grd((w + 63) / 64, (h + 3) / 4);
+  dim3 blk(64, 4), grd((ow + 63) / 64, (oh + 3) / 4);
   vwgpu_prof_scope ps(ctx, "conv2d");
-  if (edge == 1) hipLaunchKernelGGL(conv2d_kernel<1>, grd, blk, 0, ctx->stream, src, stride, w, h, kk, dst, dstride);
-  else hipLaunchKernelGGL(conv2d_kernel<0>, grd, blk, 0, ctx->stream, src, stride, w, h, kk, dst, dstride);
+  if (edge == 1) hipLaunchKernelGGL(conv2d_kernel<1>, grd, blk, 0, ctx->stream, src, stride, w, h, kk, dst, dstride, ow, oh, offx, offy);
+  else hipLaunchKernelGGL(conv2d_kernel<0>, grd, blk, 0, ctx->stream, src, stride, w, h, kk, dst, dstride, ow, oh, offx, offy);
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }
@@ -174,4 +202,35 @@ int vwgpu_launch_subtract(vwgpu_ctx* ctx, const float* a, ptrdiff_t as, const fl
   hipLaunchKernelGGL(subtract_kernel, grd, blk, 0, ctx->stream, a, as, b, bs, w, h, dst, ds);
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
+}
+
+int vwgpu_launch_ext_sub(vwgpu_ctx* ctx, const float* a, ptrdiff_t as, int w, int h, const float* b, ptrdiff_t bs,
+                         float* dst, ptrdiff_t ds, int ow, int oh, int offx, int offy) {
+  dim3 blk(64, 4), grd((ow + 63) / 64, (oh + 3) / 4);
+  vwgpu_prof_scope ps(ctx, "edge_extend_sub");
+  hipLaunchKernelGGL(ext_sub_kernel, grd, blk, 0, ctx->stream, a, as, w, h, b, bs, dst, ds, ow, oh, offx, offy);
+  VWGPU_HIP(ctx, hipGetLastError());
+  return VWGPU_OK;
+}
+
+// prefilter.filter(image) rasterised over the region [x0,x0+bw) x [y0,y0+bh), which may leave the image
+// (ParabolaSubpixelView::prerasterize crops the lazy prefilter views like this, ParabolaSubpixelView.cc:302-327).
+// scratch must hold max(w*h, bw*bh) floats.
+int vwgpu_prefilter_region(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride, int mode, float width,
+                           int x0, int y0, int bw, int bh, float* dst, float* scratch) {
+  if (mode != VWGPU_PREFILTER_LOG && mode != VWGPU_PREFILTER_MEANSUB)
+    return vwgpu_launch_ext_sub(ctx, src, stride, w, h, nullptr, 0, dst, bw, bw, bh, x0, y0);
+  float taps[1024];
+  const int nt = vwgpu_generate_gaussian_kernel((double)width, 0, taps, 1024);
+  if (nt < 0) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "prefilter width %g too large", (double)width);
+  const int c = nt ? (nt - 1) / 2 : 0;
+  if (mode == VWGPU_PREFILTER_MEANSUB) {
+    int rc = vwgpu_launch_sepconv_region(ctx, src, w, h, stride, taps, nt, c, taps, nt, c, 0, 1, scratch, bw, bw, bh, x0, y0);
+    if (rc) return rc;
+    return vwgpu_launch_ext_sub(ctx, src, stride, w, h, scratch, bw, dst, bw, bw, bh, x0, y0);
+  }
+  int rc = vwgpu_launch_sepconv(ctx, src, w, h, stride, taps, nt, c, taps, nt, c, 0, 1, scratch, w);   // gaussian on the image domain
+  if (rc) return rc;
+  const float lap[9] = {0, 1, 0, 1, -4, 1, 0, 1, 0};
+  return vwgpu_launch_conv2d_region(ctx, scratch, w, h, w, lap, 3, 3, 1, 1, 0, dst, bw, bw, bh, x0, y0);
 }

@@ -1,0 +1,128 @@
+// subpixel.hip — parabola sub-pixel refinement (vw::stereo::ParabolaSubpixelView::evaluate,
+// src/vw/Stereo/ParabolaSubpixelView.cc:31-274).
+//
+// For each pixel with integer disparity D the reference gathers the 3x3 patch of SAD costs at D + {-1,0,1}^2
+// (always AbsoluteCost, :49-51; float |a-b| summed in float64 by fast_box_sum and stored as float, :187-205), fits a
+// 2-D parabola with the pre-computed pseudo-inverse (ParabolaSubpixelView.h:83-88) and moves the disparity by
+// ((c*e - 2*b*d)/den, (c*d - 2*a*e)/den), den = 4ab - c^2, if the shift is shorter than 5 px (:242-257).
+// The reference reaches the per-pixel costs through zones of similar disparity (:72-218); the costs themselves are
+// per-pixel quantities, so this kernel computes them directly: one thread per pixel, nine windowed SADs in float64
+// over pre-filtered, pre-cropped rasters (the same `left_raster` / `right_raster` the reference rasterises, :44-45).
+// The float solve below is the reference's expression order with contraction off.
+// Exact on integer-valued imagery with PREFILTER_NONE (all sums exact); after LoG / mean-subtraction the reference's
+// running sums are position dependent and agreement is to float rounding (tests: 1e-5 abs).
+//
+// Roofline: 9*kx*ky abs-diffs per pixel against 36 B of compulsory traffic per pixel (disparity in, two images,
+// disparity out) — VALU / L1 bound; the windows of neighbouring pixels overlap and are served by the vector L1.
+#include <climits>
+
+#include "vwgpu_internal.h"
+
+namespace {
+
+// get_disparity_range over ALL pixels (invalid ones included, src/vw/Stereo/DisparityMap.h:52-66) of the disparity
+// truncated to int (the PixelMask<Vector2f> -> PixelMask<Vector2i> conversion of ParabolaSubpixelView.cc:283).
+__global__ void disparity_range_kernel(const float* __restrict__ d, int w, int h, ptrdiff_t stride_px, int* __restrict__ out4) {
+  int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
+  for (int y = blockIdx.y * blockDim.y + threadIdx.y; y < h; y += gridDim.y * blockDim.y)
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) {
+      const float* p = d + ((ptrdiff_t)y * stride_px + x) * 3;
+      const int dx = (int)p[0], dy = (int)p[1];
+      mnx = min(mnx, dx); mxx = max(mxx, dx); mny = min(mny, dy); mxy = max(mxy, dy);
+    }
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = min(mnx, __shfl_xor(mnx, o)); mny = min(mny, __shfl_xor(mny, o));
+    mxx = max(mxx, __shfl_xor(mxx, o)); mxy = max(mxy, __shfl_xor(mxy, o));
+  }
+  if (((threadIdx.y * blockDim.x + threadIdx.x) & 63) == 0) {
+    atomicMin(out4 + 0, mnx); atomicMin(out4 + 1, mny); atomicMax(out4 + 2, mxx); atomicMax(out4 + 3, mxy);
+  }
+}
+
+__global__ void range_init_kernel(int* out4) { out4[0] = out4[1] = INT_MAX; out4[2] = out4[3] = INT_MIN; }
+
+__global__ void __launch_bounds__(256)
+parabola_kernel(const float* __restrict__ disp, int w, int h, ptrdiff_t dstride_px,
+                const float* __restrict__ lras, int lrw, const float* __restrict__ rras, int rrw,
+                int range_minx, int range_miny, int kx, int ky,
+                float* __restrict__ out, ptrdiff_t ostride_px) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const float* dp = disp + ((ptrdiff_t)y * dstride_px + x) * 3;
+  float* op = out + ((ptrdiff_t)y * ostride_px + x) * 3;
+  if (dp[2] == 0.0f) { op[0] = 0.0f; op[1] = 0.0f; op[2] = 0.0f; return; }   // PixelMask<Vector2f>()  (:262-264)
+  const int Dx = (int)dp[0], Dy = (int)dp[1];
+
+  // patch[(dy+1)*3 + (dx+1)] = cost at D + (dx,dy)   (:187-205)
+  float patch[9];
+  const float* lbase = lras + (ptrdiff_t)y * lrw + x;   // left_region starts at (-hx,-hy): window top-left == (x,y)
+#pragma unroll
+  for (int ddy = -1; ddy <= 1; ++ddy) {
+#pragma unroll
+    for (int ddx = -1; ddx <= 1; ++ddx) {
+      const float* rbase = rras + (ptrdiff_t)(y + Dy + ddy - range_miny) * rrw + (x + Dx + ddx - range_minx);
+      double s = 0.0;
+      for (int j = 0; j < ky; ++j) {
+        const float* lp = lbase + (ptrdiff_t)j * lrw;
+        const float* rp = rbase + (ptrdiff_t)j * rrw;
+        for (int i = 0; i < kx; ++i) s += (double)fabsf(lp[i] - rp[i]);
+      }
+      patch[(ddy + 1) * 3 + (ddx + 1)] = (float)s;
+    }
+  }
+
+  float rx = (float)Dx, ry = (float)Dy;
+  bool all_equal = true;
+#pragma unroll
+  for (int c = 1; c < 9; ++c) all_equal = all_equal && (patch[c] == patch[c - 1]);
+  if (!all_equal) {                                      // std::equal guard (:236-237)
+    // pinvA rows a..f (ParabolaSubpixelView.h:83-88), float values of the double literals
+    const float s6 = (float)(1.0 / 6), t3 = (float)(-1.0 / 3), q4 = (float)(1.0 / 4), n4 = (float)(-1.0 / 4), n6 = (float)(-1.0 / 6);
+    const float A[6][9] = {
+        {s6, t3, s6, s6, t3, s6, s6, t3, s6},
+        {s6, s6, s6, t3, t3, t3, s6, s6, s6},
+        {q4, 0.0f, n4, 0.0f, 0.0f, 0.0f, n4, 0.0f, q4},
+        {n6, 0.0f, s6, n6, 0.0f, s6, n6, 0.0f, s6},
+        {n6, n6, n6, 0.0f, 0.0f, 0.0f, s6, s6, s6},
+        {(float)(-1.0 / 9), (float)(2.0 / 9), (float)(-1.0 / 9), (float)(2.0 / 9), (float)(5.0 / 9), (float)(2.0 / 9),
+         (float)(-1.0 / 9), (float)(2.0 / 9), (float)(-1.0 / 9)}};
+    float xv[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {                        // Matrix<float,6,9> * Vector<float,9>: sequential dot_prod
+      float acc = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) acc += A[r][c] * patch[c];
+      xv[r] = acc;
+    }
+    const float denom = 4 * xv[0] * xv[1] - (xv[2] * xv[2]);                 // 4ab - c^2  (:250)
+    const float ox = (xv[2] * xv[4] - 2 * xv[1] * xv[3]) / denom;             // (:251)
+    const float oy = (xv[2] * xv[3] - 2 * xv[0] * xv[4]) / denom;             // (:252)
+    double n2 = 0.0;                                                         // norm_2 (src/vw/Math/Vector.h:1591-1604)
+    n2 += ox * ox;
+    n2 += oy * oy;
+    if (sqrt((double)(float)n2) < 5.0f) { rx += ox; ry += oy; }              // MAX_SUBPIXEL_SHIFT (:253-257)
+  }
+  op[0] = rx; op[1] = ry; op[2] = 1.0f;
+}
+
+}  // namespace
+
+int vwgpu_launch_disparity_range(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t stride_px, int* d_out4) {
+  hipLaunchKernelGGL(range_init_kernel, dim3(1), dim3(1), 0, ctx->stream, d_out4);
+  dim3 blk(64, 4), grd(std::min((w + 63) / 64, 64), std::min((h + 3) / 4, 64));
+  vwgpu_prof_scope ps(ctx, "disparity_range");
+  hipLaunchKernelGGL(disparity_range_kernel, grd, blk, 0, ctx->stream, disp3f, w, h, stride_px, d_out4);
+  VWGPU_HIP(ctx, hipGetLastError());
+  return VWGPU_OK;
+}
+
+int vwgpu_launch_parabola(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t dstride_px,
+                          const float* lras, int lrw, const float* rras, int rrw, int range_minx, int range_miny,
+                          int kx, int ky, float* out3f, ptrdiff_t ostride_px) {
+  dim3 blk(64, 4), grd((w + 63) / 64, (h + 3) / 4);
+  vwgpu_prof_scope ps(ctx, "parabola_subpixel");
+  hipLaunchKernelGGL(parabola_kernel, grd, blk, 0, ctx->stream, disp3f, w, h, dstride_px, lras, lrw, rras, rrw,
+                     range_minx, range_miny, kx, ky, out3f, ostride_px);
+  VWGPU_HIP(ctx, hipGetLastError());
+  return VWGPU_OK;
+}

@@ -88,6 +88,7 @@ void vwgpu_destroy(vwgpu_ctx* ctx) {
   if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
   if (ctx->flags.base) (void)hipFree(ctx->flags.base);
   if (ctx->filt.base) (void)hipFree(ctx->filt.base);
+  if (ctx->misc.base) (void)hipFree(ctx->misc.base);
   if (ctx->staging.base) (void)hipFree(ctx->staging.base);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;

@@ -1,4 +1,5 @@
 // vwgpu_filters_abi.hip — extern "C" entry points of the pyramid / prefilter family (include/vwgpu.h).
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -188,6 +189,89 @@ int vwgpu_prefilter_image(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdif
   return staged<float>(ctx, src, w, h, stride, dst, w, h, dstride, [&](float* ds, float* dd) {
     return vwgpu_prefilter_image_dev(ctx, ds, w, h, w, mode, width, dd, w);
   });
+}
+
+
+// ---- parabola sub-pixel -------------------------------------------------------------------------------------
+
+int vwgpu_parabola_subpixel_dev(vwgpu_ctx* ctx, const float* d_disp, int w, int h, ptrdiff_t dstride,
+                                const float* d_left, ptrdiff_t lstride,
+                                const float* d_right, int rw, int rh, ptrdiff_t rstride,
+                                int mode, float width, int kx, int ky, float* d_out, ptrdiff_t ostride) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  ctx->err.clear();
+  if (!d_disp || !d_left || !d_right || !d_out || w <= 0 || h <= 0 || rw <= 0 || rh <= 0)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "parabola_subpixel: empty image or null pointer");
+  if (kx < 1 || ky < 1 || kx % 2 != 1 || ky % 2 != 1)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "parabola_subpixel: Kernel input not sized with odd values.");
+  if (dstride == 0) dstride = w;
+  if (ostride == 0) ostride = w;
+  if (lstride == 0) lstride = w;
+  if (rstride == 0) rstride = rw;
+  if (dstride < w || ostride < w || lstride < w || rstride < rw)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "parabola_subpixel: row stride smaller than row width");
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+
+  // entire_search_range = [min, max+1) expanded by 1 over the whole tile (ParabolaSubpixelView.cc:287-290)
+  int rc = vwgpu_arena_reserve(ctx, &ctx->misc, 256);
+  if (rc) return rc;
+  int* d_range = static_cast<int*>(ctx->misc.base);
+  rc = vwgpu_launch_disparity_range(ctx, d_disp, w, h, dstride, d_range);
+  if (rc) return rc;
+  int r4[4];
+  VWGPU_HIP(ctx, hipMemcpyAsync(r4, d_range, sizeof r4, hipMemcpyDeviceToHost, ctx->stream));
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));              // the ROI sizes depend on the data
+  const long long rminx = (long long)r4[0] - 1, rminy = (long long)r4[1] - 1;
+  const long long rsx = (long long)r4[2] + 1 - r4[0] + 2, rsy = (long long)r4[3] + 1 - r4[1] + 2;
+  if (rsx > 8192 || rsy > 8192 || rminx < -(1 << 20) || rminx > (1 << 20) || rminy < -(1 << 20) || rminy > (1 << 20))
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "parabola_subpixel: disparity range [%d,%d]x[%d,%d] is not plausible", r4[0], r4[2], r4[1], r4[3]);
+  const int hx = kx / 2, hy = ky / 2;
+  // left_region = bbox -/+ half_kernel; right_region = left_region + range.min, max += range.size  (:293-298)
+  const int lrw = w + 2 * hx, lrh = h + 2 * hy;
+  const int rrw = lrw + (int)rsx, rrh = lrh + (int)rsy;
+  const size_t lb = vwgpu_align_up((size_t)lrw * lrh * 4, 256), rb = vwgpu_align_up((size_t)rrw * rrh * 4, 256);
+  const size_t sb = vwgpu_align_up(std::max({(size_t)lrw * lrh, (size_t)rrw * rrh, (size_t)w * h, (size_t)rw * rh}) * 4, 256);
+  rc = vwgpu_arena_reserve(ctx, &ctx->filt, lb + rb + sb);
+  if (rc) return rc;
+  char* base = static_cast<char*>(ctx->filt.base);
+  float* lras = reinterpret_cast<float*>(base);
+  float* rras = reinterpret_cast<float*>(base + lb);
+  float* scratch = reinterpret_cast<float*>(base + lb + rb);
+  rc = vwgpu_prefilter_region(ctx, d_left, w, h, lstride, mode, width, -hx, -hy, lrw, lrh, lras, scratch);
+  if (rc) return rc;
+  rc = vwgpu_prefilter_region(ctx, d_right, rw, rh, rstride, mode, width, -hx + (int)rminx, -hy + (int)rminy, rrw, rrh, rras, scratch);
+  if (rc) return rc;
+  return vwgpu_launch_parabola(ctx, d_disp, w, h, dstride, lras, lrw, rras, rrw, (int)rminx, (int)rminy, kx, ky, d_out, ostride);
+}
+
+int vwgpu_parabola_subpixel(vwgpu_ctx* ctx, const float* disp, int w, int h, ptrdiff_t dstride,
+                            const float* left, ptrdiff_t lstride, const float* right, int rw, int rh, ptrdiff_t rstride,
+                            int mode, float width, int kx, int ky, float* out, ptrdiff_t ostride) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  if (!disp || !left || !right || !out || w <= 0 || h <= 0 || rw <= 0 || rh <= 0)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "parabola_subpixel: empty image or null pointer");
+  if (dstride == 0) dstride = w;
+  if (ostride == 0) ostride = w;
+  if (lstride == 0) lstride = w;
+  if (rstride == 0) rstride = rw;
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t db = vwgpu_align_up((size_t)w * h * 12, 256), lb = vwgpu_align_up((size_t)w * h * 4, 256),
+               rb = vwgpu_align_up((size_t)rw * rh * 4, 256);
+  int rc = vwgpu_arena_reserve(ctx, &ctx->staging, 2 * db + lb + rb);
+  if (rc) return rc;
+  char* base = static_cast<char*>(ctx->staging.base);
+  float* d_d = reinterpret_cast<float*>(base);
+  float* d_o = reinterpret_cast<float*>(base + db);
+  float* d_l = reinterpret_cast<float*>(base + 2 * db);
+  float* d_r = reinterpret_cast<float*>(base + 2 * db + lb);
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_d, (size_t)w * 12, disp, (size_t)dstride * 12, (size_t)w * 12, h, hipMemcpyHostToDevice, ctx->stream));
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_l, (size_t)w * 4, left, (size_t)lstride * 4, (size_t)w * 4, h, hipMemcpyHostToDevice, ctx->stream));
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_r, (size_t)rw * 4, right, (size_t)rstride * 4, (size_t)rw * 4, rh, hipMemcpyHostToDevice, ctx->stream));
+  rc = vwgpu_parabola_subpixel_dev(ctx, d_d, w, h, w, d_l, w, d_r, rw, rh, rw, mode, width, kx, ky, d_o, w);
+  if (rc) return rc;
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(out, (size_t)ostride * 12, d_o, (size_t)w * 12, (size_t)w * 12, h, hipMemcpyDeviceToHost, ctx->stream));
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VWGPU_OK;
 }
 
 }  // extern "C"

@@ -40,6 +40,7 @@ struct vwgpu_ctx {
   int* last_flag = nullptr;
   vwgpu_arena staging;   // device copies of host images for the host-pointer entry points
   vwgpu_arena filt;      // intermediate image of composite filters (prefilter_image)
+  vwgpu_arena misc;      // small device words (disparity range of parabola_subpixel)
   int num_cu = 256;
 };
 
@@ -102,3 +103,20 @@ int vwgpu_launch_mask_by_two(vwgpu_ctx* ctx, const uint8_t* src, int w, int h, p
                              uint8_t* dst, ptrdiff_t dstride);
 int vwgpu_launch_subtract(vwgpu_ctx* ctx, const float* a, ptrdiff_t as, const float* b, ptrdiff_t bs, int w, int h,
                           float* dst, ptrdiff_t ds);
+int vwgpu_launch_sepconv_region(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
+                                const float* xk, int nx, int cx, const float* yk, int ny, int cy,
+                                int edge, int step, float* dst, ptrdiff_t dstride, int ow, int oh, int offx, int offy);
+int vwgpu_launch_conv2d_region(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
+                               const float* k, int kw, int kh, int ci, int cj, int edge, float* dst, ptrdiff_t dstride,
+                               int ow, int oh, int offx, int offy);
+int vwgpu_launch_ext_sub(vwgpu_ctx* ctx, const float* a, ptrdiff_t as, int w, int h, const float* b, ptrdiff_t bs,
+                         float* dst, ptrdiff_t ds, int ow, int oh, int offx, int offy);
+int vwgpu_prefilter_region(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride, int mode, float width,
+                           int x0, int y0, int bw, int bh, float* dst, float* scratch);
+extern "C" int vwgpu_generate_gaussian_kernel(double sigma, int size, float* taps, int cap);
+
+// subpixel.hip
+int vwgpu_launch_disparity_range(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t stride_px, int* d_out4);
+int vwgpu_launch_parabola(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t dstride_px,
+                          const float* lras, int lrw, const float* rras, int rrw, int range_minx, int range_miny,
+                          int kx, int ky, float* out3f, ptrdiff_t ostride_px);

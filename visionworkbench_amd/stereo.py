@@ -104,4 +104,34 @@ def cross_corr_consistency_check(l2r, r2l, cross_corr_threshold, ctx=None):
     return l2r
 
 
-__all__ = ["calc_disparity", "cross_corr_consistency_check", "BBox2i", "CostFunctionType"]
+def parabola_subpixel(disparity, left_image, right_image, prefilter_mode, prefilter_width, kernel_size, ctx=None):
+    """vw::stereo::parabola_subpixel (src/vw/Stereo/ParabolaSubpixelView.h:112-117) rasterised over the whole image.
+
+    disparity: (rows, cols, 3) float32 PixelMask<Vector2f> {dx, dy, valid}; same rows/cols as left_image (the
+    reference asserts this, ParabolaSubpixelView.h:67-69).  Returns the refined disparity in the same layout."""
+    kx, ky = int(kernel_size[0]), int(kernel_size[1])
+    if disparity.ndim != 3 or disparity.shape[2] != 3 or tuple(disparity.shape[:2]) != tuple(left_image.shape):
+        raise ArgumentErr("SubpixelView: Disparity image must match left image.")
+    h, w = left_image.shape
+    rh, rw = right_image.shape
+    ctx = _ctx_for(left_image, ctx)
+    lib = ctx._lib
+    if _is_tensor(left_image):
+        d, l, r = disparity.contiguous(), left_image.contiguous(), right_image.contiguous()
+        if not (d.is_cuda and l.is_cuda and r.is_cuda) or d.dtype != torch.float32:
+            raise ArgumentErr("parabola_subpixel: float32 CUDA tensors required")
+        out = torch.empty_like(d)
+        ctx.set_stream(torch.cuda.current_stream(l.device).cuda_stream)
+        ctx.check(lib.vwgpu_parabola_subpixel_dev(ctx._h, d.data_ptr(), w, h, 0, l.data_ptr(), 0, r.data_ptr(), rw, rh, 0,
+                                                  int(prefilter_mode), float(prefilter_width), kx, ky, out.data_ptr(), 0))
+        return out
+    d = np.ascontiguousarray(disparity, np.float32)
+    l = np.ascontiguousarray(left_image, np.float32)
+    r = np.ascontiguousarray(right_image, np.float32)
+    out = np.empty_like(d)
+    ctx.check(lib.vwgpu_parabola_subpixel(ctx._h, d.ctypes.data, w, h, 0, l.ctypes.data, 0, r.ctypes.data, rw, rh, 0,
+                                          int(prefilter_mode), float(prefilter_width), kx, ky, out.ctypes.data, 0))
+    return out
+
+
+__all__ = ["calc_disparity", "cross_corr_consistency_check", "parabola_subpixel", "BBox2i", "CostFunctionType"]
