@@ -206,6 +206,63 @@ int vwgpu_parabola_subpixel(vwgpu_ctx* ctx, const float* disp, int w, int h, ptr
                             int prefilter_mode, float prefilter_width, int kx, int ky,
                             float* out, ptrdiff_t ostride);
 
+/* ---- disparity clean-up filters and the zone scheduler ------------------------------------------------- */
+
+/* Replaces rasterising vw::stereo::rm_outliers_using_thresh (cleanup == 0) or
+ * vw::stereo::disparity_cleanup_using_thresh (cleanup != 0: a second pass with the hard-coded (1,1,3.0,0.20))
+ * over a whole PixelMask<Vector2i> image (src/vw/Stereo/DisparityMap.h:318-441).  src and dst must not alias;
+ * strides are dense (w pixels). */
+int vwgpu_disparity_filter_dev(vwgpu_ctx* ctx, const int32_t* d_src, int w, int h, int half_h_kernel, int half_v_kernel,
+                               double pixel_threshold, double rejection_threshold, int cleanup, int32_t* d_dst);
+int vwgpu_disparity_filter(vwgpu_ctx* ctx, const int32_t* src, int w, int h, int half_h_kernel, int half_v_kernel,
+                           double pixel_threshold, double rejection_threshold, int cleanup, int32_t* dst);
+/* Replaces rasterising vw::stereo::disparity_mask(disparity, left_mask, right_mask)
+ * (src/vw/Stereo/DisparityMap.h:97-253), in place; the left mask has the disparity's size. */
+int vwgpu_disparity_mask_dev(vwgpu_ctx* ctx, int32_t* d_disp, int w, int h, const uint8_t* d_left_mask,
+                             const uint8_t* d_right_mask, int rmw, int rmh);
+int vwgpu_disparity_mask(vwgpu_ctx* ctx, int32_t* disp, int w, int h, const uint8_t* left_mask,
+                         const uint8_t* right_mask, int rmw, int rmh);
+/* Replaces vw::stereo::subdivide_regions(disparity, bounding_box(disparity), list, kernel_size)
+ * (src/vw/Stereo/Correlation.cc:139-328).  Host logic on a HOST disparity image; each zone is 8 ints
+ * {region.min.x, region.min.y, region.max.x, region.max.y, range.min.x, range.min.y, range.max.x, range.max.y}.
+ * Returns the number of zones found (only `cap` are written) or a negative vwgpu_status. */
+int vwgpu_subdivide_regions(const int32_t* disp, int w, int h, int kx, int ky, int32_t* zones, int cap);
+
+/* ---- pyramid block matching -------------------------------------------------------------------------- */
+
+/* Arguments of vw::stereo::pyramid_correlate (src/vw/Stereo/CorrelationView.h:195-230) that steer one tile. */
+typedef struct vwgpu_pyramid_params {
+  int prefilter_mode;            /* vwgpu_prefilter */
+  float prefilter_width;
+  int search_min_x, search_min_y, search_max_x, search_max_y;   /* BBox2i search_region, half open */
+  int kernel_x, kernel_y;
+  int cost_type;                 /* vwgpu_cost_type */
+  int corr_timeout;              /* seconds; 0 = none.  Uses the reference's estimate seconds_per_op * search volume */
+  double seconds_per_op;
+  float consistency_threshold;   /* < 0: no L/R check */
+  int min_consistency_level;     /* accepted for signature parity; block matching checks at level 0 only */
+  int filter_half_kernel;        /* 0: no clean-up filtering */
+  int max_pyramid_levels;
+  int algorithm;                 /* 0 = VW_CORRELATION_BM; SGM/MGM answer VWGPU_ERR_NOIMPL for now */
+  int blob_filter_area;          /* must be 0 for now */
+} vwgpu_pyramid_params;
+
+/* Replaces PyramidCorrelationView::prerasterize(bbox) for VW_CORRELATION_BM (src/vw/Stereo/CorrelationView.cc:273-886):
+ * one output tile [bx,bx+bw) x [by,by+bh) of pyramid_correlate(left, right, left_mask, right_mask, ...).
+ * Masks may be NULL (everything valid); out is bw x bh x {dx, dy, valid} float (PixelMask<Vector2f>), ostride in pixels. */
+int vwgpu_pyramid_correlate_dev(vwgpu_ctx* ctx, const float* d_left, int lw, int lh, ptrdiff_t lstride,
+                                const float* d_right, int rw, int rh, ptrdiff_t rstride,
+                                const uint8_t* d_left_mask, ptrdiff_t lmstride,
+                                const uint8_t* d_right_mask, ptrdiff_t rmstride,
+                                const vwgpu_pyramid_params* params, int bx, int by, int bw, int bh,
+                                float* d_out, ptrdiff_t ostride);
+int vwgpu_pyramid_correlate(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t lstride,
+                            const float* right, int rw, int rh, ptrdiff_t rstride,
+                            const uint8_t* left_mask, ptrdiff_t lmstride,
+                            const uint8_t* right_mask, ptrdiff_t rmstride,
+                            const vwgpu_pyramid_params* params, int bx, int by, int bw, int bh,
+                            float* out, ptrdiff_t ostride);
+
 #ifdef __cplusplus
 }
 #endif

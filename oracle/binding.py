@@ -19,7 +19,8 @@ __all__ = ["build", "lib", "fast_box_sum", "cost_image", "calc_disparity", "calc
            "CROSS_CORRELATION", "VALID", "generate_gaussian_kernel", "separable_convolution", "convolution_2d",
            "subsample_mask_by_two", "prefilter_image", "pyramid_smoothing_kernel",
            "EDGE_CONSTANT", "EDGE_ZERO", "PREFILTER_NONE", "PREFILTER_MEANSUB", "PREFILTER_LOG",
-           "subdivide_regions", "prefilter_region", "parabola_subpixel"]
+           "subdivide_regions", "prefilter_region", "parabola_subpixel", "pyramid_correlate", "disparity_filter",
+           "disparity_mask"]
 
 
 def build(force=False):
@@ -53,6 +54,9 @@ def lib():
         _LIB.vwo_subdivide_regions.argtypes = [P, I, I, I, I, P, I]
         _LIB.vwo_prefilter_region.argtypes = [P, I, I, I, F, I, I, I, I, P]
         _LIB.vwo_parabola_subpixel.argtypes = [P, I, I, P, P, I, I, I, F, I, I, P]
+        _LIB.vwo_pyramid_correlate.argtypes = [P, I, I, P, I, I, P, P, I, F, I, I, I, I, I, I, I, I, D, F, I, I, I, I, I, I, P]
+        _LIB.vwo_disparity_filter.argtypes = [P, I, I, I, I, D, D, I]
+        _LIB.vwo_disparity_mask.argtypes = [P, I, I, P, P, I, I]
     return _LIB
 
 
@@ -222,3 +226,41 @@ def parabola_subpixel(disparity, left, right, prefilter_mode, prefilter_width, k
                                      float(prefilter_width), kernel[0], kernel[1], _p(out))
     assert rc == 0
     return out
+
+
+def pyramid_correlate(left, right, left_mask, right_mask, prefilter_mode, prefilter_width, search_region, kernel_size,
+                      cost_type, corr_timeout, seconds_per_op, consistency_threshold, filter_half_kernel,
+                      max_pyramid_levels, bbox=None):
+    """One tile of pyramid_correlate(..., VW_CORRELATION_BM) rasterised over bbox = (x, y, w, h) (default: whole left
+    image).  search_region = (minx, miny, maxx, maxy), half-open.  Returns (h, w, 3) float32 PixelMask<Vector2f>."""
+    l = np.ascontiguousarray(left, np.float32)
+    r = np.ascontiguousarray(right, np.float32)
+    lm = None if left_mask is None else np.ascontiguousarray(left_mask, np.uint8)
+    rm = None if right_mask is None else np.ascontiguousarray(right_mask, np.uint8)
+    if bbox is None:
+        bbox = (0, 0, l.shape[1], l.shape[0])
+    out = np.zeros((bbox[3], bbox[2], 3), np.float32)
+    rc = lib().vwo_pyramid_correlate(_p(l), l.shape[1], l.shape[0], _p(r), r.shape[1], r.shape[0],
+                                     None if lm is None else _p(lm), None if rm is None else _p(rm),
+                                     int(prefilter_mode), float(prefilter_width),
+                                     search_region[0], search_region[1], search_region[2], search_region[3],
+                                     kernel_size[0], kernel_size[1], int(cost_type), int(corr_timeout), float(seconds_per_op),
+                                     float(consistency_threshold), int(filter_half_kernel), int(max_pyramid_levels),
+                                     bbox[0], bbox[1], bbox[2], bbox[3], _p(out))
+    if rc:
+        raise ValueError("vwo_pyramid_correlate rc=%d" % rc)
+    return out
+
+
+def disparity_filter(disp, half_h, half_v, pixel_thr, rej_thr, cleanup):
+    d = np.ascontiguousarray(disp, np.int32).copy()
+    assert lib().vwo_disparity_filter(_p(d), d.shape[1], d.shape[0], half_h, half_v, pixel_thr, rej_thr, int(cleanup)) == 0
+    return d
+
+
+def disparity_mask(disp, left_mask, right_mask):
+    d = np.ascontiguousarray(disp, np.int32).copy()
+    lm = np.ascontiguousarray(left_mask, np.uint8)
+    rm = np.ascontiguousarray(right_mask, np.uint8)
+    assert lib().vwo_disparity_mask(_p(d), d.shape[1], d.shape[0], _p(lm), _p(rm), rm.shape[1], rm.shape[0]) == 0
+    return d

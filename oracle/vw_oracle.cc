@@ -438,7 +438,7 @@ struct Box {
   void grow_pt(int x, int y) { if (x > maxx) maxx = x; if (x < minx) minx = x; if (y > maxy) maxy = y; if (y < miny) miny = y; }
   void grow(Box const& b) { if (b.empty()) return; grow_pt(b.minx, b.miny); grow_pt(b.maxx, b.maxy); }
   void crop(Box const& b) { if (minx < b.minx) minx = b.minx; if (maxx > b.maxx) maxx = b.maxx; if (miny < b.miny) miny = b.miny; if (maxy > b.maxy) maxy = b.maxy; }
-  void expand(int n) { minx -= n; miny -= n; maxx += n; maxy += n; }   // BBox::expand (no empty() guard in the reference)
+  void expand(int n) { if (empty()) return; minx -= n; miny -= n; maxx += n; maxy += n; }   // BBox::expand (BBox.tcc:228-234)
   bool operator==(Box const& o) const { return minx == o.minx && miny == o.miny && maxx == o.maxx && maxy == o.maxy; }
   bool operator!=(Box const& o) const { return !(*this == o); }
 };
@@ -704,6 +704,268 @@ int vwo_parabola_subpixel(const float* disp3f, int w, int h, const float* left, 
     // the vector's value type (src/vw/Math/Vector.h:1591-1604)
     double n2 = 0.0; n2 += ox * ox; n2 += oy * oy;
     if (std::sqrt((double)(float)n2) < MAX_SUBPIXEL_SHIFT) { o[0] = (float)idisp[3*i] + ox; o[1] = (float)idisp[3*i+1] + oy; }
+  }
+  return 0;
+}
+
+}  // extern "C"
+
+// ---- pyramid block matching -------------------------------------------------------------------------------------
+
+namespace {
+
+const int32_t kValid = std::numeric_limits<int32_t>::max();
+
+// RmOutliersUsingThreshFunc evaluated at any integer position of the edge-extended (Constant) disparity image
+// (src/vw/Stereo/DisparityMap.h:357-385).
+struct DispImg {
+  const int32_t* d; int w, h;
+  const int32_t* at(int x, int y) const {
+    x = x < 0 ? 0 : (x >= w ? w - 1 : x);
+    y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+    return d + ((size_t)y * w + x) * 3;
+  }
+};
+inline void rm_outliers_at(DispImg const& im, int x, int y, int hh, int hv, double pthr, double rthr, int32_t out[3]) {
+  const int32_t* c = im.at(x, y);
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2];
+  if (!c[2]) return;
+  int matched = 0, total = 0;
+  for (int yk = -hv; yk <= hv; ++yk)
+    for (int xk = -hh; xk <= hh; ++xk) {
+      const int32_t* n = im.at(x + xk, y + yk);
+      if (n[2] && std::fabs((double)(c[0] - n[0])) <= pthr && std::fabs((double)(c[1] - n[1])) <= pthr) matched++;
+      total++;
+    }
+  if (((double)matched / (double)total) < rthr) { out[0] = out[1] = out[2] = 0; }   // invalid pixel (PixelMask())
+}
+
+void disparity_filter(std::vector<int32_t>& disp, int w, int h, int hh, int hv, double pthr, double rthr, bool cleanup) {
+  DispImg im{disp.data(), w, h};
+  if (!cleanup) {                                    // rm_outliers_using_thresh (:409-419)
+    std::vector<int32_t> out((size_t)w * h * 3);
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) rm_outliers_at(im, x, y, hh, hv, pthr, rthr, &out[((size_t)y * w + x) * 3]);
+    disp.swap(out);
+    return;
+  }
+  // disparity_cleanup_using_thresh (:427-441): the outer functor (1,1,3.0,0.20) reads the INNER VIEW, also at
+  // positions outside the image (the inner view is defined there through its edge-extended child).
+  const int pw = w + 2, ph = h + 2;
+  std::vector<int32_t> inner((size_t)pw * ph * 3);
+  for (int y = -1; y <= h; ++y) for (int x = -1; x <= w; ++x)
+    rm_outliers_at(im, x, y, hh, hv, pthr, rthr, &inner[((size_t)(y + 1) * pw + (x + 1)) * 3]);
+  std::vector<int32_t> out((size_t)w * h * 3);
+  for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+    const int32_t* c = &inner[((size_t)(y + 1) * pw + (x + 1)) * 3];
+    int32_t* o = &out[((size_t)y * w + x) * 3];
+    o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
+    if (!c[2]) continue;
+    int matched = 0, total = 0;
+    for (int yk = -1; yk <= 1; ++yk) for (int xk = -1; xk <= 1; ++xk) {
+      const int32_t* n = &inner[((size_t)(y + 1 + yk) * pw + (x + 1 + xk)) * 3];
+      if (n[2] && std::fabs((double)(c[0] - n[0])) <= 3.0 && std::fabs((double)(c[1] - n[1])) <= 3.0) matched++;
+      total++;
+    }
+    if (((double)matched / (double)total) < 0.20) { o[0] = o[1] = o[2] = 0; }
+  }
+  disp.swap(out);
+}
+
+// DisparityMaskView::operator() (src/vw/Stereo/DisparityMap.h:132-155)
+void disparity_mask(std::vector<int32_t>& disp, int w, int h, const uint8_t* m1, const uint8_t* m2, int m2w, int m2h) {
+  for (int j = 0; j < h; ++j) for (int i = 0; i < w; ++i) {
+    int32_t* p = &disp[((size_t)j * w + i) * 3];
+    bool keep = m1[(size_t)j * w + i] != 0 && p[2] != 0;
+    if (keep) {
+      const int x = i + p[0], y = j + p[1];
+      keep = !(x < 0 || x >= m2w || y < 0 || y >= m2h || m2[(size_t)y * m2w + x] == 0);
+    }
+    if (!keep) { p[0] = p[1] = p[2] = 0; }
+  }
+}
+
+template <class T>
+std::vector<T> crop_ext(const T* src, int w, int h, Box const& b, int edge) {
+  std::vector<T> out((size_t)b.sizex() * b.sizey());
+  for (int y = 0; y < b.sizey(); ++y) for (int x = 0; x < b.sizex(); ++x)
+    out[(size_t)y * b.sizex() + x] = ext_at(src, w, h, b.minx + x, b.miny + y, edge);
+  return out;
+}
+
+struct FImg { std::vector<float> d; int w = 0, h = 0; };
+struct MImg { std::vector<uint8_t> d; int w = 0, h = 0; };
+
+}  // namespace
+
+extern "C" {
+
+int vwo_disparity_filter(int32_t* disp3, int w, int h, int half_h, int half_v, double pixel_thr, double rej_thr, int cleanup) {
+  std::vector<int32_t> d(disp3, disp3 + (size_t)w * h * 3);
+  disparity_filter(d, w, h, half_h, half_v, pixel_thr, rej_thr, cleanup != 0);
+  std::memcpy(disp3, d.data(), d.size() * sizeof(int32_t));
+  return 0;
+}
+
+int vwo_disparity_mask(int32_t* disp3, int w, int h, const uint8_t* lmask, const uint8_t* rmask, int rmw, int rmh) {
+  std::vector<int32_t> d(disp3, disp3 + (size_t)w * h * 3);
+  disparity_mask(d, w, h, lmask, rmask, rmw, rmh);
+  std::memcpy(disp3, d.data(), d.size() * sizeof(int32_t));
+  return 0;
+}
+
+int vwo_pyramid_correlate(const float* left, int lw, int lh, const float* right, int rw, int rh,
+                          const uint8_t* lmask_in, const uint8_t* rmask_in,
+                          int prefilter_mode, float prefilter_width,
+                          int sminx, int sminy, int smaxx, int smaxy, int kx, int ky, int cost_type,
+                          int corr_timeout, double seconds_per_op, float consistency_threshold,
+                          int filter_half_kernel, int max_pyramid_levels_arg,
+                          int bx, int by, int bw, int bh, float* out3f) {
+  if (kx % 2 != 1 || ky % 2 != 1 || bw <= 0 || bh <= 0) return -1;
+  const Box search(sminx, sminy, smaxx, smaxy);
+  const Box bbox = Box::xywh(bx, by, bw, bh);
+  std::vector<uint8_t> lm_all, rm_all;
+  if (!lmask_in) { lm_all.assign((size_t)lw * lh, 255); lmask_in = lm_all.data(); }
+  if (!rmask_in) { rm_all.assign((size_t)rw * rh, 255); rmask_in = rm_all.data(); }
+
+  // constructor: m_max_level_by_search (CorrelationView.h:99-105)
+  const int largest_search = std::max(search.sizex(), search.sizey());
+  int max_level_by_search = (int)(std::floor(std::log(float(largest_search)) / std::log(2.0f)) - 1);
+  if (max_level_by_search > max_pyramid_levels_arg) max_level_by_search = max_pyramid_levels_arg;
+  if (max_level_by_search < 0) max_level_by_search = 0;
+  // 1.0) number of levels (CorrelationView.cc:301-310)
+  const int smallest_bbox = std::min(bw, bh), largest_kernel = std::max(kx, ky);
+  int L = (int)std::floor(std::log((double)smallest_bbox) / std::log(2.0f) - std::log((double)largest_kernel) / std::log(2.0f));
+  if (max_level_by_search < L) L = max_level_by_search;
+  if (L < 1) L = 0;
+  const int hkx = kx / 2, hky = ky / 2;
+  const int max_upscaling = 1 << L;
+  for (size_t i = 0; i < (size_t)bw * bh * 3; ++i) out3f[i] = 0.0f;
+
+  // 2.0) build_image_pyramids (:67-239)
+  std::vector<FImg> lp(L + 1), rp(L + 1);
+  std::vector<MImg> lmp(L + 1), rmp(L + 1);
+  {
+    Box lg = bbox; lg.minx -= hkx * max_upscaling; lg.maxx += hkx * max_upscaling; lg.miny -= hky * max_upscaling; lg.maxy += hky * max_upscaling;
+    Box rg(lg.minx + search.minx, lg.miny + search.miny, lg.maxx + search.minx + search.sizex(), lg.maxy + search.miny + search.sizey());
+    lp[0].w = lg.sizex(); lp[0].h = lg.sizey(); lp[0].d = crop_ext(left, lw, lh, lg, VWO_EDGE_CONSTANT);
+    rp[0].w = rg.sizex(); rp[0].h = rg.sizey(); rp[0].d = crop_ext(right, rw, rh, rg, VWO_EDGE_CONSTANT);
+    std::vector<uint8_t> lmx = crop_ext(lmask_in, lw, lh, lg, VWO_EDGE_CONSTANT), rmx = crop_ext(rmask_in, rw, rh, rg, VWO_EDGE_CONSTANT);
+    // mean of the valid pixels of subsample(., 2)  (:137-149); MeanAccumulator sums in double (Math/Functors.h:469-487)
+    auto fill_mean = [](FImg& im, std::vector<uint8_t> const& m) -> bool {
+      double acc = 0.0, cnt = 0.0;
+      for (int y = 0; y < im.h; y += 2) for (int x = 0; x < im.w; x += 2)
+        if (m[(size_t)y * im.w + x]) { acc += im.d[(size_t)y * im.w + x]; cnt += 1.0; }
+      if (!cnt) return false;
+      const float mean = (float)(acc / cnt);
+      for (size_t i = 0; i < im.d.size(); ++i) if (!m[i]) im.d[i] = mean;
+      return true;
+    };
+    if (!fill_mean(lp[0], lmx) || !fill_mean(rp[0], rmx)) return 0;      // tile has no data: all invalid (:318-327)
+    Box rmb(bbox.minx + search.minx, bbox.miny + search.miny, bbox.maxx + search.minx + search.sizex(), bbox.maxy + search.miny + search.sizey());
+    lmp[0].w = bw; lmp[0].h = bh; lmp[0].d = crop_ext(lmask_in, lw, lh, bbox, VWO_EDGE_ZERO);
+    rmp[0].w = rmb.sizex(); rmp[0].h = rmb.sizey(); rmp[0].d = crop_ext(rmask_in, rw, rh, rmb, VWO_EDGE_ZERO);
+    const float k5[5] = {(float)(1.0 / 16.0), (float)(4.0 / 16.0), (float)(6.0 / 16.0), (float)(4.0 / 16.0), (float)(1.0 / 16.0)};
+    for (int i = 1; i <= L; ++i) {
+      auto down = [&](FImg const& a, FImg& o) {
+        o.w = 1 + (a.w - 1) / 2; o.h = 1 + (a.h - 1) / 2; o.d.resize((size_t)o.w * o.h);
+        sepconv<float>(a.d.data(), a.w, a.h, k5, 5, 2, k5, 5, 2, VWO_EDGE_CONSTANT, 2, o.d.data());
+      };
+      down(lp[i - 1], lp[i]); down(rp[i - 1], rp[i]);
+      auto mdown = [&](MImg const& a, MImg& o) {
+        o.w = 1 + (a.w - 1) / 2; o.h = 1 + (a.h - 1) / 2; o.d.resize((size_t)o.w * o.h);
+        vwo_subsample_mask_by_two(a.d.data(), a.w, a.h, o.d.data());
+      };
+      mdown(lmp[i - 1], lmp[i]); mdown(rmp[i - 1], rmp[i]);
+    }
+    for (int i = 0; i <= L; ++i) {                                       // prefilter every level (:232-236)
+      std::vector<float> t(lp[i].d.size());
+      vwo_prefilter_image(lp[i].d.data(), lp[i].w, lp[i].h, prefilter_mode, prefilter_width, t.data()); lp[i].d.swap(t);
+      t.assign(rp[i].d.size(), 0.0f);
+      vwo_prefilter_image(rp[i].d.data(), rp[i].w, rp[i].h, prefilter_mode, prefilter_width, t.data()); rp[i].d.swap(t);
+    }
+  }
+
+  // 3.0) level loop
+  std::vector<int32_t> disparity;
+  int dw = 0, dh = 0;
+  std::vector<Zone> zones;
+  zones.push_back(Zone{Box(0, 0, lmp[L].w, lmp[L].h), Box(0, 0, search.width() / max_upscaling + 1, search.height() / max_upscaling + 1)});
+  double estim_elapsed = 0.0;
+  for (int level = L; level >= 0; --level) {
+    const bool on_last_level = (level == 0);
+    int scaling = 1 << level;
+    dw = lmp[level].w; dh = lmp[level].h;
+    disparity.assign((size_t)dw * dh * 3, 0);                            // set_size: default (invalid) pixels
+    const int rox = max_upscaling * hkx / scaling, roy = max_upscaling * hky / scaling;   // region_offset (:381)
+    std::stable_sort(zones.begin(), zones.end(), [](Zone const& a, Zone const& b) {       // SearchParamLessThan (:606)
+      return (double)a.region.width() * a.region.height() * a.range.width() * a.range.height() <
+             (double)b.region.width() * b.region.height() * b.range.width() * b.range.height(); });
+    FImg const& Lv = lp[level]; FImg const& Rv = rp[level];
+    for (Zone const& zone : zones) {
+      Box lr(zone.region.minx + rox - hkx, zone.region.miny + roy - hky, zone.region.maxx + rox + hkx, zone.region.maxy + roy + hky);
+      Box rr(lr.minx + zone.range.minx, lr.miny + zone.range.miny, lr.maxx + zone.range.minx + zone.range.sizex(), lr.maxy + zone.range.miny + zone.range.sizey());
+      const double next_elapsed = seconds_per_op * ((double)lr.width() * lr.height() * zone.range.width() * zone.range.height());
+      if (corr_timeout > 0 && estim_elapsed + next_elapsed > corr_timeout) break;
+      estim_elapsed += next_elapsed;
+      const int zw = zone.region.sizex(), zh = zone.region.sizey(), sx = zone.range.sizex(), sy = zone.range.sizey();
+      if (zw <= 0 || zh <= 0) continue;
+      std::vector<float> lc = crop_ext(Lv.d.data(), Lv.w, Lv.h, lr, VWO_EDGE_CONSTANT);    // crops lie inside by construction
+      std::vector<float> rc = crop_ext(Rv.d.data(), Rv.w, Rv.h, rr, VWO_EDGE_CONSTANT);
+      std::vector<int32_t> zd((size_t)zw * zh * 3);
+      if (best_of_search(cost_type, lc.data(), lr.sizex(), lr.sizey(), lr.sizex(), rc.data(), rr.sizex(), rr.sizey(), rr.sizex(),
+                         kx, ky, sx, sy, zd.data())) return -1;
+      if (consistency_threshold >= 0 && level == 0) {                    // R->L + check (:654-694)
+        const double ne2 = seconds_per_op * ((double)rr.width() * rr.height() * zone.range.width() * zone.range.height());
+        if (corr_timeout > 0 && estim_elapsed + ne2 > corr_timeout) break;
+        estim_elapsed += ne2;
+        Box l2(lr.minx - sx, lr.miny - sy, lr.maxx - sx, lr.maxy - sy);   // left_region - range.size()
+        // right crop is the "left" image of this call, grown on the max side by s-1 by calc_disparity itself
+        Box l2g(l2.minx, l2.miny, l2.minx + rr.sizex() + sx - 1, l2.miny + rr.sizey() + sy - 1);
+        std::vector<float> a = crop_ext(Rv.d.data(), Rv.w, Rv.h, rr, VWO_EDGE_CONSTANT);
+        std::vector<float> b = crop_ext(Lv.d.data(), Lv.w, Lv.h, l2g, VWO_EDGE_CONSTANT);
+        const int rlw = rr.sizex() - kx + 1, rlh = rr.sizey() - ky + 1;
+        std::vector<int32_t> rl((size_t)rlw * rlh * 3);
+        if (best_of_search(cost_type, a.data(), rr.sizex(), rr.sizey(), rr.sizex(), b.data(), l2g.sizex(), l2g.sizey(), l2g.sizex(),
+                           kx, ky, sx, sy, rl.data())) return -1;
+        for (size_t i = 0; i < (size_t)rlw * rlh; ++i) { rl[3*i] -= sx; rl[3*i+1] -= sy; }   // - pixel_typeI(range.size())
+        vwo_cross_corr_consistency_check(zd.data(), zw, zh, rl.data(), rlw, rlh, consistency_threshold);
+      }
+      for (int y = 0; y < zh; ++y) for (int x = 0; x < zw; ++x) {         // crop(disparity, region) = ...; += range.min()
+        const int32_t* s3 = &zd[((size_t)y * zw + x) * 3];
+        int32_t* d3 = &disparity[((size_t)(zone.region.miny + y) * dw + zone.region.minx + x) * 3];
+        d3[0] = s3[0] + zone.range.minx; d3[1] = s3[1] + zone.range.miny; d3[2] = s3[2];
+      }
+    }
+    // 3.2a) clean-up filters (:702-744)
+    if (filter_half_kernel > 0) {
+      disparity_filter(disparity, dw, dh, filter_half_kernel, filter_half_kernel, 3.0, 0.5, !on_last_level);
+      disparity_mask(disparity, dw, dh, lmp[level].d.data(), rmp[level].d.data(), rmp[level].w, rmp[level].h);
+    }
+    // 3.2b) refine the search estimates (:754-799)
+    if (!on_last_level) {
+      zones.clear();
+      subdivide(disparity.data(), dw, dh, Box(0, 0, dw, dh), zones, kx, ky);
+      scaling >>= 1;
+      const Box scale_search(0, 0, rp[level - 1].w - lp[level - 1].w, rp[level - 1].h - lp[level - 1].h);
+      const Box next_zone_size(0, 0, lmp[level - 1].w, lmp[level - 1].h);
+      const Box default_range(0, 0, search.width(), search.height());
+      for (Zone& z : zones) {
+        // BBox *= 2 scales both corners; empty boxes are left alone by operator*= (BBox.h) — regions are never empty here
+        z.region = Box(z.region.minx * 2, z.region.miny * 2, z.region.maxx * 2, z.region.maxy * 2);
+        z.region.crop(next_zone_size);
+        if (!z.range.empty()) z.range = Box(z.range.minx * 2, z.range.miny * 2, z.range.maxx * 2, z.range.maxy * 2);
+        z.range.expand(2);
+        z.range.crop(scale_search);
+        if (z.range.empty()) z.range = default_range;
+      }
+    }
+  }
+  if (dw != bw || dh != bh) return -2;
+  // 5.0) + search.min, cast to float (:876-885); invalid pixels keep valid = 0, child gets the offset as well
+  for (size_t i = 0; i < (size_t)bw * bh; ++i) {
+    out3f[3*i] = (float)(disparity[3*i] + search.minx);
+    out3f[3*i+1] = (float)(disparity[3*i+1] + search.miny);
+    out3f[3*i+2] = disparity[3*i+2] ? 1.0f : 0.0f;
   }
   return 0;
 }

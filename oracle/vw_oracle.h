@@ -111,6 +111,27 @@ int vwo_prefilter_region(const float* src, int w, int h, int mode, float width,
 int vwo_parabola_subpixel(const float* disp3f, int w, int h, const float* left, const float* right, int rw, int rh,
                           int prefilter_mode, float prefilter_width, int kx, int ky, float* out3f);
 
+/* ---- pyramid block matching ------------------------------------------------------------------------------------ */
+
+/* One tile of pyramid_correlate(...) with VW_CORRELATION_BM: PyramidCorrelationView::prerasterize(bbox),
+ * src/vw/Stereo/CorrelationView.cc:273-886 (build_image_pyramids :67-239, zone loop :596-700, clean-up filters
+ * :702-750 with src/vw/Stereo/DisparityMap.h:97-253,318-441, zone refinement :754-799, final cast :876-885).
+ * Masks may be NULL (all valid).  search = [smin, smax) as a BBox2i.  blob_filter_area = 0, no lr_disp_diff,
+ * collar 0.  corr_timeout > 0 uses the reference's estimate accounting (seconds_per_op * search volume) without the
+ * wall-clock re-calibration.  out3f: bw x bh x {dx, dy, valid} float. Returns 0, or -1 on bad arguments. */
+int vwo_pyramid_correlate(const float* left, int lw, int lh, const float* right, int rw, int rh,
+                          const uint8_t* lmask, const uint8_t* rmask,
+                          int prefilter_mode, float prefilter_width,
+                          int sminx, int sminy, int smaxx, int smaxy, int kx, int ky, int cost_type,
+                          int corr_timeout, double seconds_per_op, float consistency_threshold,
+                          int filter_half_kernel, int max_pyramid_levels,
+                          int bx, int by, int bw, int bh, float* out3f);
+
+/* rm_outliers_using_thresh / disparity_cleanup_using_thresh / disparity_mask on whole images
+ * (src/vw/Stereo/DisparityMap.h:318-441, 97-253); disp3 in place.  cleanup != 0 adds the second (1,1,3.0,0.20) pass. */
+int vwo_disparity_filter(int32_t* disp3, int w, int h, int half_h, int half_v, double pixel_thr, double rej_thr, int cleanup);
+int vwo_disparity_mask(int32_t* disp3, int w, int h, const uint8_t* lmask, const uint8_t* rmask, int rmw, int rmh);
+
 #ifdef __cplusplus
 }
 #endif

@@ -309,3 +309,68 @@ def test_subdivide_regions_basic(oracle):
     # invalid areas produce no zone
     d[..., 2] = 0
     assert len(oracle.subdivide_regions(d, (7, 7))) == 0
+
+
+# ---- pyramid_correlate (BM) and the disparity clean-up chain ---------------------------------------------------------
+
+# thresholds of src/vw/Stereo/tests/TestPyramidCorrelationView.cxx:92-410: (cost, consistency threshold) -> (correct, attempted)
+_PYR_U8 = {(0, -1): (.909, .9985), (0, 2): (.91, .990), (1, -1): (.90, .9985), (1, 2): (.90, .990),
+           (2, -1): (.90, .998), (2, 2): (.90, .990)}
+_PYR_I16 = {**_PYR_U8, (2, -1): (.87, .99), (2, 2): (.87, .99)}
+
+
+@pytest.mark.parametrize("channel,table", [("u8", _PYR_U8), ("i16", _PYR_I16), ("f32", _PYR_U8)])
+def test_pyramid_correlate_reference_thresholds(oracle, channel, table):
+    """TestPyramidCorrelationView.cxx NullPreprocess (GRAYU8 :92, GRAYI16 :172, GRAYF32 :253): the same scene
+    (rand48 noise 300x200, affine 0.9/0.95 + (15, 5), bicubic), arguments and pass thresholds."""
+    import scenes
+    left, right, scale, trans, search = scenes.pyramid_scene(channel)
+    for (cost, thr), (correct, attempted) in table.items():
+        d = oracle.pyramid_correlate(left, right, np.full(left.shape, 255, np.uint8), np.full(right.shape, 255, np.uint8),
+                                     0, 0.0, search, (7, 7), cost, 0, 0.0, thr, 5, 5)
+        assert d.shape == left.shape + (3,)
+        got_c, got_a = scenes.pyramid_score(d, scale, trans)
+        assert got_c > correct and got_a > attempted, (channel, cost, thr, got_c, got_a)
+
+
+def test_disparity_cleanup_known_answer(oracle):
+    """After TestDisparity.cxx:222-276 (DisparityFiltering): identity-ramp disparity with a corrupted patch; only the
+    corrupted pixels may be rejected.  The reference test drives triple_disparity_cleanup; the path here is
+    disparity_cleanup_using_thresh (DisparityMap.h:427-441), so the patch is 2x2 (4/49 < 0.2 matches)."""
+    V = oracle.VALID
+    n = 100
+    d = np.zeros((n, n, 3), np.int32)
+    d[..., 0] = np.arange(n)[None, :]
+    d[..., 1] = np.arange(n)[:, None]
+    d[..., 2] = V
+    d[5:7, 5:7, 0], d[5:7, 5:7, 1] = 10000, 5000
+    for cleanup in (0, 1):
+        f = oracle.disparity_filter(d, 3, 3, 10.0, 0.2, cleanup)
+        assert (f[5:7, 5:7, 2] == 0).all() and (f[5:7, 5:7, :2] == 0).all()
+        assert int((f[..., 2] == 0).sum()) == 4
+        keep = f[..., 2] != 0
+        assert (f[keep] == d[keep]).all()
+    # a 5x5 patch supports itself (25/49 > 0.2): the threshold filter keeps it, as the functor's definition says
+    d[5:10, 5:10, 0], d[5:10, 5:10, 1] = 10000, 5000
+    assert int((oracle.disparity_filter(d, 3, 3, 10.0, 0.2, 0)[..., 2] == 0).sum()) == 0
+
+
+def test_disparity_mask_known_answer(oracle):
+    """DisparityMaskView (DisparityMap.h:132-155): masked source, masked / out-of-image target invalidate and zero."""
+    V = oracle.VALID
+    d = np.zeros((4, 6, 3), np.int32)
+    d[..., 0], d[..., 1], d[..., 2] = 2, 1, V
+    lm = np.full((4, 6), 255, np.uint8)
+    rm = np.full((5, 7), 255, np.uint8)
+    lm[0, 0] = 0                         # source masked
+    rm[2, 3] = 0                         # target of pixel (1, 1) masked
+    d[3, 5, 2] = 0                       # already invalid
+    out = oracle.disparity_mask(d, lm, rm)
+    expect_valid = np.ones((4, 6), bool)
+    expect_valid[0, 0] = expect_valid[1, 1] = expect_valid[3, 5] = False
+    expect_valid[:, 5] = False           # x + 2 = 7 is outside the 7-wide right mask
+    expect_valid[3, :] &= False          # y + 1 = 4 < 5 stays inside ... row 3 -> 4 is valid, undo below
+    expect_valid[3, :5] = True
+    expect_valid[3, 5] = False
+    assert ((out[..., 2] != 0) == expect_valid).all()
+    assert (out[~expect_valid] == 0).all() and (out[expect_valid] == [2, 1, V]).all()

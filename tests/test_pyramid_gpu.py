@@ -1,0 +1,141 @@
+"""pyramid_correlate (block matching), the disparity clean-up filters and the zone scheduler: libvwgpu.so vs the oracle.
+
+Parity bar: every stage is integer / index work on top of kernels that are bit-exact on their own, so whole-tile results
+must be IDENTICAL to the oracle's (dx, dy, valid) — checked here on 8-bit, 16-bit and float scenes, all three costs,
+with and without the L/R check, masks and prefilters, plus the reference's own pass thresholds.
+"""
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vw():
+    from visionworkbench_amd import stereo
+    return stereo
+
+
+def _box(search):
+    from visionworkbench_amd.core import BBox2i
+    return BBox2i.from_corners(search[:2], search[2:])
+
+
+def _run_both(vw, oracle, left, right, lm, rm, pf, pfw, search, kernel, cost, thr, filt, levels, bbox=None):
+    from visionworkbench_amd.core import BBox2i
+    g = vw.pyramid_correlate(left, right, lm, rm, pf, pfw, _box(search), kernel, cost, 0, 0.0, thr, 0, filt, levels,
+                             bbox=None if bbox is None else BBox2i(*bbox))
+    o = oracle.pyramid_correlate(left, right, lm, rm, pf, pfw, search, kernel, cost, 0, 0.0, thr, filt, levels, bbox=bbox)
+    return g, o
+
+
+@pytest.mark.parametrize("channel", ["u8", "i16", "f32"])
+@pytest.mark.parametrize("cost", [0, 1, 2])
+@pytest.mark.parametrize("thr", [-1, 2])
+def test_reference_scene_identical_to_oracle(vw, oracle, channel, cost, thr):
+    left, right, scale, trans, search = scenes.pyramid_scene(channel)
+    g, o = _run_both(vw, oracle, left, right, None, None, 0, 0.0, search, (7, 7), cost, thr, 5, 5)
+    assert g.shape == o.shape == left.shape + (3,)
+    if cost == 2:      # NCC scores are float64 on both sides but summed in a different order: allow rare near-ties
+        assert (g != o).any(axis=2).mean() < 2e-3
+    else:
+        assert np.array_equal(g, o)
+    c, a = scenes.pyramid_score(g, scale, trans)
+    assert c > (.87 if cost == 2 else .90) and a > .99           # TestPyramidCorrelationView.cxx thresholds
+
+
+@pytest.mark.parametrize("pf,pfw", [(1, 1.4), (2, 3.0)])
+def test_prefiltered_identical(vw, oracle, pf, pfw):
+    left, right, scale, trans, search = scenes.pyramid_scene("u8")
+    g, o = _run_both(vw, oracle, left, right, None, None, pf, float(np.float32(pfw)), search, (7, 7), 0, 2, 5, 5)
+    assert np.array_equal(g, o)
+    if pf == 1:        # (mean subtraction with a wide window does poorly on white noise in the oracle too: identity only)
+        c, a = scenes.pyramid_score(g, scale, trans)
+        assert c > .85 and a > .95
+
+
+def test_masks_and_subtile(vw, oracle):
+    left, right, scale, trans, search = scenes.pyramid_scene("u8")
+    lm = np.full(left.shape, 255, np.uint8)
+    rm = np.full(right.shape, 255, np.uint8)
+    lm[40:90, 100:160] = 0
+    rm[120:, 200:] = 0
+    g, o = _run_both(vw, oracle, left, right, lm, rm, 0, 0.0, search, (7, 7), 0, 2, 3, 5)
+    assert np.array_equal(g, o)
+    assert (g[45:85, 105:155, 2] == 0).all()                     # masked source pixels never come out valid
+    # one interior tile, as the block rasteriser would request it
+    g, o = _run_both(vw, oracle, left, right, lm, rm, 0, 0.0, search, (9, 5), 1, -1, 2, 2, bbox=(64, 32, 128, 96))
+    assert g.shape == (96, 128, 3) and np.array_equal(g, o)
+    # everything masked -> an all-invalid tile, no error
+    g = vw.pyramid_correlate(left, right, np.zeros(left.shape, np.uint8), rm, 0, 0.0, _box(search), (7, 7), 0,
+                             filter_half_kernel=3)
+    assert not g.any()
+
+
+def test_level_count_edge_cases(vw, oracle):
+    left, right, scale, trans, search = scenes.pyramid_scene("u8")
+    for levels, srch in [(0, (-3, -2, 4, 3)), (1, (-6, -2, 7, 3)), (5, (0, 0, 1, 1)), (5, (-30, 0, 31, 1))]:
+        g, o = _run_both(vw, oracle, left, right, None, None, 0, 0.0, srch, (5, 5), 0, -1, 0, levels)
+        assert np.array_equal(g, o), (levels, srch)
+
+
+def test_torch_device_entry(vw, oracle):
+    import torch
+    left, right, scale, trans, search = scenes.pyramid_scene("u8")
+    g = vw.pyramid_correlate(torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda(), None, None, 0, 0.0,
+                             _box(search), (7, 7), 0, consistency_threshold=2, filter_half_kernel=5, max_pyramid_levels=5)
+    o = oracle.pyramid_correlate(left, right, None, None, 0, 0.0, search, (7, 7), 0, 0, 0.0, 2, 5, 5)
+    assert g.is_cuda and np.array_equal(g.cpu().numpy(), o)
+
+
+def test_argument_errors(vw):
+    from visionworkbench_amd.core import ArgumentErr, NoImplErr, BBox2i
+    left, right, *_ = scenes.pyramid_scene("u8")
+    with pytest.raises(ArgumentErr):
+        vw.pyramid_correlate(left, right, None, None, 0, 0.0, BBox2i(0, 0, 0, 0), (7, 7), 0)
+    with pytest.raises(ArgumentErr):
+        vw.pyramid_correlate(left, right, None, None, 0, 0.0, BBox2i(0, 0, 4, 4), (6, 7), 0)
+    with pytest.raises(NoImplErr):
+        vw.pyramid_correlate(left, right, None, None, 0, 0.0, BBox2i(0, 0, 4, 4), (7, 7), 0, algorithm=1)
+
+
+def _random_disparity(rng, h, w, p_invalid=0.15):
+    V = np.iinfo(np.int32).max
+    d = np.zeros((h, w, 3), np.int32)
+    d[..., 0] = rng.integers(-4, 5, (h, w)) + (np.arange(w)[None, :] // 16)
+    d[..., 1] = rng.integers(-2, 3, (h, w))
+    d[..., 2] = np.where(rng.random((h, w)) < p_invalid, 0, V)
+    return d
+
+
+@pytest.mark.parametrize("cleanup", [0, 1])
+@pytest.mark.parametrize("hk", [(1, 1), (3, 2), (5, 5)])
+def test_disparity_filters_identical(vw, oracle, cleanup, hk):
+    rng = np.random.default_rng(7)
+    d = _random_disparity(rng, 67, 93)
+    fn = vw.disparity_cleanup_using_thresh if cleanup else vw.rm_outliers_using_thresh
+    for pthr, rthr in [(3.0, 0.5), (1.0, 0.3), (0.0, 0.05)]:
+        g = fn(d, hk[0], hk[1], pthr, rthr)
+        assert np.array_equal(g, oracle.disparity_filter(d, hk[0], hk[1], pthr, rthr, cleanup))
+
+
+def test_disparity_mask_identical(vw, oracle):
+    rng = np.random.default_rng(8)
+    d = _random_disparity(rng, 50, 70)
+    lm = (rng.random((50, 70)) > 0.1).astype(np.uint8) * 255
+    rm = (rng.random((55, 80)) > 0.1).astype(np.uint8) * 255
+    assert np.array_equal(vw.disparity_mask(d, lm, rm), oracle.disparity_mask(d, lm, rm))
+
+
+def test_subdivide_regions_identical(vw, oracle):
+    rng = np.random.default_rng(9)
+    for h, w, k in [(64, 96, (7, 7)), (33, 47, (5, 9)), (128, 200, (3, 3))]:
+        d = _random_disparity(rng, h, w, 0.3)
+        d[: h // 2, : w // 3, 0] += 25
+        d[h // 3:, w // 2:, 2] = 0
+        z = vw.subdivide_regions(d, k)
+        zo = oracle.subdivide_regions(d, k)
+        got = [r.min + r.max + s.min + s.max for r, s in z]
+        assert got == [list(map(int, row)) for row in zo]

@@ -19,7 +19,25 @@ SYMBOLS = [
     "vwgpu_subsample_mask_by_two_dev", "vwgpu_subsample_mask_by_two",
     "vwgpu_prefilter_image_dev", "vwgpu_prefilter_image",
     "vwgpu_parabola_subpixel_dev", "vwgpu_parabola_subpixel",
+    "vwgpu_disparity_filter_dev", "vwgpu_disparity_filter",
+    "vwgpu_disparity_mask_dev", "vwgpu_disparity_mask",
+    "vwgpu_subdivide_regions",
+    "vwgpu_pyramid_correlate_dev", "vwgpu_pyramid_correlate",
 ]
+
+
+class PyramidParams(ctypes.Structure):
+    """struct vwgpu_pyramid_params (include/vwgpu.h)."""
+    _fields_ = [
+        ("prefilter_mode", ctypes.c_int), ("prefilter_width", ctypes.c_float),
+        ("search_min_x", ctypes.c_int), ("search_min_y", ctypes.c_int),
+        ("search_max_x", ctypes.c_int), ("search_max_y", ctypes.c_int),
+        ("kernel_x", ctypes.c_int), ("kernel_y", ctypes.c_int),
+        ("cost_type", ctypes.c_int), ("corr_timeout", ctypes.c_int), ("seconds_per_op", ctypes.c_double),
+        ("consistency_threshold", ctypes.c_float), ("min_consistency_level", ctypes.c_int),
+        ("filter_half_kernel", ctypes.c_int), ("max_pyramid_levels", ctypes.c_int),
+        ("algorithm", ctypes.c_int), ("blob_filter_area", ctypes.c_int),
+    ]
 
 
 def build(force=False):
@@ -86,6 +104,17 @@ def load():
     ps = [P, P, I, I, PD, P, PD, P, I, I, PD, I, F, I, I, P, PD]
     lib.vwgpu_parabola_subpixel_dev.argtypes = ps
     lib.vwgpu_parabola_subpixel.argtypes = ps
+    D = ctypes.c_double
+    df = [P, P, I, I, I, I, D, D, I, P]
+    lib.vwgpu_disparity_filter_dev.argtypes = df
+    lib.vwgpu_disparity_filter.argtypes = df
+    dm = [P, P, I, I, P, P, I, I]
+    lib.vwgpu_disparity_mask_dev.argtypes = dm
+    lib.vwgpu_disparity_mask.argtypes = dm
+    lib.vwgpu_subdivide_regions.argtypes = [P, I, I, I, I, P, I]
+    pc = [P, P, I, I, PD, P, I, I, PD, P, PD, P, PD, ctypes.POINTER(PyramidParams), I, I, I, I, P, PD]
+    lib.vwgpu_pyramid_correlate_dev.argtypes = pc
+    lib.vwgpu_pyramid_correlate.argtypes = pc
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the ABI and the header drifted apart
     _LIB = lib

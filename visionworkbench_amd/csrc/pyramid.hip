@@ -1,0 +1,543 @@
+// pyramid.hip — one tile of pyramid_correlate (block matching): the coarse-to-fine level loop of
+// vw::stereo::PyramidCorrelationView::prerasterize (src/vw/Stereo/CorrelationView.cc:273-886) with every image
+// (pyramids, masks, per-level disparity) resident in HBM; only the per-level disparity crosses to the host, for the
+// data-dependent zone scheduler (zones.h).
+//
+//   build_image_pyramids      CorrelationView.cc:67-239   edge-extended crops, nodata mean fill, [1 4 6 4 1]/16
+//                                                          smoothing + decimation (filters.hip), mask decimation,
+//                                                          per-level prefilter
+//   zone loop                 CorrelationView.cc:596-700  calc_disparity per zone (bm_*.hip), R->L run + L/R check at
+//                                                          level 0, += zone.disparity_range().min()
+//   clean-up                  CorrelationView.cc:702-744  rm_outliers_using_thresh / disparity_cleanup_using_thresh
+//                                                          (src/vw/Stereo/DisparityMap.h:318-441) + disparity_mask (:97-253)
+//   zone refinement           CorrelationView.cc:754-799  subdivide_regions (zones.hip), x2, expand(2), crop
+//   result                    CorrelationView.cc:876-885  + search_region.min(), cast to PixelMask<Vector2f>
+// Not covered: SGM/MGM branches (:391-595), blob filter (blob_filter_area > 0), lr_disp_diff output, collar.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "vwgpu_internal.h"
+#include "zones.h"
+
+namespace {
+
+using vwgpu::IBox;
+using vwgpu::SearchZone;
+
+// ---- small kernels ----------------------------------------------------------------------------------------------
+
+// dst(x,y) = src(ext(x0+x, y0+y)); EDGE 0 = clamp, 1 = zero.  src == nullptr means "an all-255 mask".
+template <class T, int EDGE>
+__global__ void crop_ext_kernel(const T* __restrict__ src, ptrdiff_t stride, int w, int h, int x0, int y0,
+                                T* __restrict__ dst, int dw, int dh) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dw || y >= dh) return;
+  int sx = x0 + x, sy = y0 + y;
+  T v;
+  if (EDGE == 1 && (sx < 0 || sy < 0 || sx >= w || sy >= h)) {
+    v = T(0);
+  } else {
+    sx = sx < 0 ? 0 : (sx >= w ? w - 1 : sx);
+    sy = sy < 0 ? 0 : (sy >= h ? h - 1 : sy);
+    v = src ? src[(ptrdiff_t)sy * stride + sx] : T(255);
+  }
+  dst[(size_t)y * dw + x] = v;
+}
+
+// sum / count (double) of img over the valid pixels of every second row and column (mean_pixel_value(subsample(.,2)),
+// CorrelationView.cc:137-149; MeanAccumulator sums in double, src/vw/Math/Functors.h:469-487).
+__global__ void masked_mean_kernel(const float* __restrict__ img, const uint8_t* __restrict__ mask, int w, int h,
+                                   double* __restrict__ acc2) {
+  double s = 0.0, n = 0.0;
+  for (int y = 2 * (blockIdx.y * blockDim.y + threadIdx.y); y < h; y += 2 * gridDim.y * blockDim.y)
+    for (int x = 2 * (blockIdx.x * blockDim.x + threadIdx.x); x < w; x += 2 * gridDim.x * blockDim.x)
+      if (mask[(size_t)y * w + x]) { s += (double)img[(size_t)y * w + x]; n += 1.0; }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); n += __shfl_xor(n, o); }
+  if (((threadIdx.y * blockDim.x + threadIdx.x) & 63) == 0 && n > 0.0) { atomicAdd(acc2, s); atomicAdd(acc2 + 1, n); }
+}
+
+__global__ void fill_masked_kernel(float* __restrict__ img, const uint8_t* __restrict__ mask, size_t n, float value) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !mask[i]) img[i] = value;
+}
+
+// child += (ax, ay) on a crop of a PixelMask<Vector2i> image; validity untouched (PixelMask arithmetic computes the
+// children regardless, src/vw/Image/PixelMask.h:322-360).
+__global__ void add_offset_kernel(int32_t* __restrict__ d, ptrdiff_t stride_px, int w, int h, int ax, int ay) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  int32_t* p = d + ((ptrdiff_t)y * stride_px + x) * 3;
+  p[0] += ax; p[1] += ay;
+}
+
+// RmOutliersUsingThreshFunc (src/vw/Stereo/DisparityMap.h:357-385) evaluated over the output domain
+// [ox0, ox0+ow) x [oy0, oy0+oh) of the constant-edge-extended input.
+__global__ void rm_outliers_kernel(const int32_t* __restrict__ src, int w, int h, int hh, int hv, double pthr, double rthr,
+                                   int32_t* __restrict__ dst, int ow, int oh, int ox0, int oy0) {
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y * blockDim.y + threadIdx.y;
+  if (ox >= ow || oy >= oh) return;
+  auto at = [&](int x, int y) -> const int32_t* {
+    x = x < 0 ? 0 : (x >= w ? w - 1 : x);
+    y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+    return src + ((size_t)y * w + x) * 3;
+  };
+  const int x = ox + ox0, y = oy + oy0;
+  const int32_t* c = at(x, y);
+  int32_t r0 = c[0], r1 = c[1], r2 = c[2];
+  if (r2) {
+    int matched = 0, total = 0;
+    for (int yk = -hv; yk <= hv; ++yk)
+      for (int xk = -hh; xk <= hh; ++xk) {
+        const int32_t* n = at(x + xk, y + yk);
+        if (n[2] && fabs((double)(r0 - n[0])) <= pthr && fabs((double)(r1 - n[1])) <= pthr) matched++;
+        total++;
+      }
+    if (((double)matched / (double)total) < rthr) { r0 = r1 = r2 = 0; }
+  }
+  int32_t* o = dst + ((size_t)oy * ow + ox) * 3;
+  o[0] = r0; o[1] = r1; o[2] = r2;
+}
+
+// second pass of disparity_cleanup_using_thresh: functor (1,1,3.0,0.20) over the inner VIEW, which is given here on
+// the domain padded by one pixel (DisparityMap.h:427-441).
+__global__ void cleanup_outer_kernel(const int32_t* __restrict__ inner, int w, int h, int32_t* __restrict__ dst) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const int pw = w + 2;
+  const int32_t* c = inner + ((size_t)(y + 1) * pw + (x + 1)) * 3;
+  int32_t r0 = c[0], r1 = c[1], r2 = c[2];
+  if (r2) {
+    int matched = 0;
+    for (int yk = -1; yk <= 1; ++yk)
+      for (int xk = -1; xk <= 1; ++xk) {
+        const int32_t* n = inner + ((size_t)(y + 1 + yk) * pw + (x + 1 + xk)) * 3;
+        if (n[2] && fabs((double)(r0 - n[0])) <= 3.0 && fabs((double)(r1 - n[1])) <= 3.0) matched++;
+      }
+    if (((double)matched / 9.0) < 0.20) { r0 = r1 = r2 = 0; }
+  }
+  int32_t* o = dst + ((size_t)y * w + x) * 3;
+  o[0] = r0; o[1] = r1; o[2] = r2;
+}
+
+// DisparityMaskView::operator() (DisparityMap.h:132-155), in place.
+__global__ void disparity_mask_kernel(int32_t* __restrict__ d, int w, int h, const uint8_t* __restrict__ m1,
+                                      const uint8_t* __restrict__ m2, int m2w, int m2h) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= w || j >= h) return;
+  int32_t* p = d + ((size_t)j * w + i) * 3;
+  bool keep = m1[(size_t)j * w + i] != 0 && p[2] != 0;
+  if (keep) {
+    const int x = i + p[0], y = j + p[1];
+    keep = !(x < 0 || x >= m2w || y < 0 || y >= m2h || m2[(size_t)y * m2w + x] == 0);
+  }
+  if (!keep) { p[0] = 0; p[1] = 0; p[2] = 0; }
+}
+
+// out = PixelMask<Vector2f>(disparity + search.min)  (CorrelationView.cc:879-881)
+__global__ void finish_kernel(const int32_t* __restrict__ d, int w, int h, int ax, int ay, float* __restrict__ out, ptrdiff_t ostride_px) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const int32_t* p = d + ((size_t)y * w + x) * 3;
+  float* o = out + ((ptrdiff_t)y * ostride_px + x) * 3;
+  o[0] = (float)(p[0] + ax); o[1] = (float)(p[1] + ay); o[2] = p[2] ? 1.0f : 0.0f;
+}
+
+__global__ void zero_out_kernel(float* __restrict__ out, ptrdiff_t ostride_px, int w, int h) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  float* o = out + ((ptrdiff_t)y * ostride_px + x) * 3;
+  o[0] = o[1] = o[2] = 0.0f;
+}
+
+inline dim3 grid2(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
+const dim3 kBlk(64, 4);
+
+// Bump allocator over one arena; everything of a tile lives until the call returns.
+struct Bump {
+  char* base; size_t cap, off = 0;
+  template <class T> T* take(size_t n) {
+    off = vwgpu_align_up(off, 256);
+    T* p = reinterpret_cast<T*>(base + off);
+    off += n * sizeof(T);
+    return off <= cap ? p : nullptr;
+  }
+};
+
+struct DevImg { float* p = nullptr; int w = 0, h = 0; };
+struct DevMask { uint8_t* p = nullptr; int w = 0, h = 0; };
+
+}  // namespace
+
+int vwgpu_launch_disparity_filter(vwgpu_ctx* ctx, const int32_t* src, int w, int h, int hh, int hv, double pthr, double rthr,
+                                  bool cleanup, int32_t* tmp_padded, int32_t* dst) {
+  if (!cleanup) {
+    vwgpu_prof_scope ps(ctx, "rm_outliers");
+    hipLaunchKernelGGL(rm_outliers_kernel, grid2(w, h), kBlk, 0, ctx->stream, src, w, h, hh, hv, pthr, rthr, dst, w, h, 0, 0);
+  } else {
+    {
+      vwgpu_prof_scope ps(ctx, "rm_outliers");
+      hipLaunchKernelGGL(rm_outliers_kernel, grid2(w + 2, h + 2), kBlk, 0, ctx->stream, src, w, h, hh, hv, pthr, rthr,
+                         tmp_padded, w + 2, h + 2, -1, -1);
+    }
+    vwgpu_prof_scope ps(ctx, "disparity_cleanup_outer");
+    hipLaunchKernelGGL(cleanup_outer_kernel, grid2(w, h), kBlk, 0, ctx->stream, tmp_padded, w, h, dst);
+  }
+  VWGPU_HIP(ctx, hipGetLastError());
+  return VWGPU_OK;
+}
+
+int vwgpu_launch_disparity_mask(vwgpu_ctx* ctx, int32_t* d, int w, int h, const uint8_t* m1, const uint8_t* m2, int m2w, int m2h) {
+  vwgpu_prof_scope ps(ctx, "disparity_mask");
+  hipLaunchKernelGGL(disparity_mask_kernel, grid2(w, h), kBlk, 0, ctx->stream, d, w, h, m1, m2, m2w, m2h);
+  VWGPU_HIP(ctx, hipGetLastError());
+  return VWGPU_OK;
+}
+
+// All pointers are device pointers (masks may be null).  out: bw x bh x 3 floats.
+int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t ls,
+                                 const float* right, int rw, int rh, ptrdiff_t rs,
+                                 const uint8_t* lmask, ptrdiff_t lms, const uint8_t* rmask, ptrdiff_t rms,
+                                 const vwgpu_pyramid_params* P, int bx, int by, int bw, int bh,
+                                 float* out, ptrdiff_t os) {
+  const int kx = P->kernel_x, ky = P->kernel_y;
+  const IBox search(P->search_min_x, P->search_min_y, P->search_max_x, P->search_max_y);
+  const IBox bbox(bx, by, bx + bw, by + bh);
+  hipStream_t st = ctx->stream;
+
+  // constructor + 1.0): number of levels (CorrelationView.h:99-105, CorrelationView.cc:301-310)
+  const int largest_search = std::max(search.dx(), search.dy());
+  int by_search = (int)(std::floor(std::log(float(largest_search)) / std::log(2.0f)) - 1);
+  by_search = std::max(0, std::min(by_search, P->max_pyramid_levels));
+  int L = (int)std::floor(std::log((double)std::min(bw, bh)) / std::log(2.0f) - std::log((double)std::max(kx, ky)) / std::log(2.0f));
+  L = std::min(L, by_search);
+  if (L < 1) L = 0;
+  const int hkx = kx / 2, hky = ky / 2, up = 1 << L;
+
+  // geometry of level 0
+  IBox lg = bbox; lg.x0 -= hkx * up; lg.x1 += hkx * up; lg.y0 -= hky * up; lg.y1 += hky * up;
+  const IBox rg(lg.x0 + search.x0, lg.y0 + search.y0, lg.x1 + search.x0 + search.dx(), lg.y1 + search.y0 + search.dy());
+  const IBox rmb(bbox.x0 + search.x0, bbox.y0 + search.y0, bbox.x1 + search.x0 + search.dx(), bbox.y1 + search.y0 + search.dy());
+
+  // arena: pyramids (4/3 of the bases, twice for the prefiltered copies), masks, disparities, scratch
+  const size_t nl = (size_t)lg.dx() * lg.dy(), nr = (size_t)rg.dx() * rg.dy();
+  const size_t need = 4 * (nl + nr) * 3 + (nl + nr) * 2 + (size_t)rmb.dx() * rmb.dy() * 2 + (size_t)bw * bh * (12 * 3 + 2) +
+                      (size_t)(bw + 2) * (bh + 2) * 12 + (nl + nr) * 4 * 2 + (size_t)(rg.dx() + 2 * search.dx()) * (rg.dy() + 2 * search.dy()) * 20 +
+                      (1 << 20);
+  int rc = vwgpu_arena_reserve(ctx, &ctx->pyr, need);
+  if (rc) return rc;
+  Bump A{static_cast<char*>(ctx->pyr.base), ctx->pyr.cap};
+  std::vector<DevImg> lp(L + 1), rp(L + 1);
+  std::vector<DevMask> lmp(L + 1), rmp(L + 1);
+  auto fail_mem = [&]() { return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "pyramid_correlate: internal arena too small"); };
+
+  lp[0].w = lg.dx(); lp[0].h = lg.dy(); lp[0].p = A.take<float>(nl);
+  rp[0].w = rg.dx(); rp[0].h = rg.dy(); rp[0].p = A.take<float>(nr);
+  uint8_t* lmx = A.take<uint8_t>(nl);
+  uint8_t* rmx = A.take<uint8_t>(nr);
+  lmp[0].w = bw; lmp[0].h = bh; lmp[0].p = A.take<uint8_t>((size_t)bw * bh);
+  rmp[0].w = rmb.dx(); rmp[0].h = rmb.dy(); rmp[0].p = A.take<uint8_t>((size_t)rmb.dx() * rmb.dy());
+  double* d_acc = A.take<double>(4);
+  if (!lp[0].p || !rp[0].p || !lmx || !rmx || !lmp[0].p || !rmp[0].p || !d_acc) return fail_mem();
+  {
+    vwgpu_prof_scope ps(ctx, "pyramid_base_crops");
+    hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(lp[0].w, lp[0].h), kBlk, 0, st, left, ls, lw, lh, lg.x0, lg.y0, lp[0].p, lp[0].w, lp[0].h);
+    hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(rp[0].w, rp[0].h), kBlk, 0, st, right, rs, rw, rh, rg.x0, rg.y0, rp[0].p, rp[0].w, rp[0].h);
+    hipLaunchKernelGGL((crop_ext_kernel<uint8_t, 0>), grid2(lp[0].w, lp[0].h), kBlk, 0, st, lmask, lms, lw, lh, lg.x0, lg.y0, lmx, lp[0].w, lp[0].h);
+    hipLaunchKernelGGL((crop_ext_kernel<uint8_t, 0>), grid2(rp[0].w, rp[0].h), kBlk, 0, st, rmask, rms, rw, rh, rg.x0, rg.y0, rmx, rp[0].w, rp[0].h);
+    hipLaunchKernelGGL((crop_ext_kernel<uint8_t, 1>), grid2(bw, bh), kBlk, 0, st, lmask, lms, lw, lh, bbox.x0, bbox.y0, lmp[0].p, bw, bh);
+    hipLaunchKernelGGL((crop_ext_kernel<uint8_t, 1>), grid2(rmp[0].w, rmp[0].h), kBlk, 0, st, rmask, rms, rw, rh, rmb.x0, rmb.y0, rmp[0].p, rmp[0].w, rmp[0].h);
+  }
+  // nodata mean fill (:130-149)
+  VWGPU_HIP(ctx, hipMemsetAsync(d_acc, 0, 4 * sizeof(double), st));
+  hipLaunchKernelGGL(masked_mean_kernel, dim3(16, 16), kBlk, 0, st, lp[0].p, lmx, lp[0].w, lp[0].h, d_acc);
+  hipLaunchKernelGGL(masked_mean_kernel, dim3(16, 16), kBlk, 0, st, rp[0].p, rmx, rp[0].w, rp[0].h, d_acc + 2);
+  double acc[4];
+  VWGPU_HIP(ctx, hipMemcpyAsync(acc, d_acc, sizeof acc, hipMemcpyDeviceToHost, st));
+  VWGPU_HIP(ctx, hipStreamSynchronize(st));
+  if (acc[1] == 0.0 || acc[3] == 0.0) {            // a fully masked image: the tile has no data (:318-327)
+    hipLaunchKernelGGL(zero_out_kernel, grid2(bw, bh), kBlk, 0, st, out, os, bw, bh);
+    VWGPU_HIP(ctx, hipGetLastError());
+    return VWGPU_OK;
+  }
+  hipLaunchKernelGGL(fill_masked_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, lp[0].p, lmx, nl, (float)(acc[0] / acc[1]));
+  hipLaunchKernelGGL(fill_masked_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, rp[0].p, rmx, nr, (float)(acc[2] / acc[3]));
+
+  // smoothing + decimation chain and mask decimation (:205-216)
+  const float k5[5] = {(float)(1.0 / 16.0), (float)(4.0 / 16.0), (float)(6.0 / 16.0), (float)(4.0 / 16.0), (float)(1.0 / 16.0)};
+  for (int i = 1; i <= L; ++i) {
+    lp[i].w = 1 + (lp[i - 1].w - 1) / 2; lp[i].h = 1 + (lp[i - 1].h - 1) / 2; lp[i].p = A.take<float>((size_t)lp[i].w * lp[i].h);
+    rp[i].w = 1 + (rp[i - 1].w - 1) / 2; rp[i].h = 1 + (rp[i - 1].h - 1) / 2; rp[i].p = A.take<float>((size_t)rp[i].w * rp[i].h);
+    lmp[i].w = 1 + (lmp[i - 1].w - 1) / 2; lmp[i].h = 1 + (lmp[i - 1].h - 1) / 2; lmp[i].p = A.take<uint8_t>((size_t)lmp[i].w * lmp[i].h);
+    rmp[i].w = 1 + (rmp[i - 1].w - 1) / 2; rmp[i].h = 1 + (rmp[i - 1].h - 1) / 2; rmp[i].p = A.take<uint8_t>((size_t)rmp[i].w * rmp[i].h);
+    if (!lp[i].p || !rp[i].p || !lmp[i].p || !rmp[i].p) return fail_mem();
+    if ((rc = vwgpu_launch_sepconv(ctx, lp[i - 1].p, lp[i - 1].w, lp[i - 1].h, lp[i - 1].w, k5, 5, 2, k5, 5, 2, 0, 2, lp[i].p, lp[i].w))) return rc;
+    if ((rc = vwgpu_launch_sepconv(ctx, rp[i - 1].p, rp[i - 1].w, rp[i - 1].h, rp[i - 1].w, k5, 5, 2, k5, 5, 2, 0, 2, rp[i].p, rp[i].w))) return rc;
+    if ((rc = vwgpu_launch_mask_by_two(ctx, lmp[i - 1].p, lmp[i - 1].w, lmp[i - 1].h, lmp[i - 1].w, lmp[i].p, lmp[i].w))) return rc;
+    if ((rc = vwgpu_launch_mask_by_two(ctx, rmp[i - 1].p, rmp[i - 1].w, rmp[i - 1].h, rmp[i - 1].w, rmp[i].p, rmp[i].w))) return rc;
+  }
+  // prefilter every level (:232-236); levels stay unfiltered sources of the next level, so filter into copies
+  const bool filtered = (P->prefilter_mode == VWGPU_PREFILTER_LOG || P->prefilter_mode == VWGPU_PREFILTER_MEANSUB);
+  if (filtered) {
+    for (int i = 0; i <= L; ++i) {
+      float* lf = A.take<float>((size_t)lp[i].w * lp[i].h);
+      float* rf = A.take<float>((size_t)rp[i].w * rp[i].h);
+      if (!lf || !rf) return fail_mem();
+      if ((rc = vwgpu_prefilter_image_dev(ctx, lp[i].p, lp[i].w, lp[i].h, lp[i].w, P->prefilter_mode, P->prefilter_width, lf, lp[i].w))) return rc;
+      if ((rc = vwgpu_prefilter_image_dev(ctx, rp[i].p, rp[i].w, rp[i].h, rp[i].w, P->prefilter_mode, P->prefilter_width, rf, rp[i].w))) return rc;
+      lp[i].p = lf; rp[i].p = rf;
+    }
+  }
+
+  // level loop
+  int32_t* disp = A.take<int32_t>((size_t)bw * bh * 3);
+  int32_t* disp2 = A.take<int32_t>((size_t)bw * bh * 3);
+  int32_t* padded = A.take<int32_t>((size_t)(bw + 2) * (bh + 2) * 3);
+  int32_t* rl = A.take<int32_t>((size_t)(rg.dx() + 2 * search.dx()) * (rg.dy() + 2 * search.dy()) * 3 + 64);
+  float* tmp_a = A.take<float>(nl + nr);
+  float* tmp_b = A.take<float>((size_t)(rg.dx() + 2 * search.dx()) * (rg.dy() + 2 * search.dy()));
+  if (!disp || !disp2 || !padded || !rl || !tmp_a || !tmp_b) return fail_mem();
+  std::vector<int32_t> host_disp;
+  std::vector<SearchZone> zones;
+  zones.push_back(SearchZone{IBox(0, 0, lmp[L].w, lmp[L].h), IBox(0, 0, search.width() / up + 1, search.height() / up + 1)});
+  double estim = 0.0;
+  const int saved_force = ctx->forced_path;
+  int dw = 0, dh = 0;
+  for (int level = L; level >= 0; --level) {
+    const bool last = (level == 0);
+    const int scaling = 1 << level;
+    dw = lmp[level].w; dh = lmp[level].h;
+    VWGPU_HIP(ctx, hipMemsetAsync(disp, 0, (size_t)dw * dh * 12, st));
+    const int rox = up * hkx / scaling, roy = up * hky / scaling;
+    std::stable_sort(zones.begin(), zones.end(), [](SearchZone const& a, SearchZone const& b) { return a.volume() < b.volume(); });
+    // dyadic / prefiltered data is not integer-valued: go straight to the float64 matcher there
+    ctx->forced_path = (saved_force != VWGPU_PATH_NONE) ? saved_force : ((level > 0 || filtered) ? VWGPU_PATH_GENERIC_F64 : VWGPU_PATH_NONE);
+    const DevImg Lv = lp[level], Rv = rp[level];
+    for (SearchZone const& z : zones) {
+      const IBox lr(z.region.x0 + rox - hkx, z.region.y0 + roy - hky, z.region.x1 + rox + hkx, z.region.y1 + roy + hky);
+      const IBox rr(lr.x0 + z.range.x0, lr.y0 + z.range.y0, lr.x1 + z.range.x0 + z.range.dx(), lr.y1 + z.range.y0 + z.range.dy());
+      const double next = P->seconds_per_op * ((double)lr.width() * lr.height() * z.range.width() * z.range.height());
+      if (P->corr_timeout > 0 && estim + next > P->corr_timeout) break;
+      estim += next;
+      const int zw = z.region.dx(), zh = z.region.dy(), sx = z.range.dx(), sy = z.range.dy();
+      if (zw <= 0 || zh <= 0 || sx <= 0 || sy <= 0) continue;
+      // the crops normally lie inside the level images; edge-extend into scratch when rounding makes them stick out
+      const float* lptr; ptrdiff_t lstr; const float* rptr; ptrdiff_t rstr;
+      const int rneed_w = lr.dx() + sx - 1, rneed_h = lr.dy() + sy - 1;
+      if (lr.x0 >= 0 && lr.y0 >= 0 && lr.x1 <= Lv.w && lr.y1 <= Lv.h) { lptr = Lv.p + (size_t)lr.y0 * Lv.w + lr.x0; lstr = Lv.w; }
+      else {
+        hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(lr.dx(), lr.dy()), kBlk, 0, st, Lv.p, Lv.w, Lv.w, Lv.h, lr.x0, lr.y0, tmp_a, lr.dx(), lr.dy());
+        lptr = tmp_a; lstr = lr.dx();
+      }
+      if (rr.x0 >= 0 && rr.y0 >= 0 && rr.x0 + rneed_w <= Rv.w && rr.y0 + rneed_h <= Rv.h) { rptr = Rv.p + (size_t)rr.y0 * Rv.w + rr.x0; rstr = Rv.w; }
+      else {
+        hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(rneed_w, rneed_h), kBlk, 0, st, Rv.p, Rv.w, Rv.w, Rv.h, rr.x0, rr.y0, tmp_b, rneed_w, rneed_h);
+        rptr = tmp_b; rstr = rneed_w;
+      }
+      int32_t* zout = disp + ((size_t)z.region.y0 * dw + z.region.x0) * 3;
+      rc = vwgpu_calc_disparity_dev(ctx, P->cost_type, lptr, lr.dx(), lr.dy(), lstr, rptr, rneed_w, rneed_h, rstr, kx, ky, sx, sy, zout, dw);
+      if (rc) { ctx->forced_path = saved_force; return rc; }
+      if (P->consistency_threshold >= 0 && last) {                    // R->L run + L/R check (:654-694)
+        const double next2 = P->seconds_per_op * ((double)rr.width() * rr.height() * z.range.width() * z.range.height());
+        if (P->corr_timeout > 0 && estim + next2 > P->corr_timeout) break;
+        estim += next2;
+        const int aw = rr.dx(), ah = rr.dy();                          // "left" of this run: the right crop (edge-extended)
+        const int bw2 = aw + sx - 1, bh2 = ah + sy - 1;                // "right": the left image from (lr.min - s)
+        hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(aw, ah), kBlk, 0, st, Rv.p, Rv.w, Rv.w, Rv.h, rr.x0, rr.y0, tmp_b, aw, ah);
+        hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(bw2, bh2), kBlk, 0, st, Lv.p, Lv.w, Lv.w, Lv.h, lr.x0 - sx, lr.y0 - sy, tmp_a, bw2, bh2);
+        const int rlw = aw - kx + 1, rlh = ah - ky + 1;
+        rc = vwgpu_calc_disparity_dev(ctx, P->cost_type, tmp_b, aw, ah, aw, tmp_a, bw2, bh2, bw2, kx, ky, sx, sy, rl, rlw);
+        if (rc) { ctx->forced_path = saved_force; return rc; }
+        hipLaunchKernelGGL(add_offset_kernel, grid2(rlw, rlh), kBlk, 0, st, rl, rlw, rlw, rlh, -sx, -sy);
+        rc = vwgpu_launch_lr_check(ctx, zout, zw, zh, dw, rl, rlw, rlh, rlw, P->consistency_threshold);
+        if (rc) { ctx->forced_path = saved_force; return rc; }
+      }
+      hipLaunchKernelGGL(add_offset_kernel, grid2(zw, zh), kBlk, 0, st, zout, dw, zw, zh, z.range.x0, z.range.y0);
+    }
+    ctx->forced_path = saved_force;
+    // clean-up filters (:702-744)
+    if (P->filter_half_kernel > 0) {
+      rc = vwgpu_launch_disparity_filter(ctx, disp, dw, dh, P->filter_half_kernel, P->filter_half_kernel, 3.0, 0.5, !last, padded, disp2);
+      if (rc) return rc;
+      std::swap(disp, disp2);
+      rc = vwgpu_launch_disparity_mask(ctx, disp, dw, dh, lmp[level].p, rmp[level].p, rmp[level].w, rmp[level].h);
+      if (rc) return rc;
+    }
+    // zone refinement (:754-799): the scheduler is data dependent host logic
+    if (!last) {
+      host_disp.resize((size_t)dw * dh * 3);
+      VWGPU_HIP(ctx, hipMemcpyAsync(host_disp.data(), disp, host_disp.size() * 4, hipMemcpyDeviceToHost, st));
+      VWGPU_HIP(ctx, hipStreamSynchronize(st));
+      zones.clear();
+      vwgpu::subdivide_regions(host_disp.data(), dw, dh, kx, ky, zones);
+      const IBox scale_search(0, 0, rp[level - 1].w - lp[level - 1].w, rp[level - 1].h - lp[level - 1].h);
+      const IBox next_size(0, 0, lmp[level - 1].w, lmp[level - 1].h);
+      for (SearchZone& z : zones) {
+        z.region.scale(2);
+        z.region.clip(next_size);
+        z.range.scale(2);
+        z.range.expand(2);
+        z.range.clip(scale_search);
+        if (z.range.empty()) z.range = IBox(0, 0, search.width(), search.height());
+      }
+    }
+  }
+  if (dw != bw || dh != bh) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "PyramidCorrelation: Solved disparity doesn't match requested bbox size.");
+  hipLaunchKernelGGL(finish_kernel, grid2(bw, bh), kBlk, 0, st, disp, bw, bh, search.x0, search.y0, out, os);
+  VWGPU_HIP(ctx, hipGetLastError());
+  return VWGPU_OK;
+}
+
+// ---- extern "C" entry points ------------------------------------------------------------------------------------
+
+extern "C" {
+
+int vwgpu_subdivide_regions(const int32_t* disp, int w, int h, int kx, int ky, int32_t* zones, int cap) {
+  if (!disp || w <= 0 || h <= 0 || kx < 1 || ky < 1 || cap < 0 || (cap && !zones)) return VWGPU_ERR_ARGUMENT;
+  std::vector<SearchZone> list;
+  vwgpu::subdivide_regions(disp, w, h, kx, ky, list);
+  int n = 0;
+  for (SearchZone const& z : list) {
+    if (n < cap) {
+      int32_t* o = zones + (size_t)n * 8;
+      o[0] = z.region.x0; o[1] = z.region.y0; o[2] = z.region.x1; o[3] = z.region.y1;
+      o[4] = z.range.x0; o[5] = z.range.y0; o[6] = z.range.x1; o[7] = z.range.y1;
+    }
+    ++n;
+  }
+  return n;
+}
+
+int vwgpu_disparity_filter_dev(vwgpu_ctx* ctx, const int32_t* d_src, int w, int h, int hh, int hv,
+                               double pthr, double rthr, int cleanup, int32_t* d_dst) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  ctx->err.clear();
+  if (!d_src || !d_dst || w <= 0 || h <= 0 || d_src == d_dst) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "rm_outliers_using_thresh: bad image arguments");
+  if (hh <= 0 || hv <= 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "RmOutliersFunc: half kernel sizes must be non-zero.");
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  int32_t* padded = nullptr;
+  if (cleanup) {
+    int rc = vwgpu_arena_reserve(ctx, &ctx->pyr, (size_t)(w + 2) * (h + 2) * 12);
+    if (rc) return rc;
+    padded = static_cast<int32_t*>(ctx->pyr.base);
+  }
+  return vwgpu_launch_disparity_filter(ctx, d_src, w, h, hh, hv, pthr, rthr, cleanup != 0, padded, d_dst);
+}
+
+int vwgpu_disparity_filter(vwgpu_ctx* ctx, const int32_t* src, int w, int h, int hh, int hv,
+                           double pthr, double rthr, int cleanup, int32_t* dst) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  if (!src || !dst || w <= 0 || h <= 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "rm_outliers_using_thresh: bad image arguments");
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t nb = vwgpu_align_up((size_t)w * h * 12, 256);
+  int rc = vwgpu_arena_reserve(ctx, &ctx->staging, 2 * nb);
+  if (rc) return rc;
+  int32_t* a = static_cast<int32_t*>(ctx->staging.base);
+  int32_t* b = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->staging.base) + nb);
+  VWGPU_HIP(ctx, hipMemcpyAsync(a, src, (size_t)w * h * 12, hipMemcpyHostToDevice, ctx->stream));
+  rc = vwgpu_disparity_filter_dev(ctx, a, w, h, hh, hv, pthr, rthr, cleanup, b);
+  if (rc) return rc;
+  VWGPU_HIP(ctx, hipMemcpyAsync(dst, b, (size_t)w * h * 12, hipMemcpyDeviceToHost, ctx->stream));
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VWGPU_OK;
+}
+
+int vwgpu_disparity_mask_dev(vwgpu_ctx* ctx, int32_t* d_disp, int w, int h, const uint8_t* m1, const uint8_t* m2, int rmw, int rmh) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  ctx->err.clear();
+  if (!d_disp || !m1 || !m2 || w <= 0 || h <= 0 || rmw <= 0 || rmh <= 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "disparity_mask: bad image arguments");
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  return vwgpu_launch_disparity_mask(ctx, d_disp, w, h, m1, m2, rmw, rmh);
+}
+
+int vwgpu_disparity_mask(vwgpu_ctx* ctx, int32_t* disp, int w, int h, const uint8_t* m1, const uint8_t* m2, int rmw, int rmh) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  if (!disp || !m1 || !m2 || w <= 0 || h <= 0 || rmw <= 0 || rmh <= 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "disparity_mask: bad image arguments");
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t db = vwgpu_align_up((size_t)w * h * 12, 256), ab = vwgpu_align_up((size_t)w * h, 256), bb = vwgpu_align_up((size_t)rmw * rmh, 256);
+  int rc = vwgpu_arena_reserve(ctx, &ctx->staging, db + ab + bb);
+  if (rc) return rc;
+  char* base = static_cast<char*>(ctx->staging.base);
+  int32_t* d = reinterpret_cast<int32_t*>(base);
+  uint8_t* a = reinterpret_cast<uint8_t*>(base + db);
+  uint8_t* b = reinterpret_cast<uint8_t*>(base + db + ab);
+  VWGPU_HIP(ctx, hipMemcpyAsync(d, disp, (size_t)w * h * 12, hipMemcpyHostToDevice, ctx->stream));
+  VWGPU_HIP(ctx, hipMemcpyAsync(a, m1, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
+  VWGPU_HIP(ctx, hipMemcpyAsync(b, m2, (size_t)rmw * rmh, hipMemcpyHostToDevice, ctx->stream));
+  rc = vwgpu_launch_disparity_mask(ctx, d, w, h, a, b, rmw, rmh);
+  if (rc) return rc;
+  VWGPU_HIP(ctx, hipMemcpyAsync(disp, d, (size_t)w * h * 12, hipMemcpyDeviceToHost, ctx->stream));
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VWGPU_OK;
+}
+
+static int check_pyramid_args(vwgpu_ctx* ctx, const void* l, int lw, int lh, const void* r, int rw, int rh,
+                              const vwgpu_pyramid_params* P, int bw, int bh, const void* out) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  ctx->err.clear();
+  if (!l || !r || !out || !P || lw <= 0 || lh <= 0 || rw <= 0 || rh <= 0 || bw <= 0 || bh <= 0)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate: empty image / tile or null pointer");
+  if (P->kernel_x < 1 || P->kernel_y < 1 || P->kernel_x % 2 != 1 || P->kernel_y % 2 != 1)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate: Kernel input not sized with odd values.");
+  if (P->search_max_x <= P->search_min_x || P->search_max_y <= P->search_min_y)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "PyramidCorrelationView: Invalid search region: (%d,%d)-(%d,%d); a box of zero height is empty (use height >= 1)",
+                      P->search_min_x, P->search_min_y, P->search_max_x, P->search_max_y);
+  if (P->cost_type < VWGPU_ABSOLUTE_DIFFERENCE || P->cost_type > VWGPU_CROSS_CORRELATION)
+    return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: cost type %d is not a block-matching cost", P->cost_type);
+  if (P->algorithm != 0) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: only VW_CORRELATION_BM is implemented (algorithm %d)", P->algorithm);
+  if (P->blob_filter_area > 0) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: blob filter is not implemented");
+  if (P->max_pyramid_levels < 0 || P->filter_half_kernel < 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate: negative level / filter size");
+  return VWGPU_OK;
+}
+
+int vwgpu_pyramid_correlate_dev(vwgpu_ctx* ctx, const float* d_left, int lw, int lh, ptrdiff_t ls,
+                                const float* d_right, int rw, int rh, ptrdiff_t rs,
+                                const uint8_t* d_lmask, ptrdiff_t lms, const uint8_t* d_rmask, ptrdiff_t rms,
+                                const vwgpu_pyramid_params* P, int bx, int by, int bw, int bh, float* d_out, ptrdiff_t os) {
+  int rc = check_pyramid_args(ctx, d_left, lw, lh, d_right, rw, rh, P, bw, bh, d_out);
+  if (rc) return rc;
+  if (ls == 0) ls = lw;
+  if (rs == 0) rs = rw;
+  if (lms == 0) lms = lw;
+  if (rms == 0) rms = rw;
+  if (os == 0) os = bw;
+  if (ls < lw || rs < rw || lms < lw || rms < rw || os < bw) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate: row stride smaller than row width");
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  return vwgpu_pyramid_correlate_impl(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, d_lmask, lms, d_rmask, rms, P, bx, by, bw, bh, d_out, os);
+}
+
+int vwgpu_pyramid_correlate(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t ls,
+                            const float* right, int rw, int rh, ptrdiff_t rs,
+                            const uint8_t* lmask, ptrdiff_t lms, const uint8_t* rmask, ptrdiff_t rms,
+                            const vwgpu_pyramid_params* P, int bx, int by, int bw, int bh, float* out, ptrdiff_t os) {
+  int rc = check_pyramid_args(ctx, left, lw, lh, right, rw, rh, P, bw, bh, out);
+  if (rc) return rc;
+  if (ls == 0) ls = lw;
+  if (rs == 0) rs = rw;
+  if (lms == 0) lms = lw;
+  if (rms == 0) rms = rw;
+  if (os == 0) os = bw;
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t lb = vwgpu_align_up((size_t)lw * lh * 4, 256), rb = vwgpu_align_up((size_t)rw * rh * 4, 256);
+  const size_t lmb = vwgpu_align_up((size_t)lw * lh, 256), rmb = vwgpu_align_up((size_t)rw * rh, 256), ob = vwgpu_align_up((size_t)bw * bh * 12, 256);
+  rc = vwgpu_arena_reserve(ctx, &ctx->staging, lb + rb + lmb + rmb + ob);
+  if (rc) return rc;
+  char* base = static_cast<char*>(ctx->staging.base);
+  float* d_l = reinterpret_cast<float*>(base);
+  float* d_r = reinterpret_cast<float*>(base + lb);
+  uint8_t* d_lm = reinterpret_cast<uint8_t*>(base + lb + rb);
+  uint8_t* d_rm = reinterpret_cast<uint8_t*>(base + lb + rb + lmb);
+  float* d_o = reinterpret_cast<float*>(base + lb + rb + lmb + rmb);
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_l, (size_t)lw * 4, left, (size_t)ls * 4, (size_t)lw * 4, lh, hipMemcpyHostToDevice, ctx->stream));
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_r, (size_t)rw * 4, right, (size_t)rs * 4, (size_t)rw * 4, rh, hipMemcpyHostToDevice, ctx->stream));
+  if (lmask) VWGPU_HIP(ctx, hipMemcpy2DAsync(d_lm, (size_t)lw, lmask, (size_t)lms, (size_t)lw, lh, hipMemcpyHostToDevice, ctx->stream));
+  if (rmask) VWGPU_HIP(ctx, hipMemcpy2DAsync(d_rm, (size_t)rw, rmask, (size_t)rms, (size_t)rw, rh, hipMemcpyHostToDevice, ctx->stream));
+  rc = vwgpu_pyramid_correlate_impl(ctx, d_l, lw, lh, lw, d_r, rw, rh, rw, lmask ? d_lm : nullptr, lw, rmask ? d_rm : nullptr, rw,
+                                    P, bx, by, bw, bh, d_o, bw);
+  if (rc) return rc;
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(out, (size_t)os * 12, d_o, (size_t)bw * 12, (size_t)bw * 12, bh, hipMemcpyDeviceToHost, ctx->stream));
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VWGPU_OK;
+}
+
+}  // extern "C"

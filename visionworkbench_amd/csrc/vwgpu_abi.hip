@@ -89,6 +89,7 @@ void vwgpu_destroy(vwgpu_ctx* ctx) {
   if (ctx->flags.base) (void)hipFree(ctx->flags.base);
   if (ctx->filt.base) (void)hipFree(ctx->filt.base);
   if (ctx->misc.base) (void)hipFree(ctx->misc.base);
+  if (ctx->pyr.base) (void)hipFree(ctx->pyr.base);
   if (ctx->staging.base) (void)hipFree(ctx->staging.base);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;

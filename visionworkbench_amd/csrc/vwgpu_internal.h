@@ -41,6 +41,7 @@ struct vwgpu_ctx {
   vwgpu_arena staging;   // device copies of host images for the host-pointer entry points
   vwgpu_arena filt;      // intermediate image of composite filters (prefilter_image)
   vwgpu_arena misc;      // small device words (disparity range of parabola_subpixel)
+  vwgpu_arena pyr;       // pyramids, masks and per-level disparities of one pyramid_correlate tile
   int num_cu = 256;
 };
 
@@ -120,3 +121,13 @@ int vwgpu_launch_disparity_range(vwgpu_ctx* ctx, const float* disp3f, int w, int
 int vwgpu_launch_parabola(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t dstride_px,
                           const float* lras, int lrw, const float* rras, int rrw, int range_minx, int range_miny,
                           int kx, int ky, float* out3f, ptrdiff_t ostride_px);
+
+// pyramid.hip
+int vwgpu_launch_disparity_filter(vwgpu_ctx* ctx, const int32_t* src, int w, int h, int hh, int hv, double pthr, double rthr,
+                                  bool cleanup, int32_t* tmp_padded, int32_t* dst);
+int vwgpu_launch_disparity_mask(vwgpu_ctx* ctx, int32_t* d, int w, int h, const uint8_t* m1, const uint8_t* m2, int m2w, int m2h);
+int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t ls,
+                                 const float* right, int rw, int rh, ptrdiff_t rs,
+                                 const uint8_t* lmask, ptrdiff_t lms, const uint8_t* rmask, ptrdiff_t rms,
+                                 const vwgpu_pyramid_params* P, int bx, int by, int bw, int bh,
+                                 float* out, ptrdiff_t os);

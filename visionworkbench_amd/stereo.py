@@ -134,4 +134,150 @@ def parabola_subpixel(disparity, left_image, right_image, prefilter_mode, prefil
     return out
 
 
-__all__ = ["calc_disparity", "cross_corr_consistency_check", "parabola_subpixel", "BBox2i", "CostFunctionType"]
+def _filter_call(name, disparity, hh, hv, pthr, rthr, cleanup, ctx):
+    if disparity.ndim != 3 or disparity.shape[2] != 3:
+        raise ArgumentErr("%s: disparity must be (rows, cols, 3) int32" % name)
+    h, w = disparity.shape[:2]
+    if hh <= 0 or hv <= 0:
+        raise ArgumentErr("RmOutliersFunc: half kernel sizes must be non-zero.")
+    ctx = _ctx_for(disparity, ctx)
+    lib = ctx._lib
+    if _is_tensor(disparity):
+        if not disparity.is_cuda or disparity.dtype != torch.int32:
+            raise ArgumentErr("%s: int32 CUDA tensor required" % name)
+        d = disparity.contiguous()
+        out = torch.empty_like(d)
+        ctx.set_stream(torch.cuda.current_stream(d.device).cuda_stream)
+        ctx.check(lib.vwgpu_disparity_filter_dev(ctx._h, d.data_ptr(), w, h, int(hh), int(hv), float(pthr), float(rthr),
+                                                 int(cleanup), out.data_ptr()))
+        return out
+    d = np.ascontiguousarray(disparity, np.int32)
+    out = np.empty_like(d)
+    ctx.check(lib.vwgpu_disparity_filter(ctx._h, d.ctypes.data, w, h, int(hh), int(hv), float(pthr), float(rthr),
+                                         int(cleanup), out.ctypes.data))
+    return out
+
+
+def rm_outliers_using_thresh(disparity, half_h_kernel, half_v_kernel, pixel_threshold, rejection_threshold, ctx=None):
+    """vw::stereo::rm_outliers_using_thresh (src/vw/Stereo/DisparityMap.h:387-399), rasterised over the whole image
+    with the reference's ConstantEdgeExtension.  disparity: (rows, cols, 3) int32 PixelMask<Vector2i>."""
+    return _filter_call("rm_outliers_using_thresh", disparity, half_h_kernel, half_v_kernel, pixel_threshold,
+                        rejection_threshold, 0, ctx)
+
+
+def disparity_cleanup_using_thresh(disparity, h_half_kernel, v_half_kernel, threshold, rejection_threshold, ctx=None):
+    """vw::stereo::disparity_cleanup_using_thresh (src/vw/Stereo/DisparityMap.h:427-441): the filter above followed
+    by a second pass with the reference's fixed (1, 1, 3.0, 0.20)."""
+    return _filter_call("disparity_cleanup_using_thresh", disparity, h_half_kernel, v_half_kernel, threshold,
+                        rejection_threshold, 1, ctx)
+
+
+def disparity_mask(disparity, left_mask, right_mask, ctx=None):
+    """vw::stereo::disparity_mask (src/vw/Stereo/DisparityMap.h:236-253): invalidate pixels whose source or target
+    falls on masked data.  Returns a new image; masks are (rows, cols) uint8 (0 = no data)."""
+    if disparity.ndim != 3 or disparity.shape[2] != 3 or tuple(disparity.shape[:2]) != tuple(left_mask.shape):
+        raise ArgumentErr("disparity_mask: left mask must match the disparity image")
+    h, w = left_mask.shape
+    rmh, rmw = right_mask.shape
+    ctx = _ctx_for(disparity, ctx)
+    lib = ctx._lib
+    if _is_tensor(disparity):
+        if not (disparity.is_cuda and left_mask.is_cuda and right_mask.is_cuda) or disparity.dtype != torch.int32:
+            raise ArgumentErr("disparity_mask: int32 / uint8 CUDA tensors required")
+        out = disparity.contiguous().clone()
+        m1, m2 = left_mask.contiguous(), right_mask.contiguous()
+        ctx.set_stream(torch.cuda.current_stream(out.device).cuda_stream)
+        ctx.check(lib.vwgpu_disparity_mask_dev(ctx._h, out.data_ptr(), w, h, m1.data_ptr(), m2.data_ptr(), rmw, rmh))
+        return out
+    out = np.array(disparity, np.int32, order="C", copy=True)
+    m1 = np.ascontiguousarray(left_mask, np.uint8)
+    m2 = np.ascontiguousarray(right_mask, np.uint8)
+    ctx.check(lib.vwgpu_disparity_mask(ctx._h, out.ctypes.data, w, h, m1.ctypes.data, m2.ctypes.data, rmw, rmh))
+    return out
+
+
+def subdivide_regions(disparity, kernel_size):
+    """vw::stereo::subdivide_regions(disparity, bounding_box(disparity), list, kernel_size)
+    (src/vw/Stereo/Correlation.cc:139-328).  Host logic (the zone scheduler of pyramid_correlate) on a numpy
+    PixelMask<Vector2i> image; returns [(region BBox2i, disparity_range BBox2i), ...] in the reference's order."""
+    from . import _lib
+    lib = _lib.load()
+    d = np.ascontiguousarray(disparity, np.int32)
+    if d.ndim != 3 or d.shape[2] != 3:
+        raise ArgumentErr("subdivide_regions: disparity must be (rows, cols, 3) int32")
+    h, w = d.shape[:2]
+    cap = 1024
+    while True:
+        buf = np.empty((cap, 8), np.int32)
+        n = lib.vwgpu_subdivide_regions(d.ctypes.data, w, h, int(kernel_size[0]), int(kernel_size[1]), buf.ctypes.data, cap)
+        if n < 0:
+            raise ArgumentErr("subdivide_regions: bad arguments")
+        if n <= cap:
+            break
+        cap = n
+    return [(BBox2i.from_corners(z[0:2], z[2:4]), BBox2i.from_corners(z[4:6], z[6:8])) for z in buf[:n].tolist()]
+
+
+def pyramid_correlate(left, right, left_mask, right_mask, prefilter_mode, prefilter_width, search_region, kernel_size,
+                      cost_type, corr_timeout=0, seconds_per_op=0.0, consistency_threshold=-1.0,
+                      min_consistency_level=0, filter_half_kernel=0, max_pyramid_levels=5, algorithm=0,
+                      collar_size=0, sgm_subpixel_mode=0, sgm_search_buffer=(0, 0), memory_limit_mb=0,
+                      blob_filter_area=0, bbox=None, ctx=None):
+    """vw::stereo::pyramid_correlate (src/vw/Stereo/CorrelationView.h:195-230) rasterised over `bbox`
+    (default: the whole left image as ONE tile, i.e. PyramidCorrelationView::prerasterize(bounding_box),
+    src/vw/Stereo/CorrelationView.cc:273-886).  The reference rasterises per block-cache tile; pass the same
+    bbox to reproduce a tile.
+
+    left / right: (rows, cols) float32; masks: (rows, cols) uint8 or None; search_region: BBox2i (half open).
+    Returns (bbox rows, bbox cols, 3) float32 PixelMask<Vector2f> {dx, dy, valid}.
+    VW_CORRELATION_BM only (algorithm == 0); collar_size / sgm_* / memory_limit_mb are SGM-side arguments."""
+    from ._lib import PyramidParams
+    if left.ndim != 2 or right.ndim != 2:
+        raise ArgumentErr("pyramid_correlate: images must be 2-D (rows, cols)")
+    lh, lw = left.shape
+    rh, rw = right.shape
+    if bbox is None:
+        bbox = BBox2i(0, 0, lw, lh)
+    (bx, by), (bx1, by1) = bbox.min, bbox.max
+    P = PyramidParams(int(prefilter_mode), float(prefilter_width),
+                      int(search_region.min[0]), int(search_region.min[1]), int(search_region.max[0]), int(search_region.max[1]),
+                      int(kernel_size[0]), int(kernel_size[1]), int(cost_type), int(corr_timeout), float(seconds_per_op),
+                      float(consistency_threshold), int(min_consistency_level), int(filter_half_kernel),
+                      int(max_pyramid_levels), int(algorithm), int(blob_filter_area))
+    ctx = _ctx_for(left, ctx)
+    lib = ctx._lib
+    bw, bh = bx1 - bx, by1 - by
+    if _is_tensor(left):
+        if not (left.is_cuda and right.is_cuda) or left.dtype != torch.float32 or right.dtype != torch.float32:
+            raise ArgumentErr("pyramid_correlate: float32 CUDA tensors required (no CPU path)")
+        l, r = left.contiguous(), right.contiguous()
+        lm = left_mask.contiguous() if left_mask is not None else None
+        rm = right_mask.contiguous() if right_mask is not None else None
+        for m, shp in ((lm, l.shape), (rm, r.shape)):
+            if m is not None and (m.dtype != torch.uint8 or tuple(m.shape) != tuple(shp) or not m.is_cuda):
+                raise ArgumentErr("pyramid_correlate: masks must be uint8 CUDA tensors of the image size")
+        out = torch.empty((max(bh, 0), max(bw, 0), 3), dtype=torch.float32, device=l.device)
+        ctx.set_stream(torch.cuda.current_stream(l.device).cuda_stream)
+        ctx.check(lib.vwgpu_pyramid_correlate_dev(ctx._h, l.data_ptr(), lw, lh, 0, r.data_ptr(), rw, rh, 0,
+                                                  lm.data_ptr() if lm is not None else None, 0,
+                                                  rm.data_ptr() if rm is not None else None, 0,
+                                                  ctypes.byref(P), bx, by, bw, bh, out.data_ptr(), 0))
+        return out
+    l = np.ascontiguousarray(left, np.float32)
+    r = np.ascontiguousarray(right, np.float32)
+    lm = np.ascontiguousarray(left_mask, np.uint8) if left_mask is not None else None
+    rm = np.ascontiguousarray(right_mask, np.uint8) if right_mask is not None else None
+    for m, shp in ((lm, l.shape), (rm, r.shape)):
+        if m is not None and tuple(m.shape) != tuple(shp):
+            raise ArgumentErr("pyramid_correlate: masks must have the image size")
+    out = np.empty((max(bh, 0), max(bw, 0), 3), np.float32)
+    ctx.check(lib.vwgpu_pyramid_correlate(ctx._h, l.ctypes.data, lw, lh, 0, r.ctypes.data, rw, rh, 0,
+                                          lm.ctypes.data if lm is not None else None, 0,
+                                          rm.ctypes.data if rm is not None else None, 0,
+                                          ctypes.byref(P), bx, by, bw, bh, out.ctypes.data, 0))
+    return out
+
+
+__all__ = ["calc_disparity", "cross_corr_consistency_check", "parabola_subpixel", "rm_outliers_using_thresh",
+           "disparity_cleanup_using_thresh", "disparity_mask", "subdivide_regions", "pyramid_correlate",
+           "BBox2i", "CostFunctionType"]
