@@ -1,0 +1,37 @@
+"""Device-resident timings of the wider path (config 3 NCC + parabola, one pyramid_correlate tile).  GPU box only."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from visionworkbench_amd import stereo, synth, core
+from visionworkbench_amd.core import BBox2i
+
+
+def t(fn, n=3):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+L, R, _ = synth.stereo_pair(W, W, 129, 1)
+Lg, Rg = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+box = BBox2i(0, 0, W, W)
+for cost, k in [(0, 7), (1, 7), (2, 11), (0, 11), (0, 13)]:
+    ms = t(lambda: stereo.calc_disparity(cost, Lg, Rg, box, (129, 1), (k, k)))
+    print("calc_disparity cost=%d k=%d: %.2f ms  %.1f Gpix/s path=%d" % (cost, k, ms, (W - k + 1) ** 2 / ms / 1e6, core.default_context(0).last_path()))
+d = stereo.calc_disparity(0, Lg, Rg, box, (129, 1), (11, 11))
+df = torch.zeros((W, W, 3), dtype=torch.float32, device="cuda")
+df[5:5 + d.shape[0], 5:5 + d.shape[1]] = d.float()
+df[..., 2] = (df[..., 2] != 0).float()
+ms = t(lambda: stereo.parabola_subpixel(df, Lg, Rg, 0, 0.0, (11, 11)))
+print("parabola_subpixel k=11: %.2f ms  %.1f Gpix/s" % (ms, W * W / ms / 1e6))
+for tile in (1024, 2048):
+    if tile > W: continue
+    bb = BBox2i(256, 256, tile, tile)
+    for cost, k, pf in [(2, 11, 0), (0, 7, 0), (0, 7, 2)]:
+        ms = t(lambda: stereo.pyramid_correlate(Lg, Rg[:, 64:64 + W].contiguous(), None, None, pf, 1.4, BBox2i.from_corners((-64, -1), (64, 1)),
+                                                (k, k), cost, consistency_threshold=2, filter_half_kernel=5, max_pyramid_levels=5, bbox=bb), n=2)
+        print("pyramid_correlate tile=%d cost=%d k=%d pf=%d: %.2f ms  %.2f Gpix/s" % (tile, cost, k, pf, ms, tile * tile / ms / 1e6))

@@ -1,0 +1,288 @@
+// bm_zones.hip — all search zones of one pyramid level in ONE launch.
+//
+// PyramidCorrelationView::prerasterize runs calc_disparity once per SearchParam zone
+// (src/vw/Stereo/CorrelationView.cc:596-700); at level 0 of a 1024^2 tile that is ~2000 zones of ~32x32 pixels with
+// ~5x5 disparities each — as separate launches they cost ~600 ms of launch latency.  Here a zone is a row of a device
+// table and a workgroup serves one 32x32 output tile of one zone:
+//   * the tile's left patch and (per dy, per chunk of dx) right patch are staged in LDS with coordinates CLAMPED into
+//     the level image — exactly the ConstantEdgeExtension crops the reference hands to calc_disparity when a padded
+//     zone sticks out of the level image (CorrelationView.cc:607-616,660-668);
+//   * per disparity: horizontal kx-sums of the float cost elements (widened to float64, CostFunctions.h:72-141) into
+//     an LDS plane, then vertical ky-sums — the box sum of fast_box_sum (Algorithms.h:43-129) in a different but
+//     exact order (float data summed in float64: every partial sum is representable unless the window spans > 2^20 in
+//     magnitude, see bm_generic.hip);
+//   * best / worst / first-wins compare chain and the best == worst validity rule of best_of_search_convolution
+//     (Correlation.cc:91-133), dy outer / dx inner like the reference;
+//   * NCC: cost *= sqrt(precA * precB) with the 1/box-sum(img^2) images (CostFunctions.h:214-231) precomputed over the
+//     (clamped) union of all zone origins of the level.
+// A second tiny kernel applies the per-zone L/R consistency check (Correlate.cc:1441-1502) and the
+// `+= zone.disparity_range().min()` offset (CorrelationView.cc:696-697) for every zone at once.
+//
+// Roofline: LDS-bandwidth bound (~2*kx 4-byte + ky 8-byte LDS reads per pixel*disparity); the point of this kernel is
+// launch count, the level-0 work of a refined pyramid is only ~25 disparities per pixel.
+#include <algorithm>
+#include <vector>
+
+#include "vwgpu_internal.h"
+
+namespace {
+
+constexpr int ZT = 32;            // output tile side
+constexpr int ZTHREADS = 256;
+
+template <int COST>
+__device__ __forceinline__ double zcost(float a, float b) {
+  if (COST == VWGPU_CROSS_CORRELATION) return (double)(a * b);
+  if (COST == VWGPU_SQUARED_DIFFERENCE) { float d = a - b; return (double)(d * d); }
+  return (double)fabsf(a - b);
+}
+template <int COST>
+__device__ __forceinline__ bool zbetter(double c, double q) {
+  return COST == VWGPU_CROSS_CORRELATION ? (c > q) : (c < q);
+}
+
+struct PrecView {           // 1 / box-sum(img^2) over origins [x0, x0+w) x [y0, y0+h)
+  const double* p; int x0, y0, w, h;
+};
+
+// prec(x, y) = 1.0 / sum_{ky x kx} img(clamp)^2 for window origins (x0 + i, y0 + j)
+__global__ void zone_precision_kernel(const float* __restrict__ img, int w, int h, int kx, int ky,
+                                      double* __restrict__ prec, int x0, int y0, int pw, int ph) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= pw || j >= ph) return;
+  double s = 0.0;
+  for (int b = 0; b < ky; ++b) {
+    int yy = y0 + j + b; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+    const float* row = img + (size_t)yy * w;
+    for (int a = 0; a < kx; ++a) {
+      int xx = x0 + i + a; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+      const float v = row[xx];
+      s += (double)(v * v);
+    }
+  }
+  prec[(size_t)j * pw + i] = 1.0 / s;
+}
+
+template <int COST>
+__global__ void __launch_bounds__(ZTHREADS)
+bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __restrict__ B, int bw, int bh,
+                int kx, int ky, const vwgpu_zone_task* __restrict__ zones, const int2* __restrict__ tiles,
+                int sxc, PrecView pa, PrecView pb, int32_t* __restrict__ out) {
+  extern __shared__ char smem[];
+  const int PW = ZT + kx - 1, PH = ZT + ky - 1, RW = PW + sxc - 1;
+  float* Lp = reinterpret_cast<float*>(smem);                    // PH x PW
+  float* Rp = Lp + PH * PW;                                      // PH x RW
+  double* H = reinterpret_cast<double*>(smem + (((size_t)(PH * PW + PH * RW) * 4 + 7) & ~size_t(7)));   // 2 x PH x ZT
+
+  const int2 tl = tiles[blockIdx.x];
+  const vwgpu_zone_task z = zones[tl.x];
+  const int ox = (tl.y & 0xffff) * ZT, oy = (tl.y >> 16) * ZT;
+  const int tw = min(ZT, z.zw - ox), th = min(ZT, z.zh - oy);
+  const int pw = tw + kx - 1, ph = th + ky - 1;
+  const int t = threadIdx.x;
+  const int c = t & 31, y0 = (t >> 5) * 4;
+
+  for (int i = t; i < ph * pw; i += ZTHREADS) {
+    const int r = i / pw, q = i - r * pw;
+    int xx = z.ax + ox + q; xx = xx < 0 ? 0 : (xx >= aw ? aw - 1 : xx);
+    int yy = z.ay + oy + r; yy = yy < 0 ? 0 : (yy >= ah ? ah - 1 : yy);
+    Lp[r * PW + q] = A[(size_t)yy * aw + xx];
+  }
+  double best[4], worst[4], lprec[4];
+  int bdx[4], bdy[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    best[m] = worst[m] = 0.0; bdx[m] = bdy[m] = 0; lprec[m] = 0.0;
+    if (COST == VWGPU_CROSS_CORRELATION && c < tw && y0 + m < th)
+      lprec[m] = pa.p[(size_t)(z.ay + oy + y0 + m - pa.y0) * pa.w + (z.ax + ox + c - pa.x0)];
+  }
+  int hb = 0;
+  for (int dy = 0; dy < z.sy; ++dy) {
+    for (int dx0 = 0; dx0 < z.sx; dx0 += sxc) {
+      const int nd = min(sxc, z.sx - dx0);
+      const int rwid = pw + nd - 1;
+      __syncthreads();                                            // everyone done with the previous right patch
+      for (int i = t; i < ph * rwid; i += ZTHREADS) {
+        const int r = i / rwid, q = i - r * rwid;
+        int xx = z.bx + ox + dx0 + q; xx = xx < 0 ? 0 : (xx >= bw ? bw - 1 : xx);
+        int yy = z.by + oy + dy + r; yy = yy < 0 ? 0 : (yy >= bh ? bh - 1 : yy);
+        Rp[r * RW + q] = B[(size_t)yy * bw + xx];
+      }
+      __syncthreads();
+      for (int d = 0; d < nd; ++d) {
+        double* Hc = H + hb * (PH * ZT);
+        for (int i = t; i < ph * ZT; i += ZTHREADS) {             // horizontal sums
+          const int r = i >> 5, q = i & 31;
+          if (q < tw) {
+            const float* lp = Lp + r * PW + q;
+            const float* rp = Rp + r * RW + q + d;
+            double s = 0.0;
+            for (int a = 0; a < kx; ++a) s += zcost<COST>(lp[a], rp[a]);
+            Hc[r * ZT + q] = s;
+          }
+        }
+        __syncthreads();
+        if (c < tw) {
+          const int dx = dx0 + d;
+          const bool first = (dx == 0 && dy == 0);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int y = y0 + m;
+            if (y < th) {
+              double s = 0.0;
+              for (int b = 0; b < ky; ++b) s += Hc[(y + b) * ZT + c];
+              if (COST == VWGPU_CROSS_CORRELATION)
+                s *= sqrt(lprec[m] * pb.p[(size_t)(z.by + oy + y + dy - pb.y0) * pb.w + (z.bx + ox + c + dx - pb.x0)]);
+              if (first) { best[m] = worst[m] = s; }
+              else if (zbetter<COST>(s, best[m])) { best[m] = s; bdx[m] = dx; bdy[m] = dy; }
+              else if (!zbetter<COST>(s, worst[m])) { worst[m] = s; }
+            }
+          }
+        }
+        hb ^= 1;                                                  // next disparity writes the other plane
+      }
+    }
+  }
+  if (c < tw) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int y = y0 + m;
+      if (y < th) {
+        int32_t* o = out + ((size_t)z.out_off + (size_t)(oy + y) * z.out_stride + ox + c) * 3;
+        o[0] = bdx[m] + z.addx; o[1] = bdy[m] + z.addy;
+        o[2] = (best[m] == worst[m]) ? 0 : 0x7fffffff;
+      }
+    }
+  }
+}
+
+// Per zone: cross_corr_consistency_check(crop(disparity, zone), rl_zone, thr), then += (addx, addy).
+__global__ void zone_lr_kernel(const vwgpu_zone_task* __restrict__ zones, const int2* __restrict__ tiles,
+                               int32_t* __restrict__ l2r, const int32_t* __restrict__ r2l, float thr) {
+  const int2 tl = tiles[blockIdx.x];
+  const vwgpu_zone_task z = zones[tl.x];          // zw/zh/out_* = the L->R zone; bx/by = size of its R->L image;
+  const int ox = (tl.y & 0xffff) * ZT, oy = (tl.y >> 16) * ZT;   // ax = element offset of that image in r2l
+  const int c = ox + (threadIdx.x & 31);
+  for (int r = oy + (threadIdx.x >> 5); r < min(oy + ZT, z.zh); r += ZTHREADS / 32) {
+    if (c >= z.zw) continue;
+    int32_t* p = l2r + ((size_t)z.out_off + (size_t)r * z.out_stride + c) * 3;
+    const int dx = p[0], dy = p[1], v = p[2];
+    const int x = c + dx, y = r + dy;
+    bool keep = false;
+    if (x >= 0 && x < z.bx && y >= 0 && y < z.by) {
+      const int32_t* q = r2l + ((size_t)z.ax + (size_t)y * z.bx + x) * 3;
+      if (v != 0 && q[2] != 0) {
+        const float diff = (float)fmax(fabs((double)(dx + q[0])), fabs((double)(dy + q[1])));
+        keep = thr >= diff;
+      }
+    }
+    p[0] = dx + z.addx; p[1] = dy + z.addy;
+    if (!keep) p[2] = 0;
+  }
+}
+
+int upload_tables(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, std::vector<int2> const& tiles,
+                  const vwgpu_zone_task** d_zones, const int2** d_tiles) {
+  const size_t zb = vwgpu_align_up((size_t)n * sizeof(vwgpu_zone_task), 256), tb = tiles.size() * sizeof(int2);
+  // the previous launch may still be reading the table: alternate between two halves of the arena
+  const size_t half = vwgpu_align_up(zb + tb, 4096);
+  if (ctx->ztab.cap < 2 * half) {
+    int rc = vwgpu_arena_reserve(ctx, &ctx->ztab, 2 * half + (1 << 20));
+    if (rc) return rc;
+  }
+  ctx->ztab_parity ^= 1;
+  char* base = static_cast<char*>(ctx->ztab.base) + (ctx->ztab_parity ? ctx->ztab.cap / 2 : 0);
+  VWGPU_HIP(ctx, hipMemcpyAsync(base, zones, (size_t)n * sizeof(vwgpu_zone_task), hipMemcpyHostToDevice, ctx->stream));
+  VWGPU_HIP(ctx, hipMemcpyAsync(base + zb, tiles.data(), tb, hipMemcpyHostToDevice, ctx->stream));
+  *d_zones = reinterpret_cast<const vwgpu_zone_task*>(base);
+  *d_tiles = reinterpret_cast<const int2*>(base + zb);
+  return VWGPU_OK;
+}
+
+void build_tiles(const vwgpu_zone_task* zones, int n, std::vector<int2>& tiles) {
+  tiles.clear();
+  for (int i = 0; i < n; ++i) {
+    const int nx = (zones[i].zw + ZT - 1) / ZT, ny = (zones[i].zh + ZT - 1) / ZT;
+    for (int ty = 0; ty < ny; ++ty)
+      for (int tx = 0; tx < nx; ++tx) tiles.push_back(make_int2(i, tx | (ty << 16)));
+  }
+}
+
+}  // namespace
+
+bool vwgpu_bm_zones_supported(int kx, int ky) {
+  // LDS: left patch + right patch with at least 8 disparities per chunk + two sum planes within 64 KB
+  const size_t PW = ZT + kx - 1, PH = ZT + ky - 1;
+  return (PH * PW + PH * (PW + 7)) * 4 + 2 * PH * ZT * 8 + 16 <= 64 * 1024;
+}
+
+int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
+                          int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out) {
+  if (n <= 0) return VWGPU_OK;
+  if (!vwgpu_bm_zones_supported(kx, ky)) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "bm_zones: kernel %dx%d too large", kx, ky);
+  std::vector<int2> tiles;
+  build_tiles(zones, n, tiles);
+  if (tiles.empty()) return VWGPU_OK;
+  int max_sx = 1;
+  int ax0 = INT32_MAX, ay0 = INT32_MAX, ax1 = INT32_MIN, ay1 = INT32_MIN, bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = INT32_MIN, by1 = INT32_MIN;
+  for (int i = 0; i < n; ++i) {
+    const vwgpu_zone_task& z = zones[i];
+    if (z.zw <= 0 || z.zh <= 0) continue;
+    max_sx = std::max(max_sx, z.sx);
+    ax0 = std::min(ax0, z.ax); ay0 = std::min(ay0, z.ay); ax1 = std::max(ax1, z.ax + z.zw); ay1 = std::max(ay1, z.ay + z.zh);
+    bx0 = std::min(bx0, z.bx); by0 = std::min(by0, z.by);
+    bx1 = std::max(bx1, z.bx + z.zw + z.sx - 1); by1 = std::max(by1, z.by + z.zh + z.sy - 1);
+  }
+  const size_t PW = ZT + kx - 1, PH = ZT + ky - 1;
+  const size_t fixed = PH * PW * 4 + 2 * PH * ZT * 8 + 16;
+  int sxc = (int)std::min<size_t>((size_t)max_sx, ((64 * 1024 - fixed) / (PH * 4)) - PW + 1);
+  if (sxc < 1) sxc = 1;
+  const size_t lds = (((PH * PW + PH * (PW + sxc - 1)) * 4 + 7) & ~size_t(7)) + 2 * PH * ZT * 8;
+
+  PrecView pa{nullptr, 0, 0, 0, 0}, pb{nullptr, 0, 0, 0, 0};
+  if (cost_type == VWGPU_CROSS_CORRELATION) {
+    pa.x0 = ax0; pa.y0 = ay0; pa.w = ax1 - ax0; pa.h = ay1 - ay0;
+    pb.x0 = bx0; pb.y0 = by0; pb.w = bx1 - bx0; pb.h = by1 - by0;
+    const size_t na = vwgpu_align_up((size_t)pa.w * pa.h * 8, 256), nb = vwgpu_align_up((size_t)pb.w * pb.h * 8, 256);
+    int rc = vwgpu_arena_reserve(ctx, &ctx->scratch, na + nb);
+    if (rc) return rc;
+    double* da = static_cast<double*>(ctx->scratch.base);
+    double* db = reinterpret_cast<double*>(static_cast<char*>(ctx->scratch.base) + na);
+    vwgpu_prof_scope ps(ctx, "zone_precision");
+    hipLaunchKernelGGL(zone_precision_kernel, dim3((pa.w + 63) / 64, (pa.h + 3) / 4), dim3(64, 4), 0, ctx->stream, A, aw, ah, kx, ky, da, pa.x0, pa.y0, pa.w, pa.h);
+    hipLaunchKernelGGL(zone_precision_kernel, dim3((pb.w + 63) / 64, (pb.h + 3) / 4), dim3(64, 4), 0, ctx->stream, B, bw, bh, kx, ky, db, pb.x0, pb.y0, pb.w, pb.h);
+    pa.p = da; pb.p = db;
+  }
+  const vwgpu_zone_task* dz; const int2* dt;
+  int rc = upload_tables(ctx, zones, n, tiles, &dz, &dt);
+  if (rc) return rc;
+  vwgpu_prof_scope ps(ctx, "bm_zones");
+  const dim3 grd((unsigned)tiles.size()), blk(ZTHREADS);
+  switch (cost_type) {
+    case VWGPU_CROSS_CORRELATION:
+      hipLaunchKernelGGL(bm_zones_kernel<VWGPU_CROSS_CORRELATION>, grd, blk, lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, dt, sxc, pa, pb, out);
+      break;
+    case VWGPU_SQUARED_DIFFERENCE:
+      hipLaunchKernelGGL(bm_zones_kernel<VWGPU_SQUARED_DIFFERENCE>, grd, blk, lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, dt, sxc, pa, pb, out);
+      break;
+    default:
+      hipLaunchKernelGGL(bm_zones_kernel<VWGPU_ABSOLUTE_DIFFERENCE>, grd, blk, lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, dt, sxc, pa, pb, out);
+      break;
+  }
+  VWGPU_HIP(ctx, hipGetLastError());
+  return VWGPU_OK;
+}
+
+int vwgpu_launch_zone_lr(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, int32_t* l2r, const int32_t* r2l, float thr) {
+  if (n <= 0) return VWGPU_OK;
+  std::vector<int2> tiles;
+  build_tiles(zones, n, tiles);
+  if (tiles.empty()) return VWGPU_OK;
+  const vwgpu_zone_task* dz; const int2* dt;
+  int rc = upload_tables(ctx, zones, n, tiles, &dz, &dt);
+  if (rc) return rc;
+  vwgpu_prof_scope ps(ctx, "zone_lr_check");
+  hipLaunchKernelGGL(zone_lr_kernel, dim3((unsigned)tiles.size()), dim3(ZTHREADS), 0, ctx->stream, dz, dt, l2r, r2l, thr);
+  VWGPU_HIP(ctx, hipGetLastError());
+  return VWGPU_OK;
+}

@@ -313,6 +313,49 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     // dyadic / prefiltered data is not integer-valued: go straight to the float64 matcher there
     ctx->forced_path = (saved_force != VWGPU_PATH_NONE) ? saved_force : ((level > 0 || filtered) ? VWGPU_PATH_GENERIC_F64 : VWGPU_PATH_NONE);
     const DevImg Lv = lp[level], Rv = rp[level];
+    const bool lr_active = P->consistency_threshold >= 0 && last;
+    // One launch for all zones of the level (bm_zones.hip) unless the kernel is too large for its LDS tiles, or the
+    // level is a single big zone (max_pyramid_levels = 0: that is plain calc_disparity and has faster kernels).
+    bool batched = vwgpu_bm_zones_supported(kx, ky) && saved_force == VWGPU_PATH_NONE;
+    if (batched && zones.size() == 1 && (double)zones[0].region.dx() * zones[0].region.dy() * zones[0].range.dx() * zones[0].range.dy() > 3.2e7)
+      batched = false;
+    if (batched) {
+      std::vector<vwgpu_zone_task> t1, t2, t3;
+      size_t rl_pixels = 0;
+      for (SearchZone const& z : zones) {
+        const IBox lr(z.region.x0 + rox - hkx, z.region.y0 + roy - hky, z.region.x1 + rox + hkx, z.region.y1 + roy + hky);
+        const IBox rr(lr.x0 + z.range.x0, lr.y0 + z.range.y0, lr.x1 + z.range.x0 + z.range.dx(), lr.y1 + z.range.y0 + z.range.dy());
+        const double next = P->seconds_per_op * ((double)lr.width() * lr.height() * z.range.width() * z.range.height());
+        if (P->corr_timeout > 0 && estim + next > P->corr_timeout) break;
+        estim += next;
+        const int zw = z.region.dx(), zh = z.region.dy(), sx = z.range.dx(), sy = z.range.dy();
+        if (zw <= 0 || zh <= 0 || sx <= 0 || sy <= 0) continue;
+        if (zw > 65535 * 32 || zh > 65535 * 32) { ctx->forced_path = saved_force; return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: zone too large"); }
+        vwgpu_zone_task a{lr.x0, lr.y0, rr.x0, rr.y0, zw, zh, sx, sy, z.region.y0 * dw + z.region.x0, dw,
+                          lr_active ? 0 : z.range.x0, lr_active ? 0 : z.range.y0};
+        t1.push_back(a);
+        if (lr_active) {
+          const double next2 = P->seconds_per_op * ((double)rr.width() * rr.height() * z.range.width() * z.range.height());
+          if (P->corr_timeout > 0 && estim + next2 > P->corr_timeout) break;
+          estim += next2;
+          const int rlw = rr.dx() - kx + 1, rlh = rr.dy() - ky + 1;
+          vwgpu_zone_task b{rr.x0, rr.y0, lr.x0 - sx, lr.y0 - sy, rlw, rlh, sx, sy, (int)rl_pixels, rlw, -sx, -sy};
+          t2.push_back(b);
+          vwgpu_zone_task c{(int)rl_pixels, 0, rlw, rlh, zw, zh, sx, sy, a.out_off, dw, z.range.x0, z.range.y0};
+          t3.push_back(c);
+          rl_pixels += (size_t)rlw * rlh;
+          if (rl_pixels > (size_t)INT32_MAX / 2) { ctx->forced_path = saved_force; return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: tile too large for the L/R check buffers"); }
+        }
+      }
+      ctx->forced_path = saved_force;
+      if (lr_active && rl_pixels) { if ((rc = vwgpu_arena_reserve(ctx, &ctx->zrl, rl_pixels * 12))) return rc; }
+      if ((rc = vwgpu_launch_bm_zones(ctx, P->cost_type, Lv.p, Lv.w, Lv.h, Rv.p, Rv.w, Rv.h, kx, ky, t1.data(), (int)t1.size(), disp))) return rc;
+      if (lr_active) {
+        int32_t* rlbuf = static_cast<int32_t*>(ctx->zrl.base);
+        if ((rc = vwgpu_launch_bm_zones(ctx, P->cost_type, Rv.p, Rv.w, Rv.h, Lv.p, Lv.w, Lv.h, kx, ky, t2.data(), (int)t2.size(), rlbuf))) return rc;
+        if ((rc = vwgpu_launch_zone_lr(ctx, t3.data(), (int)t3.size(), disp, rlbuf, P->consistency_threshold))) return rc;
+      }
+    } else
     for (SearchZone const& z : zones) {
       const IBox lr(z.region.x0 + rox - hkx, z.region.y0 + roy - hky, z.region.x1 + rox + hkx, z.region.y1 + roy + hky);
       const IBox rr(lr.x0 + z.range.x0, lr.y0 + z.range.y0, lr.x1 + z.range.x0 + z.range.dx(), lr.y1 + z.range.y0 + z.range.dy());

@@ -90,6 +90,8 @@ void vwgpu_destroy(vwgpu_ctx* ctx) {
   if (ctx->filt.base) (void)hipFree(ctx->filt.base);
   if (ctx->misc.base) (void)hipFree(ctx->misc.base);
   if (ctx->pyr.base) (void)hipFree(ctx->pyr.base);
+  if (ctx->ztab.base) (void)hipFree(ctx->ztab.base);
+  if (ctx->zrl.base) (void)hipFree(ctx->zrl.base);
   if (ctx->staging.base) (void)hipFree(ctx->staging.base);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;

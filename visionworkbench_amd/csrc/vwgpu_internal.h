@@ -42,6 +42,9 @@ struct vwgpu_ctx {
   vwgpu_arena filt;      // intermediate image of composite filters (prefilter_image)
   vwgpu_arena misc;      // small device words (disparity range of parabola_subpixel)
   vwgpu_arena pyr;       // pyramids, masks and per-level disparities of one pyramid_correlate tile
+  vwgpu_arena ztab;      // zone / tile tables of the batched zone kernels (two halves, alternating)
+  int ztab_parity = 0;
+  vwgpu_arena zrl;       // right-to-left disparity images of all zones of pyramid level 0
   int num_cu = 256;
 };
 
@@ -121,6 +124,21 @@ int vwgpu_launch_disparity_range(vwgpu_ctx* ctx, const float* disp3f, int w, int
 int vwgpu_launch_parabola(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t dstride_px,
                           const float* lras, int lrw, const float* rras, int rrw, int range_minx, int range_miny,
                           int kx, int ky, float* out3f, ptrdiff_t ostride_px);
+
+// bm_zones.hip — one row per search zone (or per R->L zone image); see the kernels for the field meaning
+struct vwgpu_zone_task {
+  int ax, ay;          // origin of the zone's input crop in image A (may lie outside: coordinates are clamped)
+  int bx, by;          // origin in image B of the window for disparity (0,0)
+  int zw, zh;          // output size
+  int sx, sy;          // search volume
+  int out_off;         // pixel offset of the zone's first output pixel in the output buffer
+  int out_stride;      // pixels
+  int addx, addy;      // added to the winning disparity index of every pixel
+};
+bool vwgpu_bm_zones_supported(int kx, int ky);
+int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
+                          int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out);
+int vwgpu_launch_zone_lr(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, int32_t* l2r, const int32_t* r2l, float thr);
 
 // pyramid.hip
 int vwgpu_launch_disparity_filter(vwgpu_ctx* ctx, const int32_t* src, int w, int h, int hh, int hv, double pthr, double rthr,
