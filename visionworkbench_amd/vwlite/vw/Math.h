@@ -44,7 +44,8 @@ typedef Vector<double, 2> Vector2;
 class BBox2i {
   Vector2i m_min, m_max;
 public:
-  BBox2i() : m_min(0x7fffffff, 0x7fffffff), m_max(-0x7fffffff - 1, -0x7fffffff - 1) {}
+  // default = empty, with the reference's +-(INT32_MAX - 1) corners (src/vw/Math/BBox.tcc:37-45)
+  BBox2i() : m_min(0x7ffffffe, 0x7ffffffe), m_max(-0x7ffffffe, -0x7ffffffe) {}
   BBox2i(Vector2i const& mn, Vector2i const& mx) : m_min(mn), m_max(mx) {}
   BBox2i(int32 x, int32 y, int32 w, int32 h) : m_min(x, y), m_max(x + w, y + h) {}
   Vector2i& min() { return m_min; }  Vector2i const& min() const { return m_min; }

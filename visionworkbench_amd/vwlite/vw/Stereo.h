@@ -5,14 +5,26 @@
 //   cross_corr_consistency_check src/vw/Stereo/Correlate.h:52-58     (impl Correlate.cc:1441-1502)
 //   correlate                    legacy single-level entry, signature recovered from
 //                                src/vw/Stereo/tests/TestCorrelationView.cxx:79-82,213-215
+//   pyramid_correlate            src/vw/Stereo/CorrelationView.h:195-230 (PyramidCorrelationView :35-190, BM algorithm)
+//   parabola_subpixel            src/vw/Stereo/ParabolaSubpixelView.h:112-117
+//   prefilter_image              src/vw/Stereo/PreFilter.h:76-95
+//   rm_outliers_using_thresh / disparity_cleanup_using_thresh / disparity_mask
+//                                src/vw/Stereo/DisparityMap.h:387-441, 236-253
+//   SearchParam, subdivide_regions, calc_seconds_per_op   src/vw/Stereo/Correlation.h:66-122
 // Errors: the C ABI's status codes become the reference's exception types (src/vw/Core/Exception.h:225-253).
 // Threading: one engine context per (host thread x GPU), created lazily — the reference calls these functions
 // concurrently from its tile threads (src/vw/Image/ImageIO.h:228-251).
 #ifndef VWLITE_STEREO_H
 #define VWLITE_STEREO_H
 
+#include <chrono>
+#include <cmath>
 #include <cstdlib>
+#include <utility>
+#include <vector>
 
+#include "Engine.h"
+#include "Filter.h"
 #include "Image.h"
 #include "vwgpu.h"
 
@@ -24,31 +36,13 @@ enum CostFunctionType {                  // src/vw/Stereo/CostFunctions.h:143-14
 };
 enum PrefilterModeType { PREFILTER_NONE = 0, PREFILTER_MEANSUB = 1, PREFILTER_LOG = 2 };   // PrefilterEnum.h:24-28
 
-namespace detail {
-struct ThreadContext {
-  vwgpu_ctx* ctx = nullptr;
-  ~ThreadContext() { if (ctx) vwgpu_destroy(ctx); }
+enum CorrelationAlgorithm {              // src/vw/Stereo/CorrelationAlgorithms.h:29-35
+  VW_CORRELATION_BM = 0, VW_CORRELATION_SGM = 1, VW_CORRELATION_MGM = 2, VW_CORRELATION_FINAL_MGM = 3, VW_CORRELATION_OTHER = 4
 };
-inline vwgpu_ctx* thread_context() {
-  static thread_local ThreadContext tc;
-  if (!tc.ctx) {
-    const char* dev = std::getenv("VWGPU_DEVICE");
-    int rc = vwgpu_create(&tc.ctx, dev ? std::atoi(dev) : 0);
-    if (rc != VWGPU_OK)
-      vw_throw(LogicErr() << "vwgpu_create failed: " << vwgpu_strerror(rc) << " (no GPU; there is no CPU fallback)");
-  }
-  return tc.ctx;
-}
-inline void check(vwgpu_ctx* ctx, int rc) {
-  if (rc == VWGPU_OK) return;
-  std::string msg = vwgpu_last_error(ctx);
-  if (msg.empty()) msg = vwgpu_strerror(rc);
-  switch (rc) {
-    case VWGPU_ERR_ARGUMENT: vw_throw(ArgumentErr() << msg);
-    case VWGPU_ERR_NOIMPL: vw_throw(NoImplErr() << msg);
-    default: vw_throw(LogicErr() << msg);
-  }
-}
+
+namespace detail {
+using engine::thread_context;
+using engine::check;
 }  // namespace detail
 
 /// calc_disparity — same signature and semantics as the reference (Correlation.h:50-57).
@@ -131,6 +125,202 @@ correlate(ImageView<PixelGray<float>> const& left, ImageView<PixelGray<float>> c
   }
   for (int32 r = 0; r < H; ++r) for (int32 c = 0; c < W; ++c) l2r(c, r).child() += search_volume.min();
   return l2r;
+}
+
+/// prefilter_image — rasterised (PreFilter.h:76-95).
+inline ImageView<PixelGray<float>>
+prefilter_image(ImageView<PixelGray<float>> const& image, PrefilterModeType prefilter_mode, float prefilter_width) {
+  ImageView<PixelGray<float>> out(image.cols(), image.rows());
+  if (image.cols() == 0 || image.rows() == 0) return out;
+  vwgpu_ctx* ctx = detail::thread_context();
+  detail::check(ctx, vwgpu_prefilter_image(ctx, reinterpret_cast<const float*>(image.data()), image.cols(), image.rows(), 0,
+                                           (int)prefilter_mode, prefilter_width, reinterpret_cast<float*>(out.data()), 0));
+  return out;
+}
+
+/// parabola_subpixel — the rasterised ParabolaSubpixelView (ParabolaSubpixelView.h:112-117).
+inline ImageView<PixelMask<Vector2f>>
+parabola_subpixel(ImageViewRef<PixelMask<Vector2f>> const& disparity,
+                  ImageViewRef<PixelGray<float>> const& left_image, ImageViewRef<PixelGray<float>> const& right_image,
+                  PrefilterModeType prefilter_mode, float prefilter_width, Vector2i const& kernel_size) {
+  VW_ASSERT(disparity.cols() == left_image.cols() && disparity.rows() == left_image.rows(),
+            ArgumentErr() << "SubpixelView: Disparity image must match left image.");   // ParabolaSubpixelView.h:67-69
+  ImageView<PixelMask<Vector2f>> d = disparity, out(disparity.cols(), disparity.rows());
+  ImageView<PixelGray<float>> l = left_image, r = right_image;
+  if (d.cols() == 0 || d.rows() == 0) return out;
+  vwgpu_ctx* ctx = detail::thread_context();
+  detail::check(ctx, vwgpu_parabola_subpixel(ctx, reinterpret_cast<const float*>(d.data()), d.cols(), d.rows(), 0,
+                                             reinterpret_cast<const float*>(l.data()), 0,
+                                             reinterpret_cast<const float*>(r.data()), r.cols(), r.rows(), 0,
+                                             (int)prefilter_mode, prefilter_width, kernel_size[0], kernel_size[1],
+                                             reinterpret_cast<float*>(out.data()), 0));
+  return out;
+}
+
+namespace detail {
+inline ImageView<PixelMask<Vector2i>> disparity_filter(ImageView<PixelMask<Vector2i>> const& d, int32 hh, int32 hv,
+                                                       double pthr, double rthr, int cleanup) {
+  ImageView<PixelMask<Vector2i>> out(d.cols(), d.rows());
+  if (d.cols() == 0 || d.rows() == 0) return out;
+  vwgpu_ctx* ctx = thread_context();
+  check(ctx, vwgpu_disparity_filter(ctx, reinterpret_cast<const int32_t*>(d.data()), d.cols(), d.rows(), hh, hv, pthr, rthr, cleanup,
+                                    reinterpret_cast<int32_t*>(out.data())));
+  return out;
+}
+}  // namespace detail
+
+/// rm_outliers_using_thresh — rasterised over the whole image (DisparityMap.h:403-414).
+template <class ViewT>
+ImageView<PixelMask<Vector2i>> rm_outliers_using_thresh(ImageViewBase<ViewT> const& disparity_map, int32 half_h_kernel, int32 half_v_kernel,
+                                                        double pixel_threshold, double rejection_threshold) {
+  VW_ASSERT(half_h_kernel > 0 && half_v_kernel > 0, ArgumentErr() << "RmOutliersFunc: half kernel sizes must be non-zero.");
+  ImageView<PixelMask<Vector2i>> d = disparity_map.impl();
+  return detail::disparity_filter(d, half_h_kernel, half_v_kernel, pixel_threshold, rejection_threshold, 0);
+}
+/// disparity_cleanup_using_thresh — two passes, the second with (1,1,3.0,0.20) (DisparityMap.h:422-441).
+template <class ViewT>
+ImageView<PixelMask<Vector2i>> disparity_cleanup_using_thresh(ImageViewBase<ViewT> const& disparity_map, int32 h_half_kernel, int32 v_half_kernel,
+                                                              double pixel_threshold, double rejection_threshold) {
+  VW_ASSERT(h_half_kernel > 0 && v_half_kernel > 0, ArgumentErr() << "RmOutliersFunc: half kernel sizes must be non-zero.");
+  ImageView<PixelMask<Vector2i>> d = disparity_map.impl();
+  return detail::disparity_filter(d, h_half_kernel, v_half_kernel, pixel_threshold, rejection_threshold, 1);
+}
+/// disparity_mask — rasterised (DisparityMap.h:236-253); masks are uint8 images, 0 = no data.
+template <class ViewT, class M1, class M2>
+ImageView<PixelMask<Vector2i>> disparity_mask(ImageViewBase<ViewT> const& disparity_map, ImageViewBase<M1> const& left_mask,
+                                              ImageViewBase<M2> const& right_mask) {
+  ImageView<PixelMask<Vector2i>> d = copy(disparity_map.impl());
+  ImageView<uint8> m1 = left_mask.impl(), m2 = right_mask.impl();
+  VW_ASSERT(d.cols() == m1.cols() && d.rows() == m1.rows(), ArgumentErr() << "disparity_mask: input and left mask are not same dimensions.");
+  if (d.cols() == 0 || d.rows() == 0) return d;
+  vwgpu_ctx* ctx = detail::thread_context();
+  detail::check(ctx, vwgpu_disparity_mask(ctx, reinterpret_cast<int32_t*>(d.data()), d.cols(), d.rows(), m1.data(), m2.data(), m2.cols(), m2.rows()));
+  return d;
+}
+
+/// SearchParam / subdivide_regions — the zone scheduler (Correlation.h:66-91,118-122).
+struct SearchParam : public std::pair<BBox2i, BBox2i> {
+  SearchParam(BBox2i const& image_region, BBox2i const& disparity_range) : std::pair<BBox2i, BBox2i>(image_region, disparity_range) {}
+  BBox2i& image_region() { return this->first; }            BBox2i const& image_region() const { return this->first; }
+  BBox2i& disparity_range() { return this->second; }        BBox2i const& disparity_range() const { return this->second; }
+  double search_volume() const {
+    return (double)first.width() * (double)first.height() * (double)second.width() * (double)second.height();
+  }
+};
+struct SearchParamLessThan {
+  bool operator()(SearchParam const& A, SearchParam const& B) const { return A.search_volume() < B.search_volume(); }
+};
+inline bool subdivide_regions(ImageView<PixelMask<Vector2i>> const& disparity, BBox2i const& current_bbox,
+                              std::vector<SearchParam>& list, Vector2i const& kernel_size, int32 /*fail_count*/ = 0) {
+  // the engine scheduler works on a whole image: hand it the crop and shift the zones back
+  ImageView<PixelMask<Vector2i>> d = crop(disparity, current_bbox);
+  if (d.cols() == 0 || d.rows() == 0) return true;
+  std::vector<int32_t> zones(8 * 1024);
+  int n = vwgpu_subdivide_regions(reinterpret_cast<const int32_t*>(d.data()), d.cols(), d.rows(), kernel_size[0], kernel_size[1],
+                                  zones.data(), (int)zones.size() / 8);
+  if (n > (int)zones.size() / 8) {
+    zones.resize((size_t)n * 8);
+    n = vwgpu_subdivide_regions(reinterpret_cast<const int32_t*>(d.data()), d.cols(), d.rows(), kernel_size[0], kernel_size[1], zones.data(), n);
+  }
+  VW_ASSERT(n >= 0, ArgumentErr() << "subdivide_regions: bad arguments");
+  for (int i = 0; i < n; ++i) {
+    const int32_t* z = &zones[(size_t)i * 8];
+    list.push_back(SearchParam(BBox2i(Vector2i(z[0], z[1]) + current_bbox.min(), Vector2i(z[2], z[3]) + current_bbox.min()),
+                               BBox2i(Vector2i(z[4], z[5]), Vector2i(z[6], z[7]))));
+  }
+  return true;
+}
+
+/// calc_seconds_per_op (Correlation.cc:382-436): time a fake calc_disparity and divide by region x search volume.
+/// The reference grows the problem until one call takes a second; on the GPU that would need tens of GB, so the
+/// loop stops at 20 ms or 2048^2 — the figure only feeds pyramid_correlate's corr_timeout estimate.
+inline double calc_seconds_per_op(CostFunctionType cost_type, Vector2i const& kernel_size) {
+  double elapsed = -1.0, seconds_per_op = -1.0;
+  int lsize = 100;
+  while (elapsed < 0.02 && lsize < 2048) {
+    lsize = (int)std::ceil(lsize * 1.2) + std::max(kernel_size[0], kernel_size[1]);
+    ImageView<PixelGray<float>> fake_left(lsize, lsize), fake_right(lsize + lsize / 5, lsize + lsize / 5);
+    for (int row = 0; row < fake_left.rows(); ++row) for (int col = 0; col < fake_left.cols(); ++col) fake_left(col, row) = float(col % 2 + 2 * (row % 5));
+    for (int row = 0; row < fake_right.rows(); ++row) for (int col = 0; col < fake_right.cols(); ++col) fake_right(col, row) = float(3 * (col % 7) + row % 3);
+    const Vector2i search(std::max(lsize / 5, 1), std::max(lsize / 5, 1));
+    calc_disparity(cost_type, fake_left, fake_right, bounding_box(fake_left), search, kernel_size);   // warm-up (allocations)
+    const auto t0 = std::chrono::steady_clock::now();
+    calc_disparity(cost_type, fake_left, fake_right, bounding_box(fake_left), search, kernel_size);
+    elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    seconds_per_op = elapsed / ((double)lsize * lsize * search[0] * search[1]);
+  }
+  return seconds_per_op;
+}
+
+/// PyramidCorrelationView — lazy like the reference's (CorrelationView.h:35-190): nothing runs until a tile is
+/// requested through prerasterize(bbox) / rasterize, and every tile is independent (CorrelationView.cc:273-886).
+class PyramidCorrelationView : public ImageViewBase<PyramidCorrelationView> {
+  ImageView<PixelGray<float>> m_left, m_right;
+  ImageView<uint8> m_left_mask, m_right_mask;
+  vwgpu_pyramid_params m_p;
+public:
+  typedef PixelMask<Vector2f> pixel_type;
+  typedef pixel_type result_type;
+  typedef ImageView<pixel_type> prerasterize_type;
+
+  PyramidCorrelationView(ImageView<PixelGray<float>> const& left, ImageView<PixelGray<float>> const& right,
+                         ImageView<uint8> const& left_mask, ImageView<uint8> const& right_mask, vwgpu_pyramid_params const& p)
+      : m_left(left), m_right(right), m_left_mask(left_mask), m_right_mask(right_mask), m_p(p) {
+    VW_ASSERT(left_mask.cols() == left.cols() && left_mask.rows() == left.rows() &&
+              right_mask.cols() == right.cols() && right_mask.rows() == right.rows(),
+              ArgumentErr() << "PyramidCorrelationView: masks must match their images.");
+  }
+  int32 cols() const { return m_left.cols(); }
+  int32 rows() const { return m_left.rows(); }
+  int32 planes() const { return 1; }
+  pixel_type operator()(int32 /*i*/, int32 /*j*/, int32 /*p*/ = 0) const {
+    vw_throw(NoImplErr() << "PyramidCorrelationView::operator()(....) has not been implemented.");   // CorrelationView.h:166-171
+    return pixel_type();
+  }
+  /// One tile; the returned image is indexed from the tile's own origin (0,0) = bbox.min().
+  ImageView<pixel_type> correlate_tile(BBox2i const& bbox) const {
+    ImageView<pixel_type> out(bbox.width(), bbox.height());
+    if (bbox.empty()) return out;
+    vwgpu_ctx* ctx = detail::thread_context();
+    detail::check(ctx, vwgpu_pyramid_correlate(ctx, reinterpret_cast<const float*>(m_left.data()), m_left.cols(), m_left.rows(), 0,
+                                               reinterpret_cast<const float*>(m_right.data()), m_right.cols(), m_right.rows(), 0,
+                                               m_left_mask.data(), 0, m_right_mask.data(), 0, &m_p,
+                                               bbox.min().x(), bbox.min().y(), bbox.width(), bbox.height(),
+                                               reinterpret_cast<float*>(out.data()), 0));
+    return out;
+  }
+  prerasterize_type prerasterize(BBox2i const& bbox) const { return correlate_tile(bbox); }
+  template <class DestT> void rasterize(DestT const& dest, BBox2i const& bbox) const {
+    ImageView<pixel_type> tile = correlate_tile(bbox);
+    vw::rasterize(tile, dest, BBox2i(0, 0, bbox.width(), bbox.height()));
+  }
+};
+
+/// pyramid_correlate — the reference's argument list (CorrelationView.h:195-230).  VW_CORRELATION_BM only; the SGM-side
+/// arguments (collar_size, sgm_*, memory_limit_mb) are accepted for source compatibility.
+template <class Image1T, class Image2T, class Mask1T, class Mask2T>
+PyramidCorrelationView
+pyramid_correlate(ImageViewBase<Image1T> const& left, ImageViewBase<Image2T> const& right,
+                  ImageViewBase<Mask1T> const& left_mask, ImageViewBase<Mask2T> const& right_mask,
+                  PrefilterModeType prefilter_mode, float prefilter_width,
+                  BBox2i const& search_region, Vector2i const& kernel_size, CostFunctionType cost_type,
+                  int corr_timeout, double seconds_per_op, float consistency_threshold, int min_consistency_level,
+                  int filter_half_kernel, int32 max_pyramid_levels,
+                  CorrelationAlgorithm algorithm = VW_CORRELATION_BM, int collar_size = 0, int /*sgm_subpixel_mode*/ = 0,
+                  Vector2i /*sgm_search_buffer*/ = Vector2i(2, 2), size_t /*memory_limit_mb*/ = 6000, int blob_filter_area = 0) {
+  (void)collar_size;
+  vwgpu_pyramid_params p;
+  p.prefilter_mode = (int)prefilter_mode; p.prefilter_width = prefilter_width;
+  p.search_min_x = search_region.min().x(); p.search_min_y = search_region.min().y();
+  p.search_max_x = search_region.max().x(); p.search_max_y = search_region.max().y();
+  p.kernel_x = kernel_size[0]; p.kernel_y = kernel_size[1];
+  p.cost_type = (int)cost_type; p.corr_timeout = corr_timeout; p.seconds_per_op = seconds_per_op;
+  p.consistency_threshold = consistency_threshold; p.min_consistency_level = min_consistency_level;
+  p.filter_half_kernel = filter_half_kernel; p.max_pyramid_levels = max_pyramid_levels;
+  p.algorithm = (int)algorithm; p.blob_filter_area = blob_filter_area;
+  ImageView<PixelGray<float>> l = pixel_cast<PixelGray<float>>(left.impl()), r = pixel_cast<PixelGray<float>>(right.impl());
+  ImageView<uint8> lm = left_mask.impl(), rm = right_mask.impl();
+  return PyramidCorrelationView(l, r, lm, rm, p);
 }
 
 }  // namespace stereo
