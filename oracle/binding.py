@@ -20,12 +20,14 @@ __all__ = ["build", "lib", "fast_box_sum", "cost_image", "calc_disparity", "calc
            "subsample_mask_by_two", "prefilter_image", "pyramid_smoothing_kernel",
            "EDGE_CONSTANT", "EDGE_ZERO", "PREFILTER_NONE", "PREFILTER_MEANSUB", "PREFILTER_LOG",
            "subdivide_regions", "prefilter_region", "parabola_subpixel", "pyramid_correlate", "disparity_filter",
-           "disparity_mask"]
+           "disparity_mask", "u8_convert", "census_transform", "hamming_distance", "SemiGlobalMatcher", "calc_disparity_sgm",
+           "CENSUS_TRANSFORM", "TERNARY_CENSUS_TRANSFORM", "SUBPIXEL_NONE", "SUBPIXEL_PARABOLA", "SUBPIXEL_LINEAR",
+           "SUBPIXEL_POLY4", "SUBPIXEL_COSINE", "SUBPIXEL_LC_BLEND"]
 
 
 def build(force=False):
     so = os.path.join(_HERE, "libvw_oracle.so")
-    src = [os.path.join(_HERE, f) for f in ("vw_oracle.cc", "vw_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("vw_oracle.cc", "vw_sgm_oracle.cc", "vw_oracle.h", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B" if force else "-s"])
     return so
@@ -57,6 +59,22 @@ def lib():
         _LIB.vwo_pyramid_correlate.argtypes = [P, I, I, P, I, I, P, P, I, F, I, I, I, I, I, I, I, I, D, F, I, I, I, I, I, I, P]
         _LIB.vwo_disparity_filter.argtypes = [P, I, I, I, I, D, D, I]
         _LIB.vwo_disparity_mask.argtypes = [P, I, I, P, P, I, I]
+        Z = ctypes.c_size_t
+        _LIB.vwo_u8_convert.argtypes = [P, I, I, P]
+        _LIB.vwo_census_transform.argtypes = [P, I, I, I, I, I, P]
+        _LIB.vwo_hamming_distance.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
+        _LIB.vwo_sgm_create.argtypes = [I, I, I, I, I, I, I, I, I, I, Z, I, I, I, I]
+        _LIB.vwo_sgm_create.restype = P
+        _LIB.vwo_sgm_destroy.argtypes = [P]
+        _LIB.vwo_sgm_destroy.restype = None
+        _LIB.vwo_sgm_run.argtypes = [P, P, I, I, P, I, I, P, I, I, P, I, I, P, I, I, P, I]
+        _LIB.vwo_sgm_output_size.argtypes = [P, P, P]
+        _LIB.vwo_sgm_subpixel.argtypes = [P, P, P]
+        _LIB.vwo_sgm_buffer_size.argtypes = [P]
+        _LIB.vwo_sgm_buffer_size.restype = Z
+        _LIB.vwo_sgm_read.argtypes = [P, P, P, P, P]
+        _LIB.vwo_sgm_p1p2.argtypes = [P, P, P]
+        _LIB.vwo_calc_disparity_sgm.argtypes = [I, P, I, I, P, I, I, I, I, I, I, I, I, Z, I, P, I, I, P, I, I, P, I, I, P, P, P, P]
     return _LIB
 
 
@@ -264,3 +282,114 @@ def disparity_mask(disp, left_mask, right_mask):
     rm = np.ascontiguousarray(right_mask, np.uint8)
     assert lib().vwo_disparity_mask(_p(d), d.shape[1], d.shape[0], _p(lm), _p(rm), rm.shape[1], rm.shape[0]) == 0
     return d
+
+
+# ---- semi-global matching ---------------------------------------------------------------------------------------------
+
+CENSUS_TRANSFORM, TERNARY_CENSUS_TRANSFORM = 3, 4
+SUBPIXEL_NONE, SUBPIXEL_PARABOLA, SUBPIXEL_LINEAR, SUBPIXEL_POLY4, SUBPIXEL_COSINE, SUBPIXEL_LC_BLEND = range(6)
+
+
+def u8_convert(img):
+    a = np.ascontiguousarray(img, np.float32)
+    out = np.empty(a.shape, np.uint8)
+    assert lib().vwo_u8_convert(_p(a), a.shape[1], a.shape[0], _p(out)) == 0
+    return out
+
+
+def census_transform(img, kernel, ternary=False, threshold=5):
+    a = np.ascontiguousarray(img, np.uint8)
+    out = np.empty((a.shape[0] - kernel + 1, a.shape[1] - kernel + 1), np.uint64)
+    assert lib().vwo_census_transform(_p(a), a.shape[1], a.shape[0], kernel, int(ternary), threshold, _p(out)) == 0
+    return out
+
+
+def hamming_distance(a, b):
+    return lib().vwo_hamming_distance(int(a), int(b))
+
+
+def _opt(a, dtype):
+    if a is None:
+        return None, 0, 0
+    a = np.ascontiguousarray(a, dtype)
+    return a, a.shape[1], a.shape[0]
+
+
+class SemiGlobalMatcher:
+    """SemiGlobalMatcher(cost_type, use_mgm, min_dx, min_dy, max_dx, max_dy, kernel, subpixel, search_buffer,
+    memory_limit_mb, p1, p2, ternary_census_threshold) — src/vw/Stereo/SGM.h:108-121."""
+
+    def __init__(self, cost_type, min_dx, min_dy, max_dx, max_dy, kernel=5, subpixel=SUBPIXEL_LC_BLEND, search_buffer=(2, 2),
+                 memory_limit_mb=6000, p1=0, p2=0, ternary_thr=5, num_threads=1):
+        self._h = lib().vwo_sgm_create(int(cost_type), 0, min_dx, min_dy, max_dx, max_dy, kernel, int(subpixel),
+                                       search_buffer[0], search_buffer[1], memory_limit_mb, p1, p2, ternary_thr, num_threads)
+        if not self._h:
+            raise ValueError("vwo_sgm_create: unsupported cost type / kernel size")
+        self._geom = (min_dx, min_dy, max_dx, max_dy, kernel)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vwo_sgm_destroy(self._h)
+            self._h = None
+
+    def semi_global_matching_func(self, left, right, left_mask=None, right_mask=None, prev_disparity=None):
+        l = np.ascontiguousarray(left, np.uint8)
+        r = np.ascontiguousarray(right, np.uint8)
+        lm, lmw, lmh = _opt(left_mask, np.uint8)
+        rm, rmw, rmh = _opt(right_mask, np.uint8)
+        pd, pw, ph = _opt(prev_disparity, np.int32)
+        out = np.zeros((l.shape[0], l.shape[1], 3), np.int32)
+        rc = lib().vwo_sgm_run(self._h, _p(l), l.shape[1], l.shape[0], _p(r), r.shape[1], r.shape[0],
+                               None if lm is None else _p(lm), lmw, lmh, None if rm is None else _p(rm), rmw, rmh,
+                               None if pd is None else _p(pd), pw, ph, _p(out), l.shape[0] * l.shape[1])
+        if rc:
+            raise ValueError("vwo_sgm_run rc=%d" % rc)
+        ow, oh = ctypes.c_int(), ctypes.c_int()
+        lib().vwo_sgm_output_size(self._h, ctypes.byref(ow), ctypes.byref(oh))
+        self.shape = (oh.value, ow.value)
+        return out.reshape(-1)[:oh.value * ow.value * 3].reshape(oh.value, ow.value, 3).copy()
+
+    def create_disparity_view_subpixel(self, integer_disparity):
+        d = np.ascontiguousarray(integer_disparity, np.int32)
+        out = np.empty(d.shape, np.float32)
+        assert lib().vwo_sgm_subpixel(self._h, _p(d), _p(out)) == 0
+        return out
+
+    def buffers(self):
+        """(bounds (h,w,4) int32, starts (h,w) uint64, cost uint8[n], accum uint16[n]) after a run."""
+        h, w = self.shape
+        n = lib().vwo_sgm_buffer_size(self._h)
+        b = np.empty((h, w, 4), np.int32)
+        s = np.empty((h, w), np.uint64)
+        c = np.empty(n, np.uint8)
+        a = np.empty(n, np.uint16)
+        lib().vwo_sgm_read(self._h, _p(b), _p(s), _p(c), _p(a))
+        return b, s, c, a
+
+    def p1p2(self):
+        a, b = ctypes.c_int(), ctypes.c_int()
+        lib().vwo_sgm_p1p2(self._h, ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+
+def calc_disparity_sgm(cost_type, left, right, search_volume, kernel, subpixel=SUBPIXEL_LC_BLEND, search_buffer=(2, 2),
+                       memory_limit_mb=6000, left_mask=None, right_mask=None, prev_disparity=None, num_threads=1):
+    """calc_disparity_sgm on cropped regions: left (lh, lw) float32, right (lh+sy, lw+sx) float32.
+    Returns (integer disparity (oh, ow, 3) int32, sub-pixel disparity (oh, ow, 3) float32)."""
+    l = np.ascontiguousarray(left, np.float32)
+    r = np.ascontiguousarray(right, np.float32)
+    lm, lmw, lmh = _opt(left_mask, np.uint8)
+    rm, rmw, rmh = _opt(right_mask, np.uint8)
+    pd, pw, ph = _opt(prev_disparity, np.int32)
+    out = np.zeros((l.shape[0], l.shape[1], 3), np.int32)
+    sub = np.zeros((l.shape[0], l.shape[1], 3), np.float32)
+    ow, oh = ctypes.c_int(), ctypes.c_int()
+    rc = lib().vwo_calc_disparity_sgm(int(cost_type), _p(l), l.shape[1], l.shape[0], _p(r), r.shape[1], r.shape[0],
+                                      search_volume[0], search_volume[1], kernel, int(subpixel), search_buffer[0], search_buffer[1],
+                                      memory_limit_mb, num_threads, None if lm is None else _p(lm), lmw, lmh,
+                                      None if rm is None else _p(rm), rmw, rmh, None if pd is None else _p(pd), pw, ph,
+                                      _p(out), _p(sub), ctypes.byref(ow), ctypes.byref(oh))
+    if rc:
+        raise ValueError("vwo_calc_disparity_sgm rc=%d" % rc)
+    n = ow.value * oh.value * 3
+    return (out.reshape(-1)[:n].reshape(oh.value, ow.value, 3).copy(), sub.reshape(-1)[:n].reshape(oh.value, ow.value, 3).copy())

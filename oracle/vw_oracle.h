@@ -17,6 +17,7 @@
  */
 #ifndef VW_ORACLE_H
 #define VW_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -131,6 +132,36 @@ int vwo_pyramid_correlate(const float* left, int lw, int lh, const float* right,
  * (src/vw/Stereo/DisparityMap.h:318-441, 97-253); disp3 in place.  cleanup != 0 adds the second (1,1,3.0,0.20) pass. */
 int vwo_disparity_filter(int32_t* disp3, int w, int h, int half_h, int half_v, double pixel_thr, double rej_thr, int cleanup);
 int vwo_disparity_mask(int32_t* disp3, int w, int h, const uint8_t* lmask, const uint8_t* rmask, int rmw, int rmh);
+
+/* ---- semi-global matching (vw_sgm_oracle.cc) -------------------------------------------------------------------- */
+
+/* u8_convert: min/max stretch to [0,255] with truncation, src/vw/Image/ImageThresh.h:275-286. */
+int vwo_u8_convert(const float* src, int w, int h, uint8_t* dst);
+/* get_census_value_{3x3,5x5,7x7,9x9} / ternary variants at every pixel with a full window
+ * (src/vw/Image/CensusTransform.h:64-340); out is (w-k+1) x (h-k+1) uint64. */
+int vwo_census_transform(const uint8_t* img, int w, int h, int kernel, int ternary, int threshold, uint64_t* out);
+int vwo_hamming_distance(uint64_t a, uint64_t b);          /* src/vw/Math/Functions.h:226-260 */
+
+/* SemiGlobalMatcher (src/vw/Stereo/SGM.h:75-352): create = ctor/set_parameters, run = semi_global_matching_func +
+ * create_disparity_view, subpixel = create_disparity_view_subpixel.  cost_type 3 = CENSUS_TRANSFORM, 4 = TERNARY_CENSUS.
+ * Masks / prev may be NULL.  num_threads only enters the memory-cap check (calc_main_buf_size, SGM.cc:677-731). */
+typedef struct vwo_sgm vwo_sgm;
+vwo_sgm* vwo_sgm_create(int cost_type, int use_mgm, int min_dx, int min_dy, int max_dx, int max_dy, int kernel, int subpixel,
+                        int sbx, int sby, size_t memory_limit_mb, int p1, int p2, int ternary_thr, int num_threads);
+void vwo_sgm_destroy(vwo_sgm* s);
+int vwo_sgm_run(vwo_sgm* s, const uint8_t* left, int lw, int lh, const uint8_t* right, int rw, int rh,
+                const uint8_t* lmask, int lmw, int lmh, const uint8_t* rmask, int rmw, int rmh,
+                const int32_t* prev, int pw, int ph, int32_t* out_disp, int cap_pixels);
+int vwo_sgm_output_size(vwo_sgm* s, int* ow, int* oh);
+int vwo_sgm_subpixel(vwo_sgm* s, const int32_t* int_disp, float* out3f);
+size_t vwo_sgm_buffer_size(vwo_sgm* s);
+int vwo_sgm_read(vwo_sgm* s, int32_t* bounds4, uint64_t* starts, uint8_t* cost, uint16_t* accum);
+int vwo_sgm_p1p2(vwo_sgm* s, int* p1, int* p2);
+/* calc_disparity_sgm (src/vw/Stereo/SGM.cc:167-229) on already cropped regions: left lw x lh, right (lw+sx) x (lh+sy). */
+int vwo_calc_disparity_sgm(int cost_type, const float* left, int lw, int lh, const float* right, int rw, int rh,
+                           int sx, int sy, int kernel, int subpixel, int sbx, int sby, size_t memory_limit_mb, int num_threads,
+                           const uint8_t* lmask, int lmw, int lmh, const uint8_t* rmask, int rmw, int rmh,
+                           const int32_t* prev, int pw, int ph, int32_t* out_disp, float* out_subpixel, int* ow, int* oh);
 
 #ifdef __cplusplus
 }

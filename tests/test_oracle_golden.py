@@ -374,3 +374,87 @@ def test_disparity_mask_known_answer(oracle):
     expect_valid[3, 5] = False
     assert ((out[..., 2] != 0) == expect_valid).all()
     assert (out[~expect_valid] == 0).all() and (out[expect_valid] == [2, 1, V]).all()
+
+
+# ---- semi-global matching ----------------------------------------------------------------------------------------------
+
+_CENSUS_SRC = np.array([[1, 2, 7, 2, 2, 8, 5, 2], [1, 4, 2, 9, 8, 8, 2, 6], [5, 2, 7, 2, 2, 2, 4, 6], [1, 2, 2, 2, 1, 4, 5, 2],
+                        [6, 6, 3, 7, 2, 2, 5, 5], [1, 2, 9, 2, 2, 2, 2, 2], [7, 9, 2, 8, 5, 2, 3, 2], [1, 2, 2, 2, 2, 2, 2, 1]], np.uint8)
+
+
+def test_census_transform_point_tests(oracle):
+    """src/vw/Image/tests/TestCensusTransform.cxx:25-47 (PointTests): the image is indexed src(col,row) there."""
+    c3, c5, c7 = (oracle.census_transform(_CENSUS_SRC, k) for k in (3, 5, 7))
+    at = lambda img, col, row, k: int(img[row - k // 2, col - k // 2])
+    assert at(c3, 2, 2, 3) == 0x20 and at(c3, 4, 5, 3) == 0x86 and at(c3, 6, 1, 3) == 0xDB
+    assert at(c5, 4, 4, 5) == 0x0088F60D and at(c5, 2, 3, 5) == 0x005D03C4
+    assert at(c7, 3, 4, 7) == 0x00001C0000041400
+
+
+def test_hamming_distance_tests(oracle):
+    """TestCensusTransform.cxx:49-59 (HammingDist)."""
+    h = oracle.hamming_distance
+    assert (h(0x01, 0x00), h(0xF0, 0x00), h(0xF0, 0xB1)) == (1, 4, 2)
+    assert (h(0x00B06FFF, 0x00B06F11), h(0x0033C8BA, 0x0023C0BA)) == (6, 2)
+    assert h(0x00002820A0F038, 0x00002820000030) == 7
+
+
+def _sgm_fixture():
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sgm_fixture.npz"))
+    return d["left"], d["right"]
+
+
+def test_sgm_constant_offset(oracle):
+    """src/vw/Stereo/tests/TestSGM.cxx:28-75 on the reference's own images (tests/golden/sgm_fixture.npz, made by
+    tests/golden/make_sgm_fixture.py): > 99 % of the pixels must come out as (2, 1) after adding the search minimum."""
+    left, right = _sgm_fixture()
+    res, sub = oracle.calc_disparity_sgm(oracle.CENSUS_TRANSFORM, left.astype(np.float32), right.astype(np.float32), (9, 9), 3,
+                                         subpixel=oracle.SUBPIXEL_LC_BLEND, search_buffer=(4, 4), memory_limit_mb=1024)
+    assert res.shape == (398, 398, 3)
+    correct = ((res[..., 0] - 4 == 2) & (res[..., 1] - 4 == 1)).mean()
+    assert correct > 0.99
+    assert (np.abs(sub[..., 0] - 6) < 1).all() and (np.abs(sub[..., 1] - 5) < 1).all()
+
+
+def test_sgm_parameters_and_errors(oracle):
+    """set_parameters defaults (SGM.cc:105-160) and the NoImplErr cases of compute_disparity_costs (:1877-1890)."""
+    table = {(3, 3): (3, 70), (3, 5): (15, 750), (3, 7): (30, 1500), (3, 9): (20, 1000),
+             (4, 3): (12, 600), (4, 5): (30, 1500), (4, 7): (40, 2000), (4, 9): (40, 2000)}
+    for (cost, k), want in table.items():
+        assert oracle.SemiGlobalMatcher(cost, 0, 0, 4, 4, k).p1p2() == want
+    assert oracle.SemiGlobalMatcher(3, 0, 0, 4, 4, 5, p1=7, p2=99).p1p2() == (7, 99)
+    with pytest.raises(ValueError):
+        oracle.SemiGlobalMatcher(0, 0, 0, 4, 4, 5)          # block (MAD) cost: "only the census transform ..."
+    with pytest.raises(ValueError):
+        oracle.SemiGlobalMatcher(3, 0, 0, 4, 4, 11)         # census sizes 3, 5, 7, 9 only
+
+
+def test_sgm_masks_and_prev_disparity(oracle):
+    """populate_disp_bound_image (SGM.cc:241-499): masked left pixels get a zero search area and come out invalid; a
+    trusted half-resolution disparity narrows the range to +-search_buffer; buffers are ragged accordingly."""
+    rng = np.random.default_rng(1)
+    base = rng.integers(0, 256, (70, 90)).astype(np.uint8)
+    left = base[4:60, 4:70]
+    right = base[2:2 + 56 + 12, 1:1 + 66 + 12]          # left(x, y) = right(x + 3, y + 2)
+    m = oracle.SemiGlobalMatcher(oracle.CENSUS_TRANSFORM, 0, 0, 12, 12, 5)
+    d0 = m.semi_global_matching_func(left, right)
+    oh, ow = d0.shape[:2]
+    assert (oh, ow) == (52, 62)
+    inner = d0[6:-6, 6:-6]
+    assert ((inner[..., 0] == 3) & (inner[..., 1] == 2)).mean() > 0.98
+    lmask = np.full((oh, ow), 255, np.uint8)
+    lmask[10:20, 10:30] = 0
+    rmask = np.full((oh + 12, ow + 12), 255, np.uint8)
+    prev = np.zeros(((oh + 1) // 2, (ow + 1) // 2, 3), np.int32)
+    prev[..., 0], prev[..., 1], prev[..., 2] = 2, 1, oracle.VALID      # x2 -> (4, 2): within +-2 of the truth
+    d1 = m.semi_global_matching_func(left, right, lmask, rmask, prev)
+    b, s, c, a = m.buffers()
+    assert (d1[10:20, 10:30, 2] == 0).all()
+    assert (b[10:20, 10:30] == [0, 0, -1, -1]).all()
+    assert (b[30, 30] == [2, 0, 6, 4]).all()                           # 2*2 +- 2 in x, 2*1 +- 2 in y, clipped at 0
+    counts = (b[..., 2] - b[..., 0] + 1) * (b[..., 3] - b[..., 1] + 1)
+    assert int(counts.sum()) == len(c) == len(a)
+    assert (s.reshape(-1)[1:] == np.cumsum(counts.reshape(-1))[:-1]).all()
+    keep = lmask != 0
+    assert ((d1[..., 0] == 3) & (d1[..., 1] == 2))[keep][200:].mean() > 0.95
