@@ -48,7 +48,9 @@ typedef enum vwgpu_status {
 typedef enum vwgpu_cost_type {
   VWGPU_ABSOLUTE_DIFFERENCE = 0,
   VWGPU_SQUARED_DIFFERENCE = 1,
-  VWGPU_CROSS_CORRELATION = 2
+  VWGPU_CROSS_CORRELATION = 2,
+  VWGPU_CENSUS_TRANSFORM = 3,          /* SGM only (src/vw/Stereo/SGM.cc:1874-1893) */
+  VWGPU_TERNARY_CENSUS_TRANSFORM = 4   /* SGM only */
 } vwgpu_cost_type;
 
 /* Which kernel family served the last calc_disparity call (vwgpu_last_path). */
@@ -262,6 +264,48 @@ int vwgpu_pyramid_correlate(vwgpu_ctx* ctx, const float* left, int lw, int lh, p
                             const uint8_t* right_mask, ptrdiff_t rmstride,
                             const vwgpu_pyramid_params* params, int bx, int by, int bw, int bh,
                             float* out, ptrdiff_t ostride);
+
+/* ---- semi-global matching ---------------------------------------------------------------------------- */
+
+typedef enum vwgpu_sgm_subpixel {      /* SemiGlobalMatcher::SgmSubpixelMode, src/vw/Stereo/SGM.h:93-99 */
+  VWGPU_SUBPIXEL_NONE = 0, VWGPU_SUBPIXEL_PARABOLA = 1, VWGPU_SUBPIXEL_LINEAR = 2, VWGPU_SUBPIXEL_POLY4 = 3,
+  VWGPU_SUBPIXEL_COSINE = 4, VWGPU_SUBPIXEL_LC_BLEND = 5
+} vwgpu_sgm_subpixel;
+
+/* The arguments of vw::stereo::calc_disparity_sgm / SemiGlobalMatcher::set_parameters that are not images
+ * (src/vw/Stereo/SGM.h:108-147, 360-375). */
+typedef struct vwgpu_sgm_params {
+  int cost_type;                 /* VWGPU_CENSUS_TRANSFORM or VWGPU_TERNARY_CENSUS_TRANSFORM (others: NOIMPL, like the reference) */
+  int use_mgm;                   /* must be 0 (MGM is not implemented) */
+  int kernel_size;               /* 3, 5, 7 or 9 */
+  int subpixel_mode;             /* vwgpu_sgm_subpixel */
+  int search_buffer_x, search_buffer_y;
+  size_t memory_limit_mb;        /* cap on the cost + accumulation buffers, as in calc_main_buf_size (SGM.cc:677-731) */
+  int p1, p2;                    /* 0 = the reference's defaults for the cost type / kernel size */
+  int ternary_census_threshold;  /* the reference's default is 5 */
+  int num_threads;               /* only enters the memory-cap formula (line buffers per thread); >= 1 */
+} vwgpu_sgm_params;
+
+/* Replaces vw::stereo::calc_disparity_sgm (src/vw/Stereo/SGM.cc:167-229) on already cropped regions:
+ *   left  lw x lh float, right rw x rh float with rw >= lw + sx, rh >= lh + sy (the reference crops the right image to
+ *   left_region grown by search_volume, :190-191); search_volume (sx, sy) is INCLUSIVE here: (sx+1) x (sy+1) disparities.
+ *   left_mask (optional)  : exactly the output size; right_mask (optional): at least output size + (sx, sy);
+ *   prev_disparity (optional): half-resolution PixelMask<Vector2i> of the previous pyramid level.
+ *   out_disp : ow x oh x {dx, dy, valid} int32 with ow = lw - kernel + 1 (when the right image is large enough);
+ *   out_subpixel (optional): the matcher's create_disparity_view_subpixel (SGM.cc:1497-1614) of that result.
+ * cap_pixels = capacity of the output buffers in pixels; *ow / *oh receive the output size. */
+int vwgpu_calc_disparity_sgm_dev(vwgpu_ctx* ctx, const vwgpu_sgm_params* params,
+                                 const float* d_left, int lw, int lh, ptrdiff_t lstride,
+                                 const float* d_right, int rw, int rh, ptrdiff_t rstride, int sx, int sy,
+                                 const uint8_t* d_left_mask, int lmw, int lmh, const uint8_t* d_right_mask, int rmw, int rmh,
+                                 const int32_t* d_prev_disparity, int pw, int ph,
+                                 int32_t* d_out_disp, float* d_out_subpixel, size_t cap_pixels, int* ow, int* oh);
+int vwgpu_calc_disparity_sgm(vwgpu_ctx* ctx, const vwgpu_sgm_params* params,
+                             const float* left, int lw, int lh, ptrdiff_t lstride,
+                             const float* right, int rw, int rh, ptrdiff_t rstride, int sx, int sy,
+                             const uint8_t* left_mask, int lmw, int lmh, const uint8_t* right_mask, int rmw, int rmh,
+                             const int32_t* prev_disparity, int pw, int ph,
+                             int32_t* out_disp, float* out_subpixel, size_t cap_pixels, int* ow, int* oh);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,17 @@ SYMBOLS = [
     "vwgpu_disparity_mask_dev", "vwgpu_disparity_mask",
     "vwgpu_subdivide_regions",
     "vwgpu_pyramid_correlate_dev", "vwgpu_pyramid_correlate",
+    "vwgpu_calc_disparity_sgm_dev", "vwgpu_calc_disparity_sgm",
 ]
+
+
+class SgmParams(ctypes.Structure):
+    """struct vwgpu_sgm_params (include/vwgpu.h)."""
+    _fields_ = [
+        ("cost_type", ctypes.c_int), ("use_mgm", ctypes.c_int), ("kernel_size", ctypes.c_int), ("subpixel_mode", ctypes.c_int),
+        ("search_buffer_x", ctypes.c_int), ("search_buffer_y", ctypes.c_int), ("memory_limit_mb", ctypes.c_size_t),
+        ("p1", ctypes.c_int), ("p2", ctypes.c_int), ("ternary_census_threshold", ctypes.c_int), ("num_threads", ctypes.c_int),
+    ]
 
 
 class PyramidParams(ctypes.Structure):
@@ -115,6 +125,10 @@ def load():
     pc = [P, P, I, I, PD, P, I, I, PD, P, PD, P, PD, ctypes.POINTER(PyramidParams), I, I, I, I, P, PD]
     lib.vwgpu_pyramid_correlate_dev.argtypes = pc
     lib.vwgpu_pyramid_correlate.argtypes = pc
+    IP = ctypes.POINTER(ctypes.c_int)
+    sg = [P, ctypes.POINTER(SgmParams), P, I, I, PD, P, I, I, PD, I, I, P, I, I, P, I, I, P, I, I, P, P, ctypes.c_size_t, IP, IP]
+    lib.vwgpu_calc_disparity_sgm_dev.argtypes = sg
+    lib.vwgpu_calc_disparity_sgm.argtypes = sg
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the ABI and the header drifted apart
     _LIB = lib

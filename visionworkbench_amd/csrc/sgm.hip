@@ -1,0 +1,662 @@
+// sgm.hip — semi-global matching (vw::stereo::calc_disparity_sgm, src/vw/Stereo/SGM.cc:167-229) resident in HBM.
+//
+//   u8_convert                      ImageThresh.h:275-286        minmax_kernel + u8_convert_kernel (float64 scale, truncation)
+//   census / ternary census         CensusTransform.h:64-340     census_kernel -> one uint64 per pixel
+//   populate_disp_bound_image       SGM.cc:241-499               mask_extent kernels + bounds_kernel (masks, 2x previous level +- buffer)
+//   constrain_disp_bound_image      SGM.cc:502-672               constrain_kernel (full-search pixels adopt the box of their neighbours)
+//   calc_main_buf_size              SGM.cc:677-731               row_count_kernel + host prefix over rows + row_scan_kernel (ragged starts)
+//   compute_disparity_costs         SGM.cc:1740-1893, :40-75     cost_kernel: popcount(left_census ^ right_census) inside each pixel's bounds
+//   accum_sgm_multithread           SGM.cc:2462-2612             8 launches of path_kernel, one wavefront per scan line
+//   evaluate_path (SSE semantics)   SGM.cc:936-984, 1013-1150    saturating u16 add/sub, 8-neighbour 2-D disparity adjacency with
+//                                                                repetition at the global range border, BAD_VAL outside the prior's box
+//   select_best_disparity           SGM.cc:1159-1284             wta_kernel: (value << 16 | index) min = first minimum; tie smoothing loop
+//   create_disparity_view_subpixel  SGM.cc:1497-1614             subpixel_kernel (linear / poly4 / cosine / LC-blend / 2-D parabola)
+//
+// Layout in HBM: per output pixel a box [min_x,max_x] x [min_y,max_y] of searched disparities (4 x int32) and a uint64 start
+// into two ragged arrays: cost (u8) and accumulated cost (u16) — the reference's m_cost_buffer / m_accum_buffer
+// (SGM.cc:733-751).  Algorithmic bytes ("materialised volume" model): 20 + 11 D bytes per pixel
+// (D = disparities per pixel): cost written once (D) and read by 8 paths (8 D is served from L2 for most paths), accum
+// read-modify-written per path.  The path kernel is latency bound per step (a scan line is a serial recurrence), the
+// chip is filled by running every line of a direction concurrently (>= W or H wavefronts).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "vwgpu_internal.h"
+
+namespace {
+
+struct B4 { int x0, y0, x1, y1; };
+__device__ __forceinline__ int b4_count(B4 b) { return (b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1); }
+
+// ---- u8_convert -------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+__global__ void minmax_kernel(const float* __restrict__ img, ptrdiff_t stride, int w, int h, unsigned* __restrict__ mm) {
+  unsigned lo = 0xffffffffu, hi = 0u;
+  for (int y = blockIdx.y; y < h; y += gridDim.y)
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) {
+      const unsigned o = f2ord(img[(ptrdiff_t)y * stride + x]);
+      lo = min(lo, o); hi = max(hi, o);
+    }
+  for (int s = 32; s > 0; s >>= 1) { lo = min(lo, (unsigned)__shfl_xor((int)lo, s)); hi = max(hi, (unsigned)__shfl_xor((int)hi, s)); }
+  if ((threadIdx.x & 63) == 0) { atomicMin(mm, lo); atomicMax(mm + 1, hi); }
+}
+
+__global__ void u8_convert_kernel(const float* __restrict__ img, ptrdiff_t stride, int w, int h, const unsigned* __restrict__ mm,
+                                  uint8_t* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  double min_val = (double)ord2f(mm[0]), max_val = (double)ord2f(mm[1]);
+  if (max_val == min_val) max_val = min_val + 1.0;
+  const float old_min = (float)min_val, old_max = (float)max_val;
+  const double ratio = (old_max == old_min) ? 0.0 : (double)(255.0f - 0.0f) / (double)(old_max - old_min);
+  float v = img[(ptrdiff_t)y * stride + x];
+  if (v > old_max) v = old_max;
+  if (v < old_min) v = old_min;
+  const float n = (float)((double)(v - old_min) * ratio + (double)0.0f);
+  out[(size_t)y * w + x] = (uint8_t)n;
+}
+
+// ---- census -----------------------------------------------------------------------------------------------------------
+
+__constant__ int c9cols[32] = {0, 4, 8, 1, 3, 5, 7, 2, 4, 6, 1, 4, 7, 0, 2, 3, 5, 6, 8, 1, 4, 7, 2, 4, 6, 1, 3, 5, 7, 0, 4, 8};
+__constant__ int c9rows[32] = {0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 4, 4, 4, 5, 5, 5, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8};
+__constant__ int c7cols[32] = {0, 2, 3, 4, 6, 1, 3, 5, 0, 2, 3, 4, 6, 0, 1, 2, 4, 5, 6, 0, 2, 3, 4, 6, 1, 3, 5, 0, 2, 3, 4, 6};
+__constant__ int c7rows[32] = {0, 0, 0, 0, 0, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 6, 6, 6, 6, 6};
+
+// out(c, r) = census word of the window centred at (c + hk, r + hk); out is (w - 2hk) x (h - 2hk)
+__global__ void census_kernel(const uint8_t* __restrict__ img, int w, int h, int k, int ternary, int thr, uint64_t* __restrict__ out) {
+  const int hk = (k - 1) / 2, ow = w - 2 * hk, oh = h - 2 * hk;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y * blockDim.y + threadIdx.y;
+  if (c >= ow || r >= oh) return;
+  const int col = c + hk, row = r + hk;
+  auto at = [&](int x, int y) -> int { return img[(size_t)y * w + x]; };
+  const int center = at(col, row);
+  uint64_t o = 0, addend = 1;
+  if (!ternary) {
+    if (k == 9) {
+      for (int i = 0; i < 32; ++i) { if (at(col + c9cols[i] - 4, row + c9rows[i] - 4) > center) o += addend; addend *= 2; }
+    } else {   // 3x3 (explicit weights 128..1 = the same descending raster order), 5x5, 7x7
+      for (int y = row + hk; y >= row - hk; --y)
+        for (int x = col + hk; x >= col - hk; --x) {
+          if (y == row && x == col) continue;
+          if (at(x, y) > center) o += addend;
+          addend *= 2;
+        }
+    }
+  } else {
+    const int lo = center - thr, hi = center + thr;
+    auto tern = [&](int val) { if (val >= lo) { o += addend; if (val > hi) o += addend * 2; } addend *= 4; };
+    if (k == 7) { for (int i = 0; i < 32; ++i) tern(at(col + c7cols[i] - 3, row + c7rows[i] - 3)); }
+    else if (k == 9) { for (int i = 0; i < 32; ++i) tern(at(col + c9cols[i] - 4, row + c9rows[i] - 4)); }
+    else {
+      for (int y = row + hk; y >= row - hk; --y)
+        for (int x = col + hk; x >= col - hk; --x) { if (y == row && x == col) continue; tern(at(x, y)); }
+    }
+  }
+  out[(size_t)r * ow + c] = o;
+}
+
+// ---- disparity bounds -------------------------------------------------------------------------------------------------
+
+// ext[0] = min valid right row, ext[1] = max valid right row over columns [0, ocols) (SGM.cc:303-327, quirks kept:
+// the downward scan stops above row 0).  Initialised by the host to {rmh - 1, 0}.
+__global__ void mask_col_extent_kernel(const uint8_t* __restrict__ rmask, int rmw, int rmh, int ocols, int* __restrict__ ext) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ocols) return;
+  for (int i = rmh - 1; i > 0; --i) if (rmask[(size_t)i * rmw + c] > 0) { atomicMax(ext + 1, i); break; }
+  for (int i = 0; i < rmh; ++i) if (rmask[(size_t)i * rmw + c] > 0) { atomicMin(ext, i); break; }
+}
+// per output row: {min valid right column, max valid right column} (-1, -2 when none; SGM.cc:337-354)
+__global__ void mask_row_extent_kernel(const uint8_t* __restrict__ rmask, int rmw, int orows, int2* __restrict__ rowext) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= orows) return;
+  int mn = -1, mx = -2;
+  for (int i = rmw - 1; i > 0; --i) if (rmask[(size_t)r * rmw + i] > 0) { mx = i; break; }
+  if (mx > 0) for (int i = 0; i < rmw; ++i) if (rmask[(size_t)r * rmw + i] > 0) { mn = i; break; }
+  rowext[r] = make_int2(mn, mx);
+}
+
+struct SgmGeom { int min_dx, min_dy, max_dx, max_dy, num_dx, num_dy, sbx, sby, ocols, orows; };
+
+__global__ void bounds_kernel(SgmGeom g, const uint8_t* __restrict__ lmask, const uint8_t* __restrict__ rmask_present,
+                              const int* __restrict__ ext, const int2* __restrict__ rowext,
+                              const int32_t* __restrict__ prev, int pw, int ph,
+                              B4* __restrict__ bounds, uint8_t* __restrict__ full_search) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c >= g.ocols) return;
+  const size_t idx = (size_t)r * g.ocols + c;
+  const B4 ZERO{0, 0, -1, -1};
+  full_search[idx] = 0;
+  if (lmask && lmask[idx] == 0) { bounds[idx] = ZERO; return; }
+  bool good = false;
+  int dxs = 0, dys = 0;
+  if (prev) {
+    const int c_in = c / 2, r_in = r / 2;
+    if (!(c_in >= pw || r_in >= ph)) {
+      const int32_t* d = prev + ((size_t)r_in * pw + c_in) * 3;
+      dxs = d[0] * 2; dys = d[1] * 2;
+      const bool on_edge = (g.num_dx >= 10 && (dxs <= g.min_dx || dxs >= g.max_dx)) || (g.num_dy >= 10 && (dys <= g.min_dy || dys >= g.max_dy));
+      good = d[2] != 0 && !on_edge;
+    }
+  }
+  B4 b;
+  if (good) {
+    b.x0 = max(dxs - g.sbx, g.min_dx); b.x1 = min(dxs + g.sbx, g.max_dx);
+    b.y0 = max(dys - g.sby, g.min_dy); b.y1 = min(dys + g.sby, g.max_dy);
+  } else {
+    b = B4{g.min_dx, g.min_dy, g.max_dx, g.max_dy};
+    full_search[idx] = 255;
+  }
+  if (rmask_present) {
+    int vx0 = rowext[r].x, vx1 = rowext[r].y, vy0 = ext[0], vy1 = ext[1];
+    if (!(vx0 >= vx1 || vy0 >= vy1)) { vx0 -= c; vx1 -= c; vy0 -= r; vy1 -= r; }    // BBox -= on an empty box is a no-op
+    vx0 = max(vx0, b.x0); vy0 = max(vy0, b.y0); vx1 = min(vx1, b.x1); vy1 = min(vy1, b.y1);
+    if (vx0 > vx1 || vy0 > vy1) { bounds[idx] = ZERO; full_search[idx] = 0; return; }
+    b = B4{vx0, vy0, vx1, vy1};
+  }
+  bounds[idx] = b;
+}
+
+__global__ void constrain_kernel(SgmGeom g, const uint8_t* __restrict__ full_search, B4* __restrict__ bounds, int range, int conserve) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c >= g.ocols) return;
+  const size_t idx = (size_t)r * g.ocols + c;
+  if (!full_search[idx]) return;
+  const int r0 = max(r - range, 0), r1 = min(r + range, g.orows - 1), c0 = max(c - range, 0), c1 = min(c + range, g.ocols - 1);
+  int x0 = 0x7ffffffe, y0 = 0x7ffffffe, x1 = -0x7ffffffe, y1 = -0x7ffffffe;
+  for (int rs = r0; rs <= r1; ++rs)
+    for (int cs = c0; cs <= c1; ++cs) {
+      const size_t j = (size_t)rs * g.ocols + cs;
+      if (full_search[j]) continue;
+      const B4 v = bounds[j];
+      if (v.x0 == 0 && v.y0 == 0 && v.x1 == -1 && v.y1 == -1) continue;
+      x0 = min(x0, min(v.x0, v.x1)); x1 = max(x1, max(v.x0, v.x1));       // grow(min corner); grow(max corner)
+      y0 = min(y0, min(v.y0, v.y1)); y1 = max(y1, max(v.y0, v.y1));
+    }
+  if (x0 >= x1 || y0 >= y1) {                       // empty(): no estimate
+    if (conserve > 0) bounds[idx] = B4{0, 0, -1, -1};
+    return;
+  }
+  x0 -= 2; y0 -= 2; x1 += 2; y1 += 2;               // expand(NEARBY_DISP_EXPANSION)
+  x0 = max(x0, g.min_dx); y0 = max(y0, g.min_dy); x1 = min(x1, g.max_dx); y1 = min(y1, g.max_dy);
+  bounds[idx] = B4{x0, y0, x1, y1};
+}
+
+// ---- ragged starts ----------------------------------------------------------------------------------------------------
+
+__global__ void row_count_kernel(const B4* __restrict__ bounds, int ocols, unsigned long long* __restrict__ rowsum) {
+  const int r = blockIdx.x;
+  unsigned long long s = 0;
+  for (int c = threadIdx.x; c < ocols; c += blockDim.x) s += (unsigned long long)b4_count(bounds[(size_t)r * ocols + c]);
+  __shared__ unsigned long long sh[256];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) rowsum[r] = sh[0];
+}
+
+__global__ void row_scan_kernel(const B4* __restrict__ bounds, int ocols, const unsigned long long* __restrict__ rowoff,
+                                unsigned long long* __restrict__ starts) {
+  const int r = blockIdx.x;
+  __shared__ unsigned long long sh[256];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = rowoff[r];
+  __syncthreads();
+  for (int base = 0; base < ocols; base += 256) {
+    const int c = base + threadIdx.x;
+    const unsigned long long v = c < ocols ? (unsigned long long)b4_count(bounds[(size_t)r * ocols + c]) : 0ull;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {               // Hillis-Steele inclusive scan
+      unsigned long long t = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0ull;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (c < ocols) starts[(size_t)r * ocols + c] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry += sh[255];
+    __syncthreads();
+  }
+}
+
+// ---- cost fill --------------------------------------------------------------------------------------------------------
+
+// one wavefront per output pixel, lanes over the pixel's disparities (get_hamming_distance_costs, SGM.cc:40-75)
+__global__ void cost_kernel(const uint64_t* __restrict__ lc, int lcw, const uint64_t* __restrict__ rc, int rcw,
+                            const B4* __restrict__ bounds, const unsigned long long* __restrict__ starts, int ocols, size_t npix,
+                            int off_c, int off_r, uint8_t* __restrict__ cost) {
+  const size_t p = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= npix) return;
+  const int lane = threadIdx.x & 63;
+  const int r = (int)(p / ocols), c = (int)(p - (size_t)r * ocols);
+  const B4 b = bounds[p];
+  const int wd = b.x1 - b.x0 + 1, n = wd * (b.y1 - b.y0 + 1);
+  if (n <= 0) return;
+  const int bc = c + off_c, br = r + off_r;           // (min_col - half_kernel, min_row - half_kernel) offsets
+  const uint64_t lv = lc[(size_t)br * lcw + bc];
+  uint8_t* o = cost + starts[p];
+  for (int i = lane; i < n; i += 64) {
+    const int qy = i / wd, qx = i - qy * wd;
+    o[i] = (uint8_t)__popcll(lv ^ rc[(size_t)(br + b.y0 + qy) * rcw + bc + b.x0 + qx]);
+  }
+}
+
+// ---- path aggregation -------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ unsigned adds16(unsigned a, unsigned b) { return min(a + b, 65535u); }
+__device__ __forceinline__ unsigned subs16(unsigned a, unsigned b) { return a > b ? a - b : 0u; }
+
+// One wavefront per scan line (PixelPassTask, SGMAssist.h:705-819).  line -> start pixel as in accum_sgm_multithread
+// (SGM.cc:2488-2610): first `n_first` lines start on the first border (index i), the rest on the second (index i + skip).
+__global__ void __launch_bounds__(64)
+path_kernel(SgmGeom g, int dc, int dr, int n_first, int first_is_row_border, int second_skip,
+            const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
+            const B4* __restrict__ bounds, const unsigned long long* __restrict__ starts,
+            const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2) {
+  extern __shared__ uint16_t sm[];
+  const int num_disp = g.num_dx * g.num_dy;
+  uint16_t* full_prior = sm;                 // num_disp
+  uint16_t* prev_out = sm + num_disp;        // num_disp (packed vector of the previous pixel)
+  const int lane = threadIdx.x;
+  const int line = blockIdx.x;
+  int c, r;
+  // start pixel
+  if (line < n_first) {
+    // lines indexed along x start on the top (dr > 0) or bottom (dr < 0) row; lines indexed along y (pure horizontal
+    // passes) start on the left / right column
+    if (first_is_row_border) { c = line; r = dr > 0 ? 0 : g.orows - 1; }
+    else { r = line; c = dc > 0 ? 0 : g.ocols - 1; }
+  } else {
+    r = line - n_first + second_skip;
+    c = dc > 0 ? 0 : g.ocols - 1;
+  }
+  const unsigned BAD = (255u + p2) & 0xffffu;
+  for (int i = lane; i < num_disp; i += 64) full_prior[i] = (uint16_t)BAD;
+  __syncthreads();
+  int last_val = -1;
+  B4 bp{0, 0, -1, -1};
+  while (c >= 0 && r >= 0 && c < g.ocols && r < g.orows) {
+    const size_t p = (size_t)r * g.ocols + c;
+    const B4 b = bounds[p];
+    const int wd = b.x1 - b.x0 + 1, nd = wd * (b.y1 - b.y0 + 1);
+    const unsigned long long st = starts[p];
+    const int cur = left[(size_t)(r + min_row) * lw + (c + min_col)];
+    if (last_val < 0) {
+      for (int i = lane; i < nd; i += 64) {
+        const unsigned v = cost[st + i];
+        prev_out[i] = (uint16_t)v;
+        accum[st + i] = (uint16_t)(accum[st + i] + v);
+      }
+    } else {
+      int grad = cur - last_val; grad = grad < 0 ? -grad : grad;
+      unsigned p2_mod = p2;
+      if (grad > 0) p2_mod /= (unsigned)grad;
+      if (p2_mod < p1) p2_mod = p1;
+      // scatter the prior vector into the full-range buffer, reduce its minimum
+      const int wp = bp.x1 - bp.x0 + 1, np = wp * (bp.y1 - bp.y0 + 1);
+      unsigned mn = BAD;
+      for (int i = lane; i < np; i += 64) {
+        const int qy = i / wp, qx = i - qy * wp;
+        const unsigned v = prev_out[i];
+        mn = min(mn, v);
+        full_prior[(bp.y0 + qy - g.min_dy) * g.num_dx + (bp.x0 + qx - g.min_dx)] = (uint16_t)v;
+      }
+      for (int s = 32; s > 0; s >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, s));
+      const unsigned min_prior = mn;
+      const unsigned dJ = (min_prior + p2_mod) & 0xffffu;
+      __syncthreads();
+      for (int i = lane; i < nd; i += 64) {
+        const int qy = i / wd, qx = i - qy * wd;
+        const int dx = b.x0 + qx, dy = b.y0 + qy;
+        const int xo = dx - g.min_dx, yo = dy - g.min_dy;
+        const int xl = dx - 1 < g.min_dx ? xo : xo - 1, xm = dx + 1 > g.max_dx ? xo : xo + 1;
+        const int yl = (dy - 1 < g.min_dy ? yo : yo - 1) * g.num_dx, ym = (dy + 1 > g.max_dy ? yo : yo + 1) * g.num_dx, yc = yo * g.num_dx;
+        unsigned m = full_prior[yl + xo];
+        m = min(m, (unsigned)full_prior[yc + xl]); m = min(m, (unsigned)full_prior[yc + xm]); m = min(m, (unsigned)full_prior[ym + xo]);
+        m = min(m, (unsigned)full_prior[yl + xl]); m = min(m, (unsigned)full_prior[yl + xm]);
+        m = min(m, (unsigned)full_prior[ym + xl]); m = min(m, (unsigned)full_prior[ym + xm]);
+        unsigned res = adds16(m, p1);
+        res = min(res, min((unsigned)full_prior[yc + xo], dJ));
+        res = adds16(res, (unsigned)cost[st + i]);
+        res = subs16(res, min_prior);
+        // prev_out is still being read by nobody (scatter finished at the barrier): reuse it for this pixel's vector
+        prev_out[i] = (uint16_t)res;
+        accum[st + i] = (uint16_t)(accum[st + i] + res);
+      }
+      __syncthreads();
+      for (int i = lane; i < np; i += 64) {
+        const int qy = i / wp, qx = i - qy * wp;
+        full_prior[(bp.y0 + qy - g.min_dy) * g.num_dx + (bp.x0 + qx - g.min_dx)] = (uint16_t)BAD;
+      }
+    }
+    __syncthreads();
+    bp = b; last_val = cur;
+    c += dc; r += dr;
+  }
+}
+
+// ---- winner take all --------------------------------------------------------------------------------------------------
+
+// one wavefront per pixel; ties on the minimum trigger the reference's smoothing loop on an LDS copy
+__global__ void __launch_bounds__(256)
+wta_kernel(const B4* __restrict__ bounds, const unsigned long long* __restrict__ starts, size_t npix, int max_nd,
+           uint16_t* __restrict__ accum, int32_t* __restrict__ disp) {
+  extern __shared__ uint16_t sm[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t p = (size_t)blockIdx.x * 4 + wv;
+  if (p >= npix) return;                                   // whole wave exits together
+  uint16_t* A = sm + (size_t)wv * 2 * max_nd;
+  uint16_t* Bf = A + max_nd;
+  const B4 b = bounds[p];
+  const int width = b.x1 - b.x0 + 1, height = b.y1 - b.y0 + 1, n = width * height;
+  int32_t* o = disp + p * 3;
+  if (n <= 0) { if (lane == 0) { o[0] = 0; o[1] = 0; o[2] = 0; } return; }
+  uint16_t* av = accum + starts[p];
+  unsigned key = 0xffffffffu;
+  for (int i = lane; i < n; i += 64) { const unsigned v = av[i]; A[i] = (uint16_t)v; key = min(key, (v << 16) | (unsigned)i); }
+  for (int s = 32; s > 0; s >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, s));
+  unsigned min_val = key >> 16;
+  int cnt = 0;
+  for (int i = lane; i < n; i += 64) cnt += (A[i] == min_val);
+  for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s);
+  // NB: the reference starts min_val at 65535 and counts `==` before `<`, so an all-65535 vector counts every element
+  int iter = 0;
+  uint16_t* in = A; uint16_t* out = Bf;
+  while (cnt > 1) {
+    __builtin_amdgcn_wave_barrier();
+    unsigned k2 = 0xffffffffu;
+    for (int i = lane; i < n; i += 64) {
+      const int row = i / width, col = i - row * width;
+      int mn = -1, mx = 1;
+      double result = 0, wtot = 0;
+      if (iter < 5) {
+        if (mn + col < 0) mn = 0;
+        if (mx + col >= width) mx = 0;
+        for (int k = mn; k <= mx; ++k) { result += (double)in[i + k] * (1.0 / 3.0); wtot += (1.0 / 3.0); }
+      } else {
+        if (mn + row < 0) mn = 0;
+        if (mx + row >= height) mx = 0;
+        for (int k = mn; k <= mx; ++k) { result += (double)in[i + k * width] * (1.0 / 3.0); wtot += (1.0 / 3.0); }
+      }
+      const unsigned v = (unsigned)(uint16_t)round(result / wtot);
+      out[i] = (uint16_t)v;
+      k2 = min(k2, (v << 16) | (unsigned)i);
+    }
+    for (int s = 32; s > 0; s >>= 1) k2 = min(k2, (unsigned)__shfl_xor((int)k2, s));
+    key = k2; min_val = key >> 16;
+    __builtin_amdgcn_wave_barrier();
+    cnt = 0;
+    for (int i = lane; i < n; i += 64) cnt += (out[i] == min_val);
+    for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s);
+    uint16_t* t = in; in = out; out = t;
+    ++iter;
+    if (iter >= 6) break;
+  }
+  if (iter > 0) for (int i = lane; i < n; i += 64) av[i] = in[i];     // the accumulation vector keeps the smoothed values
+  if (lane == 0) {
+    const int mi = (int)(key & 0xffffu);
+    int dy = mi / width;
+    const int dx = mi - dy * width + b.x0;
+    dy += b.y1 - height + 1;
+    o[0] = dx; o[1] = dy; o[2] = 0x7fffffff;
+  }
+}
+
+// ---- sub-pixel --------------------------------------------------------------------------------------------------------
+
+__device__ double sp_linear(double x) { return x / 2.0; }
+__device__ double sp_poly4(double x) { return (x * x * x * x + x) / 4.0; }
+__device__ double sp_cos(double x) { const double PI = 3.14159265359; return (1 - cos(x * PI / 3.0)); }
+__device__ double sp_lcblend(double x) {
+  const double PI = 3.14159265359;
+  const double factor = 1.195 - cos(x * (PI / 2.3));
+  return sp_cos(x) * factor + sp_linear(x) * (1.0 - factor);
+}
+__device__ double sp_offset(int mode, unsigned prev, unsigned center, unsigned next, bool lb, bool rb) {
+  const double ld = (double)((int)prev - (int)center), rd = (double)((int)next - (int)center);
+  if (rd == 0 && ld == 0) return 0;
+  if (lb) return 0.5 * ((double)center / (double)next);
+  if (rb) return -1.0 * (0.5 * ((double)center / (double)prev));
+  double x = rd / ld, mult = -1.0;
+  if (ld < rd) { x = ld / rd; mult = 1.0; }
+  double value;
+  switch (mode) {
+    case 3: value = sp_poly4(x); break;
+    case 4: value = sp_cos(x); break;
+    case 5: value = sp_lcblend(x); break;
+    default: value = sp_linear(x); break;
+  }
+  return (value - 0.5) * mult;
+}
+__device__ bool sp_parabola(const double* z, double& dx, double& dy) {
+  const double pinvA[54] = {
+    1.0 / 6, -1.0 / 3, 1.0 / 6, 1.0 / 6, -1.0 / 3, 1.0 / 6, 1.0 / 6, -1.0 / 3, 1.0 / 6,
+    1.0 / 6, 1.0 / 6, 1.0 / 6, -1.0 / 3, -1.0 / 3, -1.0 / 3, 1.0 / 6, 1.0 / 6, 1.0 / 6,
+    1.0 / 4, 0.0, -1.0 / 4, 0.0, 0.0, 0.0, -1.0 / 4, 0.0, 1.0 / 4,
+    -1.0 / 6, 0.0, 1.0 / 6, -1.0 / 6, 0.0, 1.0 / 6, -1.0 / 6, 0.0, 1.0 / 6,
+    -1.0 / 6, -1.0 / 6, -1.0 / 6, 0.0, 0.0, 0.0, 1.0 / 6, 1.0 / 6, 1.0 / 6,
+    -1.0 / 9, 2.0 / 9, -1.0 / 9, 2.0 / 9, 5.0 / 9, 2.0 / 9, -1.0 / 9, 2.0 / 9, -1.0 / 9};
+  double vals[6];
+  for (int i = 0; i < 6; ++i) { double s = 0; for (int j = 0; j < 9; ++j) s += (double)(float)pinvA[i * 9 + j] * z[j]; vals[i] = s; }
+  const double denom = 4.0 * vals[0] * vals[1] - (vals[2] * vals[2]);
+  if (fabs(denom) < 0.01) return false;
+  dx = (double)(float)((vals[2] * vals[4] - 2.0 * vals[1] * vals[3]) / denom);
+  dy = (double)(float)((vals[2] * vals[3] - 2.0 * vals[0] * vals[4]) / denom);
+  dx = erf(dx / (0.34574 * sqrt(2.0))) / 2.0;
+  dy = erf(dy / (0.38944 * sqrt(2.0))) / 2.0;
+  const double nrm = sqrt(dx * dx + dy * dy);
+  if (nrm >= 0.5) { const double scale = nrm / 0.5; dx /= scale; dy /= scale; }
+  return true;
+}
+
+__global__ void subpixel_kernel(int mode, const B4* __restrict__ bounds, const unsigned long long* __restrict__ starts, size_t npix,
+                                const uint16_t* __restrict__ accum, const int32_t* __restrict__ idisp, float* __restrict__ out) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const int32_t* ip = idisp + p * 3;
+  float* o = out + p * 3;
+  if (!ip[2]) { o[0] = (float)ip[0]; o[1] = (float)ip[1]; o[2] = 0.0f; return; }
+  const int dx = ip[0], dy = ip[1];
+  if (mode == 0) { o[0] = (float)dx; o[1] = (float)dy; o[2] = 1.0f; return; }
+  const B4 b = bounds[p];
+  const int width = b.x1 - b.x0 + 1;
+  const int mi = (dy - b.y0) * width + (dx - b.x0);
+  int xl = -1, xr = 1, yu = -width, yd = width;
+  bool tb = false, bb = false, lb = false, rb = false;
+  if (dx == b.x0) { xl = 0; lb = true; }
+  if (dx == b.x1) { xr = 0; rb = true; }
+  if (dy == b.y0) { yu = 0; tb = true; }
+  if (dy == b.y1) { yd = 0; bb = true; }
+  const uint16_t* a = accum + starts[p];
+  double ddx = 0, ddy = 0;
+  bool valid = true;
+  if (mode == 1) {
+    const double z[9] = {(double)a[mi + xl + yu], (double)a[mi + yu], (double)a[mi + xr + yu], (double)a[mi + xl], (double)a[mi],
+                         (double)a[mi + xr], (double)a[mi + xl + yd], (double)a[mi + yd], (double)a[mi + xr + yd]};
+    valid = sp_parabola(z, ddx, ddy);
+  } else {
+    ddx = sp_offset(mode, a[mi + xl], a[mi], a[mi + xr], lb, rb);
+    ddy = sp_offset(mode, a[mi + yu], a[mi], a[mi + yd], tb, bb);
+  }
+  if (valid) { o[0] = (float)((double)dx + ddx); o[1] = (float)((double)dy + ddy); } else { o[0] = (float)dx; o[1] = (float)dy; }
+  o[2] = 1.0f;
+}
+
+struct Bump {
+  char* base; size_t cap, off = 0;
+  template <class T> T* take(size_t n) {
+    off = vwgpu_align_up(off, 256);
+    T* p = reinterpret_cast<T*>(base + off);
+    off += n * sizeof(T);
+    return off <= cap ? p : nullptr;
+  }
+};
+
+void default_p1p2(int cost_type, int kernel, int& p1, int& p2) {     // SGM.cc:105-160
+  const bool tern = cost_type == VWGPU_TERNARY_CENSUS_TRANSFORM;
+  if (p1 <= 0) p1 = tern ? (kernel == 3 ? 12 : kernel == 5 ? 30 : kernel == 7 ? 40 : kernel == 9 ? 40 : 30)
+                         : (kernel == 3 ? 3 : kernel == 5 ? 15 : kernel == 7 ? 30 : kernel == 9 ? 20 : 3);
+  if (p2 <= 0) p2 = tern ? (kernel == 3 ? 600 : kernel == 5 ? 1500 : kernel == 7 ? 2000 : kernel == 9 ? 2000 : 30)
+                         : (kernel == 3 ? 70 : kernel == 5 ? 750 : kernel == 7 ? 1500 : kernel == 9 ? 1000 : 22);
+}
+
+}  // namespace
+
+// left: lw x lh float (device), right: rw x rh float (device).  Masks / prev may be null.  out_disp: ocols x orows x 3 int32,
+// out_sub: optional ocols x orows x 3 float.  Returns the output size through ow / oh.
+int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left, int lw, int lh, ptrdiff_t ls,
+                   const float* right, int rw, int rh, ptrdiff_t rs, int sx, int sy,
+                   const uint8_t* lmask, int lmw, int lmh, const uint8_t* rmask, int rmw, int rmh,
+                   const int32_t* prev, int pw, int ph, int32_t* out_disp, float* out_sub, size_t out_cap_pixels, int* ow, int* oh) {
+  hipStream_t st = ctx->stream;
+  const int kernel = P->kernel_size;
+  const int hk = (kernel - 1) / 2;
+  SgmGeom g;
+  g.min_dx = 0; g.min_dy = 0; g.max_dx = sx; g.max_dy = sy; g.num_dx = sx + 1; g.num_dy = sy + 1;
+  g.sbx = P->search_buffer_x; g.sby = P->search_buffer_y;
+  // output extent (semi_global_matching_func, SGM.cc:2397-2420)
+  int min_row = hk - g.min_dy, min_col = hk - g.min_dx;
+  int max_row = std::min(lh - 1 - hk, rh - 1 - (hk + g.max_dy)), max_col = std::min(lw - 1 - hk, rw - 1 - (hk + g.max_dx));
+  if (min_row < 0) min_row = 0;
+  if (min_col < 0) min_col = 0;
+  if (max_row > lh - 1) max_row = lh - 1;
+  if (max_col > lw - 1) max_col = lw - 1;
+  g.ocols = max_col - min_col + 1; g.orows = max_row - min_row + 1;
+  if (g.ocols <= 0 || g.orows <= 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity_sgm: Kernel size too large of active region.");
+  *ow = g.ocols; *oh = g.orows;
+  const size_t npix = (size_t)g.ocols * g.orows;
+  if (npix > out_cap_pixels) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity_sgm: output buffer too small (%d x %d needed)", g.ocols, g.orows);
+  const long long num_disp = (long long)g.num_dx * g.num_dy;
+  if (num_disp > 16000) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity_sgm: %lld disparities per pixel exceed the LDS path buffers", num_disp);
+  if (lmask && !(lmw == g.ocols && lmh == g.orows)) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "Left mask size does not match the output size.");
+  if (rmask && !(rmw >= g.ocols + g.num_dx - 1 && rmh >= g.orows + g.num_dy - 1))
+    return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "Right mask size is not large enough to support search range.");
+  int p1 = P->p1, p2 = P->p2;
+  default_p1p2(P->cost_type, kernel, p1, p2);
+
+  // fixed-size part of the arena
+  const int lcw = lw - 2 * hk, lch = lh - 2 * hk, rcw = rw - 2 * hk, rch = rh - 2 * hk;
+  const size_t fixed = (size_t)lw * lh + (size_t)rw * rh + 8 * ((size_t)lcw * lch + (size_t)rcw * rch) + npix * (16 + 8 + 1) +
+                       (size_t)g.orows * (8 + 8 + 8) + (1 << 16);
+  int rc = vwgpu_arena_reserve(ctx, &ctx->sgm, fixed);
+  if (rc) return rc;
+  Bump A{static_cast<char*>(ctx->sgm.base), ctx->sgm.cap};
+  uint8_t* l8 = A.take<uint8_t>((size_t)lw * lh);
+  uint8_t* r8 = A.take<uint8_t>((size_t)rw * rh);
+  uint64_t* lc = A.take<uint64_t>((size_t)lcw * lch);
+  uint64_t* rcen = A.take<uint64_t>((size_t)rcw * rch);
+  B4* bounds = A.take<B4>(npix);
+  unsigned long long* starts = A.take<unsigned long long>(npix);
+  uint8_t* full_search = A.take<uint8_t>(npix);
+  unsigned long long* rowsum = A.take<unsigned long long>(g.orows);
+  unsigned long long* rowoff = A.take<unsigned long long>(g.orows);
+  int2* rowext = A.take<int2>(g.orows);
+  unsigned* mm = A.take<unsigned>(8);
+  int* ext = reinterpret_cast<int*>(mm + 4);
+  if (!l8 || !r8 || !lc || !rcen || !bounds || !starts || !full_search || !rowsum || !rowoff || !rowext || !mm)
+    return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "calc_disparity_sgm: internal arena too small");
+
+  // u8_convert both images (SGM.cc:210-212)
+  {
+    vwgpu_prof_scope ps(ctx, "sgm_u8_convert");
+    const unsigned init[8] = {0xffffffffu, 0u, 0xffffffffu, 0u, (unsigned)(rmh - 1), 0u, 0u, 0u};
+    VWGPU_HIP(ctx, hipMemcpyAsync(mm, init, sizeof init, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(minmax_kernel, dim3(std::min((lw + 255) / 256, 64), std::min(lh, 256)), dim3(256), 0, st, left, ls, lw, lh, mm);
+    hipLaunchKernelGGL(minmax_kernel, dim3(std::min((rw + 255) / 256, 64), std::min(rh, 256)), dim3(256), 0, st, right, rs, rw, rh, mm + 2);
+    hipLaunchKernelGGL(u8_convert_kernel, dim3((lw + 255) / 256, lh), dim3(256), 0, st, left, ls, lw, lh, mm, l8);
+    hipLaunchKernelGGL(u8_convert_kernel, dim3((rw + 255) / 256, rh), dim3(256), 0, st, right, rs, rw, rh, mm + 2, r8);
+  }
+  {
+    vwgpu_prof_scope ps(ctx, "sgm_census");
+    const int tern = P->cost_type == VWGPU_TERNARY_CENSUS_TRANSFORM;
+    hipLaunchKernelGGL(census_kernel, dim3((lcw + 63) / 64, (lch + 3) / 4), dim3(64, 4), 0, st, l8, lw, lh, kernel, tern, P->ternary_census_threshold, lc);
+    hipLaunchKernelGGL(census_kernel, dim3((rcw + 63) / 64, (rch + 3) / 4), dim3(64, 4), 0, st, r8, rw, rh, kernel, tern, P->ternary_census_threshold, rcen);
+  }
+  // per-pixel disparity bounds
+  {
+    vwgpu_prof_scope ps(ctx, "sgm_bounds");
+    if (rmask) {
+      hipLaunchKernelGGL(mask_col_extent_kernel, dim3((g.ocols + 255) / 256), dim3(256), 0, st, rmask, rmw, rmh, g.ocols, ext);
+      hipLaunchKernelGGL(mask_row_extent_kernel, dim3((g.orows + 255) / 256), dim3(256), 0, st, rmask, rmw, g.orows, rowext);
+    }
+    hipLaunchKernelGGL(bounds_kernel, dim3((g.ocols + 255) / 256, g.orows), dim3(256), 0, st, g, lmask, rmask, ext, rowext, prev, pw, ph, bounds, full_search);
+  }
+  // memory-cap loop over the conservation levels (SGM.cc:468-491) + ragged starts
+  std::vector<unsigned long long> h_rows(g.orows);
+  unsigned long long main_buf = 0;
+  bool ok = false;
+  const int threads = P->num_threads > 0 ? P->num_threads : 1;
+  for (int level = 0; level <= 3; ++level) {
+    if (prev) {
+      const int range = level == 0 ? 10 : level == 1 ? 25 : level == 2 ? 3 : 0;
+      vwgpu_prof_scope ps(ctx, "sgm_constrain");
+      hipLaunchKernelGGL(constrain_kernel, dim3((g.ocols + 255) / 256, g.orows), dim3(256), 0, st, g, full_search, bounds, range, level);
+    }
+    hipLaunchKernelGGL(row_count_kernel, dim3(g.orows), dim3(256), 0, st, bounds, g.ocols, rowsum);
+    VWGPU_HIP(ctx, hipMemcpyAsync(h_rows.data(), rowsum, (size_t)g.orows * 8, hipMemcpyDeviceToHost, st));
+    VWGPU_HIP(ctx, hipStreamSynchronize(st));
+    unsigned long long n = 0;
+    for (int r = 0; r < g.orows; ++r) { const unsigned long long v = h_rows[r]; h_rows[r] = n; n += v; }
+    if (n < 6) n = 6;
+    main_buf = n;
+    const int line_size = (int)(std::sqrt((double)(g.ocols * g.ocols + g.orows * g.orows)) + 1);
+    unsigned long long one_buf = (unsigned long long)line_size * (unsigned long long)num_disp;
+    if (one_buf > main_buf) one_buf = main_buf;
+    const double MB = 1024.0 * 1024.0;
+    const double total = (double)n * (3.0 / MB) + (double)(one_buf * threads) * (2.0 / MB);
+    if (!(total > (double)P->memory_limit_mb)) { ok = true; break; }
+  }
+  if (!ok) {   // "Unable to compute valid search ranges for SGM input": an all-invalid disparity (SGM.cc:2428-2434)
+    VWGPU_HIP(ctx, hipMemsetAsync(out_disp, 0, npix * 12, st));
+    if (out_sub) VWGPU_HIP(ctx, hipMemsetAsync(out_sub, 0, npix * 12, st));
+    return VWGPU_OK;
+  }
+  VWGPU_HIP(ctx, hipMemcpyAsync(rowoff, h_rows.data(), (size_t)g.orows * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(row_scan_kernel, dim3(g.orows), dim3(256), 0, st, bounds, g.ocols, rowoff, starts);
+
+  // the two ragged buffers (separate arena: reserving may reallocate, the fixed part above must stay put)
+  rc = vwgpu_arena_reserve(ctx, &ctx->sgm_main, (size_t)main_buf * 3 + 1024);
+  if (rc) return rc;
+  uint8_t* cost = static_cast<uint8_t*>(ctx->sgm_main.base);
+  uint16_t* accum = reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->sgm_main.base) + vwgpu_align_up((size_t)main_buf, 256));
+  VWGPU_HIP(ctx, hipMemsetAsync(accum, 0, (size_t)main_buf * 2, st));
+  {
+    vwgpu_prof_scope ps(ctx, "sgm_cost");
+    hipLaunchKernelGGL(cost_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, st, lc, lcw, rcen, rcw, bounds, starts, g.ocols, npix,
+                       min_col - hk, min_row - hk, cost);
+  }
+  // 8 directions, in the reference's order (SGM.cc:2488-2610)
+  {
+    const size_t lds = (size_t)num_disp * 2 * sizeof(uint16_t);
+    const int W = g.ocols, H = g.orows;
+    struct Dir { int dc, dr, n_first, first_is_row_border, n_second, second_skip; const char* name; };
+    const Dir dirs[8] = {
+      {0, 1, W, 1, 0, 0, "sgm_path_B"},   {0, -1, W, 1, 0, 0, "sgm_path_T"},
+      {1, 0, H, 0, 0, 0, "sgm_path_R"},   {-1, 0, H, 0, 0, 0, "sgm_path_L"},
+      {1, 1, W, 1, H - 1, 1, "sgm_path_BR"}, {-1, 1, W, 1, H - 1, 1, "sgm_path_BL"},
+      {1, -1, W, 1, H - 1, 0, "sgm_path_TR"}, {-1, -1, W, 1, H - 1, 0, "sgm_path_TL"}};
+    for (const Dir& d : dirs) {
+      vwgpu_prof_scope ps(ctx, d.name);
+      const int lines = d.n_first + d.n_second;
+      if (lines <= 0) continue;
+      hipLaunchKernelGGL(path_kernel, dim3(lines), dim3(64), lds, st, g, d.dc, d.dr, d.n_first, d.first_is_row_border, d.second_skip,
+                         l8, lw, min_col, min_row, bounds, starts, cost, accum, (unsigned)p1, (unsigned)p2);
+    }
+  }
+  {
+    vwgpu_prof_scope ps(ctx, "sgm_wta");
+    const size_t lds = (size_t)4 * 2 * num_disp * sizeof(uint16_t);
+    hipLaunchKernelGGL(wta_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), lds, st, bounds, starts, npix, (int)num_disp, accum, out_disp);
+  }
+  if (out_sub) {
+    vwgpu_prof_scope ps(ctx, "sgm_subpixel");
+    hipLaunchKernelGGL(subpixel_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, P->subpixel_mode, bounds, starts, npix, accum, out_disp, out_sub);
+  }
+  VWGPU_HIP(ctx, hipGetLastError());
+  return VWGPU_OK;
+}

@@ -92,6 +92,8 @@ void vwgpu_destroy(vwgpu_ctx* ctx) {
   if (ctx->pyr.base) (void)hipFree(ctx->pyr.base);
   if (ctx->ztab.base) (void)hipFree(ctx->ztab.base);
   if (ctx->zrl.base) (void)hipFree(ctx->zrl.base);
+  if (ctx->sgm.base) (void)hipFree(ctx->sgm.base);
+  if (ctx->sgm_main.base) (void)hipFree(ctx->sgm_main.base);
   if (ctx->staging.base) (void)hipFree(ctx->staging.base);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;

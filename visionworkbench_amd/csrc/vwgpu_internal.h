@@ -45,6 +45,8 @@ struct vwgpu_ctx {
   vwgpu_arena ztab;      // zone / tile tables of the batched zone kernels (two halves, alternating)
   int ztab_parity = 0;
   vwgpu_arena zrl;       // right-to-left disparity images of all zones of pyramid level 0
+  vwgpu_arena sgm;       // SGM: u8 images, census words, disparity bounds, ragged starts
+  vwgpu_arena sgm_main;  // SGM: ragged cost (u8) + accumulated cost (u16) buffers
   int num_cu = 256;
 };
 
@@ -149,3 +151,9 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
                                  const uint8_t* lmask, ptrdiff_t lms, const uint8_t* rmask, ptrdiff_t rms,
                                  const vwgpu_pyramid_params* P, int bx, int by, int bw, int bh,
                                  float* out, ptrdiff_t os);
+
+// sgm.hip
+int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left, int lw, int lh, ptrdiff_t ls,
+                   const float* right, int rw, int rh, ptrdiff_t rs, int sx, int sy,
+                   const uint8_t* lmask, int lmw, int lmh, const uint8_t* rmask, int rmw, int rmh,
+                   const int32_t* prev, int pw, int ph, int32_t* out_disp, float* out_sub, size_t out_cap_pixels, int* ow, int* oh);

@@ -278,6 +278,79 @@ def pyramid_correlate(left, right, left_mask, right_mask, prefilter_mode, prefil
     return out
 
 
-__all__ = ["calc_disparity", "cross_corr_consistency_check", "parabola_subpixel", "rm_outliers_using_thresh",
+SUBPIXEL_NONE, SUBPIXEL_PARABOLA, SUBPIXEL_LINEAR, SUBPIXEL_POLY4, SUBPIXEL_COSINE, SUBPIXEL_LC_BLEND = range(6)
+
+
+def calc_disparity_sgm(cost_type, left_in, right_in, left_region, search_volume, kernel_size, use_mgm=False,
+                       subpixel_mode=SUBPIXEL_LC_BLEND, search_buffer=(2, 2), memory_limit_mb=6000,
+                       left_mask=None, right_mask=None, prev_disparity=None, p1=0, p2=0, ternary_census_threshold=5,
+                       num_threads=1, with_subpixel=False, ctx=None):
+    """vw::stereo::calc_disparity_sgm (src/vw/Stereo/SGM.h:360-375, SGM.cc:167-229).
+
+    left_in / right_in: (rows, cols) float32; left_region: BBox2i inside the left image; search_volume = (sx, sy) is
+    INCLUSIVE like the reference's (the right crop is left_region grown by search_volume, so (sx+1) x (sy+1) disparities
+    are searched); kernel_size = (k, k) with k in {3, 5, 7, 9}; cost_type CENSUS_TRANSFORM / TERNARY_CENSUS_TRANSFORM.
+    Masks / prev_disparity as in SemiGlobalMatcher::semi_global_matching_func (SGM.h:149-157).
+    Returns the integer disparity (rows-k+1, cols-k+1, 3) int32; with_subpixel=True also returns the matcher's
+    create_disparity_view_subpixel result (the reference hands the matcher back through matcher_ptr for that)."""
+    from ._lib import SgmParams
+    kx, ky = int(kernel_size[0]), int(kernel_size[1])
+    sx, sy = int(search_volume[0]), int(search_volume[1])
+    if left_in.ndim != 2 or right_in.ndim != 2:
+        raise ArgumentErr("calc_disparity_sgm: images must be 2-D (rows, cols)")
+    if kx % 2 != 1 or ky % 2 != 1:
+        raise ArgumentErr("calc_disparity_sgm: Kernel input not sized with odd values.")
+    x0, y0 = left_region.min
+    x1, y1 = left_region.max
+    if x0 < 0 or y0 < 0 or x1 > left_in.shape[1] or y1 > left_in.shape[0]:
+        raise ArgumentErr("calc_disparity_sgm: Region not inside left image.")
+    lw, lh = x1 - x0, y1 - y0
+    if kx > lw or ky > lh:
+        raise ArgumentErr("calc_disparity_sgm: Kernel size too large of active region.")
+    rx1, ry1 = min(x1 + sx, right_in.shape[1]), min(y1 + sy, right_in.shape[0])
+    P = SgmParams(int(cost_type), int(bool(use_mgm)), kx, int(subpixel_mode), int(search_buffer[0]), int(search_buffer[1]),
+                  int(memory_limit_mb), int(p1), int(p2), int(ternary_census_threshold), int(num_threads))
+    ctx = _ctx_for(left_in, ctx)
+    lib = ctx._lib
+    ow, oh = ctypes.c_int(), ctypes.c_int()
+    cap = lw * lh
+
+    def shape2(a):
+        return (0, 0) if a is None else (a.shape[1], a.shape[0])
+    if _is_tensor(left_in):
+        if not (left_in.is_cuda and right_in.is_cuda) or left_in.dtype != torch.float32 or right_in.dtype != torch.float32:
+            raise ArgumentErr("calc_disparity_sgm: float32 CUDA tensors required (no CPU path)")
+        l = left_in[y0:y1, x0:x1].contiguous()
+        r = right_in[y0:ry1, x0:rx1].contiguous()
+        lm = left_mask.contiguous() if left_mask is not None else None
+        rm = right_mask.contiguous() if right_mask is not None else None
+        pd = prev_disparity.contiguous() if prev_disparity is not None else None
+        out = torch.empty((cap, 3), dtype=torch.int32, device=l.device)
+        sub = torch.empty((cap, 3), dtype=torch.float32, device=l.device) if with_subpixel else None
+        ctx.set_stream(torch.cuda.current_stream(l.device).cuda_stream)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        ctx.check(lib.vwgpu_calc_disparity_sgm_dev(ctx._h, ctypes.byref(P), l.data_ptr(), lw, lh, 0, r.data_ptr(), r.shape[1], r.shape[0], 0,
+                                                   sx, sy, ptr(lm), *shape2(lm), ptr(rm), *shape2(rm), ptr(pd), *shape2(pd),
+                                                   out.data_ptr(), ptr(sub), cap, ctypes.byref(ow), ctypes.byref(oh)))
+        n = ow.value * oh.value
+        res = out[:n].reshape(oh.value, ow.value, 3)
+        return (res, sub[:n].reshape(oh.value, ow.value, 3)) if with_subpixel else res
+    l = np.ascontiguousarray(left_in[y0:y1, x0:x1], np.float32)
+    r = np.ascontiguousarray(right_in[y0:ry1, x0:rx1], np.float32)
+    lm = np.ascontiguousarray(left_mask, np.uint8) if left_mask is not None else None
+    rm = np.ascontiguousarray(right_mask, np.uint8) if right_mask is not None else None
+    pd = np.ascontiguousarray(prev_disparity, np.int32) if prev_disparity is not None else None
+    out = np.empty((cap, 3), np.int32)
+    sub = np.empty((cap, 3), np.float32) if with_subpixel else None
+    ptr = lambda a: a.ctypes.data if a is not None else None
+    ctx.check(lib.vwgpu_calc_disparity_sgm(ctx._h, ctypes.byref(P), l.ctypes.data, lw, lh, 0, r.ctypes.data, r.shape[1], r.shape[0], 0,
+                                           sx, sy, ptr(lm), *shape2(lm), ptr(rm), *shape2(rm), ptr(pd), *shape2(pd),
+                                           out.ctypes.data, ptr(sub), cap, ctypes.byref(ow), ctypes.byref(oh)))
+    n = ow.value * oh.value
+    res = out[:n].reshape(oh.value, ow.value, 3).copy()
+    return (res, sub[:n].reshape(oh.value, ow.value, 3).copy()) if with_subpixel else res
+
+
+__all__ = ["calc_disparity", "calc_disparity_sgm", "cross_corr_consistency_check", "parabola_subpixel", "rm_outliers_using_thresh",
            "disparity_cleanup_using_thresh", "disparity_mask", "subdivide_regions", "pyramid_correlate",
            "BBox2i", "CostFunctionType"]
