@@ -245,8 +245,13 @@ typedef struct vwgpu_pyramid_params {
   int min_consistency_level;     /* accepted for signature parity; block matching checks at level 0 only */
   int filter_half_kernel;        /* 0: no clean-up filtering */
   int max_pyramid_levels;
-  int algorithm;                 /* 0 = VW_CORRELATION_BM; SGM/MGM answer VWGPU_ERR_NOIMPL for now */
+  int algorithm;                 /* 0 = VW_CORRELATION_BM, 1 = VW_CORRELATION_SGM; MGM variants answer VWGPU_ERR_NOIMPL */
   int blob_filter_area;          /* must be 0 for now */
+  /* SGM only (CorrelationView.h:211-214): */
+  int sgm_subpixel_mode;         /* vwgpu_sgm_subpixel; the reference's default is LC_BLEND */
+  int sgm_search_buffer_x, sgm_search_buffer_y;   /* default (2,2) */
+  size_t memory_limit_mb;        /* default 6000 */
+  int sgm_num_threads;           /* enters the memory-cap formula only; 0 = 1 */
 } vwgpu_pyramid_params;
 
 /* Replaces PyramidCorrelationView::prerasterize(bbox) for VW_CORRELATION_BM (src/vw/Stereo/CorrelationView.cc:273-886):

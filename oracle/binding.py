@@ -21,7 +21,7 @@ __all__ = ["build", "lib", "fast_box_sum", "cost_image", "calc_disparity", "calc
            "EDGE_CONSTANT", "EDGE_ZERO", "PREFILTER_NONE", "PREFILTER_MEANSUB", "PREFILTER_LOG",
            "subdivide_regions", "prefilter_region", "parabola_subpixel", "pyramid_correlate", "disparity_filter",
            "disparity_mask", "u8_convert", "census_transform", "hamming_distance", "SemiGlobalMatcher", "calc_disparity_sgm",
-           "CENSUS_TRANSFORM", "TERNARY_CENSUS_TRANSFORM", "SUBPIXEL_NONE", "SUBPIXEL_PARABOLA", "SUBPIXEL_LINEAR",
+           "pyramid_correlate_sgm", "CENSUS_TRANSFORM", "TERNARY_CENSUS_TRANSFORM", "SUBPIXEL_NONE", "SUBPIXEL_PARABOLA", "SUBPIXEL_LINEAR",
            "SUBPIXEL_POLY4", "SUBPIXEL_COSINE", "SUBPIXEL_LC_BLEND"]
 
 
@@ -74,6 +74,7 @@ def lib():
         _LIB.vwo_sgm_buffer_size.restype = Z
         _LIB.vwo_sgm_read.argtypes = [P, P, P, P, P]
         _LIB.vwo_sgm_p1p2.argtypes = [P, P, P]
+        _LIB.vwo_pyramid_correlate_sgm.argtypes = [P, I, I, P, I, I, P, P, I, I, I, I, I, I, F, I, I, I, I, I, I, Z, I, I, I, I, I, P]
         _LIB.vwo_calc_disparity_sgm.argtypes = [I, P, I, I, P, I, I, I, I, I, I, I, I, Z, I, P, I, I, P, I, I, P, I, I, P, P, P, P]
     return _LIB
 
@@ -393,3 +394,25 @@ def calc_disparity_sgm(cost_type, left, right, search_volume, kernel, subpixel=S
         raise ValueError("vwo_calc_disparity_sgm rc=%d" % rc)
     n = ow.value * oh.value * 3
     return (out.reshape(-1)[:n].reshape(oh.value, ow.value, 3).copy(), sub.reshape(-1)[:n].reshape(oh.value, ow.value, 3).copy())
+
+
+def pyramid_correlate_sgm(left, right, left_mask, right_mask, search_region, kernel, cost_type, consistency_threshold=-1.0,
+                          min_consistency_level=0, filter_half_kernel=0, max_pyramid_levels=5, subpixel=SUBPIXEL_LC_BLEND,
+                          search_buffer=(2, 2), memory_limit_mb=6000, num_threads=1, bbox=None):
+    """One tile of pyramid_correlate(..., VW_CORRELATION_SGM): returns (h, w, 3) float32 sub-pixel PixelMask<Vector2f>."""
+    l = np.ascontiguousarray(left, np.float32)
+    r = np.ascontiguousarray(right, np.float32)
+    lm = None if left_mask is None else np.ascontiguousarray(left_mask, np.uint8)
+    rm = None if right_mask is None else np.ascontiguousarray(right_mask, np.uint8)
+    if bbox is None:
+        bbox = (0, 0, l.shape[1], l.shape[0])
+    out = np.zeros((bbox[3], bbox[2], 3), np.float32)
+    rc = lib().vwo_pyramid_correlate_sgm(_p(l), l.shape[1], l.shape[0], _p(r), r.shape[1], r.shape[0],
+                                         None if lm is None else _p(lm), None if rm is None else _p(rm),
+                                         search_region[0], search_region[1], search_region[2], search_region[3], int(kernel), int(cost_type),
+                                         float(consistency_threshold), int(min_consistency_level), int(filter_half_kernel),
+                                         int(max_pyramid_levels), int(subpixel), search_buffer[0], search_buffer[1], memory_limit_mb,
+                                         num_threads, bbox[0], bbox[1], bbox[2], bbox[3], _p(out))
+    if rc:
+        raise ValueError("vwo_pyramid_correlate_sgm rc=%d" % rc)
+    return out

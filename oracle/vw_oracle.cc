@@ -813,14 +813,24 @@ int vwo_disparity_mask(int32_t* disp3, int w, int h, const uint8_t* lmask, const
   return 0;
 }
 
-int vwo_pyramid_correlate(const float* left, int lw, int lh, const float* right, int rw, int rh,
-                          const uint8_t* lmask_in, const uint8_t* rmask_in,
-                          int prefilter_mode, float prefilter_width,
-                          int sminx, int sminy, int smaxx, int smaxy, int kx, int ky, int cost_type,
-                          int corr_timeout, double seconds_per_op, float consistency_threshold,
-                          int filter_half_kernel, int max_pyramid_levels_arg,
-                          int bx, int by, int bw, int bh, float* out3f) {
+}  // extern "C" (reopened below)
+
+// algorithm 0 = VW_CORRELATION_BM, 1 = VW_CORRELATION_SGM (MGM variants are not restated)
+static int pyramid_impl(const float* left, int lw, int lh, const float* right, int rw, int rh,
+                        const uint8_t* lmask_in, const uint8_t* rmask_in,
+                        int prefilter_mode, float prefilter_width,
+                        int sminx, int sminy, int smaxx, int smaxy, int kx, int ky, int cost_type,
+                        int corr_timeout, double seconds_per_op, float consistency_threshold,
+                        int filter_half_kernel, int max_pyramid_levels_arg,
+                        int bx, int by, int bw, int bh, float* out3f,
+                        int algorithm, int min_consistency_level, int sgm_subpixel_mode, int sgm_sbx, int sgm_sby,
+                        size_t memory_limit_mb, int num_threads) {
   if (kx % 2 != 1 || ky % 2 != 1 || bw <= 0 || bh <= 0) return -1;
+  const bool use_sgm = algorithm != 0;
+  if (use_sgm) prefilter_mode = VWO_PREFILTER_NONE;                      // CorrelationView.h:96-97
+  std::vector<int32_t> prev_disparity, disparity_rl, prev_disparity_rl;
+  int pdw = 0, pdh = 0, rlw_ = 0, rlh_ = 0, prlw = 0, prlh = 0;
+  std::vector<float> subpixel_disparity;
   const Box search(sminx, sminy, smaxx, smaxy);
   const Box bbox = Box::xywh(bx, by, bw, bh);
   std::vector<uint8_t> lm_all, rm_all;
@@ -901,6 +911,53 @@ int vwo_pyramid_correlate(const float* left, int lw, int lh, const float* right,
       return (double)a.region.width() * a.region.height() * a.range.width() * a.range.height() <
              (double)b.region.width() * b.region.height() * b.range.width() * b.range.height(); });
     FImg const& Lv = lp[level]; FImg const& Rv = rp[level];
+    bool check_rl = false;
+    std::vector<uint8_t> right_rl_mask, left_rl_mask;
+    int rrm_w = 0, rrm_h = 0, lrm_w = 0, lrm_h = 0;
+    if (use_sgm) {                                                       // SGM branch (:391-595)
+      const int sx = search.width() / scaling, sy = search.height() / scaling;     // zone.disparity_range().size()
+      Box lr(0 + rox - hkx, 0 + roy - hky, dw + rox + hkx, dh + roy + hky);        // zone.image_region() + offset, expand(half_kernel)
+      Box rr(lr.minx, lr.miny, lr.maxx + sx, lr.maxy + sy);
+      std::vector<float> lc = crop_ext(Lv.d.data(), Lv.w, Lv.h, lr, VWO_EDGE_CONSTANT);
+      std::vector<float> rc = crop_ext(Rv.d.data(), Rv.w, Rv.h, rr, VWO_EDGE_CONSTANT);
+      const bool have_prev = level < L;
+      int ow = 0, oh = 0;
+      std::vector<int32_t> d((size_t)lr.sizex() * lr.sizey() * 3);
+      std::vector<float> sub(on_last_level ? d.size() : 0);
+      int rc_ = vwo_calc_disparity_sgm(cost_type, lc.data(), lr.sizex(), lr.sizey(), rc.data(), rr.sizex(), rr.sizey(), sx, sy, kx,
+                                       sgm_subpixel_mode, sgm_sbx, sgm_sby, memory_limit_mb, num_threads,
+                                       lmp[level].d.data(), lmp[level].w, lmp[level].h, rmp[level].d.data(), rmp[level].w, rmp[level].h,
+                                       have_prev ? prev_disparity.data() : nullptr, pdw, pdh, d.data(), on_last_level ? sub.data() : nullptr, &ow, &oh);
+      if (rc_) return rc_;
+      if (ow != dw || oh != dh) return -3;
+      std::copy(d.begin(), d.begin() + (size_t)dw * dh * 3, disparity.begin());
+      if (on_last_level) subpixel_disparity.assign(sub.begin(), sub.begin() + (size_t)dw * dh * 3);   // before the filters (:444-445)
+      if (consistency_threshold >= 0.0f && level >= min_consistency_level) {
+        check_rl = true;
+        Box rrev = rr;
+        Box lrev(lr.minx - sx, lr.miny - sy, lr.maxx - sx + 2 * sx, lr.maxy - sy + 2 * sy);
+        Box rmb_(0, 0, rrev.sizex() - 2 * hkx, rrev.sizey() - 2 * hky);
+        Box lmb_(0 - sx, 0 - sy, lrev.sizex() - 2 * hkx - sx, lrev.sizey() - 2 * hky - sy);
+        right_rl_mask = crop_ext(rmp[level].d.data(), rmp[level].w, rmp[level].h, rmb_, VWO_EDGE_ZERO);
+        left_rl_mask = crop_ext(lmp[level].d.data(), lmp[level].w, lmp[level].h, lmb_, VWO_EDGE_ZERO);
+        rrm_w = rmb_.sizex(); rrm_h = rmb_.sizey(); lrm_w = lmb_.sizex(); lrm_h = lmb_.sizey();
+        std::vector<float> a = crop_ext(Rv.d.data(), Rv.w, Rv.h, rrev, VWO_EDGE_CONSTANT);
+        std::vector<float> b = crop_ext(Lv.d.data(), Lv.w, Lv.h, lrev, VWO_EDGE_CONSTANT);
+        std::vector<int32_t> rl((size_t)rrev.sizex() * rrev.sizey() * 3);
+        int row = 0, roh = 0;
+        rc_ = vwo_calc_disparity_sgm(cost_type, a.data(), rrev.sizex(), rrev.sizey(), b.data(), lrev.sizex(), lrev.sizey(), sx, sy, kx,
+                                     sgm_subpixel_mode, sgm_sbx, sgm_sby, memory_limit_mb, num_threads,
+                                     right_rl_mask.data(), rrm_w, rrm_h, left_rl_mask.data(), lrm_w, lrm_h,
+                                     have_prev && !prev_disparity_rl.empty() ? prev_disparity_rl.data() : nullptr, prlw, prlh,
+                                     rl.data(), nullptr, &row, &roh);
+        if (rc_) return rc_;
+        rl.resize((size_t)row * roh * 3);
+        for (size_t i = 0; i < (size_t)row * roh; ++i) { rl[3*i] -= sx; rl[3*i+1] -= sy; }
+        vwo_cross_corr_consistency_check(disparity.data(), dw, dh, rl.data(), row, roh, consistency_threshold);
+        for (size_t i = 0; i < (size_t)row * roh; ++i) { rl[3*i] += sx; rl[3*i+1] += sy; }
+        disparity_rl.swap(rl); rlw_ = row; rlh_ = roh;
+      }
+    } else
     for (Zone const& zone : zones) {
       Box lr(zone.region.minx + rox - hkx, zone.region.miny + roy - hky, zone.region.maxx + rox + hkx, zone.region.maxy + roy + hky);
       Box rr(lr.minx + zone.range.minx, lr.miny + zone.range.miny, lr.maxx + zone.range.minx + zone.range.sizex(), lr.maxy + zone.range.miny + zone.range.sizey());
@@ -940,9 +997,17 @@ int vwo_pyramid_correlate(const float* left, int lw, int lh, const float* right,
     if (filter_half_kernel > 0) {
       disparity_filter(disparity, dw, dh, filter_half_kernel, filter_half_kernel, 3.0, 0.5, !on_last_level);
       disparity_mask(disparity, dw, dh, lmp[level].d.data(), rmp[level].d.data(), rmp[level].w, rmp[level].h);
+      if (!on_last_level && check_rl && use_sgm) {                       // the R->L result seeds the next level's R->L run (:722-730)
+        disparity_filter(disparity_rl, rlw_, rlh_, filter_half_kernel, filter_half_kernel, 3.0, 0.5, true);
+        disparity_mask(disparity_rl, rlw_, rlh_, right_rl_mask.data(), left_rl_mask.data(), lrm_w, lrm_h);
+      }
+    }
+    if (use_sgm) {                                                       // prev_disparity = disparity at the top of the next level (:368-371)
+      prev_disparity = disparity; pdw = dw; pdh = dh;
+      if (check_rl) { prev_disparity_rl = disparity_rl; prlw = rlw_; prlh = rlh_; } else { prev_disparity_rl.clear(); }
     }
     // 3.2b) refine the search estimates (:754-799)
-    if (!on_last_level) {
+    if (!on_last_level && !use_sgm) {
       zones.clear();
       subdivide(disparity.data(), dw, dh, Box(0, 0, dw, dh), zones, kx, ky);
       scaling >>= 1;
@@ -961,6 +1026,14 @@ int vwo_pyramid_correlate(const float* left, int lw, int lh, const float* right,
     }
   }
   if (dw != bw || dh != bh) return -2;
+  if (use_sgm) {                                                         // (:862-875) sub-pixel view, filtered pixels invalidated
+    for (size_t i = 0; i < (size_t)bw * bh; ++i) {
+      out3f[3*i] = subpixel_disparity[3*i] + (float)search.minx;
+      out3f[3*i+1] = subpixel_disparity[3*i+1] + (float)search.miny;
+      out3f[3*i+2] = (disparity[3*i+2] && subpixel_disparity[3*i+2] != 0.0f) ? 1.0f : 0.0f;
+    }
+    return 0;
+  }
   // 5.0) + search.min, cast to float (:876-885); invalid pixels keep valid = 0, child gets the offset as well
   for (size_t i = 0; i < (size_t)bw * bh; ++i) {
     out3f[3*i] = (float)(disparity[3*i] + search.minx);
@@ -968,6 +1041,30 @@ int vwo_pyramid_correlate(const float* left, int lw, int lh, const float* right,
     out3f[3*i+2] = disparity[3*i+2] ? 1.0f : 0.0f;
   }
   return 0;
+}
+
+
+extern "C" {
+
+int vwo_pyramid_correlate(const float* left, int lw, int lh, const float* right, int rw, int rh,
+                          const uint8_t* lmask, const uint8_t* rmask, int prefilter_mode, float prefilter_width,
+                          int sminx, int sminy, int smaxx, int smaxy, int kx, int ky, int cost_type,
+                          int corr_timeout, double seconds_per_op, float consistency_threshold,
+                          int filter_half_kernel, int max_pyramid_levels, int bx, int by, int bw, int bh, float* out3f) {
+  return pyramid_impl(left, lw, lh, right, rw, rh, lmask, rmask, prefilter_mode, prefilter_width, sminx, sminy, smaxx, smaxy, kx, ky,
+                      cost_type, corr_timeout, seconds_per_op, consistency_threshold, filter_half_kernel, max_pyramid_levels,
+                      bx, by, bw, bh, out3f, 0, 0, 0, 0, 0, 0, 1);
+}
+
+int vwo_pyramid_correlate_sgm(const float* left, int lw, int lh, const float* right, int rw, int rh,
+                              const uint8_t* lmask, const uint8_t* rmask,
+                              int sminx, int sminy, int smaxx, int smaxy, int kernel, int cost_type,
+                              float consistency_threshold, int min_consistency_level, int filter_half_kernel, int max_pyramid_levels,
+                              int sgm_subpixel_mode, int sgm_sbx, int sgm_sby, size_t memory_limit_mb, int num_threads,
+                              int bx, int by, int bw, int bh, float* out3f) {
+  return pyramid_impl(left, lw, lh, right, rw, rh, lmask, rmask, 0, 0.0f, sminx, sminy, smaxx, smaxy, kernel, kernel,
+                      cost_type, 0, 0.0, consistency_threshold, filter_half_kernel, max_pyramid_levels,
+                      bx, by, bw, bh, out3f, 1, min_consistency_level, sgm_subpixel_mode, sgm_sbx, sgm_sby, memory_limit_mb, num_threads);
 }
 
 }  // extern "C"

@@ -128,6 +128,15 @@ int vwo_pyramid_correlate(const float* left, int lw, int lh, const float* right,
                           int filter_half_kernel, int max_pyramid_levels,
                           int bx, int by, int bw, int bh, float* out3f);
 
+/* The same tile with VW_CORRELATION_SGM (SGM branch, CorrelationView.cc:391-595; final sub-pixel view :862-875).
+ * kernel is square; cost_type 3 = census, 4 = ternary census. */
+int vwo_pyramid_correlate_sgm(const float* left, int lw, int lh, const float* right, int rw, int rh,
+                              const uint8_t* lmask, const uint8_t* rmask,
+                              int sminx, int sminy, int smaxx, int smaxy, int kernel, int cost_type,
+                              float consistency_threshold, int min_consistency_level, int filter_half_kernel, int max_pyramid_levels,
+                              int sgm_subpixel_mode, int sgm_sbx, int sgm_sby, size_t memory_limit_mb, int num_threads,
+                              int bx, int by, int bw, int bh, float* out3f);
+
 /* rm_outliers_using_thresh / disparity_cleanup_using_thresh / disparity_mask on whole images
  * (src/vw/Stereo/DisparityMap.h:318-441, 97-253); disp3 in place.  cleanup != 0 adds the second (1,1,3.0,0.20) pass. */
 int vwo_disparity_filter(int32_t* disp3, int w, int h, int half_h, int half_v, double pixel_thr, double rej_thr, int cleanup);

@@ -137,3 +137,72 @@ def test_torch_device_entry_and_errors(vw, oracle):
         vw.calc_disparity_sgm(CENSUS, left, right, _box(50, 40), (5, 3), (5, 5), use_mgm=True)
     with pytest.raises(ArgumentErr):
         vw.calc_disparity_sgm(CENSUS, left, right, _box(51, 40), (5, 3), (5, 5))
+
+
+# ---- pyramid_correlate with VW_CORRELATION_SGM ------------------------------------------------------------------------
+
+@pytest.mark.parametrize("thr", [-1, 2])
+@pytest.mark.parametrize("k,cost", [(5, CENSUS), (7, TERNARY)])
+def test_pyramid_sgm_identical_to_oracle(vw, oracle, thr, k, cost):
+    """The SGM branch of PyramidCorrelationView::prerasterize (CorrelationView.cc:391-595, 862-875) on the scene of
+    TestPyramidCorrelationView.cxx: integer part and validity identical, sub-pixel part within 1e-5."""
+    import scenes
+    from visionworkbench_amd.core import BBox2i
+    left, right, scale, trans, search = scenes.pyramid_scene("u8")
+    g = vw.pyramid_correlate(left, right, None, None, 0, 0.0, BBox2i.from_corners(search[:2], search[2:]), (k, k), cost,
+                             consistency_threshold=thr, filter_half_kernel=5, max_pyramid_levels=5, algorithm=1)
+    o = oracle.pyramid_correlate_sgm(left, right, None, None, search, k, cost, thr, 0, 5, 5)
+    assert g.shape == o.shape == left.shape + (3,)
+    assert np.array_equal(g[..., 2], o[..., 2])
+    assert np.abs(g[..., :2] - o[..., :2]).max() < 1e-5
+    c, a = scenes.pyramid_score(np.concatenate([np.rint(g[..., :2]), g[..., 2:]], axis=2), scale, trans)
+    assert c > 0.8 and a > 0.75
+
+
+def test_pyramid_sgm_masks_and_subtile(vw, oracle):
+    import scenes
+    from visionworkbench_amd.core import BBox2i, NoImplErr
+    left, right, scale, trans, search = scenes.pyramid_scene("u8")
+    lm = np.full(left.shape, 255, np.uint8)
+    rm = np.full(right.shape, 255, np.uint8)
+    lm[40:90, 100:160] = 0
+    rm[120:, 200:] = 0
+    box = BBox2i.from_corners(search[:2], search[2:])
+    g = vw.pyramid_correlate(left, right, lm, rm, 0, 0.0, box, (5, 5), CENSUS, consistency_threshold=2, min_consistency_level=1,
+                             filter_half_kernel=3, max_pyramid_levels=3, algorithm=1, bbox=BBox2i(32, 16, 200, 150))
+    o = oracle.pyramid_correlate_sgm(left, right, lm, rm, search, 5, CENSUS, 2, 1, 3, 3, bbox=(32, 16, 200, 150))
+    assert np.array_equal(g[..., 2], o[..., 2]) and np.abs(g[..., :2] - o[..., :2]).max() < 1e-5
+    with pytest.raises(NoImplErr):
+        vw.pyramid_correlate(left, right, None, None, 0, 0.0, box, (5, 5), 0, algorithm=1)        # block cost with SGM
+    with pytest.raises(NoImplErr):
+        vw.pyramid_correlate(left, right, None, None, 0, 0.0, box, (5, 5), CENSUS, algorithm=2)   # MGM
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomized_masks_and_previous_level(vw, oracle, seed):
+    """Differential test of populate_disp_bound_image + constrain_disp_bound_image + the ragged path recurrence: random
+    kernel / search sizes, masks with empty borders, a previous-level disparity with untrusted holes and odd sizes."""
+    rng = np.random.default_rng(100 + seed)
+    V = np.iinfo(np.int32).max
+    k = int(rng.choice([3, 5, 7]))
+    sx, sy = int(rng.integers(2, 14)), int(rng.integers(1, 6))
+    h, w = int(rng.integers(40, 70)), int(rng.integers(50, 90))
+    base = rng.integers(0, 256, (h + sy + 8, w + sx + 8)).astype(np.float32)
+    left = np.ascontiguousarray(base[4:4 + h, 4:4 + w])
+    right = np.ascontiguousarray(base[2:2 + h + sy, 1:1 + w + sx])
+    oh, ow = h - k + 1, w - k + 1
+    lm = np.full((oh, ow), 255, np.uint8)
+    lm[:int(rng.integers(0, 5))] = 0
+    lm[:, :int(rng.integers(0, 5))] = 0
+    rm = np.full((oh + sy + int(rng.integers(0, 4)), ow + sx + int(rng.integers(0, 4))), 255, np.uint8)
+    rm[:int(rng.integers(0, sy + 2))] = 0
+    rm[:, :int(rng.integers(0, sx + 2))] = 0
+    rm[-int(rng.integers(1, 4)):] = 0
+    ph, pw = (oh + 1) // 2 + int(rng.integers(-3, 4)), (ow + 1) // 2 + int(rng.integers(-3, 4))
+    prev = np.zeros((ph, pw, 3), np.int32)
+    prev[..., 0] = rng.integers(0, sx // 2 + 1, (ph, pw))
+    prev[..., 1] = rng.integers(0, sy // 2 + 1, (ph, pw))
+    prev[..., 2] = np.where(rng.random((ph, pw)) < 0.3, 0, V)
+    gi, gs, oi, os_ = _both(vw, oracle, CENSUS, left, right, (sx, sy), k, 5, lm=lm, rm=rm, prev=prev)
+    assert np.array_equal(gi, oi)
+    assert np.abs(gs - os_).max() < 1e-5

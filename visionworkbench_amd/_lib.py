@@ -47,6 +47,8 @@ class PyramidParams(ctypes.Structure):
         ("consistency_threshold", ctypes.c_float), ("min_consistency_level", ctypes.c_int),
         ("filter_half_kernel", ctypes.c_int), ("max_pyramid_levels", ctypes.c_int),
         ("algorithm", ctypes.c_int), ("blob_filter_area", ctypes.c_int),
+        ("sgm_subpixel_mode", ctypes.c_int), ("sgm_search_buffer_x", ctypes.c_int), ("sgm_search_buffer_y", ctypes.c_int),
+        ("memory_limit_mb", ctypes.c_size_t), ("sgm_num_threads", ctypes.c_int),
     ]
 
 

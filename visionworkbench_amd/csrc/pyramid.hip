@@ -143,6 +143,16 @@ __global__ void finish_kernel(const int32_t* __restrict__ d, int w, int h, int a
   o[0] = (float)(p[0] + ax); o[1] = (float)(p[1] + ay); o[2] = p[2] ? 1.0f : 0.0f;
 }
 
+// SGM result: sub-pixel view + search.min, invalid where the filtered integer disparity is (CorrelationView.cc:862-875)
+__global__ void finish_sgm_kernel(const int32_t* __restrict__ d, const float* __restrict__ sub, int w, int h, float ax, float ay,
+                                  float* __restrict__ out, ptrdiff_t ostride_px) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const size_t i = ((size_t)y * w + x) * 3;
+  float* o = out + ((ptrdiff_t)y * ostride_px + x) * 3;
+  o[0] = sub[i] + ax; o[1] = sub[i + 1] + ay; o[2] = (d[i + 2] && sub[i + 2] != 0.0f) ? 1.0f : 0.0f;
+}
+
 __global__ void zero_out_kernel(float* __restrict__ out, ptrdiff_t ostride_px, int w, int h) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= w || y >= h) return;
@@ -224,7 +234,11 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   const size_t need = 4 * (nl + nr) * 3 + (nl + nr) * 2 + (size_t)rmb.dx() * rmb.dy() * 2 + (size_t)bw * bh * (12 * 3 + 2) +
                       (size_t)(bw + 2) * (bh + 2) * 12 + (nl + nr) * 4 * 2 + (size_t)(rg.dx() + 2 * search.dx()) * (rg.dy() + 2 * search.dy()) * 20 +
                       (1 << 20);
-  int rc = vwgpu_arena_reserve(ctx, &ctx->pyr, need);
+  // SGM: R->L crops (left image grown by twice the search), R->L masks, disparities of both directions and their history
+  const size_t rl_px = (size_t)(bw + search.dx() + 8) * (bh + search.dy() + 8);
+  const size_t lrev_px = (size_t)(lg.dx() + 2 * search.dx() + 8) * (lg.dy() + 2 * search.dy() + 8);
+  const size_t need_sgm = P->algorithm != 0 ? lrev_px * 4 + rl_px * (12 * 5 + 1) + lrev_px + (size_t)bw * bh * (12 + 12) + (1 << 16) : 0;
+  int rc = vwgpu_arena_reserve(ctx, &ctx->pyr, need + need_sgm);
   if (rc) return rc;
   Bump A{static_cast<char*>(ctx->pyr.base), ctx->pyr.cap};
   std::vector<DevImg> lp(L + 1), rp(L + 1);
@@ -277,7 +291,9 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     if ((rc = vwgpu_launch_mask_by_two(ctx, rmp[i - 1].p, rmp[i - 1].w, rmp[i - 1].h, rmp[i - 1].w, rmp[i].p, rmp[i].w))) return rc;
   }
   // prefilter every level (:232-236); levels stay unfiltered sources of the next level, so filter into copies
-  const bool filtered = (P->prefilter_mode == VWGPU_PREFILTER_LOG || P->prefilter_mode == VWGPU_PREFILTER_MEANSUB);
+  const bool use_sgm = P->algorithm != 0;
+  // SGM/MGM run without a prefilter (CorrelationView.h:96-97)
+  const bool filtered = !use_sgm && (P->prefilter_mode == VWGPU_PREFILTER_LOG || P->prefilter_mode == VWGPU_PREFILTER_MEANSUB);
   if (filtered) {
     for (int i = 0; i <= L; ++i) {
       float* lf = A.take<float>((size_t)lp[i].w * lp[i].h);
@@ -297,6 +313,21 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   float* tmp_a = A.take<float>(nl + nr);
   float* tmp_b = A.take<float>((size_t)(rg.dx() + 2 * search.dx()) * (rg.dy() + 2 * search.dy()));
   if (!disp || !disp2 || !padded || !rl || !tmp_a || !tmp_b) return fail_mem();
+  float* sgm_b = nullptr; float* sub = nullptr; uint8_t* rl_rmask = nullptr; uint8_t* rl_lmask = nullptr;
+  int32_t *prev_disp = nullptr, *rl_a = nullptr, *rl_b = nullptr, *rl_pad = nullptr, *prev_rl = nullptr;
+  if (use_sgm) {
+    sgm_b = A.take<float>(lrev_px); sub = A.take<float>((size_t)bw * bh * 3);
+    rl_rmask = A.take<uint8_t>(rl_px); rl_lmask = A.take<uint8_t>(lrev_px);
+    prev_disp = A.take<int32_t>((size_t)bw * bh * 3);
+    rl_a = A.take<int32_t>(rl_px * 3); rl_b = A.take<int32_t>(rl_px * 3); rl_pad = A.take<int32_t>(rl_px * 3 + 64); prev_rl = A.take<int32_t>(rl_px * 3);
+    if (!sgm_b || !sub || !rl_rmask || !rl_lmask || !prev_disp || !rl_a || !rl_b || !rl_pad || !prev_rl) return fail_mem();
+  }
+  int pdw = 0, pdh = 0, prlw = 0, prlh = 0;
+  bool have_prev_rl = false;
+  vwgpu_sgm_params SP;
+  SP.cost_type = P->cost_type; SP.use_mgm = 0; SP.kernel_size = kx; SP.subpixel_mode = P->sgm_subpixel_mode;
+  SP.search_buffer_x = P->sgm_search_buffer_x; SP.search_buffer_y = P->sgm_search_buffer_y; SP.memory_limit_mb = P->memory_limit_mb;
+  SP.p1 = 0; SP.p2 = 0; SP.ternary_census_threshold = 5; SP.num_threads = P->sgm_num_threads > 0 ? P->sgm_num_threads : 1;
   std::vector<int32_t> host_disp;
   std::vector<SearchZone> zones;
   zones.push_back(SearchZone{IBox(0, 0, lmp[L].w, lmp[L].h), IBox(0, 0, search.width() / up + 1, search.height() / up + 1)});
@@ -316,7 +347,46 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     const bool lr_active = P->consistency_threshold >= 0 && last;
     // One launch for all zones of the level (bm_zones.hip) unless the kernel is too large for its LDS tiles, or the
     // level is a single big zone (max_pyramid_levels = 0: that is plain calc_disparity and has faster kernels).
-    bool batched = vwgpu_bm_zones_supported(kx, ky) && saved_force == VWGPU_PATH_NONE;
+    bool check_rl = false;
+    int rlw = 0, rlh = 0, lrm_w = 0, lrm_h = 0;
+    if (use_sgm) {                                                      // SGM branch (CorrelationView.cc:391-595)
+      ctx->forced_path = saved_force;
+      const int sx = search.width() / scaling, sy = search.height() / scaling;   // zone.disparity_range().size(), inclusive for SGM
+      const IBox lr(rox - hkx, roy - hky, dw + rox + hkx, dh + roy + hky);
+      const IBox rr(lr.x0, lr.y0, lr.x1 + sx, lr.y1 + sy);
+      if ((size_t)rr.dx() * rr.dy() > (size_t)(rg.dx() + 2 * search.dx()) * (rg.dy() + 2 * search.dy()) || (size_t)lr.dx() * lr.dy() > nl + nr)
+        return fail_mem();
+      hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(lr.dx(), lr.dy()), kBlk, 0, st, Lv.p, Lv.w, Lv.w, Lv.h, lr.x0, lr.y0, tmp_a, lr.dx(), lr.dy());
+      hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(rr.dx(), rr.dy()), kBlk, 0, st, Rv.p, Rv.w, Rv.w, Rv.h, rr.x0, rr.y0, tmp_b, rr.dx(), rr.dy());
+      const bool have_prev = level < L;
+      int ow = 0, oh = 0;
+      rc = vwgpu_sgm_impl(ctx, &SP, tmp_a, lr.dx(), lr.dy(), lr.dx(), tmp_b, rr.dx(), rr.dy(), rr.dx(), sx, sy,
+                          lmp[level].p, lmp[level].w, lmp[level].h, rmp[level].p, rmp[level].w, rmp[level].h,
+                          have_prev ? prev_disp : nullptr, pdw, pdh, disp, last ? sub : nullptr, (size_t)dw * dh, &ow, &oh);
+      if (rc) return rc;
+      if (ow != dw || oh != dh) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "pyramid_correlate: SGM output %d x %d does not match the level size %d x %d", ow, oh, dw, dh);
+      if (P->consistency_threshold >= 0.0f && level >= P->min_consistency_level) {
+        check_rl = true;
+        const IBox lrev(lr.x0 - sx, lr.y0 - sy, lr.x1 + sx, lr.y1 + sy);          // (left_region - size).max += 2 size
+        rlw = rr.dx() - 2 * hkx; rlh = rr.dy() - 2 * hky;
+        lrm_w = lrev.dx() - 2 * hkx; lrm_h = lrev.dy() - 2 * hky;
+        if ((size_t)lrev.dx() * lrev.dy() > lrev_px || (size_t)rlw * rlh > rl_px) return fail_mem();
+        hipLaunchKernelGGL((crop_ext_kernel<uint8_t, 1>), grid2(rlw, rlh), kBlk, 0, st, rmp[level].p, rmp[level].w, rmp[level].w, rmp[level].h, 0, 0, rl_rmask, rlw, rlh);
+        hipLaunchKernelGGL((crop_ext_kernel<uint8_t, 1>), grid2(lrm_w, lrm_h), kBlk, 0, st, lmp[level].p, lmp[level].w, lmp[level].w, lmp[level].h, -sx, -sy, rl_lmask, lrm_w, lrm_h);
+        hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(lrev.dx(), lrev.dy()), kBlk, 0, st, Lv.p, Lv.w, Lv.w, Lv.h, lrev.x0, lrev.y0, sgm_b, lrev.dx(), lrev.dy());
+        int row = 0, roh = 0;
+        rc = vwgpu_sgm_impl(ctx, &SP, tmp_b, rr.dx(), rr.dy(), rr.dx(), sgm_b, lrev.dx(), lrev.dy(), lrev.dx(), sx, sy,
+                            rl_rmask, rlw, rlh, rl_lmask, lrm_w, lrm_h, (have_prev && have_prev_rl) ? prev_rl : nullptr, prlw, prlh,
+                            rl_a, nullptr, rl_px, &row, &roh);
+        if (rc) return rc;
+        if (row != rlw || roh != rlh) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "pyramid_correlate: SGM R->L output size mismatch");
+        hipLaunchKernelGGL(add_offset_kernel, grid2(rlw, rlh), kBlk, 0, st, rl_a, rlw, rlw, rlh, -sx, -sy);
+        rc = vwgpu_launch_lr_check(ctx, disp, dw, dh, dw, rl_a, rlw, rlh, rlw, P->consistency_threshold);
+        if (rc) return rc;
+        hipLaunchKernelGGL(add_offset_kernel, grid2(rlw, rlh), kBlk, 0, st, rl_a, rlw, rlw, rlh, sx, sy);
+      }
+    }
+    bool batched = !use_sgm && vwgpu_bm_zones_supported(kx, ky) && saved_force == VWGPU_PATH_NONE;
     if (batched && zones.size() == 1 && (double)zones[0].region.dx() * zones[0].region.dy() * zones[0].range.dx() * zones[0].range.dy() > 3.2e7)
       batched = false;
     if (batched) {
@@ -355,7 +425,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         if ((rc = vwgpu_launch_bm_zones(ctx, P->cost_type, Rv.p, Rv.w, Rv.h, Lv.p, Lv.w, Lv.h, kx, ky, t2.data(), (int)t2.size(), rlbuf))) return rc;
         if ((rc = vwgpu_launch_zone_lr(ctx, t3.data(), (int)t3.size(), disp, rlbuf, P->consistency_threshold))) return rc;
       }
-    } else
+    } else if (!use_sgm)
     for (SearchZone const& z : zones) {
       const IBox lr(z.region.x0 + rox - hkx, z.region.y0 + roy - hky, z.region.x1 + rox + hkx, z.region.y1 + roy + hky);
       const IBox rr(lr.x0 + z.range.x0, lr.y0 + z.range.y0, lr.x1 + z.range.x0 + z.range.dx(), lr.y1 + z.range.y0 + z.range.dy());
@@ -405,9 +475,22 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
       std::swap(disp, disp2);
       rc = vwgpu_launch_disparity_mask(ctx, disp, dw, dh, lmp[level].p, rmp[level].p, rmp[level].w, rmp[level].h);
       if (rc) return rc;
+      if (!last && check_rl && use_sgm) {           // the R->L result seeds the next level's R->L run (:722-730)
+        rc = vwgpu_launch_disparity_filter(ctx, rl_a, rlw, rlh, P->filter_half_kernel, P->filter_half_kernel, 3.0, 0.5, true, rl_pad, rl_b);
+        if (rc) return rc;
+        std::swap(rl_a, rl_b);
+        rc = vwgpu_launch_disparity_mask(ctx, rl_a, rlw, rlh, rl_rmask, rl_lmask, lrm_w, lrm_h);
+        if (rc) return rc;
+      }
+    }
+    if (use_sgm && !last) {                         // prev_disparity / prev_disparity_rl of the next level (:368-371)
+      VWGPU_HIP(ctx, hipMemcpyAsync(prev_disp, disp, (size_t)dw * dh * 12, hipMemcpyDeviceToDevice, st));
+      pdw = dw; pdh = dh;
+      have_prev_rl = check_rl;
+      if (check_rl) { std::swap(prev_rl, rl_a); prlw = rlw; prlh = rlh; }
     }
     // zone refinement (:754-799): the scheduler is data dependent host logic
-    if (!last) {
+    if (!last && !use_sgm) {
       host_disp.resize((size_t)dw * dh * 3);
       VWGPU_HIP(ctx, hipMemcpyAsync(host_disp.data(), disp, host_disp.size() * 4, hipMemcpyDeviceToHost, st));
       VWGPU_HIP(ctx, hipStreamSynchronize(st));
@@ -426,7 +509,10 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     }
   }
   if (dw != bw || dh != bh) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "PyramidCorrelation: Solved disparity doesn't match requested bbox size.");
-  hipLaunchKernelGGL(finish_kernel, grid2(bw, bh), kBlk, 0, st, disp, bw, bh, search.x0, search.y0, out, os);
+  if (use_sgm)
+    hipLaunchKernelGGL(finish_sgm_kernel, grid2(bw, bh), kBlk, 0, st, disp, sub, bw, bh, (float)search.x0, (float)search.y0, out, os);
+  else
+    hipLaunchKernelGGL(finish_kernel, grid2(bw, bh), kBlk, 0, st, disp, bw, bh, search.x0, search.y0, out, os);
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }
@@ -525,9 +611,16 @@ static int check_pyramid_args(vwgpu_ctx* ctx, const void* l, int lw, int lh, con
   if (P->search_max_x <= P->search_min_x || P->search_max_y <= P->search_min_y)
     return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "PyramidCorrelationView: Invalid search region: (%d,%d)-(%d,%d); a box of zero height is empty (use height >= 1)",
                       P->search_min_x, P->search_min_y, P->search_max_x, P->search_max_y);
-  if (P->cost_type < VWGPU_ABSOLUTE_DIFFERENCE || P->cost_type > VWGPU_CROSS_CORRELATION)
+  if (P->algorithm == 0 && (P->cost_type < VWGPU_ABSOLUTE_DIFFERENCE || P->cost_type > VWGPU_CROSS_CORRELATION))
     return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: cost type %d is not a block-matching cost", P->cost_type);
-  if (P->algorithm != 0) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: only VW_CORRELATION_BM is implemented (algorithm %d)", P->algorithm);
+  if (P->algorithm != 0 && P->algorithm != 1)
+    return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: VW_CORRELATION_BM and VW_CORRELATION_SGM are implemented (algorithm %d is MGM)", P->algorithm);
+  if (P->algorithm == 1) {
+    if (P->cost_type != VWGPU_CENSUS_TRANSFORM && P->cost_type != VWGPU_TERNARY_CENSUS_TRANSFORM)
+      return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "With SGM/MGM, only the census transform cost mode gives good results.");
+    if (P->kernel_x != P->kernel_y || (P->kernel_x != 3 && P->kernel_x != 5 && P->kernel_x != 7 && P->kernel_x != 9))
+      return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "Census transforms are only available in size 3, 5, 7, and 9.");
+  }
   if (P->blob_filter_area > 0) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: blob filter is not implemented");
   if (P->max_pyramid_levels < 0 || P->filter_half_kernel < 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate: negative level / filter size");
   return VWGPU_OK;

@@ -122,43 +122,43 @@ __global__ void mask_row_extent_kernel(const uint8_t* __restrict__ rmask, int rm
 
 struct SgmGeom { int min_dx, min_dy, max_dx, max_dy, num_dx, num_dy, sbx, sby, ocols, orows; };
 
-__global__ void bounds_kernel(SgmGeom g, const uint8_t* __restrict__ lmask, const uint8_t* __restrict__ rmask_present,
-                              const int* __restrict__ ext, const int2* __restrict__ rowext,
-                              const int32_t* __restrict__ prev, int pw, int ph,
-                              B4* __restrict__ bounds, uint8_t* __restrict__ full_search) {
+__global__ void bounds_kernel(SgmGeom g, const uint8_t* lmask, const uint8_t* rmask_present,
+                              const int* ext, const int2* rowext, const int32_t* prev, int pw, int ph,
+                              B4* bounds, uint8_t* full_search) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
   if (c >= g.ocols) return;
   const size_t idx = (size_t)r * g.ocols + c;
-  const B4 ZERO{0, 0, -1, -1};
-  full_search[idx] = 0;
-  if (lmask && lmask[idx] == 0) { bounds[idx] = ZERO; return; }
-  bool good = false;
-  int dxs = 0, dys = 0;
-  if (prev) {
-    const int c_in = c / 2, r_in = r / 2;
-    if (!(c_in >= pw || r_in >= ph)) {
-      const int32_t* d = prev + ((size_t)r_in * pw + c_in) * 3;
-      dxs = d[0] * 2; dys = d[1] * 2;
-      const bool on_edge = (g.num_dx >= 10 && (dxs <= g.min_dx || dxs >= g.max_dx)) || (g.num_dy >= 10 && (dys <= g.min_dy || dys >= g.max_dy));
-      good = d[2] != 0 && !on_edge;
+  B4 b{0, 0, -1, -1};                       // ZERO_SEARCH_AREA
+  uint8_t fs = 0;
+  if (!(lmask && lmask[idx] == 0)) {
+    bool good = false;
+    int dxs = 0, dys = 0;
+    if (prev) {
+      const int c_in = c / 2, r_in = r / 2;
+      if (!(c_in >= pw || r_in >= ph)) {
+        const int32_t* d = prev + ((size_t)r_in * pw + c_in) * 3;
+        dxs = d[0] * 2; dys = d[1] * 2;
+        const bool on_edge = (g.num_dx >= 10 && (dxs <= g.min_dx || dxs >= g.max_dx)) || (g.num_dy >= 10 && (dys <= g.min_dy || dys >= g.max_dy));
+        good = d[2] != 0 && !on_edge;
+      }
+    }
+    if (good) {
+      b.x0 = max(dxs - g.sbx, g.min_dx); b.x1 = min(dxs + g.sbx, g.max_dx);
+      b.y0 = max(dys - g.sby, g.min_dy); b.y1 = min(dys + g.sby, g.max_dy);
+    } else {
+      b.x0 = g.min_dx; b.y0 = g.min_dy; b.x1 = g.max_dx; b.y1 = g.max_dy;
+      fs = 255;
+    }
+    if (rmask_present) {
+      int vx0 = rowext[r].x, vx1 = rowext[r].y, vy0 = ext[0], vy1 = ext[1];
+      if (!(vx0 >= vx1 || vy0 >= vy1)) { vx0 -= c; vx1 -= c; vy0 -= r; vy1 -= r; }    // BBox -= on an empty box is a no-op
+      vx0 = max(vx0, b.x0); vy0 = max(vy0, b.y0); vx1 = min(vx1, b.x1); vy1 = min(vy1, b.y1);
+      if (vx0 > vx1 || vy0 > vy1) { b = B4{0, 0, -1, -1}; fs = 0; }
+      else b = B4{vx0, vy0, vx1, vy1};
     }
   }
-  B4 b;
-  if (good) {
-    b.x0 = max(dxs - g.sbx, g.min_dx); b.x1 = min(dxs + g.sbx, g.max_dx);
-    b.y0 = max(dys - g.sby, g.min_dy); b.y1 = min(dys + g.sby, g.max_dy);
-  } else {
-    b = B4{g.min_dx, g.min_dy, g.max_dx, g.max_dy};
-    full_search[idx] = 255;
-  }
-  if (rmask_present) {
-    int vx0 = rowext[r].x, vx1 = rowext[r].y, vy0 = ext[0], vy1 = ext[1];
-    if (!(vx0 >= vx1 || vy0 >= vy1)) { vx0 -= c; vx1 -= c; vy0 -= r; vy1 -= r; }    // BBox -= on an empty box is a no-op
-    vx0 = max(vx0, b.x0); vy0 = max(vy0, b.y0); vx1 = min(vx1, b.x1); vy1 = min(vy1, b.y1);
-    if (vx0 > vx1 || vy0 > vy1) { bounds[idx] = ZERO; full_search[idx] = 0; return; }
-    b = B4{vx0, vy0, vx1, vy1};
-  }
   bounds[idx] = b;
+  full_search[idx] = fs;
 }
 
 __global__ void constrain_kernel(SgmGeom g, const uint8_t* __restrict__ full_search, B4* __restrict__ bounds, int range, int conserve) {

@@ -221,8 +221,8 @@ def subdivide_regions(disparity, kernel_size):
 def pyramid_correlate(left, right, left_mask, right_mask, prefilter_mode, prefilter_width, search_region, kernel_size,
                       cost_type, corr_timeout=0, seconds_per_op=0.0, consistency_threshold=-1.0,
                       min_consistency_level=0, filter_half_kernel=0, max_pyramid_levels=5, algorithm=0,
-                      collar_size=0, sgm_subpixel_mode=0, sgm_search_buffer=(0, 0), memory_limit_mb=0,
-                      blob_filter_area=0, bbox=None, ctx=None):
+                      collar_size=0, sgm_subpixel_mode=5, sgm_search_buffer=(2, 2), memory_limit_mb=6000,
+                      blob_filter_area=0, bbox=None, sgm_num_threads=1, ctx=None):
     """vw::stereo::pyramid_correlate (src/vw/Stereo/CorrelationView.h:195-230) rasterised over `bbox`
     (default: the whole left image as ONE tile, i.e. PyramidCorrelationView::prerasterize(bounding_box),
     src/vw/Stereo/CorrelationView.cc:273-886).  The reference rasterises per block-cache tile; pass the same
@@ -230,7 +230,9 @@ def pyramid_correlate(left, right, left_mask, right_mask, prefilter_mode, prefil
 
     left / right: (rows, cols) float32; masks: (rows, cols) uint8 or None; search_region: BBox2i (half open).
     Returns (bbox rows, bbox cols, 3) float32 PixelMask<Vector2f> {dx, dy, valid}.
-    VW_CORRELATION_BM only (algorithm == 0); collar_size / sgm_* / memory_limit_mb are SGM-side arguments."""
+    algorithm 0 = VW_CORRELATION_BM (integer disparities cast to float), 1 = VW_CORRELATION_SGM (census costs only; the
+    result is the matcher's sub-pixel view, CorrelationView.cc:862-875); MGM variants raise NoImplErr.  collar_size is
+    the tile rasteriser's business (CorrelationView.h:128-132): pass the collared bbox."""
     from ._lib import PyramidParams
     if left.ndim != 2 or right.ndim != 2:
         raise ArgumentErr("pyramid_correlate: images must be 2-D (rows, cols)")
@@ -243,7 +245,8 @@ def pyramid_correlate(left, right, left_mask, right_mask, prefilter_mode, prefil
                       int(search_region.min[0]), int(search_region.min[1]), int(search_region.max[0]), int(search_region.max[1]),
                       int(kernel_size[0]), int(kernel_size[1]), int(cost_type), int(corr_timeout), float(seconds_per_op),
                       float(consistency_threshold), int(min_consistency_level), int(filter_half_kernel),
-                      int(max_pyramid_levels), int(algorithm), int(blob_filter_area))
+                      int(max_pyramid_levels), int(algorithm), int(blob_filter_area), int(sgm_subpixel_mode),
+                      int(sgm_search_buffer[0]), int(sgm_search_buffer[1]), int(memory_limit_mb), int(sgm_num_threads))
     ctx = _ctx_for(left, ctx)
     lib = ctx._lib
     bw, bh = bx1 - bx, by1 - by

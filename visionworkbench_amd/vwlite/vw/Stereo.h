@@ -296,8 +296,8 @@ public:
   }
 };
 
-/// pyramid_correlate — the reference's argument list (CorrelationView.h:195-230).  VW_CORRELATION_BM only; the SGM-side
-/// arguments (collar_size, sgm_*, memory_limit_mb) are accepted for source compatibility.
+/// pyramid_correlate — the reference's argument list (CorrelationView.h:195-230).  VW_CORRELATION_BM and VW_CORRELATION_SGM;
+/// collar_size belongs to the tile rasteriser (request the collared bbox).
 template <class Image1T, class Image2T, class Mask1T, class Mask2T>
 PyramidCorrelationView
 pyramid_correlate(ImageViewBase<Image1T> const& left, ImageViewBase<Image2T> const& right,
@@ -306,8 +306,8 @@ pyramid_correlate(ImageViewBase<Image1T> const& left, ImageViewBase<Image2T> con
                   BBox2i const& search_region, Vector2i const& kernel_size, CostFunctionType cost_type,
                   int corr_timeout, double seconds_per_op, float consistency_threshold, int min_consistency_level,
                   int filter_half_kernel, int32 max_pyramid_levels,
-                  CorrelationAlgorithm algorithm = VW_CORRELATION_BM, int collar_size = 0, int /*sgm_subpixel_mode*/ = 0,
-                  Vector2i /*sgm_search_buffer*/ = Vector2i(2, 2), size_t /*memory_limit_mb*/ = 6000, int blob_filter_area = 0) {
+                  CorrelationAlgorithm algorithm = VW_CORRELATION_BM, int collar_size = 0, int sgm_subpixel_mode = 5 /*SUBPIXEL_LC_BLEND*/,
+                  Vector2i sgm_search_buffer = Vector2i(2, 2), size_t memory_limit_mb = 6000, int blob_filter_area = 0) {
   (void)collar_size;
   vwgpu_pyramid_params p;
   p.prefilter_mode = (int)prefilter_mode; p.prefilter_width = prefilter_width;
@@ -318,6 +318,8 @@ pyramid_correlate(ImageViewBase<Image1T> const& left, ImageViewBase<Image2T> con
   p.consistency_threshold = consistency_threshold; p.min_consistency_level = min_consistency_level;
   p.filter_half_kernel = filter_half_kernel; p.max_pyramid_levels = max_pyramid_levels;
   p.algorithm = (int)algorithm; p.blob_filter_area = blob_filter_area;
+  p.sgm_subpixel_mode = sgm_subpixel_mode; p.sgm_search_buffer_x = sgm_search_buffer[0]; p.sgm_search_buffer_y = sgm_search_buffer[1];
+  p.memory_limit_mb = memory_limit_mb; p.sgm_num_threads = 1;
   ImageView<PixelGray<float>> l = pixel_cast<PixelGray<float>>(left.impl()), r = pixel_cast<PixelGray<float>>(right.impl());
   ImageView<uint8> lm = left_mask.impl(), rm = right_mask.impl();
   return PyramidCorrelationView(l, r, lm, rm, p);
