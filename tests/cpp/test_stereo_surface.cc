@@ -282,6 +282,49 @@ static void test_disparity_filters() {
   EXPECT_TRUE(BBox2i().empty() && BBox2i().min().x() == 0x7ffffffe && BBox2i().max().x() == -0x7ffffffe);
 }
 
+// --- SGM: TestSGM.cxx:28-75 (constant offset: every pixel must come out as (2,1) after adding the search minimum) --------
+static void test_sgm_constant_offset() {
+  const int min_disp_x = -4, max_disp_x = 4, min_disp_y = -4, max_disp_y = 4, kernel_size = 3;
+  uint64_t s = 21;
+  ImageView<PixelGray<float>> inputRight(420, 420);
+  for (int r = 0; r < 420; ++r) for (int c = 0; c < 420; ++c) inputRight(c, r) = (float)(splitmix(s) >> 56);
+  // smooth a little so that the 3x3 census has structure like a natural image
+  ImageView<PixelGray<float>> smooth = gaussian_filter(inputRight, 1.0);
+  // left(x, y) = right(x + 2, y + 1)
+  ImageView<PixelGray<float>> left = crop(smooth, 8 + 2, 8 + 1, 400, 400);
+  const int disp_x_range = max_disp_x - min_disp_x + 1, disp_y_range = max_disp_y - min_disp_y + 1;
+  ImageView<PixelGray<float>> right = crop(smooth, 8 + min_disp_x + 4, 8 + min_disp_y + 4, 400 + disp_x_range, 400 + disp_y_range);
+  // raw disparity d satisfies right_crop(x + d) = left(x): right_crop origin = 8, so d = (2, 1); the reference's test
+  // shifts its ROI by the search minimum instead, which only renames the origin
+  std::shared_ptr<SemiGlobalMatcher> matcher_ptr;
+  SemiGlobalMatcher::DisparityImage result =
+      calc_disparity_sgm(CENSUS_TRANSFORM, left, right, BBox2i(0, 0, left.cols(), left.rows()), Vector2i(disp_x_range, disp_y_range),
+                         Vector2i(kernel_size, kernel_size), false, SemiGlobalMatcher::SUBPIXEL_LC_BLEND, Vector2i(4, 4), 1024, matcher_ptr);
+  EXPECT_EQ(398, result.cols());
+  EXPECT_EQ(398, result.rows());
+  size_t num_correct = 0;
+  for (int row = 0; row < result.rows(); ++row) for (int col = 0; col < result.cols(); ++col)
+    if (result(col, row)[0] == 2 && result(col, row)[1] == 1) ++num_correct;
+  EXPECT_TRUE((double)num_correct / ((double)result.rows() * result.cols()) > 0.99);
+  ImageView<PixelMask<Vector2f>> sub = matcher_ptr->create_disparity_view_subpixel(result);
+  EXPECT_TRUE(std::fabs(sub(200, 200)[0] - 2.0f) < 1.0f && std::fabs(sub(200, 200)[1] - 1.0f) < 1.0f && is_valid(sub(200, 200)));
+  // identical to the oracle
+  std::vector<int32_t> want((size_t)400 * 400 * 3);
+  int ow = 0, oh = 0;
+  EXPECT_EQ(0, vwo_calc_disparity_sgm(3, &left(0, 0).v(), 400, 400, &right(0, 0).v(), right.cols(), right.rows(), disp_x_range, disp_y_range,
+                                      kernel_size, 5, 4, 4, 1024, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, want.data(), 0, &ow, &oh));
+  long bad = 0;
+  for (int r = 0; r < oh; ++r) for (int c = 0; c < ow; ++c) {
+    const int32_t* w3 = &want[((size_t)r * ow + c) * 3];
+    if (result(c, r)[0] != w3[0] || result(c, r)[1] != w3[1] || result(c, r).valid() != w3[2]) ++bad;
+  }
+  EXPECT_EQ(0, bad);
+  EXPECT_THROW(calc_disparity_sgm(ABSOLUTE_DIFFERENCE, left, right, BBox2i(0, 0, 400, 400), Vector2i(9, 9), Vector2i(3, 3), false,
+                                  SemiGlobalMatcher::SUBPIXEL_LC_BLEND, Vector2i(4, 4), 1024, matcher_ptr), NoImplErr);
+  EXPECT_THROW(calc_disparity_sgm(CENSUS_TRANSFORM, left, right, BBox2i(0, 0, 401, 400), Vector2i(9, 9), Vector2i(3, 3), false,
+                                  SemiGlobalMatcher::SUBPIXEL_LC_BLEND, Vector2i(4, 4), 1024, matcher_ptr), ArgumentErr);
+}
+
 int main() {
   static_assert(sizeof(PixelMask<Vector2i>) == 12, "layout");
   EXPECT_TRUE(BBox2i(0, 0, 129, 0).empty() && BBox2i(0, 0, 129, 0).width() == 0);
@@ -302,6 +345,7 @@ int main() {
   test_parabola_null();
   test_filters();
   test_disparity_filters();
+  test_sgm_constant_offset();
   std::printf("%d checks, %d failures\n", g_checks, g_fail);
   return g_fail ? 1 : 0;
 }

@@ -11,6 +11,7 @@
 //   rm_outliers_using_thresh / disparity_cleanup_using_thresh / disparity_mask
 //                                src/vw/Stereo/DisparityMap.h:387-441, 236-253
 //   SearchParam, subdivide_regions, calc_seconds_per_op   src/vw/Stereo/Correlation.h:66-122
+//   SemiGlobalMatcher, calc_disparity_sgm                 src/vw/Stereo/SGM.h:75-157,360-375
 // Errors: the C ABI's status codes become the reference's exception types (src/vw/Core/Exception.h:225-253).
 // Threading: one engine context per (host thread x GPU), created lazily — the reference calls these functions
 // concurrently from its tile threads (src/vw/Image/ImageIO.h:228-251).
@@ -20,6 +21,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <memory>
 #include <utility>
 #include <vector>
 
@@ -250,6 +253,80 @@ inline double calc_seconds_per_op(CostFunctionType cost_type, Vector2i const& ke
     seconds_per_op = elapsed / ((double)lsize * lsize * search[0] * search[1]);
   }
   return seconds_per_op;
+}
+
+/// SemiGlobalMatcher — the slice of the reference's class (SGM.h:75-352) that callers of calc_disparity_sgm touch: the
+/// sub-pixel mode enum and create_disparity_view_subpixel on the matcher handed back through matcher_ptr.  The engine
+/// computes the sub-pixel view in the same pass (the accumulation buffers live in HBM only during the call).
+class SemiGlobalMatcher {
+public:
+  typedef ImageView<PixelMask<Vector2i>> DisparityImage;
+  enum SgmSubpixelMode { SUBPIXEL_NONE = 0, SUBPIXEL_PARABOLA = 1, SUBPIXEL_LINEAR = 2, SUBPIXEL_POLY4 = 3,
+                         SUBPIXEL_COSINE = 4, SUBPIXEL_LC_BLEND = 5 };
+  /// SGM.h:157 — valid for the integer disparity this matcher produced.
+  ImageView<PixelMask<Vector2f>> create_disparity_view_subpixel(DisparityImage const& integer_disparity) const {
+    VW_ASSERT(integer_disparity.cols() == m_subpixel.cols() && integer_disparity.rows() == m_subpixel.rows(),
+              ArgumentErr() << "create_disparity_view_subpixel: not the disparity this matcher produced.");
+    ImageView<PixelMask<Vector2f>> out = copy(m_subpixel);
+    for (int32 r = 0; r < out.rows(); ++r)
+      for (int32 c = 0; c < out.cols(); ++c)
+        if (!is_valid(integer_disparity(c, r))) {          // SGM.cc:1523-1527
+          out(c, r) = PixelMask<Vector2f>(Vector2f(float(integer_disparity(c, r)[0]), float(integer_disparity(c, r)[1])));
+          out(c, r).invalidate();
+        }
+    return out;
+  }
+  ImageView<PixelMask<Vector2f>> m_subpixel;   // filled by calc_disparity_sgm
+};
+
+/// calc_disparity_sgm — the reference's signature (SGM.h:360-375); std::shared_ptr stands in for boost::shared_ptr.
+inline ImageView<PixelMask<Vector2i>>
+calc_disparity_sgm(CostFunctionType cost_type,
+                   ImageView<PixelGray<float>> const& left_in, ImageView<PixelGray<float>> const& right_in,
+                   BBox2i const& left_region, Vector2i const& search_volume, Vector2i const& kernel_size,
+                   bool const use_mgm, SemiGlobalMatcher::SgmSubpixelMode const& subpixel_mode,
+                   Vector2i const search_buffer, size_t const memory_limit_mb,
+                   std::shared_ptr<SemiGlobalMatcher>& matcher_ptr,
+                   ImageView<uint8> const* left_mask_ptr = 0, ImageView<uint8> const* right_mask_ptr = 0,
+                   SemiGlobalMatcher::DisparityImage const* prev_disparity = 0) {
+  VW_ASSERT(kernel_size[0] % 2 == 1 && kernel_size[1] % 2 == 1, ArgumentErr() << "calc_disparity_sgm: Kernel input not sized with odd values.");
+  VW_ASSERT(kernel_size[0] <= left_region.width() && kernel_size[1] <= left_region.height(),
+            ArgumentErr() << "calc_disparity_sgm: Kernel size too large of active region.");
+  VW_ASSERT(left_region.min().x() >= 0 && left_region.min().y() >= 0 && left_region.max().x() <= left_in.cols() &&
+            left_region.max().y() <= left_in.rows(), ArgumentErr() << "calc_disparity_sgm: Region not inside left image.");
+  BBox2i right_region = left_region;
+  right_region.max() += search_volume;                               // inclusive search volume (SGM.cc:186-191)
+  ImageView<PixelGray<float>> l = crop(left_in, left_region);
+  ImageView<PixelGray<float>> r = crop(edge_extend(right_in, ConstantEdgeExtension()), right_region);
+  vwgpu_sgm_params p;
+  p.cost_type = (int)cost_type; p.use_mgm = use_mgm ? 1 : 0; p.kernel_size = kernel_size[0]; p.subpixel_mode = (int)subpixel_mode;
+  p.search_buffer_x = search_buffer[0]; p.search_buffer_y = search_buffer[1]; p.memory_limit_mb = memory_limit_mb;
+  p.p1 = 0; p.p2 = 0; p.ternary_census_threshold = 5; p.num_threads = 1;
+  const size_t cap = (size_t)l.cols() * l.rows();
+  std::vector<int32_t> disp(cap * 3);
+  std::vector<float> sub(cap * 3);
+  int ow = 0, oh = 0;
+  vwgpu_ctx* ctx = detail::thread_context();
+  try {
+    detail::check(ctx, vwgpu_calc_disparity_sgm(ctx, &p, reinterpret_cast<const float*>(l.data()), l.cols(), l.rows(), 0,
+                                                reinterpret_cast<const float*>(r.data()), r.cols(), r.rows(), 0, search_volume[0], search_volume[1],
+                                                left_mask_ptr ? left_mask_ptr->data() : 0, left_mask_ptr ? left_mask_ptr->cols() : 0, left_mask_ptr ? left_mask_ptr->rows() : 0,
+                                                right_mask_ptr ? right_mask_ptr->data() : 0, right_mask_ptr ? right_mask_ptr->cols() : 0, right_mask_ptr ? right_mask_ptr->rows() : 0,
+                                                prev_disparity ? reinterpret_cast<const int32_t*>(prev_disparity->data()) : 0,
+                                                prev_disparity ? prev_disparity->cols() : 0, prev_disparity ? prev_disparity->rows() : 0,
+                                                disp.data(), sub.data(), cap, &ow, &oh));
+  } catch (NoImplErr const&) {
+    throw;                                                           // MAD cost / MGM / census size: as the reference's NoImplErr
+  } catch (std::exception const& e) {                                // SGM.cc:221-226
+    vw_throw(ArgumentErr() << "Failed to compute the correlation. See the online documentation (next_steps.html) for how to "
+                           << "handle failures.\nDetailed error message: " << e.what() << "\n");
+  }
+  ImageView<PixelMask<Vector2i>> out(ow, oh);
+  matcher_ptr.reset(new SemiGlobalMatcher());
+  matcher_ptr->m_subpixel.set_size(ow, oh);
+  std::memcpy(static_cast<void*>(out.data()), disp.data(), (size_t)ow * oh * 12);
+  std::memcpy(static_cast<void*>(matcher_ptr->m_subpixel.data()), sub.data(), (size_t)ow * oh * 12);
+  return out;
 }
 
 /// PyramidCorrelationView — lazy like the reference's (CorrelationView.h:35-190): nothing runs until a tile is
