@@ -551,15 +551,31 @@ constexpr Launch make_launch() {
 }
 
 // Instantiated kernel sizes.  Others fall back to the generic path.
+// Several tile heights for the headline size: a workgroup alone on a CU needs ~107 us for a 16-row tile (the kernel is
+// latency bound per wave and relies on 4 resident workgroups per CU), so small images / the row strips of a multi-GPU run
+// are cut into shorter tiles to keep >= 4 workgroups per CU (tools/time_wg_curve.py).  Taller tiles re-read fewer halo rows.
 const Launch kLaunch[] = {
-    make_launch<3, 3, 16>(), make_launch<5, 5, 16>(), make_launch<7, 7, 16>(), make_launch<7, 5, 16>(),
-    make_launch<9, 9, 12>(), make_launch<11, 11, 8>(),
+    make_launch<3, 3, 16>(), make_launch<5, 5, 16>(), make_launch<7, 7, 16>(), make_launch<7, 7, 8>(), make_launch<7, 7, 4>(),
+    make_launch<7, 5, 16>(), make_launch<9, 9, 12>(), make_launch<11, 11, 8>(),
 };
 
+// first entry of the size = the preferred (tallest) tile
 const Launch* find_launch(int kx, int ky) {
   for (const Launch& l : kLaunch)
     if (l.kx == kx && l.ky == ky) return &l;
   return nullptr;
+}
+
+// the tallest tile that still yields ~4 workgroups per CU; the shortest one otherwise
+const Launch* pick_launch(int kx, int ky, int ow, int oh, int num_cu) {
+  const Launch* last = nullptr;
+  for (const Launch& l : kLaunch) {
+    if (l.kx != kx || l.ky != ky) continue;
+    last = &l;
+    const long long wgs = (long long)((ow + l.twb - 1) / l.twb) * ((oh + l.ty - 1) / l.ty);
+    if (wgs >= 4LL * num_cu) return &l;
+  }
+  return last;
 }
 
 constexpr size_t kMaxLds = 80 * 1024;   // two workgroups per CU
@@ -590,9 +606,9 @@ int vwgpu_launch_bm_sad_u8(vwgpu_ctx* ctx,
                            int kx, int ky, int sx, int sy, int32_t* out, ptrdiff_t os,
                            int** d_fallback_flag) {
   (void)rw; (void)rh;
-  const Launch* l = find_launch(kx, ky);
-  if (!l) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "no packed-u8 kernel for %dx%d", kx, ky);
   const int ow = lw - kx + 1, oh = lh - ky + 1;
+  const Launch* l = pick_launch(kx, ky, ow, oh, ctx->num_cu);
+  if (!l) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "no packed-u8 kernel for %dx%d", kx, ky);
   const int rcw = lw + sx - 1, rch = lh + sy - 1;
   const int gx = (ow + l->twb - 1) / l->twb, gy = (oh + l->ty - 1) / l->ty;
   const int ne = entries_per_row(*l, sx);
