@@ -65,3 +65,48 @@ def test_strip_ranges_cover_everything():
         assert all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
         (la, lb), (ra, rb) = partition.strip_inputs(world - 1, world, 4096, 7, 1)
         assert lb == 4096 and rb == 4096
+
+
+def _halo_worker(rank, world, port, kernel, search, w, h, q):
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    left, right, _ = synth.stereo_pair(w, h, search[0], search[1], block=32)
+    oh = h - kernel[1] + 1
+    lb = partition.sharded_bounds(world, left.shape[0], oh, 0, kernel[1] - 1)
+    rb = partition.sharded_bounds(world, right.shape[0], oh, 0, kernel[1] - 1 + search[1] - 1)
+    a, b, na, nb = lb[rank]
+    l_own = torch.from_numpy(left[a:b].copy())                    # this rank only ever sees its own rows
+    l_ext = partition.exchange_halo(l_own, a, b, na, nb, rank, world, lb)
+    a2, b2, na2, nb2 = rb[rank]
+    r_own = torch.from_numpy(right[a2:b2].copy())
+    r_ext = partition.exchange_halo(r_own, a2, b2, na2, nb2, rank, world, rb)
+    assert np.array_equal(l_ext.numpy(), left[na:nb]) and np.array_equal(r_ext.numpy(), right[na2:nb2])
+    r0, r1 = partition.row_strip(rank, world, oh)
+    part = oracle.calc_disparity(0, l_ext.numpy()[:r1 - r0 + kernel[1] - 1], r_ext.numpy()[:r1 - r0 + kernel[1] - 1 + search[1] - 1], kernel, search)
+    parts = [None] * world
+    dist.all_gather_object(parts, part)
+    dist.barrier()
+    if rank == 0:
+        q.put(np.concatenate(parts, axis=0))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_of_a_sharded_source_image(oracle, world):
+    """The source image itself is row-sharded (no overlap); neighbours exchange the ky-1 (+sy-1) halo rows point to
+    point (nccl/RCCL on GPUs, gloo here); results must reassemble to the single-call disparity."""
+    kernel, search, w, h = (7, 7), (17, 3), 96, 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, kernel, search, w, h, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    left, right, _ = synth.stereo_pair(w, h, search[0], search[1], block=32)
+    assert np.array_equal(got, oracle.calc_disparity(0, left, right, kernel, search))

@@ -19,3 +19,62 @@ def strip_inputs(rank, world, lh, ky, sy):
     out_rows = lh - ky + 1
     r0, r1 = row_strip(rank, world, out_rows)
     return (r0, r1 + ky - 1), (r0, r1 + ky - 1 + sy - 1)
+
+
+def owned_rows(rank, world, out_rows):
+    """Input rows [a, b) whose HBM copy lives on `rank` when the SOURCE image itself is sharded (no overlap): the rows of the
+    rank's output strip; the last rank also keeps the rows below its strip (the image's bottom ky-1 (+sy-1) rows)."""
+    return row_strip(rank, world, out_rows)
+
+
+def exchange_halo(owned, a, b, need_a, need_b, rank, world, bounds, group=None):
+    """Halo exchange of a row-sharded image (the one real exchange step of the path): rank g holds rows
+    [a, b) of an image in `owned` (rows x cols tensor) and needs rows [need_a, need_b) ⊇ [a, b) for its windows — ky-1
+    (+sy-1) rows below for block matching, half_kernel * 2^levels rows on both sides (+ the search range) for a pyramid tile
+    (src/vw/Stereo/CorrelationView.cc:89-97).  `bounds[r]` = (owned_a, owned_b, need_a, need_b) of every rank (sharded_bounds).  Point-to-point isend/irecv between
+    the ranks whose ranges overlap — over xGMI one link per neighbour pair when the backend is nccl (= RCCL); works on
+    gloo for the CPU tests.  Returns the (need_b - need_a) x cols tensor.  No collective: each rank talks only to the
+    neighbours that own rows it needs."""
+    import torch
+    import torch.distributed as dist
+    if need_a > a or need_b < b:
+        raise ValueError("the needed range must contain the owned range")
+    out = torch.empty((need_b - need_a, owned.shape[1]), dtype=owned.dtype, device=owned.device)
+    out[a - need_a:b - need_a] = owned
+    ops, keep = [], []
+    for r in range(world):
+        if r == rank:
+            continue
+        ar, br = bounds[r][0], bounds[r][1]
+        # rows of rank r that I need
+        lo, hi = max(need_a, ar), min(need_b, br)
+        if lo < hi:
+            buf = torch.empty((hi - lo, owned.shape[1]), dtype=owned.dtype, device=owned.device)
+            keep.append((buf, lo, hi))
+            ops.append(dist.P2POp(dist.irecv, buf, r, group=group))
+    for r in range(world):
+        if r == rank:
+            continue
+        na, nb = bounds[r][2], bounds[r][3]          # rank r's needed range
+        lo, hi = max(na, a), min(nb, b)
+        if lo < hi:
+            ops.append(dist.P2POp(dist.isend, owned[lo - a:hi - a].contiguous(), r, group=group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for buf, lo, hi in keep:
+        out[lo - need_a:hi - need_a] = buf
+    return out
+
+
+def sharded_bounds(world, rows_total, out_rows, halo_above, halo_below):
+    """bounds[r] = (owned_a, owned_b, need_a, need_b) for every rank: owned = the output strip's rows (the last rank also owns
+    the image's remaining rows), needed = owned grown by the halos, clipped to the image."""
+    bounds = []
+    for r in range(world):
+        a, b = row_strip(r, world, out_rows)
+        if r == world - 1:
+            b = rows_total
+        bounds.append((a, b, max(0, a - halo_above), min(rows_total, (row_strip(r, world, out_rows)[1]) + halo_below)))
+    # the last rank needs nothing below the image; make sure need >= owned everywhere
+    return [(a, b, min(na, a), max(nb, b)) for (a, b, na, nb) in bounds]
