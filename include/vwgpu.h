@@ -224,6 +224,11 @@ int vwgpu_disparity_mask_dev(vwgpu_ctx* ctx, int32_t* d_disp, int w, int h, cons
                              const uint8_t* d_right_mask, int rmw, int rmh);
 int vwgpu_disparity_mask(vwgpu_ctx* ctx, int32_t* disp, int w, int h, const uint8_t* left_mask,
                          const uint8_t* right_mask, int rmw, int rmh);
+/* Replaces PyramidCorrelationView::disparity_blob_filter at one level (src/vw/Stereo/CorrelationView.cc:242-271:
+ * BlobIndexThreaded over the whole image as one tile + ErodeView): every 8-connected component of VALID pixels with at
+ * most max_blob_area pixels is erased (pixels become {0,0,0}); max_blob_area < 1 is a no-op.  In place. */
+int vwgpu_disparity_blob_filter_dev(vwgpu_ctx* ctx, int32_t* d_disp, int w, int h, int max_blob_area);
+int vwgpu_disparity_blob_filter(vwgpu_ctx* ctx, int32_t* disp, int w, int h, int max_blob_area);
 /* Replaces vw::stereo::subdivide_regions(disparity, bounding_box(disparity), list, kernel_size)
  * (src/vw/Stereo/Correlation.cc:139-328).  Host logic on a HOST disparity image; each zone is 8 ints
  * {region.min.x, region.min.y, region.max.x, region.max.y, range.min.x, range.min.y, range.max.x, range.max.y}.
@@ -246,7 +251,7 @@ typedef struct vwgpu_pyramid_params {
   int filter_half_kernel;        /* 0: no clean-up filtering */
   int max_pyramid_levels;
   int algorithm;                 /* 0 = VW_CORRELATION_BM, 1 = VW_CORRELATION_SGM; MGM variants answer VWGPU_ERR_NOIMPL */
-  int blob_filter_area;          /* must be 0 for now */
+  int blob_filter_area;          /* 0 = off; level i erases blobs of <= area / 2^i valid pixels */
   /* SGM only (CorrelationView.h:211-214): */
   int sgm_subpixel_mode;         /* vwgpu_sgm_subpixel; the reference's default is LC_BLEND */
   int sgm_search_buffer_x, sgm_search_buffer_y;   /* default (2,2) */

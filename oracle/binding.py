@@ -21,7 +21,7 @@ __all__ = ["build", "lib", "fast_box_sum", "cost_image", "calc_disparity", "calc
            "EDGE_CONSTANT", "EDGE_ZERO", "PREFILTER_NONE", "PREFILTER_MEANSUB", "PREFILTER_LOG",
            "subdivide_regions", "prefilter_region", "parabola_subpixel", "pyramid_correlate", "disparity_filter",
            "disparity_mask", "u8_convert", "census_transform", "hamming_distance", "SemiGlobalMatcher", "calc_disparity_sgm",
-           "pyramid_correlate_sgm", "CENSUS_TRANSFORM", "TERNARY_CENSUS_TRANSFORM", "SUBPIXEL_NONE", "SUBPIXEL_PARABOLA", "SUBPIXEL_LINEAR",
+           "pyramid_correlate_sgm", "blob_sizes", "disparity_blob_filter", "set_blob_filter_area", "CENSUS_TRANSFORM", "TERNARY_CENSUS_TRANSFORM", "SUBPIXEL_NONE", "SUBPIXEL_PARABOLA", "SUBPIXEL_LINEAR",
            "SUBPIXEL_POLY4", "SUBPIXEL_COSINE", "SUBPIXEL_LC_BLEND"]
 
 
@@ -60,6 +60,10 @@ def lib():
         _LIB.vwo_disparity_filter.argtypes = [P, I, I, I, I, D, D, I]
         _LIB.vwo_disparity_mask.argtypes = [P, I, I, P, P, I, I]
         Z = ctypes.c_size_t
+        _LIB.vwo_blob_sizes.argtypes = [P, I, I, P]
+        _LIB.vwo_disparity_blob_filter.argtypes = [P, I, I, I]
+        _LIB.vwo_set_blob_filter_area.argtypes = [I]
+        _LIB.vwo_set_blob_filter_area.restype = None
         _LIB.vwo_u8_convert.argtypes = [P, I, I, P]
         _LIB.vwo_census_transform.argtypes = [P, I, I, I, I, I, P]
         _LIB.vwo_hamming_distance.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
@@ -416,3 +420,21 @@ def pyramid_correlate_sgm(left, right, left_mask, right_mask, search_region, ker
     if rc:
         raise ValueError("vwo_pyramid_correlate_sgm rc=%d" % rc)
     return out
+
+
+def blob_sizes(disp):
+    d = np.ascontiguousarray(disp, np.int32)
+    out = np.zeros(d.shape[:2], np.uint32)
+    assert lib().vwo_blob_sizes(_p(d), d.shape[1], d.shape[0], _p(out)) == 0
+    return out
+
+
+def disparity_blob_filter(disp, area):
+    d = np.ascontiguousarray(disp, np.int32).copy()
+    assert lib().vwo_disparity_blob_filter(_p(d), d.shape[1], d.shape[0], int(area)) == 0
+    return d
+
+
+def set_blob_filter_area(area):
+    """blob_filter_area used by the following pyramid_correlate / pyramid_correlate_sgm calls of this thread."""
+    lib().vwo_set_blob_filter_area(int(area))

@@ -813,7 +813,51 @@ int vwo_disparity_mask(int32_t* disp3, int w, int h, const uint8_t* lmask, const
   return 0;
 }
 
+// disparity_blob_filter (src/vw/Stereo/CorrelationView.cc:242-271): BlobIndexThreaded over the whole image as ONE tile
+// (src/vw/Image/BlobIndex.h:385-455; labelling :135-262 = 8-connected components of the VALID pixels), blobs larger than
+// `area` pixels are dropped from the index (:445-453), the rest are erased by ErodeView (src/vw/Image/ErodeView.h:199-222:
+// a covered pixel becomes the default, invalid, zero pixel).
+int vwo_blob_sizes(const int32_t* disp3, int w, int h, uint32_t* sizes) {
+  if (!disp3 || !sizes || w <= 0 || h <= 0) return -1;
+  std::vector<int> label((size_t)w * h, -1);
+  std::vector<int> stack;
+  for (size_t i = 0; i < (size_t)w * h; ++i) sizes[i] = 0;
+  for (int y0 = 0; y0 < h; ++y0)
+    for (int x0 = 0; x0 < w; ++x0) {
+      const size_t s0 = (size_t)y0 * w + x0;
+      if (!disp3[s0 * 3 + 2] || label[s0] >= 0) continue;
+      std::vector<size_t> members;
+      stack.clear(); stack.push_back((int)s0); label[s0] = (int)s0;
+      while (!stack.empty()) {
+        const int c = stack.back(); stack.pop_back();
+        members.push_back((size_t)c);
+        const int cy = c / w, cx = c - cy * w;
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int nx = cx + dx, ny = cy + dy;
+            if ((dx == 0 && dy == 0) || nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
+            const size_t n = (size_t)ny * w + nx;
+            if (disp3[n * 3 + 2] && label[n] < 0) { label[n] = (int)s0; stack.push_back((int)n); }
+          }
+      }
+      for (size_t m : members) sizes[m] = (uint32_t)members.size();
+    }
+  return 0;
+}
+
+int vwo_disparity_blob_filter(int32_t* disp3, int w, int h, int area) {
+  if (!disp3 || w <= 0 || h <= 0) return -1;
+  if (area < 1) return 0;
+  std::vector<uint32_t> sizes((size_t)w * h);
+  vwo_blob_sizes(disp3, w, h, sizes.data());
+  for (size_t i = 0; i < (size_t)w * h; ++i)
+    if (sizes[i] && sizes[i] <= (uint32_t)area) { disp3[i * 3] = 0; disp3[i * 3 + 1] = 0; disp3[i * 3 + 2] = 0; }
+  return 0;
+}
+
 }  // extern "C" (reopened below)
+
+static thread_local int g_blob_filter_area = 0;
 
 // algorithm 0 = VW_CORRELATION_BM, 1 = VW_CORRELATION_SGM (MGM variants are not restated)
 static int pyramid_impl(const float* left, int lw, int lh, const float* right, int rw, int rh,
@@ -824,7 +868,7 @@ static int pyramid_impl(const float* left, int lw, int lh, const float* right, i
                         int filter_half_kernel, int max_pyramid_levels_arg,
                         int bx, int by, int bw, int bh, float* out3f,
                         int algorithm, int min_consistency_level, int sgm_subpixel_mode, int sgm_sbx, int sgm_sby,
-                        size_t memory_limit_mb, int num_threads) {
+                        size_t memory_limit_mb, int num_threads, int blob_filter_area) {
   if (kx % 2 != 1 || ky % 2 != 1 || bw <= 0 || bh <= 0) return -1;
   const bool use_sgm = algorithm != 0;
   if (use_sgm) prefilter_mode = VWO_PREFILTER_NONE;                      // CorrelationView.h:96-97
@@ -1002,6 +1046,9 @@ static int pyramid_impl(const float* left, int lw, int lh, const float* right, i
         disparity_mask(disparity_rl, rlw_, rlh_, right_rl_mask.data(), left_rl_mask.data(), lrm_w, lrm_h);
       }
     }
+    // the kernel based filtering tends to leave isolated blobs behind (:746-750)
+    vwo_disparity_blob_filter(disparity.data(), dw, dh, blob_filter_area / (1 << level));
+    if (check_rl && !on_last_level) vwo_disparity_blob_filter(disparity_rl.data(), rlw_, rlh_, blob_filter_area / (1 << level));
     if (use_sgm) {                                                       // prev_disparity = disparity at the top of the next level (:368-371)
       prev_disparity = disparity; pdw = dw; pdh = dh;
       if (check_rl) { prev_disparity_rl = disparity_rl; prlw = rlw_; prlh = rlh_; } else { prev_disparity_rl.clear(); }
@@ -1053,7 +1100,7 @@ int vwo_pyramid_correlate(const float* left, int lw, int lh, const float* right,
                           int filter_half_kernel, int max_pyramid_levels, int bx, int by, int bw, int bh, float* out3f) {
   return pyramid_impl(left, lw, lh, right, rw, rh, lmask, rmask, prefilter_mode, prefilter_width, sminx, sminy, smaxx, smaxy, kx, ky,
                       cost_type, corr_timeout, seconds_per_op, consistency_threshold, filter_half_kernel, max_pyramid_levels,
-                      bx, by, bw, bh, out3f, 0, 0, 0, 0, 0, 0, 1);
+                      bx, by, bw, bh, out3f, 0, 0, 0, 0, 0, 0, 1, g_blob_filter_area);
 }
 
 int vwo_pyramid_correlate_sgm(const float* left, int lw, int lh, const float* right, int rw, int rh,
@@ -1064,7 +1111,11 @@ int vwo_pyramid_correlate_sgm(const float* left, int lw, int lh, const float* ri
                               int bx, int by, int bw, int bh, float* out3f) {
   return pyramid_impl(left, lw, lh, right, rw, rh, lmask, rmask, 0, 0.0f, sminx, sminy, smaxx, smaxy, kernel, kernel,
                       cost_type, 0, 0.0, consistency_threshold, filter_half_kernel, max_pyramid_levels,
-                      bx, by, bw, bh, out3f, 1, min_consistency_level, sgm_subpixel_mode, sgm_sbx, sgm_sby, memory_limit_mb, num_threads);
+                      bx, by, bw, bh, out3f, 1, min_consistency_level, sgm_subpixel_mode, sgm_sbx, sgm_sby, memory_limit_mb, num_threads,
+                      g_blob_filter_area);
 }
+
+// blob_filter_area of the NEXT vwo_pyramid_correlate / _sgm call on this thread (keeps the long signatures stable)
+void vwo_set_blob_filter_area(int area) { g_blob_filter_area = area; }
 
 }  // extern "C"

@@ -137,6 +137,13 @@ int vwo_pyramid_correlate_sgm(const float* left, int lw, int lh, const float* ri
                               int sgm_subpixel_mode, int sgm_sbx, int sgm_sby, size_t memory_limit_mb, int num_threads,
                               int bx, int by, int bw, int bh, float* out3f);
 
+/* disparity_blob_filter (CorrelationView.cc:242-271): zero every valid pixel of an 8-connected component of valid pixels
+ * with at most `area` pixels; vwo_blob_sizes = the size of each pixel's component (0 for invalid pixels), the quantity
+ * get_blob_sizes reports (src/vw/Image/tests/TestBlobIndex.cxx:97-126). */
+int vwo_blob_sizes(const int32_t* disp3, int w, int h, uint32_t* sizes);
+int vwo_disparity_blob_filter(int32_t* disp3, int w, int h, int area);
+void vwo_set_blob_filter_area(int area);
+
 /* rm_outliers_using_thresh / disparity_cleanup_using_thresh / disparity_mask on whole images
  * (src/vw/Stereo/DisparityMap.h:318-441, 97-253); disp3 in place.  cleanup != 0 adds the second (1,1,3.0,0.20) pass. */
 int vwo_disparity_filter(int32_t* disp3, int w, int h, int half_h, int half_v, double pixel_thr, double rej_thr, int cleanup);

@@ -458,3 +458,20 @@ def test_sgm_masks_and_prev_disparity(oracle):
     assert (s.reshape(-1)[1:] == np.cumsum(counts.reshape(-1))[:-1]).all()
     keep = lmask != 0
     assert ((d1[..., 0] == 3) & (d1[..., 1] == 2))[keep][200:].mean() > 0.95
+
+
+def test_blob_sizes_known_answer(oracle):
+    """src/vw/Image/tests/TestBlobIndex.cxx:97-126 (BlobSizesView): 8-connected blobs of the non-zero pixels, sizes 7 / 2 / 3,
+    and the blob filter built on them (CorrelationView.cc:242-271) erases exactly the blobs of at most `area` pixels."""
+    img = np.array([[0, 0, 0, 1, 8, 0], [0, 1, 0, 0, 0, 0], [0, 1, 0, 0, 1, 1], [1, 1, 0, 0, 0, 1], [1, 0, 1, 0, 0, 0], [0, 1, 0, 0, 0, 0]], np.float32)
+    d = np.zeros((6, 6, 3), np.int32)
+    d[..., 0], d[..., 1] = 3, -2
+    d[..., 2] = np.where(img != 0, oracle.VALID, 0)
+    s = oracle.blob_sizes(d)                       # image(col, row) in the reference = s[row, col] here
+    assert (s[3, 3], s[3, 0], s[0, 3], s[3, 5]) == (0, 7, 2, 3)
+    assert int((s == 7).sum()) == 7 and int((s == 2).sum()) == 2 and int((s == 3).sum()) == 3
+    for area, left_valid in ((0, 12), (1, 12), (2, 10), (3, 7), (6, 7), (7, 0)):
+        f = oracle.disparity_blob_filter(d, area)
+        assert int((f[..., 2] != 0).sum()) == left_valid
+        gone = (d[..., 2] != 0) & (f[..., 2] == 0)
+        assert (f[gone] == 0).all() and (f[~gone] == d[~gone]).all()

@@ -139,3 +139,43 @@ def test_subdivide_regions_identical(vw, oracle):
         zo = oracle.subdivide_regions(d, k)
         got = [r.min + r.max + s.min + s.max for r, s in z]
         assert got == [list(map(int, row)) for row in zo]
+
+
+def test_blob_filter_identical(vw, oracle):
+    rng = np.random.default_rng(21)
+    for h, w, p in [(6, 6, 0.6), (64, 96, 0.55), (200, 300, 0.45), (128, 128, 0.62)]:
+        d = _random_disparity(rng, h, w, p)
+        for area in (0, 1, 2, 5, 40, 1000, h * w):
+            assert np.array_equal(vw.disparity_blob_filter(d, area), oracle.disparity_blob_filter(d, area)), (h, w, area)
+    # one long snake: a single component whose union-find tree is deep
+    d = np.zeros((40, 400, 3), np.int32)
+    d[::4, :, 2] = np.iinfo(np.int32).max
+    d[2::8, -1, 2] = d[6::8, 0, 2] = np.iinfo(np.int32).max
+    d[1::8, -1, 2] = d[3::8, -1, 2] = d[5::8, 0, 2] = d[7::8, 0, 2] = np.iinfo(np.int32).max
+    for area in (399, 3999, 4100):
+        assert np.array_equal(vw.disparity_blob_filter(d, area), oracle.disparity_blob_filter(d, area))
+
+
+@pytest.mark.parametrize("algorithm", [0, 1])
+def test_pyramid_with_blob_filter(vw, oracle, algorithm):
+    from visionworkbench_amd.core import BBox2i
+    left, right, scale, trans, search = scenes.pyramid_scene("u8")
+    box = BBox2i.from_corners(search[:2], search[2:])
+    oracle.set_blob_filter_area(40)
+    try:
+        if algorithm == 0:
+            g = vw.pyramid_correlate(left, right, None, None, 0, 0.0, box, (7, 7), 0, consistency_threshold=2, filter_half_kernel=3,
+                                     max_pyramid_levels=3, blob_filter_area=40)
+            o = oracle.pyramid_correlate(left, right, None, None, 0, 0.0, search, (7, 7), 0, 0, 0.0, 2, 3, 3)
+            assert np.array_equal(g, o)
+        else:
+            g = vw.pyramid_correlate(left, right, None, None, 0, 0.0, box, (5, 5), 3, consistency_threshold=2, filter_half_kernel=3,
+                                     max_pyramid_levels=3, algorithm=1, blob_filter_area=40)
+            o = oracle.pyramid_correlate_sgm(left, right, None, None, search, 5, 3, 2, 0, 3, 3)
+            assert np.array_equal(g[..., 2], o[..., 2]) and np.abs(g[..., :2] - o[..., :2]).max() < 1e-5
+    finally:
+        oracle.set_blob_filter_area(0)
+    # the filter must have had something to do in this scene
+    g0 = vw.pyramid_correlate(left, right, None, None, 0, 0.0, box, (7, 7) if algorithm == 0 else (5, 5), 0 if algorithm == 0 else 3,
+                              consistency_threshold=2, filter_half_kernel=3, max_pyramid_levels=3, algorithm=algorithm)
+    assert (g0[..., 2] != 0).sum() >= (g[..., 2] != 0).sum()

@@ -22,6 +22,7 @@ SYMBOLS = [
     "vwgpu_disparity_filter_dev", "vwgpu_disparity_filter",
     "vwgpu_disparity_mask_dev", "vwgpu_disparity_mask",
     "vwgpu_subdivide_regions",
+    "vwgpu_disparity_blob_filter_dev", "vwgpu_disparity_blob_filter",
     "vwgpu_pyramid_correlate_dev", "vwgpu_pyramid_correlate",
     "vwgpu_calc_disparity_sgm_dev", "vwgpu_calc_disparity_sgm",
 ]
@@ -124,6 +125,8 @@ def load():
     lib.vwgpu_disparity_mask_dev.argtypes = dm
     lib.vwgpu_disparity_mask.argtypes = dm
     lib.vwgpu_subdivide_regions.argtypes = [P, I, I, I, I, P, I]
+    lib.vwgpu_disparity_blob_filter_dev.argtypes = [P, P, I, I, I]
+    lib.vwgpu_disparity_blob_filter.argtypes = [P, P, I, I, I]
     pc = [P, P, I, I, PD, P, I, I, PD, P, PD, P, PD, ctypes.POINTER(PyramidParams), I, I, I, I, P, PD]
     lib.vwgpu_pyramid_correlate_dev.argtypes = pc
     lib.vwgpu_pyramid_correlate.argtypes = pc

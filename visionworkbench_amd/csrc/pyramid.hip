@@ -143,6 +143,58 @@ __global__ void finish_kernel(const int32_t* __restrict__ d, int w, int h, int a
   o[0] = (float)(p[0] + ax); o[1] = (float)(p[1] + ay); o[2] = p[2] ? 1.0f : 0.0f;
 }
 
+// ---- blob filter (disparity_blob_filter, CorrelationView.cc:242-271): 8-connected components of the valid pixels by a
+// lock-free union-find (roots = smallest pixel index), component sizes by atomics, components of <= area pixels erased.
+__device__ __forceinline__ int cc_find(int* L, int x) {
+  int p = L[x];
+  while (p != x) { const int g = L[p]; L[x] = g; x = p; p = g; }     // path halving; racy writes only ever shorten paths
+  return x;
+}
+__device__ __forceinline__ void cc_unite(int* L, int a, int b) {
+  while (true) {
+    a = cc_find(L, a); b = cc_find(L, b);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }                     // hang the larger root under the smaller one
+    const int old = atomicMin(&L[a], b);
+    if (old == a) return;
+    a = old;
+  }
+}
+__global__ void cc_init_kernel(const int32_t* __restrict__ d, int n, int* __restrict__ label, int* __restrict__ size) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  label[i] = d[(size_t)i * 3 + 2] ? i : -1;
+  size[i] = 0;
+}
+__global__ void cc_union_kernel(int* label, int w, int h) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const int i = y * w + x;
+  if (label[i] < 0) return;
+  if (x > 0 && label[i - 1] >= 0) cc_unite(label, i, i - 1);
+  if (y > 0) {
+    if (label[i - w] >= 0) cc_unite(label, i, i - w);
+    if (x > 0 && label[i - w - 1] >= 0) cc_unite(label, i, i - w - 1);
+    if (x + 1 < w && label[i - w + 1] >= 0) cc_unite(label, i, i - w + 1);
+  }
+}
+// the forest is final after the union kernel: read-only root walks (a compressing find here would race with the readers)
+__device__ __forceinline__ int cc_root(const int* L, int x) {
+  int p = L[x];
+  while (p != x) { x = p; p = L[x]; }
+  return x;
+}
+__global__ void cc_count_kernel(const int* __restrict__ label, int n, int* __restrict__ size) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || label[i] < 0) return;
+  atomicAdd(&size[cc_root(label, i)], 1);
+}
+__global__ void cc_erase_kernel(int32_t* __restrict__ d, const int* __restrict__ label, const int* __restrict__ size, int n, int area) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || label[i] < 0) return;
+  if (size[cc_root(label, i)] <= area) { d[(size_t)i * 3] = 0; d[(size_t)i * 3 + 1] = 0; d[(size_t)i * 3 + 2] = 0; }
+}
+
 // SGM result: sub-pixel view + search.min, invalid where the filtered integer disparity is (CorrelationView.cc:862-875)
 __global__ void finish_sgm_kernel(const int32_t* __restrict__ d, const float* __restrict__ sub, int w, int h, float ax, float ay,
                                   float* __restrict__ out, ptrdiff_t ostride_px) {
@@ -197,6 +249,21 @@ int vwgpu_launch_disparity_filter(vwgpu_ctx* ctx, const int32_t* src, int w, int
   return VWGPU_OK;
 }
 
+// scratch: 2 x w*h ints
+int vwgpu_launch_blob_filter(vwgpu_ctx* ctx, int32_t* d, int w, int h, int area, int* scratch) {
+  if (area < 1) return VWGPU_OK;
+  const int n = w * h;
+  int* label = scratch; int* size = scratch + n;
+  vwgpu_prof_scope ps(ctx, "blob_filter");
+  const dim3 g1((n + 255) / 256), b1(256);
+  hipLaunchKernelGGL(cc_init_kernel, g1, b1, 0, ctx->stream, d, n, label, size);
+  hipLaunchKernelGGL(cc_union_kernel, grid2(w, h), kBlk, 0, ctx->stream, label, w, h);
+  hipLaunchKernelGGL(cc_count_kernel, g1, b1, 0, ctx->stream, label, n, size);
+  hipLaunchKernelGGL(cc_erase_kernel, g1, b1, 0, ctx->stream, d, label, size, n, area);
+  VWGPU_HIP(ctx, hipGetLastError());
+  return VWGPU_OK;
+}
+
 int vwgpu_launch_disparity_mask(vwgpu_ctx* ctx, int32_t* d, int w, int h, const uint8_t* m1, const uint8_t* m2, int m2w, int m2h) {
   vwgpu_prof_scope ps(ctx, "disparity_mask");
   hipLaunchKernelGGL(disparity_mask_kernel, grid2(w, h), kBlk, 0, ctx->stream, d, w, h, m1, m2, m2w, m2h);
@@ -237,8 +304,9 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   // SGM: R->L crops (left image grown by twice the search), R->L masks, disparities of both directions and their history
   const size_t rl_px = (size_t)(bw + search.dx() + 8) * (bh + search.dy() + 8);
   const size_t lrev_px = (size_t)(lg.dx() + 2 * search.dx() + 8) * (lg.dy() + 2 * search.dy() + 8);
+  const size_t need_blob = P->blob_filter_area > 0 ? (size_t)(bw + search.dx() + 8) * (bh + search.dy() + 8) * 8 + 1024 : 0;
   const size_t need_sgm = P->algorithm != 0 ? lrev_px * 4 + rl_px * (12 * 5 + 1) + lrev_px + (size_t)bw * bh * (12 + 12) + (1 << 16) : 0;
-  int rc = vwgpu_arena_reserve(ctx, &ctx->pyr, need + need_sgm);
+  int rc = vwgpu_arena_reserve(ctx, &ctx->pyr, need + need_sgm + need_blob);
   if (rc) return rc;
   Bump A{static_cast<char*>(ctx->pyr.base), ctx->pyr.cap};
   std::vector<DevImg> lp(L + 1), rp(L + 1);
@@ -313,6 +381,11 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   float* tmp_a = A.take<float>(nl + nr);
   float* tmp_b = A.take<float>((size_t)(rg.dx() + 2 * search.dx()) * (rg.dy() + 2 * search.dy()));
   if (!disp || !disp2 || !padded || !rl || !tmp_a || !tmp_b) return fail_mem();
+  int* blob_scratch = nullptr;
+  if (P->blob_filter_area > 0) {
+    blob_scratch = A.take<int>((size_t)(bw + search.dx() + 8) * (bh + search.dy() + 8) * 2);
+    if (!blob_scratch) return fail_mem();
+  }
   float* sgm_b = nullptr; float* sub = nullptr; uint8_t* rl_rmask = nullptr; uint8_t* rl_lmask = nullptr;
   int32_t *prev_disp = nullptr, *rl_a = nullptr, *rl_b = nullptr, *rl_pad = nullptr, *prev_rl = nullptr;
   if (use_sgm) {
@@ -483,6 +556,12 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         if (rc) return rc;
       }
     }
+    // the kernel based filtering tends to leave isolated blobs behind (:746-750)
+    if (P->blob_filter_area > 0) {
+      const int area = P->blob_filter_area / scaling;
+      if ((rc = vwgpu_launch_blob_filter(ctx, disp, dw, dh, area, blob_scratch))) return rc;
+      if (check_rl && !last && use_sgm && (rc = vwgpu_launch_blob_filter(ctx, rl_a, rlw, rlh, area, blob_scratch))) return rc;
+    }
     if (use_sgm && !last) {                         // prev_disparity / prev_disparity_rl of the next level (:368-371)
       VWGPU_HIP(ctx, hipMemcpyAsync(prev_disp, disp, (size_t)dw * dh * 12, hipMemcpyDeviceToDevice, st));
       pdw = dw; pdh = dh;
@@ -600,6 +679,31 @@ int vwgpu_disparity_mask(vwgpu_ctx* ctx, int32_t* disp, int w, int h, const uint
   return VWGPU_OK;
 }
 
+int vwgpu_disparity_blob_filter_dev(vwgpu_ctx* ctx, int32_t* d_disp, int w, int h, int max_blob_area) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  ctx->err.clear();
+  if (!d_disp || w <= 0 || h <= 0 || (long long)w * h > 0x7fffffffLL) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "disparity_blob_filter: bad image arguments");
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = vwgpu_arena_reserve(ctx, &ctx->pyr, (size_t)w * h * 8);
+  if (rc) return rc;
+  return vwgpu_launch_blob_filter(ctx, d_disp, w, h, max_blob_area, static_cast<int*>(ctx->pyr.base));
+}
+
+int vwgpu_disparity_blob_filter(vwgpu_ctx* ctx, int32_t* disp, int w, int h, int max_blob_area) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  if (!disp || w <= 0 || h <= 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "disparity_blob_filter: bad image arguments");
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = vwgpu_arena_reserve(ctx, &ctx->staging, (size_t)w * h * 12);
+  if (rc) return rc;
+  int32_t* d = static_cast<int32_t*>(ctx->staging.base);
+  VWGPU_HIP(ctx, hipMemcpyAsync(d, disp, (size_t)w * h * 12, hipMemcpyHostToDevice, ctx->stream));
+  rc = vwgpu_disparity_blob_filter_dev(ctx, d, w, h, max_blob_area);
+  if (rc) return rc;
+  VWGPU_HIP(ctx, hipMemcpyAsync(disp, d, (size_t)w * h * 12, hipMemcpyDeviceToHost, ctx->stream));
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VWGPU_OK;
+}
+
 static int check_pyramid_args(vwgpu_ctx* ctx, const void* l, int lw, int lh, const void* r, int rw, int rh,
                               const vwgpu_pyramid_params* P, int bw, int bh, const void* out) {
   if (!ctx) return VWGPU_ERR_ARGUMENT;
@@ -621,7 +725,7 @@ static int check_pyramid_args(vwgpu_ctx* ctx, const void* l, int lw, int lh, con
     if (P->kernel_x != P->kernel_y || (P->kernel_x != 3 && P->kernel_x != 5 && P->kernel_x != 7 && P->kernel_x != 9))
       return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "Census transforms are only available in size 3, 5, 7, and 9.");
   }
-  if (P->blob_filter_area > 0) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: blob filter is not implemented");
+  if (P->blob_filter_area < 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate: negative blob filter area");
   if (P->max_pyramid_levels < 0 || P->filter_half_kernel < 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate: negative level / filter size");
   return VWGPU_OK;
 }

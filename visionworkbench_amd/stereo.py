@@ -196,6 +196,26 @@ def disparity_mask(disparity, left_mask, right_mask, ctx=None):
     return out
 
 
+def disparity_blob_filter(disparity, max_blob_area, ctx=None):
+    """PyramidCorrelationView::disparity_blob_filter at one level (src/vw/Stereo/CorrelationView.cc:242-271): erase every
+    8-connected component of valid pixels with at most max_blob_area pixels.  Returns a new image."""
+    if disparity.ndim != 3 or disparity.shape[2] != 3:
+        raise ArgumentErr("disparity_blob_filter: disparity must be (rows, cols, 3) int32")
+    h, w = disparity.shape[:2]
+    ctx = _ctx_for(disparity, ctx)
+    lib = ctx._lib
+    if _is_tensor(disparity):
+        if not disparity.is_cuda or disparity.dtype != torch.int32:
+            raise ArgumentErr("disparity_blob_filter: int32 CUDA tensor required")
+        out = disparity.contiguous().clone()
+        ctx.set_stream(torch.cuda.current_stream(out.device).cuda_stream)
+        ctx.check(lib.vwgpu_disparity_blob_filter_dev(ctx._h, out.data_ptr(), w, h, int(max_blob_area)))
+        return out
+    out = np.array(disparity, np.int32, order="C", copy=True)
+    ctx.check(lib.vwgpu_disparity_blob_filter(ctx._h, out.ctypes.data, w, h, int(max_blob_area)))
+    return out
+
+
 def subdivide_regions(disparity, kernel_size):
     """vw::stereo::subdivide_regions(disparity, bounding_box(disparity), list, kernel_size)
     (src/vw/Stereo/Correlation.cc:139-328).  Host logic (the zone scheduler of pyramid_correlate) on a numpy
@@ -355,5 +375,5 @@ def calc_disparity_sgm(cost_type, left_in, right_in, left_region, search_volume,
 
 
 __all__ = ["calc_disparity", "calc_disparity_sgm", "cross_corr_consistency_check", "parabola_subpixel", "rm_outliers_using_thresh",
-           "disparity_cleanup_using_thresh", "disparity_mask", "subdivide_regions", "pyramid_correlate",
+           "disparity_cleanup_using_thresh", "disparity_mask", "disparity_blob_filter", "subdivide_regions", "pyramid_correlate",
            "BBox2i", "CostFunctionType"]
