@@ -248,8 +248,12 @@ __global__ void cost_kernel(const uint64_t* __restrict__ lc, int lcw, const uint
 
 // ---- path aggregation -------------------------------------------------------------------------------------------------
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the global
+// loads that were just issued as a prefetch for the NEXT step of the scan-line recurrence.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ unsigned adds16(unsigned a, unsigned b) { return min(a + b, 65535u); }
-__device__ __forceinline__ unsigned subs16(unsigned a, unsigned b) { return a > b ? a - b : 0u; }
+__device__ __forceinline__ unsigned subs16(unsigned a, unsigned b) { return max(a, b) - b; }
 
 // One wavefront per scan line (PixelPassTask, SGMAssist.h:705-819).  line -> start pixel as in accum_sgm_multithread
 // (SGM.cc:2488-2610): first `n_first` lines start on the first border (index i), the rest on the second (index i + skip).
@@ -277,7 +281,7 @@ path_kernel(SgmGeom g, int dc, int dr, int n_first, int first_is_row_border, int
   }
   const unsigned BAD = (255u + p2) & 0xffffu;
   for (int i = lane; i < num_disp; i += 64) full_prior[i] = (uint16_t)BAD;
-  __syncthreads();
+  lds_barrier();
   int last_val = -1;
   B4 bp{0, 0, -1, -1};
   while (c >= 0 && r >= 0 && c < g.ocols && r < g.orows) {
@@ -309,7 +313,7 @@ path_kernel(SgmGeom g, int dc, int dr, int n_first, int first_is_row_border, int
       for (int s = 32; s > 0; s >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, s));
       const unsigned min_prior = mn;
       const unsigned dJ = (min_prior + p2_mod) & 0xffffu;
-      __syncthreads();
+      lds_barrier();
       for (int i = lane; i < nd; i += 64) {
         const int qy = i / wd, qx = i - qy * wd;
         const int dx = b.x0 + qx, dy = b.y0 + qy;
@@ -328,16 +332,169 @@ path_kernel(SgmGeom g, int dc, int dr, int n_first, int first_is_row_border, int
         prev_out[i] = (uint16_t)res;
         accum[st + i] = (uint16_t)(accum[st + i] + res);
       }
-      __syncthreads();
+      lds_barrier();
       for (int i = lane; i < np; i += 64) {
         const int qy = i / wp, qx = i - qy * wp;
         full_prior[(bp.y0 + qy - g.min_dy) * g.num_dx + (bp.x0 + qx - g.min_dx)] = (uint16_t)BAD;
       }
     }
-    __syncthreads();
+    lds_barrier();
     bp = b; last_val = cur;
     c += dc; r += dr;
   }
+}
+
+// Minimum over the 64 lanes of a wavefront with DPP moves only (no LDS traffic): butterflies inside each row of 16 lanes,
+// then the gfx9 row broadcasts; every lane of the result holds the minimum after the final readlane.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Same recurrence when EVERY pixel searches the full disparity range (no masks, no previous level — e.g. a single-level
+// SGM run): the previous pixel's vector already is the full-range buffer, so there is no scatter / reset phase.
+//  * ONE wavefront per scan line (no workgroup barrier on the serial path; the lines of a direction are the parallelism),
+//    EPT = ceil(num_disp / 64) disparities per lane; the vector is updated IN PLACE: a step reads all its neighbours into
+//    registers before it writes (LDS executes a wave's accesses in order), so every LDS address is fixed for the whole line;
+//  * ONE_D (num_dy == 1, the +-N x 1 searches): the clamped 2-D adjacency collapses to {left, right, self};
+//  * the line is processed in chunks of K pixels: cost (u8) and accumulator (u16) vectors, stored with a stride of `stride`
+//    elements (multiple of 16) per pixel, are bulk-loaded into LDS 16 bytes per lane (many loads in flight while other lines of the
+//    CU compute), the K serial steps touch LDS only, and the K updated accumulator vectors are written back as dwords.
+template <int EPT, bool ONE_D>
+__global__ void __launch_bounds__(64)
+path_uniform_kernel(SgmGeom g, int dc, int dr, int n_first, int first_is_row_border, int second_skip, int K, int stride,
+                    const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
+                    const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2) {
+  extern __shared__ uint16_t sm[];
+  const int num_disp = g.num_dx * g.num_dy;
+  uint16_t* buf = sm;                                                                // EPT*64 current path costs
+  uint16_t* p2tab = sm + EPT * 64;                                                   // max(p1, p2 / gradient), gradient 0..255
+  uint16_t* cacc = p2tab + 256;                                                      // K x stride
+  uint8_t* ccost = reinterpret_cast<uint8_t*>(cacc + (size_t)K * stride);            // K x stride
+  uint8_t* pix = ccost + (size_t)K * stride;                                         // K left-image values
+  const int tid = threadIdx.x;
+  const int line = blockIdx.x;
+  int c0, r0;
+  if (line < n_first) {
+    if (first_is_row_border) { c0 = line; r0 = dr > 0 ? 0 : g.orows - 1; }
+    else { r0 = line; c0 = dc > 0 ? 0 : g.ocols - 1; }
+  } else {
+    r0 = line - n_first + second_skip;
+    c0 = dc > 0 ? 0 : g.ocols - 1;
+  }
+  const int len_c = dc > 0 ? g.ocols - c0 : (dc < 0 ? c0 + 1 : 0x7fffffff);
+  const int len_r = dr > 0 ? g.orows - r0 : (dr < 0 ? r0 + 1 : 0x7fffffff);
+  const int len = min(len_c, len_r);
+  for (int q = tid; q < 256; q += 64) {
+    unsigned v = p2;
+    if (q > 0) v /= (unsigned)q;
+    if (v < p1) v = p1;
+    p2tab[q] = (uint16_t)v;
+  }
+  // LDS addresses of the centre and its neighbours, fixed for the whole line; dead lanes of the last slot read slot 0
+  constexpr int NN = ONE_D ? 3 : 9;
+  const uint16_t* nptr[EPT][NN];
+  bool live[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = tid + e * 64;
+    live[e] = i < num_disp;
+    const int ii = live[e] ? i : 0;
+    const int qy = ii / g.num_dx, qx = ii - qy * g.num_dx;
+    const int xl = qx - 1 < 0 ? qx : qx - 1, xm = qx + 1 > g.max_dx - g.min_dx ? qx : qx + 1;
+    const int yl = (qy - 1 < 0 ? qy : qy - 1) * g.num_dx, ym = (qy + 1 > g.max_dy - g.min_dy ? qy : qy + 1) * g.num_dx, yc = qy * g.num_dx;
+    nptr[e][0] = buf + yc + qx;
+    nptr[e][1] = buf + yc + xl; nptr[e][2] = buf + yc + xm;
+    if (!ONE_D) {
+      nptr[e][3] = buf + yl + qx; nptr[e][4] = buf + ym + qx;
+      nptr[e][5] = buf + yl + xl; nptr[e][6] = buf + yl + xm; nptr[e][7] = buf + ym + xl; nptr[e][8] = buf + ym + xm;
+    }
+  }
+  // 16-byte quanta per pixel vector (stride is a multiple of 16 elements), exact division j / q for j < 2^16 by a
+  // multiply-high with ceil(2^32 / q), and the extra global offset per chunk pixel
+  const int q_cost = stride / 16, q_acc = stride / 8;
+  const unsigned m_cost = (unsigned)((0x100000000ull + q_cost - 1) / q_cost), m_acc = (unsigned)((0x100000000ull + q_acc - 1) / q_acc);
+  const long long delta = (long long)dr * g.ocols + dc;
+  const long long d_cost = (delta - 1) * q_cost, d_acc = (delta - 1) * q_acc;
+  int last_val = -1;
+  unsigned min_prior = 0;
+  for (int base = 0; base < len; base += K) {
+    const int kk = min(K, len - base);
+    {                                                           // bulk load, 16 bytes per lane
+      const uint4* gc = reinterpret_cast<const uint4*>(cost);
+      const uint4* ga = reinterpret_cast<const uint4*>(accum);
+      uint4* lc = reinterpret_cast<uint4*>(ccost);
+      uint4* la = reinterpret_cast<uint4*>(cacc);
+      // global index of chunk element j = k * q + w:  (P0 + k * delta) * q + w  =  P0 * q + j + k * (delta - 1) * q
+      const long long pbase = (long long)(r0 + base * dr) * g.ocols + (c0 + base * dc);
+      for (int j = tid; j < kk * q_cost; j += 64) {
+        const int k = (int)__umulhi((unsigned)j, m_cost);
+        lc[j] = gc[pbase * q_cost + j + (long long)k * d_cost];
+      }
+      for (int j = tid; j < kk * q_acc; j += 64) {
+        const int k = (int)__umulhi((unsigned)j, m_acc);
+        la[j] = ga[pbase * q_acc + j + (long long)k * d_acc];
+      }
+    }
+    if (tid < kk) pix[tid] = left[(size_t)(r0 + (base + tid) * dr + min_row) * lw + (c0 + (base + tid) * dc + min_col)];
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < kk; ++k) {                              // K serial steps, LDS only
+      const int vcur = pix[k];
+      const uint8_t* cc = ccost + k * stride;
+      uint16_t* ac = cacc + k * stride;
+      unsigned res[EPT];
+      if (last_val < 0) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) res[e] = live[e] ? (unsigned)cc[tid + e * 64] : 0xffffu;
+      } else {
+        int grad = vcur - last_val; grad = grad < 0 ? -grad : grad;
+        const unsigned dJ = (min_prior + (unsigned)p2tab[grad]) & 0xffffu;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          unsigned m = *nptr[e][1];
+#pragma unroll
+          for (int q = 2; q < NN; ++q) m = min(m, (unsigned)*nptr[e][q]);
+          const unsigned ctr = *nptr[e][0];
+          if (ONE_D) m = min(m, ctr);                           // the clamped vertical neighbours are the centre itself
+          unsigned v = adds16(m, p1);
+          v = min(v, min(ctr, dJ));
+          v = adds16(v, live[e] ? (unsigned)cc[tid + e * 64] : 0u);
+          res[e] = live[e] ? subs16(v, min_prior) : 0xffffu;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();                          // all neighbour reads are issued before the in-place writes
+      unsigned mn = 0xffffu;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * 64;
+        if (live[e]) { buf[i] = (uint16_t)res[e]; ac[i] = (uint16_t)(ac[i] + res[e]); mn = min(mn, res[e]); }
+      }
+      min_prior = wave_min_u32(mn);
+      __builtin_amdgcn_wave_barrier();
+      last_val = vcur;
+    }
+    {                                                           // bulk store
+      uint4* ga = reinterpret_cast<uint4*>(accum);
+      const uint4* la = reinterpret_cast<const uint4*>(cacc);
+      const long long pbase = (long long)(r0 + base * dr) * g.ocols + (c0 + base * dc);
+      for (int j = tid; j < kk * q_acc; j += 64) {
+        const int k = (int)__umulhi((unsigned)j, m_acc);
+        ga[pbase * q_acc + j + (long long)k * d_acc] = la[j];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// starts of the uniform layout: pixel p's vectors begin at p * stride
+__global__ void uniform_starts_kernel(unsigned long long* __restrict__ starts, size_t npix, unsigned long long stride) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < npix) starts[p] = p * stride;
 }
 
 // ---- winner take all --------------------------------------------------------------------------------------------------
@@ -616,8 +773,16 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     if (out_sub) VWGPU_HIP(ctx, hipMemsetAsync(out_sub, 0, npix * 12, st));
     return VWGPU_OK;
   }
-  VWGPU_HIP(ctx, hipMemcpyAsync(rowoff, h_rows.data(), (size_t)g.orows * 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(row_scan_kernel, dim3(g.orows), dim3(256), 0, st, bounds, g.ocols, rowoff, starts);
+  // every pixel searches the whole range: no masks, no previous level (bounds_kernel then wrote the full box everywhere)
+  const bool uniform = !lmask && !rmask && !prev && num_disp <= 64 * 8;
+  const int ustride = (int)((num_disp + 15) / 16 * 16);          // per-pixel vector stride of the uniform layout (16-byte loads)
+  if (uniform) {
+    main_buf = (unsigned long long)npix * ustride;
+    hipLaunchKernelGGL(uniform_starts_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, starts, npix, (unsigned long long)ustride);
+  } else {
+    VWGPU_HIP(ctx, hipMemcpyAsync(rowoff, h_rows.data(), (size_t)g.orows * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(row_scan_kernel, dim3(g.orows), dim3(256), 0, st, bounds, g.ocols, rowoff, starts);
+  }
 
   // the two ragged buffers (separate arena: reserving may reallocate, the fixed part above must stay put)
   rc = vwgpu_arena_reserve(ctx, &ctx->sgm_main, (size_t)main_buf * 3 + 1024);
@@ -644,6 +809,24 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       vwgpu_prof_scope ps(ctx, d.name);
       const int lines = d.n_first + d.n_second;
       if (lines <= 0) continue;
+      if (uniform) {
+        const int ept = (int)((num_disp + 63) / 64);
+        // chunk length: ~12 KB of LDS per line for the cost + accumulator vectors of K pixels
+        int K = 12288 / (3 * ustride);
+        K = std::max(1, std::min(K, 32));
+        const size_t ulds = ((size_t)ept * 64 + 256) * sizeof(uint16_t) + (size_t)K * ustride * 3 + K + 16;
+        const bool one_d = g.num_dy == 1;
+#define VWGPU_PATH_U(E) do { if (one_d) hipLaunchKernelGGL((path_uniform_kernel<E, true>), dim3(lines), dim3(64), ulds, st, g, d.dc, d.dr, d.n_first, \
+                               d.first_is_row_border, d.second_skip, K, ustride, l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2); \
+                             else hipLaunchKernelGGL((path_uniform_kernel<E, false>), dim3(lines), dim3(64), ulds, st, g, d.dc, d.dr, d.n_first, \
+                               d.first_is_row_border, d.second_skip, K, ustride, l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2); } while (0)
+        switch (ept) {
+          case 1: VWGPU_PATH_U(1); break; case 2: VWGPU_PATH_U(2); break; case 3: VWGPU_PATH_U(3); break; case 4: VWGPU_PATH_U(4); break;
+          case 5: VWGPU_PATH_U(5); break; case 6: VWGPU_PATH_U(6); break; case 7: VWGPU_PATH_U(7); break; default: VWGPU_PATH_U(8); break;
+        }
+#undef VWGPU_PATH_U
+        continue;
+      }
       hipLaunchKernelGGL(path_kernel, dim3(lines), dim3(64), lds, st, g, d.dc, d.dr, d.n_first, d.first_is_row_border, d.second_skip,
                          l8, lw, min_col, min_row, bounds, starts, cost, accum, (unsigned)p1, (unsigned)p2);
     }
