@@ -57,7 +57,8 @@ typedef enum vwgpu_cost_type {
 typedef enum vwgpu_path {
   VWGPU_PATH_NONE = 0,
   VWGPU_PATH_GENERIC_F64 = 1,  /* any float input, float64 accumulators (reference arithmetic)          */
-  VWGPU_PATH_SAD_U8 = 2        /* integer-valued inputs in [0,255]: packed u8 SAD (v_qsad_pk_u16_u8)      */
+  VWGPU_PATH_SAD_U8 = 2,       /* integer-valued inputs in [0,255]: packed u8 SAD (v_qsad_pk_u16_u8)      */
+  VWGPU_PATH_DOT_U8 = 3        /* integer-valued inputs in [0,255]: SSD / NCC on v_dot4_u32_u8            */
 } vwgpu_path;
 
 /* ---- context ------------------------------------------------------------------------------------- */

@@ -249,3 +249,64 @@ def test_full_size_config2_sampled_parity(ctx, oracle):
     t = truth[:4090, :4090]
     assert (got[..., 2] == core.VALID_I32).mean() > 0.999
     assert (got[..., 0] == t).mean() > 0.9
+
+
+# ---- packed dot-product path (SSD / NCC on integer-valued data) ----------------------------------------------------------
+
+@pytest.mark.parametrize("cost", [1, 2])
+@pytest.mark.parametrize("kernel,search", [((3, 3), (5, 1)), ((7, 7), (33, 1)), ((11, 11), (129, 1)), ((5, 9), (64, 1)),
+                                           ((13, 5), (17, 1)), ((15, 15), (100, 1)), ((9, 31), (7, 1))])
+def test_dot_path_bit_exact(oracle, cost, kernel, search):
+    from visionworkbench_amd import core, stereo, synth
+    w, h = 203, 77
+    left, right, _ = synth.stereo_pair(w, h, search[0], search[1], block=32)
+    ctx = core.Context(0)
+    got = stereo.calc_disparity(cost, left, right, core.BBox2i(0, 0, w, h), search, kernel, ctx=ctx)
+    assert ctx.last_path() == core.PATH_DOT_U8
+    want = oracle.calc_disparity(cost, left, right, kernel, search)
+    assert np.array_equal(got, want)
+    ctx.close()
+
+
+@pytest.mark.parametrize("cost", [1, 2])
+def test_dot_path_ties_and_flat_areas(oracle, cost):
+    """Constant regions: every disparity ties (all costs equal -> invalid), partial ties pick the first disparity."""
+    from visionworkbench_amd import core, stereo
+    rng = np.random.default_rng(4)
+    left = rng.integers(1, 256, (60, 150)).astype(np.float32)
+    right = rng.integers(1, 256, (60, 150 + 32)).astype(np.float32)
+    left[10:40, 20:90] = 77.0
+    right[5:45, 10:140] = 77.0
+    right[:, 100:] = np.tile(right[:, 96:100], (1, 21))[:, :82]           # periodic texture: repeated exact matches
+    ctx = core.Context(0)
+    got = stereo.calc_disparity(cost, left, right, core.BBox2i(0, 0, 150, 60), (33, 1), (7, 7), ctx=ctx)
+    want = oracle.calc_disparity(cost, left, right, (7, 7), (33, 1))
+    assert ctx.last_path() == core.PATH_DOT_U8
+    assert np.array_equal(got, want)
+    assert (got[15:30, 25:50, 2] == 0).all()
+    ctx.close()
+
+
+def test_dot_path_falls_back(oracle):
+    """Non-integer pixels or an all-zero window (NCC: 1/0) raise the flag and the float64 kernel recomputes the image."""
+    from visionworkbench_amd import core, stereo, synth
+    left, right, _ = synth.stereo_pair(120, 50, 17, 1, block=32)
+    ctx = core.Context(0)
+    l2 = left.copy(); l2[20, 30] += 0.5
+    got = stereo.calc_disparity(1, l2, right, core.BBox2i(0, 0, 120, 50), (17, 1), (5, 5), ctx=ctx)
+    assert ctx.last_path() == core.PATH_GENERIC_F64
+    assert np.array_equal(got, oracle.calc_disparity(1, l2, right, (5, 5), (17, 1)))
+    r0 = right.copy(); r0[10:30, 40:70] = 0.0
+    got = stereo.calc_disparity(2, left, r0, core.BBox2i(0, 0, 120, 50), (17, 1), (5, 5), ctx=ctx)
+    assert ctx.last_path() == core.PATH_GENERIC_F64
+    assert np.array_equal(got, oracle.calc_disparity(2, left, r0, (5, 5), (17, 1)))
+    # SSD has no division: zero windows stay on the fast path
+    got = stereo.calc_disparity(1, left, r0, core.BBox2i(0, 0, 120, 50), (17, 1), (5, 5), ctx=ctx)
+    assert ctx.last_path() == core.PATH_DOT_U8
+    assert np.array_equal(got, oracle.calc_disparity(1, left, r0, (5, 5), (17, 1)))
+    # two search rows: not a dot-path shape
+    left2, right2, _ = synth.stereo_pair(120, 50, 9, 3, block=32)
+    got = stereo.calc_disparity(1, left2, right2, core.BBox2i(0, 0, 120, 50), (9, 3), (5, 5), ctx=ctx)
+    assert ctx.last_path() == core.PATH_GENERIC_F64
+    assert np.array_equal(got, oracle.calc_disparity(1, left2, right2, (5, 5), (9, 3)))
+    ctx.close()

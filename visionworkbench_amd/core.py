@@ -39,7 +39,7 @@ ABSOLUTE_DIFFERENCE = CostFunctionType.ABSOLUTE_DIFFERENCE
 SQUARED_DIFFERENCE = CostFunctionType.SQUARED_DIFFERENCE
 CROSS_CORRELATION = CostFunctionType.CROSS_CORRELATION
 
-PATH_NONE, PATH_GENERIC_F64, PATH_SAD_U8 = 0, 1, 2
+PATH_NONE, PATH_GENERIC_F64, PATH_SAD_U8, PATH_DOT_U8 = 0, 1, 2, 3
 VALID_I32 = 0x7FFFFFFF
 
 

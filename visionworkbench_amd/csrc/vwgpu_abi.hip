@@ -47,6 +47,24 @@ static void prof_clear(vwgpu_ctx* ctx) {
 
 // ---- context ------------------------------------------------------------------------------------------
 
+// Two alternating device flags: call n raises flags[n&1] on unsuitable input and clears flags[(n+1)&1] for the next call, so
+// no memset launch is needed (stream order makes this race free).  `extra` (optional) = extra_ints ints after the flags.
+int vwgpu_next_flags(vwgpu_ctx* ctx, size_t extra_ints, int** flag_set, int** flag_clear, int** extra) {
+  int rc = vwgpu_arena_reserve(ctx, &ctx->flags, 256 + extra_ints * sizeof(int));
+  if (rc) return rc;
+  int* flags = static_cast<int*>(ctx->flags.base);
+  if (ctx->flags_base_seen != ctx->flags.base) { ctx->flags_init = false; ctx->flags_base_seen = ctx->flags.base; }
+  if (!ctx->flags_init) {
+    VWGPU_HIP(ctx, hipMemsetAsync(flags, 0, 256, ctx->stream));
+    ctx->flags_init = true;
+  }
+  *flag_set = flags + (ctx->flag_parity & 1);
+  *flag_clear = flags + ((ctx->flag_parity + 1) & 1);
+  ctx->flag_parity ^= 1;
+  if (extra) *extra = flags + 64;
+  return VWGPU_OK;
+}
+
 extern "C" {
 
 int vwgpu_abi_version(void) { return VWGPU_ABI_VERSION; }
@@ -128,7 +146,7 @@ int vwgpu_synchronize(vwgpu_ctx* ctx) {
 const char* vwgpu_last_error(const vwgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
 
 int vwgpu_force_path(vwgpu_ctx* ctx, int path) {
-  if (!ctx || path < VWGPU_PATH_NONE || path > VWGPU_PATH_SAD_U8) return VWGPU_ERR_ARGUMENT;
+  if (!ctx || path < VWGPU_PATH_NONE || path > VWGPU_PATH_DOT_U8) return VWGPU_ERR_ARGUMENT;
   ctx->forced_path = path;
   return VWGPU_OK;
 }
@@ -136,12 +154,12 @@ int vwgpu_force_path(vwgpu_ctx* ctx, int path) {
 int vwgpu_last_path(const vwgpu_ctx* cctx) {
   vwgpu_ctx* ctx = const_cast<vwgpu_ctx*>(cctx);
   if (!ctx) return VWGPU_PATH_NONE;
-  if (ctx->last_path == VWGPU_PATH_SAD_U8 && ctx->last_flag) {
+  if ((ctx->last_path == VWGPU_PATH_SAD_U8 || ctx->last_path == VWGPU_PATH_DOT_U8) && ctx->last_flag) {
     // The fast path reports non-representable input through a device flag; the generic kernel then ran.
     int flag = 0;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return VWGPU_PATH_NONE;
     if (hipMemcpy(&flag, ctx->last_flag, sizeof flag, hipMemcpyDeviceToHost) != hipSuccess) return VWGPU_PATH_NONE;
-    return flag ? VWGPU_PATH_GENERIC_F64 : VWGPU_PATH_SAD_U8;
+    return flag ? VWGPU_PATH_GENERIC_F64 : ctx->last_path;
   }
   return ctx->last_path;
 }
@@ -225,6 +243,20 @@ int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
     // recomputes the whole image (its blocks return at once when the flag is clear).
     return vwgpu_launch_bm_generic_flag(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs,
                                         kx, ky, sx, sy, d_out, os, d_flag);
+  }
+  // SSD / NCC on integer-valued data: packed dot-product path, same flag protocol
+  const bool dot_ok = vwgpu_bm_dot_u8_supported(cost_type, kx, ky, sx, sy);
+  if (ctx->forced_path == VWGPU_PATH_DOT_U8 && !dot_ok)
+    return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: no dot-product path for cost %d kernel %dx%d search %dx%d",
+                      cost_type, kx, ky, sx, sy);
+  if (dot_ok && (ctx->forced_path == VWGPU_PATH_NONE || ctx->forced_path == VWGPU_PATH_DOT_U8)) {
+    int* d_flag = nullptr;
+    rc = vwgpu_launch_bm_dot_u8(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
+    if (rc) return rc;
+    ctx->last_path = VWGPU_PATH_DOT_U8;
+    ctx->last_flag = d_flag;
+    if (ctx->forced_path == VWGPU_PATH_DOT_U8) return VWGPU_OK;
+    return vwgpu_launch_bm_generic_flag(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, d_flag);
   }
   ctx->last_path = VWGPU_PATH_GENERIC_F64;
   return vwgpu_launch_bm_generic(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os);

@@ -96,6 +96,13 @@ int vwgpu_launch_bm_sad_u8(vwgpu_ctx* ctx,
                            int kx, int ky, int sx, int sy, int32_t* out, ptrdiff_t os,
                            int** d_fallback_flag);
 
+// bm_dot_u8.hip: SSD / NCC on integer-valued [0,255] inputs (v_dot4_u32_u8); same fallback-flag protocol as the SAD path
+bool vwgpu_bm_dot_u8_supported(int cost_type, int kx, int ky, int sx, int sy);
+int vwgpu_launch_bm_dot_u8(vwgpu_ctx* ctx, int cost_type, const float* left, int lw, int lh, ptrdiff_t ls,
+                           const float* right, int rw, int rh, ptrdiff_t rs, int kx, int ky, int sx, int sy,
+                           int32_t* out, ptrdiff_t os, int** d_fallback_flag);
+int vwgpu_next_flags(vwgpu_ctx* ctx, size_t extra_ints, int** flag_set, int** flag_clear, int** extra);
+
 int vwgpu_launch_lr_check(vwgpu_ctx* ctx, int32_t* l2r, int lw, int lh, ptrdiff_t ls,
                           const int32_t* r2l, int rw, int rh, ptrdiff_t rs, float thr);
 
