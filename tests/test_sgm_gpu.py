@@ -206,3 +206,42 @@ def test_randomized_masks_and_previous_level(vw, oracle, seed):
     gi, gs, oi, os_ = _both(vw, oracle, CENSUS, left, right, (sx, sy), k, 5, lm=lm, rm=rm, prev=prev)
     assert np.array_equal(gi, oi)
     assert np.abs(gs - os_).max() < 1e-5
+
+
+@pytest.mark.parametrize("sx,sy,k,w,h", [(70, 0, 5, 150, 40), (128, 0, 7, 200, 60), (64, 2, 5, 150, 50), (128, 2, 7, 220, 60), (200, 1, 5, 260, 40)])
+def test_uniform_path_many_disparities(vw, oracle, sx, sy, k, w, h):
+    """Full-range boxes everywhere -> the in-place one-wavefront path kernel, 2..7 disparities per lane, 1-D and 2-D."""
+    rng = np.random.default_rng(sx + sy)
+    base = rng.integers(0, 256, (h + sy + 8, w + sx + 8)).astype(np.float32)
+    left = np.ascontiguousarray(base[4:4 + h, 4:4 + w])
+    right = np.ascontiguousarray(base[3:3 + h + sy, 1:1 + w + sx])
+    gi, gs, oi, os_ = _both(vw, oracle, CENSUS, left, right, (sx, sy), k, 5)
+    assert np.array_equal(gi, oi) and np.abs(gs - os_).max() < 1e-5
+
+
+@pytest.mark.parametrize("sx,sy,k,w,h", [(4, 0, 7, 40, 30), (8, 0, 7, 60, 48), (3, 1, 5, 20, 16), (16, 0, 7, 100, 80)])
+def test_uniform_path_detected_from_the_boxes(vw, oracle, sx, sy, k, w, h):
+    """All-valid masks (the top level of every pyramid): the boxes come out full everywhere and the uniform kernel runs;
+    fewer than 16 disparities exercises the one-quantum-per-pixel stride."""
+    rng = np.random.default_rng(7 * sx + sy)
+    base = rng.integers(0, 256, (h + sy + 8, w + sx + 8)).astype(np.float32)
+    left = np.ascontiguousarray(base[4:4 + h, 4:4 + w])
+    right = np.ascontiguousarray(base[3:3 + h + sy, 1:1 + w + sx])
+    oh, ow = h - k + 1, w - k + 1
+    lm = np.full((oh, ow), 255, np.uint8)
+    rm = np.full((oh + sy, ow + sx), 255, np.uint8)
+    gi, gs, oi, os_ = _both(vw, oracle, CENSUS, left, right, (sx, sy), k, 5, lm=lm, rm=rm)
+    assert np.array_equal(gi, oi) and np.abs(gs - os_).max() < 1e-5
+
+
+def test_pyramid_sgm_large_tile(vw, oracle):
+    """A 640x512 tile of a 1400^2 pair, +-64 x +-1 search, 5 levels: 387 disparities at level 0 on ragged boxes."""
+    from visionworkbench_amd import synth
+    from visionworkbench_amd.core import BBox2i
+    L, R, _ = synth.stereo_pair(1400, 1400, 129, 1)
+    R = R[:, 64:64 + 1400].copy()
+    bb = (256, 192, 640, 512)
+    g = vw.pyramid_correlate(L, R, None, None, 0, 0.0, BBox2i.from_corners((-64, -1), (64, 1)), (7, 7), CENSUS, consistency_threshold=2,
+                             filter_half_kernel=5, max_pyramid_levels=5, algorithm=1, bbox=BBox2i(*bb))
+    o = oracle.pyramid_correlate_sgm(L, R, None, None, (-64, -1, 64, 1), 7, CENSUS, 2, 0, 5, 5, bbox=bb)
+    assert np.array_equal(g[..., 2], o[..., 2]) and np.abs(g[..., :2] - o[..., :2]).max() < 1e-5

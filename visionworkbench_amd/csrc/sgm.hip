@@ -255,10 +255,48 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ unsigned adds16(unsigned a, unsigned b) { return min(a + b, 65535u); }
 __device__ __forceinline__ unsigned subs16(unsigned a, unsigned b) { return max(a, b) - b; }
 
+// Minimum over the 64 lanes of a wavefront with DPP moves only (no LDS traffic): butterflies inside each row of 16 lanes,
+// then the gfx9 row broadcasts; every lane of the result holds the minimum after the final readlane.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// The scan lines of up to 8 directions in one launch.  Direction q owns blocks [line0[q], line0[q+1]); its lines start on
+// the first border (x index, or y index for the purely horizontal passes) and then on the second one, exactly as
+// accum_sgm_multithread enumerates them (SGM.cc:2488-2610).  Different directions add into the same accumulator elements,
+// so the adds are 32-bit atomics on the u16 pair that holds the element (no carry can cross the halves: the caller only
+// groups directions when 8 * (255 + max(P1, P2)) < 65536; otherwise it launches them one by one).
+struct DirSet {
+  int n;
+  int dc[8], dr[8], n_first[8], row_border[8], second_skip[8], line0[9];
+};
+__device__ __forceinline__ void line_start(const DirSet& D, const SgmGeom& g, int block, int& dc, int& dr, int& c, int& r) {
+  int q = 0;
+  while (q + 1 < D.n && block >= D.line0[q + 1]) ++q;
+  dc = D.dc[q]; dr = D.dr[q];
+  const int line = block - D.line0[q];
+  if (line < D.n_first[q]) {
+    if (D.row_border[q]) { c = line; r = dr > 0 ? 0 : g.orows - 1; }
+    else { r = line; c = dc > 0 ? 0 : g.ocols - 1; }
+  } else {
+    r = line - D.n_first[q] + D.second_skip[q];
+    c = dc > 0 ? 0 : g.ocols - 1;
+  }
+}
+__device__ __forceinline__ void accum_add_u16(uint16_t* accum, unsigned long long e, unsigned v) {
+  atomicAdd(reinterpret_cast<unsigned*>(accum) + (e >> 1), v << ((e & 1) * 16));
+}
+
 // One wavefront per scan line (PixelPassTask, SGMAssist.h:705-819).  line -> start pixel as in accum_sgm_multithread
 // (SGM.cc:2488-2610): first `n_first` lines start on the first border (index i), the rest on the second (index i + skip).
 __global__ void __launch_bounds__(64)
-path_kernel(SgmGeom g, int dc, int dr, int n_first, int first_is_row_border, int second_skip,
+path_kernel(SgmGeom g, DirSet D,
             const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
             const B4* __restrict__ bounds, const unsigned long long* __restrict__ starts,
             const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2) {
@@ -267,18 +305,8 @@ path_kernel(SgmGeom g, int dc, int dr, int n_first, int first_is_row_border, int
   uint16_t* full_prior = sm;                 // num_disp
   uint16_t* prev_out = sm + num_disp;        // num_disp (packed vector of the previous pixel)
   const int lane = threadIdx.x;
-  const int line = blockIdx.x;
-  int c, r;
-  // start pixel
-  if (line < n_first) {
-    // lines indexed along x start on the top (dr > 0) or bottom (dr < 0) row; lines indexed along y (pure horizontal
-    // passes) start on the left / right column
-    if (first_is_row_border) { c = line; r = dr > 0 ? 0 : g.orows - 1; }
-    else { r = line; c = dc > 0 ? 0 : g.ocols - 1; }
-  } else {
-    r = line - n_first + second_skip;
-    c = dc > 0 ? 0 : g.ocols - 1;
-  }
+  int c, r, dc, dr;
+  line_start(D, g, blockIdx.x, dc, dr, c, r);
   const unsigned BAD = (255u + p2) & 0xffffu;
   for (int i = lane; i < num_disp; i += 64) full_prior[i] = (uint16_t)BAD;
   lds_barrier();
@@ -294,7 +322,7 @@ path_kernel(SgmGeom g, int dc, int dr, int n_first, int first_is_row_border, int
       for (int i = lane; i < nd; i += 64) {
         const unsigned v = cost[st + i];
         prev_out[i] = (uint16_t)v;
-        accum[st + i] = (uint16_t)(accum[st + i] + v);
+        accum_add_u16(accum, st + i, v);
       }
     } else {
       int grad = cur - last_val; grad = grad < 0 ? -grad : grad;
@@ -330,7 +358,7 @@ path_kernel(SgmGeom g, int dc, int dr, int n_first, int first_is_row_border, int
         res = subs16(res, min_prior);
         // prev_out is still being read by nobody (scatter finished at the barrier): reuse it for this pixel's vector
         prev_out[i] = (uint16_t)res;
-        accum[st + i] = (uint16_t)(accum[st + i] + res);
+        accum_add_u16(accum, st + i, res);
       }
       lds_barrier();
       for (int i = lane; i < np; i += 64) {
@@ -344,18 +372,6 @@ path_kernel(SgmGeom g, int dc, int dr, int n_first, int first_is_row_border, int
   }
 }
 
-// Minimum over the 64 lanes of a wavefront with DPP moves only (no LDS traffic): butterflies inside each row of 16 lanes,
-// then the gfx9 row broadcasts; every lane of the result holds the minimum after the final readlane.
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
-  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
-  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
-  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
-  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
-  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 // Same recurrence when EVERY pixel searches the full disparity range (no masks, no previous level — e.g. a single-level
 // SGM run): the previous pixel's vector already is the full-range buffer, so there is no scatter / reset phase.
 //  * ONE wavefront per scan line (no workgroup barrier on the serial path; the lines of a direction are the parallelism),
@@ -367,7 +383,7 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 //    CU compute), the K serial steps touch LDS only, and the K updated accumulator vectors are written back as dwords.
 template <int EPT, bool ONE_D>
 __global__ void __launch_bounds__(64)
-path_uniform_kernel(SgmGeom g, int dc, int dr, int n_first, int first_is_row_border, int second_skip, int K, int stride,
+path_uniform_kernel(SgmGeom g, DirSet D, int K, int stride,
                     const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
                     const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2) {
   extern __shared__ uint16_t sm[];
@@ -378,15 +394,8 @@ path_uniform_kernel(SgmGeom g, int dc, int dr, int n_first, int first_is_row_bor
   uint8_t* ccost = reinterpret_cast<uint8_t*>(cacc + (size_t)K * stride);            // K x stride
   uint8_t* pix = ccost + (size_t)K * stride;                                         // K left-image values
   const int tid = threadIdx.x;
-  const int line = blockIdx.x;
-  int c0, r0;
-  if (line < n_first) {
-    if (first_is_row_border) { c0 = line; r0 = dr > 0 ? 0 : g.orows - 1; }
-    else { r0 = line; c0 = dc > 0 ? 0 : g.ocols - 1; }
-  } else {
-    r0 = line - n_first + second_skip;
-    c0 = dc > 0 ? 0 : g.ocols - 1;
-  }
+  int c0, r0, dc, dr;
+  line_start(D, g, blockIdx.x, dc, dr, c0, r0);
   const int len_c = dc > 0 ? g.ocols - c0 : (dc < 0 ? c0 + 1 : 0x7fffffff);
   const int len_r = dr > 0 ? g.orows - r0 : (dr < 0 ? r0 + 1 : 0x7fffffff);
   const int len = min(len_c, len_r);
@@ -417,28 +426,22 @@ path_uniform_kernel(SgmGeom g, int dc, int dr, int n_first, int first_is_row_bor
   }
   // 16-byte quanta per pixel vector (stride is a multiple of 16 elements), exact division j / q for j < 2^16 by a
   // multiply-high with ceil(2^32 / q), and the extra global offset per chunk pixel
-  const int q_cost = stride / 16, q_acc = stride / 8;
-  const unsigned m_cost = (unsigned)((0x100000000ull + q_cost - 1) / q_cost), m_acc = (unsigned)((0x100000000ull + q_acc - 1) / q_acc);
+  const int q_cost = stride / 16;
+  const unsigned m_cost = (unsigned)((0x100000000ull + q_cost - 1) / q_cost);
   const long long delta = (long long)dr * g.ocols + dc;
-  const long long d_cost = (delta - 1) * q_cost, d_acc = (delta - 1) * q_acc;
+  const long long d_cost = (delta - 1) * q_cost;
   int last_val = -1;
   unsigned min_prior = 0;
   for (int base = 0; base < len; base += K) {
     const int kk = min(K, len - base);
     {                                                           // bulk load, 16 bytes per lane
       const uint4* gc = reinterpret_cast<const uint4*>(cost);
-      const uint4* ga = reinterpret_cast<const uint4*>(accum);
       uint4* lc = reinterpret_cast<uint4*>(ccost);
-      uint4* la = reinterpret_cast<uint4*>(cacc);
       // global index of chunk element j = k * q + w:  (P0 + k * delta) * q + w  =  P0 * q + j + k * (delta - 1) * q
       const long long pbase = (long long)(r0 + base * dr) * g.ocols + (c0 + base * dc);
       for (int j = tid; j < kk * q_cost; j += 64) {
-        const int k = (int)__umulhi((unsigned)j, m_cost);
+        const int k = q_cost == 1 ? j : (int)__umulhi((unsigned)j, m_cost);     // ceil(2^32 / 1) does not fit 32 bits
         lc[j] = gc[pbase * q_cost + j + (long long)k * d_cost];
-      }
-      for (int j = tid; j < kk * q_acc; j += 64) {
-        const int k = (int)__umulhi((unsigned)j, m_acc);
-        la[j] = ga[pbase * q_acc + j + (long long)k * d_acc];
       }
     }
     if (tid < kk) pix[tid] = left[(size_t)(r0 + (base + tid) * dr + min_row) * lw + (c0 + (base + tid) * dc + min_col)];
@@ -472,19 +475,26 @@ path_uniform_kernel(SgmGeom g, int dc, int dr, int n_first, int first_is_row_bor
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
         const int i = tid + e * 64;
-        if (live[e]) { buf[i] = (uint16_t)res[e]; ac[i] = (uint16_t)(ac[i] + res[e]); mn = min(mn, res[e]); }
+        if (live[e]) { buf[i] = (uint16_t)res[e]; ac[i] = (uint16_t)res[e]; mn = min(mn, res[e]); }
       }
       min_prior = wave_min_u32(mn);
       __builtin_amdgcn_wave_barrier();
       last_val = vcur;
     }
-    {                                                           // bulk store
-      uint4* ga = reinterpret_cast<uint4*>(accum);
-      const uint4* la = reinterpret_cast<const uint4*>(cacc);
+    {                                                           // bulk add: one 32-bit atomic per pair of path costs
+      unsigned* ga = reinterpret_cast<unsigned*>(accum);
+      const unsigned* la = reinterpret_cast<const unsigned*>(cacc);
+      const int q32 = stride / 2;                               // dwords per pixel vector
+      const unsigned m32 = (unsigned)((0x100000000ull + q32 - 1) / q32);
       const long long pbase = (long long)(r0 + base * dr) * g.ocols + (c0 + base * dc);
-      for (int j = tid; j < kk * q_acc; j += 64) {
-        const int k = (int)__umulhi((unsigned)j, m_acc);
-        ga[pbase * q_acc + j + (long long)k * d_acc] = la[j];
+      const int nlive = (num_disp + 1) / 2;                     // dwords that hold live disparities
+      for (int j = tid; j < kk * q32; j += 64) {
+        const int k = (int)__umulhi((unsigned)j, m32), w = j - k * q32;
+        if (w < nlive) {
+          unsigned v = la[j];
+          if (2 * w + 1 >= num_disp) v &= 0xffffu;              // the odd tail shares its dword with a dead slot
+          atomicAdd(ga + pbase * q32 + j + (long long)k * (delta - 1) * q32, v);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -745,7 +755,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   }
   // memory-cap loop over the conservation levels (SGM.cc:468-491) + ragged starts
   std::vector<unsigned long long> h_rows(g.orows);
-  unsigned long long main_buf = 0;
+  unsigned long long main_buf = 0, n_total = 0;
   bool ok = false;
   const int threads = P->num_threads > 0 ? P->num_threads : 1;
   for (int level = 0; level <= 3; ++level) {
@@ -759,6 +769,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     VWGPU_HIP(ctx, hipStreamSynchronize(st));
     unsigned long long n = 0;
     for (int r = 0; r < g.orows; ++r) { const unsigned long long v = h_rows[r]; h_rows[r] = n; n += v; }
+    n_total = n;
     if (n < 6) n = 6;
     main_buf = n;
     const int line_size = (int)(std::sqrt((double)(g.ocols * g.ocols + g.orows * g.orows)) + 1);
@@ -774,7 +785,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     return VWGPU_OK;
   }
   // every pixel searches the whole range: no masks, no previous level (bounds_kernel then wrote the full box everywhere)
-  const bool uniform = !lmask && !rmask && !prev && num_disp <= 64 * 8;
+  const bool uniform = (unsigned long long)npix * (unsigned long long)num_disp == n_total && num_disp <= 64 * 8;
   const int ustride = (int)((num_disp + 15) / 16 * 16);          // per-pixel vector stride of the uniform layout (16-byte loads)
   if (uniform) {
     main_buf = (unsigned long long)npix * ustride;
@@ -799,36 +810,44 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   {
     const size_t lds = (size_t)num_disp * 2 * sizeof(uint16_t);
     const int W = g.ocols, H = g.orows;
-    struct Dir { int dc, dr, n_first, first_is_row_border, n_second, second_skip; const char* name; };
+    struct Dir { int dc, dr, n_first, first_is_row_border, n_second, second_skip; };
     const Dir dirs[8] = {
-      {0, 1, W, 1, 0, 0, "sgm_path_B"},   {0, -1, W, 1, 0, 0, "sgm_path_T"},
-      {1, 0, H, 0, 0, 0, "sgm_path_R"},   {-1, 0, H, 0, 0, 0, "sgm_path_L"},
-      {1, 1, W, 1, H - 1, 1, "sgm_path_BR"}, {-1, 1, W, 1, H - 1, 1, "sgm_path_BL"},
-      {1, -1, W, 1, H - 1, 0, "sgm_path_TR"}, {-1, -1, W, 1, H - 1, 0, "sgm_path_TL"}};
-    for (const Dir& d : dirs) {
-      vwgpu_prof_scope ps(ctx, d.name);
-      const int lines = d.n_first + d.n_second;
+      {0, 1, W, 1, 0, 0},   {0, -1, W, 1, 0, 0}, {1, 0, H, 0, 0, 0},       {-1, 0, H, 0, 0, 0},
+      {1, 1, W, 1, H - 1, 1}, {-1, 1, W, 1, H - 1, 1}, {1, -1, W, 1, H - 1, 0}, {-1, -1, W, 1, H - 1, 0}};
+    // all 8 directions in one launch when the packed 16-bit atomics cannot carry; one launch per direction otherwise
+    const bool together = 8 * (255 + std::max(p1, p2)) < 65536;
+    const int ept = (int)((num_disp + 63) / 64);
+    int K = 12288 / (3 * ustride);
+    K = std::max(1, std::min(K, 32));
+    const size_t ulds = ((size_t)ept * 64 + 256) * sizeof(uint16_t) + (size_t)K * ustride * 3 + K + 16;
+    const bool one_d = g.num_dy == 1;
+    for (int first = 0; first < 8; first += together ? 8 : 1) {
+      DirSet D;
+      D.n = together ? 8 : 1;
+      int lines = 0;
+      for (int q = 0; q < D.n; ++q) {
+        const Dir& d = dirs[first + q];
+        D.dc[q] = d.dc; D.dr[q] = d.dr; D.n_first[q] = d.n_first; D.row_border[q] = d.first_is_row_border; D.second_skip[q] = d.second_skip;
+        D.line0[q] = lines;
+        lines += d.n_first + d.n_second;
+      }
+      D.line0[D.n] = lines;
       if (lines <= 0) continue;
+      vwgpu_prof_scope ps(ctx, together ? "sgm_paths" : "sgm_path");
       if (uniform) {
-        const int ept = (int)((num_disp + 63) / 64);
-        // chunk length: ~12 KB of LDS per line for the cost + accumulator vectors of K pixels
-        int K = 12288 / (3 * ustride);
-        K = std::max(1, std::min(K, 32));
-        const size_t ulds = ((size_t)ept * 64 + 256) * sizeof(uint16_t) + (size_t)K * ustride * 3 + K + 16;
-        const bool one_d = g.num_dy == 1;
-#define VWGPU_PATH_U(E) do { if (one_d) hipLaunchKernelGGL((path_uniform_kernel<E, true>), dim3(lines), dim3(64), ulds, st, g, d.dc, d.dr, d.n_first, \
-                               d.first_is_row_border, d.second_skip, K, ustride, l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2); \
-                             else hipLaunchKernelGGL((path_uniform_kernel<E, false>), dim3(lines), dim3(64), ulds, st, g, d.dc, d.dr, d.n_first, \
-                               d.first_is_row_border, d.second_skip, K, ustride, l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2); } while (0)
+#define VWGPU_PATH_U(E) do { if (one_d) hipLaunchKernelGGL((path_uniform_kernel<E, true>), dim3(lines), dim3(64), ulds, st, g, D, K, ustride, \
+                               l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2); \
+                             else hipLaunchKernelGGL((path_uniform_kernel<E, false>), dim3(lines), dim3(64), ulds, st, g, D, K, ustride, \
+                               l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2); } while (0)
         switch (ept) {
           case 1: VWGPU_PATH_U(1); break; case 2: VWGPU_PATH_U(2); break; case 3: VWGPU_PATH_U(3); break; case 4: VWGPU_PATH_U(4); break;
           case 5: VWGPU_PATH_U(5); break; case 6: VWGPU_PATH_U(6); break; case 7: VWGPU_PATH_U(7); break; default: VWGPU_PATH_U(8); break;
         }
 #undef VWGPU_PATH_U
-        continue;
+      } else {
+        hipLaunchKernelGGL(path_kernel, dim3(lines), dim3(64), lds, st, g, D, l8, lw, min_col, min_row, bounds, starts, cost, accum,
+                           (unsigned)p1, (unsigned)p2);
       }
-      hipLaunchKernelGGL(path_kernel, dim3(lines), dim3(64), lds, st, g, d.dc, d.dr, d.n_first, d.first_is_row_border, d.second_skip,
-                         l8, lw, min_col, min_row, bounds, starts, cost, accum, (unsigned)p1, (unsigned)p2);
     }
   }
   {
