@@ -41,6 +41,11 @@ __global__ void disparity_range_kernel(const float* __restrict__ d, int w, int h
 
 __global__ void range_init_kernel(int* out4) { out4[0] = out4[1] = INT_MAX; out4[2] = out4[3] = INT_MIN; }
 
+// KX > 0: the window width is a compile-time constant and the nine costs are formed in one sweep over the (ky + 2) rows of
+// the right neighbourhood: every right value is loaded once (kx + 2 per row) and every left value once (three rows kept in
+// registers), instead of 9 * kx * ky loads of each.  The float64 accumulation order of each of the nine sums is unchanged
+// (rows outer, columns inner).  KX == 0: any width, the plain loops.
+template <int KX>
 __global__ void __launch_bounds__(256)
 parabola_kernel(const float* __restrict__ disp, int w, int h, ptrdiff_t dstride_px,
                 const float* __restrict__ lras, int lrw, const float* __restrict__ rras, int rrw,
@@ -56,19 +61,68 @@ parabola_kernel(const float* __restrict__ disp, int w, int h, ptrdiff_t dstride_
   // patch[(dy+1)*3 + (dx+1)] = cost at D + (dx,dy)   (:187-205)
   float patch[9];
   const float* lbase = lras + (ptrdiff_t)y * lrw + x;   // left_region starts at (-hx,-hy): window top-left == (x,y)
+  if (KX == 0) {
 #pragma unroll
-  for (int ddy = -1; ddy <= 1; ++ddy) {
+    for (int ddy = -1; ddy <= 1; ++ddy) {
 #pragma unroll
-    for (int ddx = -1; ddx <= 1; ++ddx) {
-      const float* rbase = rras + (ptrdiff_t)(y + Dy + ddy - range_miny) * rrw + (x + Dx + ddx - range_minx);
-      double s = 0.0;
-      for (int j = 0; j < ky; ++j) {
-        const float* lp = lbase + (ptrdiff_t)j * lrw;
-        const float* rp = rbase + (ptrdiff_t)j * rrw;
-        for (int i = 0; i < kx; ++i) s += (double)fabsf(lp[i] - rp[i]);
+      for (int ddx = -1; ddx <= 1; ++ddx) {
+        const float* rbase = rras + (ptrdiff_t)(y + Dy + ddy - range_miny) * rrw + (x + Dx + ddx - range_minx);
+        double s = 0.0;
+        for (int j = 0; j < ky; ++j) {
+          const float* lp = lbase + (ptrdiff_t)j * lrw;
+          const float* rp = rbase + (ptrdiff_t)j * rrw;
+          for (int i = 0; i < kx; ++i) s += (double)fabsf(lp[i] - rp[i]);
+        }
+        patch[(ddy + 1) * 3 + (ddx + 1)] = (float)s;
       }
-      patch[(ddy + 1) * 3 + (ddx + 1)] = (float)s;
     }
+  } else {
+    constexpr int K = KX > 0 ? KX : 1;
+    double s9[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) s9[a][b] = 0.0;
+    float la[K], lb[K], lc[K];                           // left rows q-1, q, q+1
+#pragma unroll
+    for (int i = 0; i < K; ++i) { la[i] = 0.0f; lb[i] = 0.0f; lc[i] = lbase[i]; }          // q = -1: row q+1 = 0
+    const float* rrow = rras + (ptrdiff_t)(y + Dy - 1 - range_miny) * rrw + (x + Dx - 1 - range_minx);
+    for (int q = -1; q <= ky; ++q) {                     // right row y + Dy + q pairs with left row q - ddy
+      float r[K + 2];
+#pragma unroll
+      for (int i = 0; i < K + 2; ++i) r[i] = rrow[i];
+      if (q - 1 >= 0) {                                  // ddy = +1: left row q-1
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int i = 0; i < K; ++i) s9[2][b] += (double)fabsf(la[i] - r[i + b]);
+      }
+      if (q >= 0 && q < ky) {                            // ddy = 0: left row q
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int i = 0; i < K; ++i) s9[1][b] += (double)fabsf(lb[i] - r[i + b]);
+      }
+      if (q + 1 < ky) {                                  // ddy = -1: left row q+1
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int i = 0; i < K; ++i) s9[0][b] += (double)fabsf(lc[i] - r[i + b]);
+      }
+      // slide the three left rows
+#pragma unroll
+      for (int i = 0; i < K; ++i) { la[i] = lb[i]; lb[i] = lc[i]; }
+      if (q + 2 < ky) {
+        const float* lp = lbase + (ptrdiff_t)(q + 2) * lrw;
+#pragma unroll
+        for (int i = 0; i < K; ++i) lc[i] = lp[i];
+      }
+      rrow += rrw;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) patch[a * 3 + b] = (float)s9[a][b];
   }
 
   float rx = (float)Dx, ry = (float)Dy;
@@ -121,8 +175,13 @@ int vwgpu_launch_parabola(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptr
                           int kx, int ky, float* out3f, ptrdiff_t ostride_px) {
   dim3 blk(64, 4), grd((w + 63) / 64, (h + 3) / 4);
   vwgpu_prof_scope ps(ctx, "parabola_subpixel");
-  hipLaunchKernelGGL(parabola_kernel, grd, blk, 0, ctx->stream, disp3f, w, h, dstride_px, lras, lrw, rras, rrw,
-                     range_minx, range_miny, kx, ky, out3f, ostride_px);
+#define VW_PARABOLA(K) hipLaunchKernelGGL(parabola_kernel<K>, grd, blk, 0, ctx->stream, disp3f, w, h, dstride_px, lras, lrw, rras, rrw, \
+                                          range_minx, range_miny, kx, ky, out3f, ostride_px)
+  switch (kx) {
+    case 3: VW_PARABOLA(3); break;   case 5: VW_PARABOLA(5); break;   case 7: VW_PARABOLA(7); break;   case 9: VW_PARABOLA(9); break;
+    case 11: VW_PARABOLA(11); break; case 13: VW_PARABOLA(13); break; case 15: VW_PARABOLA(15); break; default: VW_PARABOLA(0); break;
+  }
+#undef VW_PARABOLA
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }
