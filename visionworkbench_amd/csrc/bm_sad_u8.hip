@@ -233,25 +233,6 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   const int q = x0 + 4 * tid;                       // first of the lane's 4 output pixels
   u32 bad_acc = 0;                                  // non-zero: some input pixel is not an integer in [0,255]
   const int wg = blockIdx.y * gridDim.x + blockIdx.x;
-#if defined(VWGPU_EXP) && VWGPU_EXP == 2
-  long long ts_[24]; int nts_ = 0; const long long wc0_ = wall_clock64();
-#define STAMP() do { if (tid == 0 && nts_ < 24) ts_[nts_++] = clock64(); } while (0)
-#else
-#define STAMP() do {} while (0)
-#endif
-  STAMP();
-#if defined(VWGPU_EXP) && (VWGPU_EXP == 3 || VWGPU_EXP == 4 || VWGPU_EXP == 5)
-  {
-    bool dly = false;
-    if (VWGPU_EXP == 3) dly = (wg & 1) != 0;
-    if (VWGPU_EXP == 4) dly = ((wg >> 8) & 1) != 0;
-    if (VWGPU_EXP == 5) dly = ((wg >> 3) & 1) != 0;
-    if (!FIX && dly && wg < 512) {
-      const long long t0 = clock64();
-      while (clock64() - t0 < 40000) __builtin_amdgcn_s_sleep(32);
-    }
-  }
-#endif
   if (FIX) {
     if (need_fix[wg] == 0) return;                  // workgroup-uniform
   } else if (wg == 0 && tid == 0) {
@@ -263,7 +244,6 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   stage_u8_rows<NR>(L, ls, lw, lh, x0, y0, C::LBW, C::LBW, ent, tid, C::THREADS, bad_acc);
   stage_u8_rows<NR>(R, rs, rcw, rch, x0, y0, bpitch, bpitch, base, tid, C::THREADS, bad_acc);
   __syncthreads();
-  STAMP();
   u64 win[NR][NW];                                  // win[r][n] = bytes L[q+4n .. q+4n+7]
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -298,12 +278,10 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
     constexpr bool MAXSWEEP = FIX;
     for (int dy = 0; dy < sy; ++dy) {
       __syncthreads();                              // everyone is done with the previous base tile / windows
-      STAMP();
       if (dy > 0) stage_u8_rows<NR>(R, rs, rcw, rch, x0, y0 + dy, bpitch, bpitch, base, tid, C::THREADS, bad_acc);
       for (int t = 0; t < 4; ++t) {
         const int a_last = (sx + 2 - t) >> 2;       // last step with any valid slot
         __syncthreads();                            // base staged / previous phase's readers done
-        STAMP();
         {
           const int total = NR * ne;
           const float inv = 1.0f / (float)ne;
@@ -327,7 +305,6 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
           }
         }
         __syncthreads();
-        STAMP();
 
         // One step = one accumulator chain down the NR rows.  MASKED handles the range ends (some slots outside
         // [0,sx)); PAIR processes steps a and a+1 together so the WTA is one v_min3_u32 per pixel; PROBE adds the
@@ -445,9 +422,6 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
         if (a_hi > a_last + 1) a_hi = a_last + 1;
         if (a_lo > a_hi) a_lo = a_hi;
         int a = 0;
-#if defined(VWGPU_EXP) && VWGPU_EXP == 1
-        a = a_last + 1;   // experiment: no sweeps at all (staging + LDS builds + barriers + epilogue only)
-#endif
         for (; a < a_lo && a <= a_last; ++a) step(a, T{}, F{}, F{});
         if (!MAXSWEEP && dy == 0 && t == 0) {
           for (; a + 1 < a_hi && eq_checks < NPROBE; a += 2, ++eq_checks) step(a, F{}, T{}, T{});
@@ -471,8 +445,6 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
     return;
   }
   if (bad_acc != 0u) atomicOr(flag_set, 1);
-
-  STAMP();
   // ---- epilogue 1: decode keys, store {dx, dy, VALID} in the PixelMask<Vector2i> layout -------------------
 #pragma unroll
   for (int y = 0; y < TY; ++y) {
@@ -518,21 +490,6 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   }
   const int any = __syncthreads_or((cand_lo | cand_hi) != 0u);   // never set on textured imagery
   if (tid == 0) need_fix[wg] = any;
-  STAMP();
-#if defined(VWGPU_EXP) && VWGPU_EXP == 2
-  if (tid == 0 && wg == 0) {
-    printf("wg %d stamps:", wg);
-    for (int i = 1; i < nts_; ++i) printf(" %.1f", (double)(ts_[i] - ts_[0]) / 2400.0);
-    printf("\n");
-  }
-  if (tid == 0 && ((wg & 255) == 0 || (wg & 255) == 37)) {
-    const long long wc1_ = wall_clock64();
-    printf("wg %d start %.1f us end %.1f us (wall clock, 100 MHz); %lld shader ticks in %.1f us = %.2f GHz\n", wg,
-           (double)(wc0_ % 100000000ll) / 100.0, (double)(wc1_ % 100000000ll) / 100.0,
-           (long long)(clock64() - ts_[0]), (double)(wc1_ - wc0_) / 100.0,
-           (double)(clock64() - ts_[0]) / ((double)(wc1_ - wc0_) * 10.0));
-  }
-#endif
 }
 
 typedef void (*KernelFn)(const float*, ptrdiff_t, int, int, const float*, ptrdiff_t, int, int, int, int, int,
