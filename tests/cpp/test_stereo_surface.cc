@@ -3,6 +3,7 @@
 // src/vw/Stereo/tests/TestCorrelate.cxx:29-55, TestPyramidCorrelationView.cxx:47-170 (integer-shift scene),
 // TestSubPixel.cxx:93-140, TestDisparity.cxx:222-276, src/vw/Image/tests/TestFilter.cxx:45-141.
 // The CPU oracle (oracle/vw_oracle.h) is linked as the checker.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -325,6 +326,37 @@ static void test_sgm_constant_offset() {
                                   SemiGlobalMatcher::SUBPIXEL_LC_BLEND, Vector2i(4, 4), 1024, matcher_ptr), ArgumentErr);
 }
 
+// --- block_rasterize: the tile loop of tools/correlate (src/vw/tools/correlate.cc:207-266), 4 worker threads --------------
+static void test_block_rasterize() {
+  ImageView<PixelGray<float>> left, right;
+  pyramid_scene(left, right);
+  ImageView<uint8> lmask(300, 200), rmask(300, 200);
+  fill(lmask, uint8(255)); fill(rmask, uint8(255));
+  const BBox2i search_volume(Vector2i(-18, -7), Vector2i(18, 7));
+  PyramidCorrelationView view = pyramid_correlate(left, right, lmask, rmask, PREFILTER_NONE, 0.0f, search_volume, Vector2i(7, 7),
+                                                  ABSOLUTE_DIFFERENCE, 0, 0.0, 2, 0, 5, 5);
+  ImageView<PixelMask<Vector2f>> tiled = block_rasterize(view, Vector2i(128, 96), 4);
+  EXPECT_EQ(300, tiled.cols());
+  EXPECT_EQ(200, tiled.rows());
+  // every block must equal the oracle's prerasterize of the same block
+  ImageView<PixelMask<Vector2f>> want(300, 200);
+  for (int by = 0; by < 200; by += 96) for (int bx = 0; bx < 300; bx += 128) {
+    const int bw = std::min(128, 300 - bx), bh = std::min(96, 200 - by);
+    ImageView<PixelMask<Vector2f>> t(bw, bh);
+    EXPECT_EQ(0, vwo_pyramid_correlate(&left(0, 0).v(), 300, 200, &right(0, 0).v(), 300, 200, lmask.data(), rmask.data(), 0, 0.0f,
+                                       -18, -7, 18, 7, 7, 7, 0, 0, 0.0, 2.0f, 5, 5, bx, by, bw, bh, reinterpret_cast<float*>(t.data())));
+    for (int r = 0; r < bh; ++r) for (int c = 0; c < bw; ++c) want(bx + c, by + r) = t(c, r);
+  }
+  long bad = 0;
+  for (int r = 0; r < 200; ++r) for (int c = 0; c < 300; ++c)
+    if (!(tiled(c, r).child() == want(c, r).child()) || tiled(c, r).valid() != want(c, r).valid()) ++bad;
+  EXPECT_EQ(0, bad);
+  // errors raised inside a worker thread reach the caller
+  PyramidCorrelationView bad_view = pyramid_correlate(left, right, lmask, rmask, PREFILTER_NONE, 0.0f, search_volume, Vector2i(7, 7),
+                                                      ABSOLUTE_DIFFERENCE, 0, 0.0, 2, 0, 5, 5, VW_CORRELATION_MGM);
+  EXPECT_THROW((ImageView<PixelMask<Vector2f>>(block_rasterize(bad_view, Vector2i(128, 96), 3))), NoImplErr);
+}
+
 int main() {
   static_assert(sizeof(PixelMask<Vector2i>) == 12, "layout");
   EXPECT_TRUE(BBox2i(0, 0, 129, 0).empty() && BBox2i(0, 0, 129, 0).width() == 0);
@@ -346,6 +378,7 @@ int main() {
   test_filters();
   test_disparity_filters();
   test_sgm_constant_offset();
+  test_block_rasterize();
   std::printf("%d checks, %d failures\n", g_checks, g_fail);
   return g_fail ? 1 : 0;
 }

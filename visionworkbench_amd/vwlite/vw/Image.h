@@ -12,9 +12,13 @@
 #ifndef VWLITE_IMAGE_H
 #define VWLITE_IMAGE_H
 
+#include <atomic>
 #include <cmath>
+#include <exception>
 #include <limits>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -238,6 +242,74 @@ public:
   // Engine fast path: direct pointer when the handle wraps a plain ImageView (no copy).
   const PixelT* plain_data(int32& stride) const { return m_view->plain(stride); }
 };
+
+// block_rasterize(view, block_size, num_threads): rasterise the child view block by block from a pool of threads
+// (src/vw/Image/BlockRasterize.h:43-176 without the cache; block walk of src/vw/Image/BlockProcessor.h:63-176: blocks are
+// aligned to multiples of block_size counted from the image origin, cropped to the requested bbox, handed out in raster order).
+// Each worker calls child.rasterize(crop(dest, block - offset), block); with the engine's views every worker thread owns
+// its own GPU context, so several tiles are in flight on the device at once.
+template <class ImageT>
+class BlockRasterizeView : public ImageViewBase<BlockRasterizeView<ImageT>> {
+  std::shared_ptr<ImageT> m_child;
+  Vector2i m_block_size;
+  int32 m_num_threads;
+  static int32 round_down(int32 val, int32 mod) { return val + ((val >= 0) ? (-(val % mod)) : (((-val - 1) % mod) - mod + 1)); }
+public:
+  typedef typename ImageT::pixel_type pixel_type;
+  typedef pixel_type result_type;
+  typedef ImageView<pixel_type> prerasterize_type;
+  BlockRasterizeView(ImageT const& image, Vector2i const& block_size, int32 num_threads = 0)
+      : m_child(new ImageT(image)), m_block_size(block_size), m_num_threads(num_threads) {
+    if (m_block_size.x() <= 0 || m_block_size.y() <= 0) m_block_size = Vector2i(1024, 1024);
+    if (m_num_threads <= 0) {
+      const unsigned hc = std::thread::hardware_concurrency();
+      m_num_threads = (int32)(hc == 0 ? 1 : (hc > 8 ? 8 : hc));
+    }
+  }
+  int32 cols() const { return m_child->cols(); }
+  int32 rows() const { return m_child->rows(); }
+  int32 planes() const { return 1; }
+  ImageT const& child() const { return *m_child; }
+  result_type operator()(int32 x, int32 y) const { return (*m_child)(x, y); }
+  prerasterize_type prerasterize(BBox2i const& b) const { ImageView<pixel_type> o(b.width(), b.height()); rasterize(o, b); return o; }
+  template <class DestT> void rasterize(DestT const& dest, BBox2i const& bbox) const {
+    if (bbox.empty()) return;
+    const int32 bx0 = round_down(bbox.min().x(), m_block_size.x()), by0 = round_down(bbox.min().y(), m_block_size.y());
+    const int32 nbx = (bbox.max().x() - bx0 + m_block_size.x() - 1) / m_block_size.x();
+    const int32 nby = (bbox.max().y() - by0 + m_block_size.y() - 1) / m_block_size.y();
+    std::atomic<int32> next(0);
+    std::exception_ptr error;
+    std::mutex error_mutex;
+    auto worker = [&]() {
+      try {
+        for (;;) {
+          const int32 i = next.fetch_add(1);
+          if (i >= nbx * nby) return;
+          BBox2i block(bx0 + (i % nbx) * m_block_size.x(), by0 + (i / nbx) * m_block_size.y(), m_block_size.x(), m_block_size.y());
+          block.crop(bbox);
+          if (block.empty()) continue;
+          m_child->rasterize(crop(dest, block - bbox.min()), block);
+        }
+      } catch (...) {
+        std::lock_guard<std::mutex> lock(error_mutex);
+        if (!error) error = std::current_exception();
+        next.store(nbx * nby);
+      }
+    };
+    const int32 nt = std::min<int32>(m_num_threads, nbx * nby);
+    if (nt <= 1) worker();
+    else {
+      std::vector<std::thread> pool;
+      for (int32 t = 0; t < nt; ++t) pool.emplace_back(worker);
+      for (std::thread& t : pool) t.join();
+    }
+    if (error) std::rethrow_exception(error);
+  }
+};
+template <class ImageT>
+BlockRasterizeView<ImageT> block_rasterize(ImageViewBase<ImageT> const& image, Vector2i const& block_size, int32 num_threads = 0) {
+  return BlockRasterizeView<ImageT>(image.impl(), block_size, num_threads);
+}
 
 template <class ViewT, class ValT> void fill(ImageViewBase<ViewT> const& v, ValT const& val) {
   for (int32 r = 0; r < v.impl().rows(); ++r)
