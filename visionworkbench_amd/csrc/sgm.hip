@@ -246,6 +246,29 @@ __global__ void cost_kernel(const uint64_t* __restrict__ lc, int lcw, const uint
   }
 }
 
+// Uniform layout (every pixel searches the full range, vectors `stride` apart): one thread per 4 consecutive disparities,
+// one dword store; consecutive threads read consecutive census words of the right image.
+__global__ void cost_uniform_kernel(const uint64_t* __restrict__ lc, int lcw, const uint64_t* __restrict__ rc, int rcw,
+                                    int ocols, int orows, int num_dx, int num_disp, int stride, int off_c, int off_r,
+                                    uint32_t* __restrict__ cost32) {
+  const int q = stride / 4;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (t >= ocols * q) return;
+  const int c = t / q, w = t - c * q;
+  const int bc = c + off_c, br = r + off_r;
+  const uint64_t lv = lc[(size_t)br * lcw + bc];
+  uint32_t v = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = 4 * w + e;
+    if (i < num_disp) {
+      const int qy = i / num_dx, qx = i - qy * num_dx;
+      v |= (uint32_t)__popcll(lv ^ rc[(size_t)(br + qy) * rcw + bc + qx]) << (8 * e);
+    }
+  }
+  cost32[((size_t)r * ocols + c) * q + w] = v;
+}
+
 // ---- path aggregation -------------------------------------------------------------------------------------------------
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the global
@@ -526,11 +549,10 @@ wta_kernel(const B4* __restrict__ bounds, const unsigned long long* __restrict__
   uint16_t* av = accum + starts[p];
   unsigned key = 0xffffffffu;
   for (int i = lane; i < n; i += 64) { const unsigned v = av[i]; A[i] = (uint16_t)v; key = min(key, (v << 16) | (unsigned)i); }
-  for (int s = 32; s > 0; s >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, s));
+  key = wave_min_u32(key);
   unsigned min_val = key >> 16;
   int cnt = 0;
-  for (int i = lane; i < n; i += 64) cnt += (A[i] == min_val);
-  for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s);
+  for (int i0 = 0; i0 < n; i0 += 64) cnt += __popcll(__ballot(i0 + lane < n && A[i0 + lane] == min_val));   // every lane holds the total
   // NB: the reference starts min_val at 65535 and counts `==` before `<`, so an all-65535 vector counts every element
   int iter = 0;
   uint16_t* in = A; uint16_t* out = Bf;
@@ -554,12 +576,10 @@ wta_kernel(const B4* __restrict__ bounds, const unsigned long long* __restrict__
       out[i] = (uint16_t)v;
       k2 = min(k2, (v << 16) | (unsigned)i);
     }
-    for (int s = 32; s > 0; s >>= 1) k2 = min(k2, (unsigned)__shfl_xor((int)k2, s));
-    key = k2; min_val = key >> 16;
+    key = wave_min_u32(k2); min_val = key >> 16;
     __builtin_amdgcn_wave_barrier();
     cnt = 0;
-    for (int i = lane; i < n; i += 64) cnt += (out[i] == min_val);
-    for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s);
+    for (int i0 = 0; i0 < n; i0 += 64) cnt += __popcll(__ballot(i0 + lane < n && out[i0 + lane] == min_val));
     uint16_t* t = in; in = out; out = t;
     ++iter;
     if (iter >= 6) break;
@@ -803,8 +823,12 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   VWGPU_HIP(ctx, hipMemsetAsync(accum, 0, (size_t)main_buf * 2, st));
   {
     vwgpu_prof_scope ps(ctx, "sgm_cost");
-    hipLaunchKernelGGL(cost_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, st, lc, lcw, rcen, rcw, bounds, starts, g.ocols, npix,
-                       min_col - hk, min_row - hk, cost);
+    if (uniform)
+      hipLaunchKernelGGL(cost_uniform_kernel, dim3((unsigned)((g.ocols * (ustride / 4) + 255) / 256), g.orows), dim3(256), 0, st, lc, lcw, rcen, rcw,
+                         g.ocols, g.orows, g.num_dx, (int)num_disp, ustride, min_col - hk, min_row - hk, reinterpret_cast<uint32_t*>(cost));
+    else
+      hipLaunchKernelGGL(cost_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, st, lc, lcw, rcen, rcw, bounds, starts, g.ocols, npix,
+                         min_col - hk, min_row - hk, cost);
   }
   // 8 directions, in the reference's order (SGM.cc:2488-2610)
   {
