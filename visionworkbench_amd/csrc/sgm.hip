@@ -524,6 +524,128 @@ path_uniform_kernel(SgmGeom g, DirSet D, int K, int stride,
   }
 }
 
+// +-N x 1 searches on the packed 16-bit ALU: a lane owns PAIRS of neighbouring disparities (d_2j, d_2j+1) in one dword and the
+// whole recurrence runs on v_pk_{min,add,sub}_u16 with clamping (= the reference's saturating SSE ops, SGM.cc:936-984).
+// The left / right neighbour pairs come from the adjacent dwords through v_alignbit; because the 1-D adjacency already
+// contains the centre, the clamped neighbours at both ends of the range are represented by 0xffff guards (they never win).
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 as_us2(unsigned v) { return __builtin_bit_cast(us2, v); }
+__device__ __forceinline__ unsigned as_u32(us2 v) { return __builtin_bit_cast(unsigned, v); }
+
+template <int EPT>      // pair slots per lane: ceil(ceil(num_disp / 2) / 64)
+__global__ void __launch_bounds__(64)
+path_uniform_pk_kernel(SgmGeom g, DirSet D, int K, int stride,
+                       const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
+                       const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2) {
+  extern __shared__ uint16_t sm[];
+  const int num_disp = g.num_dx;                                                     // num_dy == 1
+  const int npairs = (num_disp + 1) / 2;
+  unsigned* buf = reinterpret_cast<unsigned*>(sm) + 1;                               // [-1 .. EPT*64]: guards at both ends
+  uint16_t* p2tab = sm + 2 * (EPT * 64 + 2);                                         // 256
+  unsigned* cacc = reinterpret_cast<unsigned*>(p2tab + 256 + 4);                     // K x stride/2 dwords, 16-byte aligned
+  uint8_t* ccost = reinterpret_cast<uint8_t*>(cacc + (size_t)K * (stride / 2));      // K x stride
+  uint8_t* pix = ccost + (size_t)K * stride;
+  const int tid = threadIdx.x;
+  int c0, r0, dc, dr;
+  line_start(D, g, blockIdx.x, dc, dr, c0, r0);
+  const int len_c = dc > 0 ? g.ocols - c0 : (dc < 0 ? c0 + 1 : 0x7fffffff);
+  const int len_r = dr > 0 ? g.orows - r0 : (dr < 0 ? r0 + 1 : 0x7fffffff);
+  const int len = min(len_c, len_r);
+  for (int q = tid; q < 256; q += 64) {
+    unsigned v = p2;
+    if (q > 0) v /= (unsigned)q;
+    if (v < p1) v = p1;
+    p2tab[q] = (uint16_t)v;
+  }
+  for (int i = tid - 1; i <= EPT * 64; i += 64) buf[i] = 0xffffffffu;               // guards + dead slots
+  bool live[EPT];
+  unsigned dead[EPT];                                                                // 0xffff0000 for the pair with a dead high half
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int j = tid + e * 64;
+    live[e] = j < npairs;
+    dead[e] = (2 * j + 1 >= num_disp) ? 0xffff0000u : 0u;
+  }
+  const us2 p1p1 = as_us2(p1 | (p1 << 16));
+  const int q_cost = stride / 16;
+  const unsigned m_cost = (unsigned)((0x100000000ull + q_cost - 1) / q_cost);
+  const long long delta = (long long)dr * g.ocols + dc;
+  const long long d_cost = (delta - 1) * q_cost;
+  const int q32 = stride / 2;
+  const unsigned m32 = (unsigned)((0x100000000ull + q32 - 1) / q32);
+  int last_val = -1;
+  unsigned min_prior = 0;
+  for (int base = 0; base < len; base += K) {
+    const int kk = min(K, len - base);
+    const long long pbase = (long long)(r0 + base * dr) * g.ocols + (c0 + base * dc);
+    {
+      const uint4* gc = reinterpret_cast<const uint4*>(cost);
+      uint4* lc = reinterpret_cast<uint4*>(ccost);
+      for (int j = tid; j < kk * q_cost; j += 64) {
+        const int k = q_cost == 1 ? j : (int)__umulhi((unsigned)j, m_cost);
+        lc[j] = gc[pbase * q_cost + j + (long long)k * d_cost];
+      }
+    }
+    if (tid < kk) pix[tid] = left[(size_t)(r0 + (base + tid) * dr + min_row) * lw + (c0 + (base + tid) * dc + min_col)];
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < kk; ++k) {
+      const int vcur = pix[k];
+      const uint16_t* cc = reinterpret_cast<const uint16_t*>(ccost + k * stride);
+      unsigned* ac = cacc + k * (stride / 2);
+      unsigned res[EPT];
+      if (last_val < 0) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const unsigned cb = live[e] ? (unsigned)cc[tid + e * 64] : 0u;
+          res[e] = ((cb & 0xffu) | ((cb & 0xff00u) << 8)) | dead[e];
+        }
+      } else {
+        int grad = vcur - last_val; grad = grad < 0 ? -grad : grad;
+        const unsigned dj = (min_prior + (unsigned)p2tab[grad]) & 0xffffu;
+        const us2 dJ = as_us2(dj | (dj << 16)), mp = as_us2(min_prior | (min_prior << 16));
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const int j = tid + e * 64;
+          const unsigned pm = buf[j - 1], pc = buf[j], pn = buf[j + 1];
+          const us2 ln = as_us2(__builtin_amdgcn_alignbit(pc, pm, 16));              // (d_2j-1, d_2j)
+          const us2 rn = as_us2(__builtin_amdgcn_alignbit(pn, pc, 16));              // (d_2j+1, d_2j+2)
+          const us2 ctr = as_us2(pc);
+          us2 m = __builtin_elementwise_min(__builtin_elementwise_min(ln, rn), ctr);
+          us2 v = __builtin_elementwise_add_sat(m, p1p1);
+          v = __builtin_elementwise_min(v, __builtin_elementwise_min(ctr, dJ));
+          const unsigned cb = live[e] ? (unsigned)cc[j] : 0u;
+          v = __builtin_elementwise_add_sat(v, as_us2((cb & 0xffu) | ((cb & 0xff00u) << 8)));
+          v = __builtin_elementwise_sub_sat(v, mp);
+          res[e] = as_u32(v) | dead[e];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();                                               // all neighbour reads before the in-place writes
+      us2 mn2 = as_us2(0xffffffffu);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int j = tid + e * 64;
+        if (live[e]) { buf[j] = res[e]; ac[j] = res[e]; mn2 = __builtin_elementwise_min(mn2, as_us2(res[e])); }
+      }
+      const unsigned mnu = as_u32(mn2);
+      min_prior = wave_min_u32(min(mnu & 0xffffu, mnu >> 16));
+      __builtin_amdgcn_wave_barrier();
+      last_val = vcur;
+    }
+    {                                                           // bulk add: one 32-bit atomic per pair of path costs
+      unsigned* ga = reinterpret_cast<unsigned*>(accum);
+      for (int j = tid; j < kk * q32; j += 64) {
+        const int k = (int)__umulhi((unsigned)j, m32), w = j - k * q32;
+        if (w < npairs) {
+          unsigned v = cacc[j];
+          if (2 * w + 1 >= num_disp) v &= 0xffffu;
+          atomicAdd(ga + pbase * q32 + j + (long long)k * (delta - 1) * q32, v);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // starts of the uniform layout: pixel p's vectors begin at p * stride
 __global__ void uniform_starts_kernel(unsigned long long* __restrict__ starts, size_t npix, unsigned long long stride) {
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -858,7 +980,14 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       D.line0[D.n] = lines;
       if (lines <= 0) continue;
       vwgpu_prof_scope ps(ctx, together ? "sgm_paths" : "sgm_path");
-      if (uniform) {
+      if (uniform && one_d && num_disp <= 256) {
+        const int pe = (int)(((num_disp + 1) / 2 + 63) / 64);
+        const size_t plds = (size_t)(pe * 64 + 2) * 4 + 256 * 2 + 8 + (size_t)K * ustride * 3 + K + 16;
+        if (pe == 1) hipLaunchKernelGGL(path_uniform_pk_kernel<1>, dim3(lines), dim3(64), plds, st, g, D, K, ustride, l8, lw, min_col, min_row,
+                                        cost, accum, (unsigned)p1, (unsigned)p2);
+        else hipLaunchKernelGGL(path_uniform_pk_kernel<2>, dim3(lines), dim3(64), plds, st, g, D, K, ustride, l8, lw, min_col, min_row,
+                                cost, accum, (unsigned)p1, (unsigned)p2);
+      } else if (uniform) {
 #define VWGPU_PATH_U(E) do { if (one_d) hipLaunchKernelGGL((path_uniform_kernel<E, true>), dim3(lines), dim3(64), ulds, st, g, D, K, ustride, \
                                l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2); \
                              else hipLaunchKernelGGL((path_uniform_kernel<E, false>), dim3(lines), dim3(64), ulds, st, g, D, K, ustride, \
