@@ -135,6 +135,16 @@ int vwgpu_cross_corr_consistency_check(vwgpu_ctx* ctx,
                                        const int32_t* r2l, int rw, int rh, ptrdiff_t rstride,
                                        float threshold);
 
+/* The same with the reference's optional lr_disp_diff output (Correlate.cc:1441-1502): diff is a PixelMask<float> image
+ * {value, valid} of dcols x drows (stride in pixels, 0 = dcols); every KEPT pixel (c, r) writes {max(|dx+dx'|, |dy+dy'|), 1}
+ * at (c + ulx, r + uly), which must lie inside the image. */
+int vwgpu_cross_corr_consistency_check_diff_dev(vwgpu_ctx* ctx, int32_t* d_l2r, int lw, int lh, ptrdiff_t lstride,
+                                                const int32_t* d_r2l, int rw, int rh, ptrdiff_t rstride, float cross_corr_threshold,
+                                                float* d_diff, int dcols, int drows, ptrdiff_t dstride, int ulx, int uly);
+int vwgpu_cross_corr_consistency_check_diff(vwgpu_ctx* ctx, int32_t* l2r, int lw, int lh, ptrdiff_t lstride,
+                                            const int32_t* r2l, int rw, int rh, ptrdiff_t rstride, float cross_corr_threshold,
+                                            float* diff, int dcols, int drows, ptrdiff_t dstride, int ulx, int uly);
+
 /* ---- image filters on the path: Gaussian pyramid and prefilters ------------------------------------- */
 
 /* vw::ConstantEdgeExtension / vw::ZeroEdgeExtension (src/vw/Image/EdgeExtension.h). */
@@ -258,6 +268,14 @@ typedef struct vwgpu_pyramid_params {
   int sgm_search_buffer_x, sgm_search_buffer_y;   /* default (2,2) */
   size_t memory_limit_mb;        /* default 6000 */
   int sgm_num_threads;           /* enters the memory-cap formula only; 0 = 1 */
+  /* Optional L-R / R-L discrepancy output of the level-0 consistency check (m_lr_disp_diff, m_region_ul,
+   * CorrelationView.h:84; cross_corr_consistency_check, Correlate.cc:1441-1502): PixelMask<float> = {value, valid} per pixel,
+   * lr_disp_diff_cols x _rows, covering image pixels starting at (region_ul_x, region_ul_y); stride in pixels (0 = cols).
+   * Device pointer for the _dev entry point, host pointer for the host one; NULL = off.  Only kept pixels are written. */
+  float* lr_disp_diff;
+  int lr_disp_diff_cols, lr_disp_diff_rows;
+  ptrdiff_t lr_disp_diff_stride;
+  int region_ul_x, region_ul_y;
 } vwgpu_pyramid_params;
 
 /* Replaces PyramidCorrelationView::prerasterize(bbox) for VW_CORRELATION_BM (src/vw/Stereo/CorrelationView.cc:273-886):

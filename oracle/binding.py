@@ -21,7 +21,7 @@ __all__ = ["build", "lib", "fast_box_sum", "cost_image", "calc_disparity", "calc
            "EDGE_CONSTANT", "EDGE_ZERO", "PREFILTER_NONE", "PREFILTER_MEANSUB", "PREFILTER_LOG",
            "subdivide_regions", "prefilter_region", "parabola_subpixel", "pyramid_correlate", "disparity_filter",
            "disparity_mask", "u8_convert", "census_transform", "hamming_distance", "SemiGlobalMatcher", "calc_disparity_sgm",
-           "pyramid_correlate_sgm", "blob_sizes", "disparity_blob_filter", "set_blob_filter_area", "CENSUS_TRANSFORM", "TERNARY_CENSUS_TRANSFORM", "SUBPIXEL_NONE", "SUBPIXEL_PARABOLA", "SUBPIXEL_LINEAR",
+           "pyramid_correlate_sgm", "blob_sizes", "disparity_blob_filter", "set_blob_filter_area", "cross_corr_consistency_check_diff", "set_lr_disp_diff", "CENSUS_TRANSFORM", "TERNARY_CENSUS_TRANSFORM", "SUBPIXEL_NONE", "SUBPIXEL_PARABOLA", "SUBPIXEL_LINEAR",
            "SUBPIXEL_POLY4", "SUBPIXEL_COSINE", "SUBPIXEL_LC_BLEND"]
 
 
@@ -64,6 +64,9 @@ def lib():
         _LIB.vwo_disparity_blob_filter.argtypes = [P, I, I, I]
         _LIB.vwo_set_blob_filter_area.argtypes = [I]
         _LIB.vwo_set_blob_filter_area.restype = None
+        _LIB.vwo_cross_corr_consistency_check_diff.argtypes = [P, I, I, P, I, I, F, P, I, I, I, I]
+        _LIB.vwo_set_lr_disp_diff.argtypes = [P, I, I, I, I]
+        _LIB.vwo_set_lr_disp_diff.restype = None
         _LIB.vwo_u8_convert.argtypes = [P, I, I, P]
         _LIB.vwo_census_transform.argtypes = [P, I, I, I, I, I, P]
         _LIB.vwo_hamming_distance.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
@@ -438,3 +441,23 @@ def disparity_blob_filter(disp, area):
 def set_blob_filter_area(area):
     """blob_filter_area used by the following pyramid_correlate / pyramid_correlate_sgm calls of this thread."""
     lib().vwo_set_blob_filter_area(int(area))
+
+
+def cross_corr_consistency_check_diff(l2r, r2l, thr, diff, ul=(0, 0)):
+    """In place on l2r and diff ((rows, cols, 2) float32 PixelMask<float>)."""
+    assert l2r.flags.c_contiguous and l2r.dtype == np.int32 and diff.flags.c_contiguous and diff.dtype == np.float32
+    r = np.ascontiguousarray(r2l, np.int32)
+    rc = lib().vwo_cross_corr_consistency_check_diff(_p(l2r), l2r.shape[1], l2r.shape[0], _p(r), r.shape[1], r.shape[0], float(thr),
+                                                     _p(diff), diff.shape[1], diff.shape[0], int(ul[0]), int(ul[1]))
+    if rc:
+        raise ValueError("lr_disp_diff does not contain the checked region")
+    return l2r
+
+
+def set_lr_disp_diff(diff, region_ul=(0, 0)):
+    """lr_disp_diff buffer ((rows, cols, 2) float32, None = off) of the following pyramid calls of this thread."""
+    if diff is None:
+        lib().vwo_set_lr_disp_diff(None, 0, 0, 0, 0)
+    else:
+        assert diff.flags.c_contiguous and diff.dtype == np.float32 and diff.shape[2] == 2
+        lib().vwo_set_lr_disp_diff(_p(diff), diff.shape[1], diff.shape[0], int(region_ul[0]), int(region_ul[1]))

@@ -251,6 +251,32 @@ int vwo_cross_corr_consistency_check(int32_t* l2r, int lw, int lh,
   return 0;
 }
 
+// The same with the optional lr_disp_diff image (:1480-1484): PixelMask<float> = {value, valid} per pixel, written for the
+// kept pixels only, at (c + ulx, r + uly).
+int vwo_cross_corr_consistency_check_diff(int32_t* l2r, int lw, int lh, const int32_t* r2l, int rw, int rh, float thr,
+                                          float* diff2, int dcols, int drows, int ulx, int uly) {
+  for (int r = 0; r < lh; ++r) {
+    for (int c = 0; c < lw; ++c) {
+      int32_t* p = l2r + ((int64_t)r * lw + c) * 3;
+      const int x = c + p[0], y = r + p[1];
+      if (x < 0 || x >= rw || y < 0 || y >= rh) { p[2] = 0; continue; }
+      const int32_t* q = r2l + ((int64_t)y * rw + x) * 3;
+      if (!p[2] || !q[2]) { p[2] = 0; continue; }
+      float diff = (float)std::max(std::fabs((double)(p[0] + q[0])), std::fabs((double)(p[1] + q[1])));
+      if (thr >= diff) {
+        if (diff2) {
+          const int dx = c + ulx, dy = r + uly;
+          if (dx < 0 || dy < 0 || dx >= dcols || dy >= drows) return -1;
+          diff2[((size_t)dy * dcols + dx) * 2] = diff; diff2[((size_t)dy * dcols + dx) * 2 + 1] = 1.0f;
+        }
+      } else {
+        p[2] = 0;
+      }
+    }
+  }
+  return 0;
+}
+
 }  // extern "C"
 
 // ---- image filters on the path ---------------------------------------------------------------------------
@@ -858,6 +884,9 @@ int vwo_disparity_blob_filter(int32_t* disp3, int w, int h, int area) {
 }  // extern "C" (reopened below)
 
 static thread_local int g_blob_filter_area = 0;
+// lr_disp_diff of the NEXT pyramid call on this thread (CorrelationView.h:84: m_lr_disp_diff, m_region_ul)
+static thread_local float* g_lr_diff = nullptr;
+static thread_local int g_lr_cols = 0, g_lr_rows = 0, g_lr_ulx = 0, g_lr_uly = 0;
 
 // algorithm 0 = VW_CORRELATION_BM, 1 = VW_CORRELATION_SGM (MGM variants are not restated)
 static int pyramid_impl(const float* left, int lw, int lh, const float* right, int rw, int rh,
@@ -872,6 +901,10 @@ static int pyramid_impl(const float* left, int lw, int lh, const float* right, i
   if (kx % 2 != 1 || ky % 2 != 1 || bw <= 0 || bh <= 0) return -1;
   const bool use_sgm = algorithm != 0;
   if (use_sgm) prefilter_mode = VWO_PREFILTER_NONE;                      // CorrelationView.h:96-97
+  float* lr_diff = g_lr_diff;
+  if (lr_diff) {                                                         // the tile must fit the buffer (CorrelationView.cc:277-283)
+    if (bx < g_lr_ulx || by < g_lr_uly || bx + bw > g_lr_ulx + g_lr_cols || by + bh > g_lr_uly + g_lr_rows) return -4;
+  }
   std::vector<int32_t> prev_disparity, disparity_rl, prev_disparity_rl;
   int pdw = 0, pdh = 0, rlw_ = 0, rlh_ = 0, prlw = 0, prlh = 0;
   std::vector<float> subpixel_disparity;
@@ -997,7 +1030,11 @@ static int pyramid_impl(const float* left, int lw, int lh, const float* right, i
         if (rc_) return rc_;
         rl.resize((size_t)row * roh * 3);
         for (size_t i = 0; i < (size_t)row * roh; ++i) { rl[3*i] -= sx; rl[3*i+1] -= sy; }
-        vwo_cross_corr_consistency_check(disparity.data(), dw, dh, rl.data(), row, roh, consistency_threshold);
+        if (level == 0 && lr_diff)                                       // ul_corner_offset = zone.min (0,0) + bbox.min - region_ul
+          vwo_cross_corr_consistency_check_diff(disparity.data(), dw, dh, rl.data(), row, roh, consistency_threshold,
+                                                lr_diff, g_lr_cols, g_lr_rows, bx - g_lr_ulx, by - g_lr_uly);
+        else
+          vwo_cross_corr_consistency_check(disparity.data(), dw, dh, rl.data(), row, roh, consistency_threshold);
         for (size_t i = 0; i < (size_t)row * roh; ++i) { rl[3*i] += sx; rl[3*i+1] += sy; }
         disparity_rl.swap(rl); rlw_ = row; rlh_ = roh;
       }
@@ -1029,7 +1066,11 @@ static int pyramid_impl(const float* left, int lw, int lh, const float* right, i
         if (best_of_search(cost_type, a.data(), rr.sizex(), rr.sizey(), rr.sizex(), b.data(), l2g.sizex(), l2g.sizey(), l2g.sizex(),
                            kx, ky, sx, sy, rl.data())) return -1;
         for (size_t i = 0; i < (size_t)rlw * rlh; ++i) { rl[3*i] -= sx; rl[3*i+1] -= sy; }   // - pixel_typeI(range.size())
-        vwo_cross_corr_consistency_check(zd.data(), zw, zh, rl.data(), rlw, rlh, consistency_threshold);
+        if (lr_diff)
+          vwo_cross_corr_consistency_check_diff(zd.data(), zw, zh, rl.data(), rlw, rlh, consistency_threshold, lr_diff, g_lr_cols, g_lr_rows,
+                                                zone.region.minx + bx - g_lr_ulx, zone.region.miny + by - g_lr_uly);
+        else
+          vwo_cross_corr_consistency_check(zd.data(), zw, zh, rl.data(), rlw, rlh, consistency_threshold);
       }
       for (int y = 0; y < zh; ++y) for (int x = 0; x < zw; ++x) {         // crop(disparity, region) = ...; += range.min()
         const int32_t* s3 = &zd[((size_t)y * zw + x) * 3];
@@ -1073,6 +1114,10 @@ static int pyramid_impl(const float* left, int lw, int lh, const float* right, i
     }
   }
   if (dw != bw || dh != bh) return -2;
+  if (lr_diff)                                                           // filtered pixels lose their discrepancy too (:846-855)
+    for (int r = 0; r < bh; ++r) for (int c = 0; c < bw; ++c)
+      if (!disparity[((size_t)r * bw + c) * 3 + 2])
+        lr_diff[((size_t)(r + by - g_lr_uly) * g_lr_cols + (c + bx - g_lr_ulx)) * 2 + 1] = 0.0f;
   if (use_sgm) {                                                         // (:862-875) sub-pixel view, filtered pixels invalidated
     for (size_t i = 0; i < (size_t)bw * bh; ++i) {
       out3f[3*i] = subpixel_disparity[3*i] + (float)search.minx;
@@ -1117,5 +1162,7 @@ int vwo_pyramid_correlate_sgm(const float* left, int lw, int lh, const float* ri
 
 // blob_filter_area of the NEXT vwo_pyramid_correlate / _sgm call on this thread (keeps the long signatures stable)
 void vwo_set_blob_filter_area(int area) { g_blob_filter_area = area; }
+// lr_disp_diff (cols x rows x {value, valid} float, NULL = off) and region_ul of the following pyramid calls of this thread
+void vwo_set_lr_disp_diff(float* buf, int cols, int rows, int ulx, int uly) { g_lr_diff = buf; g_lr_cols = cols; g_lr_rows = rows; g_lr_ulx = ulx; g_lr_uly = uly; }
 
 }  // extern "C"

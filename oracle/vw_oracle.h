@@ -143,6 +143,11 @@ int vwo_pyramid_correlate_sgm(const float* left, int lw, int lh, const float* ri
 int vwo_blob_sizes(const int32_t* disp3, int w, int h, uint32_t* sizes);
 int vwo_disparity_blob_filter(int32_t* disp3, int w, int h, int area);
 void vwo_set_blob_filter_area(int area);
+/* cross_corr_consistency_check with the optional lr_disp_diff output (Correlate.cc:1441-1502) and the pyramid's
+ * m_lr_disp_diff / m_region_ul (CorrelationView.h:84; set for the following pyramid calls of the calling thread). */
+int vwo_cross_corr_consistency_check_diff(int32_t* l2r, int lw, int lh, const int32_t* r2l, int rw, int rh, float thr,
+                                          float* diff2, int dcols, int drows, int ulx, int uly);
+void vwo_set_lr_disp_diff(float* buf, int cols, int rows, int ulx, int uly);
 
 /* rm_outliers_using_thresh / disparity_cleanup_using_thresh / disparity_mask on whole images
  * (src/vw/Stereo/DisparityMap.h:318-441, 97-253); disp3 in place.  cleanup != 0 adds the second (1,1,3.0,0.20) pass. */

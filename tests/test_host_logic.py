@@ -52,8 +52,10 @@ def test_struct_layouts_match_the_header():
     assert names == ["prefilter_mode", "prefilter_width", "search_min_x", "search_min_y", "search_max_x", "search_max_y", "kernel_x",
                      "kernel_y", "cost_type", "corr_timeout", "seconds_per_op", "consistency_threshold", "min_consistency_level",
                      "filter_half_kernel", "max_pyramid_levels", "algorithm", "blob_filter_area", "sgm_subpixel_mode",
-                     "sgm_search_buffer_x", "sgm_search_buffer_y", "memory_limit_mb", "sgm_num_threads"]
+                     "sgm_search_buffer_x", "sgm_search_buffer_y", "memory_limit_mb", "sgm_num_threads", "lr_disp_diff",
+                     "lr_disp_diff_cols", "lr_disp_diff_rows", "lr_disp_diff_stride", "region_ul_x", "region_ul_y"]
     assert P.seconds_per_op.offset % 8 == 0 and P.memory_limit_mb.offset % 8 == 0 and ctypes.sizeof(P) % 8 == 0
+    assert P.lr_disp_diff.offset % 8 == 0 and P.lr_disp_diff_stride.offset % 8 == 0
     S = _lib.SgmParams
     assert [f[0] for f in S._fields_] == ["cost_type", "use_mgm", "kernel_size", "subpixel_mode", "search_buffer_x", "search_buffer_y",
                                           "memory_limit_mb", "p1", "p2", "ternary_census_threshold", "num_threads"]
@@ -65,7 +67,8 @@ def test_struct_layouts_match_the_header():
     pos = [body.index(n) for n in ["prefilter_mode", "prefilter_width", "search_min_x", "kernel_x", "cost_type", "corr_timeout",
                                    "seconds_per_op", "consistency_threshold", "min_consistency_level", "filter_half_kernel",
                                    "max_pyramid_levels", "algorithm", "blob_filter_area", "sgm_subpixel_mode", "sgm_search_buffer_x",
-                                   "memory_limit_mb", "sgm_num_threads"]]
+                                   "memory_limit_mb", "sgm_num_threads", "float* lr_disp_diff;", "int lr_disp_diff_cols",
+                                   "ptrdiff_t lr_disp_diff_stride", "int region_ul_x"]]
     assert pos == sorted(pos)
 
 

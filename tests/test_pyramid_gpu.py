@@ -179,3 +179,58 @@ def test_pyramid_with_blob_filter(vw, oracle, algorithm):
     g0 = vw.pyramid_correlate(left, right, None, None, 0, 0.0, box, (7, 7) if algorithm == 0 else (5, 5), 0 if algorithm == 0 else 3,
                               consistency_threshold=2, filter_half_kernel=3, max_pyramid_levels=3, algorithm=algorithm)
     assert (g0[..., 2] != 0).sum() >= (g[..., 2] != 0).sum()
+
+
+def test_cross_corr_consistency_check_with_diff(vw, oracle):
+    """cross_corr_consistency_check's optional lr_disp_diff output (Correlate.cc:1441-1502)."""
+    rng = np.random.default_rng(31)
+    V = np.iinfo(np.int32).max
+    l2r = np.zeros((40, 60, 3), np.int32)
+    l2r[..., 0] = rng.integers(0, 6, (40, 60)); l2r[..., 1] = rng.integers(0, 3, (40, 60))
+    l2r[..., 2] = np.where(rng.random((40, 60)) < 0.2, 0, V)
+    r2l = np.zeros((44, 68, 3), np.int32)
+    r2l[..., 0] = -rng.integers(0, 6, (44, 68)); r2l[..., 1] = -rng.integers(0, 3, (44, 68))
+    r2l[..., 2] = np.where(rng.random((44, 68)) < 0.2, 0, V)
+    for thr in (0, 1, 2):
+        a, b = l2r.copy(), l2r.copy()
+        da = np.full((50, 70, 2), -7.0, np.float32); db = da.copy()
+        vw.cross_corr_consistency_check(a, r2l, thr, lr_disp_diff=da, ul_corner_offset=(5, 3))
+        oracle.cross_corr_consistency_check_diff(b, r2l, thr, db, (5, 3))
+        assert np.array_equal(a, b) and np.array_equal(da, db)
+        kept = a[..., 2] != 0
+        assert (da[3:43, 5:65, 1][kept] == 1.0).all() and (da[3:43, 5:65, 0][kept] <= thr).all()
+        assert (da[3:43, 5:65][~kept] == -7.0).all()                      # untouched where the pixel was rejected
+    from visionworkbench_amd.core import ArgumentErr
+    with pytest.raises(ArgumentErr):
+        vw.cross_corr_consistency_check(l2r.copy(), r2l, 1, lr_disp_diff=np.zeros((30, 70, 2), np.float32))
+
+
+@pytest.mark.parametrize("algorithm", [0, 1])
+def test_pyramid_lr_disp_diff(vw, oracle, algorithm):
+    from visionworkbench_amd.core import BBox2i, ArgumentErr
+    left, right, scale, trans, search = scenes.pyramid_scene("u8")
+    box = BBox2i.from_corners(search[:2], search[2:])
+    bb = (40, 24, 200, 150)
+    dg = np.zeros((170, 230, 2), np.float32)          # covers image pixels [30, 260) x [20, 190)
+    do = dg.copy()
+    oracle.set_lr_disp_diff(do, (30, 20))
+    try:
+        if algorithm == 0:
+            g = vw.pyramid_correlate(left, right, None, None, 0, 0.0, box, (7, 7), 0, consistency_threshold=2, filter_half_kernel=3,
+                                     max_pyramid_levels=3, bbox=BBox2i(*bb), lr_disp_diff=dg, region_ul=(30, 20))
+            o = oracle.pyramid_correlate(left, right, None, None, 0, 0.0, search, (7, 7), 0, 0, 0.0, 2, 3, 3, bbox=bb)
+            assert np.array_equal(g, o)
+        else:
+            g = vw.pyramid_correlate(left, right, None, None, 0, 0.0, box, (5, 5), 3, consistency_threshold=2, filter_half_kernel=3,
+                                     max_pyramid_levels=3, algorithm=1, bbox=BBox2i(*bb), lr_disp_diff=dg, region_ul=(30, 20))
+            o = oracle.pyramid_correlate_sgm(left, right, None, None, search, 5, 3, 2, 0, 3, 3, bbox=bb)
+            assert np.array_equal(g[..., 2], o[..., 2])
+    finally:
+        oracle.set_lr_disp_diff(None)
+    assert np.array_equal(dg, do)
+    inside = dg[4:154, 10:210]
+    assert (inside[..., 1] == (g[..., 2] != 0)).all() and (inside[..., 0][g[..., 2] != 0] <= 2).all()
+    assert not dg[:4].any() and not dg[:, :10].any()                      # nothing outside the tile was touched
+    with pytest.raises(ArgumentErr):
+        vw.pyramid_correlate(left, right, None, None, 0, 0.0, box, (7, 7), 0, consistency_threshold=2, bbox=BBox2i(0, 0, 100, 100),
+                             lr_disp_diff=dg, region_ul=(30, 20))

@@ -13,6 +13,7 @@ SYMBOLS = [
     "vwgpu_profile_enable", "vwgpu_profile_reset", "vwgpu_profile_read",
     "vwgpu_calc_disparity_dev", "vwgpu_calc_disparity",
     "vwgpu_cross_corr_consistency_check_dev", "vwgpu_cross_corr_consistency_check",
+    "vwgpu_cross_corr_consistency_check_diff_dev", "vwgpu_cross_corr_consistency_check_diff",
     "vwgpu_generate_gaussian_kernel",
     "vwgpu_separable_convolution_dev", "vwgpu_separable_convolution",
     "vwgpu_convolution_2d_dev", "vwgpu_convolution_2d",
@@ -50,6 +51,8 @@ class PyramidParams(ctypes.Structure):
         ("algorithm", ctypes.c_int), ("blob_filter_area", ctypes.c_int),
         ("sgm_subpixel_mode", ctypes.c_int), ("sgm_search_buffer_x", ctypes.c_int), ("sgm_search_buffer_y", ctypes.c_int),
         ("memory_limit_mb", ctypes.c_size_t), ("sgm_num_threads", ctypes.c_int),
+        ("lr_disp_diff", ctypes.c_void_p), ("lr_disp_diff_cols", ctypes.c_int), ("lr_disp_diff_rows", ctypes.c_int),
+        ("lr_disp_diff_stride", ctypes.c_ssize_t), ("region_ul_x", ctypes.c_int), ("region_ul_y", ctypes.c_int),
     ]
 
 
@@ -101,6 +104,9 @@ def load():
     lr = [P, P, I, I, PD, P, I, I, PD, F]
     lib.vwgpu_cross_corr_consistency_check_dev.argtypes = lr
     lib.vwgpu_cross_corr_consistency_check.argtypes = lr
+    lrd = lr + [P, I, I, PD, I, I]
+    lib.vwgpu_cross_corr_consistency_check_diff_dev.argtypes = lrd
+    lib.vwgpu_cross_corr_consistency_check_diff.argtypes = lrd
     lib.vwgpu_generate_gaussian_kernel.argtypes = [ctypes.c_double, I, P, I]
     sc = [P, P, I, I, PD, P, I, I, P, I, I, I, I, P, PD]
     lib.vwgpu_separable_convolution_dev.argtypes = sc

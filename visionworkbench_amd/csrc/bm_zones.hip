@@ -158,7 +158,8 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
 
 // Per zone: cross_corr_consistency_check(crop(disparity, zone), rl_zone, thr), then += (addx, addy).
 __global__ void zone_lr_kernel(const vwgpu_zone_task* __restrict__ zones, const int2* __restrict__ tiles,
-                               int32_t* __restrict__ l2r, const int32_t* __restrict__ r2l, float thr) {
+                               int32_t* __restrict__ l2r, const int32_t* __restrict__ r2l, float thr,
+                               float* __restrict__ diff2, ptrdiff_t dstride) {
   const int2 tl = tiles[blockIdx.x];
   const vwgpu_zone_task z = zones[tl.x];          // zw/zh/out_* = the L->R zone; bx/by = size of its R->L image;
   const int ox = (tl.y & 0xffff) * ZT, oy = (tl.y >> 16) * ZT;   // ax = element offset of that image in r2l
@@ -174,6 +175,10 @@ __global__ void zone_lr_kernel(const vwgpu_zone_task* __restrict__ zones, const 
       if (v != 0 && q[2] != 0) {
         const float diff = (float)fmax(fabs((double)(dx + q[0])), fabs((double)(dy + q[1])));
         keep = thr >= diff;
+        if (keep && diff2) {                        // lr_disp_diff(c + ul.x, r + ul.y) = PixelMask<float>(disp_diff)
+          float* d = diff2 + ((ptrdiff_t)(r + z.sy) * dstride + (c + z.sx)) * 2;
+          d[0] = diff; d[1] = 1.0f;
+        }
       }
     }
     p[0] = dx + z.addx; p[1] = dy + z.addy;
@@ -273,7 +278,8 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
   return VWGPU_OK;
 }
 
-int vwgpu_launch_zone_lr(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, int32_t* l2r, const int32_t* r2l, float thr) {
+int vwgpu_launch_zone_lr(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, int32_t* l2r, const int32_t* r2l, float thr,
+                         float* diff2, ptrdiff_t dstride) {
   if (n <= 0) return VWGPU_OK;
   std::vector<int2> tiles;
   build_tiles(zones, n, tiles);
@@ -282,7 +288,7 @@ int vwgpu_launch_zone_lr(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, in
   int rc = upload_tables(ctx, zones, n, tiles, &dz, &dt);
   if (rc) return rc;
   vwgpu_prof_scope ps(ctx, "zone_lr_check");
-  hipLaunchKernelGGL(zone_lr_kernel, dim3((unsigned)tiles.size()), dim3(ZTHREADS), 0, ctx->stream, dz, dt, l2r, r2l, thr);
+  hipLaunchKernelGGL(zone_lr_kernel, dim3((unsigned)tiles.size()), dim3(ZTHREADS), 0, ctx->stream, dz, dt, l2r, r2l, thr, diff2, dstride);
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }

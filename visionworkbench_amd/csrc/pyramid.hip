@@ -205,6 +205,13 @@ __global__ void finish_sgm_kernel(const int32_t* __restrict__ d, const float* __
   o[0] = sub[i] + ax; o[1] = sub[i + 1] + ay; o[2] = (d[i + 2] && sub[i + 2] != 0.0f) ? 1.0f : 0.0f;
 }
 
+// pixels the filters removed lose their L-R / R-L discrepancy as well (CorrelationView.cc:846-855)
+__global__ void lr_diff_invalidate_kernel(const int32_t* __restrict__ d, int w, int h, float* __restrict__ diff2, ptrdiff_t dstride, int ulx, int uly) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  if (!d[((size_t)y * w + x) * 3 + 2]) diff2[((ptrdiff_t)(y + uly) * dstride + (x + ulx)) * 2 + 1] = 0.0f;
+}
+
 __global__ void zero_out_kernel(float* __restrict__ out, ptrdiff_t ostride_px, int w, int h) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= w || y >= h) return;
@@ -276,8 +283,11 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
                                  const float* right, int rw, int rh, ptrdiff_t rs,
                                  const uint8_t* lmask, ptrdiff_t lms, const uint8_t* rmask, ptrdiff_t rms,
                                  const vwgpu_pyramid_params* P, int bx, int by, int bw, int bh,
-                                 float* out, ptrdiff_t os) {
+                                 float* out, ptrdiff_t os, float* lr_diff) {
   const int kx = P->kernel_x, ky = P->kernel_y;
+  // lr_diff: DEVICE copy of P->lr_disp_diff (or null); its geometry comes from P
+  const ptrdiff_t lr_stride = P->lr_disp_diff_stride ? P->lr_disp_diff_stride : P->lr_disp_diff_cols;
+  const int lr_ulx = bx - P->region_ul_x, lr_uly = by - P->region_ul_y;       // tile origin inside the diff image
   const IBox search(P->search_min_x, P->search_min_y, P->search_max_x, P->search_max_y);
   const IBox bbox(bx, by, bx + bw, by + bh);
   hipStream_t st = ctx->stream;
@@ -454,7 +464,8 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         if (rc) return rc;
         if (row != rlw || roh != rlh) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "pyramid_correlate: SGM R->L output size mismatch");
         hipLaunchKernelGGL(add_offset_kernel, grid2(rlw, rlh), kBlk, 0, st, rl_a, rlw, rlw, rlh, -sx, -sy);
-        rc = vwgpu_launch_lr_check(ctx, disp, dw, dh, dw, rl_a, rlw, rlh, rlw, P->consistency_threshold);
+        rc = vwgpu_launch_lr_check_diff(ctx, disp, dw, dh, dw, rl_a, rlw, rlh, rlw, P->consistency_threshold, last ? lr_diff : nullptr, lr_stride,
+                                        lr_ulx, lr_uly);
         if (rc) return rc;
         hipLaunchKernelGGL(add_offset_kernel, grid2(rlw, rlh), kBlk, 0, st, rl_a, rlw, rlw, rlh, sx, sy);
       }
@@ -484,7 +495,8 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
           const int rlw = rr.dx() - kx + 1, rlh = rr.dy() - ky + 1;
           vwgpu_zone_task b{rr.x0, rr.y0, lr.x0 - sx, lr.y0 - sy, rlw, rlh, sx, sy, (int)rl_pixels, rlw, -sx, -sy};
           t2.push_back(b);
-          vwgpu_zone_task c{(int)rl_pixels, 0, rlw, rlh, zw, zh, sx, sy, a.out_off, dw, z.range.x0, z.range.y0};
+          // (sx, sy) slots of an lr task = the zone's origin in the lr_disp_diff image (ul_corner_offset, :683-687)
+          vwgpu_zone_task c{(int)rl_pixels, 0, rlw, rlh, zw, zh, z.region.x0 + lr_ulx, z.region.y0 + lr_uly, a.out_off, dw, z.range.x0, z.range.y0};
           t3.push_back(c);
           rl_pixels += (size_t)rlw * rlh;
           if (rl_pixels > (size_t)INT32_MAX / 2) { ctx->forced_path = saved_force; return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: tile too large for the L/R check buffers"); }
@@ -496,7 +508,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
       if (lr_active) {
         int32_t* rlbuf = static_cast<int32_t*>(ctx->zrl.base);
         if ((rc = vwgpu_launch_bm_zones(ctx, P->cost_type, Rv.p, Rv.w, Rv.h, Lv.p, Lv.w, Lv.h, kx, ky, t2.data(), (int)t2.size(), rlbuf))) return rc;
-        if ((rc = vwgpu_launch_zone_lr(ctx, t3.data(), (int)t3.size(), disp, rlbuf, P->consistency_threshold))) return rc;
+        if ((rc = vwgpu_launch_zone_lr(ctx, t3.data(), (int)t3.size(), disp, rlbuf, P->consistency_threshold, lr_diff, lr_stride))) return rc;
       }
     } else if (!use_sgm)
     for (SearchZone const& z : zones) {
@@ -535,7 +547,8 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         rc = vwgpu_calc_disparity_dev(ctx, P->cost_type, tmp_b, aw, ah, aw, tmp_a, bw2, bh2, bw2, kx, ky, sx, sy, rl, rlw);
         if (rc) { ctx->forced_path = saved_force; return rc; }
         hipLaunchKernelGGL(add_offset_kernel, grid2(rlw, rlh), kBlk, 0, st, rl, rlw, rlw, rlh, -sx, -sy);
-        rc = vwgpu_launch_lr_check(ctx, zout, zw, zh, dw, rl, rlw, rlh, rlw, P->consistency_threshold);
+        rc = vwgpu_launch_lr_check_diff(ctx, zout, zw, zh, dw, rl, rlw, rlh, rlw, P->consistency_threshold, lr_diff, lr_stride,
+                                        z.region.x0 + lr_ulx, z.region.y0 + lr_uly);
         if (rc) { ctx->forced_path = saved_force; return rc; }
       }
       hipLaunchKernelGGL(add_offset_kernel, grid2(zw, zh), kBlk, 0, st, zout, dw, zw, zh, z.range.x0, z.range.y0);
@@ -588,6 +601,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     }
   }
   if (dw != bw || dh != bh) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "PyramidCorrelation: Solved disparity doesn't match requested bbox size.");
+  if (lr_diff) hipLaunchKernelGGL(lr_diff_invalidate_kernel, grid2(bw, bh), kBlk, 0, st, disp, bw, bh, lr_diff, lr_stride, lr_ulx, lr_uly);
   if (use_sgm)
     hipLaunchKernelGGL(finish_sgm_kernel, grid2(bw, bh), kBlk, 0, st, disp, sub, bw, bh, (float)search.x0, (float)search.y0, out, os);
   else
@@ -726,6 +740,11 @@ static int check_pyramid_args(vwgpu_ctx* ctx, const void* l, int lw, int lh, con
       return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "Census transforms are only available in size 3, 5, 7, and 9.");
   }
   if (P->blob_filter_area < 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate: negative blob filter area");
+  if (P->lr_disp_diff) {          // CorrelationView.cc:277-283
+    const ptrdiff_t st = P->lr_disp_diff_stride ? P->lr_disp_diff_stride : P->lr_disp_diff_cols;
+    if (P->lr_disp_diff_cols <= 0 || P->lr_disp_diff_rows <= 0 || st < P->lr_disp_diff_cols)
+      return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate: bad lr_disp_diff geometry");
+  }
   if (P->max_pyramid_levels < 0 || P->filter_half_kernel < 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate: negative level / filter size");
   return VWGPU_OK;
 }
@@ -742,8 +761,12 @@ int vwgpu_pyramid_correlate_dev(vwgpu_ctx* ctx, const float* d_left, int lw, int
   if (rms == 0) rms = rw;
   if (os == 0) os = bw;
   if (ls < lw || rs < rw || lms < lw || rms < rw || os < bw) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate: row stride smaller than row width");
+  if (P->lr_disp_diff && (bx < P->region_ul_x || by < P->region_ul_y || bx + bw > P->region_ul_x + P->lr_disp_diff_cols ||
+                          by + bh > P->region_ul_y + P->lr_disp_diff_rows))
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "The L-R to R-L difference image domain does not contain the current tile.");
   VWGPU_HIP(ctx, hipSetDevice(ctx->device));
-  return vwgpu_pyramid_correlate_impl(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, d_lmask, lms, d_rmask, rms, P, bx, by, bw, bh, d_out, os);
+  return vwgpu_pyramid_correlate_impl(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, d_lmask, lms, d_rmask, rms, P, bx, by, bw, bh, d_out, os,
+                                      P->lr_disp_diff);
 }
 
 int vwgpu_pyramid_correlate(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t ls,
@@ -760,7 +783,12 @@ int vwgpu_pyramid_correlate(vwgpu_ctx* ctx, const float* left, int lw, int lh, p
   VWGPU_HIP(ctx, hipSetDevice(ctx->device));
   const size_t lb = vwgpu_align_up((size_t)lw * lh * 4, 256), rb = vwgpu_align_up((size_t)rw * rh * 4, 256);
   const size_t lmb = vwgpu_align_up((size_t)lw * lh, 256), rmb = vwgpu_align_up((size_t)rw * rh, 256), ob = vwgpu_align_up((size_t)bw * bh * 12, 256);
-  rc = vwgpu_arena_reserve(ctx, &ctx->staging, lb + rb + lmb + rmb + ob);
+  if (P->lr_disp_diff && (bx < P->region_ul_x || by < P->region_ul_y || bx + bw > P->region_ul_x + P->lr_disp_diff_cols ||
+                          by + bh > P->region_ul_y + P->lr_disp_diff_rows))
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "The L-R to R-L difference image domain does not contain the current tile.");
+  const ptrdiff_t hdst = P->lr_disp_diff_stride ? P->lr_disp_diff_stride : P->lr_disp_diff_cols;
+  const size_t db = P->lr_disp_diff ? vwgpu_align_up((size_t)P->lr_disp_diff_cols * P->lr_disp_diff_rows * 8, 256) : 0;
+  rc = vwgpu_arena_reserve(ctx, &ctx->staging, lb + rb + lmb + rmb + ob + db);
   if (rc) return rc;
   char* base = static_cast<char*>(ctx->staging.base);
   float* d_l = reinterpret_cast<float*>(base);
@@ -772,9 +800,18 @@ int vwgpu_pyramid_correlate(vwgpu_ctx* ctx, const float* left, int lw, int lh, p
   VWGPU_HIP(ctx, hipMemcpy2DAsync(d_r, (size_t)rw * 4, right, (size_t)rs * 4, (size_t)rw * 4, rh, hipMemcpyHostToDevice, ctx->stream));
   if (lmask) VWGPU_HIP(ctx, hipMemcpy2DAsync(d_lm, (size_t)lw, lmask, (size_t)lms, (size_t)lw, lh, hipMemcpyHostToDevice, ctx->stream));
   if (rmask) VWGPU_HIP(ctx, hipMemcpy2DAsync(d_rm, (size_t)rw, rmask, (size_t)rms, (size_t)rw, rh, hipMemcpyHostToDevice, ctx->stream));
+  float* d_d = reinterpret_cast<float*>(base + lb + rb + lmb + rmb + ob);
+  vwgpu_pyramid_params Pd = *P;                     // the device-side view of the discrepancy image is dense
+  Pd.lr_disp_diff_stride = P->lr_disp_diff_cols;
+  if (P->lr_disp_diff)
+    VWGPU_HIP(ctx, hipMemcpy2DAsync(d_d, (size_t)P->lr_disp_diff_cols * 8, P->lr_disp_diff, (size_t)hdst * 8, (size_t)P->lr_disp_diff_cols * 8,
+                                    P->lr_disp_diff_rows, hipMemcpyHostToDevice, ctx->stream));
   rc = vwgpu_pyramid_correlate_impl(ctx, d_l, lw, lh, lw, d_r, rw, rh, rw, lmask ? d_lm : nullptr, lw, rmask ? d_rm : nullptr, rw,
-                                    P, bx, by, bw, bh, d_o, bw);
+                                    &Pd, bx, by, bw, bh, d_o, bw, P->lr_disp_diff ? d_d : nullptr);
   if (rc) return rc;
+  if (P->lr_disp_diff)
+    VWGPU_HIP(ctx, hipMemcpy2DAsync(P->lr_disp_diff, (size_t)hdst * 8, d_d, (size_t)P->lr_disp_diff_cols * 8, (size_t)P->lr_disp_diff_cols * 8,
+                                    P->lr_disp_diff_rows, hipMemcpyDeviceToHost, ctx->stream));
   VWGPU_HIP(ctx, hipMemcpy2DAsync(out, (size_t)os * 12, d_o, (size_t)bw * 12, (size_t)bw * 12, bh, hipMemcpyDeviceToHost, ctx->stream));
   VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VWGPU_OK;

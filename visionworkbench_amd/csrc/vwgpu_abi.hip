@@ -334,4 +334,54 @@ int vwgpu_cross_corr_consistency_check(vwgpu_ctx* ctx, int32_t* l2r, int lw, int
   return VWGPU_OK;
 }
 
+int vwgpu_cross_corr_consistency_check_diff_dev(vwgpu_ctx* ctx, int32_t* d_l2r, int lw, int lh, ptrdiff_t ls,
+                                                const int32_t* d_r2l, int rw, int rh, ptrdiff_t rs, float thr,
+                                                float* d_diff, int dcols, int drows, ptrdiff_t dstride, int ulx, int uly) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  ctx->err.clear();
+  if (!d_l2r || !d_r2l || lw < 0 || lh < 0 || rw < 0 || rh < 0)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "cross_corr_consistency_check: bad image");
+  if (!(thr >= 0.0f))
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "cross_corr_consistency_check: the threshold is less than 0.");
+  if (dstride == 0) dstride = dcols;
+  if (d_diff && (ulx < 0 || uly < 0 || ulx + lw > dcols || uly + lh > drows || dstride < dcols))
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "cross_corr_consistency_check: lr_disp_diff does not contain the checked region");
+  if (ls == 0) ls = lw;
+  if (rs == 0) rs = rw;
+  if (lw == 0 || lh == 0) return VWGPU_OK;
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  return vwgpu_launch_lr_check_diff(ctx, d_l2r, lw, lh, ls, d_r2l, rw, rh, rs, thr, d_diff, dstride, ulx, uly);
+}
+
+int vwgpu_cross_corr_consistency_check_diff(vwgpu_ctx* ctx, int32_t* l2r, int lw, int lh, ptrdiff_t ls,
+                                            const int32_t* r2l, int rw, int rh, ptrdiff_t rs, float thr,
+                                            float* diff, int dcols, int drows, ptrdiff_t dstride, int ulx, int uly) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  if (!l2r || !r2l || lw < 0 || lh < 0 || rw < 0 || rh < 0)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "cross_corr_consistency_check: bad image");
+  if (ls == 0) ls = lw;
+  if (rs == 0) rs = rw;
+  if (dstride == 0) dstride = dcols;
+  if (lw == 0 || lh == 0) return VWGPU_OK;
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t lb = vwgpu_align_up((size_t)lw * lh * 12, 256), rb = vwgpu_align_up((size_t)rw * rh * 12, 256);
+  const size_t db = diff ? vwgpu_align_up((size_t)dcols * drows * 8, 256) : 0;
+  int rc = vwgpu_arena_reserve(ctx, &ctx->staging, lb + rb + db);
+  if (rc) return rc;
+  char* base = static_cast<char*>(ctx->staging.base);
+  int32_t* d_l = reinterpret_cast<int32_t*>(base);
+  int32_t* d_r = reinterpret_cast<int32_t*>(base + lb);
+  float* d_d = reinterpret_cast<float*>(base + lb + rb);
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_l, (size_t)lw * 12, l2r, (size_t)ls * 12, (size_t)lw * 12, lh, hipMemcpyHostToDevice, ctx->stream));
+  if (rw > 0 && rh > 0)
+    VWGPU_HIP(ctx, hipMemcpy2DAsync(d_r, (size_t)rw * 12, r2l, (size_t)rs * 12, (size_t)rw * 12, rh, hipMemcpyHostToDevice, ctx->stream));
+  if (diff) VWGPU_HIP(ctx, hipMemcpy2DAsync(d_d, (size_t)dcols * 8, diff, (size_t)dstride * 8, (size_t)dcols * 8, drows, hipMemcpyHostToDevice, ctx->stream));
+  rc = vwgpu_cross_corr_consistency_check_diff_dev(ctx, d_l, lw, lh, lw, d_r, rw, rh, rw, thr, diff ? d_d : nullptr, dcols, drows, dcols, ulx, uly);
+  if (rc) return rc;
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(l2r, (size_t)ls * 12, d_l, (size_t)lw * 12, (size_t)lw * 12, lh, hipMemcpyDeviceToHost, ctx->stream));
+  if (diff) VWGPU_HIP(ctx, hipMemcpy2DAsync(diff, (size_t)dstride * 8, d_d, (size_t)dcols * 8, (size_t)dcols * 8, drows, hipMemcpyDeviceToHost, ctx->stream));
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VWGPU_OK;
+}
+
 }  // extern "C"

@@ -105,6 +105,9 @@ int vwgpu_next_flags(vwgpu_ctx* ctx, size_t extra_ints, int** flag_set, int** fl
 
 int vwgpu_launch_lr_check(vwgpu_ctx* ctx, int32_t* l2r, int lw, int lh, ptrdiff_t ls,
                           const int32_t* r2l, int rw, int rh, ptrdiff_t rs, float thr);
+int vwgpu_launch_lr_check_diff(vwgpu_ctx* ctx, int32_t* l2r, int lw, int lh, ptrdiff_t ls,
+                               const int32_t* r2l, int rw, int rh, ptrdiff_t rs, float thr,
+                               float* diff2, ptrdiff_t dstride, int ulx, int uly);
 
 // filters.hip
 int vwgpu_launch_sepconv(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
@@ -147,7 +150,9 @@ struct vwgpu_zone_task {
 bool vwgpu_bm_zones_supported(int kx, int ky);
 int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
                           int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out);
-int vwgpu_launch_zone_lr(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, int32_t* l2r, const int32_t* r2l, float thr);
+// lr tasks: ax = pixel offset of the zone's R->L image, (bx, by) = its size, (sx, sy) = the zone's origin in the diff image
+int vwgpu_launch_zone_lr(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, int32_t* l2r, const int32_t* r2l, float thr,
+                         float* diff2, ptrdiff_t dstride);
 
 // pyramid.hip
 int vwgpu_launch_disparity_filter(vwgpu_ctx* ctx, const int32_t* src, int w, int h, int hh, int hv, double pthr, double rthr,
@@ -158,7 +163,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
                                  const float* right, int rw, int rh, ptrdiff_t rs,
                                  const uint8_t* lmask, ptrdiff_t lms, const uint8_t* rmask, ptrdiff_t rms,
                                  const vwgpu_pyramid_params* P, int bx, int by, int bw, int bh,
-                                 float* out, ptrdiff_t os);
+                                 float* out, ptrdiff_t os, float* lr_diff);
 
 // sgm.hip
 int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left, int lw, int lh, ptrdiff_t ls,

@@ -79,12 +79,34 @@ def calc_disparity(cost_type, left_in, right_in, left_region, search_volume, ker
     return out
 
 
-def cross_corr_consistency_check(l2r, r2l, cross_corr_threshold, ctx=None):
+def cross_corr_consistency_check(l2r, r2l, cross_corr_threshold, lr_disp_diff=None, ul_corner_offset=(0, 0), ctx=None):
     """vw::stereo::cross_corr_consistency_check (src/vw/Stereo/Correlate.cc:1441-1502), IN PLACE on l2r.
 
-    l2r, r2l: (rows, cols, 3) int32 PixelMask<Vector2i> images."""
+    l2r, r2l: (rows, cols, 3) int32 PixelMask<Vector2i> images.  lr_disp_diff (optional, modified in place): (rows, cols, 2)
+    float32 PixelMask<float> {value, valid}; every kept pixel stores its discrepancy at (c, r) + ul_corner_offset."""
     ctx = _ctx_for(l2r, ctx)
     lib = ctx._lib
+    if lr_disp_diff is not None:
+        ux, uy = int(ul_corner_offset[0]), int(ul_corner_offset[1])
+        if lr_disp_diff.ndim != 3 or lr_disp_diff.shape[2] != 2:
+            raise ArgumentErr("cross_corr_consistency_check: lr_disp_diff must be (rows, cols, 2) float32")
+        dr, dc = lr_disp_diff.shape[:2]
+        if _is_tensor(l2r):
+            if not (l2r.is_cuda and r2l.is_cuda and lr_disp_diff.is_cuda and l2r.is_contiguous() and r2l.is_contiguous()
+                    and lr_disp_diff.is_contiguous() and lr_disp_diff.dtype == torch.float32):
+                raise ArgumentErr("cross_corr_consistency_check: contiguous CUDA tensors required")
+            ctx.set_stream(torch.cuda.current_stream(l2r.device).cuda_stream)
+            ctx.check(lib.vwgpu_cross_corr_consistency_check_diff_dev(ctx._h, l2r.data_ptr(), l2r.shape[1], l2r.shape[0], 0, r2l.data_ptr(),
+                                                                      r2l.shape[1], r2l.shape[0], 0, float(cross_corr_threshold),
+                                                                      lr_disp_diff.data_ptr(), dc, dr, 0, ux, uy))
+            return l2r
+        if not (l2r.flags.c_contiguous and l2r.dtype == np.int32 and lr_disp_diff.flags.c_contiguous and lr_disp_diff.dtype == np.float32):
+            raise ArgumentErr("cross_corr_consistency_check: contiguous int32 / float32 arrays required (modified in place)")
+        r2l = np.ascontiguousarray(r2l, np.int32)
+        ctx.check(lib.vwgpu_cross_corr_consistency_check_diff(ctx._h, l2r.ctypes.data, l2r.shape[1], l2r.shape[0], 0, r2l.ctypes.data,
+                                                              r2l.shape[1], r2l.shape[0], 0, float(cross_corr_threshold),
+                                                              lr_disp_diff.ctypes.data, dc, dr, 0, ux, uy))
+        return l2r
     if _is_tensor(l2r):
         if not (l2r.is_cuda and r2l.is_cuda and l2r.is_contiguous() and r2l.is_contiguous()):
             raise ArgumentErr("cross_corr_consistency_check: contiguous CUDA tensors required")
@@ -242,7 +264,7 @@ def pyramid_correlate(left, right, left_mask, right_mask, prefilter_mode, prefil
                       cost_type, corr_timeout=0, seconds_per_op=0.0, consistency_threshold=-1.0,
                       min_consistency_level=0, filter_half_kernel=0, max_pyramid_levels=5, algorithm=0,
                       collar_size=0, sgm_subpixel_mode=5, sgm_search_buffer=(2, 2), memory_limit_mb=6000,
-                      blob_filter_area=0, bbox=None, sgm_num_threads=1, ctx=None):
+                      blob_filter_area=0, bbox=None, sgm_num_threads=1, lr_disp_diff=None, region_ul=(0, 0), ctx=None):
     """vw::stereo::pyramid_correlate (src/vw/Stereo/CorrelationView.h:195-230) rasterised over `bbox`
     (default: the whole left image as ONE tile, i.e. PyramidCorrelationView::prerasterize(bounding_box),
     src/vw/Stereo/CorrelationView.cc:273-886).  The reference rasterises per block-cache tile; pass the same
@@ -252,7 +274,10 @@ def pyramid_correlate(left, right, left_mask, right_mask, prefilter_mode, prefil
     Returns (bbox rows, bbox cols, 3) float32 PixelMask<Vector2f> {dx, dy, valid}.
     algorithm 0 = VW_CORRELATION_BM (integer disparities cast to float), 1 = VW_CORRELATION_SGM (census costs only; the
     result is the matcher's sub-pixel view, CorrelationView.cc:862-875); MGM variants raise NoImplErr.  collar_size is
-    the tile rasteriser's business (CorrelationView.h:128-132): pass the collared bbox."""
+    the tile rasteriser's business (CorrelationView.h:128-132): pass the collared bbox.
+    lr_disp_diff (optional, modified in place): (rows, cols, 2) float32 PixelMask<float> image covering the image pixels from
+    region_ul on; the level-0 consistency check stores the L-R / R-L discrepancy of the pixels it keeps there and pixels
+    the filters remove are invalidated again (CorrelationView.h:84, .cc:277-283, 683-693, 846-855)."""
     from ._lib import PyramidParams
     if left.ndim != 2 or right.ndim != 2:
         raise ArgumentErr("pyramid_correlate: images must be 2-D (rows, cols)")
@@ -266,7 +291,19 @@ def pyramid_correlate(left, right, left_mask, right_mask, prefilter_mode, prefil
                       int(kernel_size[0]), int(kernel_size[1]), int(cost_type), int(corr_timeout), float(seconds_per_op),
                       float(consistency_threshold), int(min_consistency_level), int(filter_half_kernel),
                       int(max_pyramid_levels), int(algorithm), int(blob_filter_area), int(sgm_subpixel_mode),
-                      int(sgm_search_buffer[0]), int(sgm_search_buffer[1]), int(memory_limit_mb), int(sgm_num_threads))
+                      int(sgm_search_buffer[0]), int(sgm_search_buffer[1]), int(memory_limit_mb), int(sgm_num_threads),
+                      None, 0, 0, 0, int(region_ul[0]), int(region_ul[1]))
+    if lr_disp_diff is not None:
+        if lr_disp_diff.ndim != 3 or lr_disp_diff.shape[2] != 2:
+            raise ArgumentErr("pyramid_correlate: lr_disp_diff must be (rows, cols, 2) float32")
+        if _is_tensor(lr_disp_diff) != _is_tensor(left):
+            raise ArgumentErr("pyramid_correlate: lr_disp_diff must live where the images live")
+        ok = (lr_disp_diff.is_cuda and lr_disp_diff.is_contiguous() and lr_disp_diff.dtype == torch.float32) if _is_tensor(lr_disp_diff) \
+            else (lr_disp_diff.flags.c_contiguous and lr_disp_diff.dtype == np.float32)
+        if not ok:
+            raise ArgumentErr("pyramid_correlate: lr_disp_diff must be contiguous float32")
+        P.lr_disp_diff = lr_disp_diff.data_ptr() if _is_tensor(lr_disp_diff) else lr_disp_diff.ctypes.data
+        P.lr_disp_diff_rows, P.lr_disp_diff_cols = int(lr_disp_diff.shape[0]), int(lr_disp_diff.shape[1])
     ctx = _ctx_for(left, ctx)
     lib = ctx._lib
     bw, bh = bx1 - bx, by1 - by

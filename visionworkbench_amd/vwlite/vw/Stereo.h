@@ -298,7 +298,7 @@ calc_disparity_sgm(CostFunctionType cost_type,
   right_region.max() += search_volume;                               // inclusive search volume (SGM.cc:186-191)
   ImageView<PixelGray<float>> l = crop(left_in, left_region);
   ImageView<PixelGray<float>> r = crop(edge_extend(right_in, ConstantEdgeExtension()), right_region);
-  vwgpu_sgm_params p;
+  vwgpu_sgm_params p = vwgpu_sgm_params();
   p.cost_type = (int)cost_type; p.use_mgm = use_mgm ? 1 : 0; p.kernel_size = kernel_size[0]; p.subpixel_mode = (int)subpixel_mode;
   p.search_buffer_x = search_buffer[0]; p.search_buffer_y = search_buffer[1]; p.memory_limit_mb = memory_limit_mb;
   p.p1 = 0; p.p2 = 0; p.ternary_census_threshold = 5; p.num_threads = 1;
@@ -386,7 +386,7 @@ pyramid_correlate(ImageViewBase<Image1T> const& left, ImageViewBase<Image2T> con
                   CorrelationAlgorithm algorithm = VW_CORRELATION_BM, int collar_size = 0, int sgm_subpixel_mode = 5 /*SUBPIXEL_LC_BLEND*/,
                   Vector2i sgm_search_buffer = Vector2i(2, 2), size_t memory_limit_mb = 6000, int blob_filter_area = 0) {
   (void)collar_size;
-  vwgpu_pyramid_params p;
+  vwgpu_pyramid_params p = vwgpu_pyramid_params();   // lr_disp_diff = NULL
   p.prefilter_mode = (int)prefilter_mode; p.prefilter_width = prefilter_width;
   p.search_min_x = search_region.min().x(); p.search_min_y = search_region.min().y();
   p.search_max_x = search_region.max().x(); p.search_max_y = search_region.max().y();
