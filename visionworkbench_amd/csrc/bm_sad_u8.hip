@@ -508,10 +508,11 @@ constexpr Launch make_launch() {
 }
 
 // Instantiated kernel sizes.  Others fall back to the generic path.
-// Two tile heights for the headline size: a workgroup alone on a CU needs ~107 us for a 16-row tile (the kernel is latency
-// bound per wave and relies on several resident workgroups per CU), so small images / the row strips of a multi-GPU run
-// use 8-row tiles unless 16-row tiles already give >= 8 workgroups per CU (tools/time_strips.py: the 8-row variant costs 2 %
-// on the full 4096^2 image and wins from 1/4 strips down; 4-row tiles never win).  Taller tiles re-read fewer halo rows.
+// Two tile heights for the headline size.  A workgroup is 4 waves x 256 columns x TY rows; the 4096^2 image is 4 x 256 = 1024
+// of them with TY = 16 — 4 per CU, one round — and the kernel time is linear in workgroups per CU (107 us for one, 407 us for
+// four: issue bound from the first wave per SIMD).  A 1/8 row strip is only 128 such workgroups (half the CUs idle), so
+// small images / multi-GPU strips use 8-row tiles when 16-row tiles would leave fewer than 2 workgroups per CU
+// (tools/time_strips.py: 1/4 strip 137 -> 128 us, 1/8 strip 128 -> 84 us; 4-row tiles never win — 10/4 halo rows).
 const Launch kLaunch[] = {
     make_launch<3, 3, 16>(), make_launch<5, 5, 16>(), make_launch<7, 7, 16>(), make_launch<7, 7, 8>(),
     make_launch<7, 5, 16>(), make_launch<9, 9, 12>(), make_launch<11, 11, 8>(),
@@ -524,14 +525,14 @@ const Launch* find_launch(int kx, int ky) {
   return nullptr;
 }
 
-// the tallest tile that still yields >= 8 workgroups per CU; the shortest one otherwise
+// the tallest tile that still yields >= 2 workgroups per CU; the shortest one otherwise
 const Launch* pick_launch(int kx, int ky, int ow, int oh, int num_cu) {
   const Launch* last = nullptr;
   for (const Launch& l : kLaunch) {
     if (l.kx != kx || l.ky != ky) continue;
     last = &l;
     const long long wgs = (long long)((ow + l.twb - 1) / l.twb) * ((oh + l.ty - 1) / l.ty);
-    if (wgs >= 8LL * num_cu) return &l;
+    if (wgs >= 2LL * num_cu) return &l;
   }
   return last;
 }
