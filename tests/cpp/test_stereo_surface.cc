@@ -128,6 +128,31 @@ static void test_legacy_correlate() {
 }
 
 
+// TestCorrelationView.cxx:42-49 scene (19x25 noise, right = left moved by (1,1) with clamped edges) through the legacy
+// correlate() with each prefilter object; thresholds are that file's (:79-300).
+template <class PreFilterT>
+static void test_legacy_prefilter(PreFilterT const& pf, float correct_sad, float correct_ssd, float correct_ncc) {
+  uint64_t s = 10;
+  ImageView<PixelGray<float>> input1(19, 25), input2(19, 25);
+  for (int r = 0; r < 25; ++r) for (int c = 0; c < 19; ++c) input1(c, r) = (float)(splitmix(s) >> 56);
+  for (int r = 0; r < 25; ++r) for (int c = 0; c < 19; ++c) input2(c, r) = input1(std::max(c - 1, 0), std::max(r - 1, 0));
+  const float want[3] = {correct_sad, correct_ssd, correct_ncc};
+  for (int cost = 0; cost < 3; ++cost)
+    for (float thr : {-1.0f, 2.0f}) {
+      ImageView<PixelMask<Vector2i>> d = correlate(input1, input2, pf, BBox2i(1, 1, 1, 1), Vector2i(7, 7), (CostFunctionType)cost, thr);
+      EXPECT_EQ(input1.cols(), d.cols());
+      EXPECT_EQ(input1.rows(), d.rows());
+      long valid = 0, correct = 0;
+      for (int r = 0; r < 25; ++r) for (int c = 0; c < 19; ++c)
+        if (is_valid(d(c, r))) { ++valid; if (d(c, r).child() == Vector2i(1, 1)) ++correct; }
+      EXPECT_TRUE(valid > 0 && (float)correct / (float)valid > want[cost]);
+      // With the L/R check on, the last row and column point at right pixels outside the image and are dropped by
+      // cross_corr_consistency_check (Correlate.cc:38-45): 18*24 of 19*25 pixels can survive.
+      EXPECT_TRUE((float)valid / (19.0f * 25.0f) > (thr < 0 ? 0.99f : 0.9f));
+    }
+}
+
+
 // --- pyramid_correlate: TestPyramidCorrelationView-style scene (noise 300x200; the right image is the left one moved
 // by a position dependent integer shift so that no interpolation code is needed) -----------------------------------
 static void pyramid_scene(ImageView<PixelGray<float>>& left, ImageView<PixelGray<float>>& right) {
@@ -369,6 +394,9 @@ int main() {
   test_cross_corr_consistency();
   test_errors();
   test_legacy_correlate();
+  test_legacy_prefilter(NullOperation(), .983f, .966f, .966f);
+  test_legacy_prefilter(LaplacianOfGaussian(1.4f), .81f, .8f, .8f);
+  test_legacy_prefilter(SubtractedMean(5.0f), .93f, .93f, .92f);
   for (int cost = 0; cost < 3; ++cost) {
     test_pyramid_correlate((CostFunctionType)cost, -1, PREFILTER_NONE);
     test_pyramid_correlate((CostFunctionType)cost, 2, PREFILTER_NONE);

@@ -98,14 +98,15 @@ inline void cross_corr_consistency_check(ImageView<PixelMask<Vector2i>> const& l
 }
 
 /// Legacy correlate(): prefilter -> calc_disparity over the whole left image -> optional R->L run + L/R check.
-/// search_volume is a BBox2i of signed disparities [min, max); the result holds signed disparities
-/// (offset by search_volume.min()), like the legacy view did.  Only the Null prefilter is wired so far.
+/// search_volume is a BBox2i of signed disparities, max() INCLUSIVE as the legacy view took it (its own test searches
+/// BBox2i(1,1,1,1) and expects valid (1,1) answers, TestCorrelationView.cxx:46,64-66); the result holds signed disparities
+/// (offset by search_volume.min()), like the legacy view did.  The overload taking a prefilter object follows below.
 inline ImageView<PixelMask<Vector2i>>
 correlate(ImageView<PixelGray<float>> const& left, ImageView<PixelGray<float>> const& right,
           BBox2i const& search_volume, Vector2i const& kernel_size,
           CostFunctionType cost_type = ABSOLUTE_DIFFERENCE, float consistency_threshold = -1) {
   const Vector2i half(kernel_size[0] / 2, kernel_size[1] / 2);
-  const Vector2i s = search_volume.size();
+  const Vector2i s = search_volume.size() + Vector2i(1, 1);
   // Pad so that every pixel of `left` gets a disparity: windows are centred (edge-extended with zeros like the
   // legacy CorrelationView) and the right crop is shifted by search_volume.min().
   const int32 W = left.cols(), H = left.rows();
@@ -118,10 +119,10 @@ correlate(ImageView<PixelGray<float>> const& left, ImageView<PixelGray<float>> c
     // R->L: search the left image around each right pixel over the mirrored range.
     ImageView<PixelGray<float>> rp2 = crop(edge_extend(right, ZeroEdgeExtension()), -half[0], -half[1], W + 2 * half[0], H + 2 * half[1]);
     ImageView<PixelGray<float>> lp2 = crop(edge_extend(left, ZeroEdgeExtension()),
-                                          -half[0] - (search_volume.max().x() - 1), -half[1] - (search_volume.max().y() - 1),
+                                          -half[0] - search_volume.max().x(), -half[1] - search_volume.max().y(),
                                           W + 2 * half[0] + s[0] - 1, H + 2 * half[1] + s[1] - 1);
     ImageView<PixelMask<Vector2i>> r2l = calc_disparity(cost_type, rp2, lp2, bounding_box(rp2), s, kernel_size);
-    const Vector2i lmin = search_volume.min(), rmin(-(search_volume.max().x() - 1), -(search_volume.max().y() - 1));
+    const Vector2i lmin = search_volume.min(), rmin(-search_volume.max().x(), -search_volume.max().y());
     for (int32 r = 0; r < H; ++r) for (int32 c = 0; c < W; ++c) { l2r(c, r).child() += lmin; r2l(c, r).child() += rmin; }
     cross_corr_consistency_check(l2r, r2l, consistency_threshold);
     return l2r;
@@ -139,6 +140,31 @@ prefilter_image(ImageView<PixelGray<float>> const& image, PrefilterModeType pref
   detail::check(ctx, vwgpu_prefilter_image(ctx, reinterpret_cast<const float*>(image.data()), image.cols(), image.rows(), 0,
                                            (int)prefilter_mode, prefilter_width, reinterpret_cast<float*>(out.data()), 0));
   return out;
+}
+
+/// The prefilter objects of PreFilter.h:40-73; filter() returns the rasterised image (zero outside, like ConstantEdgeExtension
+/// views do once rasterised over the image's own box).
+struct NullOperation {
+  ImageView<PixelGray<float>> filter(ImageView<PixelGray<float>> const& image) const { return prefilter_image(image, PREFILTER_NONE, 0.0f); }
+};
+struct LaplacianOfGaussian {
+  float kernel_width;
+  explicit LaplacianOfGaussian(float size) : kernel_width(size) {}
+  ImageView<PixelGray<float>> filter(ImageView<PixelGray<float>> const& image) const { return prefilter_image(image, PREFILTER_LOG, kernel_width); }
+};
+struct SubtractedMean {
+  float kernel_width;
+  explicit SubtractedMean(float size) : kernel_width(size) {}
+  ImageView<PixelGray<float>> filter(ImageView<PixelGray<float>> const& image) const { return prefilter_image(image, PREFILTER_MEANSUB, kernel_width); }
+};
+
+/// Legacy correlate() with a prefilter object (TestCorrelationView.cxx:79-84 call shape).
+template <class PreFilterT>
+inline ImageView<PixelMask<Vector2i>>
+correlate(ImageView<PixelGray<float>> const& left, ImageView<PixelGray<float>> const& right, PreFilterT const& prefilter,
+          BBox2i const& search_volume, Vector2i const& kernel_size,
+          CostFunctionType cost_type = ABSOLUTE_DIFFERENCE, float consistency_threshold = -1) {
+  return correlate(prefilter.filter(left), prefilter.filter(right), search_volume, kernel_size, cost_type, consistency_threshold);
 }
 
 /// parabola_subpixel — the rasterised ParabolaSubpixelView (ParabolaSubpixelView.h:112-117).
