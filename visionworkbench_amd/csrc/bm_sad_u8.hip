@@ -117,6 +117,30 @@ __device__ __forceinline__ u32 pack4_check(float4 v, u32& acc) {
   return p;
 }
 
+// Groups straddling the right image edge (x < w <= x+3, at most one per row): the vector paths wrote 0 there.
+template <int NROWS>
+__device__ __forceinline__ void patch_right_edge(const float* __restrict__ img, ptrdiff_t stride, int w, int h,
+                                                 int x0, int y0, int ndw, int dst_pitch_dw,
+                                                 u32* __restrict__ dst, int tid, int nthreads, u32& acc) {
+  const int ge = (w - x0) >> 2;
+  if (ge >= 0 && ge < ndw && ((w - x0) & 3) != 0) {
+    for (int r = tid; r < NROWS; r += nthreads) {
+      const int y = y0 + r;
+      u32 p = 0;
+      if (y < h) {
+        const float* row = img + (ptrdiff_t)y * stride;
+        const int x = x0 + 4 * ge;
+        bool bad = false;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (x + b < w) p |= to_u8(row[x + b], bad) << (8 * b);
+        if (bad) acc |= 1u;
+      }
+      dst[r * dst_pitch_dw + ge] = p;
+    }
+  }
+}
+
 // Loads NROWS rows of a float image as packed u8 dwords into LDS: dst[r][g] = bytes (x0+4g .. x0+4g+3), zero
 // outside [0,w) x [0,h).  Row base pointers are workgroup-uniform (scalar), the per-lane part of the address is one
 // offset shared by all rows, and all NROWS loads of a thread are unconditional (out-of-range groups read offset 0 of
@@ -181,24 +205,7 @@ __device__ __forceinline__ void stage_u8_rows(const float* __restrict__ img, ptr
       }
     }
   }
-  // right-edge groups: x < w <= x+3
-  const int ge = (w - x0) >> 2;
-  if (ge >= 0 && ge < ndw && ((w - x0) & 3) != 0) {
-    for (int r = tid; r < NROWS; r += nthreads) {
-      const int y = y0 + r;
-      u32 p = 0;
-      if (y < h) {
-        const float* row = img + (ptrdiff_t)y * stride;
-        const int x = x0 + 4 * ge;
-        bool bad = false;
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          if (x + b < w) p |= to_u8(row[x + b], bad) << (8 * b);
-        if (bad) acc |= 1u;
-      }
-      dst[r * dst_pitch_dw + ge] = p;
-    }
-  }
+  patch_right_edge<NROWS>(img, stride, w, h, x0, y0, ndw, dst_pitch_dw, dst, tid, nthreads, acc);
 }
 
 // idx / d and idx % d for 0 <= idx < 2^20 without an integer division (d is workgroup-uniform, inv = 1.0f / d).
