@@ -16,4 +16,11 @@ for sx in (4, 8, 16, 32, 64, 128, 129, 256):
     for _ in range(20): fn()
     torch.cuda.synchronize()
     us = (time.perf_counter() - t0) / 20 * 1e6
-    print("sx=%3d: %7.1f us   %.3f us per disparity   path=%d" % (sx, us, us / sx, core.default_context(0).last_path()))
+    ctx = core.default_context(0)
+    ctx.profile_reset(); ctx.profile_enable(True)
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); ctx.profile_enable(False)
+    per = {}
+    for name, ms in ctx.profile_read(256): per.setdefault(name, []).append(ms * 1e3)
+    ks = "  ".join("%s %.1f" % (k, sum(v) / len(v)) for k, v in per.items())
+    print("sx=%3d: %7.1f us   %.3f us per disparity   path=%d   [%s]" % (sx, us, us / sx, ctx.last_path(), ks))

@@ -173,7 +173,7 @@ __device__ __forceinline__ void stage_u8_rows(const float* __restrict__ img, ptr
       const u32 p = pack4_check(v[r], a);
       const bool inb = colin && (y0 + r < h);
       if (inb) acc |= a;
-      dst[r * dst_pitch_dw + g] = inb ? p : 0u;
+      if (colin || x >= w) dst[r * dst_pitch_dw + g] = inb ? p : 0u;   // a straddling group belongs to patch_right_edge
     }
   }
   // remainder columns [nthreads, ndw): NROWS * rem items spread over all threads, 4 in flight per thread
@@ -192,7 +192,7 @@ __device__ __forceinline__ void stage_u8_rows(const float* __restrict__ img, ptr
         if (c >= rem) { ++r; c -= rem; }
         const int g = nthreads + c, x = x0 + 4 * g;
         inb[k] = (idx < total) && (x + 3 < w) && (y0 + r < h);
-        di[k] = (idx < total) ? r * dst_pitch_dw + g : -1;
+        di[k] = (idx < total && (x + 3 < w || x >= w)) ? r * dst_pitch_dw + g : -1;   // not the straddling group
         const float* src = inb[k] ? img + (ptrdiff_t)(y0 + r) * stride + x : img;
         v[k] = load4(src, 0, inb[k]);
       }
@@ -269,12 +269,12 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
     MN[y][0] = MN[y][1] = 0xffffffffu;
     MX[y][0] = MX[y][1] = 0u;
   }
-  // bit y*4+s: "all compared costs of pixel (y,s) were equal"; only the TY*4 bits of real pixels start set
-  u32 eq_lo = (TY * 4 >= 32) ? 0xffffffffu : ((1u << ((TY * 4) & 31)) - 1u);
-  u32 eq_hi = (TY * 4 >= 64) ? 0xffffffffu : ((TY * 4 > 32) ? ((1u << ((TY * 4 - 32) & 31)) - 1u) : 0u);
+  // bit y: "in every probed step pair, some in-image pixel of this lane's row y had two equal costs".  A superset of
+  // the rows that hold an invalid pixel (all costs equal), kept per row rather than per pixel: one min tree and one
+  // bit per row is all the bookkeeping a probe costs.  On noise one pixel pair is equal with p ~ 7e-4, so a row of 4
+  // survives NPROBE = 4 probes with ~6e-11; a flat (truly invalid) pixel always passes.
+  u32 eq_rows = (1u << TY) - 1u;
   int eq_checks = 0;
-  // Probed step pairs: a pixel stays a candidate only if all NPROBE compared cost pairs were equal.  On noise one
-  // pair is equal with p ~ 7e-4, so 4 pairs leave ~2e-13 per pixel; a flat (truly invalid) pixel always passes.
   constexpr int NPROBE = 4;
   const u32 zero = 0;
 
@@ -396,12 +396,17 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
                   key_sub<0>(kinB[0], nB0, oB0); key_sub<1>(kinB[1], nB0, oB0);
                   key_sub<0>(kinB[2], nB1, oB1); key_sub<1>(kinB[3], nB1, oB1);
                   if (PROBE) {
-                    u32 ne_bits = 0;
-                    if ((kinA[0] ^ kinB[0]) >> 16) ne_bits |= 1u << ((y * 4 + 0) & 31);
-                    if ((kinA[1] ^ kinB[1]) >> 16) ne_bits |= 1u << ((y * 4 + 1) & 31);
-                    if ((kinA[2] ^ kinB[2]) >> 16) ne_bits |= 1u << ((y * 4 + 2) & 31);
-                    if ((kinA[3] ^ kinB[3]) >> 16) ne_bits |= 1u << ((y * 4 + 3) & 31);
-                    if (y * 4 < 32) eq_lo &= ~ne_bits; else eq_hi &= ~ne_bits;
+                    // cost fields differ <=> xor >= 2^16; pixels right of the image (zero padding: every cost equal)
+                    // must not count.  (volatile: the keys are rewritten in place by the SDWA subtractions, so these
+                    // reads must stay in program order or the compiler copies every key and spills the windows)
+                    u32 x[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                      asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x[i]) : "v"(kinA[i]), "v"(kinB[i]));
+                      x[i] = (q + i < ow) ? x[i] : 0xffffffffu;
+                    }
+                    const u32 m01 = x[0] < x[1] ? x[0] : x[1], m23 = x[2] < x[3] ? x[2] : x[3];
+                    if ((m01 < m23 ? m01 : m23) >> 16) eq_rows &= ~(1u << y);
                   }
                   umin3_acc(K[y][0], kinA[0], kinB[0]);
                   umin3_acc(K[y][1], kinA[1], kinB[1]);
@@ -452,51 +457,63 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
     return;
   }
   if (bad_acc != 0u) atomicOr(flag_set, 1);
-  // ---- epilogue 1: decode keys, store {dx, dy, VALID} in the PixelMask<Vector2i> layout -------------------
+  // ---- validity: only rows in which some pixel's probed costs were all equal can hold an invalid pixel -----------
+  u32 cand = eq_checks < NPROBE ? (1u << TY) - 1u : eq_rows;   // small search range: nothing is known -> every row
+  // rows outside the output image (zero padding: every cost equal) must not trigger the second sweep
 #pragma unroll
-  for (int y = 0; y < TY; ++y) {
-    const int oy = y0 + y;
-    if (oy >= oh) continue;
-    int32_t* orow = out + ((ptrdiff_t)oy * os + q) * 3;
-    int32_t v[12];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const u32 di = K[y][s] & 0xffffu;
-      int dx, dy;
-      if (sy == 1) { dx = (int)di; dy = 0; } else { dy = (int)(di / (u32)sx); dx = (int)(di - (u32)dy * (u32)sx); }
-      v[3 * s] = dx;
-      v[3 * s + 1] = dy;
-      v[3 * s + 2] = 0x7fffffff;
-    }
-    if (q + 3 < ow) {
-#pragma unroll
-      for (int i = 0; i < 12; ++i) orow[i] = v[i];
-    } else {
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        if (q + s < ow) { orow[3 * s] = v[3 * s]; orow[3 * s + 1] = v[3 * s + 1]; orow[3 * s + 2] = v[3 * s + 2]; }
-    }
-  }
+  for (int y = 0; y < TY; ++y)
+    if (y0 + y >= oh || q >= ow) cand &= ~(1u << y);
+  const int any = __syncthreads_or(cand != 0u);     // never set on textured imagery; also: the entry array is free now
+  if (tid == 0) need_fix[wg] = any;
 
-  // ---- validity: only pixels whose probed costs were all equal can be invalid ---------------------------------
-  static_assert(TY * 4 <= 64, "equality bitmap holds 64 pixels per lane");
-  u32 cand_lo = eq_lo, cand_hi = eq_hi;
-  if (eq_checks < NPROBE) {                         // small search range: nothing is known -> every real pixel
-    cand_lo = (TY * 4 >= 32) ? 0xffffffffu : ((1u << ((TY * 4) & 31)) - 1u);
-    cand_hi = (TY * 4 >= 64) ? 0xffffffffu : ((TY * 4 > 32) ? ((1u << ((TY * 4 - 32) & 31)) - 1u) : 0u);
-  }
-  // pixels outside the output image (zero padding: every cost equal) must not trigger the second sweep
+  // ---- epilogue: decode keys, store {dx, dy, VALID} in the PixelMask<Vector2i> layout ----------------------------
+  // A lane owns 4 pixels = 12 consecutive dwords, so direct stores would be 48-byte strided (measured: 80 us of the
+  // 400 on the 4096^2 case).  Each wave transposes its 256-pixel row (768 dwords) through LDS and writes it as
+  // three fully coalesced 1 KiB stores.
+  {
+    const int wv = tid >> 6, lane = tid & 63;
+    u32* ob = ent + (size_t)wv * 768;
+    const int xw = x0 + 256 * wv;
+    int nd = (ow - xw) * 3;                         // dwords of this wave's row segment inside the image
+    nd = nd < 0 ? 0 : (nd > 768 ? 768 : nd);
+    // di / sx for di < 2^16 as a multiply-high by ceil(2^32 / sx) (exact: di * (magic * sx - 2^32) < 2^32); sx == 1 apart
+    const u32 sx_magic = sx > 1 ? (u32)(0xffffffffu / (u32)sx) + 1u : 0u;
+    struct __attribute__((packed, aligned(4))) U4 { u32 x, y, z, w; };
 #pragma unroll
-  for (int y = 0; y < TY; ++y) {
+    for (int y = 0; y < TY; ++y) {
+      const int oy = y0 + y;
+      if (oy >= oh) continue;
+      u32 v[12];
 #pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) {
-      if (y0 + y >= oh || q + s2 >= ow) {
-        if (y * 4 + s2 < 32) cand_lo &= ~(1u << ((y * 4 + s2) & 31)); else cand_hi &= ~(1u << ((y * 4 + s2) & 31));
+      for (int s = 0; s < 4; ++s) {
+        const u32 di = K[y][s] & 0xffffu;
+        u32 dx, dy;
+        if (sy == 1) { dx = di; dy = 0; }
+        else { dy = sx == 1 ? di : __umulhi(di, sx_magic); dx = di - dy * (u32)sx; }
+        v[3 * s] = dx;
+        v[3 * s + 1] = dy;
+        v[3 * s + 2] = 0x7fffffffu;
+      }
+      uint4* ow4 = reinterpret_cast<uint4*>(ob + lane * 12);
+      ow4[0] = make_uint4(v[0], v[1], v[2], v[3]);
+      ow4[1] = make_uint4(v[4], v[5], v[6], v[7]);
+      ow4[2] = make_uint4(v[8], v[9], v[10], v[11]);
+      int32_t* orow = out + ((ptrdiff_t)oy * os + xw) * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int idx = k * 256 + lane * 4;
+        const uint4 t = *reinterpret_cast<const uint4*>(ob + idx);
+        if (idx + 3 < nd) {
+          U4 u; u.x = t.x; u.y = t.y; u.z = t.z; u.w = t.w;
+          *reinterpret_cast<U4*>(orow + idx) = u;
+        } else {
+          if (idx < nd) orow[idx] = (int32_t)t.x;
+          if (idx + 1 < nd) orow[idx + 1] = (int32_t)t.y;
+          if (idx + 2 < nd) orow[idx + 2] = (int32_t)t.z;
+        }
       }
     }
   }
-  const int any = __syncthreads_or((cand_lo | cand_hi) != 0u);   // never set on textured imagery
-  if (tid == 0) need_fix[wg] = any;
 }
 
 typedef void (*KernelFn)(const float*, ptrdiff_t, int, int, const float*, ptrdiff_t, int, int, int, int, int,
