@@ -290,12 +290,7 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
         const int a_last = (sx + 2 - t) >> 2;       // last step with any valid slot
         __syncthreads();                            // base staged / previous phase's readers done
         {
-          const int total = NR * ne;
-          const float inv = 1.0f / (float)ne;
-#pragma unroll 4
-          for (int idx = tid; idx < total; idx += C::THREADS) {
-            int r, m;
-            divmod_small(idx, ne, inv, r, m);
+          auto build = [&](int r, int m) __attribute__((always_inline)) {
             const u32* bp = base + (size_t)r * bpitch + m;
             u32 b[NW + 1];
 #pragma unroll
@@ -306,9 +301,20 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
 #pragma unroll
             for (int n = 0; n < NW; ++n) w[n] = __builtin_amdgcn_alignbyte(b[n + 1], b[n], t);
             w[NW - 1] &= C::LAST_MASK;
-            u32* e = ent + (size_t)idx * EW;
+            u32* e = ent + ((size_t)r * ne + m) * EW;
             if (EW == 2) *reinterpret_cast<uint2*>(e) = make_uint2(w[0], w[1]);
             else *reinterpret_cast<uint4*>(e) = make_uint4(w[0], w[1], w[2 % EW], w[3 % EW]);
+          };
+          // entries 0..THREADS-1 of every row: column = tid, no index arithmetic (ne > THREADS always)
+#pragma unroll 4
+          for (int r = 0; r < NR; ++r) build(r, tid);
+          // the search margin: NR * (ne - THREADS) entries spread over the workgroup
+          const int rem = ne - C::THREADS, total = NR * rem;
+          const float inv = 1.0f / (float)rem;
+          for (int idx = tid; idx < total; idx += C::THREADS) {
+            int r, m;
+            divmod_small(idx, rem, inv, r, m);
+            build(r, C::THREADS + m);
           }
         }
         __syncthreads();
