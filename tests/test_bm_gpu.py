@@ -27,6 +27,17 @@ def ctx(torch_cuda):
     c.close()
 
 
+@pytest.fixture(params=["auto", "one-group"])
+def sad_variant(request, monkeypatch):
+    """Small images run the packed-u8 matcher with two wave groups per tile (the launcher's choice for grids that do not
+    fill the chip); VWGPU_SAD_SPLIT=0 forces the one-group kernel the full-size case uses, so both see every case."""
+    if request.param == "one-group":
+        monkeypatch.setenv("VWGPU_SAD_SPLIT", "0")
+    else:
+        monkeypatch.delenv("VWGPU_SAD_SPLIT", raising=False)
+    return request.param
+
+
 def _gpu(ctx, cost, left, right, kernel, search, path=core.PATH_NONE, device=True):
     from visionworkbench_amd import stereo
     import torch
@@ -96,7 +107,7 @@ def test_parity_vs_oracle_integer_inputs(ctx, oracle, w, h, kernel, search, cost
 
 
 @pytest.mark.parametrize("w,h,kernel,search", [c for c in CASES if c[2] != (13, 15)])
-def test_packed_u8_path_is_used_and_equals_generic(ctx, oracle, w, h, kernel, search):
+def test_packed_u8_path_is_used_and_equals_generic(ctx, oracle, sad_variant, w, h, kernel, search):
     left, right, _ = synth.stereo_pair(w, h, search[0], search[1], block=32, seeds=(31, 32, 33), smooth=True)
     fast, p_fast = _gpu(ctx, ABS, left, right, kernel, search, path=core.PATH_SAD_U8)
     gen, p_gen = _gpu(ctx, ABS, left, right, kernel, search, path=core.PATH_GENERIC_F64)
@@ -106,7 +117,7 @@ def test_packed_u8_path_is_used_and_equals_generic(ctx, oracle, w, h, kernel, se
     assert np.array_equal(fast, want), "mismatching pixels: %d" % int((fast != want).any(-1).sum())
 
 
-def test_ties_and_flat_regions(ctx, oracle):
+def test_ties_and_flat_regions(ctx, oracle, sad_variant):
     """Many exact ties and constant areas: first-wins tie-breaking and best==worst invalidation."""
     rng = np.random.RandomState(5)
     left = (rng.randint(0, 3, (60, 140)) * 100).astype(np.float32)
@@ -161,7 +172,7 @@ def test_non_integer_input_falls_back_to_generic(ctx, oracle):
         assert p == core.PATH_GENERIC_F64
 
 
-def test_strided_region_crop(ctx, oracle):
+def test_strided_region_crop(ctx, oracle, sad_variant):
     """calc_disparity with a left_region inside a larger image (Correlation.cc:356-359 crops)."""
     import torch
     from visionworkbench_amd import stereo

@@ -39,6 +39,7 @@
 //
 // Limits (else the generic path): SAD only; kernel sizes in kLaunch; 4*ceil(kx/4)*ky*255 < 65536;
 // sx*sy <= 65535; LDS footprint <= 80 KiB.
+#include <cstdlib>
 #include <type_traits>
 
 #include "vwgpu_internal.h"
@@ -221,8 +222,13 @@ __device__ __forceinline__ void divmod_small(int idx, int d, float inv, int& quo
 //               invalid).  FIX = true: the validity fix-up launched right after it; workgroups whose need_fix
 //               entry is clear return at once, the others recompute packed best/worst costs and invalidate
 //               pixels with best == worst (Correlation.cc:121-133).
-template <int KX, int KY, int TY, bool FIX>
-__global__ void __launch_bounds__((KX <= 8 ? 256 : 128), (TY <= 8 && KX <= 8 ? 3 : 2))
+// SPLIT: for grids too small to give every SIMD two waves (a 1/8 row strip of the 4096^2 case is 256 eight-row tiles):
+//        the workgroup has TWO wave groups on the same tile.  Both hold the LEFT windows; wave w of group 0 and wave w
+//        of group 1 cover the same pixels and sit on the same SIMD, draw the step items of a phase from a shared LDS
+//        counter (the arbiter favours the older wave, so a fixed split would leave one group waiting), and the partial
+//        keys are merged through LDS at the end of the tile — a key minimum is order independent.
+template <int KX, int KY, int TY, bool FIX, bool SPLIT>
+__global__ void __launch_bounds__((SPLIT ? 2 : 1) * (KX <= 8 ? 256 : 128), (SPLIT ? 1 : (TY <= 8 && KX <= 8 ? 3 : 2)))
 bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
                  const float* __restrict__ R, ptrdiff_t rs, int rcw, int rch,
                  int sx, int sy, int ne, int32_t* __restrict__ out, ptrdiff_t os, int ow, int oh,
@@ -234,8 +240,15 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   u32* ent = lds;                                   // [NR][ne][EW]   word groups of the current byte phase
   const int bpitch = ne + NW + 1;                   // dwords per row of the RIGHT u8 base tile
   u32* base = lds + (size_t)NR * ne * EW;           // [NR][bpitch]
+  u32* item_ctr = base + (size_t)NR * bpitch;       // SPLIT: one work item counter per wave pair
+  static_assert(!(FIX && SPLIT), "the fix-up sweep is not split");
 
+  constexpr int PT = C::THREADS;                    // threads that map to pixels
+  constexpr int NT = SPLIT ? 2 * PT : PT;           // threads of the workgroup
   const int tid = threadIdx.x;
+  const int grp = SPLIT ? __builtin_amdgcn_readfirstlane(tid / PT) : 0;    // wave-uniform
+  const int ltid = SPLIT ? tid % PT : tid;
+  const int pair_id = __builtin_amdgcn_readfirstlane(ltid >> 6);
   // XCD-aware tile order: workgroup i runs on XCD i % 8 (round-robin dispatch), so XCD x takes the contiguous band of
   // tiles [x * per, (x + 1) * per) — whole tile rows in raster order.  Tiles that share halo rows (ky-1 of TY+ky-1) or
   // output cache lines are then staged at the same time behind the same L2 instead of being fetched once per XCD
@@ -245,7 +258,7 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   if (wg >= ntiles) return;                         // grid rounded up to a multiple of 8
   const int x0 = (wg % gxt) * C::TWB;
   const int y0 = (wg / gxt) * TY;
-  const int q = x0 + 4 * tid;                       // first of the lane's 4 output pixels
+  const int q = x0 + 4 * ltid;                      // first of the lane's 4 output pixels
   u32 bad_acc = 0;                                  // non-zero: some input pixel is not an integer in [0,255]
   if (FIX) {
     if (need_fix[wg] == 0) return;                  // workgroup-uniform
@@ -255,15 +268,15 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
 
   // ---- LEFT: float tile -> u8 in LDS (borrowing the entry array) -> per-lane register windows ----
   // Both tiles are staged before anything else is live in registers (the LEFT tile borrows the entry array).
-  stage_u8_rows<NR>(L, ls, lw, lh, x0, y0, C::LBW, C::LBW, ent, tid, C::THREADS, bad_acc);
-  stage_u8_rows<NR>(R, rs, rcw, rch, x0, y0, bpitch, bpitch, base, tid, C::THREADS, bad_acc);
+  stage_u8_rows<NR>(L, ls, lw, lh, x0, y0, C::LBW, C::LBW, ent, tid, NT, bad_acc);
+  stage_u8_rows<NR>(R, rs, rcw, rch, x0, y0, bpitch, bpitch, base, tid, NT, bad_acc);
   __syncthreads();
   u64 win[NR][NW];                                  // win[r][n] = bytes L[q+4n .. q+4n+7]
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     u32 a[NW + 1];
 #pragma unroll
-    for (int n = 0; n <= NW; ++n) a[n] = ent[r * C::LBW + tid + n];
+    for (int n = 0; n <= NW; ++n) a[n] = ent[r * C::LBW + ltid + n];
 #pragma unroll
     for (int n = 0; n < NW; ++n) win[r][n] = (u64)a[n] | ((u64)a[n + 1] << 32);
   }
@@ -292,7 +305,7 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
     constexpr bool MAXSWEEP = FIX;
     for (int dy = 0; dy < sy; ++dy) {
       __syncthreads();                              // everyone is done with the previous base tile / windows
-      if (dy > 0) stage_u8_rows<NR>(R, rs, rcw, rch, x0, y0 + dy, bpitch, bpitch, base, tid, C::THREADS, bad_acc);
+      if (dy > 0) stage_u8_rows<NR>(R, rs, rcw, rch, x0, y0 + dy, bpitch, bpitch, base, tid, NT, bad_acc);
       for (int t = 0; t < 4; ++t) {
         const int a_last = (sx + 2 - t) >> 2;       // last step with any valid slot
         __syncthreads();                            // base staged / previous phase's readers done
@@ -312,17 +325,19 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
             if (EW == 2) *reinterpret_cast<uint2*>(e) = make_uint2(w[0], w[1]);
             else *reinterpret_cast<uint4*>(e) = make_uint4(w[0], w[1], w[2 % EW], w[3 % EW]);
           };
-          // entries 0..THREADS-1 of every row: column = tid, no index arithmetic (ne > THREADS always)
+          // entries 0..PT-1 of every row: column = ltid, no index arithmetic (ne > PT always); SPLIT: rows alternate
+          // between the two wave groups
 #pragma unroll 4
-          for (int r = 0; r < NR; ++r) build(r, tid);
-          // the search margin: NR * (ne - THREADS) entries spread over the workgroup
-          const int rem = ne - C::THREADS, total = NR * rem;
+          for (int r = grp; r < NR; r += NT / PT) build(r, ltid);
+          // the search margin: NR * (ne - PT) entries spread over the workgroup
+          const int rem = ne - PT, total = NR * rem;
           const float inv = 1.0f / (float)rem;
-          for (int idx = tid; idx < total; idx += C::THREADS) {
+          for (int idx = tid; idx < total; idx += NT) {
             int r, m;
             divmod_small(idx, rem, inv, r, m);
-            build(r, C::THREADS + m);
+            build(r, PT + m);
           }
+          if (SPLIT && tid < PT / 64) item_ctr[tid] = 0u;
         }
         __syncthreads();
 
@@ -346,7 +361,7 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
               if (d < 0 || d >= sx) orA[i >> 1] |= (i & 1) ? 0xffff0000u : 0x0000ffffu;
             }
           }
-          const u32* ep = ent + (size_t)(tid + a) * EW;
+          const u32* ep = ent + (size_t)(ltid + a) * EW;
           u64 accA = 0, accB = 0;
           u64 PA[NR], PB[NR];
           // LDS reads are issued PF rows ahead by hand: the volatile asm statements below are scheduling barriers
@@ -446,13 +461,30 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
         int a_hi = (sx - 1 - t >= 0) ? ((sx - 1 - t) >> 2) + 1 : 0;   // exclusive
         if (a_hi > a_last + 1) a_hi = a_last + 1;
         if (a_lo > a_hi) a_lo = a_hi;
-        int a = 0;
-        for (; a < a_lo && a <= a_last; ++a) step(a, T{}, F{}, F{});
-        if (!MAXSWEEP && dy == 0 && t == 0) {
-          for (; a + 1 < a_hi && eq_checks < NPROBE; a += 2, ++eq_checks) step(a, F{}, T{}, T{});
-        }
-        for (; a + 1 < a_hi; a += 2) step(a, F{}, T{}, F{});
-        for (; a <= a_last; ++a) step(a, T{}, F{}, F{});
+        // The phase as a list of work items: [n1 masked singles][npair pairs, the first nprobe probed][n4 masked singles].
+        const int n1 = a_lo;
+        const int npair = (a_hi - n1) > 0 ? (a_hi - n1) >> 1 : 0;
+        int nprobe = 0;
+        if (!MAXSWEEP && dy == 0 && t == 0) nprobe = npair < NPROBE - eq_checks ? npair : NPROBE - eq_checks;
+        const int a4 = n1 + 2 * npair;
+        const int n4 = a_last - a4 + 1 > 0 ? a_last - a4 + 1 : 0;
+        const int nitems = n1 + npair + n4;
+        int seq = 0;
+        auto next_item = [&]() __attribute__((always_inline)) -> int {
+          if (!SPLIT) return seq++;
+          int lane, v = 0;
+          asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+          if (lane == 0) v = (int)atomicAdd(&item_ctr[pair_id], 1u);
+          return __builtin_amdgcn_readfirstlane(v);
+        };
+        // item indices only grow, so a wave walks the four loops in order (one loop per step flavour keeps the register
+        // allocation of the hot pair loop)
+        int i = next_item();
+        for (; i < n1; i = next_item()) step(i, T{}, F{}, F{});
+        for (; i < n1 + nprobe; i = next_item()) step(n1 + 2 * (i - n1), F{}, T{}, T{});
+        for (; i < n1 + npair; i = next_item()) step(n1 + 2 * (i - n1), F{}, T{}, F{});
+        for (; i < nitems; i = next_item()) step(a4 + (i - n1 - npair), T{}, F{}, F{});
+        eq_checks += nprobe;
       }
     }
   }
@@ -470,12 +502,42 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
     return;
   }
   if (bad_acc != 0u) atomicOr(flag_set, 1);
+  // ---- SPLIT: merge the two wave groups.  Group 0 finishes rows [0,TY/2), group 1 rows [TY/2,TY): each hands the
+  // other its partial keys of the other's rows (and its equality bits) through the entry array, free by now.
+  auto row_mine = [&](int y) __attribute__((always_inline)) -> bool { return !SPLIT || ((y >= TY / 2) == (grp == 1)); };
+  if (SPLIT) {
+    u32* xk = ent;                                  // [TY/2][4][PT] keys, then [PT] equality words
+    u32* xe = ent + (TY / 2) * 4 * PT;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {       // round 0: group 1 -> group 0 (upper rows), round 1: the reverse
+      const int src = 1 - round, ybase = round * (TY / 2);
+      __syncthreads();                              // steps done / previous round read
+      if (grp == src) {
+#pragma unroll
+        for (int y = 0; y < TY / 2; ++y)
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) xk[(y * 4 + s2) * PT + ltid] = K[ybase + y][s2];
+        xe[ltid] = eq_rows;
+      }
+      __syncthreads();
+      if (grp != src) {
+#pragma unroll
+        for (int y = 0; y < TY / 2; ++y)
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) {
+            const u32 o = xk[(y * 4 + s2) * PT + ltid];
+            K[ybase + y][s2] = o < K[ybase + y][s2] ? o : K[ybase + y][s2];
+          }
+        eq_rows &= xe[ltid];                        // round 1 hands the AND of both back, so both groups agree
+      }
+    }
+  }
   // ---- validity: only rows in which some pixel's probed costs were all equal can hold an invalid pixel -----------
   u32 cand = eq_checks < NPROBE ? (1u << TY) - 1u : eq_rows;   // small search range: nothing is known -> every row
   // rows outside the output image (zero padding: every cost equal) must not trigger the second sweep
 #pragma unroll
   for (int y = 0; y < TY; ++y)
-    if (y0 + y >= oh || q >= ow) cand &= ~(1u << y);
+    if (y0 + y >= oh || q >= ow || !row_mine(y)) cand &= ~(1u << y);
   const int any = __syncthreads_or(cand != 0u);     // never set on textured imagery; also: the entry array is free now
   if (tid == 0) need_fix[wg] = any;
 
@@ -484,8 +546,8 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   // 400 on the 4096^2 case).  Each wave transposes its 256-pixel row (768 dwords) through LDS and writes it as
   // three fully coalesced 1 KiB stores.
   {
-    const int wv = tid >> 6, lane = tid & 63;
-    u32* ob = ent + (size_t)wv * 768;
+    const int wv = ltid >> 6, lane = ltid & 63;
+    u32* ob = ent + (size_t)(grp * (PT / 64) + wv) * 768;
     const int xw = x0 + 256 * wv;
     int nd = (ow - xw) * 3;                         // dwords of this wave's row segment inside the image
     nd = nd < 0 ? 0 : (nd > 768 ? 768 : nd);
@@ -495,7 +557,7 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
 #pragma unroll
     for (int y = 0; y < TY; ++y) {
       const int oy = y0 + y;
-      if (oy >= oh) continue;
+      if (oy >= oh || !row_mine(y)) continue;
       u32 v[12];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -535,13 +597,15 @@ struct Launch {
   int kx, ky, ty;
   int threads, twb, nr, ew, nw;
   KernelFn fn, fix_fn;
+  KernelFn split_fn;         // the two-wave-group matcher for small grids (nullptr: not instantiated for this size)
 };
 
-template <int KX, int KY, int TY>
+template <int KX, int KY, int TY, bool WITH_SPLIT = false>
 constexpr Launch make_launch() {
   typedef Cfg<KX, KY, TY> C;
   return Launch{KX, KY, TY, C::THREADS, C::TWB, C::NR, C::EW, C::NW,
-                bm_sad_u8_kernel<KX, KY, TY, false>, bm_sad_u8_kernel<KX, KY, TY, true>};
+                bm_sad_u8_kernel<KX, KY, TY, false, false>, bm_sad_u8_kernel<KX, KY, TY, true, false>,
+                WITH_SPLIT ? bm_sad_u8_kernel<KX, KY, TY, false, WITH_SPLIT> : nullptr};
 }
 
 // Instantiated kernel sizes.  Others fall back to the generic path.
@@ -551,7 +615,7 @@ constexpr Launch make_launch() {
 // small images / multi-GPU strips use 8-row tiles when 16-row tiles would leave fewer than 2 workgroups per CU
 // (tools/time_strips.py: 1/4 strip 137 -> 128 us, 1/8 strip 128 -> 84 us; 4-row tiles never win — 10/4 halo rows).
 const Launch kLaunch[] = {
-    make_launch<3, 3, 16>(), make_launch<5, 5, 16>(), make_launch<7, 7, 16>(), make_launch<7, 7, 8>(),
+    make_launch<3, 3, 16>(), make_launch<5, 5, 16>(), make_launch<7, 7, 16>(), make_launch<7, 7, 8, true>(),
     make_launch<7, 5, 16>(), make_launch<9, 9, 12>(), make_launch<11, 11, 8>(),
 };
 
@@ -563,14 +627,18 @@ const Launch* find_launch(int kx, int ky) {
 }
 
 // the tallest tile that still yields >= 2 workgroups per CU; the shortest one otherwise
-const Launch* pick_launch(int kx, int ky, int ow, int oh, int num_cu) {
+// *split: not even the shortest tile yields 2 workgroups per CU -> run its two-wave-group variant if there is one
+const Launch* pick_launch(int kx, int ky, int ow, int oh, int num_cu, bool* split) {
   const Launch* last = nullptr;
+  *split = false;
   for (const Launch& l : kLaunch) {
     if (l.kx != kx || l.ky != ky) continue;
     last = &l;
     const long long wgs = (long long)((ow + l.twb - 1) / l.twb) * ((oh + l.ty - 1) / l.ty);
     if (wgs >= 2LL * num_cu) return &l;
   }
+  *split = last && last->split_fn;
+  if (const char* force = getenv("VWGPU_SAD_SPLIT")) *split = last && last->split_fn && force[0] == '1';   // testing aid
   return last;
 }
 
@@ -603,7 +671,8 @@ int vwgpu_launch_bm_sad_u8(vwgpu_ctx* ctx,
                            int** d_fallback_flag) {
   (void)rw; (void)rh;
   const int ow = lw - kx + 1, oh = lh - ky + 1;
-  const Launch* l = pick_launch(kx, ky, ow, oh, ctx->num_cu);
+  bool split = false;
+  const Launch* l = pick_launch(kx, ky, ow, oh, ctx->num_cu, &split);
   if (!l) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "no packed-u8 kernel for %dx%d", kx, ky);
   const int rcw = lw + sx - 1, rch = lh + sy - 1;
   const int gx = (ow + l->twb - 1) / l->twb, gy = (oh + l->ty - 1) / l->ty;
@@ -624,17 +693,18 @@ int vwgpu_launch_bm_sad_u8(vwgpu_ctx* ctx,
   ctx->flag_parity ^= 1;
   int* need_fix = flags + 64;                       // one int per workgroup, written by every matcher launch
   *d_fallback_flag = flag_set;
-  const size_t shmem = lds_bytes(*l, sx);
+  const size_t shmem = lds_bytes(*l, sx) + (split ? 64 : 0);   // + the item counters of the split variant
+  const KernelFn main_fn = split ? l->split_fn : l->fn;
   const unsigned grid1 = (unsigned)((gx * gy + 7) / 8 * 8);   // one tile per workgroup, see the XCD note in the kernel
   if (shmem > 64 * 1024) {
-    VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(l->fn),
+    VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(main_fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(l->fix_fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   }
   {
     vwgpu_prof_scope ps(ctx, "bm_sad_u8");
-    hipLaunchKernelGGL(l->fn, dim3(grid1), dim3(l->threads), shmem, ctx->stream,
+    hipLaunchKernelGGL(main_fn, dim3(grid1), dim3(split ? 2 * l->threads : l->threads), shmem, ctx->stream,
                        left, ls, lw, lh, right, rs, rcw, rch, sx, sy, ne, out, os, ow, oh,
                        flag_set, flag_clear, need_fix, gx, gx * gy);
   }
