@@ -262,6 +262,37 @@ def test_full_size_config2_sampled_parity(ctx, oracle):
     assert (got[..., 0] == t).mean() > 0.9
 
 
+@pytest.mark.parametrize("rows,variant", [(1028, None), (517, None), (1028, "0"), (2051, "1")])
+def test_row_strip_sizes_sampled_parity(ctx, oracle, monkeypatch, rows, variant):
+    """The strips a 4096^2 pair is cut into on 4 and 8 GPUs (and the tile-height / wave-group variants the launcher picks
+    for them: 16-row two-group tiles for 1/4, 8-row two-group tiles for 1/8; the env pins the other flavour): full-width
+    strip on the GPU, the oracle on sampled padded crops, bit for bit."""
+    import torch
+    from visionworkbench_amd import stereo
+    if variant is None:
+        monkeypatch.delenv("VWGPU_SAD_SPLIT", raising=False)
+    else:
+        monkeypatch.setenv("VWGPU_SAD_SPLIT", variant)
+    W = 4096
+    left, right, _ = synth.stereo_pair(W, rows, 129, 1)
+    lt, rt = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    got = stereo.calc_disparity(ABS, lt, rt, vwa.bounding_box(left), (129, 1), (7, 7), ctx=ctx)
+    torch.cuda.synchronize()
+    assert ctx.last_path() == core.PATH_SAD_U8
+    got = got.cpu().numpy()
+    oh = rows - 6
+    assert got.shape == (oh, 4090, 3)
+    rng = np.random.RandomState(rows)
+    spots = [(0, 0), (4090 - 96, oh - 48), (1000, oh - 48), (4090 - 96, 3), (1020, 5)] + \
+            [(int(rng.randint(0, 4090 - 96)), int(rng.randint(0, oh - 48))) for _ in range(5)]
+    for (x, y) in spots:
+        tw, th = 96, 48
+        want = oracle.calc_disparity(ABS, left[y:y + th + 6, x:x + tw + 6], right[y:y + th + 6, x:x + tw + 6 + 128],
+                                     (7, 7), (129, 1))
+        assert np.array_equal(got[y:y + th, x:x + tw], want), (x, y)
+    assert (got[..., 2] == core.VALID_I32).mean() > 0.999
+
+
 # ---- packed dot-product path (SSD / NCC on integer-valued data) ----------------------------------------------------------
 
 @pytest.mark.parametrize("cost", [1, 2])

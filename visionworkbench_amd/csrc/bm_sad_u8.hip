@@ -615,7 +615,7 @@ constexpr Launch make_launch() {
 // small images / multi-GPU strips use 8-row tiles when 16-row tiles would leave fewer than 2 workgroups per CU
 // (tools/time_strips.py: 1/4 strip 137 -> 128 us, 1/8 strip 128 -> 84 us; 4-row tiles never win — 10/4 halo rows).
 const Launch kLaunch[] = {
-    make_launch<3, 3, 16>(), make_launch<5, 5, 16>(), make_launch<7, 7, 16>(), make_launch<7, 7, 8, true>(),
+    make_launch<3, 3, 16>(), make_launch<5, 5, 16>(), make_launch<7, 7, 16, true>(), make_launch<7, 7, 8, true>(),
     make_launch<7, 5, 16>(), make_launch<9, 9, 12>(), make_launch<11, 11, 8>(),
 };
 
@@ -626,20 +626,34 @@ const Launch* find_launch(int kx, int ky) {
   return nullptr;
 }
 
-// the tallest tile that still yields >= 2 workgroups per CU; the shortest one otherwise
-// *split: not even the shortest tile yields 2 workgroups per CU -> run its two-wave-group variant if there is one
+// Picks tile height and one- or two-group matcher by a small cost model of the busiest CU (units = tile rows of step
+// work on a saturated SIMD pair; constants from tools/time_strips.py and the in-kernel timeline of DESIGN.md 4.1):
+//   n        tiles on the busiest CU = ceil(workgroups / CUs)
+//   steps    one group : rows * 0.5 * n when >= 2 tiles share the SIMDs, rows * 0.74 for a lone 4-wave workgroup (one wave
+//                        per SIMD reaches ~2/3 of the issue rate);  two groups: rows * 0.55 * n (8 waves on one tile)
+//   rounds   sequential staging / output phases: ceil(n / resident) for one group, n for two; ~4.5 row-units each
+// 4096^2: 16-row tiles, one group (4 per CU).  1/4 strip: 16-row tiles, two groups (exactly one per CU; 8-row tiles would
+// put a third tile on a few CUs).  1/8 strip: 8-row tiles, two groups.
 const Launch* pick_launch(int kx, int ky, int ow, int oh, int num_cu, bool* split) {
-  const Launch* last = nullptr;
+  const Launch* best = nullptr;
+  double best_cost = 0.0;
   *split = false;
+  const char* force = getenv("VWGPU_SAD_SPLIT");    // testing aid: "0" / "1" pin the matcher flavour
   for (const Launch& l : kLaunch) {
     if (l.kx != kx || l.ky != ky) continue;
-    last = &l;
     const long long wgs = (long long)((ow + l.twb - 1) / l.twb) * ((oh + l.ty - 1) / l.ty);
-    if (wgs >= 2LL * num_cu) return &l;
+    const double n = (double)((wgs + num_cu - 1) / num_cu);
+    const int resident = (l.ty <= 8 && l.kx <= 8) ? 3 : 2;
+    for (int sp = 0; sp < 2; ++sp) {
+      if (sp && !l.split_fn) continue;
+      if (force && l.split_fn && (force[0] == '1') != (sp == 1)) continue;
+      const double steps = sp ? l.nr * 0.55 * n : (n < 2.0 ? l.nr * 0.74 : l.nr * 0.5 * n);
+      const double rounds = sp ? n : (double)(((long long)n + resident - 1) / resident);
+      const double cost = steps + 4.5 * rounds;
+      if (!best || cost < best_cost) { best = &l; best_cost = cost; *split = sp != 0; }
+    }
   }
-  *split = last && last->split_fn;
-  if (const char* force = getenv("VWGPU_SAD_SPLIT")) *split = last && last->split_fn && force[0] == '1';   // testing aid
-  return last;
+  return best;
 }
 
 constexpr size_t kMaxLds = 80 * 1024;   // two workgroups per CU
