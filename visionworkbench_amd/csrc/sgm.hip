@@ -22,6 +22,7 @@
 #include <cmath>
 #include <vector>
 
+#include <cstdlib>
 #include "vwgpu_internal.h"
 
 namespace {
@@ -638,7 +639,13 @@ path_uniform_pk_kernel(SgmGeom g, DirSet D, int K, int stride,
         if (w < npairs) {
           unsigned v = cacc[j];
           if (2 * w + 1 >= num_disp) v &= 0xffffu;
+#ifdef VWX_PLAINADD
+          ga[pbase * q32 + j + (long long)k * (delta - 1) * q32] += v;
+#elif defined(VWX_NOADD)
+          if (v == 0x12345678u) ga[0] = v;
+#else
           atomicAdd(ga + pbase * q32 + j + (long long)k * (delta - 1) * q32, v);
+#endif
         }
       }
     }
@@ -963,8 +970,11 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     // all 8 directions in one launch when the packed 16-bit atomics cannot carry; one launch per direction otherwise
     const bool together = 8 * (255 + std::max(p1, p2)) < 65536;
     const int ept = (int)((num_disp + 63) / 64);
-    int K = 12288 / (3 * ustride);
-    K = std::max(1, std::min(K, 32));
+    // pixels per staged chunk: small chunks keep the LDS footprint of a one-wave workgroup near 4 KB, so ~30 of them fit
+    // a CU — the per-pixel recurrence is a serial LDS / DPP chain that only occupancy hides (2048^2, D = 129: 10.7 ms
+    // with 28-pixel chunks, 8.8 ms with 8..12)
+    int K = 4096 / (3 * ustride);
+    K = std::max(4, std::min(K, 32));
     const size_t ulds = ((size_t)ept * 64 + 256) * sizeof(uint16_t) + (size_t)K * ustride * 3 + K + 16;
     const bool one_d = g.num_dy == 1;
     for (int first = 0; first < 8; first += together ? 8 : 1) {
