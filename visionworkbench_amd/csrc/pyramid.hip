@@ -13,6 +13,7 @@
 //   zone refinement           CorrelationView.cc:754-799  subdivide_regions (zones.hip), x2, expand(2), crop
 //   result                    CorrelationView.cc:876-885  + search_region.min(), cast to PixelMask<Vector2f>
 // Not covered: SGM/MGM branches (:391-595), blob filter (blob_filter_area > 0), lr_disp_diff output, collar.
+#include <climits>
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -278,6 +279,43 @@ int vwgpu_launch_disparity_mask(vwgpu_ctx* ctx, int32_t* d, int w, int h, const 
   return VWGPU_OK;
 }
 
+// Zone scheduler, device part: one wave per leaf box of the quad tree measures the element-wise min / max of the VALID
+// disparities inside the box and inside the box grown by 1 px (clipped to the image) — what subdivide_regions reads
+// (Correlation.cc:149-171).  out: 10 ints per leaf (vwgpu::LeafExtent).
+__global__ void __launch_bounds__(64)
+zone_extent_kernel(const int32_t* __restrict__ disp, int w, int h, const int4* __restrict__ rects, int n, int32_t* __restrict__ out) {
+  const int leaf = blockIdx.x;
+  if (leaf >= n) return;
+  const int4 r = rects[leaf];                       // x0, y0, x1, y1
+  const int ax0 = max(r.x - 1, 0), ay0 = max(r.y - 1, 0), ax1 = min(r.z + 1, w), ay1 = min(r.w + 1, h);
+  const int aw = ax1 - ax0, count = aw * (ay1 - ay0);
+  int any = 0, lox = INT_MAX, loy = INT_MAX, hix = INT_MIN, hiy = INT_MIN;
+  int anya = 0, loxa = INT_MAX, loya = INT_MAX, hixa = INT_MIN, hiya = INT_MIN;
+  for (int i = threadIdx.x; i < count; i += 64) {
+    const int yy = i / aw, x = ax0 + (i - yy * aw), y = ay0 + yy;
+    const int32_t* p = disp + ((size_t)y * w + x) * 3;
+    if (!p[2]) continue;
+    const int dx = p[0], dy = p[1];
+    anya = 1; loxa = min(loxa, dx); hixa = max(hixa, dx); loya = min(loya, dy); hiya = max(hiya, dy);
+    if (x >= r.x && x < r.z && y >= r.y && y < r.w) {
+      any = 1; lox = min(lox, dx); hix = max(hix, dx); loy = min(loy, dy); hiy = max(hiy, dy);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    any |= __shfl_xor(any, o); anya |= __shfl_xor(anya, o);
+    lox = min(lox, __shfl_xor(lox, o)); loy = min(loy, __shfl_xor(loy, o));
+    hix = max(hix, __shfl_xor(hix, o)); hiy = max(hiy, __shfl_xor(hiy, o));
+    loxa = min(loxa, __shfl_xor(loxa, o)); loya = min(loya, __shfl_xor(loya, o));
+    hixa = max(hixa, __shfl_xor(hixa, o)); hiya = max(hiya, __shfl_xor(hiya, o));
+  }
+  if (threadIdx.x == 0) {
+    int32_t* o = out + (size_t)leaf * 10;
+    o[0] = any; o[1] = lox; o[2] = loy; o[3] = hix; o[4] = hiy;
+    o[5] = anya; o[6] = loxa; o[7] = loya; o[8] = hixa; o[9] = hiya;
+  }
+}
+
 // All pointers are device pointers (masks may be null).  out: bw x bh x 3 floats.
 int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t ls,
                                  const float* right, int rw, int rh, ptrdiff_t rs,
@@ -411,7 +449,8 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   SP.cost_type = P->cost_type; SP.use_mgm = 0; SP.kernel_size = kx; SP.subpixel_mode = P->sgm_subpixel_mode;
   SP.search_buffer_x = P->sgm_search_buffer_x; SP.search_buffer_y = P->sgm_search_buffer_y; SP.memory_limit_mb = P->memory_limit_mb;
   SP.p1 = 0; SP.p2 = 0; SP.ternary_census_threshold = 5; SP.num_threads = P->sgm_num_threads > 0 ? P->sgm_num_threads : 1;
-  std::vector<int32_t> host_disp;
+  std::vector<vwgpu::IBox> leaves;
+  std::vector<vwgpu::LeafExtent> leaf_ext;
   std::vector<SearchZone> zones;
   zones.push_back(SearchZone{IBox(0, 0, lmp[L].w, lmp[L].h), IBox(0, 0, search.width() / up + 1, search.height() / up + 1)});
   double estim = 0.0;
@@ -583,11 +622,26 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     }
     // zone refinement (:754-799): the scheduler is data dependent host logic
     if (!last && !use_sgm) {
-      host_disp.resize((size_t)dw * dh * 3);
-      VWGPU_HIP(ctx, hipMemcpyAsync(host_disp.data(), disp, host_disp.size() * 4, hipMemcpyDeviceToHost, st));
+      // The quad tree of boxes is fixed by (dw, dh): its leaves are measured on the device (box + 1-px neighbourhood),
+      // only that table comes back, and the accept / retry / merge recursion runs on it (zones.hip).
+      leaves.clear();
+      vwgpu::enumerate_leaves(dw, dh, leaves);
+      const size_t nleaf = leaves.size();
+      const size_t rect_bytes = vwgpu_align_up(nleaf * sizeof(int4), 256), ext_bytes = nleaf * sizeof(vwgpu::LeafExtent);
+      if ((rc = vwgpu_arena_reserve(ctx, &ctx->zext, rect_bytes + ext_bytes + 256))) return rc;
+      int4* d_rects = static_cast<int4*>(ctx->zext.base);
+      int32_t* d_ext = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->zext.base) + rect_bytes);
+      static_assert(sizeof(vwgpu::IBox) == sizeof(int4), "leaf boxes upload as int4");
+      VWGPU_HIP(ctx, hipMemcpyAsync(d_rects, leaves.data(), nleaf * sizeof(int4), hipMemcpyHostToDevice, st));
+      {
+        vwgpu_prof_scope ps(ctx, "zone_extents");
+        hipLaunchKernelGGL(zone_extent_kernel, dim3((unsigned)nleaf), dim3(64), 0, st, disp, dw, dh, d_rects, (int)nleaf, d_ext);
+      }
+      leaf_ext.resize(nleaf);
+      VWGPU_HIP(ctx, hipMemcpyAsync(leaf_ext.data(), d_ext, ext_bytes, hipMemcpyDeviceToHost, st));
       VWGPU_HIP(ctx, hipStreamSynchronize(st));
       zones.clear();
-      vwgpu::subdivide_regions(host_disp.data(), dw, dh, kx, ky, zones);
+      vwgpu::subdivide_regions_from_leaves(dw, dh, kx, ky, leaf_ext.data(), nleaf, zones);
       const IBox scale_search(0, 0, rp[level - 1].w - lp[level - 1].w, rp[level - 1].h - lp[level - 1].h);
       const IBox next_size(0, 0, lmp[level - 1].w, lmp[level - 1].h);
       for (SearchZone& z : zones) {

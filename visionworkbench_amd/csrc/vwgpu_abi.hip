@@ -110,6 +110,7 @@ void vwgpu_destroy(vwgpu_ctx* ctx) {
   if (ctx->pyr.base) (void)hipFree(ctx->pyr.base);
   if (ctx->ztab.base) (void)hipFree(ctx->ztab.base);
   if (ctx->zrl.base) (void)hipFree(ctx->zrl.base);
+  if (ctx->zext.base) (void)hipFree(ctx->zext.base);
   if (ctx->sgm.base) (void)hipFree(ctx->sgm.base);
   if (ctx->sgm_main.base) (void)hipFree(ctx->sgm_main.base);
   if (ctx->staging.base) (void)hipFree(ctx->staging.base);

@@ -45,6 +45,7 @@ struct vwgpu_ctx {
   vwgpu_arena ztab;      // zone / tile tables of the batched zone kernels (two halves, alternating)
   int ztab_parity = 0;
   vwgpu_arena zrl;       // right-to-left disparity images of all zones of pyramid level 0
+  vwgpu_arena zext;      // zone scheduler: leaf boxes of the quad tree and their measured disparity extents
   vwgpu_arena sgm;       // SGM: u8 images, census words, disparity bounds, ragged starts
   vwgpu_arena sgm_main;  // SGM: ragged cost (u8) + accumulated cost (u16) buffers
   int num_cu = 256;

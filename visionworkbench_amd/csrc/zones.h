@@ -37,4 +37,15 @@ struct SearchZone {
 // disp: w x h x {dx, dy, valid} int32 (host memory).  Appends zones to `out`.
 void subdivide_regions(const int32_t* disp, int w, int h, int kx, int ky, std::vector<SearchZone>& out);
 
+// The same scheduler with the pixel work left on the device.  The quad tree of boxes depends on the image size only, so
+// its leaves can be listed up front (depth-first, the order the recursion meets them); a kernel measures, per leaf, the
+// disparity extent of the box and of its 1-px neighbourhood (zone_extent_kernel, bm_zones.hip), and the recursion then
+// runs on that small table instead of the image.
+struct LeafExtent {          // 10 ints per leaf, as the kernel writes them
+  int32_t any, lo_x, lo_y, hi_x, hi_y;            // valid disparities inside the box
+  int32_t any_a, lo_xa, lo_ya, hi_xa, hi_ya;      // ... inside the box grown by 1 px (clipped to the image)
+};
+void enumerate_leaves(int w, int h, std::vector<IBox>& leaves);
+void subdivide_regions_from_leaves(int w, int h, int kx, int ky, const LeafExtent* leaf, size_t nleaf, std::vector<SearchZone>& out);
+
 }  // namespace vwgpu
