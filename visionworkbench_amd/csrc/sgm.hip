@@ -317,6 +317,16 @@ __device__ __forceinline__ void accum_add_u16(uint16_t* accum, unsigned long lon
   atomicAdd(reinterpret_cast<unsigned*>(accum) + (e >> 1), v << ((e & 1) * 16));
 }
 
+// i / d and i % d for 0 <= i < 2^16, 1 <= d < 2^16 through one reciprocal (an integer division is ~25 VALU instructions
+// and the recurrence below needs three per pixel).
+__device__ __forceinline__ void divmod_f(int i, int d, float inv, int& quo, int& rem) {
+  int q = (int)(((float)i + 0.5f) * inv);
+  int r = i - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) { ++q; r -= d; }
+  quo = q; rem = r;
+}
+
 // One wavefront per scan line (PixelPassTask, SGMAssist.h:705-819).  line -> start pixel as in accum_sgm_multithread
 // (SGM.cc:2488-2610): first `n_first` lines start on the first border (index i), the rest on the second (index i + skip).
 __global__ void __launch_bounds__(64)
@@ -336,15 +346,47 @@ path_kernel(SgmGeom g, DirSet D,
   lds_barrier();
   int last_val = -1;
   B4 bp{0, 0, -1, -1};
-  while (c >= 0 && r >= 0 && c < g.ocols && r < g.orows) {
+  // Software pipeline over the pixels of the line: the per-pixel records (box, vector start, grey value) of pixel k+1 are
+  // requested while pixel k is processed, and its first two cost bytes per lane right after the scatter phase — the
+  // dependent chain box/start -> cost -> recurrence would otherwise expose two memory round trips per pixel.
+  auto inside = [&](int cc, int rr) { return cc >= 0 && rr >= 0 && cc < g.ocols && rr < g.orows; };
+  B4 b{0, 0, -1, -1};
+  unsigned long long st = 0;
+  int cur = 0;
+  unsigned cv0 = 0, cv1 = 0;                    // cost[st + lane], cost[st + lane + 64] of the current pixel
+  if (inside(c, r)) {
     const size_t p = (size_t)r * g.ocols + c;
-    const B4 b = bounds[p];
+    b = bounds[p]; st = starts[p];
+    cur = left[(size_t)(r + min_row) * lw + (c + min_col)];
+    const int nd0 = (b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
+    if (lane < nd0) cv0 = cost[st + lane];
+    if (lane + 64 < nd0) cv1 = cost[st + lane + 64];
+  }
+  while (inside(c, r)) {
     const int wd = b.x1 - b.x0 + 1, nd = wd * (b.y1 - b.y0 + 1);
-    const unsigned long long st = starts[p];
-    const int cur = left[(size_t)(r + min_row) * lw + (c + min_col)];
+    // request the next pixel's records
+    const int cn = c + dc, rn = r + dr;
+    const bool has_next = inside(cn, rn);
+    B4 b_n{0, 0, -1, -1};
+    unsigned long long st_n = 0;
+    int cur_n = 0;
+    if (has_next) {
+      const size_t pn = (size_t)rn * g.ocols + cn;
+      b_n = bounds[pn]; st_n = starts[pn];
+      cur_n = left[(size_t)(rn + min_row) * lw + (cn + min_col)];
+    }
+    unsigned cn0 = 0, cn1 = 0;
+    auto request_next_cost = [&]() {
+      if (!has_next) return;
+      const int ndn = (b_n.x1 - b_n.x0 + 1) * (b_n.y1 - b_n.y0 + 1);
+      if (lane < ndn) cn0 = cost[st_n + lane];
+      if (lane + 64 < ndn) cn1 = cost[st_n + lane + 64];
+    };
+    auto cost_at = [&](int i) -> unsigned { return i < 64 ? cv0 : (i < 128 ? cv1 : (unsigned)cost[st + i]); };
     if (last_val < 0) {
+      request_next_cost();
       for (int i = lane; i < nd; i += 64) {
-        const unsigned v = cost[st + i];
+        const unsigned v = cost_at(i);
         prev_out[i] = (uint16_t)v;
         accum_add_u16(accum, st + i, v);
       }
@@ -355,19 +397,22 @@ path_kernel(SgmGeom g, DirSet D,
       if (p2_mod < p1) p2_mod = p1;
       // scatter the prior vector into the full-range buffer, reduce its minimum
       const int wp = bp.x1 - bp.x0 + 1, np = wp * (bp.y1 - bp.y0 + 1);
+      const float inv_wp = __builtin_amdgcn_rcpf((float)wp), inv_wd = __builtin_amdgcn_rcpf((float)wd);
       unsigned mn = BAD;
       for (int i = lane; i < np; i += 64) {
-        const int qy = i / wp, qx = i - qy * wp;
+        int qy, qx;
+        divmod_f(i, wp, inv_wp, qy, qx);
         const unsigned v = prev_out[i];
         mn = min(mn, v);
         full_prior[(bp.y0 + qy - g.min_dy) * g.num_dx + (bp.x0 + qx - g.min_dx)] = (uint16_t)v;
       }
-      for (int s = 32; s > 0; s >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, s));
-      const unsigned min_prior = mn;
+      const unsigned min_prior = wave_min_u32(mn);
       const unsigned dJ = (min_prior + p2_mod) & 0xffffu;
+      request_next_cost();
       lds_barrier();
       for (int i = lane; i < nd; i += 64) {
-        const int qy = i / wd, qx = i - qy * wd;
+        int qy, qx;
+        divmod_f(i, wd, inv_wd, qy, qx);
         const int dx = b.x0 + qx, dy = b.y0 + qy;
         const int xo = dx - g.min_dx, yo = dy - g.min_dy;
         const int xl = dx - 1 < g.min_dx ? xo : xo - 1, xm = dx + 1 > g.max_dx ? xo : xo + 1;
@@ -378,7 +423,7 @@ path_kernel(SgmGeom g, DirSet D,
         m = min(m, (unsigned)full_prior[ym + xl]); m = min(m, (unsigned)full_prior[ym + xm]);
         unsigned res = adds16(m, p1);
         res = min(res, min((unsigned)full_prior[yc + xo], dJ));
-        res = adds16(res, (unsigned)cost[st + i]);
+        res = adds16(res, cost_at(i));
         res = subs16(res, min_prior);
         // prev_out is still being read by nobody (scatter finished at the barrier): reuse it for this pixel's vector
         prev_out[i] = (uint16_t)res;
@@ -386,13 +431,140 @@ path_kernel(SgmGeom g, DirSet D,
       }
       lds_barrier();
       for (int i = lane; i < np; i += 64) {
-        const int qy = i / wp, qx = i - qy * wp;
+        int qy, qx;
+        divmod_f(i, wp, inv_wp, qy, qx);
         full_prior[(bp.y0 + qy - g.min_dy) * g.num_dx + (bp.x0 + qx - g.min_dx)] = (uint16_t)BAD;
       }
     }
     lds_barrier();
     bp = b; last_val = cur;
-    c += dc; r += dr;
+    b = b_n; st = st_n; cur = cur_n; cv0 = cn0; cv1 = cn1;
+    c = cn; r = rn;
+  }
+}
+
+// The ragged recurrence for num_disp <= 64 * R, in place.  The full-range buffer always holds the PREVIOUS pixel's vector at
+// its box cells and BAD_VAL elsewhere, so a step is: read the neighbours of every cell of the current box into registers,
+// barrier, write the new values at the current box's cells, put BAD_VAL back into the cells of the previous box that the
+// current one does not cover (usually none or a rim: neighbouring pixels descend from the same coarser pixel), barrier.
+// No scatter / reset pass over the whole previous vector, no second copy of the vector, two barriers instead of three, and
+// the minimum of the new vector is reduced from registers.
+template <int R>
+__global__ void __launch_bounds__(64)
+path_inplace_kernel(SgmGeom g, DirSet D,
+                    const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
+                    const B4* __restrict__ bounds, const unsigned long long* __restrict__ starts,
+                    const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2) {
+  extern __shared__ uint16_t sm[];
+  const int num_disp = g.num_dx * g.num_dy;
+  uint16_t* full_prior = sm;                 // num_disp
+  const int lane = threadIdx.x;
+  int c, r, dc, dr;
+  line_start(D, g, blockIdx.x, dc, dr, c, r);
+  const unsigned BAD = (255u + p2) & 0xffffu;
+  for (int i = lane; i < num_disp; i += 64) full_prior[i] = (uint16_t)BAD;
+  lds_barrier();
+  auto inside = [&](int cc, int rr) { return cc >= 0 && rr >= 0 && cc < g.ocols && rr < g.orows; };
+  int last_val = -1;
+  unsigned min_prior = 0;
+  B4 bp{0, 0, -1, -1};
+  B4 b{0, 0, -1, -1};
+  unsigned long long st = 0;
+  int cur = 0;
+  unsigned cv0 = 0, cv1 = 0;                    // cost[st + lane], cost[st + lane + 64] of the current pixel (prefetched)
+  if (inside(c, r)) {
+    const size_t p = (size_t)r * g.ocols + c;
+    b = bounds[p]; st = starts[p];
+    cur = left[(size_t)(r + min_row) * lw + (c + min_col)];
+    const int nd0 = (b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
+    if (lane < nd0) cv0 = cost[st + lane];
+    if (lane + 64 < nd0) cv1 = cost[st + lane + 64];
+  }
+  while (inside(c, r)) {
+    const int wd = b.x1 - b.x0 + 1, nd = wd * (b.y1 - b.y0 + 1);
+    const int cn = c + dc, rn = r + dr;
+    const bool has_next = inside(cn, rn);
+    B4 b_n{0, 0, -1, -1};
+    unsigned long long st_n = 0;
+    int cur_n = 0;
+    if (has_next) {                               // the next pixel's records: one memory round trip ahead
+      const size_t pn = (size_t)rn * g.ocols + cn;
+      b_n = bounds[pn]; st_n = starts[pn];
+      cur_n = left[(size_t)(rn + min_row) * lw + (cn + min_col)];
+    }
+    const float inv_wd = __builtin_amdgcn_rcpf((float)wd);
+    unsigned res[R];
+    int cell[R];
+    unsigned p2_mod = p2;
+    if (last_val >= 0) {
+      int grad = cur - last_val; grad = grad < 0 ? -grad : grad;
+      if (grad > 0) p2_mod /= (unsigned)grad;
+      if (p2_mod < p1) p2_mod = p1;
+    }
+    const unsigned dJ = (min_prior + p2_mod) & 0xffffu;
+    // ---- phase 1: every read of the previous vector
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int i = lane + 64 * k;
+      res[k] = 0xffffu; cell[k] = -1;
+      if (64 * k >= nd) continue;                 // wave-uniform
+      if (i < nd) {
+        int qy, qx;
+        divmod_f(i, wd, inv_wd, qy, qx);
+        const int dx = b.x0 + qx, dy = b.y0 + qy;
+        const int xo = dx - g.min_dx, yo = dy - g.min_dy;
+        cell[k] = yo * g.num_dx + xo;
+        const unsigned cb = k == 0 ? cv0 : (k == 1 ? cv1 : (unsigned)cost[st + i]);
+        if (last_val < 0) res[k] = cb;
+        else {
+          const int xl = dx - 1 < g.min_dx ? xo : xo - 1, xm = dx + 1 > g.max_dx ? xo : xo + 1;
+          const int yl = (dy - 1 < g.min_dy ? yo : yo - 1) * g.num_dx, ym = (dy + 1 > g.max_dy ? yo : yo + 1) * g.num_dx, yc = yo * g.num_dx;
+          unsigned m = full_prior[yl + xo];
+          m = min(m, (unsigned)full_prior[yc + xl]); m = min(m, (unsigned)full_prior[yc + xm]); m = min(m, (unsigned)full_prior[ym + xo]);
+          m = min(m, (unsigned)full_prior[yl + xl]); m = min(m, (unsigned)full_prior[yl + xm]);
+          m = min(m, (unsigned)full_prior[ym + xl]); m = min(m, (unsigned)full_prior[ym + xm]);
+          unsigned v = adds16(m, p1);
+          v = min(v, min((unsigned)full_prior[yc + xo], dJ));
+          v = adds16(v, cb);
+          res[k] = subs16(v, min_prior);
+        }
+      }
+    }
+    // the next pixel's first cost bytes (its vector start has arrived by now)
+    unsigned cn0 = 0, cn1 = 0;
+    if (has_next) {
+      const int ndn = (b_n.x1 - b_n.x0 + 1) * (b_n.y1 - b_n.y0 + 1);
+      if (lane < ndn) cn0 = cost[st_n + lane];
+      if (lane + 64 < ndn) cn1 = cost[st_n + lane + 64];
+    }
+    lds_barrier();
+    // ---- phase 2: the new vector goes to its cells, cells only the previous box covered go back to BAD_VAL
+    unsigned mn = BAD;                           // (the minimum of an empty vector is BAD_VAL, SGMAssist.h)
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (64 * k >= nd) continue;
+      if (cell[k] >= 0) {
+        full_prior[cell[k]] = (uint16_t)res[k];
+        accum_add_u16(accum, st + lane + 64 * k, res[k]);
+        mn = min(mn, res[k]);
+      }
+    }
+    if (last_val >= 0 && (bp.x0 < b.x0 || bp.x1 > b.x1 || bp.y0 < b.y0 || bp.y1 > b.y1)) {   // wave-uniform
+      const int wp = bp.x1 - bp.x0 + 1, np = wp * (bp.y1 - bp.y0 + 1);
+      const float inv_wp = __builtin_amdgcn_rcpf((float)wp);
+      for (int i = lane; i < np; i += 64) {
+        int qy, qx;
+        divmod_f(i, wp, inv_wp, qy, qx);
+        const int dx = bp.x0 + qx, dy = bp.y0 + qy;
+        if (dx < b.x0 || dx > b.x1 || dy < b.y0 || dy > b.y1)
+          full_prior[(dy - g.min_dy) * g.num_dx + (dx - g.min_dx)] = (uint16_t)BAD;
+      }
+    }
+    min_prior = wave_min_u32(mn);
+    lds_barrier();
+    bp = b; last_val = cur;
+    b = b_n; st = st_n; cur = cur_n; cv0 = cn0; cv1 = cn1;
+    c = cn; r = rn;
   }
 }
 
@@ -1008,8 +1180,16 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
         }
 #undef VWGPU_PATH_U
       } else {
-        hipLaunchKernelGGL(path_kernel, dim3(lines), dim3(64), lds, st, g, D, l8, lw, min_col, min_row, bounds, starts, cost, accum,
-                           (unsigned)p1, (unsigned)p2);
+#define VWGPU_PATH_IP(RR) hipLaunchKernelGGL(path_inplace_kernel<RR>, dim3(lines), dim3(64), (size_t)num_disp * sizeof(uint16_t), st, g, D, l8, lw, \
+                                             min_col, min_row, bounds, starts, cost, accum, (unsigned)p1, (unsigned)p2)
+        if (num_disp <= 64) VWGPU_PATH_IP(1);
+        else if (num_disp <= 128) VWGPU_PATH_IP(2);
+        else if (num_disp <= 256) VWGPU_PATH_IP(4);
+        else if (num_disp <= 512) VWGPU_PATH_IP(8);
+        else
+          hipLaunchKernelGGL(path_kernel, dim3(lines), dim3(64), lds, st, g, D, l8, lw, min_col, min_row, bounds, starts, cost, accum,
+                             (unsigned)p1, (unsigned)p2);
+#undef VWGPU_PATH_IP
       }
     }
   }
