@@ -109,6 +109,22 @@ def test_masks_prev_disparity_and_memory_levels(vw, oracle):
     assert (gi[10:20, 10:30, 2] == 0).all()
 
 
+@pytest.mark.parametrize("search", [(30, 20), (40, 30)])
+def test_large_two_d_search_with_masks(vw, oracle, search):
+    """Ragged vectors with many disparities: 31 x 21 = 651 (in-place kernel, 16 slots per lane) and 41 x 31 = 1271 (the
+    three-phase kernel that takes any size); the left mask makes the boxes non-uniform."""
+    rng = np.random.default_rng(21)
+    sx, sy = search
+    left, right = _pair(rng, 40, 56, sx, sy)
+    k = 5
+    oh, ow = 40 - k + 1, 56 - k + 1
+    lm = np.full((oh, ow), 255, np.uint8)
+    lm[5:12, 8:20] = 0
+    gi, gs, oi, os_ = _both(vw, oracle, CENSUS, left, right, search, k, 5, lm=lm)
+    assert np.array_equal(gi, oi)
+    assert np.abs(gs - os_).max() < 1e-5
+
+
 def test_float_range_is_stretched(vw, oracle):
     """u8_convert (ImageThresh.h:275-286): any float range, including negative values and a constant image."""
     rng = np.random.default_rng(12)

@@ -1186,7 +1186,8 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
         else if (num_disp <= 128) VWGPU_PATH_IP(2);
         else if (num_disp <= 256) VWGPU_PATH_IP(4);
         else if (num_disp <= 512) VWGPU_PATH_IP(8);
-        else
+        else if (num_disp <= 1024) VWGPU_PATH_IP(16);
+        else                                        // very large 2-D searches: the three-phase kernel, any size
           hipLaunchKernelGGL(path_kernel, dim3(lines), dim3(64), lds, st, g, D, l8, lw, min_col, min_row, bounds, starts, cost, accum,
                              (unsigned)p1, (unsigned)p2);
 #undef VWGPU_PATH_IP
