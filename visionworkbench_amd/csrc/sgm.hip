@@ -458,12 +458,21 @@ path_inplace_kernel(SgmGeom g, DirSet D,
   extern __shared__ uint16_t sm[];
   const int num_disp = g.num_dx * g.num_dy;
   uint16_t* full_prior = sm;                 // num_disp
+  uint16_t* p2tab = sm + ((num_disp + 1) & ~1);   // 256: max(P1, P2 / |grey step|), the adaptive P2 of SGM.cc:813-818
   const int lane = threadIdx.x;
   int c, r, dc, dr;
   line_start(D, g, blockIdx.x, dc, dr, c, r);
   const unsigned BAD = (255u + p2) & 0xffffu;
   for (int i = lane; i < num_disp; i += 64) full_prior[i] = (uint16_t)BAD;
+  for (int q = lane; q < 256; q += 64) {
+    unsigned v = p2;
+    if (q > 0) v /= (unsigned)q;
+    if (v < p1) v = p1;
+    p2tab[q] = (uint16_t)v;
+  }
   lds_barrier();
+  const long long delta = (long long)dr * g.ocols + dc;         // pixel index step along the line
+  const long long ldelta = (long long)dr * lw + dc;
   auto inside = [&](int cc, int rr) { return cc >= 0 && rr >= 0 && cc < g.ocols && rr < g.orows; };
   int last_val = -1;
   unsigned min_prior = 0;
@@ -472,10 +481,11 @@ path_inplace_kernel(SgmGeom g, DirSet D,
   unsigned long long st = 0;
   int cur = 0;
   unsigned cv0 = 0, cv1 = 0;                    // cost[st + lane], cost[st + lane + 64] of the current pixel (prefetched)
+  long long p = (long long)r * g.ocols + c;
+  long long lp = (long long)(r + min_row) * lw + (c + min_col);
   if (inside(c, r)) {
-    const size_t p = (size_t)r * g.ocols + c;
     b = bounds[p]; st = starts[p];
-    cur = left[(size_t)(r + min_row) * lw + (c + min_col)];
+    cur = left[lp];
     const int nd0 = (b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
     if (lane < nd0) cv0 = cost[st + lane];
     if (lane + 64 < nd0) cv1 = cost[st + lane + 64];
@@ -487,21 +497,16 @@ path_inplace_kernel(SgmGeom g, DirSet D,
     B4 b_n{0, 0, -1, -1};
     unsigned long long st_n = 0;
     int cur_n = 0;
+    p += delta; lp += ldelta;
     if (has_next) {                               // the next pixel's records: one memory round trip ahead
-      const size_t pn = (size_t)rn * g.ocols + cn;
-      b_n = bounds[pn]; st_n = starts[pn];
-      cur_n = left[(size_t)(rn + min_row) * lw + (cn + min_col)];
+      b_n = bounds[p]; st_n = starts[p];
+      cur_n = left[lp];
     }
     const float inv_wd = __builtin_amdgcn_rcpf((float)wd);
     unsigned res[R];
     int cell[R];
-    unsigned p2_mod = p2;
-    if (last_val >= 0) {
-      int grad = cur - last_val; grad = grad < 0 ? -grad : grad;
-      if (grad > 0) p2_mod /= (unsigned)grad;
-      if (p2_mod < p1) p2_mod = p1;
-    }
-    const unsigned dJ = (min_prior + p2_mod) & 0xffffu;
+    int grad = cur - last_val; grad = grad < 0 ? -grad : grad;
+    const unsigned dJ = (min_prior + (unsigned)p2tab[last_val >= 0 ? grad : 0]) & 0xffffu;
     // ---- phase 1: every read of the previous vector
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -1180,7 +1185,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
         }
 #undef VWGPU_PATH_U
       } else {
-#define VWGPU_PATH_IP(RR) hipLaunchKernelGGL(path_inplace_kernel<RR>, dim3(lines), dim3(64), (size_t)num_disp * sizeof(uint16_t), st, g, D, l8, lw, \
+#define VWGPU_PATH_IP(RR) hipLaunchKernelGGL(path_inplace_kernel<RR>, dim3(lines), dim3(64), ((size_t)num_disp + 2 + 256) * sizeof(uint16_t), st, g, D, l8, lw, \
                                              min_col, min_row, bounds, starts, cost, accum, (unsigned)p1, (unsigned)p2)
         if (num_disp <= 64) VWGPU_PATH_IP(1);
         else if (num_disp <= 128) VWGPU_PATH_IP(2);
