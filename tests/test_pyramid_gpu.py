@@ -74,6 +74,38 @@ def test_masks_and_subtile(vw, oracle):
     assert not g.any()
 
 
+@pytest.mark.parametrize("algorithm", [0, 1])
+def test_interior_tile_of_a_larger_pair_stages_a_window(vw, oracle, algorithm):
+    """The host entry ships only the window of the sources a tile can touch (tile + pyramid padding + search); for a tile
+    well inside a larger pair that window is a strict sub-rectangle on every side, and the result must not change —
+    BM with masks, and the SGM branch (R->L runs read further out)."""
+    from visionworkbench_amd.core import BBox2i
+    rng = np.random.default_rng(5)
+    H, W = 420, 640
+    left = np.floor(rng.random((H, W)) * 256).astype(np.float32)
+    right = np.empty_like(left)
+    for y0 in range(0, H, 60):
+        sh = int(rng.integers(-5, 6))
+        right[y0:y0 + 60] = np.roll(left[y0:y0 + 60], sh, axis=1)
+    lm = np.full(left.shape, 255, np.uint8)
+    rm = np.full(right.shape, 255, np.uint8)
+    lm[230:250, 300:330] = 0
+    search = (-6, -1, 6, 1)
+    bbox = (260, 190, 96, 64)
+    if algorithm == 0:
+        g, o = _run_both(vw, oracle, left, right, lm, rm, 0, 0.0, search, (7, 7), 0, 2, 3, 2, bbox=bbox)
+    else:
+        g = vw.pyramid_correlate(left, right, lm, rm, 0, 0.0, _box(search), (5, 5), 3, consistency_threshold=2, filter_half_kernel=3,
+                                 max_pyramid_levels=2, algorithm=1, bbox=BBox2i(*bbox))
+        o = oracle.pyramid_correlate_sgm(left, right, lm, rm, search, 5, 3, 2, 0, 3, 2, bbox=bbox)
+    assert g.shape == (64, 96, 3)
+    if algorithm == 0:
+        assert np.array_equal(g, o)
+    else:
+        assert np.array_equal(g[..., 2], o[..., 2]) and np.abs(g - o).max() < 1e-5
+    assert (g[..., 2] != 0).mean() > 0.5
+
+
 def test_level_count_edge_cases(vw, oracle):
     left, right, scale, trans, search = scenes.pyramid_scene("u8")
     for levels, srch in [(0, (-3, -2, 4, 3)), (1, (-6, -2, 7, 3)), (5, (0, 0, 1, 1)), (5, (-30, 0, 31, 1))]:

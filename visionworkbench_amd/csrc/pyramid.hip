@@ -835,8 +835,26 @@ int vwgpu_pyramid_correlate(vwgpu_ctx* ctx, const float* left, int lw, int lh, p
   if (rms == 0) rms = rw;
   if (os == 0) os = bw;
   VWGPU_HIP(ctx, hipSetDevice(ctx->device));
-  const size_t lb = vwgpu_align_up((size_t)lw * lh * 4, 256), rb = vwgpu_align_up((size_t)rw * rh * 4, 256);
-  const size_t lmb = vwgpu_align_up((size_t)lw * lh, 256), rmb = vwgpu_align_up((size_t)rw * rh, 256), ob = vwgpu_align_up((size_t)bw * bh * 12, 256);
+  // Only the window of the sources this tile can touch goes to the device — the reference's prerasterize also pulls just
+  // its padded ROIs through the views (CorrelationView.cc:89-97) — not the whole images: a 1024^2 tile of a 32768^2 pair
+  // stages ~2000^2 pixels per image.  Window = tile grown by half_kernel * 2^max_levels (pyramid padding), twice the
+  // search extent (R->L runs of the SGM branch) and the search range itself, cut at the image borders; both images and
+  // masks share the window origin, so disparities and the edge extension at true image borders are unchanged.
+  const int upb = 1 << std::max(0, std::min(P->max_pyramid_levels, 12));
+  const int sdx = P->search_max_x - P->search_min_x, sdy = P->search_max_y - P->search_min_y;
+  const long long padx = (long long)(P->kernel_x / 2) * upb + 2LL * std::max(sdx, 0) + 8;
+  const long long pady = (long long)(P->kernel_y / 2) * upb + 2LL * std::max(sdy, 0) + 8;
+  const long long wx0 = std::max<long long>(0, (long long)bx - padx + std::min(P->search_min_x, 0));
+  const long long wy0 = std::max<long long>(0, (long long)by - pady + std::min(P->search_min_y, 0));
+  const long long wx1 = (long long)bx + bw + padx + std::max(P->search_max_x, 0);
+  const long long wy1 = (long long)by + bh + pady + std::max(P->search_max_y, 0);
+  const int ox = (int)std::min<long long>(wx0, std::min(lw, rw)), oy = (int)std::min<long long>(wy0, std::min(lh, rh));
+  const int lww = (int)(std::min<long long>(wx1, lw) - ox), lwh = (int)(std::min<long long>(wy1, lh) - oy);
+  const int rww = (int)(std::min<long long>(wx1, rw) - ox), rwh = (int)(std::min<long long>(wy1, rh) - oy);
+  if (lww <= 0 || lwh <= 0 || rww <= 0 || rwh <= 0)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate: the tile lies outside the images");
+  const size_t lb = vwgpu_align_up((size_t)lww * lwh * 4, 256), rb = vwgpu_align_up((size_t)rww * rwh * 4, 256);
+  const size_t lmb = vwgpu_align_up((size_t)lww * lwh, 256), rmb = vwgpu_align_up((size_t)rww * rwh, 256), ob = vwgpu_align_up((size_t)bw * bh * 12, 256);
   if (P->lr_disp_diff && (bx < P->region_ul_x || by < P->region_ul_y || bx + bw > P->region_ul_x + P->lr_disp_diff_cols ||
                           by + bh > P->region_ul_y + P->lr_disp_diff_rows))
     return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "The L-R to R-L difference image domain does not contain the current tile.");
@@ -850,18 +868,22 @@ int vwgpu_pyramid_correlate(vwgpu_ctx* ctx, const float* left, int lw, int lh, p
   uint8_t* d_lm = reinterpret_cast<uint8_t*>(base + lb + rb);
   uint8_t* d_rm = reinterpret_cast<uint8_t*>(base + lb + rb + lmb);
   float* d_o = reinterpret_cast<float*>(base + lb + rb + lmb + rmb);
-  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_l, (size_t)lw * 4, left, (size_t)ls * 4, (size_t)lw * 4, lh, hipMemcpyHostToDevice, ctx->stream));
-  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_r, (size_t)rw * 4, right, (size_t)rs * 4, (size_t)rw * 4, rh, hipMemcpyHostToDevice, ctx->stream));
-  if (lmask) VWGPU_HIP(ctx, hipMemcpy2DAsync(d_lm, (size_t)lw, lmask, (size_t)lms, (size_t)lw, lh, hipMemcpyHostToDevice, ctx->stream));
-  if (rmask) VWGPU_HIP(ctx, hipMemcpy2DAsync(d_rm, (size_t)rw, rmask, (size_t)rms, (size_t)rw, rh, hipMemcpyHostToDevice, ctx->stream));
+  const float* lsrc = left + (ptrdiff_t)oy * ls + ox;
+  const float* rsrc = right + (ptrdiff_t)oy * rs + ox;
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_l, (size_t)lww * 4, lsrc, (size_t)ls * 4, (size_t)lww * 4, lwh, hipMemcpyHostToDevice, ctx->stream));
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_r, (size_t)rww * 4, rsrc, (size_t)rs * 4, (size_t)rww * 4, rwh, hipMemcpyHostToDevice, ctx->stream));
+  if (lmask) VWGPU_HIP(ctx, hipMemcpy2DAsync(d_lm, (size_t)lww, lmask + (ptrdiff_t)oy * lms + ox, (size_t)lms, (size_t)lww, lwh, hipMemcpyHostToDevice, ctx->stream));
+  if (rmask) VWGPU_HIP(ctx, hipMemcpy2DAsync(d_rm, (size_t)rww, rmask + (ptrdiff_t)oy * rms + ox, (size_t)rms, (size_t)rww, rwh, hipMemcpyHostToDevice, ctx->stream));
   float* d_d = reinterpret_cast<float*>(base + lb + rb + lmb + rmb + ob);
   vwgpu_pyramid_params Pd = *P;                     // the device-side view of the discrepancy image is dense
   Pd.lr_disp_diff_stride = P->lr_disp_diff_cols;
+  Pd.region_ul_x = P->region_ul_x - ox;             // everything below runs in window coordinates
+  Pd.region_ul_y = P->region_ul_y - oy;
   if (P->lr_disp_diff)
     VWGPU_HIP(ctx, hipMemcpy2DAsync(d_d, (size_t)P->lr_disp_diff_cols * 8, P->lr_disp_diff, (size_t)hdst * 8, (size_t)P->lr_disp_diff_cols * 8,
                                     P->lr_disp_diff_rows, hipMemcpyHostToDevice, ctx->stream));
-  rc = vwgpu_pyramid_correlate_impl(ctx, d_l, lw, lh, lw, d_r, rw, rh, rw, lmask ? d_lm : nullptr, lw, rmask ? d_rm : nullptr, rw,
-                                    &Pd, bx, by, bw, bh, d_o, bw, P->lr_disp_diff ? d_d : nullptr);
+  rc = vwgpu_pyramid_correlate_impl(ctx, d_l, lww, lwh, lww, d_r, rww, rwh, rww, lmask ? d_lm : nullptr, lww, rmask ? d_rm : nullptr, rww,
+                                    &Pd, bx - ox, by - oy, bw, bh, d_o, bw, P->lr_disp_diff ? d_d : nullptr);
   if (rc) return rc;
   if (P->lr_disp_diff)
     VWGPU_HIP(ctx, hipMemcpy2DAsync(P->lr_disp_diff, (size_t)hdst * 8, d_d, (size_t)P->lr_disp_diff_cols * 8, (size_t)P->lr_disp_diff_cols * 8,
