@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include <vw/FileIO.h>
 #include <vw/Stereo.h>
 
 #include "../../oracle/vw_oracle.h"
@@ -382,6 +383,50 @@ static void test_block_rasterize() {
   EXPECT_THROW((ImageView<PixelMask<Vector2f>>(block_rasterize(bad_view, Vector2i(128, 96), 3))), NoImplErr);
 }
 
+// --- file-backed sources + block writer (ImageIO.h:257-314, DiskImageView): the per-tile loop of tools/correlate.cc ---
+static void test_disk_views_and_block_write() {
+  const char* tmp = std::getenv("TMPDIR");
+  const std::string dir = tmp ? tmp : "/tmp";
+  const std::string lf = dir + "/vwlite_left.pfm", rf = dir + "/vwlite_right.pgm", df = dir + "/vwlite_disp.pfm";
+  ImageView<PixelGray<float>> left, right;
+  pyramid_scene(left, right);
+  write_image(lf, left);                                        // 1-channel PFM (bottom-up rows, little endian)
+  {                                                             // the right image as an 8-bit PGM (top-down rows)
+    FILE* f = std::fopen(rf.c_str(), "wb");
+    std::fprintf(f, "P5\n# made by the test\n300 200\n255\n");
+    for (int r = 0; r < 200; ++r) for (int c = 0; c < 300; ++c) std::fputc((int)right(c, r).v(), f);
+    std::fclose(f);
+  }
+  DiskImageView<PixelGray<float>> dl(lf), dr(rf);
+  EXPECT_EQ(300, dl.cols()); EXPECT_EQ(200, dl.rows()); EXPECT_EQ(300, dr.cols()); EXPECT_EQ(200, dr.rows());
+  ImageView<PixelGray<float>> part = crop(dl, BBox2i(17, 33, 40, 25)), partr = crop(dr, BBox2i(250, 170, 50, 30));
+  long bad = 0;
+  for (int r = 0; r < 25; ++r) for (int c = 0; c < 40; ++c) if (part(c, r).v() != left(17 + c, 33 + r).v()) ++bad;
+  for (int r = 0; r < 30; ++r) for (int c = 0; c < 50; ++c) if (partr(c, r).v() != right(250 + c, 170 + r).v()) ++bad;
+  EXPECT_EQ(0, bad);
+  // the correlator pulled through file-backed views, block by block, written as it goes
+  ImageView<uint8> lmask(300, 200), rmask(300, 200);
+  fill(lmask, uint8(255)); fill(rmask, uint8(255));
+  const BBox2i search_volume(Vector2i(-18, -7), Vector2i(18, 7));
+  block_write_image(df, pyramid_correlate(dl, dr, lmask, rmask, PREFILTER_NONE, 0.0f, search_volume, Vector2i(7, 7),
+                                          ABSOLUTE_DIFFERENCE, 0, 0.0, 2, 0, 5, 5), Vector2i(128, 96), 3);
+  DiskImageView<PixelMask<Vector2f>> dd(df);
+  ImageView<PixelMask<Vector2f>> got = dd;
+  ImageView<PixelMask<Vector2f>> want = block_rasterize(pyramid_correlate(left, right, lmask, rmask, PREFILTER_NONE, 0.0f, search_volume,
+                                                                          Vector2i(7, 7), ABSOLUTE_DIFFERENCE, 0, 0.0, 2, 0, 5, 5),
+                                                        Vector2i(128, 96), 2);
+  EXPECT_EQ(300, got.cols()); EXPECT_EQ(200, got.rows());
+  bad = 0; long valid = 0;
+  for (int r = 0; r < 200; ++r) for (int c = 0; c < 300; ++c) {
+    if (!(got(c, r).child() == want(c, r).child()) || is_valid(got(c, r)) != is_valid(want(c, r))) ++bad;
+    if (is_valid(got(c, r))) ++valid;
+  }
+  EXPECT_EQ(0, bad);
+  EXPECT_TRUE(valid > 300 * 200 * 0.8);
+  EXPECT_THROW(DiskImageView<PixelGray<float>>(dir + "/no_such_file.pfm"), IOErr);
+  std::remove(lf.c_str()); std::remove(rf.c_str()); std::remove(df.c_str());
+}
+
 int main() {
   static_assert(sizeof(PixelMask<Vector2i>) == 12, "layout");
   EXPECT_TRUE(BBox2i(0, 0, 129, 0).empty() && BBox2i(0, 0, 129, 0).width() == 0);
@@ -407,6 +452,7 @@ int main() {
   test_disparity_filters();
   test_sgm_constant_offset();
   test_block_rasterize();
+  test_disk_views_and_block_write();
   std::printf("%d checks, %d failures\n", g_checks, g_fail);
   return g_fail ? 1 : 0;
 }

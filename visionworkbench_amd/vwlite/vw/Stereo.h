@@ -358,16 +358,18 @@ calc_disparity_sgm(CostFunctionType cost_type,
 /// PyramidCorrelationView — lazy like the reference's (CorrelationView.h:35-190): nothing runs until a tile is
 /// requested through prerasterize(bbox) / rasterize, and every tile is independent (CorrelationView.cc:273-886).
 class PyramidCorrelationView : public ImageViewBase<PyramidCorrelationView> {
-  ImageView<PixelGray<float>> m_left, m_right;
-  ImageView<uint8> m_left_mask, m_right_mask;
+  // Type-erased handles, as in the reference (CorrelationView.h:38-45): nothing is rasterised until a tile is requested,
+  // and then only the window that tile can touch (CorrelationView.cc:89-97) — the sources may be file-backed views.
+  ImageViewRef<PixelGray<float>> m_left, m_right;
+  ImageViewRef<uint8> m_left_mask, m_right_mask;
   vwgpu_pyramid_params m_p;
 public:
   typedef PixelMask<Vector2f> pixel_type;
   typedef pixel_type result_type;
   typedef ImageView<pixel_type> prerasterize_type;
 
-  PyramidCorrelationView(ImageView<PixelGray<float>> const& left, ImageView<PixelGray<float>> const& right,
-                         ImageView<uint8> const& left_mask, ImageView<uint8> const& right_mask, vwgpu_pyramid_params const& p)
+  PyramidCorrelationView(ImageViewRef<PixelGray<float>> const& left, ImageViewRef<PixelGray<float>> const& right,
+                         ImageViewRef<uint8> const& left_mask, ImageViewRef<uint8> const& right_mask, vwgpu_pyramid_params const& p)
       : m_left(left), m_right(right), m_left_mask(left_mask), m_right_mask(right_mask), m_p(p) {
     VW_ASSERT(left_mask.cols() == left.cols() && left_mask.rows() == left.rows() &&
               right_mask.cols() == right.cols() && right_mask.rows() == right.rows(),
@@ -385,10 +387,42 @@ public:
     ImageView<pixel_type> out(bbox.width(), bbox.height());
     if (bbox.empty()) return out;
     vwgpu_ctx* ctx = detail::thread_context();
-    detail::check(ctx, vwgpu_pyramid_correlate(ctx, reinterpret_cast<const float*>(m_left.data()), m_left.cols(), m_left.rows(), 0,
-                                               reinterpret_cast<const float*>(m_right.data()), m_right.cols(), m_right.rows(), 0,
-                                               m_left_mask.data(), 0, m_right_mask.data(), 0, &m_p,
-                                               bbox.min().x(), bbox.min().y(), bbox.width(), bbox.height(),
+    int32 ls = 0, rs = 0, lms = 0, rms = 0;
+    const PixelGray<float>* lp = m_left.plain_data(ls);
+    const PixelGray<float>* rp = m_right.plain_data(rs);
+    const uint8* lmp = m_left_mask.plain_data(lms);
+    const uint8* rmp = m_right_mask.plain_data(rms);
+    if (lp && rp && lmp && rmp) {                  // plain in-memory images: used in place (the engine ships the window)
+      detail::check(ctx, vwgpu_pyramid_correlate(ctx, reinterpret_cast<const float*>(lp), m_left.cols(), m_left.rows(), ls,
+                                                 reinterpret_cast<const float*>(rp), m_right.cols(), m_right.rows(), rs,
+                                                 lmp, lms, rmp, rms, &m_p,
+                                                 bbox.min().x(), bbox.min().y(), bbox.width(), bbox.height(),
+                                                 reinterpret_cast<float*>(out.data()), 0));
+      return out;
+    }
+    // lazy sources: rasterise the tile's window only.  Window = tile grown by the pyramid padding half_kernel * 2^levels,
+    // twice the search extent (the SGM branch's R->L runs) and the search range, cut at the image borders; all four
+    // rasters share its origin, so the engine sees a smaller pair in which the tile sits at bbox - origin.
+    const int64 up = int64(1) << std::max(0, std::min<int>(m_p.max_pyramid_levels, 12));
+    const int64 sdx = std::max(0, m_p.search_max_x - m_p.search_min_x), sdy = std::max(0, m_p.search_max_y - m_p.search_min_y);
+    const int64 padx = (m_p.kernel_x / 2) * up + 2 * sdx + 8, pady = (m_p.kernel_y / 2) * up + 2 * sdy + 8;
+    const int64 wx0 = std::max<int64>(0, bbox.min().x() - padx + std::min(m_p.search_min_x, 0));
+    const int64 wy0 = std::max<int64>(0, bbox.min().y() - pady + std::min(m_p.search_min_y, 0));
+    const int64 wx1 = int64(bbox.max().x()) + padx + std::max(m_p.search_max_x, 0);
+    const int64 wy1 = int64(bbox.max().y()) + pady + std::max(m_p.search_max_y, 0);
+    const int32 ox = (int32)std::min<int64>(wx0, std::min(m_left.cols(), m_right.cols()));
+    const int32 oy = (int32)std::min<int64>(wy0, std::min(m_left.rows(), m_right.rows()));
+    const BBox2i lwin(ox, oy, (int32)(std::min<int64>(wx1, m_left.cols()) - ox), (int32)(std::min<int64>(wy1, m_left.rows()) - oy));
+    const BBox2i rwin(ox, oy, (int32)(std::min<int64>(wx1, m_right.cols()) - ox), (int32)(std::min<int64>(wy1, m_right.rows()) - oy));
+    VW_ASSERT(!lwin.empty() && !rwin.empty(), ArgumentErr() << "PyramidCorrelationView: the tile lies outside the images.");
+    ImageView<PixelGray<float>> l = m_left.prerasterize(lwin), r = m_right.prerasterize(rwin);
+    ImageView<uint8> lm = m_left_mask.prerasterize(lwin), rm = m_right_mask.prerasterize(rwin);
+    vwgpu_pyramid_params p = m_p;
+    p.region_ul_x -= ox; p.region_ul_y -= oy;
+    detail::check(ctx, vwgpu_pyramid_correlate(ctx, reinterpret_cast<const float*>(l.data()), l.cols(), l.rows(), 0,
+                                               reinterpret_cast<const float*>(r.data()), r.cols(), r.rows(), 0,
+                                               lm.data(), 0, rm.data(), 0, &p,
+                                               bbox.min().x() - ox, bbox.min().y() - oy, bbox.width(), bbox.height(),
                                                reinterpret_cast<float*>(out.data()), 0));
     return out;
   }
@@ -398,6 +432,17 @@ public:
     vw::rasterize(tile, dest, BBox2i(0, 0, bbox.width(), bbox.height()));
   }
 };
+
+namespace detail {
+// A plain ImageView<PixelGray<float>> is wrapped as it is (the engine then reads it in place); anything else goes through a
+// lazy pixel_cast.
+inline ImageViewRef<PixelGray<float>> gray_float_ref(ImageView<PixelGray<float>> const& v) { return ImageViewRef<PixelGray<float>>(v); }
+template <class ViewT> ImageViewRef<PixelGray<float>> gray_float_ref(ImageViewBase<ViewT> const& v) {
+  return ImageViewRef<PixelGray<float>>(pixel_cast<PixelGray<float>>(v.impl()));
+}
+inline ImageViewRef<uint8> mask_ref(ImageView<uint8> const& v) { return ImageViewRef<uint8>(v); }
+template <class ViewT> ImageViewRef<uint8> mask_ref(ImageViewBase<ViewT> const& v) { return ImageViewRef<uint8>(pixel_cast<uint8>(v.impl())); }
+}  // namespace detail
 
 /// pyramid_correlate — the reference's argument list (CorrelationView.h:195-230).  VW_CORRELATION_BM and VW_CORRELATION_SGM;
 /// collar_size belongs to the tile rasteriser (request the collared bbox).
@@ -423,9 +468,8 @@ pyramid_correlate(ImageViewBase<Image1T> const& left, ImageViewBase<Image2T> con
   p.algorithm = (int)algorithm; p.blob_filter_area = blob_filter_area;
   p.sgm_subpixel_mode = sgm_subpixel_mode; p.sgm_search_buffer_x = sgm_search_buffer[0]; p.sgm_search_buffer_y = sgm_search_buffer[1];
   p.memory_limit_mb = memory_limit_mb; p.sgm_num_threads = 1;
-  ImageView<PixelGray<float>> l = pixel_cast<PixelGray<float>>(left.impl()), r = pixel_cast<PixelGray<float>>(right.impl());
-  ImageView<uint8> lm = left_mask.impl(), rm = right_mask.impl();
-  return PyramidCorrelationView(l, r, lm, rm, p);
+  return PyramidCorrelationView(detail::gray_float_ref(left.impl()), detail::gray_float_ref(right.impl()),
+                                detail::mask_ref(left_mask.impl()), detail::mask_ref(right_mask.impl()), p);
 }
 
 }  // namespace stereo
