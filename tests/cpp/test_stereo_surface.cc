@@ -408,8 +408,8 @@ static void test_disk_views_and_block_write() {
   ImageView<uint8> lmask(300, 200), rmask(300, 200);
   fill(lmask, uint8(255)); fill(rmask, uint8(255));
   const BBox2i search_volume(Vector2i(-18, -7), Vector2i(18, 7));
-  block_write_image(df, pyramid_correlate(dl, dr, lmask, rmask, PREFILTER_NONE, 0.0f, search_volume, Vector2i(7, 7),
-                                          ABSOLUTE_DIFFERENCE, 0, 0.0, 2, 0, 5, 5), Vector2i(128, 96), 3);
+  block_write_image(df, pyramid_correlate(dl, dr, constant_view(uint8(255), dl), constant_view(uint8(255), dr), PREFILTER_NONE, 0.0f,
+                                          search_volume, Vector2i(7, 7), ABSOLUTE_DIFFERENCE, 0, 0.0, 2, 0, 5, 5), Vector2i(128, 96), 3);
   DiskImageView<PixelMask<Vector2f>> dd(df);
   ImageView<PixelMask<Vector2f>> got = dd;
   ImageView<PixelMask<Vector2f>> want = block_rasterize(pyramid_correlate(left, right, lmask, rmask, PREFILTER_NONE, 0.0f, search_volume,

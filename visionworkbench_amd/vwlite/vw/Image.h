@@ -185,6 +185,29 @@ template <class ViewT> EdgeExtensionView<ViewT, ConstantEdgeExtension> edge_exte
   return EdgeExtensionView<ViewT, ConstantEdgeExtension>(v.impl());
 }
 
+// constant_view(value, cols, rows) / constant_view(value, like_view): a view with the same value everywhere
+// (src/vw/Image/Algorithms.h ConstantView) — e.g. an all-valid mask without allocating one.
+template <class PixelT>
+class ConstantView : public ImageViewBase<ConstantView<PixelT>> {
+  PixelT m_value;
+  int32 m_cols, m_rows;
+public:
+  typedef PixelT pixel_type;
+  typedef PixelT result_type;
+  typedef ConstantView prerasterize_type;
+  ConstantView(PixelT const& value, int32 cols, int32 rows) : m_value(value), m_cols(cols), m_rows(rows) {}
+  int32 cols() const { return m_cols; }  int32 rows() const { return m_rows; }  int32 planes() const { return 1; }
+  result_type operator()(int32, int32) const { return m_value; }
+  prerasterize_type prerasterize(BBox2i const&) const { return *this; }
+  template <class DestT> void rasterize(DestT const& dest, BBox2i const& bbox) const {
+    for (int32 r = 0; r < bbox.height(); ++r) for (int32 c = 0; c < bbox.width(); ++c) dest(c, r) = m_value;
+  }
+};
+template <class PixelT> ConstantView<PixelT> constant_view(PixelT const& value, int32 cols, int32 rows) { return ConstantView<PixelT>(value, cols, rows); }
+template <class PixelT, class ViewT> ConstantView<PixelT> constant_view(PixelT const& value, ImageViewBase<ViewT> const& like) {
+  return ConstantView<PixelT>(value, like.impl().cols(), like.impl().rows());
+}
+
 // pixel_cast<DestPixelT>(view): lazy per-pixel conversion.
 template <class ChildT, class DestPixelT>
 class PixelCastView : public ImageViewBase<PixelCastView<ChildT, DestPixelT>> {
