@@ -40,16 +40,23 @@ bm_dot_u8_kernel(const float* __restrict__ left, ptrdiff_t ls, int lw, int lh,
                  DotGeom g, int32_t* __restrict__ out, ptrdiff_t os, int ow, int oh,
                  int* __restrict__ flag_set, int* __restrict__ flag_clear) {
   extern __shared__ uint32_t smem[];
-  const int tid = threadIdx.x, xl = tid & 63, dg = tid >> 6;
+  const int tid = threadIdx.x, xl = tid & 63;
+  const int dg = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar, so the per-disparity guards below are scalar branches
   const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TYR;
   if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) *flag_clear = 0;
 
   const int nr = g.nr, lws = g.lws, rws = g.rws;
-  uint32_t* Lph = smem;                                   // [4][nr][lws]
-  uint32_t* Rph = Lph + 4 * nr * lws;                     // [4][nr][rws]
-  uint32_t* A2row = Rph + 4 * nr * rws;                   // [TX]
+  // Byte-indexed word arrays: UL[r][b] = the 32-bit word made of bytes [b, b+3] of staged row r, for EVERY byte offset b.
+  // Window word n of a window that starts at byte c is U[r][c + 4n]: lane = column makes consecutive lanes read
+  // consecutive dwords (no bank conflicts), and the unrolled disparity index is an immediate offset (no address math).
+  const int LL = 4 * lws, RL = 4 * rws;                   // dwords per row of UL / UR
+  uint32_t* UL = smem;                                    // [nr][LL]
+  uint32_t* UR = UL + nr * LL;                            // [nr][RL]
+  uint32_t* Lph = UR + nr * RL;                           // [nr][lws]   the staged bytes (aligned words)
+  uint32_t* Rph = Lph + nr * lws;                         // [nr][rws]
+  uint32_t* A2row = Rph + nr * rws;                       // [TX]
   uint32_t* B2row = A2row + TX;                           // [256]
-  double* precL = reinterpret_cast<double*>(B2row + 256); // [TX]      (NCC)
+  double* precL = reinterpret_cast<double*>(smem + (((B2row + 256) - smem + 1) & ~(ptrdiff_t)1)); // [TX]  (NCC), 8-byte aligned
   double* precR = precL + TX;                             // [256]     (NCC)
   double* mbest = precR + 256;                            // [3][TX]
   double* mworst = mbest + 3 * TX;                        // [3][TX]
@@ -87,20 +94,16 @@ bm_dot_u8_kernel(const float* __restrict__ left, ptrdiff_t ls, int lw, int lh,
     }
   }
   __syncthreads();
-  // byte-phase copies: word w of phase p = bytes [4w+p, 4w+p+3]
-  for (int i = tid; i < nr * lws; i += NTHREADS) {
-    const int w = i % lws;
-    const uint32_t a = Lph[i], b = (w + 1 < lws) ? Lph[i + 1] : 0u;
-    Lph[1 * nr * lws + i] = (a >> 8) | (b << 24);
-    Lph[2 * nr * lws + i] = (a >> 16) | (b << 16);
-    Lph[3 * nr * lws + i] = (a >> 24) | (b << 8);
+  // byte-indexed words from the aligned ones (zero beyond the row)
+  for (int i = tid; i < nr * LL; i += NTHREADS) {
+    const int r = i / LL, b = i - r * LL, w = b >> 2;
+    const uint32_t a = Lph[r * lws + w], hi = (w + 1 < lws) ? Lph[r * lws + w + 1] : 0u;
+    UL[i] = __builtin_amdgcn_alignbyte(hi, a, b & 3);
   }
-  for (int i = tid; i < nr * rws; i += NTHREADS) {
-    const int w = i % rws;
-    const uint32_t a = Rph[i], b = (w + 1 < rws) ? Rph[i + 1] : 0u;
-    Rph[1 * nr * rws + i] = (a >> 8) | (b << 24);
-    Rph[2 * nr * rws + i] = (a >> 16) | (b << 16);
-    Rph[3 * nr * rws + i] = (a >> 24) | (b << 8);
+  for (int i = tid; i < nr * RL; i += NTHREADS) {
+    const int r = i / RL, b = i - r * RL, w = b >> 2;
+    const uint32_t a = Rph[r * rws + w], hi = (w + 1 < rws) ? Rph[r * rws + w + 1] : 0u;
+    UR[i] = __builtin_amdgcn_alignbyte(hi, a, b & 3);
   }
   __syncthreads();
 
@@ -109,30 +112,22 @@ bm_dot_u8_kernel(const float* __restrict__ left, ptrdiff_t ls, int lw, int lh,
   // this wave's disparities
   const int dpt = (sx + 3) / 4;
   const int dbeg = dg * dpt, dcnt = max(0, min(dpt, sx - dbeg));
-  const uint32_t* Lrow = Lph + (xl & 3) * nr * lws + (xl >> 2);           // + r * lws + n
+  const uint32_t* Lrow = UL + xl;                                         // + r * LL + 4 * n
   // running window sums
   uint32_t S[DCH];
 #pragma unroll
   for (int i = 0; i < DCH; ++i) S[i] = 0;
   uint32_t a2 = 0, b2 = 0;                                                // thread xl < TX (wave 0): A2 column; thread tid < nb: B2 column
-  const uint32_t* Bself = Rph + (tid & 3) * nr * rws + (tid >> 2);        // window origin x' = tid
+  const uint32_t* Bself = UR + tid;                                       // window origin x' = tid
   const bool ownB = tid < g.nb, ownA = dg == 0;
+  const int dlast = dcnt - 1;                                             // last slot of this wave's share
+  const bool full = dcnt == DCH;                                          // wave-uniform
 
-  auto row_dot = [&](const uint32_t* lrow, const uint32_t* rrow) -> uint32_t {      // sum_n dot4(L word n, R word n)
-    uint32_t s = 0;
-#pragma unroll
-    for (int n = 0; n < NW; ++n) {
-      uint32_t lwv = lrow[n];
-      if (n == NW - 1) lwv &= kmask;
-      s = __builtin_amdgcn_udot4(lwv, rrow[n], s, false);
-    }
-    return s;
-  };
   auto self_dot = [&](const uint32_t* row) -> uint32_t {
     uint32_t s = 0;
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
-      const uint32_t v = row[n];
+      const uint32_t v = row[4 * n];
       s = __builtin_amdgcn_udot4(n == NW - 1 ? (v & kmask) : v, v, s, false);
     }
     return s;
@@ -143,30 +138,44 @@ bm_dot_u8_kernel(const float* __restrict__ left, ptrdiff_t ls, int lw, int lh,
     const int gy = y0 + y;
     if (gy >= oh) break;                                                   // uniform
     // ---- update the running sums to the window rows [y, y + ky) ----
-    if (y == 0) {
-      for (int r = 0; r < ky; ++r) {
-        if (ownA) a2 += self_dot(Lrow + r * lws);
-        if (ownB) b2 += self_dot(Bself + r * rws);
+    // The slot loops carry no per-slot branch (a guard per disparity serialises every LDS round trip): slots past this
+    // wave's share re-read its last disparity — same addresses, a duplicate cost that can neither win (strict compare,
+    // larger index) nor change the worst value.
+    auto add_row = [&](int r, bool subtract) __attribute__((always_inline)) {
+      uint32_t lw_[NW];
+#pragma unroll
+      for (int n = 0; n < NW; ++n) { lw_[n] = Lrow[r * LL + 4 * n]; if (n == NW - 1) lw_[n] &= kmask; }
+      const uint32_t* rb = UR + r * RL + xl + dbeg;
+      if (full) {                                                           // every slot live: the slot index is an immediate offset
 #pragma unroll
         for (int i = 0; i < DCH; ++i) {
-          if (i < dcnt) {
-            const int xx = xl + dbeg + i;
-            S[i] += row_dot(Lrow + r * lws, Rph + (xx & 3) * nr * rws + r * rws + (xx >> 2));
-          }
+          uint32_t sdot = 0;
+#pragma unroll
+          for (int n = 0; n < NW; ++n) sdot = __builtin_amdgcn_udot4(lw_[n], rb[i + 4 * n], sdot, false);
+          S[i] = subtract ? S[i] - sdot : S[i] + sdot;
         }
+      } else {
+#pragma unroll
+        for (int i = 0; i < DCH; ++i) {
+          const int xi = i < dlast ? i : dlast;                             // scalar
+          uint32_t sdot = 0;
+#pragma unroll
+          for (int n = 0; n < NW; ++n) sdot = __builtin_amdgcn_udot4(lw_[n], rb[xi + 4 * n], sdot, false);
+          S[i] = subtract ? S[i] - sdot : S[i] + sdot;
+        }
+      }
+    };
+    if (y == 0) {
+      for (int r = 0; r < ky; ++r) {
+        if (ownA) a2 += self_dot(Lrow + r * LL);
+        if (ownB) b2 += self_dot(Bself + r * RL);
+        if (dcnt > 0) add_row(r, false);
       }
     } else {
       const int re = y + ky - 1, rl = y - 1;
-      if (ownA) a2 += self_dot(Lrow + re * lws) - self_dot(Lrow + rl * lws);
-      if (ownB) b2 += self_dot(Bself + re * rws) - self_dot(Bself + rl * rws);
-#pragma unroll
-      for (int i = 0; i < DCH; ++i) {
-        if (i < dcnt) {
-          const int xx = xl + dbeg + i;
-          const uint32_t* rb = Rph + (xx & 3) * nr * rws + (xx >> 2);
-          S[i] += row_dot(Lrow + re * lws, rb + re * rws) - row_dot(Lrow + rl * lws, rb + rl * rws);
-        }
-      }
+      if (ownA) a2 += self_dot(Lrow + re * LL) - self_dot(Lrow + rl * LL);
+      if (ownB) b2 += self_dot(Bself + re * RL) - self_dot(Bself + rl * RL);
+      if (dcnt > 0) { add_row(re, false); add_row(rl, true); }
     }
     if (ownA) {
       A2row[xl] = a2;
@@ -182,26 +191,33 @@ bm_dot_u8_kernel(const float* __restrict__ left, ptrdiff_t ls, int lw, int lh,
     int bidx = 0;
     if (COST == VWGPU_CROSS_CORRELATION) {
       const double pl = precL[xl];
+      if (dcnt > 0) {
 #pragma unroll
-      for (int i = 0; i < DCH; ++i) {
-        if (i < dcnt) {
-          const double c = (double)S[i] * sqrt(pl * precR[xl + dbeg + i]);
+        for (int i = 0; i < DCH; ++i) {
+          const int xi = i < dlast ? i : dlast;
+          const double c = (double)S[i] * sqrt(pl * precR[xl + dbeg + xi]);
           if (i == 0) { best = worst = c; bidx = dbeg; }
-          else { if (c > best) { best = c; bidx = dbeg + i; } if (c < worst) worst = c; }
+          else { if (c > best) { best = c; bidx = dbeg + xi; } if (c < worst) worst = c; }
         }
       }
     } else {
+      // cost = A2 + B2 - 2 S < 2^25 (kx, ky <= 16, 31): cost << 6 | slot is one v_min_u32 per slot, and the slot order inside
+      // the key keeps "first wins" (DCH <= 64 slots)
       const uint32_t al = A2row[xl];
-      uint32_t ub = 0, uw = 0;
+      uint32_t kb = 0xffffffffu, uw = 0;
+      if (dcnt > 0) {
+        const uint32_t* b2p = B2row + xl + dbeg;
 #pragma unroll
-      for (int i = 0; i < DCH; ++i) {
-        if (i < dcnt) {
-          const uint32_t c = al + B2row[xl + dbeg + i] - 2u * S[i];
-          if (i == 0) { ub = uw = c; bidx = dbeg; }
-          else { if (c < ub) { ub = c; bidx = dbeg + i; } if (c > uw) uw = c; }
+        for (int i = 0; i < DCH; ++i) {
+          const int xi = full ? i : (i < dlast ? i : dlast);
+          const uint32_t c = al + b2p[xi] - 2u * S[i];
+          const uint32_t key = (c << 6) | (uint32_t)xi;
+          kb = key < kb ? key : kb;
+          uw = c > uw ? c : uw;
         }
+        bidx = dbeg + (int)(kb & 63u);
       }
-      best = (double)ub; worst = (double)uw;
+      best = (double)(kb >> 6); worst = (double)uw;
     }
     if (dg > 0 && dcnt > 0) { mbest[(dg - 1) * TX + xl] = best; mworst[(dg - 1) * TX + xl] = worst; midx[(dg - 1) * TX + xl] = bidx; }
     __syncthreads();
@@ -224,7 +240,7 @@ bm_dot_u8_kernel(const float* __restrict__ left, ptrdiff_t ls, int lw, int lh,
 }
 
 size_t dot_lds_bytes(const DotGeom& g) {
-  return (size_t)(4 * g.nr * (g.lws + g.rws) + TX + 256) * 4 + (size_t)(TX + 256 + 6 * TX) * 8 + 3 * TX * 4;
+  return (size_t)(5 * g.nr * (g.lws + g.rws) + TX + 256 + 2) * 4 + (size_t)(TX + 256 + 6 * TX) * 8 + 3 * TX * 4;
 }
 
 DotGeom make_geom(int kx, int ky, int sx) {
@@ -242,7 +258,9 @@ typedef void (*DotFn)(const float*, ptrdiff_t, int, int, const float*, ptrdiff_t
 
 template <int COST>
 DotFn pick(int nw, int dpt) {
-#define VW_DOT(N) (dpt <= 12 ? (DotFn)bm_dot_u8_kernel<COST, N, 12> : dpt <= 24 ? (DotFn)bm_dot_u8_kernel<COST, N, 24> : (DotFn)bm_dot_u8_kernel<COST, N, 40>)
+// slots per lane: 33 = ceil(129 / 4), the +-64 px search, so that three of its four waves run the branch-free full path
+#define VW_DOT(N) (dpt <= 12 ? (DotFn)bm_dot_u8_kernel<COST, N, 12> : dpt <= 24 ? (DotFn)bm_dot_u8_kernel<COST, N, 24> : \
+                   dpt <= 33 ? (DotFn)bm_dot_u8_kernel<COST, N, 33> : (DotFn)bm_dot_u8_kernel<COST, N, 40>)
   switch (nw) {
     case 1: return VW_DOT(1);
     case 2: return VW_DOT(2);
