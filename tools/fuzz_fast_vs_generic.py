@@ -1,4 +1,4 @@
-"""Randomised cross-check of the packed-u8 SAD matcher against the generic float64 kernel (itself pinned to the oracle by
+"""Randomised cross-check of the packed-u8 matchers (SAD; with cost 1 / 2 as third argument: the SSD / NCC dot kernel) against the generic float64 kernel (itself pinned to the oracle by
 tests/test_bm_gpu.py): random sizes, kernels, 1-D / 2-D searches, flat patches, both matcher flavours.  GPU box only."""
 import os, sys
 import numpy as np, torch
@@ -8,15 +8,19 @@ from visionworkbench_amd import core, stereo
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+COST = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ctx = vwa.Context(0)
 kernels = [(3, 3), (5, 5), (7, 7), (7, 5), (9, 9), (11, 11)]
 bad = 0
 for it in range(N):
     kx, ky = kernels[rng.integers(len(kernels))]
-    sx = int(rng.integers(1, 140)); sy = int(rng.choice([1, 1, 1, 2, 3]))
+    if COST:
+        kx, ky = int(rng.integers(1, 9)) * 2 - 1, int(rng.integers(1, 9)) * 2 - 1
+    sx = int(rng.integers(1, 140)); sy = int(rng.choice([1, 1, 1, 2, 3])) if COST == 0 else 1
     w = int(rng.integers(kx, 2600)); h = int(rng.integers(ky, 200))
-    left = np.floor(rng.random((h, w)) * 256).astype(np.float32)
-    right = np.floor(rng.random((h + sy - 1, w + sx - 1)) * 256).astype(np.float32)
+    lo = 1 if COST == 2 else 0                       # NCC: no all-zero windows (1/0 sends the tile to the generic kernel anyway)
+    left = np.floor(rng.random((h, w)) * (256 - lo)).astype(np.float32) + lo
+    right = np.floor(rng.random((h + sy - 1, w + sx - 1)) * (256 - lo)).astype(np.float32) + lo
     # paste shifted copies so that there is structure, and flat patches so that validity matters
     d = int(rng.integers(0, sx))
     right[:h, d:d + w] = np.where(rng.random((h, w)) < 0.7, left, right[:h, d:d + w])
@@ -27,10 +31,10 @@ for it in range(N):
     os.environ["VWGPU_SAD_SPLIT"] = str(int(rng.integers(0, 2)))
     lt, rt = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
     ctx.force_path(core.PATH_NONE)
-    a = stereo.calc_disparity(0, lt, rt, vwa.bounding_box(left), (sx, sy), (kx, ky), ctx=ctx).cpu().numpy()
+    a = stereo.calc_disparity(COST, lt, rt, vwa.bounding_box(left), (sx, sy), (kx, ky), ctx=ctx).cpu().numpy()
     pa = ctx.last_path()
     ctx.force_path(core.PATH_GENERIC_F64)
-    b = stereo.calc_disparity(0, lt, rt, vwa.bounding_box(left), (sx, sy), (kx, ky), ctx=ctx).cpu().numpy()
+    b = stereo.calc_disparity(COST, lt, rt, vwa.bounding_box(left), (sx, sy), (kx, ky), ctx=ctx).cpu().numpy()
     ctx.force_path(core.PATH_NONE)
     if not np.array_equal(a, b):
         bad += 1
