@@ -718,10 +718,10 @@ path_uniform_pk_kernel(SgmGeom g, DirSet D, int K, int stride,
   extern __shared__ uint16_t sm[];
   const int num_disp = g.num_dx;                                                     // num_dy == 1
   const int npairs = (num_disp + 1) / 2;
-  unsigned* buf = reinterpret_cast<unsigned*>(sm) + 1;                               // [-1 .. EPT*64]: guards at both ends
-  uint16_t* p2tab = sm + 2 * (EPT * 64 + 2);                                         // 256
-  unsigned* cacc = reinterpret_cast<unsigned*>(p2tab + 256 + 4);                     // K x stride/2 dwords, 16-byte aligned
-  uint8_t* ccost = reinterpret_cast<uint8_t*>(cacc + (size_t)K * (stride / 2));      // K x stride
+  unsigned* buf = reinterpret_cast<unsigned*>(sm) + 1;                               // [-1 .. EPT*64]: guards at both ends, then a sink
+  uint16_t* p2tab = sm + 2 * (EPT * 64 + 4);                                         // 256
+  unsigned* cacc = reinterpret_cast<unsigned*>(p2tab + 256);                         // K x stride/2 dwords (+ a sink), 16-byte aligned
+  uint8_t* ccost = reinterpret_cast<uint8_t*>(cacc + (size_t)K * (stride / 2) + 4);  // K x stride
   uint8_t* pix = ccost + (size_t)K * stride;
   const int tid = threadIdx.x;
   int c0, r0, dc, dr;
@@ -735,15 +735,21 @@ path_uniform_pk_kernel(SgmGeom g, DirSet D, int K, int stride,
     if (v < p1) v = p1;
     p2tab[q] = (uint16_t)v;
   }
-  for (int i = tid - 1; i <= EPT * 64; i += 64) buf[i] = 0xffffffffu;               // guards + dead slots
-  bool live[EPT];
-  unsigned dead[EPT];                                                                // 0xffff0000 for the pair with a dead high half
+  for (int i = tid - 1; i <= EPT * 64 + 2; i += 64) buf[i] = 0xffffffffu;           // guards + dead slots + sink
+  // No branch on "does this lane's slot exist": a missing pair reads slot 0's cost with a zero mask, carries 0xffffffff
+  // (never the minimum) and writes to a sink dword, so the per-pixel step is straight-line code.
+  int jr[EPT], jw[EPT];                                                              // slot to read costs from / to write to
+  unsigned cmask[EPT], dead[EPT];                                                    // dead: 0xffff0000 half-dead pair, ~0 missing pair
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int j = tid + e * 64;
-    live[e] = j < npairs;
-    dead[e] = (2 * j + 1 >= num_disp) ? 0xffff0000u : 0u;
+    const bool live = j < npairs;
+    jr[e] = live ? j : 0;
+    jw[e] = live ? j : EPT * 64 + 1;                                                 // buf's sink
+    cmask[e] = live ? 0xffffffffu : 0u;
+    dead[e] = !live ? 0xffffffffu : ((2 * j + 1 >= num_disp) ? 0xffff0000u : 0u);
   }
+  unsigned* const acc_sink = cacc + (size_t)K * (stride / 2);
   const us2 p1p1 = as_us2(p1 | (p1 << 16));
   const int q_cost = stride / 16;
   const unsigned m_cost = (unsigned)((0x100000000ull + q_cost - 1) / q_cost);
@@ -766,15 +772,15 @@ path_uniform_pk_kernel(SgmGeom g, DirSet D, int K, int stride,
     }
     if (tid < kk) pix[tid] = left[(size_t)(r0 + (base + tid) * dr + min_row) * lw + (c0 + (base + tid) * dc + min_col)];
     __builtin_amdgcn_wave_barrier();
-    for (int k = 0; k < kk; ++k) {
+    const uint16_t* cc = reinterpret_cast<const uint16_t*>(ccost);
+    unsigned* ac = cacc;
+    for (int k = 0; k < kk; ++k, cc += stride / 2, ac += stride / 2) {
       const int vcur = pix[k];
-      const uint16_t* cc = reinterpret_cast<const uint16_t*>(ccost + k * stride);
-      unsigned* ac = cacc + k * (stride / 2);
       unsigned res[EPT];
       if (last_val < 0) {
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-          const unsigned cb = live[e] ? (unsigned)cc[tid + e * 64] : 0u;
+          const unsigned cb = (unsigned)cc[jr[e]] & cmask[e];
           res[e] = ((cb & 0xffu) | ((cb & 0xff00u) << 8)) | dead[e];
         }
       } else {
@@ -791,7 +797,7 @@ path_uniform_pk_kernel(SgmGeom g, DirSet D, int K, int stride,
           us2 m = __builtin_elementwise_min(__builtin_elementwise_min(ln, rn), ctr);
           us2 v = __builtin_elementwise_add_sat(m, p1p1);
           v = __builtin_elementwise_min(v, __builtin_elementwise_min(ctr, dJ));
-          const unsigned cb = live[e] ? (unsigned)cc[j] : 0u;
+          const unsigned cb = (unsigned)cc[jr[e]] & cmask[e];
           v = __builtin_elementwise_add_sat(v, as_us2((cb & 0xffu) | ((cb & 0xff00u) << 8)));
           v = __builtin_elementwise_sub_sat(v, mp);
           res[e] = as_u32(v) | dead[e];
@@ -801,8 +807,9 @@ path_uniform_pk_kernel(SgmGeom g, DirSet D, int K, int stride,
       us2 mn2 = as_us2(0xffffffffu);
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
-        const int j = tid + e * 64;
-        if (live[e]) { buf[j] = res[e]; ac[j] = res[e]; mn2 = __builtin_elementwise_min(mn2, as_us2(res[e])); }
+        buf[jw[e]] = res[e];
+        *(cmask[e] ? ac + jr[e] : acc_sink) = res[e];
+        mn2 = __builtin_elementwise_min(mn2, as_us2(res[e]));
       }
       const unsigned mnu = as_u32(mn2);
       min_prior = wave_min_u32(min(mnu & 0xffffu, mnu >> 16));
@@ -816,13 +823,7 @@ path_uniform_pk_kernel(SgmGeom g, DirSet D, int K, int stride,
         if (w < npairs) {
           unsigned v = cacc[j];
           if (2 * w + 1 >= num_disp) v &= 0xffffu;
-#ifdef VWX_PLAINADD
-          ga[pbase * q32 + j + (long long)k * (delta - 1) * q32] += v;
-#elif defined(VWX_NOADD)
-          if (v == 0x12345678u) ga[0] = v;
-#else
           atomicAdd(ga + pbase * q32 + j + (long long)k * (delta - 1) * q32, v);
-#endif
         }
       }
     }
@@ -1169,7 +1170,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       vwgpu_prof_scope ps(ctx, together ? "sgm_paths" : "sgm_path");
       if (uniform && one_d && num_disp <= 256) {
         const int pe = (int)(((num_disp + 1) / 2 + 63) / 64);
-        const size_t plds = (size_t)(pe * 64 + 2) * 4 + 256 * 2 + 8 + (size_t)K * ustride * 3 + K + 16;
+        const size_t plds = (size_t)(pe * 64 + 4) * 4 + 256 * 2 + ((size_t)K * ustride * 2 + 16) + (size_t)K * ustride + K + 16;
         if (pe == 1) hipLaunchKernelGGL(path_uniform_pk_kernel<1>, dim3(lines), dim3(64), plds, st, g, D, K, ustride, l8, lw, min_col, min_row,
                                         cost, accum, (unsigned)p1, (unsigned)p2);
         else hipLaunchKernelGGL(path_uniform_pk_kernel<2>, dim3(lines), dim3(64), plds, st, g, D, K, ustride, l8, lw, min_col, min_row,
