@@ -43,7 +43,14 @@ __global__ void minmax_kernel(const float* __restrict__ img, ptrdiff_t stride, i
       lo = min(lo, o); hi = max(hi, o);
     }
   for (int s = 32; s > 0; s >>= 1) { lo = min(lo, (unsigned)__shfl_xor((int)lo, s)); hi = max(hi, (unsigned)__shfl_xor((int)hi, s)); }
-  if ((threadIdx.x & 63) == 0) { atomicMin(mm, lo); atomicMax(mm + 1, hi); }
+  // one pair of atomics per workgroup: same-address atomics serialise at the L2
+  __shared__ unsigned part[4][2];
+  if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = lo; part[threadIdx.x >> 6][1] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) { lo = min(lo, part[k][0]); hi = max(hi, part[k][1]); }
+    atomicMin(mm, lo); atomicMax(mm + 1, hi);
+  }
 }
 
 __global__ void u8_convert_kernel(const float* __restrict__ img, ptrdiff_t stride, int w, int h, const unsigned* __restrict__ mm,
@@ -1060,8 +1067,8 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     vwgpu_prof_scope ps(ctx, "sgm_u8_convert");
     const unsigned init[8] = {0xffffffffu, 0u, 0xffffffffu, 0u, (unsigned)(rmh - 1), 0u, 0u, 0u};
     VWGPU_HIP(ctx, hipMemcpyAsync(mm, init, sizeof init, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(minmax_kernel, dim3(std::min((lw + 255) / 256, 64), std::min(lh, 256)), dim3(256), 0, st, left, ls, lw, lh, mm);
-    hipLaunchKernelGGL(minmax_kernel, dim3(std::min((rw + 255) / 256, 64), std::min(rh, 256)), dim3(256), 0, st, right, rs, rw, rh, mm + 2);
+    hipLaunchKernelGGL(minmax_kernel, dim3(std::min((lw + 255) / 256, 8), std::min(lh, 128)), dim3(256), 0, st, left, ls, lw, lh, mm);
+    hipLaunchKernelGGL(minmax_kernel, dim3(std::min((rw + 255) / 256, 8), std::min(rh, 128)), dim3(256), 0, st, right, rs, rw, rh, mm + 2);
     hipLaunchKernelGGL(u8_convert_kernel, dim3((lw + 255) / 256, lh), dim3(256), 0, st, left, ls, lw, lh, mm, l8);
     hipLaunchKernelGGL(u8_convert_kernel, dim3((rw + 255) / 256, rh), dim3(256), 0, st, right, rs, rw, rh, mm + 2, r8);
   }
