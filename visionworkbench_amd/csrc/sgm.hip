@@ -114,9 +114,17 @@ __global__ void census_kernel(const uint8_t* __restrict__ img, int w, int h, int
 // the downward scan stops above row 0).  Initialised by the host to {rmh - 1, 0}.
 __global__ void mask_col_extent_kernel(const uint8_t* __restrict__ rmask, int rmw, int rmh, int ocols, int* __restrict__ ext) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ocols) return;
-  for (int i = rmh - 1; i > 0; --i) if (rmask[(size_t)i * rmw + c] > 0) { atomicMax(ext + 1, i); break; }
-  for (int i = 0; i < rmh; ++i) if (rmask[(size_t)i * rmw + c] > 0) { atomicMin(ext, i); break; }
+  int hi = -1, lo = 0x7fffffff;
+  if (c < ocols) {
+    for (int i = rmh - 1; i > 0; --i) if (rmask[(size_t)i * rmw + c] > 0) { hi = i; break; }
+    for (int i = 0; i < rmh; ++i) if (rmask[(size_t)i * rmw + c] > 0) { lo = i; break; }
+  }
+  // one pair of atomics per wave (a column each used to send its own to the same two words)
+  for (int s = 32; s > 0; s >>= 1) { hi = max(hi, __shfl_xor(hi, s)); lo = min(lo, __shfl_xor(lo, s)); }
+  if ((threadIdx.x & 63) == 0) {
+    if (hi >= 0) atomicMax(ext + 1, hi);
+    if (lo != 0x7fffffff) atomicMin(ext, lo);
+  }
 }
 // per output row: {min valid right column, max valid right column} (-1, -2 when none; SGM.cc:337-354)
 __global__ void mask_row_extent_kernel(const uint8_t* __restrict__ rmask, int rmw, int orows, int2* __restrict__ rowext) {
