@@ -854,23 +854,49 @@ __global__ void uniform_starts_kernel(unsigned long long* __restrict__ starts, s
 
 // ---- winner take all --------------------------------------------------------------------------------------------------
 
-// one wavefront per pixel; ties on the minimum trigger the reference's smoothing loop on an LDS copy
+// One wavefront per pixel, WTA_PPW consecutive pixels per wavefront: their records (box, vector start) and the first 128
+// elements of their vectors are requested together before the first one is reduced — a pixel is two dependent memory round
+// trips (record -> vector) and a few dozen instructions, so one pixel per wave was pure latency (1.5 ms for 2048^2 x 129).
+// Ties on the minimum trigger the reference's smoothing loop on an LDS copy.
+constexpr int WTA_PPW = 4;
 __global__ void __launch_bounds__(256)
 wta_kernel(const B4* __restrict__ bounds, const unsigned long long* __restrict__ starts, size_t npix, int max_nd,
            uint16_t* __restrict__ accum, int32_t* __restrict__ disp) {
   extern __shared__ uint16_t sm[];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t p = (size_t)blockIdx.x * 4 + wv;
-  if (p >= npix) return;                                   // whole wave exits together
+  const size_t p0 = ((size_t)blockIdx.x * 4 + wv) * WTA_PPW;
+  if (p0 >= npix) return;                                  // whole wave exits together
   uint16_t* A = sm + (size_t)wv * 2 * max_nd;
   uint16_t* Bf = A + max_nd;
-  const B4 b = bounds[p];
+  B4 bq[WTA_PPW];
+  unsigned long long sq[WTA_PPW];
+  unsigned v0[WTA_PPW], v1[WTA_PPW];
+#pragma unroll
+  for (int q = 0; q < WTA_PPW; ++q) {
+    const size_t pq = p0 + q < npix ? p0 + q : npix - 1;
+    bq[q] = bounds[pq]; sq[q] = starts[pq];
+  }
+#pragma unroll
+  for (int q = 0; q < WTA_PPW; ++q) {
+    const int nq = (bq[q].x1 - bq[q].x0 + 1) * (bq[q].y1 - bq[q].y0 + 1);
+    v0[q] = lane < nq ? accum[sq[q] + lane] : 0u;
+    v1[q] = lane + 64 < nq ? accum[sq[q] + lane + 64] : 0u;
+  }
+#pragma unroll
+  for (int q = 0; q < WTA_PPW; ++q) {
+  const size_t p = p0 + q;
+  if (p >= npix) break;                                    // wave-uniform
+  const B4 b = bq[q];
   const int width = b.x1 - b.x0 + 1, height = b.y1 - b.y0 + 1, n = width * height;
   int32_t* o = disp + p * 3;
-  if (n <= 0) { if (lane == 0) { o[0] = 0; o[1] = 0; o[2] = 0; } return; }
-  uint16_t* av = accum + starts[p];
+  if (n <= 0) { if (lane == 0) { o[0] = 0; o[1] = 0; o[2] = 0; } continue; }
+  uint16_t* av = accum + sq[q];
   unsigned key = 0xffffffffu;
-  for (int i = lane; i < n; i += 64) { const unsigned v = av[i]; A[i] = (uint16_t)v; key = min(key, (v << 16) | (unsigned)i); }
+  __builtin_amdgcn_wave_barrier();                         // the previous pixel's LDS traffic is done
+  for (int i = lane; i < n; i += 64) {
+    const unsigned v = i < 64 ? v0[q] : (i < 128 ? v1[q] : (unsigned)av[i]);
+    A[i] = (uint16_t)v; key = min(key, (v << 16) | (unsigned)i);
+  }
   key = wave_min_u32(key);
   unsigned min_val = key >> 16;
   int cnt = 0;
@@ -914,6 +940,7 @@ wta_kernel(const B4* __restrict__ bounds, const unsigned long long* __restrict__
     dy += b.y1 - height + 1;
     o[0] = dx; o[1] = dy; o[2] = 0x7fffffff;
   }
+  }  // pixels of this wave
 }
 
 // ---- sub-pixel --------------------------------------------------------------------------------------------------------
@@ -1218,7 +1245,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   {
     vwgpu_prof_scope ps(ctx, "sgm_wta");
     const size_t lds = (size_t)4 * 2 * num_disp * sizeof(uint16_t);
-    hipLaunchKernelGGL(wta_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), lds, st, bounds, starts, npix, (int)num_disp, accum, out_disp);
+    hipLaunchKernelGGL(wta_kernel, dim3((unsigned)((npix + 4 * WTA_PPW - 1) / (4 * WTA_PPW))), dim3(256), lds, st, bounds, starts, npix, (int)num_disp, accum, out_disp);
   }
   if (out_sub) {
     vwgpu_prof_scope ps(ctx, "sgm_subpixel");
