@@ -12,9 +12,11 @@
 //
 // Issue-bound, not HBM-bound: 4096^2 x 129 disparities = 2.16 G (pixel, disparity) evaluations against
 // 337 MB of compulsory HBM traffic (42 us).  Measured on MI355X (profiles/r01_ubench_valu.txt): an ordinary
-// VALU op issues 16 lanes/clk/SIMD (64 lane-ops/clk/CU), v_qsad_pk_u16_u8 is quarter rate (16 abs-diffs
-// in 16 clk/wave = the same 4 abs-diffs per lane-slot as v_sad_u8), so the floor of this formulation is
-// ~17 lane-slots per 4 evaluations (11 qsad incl. the ky-1 halo rows + 4 key + 2 min3).
+// VALU op issues 16 lanes/clk/SIMD (64 lane-ops/clk/CU), v_qsad_pk_u16_u8 is quarter rate in isolation (16 abs-diffs
+// in 16 clk/wave = the same 4 abs-diffs per lane-slot as v_sad_u8), so the floor of this formulation per 4
+// evaluations is 2 qsad x 22/16 halo rows + 4 key + 2 min3.  Measured: a pair step (8 disparities x 4 pixels x 16
+// rows per lane) takes 0.92 us of a SIMD shared by two waves — the step loops run at that issue limit; what is left
+// are the staging / output phases (DESIGN.md 4.1 has the in-kernel timeline).
 //
 //   mapping   lane <-> 4 consecutive output pixels (q..q+3) x TY output rows; wave <-> 256 x TY pixels;
 //             workgroup = 4 (or 2) waves side by side.
@@ -33,9 +35,14 @@
 //             float tile is converted to a u8 base tile in LDS once, and for each t the workgroup derives
 //             one array of pre-shifted, pre-masked word groups (v_alignbyte_b32), then walks a = 0..A with
 //             one 8/16-byte LDS read per row.
-//   validity  invalid <=> all sx*sy costs equal.  Instead of tracking the worst cost everywhere, four costs
-//             per pixel are compared during the first sweep; only if some pixel of the workgroup has all four
-//             equal (never on textured data, always on flat data) a second launch (FIX = true) recomputes packed best/worst.
+//   validity  invalid <=> all sx*sy costs equal.  Instead of tracking the worst cost everywhere, four cost pairs are
+//             compared during the first sweep (one bit per lane and row: "some pixel of the row had equal costs in every
+//             probe"); only workgroups with a surviving row (never on textured data, always on flat data) do work in
+//             the second launch (FIX = true), which recomputes packed best / worst and invalidates.
+//   output    a lane's 4 pixels are 12 consecutive dwords, i.e. 48-byte strided stores; each wave transposes its row
+//             through LDS and writes three coalesced 1 KiB pieces instead.
+//   grids     1-D grid, tile = XCD-banded raster order; grids too small for two waves per SIMD run the two-wave-group
+//             variant (SPLIT); tile height and variant are picked by pick_launch's cost model.
 //
 // Limits (else the generic path): SAD only; kernel sizes in kLaunch; 4*ceil(kx/4)*ky*255 < 65536;
 // sx*sy <= 65535; LDS footprint <= 80 KiB.
