@@ -62,7 +62,10 @@ bm_generic_kernel(const float* __restrict__ left, ptrdiff_t ls, int lw, int lh,
                   int32_t* __restrict__ out, ptrdiff_t os, int ow, int oh,
                   const int* __restrict__ run_flag) {
   if (run_flag && *run_flag == 0) return;  // the fast path already produced the result
-  __shared__ double colbuf[2][GEN_THREADS];
+  // Column sums of all GEN_TY output rows of one disparity go to an LDS plane at once (two planes, alternating): ONE barrier
+  // per disparity instead of one per (disparity, row) — the first version spent its time in 16 x sx x sy barrier phases with
+  // a global-load round trip inside each.
+  __shared__ double plane[2][GEN_TY][GEN_THREADS];
 
   const int c = threadIdx.x;
   const int tile_w = GEN_THREADS - kx + 1;
@@ -82,7 +85,8 @@ bm_generic_kernel(const float* __restrict__ left, ptrdiff_t ls, int lw, int lh,
     for (int dx = 0; dx < sx; ++dx) {
       const float* lp = left + col;
       const float* rp = right + (ptrdiff_t)dy * rs + col + dx;
-      // column sum over the first ky rows of the tile (Algorithms.h:62-75)
+      // column sum over the first ky rows of the tile (Algorithms.h:62-75), then slid down the tile's rows
+      // (Algorithms.h:100-103: two statements)
       double cs = 0.0;
       if (col_ok) {
         for (int j = 0; j < ky; ++j) {
@@ -90,35 +94,39 @@ bm_generic_kernel(const float* __restrict__ left, ptrdiff_t ls, int lw, int lh,
           if (r < lh) cs += cost_elem<COST>(lp[(ptrdiff_t)r * ls], rp[(ptrdiff_t)r * rs]);
         }
       }
-      const bool first = (dx == 0 && dy == 0);
 #pragma unroll
       for (int y = 0; y < GEN_TY; ++y) {
-        colbuf[p][c] = cs;
-        __syncthreads();
-        const int oy = y0 + y;
-        if (out_col && oy < oh) {
-          double s = 0.0;
-          for (int i = 0; i < kx; ++i) s += colbuf[p][c + i];
-          if (COST == VWGPU_CROSS_CORRELATION) {
-            // cost_metric *= sqrt(left_precision * crop(right_precision, bbox + disparity))  (:227-231)
-            s *= sqrt(lprec[(size_t)oy * ow + col] * rprec[(size_t)(oy + dy) * rpw + col + dx]);
-          }
-          if (first) {
-            best[y] = worst[y] = s;                       // Correlation.cc:110-117
-          } else if (better<COST>(s, best[y])) {          // :95-98
-            best[y] = s; bdx[y] = dx; bdy[y] = dy;
-          } else if (!better<COST>(s, worst[y])) {        // :99-102
-            worst[y] = s;
-          }
-        }
-        p ^= 1;
-        // slide the column sum one row down (Algorithms.h:100-103: two statements)
-        const int rf = oy + ky;
+        plane[p][y][c] = cs;
+        const int oy = y0 + y, rf = oy + ky;
         if (col_ok && rf < lh) {
           cs += cost_elem<COST>(lp[(ptrdiff_t)rf * ls], rp[(ptrdiff_t)rf * rs]);
           cs -= cost_elem<COST>(lp[(ptrdiff_t)oy * ls], rp[(ptrdiff_t)oy * rs]);
         }
       }
+      __syncthreads();                                    // plane p complete; plane p^1 (previous disparity) fully consumed
+      const bool first = (dx == 0 && dy == 0);
+      if (out_col) {
+#pragma unroll
+        for (int y = 0; y < GEN_TY; ++y) {
+          const int oy = y0 + y;
+          if (oy < oh) {
+            double s = 0.0;
+            for (int i = 0; i < kx; ++i) s += plane[p][y][c + i];
+            if (COST == VWGPU_CROSS_CORRELATION) {
+              // cost_metric *= sqrt(left_precision * crop(right_precision, bbox + disparity))  (:227-231)
+              s *= sqrt(lprec[(size_t)oy * ow + col] * rprec[(size_t)(oy + dy) * rpw + col + dx]);
+            }
+            if (first) {
+              best[y] = worst[y] = s;                       // Correlation.cc:110-117
+            } else if (better<COST>(s, best[y])) {          // :95-98
+              best[y] = s; bdx[y] = dx; bdy[y] = dy;
+            } else if (!better<COST>(s, worst[y])) {        // :99-102
+              worst[y] = s;
+            }
+          }
+        }
+      }
+      p ^= 1;
     }
   }
 
