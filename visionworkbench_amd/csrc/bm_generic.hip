@@ -53,7 +53,9 @@ __global__ void ncc_precision_kernel(const float* __restrict__ img, ptrdiff_t st
   prec[(size_t)y * ow + x] = 1.0 / s;
 }
 
-template <int COST>
+// KX > 0: the window width is a compile-time constant, so the horizontal sum of each evaluation is kx unrolled LDS reads and
+// adds; with a run-time width the loop overhead was ~100 of the ~137 VALU instructions per evaluation (PMC).  KX == 0: any width.
+template <int COST, int KX>
 __global__ void __launch_bounds__(GEN_THREADS)
 bm_generic_kernel(const float* __restrict__ left, ptrdiff_t ls, int lw, int lh,
                   const float* __restrict__ right, ptrdiff_t rs,
@@ -62,10 +64,10 @@ bm_generic_kernel(const float* __restrict__ left, ptrdiff_t ls, int lw, int lh,
                   int32_t* __restrict__ out, ptrdiff_t os, int ow, int oh,
                   const int* __restrict__ run_flag) {
   if (run_flag && *run_flag == 0) return;  // the fast path already produced the result
-  // Column sums of all GEN_TY output rows of one disparity go to an LDS plane at once (two planes, alternating): ONE barrier
-  // per disparity instead of one per (disparity, row) — the first version spent its time in 16 x sx x sy barrier phases with
-  // a global-load round trip inside each.
-  __shared__ double plane[2][GEN_TY][GEN_THREADS];
+  // Column sums of all GEN_TY output rows of one disparity go to an LDS plane at once: two barriers per disparity instead of
+  // one per (disparity, row) with a global-load round trip inside each.  One 32 KB plane (not two alternating ones): four
+  // workgroups per CU hide the LDS / global latency better than a saved barrier does.
+  __shared__ double plane[1][GEN_TY][GEN_THREADS];
 
   const int c = threadIdx.x;
   const int tile_w = GEN_THREADS - kx + 1;
@@ -83,27 +85,28 @@ bm_generic_kernel(const float* __restrict__ left, ptrdiff_t ls, int lw, int lh,
   int p = 0;
   for (int dy = 0; dy < sy; ++dy) {
     for (int dx = 0; dx < sx; ++dx) {
-      const float* lp = left + col;
-      const float* rp = right + (ptrdiff_t)dy * rs + col + dx;
+      // running row pointers (no 64-bit multiply per access): *_b = the row that leaves the window, *_f = the row that enters
+      const float* lb = left + (ptrdiff_t)y0 * ls + col;
+      const float* rb = right + (ptrdiff_t)(y0 + dy) * rs + col + dx;
+      const float* lf = lb;
+      const float* rf_ = rb;
       // column sum over the first ky rows of the tile (Algorithms.h:62-75), then slid down the tile's rows
       // (Algorithms.h:100-103: two statements)
       double cs = 0.0;
-      if (col_ok) {
-        for (int j = 0; j < ky; ++j) {
-          const int r = y0 + j;
-          if (r < lh) cs += cost_elem<COST>(lp[(ptrdiff_t)r * ls], rp[(ptrdiff_t)r * rs]);
-        }
+      for (int j = 0; j < ky; ++j) {
+        if (col_ok && y0 + j < lh) cs += cost_elem<COST>(*lf, *rf_);
+        lf += ls; rf_ += rs;
       }
 #pragma unroll
       for (int y = 0; y < GEN_TY; ++y) {
         plane[p][y][c] = cs;
-        const int oy = y0 + y, rf = oy + ky;
-        if (col_ok && rf < lh) {
-          cs += cost_elem<COST>(lp[(ptrdiff_t)rf * ls], rp[(ptrdiff_t)rf * rs]);
-          cs -= cost_elem<COST>(lp[(ptrdiff_t)oy * ls], rp[(ptrdiff_t)oy * rs]);
+        if (col_ok && y0 + y + ky < lh) {
+          cs += cost_elem<COST>(*lf, *rf_);
+          cs -= cost_elem<COST>(*lb, *rb);
         }
+        lf += ls; rf_ += rs; lb += ls; rb += rs;
       }
-      __syncthreads();                                    // plane p complete; plane p^1 (previous disparity) fully consumed
+      __syncthreads();                                    // plane complete
       const bool first = (dx == 0 && dy == 0);
       if (out_col) {
 #pragma unroll
@@ -111,7 +114,12 @@ bm_generic_kernel(const float* __restrict__ left, ptrdiff_t ls, int lw, int lh,
           const int oy = y0 + y;
           if (oy < oh) {
             double s = 0.0;
-            for (int i = 0; i < kx; ++i) s += plane[p][y][c + i];
+            if (KX > 0) {
+#pragma unroll
+              for (int i = 0; i < KX; ++i) s += plane[p][y][c + i];
+            } else {
+              for (int i = 0; i < kx; ++i) s += plane[p][y][c + i];
+            }
             if (COST == VWGPU_CROSS_CORRELATION) {
               // cost_metric *= sqrt(left_precision * crop(right_precision, bbox + disparity))  (:227-231)
               s *= sqrt(lprec[(size_t)oy * ow + col] * rprec[(size_t)(oy + dy) * rpw + col + dx]);
@@ -126,7 +134,7 @@ bm_generic_kernel(const float* __restrict__ left, ptrdiff_t ls, int lw, int lh,
           }
         }
       }
-      p ^= 1;
+      __syncthreads();                                    // plane consumed
     }
   }
 
@@ -185,20 +193,18 @@ int vwgpu_launch_bm_generic_flag(vwgpu_ctx* ctx, int cost_type,
   dim3 grd((ow + tile_w - 1) / tile_w, (oh + GEN_TY - 1) / GEN_TY);
   dim3 blk(GEN_THREADS);
   vwgpu_prof_scope ps(ctx, "bm_generic");
+#define VW_GEN(C, K) hipLaunchKernelGGL((bm_generic_kernel<C, K>), grd, blk, 0, ctx->stream, \
+                                       left, ls, lw, lh, right, rs, kx, ky, sx, sy, lprec, rprec, rpw, out, os, ow, oh, run_flag)
+#define VW_GEN_K(C) do { switch (kx) { case 3: VW_GEN(C, 3); break; case 5: VW_GEN(C, 5); break; case 7: VW_GEN(C, 7); break; \
+                                      case 9: VW_GEN(C, 9); break; case 11: VW_GEN(C, 11); break; case 13: VW_GEN(C, 13); break; \
+                                      case 15: VW_GEN(C, 15); break; default: VW_GEN(C, 0); break; } } while (0)
   switch (cost_type) {
-    case VWGPU_CROSS_CORRELATION:
-      hipLaunchKernelGGL(bm_generic_kernel<VWGPU_CROSS_CORRELATION>, grd, blk, 0, ctx->stream,
-                         left, ls, lw, lh, right, rs, kx, ky, sx, sy, lprec, rprec, rpw, out, os, ow, oh, run_flag);
-      break;
-    case VWGPU_SQUARED_DIFFERENCE:
-      hipLaunchKernelGGL(bm_generic_kernel<VWGPU_SQUARED_DIFFERENCE>, grd, blk, 0, ctx->stream,
-                         left, ls, lw, lh, right, rs, kx, ky, sx, sy, lprec, rprec, rpw, out, os, ow, oh, run_flag);
-      break;
-    default:
-      hipLaunchKernelGGL(bm_generic_kernel<VWGPU_ABSOLUTE_DIFFERENCE>, grd, blk, 0, ctx->stream,
-                         left, ls, lw, lh, right, rs, kx, ky, sx, sy, lprec, rprec, rpw, out, os, ow, oh, run_flag);
-      break;
+    case VWGPU_CROSS_CORRELATION: VW_GEN_K(VWGPU_CROSS_CORRELATION); break;
+    case VWGPU_SQUARED_DIFFERENCE: VW_GEN_K(VWGPU_SQUARED_DIFFERENCE); break;
+    default: VW_GEN_K(VWGPU_ABSOLUTE_DIFFERENCE); break;
   }
+#undef VW_GEN_K
+#undef VW_GEN
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }
