@@ -63,7 +63,9 @@ __global__ void zone_precision_kernel(const float* __restrict__ img, int w, int 
   prec[(size_t)j * pw + i] = 1.0 / s;
 }
 
-template <int COST>
+// KS > 0: a square KS x KS window known at compile time — the horizontal and vertical window sums are unrolled (with run-time
+// sizes the loop overhead outweighed the sums, as PMC showed for bm_generic).  KS == 0: any kx, ky.
+template <int COST, int KS>
 __global__ void __launch_bounds__(ZTHREADS)
 bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __restrict__ B, int bw, int bh,
                 int kx, int ky, const vwgpu_zone_task* __restrict__ zones, const int2* __restrict__ tiles,
@@ -117,7 +119,12 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
             const float* lp = Lp + r * PW + q;
             const float* rp = Rp + r * RW + q + d;
             double s = 0.0;
-            for (int a = 0; a < kx; ++a) s += zcost<COST>(lp[a], rp[a]);
+            if (KS > 0) {
+#pragma unroll
+              for (int a = 0; a < KS; ++a) s += zcost<COST>(lp[a], rp[a]);
+            } else {
+              for (int a = 0; a < kx; ++a) s += zcost<COST>(lp[a], rp[a]);
+            }
             Hc[r * ZT + q] = s;
           }
         }
@@ -130,7 +137,12 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
             const int y = y0 + m;
             if (y < th) {
               double s = 0.0;
-              for (int b = 0; b < ky; ++b) s += Hc[(y + b) * ZT + c];
+              if (KS > 0) {
+#pragma unroll
+                for (int b = 0; b < KS; ++b) s += Hc[(y + b) * ZT + c];
+              } else {
+                for (int b = 0; b < ky; ++b) s += Hc[(y + b) * ZT + c];
+              }
               if (COST == VWGPU_CROSS_CORRELATION)
                 s *= sqrt(lprec[m] * pb.p[(size_t)(z.by + oy + y + dy - pb.y0) * pb.w + (z.bx + ox + c + dx - pb.x0)]);
               if (first) { best[m] = worst[m] = s; }
@@ -263,17 +275,17 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
   if (rc) return rc;
   vwgpu_prof_scope ps(ctx, "bm_zones");
   const dim3 grd((unsigned)tiles.size()), blk(ZTHREADS);
+#define VW_ZN(C, K) hipLaunchKernelGGL((bm_zones_kernel<C, K>), grd, blk, lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, dt, sxc, pa, pb, out)
+#define VW_ZN_K(C) do { switch (kx == ky ? kx : 0) { case 3: VW_ZN(C, 3); break; case 5: VW_ZN(C, 5); break; case 7: VW_ZN(C, 7); break; \
+                                                     case 9: VW_ZN(C, 9); break; case 11: VW_ZN(C, 11); break; case 13: VW_ZN(C, 13); break; \
+                                                     default: VW_ZN(C, 0); break; } } while (0)
   switch (cost_type) {
-    case VWGPU_CROSS_CORRELATION:
-      hipLaunchKernelGGL(bm_zones_kernel<VWGPU_CROSS_CORRELATION>, grd, blk, lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, dt, sxc, pa, pb, out);
-      break;
-    case VWGPU_SQUARED_DIFFERENCE:
-      hipLaunchKernelGGL(bm_zones_kernel<VWGPU_SQUARED_DIFFERENCE>, grd, blk, lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, dt, sxc, pa, pb, out);
-      break;
-    default:
-      hipLaunchKernelGGL(bm_zones_kernel<VWGPU_ABSOLUTE_DIFFERENCE>, grd, blk, lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, dt, sxc, pa, pb, out);
-      break;
+    case VWGPU_CROSS_CORRELATION: VW_ZN_K(VWGPU_CROSS_CORRELATION); break;
+    case VWGPU_SQUARED_DIFFERENCE: VW_ZN_K(VWGPU_SQUARED_DIFFERENCE); break;
+    default: VW_ZN_K(VWGPU_ABSOLUTE_DIFFERENCE); break;
   }
+#undef VW_ZN_K
+#undef VW_ZN
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }
