@@ -58,7 +58,8 @@ typedef enum vwgpu_path {
   VWGPU_PATH_NONE = 0,
   VWGPU_PATH_GENERIC_F64 = 1,  /* any float input, float64 accumulators (reference arithmetic)          */
   VWGPU_PATH_SAD_U8 = 2,       /* integer-valued inputs in [0,255]: packed u8 SAD (v_qsad_pk_u16_u8)      */
-  VWGPU_PATH_DOT_U8 = 3        /* integer-valued inputs in [0,255]: SSD / NCC on v_dot4_u32_u8            */
+  VWGPU_PATH_DOT_U8 = 3,       /* integer-valued inputs in [0,255]: SSD / NCC on v_dot4_u32_u8            */
+  VWGPU_PATH_EXACT_ORDER = 4   /* inputs whose box sums round: the reference's serial summation order     */
 } vwgpu_path;
 
 /* ---- context ------------------------------------------------------------------------------------- */
@@ -80,6 +81,19 @@ int vwgpu_synchronize(vwgpu_ctx* ctx);
 const char* vwgpu_strerror(int status);
 /* Detail text of the last failing call on this context ("" if none). */
 const char* vwgpu_last_error(const vwgpu_ctx* ctx);
+
+/* Per-context options.
+ *   VWGPU_OPT_DEFER_EXACTNESS  calc_disparity_dev picks its kernel family from the DATA: integer-valued pixels in [0,255] take
+ *       the packed kernels, other inputs the float64 kernel when every box-sum partial is exactly representable (then any
+ *       summation order returns the reference's bits), and the reference's own serial summation order otherwise
+ *       (VWGPU_PATH_EXACT_ORDER).  The classes are measured on the device; by default (0) the call waits for them, so that
+ *       the result is bit-exact for any input.  1 = pipelined callers that queue many calls without a host round trip: the
+ *       call never waits — packed kernels first, the float64 kernel behind a device flag — and vwgpu_last_path() reports
+ *       afterwards which family produced the result (bench.py asserts VWGPU_PATH_SAD_U8).
+ *   VWGPU_OPT_DEVICE_COUNT (read only): HIP devices visible to the process. */
+typedef enum vwgpu_option { VWGPU_OPT_DEFER_EXACTNESS = 1, VWGPU_OPT_DEVICE_COUNT = 2 } vwgpu_option;
+int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value);
+int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value);
 
 /* Forces a kernel family (testing / benchmarking): VWGPU_PATH_NONE = automatic dispatch (default). */
 int vwgpu_force_path(vwgpu_ctx* ctx, int path);
@@ -108,7 +122,9 @@ int vwgpu_profile_read(vwgpu_ctx* ctx, const char** names, float* ms, int cap);
  *
  * Semantics kept from the reference: raster order dy-outer/dx-inner, strict comparison, first wins;
  * a pixel is invalid iff its best and worst cost are equal (so search_volume (1,1) is all-invalid).
- * Bit-exact against the reference when pixel values are integer-valued floats. */
+ * Bit-exact against the reference for any float input: inputs whose box sums could round take the kernels that
+ * follow fast_box_sum's serial summation order (VWGPU_PATH_EXACT_ORDER; up to 512 disparities per call, beyond that
+ * the float64 kernel with tile-local sums serves them).  See VWGPU_OPT_DEFER_EXACTNESS for the asynchronous variant. */
 int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
                              const float* d_left, int lw, int lh, ptrdiff_t lstride,
                              const float* d_right, int rw, int rh, ptrdiff_t rstride,
@@ -120,6 +136,18 @@ int vwgpu_calc_disparity(vwgpu_ctx* ctx, int cost_type,
                          const float* right, int rw, int rh, ptrdiff_t rstride,
                          int kx, int ky, int sx, int sy,
                          int32_t* out, ptrdiff_t ostride);
+
+/* ---- box sums ------------------------------------------------------------------------------------------ */
+
+/* Replaces vw::stereo::fast_box_sum<double>(image, kernel) (src/vw/Stereo/Algorithms.h:41-129): out(x, y) = sum of the
+ * kx x ky window whose top-left pixel is (x, y), float64, (w-kx+1) x (h-ky+1) pixels, ostride in ELEMENTS (0 = dense).
+ * The sums are formed in the reference's order (running column sums down the rows, running row sums along the columns:
+ * :62-75, :81-110), so the result is bit-identical for ANY float input, not just exactly summable ones.
+ * kx, ky must be odd (the reference's always-on VW_ASSERT, :45-46) and fit the image. */
+int vwgpu_fast_box_sum_dev(vwgpu_ctx* ctx, const float* d_img, int w, int h, ptrdiff_t stride, int kx, int ky,
+                           double* d_out, ptrdiff_t ostride);
+int vwgpu_fast_box_sum(vwgpu_ctx* ctx, const float* img, int w, int h, ptrdiff_t stride, int kx, int ky,
+                       double* out, ptrdiff_t ostride);
 
 /* ---- left/right consistency check --------------------------------------------------------------- */
 

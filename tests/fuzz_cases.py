@@ -1,0 +1,112 @@
+"""Seeded random case generators shared by the gpu-marked fuzz tests (tests/test_fuzz_gpu.py) and the command-line
+aids in tools/fuzz_*.py / tools/replay_pyramid_case.py.  A case is a plain dict; every generator is a pure function of
+(seed, index stream), so a failing case can be replayed from the numbers the test prints."""
+import numpy as np
+
+KERNELS_SAD = [(3, 3), (5, 5), (7, 7), (7, 5), (9, 9), (11, 11)]
+
+
+def bm_cases(n, seed, cost):
+    """calc_disparity: random sizes / kernels / 1-D and 2-D searches, shifted copies + flat patches (validity)."""
+    rng = np.random.default_rng(seed)
+    for it in range(n):
+        kx, ky = KERNELS_SAD[rng.integers(len(KERNELS_SAD))]
+        if cost:
+            kx, ky = int(rng.integers(1, 9)) * 2 - 1, int(rng.integers(1, 9)) * 2 - 1
+        sx = int(rng.integers(1, 140))
+        sy = int(rng.choice([1, 1, 1, 2, 3])) if cost == 0 else 1
+        w = int(rng.integers(kx, 2600))
+        h = int(rng.integers(ky, 200))
+        lo = 1 if cost == 2 else 0                     # NCC: no all-zero windows (1/0 is the float64 kernel's business)
+        left = np.floor(rng.random((h, w)) * (256 - lo)).astype(np.float32) + lo
+        right = np.floor(rng.random((h + sy - 1, w + sx - 1)) * (256 - lo)).astype(np.float32) + lo
+        d = int(rng.integers(0, sx))
+        right[:h, d:d + w] = np.where(rng.random((h, w)) < 0.7, left, right[:h, d:d + w])
+        if rng.random() < 0.5:
+            y0, x0 = int(rng.integers(0, h)), int(rng.integers(0, w))
+            left[y0:y0 + 20, x0:x0 + 40] = 7.0
+            right[y0:y0 + 24, x0:x0 + 60 + sx] = 7.0
+        split = str(int(rng.integers(0, 2)))
+        yield dict(it=it, cost=cost, kernel=(kx, ky), search=(sx, sy), left=left, right=right, split=split)
+
+
+def pyramid_cases(n, seed, prefilters=(0,), costs=(0, 0, 1), float_scene=0.0):
+    """pyramid_correlate: random scenes (row bands shifted by different amounts), search boxes, kernels, thresholds, filter
+    radii, level counts, masks, interior / border tiles.  `float_scene` = probability of a non-integer (smooth float)
+    texture, the input class on which the reference's running box sums round position-dependently."""
+    rng = np.random.default_rng(seed)
+    for it in range(n):
+        H, W = int(rng.integers(90, 360)), int(rng.integers(120, 520))
+        left = np.floor(rng.random((H, W)) * 256).astype(np.float32)
+        aux = np.random.default_rng([seed, 1000003 + it])   # options added later draw from their own stream, so that
+        is_float = aux.random() < float_scene               # (index, seed) of the original generator still replays
+        if is_float:
+            left = (left * np.float32(0.37) + aux.random((H, W)).astype(np.float32)).astype(np.float32)
+        right = np.empty_like(left)
+        band = int(rng.integers(20, 90))
+        for y0 in range(0, H, band):
+            right[y0:y0 + band] = np.roll(left[y0:y0 + band], int(rng.integers(-7, 8)), axis=1)
+        if rng.random() < 0.5:
+            right = np.roll(right, int(rng.integers(-2, 3)), axis=0)
+        mx, my = int(rng.integers(1, 12)), int(rng.integers(0, 4))
+        search = (-mx, -my, mx + int(rng.integers(0, 3)), my + 1)
+        k = int(rng.choice([3, 5, 7, 9]))
+        ky = int(rng.choice([k, k, 5]))
+        cost = int(rng.choice(list(costs)))
+        thr = float(rng.choice([-1, 1, 2]))
+        filt = int(rng.choice([0, 3, 5]))
+        levels = int(rng.integers(0, 5))
+        lm = rm = None
+        if rng.random() < 0.4:
+            lm = np.full(left.shape, 255, np.uint8)
+            rm = np.full(right.shape, 255, np.uint8)
+            y0, x0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+            lm[y0:y0 + 30, x0:x0 + 50] = 0
+            rm[:, -int(rng.integers(1, 40)):] = 0
+        bbox = None
+        if rng.random() < 0.6:
+            bw, bh = int(rng.integers(24, min(200, W))), int(rng.integers(24, min(160, H)))
+            bbox = (int(rng.integers(0, W - bw + 1)), int(rng.integers(0, H - bh + 1)), bw, bh)
+        pf = int(aux.choice(list(prefilters)))
+        pfw = 0.0 if pf == 0 else float(aux.choice([1.4, 2.0, 3.0]))
+        yield dict(it=it, left=left, right=right, lm=lm, rm=rm, search=search, kernel=(k, ky), cost=cost, thr=thr,
+                   filt=filt, levels=levels, bbox=bbox, pf=pf, pfw=pfw, is_float=is_float)
+
+
+def sgm_cases(n, seed):
+    """calc_disparity_sgm: random sizes, 1-D / 2-D searches, kernels, cost types, masks, previous-level disparities,
+    memory limits, sub-pixel modes."""
+    rng = np.random.default_rng(seed)
+    for it in range(n):
+        k = int(rng.choice([3, 5, 7, 9]))
+        cost = int(rng.choice([3, 4]))
+        sx = int(rng.integers(0, 70))
+        sy = int(rng.choice([0, 0, 1, 2, 6]))
+        if rng.random() < 0.2:
+            sx = int(rng.integers(100, 140))
+            sy = 0
+        h = int(rng.integers(k + 2, 70))
+        w = int(rng.integers(k + 2, 120))
+        base = rng.random((h + sy + 8, w + sx + 8))
+        scale = float(rng.choice([255.0, 1.0, 4000.0]))
+        base = (base * scale).astype(np.float32)
+        d0 = (int(rng.integers(0, sx + 1)), int(rng.integers(0, sy + 1)))
+        left = np.ascontiguousarray(base[4:4 + h, 4:4 + w])
+        right = np.ascontiguousarray(base[4 - min(d0[1], 4):4 - min(d0[1], 4) + h + sy, 4 - min(d0[0], 4):4 - min(d0[0], 4) + w + sx])
+        oh, ow = h - k + 1, w - k + 1
+        lm = rm = prev = None
+        if rng.random() < 0.4:
+            lm = np.full((oh, ow), 255, np.uint8)
+            y0, x0 = int(rng.integers(0, oh)), int(rng.integers(0, ow))
+            lm[y0:y0 + 9, x0:x0 + 14] = 0
+        if rng.random() < 0.3:
+            rm = np.full((oh + sy, ow + sx), 255, np.uint8)
+            rm[:, -int(rng.integers(1, 6)):] = 0
+        if rng.random() < 0.4:
+            prev = np.zeros(((oh + 1) // 2, (ow + 1) // 2, 3), np.int32)
+            prev[..., 0] = rng.integers(0, sx // 2 + 1, prev.shape[:2])
+            prev[..., 1] = rng.integers(0, sy // 2 + 1, prev.shape[:2])
+            prev[..., 2] = np.where(rng.random(prev.shape[:2]) < 0.85, np.iinfo(np.int32).max, 0)
+        sub = int(rng.choice([0, 1, 2, 3, 4, 5])) if (sx > 0 or sy > 0) else 0
+        mem = int(rng.choice([6000, 6000, 1]))
+        yield dict(it=it, k=k, cost=cost, search=(sx, sy), left=left, right=right, lm=lm, rm=rm, prev=prev, sub=sub, mem=mem)

@@ -155,21 +155,35 @@ def test_minimum_size_image(ctx, oracle):
 
 
 def test_non_integer_input_falls_back_to_generic(ctx, oracle):
-    """Float textures are outside the bit-exact domain: the packed path must refuse them (device flag) and the
-    float64 kernel must take over; the mismatch rate against the reference's serial sums is reported, not zero."""
+    """Float textures are outside the packed kernels' domain: they must refuse them (device flag) and a float64 kernel
+    must take over — the tile kernel when every partial box sum is representable (any order gives the reference's bits),
+    the exact-order kernels otherwise (tests/test_exact_order_gpu.py).  Either way the result is the oracle's."""
     left = synth.noise_f32(41, 48, 120, 0.0, 1.0)
     right = np.concatenate([synth.noise_f32(42, 48, 8), left, synth.noise_f32(43, 48, 8)], axis=1)
     got, path = _gpu(ctx, ABS, left, right, (7, 7), (17, 1))
-    assert path == core.PATH_GENERIC_F64
+    assert path in (core.PATH_GENERIC_F64, core.PATH_EXACT_ORDER)
     want = oracle.calc_disparity(ABS, left, right, (7, 7), (17, 1))
     assert (got[..., 0] == 8).mean() > 0.99
-    assert (got != want).any(-1).mean() < 0.01
+    assert np.array_equal(got, want)
     # 255.5 / negative / NaN also force the fallback
     for bad in (255.5, -1.0, float("nan"), 256.0):
         l2, r2, _ = synth.stereo_pair(64, 24, 9)
         l2[3, 5] = bad
+        g2, p = _gpu(ctx, ABS, l2, r2, (5, 5), (9, 1))
+        assert p in (core.PATH_GENERIC_F64, core.PATH_EXACT_ORDER)
+        assert np.array_equal(g2, oracle.calc_disparity(ABS, l2, r2, (5, 5), (9, 1)))
+    # pipelined callers (VWGPU_OPT_DEFER_EXACTNESS): no host round trip, the flag is read by vwgpu_last_path afterwards
+    ctx.set_option(core.OPT_DEFER_EXACTNESS, 1)
+    try:
+        l2, r2, _ = synth.stereo_pair(64, 24, 9)
         _, p = _gpu(ctx, ABS, l2, r2, (5, 5), (9, 1))
+        assert p == core.PATH_SAD_U8
+        l2[3, 5] = 0.5
+        g2, p = _gpu(ctx, ABS, l2, r2, (5, 5), (9, 1))
         assert p == core.PATH_GENERIC_F64
+        assert np.array_equal(g2, oracle.calc_disparity(ABS, l2, r2, (5, 5), (9, 1)))
+    finally:
+        ctx.set_option(core.OPT_DEFER_EXACTNESS, 0)
 
 
 def test_strided_region_crop(ctx, oracle, sad_variant):

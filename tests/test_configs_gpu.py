@@ -1,0 +1,127 @@
+"""Parity evidence AT the sizes BASELINE.json names (configs 2-5), through the C ABI, against the CPU oracle.
+
+  config 2  4096^2, 7x7 SAD, 129x1            the whole 4090^2 disparity image, bit for bit
+  config 3  4096^2, 11x11 NCC + parabola      the whole 4086^2 integer image bit for bit, then the whole sub-pixel image
+  config 4  16384-wide census-SGM strips      SGM is global along every scan line (no crop reproduces a strip), so the
+                                              oracle runs strips it can finish in seconds — 16384 columns x 129
+                                              disparities, the kernel and row length of the config — and a 2048-wide,
+                                              256-row strip; the full 16384 x 2048 strip is checked against ground truth
+  config 5  1024^2 tiles of a 32768-wide pair pyramid_correlate BM-NCC (5 levels, L/R check, filters) and SGM + sub-pixel
+The oracle legs run on the host cores of the GPU box (tile threads as the reference runs them)."""
+import os
+
+import numpy as np
+import pytest
+
+import visionworkbench_amd as vwa
+from visionworkbench_amd import core, stereo, synth
+from visionworkbench_amd.core import BBox2i
+
+pytestmark = pytest.mark.gpu
+NCPU = os.cpu_count() or 8
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked tests need a GPU"
+    c = vwa.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def pair4096():
+    return synth.stereo_pair(4096, 4096, 129, 1)
+
+
+def test_config2_full_image_identical(ctx, oracle, pair4096):
+    import torch
+    left, right, truth = pair4096
+    got = stereo.calc_disparity(0, torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda(), vwa.bounding_box(left), (129, 1), (7, 7), ctx=ctx)
+    torch.cuda.synchronize()
+    assert ctx.last_path() == core.PATH_SAD_U8
+    got = got.cpu().numpy()
+    want, tiles = oracle.calc_disparity_tiled(0, left, right, (7, 7), (129, 1), tile=256, threads=NCPU)
+    assert want.shape == got.shape == (4090, 4090, 3) and tiles == 256
+    assert np.array_equal(got, want), int((got != want).any(-1).sum())
+    assert (got[..., 2] == core.VALID_I32).mean() > 0.999 and (got[..., 0] == truth[:4090, :4090]).mean() > 0.9
+
+
+def test_config3_ncc_then_parabola_full_image(ctx, oracle, pair4096):
+    import torch
+    left, right, truth = pair4096
+    lt, rt = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    got = stereo.calc_disparity(2, lt, rt, vwa.bounding_box(left), (129, 1), (11, 11), ctx=ctx)
+    torch.cuda.synchronize()
+    assert ctx.last_path() == core.PATH_DOT_U8
+    got = got.cpu().numpy()
+    want, _ = oracle.calc_disparity_tiled(2, left, right, (11, 11), (129, 1), tile=256, threads=NCPU)
+    assert got.shape == (4086, 4086, 3)
+    assert np.array_equal(got, want), int((got != want).any(-1).sum())
+    # parabola_subpixel takes a disparity of the left image's size, window-centred (ParabolaSubpixelView.cc:277-330)
+    disp = np.zeros((4096, 4096, 3), np.float32)
+    disp[5:5 + 4086, 5:5 + 4086, :2] = got[..., :2]
+    disp[5:5 + 4086, 5:5 + 4086, 2] = got[..., 2] != 0
+    sub = stereo.parabola_subpixel(torch.from_numpy(disp).cuda(), lt, rt, 0, 0.0, (11, 11), ctx=ctx)
+    torch.cuda.synchronize()
+    sub = sub.cpu().numpy()
+    ref = oracle.parabola_subpixel(disp, left, right, 0, 0.0, (11, 11))
+    assert np.array_equal(sub[..., 2], ref[..., 2])
+    assert np.array_equal(sub, ref), float(np.abs(sub - ref).max())       # integer imagery: every sum is exact
+
+
+@pytest.mark.parametrize("w,rows", [(16384, 38), (2048, 262)])
+def test_config4_sgm_strips_identical(oracle, w, rows):
+    """census 7x7, 129 disparities, 8 paths, LC-blend sub-pixel on strips as wide as config 4's rows."""
+    left, right, truth = synth.stereo_pair(w, rows, 129, 1)
+    gi, gs = stereo.calc_disparity_sgm(3, left, right, BBox2i(0, 0, w, rows), (128, 0), (7, 7), with_subpixel=True)
+    oi, os_ = oracle.calc_disparity_sgm(3, left, right, (128, 0), 7)
+    assert gi.shape == oi.shape == (rows - 6, w - 6, 3)
+    assert np.array_equal(gi, oi), int((gi != oi).any(-1).sum())
+    assert np.abs(gs - os_).max() < 1e-5
+
+
+def test_config4_full_strip_ground_truth():
+    """One GPU's share of config 4 (16384 x 2048 rows + kernel halo): no oracle can run it in seconds; the synthetic pair's
+    known block shifts are the check (SGM must recover them away from the block seams)."""
+    w, rows = 16384, 2048 + 6
+    left, right, truth = synth.stereo_pair(w, rows, 129, 1)
+    gi = stereo.calc_disparity_sgm(3, left, right, BBox2i(0, 0, w, rows), (128, 0), (7, 7))
+    assert gi.shape == (2048, w - 6, 3)
+    t = truth[3:3 + 2048, 3:3 + w - 6]
+    valid = gi[..., 2] != 0
+    assert valid.mean() > 0.99
+    assert (gi[..., 0] == t)[valid].mean() > 0.97
+
+
+@pytest.fixture(scope="module")
+def pair32768():
+    return synth.stereo_pair(32768, 3072, 129, 1)
+
+
+def test_config5_bm_ncc_tile_of_a_32768_wide_pair(oracle, pair32768):
+    left, right, truth = pair32768
+    right = np.ascontiguousarray(right[:, 64:64 + 32768])     # same size as left; true disparity = truth - 64 in [-48, 48]
+    search = (-64, -1, 65, 2)
+    bbox = (20000, 1024, 1024, 1024)
+    g = stereo.pyramid_correlate(left, right, None, None, 0, 0.0, BBox2i.from_corners(search[:2], search[2:]), (11, 11), 2, 0, 0.0, 2.0, 0, 5, 5,
+                                 bbox=BBox2i(*bbox))
+    o = oracle.pyramid_correlate(left, right, None, None, 0, 0.0, search, (11, 11), 2, 0, 0.0, 2.0, 5, 5, bbox=bbox)
+    assert g.shape == (1024, 1024, 3)
+    assert np.array_equal(g, o), int((g != o).any(-1).sum())
+    t = truth[1024:2048, 20000:21024] - 64
+    ok = g[..., 2] != 0
+    assert ok.mean() > 0.8 and (g[..., 0] == t)[ok].mean() > 0.98
+
+
+def test_config5_sgm_tile_of_a_32768_wide_pair(oracle, pair32768):
+    left, right, truth = pair32768
+    right = np.ascontiguousarray(right[:, 64:64 + 32768])
+    search = (-64, -1, 65, 2)
+    bbox = (11111, 700, 1024, 1024)
+    g = stereo.pyramid_correlate(left, right, None, None, 0, 0.0, BBox2i.from_corners(search[:2], search[2:]), (7, 7), 3, 0, 0.0, 2.0, 0, 5, 5,
+                                 algorithm=1, bbox=BBox2i(*bbox))
+    o = oracle.pyramid_correlate_sgm(left, right, None, None, search, 7, 3, 2.0, 0, 5, 5, bbox=bbox)
+    assert np.array_equal(g[..., 2], o[..., 2]), int((g[..., 2] != o[..., 2]).sum())
+    assert np.abs(g - o).max() < 1e-5

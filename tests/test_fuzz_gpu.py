@@ -1,0 +1,94 @@
+"""Seeded, bounded randomised cross-checks under pytest -m gpu (the long-running versions are tools/fuzz_*.py):
+  * packed SAD / SSD / NCC matchers vs the generic float64 kernel (itself pinned to the oracle in test_bm_gpu.py),
+  * pyramid_correlate vs the oracle (tiles, masks, thresholds, filters, level counts; integer scenes, float scenes and
+    LoG / mean-subtracted prefilters — the inputs on which the reference's running box sums are order dependent),
+  * calc_disparity_sgm vs the oracle (masks, previous-level bounds, memory levels, every sub-pixel mode).
+Every case must be IDENTICAL; a failure prints (generator, seed, index) for tools/replay_pyramid_case.py."""
+import os
+
+import numpy as np
+import pytest
+
+import fuzz_cases
+import visionworkbench_amd as vwa
+from visionworkbench_amd import core, stereo
+from visionworkbench_amd.core import BBox2i
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked tests need a GPU"
+    c = vwa.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("cost,n,seed", [(0, 120, 101), (1, 60, 102), (2, 60, 103)])
+def test_fuzz_fast_paths_equal_generic(ctx, monkeypatch, cost, n, seed):
+    import torch
+    bad = []
+    for c in fuzz_cases.bm_cases(n, seed, cost):
+        monkeypatch.setenv("VWGPU_SAD_SPLIT", c["split"])
+        lt, rt = torch.from_numpy(c["left"]).cuda(), torch.from_numpy(c["right"]).cuda()
+        ctx.force_path(core.PATH_NONE)
+        a = stereo.calc_disparity(cost, lt, rt, vwa.bounding_box(c["left"]), c["search"], c["kernel"], ctx=ctx).cpu().numpy()
+        ctx.force_path(core.PATH_GENERIC_F64)
+        b = stereo.calc_disparity(cost, lt, rt, vwa.bounding_box(c["left"]), c["search"], c["kernel"], ctx=ctx).cpu().numpy()
+        ctx.force_path(core.PATH_NONE)
+        if not np.array_equal(a, b):
+            bad.append((c["it"], c["kernel"], c["search"], c["left"].shape, int((a != b).any(-1).sum())))
+    assert not bad, "bm_cases(seed=%d, cost=%d): %s" % (seed, cost, bad)
+
+
+def _pyramid_pair(oracle, c):
+    s = c["search"]
+    g = stereo.pyramid_correlate(c["left"], c["right"], c["lm"], c["rm"], c["pf"], c["pfw"], BBox2i.from_corners(s[:2], s[2:]), c["kernel"],
+                                 c["cost"], 0, 0.0, c["thr"], 0, c["filt"], c["levels"], bbox=None if c["bbox"] is None else BBox2i(*c["bbox"]))
+    o = oracle.pyramid_correlate(c["left"], c["right"], c["lm"], c["rm"], c["pf"], c["pfw"], s, c["kernel"], c["cost"], 0, 0.0, c["thr"],
+                                 c["filt"], c["levels"], bbox=c["bbox"])
+    return g, o
+
+
+@pytest.mark.parametrize("n,seed,float_p,prefilters,costs", [
+    (70, 201, 0.0, (0,), (0, 0, 1)),            # the round-1 generator: integer scenes, SAD / SSD
+    (40, 202, 0.0, (0,), (2,)),                 # NCC
+    (50, 203, 1.0, (0,), (0, 1, 2)),            # float textures: order-dependent running sums
+    (50, 204, 0.0, (1, 2), (0, 1, 2)),          # mean-subtracted / LoG prefilters (tools/correlate.cc default)
+])
+def test_fuzz_pyramid_identical_to_oracle(oracle, n, seed, float_p, prefilters, costs):
+    bad = []
+    for c in fuzz_cases.pyramid_cases(n, seed, prefilters=prefilters, costs=costs, float_scene=float_p):
+        g, o = _pyramid_pair(oracle, c)
+        if not np.array_equal(g, o):
+            bad.append((c["it"], int((g != o).any(-1).sum())))
+    assert not bad, "pyramid_cases(seed=%d, float=%g, prefilters=%s, costs=%s): (index, differing pixels) %s" % (seed, float_p, prefilters, costs, bad)
+
+
+def test_round1_fuzz_finding_ssd_ties_in_mean_filled_border(oracle):
+    """Case 153 of seed 10 (round 1: 10 differing pixels — exact SSD ties inside the mean-filled area next to a masked
+    border, broken by the rounding order of the reference's running box sums, Algorithms.h:81-110)."""
+    c = None
+    for c in fuzz_cases.pyramid_cases(154, 10):
+        pass
+    for thr in (c["thr"], -1.0):
+        c2 = dict(c, thr=thr)
+        g, o = _pyramid_pair(oracle, c2)
+        assert np.array_equal(g, o), int((g != o).any(-1).sum())
+
+
+@pytest.mark.parametrize("n,seed", [(120, 301)])
+def test_fuzz_sgm_identical_to_oracle(oracle, n, seed):
+    bad = []
+    for c in fuzz_cases.sgm_cases(n, seed):
+        h, w = c["left"].shape
+        gi, gs = stereo.calc_disparity_sgm(c["cost"], c["left"], c["right"], BBox2i(0, 0, w, h), c["search"], (c["k"], c["k"]),
+                                           subpixel_mode=c["sub"], search_buffer=(2, 2), memory_limit_mb=c["mem"], left_mask=c["lm"],
+                                           right_mask=c["rm"], prev_disparity=c["prev"], with_subpixel=True)
+        oi, os_ = oracle.calc_disparity_sgm(c["cost"], c["left"], c["right"], c["search"], c["k"], subpixel=c["sub"], search_buffer=(2, 2),
+                                            memory_limit_mb=c["mem"], left_mask=c["lm"], right_mask=c["rm"], prev_disparity=c["prev"])
+        if not (np.array_equal(gi, oi) and (gs is None or np.abs(gs - os_).max() < 1e-5)):
+            bad.append((c["it"], int((gi != oi).any(-1).sum())))
+    assert not bad, "sgm_cases(seed=%d): %s" % (seed, bad)

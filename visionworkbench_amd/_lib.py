@@ -9,9 +9,9 @@ _LIB = None
 
 SYMBOLS = [
     "vwgpu_abi_version", "vwgpu_create", "vwgpu_destroy", "vwgpu_set_stream", "vwgpu_reset_stream", "vwgpu_synchronize",
-    "vwgpu_strerror", "vwgpu_last_error", "vwgpu_force_path", "vwgpu_last_path",
+    "vwgpu_strerror", "vwgpu_last_error", "vwgpu_force_path", "vwgpu_last_path", "vwgpu_set_option", "vwgpu_get_option",
     "vwgpu_profile_enable", "vwgpu_profile_reset", "vwgpu_profile_read",
-    "vwgpu_calc_disparity_dev", "vwgpu_calc_disparity",
+    "vwgpu_calc_disparity_dev", "vwgpu_calc_disparity", "vwgpu_fast_box_sum_dev", "vwgpu_fast_box_sum",
     "vwgpu_cross_corr_consistency_check_dev", "vwgpu_cross_corr_consistency_check",
     "vwgpu_cross_corr_consistency_check_diff_dev", "vwgpu_cross_corr_consistency_check_diff",
     "vwgpu_generate_gaussian_kernel",
@@ -95,12 +95,17 @@ def load():
     lib.vwgpu_last_error.restype = ctypes.c_char_p
     lib.vwgpu_force_path.argtypes = [P, I]
     lib.vwgpu_last_path.argtypes = [P]
+    lib.vwgpu_set_option.argtypes = [P, I, I]
+    lib.vwgpu_get_option.argtypes = [P, I, ctypes.POINTER(ctypes.c_int)]
     lib.vwgpu_profile_enable.argtypes = [P, I]
     lib.vwgpu_profile_reset.argtypes = [P]
     lib.vwgpu_profile_read.argtypes = [P, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(F), I]
     bm = [P, I, P, I, I, PD, P, I, I, PD, I, I, I, I, P, PD]
     lib.vwgpu_calc_disparity_dev.argtypes = bm
     lib.vwgpu_calc_disparity.argtypes = bm
+    bs = [P, P, I, I, PD, I, I, P, PD]
+    lib.vwgpu_fast_box_sum_dev.argtypes = bs
+    lib.vwgpu_fast_box_sum.argtypes = bs
     lr = [P, P, I, I, PD, P, I, I, PD, F]
     lib.vwgpu_cross_corr_consistency_check_dev.argtypes = lr
     lib.vwgpu_cross_corr_consistency_check.argtypes = lr

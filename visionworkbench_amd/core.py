@@ -39,7 +39,8 @@ ABSOLUTE_DIFFERENCE = CostFunctionType.ABSOLUTE_DIFFERENCE
 SQUARED_DIFFERENCE = CostFunctionType.SQUARED_DIFFERENCE
 CROSS_CORRELATION = CostFunctionType.CROSS_CORRELATION
 
-PATH_NONE, PATH_GENERIC_F64, PATH_SAD_U8, PATH_DOT_U8 = 0, 1, 2, 3
+PATH_NONE, PATH_GENERIC_F64, PATH_SAD_U8, PATH_DOT_U8, PATH_EXACT_ORDER = 0, 1, 2, 3, 4
+OPT_DEFER_EXACTNESS, OPT_DEVICE_COUNT = 1, 2      # vwgpu_option
 VALID_I32 = 0x7FFFFFFF
 
 
@@ -128,6 +129,15 @@ class Context:
 
     def last_path(self):
         return self._lib.vwgpu_last_path(self._h)
+
+    def set_option(self, option, value):
+        """vwgpu_set_option: e.g. (OPT_DEFER_EXACTNESS, 1) for pipelined callers that must not wait for the input-class flags."""
+        self.check(self._lib.vwgpu_set_option(self._h, int(option), int(value)))
+
+    def get_option(self, option):
+        v = ctypes.c_int(0)
+        self.check(self._lib.vwgpu_get_option(self._h, int(option), ctypes.byref(v)))
+        return v.value
 
     def profile_enable(self, on=True):
         self.check(self._lib.vwgpu_profile_enable(self._h, 1 if on else 0))

@@ -1,0 +1,557 @@
+// bm_exact.hip — block matching and box sums in the reference's OWN summation order, for inputs on which that
+// order matters.
+//
+// fast_box_sum (src/vw/Stereo/Algorithms.h:43-129) is two families of serial float64 recurrences:
+//     col_sum(x, 0)   = ((0 + e(x,0)) + e(x,1)) + ... + e(x,ky-1)                          (:62-75)
+//     col_sum(x, y+1) = (col_sum(x, y) + e(x, y+ky)) - e(x, y)                             (:100-103, two statements)
+//     row_sum(0, y)   = ((0 + col_sum(0,y)) + col_sum(1,y)) + ... + col_sum(kx-1,y)        (:84, std::accumulate)
+//     row_sum(x+1, y) = row_sum(x, y) + (col_sum(x+kx, y) - col_sum(x, y))                 (:92)
+// and best_of_search_convolution (src/vw/Stereo/Correlation.cc:64-119) runs them once per disparity over the whole
+// left raster.  When every partial sum is exactly representable (integer-valued imagery, most float imagery) the
+// order is irrelevant and the tile-parallel kernels (bm_sad_u8 / bm_dot_u8 / bm_generic / bm_zones) return the same
+// bits.  Otherwise — LoG / mean-subtracted imagery with values near zero, mean-filled nodata, deep pyramid levels
+// with SSD / NCC — the roundings depend on the raster position, and exact cost ties are broken by them.  The chains
+// are serial only along ONE axis each: every (column, disparity) pair is an independent chain down the rows and
+// every (row, disparity) pair an independent chain along the columns, so the reference order IS reproducible in
+// parallel — with the column sums of all disparities held in HBM between the two passes:
+//
+//   pass 1  bmx_col_kernel   thread <-> (zone, column, disparity), serial in y: writes col_sum(x, y, d) into the
+//                            zone's volume [row][column][disparity] (disparity fastest: lanes <-> disparities, so the
+//                            right-image reads and the volume writes are coalesced, the left pixel is a broadcast);
+//   pass 2  bmx_row_kernel   wave <-> (zone, 64 / lanes rows), lane <-> disparity, serial in x: the row recurrence
+//                            from coalesced volume reads, NCC scaling, then the winner across the disparity lanes
+//                            (lexicographic (cost, index) minimum == "strict compare, first wins"; the worst cost is
+//                            the plain extremum); a pixel whose costs contain a NaN is replayed by ONE lane with the
+//                            reference's compare chain verbatim (Correlation.cc:91-117), from costs parked in LDS.
+//
+// A "zone" is one calc_disparity problem: a SearchParam zone of a pyramid level (CorrelationView.cc:596-700; crops
+// with clamped coordinates = the ConstantEdgeExtension crops the reference hands over) or a whole raster.  NCC side
+// cars (CostFunctions.h:214-219: 1.0 / fast_box_sum(square(crop))) go through the same two passes with one
+// "disparity" per zone crop; vwgpu_fast_box_sum exports that form (Algorithms.h:41-43).
+//
+// HBM traffic: 8 B written + 8 B read per (pixel, disparity) — the price of the reference's order; the volume of a
+// whole-raster call is processed in row bands (column-chain state carried between bands) so that it stays within a
+// scratch budget.  Roofline: HBM bound by design (16 B per evaluation); it is the correctness path, not the headline.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "vwgpu_internal.h"
+
+namespace {
+
+constexpr int XCOST_BOX = 3;        // out = box sum of A                      (fast_box_sum)
+constexpr int XCOST_PREC = 4;       // out = 1.0 / box sum of A * A            (NCCCost side car)
+constexpr int XMAX_CHUNKS = 8;      // 64-disparity chunks per lane: up to 512 disparities per zone
+
+struct XZone {
+  int ax, ay, bx, by;               // crop origins in A / B (clamped reads)
+  int zw, zh;                       // output size; crop = (zw + kx - 1) x (zh + ky - 1)
+  int sx, sy;
+  int out_off, out_stride, addx, addy;
+  int lanes_log2;                   // lanes per unit = 1 << lanes_log2  (>= min(D, 64), power of two)
+  int nchunk;                       // ceil(D / 64)
+  long long vol;                    // offset (doubles) of the column-sum volume [rows][cw][dp]
+  long long lprec, rprec;           // NCC: offsets (doubles) of the zone's precision images; box modes: lprec = output offset
+};
+
+template <int COST>
+__device__ __forceinline__ double xelem(float a, float b) {
+  if (COST == VWGPU_CROSS_CORRELATION) return (double)(a * b);                       // CostFunctions.h:120-127
+  if (COST == VWGPU_SQUARED_DIFFERENCE) { const float d = a - b; return (double)(d * d); }   // :94-101
+  if (COST == XCOST_BOX) return (double)a;
+  if (COST == XCOST_PREC) return (double)(a * a);                                    // square(): float product
+  return (double)fabsf(a - b);                                                        // :72-81
+}
+template <int COST>
+__device__ __forceinline__ bool xbetter(double c, double q) {
+  return COST == VWGPU_CROSS_CORRELATION ? (c > q) : (c < q);
+}
+__device__ __forceinline__ int xclamp(int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
+
+// ---- pass 1: column chains -----------------------------------------------------------------------------------------
+// items[i] = {zone, first column, disparity chunk, -}.  Rows [y_begin, y_end) of every zone are produced (clipped to
+// the zone); y_begin > 0 resumes the chains from `state` (single-zone band mode), and `state` receives them at the end.
+template <int COST>
+__global__ void __launch_bounds__(256)
+bmx_col_kernel(const float* __restrict__ A, int aw, int ah, ptrdiff_t as, const float* __restrict__ B, int bw, int bh, ptrdiff_t bs,
+               int kx, int ky, const XZone* __restrict__ zones, const int4* __restrict__ items, double* __restrict__ vol,
+               int y_begin, int y_end, double* __restrict__ state) {
+  constexpr bool BOX = (COST == XCOST_BOX || COST == XCOST_PREC);
+  const int4 it = items[blockIdx.x];
+  const XZone z = zones[it.x];
+  const int cw = z.zw + kx - 1;
+  const int lanes = 1 << z.lanes_log2;
+  const int col = it.y + ((int)threadIdx.x >> z.lanes_log2);
+  const int d = it.z * 64 + ((int)threadIdx.x & (lanes - 1));
+  const int D = z.sx * z.sy;
+  if (col >= cw || d >= D) return;
+  const int dp = z.nchunk == 1 ? lanes : z.nchunk * 64;
+  const int dy = BOX ? 0 : d / z.sx, dx = BOX ? 0 : d - dy * z.sx;
+  const float* ac = A + xclamp(z.ax + col, aw);
+  const float* bc = BOX ? nullptr : B + xclamp(z.bx + col + dx, bw);
+  auto elem = [&](int y) __attribute__((always_inline)) -> double {
+    const float a = ac[(ptrdiff_t)xclamp(z.ay + y, ah) * as];
+    const float b = BOX ? 0.0f : bc[(ptrdiff_t)xclamp(z.by + y + dy, bh) * bs];
+    return xelem<COST>(a, b);
+  };
+  const int y0 = y_begin < 0 ? 0 : y_begin, y1 = y_end < z.zh ? y_end : z.zh;
+  double cs;
+  if (y0 == 0) {
+    cs = 0.0;                                           // std::valarray<AccumT> col_sum(cols): zero-initialised
+    for (int j = 0; j < ky; ++j) cs += elem(j);         // Algorithms.h:62-75
+  } else {
+    cs = state[(size_t)col * dp + d];
+  }
+  double* v = vol + z.vol + (size_t)col * dp + d;
+  const size_t rstride = (size_t)cw * dp;
+  for (int y = y0; y < y1; ++y) {
+    v[(size_t)(y - y0) * rstride] = cs;
+    if (y + 1 < z.zh) {                                 // Algorithms.h:100-103: two statements, this order
+      cs += elem(y + ky);
+      cs -= elem(y);
+    }
+  }
+  if (state) state[(size_t)col * dp + d] = cs;
+}
+
+// ---- pass 2: row chains + winner -----------------------------------------------------------------------------------
+// items[i] = {zone, first row}; one wave per item, 64 / lanes rows per wave.  NCH = 64-disparity chunks a lane can hold
+// (instantiated for 1, 3 and XMAX_CHUNKS; the launcher picks by the largest zone).
+template <int COST, int NCH>
+__global__ void __launch_bounds__(256)
+bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__ items, const double* __restrict__ vol,
+               int y_begin, int y_end, const double* __restrict__ prec, int32_t* __restrict__ out, double* __restrict__ outd) {
+  constexpr bool BOX = (COST == XCOST_BOX || COST == XCOST_PREC);
+  constexpr bool NCC = (COST == VWGPU_CROSS_CORRELATION);
+  __shared__ double park[4][NCH][64];           // costs of a NaN pixel, for the verbatim replay
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int2 it = items[blockIdx.x * 4 + wave];
+  if (it.x < 0) return;
+  const XZone z = zones[it.x];
+  const int cw = z.zw + kx - 1;
+  const int lanes = 1 << z.lanes_log2;
+  const int g = lane >> z.lanes_log2, dl = lane & (lanes - 1);
+  const int y = it.y + g;
+  const int ylim = y_end < z.zh ? y_end : z.zh;
+  const bool row_ok = y < ylim;
+  const int D = z.sx * z.sy;
+  const int dp = z.nchunk == 1 ? lanes : z.nchunk * 64;
+  const int nch = z.nchunk;
+  const double* base = vol + z.vol + (size_t)(row_ok ? y - y_begin : 0) * cw * dp;
+
+  double r[NCH];
+  int dk[NCH];
+  const double* rp[NCH];
+  bool act[NCH];
+  const int rpw = z.zw + z.sx - 1;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    dk[k] = k * 64 + dl;
+    act[k] = row_ok && k < nch && dk[k] < D;
+    r[k] = 0.0;
+    rp[k] = nullptr;
+    if (act[k]) {
+      for (int i = 0; i < kx; ++i) r[k] += base[(size_t)i * dp + dk[k]];       // Algorithms.h:84: accumulate from 0
+      if (NCC) {
+        const int dy = dk[k] / z.sx, dx = dk[k] - dy * z.sx;
+        rp[k] = prec + z.rprec + (size_t)(y + dy) * rpw + dx;
+      }
+    }
+  }
+  const double* lp = NCC ? prec + z.lprec + (size_t)(row_ok ? y : 0) * z.zw : nullptr;
+  const double SENT_BEST = NCC ? -INFINITY : INFINITY, SENT_WORST = NCC ? INFINITY : -INFINITY;
+
+  int res_d = 0, res_v = 0;                             // buffered result of the step x with (x & (lanes-1)) == dl
+  for (int x = 0; x < z.zw; ++x) {
+    if (BOX) {                                          // one chain per lane: the sum itself is the result
+      if (act[0]) {
+        outd[z.lprec + (size_t)y * z.zw + x] = (COST == XCOST_PREC) ? 1.0 / r[0] : r[0];
+        if (x + 1 < z.zw) r[0] += base[(size_t)(x + kx) * dp] - base[(size_t)x * dp];
+      }
+      continue;
+    }
+    // this lane's candidates, in disparity order
+    double c[NCH];
+    double best = SENT_BEST, worst = SENT_WORST;
+    int bd = INT_MAX;
+    bool nan = false;
+    const double lpx = NCC && row_ok ? lp[x] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      c[k] = 0.0;
+      if (k < nch && act[k]) {
+        double v = r[k];
+        if (NCC) v *= sqrt(lpx * rp[k][x]);             // CostFunctions.h:227-231
+        c[k] = v;
+        nan |= (v != v);
+        if (xbetter<COST>(v, best) || (v == best && dk[k] < bd)) { best = v; bd = dk[k]; }
+        if (xbetter<COST>(worst, v)) worst = v;
+      }
+    }
+    // advance the chains (Algorithms.h:92): independent of the reduction below
+    if (x + 1 < z.zw) {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+        if (k < nch && act[k]) r[k] += base[(size_t)(x + kx) * dp + dk[k]] - base[(size_t)x * dp + dk[k]];
+    }
+    // winner across the disparity lanes of the row's group
+    int nanw = nan ? 1 : 0;
+    for (int o = lanes >> 1; o > 0; o >>= 1) {
+      const double oc = __shfl_xor(best, o), ow = __shfl_xor(worst, o);
+      const int od = __shfl_xor(bd, o);
+      nanw |= __shfl_xor(nanw, o);
+      if (xbetter<COST>(oc, best) || (oc == best && od < bd)) { best = oc; bd = od; }
+      if (xbetter<COST>(worst, ow)) worst = ow;
+    }
+    if (__any(nanw)) {                                  // wave-uniform: some pixel of this step has a NaN cost
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+        if (k < nch) park[wave][k][lane] = c[k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (nanw && dl == 0 && row_ok) {                  // Correlation.cc:91-117, verbatim
+        double b2 = 0.0, w2 = 0.0;
+        int i2 = 0;
+        for (int d = 0; d < D; ++d) {
+          const double v = nch == 1 ? park[wave][0][g * lanes + d] : park[wave][d >> 6][d & 63];
+          if (d == 0) { b2 = w2 = v; }
+          else if (xbetter<COST>(v, b2)) { b2 = v; i2 = d; }
+          else if (!xbetter<COST>(v, w2)) { w2 = v; }
+        }
+        best = b2; worst = w2; bd = i2;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lanes > 1) {                                  // hand the replayed result to the lane that buffers this step
+        const int src = g * lanes;
+        const double b3 = __shfl(best, src), w3 = __shfl(worst, src);
+        const int d3 = __shfl(bd, src);
+        if (nanw) { best = b3; worst = w3; bd = d3; }
+      }
+    }
+    const int slot = x & (lanes - 1);
+    if (dl == slot) { res_d = bd; res_v = (best == worst) ? 0 : 0x7fffffff; }   // Correlation.cc:121-133
+    if (slot == lanes - 1 || x == z.zw - 1) {
+      const int xb = x - slot;
+      if (row_ok && dl <= slot) {
+        const int dy = res_d / z.sx, dx = res_d - dy * z.sx;
+        int32_t* o = out + ((size_t)z.out_off + (size_t)y * z.out_stride + xb + dl) * 3;
+        o[0] = dx + z.addx; o[1] = dy + z.addy; o[2] = res_v;
+      }
+    }
+  }
+}
+
+// ---- order-freeness of an image: lowest set bit and magnitude of its pixels ------------------------------------------
+// cell[0] = min over non-zero pixels of the exponent of the lowest set mantissa bit, cell[1] = max exponent,
+// cell[2] != 0: a non-finite pixel.  (Every pixel is an integer multiple of 2^cell[0] and smaller than 2^(cell[1]+1).)
+__global__ void __launch_bounds__(256)
+float_grain_kernel(const float* __restrict__ img, int w, int h, ptrdiff_t stride, int* __restrict__ cell) {
+  int lo = INT_MAX, hi = INT_MIN, bad = 0;
+  for (int y = blockIdx.y; y < h; y += gridDim.y)
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) {
+      const unsigned u = __float_as_uint(img[(ptrdiff_t)y * stride + x]);
+      const int e = (int)((u >> 23) & 0xffu);
+      unsigned m = u & 0x7fffffu;
+      if (e == 0xff) { bad = 1; continue; }
+      if (e == 0 && m == 0) continue;                   // +-0
+      int base;
+      if (e == 0) base = -149;                          // subnormal: m * 2^-149
+      else { m |= 0x800000u; base = e - 127 - 23; }
+      lo = min(lo, base + (__ffs((int)m) - 1));
+      hi = max(hi, base + (31 - __clz((int)m)));
+    }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); bad |= __shfl_xor(bad, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (lo != INT_MAX) { atomicMin(&cell[0], lo); atomicMax(&cell[1], hi); }
+    if (bad) atomicOr(&cell[2], 1);
+  }
+}
+
+int lanes_log2_for(int D) {
+  int l = 0;
+  while ((1 << l) < D && l < 6) ++l;
+  return l;
+}
+
+size_t exact_scratch_budget() {
+  const char* e = getenv("VWGPU_EXACT_SCRATCH_MB");
+  const long mb = e ? atol(e) : 4096;
+  return (size_t)(mb < 16 ? 16 : mb) << 20;
+}
+
+struct Tables {
+  std::vector<XZone> zones;
+  std::vector<int4> col_items;
+  std::vector<int2> row_items;
+  size_t vol_doubles = 0;
+};
+
+// appends one zone; rows = the number of volume rows to reserve for it
+void add_zone(Tables& t, XZone z, int kx, int rows, bool box) {
+  const int D = box ? 1 : z.sx * z.sy;
+  z.lanes_log2 = lanes_log2_for(D);
+  z.nchunk = (D + 63) / 64;
+  const int lanes = 1 << z.lanes_log2;
+  const int dp = z.nchunk == 1 ? lanes : z.nchunk * 64;
+  const int cw = z.zw + kx - 1;
+  z.vol = (long long)t.vol_doubles;
+  t.vol_doubles += (size_t)rows * cw * dp;
+  t.zones.push_back(z);
+}
+
+void build_items(Tables& t, int kx, int y_begin, int y_end) {
+  t.col_items.clear();
+  t.row_items.clear();
+  for (size_t i = 0; i < t.zones.size(); ++i) {
+    const XZone& z = t.zones[i];
+    const int lanes = 1 << z.lanes_log2, cpw = 256 / lanes, cw = z.zw + kx - 1, rpw = 64 / lanes;
+    for (int c = 0; c < z.nchunk; ++c)
+      for (int x0 = 0; x0 < cw; x0 += cpw) t.col_items.push_back(make_int4((int)i, x0, c, 0));
+    const int y1 = std::min(y_end, z.zh);
+    for (int y0 = std::max(y_begin, 0); y0 < y1; y0 += rpw) t.row_items.push_back(make_int2((int)i, y0));
+  }
+  while (t.row_items.size() % 4) t.row_items.push_back(make_int2(-1, 0));
+}
+
+struct DevTables { const XZone* zones; const int4* col; const int2* row; };
+
+int upload(vwgpu_ctx* ctx, const Tables& t, char*& cursor, char* end, DevTables* d) {
+  const size_t zb = vwgpu_align_up(t.zones.size() * sizeof(XZone), 256), cb = vwgpu_align_up(t.col_items.size() * sizeof(int4), 256),
+               rb = vwgpu_align_up(t.row_items.size() * sizeof(int2), 256);
+  if (cursor + zb + cb + rb > end) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "bm_exact: table arena too small");
+  VWGPU_HIP(ctx, hipMemcpyAsync(cursor, t.zones.data(), t.zones.size() * sizeof(XZone), hipMemcpyHostToDevice, ctx->stream));
+  d->zones = reinterpret_cast<const XZone*>(cursor); cursor += zb;
+  VWGPU_HIP(ctx, hipMemcpyAsync(cursor, t.col_items.data(), t.col_items.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+  d->col = reinterpret_cast<const int4*>(cursor); cursor += cb;
+  VWGPU_HIP(ctx, hipMemcpyAsync(cursor, t.row_items.data(), t.row_items.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+  d->row = reinterpret_cast<const int2*>(cursor); cursor += rb;
+  return VWGPU_OK;
+}
+
+size_t table_bytes(const Tables& t) {
+  return vwgpu_align_up(t.zones.size() * sizeof(XZone), 256) + vwgpu_align_up(t.col_items.size() * sizeof(int4), 256) +
+         vwgpu_align_up(t.row_items.size() * sizeof(int2), 256);
+}
+
+template <int COST>
+void launch_pair(vwgpu_ctx* ctx, const char* n1, const char* n2, const float* A, int aw, int ah, ptrdiff_t as,
+                 const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky, const Tables& t, const DevTables& d, double* vol,
+                 int y_begin, int y_end, double* state, const double* prec, int32_t* out, double* outd) {
+  if (!t.col_items.empty()) {
+    vwgpu_prof_scope ps(ctx, n1);
+    hipLaunchKernelGGL((bmx_col_kernel<COST>), dim3((unsigned)t.col_items.size()), dim3(256), 0, ctx->stream,
+                       A, aw, ah, as, B, bw, bh, bs, kx, ky, d.zones, d.col, vol, y_begin, y_end, state);
+  }
+  if (!t.row_items.empty()) {
+    vwgpu_prof_scope ps(ctx, n2);
+    int nch = 1;
+    for (const XZone& z : t.zones) nch = std::max(nch, z.nchunk);
+    const dim3 grd((unsigned)(t.row_items.size() / 4)), blk(256);
+    if (nch == 1)
+      hipLaunchKernelGGL((bmx_row_kernel<COST, 1>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd);
+    else if (nch <= 3)
+      hipLaunchKernelGGL((bmx_row_kernel<COST, 3>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd);
+    else
+      hipLaunchKernelGGL((bmx_row_kernel<COST, XMAX_CHUNKS>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd);
+  }
+}
+
+}  // namespace
+
+bool vwgpu_bm_exact_supported(int sx, int sy) { return (long long)sx * sy <= 64LL * XMAX_CHUNKS; }
+
+// The order-freeness test.  Every pixel of both images is an integer multiple of g = 2^lo and smaller than 2^(hi+1); then
+// every cost element is a multiple of g (SAD) or g^2 (SSD / NCC: the float product rounds to a coarser multiple) and
+// every intermediate value of the reference's chains — at most 2 * kx * ky elements in magnitude — is exactly
+// representable in float64 iff it stays below 2^53 units, in which case ANY summation order returns the same bits.
+bool vwgpu_sums_order_free(int cost_type, int kx, int ky, int lo, int hi, int nonfinite) {
+  if (nonfinite) return false;
+  if (lo == INT_MAX) return true;                       // all-zero images
+  int lg = 0;
+  while ((1LL << lg) < (long long)kx * ky) ++lg;
+  const long long E = (long long)hi + 1;                // |pixel| < 2^E
+  long long bits;
+  if (cost_type == VWGPU_ABSOLUTE_DIFFERENCE) bits = (E + 1) + lg + 1 - lo;              // |a-b| < 2^(E+1)
+  else if (cost_type == VWGPU_SQUARED_DIFFERENCE) bits = 2 * (E + 1) + 1 + lg + 1 - 2LL * lo;
+  else bits = 2 * E + 1 + lg + 1 - 2LL * lo;
+  return bits <= 53;
+}
+
+// Measures (lo, hi, nonfinite) over up to two images.  Synchronises the stream.
+int vwgpu_float_grain(vwgpu_ctx* ctx, const float* a, int aw, int ah, ptrdiff_t as, const float* b, int bw, int bh, ptrdiff_t bs,
+                      int* lo, int* hi, int* nonfinite) {
+  int rc = vwgpu_arena_reserve(ctx, &ctx->misc, 256);
+  if (rc) return rc;
+  int* cell = static_cast<int*>(ctx->misc.base) + 16;
+  const int init[3] = {INT_MAX, INT_MIN, 0};
+  VWGPU_HIP(ctx, hipMemcpyAsync(cell, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+  {
+    vwgpu_prof_scope ps(ctx, "float_grain");
+    if (a && aw > 0 && ah > 0)
+      hipLaunchKernelGGL(float_grain_kernel, dim3((unsigned)std::min((aw + 255) / 256, 16), (unsigned)std::min(ah, 512)), dim3(256), 0,
+                         ctx->stream, a, aw, ah, as, cell);
+    if (b && bw > 0 && bh > 0)
+      hipLaunchKernelGGL(float_grain_kernel, dim3((unsigned)std::min((bw + 255) / 256, 16), (unsigned)std::min(bh, 512)), dim3(256), 0,
+                         ctx->stream, b, bw, bh, bs, cell);
+  }
+  int got[3];
+  VWGPU_HIP(ctx, hipMemcpyAsync(got, cell, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *lo = got[0]; *hi = got[1]; *nonfinite = got[2];
+  return VWGPU_OK;
+}
+
+// Same, asynchronous: (lo, hi, nonfinite) of image pair i land in d_cells[3*i ..]; cells must have been initialised
+// with {INT_MAX, INT_MIN, 0}.
+void vwgpu_launch_float_grain(vwgpu_ctx* ctx, const float* a, int aw, int ah, ptrdiff_t as, int* d_cell) {
+  if (!a || aw <= 0 || ah <= 0) return;
+  hipLaunchKernelGGL(float_grain_kernel, dim3((unsigned)std::min((aw + 255) / 256, 16), (unsigned)std::min(ah, 512)), dim3(256), 0,
+                     ctx->stream, a, aw, ah, as, d_cell);
+}
+
+// One group of zones (its column-sum volumes fit the scratch budget, or it is a single zone swept in row bands).
+static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, ptrdiff_t as,
+                     const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky,
+                     const vwgpu_zone_task* zones, int n, int32_t* out) {
+  const bool ncc = cost_type == VWGPU_CROSS_CORRELATION;
+  Tables match, boxa, boxb;
+  size_t prec_doubles = 0;
+  for (int i = 0; i < n; ++i) {
+    const vwgpu_zone_task& s = zones[i];
+    XZone z{};
+    z.ax = s.ax; z.ay = s.ay; z.bx = s.bx; z.by = s.by; z.zw = s.zw; z.zh = s.zh; z.sx = s.sx; z.sy = s.sy;
+    z.out_off = s.out_off; z.out_stride = s.out_stride; z.addx = s.addx; z.addy = s.addy;
+    if (ncc) {
+      // NCCCost ctor over the zone's own crops (CostFunctions.h:214-219): box sums restart at the crop origin
+      z.lprec = (long long)prec_doubles; prec_doubles += (size_t)s.zw * s.zh;
+      z.rprec = (long long)prec_doubles; prec_doubles += (size_t)(s.zw + s.sx - 1) * (s.zh + s.sy - 1);
+      XZone a{}; a.ax = s.ax; a.ay = s.ay; a.zw = s.zw; a.zh = s.zh; a.sx = a.sy = 1; a.lprec = z.lprec;
+      add_zone(boxa, a, kx, a.zh, true);
+      XZone b{}; b.ax = s.bx; b.ay = s.by; b.zw = s.zw + s.sx - 1; b.zh = s.zh + s.sy - 1; b.sx = b.sy = 1; b.lprec = z.rprec;
+      add_zone(boxb, b, kx, b.zh, true);
+    }
+    add_zone(match, z, kx, z.zh, false);
+  }
+  if (match.zones.empty()) return VWGPU_OK;
+
+  // band mode: a single zone whose volume exceeds the budget is swept in row bands
+  const size_t budget = exact_scratch_budget();
+  int band = INT_MAX;
+  size_t state_doubles = 0;
+  if (match.vol_doubles * 8 > budget && match.zones.size() == 1) {
+    XZone& z = match.zones[0];
+    const int lanes = 1 << z.lanes_log2, dp = z.nchunk == 1 ? lanes : z.nchunk * 64, cw = z.zw + kx - 1;
+    const size_t row = (size_t)cw * dp * 8;
+    band = (int)std::max<size_t>(1, budget / row);
+    if (band >= z.zh) band = INT_MAX;
+    else { match.vol_doubles = (size_t)band * cw * dp; state_doubles = (size_t)cw * dp; }
+  }
+  const size_t vol_need = std::max(match.vol_doubles, std::max(boxa.vol_doubles, boxb.vol_doubles));
+  int rc = vwgpu_arena_reserve(ctx, &ctx->xvol, (vol_need + state_doubles + prec_doubles) * 8 + 1024);
+  if (rc) return rc;
+  double* vol = static_cast<double*>(ctx->xvol.base);
+  double* state = state_doubles ? vol + vol_need : nullptr;
+  double* prec = vol + vol_need + state_doubles;
+
+  build_items(match, kx, 0, band);
+  build_items(boxa, kx, 0, INT_MAX);
+  build_items(boxb, kx, 0, INT_MAX);
+  // tables of every launch of this call live side by side (uploads are stream ordered)
+  size_t tb = table_bytes(match) + table_bytes(boxa) + table_bytes(boxb) + 4096;
+  if (band != INT_MAX) tb += (size_t)((match.zones[0].zh + band - 1) / band) * (table_bytes(match) + 1024);
+  rc = vwgpu_arena_reserve(ctx, &ctx->xtab, tb);
+  if (rc) return rc;
+  char* cur = static_cast<char*>(ctx->xtab.base);
+  char* end = cur + ctx->xtab.cap;
+  DevTables d;
+  if (ncc) {
+    if ((rc = upload(ctx, boxa, cur, end, &d))) return rc;
+    launch_pair<XCOST_PREC>(ctx, "bmx_prec_col", "bmx_prec_row", A, aw, ah, as, nullptr, 0, 0, 0, kx, ky, boxa, d, vol, 0, INT_MAX, nullptr, nullptr, nullptr, prec);
+    if ((rc = upload(ctx, boxb, cur, end, &d))) return rc;
+    launch_pair<XCOST_PREC>(ctx, "bmx_prec_col", "bmx_prec_row", B, bw, bh, bs, nullptr, 0, 0, 0, kx, ky, boxb, d, vol, 0, INT_MAX, nullptr, nullptr, nullptr, prec);
+  }
+  const int zh0 = match.zones[0].zh;
+  const int nbands = band == INT_MAX ? 1 : (zh0 + band - 1) / band;
+  for (int b = 0; b < nbands; ++b) {
+    const int yb = band == INT_MAX ? 0 : b * band, ye = band == INT_MAX ? INT_MAX : yb + band;
+    if (band != INT_MAX) build_items(match, kx, yb, ye);
+    if ((rc = upload(ctx, match, cur, end, &d))) return rc;
+    switch (cost_type) {
+      case VWGPU_CROSS_CORRELATION:
+        launch_pair<VWGPU_CROSS_CORRELATION>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr); break;
+      case VWGPU_SQUARED_DIFFERENCE:
+        launch_pair<VWGPU_SQUARED_DIFFERENCE>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr); break;
+      default:
+        launch_pair<VWGPU_ABSOLUTE_DIFFERENCE>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr); break;
+    }
+  }
+  VWGPU_HIP(ctx, hipGetLastError());
+  return VWGPU_OK;
+}
+
+// All zones in the reference's summation order.  A / B dense or strided images (clamped reads).  Zones are processed in
+// groups whose column-sum volumes fit the scratch budget (VWGPU_EXACT_SCRATCH_MB, default 4096).
+int vwgpu_launch_bm_exact(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, ptrdiff_t as,
+                          const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky,
+                          const vwgpu_zone_task* zones, int n, int32_t* out) {
+  const size_t budget = exact_scratch_budget();
+  std::vector<vwgpu_zone_task> group;
+  size_t bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    const vwgpu_zone_task& s = zones[i];
+    if (s.zw <= 0 || s.zh <= 0 || s.sx <= 0 || s.sy <= 0) continue;
+    if (!vwgpu_bm_exact_supported(s.sx, s.sy))
+      return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "bm_exact: %d x %d disparities exceed %d per zone", s.sx, s.sy, 64 * XMAX_CHUNKS);
+    const int D = s.sx * s.sy, nchunk = (D + 63) / 64, dp = nchunk == 1 ? (1 << lanes_log2_for(D)) : nchunk * 64;
+    const size_t need = (size_t)s.zh * (s.zw + kx - 1) * dp * 8;
+    if (!group.empty() && bytes + need > budget) {
+      int rc = run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, group.data(), (int)group.size(), out);
+      if (rc) return rc;
+      group.clear(); bytes = 0;
+    }
+    group.push_back(s);
+    bytes += need;
+  }
+  if (group.empty()) return VWGPU_OK;
+  return run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, group.data(), (int)group.size(), out);
+}
+
+// fast_box_sum<double>(image, kernel) (Algorithms.h:41-43) in the reference's order.  d_out: (w-kx+1) x (h-ky+1) doubles, dense.
+int vwgpu_launch_box_sum_exact(vwgpu_ctx* ctx, const float* img, int w, int h, ptrdiff_t stride, int kx, int ky, double* d_out) {
+  Tables t;
+  XZone z{};
+  z.zw = w - kx + 1; z.zh = h - ky + 1; z.sx = z.sy = 1; z.lprec = 0;
+  add_zone(t, z, kx, z.zh, true);
+  const size_t budget = exact_scratch_budget();
+  int band = INT_MAX;
+  size_t state_doubles = 0;
+  if (t.vol_doubles * 8 > budget) {
+    band = (int)std::max<size_t>(1, budget / ((size_t)w * 8));
+    t.vol_doubles = (size_t)band * w;
+    state_doubles = (size_t)w;
+  }
+  int rc = vwgpu_arena_reserve(ctx, &ctx->xvol, (t.vol_doubles + state_doubles) * 8 + 1024);
+  if (rc) return rc;
+  double* vol = static_cast<double*>(ctx->xvol.base);
+  double* state = state_doubles ? vol + t.vol_doubles : nullptr;
+  build_items(t, kx, 0, band);
+  const int nb = band == INT_MAX ? 1 : (z.zh + band - 1) / band;
+  rc = vwgpu_arena_reserve(ctx, &ctx->xtab, (size_t)nb * (table_bytes(t) + 1024) + 4096);
+  if (rc) return rc;
+  char* cur = static_cast<char*>(ctx->xtab.base);
+  char* end = cur + ctx->xtab.cap;
+  for (int b = 0; b < nb; ++b) {
+    const int yb = band == INT_MAX ? 0 : b * band, ye = band == INT_MAX ? INT_MAX : yb + band;
+    if (band != INT_MAX) build_items(t, kx, yb, ye);
+    DevTables d;
+    if ((rc = upload(ctx, t, cur, end, &d))) return rc;
+    launch_pair<XCOST_BOX>(ctx, "box_sum_col", "box_sum_row", img, w, h, stride, nullptr, 0, 0, 0, kx, ky, t, d, vol, yb, ye, state, nullptr, nullptr, d_out);
+  }
+  VWGPU_HIP(ctx, hipGetLastError());
+  return VWGPU_OK;
+}

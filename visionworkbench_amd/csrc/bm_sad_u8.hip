@@ -704,7 +704,7 @@ int vwgpu_launch_bm_sad_u8(vwgpu_ctx* ctx,
   int rc = vwgpu_arena_reserve(ctx, &ctx->flags, 256 + (size_t)gx * gy * sizeof(int));
   if (rc) return rc;
   int* flags = static_cast<int*>(ctx->flags.base);
-  if (ctx->flags_base_seen != ctx->flags.base) { ctx->flags_init = false; ctx->flags_base_seen = ctx->flags.base; }
+  if (ctx->flags_base_seen != ctx->flags.base) { ctx->flags_init = false; ctx->flags_base_seen = ctx->flags.base; ctx->last_flag = nullptr; }
   if (!ctx->flags_init) {
     VWGPU_HIP(ctx, hipMemsetAsync(flags, 0, 256, ctx->stream));
     ctx->flags_init = true;

@@ -12,7 +12,12 @@
 //                                                          (src/vw/Stereo/DisparityMap.h:318-441) + disparity_mask (:97-253)
 //   zone refinement           CorrelationView.cc:754-799  subdivide_regions (zones.hip), x2, expand(2), crop
 //   result                    CorrelationView.cc:876-885  + search_region.min(), cast to PixelMask<Vector2f>
-// Not covered: SGM/MGM branches (:391-595), blob filter (blob_filter_area > 0), lr_disp_diff output, collar.
+//   SGM branch                CorrelationView.cc:391-595  per-level calc_disparity_sgm seeded by the previous level (sgm.hip),
+//                                                          R->L run, sub-pixel view; blob filter (:242-271), lr_disp_diff
+// Inputs whose box sums would round (prefiltered imagery, mean-filled nodata, deep levels with SSD / NCC) are matched in
+// the reference's own summation order (bm_exact.hip); the class of every level is measured on the device.
+// Not covered: the MGM variants (VW_CORRELATION_MGM / _FINAL_MGM answer NoImplErr); collar_size is applied by the caller
+// (PyramidCorrelationView::rasterize, CorrelationView.h:123-133: a larger tile is rasterised and cropped).
 #include <climits>
 #include <algorithm>
 #include <cmath>
@@ -47,15 +52,73 @@ __global__ void crop_ext_kernel(const T* __restrict__ src, ptrdiff_t stride, int
 }
 
 // sum / count (double) of img over the valid pixels of every second row and column (mean_pixel_value(subsample(.,2)),
-// CorrelationView.cc:137-149; MeanAccumulator sums in double, src/vw/Math/Functors.h:469-487).
-__global__ void masked_mean_kernel(const float* __restrict__ img, const uint8_t* __restrict__ mask, int w, int h,
-                                   double* __restrict__ acc2) {
+// CorrelationView.cc:137-149; MeanAccumulator sums in double, src/vw/Math/Functors.h:469-487).  Every workgroup writes ONE
+// partial {sum, count} formed in a fixed order, and cell[] receives the lowest set bit / largest exponent of the summed
+// pixels: when count * 2^(hi+1) / 2^lo < 2^53 every partial sum is exactly representable and the host adds the partials
+// (any order returns the reference's serial sum); otherwise masked_mean_serial_kernel walks the pixels in raster order.
+__global__ void __launch_bounds__(256)
+masked_mean_kernel(const float* __restrict__ img, const uint8_t* __restrict__ mask, int w, int h,
+                   double* __restrict__ part, int* __restrict__ cell) {
+  __shared__ double ws[4][2];
   double s = 0.0, n = 0.0;
+  int lo = INT_MAX, hi = INT_MIN, bad = 0;
   for (int y = 2 * (blockIdx.y * blockDim.y + threadIdx.y); y < h; y += 2 * gridDim.y * blockDim.y)
     for (int x = 2 * (blockIdx.x * blockDim.x + threadIdx.x); x < w; x += 2 * gridDim.x * blockDim.x)
-      if (mask[(size_t)y * w + x]) { s += (double)img[(size_t)y * w + x]; n += 1.0; }
-  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); n += __shfl_xor(n, o); }
-  if (((threadIdx.y * blockDim.x + threadIdx.x) & 63) == 0 && n > 0.0) { atomicAdd(acc2, s); atomicAdd(acc2 + 1, n); }
+      if (mask[(size_t)y * w + x]) {
+        const float v = img[(size_t)y * w + x];
+        s += (double)v; n += 1.0;
+        const unsigned u = __float_as_uint(v);
+        const int e = (int)((u >> 23) & 0xffu);
+        unsigned m = u & 0x7fffffu;
+        if (e == 0xff) bad = 1;
+        else if (e != 0 || m != 0) {
+          int base;
+          if (e == 0) base = -149; else { m |= 0x800000u; base = e - 127 - 23; }
+          lo = min(lo, base + (__ffs((int)m) - 1));
+          hi = max(hi, base + (31 - __clz((int)m)));
+        }
+      }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o); n += __shfl_xor(n, o);
+    lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); bad |= __shfl_xor(bad, o);
+  }
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  if ((tid & 63) == 0) {
+    ws[tid >> 6][0] = s; ws[tid >> 6][1] = n;
+    if (lo != INT_MAX) { atomicMin(&cell[0], lo); atomicMax(&cell[1], hi); }
+    if (bad) atomicOr(&cell[2], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double* p = part + 2 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
+    p[0] = ((ws[0][0] + ws[1][0]) + ws[2][0]) + ws[3][0];
+    p[1] = ((ws[0][1] + ws[1][1]) + ws[2][1]) + ws[3][1];
+  }
+}
+
+// The reference's serial accumulation (m_accum += value in raster order), one wave: 64 pixels are fetched at a time and
+// added one by one.  Only for images whose sum is not exactly representable along the way (see above).
+__global__ void __launch_bounds__(64)
+masked_mean_serial_kernel(const float* __restrict__ img, const uint8_t* __restrict__ mask, int w, int h, double* __restrict__ acc2) {
+  const int ws = (w + 1) / 2, hs = (h + 1) / 2;
+  const long long total = (long long)ws * hs;
+  double s = 0.0, n = 0.0;
+  for (long long i0 = 0; i0 < total; i0 += 64) {
+    const long long i = i0 + threadIdx.x;
+    float v = 0.0f;
+    int ok = 0;
+    if (i < total) {
+      const int y = 2 * (int)(i / ws), x = 2 * (int)(i % ws);
+      ok = mask[(size_t)y * w + x] != 0;
+      v = img[(size_t)y * w + x];
+    }
+    const unsigned long long okm = __ballot(ok);
+#pragma unroll 8
+    for (int l = 0; l < 64; ++l) {
+      if ((okm >> l) & 1ull) { s += (double)__shfl(v, l); n += 1.0; }
+    }
+  }
+  if (threadIdx.x == 0) { acc2[0] = s; acc2[1] = n; }
 }
 
 __global__ void fill_masked_kernel(float* __restrict__ img, const uint8_t* __restrict__ mask, size_t n, float value) {
@@ -348,7 +411,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   const size_t nl = (size_t)lg.dx() * lg.dy(), nr = (size_t)rg.dx() * rg.dy();
   const size_t need = 4 * (nl + nr) * 3 + (nl + nr) * 2 + (size_t)rmb.dx() * rmb.dy() * 2 + (size_t)bw * bh * (12 * 3 + 2) +
                       (size_t)(bw + 2) * (bh + 2) * 12 + (nl + nr) * 4 * 2 + (size_t)(rg.dx() + 2 * search.dx()) * (rg.dy() + 2 * search.dy()) * 20 +
-                      (1 << 20);
+                      (size_t)(lg.dx() + 2 * search.dx() + 2) * (lg.dy() + 2 * search.dy() + 2) * 4 + (1 << 20);
   // SGM: R->L crops (left image grown by twice the search), R->L masks, disparities of both directions and their history
   const size_t rl_px = (size_t)(bw + search.dx() + 8) * (bh + search.dy() + 8);
   const size_t lrev_px = (size_t)(lg.dx() + 2 * search.dx() + 8) * (lg.dy() + 2 * search.dy() + 8);
@@ -368,6 +431,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   lmp[0].w = bw; lmp[0].h = bh; lmp[0].p = A.take<uint8_t>((size_t)bw * bh);
   rmp[0].w = rmb.dx(); rmp[0].h = rmb.dy(); rmp[0].p = A.take<uint8_t>((size_t)rmb.dx() * rmb.dy());
   double* d_acc = A.take<double>(4);
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
   if (!lp[0].p || !rp[0].p || !lmx || !rmx || !lmp[0].p || !rmp[0].p || !d_acc) return fail_mem();
   {
     vwgpu_prof_scope ps(ctx, "pyramid_base_crops");
@@ -379,12 +443,41 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     hipLaunchKernelGGL((crop_ext_kernel<uint8_t, 1>), grid2(rmp[0].w, rmp[0].h), kBlk, 0, st, rmask, rms, rw, rh, rmb.x0, rmb.y0, rmp[0].p, rmp[0].w, rmp[0].h);
   }
   // nodata mean fill (:130-149)
-  VWGPU_HIP(ctx, hipMemsetAsync(d_acc, 0, 4 * sizeof(double), st));
-  hipLaunchKernelGGL(masked_mean_kernel, dim3(16, 16), kBlk, 0, st, lp[0].p, lmx, lp[0].w, lp[0].h, d_acc);
-  hipLaunchKernelGGL(masked_mean_kernel, dim3(16, 16), kBlk, 0, st, rp[0].p, rmx, rp[0].w, rp[0].h, d_acc + 2);
-  double acc[4];
-  VWGPU_HIP(ctx, hipMemcpyAsync(acc, d_acc, sizeof acc, hipMemcpyDeviceToHost, st));
-  VWGPU_HIP(ctx, hipStreamSynchronize(st));
+  {
+    constexpr int NB = 256;                         // workgroups per image
+    double* d_part = A.take<double>(2 * 2 * NB);
+    int* d_cell = A.take<int>(8);
+    if (!d_part || !d_cell) return fail_mem();
+    const int init[8] = {INT_MAX, INT_MIN, 0, 0, INT_MAX, INT_MIN, 0, 0};
+    VWGPU_HIP(ctx, hipMemcpyAsync(d_cell, init, sizeof init, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(masked_mean_kernel, dim3(16, 16), kBlk, 0, st, lp[0].p, lmx, lp[0].w, lp[0].h, d_part, d_cell);
+    hipLaunchKernelGGL(masked_mean_kernel, dim3(16, 16), kBlk, 0, st, rp[0].p, rmx, rp[0].w, rp[0].h, d_part + 2 * NB, d_cell + 4);
+    double part[2 * 2 * NB];
+    int cell[8];
+    VWGPU_HIP(ctx, hipMemcpyAsync(part, d_part, sizeof part, hipMemcpyDeviceToHost, st));
+    VWGPU_HIP(ctx, hipMemcpyAsync(cell, d_cell, sizeof cell, hipMemcpyDeviceToHost, st));
+    VWGPU_HIP(ctx, hipStreamSynchronize(st));
+    bool serial[2];
+    for (int im = 0; im < 2; ++im) {
+      double s = 0.0, n = 0.0;
+      for (int b = 0; b < NB; ++b) { s += part[(im * NB + b) * 2]; n += part[(im * NB + b) * 2 + 1]; }
+      acc[2 * im] = s; acc[2 * im + 1] = n;
+      const int lo = cell[4 * im], hi = cell[4 * im + 1];
+      int lgn = 0;
+      while ((1LL << lgn) < (long long)n + 1) ++lgn;
+      // every partial sum of <= n pixels < 2^(hi+1), all multiples of 2^lo, is exact iff it needs <= 53 bits
+      serial[im] = cell[4 * im + 2] != 0 || (lo != INT_MAX && (long long)hi + 1 + lgn - lo > 53);
+    }
+    if (serial[0] || serial[1]) {
+      if (serial[0]) hipLaunchKernelGGL(masked_mean_serial_kernel, dim3(1), dim3(64), 0, st, lp[0].p, lmx, lp[0].w, lp[0].h, d_acc);
+      if (serial[1]) hipLaunchKernelGGL(masked_mean_serial_kernel, dim3(1), dim3(64), 0, st, rp[0].p, rmx, rp[0].w, rp[0].h, d_acc + 2);
+      double got[4];
+      VWGPU_HIP(ctx, hipMemcpyAsync(got, d_acc, sizeof got, hipMemcpyDeviceToHost, st));
+      VWGPU_HIP(ctx, hipStreamSynchronize(st));
+      if (serial[0]) { acc[0] = got[0]; acc[1] = got[1]; }
+      if (serial[1]) { acc[2] = got[2]; acc[3] = got[3]; }
+    }
+  }
   if (acc[1] == 0.0 || acc[3] == 0.0) {            // a fully masked image: the tile has no data (:318-327)
     hipLaunchKernelGGL(zero_out_kernel, grid2(bw, bh), kBlk, 0, st, out, os, bw, bh);
     VWGPU_HIP(ctx, hipGetLastError());
@@ -421,13 +514,38 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     }
   }
 
+  // Class of every level: when the box sums of a level could round, its zones are matched in the reference's own
+  // summation order (bm_exact.hip); integer imagery and most float imagery are order free and take the tile kernels.
+  std::vector<char> exact_level(L + 1, 0);
+  if (!use_sgm) {
+    int* d_cells = A.take<int>(4 * (size_t)(L + 1));
+    if (!d_cells) return fail_mem();
+    std::vector<int> cells(4 * (size_t)(L + 1));
+    for (int i = 0; i <= L; ++i) { cells[4 * i] = INT_MAX; cells[4 * i + 1] = INT_MIN; cells[4 * i + 2] = 0; cells[4 * i + 3] = 0; }
+    VWGPU_HIP(ctx, hipMemcpyAsync(d_cells, cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    {
+      vwgpu_prof_scope ps(ctx, "float_grain");
+      for (int i = 0; i <= L; ++i) {
+        vwgpu_launch_float_grain(ctx, lp[i].p, lp[i].w, lp[i].h, lp[i].w, d_cells + 4 * i);
+        vwgpu_launch_float_grain(ctx, rp[i].p, rp[i].w, rp[i].h, rp[i].w, d_cells + 4 * i);
+      }
+    }
+    VWGPU_HIP(ctx, hipMemcpyAsync(cells.data(), d_cells, cells.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    VWGPU_HIP(ctx, hipStreamSynchronize(st));
+    for (int i = 0; i <= L; ++i)
+      exact_level[i] = !vwgpu_sums_order_free(P->cost_type, kx, ky, cells[4 * i], cells[4 * i + 1], cells[4 * i + 2]);
+  }
+
   // level loop
   int32_t* disp = A.take<int32_t>((size_t)bw * bh * 3);
   int32_t* disp2 = A.take<int32_t>((size_t)bw * bh * 3);
   int32_t* padded = A.take<int32_t>((size_t)(bw + 2) * (bh + 2) * 3);
   int32_t* rl = A.take<int32_t>((size_t)(rg.dx() + 2 * search.dx()) * (rg.dy() + 2 * search.dy()) * 3 + 64);
-  float* tmp_a = A.take<float>(nl + nr);
-  float* tmp_b = A.take<float>((size_t)(rg.dx() + 2 * search.dx()) * (rg.dy() + 2 * search.dy()));
+  // tmp_a also receives the edge-extended LEFT crop of an R->L run: (zone + 2 * search - 1) per axis, at most the level size + 2 * search
+  const size_t tmp_a_px = std::max(nl + nr, (size_t)(lg.dx() + 2 * search.dx() + 2) * (lg.dy() + 2 * search.dy() + 2));
+  const size_t tmp_b_px = (size_t)(rg.dx() + 2 * search.dx()) * (rg.dy() + 2 * search.dy());
+  float* tmp_a = A.take<float>(tmp_a_px);
+  float* tmp_b = A.take<float>(tmp_b_px);
   if (!disp || !disp2 || !padded || !rl || !tmp_a || !tmp_b) return fail_mem();
   int* blob_scratch = nullptr;
   if (P->blob_filter_area > 0) {
@@ -463,8 +581,10 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     VWGPU_HIP(ctx, hipMemsetAsync(disp, 0, (size_t)dw * dh * 12, st));
     const int rox = up * hkx / scaling, roy = up * hky / scaling;
     std::stable_sort(zones.begin(), zones.end(), [](SearchZone const& a, SearchZone const& b) { return a.volume() < b.volume(); });
-    // dyadic / prefiltered data is not integer-valued: go straight to the float64 matcher there
-    ctx->forced_path = (saved_force != VWGPU_PATH_NONE) ? saved_force : ((level > 0 || filtered) ? VWGPU_PATH_GENERIC_F64 : VWGPU_PATH_NONE);
+    // dyadic / prefiltered data is not integer-valued: go straight to the float64 matcher there, or to the exact-order
+    // kernels when the level's sums could round
+    const int level_path = exact_level[level] ? VWGPU_PATH_EXACT_ORDER : ((level > 0 || filtered) ? VWGPU_PATH_GENERIC_F64 : VWGPU_PATH_NONE);
+    ctx->forced_path = (saved_force != VWGPU_PATH_NONE) ? saved_force : level_path;
     const DevImg Lv = lp[level], Rv = rp[level];
     const bool lr_active = P->consistency_threshold >= 0 && last;
     // One launch for all zones of the level (bm_zones.hip) unless the kernel is too large for its LDS tiles, or the
@@ -476,8 +596,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
       const int sx = search.width() / scaling, sy = search.height() / scaling;   // zone.disparity_range().size(), inclusive for SGM
       const IBox lr(rox - hkx, roy - hky, dw + rox + hkx, dh + roy + hky);
       const IBox rr(lr.x0, lr.y0, lr.x1 + sx, lr.y1 + sy);
-      if ((size_t)rr.dx() * rr.dy() > (size_t)(rg.dx() + 2 * search.dx()) * (rg.dy() + 2 * search.dy()) || (size_t)lr.dx() * lr.dy() > nl + nr)
-        return fail_mem();
+      if ((size_t)rr.dx() * rr.dy() > tmp_b_px || (size_t)lr.dx() * lr.dy() > tmp_a_px) return fail_mem();
       hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(lr.dx(), lr.dy()), kBlk, 0, st, Lv.p, Lv.w, Lv.w, Lv.h, lr.x0, lr.y0, tmp_a, lr.dx(), lr.dy());
       hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(rr.dx(), rr.dy()), kBlk, 0, st, Rv.p, Rv.w, Rv.w, Rv.h, rr.x0, rr.y0, tmp_b, rr.dx(), rr.dy());
       const bool have_prev = level < L;
@@ -542,11 +661,17 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         }
       }
       ctx->forced_path = saved_force;
+      bool exact = exact_level[level] != 0;
+      for (vwgpu_zone_task const& z : t1) exact = exact && vwgpu_bm_exact_supported(z.sx, z.sy);
       if (lr_active && rl_pixels) { if ((rc = vwgpu_arena_reserve(ctx, &ctx->zrl, rl_pixels * 12))) return rc; }
-      if ((rc = vwgpu_launch_bm_zones(ctx, P->cost_type, Lv.p, Lv.w, Lv.h, Rv.p, Rv.w, Rv.h, kx, ky, t1.data(), (int)t1.size(), disp))) return rc;
+      if (exact) rc = vwgpu_launch_bm_exact(ctx, P->cost_type, Lv.p, Lv.w, Lv.h, Lv.w, Rv.p, Rv.w, Rv.h, Rv.w, kx, ky, t1.data(), (int)t1.size(), disp);
+      else rc = vwgpu_launch_bm_zones(ctx, P->cost_type, Lv.p, Lv.w, Lv.h, Rv.p, Rv.w, Rv.h, kx, ky, t1.data(), (int)t1.size(), disp);
+      if (rc) return rc;
       if (lr_active) {
         int32_t* rlbuf = static_cast<int32_t*>(ctx->zrl.base);
-        if ((rc = vwgpu_launch_bm_zones(ctx, P->cost_type, Rv.p, Rv.w, Rv.h, Lv.p, Lv.w, Lv.h, kx, ky, t2.data(), (int)t2.size(), rlbuf))) return rc;
+        if (exact) rc = vwgpu_launch_bm_exact(ctx, P->cost_type, Rv.p, Rv.w, Rv.h, Rv.w, Lv.p, Lv.w, Lv.h, Lv.w, kx, ky, t2.data(), (int)t2.size(), rlbuf);
+        else rc = vwgpu_launch_bm_zones(ctx, P->cost_type, Rv.p, Rv.w, Rv.h, Lv.p, Lv.w, Lv.h, kx, ky, t2.data(), (int)t2.size(), rlbuf);
+        if (rc) return rc;
         if ((rc = vwgpu_launch_zone_lr(ctx, t3.data(), (int)t3.size(), disp, rlbuf, P->consistency_threshold, lr_diff, lr_stride))) return rc;
       }
     } else if (!use_sgm)
@@ -561,6 +686,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
       // the crops normally lie inside the level images; edge-extend into scratch when rounding makes them stick out
       const float* lptr; ptrdiff_t lstr; const float* rptr; ptrdiff_t rstr;
       const int rneed_w = lr.dx() + sx - 1, rneed_h = lr.dy() + sy - 1;
+      if ((size_t)lr.dx() * lr.dy() > tmp_a_px || (size_t)rneed_w * rneed_h > tmp_b_px) { ctx->forced_path = saved_force; return fail_mem(); }
       if (lr.x0 >= 0 && lr.y0 >= 0 && lr.x1 <= Lv.w && lr.y1 <= Lv.h) { lptr = Lv.p + (size_t)lr.y0 * Lv.w + lr.x0; lstr = Lv.w; }
       else {
         hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(lr.dx(), lr.dy()), kBlk, 0, st, Lv.p, Lv.w, Lv.w, Lv.h, lr.x0, lr.y0, tmp_a, lr.dx(), lr.dy());
@@ -572,6 +698,8 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         rptr = tmp_b; rstr = rneed_w;
       }
       int32_t* zout = disp + ((size_t)z.region.y0 * dw + z.region.x0) * 3;
+      if (saved_force == VWGPU_PATH_NONE && level_path == VWGPU_PATH_EXACT_ORDER)
+        ctx->forced_path = vwgpu_bm_exact_supported(sx, sy) ? VWGPU_PATH_EXACT_ORDER : VWGPU_PATH_GENERIC_F64;
       rc = vwgpu_calc_disparity_dev(ctx, P->cost_type, lptr, lr.dx(), lr.dy(), lstr, rptr, rneed_w, rneed_h, rstr, kx, ky, sx, sy, zout, dw);
       if (rc) { ctx->forced_path = saved_force; return rc; }
       if (P->consistency_threshold >= 0 && last) {                    // R->L run + L/R check (:654-694)
@@ -580,6 +708,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         estim += next2;
         const int aw = rr.dx(), ah = rr.dy();                          // "left" of this run: the right crop (edge-extended)
         const int bw2 = aw + sx - 1, bh2 = ah + sy - 1;                // "right": the left image from (lr.min - s)
+        if ((size_t)aw * ah > tmp_b_px || (size_t)bw2 * bh2 > tmp_a_px) { ctx->forced_path = saved_force; return fail_mem(); }
         hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(aw, ah), kBlk, 0, st, Rv.p, Rv.w, Rv.w, Rv.h, rr.x0, rr.y0, tmp_b, aw, ah);
         hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(bw2, bh2), kBlk, 0, st, Lv.p, Lv.w, Lv.w, Lv.h, lr.x0 - sx, lr.y0 - sy, tmp_a, bw2, bh2);
         const int rlw = aw - kx + 1, rlh = ah - ky + 1;

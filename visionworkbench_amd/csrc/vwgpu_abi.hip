@@ -53,7 +53,7 @@ int vwgpu_next_flags(vwgpu_ctx* ctx, size_t extra_ints, int** flag_set, int** fl
   int rc = vwgpu_arena_reserve(ctx, &ctx->flags, 256 + extra_ints * sizeof(int));
   if (rc) return rc;
   int* flags = static_cast<int*>(ctx->flags.base);
-  if (ctx->flags_base_seen != ctx->flags.base) { ctx->flags_init = false; ctx->flags_base_seen = ctx->flags.base; }
+  if (ctx->flags_base_seen != ctx->flags.base) { ctx->flags_init = false; ctx->flags_base_seen = ctx->flags.base; ctx->last_flag = nullptr; }
   if (!ctx->flags_init) {
     VWGPU_HIP(ctx, hipMemsetAsync(flags, 0, 256, ctx->stream));
     ctx->flags_init = true;
@@ -113,6 +113,8 @@ void vwgpu_destroy(vwgpu_ctx* ctx) {
   if (ctx->zext.base) (void)hipFree(ctx->zext.base);
   if (ctx->sgm.base) (void)hipFree(ctx->sgm.base);
   if (ctx->sgm_main.base) (void)hipFree(ctx->sgm_main.base);
+  if (ctx->xvol.base) (void)hipFree(ctx->xvol.base);
+  if (ctx->xtab.base) (void)hipFree(ctx->xtab.base);
   if (ctx->staging.base) (void)hipFree(ctx->staging.base);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -147,9 +149,28 @@ int vwgpu_synchronize(vwgpu_ctx* ctx) {
 const char* vwgpu_last_error(const vwgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
 
 int vwgpu_force_path(vwgpu_ctx* ctx, int path) {
-  if (!ctx || path < VWGPU_PATH_NONE || path > VWGPU_PATH_DOT_U8) return VWGPU_ERR_ARGUMENT;
+  if (!ctx || path < VWGPU_PATH_NONE || path > VWGPU_PATH_EXACT_ORDER) return VWGPU_ERR_ARGUMENT;
   ctx->forced_path = path;
   return VWGPU_OK;
+}
+
+int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  if (option == VWGPU_OPT_DEFER_EXACTNESS) { ctx->defer_exact = value != 0; return VWGPU_OK; }
+  return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "vwgpu_set_option: unknown or read-only option %d", option);
+}
+
+int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value) {
+  if (!value) return VWGPU_ERR_ARGUMENT;
+  if (option == VWGPU_OPT_DEVICE_COUNT) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return VWGPU_ERR_HIP;
+    *value = n;
+    return VWGPU_OK;
+  }
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  if (option == VWGPU_OPT_DEFER_EXACTNESS) { *value = ctx->defer_exact ? 1 : 0; return VWGPU_OK; }
+  return VWGPU_ERR_ARGUMENT;
 }
 
 int vwgpu_last_path(const vwgpu_ctx* cctx) {
@@ -220,6 +241,30 @@ static int check_bm_args(vwgpu_ctx* ctx, int cost_type, const void* l, int lw, i
   return VWGPU_OK;
 }
 
+// Inputs outside the packed kernels' domain: float64 kernel with tile-local sums when every partial sum is exactly
+// representable (any order returns the reference's bits), the reference's serial summation order otherwise.
+static int calc_disparity_classified(vwgpu_ctx* ctx, int cost_type, const float* d_left, int lw, int lh, ptrdiff_t ls,
+                                     const float* d_right, int rw, int rh, ptrdiff_t rs, int kx, int ky, int sx, int sy,
+                                     int32_t* d_out, ptrdiff_t os) {
+  bool exact = ctx->forced_path == VWGPU_PATH_EXACT_ORDER;
+  if (ctx->forced_path == VWGPU_PATH_NONE && vwgpu_bm_exact_supported(sx, sy)) {
+    int lo = 0, hi = 0, nonfinite = 0;
+    int rc = vwgpu_float_grain(ctx, d_left, lw, lh, ls, d_right, lw + sx - 1, lh + sy - 1, rs, &lo, &hi, &nonfinite);
+    if (rc) return rc;
+    exact = !vwgpu_sums_order_free(cost_type, kx, ky, lo, hi, nonfinite);
+  }
+  ctx->last_flag = nullptr;
+  if (exact) {
+    if (!vwgpu_bm_exact_supported(sx, sy))
+      return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: the exact-order path serves up to 512 disparities (%d x %d asked)", sx, sy);
+    ctx->last_path = VWGPU_PATH_EXACT_ORDER;
+    vwgpu_zone_task z{0, 0, 0, 0, lw - kx + 1, lh - ky + 1, sx, sy, 0, (int)os, 0, 0};
+    return vwgpu_launch_bm_exact(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, &z, 1, d_out);
+  }
+  ctx->last_path = VWGPU_PATH_GENERIC_F64;
+  return vwgpu_launch_bm_generic(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os);
+}
+
 int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
                              const float* d_left, int lw, int lh, ptrdiff_t ls,
                              const float* d_right, int rw, int rh, ptrdiff_t rs,
@@ -228,39 +273,39 @@ int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
   if (rc) return rc;
   VWGPU_HIP(ctx, hipSetDevice(ctx->device));
   if (os == 0) os = lw - kx + 1;
+  if (os > INT32_MAX) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity: output stride too large");
 
-  const bool fast_ok = vwgpu_bm_sad_u8_supported(cost_type, kx, ky, sx, sy);
-  if (ctx->forced_path == VWGPU_PATH_SAD_U8 && !fast_ok)
+  const bool sad_ok = vwgpu_bm_sad_u8_supported(cost_type, kx, ky, sx, sy);
+  const bool dot_ok = !sad_ok && vwgpu_bm_dot_u8_supported(cost_type, kx, ky, sx, sy);
+  if (ctx->forced_path == VWGPU_PATH_SAD_U8 && !sad_ok)
     return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: no packed-u8 path for cost %d kernel %dx%d search %dx%d",
                       cost_type, kx, ky, sx, sy);
-  if (fast_ok && ctx->forced_path != VWGPU_PATH_GENERIC_F64) {
-    int* d_flag = nullptr;
-    rc = vwgpu_launch_bm_sad_u8(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
-    if (rc) return rc;
-    ctx->last_path = VWGPU_PATH_SAD_U8;
-    ctx->last_flag = d_flag;
-    if (ctx->forced_path == VWGPU_PATH_SAD_U8) return VWGPU_OK;   // caller inspects vwgpu_last_path()
-    // Inputs that are not integer-valued in [0,255] raise the device flag; the generic kernel then
-    // recomputes the whole image (its blocks return at once when the flag is clear).
-    return vwgpu_launch_bm_generic_flag(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs,
-                                        kx, ky, sx, sy, d_out, os, d_flag);
-  }
-  // SSD / NCC on integer-valued data: packed dot-product path, same flag protocol
-  const bool dot_ok = vwgpu_bm_dot_u8_supported(cost_type, kx, ky, sx, sy);
   if (ctx->forced_path == VWGPU_PATH_DOT_U8 && !dot_ok)
     return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: no dot-product path for cost %d kernel %dx%d search %dx%d",
                       cost_type, kx, ky, sx, sy);
-  if (dot_ok && (ctx->forced_path == VWGPU_PATH_NONE || ctx->forced_path == VWGPU_PATH_DOT_U8)) {
-    int* d_flag = nullptr;
-    rc = vwgpu_launch_bm_dot_u8(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
-    if (rc) return rc;
-    ctx->last_path = VWGPU_PATH_DOT_U8;
-    ctx->last_flag = d_flag;
-    if (ctx->forced_path == VWGPU_PATH_DOT_U8) return VWGPU_OK;
+  const bool try_packed = (sad_ok && (ctx->forced_path == VWGPU_PATH_NONE || ctx->forced_path == VWGPU_PATH_SAD_U8)) ||
+                          (dot_ok && (ctx->forced_path == VWGPU_PATH_NONE || ctx->forced_path == VWGPU_PATH_DOT_U8));
+  if (!try_packed)
+    return calc_disparity_classified(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os);
+
+  // Integer-valued inputs in [0,255]: the packed kernels; they check the domain while converting and raise a device flag.
+  int* d_flag = nullptr;
+  if (sad_ok) rc = vwgpu_launch_bm_sad_u8(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
+  else rc = vwgpu_launch_bm_dot_u8(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
+  if (rc) return rc;
+  ctx->last_path = sad_ok ? VWGPU_PATH_SAD_U8 : VWGPU_PATH_DOT_U8;
+  ctx->last_flag = d_flag;
+  if (ctx->forced_path != VWGPU_PATH_NONE) return VWGPU_OK;       // caller inspects vwgpu_last_path()
+  if (ctx->defer_exact)
+    // pipelined callers: no host round trip; the float64 kernel recomputes the image if the flag is up (its blocks
+    // return at once otherwise) and vwgpu_last_path() tells afterwards
     return vwgpu_launch_bm_generic_flag(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, d_flag);
-  }
-  ctx->last_path = VWGPU_PATH_GENERIC_F64;
-  return vwgpu_launch_bm_generic(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os);
+  int flag = 0;
+  VWGPU_HIP(ctx, hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->last_flag = nullptr;
+  if (!flag) return VWGPU_OK;
+  return calc_disparity_classified(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os);
 }
 
 int vwgpu_calc_disparity(vwgpu_ctx* ctx, int cost_type,
@@ -288,6 +333,57 @@ int vwgpu_calc_disparity(vwgpu_ctx* ctx, int cost_type,
   rc = vwgpu_calc_disparity_dev(ctx, cost_type, d_l, lw, lh, lw, d_r, rcw, rch, rcw, kx, ky, sx, sy, d_o, ow);
   if (rc) return rc;
   VWGPU_HIP(ctx, hipMemcpy2DAsync(out, (size_t)os * 12, d_o, (size_t)ow * 12, (size_t)ow * 12, oh, hipMemcpyDeviceToHost, ctx->stream));
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VWGPU_OK;
+}
+
+// ---- fast_box_sum -------------------------------------------------------------------------------------------
+
+static int check_box_args(vwgpu_ctx* ctx, const void* img, int w, int h, ptrdiff_t stride, int kx, int ky, const void* out, ptrdiff_t os) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  ctx->err.clear();
+  if (!img || !out) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "fast_box_sum: null image pointer");
+  if (kx < 1 || ky < 1 || kx % 2 != 1 || ky % 2 != 1)       // Algorithms.h:45-46, an always-on VW_ASSERT
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "fast_box_sum: Kernel input not sized with odd values.");
+  if (w < kx || h < ky) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "fast_box_sum: Image is not big enough for kernel.");
+  if (stride < w || (os != 0 && os < w - kx + 1)) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "fast_box_sum: row stride smaller than row width");
+  return VWGPU_OK;
+}
+
+int vwgpu_fast_box_sum_dev(vwgpu_ctx* ctx, const float* d_img, int w, int h, ptrdiff_t stride, int kx, int ky,
+                           double* d_out, ptrdiff_t os) {
+  if (stride == 0) stride = w;
+  int rc = check_box_args(ctx, d_img, w, h, stride, kx, ky, d_out, os);
+  if (rc) return rc;
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  const int ow = w - kx + 1, oh = h - ky + 1;
+  if (os == 0 || os == ow) return vwgpu_launch_box_sum_exact(ctx, d_img, w, h, stride, kx, ky, d_out);
+  // strided destination: through a dense scratch image
+  rc = vwgpu_arena_reserve(ctx, &ctx->filt, (size_t)ow * oh * sizeof(double));
+  if (rc) return rc;
+  double* tmp = static_cast<double*>(ctx->filt.base);
+  rc = vwgpu_launch_box_sum_exact(ctx, d_img, w, h, stride, kx, ky, tmp);
+  if (rc) return rc;
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_out, (size_t)os * 8, tmp, (size_t)ow * 8, (size_t)ow * 8, oh, hipMemcpyDeviceToDevice, ctx->stream));
+  return VWGPU_OK;
+}
+
+int vwgpu_fast_box_sum(vwgpu_ctx* ctx, const float* img, int w, int h, ptrdiff_t stride, int kx, int ky, double* out, ptrdiff_t os) {
+  if (stride == 0) stride = w;
+  int rc = check_box_args(ctx, img, w, h, stride, kx, ky, out, os);
+  if (rc) return rc;
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  const int ow = w - kx + 1, oh = h - ky + 1;
+  if (os == 0) os = ow;
+  const size_t ib = vwgpu_align_up((size_t)w * h * sizeof(float), 256), ob = (size_t)ow * oh * sizeof(double);
+  rc = vwgpu_arena_reserve(ctx, &ctx->staging, ib + ob);
+  if (rc) return rc;
+  float* d_i = static_cast<float*>(ctx->staging.base);
+  double* d_o = reinterpret_cast<double*>(static_cast<char*>(ctx->staging.base) + ib);
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_i, (size_t)w * 4, img, (size_t)stride * 4, (size_t)w * 4, h, hipMemcpyHostToDevice, ctx->stream));
+  rc = vwgpu_launch_box_sum_exact(ctx, d_i, w, h, w, kx, ky, d_o);
+  if (rc) return rc;
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(out, (size_t)os * 8, d_o, (size_t)ow * 8, (size_t)ow * 8, oh, hipMemcpyDeviceToHost, ctx->stream));
   VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VWGPU_OK;
 }

@@ -48,6 +48,9 @@ struct vwgpu_ctx {
   vwgpu_arena zext;      // zone scheduler: leaf boxes of the quad tree and their measured disparity extents
   vwgpu_arena sgm;       // SGM: u8 images, census words, disparity bounds, ragged starts
   vwgpu_arena sgm_main;  // SGM: ragged cost (u8) + accumulated cost (u16) buffers
+  vwgpu_arena xvol;      // exact-order path: column-sum volumes, band state, per-zone NCC precision images (bm_exact.hip)
+  vwgpu_arena xtab;      // exact-order path: zone / work-item tables of one call
+  bool defer_exact = false;   // VWGPU_OPT_DEFER_EXACTNESS: calc_disparity_dev never waits for the input-class flags
   int num_cu = 256;
 };
 
@@ -103,6 +106,19 @@ int vwgpu_launch_bm_dot_u8(vwgpu_ctx* ctx, int cost_type, const float* left, int
                            const float* right, int rw, int rh, ptrdiff_t rs, int kx, int ky, int sx, int sy,
                            int32_t* out, ptrdiff_t os, int** d_fallback_flag);
 int vwgpu_next_flags(vwgpu_ctx* ctx, size_t extra_ints, int** flag_set, int** flag_clear, int** extra);
+
+// bm_exact.hip: the reference's own summation order (serial column / row chains of fast_box_sum) for inputs whose
+// partial sums are not exactly representable; see the file header.
+struct vwgpu_zone_task;
+bool vwgpu_bm_exact_supported(int sx, int sy);
+bool vwgpu_sums_order_free(int cost_type, int kx, int ky, int lo, int hi, int nonfinite);
+int vwgpu_float_grain(vwgpu_ctx* ctx, const float* a, int aw, int ah, ptrdiff_t as, const float* b, int bw, int bh, ptrdiff_t bs,
+                      int* lo, int* hi, int* nonfinite);
+void vwgpu_launch_float_grain(vwgpu_ctx* ctx, const float* a, int aw, int ah, ptrdiff_t as, int* d_cell);
+int vwgpu_launch_bm_exact(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, ptrdiff_t as,
+                          const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky,
+                          const vwgpu_zone_task* zones, int n, int32_t* out);
+int vwgpu_launch_box_sum_exact(vwgpu_ctx* ctx, const float* img, int w, int h, ptrdiff_t stride, int kx, int ky, double* d_out);
 
 int vwgpu_launch_lr_check(vwgpu_ctx* ctx, int32_t* l2r, int lw, int lh, ptrdiff_t ls,
                           const int32_t* r2l, int rw, int rh, ptrdiff_t rs, float thr);

@@ -79,6 +79,30 @@ def calc_disparity(cost_type, left_in, right_in, left_region, search_volume, ker
     return out
 
 
+def fast_box_sum(image, kernel, ctx=None):
+    """vw::stereo::fast_box_sum<double>(image, kernel) (src/vw/Stereo/Algorithms.h:41-129): float64 sums of every
+    kx x ky window, (rows-ky+1, cols-kx+1), formed in the reference's running-sum order (bit-identical for any float input)."""
+    kx, ky = int(kernel[0]), int(kernel[1])
+    if image.ndim != 2:
+        raise ArgumentErr("fast_box_sum: the image must be 2-D (rows, cols)")
+    h, w = image.shape
+    ctx = _ctx_for(image, ctx)
+    lib = ctx._lib
+    if _is_tensor(image):
+        if not image.is_cuda or image.dtype != torch.float32:
+            raise ArgumentErr("fast_box_sum: torch input must be a float32 CUDA tensor (no CPU path)")
+        if image.stride(1) != 1:
+            image = image.contiguous()
+        out = torch.empty((max(h - ky + 1, 0), max(w - kx + 1, 0)), dtype=torch.float64, device=image.device)
+        ctx.set_stream(torch.cuda.current_stream(image.device).cuda_stream)
+        ctx.check(lib.vwgpu_fast_box_sum_dev(ctx._h, image.data_ptr(), w, h, image.stride(0), kx, ky, out.data_ptr(), 0))
+        return out
+    img = np.ascontiguousarray(image, np.float32)
+    out = np.empty((max(h - ky + 1, 0), max(w - kx + 1, 0)), np.float64)
+    ctx.check(lib.vwgpu_fast_box_sum(ctx._h, img.ctypes.data, w, h, w, kx, ky, out.ctypes.data, 0))
+    return out
+
+
 def cross_corr_consistency_check(l2r, r2l, cross_corr_threshold, lr_disp_diff=None, ul_corner_offset=(0, 0), ctx=None):
     """vw::stereo::cross_corr_consistency_check (src/vw/Stereo/Correlate.cc:1441-1502), IN PLACE on l2r.
 
