@@ -42,8 +42,8 @@ def test_config2_full_image_identical(ctx, oracle, pair4096):
     torch.cuda.synchronize()
     assert ctx.last_path() == core.PATH_SAD_U8
     got = got.cpu().numpy()
-    want, tiles = oracle.calc_disparity_tiled(0, left, right, (7, 7), (129, 1), tile=256, threads=NCPU)
-    assert want.shape == got.shape == (4090, 4090, 3) and tiles == 256
+    want, done = oracle.calc_disparity_tiled(0, left, right, (7, 7), (129, 1), tile=256, threads=NCPU)
+    assert want.shape == got.shape == (4090, 4090, 3) and done == 4090 * 4090
     assert np.array_equal(got, want), int((got != want).any(-1).sum())
     assert (got[..., 2] == core.VALID_I32).mean() > 0.999 and (got[..., 0] == truth[:4090, :4090]).mean() > 0.9
 
@@ -87,7 +87,9 @@ def test_config4_full_strip_ground_truth():
     known block shifts are the check (SGM must recover them away from the block seams)."""
     w, rows = 16384, 2048 + 6
     left, right, truth = synth.stereo_pair(w, rows, 129, 1)
-    gi = stereo.calc_disparity_sgm(3, left, right, BBox2i(0, 0, w, rows), (128, 0), (7, 7))
+    # 33.5 M pixels x 129 disparities x (u8 cost + u16 accumulator) = 13 GB: above the reference's default cap of 6000 MB,
+    # under which calc_main_buf_size's conservation levels (SGM.cc:502-672) leave a single-level search with no pixels
+    gi = stereo.calc_disparity_sgm(3, left, right, BBox2i(0, 0, w, rows), (128, 0), (7, 7), memory_limit_mb=20000)
     assert gi.shape == (2048, w - 6, 3)
     t = truth[3:3 + 2048, 3:3 + w - 6]
     valid = gi[..., 2] != 0

@@ -46,6 +46,13 @@ VWLITE_EXCEPTION(NoImplErr, Exception);
 
 template <class ExcT> inline void vw_throw(ExcT const& e) { throw e; }
 
+namespace engine {
+// Worker threads of the block rasterisers (block_rasterize, block_write_image) announce their pool index here; the engine
+// wrappers (vw/Engine.h) bind worker w to GPU devices[w % ndev] with one context per (thread x GPU) — the reference's tile
+// threads (src/vw/Image/ImageIO.h:228-251) spread over the GPUs of the node.
+inline int& thread_worker_index() { static thread_local int idx = 0; return idx; }
+}  // namespace engine
+
 #define VW_ASSERT(cond, excep) do { if (!(cond)) vw::vw_throw(excep); } while (0)
 // VW_DEBUG_ASSERT is compiled out in the reference's release builds (Exception.h:286-289); the engine
 // re-checks the same conditions behind the C ABI, so they are always on here.

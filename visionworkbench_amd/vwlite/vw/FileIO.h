@@ -204,7 +204,8 @@ void block_write_image(std::string const& path, ImageViewBase<ViewT> const& view
   std::atomic<int32> next(0);
   std::exception_ptr error;
   std::mutex error_mutex;
-  auto worker = [&]() {
+  auto worker = [&](int32 index) {
+    engine::thread_worker_index() = index;        // worker w -> GPU w % ndev (vw/Engine.h)
     try {
       for (;;) {
         const int32 i = next.fetch_add(1);
@@ -222,10 +223,10 @@ void block_write_image(std::string const& path, ImageViewBase<ViewT> const& view
     }
   };
   const int32 nt = std::min<int32>(num_threads, nbx * nby);
-  if (nt <= 1) worker();
+  if (nt <= 1) worker(engine::thread_worker_index());
   else {
     std::vector<std::thread> pool;
-    for (int32 t = 0; t < nt; ++t) pool.emplace_back(worker);
+    for (int32 t = 0; t < nt; ++t) pool.emplace_back(worker, t);
     for (std::thread& t : pool) t.join();
   }
   if (error) std::rethrow_exception(error);

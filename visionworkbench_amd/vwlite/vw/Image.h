@@ -303,7 +303,8 @@ public:
     std::atomic<int32> next(0);
     std::exception_ptr error;
     std::mutex error_mutex;
-    auto worker = [&]() {
+    auto worker = [&](int32 index) {
+      engine::thread_worker_index() = index;      // the engine wrappers bind worker w to GPU w % ndev (vw/Engine.h)
       try {
         for (;;) {
           const int32 i = next.fetch_add(1);
@@ -320,10 +321,10 @@ public:
       }
     };
     const int32 nt = std::min<int32>(m_num_threads, nbx * nby);
-    if (nt <= 1) worker();
+    if (nt <= 1) worker(engine::thread_worker_index());
     else {
       std::vector<std::thread> pool;
-      for (int32 t = 0; t < nt; ++t) pool.emplace_back(worker);
+      for (int32 t = 0; t < nt; ++t) pool.emplace_back(worker, t);
       for (std::thread& t : pool) t.join();
     }
     if (error) std::rethrow_exception(error);
