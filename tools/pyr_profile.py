@@ -1,4 +1,6 @@
-"""Per-kernel launch counts / device time inside one pyramid_correlate tile (vwgpu_profile_*).  GPU box only."""
+"""Per-kernel launch counts / device time inside one pyramid_correlate tile (vwgpu_profile_*), for the input classes that
+pick different matchers: integer imagery (tile kernels), LoG / mean-subtracted imagery and NCC (exact-order kernels when a
+level's box sums could round).  GPU box only.  usage: python tools/pyr_profile.py [tile] [prefilter cost kernel]..."""
 import sys, time, collections
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -6,20 +8,23 @@ from visionworkbench_amd import stereo, synth, core
 from visionworkbench_amd.core import BBox2i
 W = 4096
 tile = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+cases = [(0, 0, 7), (2, 0, 7), (1, 0, 7), (0, 2, 11), (2, 2, 11), (0, 1, 7)]
 L, R, _ = synth.stereo_pair(W, W, 129, 1)
 Lg, Rg = torch.from_numpy(L).cuda(), torch.from_numpy(R[:, 64:64 + W].copy()).cuda()
 ctx = core.default_context(0)
-args = dict(consistency_threshold=2, filter_half_kernel=5, max_pyramid_levels=5, bbox=BBox2i(256, 256, tile, tile))
-run = lambda: stereo.pyramid_correlate(Lg, Rg, None, None, 0, 0.0, BBox2i.from_corners((-64, -1), (64, 1)), (7, 7), 0, **args)
-run(); torch.cuda.synchronize()
-t0 = time.perf_counter(); out = run(); torch.cuda.synchronize(); wall = time.perf_counter() - t0
-ctx.profile_enable(True); ctx.profile_reset()
-run(); torch.cuda.synchronize()
-rec = ctx.profile_read(1 << 16)
-ctx.profile_enable(False)
-agg = collections.OrderedDict()
-for n, ms in rec:
-    a = agg.setdefault(n, [0, 0.0]); a[0] += 1; a[1] += ms
-print("wall %.1f ms; valid %.3f" % (wall * 1e3, float((out[..., 2] != 0).float().mean())))
-for n, (c, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print("%-28s launches %6d  device %.2f ms" % (n, c, ms))
+for pf, cost, k in cases:
+    args = dict(consistency_threshold=2, filter_half_kernel=5, max_pyramid_levels=5, bbox=BBox2i(256, 256, tile, tile))
+    run = lambda: stereo.pyramid_correlate(Lg, Rg, None, None, pf, 1.4 if pf else 0.0, BBox2i.from_corners((-64, -1), (64, 1)), (k, k), cost, **args)
+    run(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); out = run(); torch.cuda.synchronize(); wall = time.perf_counter() - t0
+    ctx.profile_enable(True); ctx.profile_reset()
+    run(); torch.cuda.synchronize()
+    rec = ctx.profile_read(1 << 16)
+    ctx.profile_enable(False)
+    agg = collections.OrderedDict()
+    for n, ms in rec:
+        a = agg.setdefault(n, [0, 0.0]); a[0] += 1; a[1] += ms
+    print("== prefilter %d cost %d kernel %dx%d tile %d^2: wall %.2f ms; kernels %.2f ms; valid %.3f" %
+          (pf, cost, k, k, tile, wall * 1e3, sum(v[1] for v in agg.values()), float((out[..., 2] != 0).float().mean())))
+    for n, (c, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
+        print("   %-28s launches %6d  device %.3f ms" % (n, c, ms))

@@ -987,8 +987,11 @@ int vwgpu_pyramid_correlate(vwgpu_ctx* ctx, const float* left, int lw, int lh, p
   if (P->lr_disp_diff && (bx < P->region_ul_x || by < P->region_ul_y || bx + bw > P->region_ul_x + P->lr_disp_diff_cols ||
                           by + bh > P->region_ul_y + P->lr_disp_diff_rows))
     return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "The L-R to R-L difference image domain does not contain the current tile.");
+  // The discrepancy image is shared by the tile threads (each writes its own pixels, CorrelationView.cc:683-694): only the
+  // tile's rectangle of it is staged, so that concurrent tiles never write back each other's stale pixels.
   const ptrdiff_t hdst = P->lr_disp_diff_stride ? P->lr_disp_diff_stride : P->lr_disp_diff_cols;
-  const size_t db = P->lr_disp_diff ? vwgpu_align_up((size_t)P->lr_disp_diff_cols * P->lr_disp_diff_rows * 8, 256) : 0;
+  const size_t db = P->lr_disp_diff ? vwgpu_align_up((size_t)bw * bh * 8, 256) : 0;
+  float* h_diff = P->lr_disp_diff ? P->lr_disp_diff + ((ptrdiff_t)(by - P->region_ul_y) * hdst + (bx - P->region_ul_x)) * 2 : nullptr;
   rc = vwgpu_arena_reserve(ctx, &ctx->staging, lb + rb + lmb + rmb + ob + db);
   if (rc) return rc;
   char* base = static_cast<char*>(ctx->staging.base);
@@ -1004,19 +1007,17 @@ int vwgpu_pyramid_correlate(vwgpu_ctx* ctx, const float* left, int lw, int lh, p
   if (lmask) VWGPU_HIP(ctx, hipMemcpy2DAsync(d_lm, (size_t)lww, lmask + (ptrdiff_t)oy * lms + ox, (size_t)lms, (size_t)lww, lwh, hipMemcpyHostToDevice, ctx->stream));
   if (rmask) VWGPU_HIP(ctx, hipMemcpy2DAsync(d_rm, (size_t)rww, rmask + (ptrdiff_t)oy * rms + ox, (size_t)rms, (size_t)rww, rwh, hipMemcpyHostToDevice, ctx->stream));
   float* d_d = reinterpret_cast<float*>(base + lb + rb + lmb + rmb + ob);
-  vwgpu_pyramid_params Pd = *P;                     // the device-side view of the discrepancy image is dense
-  Pd.lr_disp_diff_stride = P->lr_disp_diff_cols;
-  Pd.region_ul_x = P->region_ul_x - ox;             // everything below runs in window coordinates
-  Pd.region_ul_y = P->region_ul_y - oy;
+  vwgpu_pyramid_params Pd = *P;                     // the device-side discrepancy image is the tile's rectangle, dense
+  Pd.lr_disp_diff_cols = bw; Pd.lr_disp_diff_rows = bh; Pd.lr_disp_diff_stride = bw;
+  Pd.region_ul_x = bx - ox;                         // everything below runs in window coordinates
+  Pd.region_ul_y = by - oy;
   if (P->lr_disp_diff)
-    VWGPU_HIP(ctx, hipMemcpy2DAsync(d_d, (size_t)P->lr_disp_diff_cols * 8, P->lr_disp_diff, (size_t)hdst * 8, (size_t)P->lr_disp_diff_cols * 8,
-                                    P->lr_disp_diff_rows, hipMemcpyHostToDevice, ctx->stream));
+    VWGPU_HIP(ctx, hipMemcpy2DAsync(d_d, (size_t)bw * 8, h_diff, (size_t)hdst * 8, (size_t)bw * 8, bh, hipMemcpyHostToDevice, ctx->stream));
   rc = vwgpu_pyramid_correlate_impl(ctx, d_l, lww, lwh, lww, d_r, rww, rwh, rww, lmask ? d_lm : nullptr, lww, rmask ? d_rm : nullptr, rww,
                                     &Pd, bx - ox, by - oy, bw, bh, d_o, bw, P->lr_disp_diff ? d_d : nullptr);
   if (rc) return rc;
   if (P->lr_disp_diff)
-    VWGPU_HIP(ctx, hipMemcpy2DAsync(P->lr_disp_diff, (size_t)hdst * 8, d_d, (size_t)P->lr_disp_diff_cols * 8, (size_t)P->lr_disp_diff_cols * 8,
-                                    P->lr_disp_diff_rows, hipMemcpyDeviceToHost, ctx->stream));
+    VWGPU_HIP(ctx, hipMemcpy2DAsync(h_diff, (size_t)hdst * 8, d_d, (size_t)bw * 8, (size_t)bw * 8, bh, hipMemcpyDeviceToHost, ctx->stream));
   VWGPU_HIP(ctx, hipMemcpy2DAsync(out, (size_t)os * 12, d_o, (size_t)bw * 12, (size_t)bw * 12, bh, hipMemcpyDeviceToHost, ctx->stream));
   VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VWGPU_OK;

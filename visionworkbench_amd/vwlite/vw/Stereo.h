@@ -2,6 +2,7 @@
 // implemented on libvwgpu.so (include/vwgpu.h).  Header-only; link with -lvwgpu.
 //
 //   calc_disparity               src/vw/Stereo/Correlation.h:50-57   (impl Correlation.cc:330-375)
+//   fast_box_sum                 src/vw/Stereo/Algorithms.h:41-129
 //   cross_corr_consistency_check src/vw/Stereo/Correlate.h:52-58     (impl Correlate.cc:1441-1502)
 //   correlate                    legacy single-level entry, signature recovered from
 //                                src/vw/Stereo/tests/TestCorrelationView.cxx:79-82,213-215
@@ -95,6 +96,24 @@ inline void cross_corr_consistency_check(ImageView<PixelMask<Vector2i>> const& l
   detail::check(ctx, vwgpu_cross_corr_consistency_check(ctx, reinterpret_cast<int32_t*>(l2r.data()), l2r.cols(), l2r.rows(), 0,
                                                         reinterpret_cast<const int32_t*>(r2l.data()), r2l.cols(), r2l.rows(), 0,
                                                         cross_corr_threshold));
+}
+
+/// fast_box_sum<AccumulatorType>(image, kernel) — Algorithms.h:41-43.  The engine forms the sums in float64 in the
+/// reference's running-sum order (the only accumulator the reference's callers use is double, CostFunctions.h:55-57);
+/// other accumulator types receive the rounded float64 sums.
+template <class AccumulatorType, class ViewT>
+ImageView<AccumulatorType> fast_box_sum(ImageViewBase<ViewT> const& image, Vector2i const& kernel) {
+  VW_ASSERT(kernel[0] % 2 == 1 && kernel[1] % 2 == 1, ArgumentErr() << "fast_box_sum: Kernel input not sized with odd values.");
+  ImageView<PixelGray<float>> in = pixel_cast<PixelGray<float>>(image.impl());
+  VW_ASSERT(in.cols() >= kernel[0] && in.rows() >= kernel[1], ArgumentErr() << "fast_box_sum: Image is not big enough for kernel.");
+  const int32 ow = in.cols() - kernel[0] + 1, oh = in.rows() - kernel[1] + 1;
+  ImageView<double> sums(ow, oh);
+  vwgpu_ctx* ctx = detail::thread_context();
+  detail::check(ctx, vwgpu_fast_box_sum(ctx, reinterpret_cast<const float*>(in.data()), in.cols(), in.rows(), 0, kernel[0], kernel[1],
+                                        sums.data(), 0));
+  ImageView<AccumulatorType> out(ow, oh);
+  for (int32 r = 0; r < oh; ++r) for (int32 c = 0; c < ow; ++c) out(c, r) = AccumulatorType(sums(c, r));
+  return out;
 }
 
 /// Legacy correlate(): prefilter -> calc_disparity over the whole left image -> optional R->L run + L/R check.
@@ -363,14 +382,24 @@ class PyramidCorrelationView : public ImageViewBase<PyramidCorrelationView> {
   ImageViewRef<PixelGray<float>> m_left, m_right;
   ImageViewRef<uint8> m_left_mask, m_right_mask;
   vwgpu_pyramid_params m_p;
+  int m_collar_size;                                      ///< Expand the size of the image for each tile before correlating
+  ImageView<PixelMask<float>>* m_lr_disp_diff;            ///< L-R / R-L discrepancy output (CorrelationView.h:84), or NULL
+  Vector2i m_region_ul;
 public:
   typedef PixelMask<Vector2f> pixel_type;
   typedef pixel_type result_type;
-  typedef ImageView<pixel_type> prerasterize_type;
+  typedef CropView<ImageView<pixel_type>> prerasterize_type;
 
   PyramidCorrelationView(ImageViewRef<PixelGray<float>> const& left, ImageViewRef<PixelGray<float>> const& right,
-                         ImageViewRef<uint8> const& left_mask, ImageViewRef<uint8> const& right_mask, vwgpu_pyramid_params const& p)
-      : m_left(left), m_right(right), m_left_mask(left_mask), m_right_mask(right_mask), m_p(p) {
+                         ImageViewRef<uint8> const& left_mask, ImageViewRef<uint8> const& right_mask, vwgpu_pyramid_params const& p,
+                         int collar_size = 0, ImageView<PixelMask<float>>* lr_disp_diff = NULL, Vector2i const& region_ul = Vector2i(0, 0))
+      : m_left(left), m_right(right), m_left_mask(left_mask), m_right_mask(right_mask), m_p(p), m_collar_size(collar_size),
+        m_lr_disp_diff(lr_disp_diff), m_region_ul(region_ul) {
+    if (m_lr_disp_diff) {                                 // the tile threads write disjoint pixels of the caller's image
+      m_p.lr_disp_diff = reinterpret_cast<float*>(m_lr_disp_diff->data());
+      m_p.lr_disp_diff_cols = m_lr_disp_diff->cols(); m_p.lr_disp_diff_rows = m_lr_disp_diff->rows(); m_p.lr_disp_diff_stride = 0;
+      m_p.region_ul_x = region_ul[0]; m_p.region_ul_y = region_ul[1];
+    }
     VW_ASSERT(left_mask.cols() == left.cols() && left_mask.rows() == left.rows() &&
               right_mask.cols() == right.cols() && right_mask.rows() == right.rows(),
               ArgumentErr() << "PyramidCorrelationView: masks must match their images.");
@@ -426,10 +455,15 @@ public:
                                                reinterpret_cast<float*>(out.data()), 0));
     return out;
   }
-  prerasterize_type prerasterize(BBox2i const& bbox) const { return correlate_tile(bbox); }
+  /// CorrelationView.cc:876-885: the tile wrapped so that GLOBAL pixel coordinates inside bbox address it.
+  prerasterize_type prerasterize(BBox2i const& bbox) const {
+    return prerasterize_type(correlate_tile(bbox), -bbox.min().x(), -bbox.min().y(), cols(), rows());
+  }
+  /// CorrelationView.h:123-133: the tile is correlated over the collared box and its centre is kept.
   template <class DestT> void rasterize(DestT const& dest, BBox2i const& bbox) const {
-    ImageView<pixel_type> tile = correlate_tile(bbox);
-    vw::rasterize(tile, dest, BBox2i(0, 0, bbox.width(), bbox.height()));
+    BBox2i proc_bbox = bbox;
+    if (m_collar_size > 0) proc_bbox.expand(m_collar_size);
+    vw::rasterize(prerasterize(proc_bbox), dest, bbox);
   }
 };
 
@@ -444,8 +478,10 @@ inline ImageViewRef<uint8> mask_ref(ImageView<uint8> const& v) { return ImageVie
 template <class ViewT> ImageViewRef<uint8> mask_ref(ImageViewBase<ViewT> const& v) { return ImageViewRef<uint8>(pixel_cast<uint8>(v.impl())); }
 }  // namespace detail
 
-/// pyramid_correlate — the reference's argument list (CorrelationView.h:195-230).  VW_CORRELATION_BM and VW_CORRELATION_SGM;
-/// collar_size belongs to the tile rasteriser (request the collared bbox).
+/// pyramid_correlate — the reference's argument list (CorrelationView.h:195-230), verbatim; the image / mask arguments
+/// accept any view (the reference takes ImageViewRef handles, which convert from any view as well).  VW_CORRELATION_BM and
+/// VW_CORRELATION_SGM are implemented, the MGM variants answer NoImplErr when a tile is requested.  write_debug_images is
+/// accepted and ignored (the reference's debug dumps are TIFF files written next to the process).
 template <class Image1T, class Image2T, class Mask1T, class Mask2T>
 PyramidCorrelationView
 pyramid_correlate(ImageViewBase<Image1T> const& left, ImageViewBase<Image2T> const& right,
@@ -454,10 +490,13 @@ pyramid_correlate(ImageViewBase<Image1T> const& left, ImageViewBase<Image2T> con
                   BBox2i const& search_region, Vector2i const& kernel_size, CostFunctionType cost_type,
                   int corr_timeout, double seconds_per_op, float consistency_threshold, int min_consistency_level,
                   int filter_half_kernel, int32 max_pyramid_levels,
-                  CorrelationAlgorithm algorithm = VW_CORRELATION_BM, int collar_size = 0, int sgm_subpixel_mode = 5 /*SUBPIXEL_LC_BLEND*/,
-                  Vector2i sgm_search_buffer = Vector2i(2, 2), size_t memory_limit_mb = 6000, int blob_filter_area = 0) {
-  (void)collar_size;
-  vwgpu_pyramid_params p = vwgpu_pyramid_params();   // lr_disp_diff = NULL
+                  CorrelationAlgorithm algorithm = VW_CORRELATION_BM, int collar_size = 0,
+                  SemiGlobalMatcher::SgmSubpixelMode sgm_subpixel_mode = SemiGlobalMatcher::SUBPIXEL_LC_BLEND,
+                  Vector2i sgm_search_buffer = Vector2i(2, 2), size_t memory_limit_mb = 6000, int blob_filter_area = 0,
+                  ImageView<PixelMask<float>>* lr_disp_diff = NULL, Vector2i const& region_ul = Vector2i(0, 0),
+                  bool write_debug_images = false) {
+  (void)write_debug_images;
+  vwgpu_pyramid_params p = vwgpu_pyramid_params();   // lr_disp_diff is wired by the view's constructor
   p.prefilter_mode = (int)prefilter_mode; p.prefilter_width = prefilter_width;
   p.search_min_x = search_region.min().x(); p.search_min_y = search_region.min().y();
   p.search_max_x = search_region.max().x(); p.search_max_y = search_region.max().y();
@@ -466,10 +505,10 @@ pyramid_correlate(ImageViewBase<Image1T> const& left, ImageViewBase<Image2T> con
   p.consistency_threshold = consistency_threshold; p.min_consistency_level = min_consistency_level;
   p.filter_half_kernel = filter_half_kernel; p.max_pyramid_levels = max_pyramid_levels;
   p.algorithm = (int)algorithm; p.blob_filter_area = blob_filter_area;
-  p.sgm_subpixel_mode = sgm_subpixel_mode; p.sgm_search_buffer_x = sgm_search_buffer[0]; p.sgm_search_buffer_y = sgm_search_buffer[1];
+  p.sgm_subpixel_mode = (int)sgm_subpixel_mode; p.sgm_search_buffer_x = sgm_search_buffer[0]; p.sgm_search_buffer_y = sgm_search_buffer[1];
   p.memory_limit_mb = memory_limit_mb; p.sgm_num_threads = 1;
   return PyramidCorrelationView(detail::gray_float_ref(left.impl()), detail::gray_float_ref(right.impl()),
-                                detail::mask_ref(left_mask.impl()), detail::mask_ref(right_mask.impl()), p);
+                                detail::mask_ref(left_mask.impl()), detail::mask_ref(right_mask.impl()), p, collar_size, lr_disp_diff, region_ul);
 }
 
 }  // namespace stereo
