@@ -11,9 +11,14 @@ already resident in HBM, output (PixelMask<Vector2i>, 12 B/px) left in HBM.
   block matching needs no exchange step, so there is no data-path collective.  Total work is fixed:
   scaling = "strong".
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+Prints ONE JSON line on rank 0 (contract in the task statement) with three extra objects:
   roofline     HBM roofline of the hot path's kernels: algorithmic bytes / HIP-event time
-  cpu_baseline the CPU oracle (restated reference, tile-threaded like the reference) on a bounded sample
+  cpu_baseline the CPU oracle (restated reference, tile-threaded like the reference) on a bounded sample; its full-image
+               pass is also the checker of the timed result (every one of the 4090^2 pixels must be identical)
+  extra        (N = 1) the other measured points of the path, each with its algorithmic bytes, kernel time and roofline
+               fraction: the same pair at +-16 px (33 disparities: where the HBM bound is arithmetically in reach), BASELINE
+               config 3 (11x11 NCC, then parabola_subpixel) and the SGM building block of config 4 (2048^2, census 7x7,
+               129 disparities).  They are not part of `value`.
 """
 import argparse
 import json
@@ -71,12 +76,81 @@ def cpu_baseline(left, right, budget_s=12.0):
             "single_thread_ns_per_pixel_disparity": ns_per_op}
 
 
+def measure(ctx, torch, fn, reps, warm=2):
+    """Device-resident timing of fn(): (wall ms per call without profiling, {kernel: avg us per call} from HIP events)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    ctx.profile_enable(False)
+    per = {}
+    for name, ms in ctx.profile_read(1 << 14):
+        per[name] = per.get(name, 0.0) + ms
+    return wall, {k: v / reps * 1e3 for k, v in per.items()}
+
+
+def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right):
+    """The other measured points of the path (see the module docstring).  Bounded: a few dozen calls in total."""
+    out = []
+
+    def entry(name, model_bytes, model, wall, kern, hot, pixels, **kw):
+        t_hot = sum(v for k, v in kern.items() if k in hot)
+        e = {"name": name, "algorithmic_bytes": int(model_bytes), "bytes_model": model, "kernels_us": {k: round(v, 2) for k, v in kern.items()},
+             "hot_kernels": sorted(k for k in kern if k in hot), "hot_us": round(t_hot, 2), "wall_ms_per_call": round(wall, 4),
+             "Mpix_per_s": round(pixels / (wall * 1e-3) / 1e6, 1),
+             "roofline_frac": round(model_bytes / (t_hot * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if t_hot > 0 else None}
+        e.update(kw)
+        out.append(e)
+
+    bb = vwa.bounding_box(left)
+    # (1) the headline kernel at +-16 px: 33 disparities
+    r33 = rt[:, 48:48 + W + 32].contiguous()
+    wall, kern = measure(ctx, torch, lambda: stereo.calc_disparity(0, lt, r33, bb, (33, 1), KERNEL, ctx=ctx), 40)
+    entry("4096^2, 7x7 SAD, search 33x1 (+-16 px)", algorithmic_bytes(W, H, 7, 7, 33, 1), "4LW + 4RW + 12 out (SURVEY 8d)", wall, kern,
+          {"bm_sad_u8"}, (W - 6) * (H - 6), path=ctx.last_path())
+    # (2) BASELINE config 3: 11x11 NCC over 129x1, then parabola_subpixel on the result
+    wall, kern = measure(ctx, torch, lambda: stereo.calc_disparity(2, lt, rt, bb, SEARCH, (11, 11), ctx=ctx), 10)
+    entry("config 3a: 4096^2, 11x11 NCC, search 129x1", algorithmic_bytes(W, H, 11, 11, 129, 1), "4LW + 4RW + 12 out (SURVEY 8d)", wall, kern,
+          {"bm_dot_u8", "bm_dot_u8_precision", "ncc_precision_left", "ncc_precision_right"}, (W - 10) * (H - 10), path=ctx.last_path())
+    d = stereo.calc_disparity(2, lt, rt, bb, SEARCH, (11, 11), ctx=ctx)
+    disp = torch.zeros((H, W, 3), dtype=torch.float32, device=lt.device)
+    disp[5:5 + H - 10, 5:5 + W - 10, :2] = d[..., :2].float()
+    disp[5:5 + H - 10, 5:5 + W - 10, 2] = (d[..., 2] != 0).float()
+    wall, kern = measure(ctx, torch, lambda: stereo.parabola_subpixel(disp, lt, rt, 0, 0.0, (11, 11), ctx=ctx), 10)
+    pb = 4 * W * H + 4 * (W + 128) * H + 12 * W * H + 12 * W * H
+    entry("config 3b: parabola_subpixel 11x11 on the 4096^2 NCC result", pb, "4LW + 4RW + 12 disparity in + 12 out (SURVEY 8d)", wall, kern,
+          {k for k in kern if k.startswith("parabola") or k == "disparity_range"}, W * H)
+    # (3) SGM building block of config 4: 2048^2, census 7x7, 129 disparities, 8 paths, LC-blend sub-pixel
+    n = 2048
+    ls, rs_ = lt[:n, :n].contiguous(), rt[:n, :n + 128].contiguous()
+    sgm = lambda: stereo.calc_disparity_sgm(3, ls, rs_, vwa.BBox2i(0, 0, n, n), (128, 0), (7, 7), with_subpixel=True, memory_limit_mb=200000, ctx=ctx)
+    wall, kern = measure(ctx, torch, sgm, 5, warm=1)
+    npx = (n - 6) * (n - 6)
+    entry("config 4 building block: SGM 2048^2, census 7x7, 129 disparities", npx * (20 + 11 * 129),
+          "materialised volume (20 + 11 D) B/px (SURVEY 8d; the minimum model is 20 + 4 D = 536 B/px)", wall, kern,
+          {k for k in kern if k.startswith("sgm")}, npx, min_model_frac=None)
+    e = out[-1]
+    if e["hot_us"]:
+        e["min_model_frac"] = round(npx * 536 / (e["hot_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)     # 0.36 ms each: long enough to amortise the ~1.3 ms of barrier + first-launch latency
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra measured points (config 3, SGM block, +-16 px)")
     args = ap.parse_args()
 
     import torch
@@ -133,6 +207,10 @@ def main():
         r_strip = torch.from_numpy(right[ra:rb]).to(dev)
     region = vwa.BBox2i(0, 0, W, r1 - r0 + ky - 1)
     ctx = vwa.Context(local)
+    # K steps are queued back to back: the engine must not wait for the input-class flags of each call (a host round trip
+    # per step).  It runs the packed kernels, keeps the float64 kernel behind the device flag, and vwgpu_last_path() says
+    # afterwards which family produced the result — asserted below, together with the result itself.
+    ctx.set_option(core.OPT_DEFER_EXACTNESS, 1)
 
     def step():
         return stereo.calc_disparity(core.ABSOLUTE_DIFFERENCE, l_strip, r_strip, region, SEARCH, KERNEL, ctx=ctx)
@@ -167,9 +245,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    # sanity: the result of the timed work is a real disparity map
+    # sanity: the result of the timed work is a real disparity map, produced by the kernel family the line reports
     got = out[:8, :64].cpu().numpy()
     assert got.shape == (8, 64, 3) and (got[..., 0] >= 0).all() and (got[..., 0] < sx).all()
+    assert ctx.last_path() == path, "the kernel family changed during the timed region"
+    ctx.set_option(core.OPT_DEFER_EXACTNESS, 0)
 
     if rank == 0:
         per_kernel = {}
@@ -183,11 +263,13 @@ def main():
         strip_bytes = algorithmic_bytes(W, r1 - r0 + ky - 1, kx, ky, sx, sy)
         achieved = strip_bytes / (t_hot_us * 1e-6) / 1e9 if t_hot_us > 0 else 0.0
         evals = (r1 - r0) * ow * sx * sy
-        traffic = None
+        traffic = traffic_src = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tfile))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_src = "profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run" % tj.get("round", "r01")
             except Exception:
                 traffic = None
         res = {
@@ -206,7 +288,7 @@ def main():
                        "partition": "%d row strip(s), no collective in the timed region" % world, "halo": halo,
                        "path": {core.PATH_SAD_U8: "packed-u8 qsad", core.PATH_GENERIC_F64: "generic f64"}.get(path, "?")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "+".join(hot), "algorithmic_bytes_per_launch": strip_bytes,
                          "avg_us_per_launch": {k: kavg_us.get(k) for k in kavg_us},
                          "issue_bound_frac": (evals / (t_hot_us * 1e-6)) / (LANES * FCLK_HZ) if t_hot_us > 0 else None,
@@ -216,8 +298,16 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(left, right)
+            # the checker: one full-image pass of the oracle against the result of the timed work, every pixel
+            import oracle
+            want, _ = oracle.calc_disparity_tiled(0, left, right, KERNEL, SEARCH, tile=256, threads=os.cpu_count() or 1)
+            same = bool(np.array_equal(out.cpu().numpy(), want))
+            res["cpu_baseline"]["result_identical_to_oracle"] = same
+            assert same, "the timed result differs from the CPU oracle"
         else:
             res["cpu_baseline"] = None
+        if world == 1 and not args.no_extra:
+            res["extra"] = extra_points(ctx, torch, stereo, core, vwa, synth, l_strip, r_strip, left, right)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -247,26 +247,47 @@ bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__
 // ---- order-freeness of an image: lowest set bit and magnitude of its pixels ------------------------------------------
 // cell[0] = min over non-zero pixels of the exponent of the lowest set mantissa bit, cell[1] = max exponent,
 // cell[2] != 0: a non-finite pixel.  (Every pixel is an integer multiple of 2^cell[0] and smaller than 2^(cell[1]+1).)
+// One launch measures up to GRAIN_MAX images (blockIdx.y = image), GRAIN_BLOCKS workgroups each: one set of atomics per
+// WORKGROUP and few workgroups, because same-address atomics serialise at the L2.
+constexpr int GRAIN_MAX = 32, GRAIN_BLOCKS = 32;
+struct GrainJobs {
+  const float* img[GRAIN_MAX];
+  int w[GRAIN_MAX], h[GRAIN_MAX];
+  long long stride[GRAIN_MAX];
+  int* cell[GRAIN_MAX];
+};
 __global__ void __launch_bounds__(256)
-float_grain_kernel(const float* __restrict__ img, int w, int h, ptrdiff_t stride, int* __restrict__ cell) {
+float_grain_kernel(GrainJobs jobs) {
+  const int j = blockIdx.y;
+  const float* __restrict__ img = jobs.img[j];
+  const int w = jobs.w[j], h = jobs.h[j];
+  const ptrdiff_t stride = (ptrdiff_t)jobs.stride[j];
   int lo = INT_MAX, hi = INT_MIN, bad = 0;
-  for (int y = blockIdx.y; y < h; y += gridDim.y)
-    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) {
-      const unsigned u = __float_as_uint(img[(ptrdiff_t)y * stride + x]);
-      const int e = (int)((u >> 23) & 0xffu);
-      unsigned m = u & 0x7fffffu;
-      if (e == 0xff) { bad = 1; continue; }
-      if (e == 0 && m == 0) continue;                   // +-0
-      int base;
-      if (e == 0) base = -149;                          // subnormal: m * 2^-149
-      else { m |= 0x800000u; base = e - 127 - 23; }
-      lo = min(lo, base + (__ffs((int)m) - 1));
-      hi = max(hi, base + (31 - __clz((int)m)));
-    }
+  const int cols_per_row = (w + 255) / 256;                     // column chunks of 256 pixels
+  const long long nchunks = (long long)cols_per_row * h;
+  for (long long c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int y = (int)(c / cols_per_row), x = (int)(c % cols_per_row) * 256 + threadIdx.x;
+    if (x >= w) continue;
+    const unsigned u = __float_as_uint(img[(ptrdiff_t)y * stride + x]);
+    const int e = (int)((u >> 23) & 0xffu);
+    unsigned m = u & 0x7fffffu;
+    if (e == 0xff) { bad = 1; continue; }
+    if (e == 0 && m == 0) continue;                             // +-0
+    int base;
+    if (e == 0) base = -149;                                    // subnormal: m * 2^-149
+    else { m |= 0x800000u; base = e - 127 - 23; }
+    lo = min(lo, base + (__ffs((int)m) - 1));
+    hi = max(hi, base + (31 - __clz((int)m)));
+  }
   for (int o = 32; o > 0; o >>= 1) {
     lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); bad |= __shfl_xor(bad, o);
   }
-  if ((threadIdx.x & 63) == 0) {
+  __shared__ int part[4][3];
+  if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = lo; part[threadIdx.x >> 6][1] = hi; part[threadIdx.x >> 6][2] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; ++i) { lo = min(lo, part[i][0]); hi = max(hi, part[i][1]); bad |= part[i][2]; }
+    int* cell = jobs.cell[j];
     if (lo != INT_MAX) { atomicMin(&cell[0], lo); atomicMax(&cell[1], hi); }
     if (bad) atomicOr(&cell[2], 1);
   }
@@ -382,6 +403,23 @@ bool vwgpu_sums_order_free(int cost_type, int kx, int ky, int lo, int hi, int no
   return bits <= 53;
 }
 
+// Measures images[i] into d_cells[i] (3 ints each, initialised by the caller with {INT_MAX, INT_MIN, 0}); several images may
+// share a cell.  Asynchronous.
+void vwgpu_launch_float_grain(vwgpu_ctx* ctx, int n, const float* const* img, const int* w, const int* h, const ptrdiff_t* stride, int* const* d_cells) {
+  for (int i0 = 0; i0 < n; i0 += GRAIN_MAX) {
+    GrainJobs jobs;
+    int m = 0;
+    for (int i = i0; i < n && m < GRAIN_MAX; ++i) {
+      if (!img[i] || w[i] <= 0 || h[i] <= 0) continue;
+      jobs.img[m] = img[i]; jobs.w[m] = w[i]; jobs.h[m] = h[i]; jobs.stride[m] = stride[i]; jobs.cell[m] = d_cells[i];
+      ++m;
+    }
+    if (m == 0) continue;
+    vwgpu_prof_scope ps(ctx, "float_grain");
+    hipLaunchKernelGGL(float_grain_kernel, dim3(GRAIN_BLOCKS, (unsigned)m), dim3(256), 0, ctx->stream, jobs);
+  }
+}
+
 // Measures (lo, hi, nonfinite) over up to two images.  Synchronises the stream.
 int vwgpu_float_grain(vwgpu_ctx* ctx, const float* a, int aw, int ah, ptrdiff_t as, const float* b, int bw, int bh, ptrdiff_t bs,
                       int* lo, int* hi, int* nonfinite) {
@@ -390,28 +428,16 @@ int vwgpu_float_grain(vwgpu_ctx* ctx, const float* a, int aw, int ah, ptrdiff_t 
   int* cell = static_cast<int*>(ctx->misc.base) + 16;
   const int init[3] = {INT_MAX, INT_MIN, 0};
   VWGPU_HIP(ctx, hipMemcpyAsync(cell, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-  {
-    vwgpu_prof_scope ps(ctx, "float_grain");
-    if (a && aw > 0 && ah > 0)
-      hipLaunchKernelGGL(float_grain_kernel, dim3((unsigned)std::min((aw + 255) / 256, 16), (unsigned)std::min(ah, 512)), dim3(256), 0,
-                         ctx->stream, a, aw, ah, as, cell);
-    if (b && bw > 0 && bh > 0)
-      hipLaunchKernelGGL(float_grain_kernel, dim3((unsigned)std::min((bw + 255) / 256, 16), (unsigned)std::min(bh, 512)), dim3(256), 0,
-                         ctx->stream, b, bw, bh, bs, cell);
-  }
+  const float* imgs[2] = {a, b};
+  const int ws[2] = {aw, bw}, hs[2] = {ah, bh};
+  const ptrdiff_t ss[2] = {as, bs};
+  int* cells[2] = {cell, cell};
+  vwgpu_launch_float_grain(ctx, 2, imgs, ws, hs, ss, cells);
   int got[3];
   VWGPU_HIP(ctx, hipMemcpyAsync(got, cell, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
   VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *lo = got[0]; *hi = got[1]; *nonfinite = got[2];
   return VWGPU_OK;
-}
-
-// Same, asynchronous: (lo, hi, nonfinite) of image pair i land in d_cells[3*i ..]; cells must have been initialised
-// with {INT_MAX, INT_MIN, 0}.
-void vwgpu_launch_float_grain(vwgpu_ctx* ctx, const float* a, int aw, int ah, ptrdiff_t as, int* d_cell) {
-  if (!a || aw <= 0 || ah <= 0) return;
-  hipLaunchKernelGGL(float_grain_kernel, dim3((unsigned)std::min((aw + 255) / 256, 16), (unsigned)std::min(ah, 512)), dim3(256), 0,
-                     ctx->stream, a, aw, ah, as, d_cell);
 }
 
 // One group of zones (its column-sum volumes fit the scratch budget, or it is a single zone swept in row bands).

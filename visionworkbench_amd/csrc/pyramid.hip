@@ -524,11 +524,10 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     for (int i = 0; i <= L; ++i) { cells[4 * i] = INT_MAX; cells[4 * i + 1] = INT_MIN; cells[4 * i + 2] = 0; cells[4 * i + 3] = 0; }
     VWGPU_HIP(ctx, hipMemcpyAsync(d_cells, cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice, st));
     {
-      vwgpu_prof_scope ps(ctx, "float_grain");
-      for (int i = 0; i <= L; ++i) {
-        vwgpu_launch_float_grain(ctx, lp[i].p, lp[i].w, lp[i].h, lp[i].w, d_cells + 4 * i);
-        vwgpu_launch_float_grain(ctx, rp[i].p, rp[i].w, rp[i].h, rp[i].w, d_cells + 4 * i);
-      }
+      std::vector<const float*> gi; std::vector<int> gw, gh; std::vector<ptrdiff_t> gs; std::vector<int*> gc;
+      for (int i = 0; i <= L; ++i)
+        for (DevImg const* im : {&lp[i], &rp[i]}) { gi.push_back(im->p); gw.push_back(im->w); gh.push_back(im->h); gs.push_back(im->w); gc.push_back(d_cells + 4 * i); }
+      vwgpu_launch_float_grain(ctx, (int)gi.size(), gi.data(), gw.data(), gh.data(), gs.data(), gc.data());
     }
     VWGPU_HIP(ctx, hipMemcpyAsync(cells.data(), d_cells, cells.size() * sizeof(int), hipMemcpyDeviceToHost, st));
     VWGPU_HIP(ctx, hipStreamSynchronize(st));

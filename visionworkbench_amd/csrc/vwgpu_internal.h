@@ -114,7 +114,7 @@ bool vwgpu_bm_exact_supported(int sx, int sy);
 bool vwgpu_sums_order_free(int cost_type, int kx, int ky, int lo, int hi, int nonfinite);
 int vwgpu_float_grain(vwgpu_ctx* ctx, const float* a, int aw, int ah, ptrdiff_t as, const float* b, int bw, int bh, ptrdiff_t bs,
                       int* lo, int* hi, int* nonfinite);
-void vwgpu_launch_float_grain(vwgpu_ctx* ctx, const float* a, int aw, int ah, ptrdiff_t as, int* d_cell);
+void vwgpu_launch_float_grain(vwgpu_ctx* ctx, int n, const float* const* img, const int* w, const int* h, const ptrdiff_t* stride, int* const* d_cells);
 int vwgpu_launch_bm_exact(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, ptrdiff_t as,
                           const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky,
                           const vwgpu_zone_task* zones, int n, int32_t* out);
