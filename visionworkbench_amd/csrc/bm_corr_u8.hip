@@ -1,0 +1,434 @@
+// bm_corr_u8.hip — SSD and NCC block matching for integer-valued imagery in [0,255], register-blocked.
+//
+// Replaces best_of_search_convolution + fast_box_sum + SquaredCost / NCCCost (src/vw/Stereo/Correlation.cc:33-137,
+// src/vw/Stereo/Algorithms.h:43-129, src/vw/Stereo/CostFunctions.h:94-141,179-236) on the domain of the packed SAD path:
+// there every quantity the reference accumulates in float64 is an exactly representable integer,
+//     S(x,y,d) = sum_window L * R,   A2(x,y) = sum_window L^2,   B2(x,y) = sum_window R^2,
+//     SSD cost = A2(x,y) + B2(x+d,y) - 2 S                               compared as integers,
+//     NCC cost = double(S) * sqrt((1.0 / A2(x,y)) * (1.0 / B2(x+d,y)))   the reference's float64 sequence, maximised.
+//
+//   mapping   lane <-> one output column, TY output rows; workgroup = 4 waves = 256 columns x TY rows.
+//   products  the lane's LEFT window words (kx bytes per row, all TY+ky-1 rows) stay in registers; the RIGHT words come
+//             from an LDS array holding the 32-bit word at EVERY byte offset of the staged rows (consecutive lanes read
+//             consecutive dwords: conflict free), so one disparity step is a chain of v_dot4_u32_u8 down the rows whose
+//             accumulator is the vertical prefix sum; the ky-row window sum is P[r] - P[r-ky].
+//   SSD       the lane folds B2 (from an LDS table, one read per evaluation) and the disparity index into one 32-bit key
+//             ((B2 + A2max - 2S) << 8 | d: SSD >= 0 bounds the field to 24 bits for kx*ky <= 129) and keeps min / max keys
+//             with v_min3 / v_max3 over disparity pairs; valid <=> min cost != max cost (Correlation.cc:121-133).
+//   NCC       the float64 score is needed only where it can decide: sweep 1 maximises an fp32 score S * fl32(1/sqrt(B2))
+//             (relative error < 2^-22), sweep 2 re-walks the disparities and records the candidates within 2^-20 of that
+//             maximum (almost always one), and ncc_resolve_kernel evaluates the reference's float64 sequence for those
+//             candidates in disparity order (strict compare, first wins).  Pixels whose scores all lie inside the margin
+//             (flat patches: validity undecidable in fp32) and pixels with more than four candidates are evaluated in full
+//             by the resolve kernel, verbatim (Correlation.cc:91-133).
+// Inputs that are not integers in [0,255], or an all-zero window under NCC (1/0), raise the device flag and the float64
+// kernel recomputes the image (the protocol of bm_sad_u8.hip).  One search row (sy == 1).
+//
+// Roofline: HBM bound by the task's definition (20 B per output pixel), VALU-issue bound in fact: per evaluation
+// (TY + ky - 1) / TY * ceil(kx / 4) dot4 + 4 ops (SSD) or + 4 ops per sweep (NCC).
+#include <algorithm>
+#include <cmath>
+
+#include "vwgpu_internal.h"
+#include "u8_tile.h"
+
+namespace {
+
+using namespace vwgpu_u8;
+typedef uint64_t u64;
+
+constexpr int CTW = 256;          // output columns per workgroup (lane = column)
+constexpr int CTHREADS = 256;
+constexpr int NCC_SLOTS = 4;      // candidate slots per pixel
+constexpr unsigned NCC_FULL = 255u;   // candidate count meaning "evaluate every disparity"
+
+struct CorrGeom {
+  int sx;
+  int nbx;       // right window origins per row = CTW + sx - 1
+  int rwd;       // aligned dwords per staged right row
+  int urp;       // dwords per row of the every-byte word array
+};
+
+__device__ __forceinline__ u32 umin3(u32 a, u32 b, u32 c) { u32 r; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ u32 umax3(u32 a, u32 b, u32 c) { u32 r; asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float fmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float fmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+template <int COST, int KX, int KY, int TY>
+__global__ void __launch_bounds__(CTHREADS, 2)
+bm_corr_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
+                  const float* __restrict__ R, ptrdiff_t rs, int rcw, int rch, CorrGeom g,
+                  int32_t* __restrict__ out, ptrdiff_t os, int ow, int oh,
+                  int* __restrict__ flag_set, int* __restrict__ flag_clear,
+                  u32* __restrict__ a2img, u32* __restrict__ b2img, int b2w,
+                  u32* __restrict__ cand, uint8_t* __restrict__ cnt_img) {
+  constexpr bool NCC = (COST == VWGPU_CROSS_CORRELATION);
+  constexpr int NW = (KX + 3) / 4, NR = TY + KY - 1;
+  constexpr int LWD = CTW / 4 + NW + 1;                         // aligned dwords per staged left row
+  constexpr u32 KMASK = (KX % 4 == 0) ? 0xffffffffu : ((1u << (8 * (KX % 4))) - 1u);
+  constexpr u32 OFFK = (u32)KX * KY * 65025u;                   // >= A2: SSD >= 0  =>  B2 - 2S + OFFK >= 0
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  const int sx = g.sx, nbx = g.nbx, RWD = g.rwd, URP = g.urp;
+  u32* UR = lds;                                                 // [NR][URP]  word at every byte offset of the right rows
+  u32* XR = UR + (size_t)NR * URP;                               // [NR][RWD] aligned right words, then [TY][nbx] B2 table
+  const size_t xr_dw = (size_t)NR * RWD > (size_t)TY * nbx ? (size_t)NR * RWD : (size_t)TY * nbx;
+  u32* LW = XR + xr_dw;                                          // [NR][LWD] aligned left words
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * CTW, y0 = blockIdx.y * TY;
+  const int x = x0 + tid;
+  if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) *flag_clear = 0;     // the NEXT call's flag
+
+  // ---- stage both tiles as packed u8 (checks the domain) ----
+  u32 bad_acc = 0;
+  stage_u8_rows<NR>(L, ls, lw, lh, x0, y0, LWD, LWD, LW, tid, CTHREADS, bad_acc);
+  stage_u8_rows<NR>(R, rs, rcw, rch, x0, y0, RWD, RWD, XR, tid, CTHREADS, bad_acc);
+  __syncthreads();
+
+  // ---- LEFT window words of this lane's column; NCC: A2 of its TY pixels ----
+  u32 lwn[NR][NW];
+  {
+    const int w0 = tid >> 2, sh = tid & 3;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      u32 a[NW + 1];
+#pragma unroll
+      for (int n = 0; n <= NW; ++n) a[n] = LW[r * LWD + w0 + n];
+#pragma unroll
+      for (int n = 0; n < NW; ++n) lwn[r][n] = __builtin_amdgcn_alignbyte(a[n + 1], a[n], sh);
+      lwn[r][NW - 1] &= KMASK;
+    }
+  }
+  bool zero_window = false;
+  if (NCC) {
+    u32 h[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      u32 s = 0;
+#pragma unroll
+      for (int n = 0; n < NW; ++n) s = __builtin_amdgcn_udot4(lwn[r][n], lwn[r][n], s, false);
+      h[r] = s;
+    }
+    u32 a2 = 0;
+#pragma unroll
+    for (int r = 0; r < KY - 1; ++r) a2 += h[r];
+#pragma unroll
+    for (int y = 0; y < TY; ++y) {
+      a2 += h[y + KY - 1];
+      if (x < ow && y0 + y < oh) { a2img[(size_t)(y0 + y) * ow + x] = a2; zero_window |= (a2 == 0); }
+      a2 -= h[y];
+    }
+  }
+  // ---- every-byte word array of the right rows ----
+  for (int i = tid; i < NR * URP; i += CTHREADS) {
+    const int r = i / URP, b = i - r * URP, w = b >> 2;
+    UR[i] = __builtin_amdgcn_alignbyte(XR[r * RWD + w + 1], XR[r * RWD + w], b & 3);
+  }
+  __syncthreads();                                               // UR complete, aligned right words dead
+  // ---- B2 table over [TY][nbx]: SSD key part (B2 + OFFK) << 8, NCC fp32 1/sqrt(B2) ----
+  u32* B2K = XR;
+  for (int xp = tid; xp < nbx; xp += CTHREADS) {
+    u32 h[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      u32 s = 0;
+#pragma unroll
+      for (int n = 0; n < NW; ++n) {
+        u32 v = UR[r * URP + xp + 4 * n];
+        if (n == NW - 1) v &= KMASK;
+        s = __builtin_amdgcn_udot4(v, v, s, false);
+      }
+      h[r] = s;
+    }
+    u32 b2 = 0;
+#pragma unroll
+    for (int r = 0; r < KY - 1; ++r) b2 += h[r];
+#pragma unroll
+    for (int y = 0; y < TY; ++y) {
+      b2 += h[y + KY - 1];
+      if (NCC) {
+        B2K[y * nbx + xp] = __float_as_uint((float)(1.0 / sqrt((double)b2)));
+        const bool inside = (x0 + xp < rcw - KX + 1) && (y0 + y < rch - KY + 1);
+        if (inside) { b2img[(size_t)(y0 + y) * b2w + x0 + xp] = b2; zero_window |= (b2 == 0); }
+      } else {
+        B2K[y * nbx + xp] = (b2 + OFFK) << 8;
+      }
+      b2 -= h[y];
+    }
+  }
+  __syncthreads();
+
+  // ---- disparity sweeps ----
+  const u32* ur0 = UR + tid;
+  const u32* bk0 = B2K + tid;
+  // One pair of disparities (d, e): dot4 chains down the rows, window sums by prefix difference.  FN(y, sd, se) consumes them.
+  auto chain = [&](int d, int e, auto&& fn) __attribute__((always_inline)) {
+    u32 pa[NR], pb[NR];
+    u32 accA = 0, accB = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+#pragma unroll
+      for (int n = 0; n < NW; ++n) {
+        accA = __builtin_amdgcn_udot4(lwn[r][n], ur0[r * URP + d + 4 * n], accA, false);
+        accB = __builtin_amdgcn_udot4(lwn[r][n], ur0[r * URP + e + 4 * n], accB, false);
+      }
+      pa[r] = accA; pb[r] = accB;
+      if (r >= KY - 1) {
+        const int y = r - (KY - 1);
+        const u32 sa = r >= KY ? pa[r] - pa[r - KY] : pa[r];
+        const u32 sb = r >= KY ? pb[r] - pb[r - KY] : pb[r];
+        fn(y, sa, sb);
+      }
+    }
+  };
+
+  if (!NCC) {
+    u32 K[TY], Wk[TY];
+#pragma unroll
+    for (int y = 0; y < TY; ++y) { K[y] = 0xffffffffu; Wk[y] = 0u; }
+    for (int d = 0; d < sx; d += 2) {
+      const int e = d + 1 < sx ? d + 1 : d;                      // an odd tail evaluates its last disparity twice: harmless
+      chain(d, e, [&](int y, u32 sa, u32 sb) __attribute__((always_inline)) {
+        const u32 ka = bk0[y * nbx + d] + (u32)d - (sa << 9);    // ((B2 + OFFK - 2 S) << 8) | d
+        const u32 kb = bk0[y * nbx + e] + (u32)e - (sb << 9);
+        K[y] = umin3(K[y], ka, kb);
+        Wk[y] = umax3(Wk[y], ka, kb);
+      });
+    }
+    if (x < ow) {
+#pragma unroll
+      for (int y = 0; y < TY; ++y) {
+        if (y0 + y < oh) {
+          int32_t* o = out + ((ptrdiff_t)(y0 + y) * os + x) * 3;
+          o[0] = (int32_t)(K[y] & 0xffu); o[1] = 0;
+          o[2] = ((K[y] >> 8) == (Wk[y] >> 8)) ? 0 : 0x7fffffff;   // best == worst (Correlation.cc:121-133)
+        }
+      }
+    }
+  } else {
+    float M[TY], Mn[TY];
+#pragma unroll
+    for (int y = 0; y < TY; ++y) { M[y] = 0.0f; Mn[y] = INFINITY; }
+    for (int d = 0; d < sx; d += 2) {                            // sweep 1: fp32 maximum / minimum of the score
+      const int e = d + 1 < sx ? d + 1 : d;
+      chain(d, e, [&](int y, u32 sa, u32 sb) __attribute__((always_inline)) {
+        const float va = (float)sa * __uint_as_float(bk0[y * nbx + d]);
+        const float vb = (float)sb * __uint_as_float(bk0[y * nbx + e]);
+        M[y] = fmax3(M[y], va, vb);
+        Mn[y] = fmin3(Mn[y], va, vb);
+      });
+    }
+    u64 cnt = 0;                                                  // 4 bits per row: candidates recorded so far
+    u32 undecided = 0;
+#pragma unroll
+    for (int y = 0; y < TY; ++y) {
+      const float thr = M[y] * 0.99999905f;                       // 1 - 2^-20: the fp32 score is good to 2^-22
+      if (Mn[y] >= thr) undecided |= 1u << y;                     // every score inside the margin: resolve in full
+      M[y] = thr;
+    }
+    const bool col_ok = x < ow;
+    for (int d = 0; d < sx; d += 2) {                            // sweep 2: the candidates, in disparity order
+      const int e = d + 1 < sx ? d + 1 : d;
+      chain(d, e, [&](int y, u32 sa, u32 sb) __attribute__((always_inline)) {
+        const float va = (float)sa * __uint_as_float(bk0[y * nbx + d]);
+        const float vb = (float)sb * __uint_as_float(bk0[y * nbx + e]);
+        const bool ca = va >= M[y], cb = (vb >= M[y]) && (e != d);
+        if (__any((ca || cb) && col_ok && (y0 + y < oh))) {
+          if (col_ok && y0 + y < oh) {
+            u32* slot = cand + ((size_t)(y0 + y) * ow + x) * NCC_SLOTS;
+            u32 c = (u32)(cnt >> (4 * y)) & 15u;
+            if (ca) { if (c < NCC_SLOTS) slot[c] = (u32)d | (sa << 8); if (c < 15u) ++c; }
+            if (cb) { if (c < NCC_SLOTS) slot[c] = (u32)e | (sb << 8); if (c < 15u) ++c; }
+            cnt = (cnt & ~((u64)15 << (4 * y))) | ((u64)c << (4 * y));
+          }
+        }
+      });
+    }
+    if (col_ok) {
+#pragma unroll
+      for (int y = 0; y < TY; ++y) {
+        if (y0 + y < oh) {
+          const u32 c = (u32)(cnt >> (4 * y)) & 15u;
+          cnt_img[(size_t)(y0 + y) * ow + x] = (uint8_t)(((undecided >> y) & 1u) || c > NCC_SLOTS || c == 0 ? NCC_FULL : c);
+        }
+      }
+    }
+  }
+  if (bad_acc != 0u || zero_window) atomicOr(flag_set, 1);
+}
+
+// NCC: the reference's float64 score for the recorded candidates (Correlation.cc:91-133 reduces to "maximum, first wins" on
+// them); pixels that need every disparity are queued for ncc_full_kernel.
+__global__ void __launch_bounds__(256)
+ncc_resolve_kernel(int sx, const u32* __restrict__ a2img, const u32* __restrict__ b2img, int b2w,
+                   const u32* __restrict__ cand, const uint8_t* __restrict__ cnt_img,
+                   int32_t* __restrict__ out, ptrdiff_t os, int ow, int oh, const int* __restrict__ flag,
+                   u32* __restrict__ full_list, u32* __restrict__ full_count, u32 cap) {
+  if (*flag) return;                                              // the float64 kernel recomputes the image
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= ow || y >= oh) return;
+  const size_t p = (size_t)y * ow + x;
+  const unsigned n = cnt_img[p];
+  if (n == NCC_FULL) {
+    const u32 i = atomicAdd(full_count, 1u);
+    if (i < cap) full_list[i] = (u32)p;
+    return;
+  }
+  const double pl = 1.0 / (double)a2img[p];                       // NCCCost ctor, CostFunctions.h:214-219
+  double best = 0.0;
+  int bd = 0;
+  for (unsigned i = 0; i < n; ++i) {                              // candidates are stored in disparity order
+    const u32 c = cand[p * NCC_SLOTS + i];
+    const int d = (int)(c & 0xffu);
+    const double pr = 1.0 / (double)b2img[(size_t)y * b2w + x + d];
+    const double v = (double)(c >> 8) * sqrt(pl * pr);            // cost_modification, :227-231
+    if (i == 0 || v > best) { best = v; bd = d; }
+  }
+  int32_t* o = out + ((ptrdiff_t)y * os + x) * 3;
+  o[0] = bd; o[1] = 0; o[2] = 0x7fffffff;                         // decided by the sweeps: minimum != maximum
+}
+
+// NCC, every disparity of the queued pixels: one wave per pixel, lane <-> disparity.  More queued pixels than `cap`
+// (a largely flat image) raise the device flag instead: the float64 kernel then recomputes the image.
+__global__ void __launch_bounds__(256)
+ncc_full_kernel(const float* __restrict__ L, ptrdiff_t ls, const float* __restrict__ R, ptrdiff_t rs, int kx, int ky, int sx,
+                const u32* __restrict__ a2img, const u32* __restrict__ b2img, int b2w,
+                int32_t* __restrict__ out, ptrdiff_t os, int ow, int* __restrict__ flag,
+                const u32* __restrict__ full_list, const u32* __restrict__ full_count, u32 cap) {
+  if (*flag) return;
+  const u32 total = *full_count;
+  if (total > cap) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flag, 1);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const u32 nwaves = gridDim.x * 4u;
+  for (u32 e = blockIdx.x * 4u + (threadIdx.x >> 6); e < total; e += nwaves) {
+    const u32 p = full_list[e];
+    const int y = (int)(p / (u32)ow), x = (int)(p - (u32)y * (u32)ow);
+    const double pl = 1.0 / (double)a2img[p];
+    double best = 0.0, worst = 0.0;
+    int bd = 0;
+    for (int d0 = 0; d0 < sx; d0 += 64) {
+      const int d = d0 + lane;
+      const bool act = d < sx;
+      u32 S = 0;
+      if (act)
+        for (int j = 0; j < ky; ++j) {
+          const float* lp = L + (ptrdiff_t)(y + j) * ls + x;
+          const float* rp = R + (ptrdiff_t)(y + j) * rs + x + d;
+          for (int i = 0; i < kx; ++i) S += (u32)lp[i] * (u32)rp[i];
+        }
+      double v = act ? (double)S * sqrt(pl * (1.0 / (double)b2img[(size_t)y * b2w + x + d])) : -1.0;   // scores are >= 0
+      double w = act ? v : INFINITY;
+      int vd = act ? d : 0x7fffffff;
+      for (int o = 32; o > 0; o >>= 1) {                          // (maximum, smallest index) and minimum across the lanes
+        const double ov = __shfl_xor(v, o), owv = __shfl_xor(w, o);
+        const int od = __shfl_xor(vd, o);
+        if (ov > v || (ov == v && od < vd)) { v = ov; vd = od; }
+        if (owv < w) w = owv;
+      }
+      if (d0 == 0) { best = v; bd = vd; worst = w; }
+      else { if (v > best) { best = v; bd = vd; } if (w < worst) worst = w; }
+    }
+    if (lane == 0) {
+      int32_t* o = out + ((ptrdiff_t)y * os + x) * 3;
+      o[0] = bd; o[1] = 0; o[2] = (best == worst) ? 0 : 0x7fffffff;   // Correlation.cc:121-133
+    }
+  }
+}
+
+typedef void (*CorrFn)(const float*, ptrdiff_t, int, int, const float*, ptrdiff_t, int, int, CorrGeom, int32_t*, ptrdiff_t, int, int, int*, int*,
+                       u32*, u32*, int, u32*, uint8_t*);
+struct CorrLaunch { int cost, kx, ky, ty; CorrFn fn; };
+#define VW_CORR(C, KX, KY, TY) CorrLaunch{C, KX, KY, TY, bm_corr_u8_kernel<C, KX, KY, TY>}
+const CorrLaunch kCorr[] = {
+    VW_CORR(VWGPU_SQUARED_DIFFERENCE, 3, 3, 16), VW_CORR(VWGPU_SQUARED_DIFFERENCE, 5, 5, 16), VW_CORR(VWGPU_SQUARED_DIFFERENCE, 7, 7, 16),
+    VW_CORR(VWGPU_SQUARED_DIFFERENCE, 9, 9, 16), VW_CORR(VWGPU_SQUARED_DIFFERENCE, 11, 11, 16),
+    VW_CORR(VWGPU_CROSS_CORRELATION, 3, 3, 16), VW_CORR(VWGPU_CROSS_CORRELATION, 5, 5, 16), VW_CORR(VWGPU_CROSS_CORRELATION, 7, 7, 16),
+    VW_CORR(VWGPU_CROSS_CORRELATION, 9, 9, 16), VW_CORR(VWGPU_CROSS_CORRELATION, 11, 11, 16),
+};
+#undef VW_CORR
+
+const CorrLaunch* find_corr(int cost, int kx, int ky) {
+  for (const CorrLaunch& l : kCorr)
+    if (l.cost == cost && l.kx == kx && l.ky == ky) return &l;
+  return nullptr;
+}
+
+CorrGeom corr_geom(int kx, int sx) {
+  CorrGeom g;
+  const int nw = (kx + 3) / 4;
+  g.sx = sx;
+  g.nbx = CTW + sx - 1;
+  g.urp = g.nbx + 4 * nw;
+  g.rwd = (g.urp + 3) / 4 + 1;
+  return g;
+}
+
+size_t corr_lds_bytes(const CorrLaunch& l, const CorrGeom& g) {
+  const int nw = (l.kx + 3) / 4, nr = l.ty + l.ky - 1;
+  const size_t xr = std::max((size_t)nr * g.rwd, (size_t)l.ty * g.nbx);
+  return ((size_t)nr * g.urp + xr + (size_t)nr * (CTW / 4 + nw + 1)) * sizeof(u32);
+}
+
+}  // namespace
+
+bool vwgpu_bm_corr_u8_supported(int cost_type, int kx, int ky, int sx, int sy) {
+  const CorrLaunch* l = find_corr(cost_type, kx, ky);
+  if (!l || sy != 1 || sx > 256) return false;
+  return corr_lds_bytes(*l, corr_geom(kx, sx)) <= 80 * 1024;     // two workgroups per CU
+}
+
+int vwgpu_launch_bm_corr_u8(vwgpu_ctx* ctx, int cost_type, const float* left, int lw, int lh, ptrdiff_t ls,
+                            const float* right, int rw, int rh, ptrdiff_t rs, int kx, int ky, int sx, int sy,
+                            int32_t* out, ptrdiff_t os, int** d_fallback_flag) {
+  (void)rw; (void)rh; (void)sy;
+  const CorrLaunch* l = find_corr(cost_type, kx, ky);
+  if (!l) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "no register-blocked SSD / NCC kernel for %dx%d", kx, ky);
+  const int ow = lw - kx + 1, oh = lh - ky + 1;
+  const int rcw = lw + sx - 1, rch = lh;
+  const CorrGeom g = corr_geom(kx, sx);
+  int* flag_set = nullptr; int* flag_clear = nullptr;
+  int rc = vwgpu_next_flags(ctx, 0, &flag_set, &flag_clear, nullptr);
+  if (rc) return rc;
+  *d_fallback_flag = flag_set;
+  const bool ncc = cost_type == VWGPU_CROSS_CORRELATION;
+  u32 *a2 = nullptr, *b2 = nullptr, *cand = nullptr, *full_list = nullptr, *full_count = nullptr;
+  uint8_t* cnt = nullptr;
+  const int b2w = rcw - kx + 1;
+  // pixels evaluated over every disparity by ncc_full_kernel: at most ~3 % of the image, beyond that the float64 kernel is faster
+  const u32 cap = (u32)std::max<size_t>(4096, (size_t)ow * oh / 32);
+  if (ncc) {
+    if ((size_t)ow * oh >= 0xffffffffull) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "bm_corr_u8: image too large");
+    const size_t na = vwgpu_align_up((size_t)ow * oh * 4, 256), nb = vwgpu_align_up((size_t)b2w * oh * 4, 256),
+                 nc = vwgpu_align_up((size_t)ow * oh * NCC_SLOTS * 4, 256), nn = vwgpu_align_up((size_t)ow * oh, 256),
+                 nl = vwgpu_align_up((size_t)cap * 4 + 256, 256);
+    rc = vwgpu_arena_reserve(ctx, &ctx->scratch, na + nb + nc + nn + nl);
+    if (rc) return rc;
+    char* base = static_cast<char*>(ctx->scratch.base);
+    a2 = reinterpret_cast<u32*>(base); b2 = reinterpret_cast<u32*>(base + na);
+    cand = reinterpret_cast<u32*>(base + na + nb); cnt = reinterpret_cast<uint8_t*>(base + na + nb + nc);
+    full_count = reinterpret_cast<u32*>(base + na + nb + nc + nn); full_list = full_count + 64;
+    VWGPU_HIP(ctx, hipMemsetAsync(full_count, 0, 4, ctx->stream));
+  }
+  const size_t shmem = corr_lds_bytes(*l, g);
+  if (shmem > 64 * 1024)
+    VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(l->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  {
+    vwgpu_prof_scope ps(ctx, "bm_corr_u8");
+    hipLaunchKernelGGL(l->fn, dim3((ow + CTW - 1) / CTW, (oh + l->ty - 1) / l->ty), dim3(CTHREADS), shmem, ctx->stream,
+                       left, ls, lw, lh, right, rs, rcw, rch, g, out, os, ow, oh, flag_set, flag_clear, a2, b2, b2w, cand, cnt);
+  }
+  if (ncc) {
+    {
+      vwgpu_prof_scope ps(ctx, "ncc_resolve");
+      hipLaunchKernelGGL(ncc_resolve_kernel, dim3((ow + 63) / 64, (oh + 3) / 4), dim3(256), 0, ctx->stream,
+                         sx, a2, b2, b2w, cand, cnt, out, os, ow, oh, flag_set, full_list, full_count, cap);
+    }
+    vwgpu_prof_scope ps(ctx, "ncc_full");
+    hipLaunchKernelGGL(ncc_full_kernel, dim3(2048), dim3(256), 0, ctx->stream, left, ls, right, rs, kx, ky, sx, a2, b2, b2w,
+                       out, os, ow, flag_set, full_list, full_count, cap);
+  }
+  VWGPU_HIP(ctx, hipGetLastError());
+  return VWGPU_OK;
+}

@@ -265,19 +265,30 @@ float_grain_kernel(GrainJobs jobs) {
   int lo = INT_MAX, hi = INT_MIN, bad = 0;
   const int cols_per_row = (w + 255) / 256;                     // column chunks of 256 pixels
   const long long nchunks = (long long)cols_per_row * h;
-  for (long long c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    const int y = (int)(c / cols_per_row), x = (int)(c % cols_per_row) * 256 + threadIdx.x;
-    if (x >= w) continue;
-    const unsigned u = __float_as_uint(img[(ptrdiff_t)y * stride + x]);
+  auto take = [&](unsigned u) __attribute__((always_inline)) {
     const int e = (int)((u >> 23) & 0xffu);
     unsigned m = u & 0x7fffffu;
-    if (e == 0xff) { bad = 1; continue; }
-    if (e == 0 && m == 0) continue;                             // +-0
+    if (e == 0xff) { bad = 1; return; }
+    if (e == 0 && m == 0) return;                               // +-0
     int base;
     if (e == 0) base = -149;                                    // subnormal: m * 2^-149
     else { m |= 0x800000u; base = e - 127 - 23; }
     lo = min(lo, base + (__ffs((int)m) - 1));
     hi = max(hi, base + (31 - __clz((int)m)));
+  };
+  // eight loads in flight per thread (out-of-range chunks read pixel 0 of the image, which is harmless to count twice)
+  for (long long c0 = blockIdx.x; c0 < nchunks; c0 += 8LL * gridDim.x) {
+    unsigned u[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const long long c = c0 + (long long)k * gridDim.x;
+      const int y = c < nchunks ? (int)(c / cols_per_row) : 0;
+      int x = c < nchunks ? (int)(c % cols_per_row) * 256 + (int)threadIdx.x : 0;
+      if (x >= w) x = 0;
+      u[k] = __float_as_uint(img[(ptrdiff_t)y * stride + x]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) take(u[k]);
   }
   for (int o = 32; o > 0; o >>= 1) {
     lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); bad |= __shfl_xor(bad, o);

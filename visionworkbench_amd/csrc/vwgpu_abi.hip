@@ -1,5 +1,6 @@
 // vwgpu_abi.hip — extern "C" entry points of libvwgpu.so (declared in include/vwgpu.h).
 // Argument validation, path dispatch, host staging, error text.  No kernels here.
+#include <cstdlib>
 #include <cstring>
 
 #include "vwgpu_internal.h"
@@ -276,7 +277,8 @@ int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
   if (os > INT32_MAX) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity: output stride too large");
 
   const bool sad_ok = vwgpu_bm_sad_u8_supported(cost_type, kx, ky, sx, sy);
-  const bool dot_ok = !sad_ok && vwgpu_bm_dot_u8_supported(cost_type, kx, ky, sx, sy);
+  const bool corr_ok = !sad_ok && vwgpu_bm_corr_u8_supported(cost_type, kx, ky, sx, sy) && !getenv("VWGPU_NO_CORR_U8");
+  const bool dot_ok = !sad_ok && (corr_ok || vwgpu_bm_dot_u8_supported(cost_type, kx, ky, sx, sy));
   if (ctx->forced_path == VWGPU_PATH_SAD_U8 && !sad_ok)
     return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: no packed-u8 path for cost %d kernel %dx%d search %dx%d",
                       cost_type, kx, ky, sx, sy);
@@ -291,6 +293,7 @@ int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
   // Integer-valued inputs in [0,255]: the packed kernels; they check the domain while converting and raise a device flag.
   int* d_flag = nullptr;
   if (sad_ok) rc = vwgpu_launch_bm_sad_u8(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
+  else if (corr_ok) rc = vwgpu_launch_bm_corr_u8(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
   else rc = vwgpu_launch_bm_dot_u8(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
   if (rc) return rc;
   ctx->last_path = sad_ok ? VWGPU_PATH_SAD_U8 : VWGPU_PATH_DOT_U8;
