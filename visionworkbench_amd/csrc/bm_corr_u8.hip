@@ -15,12 +15,11 @@
 //   SSD       the lane folds B2 (from an LDS table, one read per evaluation) and the disparity index into one 32-bit key
 //             ((B2 + A2max - 2S) << 8 | d: SSD >= 0 bounds the field to 24 bits for kx*ky <= 129) and keeps min / max keys
 //             with v_min3 / v_max3 over disparity pairs; valid <=> min cost != max cost (Correlation.cc:121-133).
-//   NCC       the float64 score is needed only where it can decide: sweep 1 maximises an fp32 score S * fl32(1/sqrt(B2))
-//             (relative error < 2^-22), sweep 2 re-walks the disparities and records the candidates within 2^-20 of that
-//             maximum (almost always one), and ncc_resolve_kernel evaluates the reference's float64 sequence for those
-//             candidates in disparity order (strict compare, first wins).  Pixels whose scores all lie inside the margin
-//             (flat patches: validity undecidable in fp32) and pixels with more than four candidates are evaluated in full
-//             by the resolve kernel, verbatim (Correlation.cc:91-133).
+//   NCC       the float64 score is needed only where it can decide.  The lane tracks the two largest fp32 scores
+//             S * fl32(1/sqrt(B2)) (relative error < 2^-22; A2 is a per-pixel constant) and the disparity of the largest:
+//             when the runner-up is more than 2^-20 below, the reference's float64 sequence orders them the same way, so the
+//             recorded disparity is its winner and the pixel is valid.  The other pixels (near ties, flat patches) are queued
+//             and ncc_full_kernel evaluates the float64 sequence for every disparity of them (Correlation.cc:91-133).
 // Inputs that are not integers in [0,255], or an all-zero window under NCC (1/0), raise the device flag and the float64
 // kernel recomputes the image (the protocol of bm_sad_u8.hip).  One search row (sy == 1).
 //
@@ -39,8 +38,6 @@ typedef uint64_t u64;
 
 constexpr int CTW = 256;          // output columns per workgroup (lane = column)
 constexpr int CTHREADS = 256;
-constexpr int NCC_SLOTS = 4;      // candidate slots per pixel
-constexpr unsigned NCC_FULL = 255u;   // candidate count meaning "evaluate every disparity"
 
 struct CorrGeom {
   int sx;
@@ -61,7 +58,7 @@ bm_corr_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
                   int32_t* __restrict__ out, ptrdiff_t os, int ow, int oh,
                   int* __restrict__ flag_set, int* __restrict__ flag_clear,
                   u32* __restrict__ a2img, u32* __restrict__ b2img, int b2w,
-                  u32* __restrict__ cand, uint8_t* __restrict__ cnt_img) {
+                  u32* __restrict__ full_list, u32* __restrict__ full_count, u32 cap) {
   constexpr bool NCC = (COST == VWGPU_CROSS_CORRELATION);
   constexpr int NW = (KX + 3) / 4, NR = TY + KY - 1;
   constexpr int LWD = CTW / 4 + NW + 1;                         // aligned dwords per staged left row
@@ -158,26 +155,54 @@ bm_corr_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   __syncthreads();
 
   // ---- disparity sweeps ----
+  // Disparities are walked in quads {d0, d0+4, d0+8, d0+12}: word n of disparity d is the word n-1 of disparity d+4, so a
+  // quad needs NW + 3 right words per row instead of 4 NW — the LDS pipe (32 dwords per clock and CU) cannot feed one fresh
+  // word to every dot4 (64 lanes per clock and CU).  Each chain's accumulator is the vertical prefix sum; the ky-row window
+  // sum is P[r] - P[r-ky].  LDS reads are issued PF rows ahead and pinned there (sched_barrier): left to itself the
+  // scheduler sinks every read next to its use and the chains wait out the LDS latency row by row.
   const u32* ur0 = UR + tid;
   const u32* bk0 = B2K + tid;
-  // One pair of disparities (d, e): dot4 chains down the rows, window sums by prefix difference.  FN(y, sd, se) consumes them.
-  auto chain = [&](int d, int e, auto&& fn) __attribute__((always_inline)) {
-    u32 pa[NR], pb[NR];
-    u32 accA = 0, accB = 0;
+  constexpr int Q = 4, NWQ = Q + NW - 1, PF = 3;
+  auto quad = [&](int d0, auto&& fn) __attribute__((always_inline)) {
+    u32 Wd[NR][NWQ], Bq[TY][Q], P[Q][NR], acc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = 0;
+    auto fetch = [&](int r) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < NWQ; ++j) Wd[r][j] = ur0[r * URP + d0 + 4 * j];
+      if (r >= KY - 1) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) Bq[r - (KY - 1)][q] = bk0[(r - (KY - 1)) * nbx + d0 + 4 * q];
+      }
+    };
+#pragma unroll
+    for (int r = 0; r < PF && r < NR; ++r) fetch(r);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
+      if (r + PF < NR) fetch(r + PF);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int n = 0; n < NW; ++n) {
-        accA = __builtin_amdgcn_udot4(lwn[r][n], ur0[r * URP + d + 4 * n], accA, false);
-        accB = __builtin_amdgcn_udot4(lwn[r][n], ur0[r * URP + e + 4 * n], accB, false);
-      }
-      pa[r] = accA; pb[r] = accB;
+      for (int n = 0; n < NW; ++n)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] = __builtin_amdgcn_udot4(lwn[r][n], Wd[r][q + n], acc[q], false);
+#pragma unroll
+      for (int q = 0; q < Q; ++q) P[q][r] = acc[q];
       if (r >= KY - 1) {
-        const int y = r - (KY - 1);
-        const u32 sa = r >= KY ? pa[r] - pa[r - KY] : pa[r];
-        const u32 sb = r >= KY ? pb[r] - pb[r - KY] : pb[r];
-        fn(y, sa, sb);
+        u32 sq[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) sq[q] = r >= KY ? P[q][r] - P[q][r - KY] : P[q][r];
+        fn(r - (KY - 1), sq, Bq[r - (KY - 1)]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // the quads of one sweep: phase t = d mod 4, then steps of 16; the last quad of a phase may hold fewer than 4 disparities
+  auto sweep = [&](auto&& full, auto&& tail) __attribute__((always_inline)) {
+    for (int t = 0; t < 4; ++t) {
+      const int nt = (sx - t + 3) >> 2;                          // disparities congruent to t
+      int a0 = 0;
+      for (; a0 + Q <= nt; a0 += Q) full(4 * a0 + t);
+      if (a0 < nt) tail(4 * a0 + t, nt - a0);
     }
   };
 
@@ -185,15 +210,25 @@ bm_corr_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
     u32 K[TY], Wk[TY];
 #pragma unroll
     for (int y = 0; y < TY; ++y) { K[y] = 0xffffffffu; Wk[y] = 0u; }
-    for (int d = 0; d < sx; d += 2) {
-      const int e = d + 1 < sx ? d + 1 : d;                      // an odd tail evaluates its last disparity twice: harmless
-      chain(d, e, [&](int y, u32 sa, u32 sb) __attribute__((always_inline)) {
-        const u32 ka = bk0[y * nbx + d] + (u32)d - (sa << 9);    // ((B2 + OFFK - 2 S) << 8) | d
-        const u32 kb = bk0[y * nbx + e] + (u32)e - (sb << 9);
-        K[y] = umin3(K[y], ka, kb);
-        Wk[y] = umax3(Wk[y], ka, kb);
-      });
-    }
+    sweep(
+        [&](int d0) __attribute__((always_inline)) {
+          quad(d0, [&](int y, const u32* sq, const u32* bq) __attribute__((always_inline)) {
+            u32 k[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) k[q] = bq[q] + (u32)(d0 + 4 * q) - (sq[q] << 9);   // ((B2 + OFFK - 2 S) << 8) | d
+            K[y] = umin3(umin3(K[y], k[0], k[1]), k[2], k[3]);
+            Wk[y] = umax3(umax3(Wk[y], k[0], k[1]), k[2], k[3]);
+          });
+        },
+        [&](int d0, int nv) __attribute__((always_inline)) {
+          quad(d0, [&](int y, const u32* sq, const u32* bq) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+              const u32 k = bq[q] + (u32)(d0 + 4 * q) - (sq[q] << 9);
+              if (q < nv) { K[y] = K[y] < k ? K[y] : k; Wk[y] = Wk[y] > k ? Wk[y] : k; }
+            }
+          });
+        });
     if (x < ow) {
 #pragma unroll
       for (int y = 0; y < TY; ++y) {
@@ -205,86 +240,52 @@ bm_corr_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
       }
     }
   } else {
-    float M[TY], Mn[TY];
+    // One sweep: the two largest fp32 scores M1 >= M2 of every pixel and the (disparity, S) of the largest.  When M2 stays
+    // below M1 * (1 - 2^-20) the float64 sequence of the reference cannot order the two differently (the fp32 score is good
+    // to 2^-22), so the recorded disparity IS the reference's winner and the pixel is valid (worst < best).  Otherwise — near
+    // ties, flat patches, a single disparity — the pixel is queued for ncc_full_kernel.
+    float M1[TY], M2[TY];
+    u32 C[TY];
 #pragma unroll
-    for (int y = 0; y < TY; ++y) { M[y] = 0.0f; Mn[y] = INFINITY; }
-    for (int d = 0; d < sx; d += 2) {                            // sweep 1: fp32 maximum / minimum of the score
-      const int e = d + 1 < sx ? d + 1 : d;
-      chain(d, e, [&](int y, u32 sa, u32 sb) __attribute__((always_inline)) {
-        const float va = (float)sa * __uint_as_float(bk0[y * nbx + d]);
-        const float vb = (float)sb * __uint_as_float(bk0[y * nbx + e]);
-        M[y] = fmax3(M[y], va, vb);
-        Mn[y] = fmin3(Mn[y], va, vb);
-      });
-    }
-    u64 cnt = 0;                                                  // 4 bits per row: candidates recorded so far
-    u32 undecided = 0;
+    for (int y = 0; y < TY; ++y) { M1[y] = -1.0f; M2[y] = -1.0f; C[y] = 0u; }
+    auto take = [&](int y, u32 sv, u32 bv, int d) __attribute__((always_inline)) {
+      const float v = (float)sv * __uint_as_float(bv);
+      const u32 pay = (sv << 8) | (u32)d;
+      M2[y] = __builtin_amdgcn_fmed3f(M1[y], M2[y], v);          // second largest so far
+      C[y] = v > M1[y] ? pay : C[y];                              // strict: the first disparity of equal fp32 scores is kept
+      M1[y] = fmaxf(M1[y], v);
+    };
+    sweep(
+        [&](int d0) __attribute__((always_inline)) {
+          quad(d0, [&](int y, const u32* sq, const u32* bq) __attribute__((always_inline)) {
 #pragma unroll
-    for (int y = 0; y < TY; ++y) {
-      const float thr = M[y] * 0.99999905f;                       // 1 - 2^-20: the fp32 score is good to 2^-22
-      if (Mn[y] >= thr) undecided |= 1u << y;                     // every score inside the margin: resolve in full
-      M[y] = thr;
-    }
-    const bool col_ok = x < ow;
-    for (int d = 0; d < sx; d += 2) {                            // sweep 2: the candidates, in disparity order
-      const int e = d + 1 < sx ? d + 1 : d;
-      chain(d, e, [&](int y, u32 sa, u32 sb) __attribute__((always_inline)) {
-        const float va = (float)sa * __uint_as_float(bk0[y * nbx + d]);
-        const float vb = (float)sb * __uint_as_float(bk0[y * nbx + e]);
-        const bool ca = va >= M[y], cb = (vb >= M[y]) && (e != d);
-        if (__any((ca || cb) && col_ok && (y0 + y < oh))) {
-          if (col_ok && y0 + y < oh) {
-            u32* slot = cand + ((size_t)(y0 + y) * ow + x) * NCC_SLOTS;
-            u32 c = (u32)(cnt >> (4 * y)) & 15u;
-            if (ca) { if (c < NCC_SLOTS) slot[c] = (u32)d | (sa << 8); if (c < 15u) ++c; }
-            if (cb) { if (c < NCC_SLOTS) slot[c] = (u32)e | (sb << 8); if (c < 15u) ++c; }
-            cnt = (cnt & ~((u64)15 << (4 * y))) | ((u64)c << (4 * y));
-          }
-        }
-      });
-    }
-    if (col_ok) {
+            for (int q = 0; q < Q; ++q) take(y, sq[q], bq[q], d0 + 4 * q);
+          });
+        },
+        [&](int d0, int nv) __attribute__((always_inline)) {
+          quad(d0, [&](int y, const u32* sq, const u32* bq) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+              if (q < nv) take(y, sq[q], bq[q], d0 + 4 * q);
+          });
+        });
+    if (x < ow) {
 #pragma unroll
       for (int y = 0; y < TY; ++y) {
         if (y0 + y < oh) {
-          const u32 c = (u32)(cnt >> (4 * y)) & 15u;
-          cnt_img[(size_t)(y0 + y) * ow + x] = (uint8_t)(((undecided >> y) & 1u) || c > NCC_SLOTS || c == 0 ? NCC_FULL : c);
+          const size_t p = (size_t)(y0 + y) * ow + x;
+          if (sx == 1 || M2[y] >= M1[y] * 0.99999905f) {          // 1 - 2^-20 (also: all scores zero); one disparity: best == worst
+            const u32 i = atomicAdd(full_count, 1u);
+            if (i < cap) full_list[i] = (u32)p;
+          } else {
+            int32_t* o = out + ((ptrdiff_t)(y0 + y) * os + x) * 3;
+            o[0] = (int32_t)(C[y] & 0xffu); o[1] = 0; o[2] = 0x7fffffff;
+          }
         }
       }
     }
   }
   if (bad_acc != 0u || zero_window) atomicOr(flag_set, 1);
-}
-
-// NCC: the reference's float64 score for the recorded candidates (Correlation.cc:91-133 reduces to "maximum, first wins" on
-// them); pixels that need every disparity are queued for ncc_full_kernel.
-__global__ void __launch_bounds__(256)
-ncc_resolve_kernel(int sx, const u32* __restrict__ a2img, const u32* __restrict__ b2img, int b2w,
-                   const u32* __restrict__ cand, const uint8_t* __restrict__ cnt_img,
-                   int32_t* __restrict__ out, ptrdiff_t os, int ow, int oh, const int* __restrict__ flag,
-                   u32* __restrict__ full_list, u32* __restrict__ full_count, u32 cap) {
-  if (*flag) return;                                              // the float64 kernel recomputes the image
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= ow || y >= oh) return;
-  const size_t p = (size_t)y * ow + x;
-  const unsigned n = cnt_img[p];
-  if (n == NCC_FULL) {
-    const u32 i = atomicAdd(full_count, 1u);
-    if (i < cap) full_list[i] = (u32)p;
-    return;
-  }
-  const double pl = 1.0 / (double)a2img[p];                       // NCCCost ctor, CostFunctions.h:214-219
-  double best = 0.0;
-  int bd = 0;
-  for (unsigned i = 0; i < n; ++i) {                              // candidates are stored in disparity order
-    const u32 c = cand[p * NCC_SLOTS + i];
-    const int d = (int)(c & 0xffu);
-    const double pr = 1.0 / (double)b2img[(size_t)y * b2w + x + d];
-    const double v = (double)(c >> 8) * sqrt(pl * pr);            // cost_modification, :227-231
-    if (i == 0 || v > best) { best = v; bd = d; }
-  }
-  int32_t* o = out + ((ptrdiff_t)y * os + x) * 3;
-  o[0] = bd; o[1] = 0; o[2] = 0x7fffffff;                         // decided by the sweeps: minimum != maximum
 }
 
 // NCC, every disparity of the queued pixels: one wave per pixel, lane <-> disparity.  More queued pixels than `cap`
@@ -338,7 +339,7 @@ ncc_full_kernel(const float* __restrict__ L, ptrdiff_t ls, const float* __restri
 }
 
 typedef void (*CorrFn)(const float*, ptrdiff_t, int, int, const float*, ptrdiff_t, int, int, CorrGeom, int32_t*, ptrdiff_t, int, int, int*, int*,
-                       u32*, u32*, int, u32*, uint8_t*);
+                       u32*, u32*, int, u32*, u32*, u32);
 struct CorrLaunch { int cost, kx, ky, ty; CorrFn fn; };
 #define VW_CORR(C, KX, KY, TY) CorrLaunch{C, KX, KY, TY, bm_corr_u8_kernel<C, KX, KY, TY>}
 const CorrLaunch kCorr[] = {
@@ -360,7 +361,7 @@ CorrGeom corr_geom(int kx, int sx) {
   const int nw = (kx + 3) / 4;
   g.sx = sx;
   g.nbx = CTW + sx - 1;
-  g.urp = g.nbx + 4 * nw;
+  g.urp = g.nbx + 4 * nw + 16;                                  // + the words a clamped tail quad may touch
   g.rwd = (g.urp + 3) / 4 + 1;
   return g;
 }
@@ -393,22 +394,19 @@ int vwgpu_launch_bm_corr_u8(vwgpu_ctx* ctx, int cost_type, const float* left, in
   if (rc) return rc;
   *d_fallback_flag = flag_set;
   const bool ncc = cost_type == VWGPU_CROSS_CORRELATION;
-  u32 *a2 = nullptr, *b2 = nullptr, *cand = nullptr, *full_list = nullptr, *full_count = nullptr;
-  uint8_t* cnt = nullptr;
+  u32 *a2 = nullptr, *b2 = nullptr, *full_list = nullptr, *full_count = nullptr;
   const int b2w = rcw - kx + 1;
   // pixels evaluated over every disparity by ncc_full_kernel: at most ~3 % of the image, beyond that the float64 kernel is faster
   const u32 cap = (u32)std::max<size_t>(4096, (size_t)ow * oh / 32);
   if (ncc) {
     if ((size_t)ow * oh >= 0xffffffffull) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "bm_corr_u8: image too large");
     const size_t na = vwgpu_align_up((size_t)ow * oh * 4, 256), nb = vwgpu_align_up((size_t)b2w * oh * 4, 256),
-                 nc = vwgpu_align_up((size_t)ow * oh * NCC_SLOTS * 4, 256), nn = vwgpu_align_up((size_t)ow * oh, 256),
                  nl = vwgpu_align_up((size_t)cap * 4 + 256, 256);
-    rc = vwgpu_arena_reserve(ctx, &ctx->scratch, na + nb + nc + nn + nl);
+    rc = vwgpu_arena_reserve(ctx, &ctx->scratch, na + nb + nl);
     if (rc) return rc;
     char* base = static_cast<char*>(ctx->scratch.base);
     a2 = reinterpret_cast<u32*>(base); b2 = reinterpret_cast<u32*>(base + na);
-    cand = reinterpret_cast<u32*>(base + na + nb); cnt = reinterpret_cast<uint8_t*>(base + na + nb + nc);
-    full_count = reinterpret_cast<u32*>(base + na + nb + nc + nn); full_list = full_count + 64;
+    full_count = reinterpret_cast<u32*>(base + na + nb); full_list = full_count + 64;
     VWGPU_HIP(ctx, hipMemsetAsync(full_count, 0, 4, ctx->stream));
   }
   const size_t shmem = corr_lds_bytes(*l, g);
@@ -417,14 +415,9 @@ int vwgpu_launch_bm_corr_u8(vwgpu_ctx* ctx, int cost_type, const float* left, in
   {
     vwgpu_prof_scope ps(ctx, "bm_corr_u8");
     hipLaunchKernelGGL(l->fn, dim3((ow + CTW - 1) / CTW, (oh + l->ty - 1) / l->ty), dim3(CTHREADS), shmem, ctx->stream,
-                       left, ls, lw, lh, right, rs, rcw, rch, g, out, os, ow, oh, flag_set, flag_clear, a2, b2, b2w, cand, cnt);
+                       left, ls, lw, lh, right, rs, rcw, rch, g, out, os, ow, oh, flag_set, flag_clear, a2, b2, b2w, full_list, full_count, cap);
   }
   if (ncc) {
-    {
-      vwgpu_prof_scope ps(ctx, "ncc_resolve");
-      hipLaunchKernelGGL(ncc_resolve_kernel, dim3((ow + 63) / 64, (oh + 3) / 4), dim3(256), 0, ctx->stream,
-                         sx, a2, b2, b2w, cand, cnt, out, os, ow, oh, flag_set, full_list, full_count, cap);
-    }
     vwgpu_prof_scope ps(ctx, "ncc_full");
     hipLaunchKernelGGL(ncc_full_kernel, dim3(2048), dim3(256), 0, ctx->stream, left, ls, right, rs, kx, ky, sx, a2, b2, b2w,
                        out, os, ow, flag_set, full_list, full_count, cap);

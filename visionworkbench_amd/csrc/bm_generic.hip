@@ -40,7 +40,8 @@ __device__ __forceinline__ bool better(double c, double q) {
 
 // NCC side-car: prec(x,y) = 1.0 / sum_{ky x kx}(img^2) in float64 (NCCCost ctor, CostFunctions.h:214-219).
 __global__ void ncc_precision_kernel(const float* __restrict__ img, ptrdiff_t stride, int w, int h,
-                                     int kx, int ky, double* __restrict__ prec) {
+                                     int kx, int ky, double* __restrict__ prec, const int* __restrict__ run_flag) {
+  if (run_flag && *run_flag == 0) return;  // the fast path already produced the result
   const int ow = w - kx + 1, oh = h - ky + 1;
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -180,12 +181,12 @@ int vwgpu_launch_bm_generic_flag(vwgpu_ctx* ctx, int cost_type,
     {
       vwgpu_prof_scope ps(ctx, "ncc_precision_left");
       dim3 grd((ow + 63) / 64, (oh + 3) / 4);
-      hipLaunchKernelGGL(ncc_precision_kernel, grd, blk, 0, ctx->stream, left, ls, lw, lh, kx, ky, lprec);
+      hipLaunchKernelGGL(ncc_precision_kernel, grd, blk, 0, ctx->stream, left, ls, lw, lh, kx, ky, lprec, run_flag);
     }
     {
       vwgpu_prof_scope ps(ctx, "ncc_precision_right");
       dim3 grd((rpw + 63) / 64, (rph + 3) / 4);
-      hipLaunchKernelGGL(ncc_precision_kernel, grd, blk, 0, ctx->stream, right, rs, rcw, rch, kx, ky, rprec);
+      hipLaunchKernelGGL(ncc_precision_kernel, grd, blk, 0, ctx->stream, right, rs, rcw, rch, kx, ky, rprec, run_flag);
     }
   }
 
