@@ -52,7 +52,16 @@ __global__ void range_init_kernel(int* out4) { out4[0] = out4[1] = INT_MAX; out4
 // the right neighbourhood: every right value is loaded once (kx + 2 per row) and every left value once (three rows kept in
 // registers), instead of 9 * kx * ky loads of each.  The float64 accumulation order of each of the nine sums is unchanged
 // (rows outer, columns inner).  KX == 0: any width, the plain loops.
-template <int KX>
+// INT: every pixel of both rasters is an integer of magnitude < 2^21 (measured by the caller): the nine sums are then exact
+// integers below 2^31 in any arithmetic, so they are formed with v_sad_u32 (one instruction per abs-diff instead of
+// subtract + widen + float64 add) and converted once — the same float the reference's float64 sum rounds to.
+__device__ __forceinline__ unsigned sad_u32(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+template <int KX, bool INT>
 __global__ void __launch_bounds__(256)
 parabola_kernel(const float* __restrict__ disp, int w, int h, ptrdiff_t dstride_px,
                 const float* __restrict__ lras, int lrw, const float* __restrict__ rras, int rrw,
@@ -83,6 +92,53 @@ parabola_kernel(const float* __restrict__ disp, int w, int h, ptrdiff_t dstride_
         patch[(ddy + 1) * 3 + (ddx + 1)] = (float)s;
       }
     }
+  } else if (INT) {
+    constexpr int K = KX > 0 ? KX : 1;
+    constexpr int OFF = 1 << 21;
+    unsigned s9[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) s9[a][b] = 0u;
+    unsigned la[K], lb[K], lc[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) { la[i] = 0u; lb[i] = 0u; lc[i] = (unsigned)((int)lbase[i] + OFF); }
+    const float* rrow = rras + (ptrdiff_t)(y + Dy - 1 - range_miny) * rrw + (x + Dx - 1 - range_minx);
+    for (int q = -1; q <= ky; ++q) {
+      unsigned r[K + 2];
+#pragma unroll
+      for (int i = 0; i < K + 2; ++i) r[i] = (unsigned)((int)rrow[i] + OFF);
+      if (q - 1 >= 0) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int i = 0; i < K; ++i) s9[2][b] = sad_u32(la[i], r[i + b], s9[2][b]);
+      }
+      if (q >= 0 && q < ky) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int i = 0; i < K; ++i) s9[1][b] = sad_u32(lb[i], r[i + b], s9[1][b]);
+      }
+      if (q + 1 < ky) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int i = 0; i < K; ++i) s9[0][b] = sad_u32(lc[i], r[i + b], s9[0][b]);
+      }
+#pragma unroll
+      for (int i = 0; i < K; ++i) { la[i] = lb[i]; lb[i] = lc[i]; }
+      if (q + 2 < ky) {
+        const float* lp = lbase + (ptrdiff_t)(q + 2) * lrw;
+#pragma unroll
+        for (int i = 0; i < K; ++i) lc[i] = (unsigned)((int)lp[i] + OFF);
+      }
+      rrow += rrw;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) patch[a * 3 + b] = (float)s9[a][b];
   } else {
     constexpr int K = KX > 0 ? KX : 1;
     double s9[3][3];
@@ -179,11 +235,13 @@ int vwgpu_launch_disparity_range(vwgpu_ctx* ctx, const float* disp3f, int w, int
 
 int vwgpu_launch_parabola(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t dstride_px,
                           const float* lras, int lrw, const float* rras, int rrw, int range_minx, int range_miny,
-                          int kx, int ky, float* out3f, ptrdiff_t ostride_px) {
+                          int kx, int ky, float* out3f, ptrdiff_t ostride_px, bool small_integers) {
   dim3 blk(64, 4), grd((w + 63) / 64, (h + 3) / 4);
-  vwgpu_prof_scope ps(ctx, "parabola_subpixel");
-#define VW_PARABOLA(K) hipLaunchKernelGGL(parabola_kernel<K>, grd, blk, 0, ctx->stream, disp3f, w, h, dstride_px, lras, lrw, rras, rrw, \
-                                          range_minx, range_miny, kx, ky, out3f, ostride_px)
+  vwgpu_prof_scope ps(ctx, small_integers ? "parabola_subpixel_int" : "parabola_subpixel");
+#define VW_PARABOLA(K) do { if (small_integers && K > 0) hipLaunchKernelGGL((parabola_kernel<K, true>), grd, blk, 0, ctx->stream, disp3f, w, h, dstride_px, \
+                                          lras, lrw, rras, rrw, range_minx, range_miny, kx, ky, out3f, ostride_px); \
+                            else hipLaunchKernelGGL((parabola_kernel<K, false>), grd, blk, 0, ctx->stream, disp3f, w, h, dstride_px, lras, lrw, rras, rrw, \
+                                          range_minx, range_miny, kx, ky, out3f, ostride_px); } while (0)
   switch (kx) {
     case 3: VW_PARABOLA(3); break;   case 5: VW_PARABOLA(5); break;   case 7: VW_PARABOLA(7); break;   case 9: VW_PARABOLA(9); break;
     case 11: VW_PARABOLA(11); break; case 13: VW_PARABOLA(13); break; case 15: VW_PARABOLA(15); break; default: VW_PARABOLA(0); break;

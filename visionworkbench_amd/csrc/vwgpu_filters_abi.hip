@@ -3,6 +3,8 @@
 #include <cmath>
 #include <vector>
 
+#include <climits>
+
 #include "vwgpu_internal.h"
 
 namespace {
@@ -218,9 +220,22 @@ int vwgpu_parabola_subpixel_dev(vwgpu_ctx* ctx, const float* d_disp, int w, int 
   int* d_range = static_cast<int*>(ctx->misc.base);
   rc = vwgpu_launch_disparity_range(ctx, d_disp, w, h, dstride, d_range);
   if (rc) return rc;
+  // class of the imagery, measured in the same round trip: small integers take the integer SAD form of the kernel
+  int* d_grain = d_range + 8;
+  int grain[3] = {INT_MAX, INT_MIN, 0};
+  if (mode == VWGPU_PREFILTER_NONE) {
+    VWGPU_HIP(ctx, hipMemcpyAsync(d_grain, grain, sizeof grain, hipMemcpyHostToDevice, ctx->stream));
+    const float* imgs[2] = {d_left, d_right};
+    const int ws[2] = {w, rw}, hs[2] = {h, rh};
+    const ptrdiff_t ss[2] = {lstride, rstride};
+    int* cells[2] = {d_grain, d_grain};
+    vwgpu_launch_float_grain(ctx, 2, imgs, ws, hs, ss, cells);
+    VWGPU_HIP(ctx, hipMemcpyAsync(grain, d_grain, sizeof grain, hipMemcpyDeviceToHost, ctx->stream));
+  }
   int r4[4];
   VWGPU_HIP(ctx, hipMemcpyAsync(r4, d_range, sizeof r4, hipMemcpyDeviceToHost, ctx->stream));
   VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));              // the ROI sizes depend on the data
+  const bool small_integers = mode == VWGPU_PREFILTER_NONE && !grain[2] && (grain[0] == INT_MAX || (grain[0] >= 0 && grain[1] <= 20));
   const long long rminx = (long long)r4[0] - 1, rminy = (long long)r4[1] - 1;
   const long long rsx = (long long)r4[2] + 1 - r4[0] + 2, rsy = (long long)r4[3] + 1 - r4[1] + 2;
   if (rsx > 8192 || rsy > 8192 || rminx < -(1 << 20) || rminx > (1 << 20) || rminy < -(1 << 20) || rminy > (1 << 20))
@@ -241,7 +256,7 @@ int vwgpu_parabola_subpixel_dev(vwgpu_ctx* ctx, const float* d_disp, int w, int 
   if (rc) return rc;
   rc = vwgpu_prefilter_region(ctx, d_right, rw, rh, rstride, mode, width, -hx + (int)rminx, -hy + (int)rminy, rrw, rrh, rras, scratch);
   if (rc) return rc;
-  return vwgpu_launch_parabola(ctx, d_disp, w, h, dstride, lras, lrw, rras, rrw, (int)rminx, (int)rminy, kx, ky, d_out, ostride);
+  return vwgpu_launch_parabola(ctx, d_disp, w, h, dstride, lras, lrw, rras, rrw, (int)rminx, (int)rminy, kx, ky, d_out, ostride, small_integers);
 }
 
 int vwgpu_parabola_subpixel(vwgpu_ctx* ctx, const float* disp, int w, int h, ptrdiff_t dstride,
