@@ -120,7 +120,7 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right):
     # (2) BASELINE config 3: 11x11 NCC over 129x1, then parabola_subpixel on the result
     wall, kern = measure(ctx, torch, lambda: stereo.calc_disparity(2, lt, rt, bb, SEARCH, (11, 11), ctx=ctx), 10)
     entry("config 3a: 4096^2, 11x11 NCC, search 129x1", algorithmic_bytes(W, H, 11, 11, 129, 1), "4LW + 4RW + 12 out (SURVEY 8d)", wall, kern,
-          {"bm_dot_u8", "bm_dot_u8_precision", "ncc_precision_left", "ncc_precision_right"}, (W - 10) * (H - 10), path=ctx.last_path())
+          {"bm_corr_u8", "ncc_full", "bm_dot_u8"}, (W - 10) * (H - 10), path=ctx.last_path())
     d = stereo.calc_disparity(2, lt, rt, bb, SEARCH, (11, 11), ctx=ctx)
     disp = torch.zeros((H, W, 3), dtype=torch.float32, device=lt.device)
     disp[5:5 + H - 10, 5:5 + W - 10, :2] = d[..., :2].float()
@@ -128,7 +128,7 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right):
     wall, kern = measure(ctx, torch, lambda: stereo.parabola_subpixel(disp, lt, rt, 0, 0.0, (11, 11), ctx=ctx), 10)
     pb = 4 * W * H + 4 * (W + 128) * H + 12 * W * H + 12 * W * H
     entry("config 3b: parabola_subpixel 11x11 on the 4096^2 NCC result", pb, "4LW + 4RW + 12 disparity in + 12 out (SURVEY 8d)", wall, kern,
-          {k for k in kern if k.startswith("parabola") or k == "disparity_range"}, W * H)
+          {k for k in kern if k.startswith("parabola") or k in ("disparity_range", "float_grain", "edge_extend_sub")}, W * H)
     # (3) SGM building block of config 4: 2048^2, census 7x7, 129 disparities, 8 paths, LC-blend sub-pixel
     n = 2048
     ls, rs_ = lt[:n, :n].contiguous(), rt[:n, :n + 128].contiguous()

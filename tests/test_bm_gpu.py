@@ -346,8 +346,8 @@ def test_dot_path_ties_and_flat_areas(oracle, cost):
         left2 = rng.integers(1, 256, (200, 400)).astype(np.float32)
         right2 = rng.integers(1, 256, (200, 400 + 32)).astype(np.float32)
         right2[:, 9:409] = left2
-        left2[50:70, 100:130] = 9.0
-        right2[40:80, 80:200] = 9.0
+        left2[50:70, 100:130] = 9.0                 # (a flat RIGHT patch scores higher than any texture: keep it small, every
+        right2[45:75, 100:150] = 9.0                #  pixel that can see it becomes a near tie)
         got2 = stereo.calc_disparity(cost, left2, right2, core.BBox2i(0, 0, 400, 200), (33, 1), (7, 7), ctx=ctx)
         assert ctx.last_path() == core.PATH_DOT_U8
         assert np.array_equal(got2, oracle.calc_disparity(cost, left2, right2, (7, 7), (33, 1)))

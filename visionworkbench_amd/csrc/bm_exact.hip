@@ -420,14 +420,18 @@ void vwgpu_launch_float_grain(vwgpu_ctx* ctx, int n, const float* const* img, co
   for (int i0 = 0; i0 < n; i0 += GRAIN_MAX) {
     GrainJobs jobs;
     int m = 0;
+    size_t largest = 0;
     for (int i = i0; i < n && m < GRAIN_MAX; ++i) {
       if (!img[i] || w[i] <= 0 || h[i] <= 0) continue;
       jobs.img[m] = img[i]; jobs.w[m] = w[i]; jobs.h[m] = h[i]; jobs.stride[m] = stride[i]; jobs.cell[m] = d_cells[i];
+      largest = std::max(largest, (size_t)w[i] * h[i]);
       ++m;
     }
     if (m == 0) continue;
+    // workgroups per image: ~64 K pixels each (8 loads in flight per thread), at least GRAIN_BLOCKS, at most 512
+    const unsigned blocks = (unsigned)std::min<size_t>(512, std::max<size_t>(GRAIN_BLOCKS, largest >> 16));
     vwgpu_prof_scope ps(ctx, "float_grain");
-    hipLaunchKernelGGL(float_grain_kernel, dim3(GRAIN_BLOCKS, (unsigned)m), dim3(256), 0, ctx->stream, jobs);
+    hipLaunchKernelGGL(float_grain_kernel, dim3(blocks, (unsigned)m), dim3(256), 0, ctx->stream, jobs);
   }
 }
 
