@@ -110,3 +110,77 @@ def test_halo_exchange_of_a_sharded_source_image(oracle, world):
         assert p.exitcode == 0
     left, right, _ = synth.stereo_pair(w, h, search[0], search[1], block=32)
     assert np.array_equal(got, oracle.calc_disparity(0, left, right, kernel, search))
+
+
+# ---- pyramid tiles and SGM strips of a row-sharded pair (BASELINE configs 4 and 5) -------------------------------------------
+
+def _tile_worker(rank, world, port, sgm, collar, q):
+    """Each rank owns a row strip of BOTH images, fetches the rows its tiles can touch from the neighbours (pyramid padding
+    half_kernel * 2^levels + search, CorrelationView.cc:89-97; + the collar, CorrelationView.h:123-133) and correlates its
+    tiles from that window alone."""
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, h, levels, k = 200, 240, 2, 7
+    search = (-6, -1, 7, 2)
+    left, right, _ = synth.stereo_pair(w, h, 13, 1, block=32)
+    right = np.ascontiguousarray(right[:, 6:6 + w])
+    a, b = partition.row_strip(rank, world, h)
+    above, below = partition.pyramid_halo_rows(k, levels, search[1], search[3], collar)
+    lwin, l0 = partition.fetch_strip_window(torch.from_numpy(left[a:b].copy()), rank, world, h, above, below)
+    rwin, r0 = partition.fetch_strip_window(torch.from_numpy(right[a:b].copy()), rank, world, h, above, below)
+    assert l0 == r0 == max(0, a - above)
+    lwin, rwin = lwin.numpy(), rwin.numpy()
+    assert np.array_equal(lwin, left[l0:l0 + lwin.shape[0]])
+    parts = []
+    for (x, y, tw, th) in partition.strip_tiles(rank, world, h, w, tile=96):
+        # tile + collar semantics: correlate the collared box, keep its centre (the box may leave the image: edge extension)
+        big = (x - collar, y - collar - l0, tw + 2 * collar, th + 2 * collar)
+        if sgm:
+            t = oracle.pyramid_correlate_sgm(lwin, rwin, None, None, search, k, 3, 2.0, 0, 3, levels, bbox=big)
+        else:
+            t = oracle.pyramid_correlate(lwin, rwin, None, None, 0, 0.0, search, (k, k), 0, 0, 0.0, 2.0, 3, levels, bbox=big)
+        parts.append(((x, y, tw, th), t[collar:collar + th, collar:collar + tw].copy()))
+    allparts = [None] * world
+    dist.all_gather_object(allparts, parts)
+    dist.barrier()
+    if rank == 0:
+        out = np.zeros((h, w, 3), np.float32)
+        for pl in allparts:
+            for (x, y, tw, th), t in pl:
+                out[y:y + th, x:x + tw] = t
+        q.put(out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sgm,collar", [(False, 0), (True, 16)])
+def test_sharded_source_pyramid_tiles_and_sgm_collar(oracle, sgm, collar):
+    """World 2: the reassembled tiles equal the same (collared) tiles computed from the whole pair."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, sgm, collar, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w, h, levels, k = 200, 240, 2, 7
+    search = (-6, -1, 7, 2)
+    left, right, _ = synth.stereo_pair(w, h, 13, 1, block=32)
+    right = np.ascontiguousarray(right[:, 6:6 + w])
+    want = np.zeros((h, w, 3), np.float32)
+    for rank in range(world):
+        for (x, y, tw, th) in partition.strip_tiles(rank, world, h, w, tile=96):
+            big = (x - collar, y - collar, tw + 2 * collar, th + 2 * collar)
+            if sgm:
+                t = oracle.pyramid_correlate_sgm(left, right, None, None, search, k, 3, 2.0, 0, 3, levels, bbox=big)
+            else:
+                t = oracle.pyramid_correlate(left, right, None, None, 0, 0.0, search, (k, k), 0, 0, 0.0, 2.0, 3, levels, bbox=big)
+            want[y:y + th, x:x + tw] = t[collar:collar + th, collar:collar + tw]
+    assert np.array_equal(got[..., 2], want[..., 2])
+    assert np.abs(got - want).max() < 1e-6
+    assert (got[..., 2] != 0).mean() > 0.5

@@ -78,3 +78,39 @@ def sharded_bounds(world, rows_total, out_rows, halo_above, halo_below):
         bounds.append((a, b, max(0, a - halo_above), min(rows_total, (row_strip(r, world, out_rows)[1]) + halo_below)))
     # the last rank needs nothing below the image; make sure need >= owned everywhere
     return [(a, b, min(na, a), max(nb, b)) for (a, b, na, nb) in bounds]
+
+
+# ---- pyramid / SGM tiles of a row-sharded pair ----------------------------------------------------------------------------
+
+def pyramid_halo_rows(kernel_y, max_pyramid_levels, search_min_y, search_max_y, collar=0):
+    """Rows above / below a tile that PyramidCorrelationView::prerasterize can touch (src/vw/Stereo/CorrelationView.cc:89-97:
+    the tile grows by half_kernel * 2^levels, the right ROI additionally by the search range; the SGM branch's R->L runs by
+    twice the search extent) — the window vwgpu_pyramid_correlate stages (csrc/pyramid.hip) — plus the collar of
+    PyramidCorrelationView::rasterize (CorrelationView.h:123-133).  Returns (above, below)."""
+    up = 1 << max(0, min(int(max_pyramid_levels), 12))
+    sdy = max(0, search_max_y - search_min_y)
+    pad = (kernel_y // 2) * up + 2 * sdy + 8 + int(collar)
+    return pad - min(search_min_y, 0), pad + max(search_max_y, 0)
+
+
+def strip_tiles(rank, world, rows, cols, tile=1024):
+    """The output tiles (x, y, w, h) of rank's row strip: rows [rank*rows/world, (rank+1)*rows/world) cut into tile x tile
+    blocks (tools/correlate.cc:266 uses 1024), raster order."""
+    r0, r1 = row_strip(rank, world, rows)
+    out = []
+    for y in range(r0, r1, tile):
+        for x in range(0, cols, tile):
+            out.append((x, y, min(tile, cols - x), min(tile, r1 - y)))
+    return out
+
+
+def fetch_strip_window(owned, rank, world, rows_total, halo_above, halo_below, group=None):
+    """The rows a rank's tiles can touch, for a source image whose rows are sharded by row_strip(): owned = rows
+    [row_strip(rank)] of the image; returns (window tensor, first row of the window).  One isend/irecv per neighbour whose
+    rows are needed (RCCL over xGMI on GPUs, gloo on CPU)."""
+    bounds = []
+    for r in range(world):
+        a, b = row_strip(r, world, rows_total)
+        bounds.append((a, b, max(0, a - halo_above), min(rows_total, b + halo_below)))
+    a, b, na, nb = bounds[rank]
+    return exchange_halo(owned, a, b, na, nb, rank, world, bounds, group=group), na

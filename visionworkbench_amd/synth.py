@@ -56,3 +56,27 @@ def noise_f32(seed, h, w, lo=0.0, hi=1.0):
     """Non-integer float texture (mismatch-rate runs; bit-exact parity is not defined on these)."""
     u = (splitmix64(seed, h * w) >> np.uint64(40)).astype(np.float64) / float(1 << 24)
     return (lo + (hi - lo) * u).astype(np.float32).reshape(h, w)
+
+
+def stereo_pair_rows(w, h, sx, r0, r1, block=256, jitter=None, seeds=(10, 11, 12)):
+    """Rows [r0, r1) of stereo_pair(w, h, sx, 1, block, jitter, seeds) without generating the rest (one search row, so a
+    right row depends on the same left row only): for pairs too large to build whole on every rank."""
+    centre = (sx - 1) // 2
+    if jitter is None:
+        jitter = max(0, min(48, centre - 1, sx - 1 - centre - 1)) if sx > 2 else 0
+    n = r1 - r0
+    rw = w + sx - 1
+    left = (splitmix64(seeds[0], n * w, offset=r0 * w) >> np.uint64(56)).astype(np.uint8).reshape(n, w)
+    right = (splitmix64(seeds[1], n * rw, offset=r0 * rw) >> np.uint64(56)).astype(np.uint8).reshape(n, rw)
+    nbx, nby = (w + block - 1) // block, (h + block - 1) // block
+    r = splitmix64(seeds[2], nbx * nby)
+    shifts = (r % np.uint64(2 * jitter + 1)).astype(np.int64) - jitter
+    truth = np.zeros((n, w), np.int32)
+    for by in range(r0 // block, (r1 + block - 1) // block):
+        y0, y1 = max(by * block, r0) - r0, min(h, (by + 1) * block, r1) - r0
+        for bx in range(nbx):
+            s = int(shifts[by * nbx + bx])
+            x0, x1 = bx * block, min(w, (bx + 1) * block)
+            right[y0:y1, x0 + centre + s:x1 + centre + s] = left[y0:y1, x0:x1]
+            truth[y0:y1, x0:x1] = centre + s
+    return left.astype(np.float32), right.astype(np.float32), truth
