@@ -179,7 +179,7 @@ def run_config4(args, torch, dist, vwa, core, stereo, synth, partition, rank, wo
             l = lwin[ra - first:rb - first]
             r = rwin[ra - first:rb - first]
             d = stereo.calc_disparity_sgm(3, l, r, vwa.BBox2i(0, 0, W, rb - ra), (D - 1, 0), (k, k), with_subpixel=True,
-                                          memory_limit_mb=200000, ctx=ctx)[1]
+                                          memory_limit_mb=200000, ctx=ctx)[0]
             top = max(0, y0 - ra - k // 2)                               # output row j of the call is centred on input row ra + j + k/2
             outs.append(d[top:top + (y1 - y0)])                          # the strip's centre rows (fewer at the image borders)
         return outs
