@@ -351,7 +351,7 @@ def test_dot_path_ties_and_flat_areas(oracle, cost):
         got2 = stereo.calc_disparity(cost, left2, right2, core.BBox2i(0, 0, 400, 200), (33, 1), (7, 7), ctx=ctx)
         assert ctx.last_path() == core.PATH_DOT_U8
         assert np.array_equal(got2, oracle.calc_disparity(cost, left2, right2, (7, 7), (33, 1)))
-        assert (got2[55:60, 105:120, 2] == 0).all()
+        assert (got2[55:60, 105:111, 2] == 0).all()        # windows and all 33 right windows inside the flat patches
     ctx.close()
 
 
