@@ -378,3 +378,54 @@ def test_dot_path_falls_back(oracle):
     assert ctx.last_path() == core.PATH_GENERIC_F64
     assert np.array_equal(got, oracle.calc_disparity(1, left2, right2, (5, 5), (9, 3)))
     ctx.close()
+
+
+# ---- packed-u16 SAD path (16-bit imagery) ---------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("w,h,kernel,sx", [(300, 70, (7, 7), 129), (97, 40, (5, 5), 9), (640, 33, (11, 11), 64), (258, 50, (3, 3), 1),
+                                           (513, 21, (7, 5), 200), (1100, 60, (9, 9), 33), (64, 16, (7, 7), 2)])
+def test_u16_path_bit_exact(ctx, oracle, w, h, kernel, sx):
+    """Integer-valued pixels above 255 (16-bit sensors; the scale-32767 cases of TestCorrelation.cxx:45-214): v_sad_u16 kernel,
+    identical to the oracle — shifted copies, flat patches (validity), values at both ends of the range."""
+    rng = np.random.default_rng(w * 7 + sx)
+    left = np.floor(rng.random((h, w)) * 65536).astype(np.float32)
+    right = np.floor(rng.random((h, w + sx - 1)) * 65536).astype(np.float32)
+    d = int(rng.integers(0, sx))
+    right[:, d:d + w] = np.where(rng.random((h, w)) < 0.7, left, right[:, d:d + w])
+    left[3:12, 10:40] = 65535.0
+    right[2:14, 5:60 + sx] = 65535.0
+    left[0, 0] = 0.0
+    got, path = _gpu(ctx, ABS, left, right, kernel, (sx, 1))
+    assert path == core.PATH_SAD_U16
+    want = oracle.calc_disparity(ABS, left, right, kernel, (sx, 1))
+    assert np.array_equal(got, want), int((got != want).any(-1).sum())
+    ctx.force_path(core.PATH_NONE)
+    # negative or fractional pixels leave the domain: the float64 kernel serves them, same result as the oracle
+    left[5, 7] = -3.0
+    got, path = _gpu(ctx, ABS, left, right, kernel, (sx, 1))
+    assert path == core.PATH_GENERIC_F64
+    assert np.array_equal(got, oracle.calc_disparity(ABS, left, right, kernel, (sx, 1)))
+
+
+def test_u16_path_random_cross_check(ctx):
+    """Seeded random sizes / searches: packed-u16 kernel vs the float64 kernel (pinned to the oracle above)."""
+    import torch
+    from visionworkbench_amd import stereo
+    rng = np.random.default_rng(55)
+    kernels = [(3, 3), (5, 5), (7, 7), (7, 5), (9, 9), (11, 11)]
+    for it in range(60):
+        kx, ky = kernels[rng.integers(len(kernels))]
+        sx = int(rng.integers(1, 200))
+        w, h = int(rng.integers(kx, 1500)), int(rng.integers(ky, 120))
+        scale = float(rng.choice([65536, 4096, 300]))
+        left = np.floor(rng.random((h, w)) * scale).astype(np.float32)
+        right = np.floor(rng.random((h, w + sx - 1)) * scale).astype(np.float32)
+        d = int(rng.integers(0, sx))
+        right[:, d:d + w] = np.where(rng.random((h, w)) < 0.6, left, right[:, d:d + w])
+        lt, rt = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+        ctx.force_path(core.PATH_SAD_U16)
+        a = stereo.calc_disparity(ABS, lt, rt, vwa.bounding_box(left), (sx, 1), (kx, ky), ctx=ctx).cpu().numpy()
+        ctx.force_path(core.PATH_GENERIC_F64)
+        b = stereo.calc_disparity(ABS, lt, rt, vwa.bounding_box(left), (sx, 1), (kx, ky), ctx=ctx).cpu().numpy()
+        ctx.force_path(core.PATH_NONE)
+        assert np.array_equal(a, b), (it, kx, ky, sx, w, h, int((a != b).any(-1).sum()))

@@ -1,5 +1,6 @@
 // vwgpu_abi.hip — extern "C" entry points of libvwgpu.so (declared in include/vwgpu.h).
 // Argument validation, path dispatch, host staging, error text.  No kernels here.
+#include <climits>
 #include <cstdlib>
 #include <cstring>
 
@@ -150,7 +151,7 @@ int vwgpu_synchronize(vwgpu_ctx* ctx) {
 const char* vwgpu_last_error(const vwgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
 
 int vwgpu_force_path(vwgpu_ctx* ctx, int path) {
-  if (!ctx || path < VWGPU_PATH_NONE || path > VWGPU_PATH_EXACT_ORDER) return VWGPU_ERR_ARGUMENT;
+  if (!ctx || path < VWGPU_PATH_NONE || path > VWGPU_PATH_SAD_U16) return VWGPU_ERR_ARGUMENT;
   ctx->forced_path = path;
   return VWGPU_OK;
 }
@@ -177,7 +178,7 @@ int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value) {
 int vwgpu_last_path(const vwgpu_ctx* cctx) {
   vwgpu_ctx* ctx = const_cast<vwgpu_ctx*>(cctx);
   if (!ctx) return VWGPU_PATH_NONE;
-  if ((ctx->last_path == VWGPU_PATH_SAD_U8 || ctx->last_path == VWGPU_PATH_DOT_U8) && ctx->last_flag) {
+  if ((ctx->last_path == VWGPU_PATH_SAD_U8 || ctx->last_path == VWGPU_PATH_DOT_U8 || ctx->last_path == VWGPU_PATH_SAD_U16) && ctx->last_flag) {
     // The fast path reports non-representable input through a device flag; the generic kernel then ran.
     int flag = 0;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return VWGPU_PATH_NONE;
@@ -248,13 +249,31 @@ static int calc_disparity_classified(vwgpu_ctx* ctx, int cost_type, const float*
                                      const float* d_right, int rw, int rh, ptrdiff_t rs, int kx, int ky, int sx, int sy,
                                      int32_t* d_out, ptrdiff_t os) {
   bool exact = ctx->forced_path == VWGPU_PATH_EXACT_ORDER;
-  if (ctx->forced_path == VWGPU_PATH_NONE && vwgpu_bm_exact_supported(sx, sy)) {
+  ctx->last_flag = nullptr;
+  if (ctx->forced_path == VWGPU_PATH_NONE) {
     int lo = 0, hi = 0, nonfinite = 0;
     int rc = vwgpu_float_grain(ctx, d_left, lw, lh, ls, d_right, lw + sx - 1, lh + sy - 1, rs, &lo, &hi, &nonfinite);
     if (rc) return rc;
-    exact = !vwgpu_sums_order_free(cost_type, kx, ky, lo, hi, nonfinite);
+    if (vwgpu_bm_exact_supported(sx, sy)) exact = !vwgpu_sums_order_free(cost_type, kx, ky, lo, hi, nonfinite);
+    // integers below 2^16 (16-bit imagery): the packed-u16 SAD kernel; it checks the sign itself and raises its flag
+    if (!exact && !nonfinite && lo != INT_MAX && lo >= 0 && hi <= 15 && vwgpu_bm_sad_u16_supported(cost_type, kx, ky, sx, sy)) {
+      int* d_flag = nullptr;
+      rc = vwgpu_launch_bm_sad_u16(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
+      if (rc) return rc;
+      int flag = 0;
+      VWGPU_HIP(ctx, hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+      VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (!flag) { ctx->last_path = VWGPU_PATH_SAD_U16; return VWGPU_OK; }
+    }
+  } else if (ctx->forced_path == VWGPU_PATH_SAD_U16) {
+    if (!vwgpu_bm_sad_u16_supported(cost_type, kx, ky, sx, sy))
+      return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: no packed-u16 path for cost %d kernel %dx%d search %dx%d", cost_type, kx, ky, sx, sy);
+    int* d_flag = nullptr;
+    int rc = vwgpu_launch_bm_sad_u16(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
+    ctx->last_path = VWGPU_PATH_SAD_U16;
+    ctx->last_flag = d_flag;
+    return rc;
   }
-  ctx->last_flag = nullptr;
   if (exact) {
     if (!vwgpu_bm_exact_supported(sx, sy))
       return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: the exact-order path serves up to 512 disparities (%d x %d asked)", sx, sy);

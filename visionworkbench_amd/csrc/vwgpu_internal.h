@@ -106,6 +106,11 @@ int vwgpu_launch_bm_dot_u8(vwgpu_ctx* ctx, int cost_type, const float* left, int
                            const float* right, int rw, int rh, ptrdiff_t rs, int kx, int ky, int sx, int sy,
                            int32_t* out, ptrdiff_t os, int** d_fallback_flag);
 int vwgpu_next_flags(vwgpu_ctx* ctx, size_t extra_ints, int** flag_set, int** flag_clear, int** extra);
+// bm_sad_u16.hip: SAD for integer-valued imagery in [0,65535] (v_sad_u16 on pixel pairs); same fallback-flag protocol
+bool vwgpu_bm_sad_u16_supported(int cost_type, int kx, int ky, int sx, int sy);
+int vwgpu_launch_bm_sad_u16(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t ls,
+                            const float* right, int rw, int rh, ptrdiff_t rs, int kx, int ky, int sx, int sy,
+                            int32_t* out, ptrdiff_t os, int** d_fallback_flag);
 // bm_corr_u8.hip: register-blocked SSD / NCC for the same inputs (preferred over bm_dot_u8 where instantiated)
 bool vwgpu_bm_corr_u8_supported(int cost_type, int kx, int ky, int sx, int sy);
 int vwgpu_launch_bm_corr_u8(vwgpu_ctx* ctx, int cost_type, const float* left, int lw, int lh, ptrdiff_t ls,
