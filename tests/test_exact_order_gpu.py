@@ -112,8 +112,11 @@ def test_order_free_floats_keep_the_fast_kernels(ctx, oracle):
     i16 = np.floor(synth.noise_f32(44, 40, 100, 0.0, 32767.0)).astype(np.float32)
     r16 = np.concatenate([i16[:, 5:], np.floor(synth.noise_f32(45, 40, 21, 0.0, 32767.0))], axis=1).astype(np.float32)
     got = stereo.calc_disparity(ABS, i16, r16, vwa.bounding_box(i16), (17, 1), (7, 7), ctx=ctx)
-    assert ctx.last_path() == core.PATH_GENERIC_F64
+    assert ctx.last_path() == core.PATH_SAD_U16                   # integers below 2^16: the packed-u16 kernel
     assert np.array_equal(got, oracle.calc_disparity(ABS, i16, r16, (7, 7), (17, 1)))
+    got = stereo.calc_disparity(SQ, i16, r16, vwa.bounding_box(i16), (17, 1), (7, 7), ctx=ctx)
+    assert ctx.last_path() == core.PATH_GENERIC_F64               # SSD of 16-bit integers: order free, float64 tile kernel
+    assert np.array_equal(got, oracle.calc_disparity(SQ, i16, r16, (7, 7), (17, 1)))
 
 
 @pytest.mark.parametrize("cost", [ABS, SQ, NCC])
