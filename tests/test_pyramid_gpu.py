@@ -266,3 +266,20 @@ def test_pyramid_lr_disp_diff(vw, oracle, algorithm):
     with pytest.raises(ArgumentErr):
         vw.pyramid_correlate(left, right, None, None, 0, 0.0, box, (7, 7), 0, consistency_threshold=2, bbox=BBox2i(0, 0, 100, 100),
                              lr_disp_diff=dg, region_ul=(30, 20))
+
+
+def test_corr_timeout_estimate(vw, oracle):
+    """corr_timeout (CorrelationView.cc:620-637): zones are dropped when seconds_per_op * search volume would pass the budget.
+    While the estimate stays within 2 s of the last wall-clock measurement it is the estimate alone that decides — identical to
+    the oracle; a seconds_per_op calibrated for a slow CPU is re-measured against the wall clock and cannot stop the GPU early."""
+    left, right, scale, trans, search = scenes.pyramid_scene("u8")
+    # per-zone estimates of a few ms: the budget runs out in the middle of level 0 on both sides
+    g = vw.pyramid_correlate(left, right, None, None, 0, 0.0, _box(search), (7, 7), 0, 1, 2e-7, -1, 0, 5, 5)
+    o = oracle.pyramid_correlate(left, right, None, None, 0, 0.0, search, (7, 7), 0, 1, 2e-7, -1, 5, 5)
+    assert np.array_equal(g, o)
+    full = vw.pyramid_correlate(left, right, None, None, 0, 0.0, _box(search), (7, 7), 0, 0, 0.0, -1, 0, 5, 5)
+    assert (g[..., 2] != 0).sum() < 0.8 * (full[..., 2] != 0).sum()          # the budget really ran out
+    # an absurd seconds_per_op (3 s per top-level zone): the reference would re-measure after 2 s of ESTIMATE and carry on with the
+    # wall clock; so does the engine: the tile completes
+    g2 = vw.pyramid_correlate(left, right, None, None, 0, 0.0, _box(search), (7, 7), 0, 5, 1e-3, -1, 0, 5, 5)
+    assert (g2[..., 2] != 0).mean() > 0.5

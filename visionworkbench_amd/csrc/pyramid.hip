@@ -18,7 +18,10 @@
 // the reference's own summation order (bm_exact.hip); the class of every level is measured on the device.
 // Not covered: the MGM variants (VW_CORRELATION_MGM / _FINAL_MGM answer NoImplErr); collar_size is applied by the caller
 // (PyramidCorrelationView::rasterize, CorrelationView.h:123-133: a larger tile is rasterised and cropped).
+#include <chrono>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -570,7 +573,17 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   std::vector<vwgpu::LeafExtent> leaf_ext;
   std::vector<SearchZone> zones;
   zones.push_back(SearchZone{IBox(0, 0, lmp[L].w, lmp[L].h), IBox(0, 0, search.width() / up + 1, search.height() / up + 1)});
-  double estim = 0.0;
+  // corr_timeout accounting (CorrelationView.cc:285-287,354-357,620-637): the estimate seconds_per_op * search volume is
+  // replaced by the wall clock whenever it has advanced by more than measure_spacing (2 s) since the last measurement
+  // (std::time: whole seconds), so a seconds_per_op calibrated for the CPU cannot make the GPU quit after milliseconds.
+  double estim = 0.0, prev_estim = 0.0;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto remeasure = [&]() {
+    if (P->corr_timeout > 0 && estim - prev_estim > 2.0) {
+      estim = std::floor(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+      prev_estim = estim;
+    }
+  };
   const int saved_force = ctx->forced_path;
   int dw = 0, dh = 0;
   for (int level = L; level >= 0; --level) {
@@ -639,6 +652,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         const double next = P->seconds_per_op * ((double)lr.width() * lr.height() * z.range.width() * z.range.height());
         if (P->corr_timeout > 0 && estim + next > P->corr_timeout) break;
         estim += next;
+        remeasure();
         const int zw = z.region.dx(), zh = z.region.dy(), sx = z.range.dx(), sy = z.range.dy();
         if (zw <= 0 || zh <= 0 || sx <= 0 || sy <= 0) continue;
         if (zw > 65535 * 32 || zh > 65535 * 32) { ctx->forced_path = saved_force; return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: zone too large"); }
@@ -662,6 +676,11 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
       ctx->forced_path = saved_force;
       bool exact = exact_level[level] != 0;
       for (vwgpu_zone_task const& z : t1) exact = exact && vwgpu_bm_exact_supported(z.sx, z.sy);
+      if (getenv("VWGPU_DEBUG_ZONES")) {           // development aid: the shape of a level's work
+        size_t px = 0, ev = 0; int maxd = 0, maxw = 0, maxh = 0;
+        for (vwgpu_zone_task const& z : t1) { px += (size_t)z.zw * z.zh; ev += (size_t)z.zw * z.zh * z.sx * z.sy; maxd = std::max(maxd, z.sx * z.sy); maxw = std::max(maxw, z.zw); maxh = std::max(maxh, z.zh); }
+        fprintf(stderr, "level %d: %zu zones, %zu px, %zu evaluations, max D %d, max zone %d x %d, exact %d\n", level, t1.size(), px, ev, maxd, maxw, maxh, (int)exact);
+      }
       if (lr_active && rl_pixels) { if ((rc = vwgpu_arena_reserve(ctx, &ctx->zrl, rl_pixels * 12))) return rc; }
       if (exact) rc = vwgpu_launch_bm_exact(ctx, P->cost_type, Lv.p, Lv.w, Lv.h, Lv.w, Rv.p, Rv.w, Rv.h, Rv.w, kx, ky, t1.data(), (int)t1.size(), disp);
       else rc = vwgpu_launch_bm_zones(ctx, P->cost_type, Lv.p, Lv.w, Lv.h, Rv.p, Rv.w, Rv.h, kx, ky, t1.data(), (int)t1.size(), disp);
@@ -680,6 +699,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
       const double next = P->seconds_per_op * ((double)lr.width() * lr.height() * z.range.width() * z.range.height());
       if (P->corr_timeout > 0 && estim + next > P->corr_timeout) break;
       estim += next;
+      remeasure();
       const int zw = z.region.dx(), zh = z.region.dy(), sx = z.range.dx(), sy = z.range.dy();
       if (zw <= 0 || zh <= 0 || sx <= 0 || sy <= 0) continue;
       // the crops normally lie inside the level images; edge-extend into scratch when rounding makes them stick out
