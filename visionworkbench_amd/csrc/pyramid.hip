@@ -569,7 +569,6 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   SP.cost_type = P->cost_type; SP.use_mgm = 0; SP.kernel_size = kx; SP.subpixel_mode = P->sgm_subpixel_mode;
   SP.search_buffer_x = P->sgm_search_buffer_x; SP.search_buffer_y = P->sgm_search_buffer_y; SP.memory_limit_mb = P->memory_limit_mb;
   SP.p1 = 0; SP.p2 = 0; SP.ternary_census_threshold = 5; SP.num_threads = P->sgm_num_threads > 0 ? P->sgm_num_threads : 1;
-  std::vector<vwgpu::IBox> leaves;
   std::vector<vwgpu::LeafExtent> leaf_ext;
   std::vector<SearchZone> zones;
   zones.push_back(SearchZone{IBox(0, 0, lmp[L].w, lmp[L].h), IBox(0, 0, search.width() / up + 1, search.height() / up + 1)});
@@ -578,6 +577,10 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   // (std::time: whole seconds), so a seconds_per_op calibrated for the CPU cannot make the GPU quit after milliseconds.
   double estim = 0.0, prev_estim = 0.0;
   const auto t_start = std::chrono::steady_clock::now();
+  const bool dbg_time = getenv("VWGPU_DEBUG_TIMING") != nullptr;     // development aid: host-side timeline of a tile on stderr
+  auto stamp = [&](const char* what, int level) {
+    if (dbg_time) fprintf(stderr, "  [%8.1f us] level %d %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(), level, what);
+  };
   auto remeasure = [&]() {
     if (P->corr_timeout > 0 && estim - prev_estim > 2.0) {
       estim = std::floor(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
@@ -589,6 +592,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   for (int level = L; level >= 0; --level) {
     const bool last = (level == 0);
     const int scaling = 1 << level;
+    stamp("begin", level);
     dw = lmp[level].w; dh = lmp[level].h;
     VWGPU_HIP(ctx, hipMemsetAsync(disp, 0, (size_t)dw * dh * 12, st));
     const int rox = up * hkx / scaling, roy = up * hky / scaling;
@@ -674,6 +678,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         }
       }
       ctx->forced_path = saved_force;
+      stamp("zone tables built", level);
       bool exact = exact_level[level] != 0;
       for (vwgpu_zone_task const& z : t1) exact = exact && vwgpu_bm_exact_supported(z.sx, z.sy);
       if (getenv("VWGPU_DEBUG_ZONES")) {           // development aid: the shape of a level's work
@@ -741,6 +746,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
       hipLaunchKernelGGL(add_offset_kernel, grid2(zw, zh), kBlk, 0, st, zout, dw, zw, zh, z.range.x0, z.range.y0);
     }
     ctx->forced_path = saved_force;
+    stamp("matchers queued", level);
     // clean-up filters (:702-744)
     if (P->filter_half_kernel > 0) {
       rc = vwgpu_launch_disparity_filter(ctx, disp, dw, dh, P->filter_half_kernel, P->filter_half_kernel, 3.0, 0.5, !last, padded, disp2);
@@ -772,22 +778,34 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     if (!last && !use_sgm) {
       // The quad tree of boxes is fixed by (dw, dh): its leaves are measured on the device (box + 1-px neighbourhood),
       // only that table comes back, and the accept / retry / merge recursion runs on it (zones.hip).
-      leaves.clear();
-      vwgpu::enumerate_leaves(dw, dh, leaves);
+      const std::vector<vwgpu::IBox>& leaves = vwgpu::cached_leaves(dw, dh);
       const size_t nleaf = leaves.size();
-      const size_t rect_bytes = vwgpu_align_up(nleaf * sizeof(int4), 256), ext_bytes = nleaf * sizeof(vwgpu::LeafExtent);
-      if ((rc = vwgpu_arena_reserve(ctx, &ctx->zext, rect_bytes + ext_bytes + 256))) return rc;
-      int4* d_rects = static_cast<int4*>(ctx->zext.base);
-      int32_t* d_ext = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->zext.base) + rect_bytes);
       static_assert(sizeof(vwgpu::IBox) == sizeof(int4), "leaf boxes upload as int4");
-      VWGPU_HIP(ctx, hipMemcpyAsync(d_rects, leaves.data(), nleaf * sizeof(int4), hipMemcpyHostToDevice, st));
+      // the leaf boxes of a level size go to the device once per context
+      int4* d_rects = nullptr;
+      for (auto& lr : ctx->leaf_rects)
+        if (lr.w == dw && lr.h == dh && lr.n == nleaf) d_rects = static_cast<int4*>(lr.d_rects);
+      if (!d_rects) {
+        void* p = nullptr;
+        VWGPU_HIP(ctx, hipMalloc(&p, std::max<size_t>(nleaf, 1) * sizeof(int4)));
+        VWGPU_HIP(ctx, hipMemcpyAsync(p, leaves.data(), nleaf * sizeof(int4), hipMemcpyHostToDevice, st));
+        VWGPU_HIP(ctx, hipStreamSynchronize(st));                 // the host list may be evicted from its cache later
+        if (ctx->leaf_rects.size() >= 64) { (void)hipFree(ctx->leaf_rects.front().d_rects); ctx->leaf_rects.erase(ctx->leaf_rects.begin()); }
+        ctx->leaf_rects.push_back({dw, dh, nleaf, p});
+        d_rects = static_cast<int4*>(p);
+      }
+      const size_t ext_bytes = nleaf * sizeof(vwgpu::LeafExtent);
+      if ((rc = vwgpu_arena_reserve(ctx, &ctx->zext, ext_bytes + 256))) return rc;
+      int32_t* d_ext = static_cast<int32_t*>(ctx->zext.base);
       {
         vwgpu_prof_scope ps(ctx, "zone_extents");
         hipLaunchKernelGGL(zone_extent_kernel, dim3((unsigned)nleaf), dim3(64), 0, st, disp, dw, dh, d_rects, (int)nleaf, d_ext);
       }
       leaf_ext.resize(nleaf);
       VWGPU_HIP(ctx, hipMemcpyAsync(leaf_ext.data(), d_ext, ext_bytes, hipMemcpyDeviceToHost, st));
+      stamp("level queued, waiting", level);
       VWGPU_HIP(ctx, hipStreamSynchronize(st));
+      stamp("leaf extents on the host", level);
       zones.clear();
       vwgpu::subdivide_regions_from_leaves(dw, dh, kx, ky, leaf_ext.data(), nleaf, zones);
       const IBox scale_search(0, 0, rp[level - 1].w - lp[level - 1].w, rp[level - 1].h - lp[level - 1].h);
@@ -800,6 +818,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         z.range.clip(scale_search);
         if (z.range.empty()) z.range = IBox(0, 0, search.width(), search.height());
       }
+      stamp("zones of the next level ready", level);
     }
   }
   if (dw != bw || dh != bh) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "PyramidCorrelation: Solved disparity doesn't match requested bbox size.");

@@ -115,6 +115,7 @@ void vwgpu_destroy(vwgpu_ctx* ctx) {
   if (ctx->zext.base) (void)hipFree(ctx->zext.base);
   if (ctx->sgm.base) (void)hipFree(ctx->sgm.base);
   if (ctx->sgm_main.base) (void)hipFree(ctx->sgm_main.base);
+  for (auto& lr : ctx->leaf_rects) if (lr.d_rects) (void)hipFree(lr.d_rects);
   if (ctx->xvol.base) (void)hipFree(ctx->xvol.base);
   if (ctx->xtab.base) (void)hipFree(ctx->xtab.base);
   if (ctx->staging.base) (void)hipFree(ctx->staging.base);

@@ -50,6 +50,8 @@ struct vwgpu_ctx {
   vwgpu_arena sgm_main;  // SGM: ragged cost (u8) + accumulated cost (u16) buffers
   vwgpu_arena xvol;      // exact-order path: column-sum volumes, band state, per-zone NCC precision images (bm_exact.hip)
   vwgpu_arena xtab;      // exact-order path: zone / work-item tables of one call
+  struct LeafRects { int w, h; size_t n; void* d_rects; };
+  std::vector<LeafRects> leaf_rects;   // zone scheduler: device copies of the leaf boxes of the level sizes seen so far
   bool defer_exact = false;   // VWGPU_OPT_DEFER_EXACTNESS: calc_disparity_dev never waits for the input-class flags
   int num_cu = 256;
 };

@@ -46,6 +46,7 @@ struct LeafExtent {          // 10 ints per leaf, as the kernel writes them
   int32_t any_a, lo_xa, lo_ya, hi_xa, hi_ya;      // ... inside the box grown by 1 px (clipped to the image)
 };
 void enumerate_leaves(int w, int h, std::vector<IBox>& leaves);
+const std::vector<IBox>& cached_leaves(int w, int h);     // the same list, kept per thread and image size
 void subdivide_regions_from_leaves(int w, int h, int kx, int ky, const LeafExtent* leaf, size_t nleaf, std::vector<SearchZone>& out);
 
 }  // namespace vwgpu

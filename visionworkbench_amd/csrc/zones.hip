@@ -157,18 +157,52 @@ void subdivide_regions(const int32_t* disp, int w, int h, int kx, int ky, std::v
   split(tree, 0, disp, w, h, kx, ky, 0, out);
 }
 
-void enumerate_leaves(int w, int h, std::vector<IBox>& leaves) {
-  std::vector<Node> tree;
-  tree.reserve(((size_t)w * h) / 48 + 16);
-  build(tree, nullptr, w, IBox(0, 0, w, h), nullptr, nullptr, &leaves);
+// The tree of boxes for an image size, built once per thread (a context lives on one thread and its tiles repeat the same level
+// sizes): the per-call work is filling the leaf extents, the bottom-up unions and the accept / retry / merge walk.
+namespace {
+struct CachedTree {
+  int w = -1, h = -1;
+  std::vector<Node> nodes;          // depth-first preorder: children follow their parent
+  std::vector<int> leaf_nodes;      // node index of every leaf, in leaf order
+  std::vector<IBox> leaves;
+};
+CachedTree& cached_tree(int w, int h) {
+  static thread_local std::vector<CachedTree> cache;
+  for (CachedTree& t : cache)
+    if (t.w == w && t.h == h) return t;
+  if (cache.size() >= 32) cache.erase(cache.begin());
+  cache.emplace_back();
+  CachedTree& t = cache.back();
+  t.w = w; t.h = h;
+  t.nodes.reserve(((size_t)w * h) / 48 + 16);
+  build(t.nodes, nullptr, w, IBox(0, 0, w, h), nullptr, nullptr, &t.leaves);
+  for (size_t i = 0; i < t.nodes.size(); ++i)
+    if (t.nodes[i].child[0] < 0) t.leaf_nodes.push_back((int)i);
+  return t;
 }
+}  // namespace
+
+const std::vector<IBox>& cached_leaves(int w, int h) { return cached_tree(w, h).leaves; }
+
+void enumerate_leaves(int w, int h, std::vector<IBox>& leaves) { leaves = cached_tree(w, h).leaves; }
 
 void subdivide_regions_from_leaves(int w, int h, int kx, int ky, const LeafExtent* leaf, size_t nleaf, std::vector<SearchZone>& out) {
-  std::vector<Node> tree;
-  tree.reserve(nleaf * 2 + 16);
-  size_t next = 0;
-  build(tree, nullptr, w, IBox(0, 0, w, h), leaf, &next);
-  split(tree, 0, nullptr, w, h, kx, ky, 0, out);
+  CachedTree& t = cached_tree(w, h);
+  if (nleaf != t.leaf_nodes.size()) return;
+  for (size_t i = 0; i < nleaf; ++i) {
+    const LeafExtent& e = leaf[i];
+    Node& n = t.nodes[t.leaf_nodes[i]];
+    n.ext.any = e.any != 0; n.ext.lo_x = e.lo_x; n.ext.lo_y = e.lo_y; n.ext.hi_x = e.hi_x; n.ext.hi_y = e.hi_y;
+    n.around.any = e.any_a != 0; n.around.lo_x = e.lo_xa; n.around.lo_y = e.lo_ya; n.around.hi_x = e.hi_xa; n.around.hi_y = e.hi_ya;
+  }
+  for (size_t i = t.nodes.size(); i-- > 0;) {                     // unions bottom up: children have larger indices
+    Node& n = t.nodes[i];
+    if (n.child[0] < 0) continue;
+    Extent e;
+    for (int c = 0; c < 4; ++c) e = unite(e, t.nodes[n.child[c]].ext);
+    n.ext = e;
+  }
+  split(t.nodes, 0, nullptr, w, h, kx, ky, 0, out);
 }
 
 }  // namespace vwgpu
