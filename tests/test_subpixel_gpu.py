@@ -57,8 +57,11 @@ def test_null_test_golden(ctx, oracle, mode):
 
 
 @pytest.mark.parametrize("kernel", [(7, 7), (11, 11), (5, 3)])
-def test_integer_imagery_is_bit_exact(ctx, oracle, kernel):
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (1.0, -100.0), (200.0, 0.0), (3000.0, -70000.0)])
+def test_integer_imagery_is_bit_exact(ctx, oracle, kernel, scale, offset):
+    """Integer imagery: bytes (v_sad_u8 form), negative / 16-bit / 20-bit integers (v_sad_u32 form) — all exact."""
     left, right, _ = synth.stereo_pair(160, 70, 17, 3, block=32, seeds=(41, 42, 43), smooth=True)
+    left, right = left * np.float32(scale) + np.float32(offset), right * np.float32(scale) + np.float32(offset)
     right = np.ascontiguousarray(right[:70 + 2, :160 + 16])
     disp = _disp_from_bm(oracle, left, right, kernel, (17, 3))
     disp[5:9, 20:40, 2] = 0                                       # some invalid pixels

@@ -246,7 +246,8 @@ bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__
 
 // ---- order-freeness of an image: lowest set bit and magnitude of its pixels ------------------------------------------
 // cell[0] = min over non-zero pixels of the exponent of the lowest set mantissa bit, cell[1] = max exponent,
-// cell[2] != 0: a non-finite pixel.  (Every pixel is an integer multiple of 2^cell[0] and smaller than 2^(cell[1]+1).)
+// cell[2] bit 0: a non-finite pixel, bit 1: a negative pixel.  (Every pixel is an integer multiple of 2^cell[0] and smaller
+// in magnitude than 2^(cell[1]+1).)
 // One launch measures up to GRAIN_MAX images (blockIdx.y = image), GRAIN_BLOCKS workgroups each: one set of atomics per
 // WORKGROUP and few workgroups, because same-address atomics serialise at the L2.
 constexpr int GRAIN_MAX = 32, GRAIN_BLOCKS = 32;
@@ -268,8 +269,9 @@ float_grain_kernel(GrainJobs jobs) {
   auto take = [&](unsigned u) __attribute__((always_inline)) {
     const int e = (int)((u >> 23) & 0xffu);
     unsigned m = u & 0x7fffffu;
-    if (e == 0xff) { bad = 1; return; }
+    if (e == 0xff) { bad |= 1; return; }
     if (e == 0 && m == 0) return;                               // +-0
+    if (u >> 31) bad |= 2;                                      // a negative pixel
     int base;
     if (e == 0) base = -149;                                    // subnormal: m * 2^-149
     else { m |= 0x800000u; base = e - 127 - 23; }
@@ -300,7 +302,7 @@ float_grain_kernel(GrainJobs jobs) {
     for (int i = 1; i < 4; ++i) { lo = min(lo, part[i][0]); hi = max(hi, part[i][1]); bad |= part[i][2]; }
     int* cell = jobs.cell[j];
     if (lo != INT_MAX) { atomicMin(&cell[0], lo); atomicMax(&cell[1], hi); }
-    if (bad) atomicOr(&cell[2], 1);
+    if (bad) atomicOr(&cell[2], bad);
   }
 }
 
@@ -402,7 +404,7 @@ bool vwgpu_bm_exact_supported(int sx, int sy) { return (long long)sx * sy <= 64L
 // every intermediate value of the reference's chains — at most 2 * kx * ky elements in magnitude — is exactly
 // representable in float64 iff it stays below 2^53 units, in which case ANY summation order returns the same bits.
 bool vwgpu_sums_order_free(int cost_type, int kx, int ky, int lo, int hi, int nonfinite) {
-  if (nonfinite) return false;
+  if (nonfinite & 1) return false;
   if (lo == INT_MAX) return true;                       // all-zero images
   int lg = 0;
   while ((1LL << lg) < (long long)kx * ky) ++lg;

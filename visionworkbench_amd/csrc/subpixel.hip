@@ -61,7 +61,7 @@ __device__ __forceinline__ unsigned sad_u32(unsigned a, unsigned b, unsigned c) 
   return r;
 }
 
-template <int KX, bool INT>
+template <int KX, int INT>      // INT: 0 float64 sums, 1 integers below 2^21 (v_sad_u32), 2 integers in [0,255] (v_sad_u8 on packed bytes)
 __global__ void __launch_bounds__(256)
 parabola_kernel(const float* __restrict__ disp, int w, int h, ptrdiff_t dstride_px,
                 const float* __restrict__ lras, int lrw, const float* __restrict__ rras, int rrw,
@@ -92,7 +92,74 @@ parabola_kernel(const float* __restrict__ disp, int w, int h, ptrdiff_t dstride_
         patch[(ddy + 1) * 3 + (ddx + 1)] = (float)s;
       }
     }
-  } else if (INT) {
+  } else if (INT == 2) {
+    // Bytes: a row of the window is NW dwords (the last one masked); the three x shifts of the right row are byte alignments
+    // of the same kx + 2 bytes.  One v_sad_u8 covers four abs-diffs.
+    constexpr int K = KX > 0 ? KX : 1;
+    constexpr int NW = (K + 3) / 4, NB = (K + 2 + 3) / 4 + 1;       // dwords of a left row / of the kx + 2 right bytes (+1 for the alignment)
+    constexpr unsigned LAST = (K % 4 == 0) ? 0xffffffffu : ((1u << (8 * (K % 4))) - 1u);
+    unsigned s9[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) s9[a][b] = 0u;
+    auto pack_row = [&](const float* p, int n, unsigned* w, int nw) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < nw; ++j) {
+        unsigned v = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * j + e < n) v = __builtin_amdgcn_cvt_pk_u8_f32(p[4 * j + e], e, v);
+        w[j] = v;
+      }
+    };
+    unsigned la[NW], lb[NW], lc[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) { la[j] = 0u; lb[j] = 0u; }
+    pack_row(lbase, K, lc, NW);
+    const float* rrow = rras + (ptrdiff_t)(y + Dy - 1 - range_miny) * rrw + (x + Dx - 1 - range_minx);
+    for (int q = -1; q <= ky; ++q) {
+      unsigned rb[NB];
+      pack_row(rrow, K + 2, rb, NB);
+      unsigned rs[3][NW];                                  // the window bytes at x shift b = 0, 1, 2
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          rs[b][j] = b == 0 ? rb[j] : __builtin_amdgcn_alignbyte(rb[j + 1], rb[j], b);
+          if (j == NW - 1) rs[b][j] &= LAST;
+        }
+      if (q - 1 >= 0) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int j = 0; j < NW; ++j) s9[2][b] = __builtin_amdgcn_sad_u8(la[j], rs[b][j], s9[2][b]);
+      }
+      if (q >= 0 && q < ky) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int j = 0; j < NW; ++j) s9[1][b] = __builtin_amdgcn_sad_u8(lb[j], rs[b][j], s9[1][b]);
+      }
+      if (q + 1 < ky) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int j = 0; j < NW; ++j) s9[0][b] = __builtin_amdgcn_sad_u8(lc[j], rs[b][j], s9[0][b]);
+      }
+#pragma unroll
+      for (int j = 0; j < NW; ++j) { la[j] = lb[j]; lb[j] = lc[j]; }
+      if (q + 2 < ky) {
+        pack_row(lbase + (ptrdiff_t)(q + 2) * lrw, K, lc, NW);
+        lc[NW - 1] &= LAST;
+      }
+      rrow += rrw;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) patch[a * 3 + b] = (float)s9[a][b];
+  } else if (INT == 1) {
     constexpr int K = KX > 0 ? KX : 1;
     constexpr int OFF = 1 << 21;
     unsigned s9[3][3];
@@ -235,12 +302,14 @@ int vwgpu_launch_disparity_range(vwgpu_ctx* ctx, const float* disp3f, int w, int
 
 int vwgpu_launch_parabola(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t dstride_px,
                           const float* lras, int lrw, const float* rras, int rrw, int range_minx, int range_miny,
-                          int kx, int ky, float* out3f, ptrdiff_t ostride_px, bool small_integers) {
+                          int kx, int ky, float* out3f, ptrdiff_t ostride_px, int integer_class) {
   dim3 blk(64, 4), grd((w + 63) / 64, (h + 3) / 4);
-  vwgpu_prof_scope ps(ctx, small_integers ? "parabola_subpixel_int" : "parabola_subpixel");
-#define VW_PARABOLA(K) do { if (small_integers && K > 0) hipLaunchKernelGGL((parabola_kernel<K, true>), grd, blk, 0, ctx->stream, disp3f, w, h, dstride_px, \
+  vwgpu_prof_scope ps(ctx, integer_class == 2 ? "parabola_subpixel_u8" : (integer_class == 1 ? "parabola_subpixel_int" : "parabola_subpixel"));
+#define VW_PARABOLA(K) do { if (integer_class == 2 && K > 0) hipLaunchKernelGGL((parabola_kernel<K, 2>), grd, blk, 0, ctx->stream, disp3f, w, h, dstride_px, \
                                           lras, lrw, rras, rrw, range_minx, range_miny, kx, ky, out3f, ostride_px); \
-                            else hipLaunchKernelGGL((parabola_kernel<K, false>), grd, blk, 0, ctx->stream, disp3f, w, h, dstride_px, lras, lrw, rras, rrw, \
+                            else if (integer_class == 1 && K > 0) hipLaunchKernelGGL((parabola_kernel<K, 1>), grd, blk, 0, ctx->stream, disp3f, w, h, dstride_px, \
+                                          lras, lrw, rras, rrw, range_minx, range_miny, kx, ky, out3f, ostride_px); \
+                            else hipLaunchKernelGGL((parabola_kernel<K, 0>), grd, blk, 0, ctx->stream, disp3f, w, h, dstride_px, lras, lrw, rras, rrw, \
                                           range_minx, range_miny, kx, ky, out3f, ostride_px); } while (0)
   switch (kx) {
     case 3: VW_PARABOLA(3); break;   case 5: VW_PARABOLA(5); break;   case 7: VW_PARABOLA(7); break;   case 9: VW_PARABOLA(9); break;

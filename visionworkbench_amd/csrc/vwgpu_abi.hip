@@ -257,7 +257,7 @@ static int calc_disparity_classified(vwgpu_ctx* ctx, int cost_type, const float*
     if (rc) return rc;
     if (vwgpu_bm_exact_supported(sx, sy)) exact = !vwgpu_sums_order_free(cost_type, kx, ky, lo, hi, nonfinite);
     // integers below 2^16 (16-bit imagery): the packed-u16 SAD kernel; it checks the sign itself and raises its flag
-    if (!exact && !nonfinite && lo != INT_MAX && lo >= 0 && hi <= 15 && vwgpu_bm_sad_u16_supported(cost_type, kx, ky, sx, sy)) {
+    if (!exact && !nonfinite && lo != INT_MAX && lo >= 0 && hi <= 15 && vwgpu_bm_sad_u16_supported(cost_type, kx, ky, sx, sy)) {   // (nonfinite bit 1 = negative pixels)
       int* d_flag = nullptr;
       rc = vwgpu_launch_bm_sad_u16(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
       if (rc) return rc;

@@ -235,7 +235,10 @@ int vwgpu_parabola_subpixel_dev(vwgpu_ctx* ctx, const float* d_disp, int w, int 
   int r4[4];
   VWGPU_HIP(ctx, hipMemcpyAsync(r4, d_range, sizeof r4, hipMemcpyDeviceToHost, ctx->stream));
   VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));              // the ROI sizes depend on the data
-  const bool small_integers = mode == VWGPU_PREFILTER_NONE && !grain[2] && (grain[0] == INT_MAX || (grain[0] >= 0 && grain[1] <= 20));
+  // 0: any float (float64 sums); 1: integers of magnitude below 2^21; 2: integers in [0,255]
+  int integer_class = 0;
+  if (mode == VWGPU_PREFILTER_NONE && !(grain[2] & 1) && (grain[0] == INT_MAX || (grain[0] >= 0 && grain[1] <= 20)))
+    integer_class = ((grain[0] == INT_MAX || grain[1] <= 7) && !(grain[2] & 2)) ? 2 : 1;     // bytes need non-negative pixels
   const long long rminx = (long long)r4[0] - 1, rminy = (long long)r4[1] - 1;
   const long long rsx = (long long)r4[2] + 1 - r4[0] + 2, rsy = (long long)r4[3] + 1 - r4[1] + 2;
   if (rsx > 8192 || rsy > 8192 || rminx < -(1 << 20) || rminx > (1 << 20) || rminy < -(1 << 20) || rminy > (1 << 20))
@@ -256,7 +259,7 @@ int vwgpu_parabola_subpixel_dev(vwgpu_ctx* ctx, const float* d_disp, int w, int 
   if (rc) return rc;
   rc = vwgpu_prefilter_region(ctx, d_right, rw, rh, rstride, mode, width, -hx + (int)rminx, -hy + (int)rminy, rrw, rrh, rras, scratch);
   if (rc) return rc;
-  return vwgpu_launch_parabola(ctx, d_disp, w, h, dstride, lras, lrw, rras, rrw, (int)rminx, (int)rminy, kx, ky, d_out, ostride, small_integers);
+  return vwgpu_launch_parabola(ctx, d_disp, w, h, dstride, lras, lrw, rras, rrw, (int)rminx, (int)rminy, kx, ky, d_out, ostride, integer_class);
 }
 
 int vwgpu_parabola_subpixel(vwgpu_ctx* ctx, const float* disp, int w, int h, ptrdiff_t dstride,

@@ -164,7 +164,7 @@ extern "C" int vwgpu_generate_gaussian_kernel(double sigma, int size, float* tap
 int vwgpu_launch_disparity_range(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t stride_px, int* d_out4);
 int vwgpu_launch_parabola(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t dstride_px,
                           const float* lras, int lrw, const float* rras, int rrw, int range_minx, int range_miny,
-                          int kx, int ky, float* out3f, ptrdiff_t ostride_px, bool small_integers = false);
+                          int kx, int ky, float* out3f, ptrdiff_t ostride_px, int integer_class = 0);
 
 // bm_zones.hip — one row per search zone (or per R->L zone image); see the kernels for the field meaning
 struct vwgpu_zone_task {
