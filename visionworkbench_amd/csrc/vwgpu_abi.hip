@@ -246,14 +246,16 @@ static int check_bm_args(vwgpu_ctx* ctx, int cost_type, const void* l, int lw, i
 
 // Inputs outside the packed kernels' domain: float64 kernel with tile-local sums when every partial sum is exactly
 // representable (any order returns the reference's bits), the reference's serial summation order otherwise.
+struct Grain { bool known = false; int lo = 0, hi = 0, nonfinite = 0; };
+
 static int calc_disparity_classified(vwgpu_ctx* ctx, int cost_type, const float* d_left, int lw, int lh, ptrdiff_t ls,
                                      const float* d_right, int rw, int rh, ptrdiff_t rs, int kx, int ky, int sx, int sy,
-                                     int32_t* d_out, ptrdiff_t os) {
+                                     int32_t* d_out, ptrdiff_t os, Grain gr = Grain()) {
   bool exact = ctx->forced_path == VWGPU_PATH_EXACT_ORDER;
   ctx->last_flag = nullptr;
   if (ctx->forced_path == VWGPU_PATH_NONE) {
-    int lo = 0, hi = 0, nonfinite = 0;
-    int rc = vwgpu_float_grain(ctx, d_left, lw, lh, ls, d_right, lw + sx - 1, lh + sy - 1, rs, &lo, &hi, &nonfinite);
+    int lo = gr.lo, hi = gr.hi, nonfinite = gr.nonfinite;
+    int rc = gr.known ? VWGPU_OK : vwgpu_float_grain(ctx, d_left, lw, lh, ls, d_right, lw + sx - 1, lh + sy - 1, rs, &lo, &hi, &nonfinite);
     if (rc) return rc;
     if (vwgpu_bm_exact_supported(sx, sy)) exact = !vwgpu_sums_order_free(cost_type, kx, ky, lo, hi, nonfinite);
     // integers below 2^16 (16-bit imagery): the packed-u16 SAD kernel; it checks the sign itself and raises its flag
@@ -310,6 +312,16 @@ int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
   if (!try_packed)
     return calc_disparity_classified(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os);
 
+  // A context whose previous call was not byte imagery measures the class first (0.1 ms at 4096^2) instead of spending a packed-u8
+  // launch on data that will be refused again; the order of the attempts is all this changes.
+  if (ctx->forced_path == VWGPU_PATH_NONE && !ctx->defer_exact && ctx->measure_first) {
+    Grain gr;
+    rc = vwgpu_float_grain(ctx, d_left, lw, lh, ls, d_right, lw + sx - 1, lh + sy - 1, rs, &gr.lo, &gr.hi, &gr.nonfinite);
+    if (rc) return rc;
+    gr.known = true;
+    const bool bytes = !gr.nonfinite && (gr.lo == INT_MAX || (gr.lo >= 0 && gr.hi <= 7));
+    if (!bytes) return calc_disparity_classified(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, gr);
+  }
   // Integer-valued inputs in [0,255]: the packed kernels; they check the domain while converting and raise a device flag.
   int* d_flag = nullptr;
   if (sad_ok) rc = vwgpu_launch_bm_sad_u8(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
@@ -327,6 +339,7 @@ int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
   VWGPU_HIP(ctx, hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
   VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->last_flag = nullptr;
+  ctx->measure_first = flag != 0;
   if (!flag) return VWGPU_OK;
   return calc_disparity_classified(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os);
 }

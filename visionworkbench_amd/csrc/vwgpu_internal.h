@@ -52,6 +52,7 @@ struct vwgpu_ctx {
   vwgpu_arena xtab;      // exact-order path: zone / work-item tables of one call
   struct LeafRects { int w, h; size_t n; void* d_rects; };
   std::vector<LeafRects> leaf_rects;   // zone scheduler: device copies of the leaf boxes of the level sizes seen so far
+  bool measure_first = false; // the previous calc_disparity was refused by the packed-u8 kernels: measure the input class first
   bool defer_exact = false;   // VWGPU_OPT_DEFER_EXACTNESS: calc_disparity_dev never waits for the input-class flags
   int num_cu = 256;
 };
