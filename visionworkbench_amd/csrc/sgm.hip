@@ -725,9 +725,22 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2 as_us2(unsigned v) { return __builtin_bit_cast(us2, v); }
 __device__ __forceinline__ unsigned as_u32(us2 v) { return __builtin_bit_cast(unsigned, v); }
 
+// A launch may cover a WINDOW of the output (a band of rows or of columns) instead of the whole image: lines are then
+// enumerated on the window's borders, a line whose predecessor pixel lies inside the image (i.e. in the band processed before)
+// resumes from the state that band saved — the previous pixel's path vector, its minimum and its grey value — and a line that
+// leaves the window into the image saves its state for the next band.  Bands keep the accumulated-cost vectors of a launch
+// inside the 256 MB memory-side cache: the 8 read-modify-write passes over the u16 sums are what bounds the whole-image launch.
+struct Band {
+  int x0, y0, w, h;             // window in output pixels
+  int axis;                     // 0: no carry (whole image), 1: row bands (state indexed by column), 2: column bands (by row)
+  int cs;                       // dwords per saved line state
+  const unsigned* cin;          // [direction of the launch][columns or rows][cs]
+  unsigned* cout;
+};
+
 template <int EPT>      // pair slots per lane: ceil(ceil(num_disp / 2) / 64)
 __global__ void __launch_bounds__(64)
-path_uniform_pk_kernel(SgmGeom g, DirSet D, int K, int stride,
+path_uniform_pk_kernel(SgmGeom g, DirSet D, Band B, int K, int stride,
                        const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
                        const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2) {
   extern __shared__ uint16_t sm[];
@@ -740,10 +753,26 @@ path_uniform_pk_kernel(SgmGeom g, DirSet D, int K, int stride,
   uint8_t* pix = ccost + (size_t)K * stride;
   const int tid = threadIdx.x;
   int c0, r0, dc, dr;
-  line_start(D, g, blockIdx.x, dc, dr, c0, r0);
-  const int len_c = dc > 0 ? g.ocols - c0 : (dc < 0 ? c0 + 1 : 0x7fffffff);
-  const int len_r = dr > 0 ? g.orows - r0 : (dr < 0 ? r0 + 1 : 0x7fffffff);
+  SgmGeom gw = g;                                                                    // the window plays the image for the line enumeration
+  gw.ocols = B.w; gw.orows = B.h;
+  line_start(D, gw, blockIdx.x, dc, dr, c0, r0);
+  const int len_c = dc > 0 ? B.w - c0 : (dc < 0 ? c0 + 1 : 0x7fffffff);
+  const int len_r = dr > 0 ? B.h - r0 : (dr < 0 ? r0 + 1 : 0x7fffffff);
   const int len = min(len_c, len_r);
+  c0 += B.x0; r0 += B.y0;                                                            // image coordinates from here on
+  int dirq = 0;
+  while (dirq + 1 < D.n && (int)blockIdx.x >= D.line0[dirq + 1]) ++dirq;
+  const int nidx = B.axis == 1 ? g.ocols : g.orows;                                  // saved states per direction
+  const unsigned* cin = nullptr;
+  unsigned* cout = nullptr;
+  if (B.axis) {
+    const int pc = c0 - dc, pr = r0 - dr;                                            // predecessor of the first pixel
+    if (B.cin && pc >= 0 && pc < g.ocols && pr >= 0 && pr < g.orows)
+      cin = B.cin + ((size_t)dirq * nidx + (B.axis == 1 ? c0 : r0)) * B.cs;
+    const int nc = c0 + len * dc, nr = r0 + len * dr;                                // successor of the last pixel
+    if (B.cout && nc >= 0 && nc < g.ocols && nr >= 0 && nr < g.orows)
+      cout = B.cout + ((size_t)dirq * nidx + (B.axis == 1 ? nc : nr)) * B.cs;
+  }
   for (int q = tid; q < 256; q += 64) {
     unsigned v = p2;
     if (q > 0) v /= (unsigned)q;
@@ -774,6 +803,14 @@ path_uniform_pk_kernel(SgmGeom g, DirSet D, int K, int stride,
   const unsigned m32 = (unsigned)((0x100000000ull + q32 - 1) / q32);
   int last_val = -1;
   unsigned min_prior = 0;
+  if (cin) {                                                                         // resume the line where the previous band left it
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) buf[tid + e * 64] = cin[tid + e * 64];
+    last_val = (int)cin[EPT * 64];
+    min_prior = cin[EPT * 64 + 1];
+    __builtin_amdgcn_wave_barrier();
+  }
   for (int base = 0; base < len; base += K) {
     const int kk = min(K, len - base);
     const long long pbase = (long long)(r0 + base * dr) * g.ocols + (c0 + base * dc);
@@ -843,6 +880,11 @@ path_uniform_pk_kernel(SgmGeom g, DirSet D, int K, int stride,
       }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if (cout) {                                                                        // hand the line to the next band
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) cout[tid + e * 64] = buf[tid + e * 64];
+    if (tid == 0) { cout[EPT * 64] = (unsigned)last_val; cout[EPT * 64 + 1] = min_prior; }
   }
 }
 
@@ -1213,10 +1255,71 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       if (uniform && one_d && num_disp <= 256) {
         const int pe = (int)(((num_disp + 1) / 2 + 63) / 64);
         const size_t plds = (size_t)(pe * 64 + 4) * 4 + 256 * 2 + ((size_t)K * ustride * 2 + 16) + (size_t)K * ustride + K + 16;
-        if (pe == 1) hipLaunchKernelGGL(path_uniform_pk_kernel<1>, dim3(lines), dim3(64), plds, st, g, D, K, ustride, l8, lw, min_col, min_row,
-                                        cost, accum, (unsigned)p1, (unsigned)p2);
-        else hipLaunchKernelGGL(path_uniform_pk_kernel<2>, dim3(lines), dim3(64), plds, st, g, D, K, ustride, l8, lw, min_col, min_row,
-                                cost, accum, (unsigned)p1, (unsigned)p2);
+        auto launch_pk = [&](const DirSet& DS, const Band& Bd, int nlines) {
+          if (pe == 1) hipLaunchKernelGGL(path_uniform_pk_kernel<1>, dim3(nlines), dim3(64), plds, st, g, DS, Bd, K, ustride, l8, lw, min_col, min_row,
+                                          cost, accum, (unsigned)p1, (unsigned)p2);
+          else hipLaunchKernelGGL(path_uniform_pk_kernel<2>, dim3(nlines), dim3(64), plds, st, g, DS, Bd, K, ustride, l8, lw, min_col, min_row,
+                                  cost, accum, (unsigned)p1, (unsigned)p2);
+        };
+        // Bands: the accumulated-cost (u16) and cost (u8) vectors of a band of rows (or of columns, for wide strips) should fit the
+        // memory-side cache while the three directions that cross the band add into them.
+        const char* env = getenv("VWGPU_SGM_BAND_MB");
+        const size_t band_bytes = (size_t)(env ? atol(env) : 96) << 20;
+        const size_t per_px = (size_t)ustride * 3;
+        int axis = 0, bsz = 0;
+        if (together && band_bytes > 0) {
+          const size_t rows = band_bytes / ((size_t)W * per_px), cols = band_bytes / ((size_t)H * per_px);
+          if (rows >= 48 && (size_t)H >= 2 * rows) { axis = 1; bsz = (int)rows; }
+          else if (cols >= 48 && (size_t)W >= 2 * cols) { axis = 2; bsz = (int)cols; }
+        }
+        if (!axis) {
+          Band whole{0, 0, W, H, 0, 0, nullptr, nullptr};
+          launch_pk(D, whole, lines);
+        } else {
+          // Phase A, one launch over the whole image: the two directions that run along the bands (no line crosses a band border).
+          // Phases B / C: the bands in sweep order, three directions each, line states handed from band to band.
+          auto make_set = [&](const int* which, int n, int w, int h, DirSet& S) {
+            int total = 0;
+            S.n = n;
+            for (int q = 0; q < n; ++q) {
+              const Dir& d = dirs[which[q]];
+              const bool diag = d.dc != 0 && d.dr != 0;
+              S.dc[q] = d.dc; S.dr[q] = d.dr;
+              S.row_border[q] = d.dr != 0;                            // vertical and diagonal lines start on a row border first
+              S.n_first[q] = d.dr != 0 ? w : h;
+              S.second_skip[q] = diag ? (d.dr > 0 ? 1 : 0) : 0;
+              S.line0[q] = total;
+              total += S.n_first[q] + (diag ? h - 1 : 0);
+            }
+            S.line0[n] = total;
+            return total;
+          };
+          const int cs = pe * 64 + 2;
+          const int nidx = axis == 1 ? W : H;
+          rc = vwgpu_arena_reserve(ctx, &ctx->misc, 1024 + 2 * 3 * (size_t)nidx * cs * 4);
+          if (rc) return rc;
+          unsigned* carry[2] = {reinterpret_cast<unsigned*>(static_cast<char*>(ctx->misc.base) + 1024),
+                                reinterpret_cast<unsigned*>(static_cast<char*>(ctx->misc.base) + 1024) + 3 * (size_t)nidx * cs};
+          // dirs[]: 0 T->B, 1 B->T, 2 L->R, 3 R->L, 4 TL->BR, 5 TR->BL, 6 BL->TR, 7 BR->TL
+          const int along[2] = {axis == 1 ? 2 : 0, axis == 1 ? 3 : 1};
+          const int fwd[3] = {axis == 1 ? 0 : 2, 4, axis == 1 ? 5 : 6};
+          const int bwd[3] = {axis == 1 ? 1 : 3, axis == 1 ? 6 : 5, 7};
+          DirSet S;
+          Band whole{0, 0, W, H, 0, 0, nullptr, nullptr};
+          launch_pk(S, whole, make_set(along, 2, W, H, S));
+          const int total_len = axis == 1 ? H : W, nb = (total_len + bsz - 1) / bsz;
+          for (int phase = 0; phase < 2; ++phase) {
+            int pp = 0;
+            for (int bi = 0; bi < nb; ++bi) {
+              const int b = phase == 0 ? bi : nb - 1 - bi;
+              const int o0 = b * bsz, o1 = std::min(total_len, o0 + bsz);
+              Band Bd{axis == 1 ? 0 : o0, axis == 1 ? o0 : 0, axis == 1 ? W : o1 - o0, axis == 1 ? o1 - o0 : H, axis, cs,
+                      bi > 0 ? carry[pp] : nullptr, bi + 1 < nb ? carry[pp ^ 1] : nullptr};
+              launch_pk(S, Bd, make_set(phase == 0 ? fwd : bwd, 3, Bd.w, Bd.h, S));
+              pp ^= 1;
+            }
+          }
+        }
       } else if (uniform) {
 #define VWGPU_PATH_U(E) do { if (one_d) hipLaunchKernelGGL((path_uniform_kernel<E, true>), dim3(lines), dim3(64), ulds, st, g, D, K, ustride, \
                                l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2); \
