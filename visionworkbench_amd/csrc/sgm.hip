@@ -24,6 +24,7 @@
 
 #include <cstdlib>
 #include "vwgpu_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -265,13 +266,15 @@ __global__ void cost_kernel(const uint64_t* __restrict__ lc, int lcw, const uint
 // Uniform layout (every pixel searches the full range, vectors `stride` apart, stride a multiple of 16): one thread per 16
 // consecutive disparities — 16 census words of the right image in flight, one 16-byte store (4 disparities and a dword store per
 // thread ran at 0.7 TB/s: 0.79 ms for the 541 MB of a 2048^2 x 129 volume).
-__global__ void cost_uniform_kernel(const uint64_t* __restrict__ lc, int lcw, const uint64_t* __restrict__ rc, int rcw,
-                                    int ocols, int orows, int num_dx, int num_disp, int stride, int off_c, int off_r,
-                                    uint32_t* __restrict__ cost32) {
+// ONE_ROW: num_dy == 1, the disparity index is the column offset.
+template <bool ONE_ROW>
+__global__ void cost_uniform16_kernel(const uint64_t* __restrict__ lc, int lcw, const uint64_t* __restrict__ rc, int rcw,
+                                      int ocols, int orows, int num_dx, int num_disp, int stride, int off_c, int off_r,
+                                      uint32_t* __restrict__ cost32) {
   const int q = stride / 16;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-  if (t >= ocols * q) return;
-  const int c = t / q, w = t - c * q;
+  // thread <-> (pixel column c = blockIdx.x * 16 + threadIdx.y, 16-disparity group w = threadIdx.x): no division at all
+  const int w = threadIdx.x, c = blockIdx.x * blockDim.y + threadIdx.y, r = blockIdx.y;
+  if (w >= q || c >= ocols) return;
   const int bc = c + off_c, br = r + off_r;
   const uint64_t lv = lc[(size_t)br * lcw + bc];
   uint64_t rv[16];
@@ -279,7 +282,7 @@ __global__ void cost_uniform_kernel(const uint64_t* __restrict__ lc, int lcw, co
   for (int e = 0; e < 16; ++e) {
     const int i = 16 * w + e;
     const int ii = i < num_disp ? i : 0;                  // dead slots read disparity 0 and are zeroed below
-    const int qy = ii / num_dx, qx = ii - qy * num_dx;
+    const int qy = ONE_ROW ? 0 : ii / num_dx, qx = ii - qy * num_dx;
     rv[e] = rc[(size_t)(br + qy) * rcw + bc + qx];
   }
   uint32_t v[4] = {0u, 0u, 0u, 0u};
@@ -287,6 +290,37 @@ __global__ void cost_uniform_kernel(const uint64_t* __restrict__ lc, int lcw, co
   for (int e = 0; e < 16; ++e)
     if (16 * w + e < num_disp) v[e >> 2] |= (uint32_t)__popcll(lv ^ rv[e]) << (8 * (e & 3));
   reinterpret_cast<uint4*>(cost32)[((size_t)r * ocols + c) * q + w] = make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// One search row (num_dy == 1), uniform layout: a workgroup owns 256 consecutive pixels of a row, stages the 256 + D - 1 census
+// words of the right image they can reach in LDS once (6 KB at most) and every lane walks its pixel's disparities through
+// conflict-free 8-byte LDS reads (lane c reads word c + d).  The thread-per-16-disparities kernel above asked the L1 for 9-18
+// cache lines per wave load and ran at 0.7 TB/s (0.88 ms for the 606 MB of a 2048^2 x 129 volume).
+__global__ void __launch_bounds__(256)
+cost_row_kernel(const uint64_t* __restrict__ lc, int lcw, const uint64_t* __restrict__ rc, int rcw, int ocols, int num_disp, int stride,
+                int off_c, int off_r, uint4* __restrict__ cost16) {
+  extern __shared__ uint64_t words[];
+  const int tid = threadIdx.x, c0 = blockIdx.x * 256, r = blockIdx.y;
+  const int br = r + off_r, bc0 = c0 + off_c;
+  const uint64_t* rrow = rc + (size_t)br * rcw;
+  for (int i = tid; i < 256 + num_disp - 1; i += 256) words[i] = rrow[min(bc0 + i, rcw - 1)];
+  const int c = c0 + tid;
+  const uint64_t lv = lc[(size_t)br * lcw + min(bc0 + tid, lcw - 1)];
+  __syncthreads();
+  if (c >= ocols) return;
+  const int q = stride / 16;
+  uint4* o = cost16 + ((size_t)r * ocols + c) * q;
+  for (int w = 0; w < q; ++w) {
+    unsigned v[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = 16 * w + e;
+      const uint64_t rv = words[tid + min(i, num_disp - 1)];
+      const unsigned cst = i < num_disp ? (unsigned)__popcll(lv ^ rv) : 0u;      // dead slots of the stride are zero
+      v[e >> 2] |= cst << (8 * (e & 3));
+    }
+    o[w] = make_uint4(v[0], v[1], v[2], v[3]);
+  }
 }
 
 // ---- path aggregation -------------------------------------------------------------------------------------------------
@@ -316,7 +350,7 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 // so the adds are 32-bit atomics on the u16 pair that holds the element (no carry can cross the halves: the caller only
 // groups directions when 8 * (255 + max(P1, P2)) < 65536; otherwise it launches them one by one).
 struct DirSet {
-  int n;
+  int n, rev_second;
   int dc[8], dr[8], n_first[8], row_border[8], second_skip[8], line0[9];
 };
 __device__ __forceinline__ void line_start(const DirSet& D, const SgmGeom& g, int block, int& dc, int& dr, int& c, int& r) {
@@ -892,6 +926,258 @@ path_uniform_pk_kernel(SgmGeom g, DirSet D, Band B, int K, int stride,
   }
 }
 
+// ---- register-resident scan lines ---------------------------------------------------------------------------------------
+// The kernel above spends ~95 issue slots per pixel step (LDS neighbour exchange with two wave barriers, a staged chunk of costs,
+// a staged chunk of results, a bulk atomic pass with index arithmetic) and, with lane <-> pair j and j + 64, runs the whole second
+// slot for ONE live pair at 129 disparities.  Here the path vector never leaves the registers:
+//   * lane l owns the EPT CONSECUTIVE pairs l * EPT .. l * EPT + EPT - 1 (129 disparities: 33 lanes x 2 pairs), so the d-1 / d+1
+//     neighbours are the lane's own registers (`v_alignbit`) except at the two ends, which come from lane l-1 / l+1 by one DPP
+//     wave shift each;
+//   * the lane's cost bytes of a step are EPT * 2 consecutive bytes: one global load per step, issued a chunk of KC steps ahead
+//     into a second register set (no LDS, no barrier);
+//   * the lane's results are EPT consecutive dwords of the accumulator: one 64-bit (or 32-bit) atomic per step straight from the
+//     registers, addressed by a scalar base that advances by the line's stride;
+//   * everything that is uniform over the wave (the adaptive P2 of the step, min_prior, the penalties) lives on the scalar unit:
+//     the P2 values of 64 steps are computed at once, lane k for step k, and read back with v_readlane.
+// A line without predecessor starts from r = 0, min_prior = 0: min(prev..) = 0 and min(.., ctr = 0, ..) = 0, so the general step
+// yields the plain cost, exactly the reference's first pixel (SGM.cc:1013-1150).
+__device__ __forceinline__ unsigned wave_shr1(unsigned v, unsigned edge) {      // lane l <- lane l-1, lane 0 <- edge
+  return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ unsigned wave_shl1(unsigned v, unsigned edge) {      // lane l <- lane l+1, lane 63 <- edge
+  return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xF, 0xF, false);
+}
+
+template <int EPT>
+struct CostWords { static constexpr int N = EPT == 3 ? 3 : (EPT + 1) / 2; };
+
+template <int EPT>
+__device__ __forceinline__ void load_cost_words(const uint8_t* p, bool in, unsigned (&w)[CostWords<EPT>::N]) {
+  if constexpr (EPT == 1) w[0] = in ? (unsigned)*reinterpret_cast<const uint16_t*>(p) : 0u;
+  else if constexpr (EPT == 2) w[0] = in ? *reinterpret_cast<const unsigned*>(p) : 0u;
+  else if constexpr (EPT == 3) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) w[e] = in ? (unsigned)reinterpret_cast<const uint16_t*>(p)[e] : 0u;
+  } else {
+    const uint2 v = in ? *reinterpret_cast<const uint2*>(p) : make_uint2(0u, 0u);
+    w[0] = v.x; w[1] = v.y;
+  }
+}
+template <int EPT>
+__device__ __forceinline__ unsigned cost_pair(const unsigned (&w)[CostWords<EPT>::N], int e) {   // (c_2j, c_2j+1) as two u16
+  if constexpr (EPT == 3) return __builtin_amdgcn_perm(0u, w[e], 0x0c010c00u);
+  else return __builtin_amdgcn_perm(0u, w[e >> 1], (e & 1) ? 0x0c030c02u : 0x0c010c00u);
+}
+
+// Wave minimum with the DPP source fused into v_min_u32 (the compiler emits v_mov_dpp + v_min for the builtin form); a VALU
+// result needs two wait states before a DPP read, hence the s_nop 1 in front of every step of the dependent chain.
+__device__ __forceinline__ unsigned wave_min_u32_fused(unsigned v) {
+  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "s_nop 1"
+               : "+v"(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// dst keeps its value in the lane without a source (lane 0 / lane 63): initialised once to the guard 0xffffffff, never rewritten.
+__device__ __forceinline__ void wave_shr1_keep(unsigned& dst, unsigned src) {
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(dst) : "v"(src));
+}
+__device__ __forceinline__ void wave_shl1_keep(unsigned& dst, unsigned src) {
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(dst) : "v"(src));
+}
+
+// ACC: how the path costs reach the accumulated-cost volume.
+//   ACC_ATOMIC  64-bit atomics (pairs of dwords) — needed when several directions share a launch.  Measured on 2048^2 x 129, all
+//               8 directions in one launch: 8.0 ms, of which the recurrence is 3.05 ms (ACC_NONE) — device-scope atomics are executed at
+//               the memory side, one 1.2 GB read-modify-write pass per direction; 32-bit atomics: 13.4 ms;
+//   ACC_STORE   plain store: the first direction of a call initialises the volume (no memset);
+//   ACC_RMW     load (fetched a chunk ahead, like the costs) + v_pk_add_u16 + store: race-free when the launch holds ONE direction,
+//               because then every pixel lies on exactly one line.  u16 wrap-around per element, as the reference's `+=`;
+//   ACC_NONE    timing experiments only.
+// No load of the step loop sits under a condition: a lane outside the pixel's vector reads lane 0's bytes, and the fetch pointers
+// stop advancing at the last pixel of the line — with conditional loads the compiler falls back to s_waitcnt vmcnt(0) in front
+// of every chunk, i.e. no prefetch at all (measured: 770 clk per step).
+enum { ACC_ATOMIC = 1, ACC_STORE = 2, ACC_NONE = 3, ACC_RMW = 4 };
+#ifndef VWGPU_PATH_KC
+#define VWGPU_PATH_KC 8
+#endif
+template <int EPT, int ACC, int KC>
+__global__ void __launch_bounds__(64)
+path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
+                        const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned* __restrict__ dump, unsigned p1, unsigned p2) {
+  constexpr int NW = CostWords<EPT>::N;
+  const int num_disp = g.num_dx;                                                     // num_dy == 1
+  const int npairs = (num_disp + 1) / 2;
+  const int tid = threadIdx.x;
+  // the tables are indexed dynamically (they land in scratch): readfirstlane tells the compiler the values are wave-uniform
+  int dirq = 0;
+  while (dirq + 1 < D.n && (int)blockIdx.x >= D.line0[dirq + 1]) ++dirq;
+  dirq = __builtin_amdgcn_readfirstlane(dirq);
+  const int dc = __builtin_amdgcn_readfirstlane(D.dc[dirq]), dr = __builtin_amdgcn_readfirstlane(D.dr[dirq]);
+  const int ww = g.ocols, wh = g.orows;
+  int c0, r0;
+  {
+    const int line = (int)blockIdx.x - __builtin_amdgcn_readfirstlane(D.line0[dirq]);
+    const int nf = __builtin_amdgcn_readfirstlane(D.n_first[dirq]);
+    if (line < nf) {
+      if (__builtin_amdgcn_readfirstlane(D.row_border[dirq])) { c0 = line; r0 = dr > 0 ? 0 : wh - 1; }
+      else { r0 = line; c0 = dc > 0 ? 0 : ww - 1; }
+    } else {
+      // The side-border lines of a diagonal direction in the order opposite to the row-border ones (long -> short, then short ->
+      // long): all lines of a launch are resident at once, and lines i, i + n, i + 2n ... share a SIMD.
+      int i = line - nf;
+      if (D.rev_second && (dc > 0) == (dr > 0)) i = wh - 2 - i;
+      r0 = i + __builtin_amdgcn_readfirstlane(D.second_skip[dirq]);
+      c0 = dc > 0 ? 0 : ww - 1;
+    }
+  }
+  const int len_c = dc > 0 ? ww - c0 : (dc < 0 ? c0 + 1 : 0x7fffffff);
+  const int len_r = dr > 0 ? wh - r0 : (dr < 0 ? r0 + 1 : 0x7fffffff);
+  const int len = min(len_c, len_r);
+  const int q32 = stride / 2;
+  unsigned dead[EPT], r[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int j = tid * EPT + e;
+    dead[e] = j >= npairs ? 0xffffffffu : ((2 * j + 1 >= num_disp) ? 0xffff0000u : 0u);
+    r[e] = dead[e];                                      // no predecessor: r = 0 in the live elements (see above)
+  }
+  const bool in = tid * EPT + EPT <= q32;               // the lane's dwords / cost bytes lie inside the pixel's vector
+  int last_val = 0;
+  unsigned min_prior = 0;
+  // uniform (scalar) running pointers + a 32-bit lane offset for the loads; a per-lane pointer with a per-lane stride for the stores
+  const long long delta = (long long)dr * g.ocols + dc;
+  const long long pbase = (long long)r0 * g.ocols + c0;
+  const unsigned loff_c = in ? (unsigned)(tid * EPT * 2) : 0u, loff_a = in ? (unsigned)(tid * EPT) : 0u;
+  const uint8_t* cfetch = cost + pbase * stride;                    // cost vector of the next step to fetch
+  const long long cstep = delta * stride;
+  const unsigned* afetch = reinterpret_cast<const unsigned*>(accum) + pbase * q32;
+  const long long astep = delta * q32;
+  unsigned* astore = in ? reinterpret_cast<unsigned*>(accum) + pbase * q32 + loff_a : dump + tid * 4;
+  const long long astore_step = in ? astep : 0;
+  const us2 p1p1 = as_us2(p1 | (p1 << 16));
+  const uint8_t* lp = left + (size_t)(r0 + min_row) * lw + (c0 + min_col);
+  const long long lstep = (long long)dr * lw + dc;
+
+  unsigned penv = 0;
+  int pvn = (int)lp[min(tid, len - 1) * lstep];                     // grey values of the first 64 steps
+  auto refresh = [&](int s0) __attribute__((always_inline)) {      // s0 % 64 == 0: penalties of steps s0 .. s0 + 63
+    const int pv = pvn;
+    pvn = (int)lp[min(s0 + 64 + tid, len - 1) * lstep];             // next block's, a block ahead
+    const int prev = (int)wave_shr1((unsigned)pv, (unsigned)last_val);
+    int grad = pv - prev; grad = grad < 0 ? -grad : grad;
+    unsigned v = p2 / (unsigned)max(grad, 1);                        // branch-free: p2 itself where the grey value does not change
+    if (v < p1) v = p1;
+    penv = v & 0xffffu;
+    last_val = __builtin_amdgcn_readlane(pv, min(63, len - 1 - s0));
+  };
+  unsigned pm = 0xffffffffu, pn = 0xffffffffu;                      // lane 0 / lane 63 keep the guard for good
+  auto step = [&](const unsigned (&w)[NW], const unsigned (&aw)[EPT], int s) __attribute__((always_inline)) {
+    const unsigned pen = (unsigned)__builtin_amdgcn_readlane((int)penv, s & 63);
+    const unsigned dj = (min_prior + pen) & 0xffffu;
+    const us2 dJ = as_us2(dj | (dj << 16)), mp = as_us2(min_prior | (min_prior << 16));
+#ifndef VWGPU_EXP_NODPP
+    wave_shr1_keep(pm, r[EPT - 1]);
+    wave_shl1_keep(pn, r[0]);
+#endif
+    unsigned al[EPT + 1];                                           // al[e] = (d_2j-1, d_2j) of pair e; al[e+1] = (d_2j+1, d_2j+2)
+    al[0] = __builtin_amdgcn_alignbit(r[0], pm, 16);
+#pragma unroll
+    for (int e = 1; e < EPT; ++e) al[e] = __builtin_amdgcn_alignbit(r[e], r[e - 1], 16);
+    al[EPT] = __builtin_amdgcn_alignbit(pn, r[EPT - 1], 16);
+    us2 mn2 = as_us2(0xffffffffu);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const us2 ctr = as_us2(r[e]);
+      us2 m = __builtin_elementwise_min(__builtin_elementwise_min(as_us2(al[e]), as_us2(al[e + 1])), ctr);
+      us2 v = __builtin_elementwise_add_sat(m, p1p1);
+      v = __builtin_elementwise_min(v, __builtin_elementwise_min(ctr, dJ));
+      v = __builtin_elementwise_add_sat(v, as_us2(cost_pair<EPT>(w, e)));
+      v = __builtin_elementwise_sub_sat(v, mp);
+      r[e] = as_u32(v) | dead[e];
+      mn2 = e == 0 ? as_us2(r[e]) : __builtin_elementwise_min(mn2, as_us2(r[e]));
+    }
+    // dead halves put garbage into the padding of the pixel's vector (never read)
+    if constexpr (ACC == ACC_ATOMIC) {
+      if (in) {
+        if constexpr (EPT == 2 || EPT == 4) {
+#pragma unroll
+          for (int e = 0; e < EPT; e += 2)
+            atomicAdd(reinterpret_cast<unsigned long long*>(astore + e), (unsigned long long)r[e] | ((unsigned long long)r[e + 1] << 32));
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) atomicAdd(astore + e, r[e]);
+        }
+      }
+    } else if constexpr (ACC != ACC_NONE) {
+      unsigned o[EPT];
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) o[e] = ACC == ACC_RMW ? as_u32(as_us2(aw[e]) + as_us2(r[e])) : r[e];
+      if (in) {                                                      // (a shared dump slot for the other lanes: 8.5 ms instead of 5)
+        if constexpr (EPT == 2) *reinterpret_cast<uint2*>(astore) = make_uint2(o[0], o[1]);
+        else if constexpr (EPT == 4) *reinterpret_cast<uint4*>(astore) = make_uint4(o[0], o[1], o[2], o[3]);
+        else {
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) astore[e] = o[e];
+        }
+      }
+    }
+    astore += astore_step;
+    const unsigned mnu = as_u32(mn2);
+#ifdef VWGPU_EXP_NOREDUCE
+    min_prior = (unsigned)__builtin_amdgcn_readlane((int)min(mnu & 0xffffu, mnu >> 16), 5);
+#else
+    min_prior = wave_min_u32_fused(min(mnu & 0xffffu, mnu >> 16));
+#endif
+  };
+  auto fetch = [&](unsigned (&buf)[KC][NW], unsigned (&abuf)[KC][EPT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      load_cost_words<EPT>(cfetch + loff_c, true, buf[k]);
+      if constexpr (ACC == ACC_RMW) {
+        const unsigned* a = afetch + loff_a;
+        if constexpr (EPT == 2) { const uint2 v = *reinterpret_cast<const uint2*>(a); abuf[k][0] = v.x; abuf[k][1] = v.y; }
+        else if constexpr (EPT == 4) { const uint4 v = *reinterpret_cast<const uint4*>(a); abuf[k][0] = v.x; abuf[k][1] = v.y; abuf[k][2] = v.z; abuf[k][3] = v.w; }
+        else {
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) abuf[k][e] = a[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) abuf[k][e] = 0u;
+      }
+      cfetch += cstep;                                               // runs up to 2 KC steps past the line: guard zones (host side)
+      afetch += astep;
+    }
+  };
+  auto steps = [&](const unsigned (&buf)[KC][NW], const unsigned (&abuf)[KC][EPT], int s0, auto guarded) __attribute__((always_inline)) {
+    if ((s0 & 63) == 0 && s0 < len) refresh(s0);
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+      if (!decltype(guarded)::value || s0 + k < len) step(buf[k], abuf[k], s0 + k);
+  };
+
+  unsigned ca[KC][NW], cb[KC][NW], aa[KC][EPT], ab[KC][EPT];
+  const int nfull = len / KC;
+  fetch(ca, aa);
+  int ch = 0;
+  for (; ch + 2 <= nfull; ch += 2) {                                // full chunks: no per-step test
+    fetch(cb, ab);
+    steps(ca, aa, ch * KC, std::false_type());
+    fetch(ca, aa);
+    steps(cb, ab, (ch + 1) * KC, std::false_type());
+  }
+  if (ch * KC < len) {                                              // the last one or two chunks
+    fetch(cb, ab);
+    steps(ca, aa, ch * KC, std::true_type());
+    steps(cb, ab, (ch + 1) * KC, std::true_type());
+  }
+}
+
 // starts of the uniform layout: pixel p's vectors begin at p * stride
 __global__ void uniform_starts_kernel(unsigned long long* __restrict__ starts, size_t npix, unsigned long long stride) {
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -913,6 +1199,12 @@ wta_kernel(const B4* __restrict__ bounds, const unsigned long long* __restrict__
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t p0 = ((size_t)blockIdx.x * 4 + wv) * WTA_PPW;
   if (p0 >= npix) return;                                  // whole wave exits together
+  if (todo) {                                              // nothing left for this wave: leave before requesting any vector
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < WTA_PPW; ++q) any |= todo[p0 + q < npix ? p0 + q : npix - 1] != 0;
+    if (!any) return;
+  }
   uint16_t* A = sm + (size_t)wv * 2 * max_nd;
   uint16_t* Bf = A + max_nd;
   B4 bq[WTA_PPW];
@@ -1262,16 +1554,35 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   }
 
   // the two ragged buffers (separate arena: reserving may reallocate, the fixed part above must stay put)
-  rc = vwgpu_arena_reserve(ctx, &ctx->sgm_main, (size_t)main_buf * 3 + 1024);
+  // The register-resident path kernel fetches two chunks of steps ahead without looking at the end of its line: up to 16 steps
+  // past either end, i.e. 16 rows + 16 pixels before / behind a volume.  Guard zones keep those (unused) reads inside the arena.
+  const size_t guard = uniform ? vwgpu_align_up((size_t)2 * VWGPU_PATH_KC * ((size_t)g.ocols + 1) * ustride * 2, 256) : 0;
+  rc = vwgpu_arena_reserve(ctx, &ctx->sgm_main, (size_t)main_buf * 3 + 1024 + 3 * guard);
   if (rc) return rc;
-  uint8_t* cost = static_cast<uint8_t*>(ctx->sgm_main.base);
-  uint16_t* accum = reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->sgm_main.base) + vwgpu_align_up((size_t)main_buf, 256));
-  VWGPU_HIP(ctx, hipMemsetAsync(accum, 0, (size_t)main_buf * 2, st));
+  uint8_t* cost = static_cast<uint8_t*>(ctx->sgm_main.base) + guard;
+  uint16_t* accum = reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->sgm_main.base) + 2 * guard + vwgpu_align_up((size_t)main_buf, 256));
+  // 0: one direction per launch, plain store / read-modify-write (default); 1: all directions in one launch, 64-bit atomics;
+  // 2: the older LDS-staged kernel with 32-bit atomics
+  static const int paths_mode = getenv("VWGPU_SGM_PATHS") ? atoi(getenv("VWGPU_SGM_PATHS")) : 0;
+  const bool dir_paths = uniform && g.num_dy == 1 && paths_mode == 0;      // the first direction initialises the volume
+  if (!dir_paths) VWGPU_HIP(ctx, hipMemsetAsync(accum, 0, (size_t)main_buf * 2, st));
   {
     vwgpu_prof_scope ps(ctx, "sgm_cost");
     if (uniform)
-      hipLaunchKernelGGL(cost_uniform_kernel, dim3((unsigned)((g.ocols * (ustride / 16) + 255) / 256), g.orows), dim3(256), 0, st, lc, lcw, rcen, rcw,
-                         g.ocols, g.orows, g.num_dx, (int)num_disp, ustride, min_col - hk, min_row - hk, reinterpret_cast<uint32_t*>(cost));
+    {
+      const int qd = ustride / 16;                          // 16-disparity groups per pixel (<= 32 for 512 disparities)
+      const dim3 blk(qd, std::max(1, 256 / qd)), grd((g.ocols + blk.y - 1) / blk.y, g.orows);
+      static const bool old_cost = getenv("VWGPU_SGM_OLD_COST") && atoi(getenv("VWGPU_SGM_OLD_COST")) != 0;
+      if (g.num_dy == 1 && !old_cost)
+        hipLaunchKernelGGL(cost_row_kernel, dim3((g.ocols + 255) / 256, g.orows), dim3(256), (size_t)(256 + num_disp) * 8, st, lc, lcw, rcen, rcw,
+                           g.ocols, (int)num_disp, ustride, min_col - hk, min_row - hk, reinterpret_cast<uint4*>(cost));
+      else if (g.num_dy == 1)
+        hipLaunchKernelGGL(cost_uniform16_kernel<true>, grd, blk, 0, st, lc, lcw, rcen, rcw, g.ocols, g.orows, g.num_dx, (int)num_disp, ustride,
+                           min_col - hk, min_row - hk, reinterpret_cast<uint32_t*>(cost));
+      else
+        hipLaunchKernelGGL(cost_uniform16_kernel<false>, grd, blk, 0, st, lc, lcw, rcen, rcw, g.ocols, g.orows, g.num_dx, (int)num_disp, ustride,
+                           min_col - hk, min_row - hk, reinterpret_cast<uint32_t*>(cost));
+    }
     else
       hipLaunchKernelGGL(cost_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, st, lc, lcw, rcen, rcw, bounds, starts, g.ocols, npix,
                          min_col - hk, min_row - hk, cost);
@@ -1294,8 +1605,43 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     K = std::max(4, std::min(K, 32));
     const size_t ulds = ((size_t)ept * 64 + 256) * sizeof(uint16_t) + (size_t)K * ustride * 3 + K + 16;
     const bool one_d = g.num_dy == 1;
+    if (dir_paths) {
+      // One direction per launch: every pixel lies on exactly one line of a launch, so the path costs are accumulated with plain
+      // loads and stores, and the first direction stores (no memset).  (Tried: bands of rows with the directions pipelined over
+      // them, so that a band's vectors are revisited while they sit in the memory-side cache — lines of a few hundred steps pay
+      // their start-up latencies too often: 7.7 ms with 231-row bands, 15 ms with 74-row bands, against 5.9 ms unbanded.)
+      vwgpu_prof_scope ps(ctx, "sgm_paths");
+      int pe = (int)(((num_disp + 1) / 2 + 63) / 64);
+      if (pe == 3) pe = 4;                                            // a lane's pairs must not straddle the end of the vector (stride % 16 == 0)
+      static const int acc_probe = getenv("VWGPU_SGM_ACC") ? atoi(getenv("VWGPU_SGM_ACC")) : 0;   // timing experiments only: 2 store, 3 none
+      static const int rev_second = getenv("VWGPU_SGM_REV") ? atoi(getenv("VWGPU_SGM_REV")) : 1;
+      rc = vwgpu_arena_reserve(ctx, &ctx->misc, 1024 + 1024);
+      if (rc) return rc;
+      unsigned* dump = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->misc.base) + 1024);
+      // dirs[]: 0 T->B, 1 B->T, 2 L->R, 3 R->L, 4 TL->BR, 5 TR->BL, 6 BL->TR, 7 BR->TL
+      const int order[8] = {2, 3, 0, 1, 4, 5, 6, 7};
+      for (int q = 0; q < 8; ++q) {
+        const Dir& d = dirs[order[q]];
+        DirSet S;
+        S.n = 1; S.rev_second = rev_second;
+        S.dc[0] = d.dc; S.dr[0] = d.dr; S.n_first[0] = d.n_first; S.row_border[0] = d.first_is_row_border; S.second_skip[0] = d.second_skip;
+        S.line0[0] = 0;
+        const int nlines = d.n_first + d.n_second;
+        S.line0[1] = nlines;
+        if (nlines <= 0) continue;
+        const int acc = acc_probe ? acc_probe : (q == 0 ? ACC_STORE : ACC_RMW);
+#define VWGPU_PATH_DIR1(E, A) hipLaunchKernelGGL((path_uniform_reg_kernel<E, A, VWGPU_PATH_KC>), dim3(nlines), dim3(64), 0, st, g, S, ustride, l8, lw, \
+                                 min_col, min_row, cost, accum, dump, (unsigned)p1, (unsigned)p2)
+#define VWGPU_PATH_DIR(E) do { if (acc == ACC_STORE) VWGPU_PATH_DIR1(E, ACC_STORE); else if (acc == ACC_NONE) VWGPU_PATH_DIR1(E, ACC_NONE); \
+                               else VWGPU_PATH_DIR1(E, ACC_RMW); } while (0)
+        switch (pe) { case 1: VWGPU_PATH_DIR(1); break; case 2: VWGPU_PATH_DIR(2); break; default: VWGPU_PATH_DIR(4); break; }
+#undef VWGPU_PATH_DIR
+#undef VWGPU_PATH_DIR1
+      }
+    } else
     for (int first = 0; first < 8; first += together ? 8 : 1) {
       DirSet D;
+      D.rev_second = 0;
       D.n = together ? 8 : 1;
       int lines = 0;
       for (int q = 0; q < D.n; ++q) {
@@ -1307,10 +1653,18 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       D.line0[D.n] = lines;
       if (lines <= 0) continue;
       vwgpu_prof_scope ps(ctx, together ? "sgm_paths" : "sgm_path");
-      if (uniform && one_d && num_disp <= 256) {
+      if (uniform && one_d && (num_disp <= 256 || paths_mode != 2)) {
         const int pe = (int)(((num_disp + 1) / 2 + 63) / 64);
         const size_t plds = (size_t)(pe * 64 + 4) * 4 + 256 * 2 + ((size_t)K * ustride * 2 + 16) + (size_t)K * ustride + K + 16;
+        const bool old_paths = paths_mode == 2;
         auto launch_pk = [&](const DirSet& DS, const Band& Bd, int nlines) {
+#define VWGPU_PATH_REG(E) hipLaunchKernelGGL((path_uniform_reg_kernel<E, ACC_ATOMIC, 8>), dim3(nlines), dim3(64), 0, st, g, DS, ustride, l8, lw, \
+                                 min_col, min_row, cost, accum, (unsigned*)nullptr, (unsigned)p1, (unsigned)p2)
+          if (!old_paths) {                                          // every direction on the whole image, atomics
+            switch (pe) { case 1: VWGPU_PATH_REG(1); break; case 2: VWGPU_PATH_REG(2); break; default: VWGPU_PATH_REG(4); break; }
+            return;
+          }
+#undef VWGPU_PATH_REG
           if (pe == 1) hipLaunchKernelGGL(path_uniform_pk_kernel<1>, dim3(nlines), dim3(64), plds, st, g, DS, Bd, K, ustride, l8, lw, min_col, min_row,
                                           cost, accum, (unsigned)p1, (unsigned)p2);
           else hipLaunchKernelGGL(path_uniform_pk_kernel<2>, dim3(nlines), dim3(64), plds, st, g, DS, Bd, K, ustride, l8, lw, min_col, min_row,
@@ -1322,7 +1676,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
         const size_t band_bytes = (size_t)(env ? atol(env) : 96) << 20;
         const size_t per_px = (size_t)ustride * 3;
         int axis = 0, bsz = 0;
-        if (together && band_bytes > 0) {
+        if (together && band_bytes > 0 && old_paths) {
           const size_t rows = band_bytes / ((size_t)W * per_px), cols = band_bytes / ((size_t)H * per_px);
           if (rows >= 48 && (size_t)H >= 2 * rows) { axis = 1; bsz = (int)rows; }
           else if (cols >= 48 && (size_t)W >= 2 * cols) { axis = 2; bsz = (int)cols; }
@@ -1360,6 +1714,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
           const int fwd[3] = {axis == 1 ? 0 : 2, 4, axis == 1 ? 5 : 6};
           const int bwd[3] = {axis == 1 ? 1 : 3, axis == 1 ? 6 : 5, 7};
           DirSet S;
+          S.rev_second = 0;
           Band whole{0, 0, W, H, 0, 0, nullptr, nullptr};
           launch_pk(S, whole, make_set(along, 2, W, H, S));
           const int total_len = axis == 1 ? H : W, nb = (total_len + bsz - 1) / bsz;
