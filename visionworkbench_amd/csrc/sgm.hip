@@ -6,7 +6,10 @@
 //   constrain_disp_bound_image      SGM.cc:502-672               constrain_kernel (full-search pixels adopt the box of their neighbours)
 //   calc_main_buf_size              SGM.cc:677-731               row_count_kernel + host prefix over rows + row_scan_kernel (ragged starts)
 //   compute_disparity_costs         SGM.cc:1740-1893, :40-75     cost_kernel: popcount(left_census ^ right_census) inside each pixel's bounds
-//   accum_sgm_multithread           SGM.cc:2462-2612             8 launches of path_kernel, one wavefront per scan line
+//   accum_sgm_multithread           SGM.cc:2462-2612             one wavefront per scan line: path_uniform_reg_kernel (one search row, every
+//                                                                pixel the full range: path vector in registers, one direction per launch,
+//                                                                plain read-modify-write of the sums), path_uniform_kernel / path_inplace_kernel
+//                                                                / path_kernel (2-D or ragged boxes, all directions in one launch, atomics)
 //   evaluate_path (SSE semantics)   SGM.cc:936-984, 1013-1150    saturating u16 add/sub, 8-neighbour 2-D disparity adjacency with
 //                                                                repetition at the global range border, BAD_VAL outside the prior's box
 //   select_best_disparity           SGM.cc:1159-1284             wta_kernel: (value << 16 | index) min = first minimum; tie smoothing loop
@@ -15,9 +18,8 @@
 // Layout in HBM: per output pixel a box [min_x,max_x] x [min_y,max_y] of searched disparities (4 x int32) and a uint64 start
 // into two ragged arrays: cost (u8) and accumulated cost (u16) — the reference's m_cost_buffer / m_accum_buffer
 // (SGM.cc:733-751).  Algorithmic bytes ("materialised volume" model): 20 + 11 D bytes per pixel
-// (D = disparities per pixel): cost written once (D) and read by 8 paths (8 D is served from L2 for most paths), accum
-// read-modify-written per path.  The path kernel is latency bound per step (a scan line is a serial recurrence), the
-// chip is filled by running every line of a direction concurrently (>= W or H wavefronts).
+// (D = disparities per pixel): cost written once (D) and read by 8 paths, accum read-modify-written per path — 23 GB for
+// 2048^2 x 129, which is what bounds the uniform path today (5.5 ms = 4.2 TB/s; the recurrence alone runs in 2.9 ms).
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -763,169 +765,6 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2 as_us2(unsigned v) { return __builtin_bit_cast(us2, v); }
 __device__ __forceinline__ unsigned as_u32(us2 v) { return __builtin_bit_cast(unsigned, v); }
 
-// A launch may cover a WINDOW of the output (a band of rows or of columns) instead of the whole image: lines are then
-// enumerated on the window's borders, a line whose predecessor pixel lies inside the image (i.e. in the band processed before)
-// resumes from the state that band saved — the previous pixel's path vector, its minimum and its grey value — and a line that
-// leaves the window into the image saves its state for the next band.  Bands keep the accumulated-cost vectors of a launch
-// inside the 256 MB memory-side cache: the 8 read-modify-write passes over the u16 sums are what bounds the whole-image launch.
-struct Band {
-  int x0, y0, w, h;             // window in output pixels
-  int axis;                     // 0: no carry (whole image), 1: row bands (state indexed by column), 2: column bands (by row)
-  int cs;                       // dwords per saved line state
-  const unsigned* cin;          // [direction of the launch][columns or rows][cs]
-  unsigned* cout;
-};
-
-template <int EPT>      // pair slots per lane: ceil(ceil(num_disp / 2) / 64)
-__global__ void __launch_bounds__(64)
-path_uniform_pk_kernel(SgmGeom g, DirSet D, Band B, int K, int stride,
-                       const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
-                       const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2) {
-  extern __shared__ uint16_t sm[];
-  const int num_disp = g.num_dx;                                                     // num_dy == 1
-  const int npairs = (num_disp + 1) / 2;
-  unsigned* buf = reinterpret_cast<unsigned*>(sm) + 1;                               // [-1 .. EPT*64]: guards at both ends, then a sink
-  uint16_t* p2tab = sm + 2 * (EPT * 64 + 4);                                         // 256
-  unsigned* cacc = reinterpret_cast<unsigned*>(p2tab + 256);                         // K x stride/2 dwords (+ a sink), 16-byte aligned
-  uint8_t* ccost = reinterpret_cast<uint8_t*>(cacc + (size_t)K * (stride / 2) + 4);  // K x stride
-  uint8_t* pix = ccost + (size_t)K * stride;
-  const int tid = threadIdx.x;
-  int c0, r0, dc, dr;
-  SgmGeom gw = g;                                                                    // the window plays the image for the line enumeration
-  gw.ocols = B.w; gw.orows = B.h;
-  line_start(D, gw, blockIdx.x, dc, dr, c0, r0);
-  const int len_c = dc > 0 ? B.w - c0 : (dc < 0 ? c0 + 1 : 0x7fffffff);
-  const int len_r = dr > 0 ? B.h - r0 : (dr < 0 ? r0 + 1 : 0x7fffffff);
-  const int len = min(len_c, len_r);
-  c0 += B.x0; r0 += B.y0;                                                            // image coordinates from here on
-  int dirq = 0;
-  while (dirq + 1 < D.n && (int)blockIdx.x >= D.line0[dirq + 1]) ++dirq;
-  const int nidx = B.axis == 1 ? g.ocols : g.orows;                                  // saved states per direction
-  const unsigned* cin = nullptr;
-  unsigned* cout = nullptr;
-  if (B.axis) {
-    const int pc = c0 - dc, pr = r0 - dr;                                            // predecessor of the first pixel
-    if (B.cin && pc >= 0 && pc < g.ocols && pr >= 0 && pr < g.orows)
-      cin = B.cin + ((size_t)dirq * nidx + (B.axis == 1 ? c0 : r0)) * B.cs;
-    const int nc = c0 + len * dc, nr = r0 + len * dr;                                // successor of the last pixel
-    if (B.cout && nc >= 0 && nc < g.ocols && nr >= 0 && nr < g.orows)
-      cout = B.cout + ((size_t)dirq * nidx + (B.axis == 1 ? nc : nr)) * B.cs;
-  }
-  for (int q = tid; q < 256; q += 64) {
-    unsigned v = p2;
-    if (q > 0) v /= (unsigned)q;
-    if (v < p1) v = p1;
-    p2tab[q] = (uint16_t)v;
-  }
-  for (int i = tid - 1; i <= EPT * 64 + 2; i += 64) buf[i] = 0xffffffffu;           // guards + dead slots + sink
-  // No branch on "does this lane's slot exist": a missing pair reads slot 0's cost with a zero mask, carries 0xffffffff
-  // (never the minimum) and writes to a sink dword, so the per-pixel step is straight-line code.
-  int jr[EPT], jw[EPT];                                                              // slot to read costs from / to write to
-  unsigned cmask[EPT], dead[EPT];                                                    // dead: 0xffff0000 half-dead pair, ~0 missing pair
-#pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    const int j = tid + e * 64;
-    const bool live = j < npairs;
-    jr[e] = live ? j : 0;
-    jw[e] = live ? j : EPT * 64 + 1;                                                 // buf's sink
-    cmask[e] = live ? 0xffffffffu : 0u;
-    dead[e] = !live ? 0xffffffffu : ((2 * j + 1 >= num_disp) ? 0xffff0000u : 0u);
-  }
-  unsigned* const acc_sink = cacc + (size_t)K * (stride / 2);
-  const us2 p1p1 = as_us2(p1 | (p1 << 16));
-  const int q_cost = stride / 16;
-  const unsigned m_cost = (unsigned)((0x100000000ull + q_cost - 1) / q_cost);
-  const long long delta = (long long)dr * g.ocols + dc;
-  const long long d_cost = (delta - 1) * q_cost;
-  const int q32 = stride / 2;
-  const unsigned m32 = (unsigned)((0x100000000ull + q32 - 1) / q32);
-  int last_val = -1;
-  unsigned min_prior = 0;
-  if (cin) {                                                                         // resume the line where the previous band left it
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) buf[tid + e * 64] = cin[tid + e * 64];
-    last_val = (int)cin[EPT * 64];
-    min_prior = cin[EPT * 64 + 1];
-    __builtin_amdgcn_wave_barrier();
-  }
-  for (int base = 0; base < len; base += K) {
-    const int kk = min(K, len - base);
-    const long long pbase = (long long)(r0 + base * dr) * g.ocols + (c0 + base * dc);
-    {
-      const uint4* gc = reinterpret_cast<const uint4*>(cost);
-      uint4* lc = reinterpret_cast<uint4*>(ccost);
-      for (int j = tid; j < kk * q_cost; j += 64) {
-        const int k = q_cost == 1 ? j : (int)__umulhi((unsigned)j, m_cost);
-        lc[j] = gc[pbase * q_cost + j + (long long)k * d_cost];
-      }
-    }
-    if (tid < kk) pix[tid] = left[(size_t)(r0 + (base + tid) * dr + min_row) * lw + (c0 + (base + tid) * dc + min_col)];
-    __builtin_amdgcn_wave_barrier();
-    const uint16_t* cc = reinterpret_cast<const uint16_t*>(ccost);
-    unsigned* ac = cacc;
-    for (int k = 0; k < kk; ++k, cc += stride / 2, ac += stride / 2) {
-      const int vcur = pix[k];
-      unsigned res[EPT];
-      if (last_val < 0) {
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-          const unsigned cb = (unsigned)cc[jr[e]] & cmask[e];
-          res[e] = ((cb & 0xffu) | ((cb & 0xff00u) << 8)) | dead[e];
-        }
-      } else {
-        int grad = vcur - last_val; grad = grad < 0 ? -grad : grad;
-        const unsigned dj = (min_prior + (unsigned)p2tab[grad]) & 0xffffu;
-        const us2 dJ = as_us2(dj | (dj << 16)), mp = as_us2(min_prior | (min_prior << 16));
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-          const int j = tid + e * 64;
-          const unsigned pm = buf[j - 1], pc = buf[j], pn = buf[j + 1];
-          const us2 ln = as_us2(__builtin_amdgcn_alignbit(pc, pm, 16));              // (d_2j-1, d_2j)
-          const us2 rn = as_us2(__builtin_amdgcn_alignbit(pn, pc, 16));              // (d_2j+1, d_2j+2)
-          const us2 ctr = as_us2(pc);
-          us2 m = __builtin_elementwise_min(__builtin_elementwise_min(ln, rn), ctr);
-          us2 v = __builtin_elementwise_add_sat(m, p1p1);
-          v = __builtin_elementwise_min(v, __builtin_elementwise_min(ctr, dJ));
-          const unsigned cb = (unsigned)cc[jr[e]] & cmask[e];
-          v = __builtin_elementwise_add_sat(v, as_us2((cb & 0xffu) | ((cb & 0xff00u) << 8)));
-          v = __builtin_elementwise_sub_sat(v, mp);
-          res[e] = as_u32(v) | dead[e];
-        }
-      }
-      __builtin_amdgcn_wave_barrier();                                               // all neighbour reads before the in-place writes
-      us2 mn2 = as_us2(0xffffffffu);
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        buf[jw[e]] = res[e];
-        *(cmask[e] ? ac + jr[e] : acc_sink) = res[e];
-        mn2 = __builtin_elementwise_min(mn2, as_us2(res[e]));
-      }
-      const unsigned mnu = as_u32(mn2);
-      min_prior = wave_min_u32(min(mnu & 0xffffu, mnu >> 16));
-      __builtin_amdgcn_wave_barrier();
-      last_val = vcur;
-    }
-    {                                                           // bulk add: one 32-bit atomic per pair of path costs
-      unsigned* ga = reinterpret_cast<unsigned*>(accum);
-      for (int j = tid; j < kk * q32; j += 64) {
-        const int k = (int)__umulhi((unsigned)j, m32), w = j - k * q32;
-        if (w < npairs) {
-          unsigned v = cacc[j];
-          if (2 * w + 1 >= num_disp) v &= 0xffffu;
-          atomicAdd(ga + pbase * q32 + j + (long long)k * (delta - 1) * q32, v);
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (cout) {                                                                        // hand the line to the next band
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) cout[tid + e * 64] = buf[tid + e * 64];
-    if (tid == 0) { cout[EPT * 64] = (unsigned)last_val; cout[EPT * 64 + 1] = min_prior; }
-  }
-}
-
 // ---- register-resident scan lines ---------------------------------------------------------------------------------------
 // The kernel above spends ~95 issue slots per pixel step (LDS neighbour exchange with two wave barriers, a staged chunk of costs,
 // a staged chunk of results, a bulk atomic pass with index arithmetic) and, with lane <-> pair j and j + 64, runs the whole second
@@ -1008,7 +847,7 @@ enum { ACC_ATOMIC = 1, ACC_STORE = 2, ACC_NONE = 3, ACC_RMW = 4 };
 template <int EPT, int ACC, int KC>
 __global__ void __launch_bounds__(64)
 path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
-                        const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned* __restrict__ dump, unsigned p1, unsigned p2) {
+                        const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2) {
   constexpr int NW = CostWords<EPT>::N;
   const int num_disp = g.num_dx;                                                     // num_dy == 1
   const int npairs = (num_disp + 1) / 2;
@@ -1057,8 +896,8 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
   const long long cstep = delta * stride;
   const unsigned* afetch = reinterpret_cast<const unsigned*>(accum) + pbase * q32;
   const long long astep = delta * q32;
-  unsigned* astore = in ? reinterpret_cast<unsigned*>(accum) + pbase * q32 + loff_a : dump + tid * 4;
-  const long long astore_step = in ? astep : 0;
+  unsigned* astore = reinterpret_cast<unsigned*>(accum) + pbase * q32 + loff_a;      // stores are masked by `in`
+  const long long astore_step = astep;
   const us2 p1p1 = as_us2(p1 | (p1 << 16));
   const uint8_t* lp = left + (size_t)(r0 + min_row) * lw + (c0 + min_col);
   const long long lstep = (long long)dr * lw + dc;
@@ -1561,8 +1400,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   if (rc) return rc;
   uint8_t* cost = static_cast<uint8_t*>(ctx->sgm_main.base) + guard;
   uint16_t* accum = reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->sgm_main.base) + 2 * guard + vwgpu_align_up((size_t)main_buf, 256));
-  // 0: one direction per launch, plain store / read-modify-write (default); 1: all directions in one launch, 64-bit atomics;
-  // 2: the older LDS-staged kernel with 32-bit atomics
+  // 0: one direction per launch, plain store / read-modify-write (default); 1: all directions in one launch, 64-bit atomics
   static const int paths_mode = getenv("VWGPU_SGM_PATHS") ? atoi(getenv("VWGPU_SGM_PATHS")) : 0;
   const bool dir_paths = uniform && g.num_dy == 1 && paths_mode == 0;      // the first direction initialises the volume
   if (!dir_paths) VWGPU_HIP(ctx, hipMemsetAsync(accum, 0, (size_t)main_buf * 2, st));
@@ -1615,9 +1453,6 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       if (pe == 3) pe = 4;                                            // a lane's pairs must not straddle the end of the vector (stride % 16 == 0)
       static const int acc_probe = getenv("VWGPU_SGM_ACC") ? atoi(getenv("VWGPU_SGM_ACC")) : 0;   // timing experiments only: 2 store, 3 none
       static const int rev_second = getenv("VWGPU_SGM_REV") ? atoi(getenv("VWGPU_SGM_REV")) : 1;
-      rc = vwgpu_arena_reserve(ctx, &ctx->misc, 1024 + 1024);
-      if (rc) return rc;
-      unsigned* dump = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->misc.base) + 1024);
       // dirs[]: 0 T->B, 1 B->T, 2 L->R, 3 R->L, 4 TL->BR, 5 TR->BL, 6 BL->TR, 7 BR->TL
       const int order[8] = {2, 3, 0, 1, 4, 5, 6, 7};
       for (int q = 0; q < 8; ++q) {
@@ -1631,7 +1466,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
         if (nlines <= 0) continue;
         const int acc = acc_probe ? acc_probe : (q == 0 ? ACC_STORE : ACC_RMW);
 #define VWGPU_PATH_DIR1(E, A) hipLaunchKernelGGL((path_uniform_reg_kernel<E, A, VWGPU_PATH_KC>), dim3(nlines), dim3(64), 0, st, g, S, ustride, l8, lw, \
-                                 min_col, min_row, cost, accum, dump, (unsigned)p1, (unsigned)p2)
+                                 min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2)
 #define VWGPU_PATH_DIR(E) do { if (acc == ACC_STORE) VWGPU_PATH_DIR1(E, ACC_STORE); else if (acc == ACC_NONE) VWGPU_PATH_DIR1(E, ACC_NONE); \
                                else VWGPU_PATH_DIR1(E, ACC_RMW); } while (0)
         switch (pe) { case 1: VWGPU_PATH_DIR(1); break; case 2: VWGPU_PATH_DIR(2); break; default: VWGPU_PATH_DIR(4); break; }
@@ -1653,83 +1488,13 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       D.line0[D.n] = lines;
       if (lines <= 0) continue;
       vwgpu_prof_scope ps(ctx, together ? "sgm_paths" : "sgm_path");
-      if (uniform && one_d && (num_disp <= 256 || paths_mode != 2)) {
-        const int pe = (int)(((num_disp + 1) / 2 + 63) / 64);
-        const size_t plds = (size_t)(pe * 64 + 4) * 4 + 256 * 2 + ((size_t)K * ustride * 2 + 16) + (size_t)K * ustride + K + 16;
-        const bool old_paths = paths_mode == 2;
-        auto launch_pk = [&](const DirSet& DS, const Band& Bd, int nlines) {
-#define VWGPU_PATH_REG(E) hipLaunchKernelGGL((path_uniform_reg_kernel<E, ACC_ATOMIC, 8>), dim3(nlines), dim3(64), 0, st, g, DS, ustride, l8, lw, \
-                                 min_col, min_row, cost, accum, (unsigned*)nullptr, (unsigned)p1, (unsigned)p2)
-          if (!old_paths) {                                          // every direction on the whole image, atomics
-            switch (pe) { case 1: VWGPU_PATH_REG(1); break; case 2: VWGPU_PATH_REG(2); break; default: VWGPU_PATH_REG(4); break; }
-            return;
-          }
+      if (uniform && one_d && paths_mode == 1) {                     // every direction on the whole image in one launch, 64-bit atomics
+        int pe = (int)(((num_disp + 1) / 2 + 63) / 64);
+        if (pe == 3) pe = 4;
+#define VWGPU_PATH_REG(E) hipLaunchKernelGGL((path_uniform_reg_kernel<E, ACC_ATOMIC, VWGPU_PATH_KC>), dim3(lines), dim3(64), 0, st, g, D, ustride, l8, lw, \
+                                 min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2)
+        switch (pe) { case 1: VWGPU_PATH_REG(1); break; case 2: VWGPU_PATH_REG(2); break; default: VWGPU_PATH_REG(4); break; }
 #undef VWGPU_PATH_REG
-          if (pe == 1) hipLaunchKernelGGL(path_uniform_pk_kernel<1>, dim3(nlines), dim3(64), plds, st, g, DS, Bd, K, ustride, l8, lw, min_col, min_row,
-                                          cost, accum, (unsigned)p1, (unsigned)p2);
-          else hipLaunchKernelGGL(path_uniform_pk_kernel<2>, dim3(nlines), dim3(64), plds, st, g, DS, Bd, K, ustride, l8, lw, min_col, min_row,
-                                  cost, accum, (unsigned)p1, (unsigned)p2);
-        };
-        // Bands: the accumulated-cost (u16) and cost (u8) vectors of a band of rows (or of columns, for wide strips) should fit the
-        // memory-side cache while the three directions that cross the band add into them.
-        const char* env = getenv("VWGPU_SGM_BAND_MB");
-        const size_t band_bytes = (size_t)(env ? atol(env) : 96) << 20;
-        const size_t per_px = (size_t)ustride * 3;
-        int axis = 0, bsz = 0;
-        if (together && band_bytes > 0 && old_paths) {
-          const size_t rows = band_bytes / ((size_t)W * per_px), cols = band_bytes / ((size_t)H * per_px);
-          if (rows >= 48 && (size_t)H >= 2 * rows) { axis = 1; bsz = (int)rows; }
-          else if (cols >= 48 && (size_t)W >= 2 * cols) { axis = 2; bsz = (int)cols; }
-        }
-        if (!axis) {
-          Band whole{0, 0, W, H, 0, 0, nullptr, nullptr};
-          launch_pk(D, whole, lines);
-        } else {
-          // Phase A, one launch over the whole image: the two directions that run along the bands (no line crosses a band border).
-          // Phases B / C: the bands in sweep order, three directions each, line states handed from band to band.
-          auto make_set = [&](const int* which, int n, int w, int h, DirSet& S) {
-            int total = 0;
-            S.n = n;
-            for (int q = 0; q < n; ++q) {
-              const Dir& d = dirs[which[q]];
-              const bool diag = d.dc != 0 && d.dr != 0;
-              S.dc[q] = d.dc; S.dr[q] = d.dr;
-              S.row_border[q] = d.dr != 0;                            // vertical and diagonal lines start on a row border first
-              S.n_first[q] = d.dr != 0 ? w : h;
-              S.second_skip[q] = diag ? (d.dr > 0 ? 1 : 0) : 0;
-              S.line0[q] = total;
-              total += S.n_first[q] + (diag ? h - 1 : 0);
-            }
-            S.line0[n] = total;
-            return total;
-          };
-          const int cs = pe * 64 + 2;
-          const int nidx = axis == 1 ? W : H;
-          rc = vwgpu_arena_reserve(ctx, &ctx->misc, 1024 + 2 * 3 * (size_t)nidx * cs * 4);
-          if (rc) return rc;
-          unsigned* carry[2] = {reinterpret_cast<unsigned*>(static_cast<char*>(ctx->misc.base) + 1024),
-                                reinterpret_cast<unsigned*>(static_cast<char*>(ctx->misc.base) + 1024) + 3 * (size_t)nidx * cs};
-          // dirs[]: 0 T->B, 1 B->T, 2 L->R, 3 R->L, 4 TL->BR, 5 TR->BL, 6 BL->TR, 7 BR->TL
-          const int along[2] = {axis == 1 ? 2 : 0, axis == 1 ? 3 : 1};
-          const int fwd[3] = {axis == 1 ? 0 : 2, 4, axis == 1 ? 5 : 6};
-          const int bwd[3] = {axis == 1 ? 1 : 3, axis == 1 ? 6 : 5, 7};
-          DirSet S;
-          S.rev_second = 0;
-          Band whole{0, 0, W, H, 0, 0, nullptr, nullptr};
-          launch_pk(S, whole, make_set(along, 2, W, H, S));
-          const int total_len = axis == 1 ? H : W, nb = (total_len + bsz - 1) / bsz;
-          for (int phase = 0; phase < 2; ++phase) {
-            int pp = 0;
-            for (int bi = 0; bi < nb; ++bi) {
-              const int b = phase == 0 ? bi : nb - 1 - bi;
-              const int o0 = b * bsz, o1 = std::min(total_len, o0 + bsz);
-              Band Bd{axis == 1 ? 0 : o0, axis == 1 ? o0 : 0, axis == 1 ? W : o1 - o0, axis == 1 ? o1 - o0 : H, axis, cs,
-                      bi > 0 ? carry[pp] : nullptr, bi + 1 < nb ? carry[pp ^ 1] : nullptr};
-              launch_pk(S, Bd, make_set(phase == 0 ? fwd : bwd, 3, Bd.w, Bd.h, S));
-              pp ^= 1;
-            }
-          }
-        }
       } else if (uniform) {
 #define VWGPU_PATH_U(E) do { if (one_d) hipLaunchKernelGGL((path_uniform_kernel<E, true>), dim3(lines), dim3(64), ulds, st, g, D, K, ustride, \
                                l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2); \
