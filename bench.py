@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)     # 0.36 ms each: long enough to amortise the ~1.3 ms of barrier + first-launch latency
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle-ms", type=float, default=250.0, dest="settle_ms")   # untimed load before the warm-up steps (clock ramp)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measured points (config 3, SGM block, +-16 px)")
     ap.add_argument("--workload", default="config2", choices=["config2", "config4"],
@@ -310,7 +311,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # Clock settle: a fresh box idles at ~600 MHz and takes some tens of milliseconds of load to reach its sustained clock; a short
+    # run (the driver's 20 steps = 7 ms) would otherwise time the ramp (round 1: 378 us per launch in the driver's run against 348 us
+    # in a 400-step run).  Untimed, before the W warm-up steps, reported in config.clock_settle_ms.
     out = None
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        for _ in range(32):
+            out = step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         out = step()
     barrier()
@@ -375,6 +384,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 4096x4096 pair, 7x7 SAD, search_volume 129x1, calc_disparity",
                        "kernel": list(KERNEL), "search_volume": list(SEARCH),
                        "partition": "%d row strip(s), no collective in the timed region" % world, "halo": halo,
+                       "clock_settle_ms": args.settle_ms,
                        "path": {core.PATH_SAD_U8: "packed-u8 qsad", core.PATH_GENERIC_F64: "generic f64"}.get(path, "?")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

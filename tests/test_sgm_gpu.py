@@ -235,6 +235,19 @@ def test_uniform_path_many_disparities(vw, oracle, sx, sy, k, w, h):
     assert np.array_equal(gi, oi) and np.abs(gs - os_).max() < 1e-5
 
 
+@pytest.mark.parametrize("sx,k,w,h", [(6, 3, 11, 9), (63, 5, 120, 21), (126, 5, 180, 24), (127, 5, 180, 24), (129, 5, 190, 22), (254, 5, 300, 20),
+                                      (255, 5, 300, 20), (300, 5, 340, 18), (383, 3, 400, 12), (511, 3, 540, 11)])
+def test_register_path_kernel_lane_layouts(vw, oracle, sx, k, w, h):
+    """path_uniform_reg_kernel: 1, 2 and 4 disparity pairs per lane (3 is served as 4), odd and even counts, vectors that fill the
+    stride exactly, lines shorter than one prefetch chunk (the 9 x 7 output), the store / read-modify-write direction order."""
+    rng = np.random.default_rng(1000 + sx)
+    base = rng.integers(0, 256, (h + 8, w + sx + 8)).astype(np.float32)
+    left = np.ascontiguousarray(base[4:4 + h, 4:4 + w])
+    right = np.ascontiguousarray(base[4:4 + h, 2:2 + w + sx])
+    gi, gs, oi, os_ = _both(vw, oracle, CENSUS, left, right, (sx, 0), k, 5)
+    assert np.array_equal(gi, oi) and np.abs(gs - os_).max() < 1e-5
+
+
 @pytest.mark.parametrize("sx,sy,k,w,h", [(4, 0, 7, 40, 30), (8, 0, 7, 60, 48), (3, 1, 5, 20, 16), (16, 0, 7, 100, 80)])
 def test_uniform_path_detected_from_the_boxes(vw, oracle, sx, sy, k, w, h):
     """All-valid masks (the top level of every pyramid): the boxes come out full everywhere and the uniform kernel runs;
