@@ -349,6 +349,11 @@ void build_items(Tables& t, int kx, int y_begin, int y_end) {
     const int y1 = std::min(y_end, z.zh);
     for (int y0 = std::max(y_begin, 0); y0 < y1; y0 += rpw) t.row_items.push_back(make_int2((int)i, y0));
   }
+  // Longest chains first: a row item is a serial recurrence of zw steps, and the zones arrive sorted by ascending search volume —
+  // the 512-wide level-0 zones would start last and finish alone (LoG + NCC tile: 5.57 -> 5.32 ms of bmx_row).
+  std::stable_sort(t.row_items.begin(), t.row_items.end(), [&](const int2& a, const int2& b) {
+      return (long long)t.zones[a.x].zw * t.zones[a.x].nchunk > (long long)t.zones[b.x].zw * t.zones[b.x].nchunk;
+    });
   while (t.row_items.size() % 4) t.row_items.push_back(make_int2(-1, 0));
 }
 

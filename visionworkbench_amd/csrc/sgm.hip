@@ -1410,13 +1410,9 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     {
       const int qd = ustride / 16;                          // 16-disparity groups per pixel (<= 32 for 512 disparities)
       const dim3 blk(qd, std::max(1, 256 / qd)), grd((g.ocols + blk.y - 1) / blk.y, g.orows);
-      static const bool old_cost = getenv("VWGPU_SGM_OLD_COST") && atoi(getenv("VWGPU_SGM_OLD_COST")) != 0;
-      if (g.num_dy == 1 && !old_cost)
+      if (g.num_dy == 1)
         hipLaunchKernelGGL(cost_row_kernel, dim3((g.ocols + 255) / 256, g.orows), dim3(256), (size_t)(256 + num_disp) * 8, st, lc, lcw, rcen, rcw,
                            g.ocols, (int)num_disp, ustride, min_col - hk, min_row - hk, reinterpret_cast<uint4*>(cost));
-      else if (g.num_dy == 1)
-        hipLaunchKernelGGL(cost_uniform16_kernel<true>, grd, blk, 0, st, lc, lcw, rcen, rcw, g.ocols, g.orows, g.num_dx, (int)num_disp, ustride,
-                           min_col - hk, min_row - hk, reinterpret_cast<uint32_t*>(cost));
       else
         hipLaunchKernelGGL(cost_uniform16_kernel<false>, grd, blk, 0, st, lc, lcw, rcen, rcw, g.ocols, g.orows, g.num_dx, (int)num_disp, ustride,
                            min_col - hk, min_row - hk, reinterpret_cast<uint32_t*>(cost));
@@ -1452,13 +1448,12 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       int pe = (int)(((num_disp + 1) / 2 + 63) / 64);
       if (pe == 3) pe = 4;                                            // a lane's pairs must not straddle the end of the vector (stride % 16 == 0)
       static const int acc_probe = getenv("VWGPU_SGM_ACC") ? atoi(getenv("VWGPU_SGM_ACC")) : 0;   // timing experiments only: 2 store, 3 none
-      static const int rev_second = getenv("VWGPU_SGM_REV") ? atoi(getenv("VWGPU_SGM_REV")) : 1;
       // dirs[]: 0 T->B, 1 B->T, 2 L->R, 3 R->L, 4 TL->BR, 5 TR->BL, 6 BL->TR, 7 BR->TL
       const int order[8] = {2, 3, 0, 1, 4, 5, 6, 7};
       for (int q = 0; q < 8; ++q) {
         const Dir& d = dirs[order[q]];
         DirSet S;
-        S.n = 1; S.rev_second = rev_second;
+        S.n = 1; S.rev_second = 1;
         S.dc[0] = d.dc; S.dr[0] = d.dr; S.n_first[0] = d.n_first; S.row_border[0] = d.first_is_row_border; S.second_skip[0] = d.second_skip;
         S.line0[0] = 0;
         const int nlines = d.n_first + d.n_second;
