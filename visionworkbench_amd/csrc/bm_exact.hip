@@ -164,15 +164,27 @@ bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__
   const double* lp = NCC ? prec + z.lprec + (size_t)(row_ok ? y : 0) * z.zw : nullptr;
   const double SENT_BEST = NCC ? -INFINITY : INFINITY, SENT_WORST = NCC ? INFINITY : -INFINITY;
 
+  if (BOX) {                                            // one chain per lane (lanes == 1, dp == 1): the sum itself is the result
+    if (!act[0]) return;
+    double* o = outd + z.lprec + (size_t)y * z.zw;
+    const double* lead = base + kx;
+    auto put = [&](int x) __attribute__((always_inline)) { o[x] = (COST == XCOST_PREC) ? 1.0 / r[0] : r[0]; };
+    int x = 0;
+    for (; x + 4 < z.zw; x += 4) {                      // four steps' operands requested together: the chain itself is serial
+      double l[4], t[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { l[i] = lead[x + i]; t[i] = base[x + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { put(x + i); r[0] += l[i] - t[i]; }
+    }
+    for (; x < z.zw; ++x) {
+      put(x);
+      if (x + 1 < z.zw) r[0] += lead[x] - base[x];
+    }
+    return;
+  }
   int res_d = 0, res_v = 0;                             // buffered result of the step x with (x & (lanes-1)) == dl
   for (int x = 0; x < z.zw; ++x) {
-    if (BOX) {                                          // one chain per lane: the sum itself is the result
-      if (act[0]) {
-        outd[z.lprec + (size_t)y * z.zw + x] = (COST == XCOST_PREC) ? 1.0 / r[0] : r[0];
-        if (x + 1 < z.zw) r[0] += base[(size_t)(x + kx) * dp] - base[(size_t)x * dp];
-      }
-      continue;
-    }
     // this lane's candidates, in disparity order
     double c[NCH];
     double best = SENT_BEST, worst = SENT_WORST;
