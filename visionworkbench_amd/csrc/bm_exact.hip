@@ -183,31 +183,54 @@ bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__
     }
     return;
   }
+  // The operands of a step — the two column sums that advance each chain and, for NCC, the precisions — are requested one step
+  // ahead, unconditionally (idle lanes / chunks read a valid dummy address, the last step re-reads clamped indices): loaded and
+  // consumed in the same step they cost a memory round trip per step; a load under a lane condition makes the compiler drain
+  // every outstanding request (s_waitcnt vmcnt(0)) before the next use.
+  int off[NCH];
+  const double* rps[NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    off[k] = act[k] ? dk[k] : 0;
+    rps[k] = (NCC && act[k]) ? rp[k] : prec;
+  }
+  const double* lps = NCC ? (row_ok ? lp : prec) : nullptr;
+  double pl[NCH], pt[NCH], crp[NCH], nrp[NCH];
+  double clp = 0.0, nlp = 0.0;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) { pl[k] = pt[k] = crp[k] = nrp[k] = 0.0; if (NCC && k < nch) crp[k] = rps[k][0]; }
+  if (NCC) clp = lps[0];
+
   int res_d = 0, res_v = 0;                             // buffered result of the step x with (x & (lanes-1)) == dl
   for (int x = 0; x < z.zw; ++x) {
+    {
+      const size_t li = (size_t)min(x + kx, cw - 1) * dp, ti = (size_t)x * dp;
+      const int xn = min(x + 1, z.zw - 1);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+        if (k < nch) {                                  // wave-uniform
+          pl[k] = base[li + off[k]]; pt[k] = base[ti + off[k]];
+          if (NCC) nrp[k] = rps[k][xn];
+        }
+      if (NCC) nlp = lps[xn];
+    }
     // this lane's candidates, in disparity order
     double c[NCH];
     double best = SENT_BEST, worst = SENT_WORST;
     int bd = INT_MAX;
     bool nan = false;
-    const double lpx = NCC && row_ok ? lp[x] : 0.0;
+    const double lpx = clp;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       c[k] = 0.0;
       if (k < nch && act[k]) {
         double v = r[k];
-        if (NCC) v *= sqrt(lpx * rp[k][x]);             // CostFunctions.h:227-231
+        if (NCC) v *= sqrt(lpx * crp[k]);               // CostFunctions.h:227-231
         c[k] = v;
         nan |= (v != v);
         if (xbetter<COST>(v, best) || (v == best && dk[k] < bd)) { best = v; bd = dk[k]; }
         if (xbetter<COST>(worst, v)) worst = v;
       }
-    }
-    // advance the chains (Algorithms.h:92): independent of the reduction below
-    if (x + 1 < z.zw) {
-#pragma unroll
-      for (int k = 0; k < NCH; ++k)
-        if (k < nch && act[k]) r[k] += base[(size_t)(x + kx) * dp + dk[k]] - base[(size_t)x * dp + dk[k]];
     }
     // winner across the disparity lanes of the row's group
     int nanw = nan ? 1 : 0;
@@ -218,6 +241,15 @@ bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__
       if (xbetter<COST>(oc, best) || (oc == best && od < bd)) { best = oc; bd = od; }
       if (xbetter<COST>(worst, ow)) worst = ow;
     }
+    // advance the chains (Algorithms.h:92) with the operands requested at the top of the step
+    if (x + 1 < z.zw) {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+        if (k < nch && act[k]) r[k] += pl[k] - pt[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) crp[k] = nrp[k];
+    clp = nlp;
     if (__any(nanw)) {                                  // wave-uniform: some pixel of this step has a NaN cost
 #pragma unroll
       for (int k = 0; k < NCH; ++k)
