@@ -107,9 +107,21 @@ bmx_col_kernel(const float* __restrict__ A, int aw, int ah, ptrdiff_t as, const 
   }
   double* v = vol + z.vol + (size_t)col * dp + d;
   const size_t rstride = (size_t)cw * dp;
-  for (int y = y0; y < y1; ++y) {
+  int y = y0;
+  for (; y + 4 <= y1 && y + 4 < z.zh; y += 4) {         // four rows' pixels requested together: the chain itself is serial
+    double in[4], out[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { in[i] = elem(y + ky + i); out[i] = elem(y + i); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[(size_t)(y + i - y0) * rstride] = cs;
+      cs += in[i];                                      // Algorithms.h:100-103: two statements, this order
+      cs -= out[i];
+    }
+  }
+  for (; y < y1; ++y) {
     v[(size_t)(y - y0) * rstride] = cs;
-    if (y + 1 < z.zh) {                                 // Algorithms.h:100-103: two statements, this order
+    if (y + 1 < z.zh) {
       cs += elem(y + ky);
       cs -= elem(y);
     }
