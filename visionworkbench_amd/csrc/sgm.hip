@@ -542,8 +542,8 @@ path_inplace_kernel(SgmGeom g, DirSet D,
     b = bounds[p]; st = starts[p];
     cur = left[lp];
     const int nd0 = (b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
-    if (lane < nd0) cv0 = cost[st + lane];
-    if (lane + 64 < nd0) cv1 = cost[st + lane + 64];
+    cv0 = cost[st + max(min(lane, nd0 - 1), 0)];                    // unconditional, clamped (see the loop)
+    cv1 = cost[st + max(min(lane + 64, nd0 - 1), 0)];
   }
   while (inside(c, r)) {
     const int wd = b.x1 - b.x0 + 1, nd = wd * (b.y1 - b.y0 + 1);
@@ -552,11 +552,12 @@ path_inplace_kernel(SgmGeom g, DirSet D,
     B4 b_n{0, 0, -1, -1};
     unsigned long long st_n = 0;
     int cur_n = 0;
-    p += delta; lp += ldelta;
-    if (has_next) {                               // the next pixel's records: one memory round trip ahead
-      b_n = bounds[p]; st_n = starts[p];
-      cur_n = left[lp];
-    }
+    // The next pixel's records, one memory round trip ahead.  No load of the loop sits under a condition (the last pixel of a
+    // line re-reads its own records; lanes beyond a box read its last cost byte): a conditional load makes the compiler drain
+    // all outstanding requests (s_waitcnt vmcnt(0)) right after issuing them, i.e. no prefetch at all.
+    if (has_next) { p += delta; lp += ldelta; }   // wave-uniform
+    b_n = bounds[p]; st_n = starts[p];
+    cur_n = left[lp];
     const float inv_wd = __builtin_amdgcn_rcpf((float)wd);
     unsigned res[R];
     int cell[R];
@@ -591,11 +592,11 @@ path_inplace_kernel(SgmGeom g, DirSet D,
       }
     }
     // the next pixel's first cost bytes (its vector start has arrived by now)
-    unsigned cn0 = 0, cn1 = 0;
-    if (has_next) {
+    unsigned cn0, cn1;
+    {
       const int ndn = (b_n.x1 - b_n.x0 + 1) * (b_n.y1 - b_n.y0 + 1);
-      if (lane < ndn) cn0 = cost[st_n + lane];
-      if (lane + 64 < ndn) cn1 = cost[st_n + lane + 64];
+      cn0 = cost[st_n + max(min(lane, ndn - 1), 0)];
+      cn1 = cost[st_n + max(min(lane + 64, ndn - 1), 0)];
     }
     lds_barrier();
     // ---- phase 2: the new vector goes to its cells, cells only the previous box covered go back to BAD_VAL
