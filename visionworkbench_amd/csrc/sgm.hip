@@ -368,6 +368,13 @@ __device__ __forceinline__ void line_start(const DirSet& D, const SgmGeom& g, in
     c = dc > 0 ? 0 : g.ocols - 1;
   }
 }
+__device__ __forceinline__ unsigned wave_shr1(unsigned v, unsigned edge) {      // lane l <- lane l-1, lane 0 <- edge
+  return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ unsigned wave_shl1(unsigned v, unsigned edge) {      // lane l <- lane l+1, lane 63 <- edge
+  return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xF, 0xF, false);
+}
+
 __device__ __forceinline__ void accum_add_u16(uint16_t* accum, unsigned long long e, unsigned v) {
   atomicAdd(reinterpret_cast<unsigned*>(accum) + (e >> 1), v << ((e & 1) * 16));
 }
@@ -517,6 +524,17 @@ path_inplace_kernel(SgmGeom g, DirSet D,
   const int lane = threadIdx.x;
   int c, r, dc, dr;
   line_start(D, g, blockIdx.x, dc, dr, c, r);
+  // wave-uniform values live in SGPRs: with 8 waves per SIMD the vector ALU is the contended unit, the scalar unit is not
+  dc = __builtin_amdgcn_readfirstlane(dc); dr = __builtin_amdgcn_readfirstlane(dr);
+  c = __builtin_amdgcn_readfirstlane(c); r = __builtin_amdgcn_readfirstlane(r);
+  auto uni = [](B4 v) __attribute__((always_inline)) {
+    return B4{__builtin_amdgcn_readfirstlane(v.x0), __builtin_amdgcn_readfirstlane(v.y0), __builtin_amdgcn_readfirstlane(v.x1),
+              __builtin_amdgcn_readfirstlane(v.y1)};
+  };
+  auto uni64 = [](unsigned long long v) __attribute__((always_inline)) {
+    return (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
+           ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
+  };
   const unsigned BAD = (255u + p2) & 0xffffu;
   for (int i = lane; i < num_disp; i += 64) full_prior[i] = (uint16_t)BAD;
   for (int q = lane; q < 256; q += 64) {
@@ -539,8 +557,8 @@ path_inplace_kernel(SgmGeom g, DirSet D,
   long long p = (long long)r * g.ocols + c;
   long long lp = (long long)(r + min_row) * lw + (c + min_col);
   if (inside(c, r)) {
-    b = bounds[p]; st = starts[p];
-    cur = left[lp];
+    b = uni(bounds[p]); st = uni64(starts[p]);
+    cur = __builtin_amdgcn_readfirstlane((int)left[lp]);
     const int nd0 = (b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
     cv0 = cost[st + max(min(lane, nd0 - 1), 0)];                    // unconditional, clamped (see the loop)
     cv1 = cost[st + max(min(lane + 64, nd0 - 1), 0)];
@@ -604,10 +622,21 @@ path_inplace_kernel(SgmGeom g, DirSet D,
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       if (64 * k >= nd) continue;
-      if (cell[k] >= 0) {
+      const bool on = cell[k] >= 0;
+      if (on) {
         full_prior[cell[k]] = (uint16_t)res[k];
-        accum_add_u16(accum, st + lane + 64 * k, res[k]);
         mn = min(mn, res[k]);
+      }
+      // The sums are u16 pairs in dwords and device-scope atomics are executed at the memory side, one lane-operation at a time:
+      // the lane whose element is the low half of a dword adds its right neighbour's value with it (half the atomics).  Lane 0
+      // always adds its own element (it may be a high half), lane 63 only its own (its neighbour is lane 0 of the next chunk).
+      const unsigned mine = on ? res[k] : 0u;
+      const unsigned next = wave_shl1(mine, 0u);
+      const unsigned long long e = st + (unsigned)(lane + 64 * k);
+      const bool low = (e & 1ull) == 0;
+      if (on && (low || lane == 0)) {
+        const unsigned v = low ? (mine | (lane < 63 ? next << 16 : 0u)) : (mine << 16);
+        atomicAdd(reinterpret_cast<unsigned*>(accum) + (e >> 1), v);
       }
     }
     if (last_val >= 0 && (bp.x0 < b.x0 || bp.x1 > b.x1 || bp.y0 < b.y0 || bp.y1 > b.y1)) {   // wave-uniform
@@ -624,7 +653,7 @@ path_inplace_kernel(SgmGeom g, DirSet D,
     min_prior = wave_min_u32(mn);
     lds_barrier();
     bp = b; last_val = cur;
-    b = b_n; st = st_n; cur = cur_n; cv0 = cn0; cv1 = cn1;
+    b = uni(b_n); st = uni64(st_n); cur = __builtin_amdgcn_readfirstlane(cur_n); cv0 = cn0; cv1 = cn1;
     c = cn; r = rn;
   }
 }
@@ -781,13 +810,6 @@ __device__ __forceinline__ unsigned as_u32(us2 v) { return __builtin_bit_cast(un
 //     the P2 values of 64 steps are computed at once, lane k for step k, and read back with v_readlane.
 // A line without predecessor starts from r = 0, min_prior = 0: min(prev..) = 0 and min(.., ctr = 0, ..) = 0, so the general step
 // yields the plain cost, exactly the reference's first pixel (SGM.cc:1013-1150).
-__device__ __forceinline__ unsigned wave_shr1(unsigned v, unsigned edge) {      // lane l <- lane l-1, lane 0 <- edge
-  return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xF, 0xF, false);
-}
-__device__ __forceinline__ unsigned wave_shl1(unsigned v, unsigned edge) {      // lane l <- lane l+1, lane 63 <- edge
-  return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xF, 0xF, false);
-}
-
 template <int EPT>
 struct CostWords { static constexpr int N = EPT == 3 ? 3 : (EPT + 1) / 2; };
 
