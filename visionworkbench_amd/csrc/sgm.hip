@@ -582,11 +582,8 @@ path_inplace_kernel(SgmGeom g, DirSet D,
     int grad = cur - last_val; grad = grad < 0 ? -grad : grad;
     const unsigned dJ = (min_prior + (unsigned)p2tab[last_val >= 0 ? grad : 0]) & 0xffffu;
     // ---- phase 1: every read of the previous vector
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
+    auto phase1 = [&](int k) __attribute__((always_inline)) {
       const int i = lane + 64 * k;
-      res[k] = 0xffffu; cell[k] = -1;
-      if (64 * k >= nd) continue;                 // wave-uniform
       if (i < nd) {
         int qy, qx;
         divmod_f(i, wd, inv_wd, qy, qx);
@@ -608,6 +605,14 @@ path_inplace_kernel(SgmGeom g, DirSet D,
           res[k] = subs16(v, min_prior);
         }
       }
+    };
+#pragma unroll
+    for (int k = 0; k < R; ++k) { res[k] = 0xffffu; cell[k] = -1; }
+    phase1(0);                                    // boxes of up to 64 cells (nearly all): no chunk loop, no per-chunk branches
+    if (nd > 64) {
+#pragma unroll
+      for (int k = 1; k < R; ++k)
+        if (64 * k < nd) phase1(k);               // wave-uniform
     }
     // the next pixel's first cost bytes (its vector start has arrived by now)
     unsigned cn0, cn1;
@@ -619,9 +624,7 @@ path_inplace_kernel(SgmGeom g, DirSet D,
     lds_barrier();
     // ---- phase 2: the new vector goes to its cells, cells only the previous box covered go back to BAD_VAL
     unsigned mn = BAD;                           // (the minimum of an empty vector is BAD_VAL, SGMAssist.h)
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-      if (64 * k >= nd) continue;
+    auto phase2 = [&](int k) __attribute__((always_inline)) {
       const bool on = cell[k] >= 0;
       if (on) {
         full_prior[cell[k]] = (uint16_t)res[k];
@@ -638,6 +641,12 @@ path_inplace_kernel(SgmGeom g, DirSet D,
         const unsigned v = low ? (mine | (lane < 63 ? next << 16 : 0u)) : (mine << 16);
         atomicAdd(reinterpret_cast<unsigned*>(accum) + (e >> 1), v);
       }
+    };
+    phase2(0);
+    if (nd > 64) {
+#pragma unroll
+      for (int k = 1; k < R; ++k)
+        if (64 * k < nd) phase2(k);
     }
     if (last_val >= 0 && (bp.x0 < b.x0 || bp.x1 > b.x1 || bp.y0 < b.y0 || bp.y1 > b.y1)) {   // wave-uniform
       const int wp = bp.x1 - bp.x0 + 1, np = wp * (bp.y1 - bp.y0 + 1);
