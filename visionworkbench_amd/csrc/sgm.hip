@@ -368,6 +368,19 @@ __device__ __forceinline__ void line_start(const DirSet& D, const SgmGeom& g, in
     c = dc > 0 ? 0 : g.ocols - 1;
   }
 }
+// Wave minimum with the DPP source fused into v_min_u32 (the compiler emits v_mov_dpp + v_min for the builtin form); a VALU
+// result needs two wait states before a DPP read, hence the s_nop 1 in front of every step of the dependent chain.
+__device__ __forceinline__ unsigned wave_min_u32_fused(unsigned v) {
+  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "s_nop 1"
+               : "+v"(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ unsigned wave_shr1(unsigned v, unsigned edge) {      // lane l <- lane l-1, lane 0 <- edge
   return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xF, 0xF, false);
 }
@@ -556,17 +569,24 @@ path_inplace_kernel(SgmGeom g, DirSet D,
   unsigned cv0 = 0, cv1 = 0;                    // cost[st + lane], cost[st + lane + 64] of the current pixel (prefetched)
   long long p = (long long)r * g.ocols + c;
   long long lp = (long long)(r + min_row) * lw + (c + min_col);
+  // steps of the line inside the image (line_start() puts the first pixel on a border)
+  int len = 0;
   if (inside(c, r)) {
+    const int len_c = dc > 0 ? g.ocols - c : (dc < 0 ? c + 1 : 0x7fffffff);
+    const int len_r = dr > 0 ? g.orows - r : (dr < 0 ? r + 1 : 0x7fffffff);
+    len = min(len_c, len_r);
+  }
+  if (len > 0) {
     b = uni(bounds[p]); st = uni64(starts[p]);
     cur = __builtin_amdgcn_readfirstlane((int)left[lp]);
     const int nd0 = (b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
     cv0 = cost[st + max(min(lane, nd0 - 1), 0)];                    // unconditional, clamped (see the loop)
     cv1 = cost[st + max(min(lane + 64, nd0 - 1), 0)];
   }
-  while (inside(c, r)) {
+  int wd_prev = -1, qy0 = 0, qx0 = 0;             // lane's cell coordinates inside a box of width wd_prev (chunk 0)
+  for (int step = 0; step < len; ++step) {
     const int wd = b.x1 - b.x0 + 1, nd = wd * (b.y1 - b.y0 + 1);
-    const int cn = c + dc, rn = r + dr;
-    const bool has_next = inside(cn, rn);
+    const bool has_next = step + 1 < len;
     B4 b_n{0, 0, -1, -1};
     unsigned long long st_n = 0;
     int cur_n = 0;
@@ -577,6 +597,10 @@ path_inplace_kernel(SgmGeom g, DirSet D,
     b_n = bounds[p]; st_n = starts[p];
     cur_n = left[lp];
     const float inv_wd = __builtin_amdgcn_rcpf((float)wd);
+    if (wd != wd_prev) {                          // wave-uniform: the box width changes every other pixel at most
+      divmod_f(lane, max(wd, 1), inv_wd, qy0, qx0);
+      wd_prev = wd;
+    }
     unsigned res[R];
     int cell[R];
     int grad = cur - last_val; grad = grad < 0 ? -grad : grad;
@@ -585,8 +609,8 @@ path_inplace_kernel(SgmGeom g, DirSet D,
     auto phase1 = [&](int k) __attribute__((always_inline)) {
       const int i = lane + 64 * k;
       if (i < nd) {
-        int qy, qx;
-        divmod_f(i, wd, inv_wd, qy, qx);
+        int qy = qy0, qx = qx0;
+        if (k > 0) divmod_f(i, wd, inv_wd, qy, qx);
         const int dx = b.x0 + qx, dy = b.y0 + qy;
         const int xo = dx - g.min_dx, yo = dy - g.min_dy;
         cell[k] = yo * g.num_dx + xo;
@@ -659,11 +683,10 @@ path_inplace_kernel(SgmGeom g, DirSet D,
           full_prior[(dy - g.min_dy) * g.num_dx + (dx - g.min_dx)] = (uint16_t)BAD;
       }
     }
-    min_prior = wave_min_u32(mn);
+    min_prior = wave_min_u32_fused(mn);
     lds_barrier();
     bp = b; last_val = cur;
     b = uni(b_n); st = uni64(st_n); cur = __builtin_amdgcn_readfirstlane(cur_n); cv0 = cn0; cv1 = cn1;
-    c = cn; r = rn;
   }
 }
 
@@ -840,19 +863,6 @@ __device__ __forceinline__ unsigned cost_pair(const unsigned (&w)[CostWords<EPT>
   else return __builtin_amdgcn_perm(0u, w[e >> 1], (e & 1) ? 0x0c030c02u : 0x0c010c00u);
 }
 
-// Wave minimum with the DPP source fused into v_min_u32 (the compiler emits v_mov_dpp + v_min for the builtin form); a VALU
-// result needs two wait states before a DPP read, hence the s_nop 1 in front of every step of the dependent chain.
-__device__ __forceinline__ unsigned wave_min_u32_fused(unsigned v) {
-  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-               "s_nop 1"
-               : "+v"(v));
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
 // dst keeps its value in the lane without a source (lane 0 / lane 63): initialised once to the guard 0xffffffff, never rewritten.
 __device__ __forceinline__ void wave_shr1_keep(unsigned& dst, unsigned src) {
   asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(dst) : "v"(src));
