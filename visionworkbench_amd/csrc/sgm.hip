@@ -113,30 +113,32 @@ __global__ void census_kernel(const uint8_t* __restrict__ img, int w, int h, int
 
 // ---- disparity bounds -------------------------------------------------------------------------------------------------
 
-// ext[0] = min valid right row, ext[1] = max valid right row over columns [0, ocols) (SGM.cc:303-327, quirks kept:
-// the downward scan stops above row 0).  Initialised by the host to {rmh - 1, 0}.
-__global__ void mask_col_extent_kernel(const uint8_t* __restrict__ rmask, int rmw, int rmh, int ocols, int* __restrict__ ext) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  int hi = -1, lo = 0x7fffffff;
-  if (c < ocols) {
-    for (int i = rmh - 1; i > 0; --i) if (rmask[(size_t)i * rmw + c] > 0) { hi = i; break; }
-    for (int i = 0; i < rmh; ++i) if (rmask[(size_t)i * rmw + c] > 0) { lo = i; break; }
-  }
-  // one pair of atomics per wave (a column each used to send its own to the same two words)
-  for (int s = 32; s > 0; s >>= 1) { hi = max(hi, __shfl_xor(hi, s)); lo = min(lo, __shfl_xor(lo, s)); }
-  if ((threadIdx.x & 63) == 0) {
-    if (hi >= 0) atomicMax(ext + 1, hi);
-    if (lo != 0x7fffffff) atomicMin(ext, lo);
+// Rows of the right mask that hold a valid pixel in the columns [0, ocols): ext[0] = first such row, ext[1] = last such row >= 1
+// (SGM.cc:303-327 scans every column from both ends, the scan from the bottom stopping above row 0 — quirk kept).  Initialised by
+// the host to {rmh - 1, 0}.  One wave per row, coalesced.
+__global__ void __launch_bounds__(256)
+mask_col_extent_kernel(const uint8_t* __restrict__ rmask, int rmw, int rmh, int ocols, int* __restrict__ ext) {
+  const int row = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rmh) return;
+  const uint8_t* m = rmask + (size_t)row * rmw;
+  bool any = false;
+  for (int c = lane; c < ocols && c < rmw; c += 64) any |= m[c] > 0;
+  if (__any(any) && lane == 0) {
+    atomicMin(ext, row);
+    if (row > 0) atomicMax(ext + 1, row);
   }
 }
-// per output row: {min valid right column, max valid right column} (-1, -2 when none; SGM.cc:337-354)
-__global__ void mask_row_extent_kernel(const uint8_t* __restrict__ rmask, int rmw, int orows, int2* __restrict__ rowext) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+// Per row of the right mask: (first, last) valid column, the last one searched down to column 1 only ((-1, -2) without one).
+__global__ void __launch_bounds__(256)
+mask_row_extent_kernel(const uint8_t* __restrict__ rmask, int rmw, int orows, int2* __restrict__ rowext) {
+  const int r = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= orows) return;
-  int mn = -1, mx = -2;
-  for (int i = rmw - 1; i > 0; --i) if (rmask[(size_t)r * rmw + i] > 0) { mx = i; break; }
-  if (mx > 0) for (int i = 0; i < rmw; ++i) if (rmask[(size_t)r * rmw + i] > 0) { mn = i; break; }
-  rowext[r] = make_int2(mn, mx);
+  const uint8_t* m = rmask + (size_t)r * rmw;
+  int mn = 0x7fffffff, mx = -2;
+  for (int i = lane; i < rmw; i += 64)
+    if (m[i] > 0) { mn = min(mn, i); if (i > 0) mx = max(mx, i); }
+  for (int s = 32; s > 0; s >>= 1) { mn = min(mn, __shfl_xor(mn, s)); mx = max(mx, __shfl_xor(mx, s)); }
+  if (lane == 0) rowext[r] = mx > 0 ? make_int2(mn, mx) : make_int2(-1, -2);
 }
 
 struct SgmGeom { int min_dx, min_dy, max_dx, max_dy, num_dx, num_dy, sbx, sby, ocols, orows; };
@@ -1387,8 +1389,8 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   {
     vwgpu_prof_scope ps(ctx, "sgm_bounds");
     if (rmask) {
-      hipLaunchKernelGGL(mask_col_extent_kernel, dim3((g.ocols + 255) / 256), dim3(256), 0, st, rmask, rmw, rmh, g.ocols, ext);
-      hipLaunchKernelGGL(mask_row_extent_kernel, dim3((g.orows + 255) / 256), dim3(256), 0, st, rmask, rmw, g.orows, rowext);
+      hipLaunchKernelGGL(mask_col_extent_kernel, dim3((rmh + 3) / 4), dim3(256), 0, st, rmask, rmw, rmh, g.ocols, ext);
+      hipLaunchKernelGGL(mask_row_extent_kernel, dim3((g.orows + 3) / 4), dim3(256), 0, st, rmask, rmw, g.orows, rowext);
     }
     hipLaunchKernelGGL(bounds_kernel, dim3((g.ocols + 255) / 256, g.orows), dim3(256), 0, st, g, lmask, rmask, ext, rowext, prev, pw, ph, bounds, full_search);
   }
