@@ -113,34 +113,57 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
       __syncthreads();
       for (int d = 0; d < nd; ++d) {
         double* Hc = H + hb * (PH * ZT);
+        if (KS > 0) {
+          // Four adjacent columns per thread: KS + 3 cost elements are formed once and the window slides (s' = s - e[j] + e[j + KS]),
+          // 2 (KS + 3) LDS reads and 3 KS + ... adds for four sums instead of 8 KS reads and 4 KS adds.  The slide is exact here:
+          // this kernel only runs on data whose running sums are exactly representable (vwgpu_sums_order_free).
+          for (int i = t; i < ph * (ZT / 4); i += ZTHREADS) {
+            const int r = i >> 3, q = (i & 7) * 4;
+            if (q < tw) {
+              const float* lp = Lp + r * PW + q;
+              const float* rp = Rp + r * RW + q + d;
+              double e[KS > 0 ? KS + 3 : 1];
+#pragma unroll
+              for (int a = 0; a < KS + 3; ++a) e[a] = zcost<COST>(lp[a], rp[a]);
+              double s0 = 0.0;
+#pragma unroll
+              for (int a = 0; a < KS; ++a) s0 += e[a];
+              const double s1 = s0 - e[0] + e[KS], s2 = s1 - e[1] + e[KS + 1], s3 = s2 - e[2] + e[KS + 2];
+              double* h = Hc + r * ZT + q;
+              h[0] = s0; h[1] = s1; h[2] = s2; h[3] = s3;
+            }
+          }
+        } else {
         for (int i = t; i < ph * ZT; i += ZTHREADS) {             // horizontal sums
           const int r = i >> 5, q = i & 31;
           if (q < tw) {
             const float* lp = Lp + r * PW + q;
             const float* rp = Rp + r * RW + q + d;
             double s = 0.0;
-            if (KS > 0) {
-#pragma unroll
-              for (int a = 0; a < KS; ++a) s += zcost<COST>(lp[a], rp[a]);
-            } else {
-              for (int a = 0; a < kx; ++a) s += zcost<COST>(lp[a], rp[a]);
-            }
+            for (int a = 0; a < kx; ++a) s += zcost<COST>(lp[a], rp[a]);
             Hc[r * ZT + q] = s;
           }
+        }
         }
         __syncthreads();
         if (c < tw) {
           const int dx = dx0 + d;
           const bool first = (dx == 0 && dy == 0);
+          double vs[4] = {0.0, 0.0, 0.0, 0.0};
+          if (KS > 0) {                                           // the same slide down the rows (rows beyond th hold stale planes: unused)
+            double h[KS > 0 ? KS + 3 : 1];
+#pragma unroll
+            for (int b = 0; b < KS + 3; ++b) h[b] = Hc[min(y0 + b, PH - 1) * ZT + c];
+#pragma unroll
+            for (int b = 0; b < KS; ++b) vs[0] += h[b];
+            vs[1] = vs[0] - h[0] + h[KS]; vs[2] = vs[1] - h[1] + h[KS + 1]; vs[3] = vs[2] - h[2] + h[KS + 2];
+          }
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             const int y = y0 + m;
             if (y < th) {
-              double s = 0.0;
-              if (KS > 0) {
-#pragma unroll
-                for (int b = 0; b < KS; ++b) s += Hc[(y + b) * ZT + c];
-              } else {
+              double s = vs[m];
+              if (KS == 0) {
                 for (int b = 0; b < ky; ++b) s += Hc[(y + b) * ZT + c];
               }
               if (COST == VWGPU_CROSS_CORRELATION)
