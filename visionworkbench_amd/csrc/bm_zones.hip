@@ -21,6 +21,7 @@
 // Roofline: LDS-bandwidth bound (~2*kx 4-byte + ky 8-byte LDS reads per pixel*disparity); the point of this kernel is
 // launch count, the level-0 work of a refined pyramid is only ~25 disparities per pixel.
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "vwgpu_internal.h"
@@ -232,8 +233,14 @@ int upload_tables(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, std::vect
   }
   ctx->ztab_parity ^= 1;
   char* base = static_cast<char*>(ctx->ztab.base) + (ctx->ztab_parity ? ctx->ztab.cap / 2 : 0);
-  VWGPU_HIP(ctx, hipMemcpyAsync(base, zones, (size_t)n * sizeof(vwgpu_zone_task), hipMemcpyHostToDevice, ctx->stream));
-  VWGPU_HIP(ctx, hipMemcpyAsync(base + zb, tiles.data(), tb, hipMemcpyHostToDevice, ctx->stream));
+  if (char* h = static_cast<char*>(vwgpu_host_ring(ctx, zb + tb))) {   // one asynchronous copy from pinned memory
+    memcpy(h, zones, (size_t)n * sizeof(vwgpu_zone_task));
+    memcpy(h + zb, tiles.data(), tb);
+    VWGPU_HIP(ctx, hipMemcpyAsync(base, h, zb + tb, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    VWGPU_HIP(ctx, hipMemcpyAsync(base, zones, (size_t)n * sizeof(vwgpu_zone_task), hipMemcpyHostToDevice, ctx->stream));
+    VWGPU_HIP(ctx, hipMemcpyAsync(base + zb, tiles.data(), tb, hipMemcpyHostToDevice, ctx->stream));
+  }
   *d_zones = reinterpret_cast<const vwgpu_zone_task*>(base);
   *d_tiles = reinterpret_cast<const int2*>(base + zb);
   return VWGPU_OK;

@@ -830,13 +830,14 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         vwgpu_prof_scope ps(ctx, "zone_extents");
         hipLaunchKernelGGL(zone_extent_kernel, dim3((unsigned)nleaf), dim3(64), 0, st, disp, dw, dh, d_rects, (int)nleaf, d_ext);
       }
-      leaf_ext.resize(nleaf);
-      VWGPU_HIP(ctx, hipMemcpyAsync(leaf_ext.data(), d_ext, ext_bytes, hipMemcpyDeviceToHost, st));
+      const vwgpu::LeafExtent* h_ext = static_cast<const vwgpu::LeafExtent*>(vwgpu_host_ring(ctx, ext_bytes));
+      if (!h_ext) { leaf_ext.resize(nleaf); h_ext = leaf_ext.data(); }
+      VWGPU_HIP(ctx, hipMemcpyAsync(const_cast<vwgpu::LeafExtent*>(h_ext), d_ext, ext_bytes, hipMemcpyDeviceToHost, st));
       stamp("level queued, waiting", level);
       VWGPU_HIP(ctx, hipStreamSynchronize(st));
       stamp("leaf extents on the host", level);
       zones.clear();
-      vwgpu::subdivide_regions_from_leaves(dw, dh, kx, ky, leaf_ext.data(), nleaf, zones);
+      vwgpu::subdivide_regions_from_leaves(dw, dh, kx, ky, h_ext, nleaf, zones);
       const IBox scale_search(0, 0, rp[level - 1].w - lp[level - 1].w, rp[level - 1].h - lp[level - 1].h);
       const IBox next_size(0, 0, lmp[level - 1].w, lmp[level - 1].h);
       for (SearchZone& z : zones) {

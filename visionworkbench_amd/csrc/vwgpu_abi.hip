@@ -31,6 +31,21 @@ int vwgpu_arena_reserve(vwgpu_ctx* ctx, vwgpu_arena* a, size_t bytes) {
   return VWGPU_OK;
 }
 
+void* vwgpu_host_ring(vwgpu_ctx* ctx, size_t bytes) {
+  constexpr size_t CAP = 16u << 20;
+  if (!ctx->host_ring) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, CAP, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    ctx->host_ring = static_cast<char*>(p); ctx->host_cap = CAP; ctx->host_pos = 0;
+  }
+  bytes = vwgpu_align_up(bytes, 256);
+  if (bytes > ctx->host_cap / 4) return nullptr;
+  if (ctx->host_pos + bytes > ctx->host_cap) ctx->host_pos = 0;
+  void* out = ctx->host_ring + ctx->host_pos;
+  ctx->host_pos += bytes;
+  return out;
+}
+
 vwgpu_prof_scope::vwgpu_prof_scope(vwgpu_ctx* c, const char* name) : ctx(c) {
   if (!ctx->profiling) return;
   hipEvent_t a = nullptr;
@@ -113,6 +128,7 @@ void vwgpu_destroy(vwgpu_ctx* ctx) {
   if (ctx->ztab.base) (void)hipFree(ctx->ztab.base);
   if (ctx->zrl.base) (void)hipFree(ctx->zrl.base);
   if (ctx->zext.base) (void)hipFree(ctx->zext.base);
+  if (ctx->host_ring) (void)hipHostFree(ctx->host_ring);
   if (ctx->sgm.base) (void)hipFree(ctx->sgm.base);
   if (ctx->sgm_main.base) (void)hipFree(ctx->sgm_main.base);
   for (auto& lr : ctx->leaf_rects) if (lr.d_rects) (void)hipFree(lr.d_rects);

@@ -50,6 +50,12 @@ struct vwgpu_ctx {
   vwgpu_arena sgm_main;  // SGM: ragged cost (u8) + accumulated cost (u16) buffers
   vwgpu_arena xvol;      // exact-order path: column-sum volumes, band state, per-zone NCC precision images (bm_exact.hip)
   vwgpu_arena xtab;      // exact-order path: zone / work-item tables of one call
+  // Pinned host memory for the small tables that cross PCIe inside a call (zone / tile tables up, leaf extents down): a copy from or
+  // to pageable memory is staged by the runtime and blocks the calling thread.  A ring: vwgpu_host_ring() hands out the next
+  // piece and wraps around; a piece stays untouched for at least `cap / 2` bytes of later requests (callers synchronise the
+  // stream at least once per pyramid level, long before that).
+  char* host_ring = nullptr;
+  size_t host_cap = 0, host_pos = 0;
   struct LeafRects { int w, h; size_t n; void* d_rects; };
   std::vector<LeafRects> leaf_rects;   // zone scheduler: device copies of the leaf boxes of the level sizes seen so far
   bool measure_first = false; // the previous calc_disparity was refused by the packed-u8 kernels: measure the input class first
@@ -59,6 +65,7 @@ struct vwgpu_ctx {
 
 int vwgpu_fail(vwgpu_ctx* ctx, int status, const char* fmt, ...);
 int vwgpu_arena_reserve(vwgpu_ctx* ctx, vwgpu_arena* a, size_t bytes);
+void* vwgpu_host_ring(vwgpu_ctx* ctx, size_t bytes);     // nullptr: the request does not fit (the caller copies from its own memory)
 
 #define VWGPU_HIP(ctx, call)                                                                     \
   do {                                                                                           \
