@@ -324,7 +324,7 @@ __global__ void cost_uniform16_kernel(const uint64_t* __restrict__ lc, int lcw, 
 // cache lines per wave load and ran at 0.7 TB/s (0.88 ms for the 606 MB of a 2048^2 x 129 volume).
 __global__ void __launch_bounds__(256)
 cost_row_kernel(const uint64_t* __restrict__ lc, int lcw, const uint64_t* __restrict__ rc, int rcw, int ocols, int num_disp, int stride,
-                int off_c, int off_r, uint4* __restrict__ cost16) {
+                int off_c, int off_r, uint8_t* __restrict__ cost) {
   extern __shared__ uint64_t words[];
   const int tid = threadIdx.x, c0 = blockIdx.x * 256, r = blockIdx.y;
   const int br = r + off_r, bc0 = c0 + off_c;
@@ -334,18 +334,18 @@ cost_row_kernel(const uint64_t* __restrict__ lc, int lcw, const uint64_t* __rest
   const uint64_t lv = lc[(size_t)br * lcw + min(bc0 + tid, lcw - 1)];
   __syncthreads();
   if (c >= ocols) return;
-  const int q = stride / 16;
-  uint4* o = cost16 + ((size_t)r * ocols + c) * q;
+  const int q = stride / 8;                              // stride % 8 == 0: 8 disparities per 8-byte store
+  uint2* o = reinterpret_cast<uint2*>(cost + ((size_t)r * ocols + c) * stride);
   for (int w = 0; w < q; ++w) {
-    unsigned v[4] = {0u, 0u, 0u, 0u};
+    unsigned v[2] = {0u, 0u};
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int i = 16 * w + e;
+    for (int e = 0; e < 8; ++e) {
+      const int i = 8 * w + e;
       const uint64_t rv = words[tid + min(i, num_disp - 1)];
       const unsigned cst = i < num_disp ? (unsigned)__popcll(lv ^ rv) : 0u;      // dead slots of the stride are zero
       v[e >> 2] |= cst << (8 * (e & 3));
     }
-    o[w] = make_uint4(v[0], v[1], v[2], v[3]);
+    o[w] = make_uint2(v[0], v[1]);
   }
 }
 
@@ -1449,7 +1449,9 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   }
   // every pixel searches the whole range: no masks, no previous level (bounds_kernel then wrote the full box everywhere)
   const bool uniform = (unsigned long long)npix * (unsigned long long)num_disp == n_total && num_disp <= 64 * 8;
-  const int ustride = (int)((num_disp + 15) / 16 * 16);          // per-pixel vector stride of the uniform layout (16-byte loads)
+  // per-pixel vector stride of the uniform layout: one search row -> a multiple of 8 (the register-resident path kernel moves 8 or
+  // 16 bytes per lane; every byte of padding is carried through 8 read-modify-write passes), 2-D searches -> 16 (16-byte LDS chunks)
+  const int ustride = g.num_dy == 1 ? (int)((num_disp + 7) / 8 * 8) : (int)((num_disp + 15) / 16 * 16);
   if (uniform) {
     main_buf = (unsigned long long)npix * ustride;
     hipLaunchKernelGGL(uniform_starts_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, starts, npix, (unsigned long long)ustride);
@@ -1478,7 +1480,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       const dim3 blk(qd, std::max(1, 256 / qd)), grd((g.ocols + blk.y - 1) / blk.y, g.orows);
       if (g.num_dy == 1)
         hipLaunchKernelGGL(cost_row_kernel, dim3((g.ocols + 255) / 256, g.orows), dim3(256), (size_t)(256 + num_disp) * 8, st, lc, lcw, rcen, rcw,
-                           g.ocols, (int)num_disp, ustride, min_col - hk, min_row - hk, reinterpret_cast<uint4*>(cost));
+                           g.ocols, (int)num_disp, ustride, min_col - hk, min_row - hk, cost);
       else
         hipLaunchKernelGGL(cost_uniform16_kernel<false>, grd, blk, 0, st, lc, lcw, rcen, rcw, g.ocols, g.orows, g.num_dx, (int)num_disp, ustride,
                            min_col - hk, min_row - hk, reinterpret_cast<uint32_t*>(cost));
@@ -1512,7 +1514,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       // their start-up latencies too often: 7.7 ms with 231-row bands, 15 ms with 74-row bands, against 5.9 ms unbanded.)
       vwgpu_prof_scope ps(ctx, "sgm_paths");
       int pe = (int)(((num_disp + 1) / 2 + 63) / 64);
-      if (pe == 3) pe = 4;                                            // a lane's pairs must not straddle the end of the vector (stride % 16 == 0)
+      if (pe == 3) pe = 4;                                            // a lane's pairs must not straddle the end of the vector (stride % 8 == 0: 4 divides stride / 2)
       static const int acc_probe = getenv("VWGPU_SGM_ACC") ? atoi(getenv("VWGPU_SGM_ACC")) : 0;   // timing experiments only: 2 store, 3 none
       // dirs[]: 0 T->B, 1 B->T, 2 L->R, 3 R->L, 4 TL->BR, 5 TR->BL, 6 BL->TR, 7 BR->TL
       const int order[8] = {2, 3, 0, 1, 4, 5, 6, 7};
