@@ -141,6 +141,33 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right):
     e = out[-1]
     if e["hot_us"]:
         e["min_model_frac"] = round(npx * 536 / (e["hot_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    # (4) the tile loop of config 5 (tools/correlate.cc:207-266): pyramid_correlate over the 4096^2 pair in 1024^2 tiles, pulled by
+    # 4 tile threads, each with its own engine context and stream — the way block_write_image runs the reference's view
+    import threading
+    rc = rt[:, 64:64 + W].contiguous()
+    tiles = [vwa.BBox2i(x, y, 1024, 1024) for y in range(0, H, 1024) for x in range(0, W, 1024)]
+    search = vwa.BBox2i.from_corners((-64, -1), (64, 1))
+    for label, pf, pw, cost, kk in (("SAD 7x7", 0, 0.0, 0, 7), ("LoG 1.4 + NCC 11x11 (the correlate tool's defaults)", 2, 1.4, 2, 11)):
+        T = 4
+        ctxs = [vwa.Context(lt.device.index) for _ in range(T)]
+        streams = [torch.cuda.Stream(device=lt.device) for _ in range(T)]
+        def work(t):
+            with torch.cuda.stream(streams[t]):
+                for i in range(t, len(tiles), T):
+                    stereo.pyramid_correlate(lt, rc, None, None, pf, pw, search, (kk, kk), cost, consistency_threshold=2, filter_half_kernel=5,
+                                             max_pyramid_levels=5, bbox=tiles[i], ctx=ctxs[t])
+        best = None
+        for rep in range(3):
+            torch.cuda.synchronize(lt.device); t0 = time.perf_counter()
+            th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+            [x.start() for x in th]; [x.join() for x in th]
+            torch.cuda.synchronize(lt.device); dt_ = time.perf_counter() - t0
+            if rep > 0: best = dt_ if best is None else min(best, dt_)
+        for c_ in ctxs: c_.close()
+        out.append({"name": "config 5 building block: pyramid_correlate tile loop, 4096^2 in 16 tiles of 1024^2, %s, +-64 x +-1, 5 levels, L/R check, "
+                            "4 tile threads" % label, "wall_ms_per_pair": round(best * 1e3, 2), "ms_per_tile": round(best * 1e3 / len(tiles), 3),
+                    "Mpix_per_s": round(W * H / best / 1e6, 1), "roofline_frac": None,
+                    "note": "throughput of the threaded tile loop; per-kernel times of one tile: tools/pyr_profile.py"})
     return out
 
 
