@@ -129,6 +129,15 @@ bmx_col_kernel(const float* __restrict__ A, int aw, int ah, ptrdiff_t as, const 
   if (state) state[(size_t)col * dp + d] = cs;
 }
 
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)dpp_i32<CTRL>((int)(unsigned)b), hi = (unsigned)dpp_i32<CTRL>((int)(unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // ---- pass 2: row chains + winner -----------------------------------------------------------------------------------
 // items[i] = {zone, first row}; one wave per item, 64 / lanes rows per wave.  NCH = 64-disparity chunks a lane can hold
 // (instantiated for 1, 3 and XMAX_CHUNKS; the launcher picks by the largest zone).
@@ -246,13 +255,19 @@ bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__
     }
     // winner across the disparity lanes of the row's group
     int nanw = nan ? 1 : 0;
-    for (int o = lanes >> 1; o > 0; o >>= 1) {
-      const double oc = __shfl_xor(best, o), ow = __shfl_xor(worst, o);
-      const int od = __shfl_xor(bd, o);
-      nanw |= __shfl_xor(nanw, o);
+    // butterfly over the group's lanes: partners 32 and 16 lanes away through ds_bpermute, the four nearest stages as DPP moves
+    // (quad permutes, row_half_mirror, row_mirror: inside an aligned group of 2 / 4 / 8 / 16 lanes they pair the same halves)
+    auto fold = [&](double oc, double ow, int od, int on) __attribute__((always_inline)) {
+      nanw |= on;
       if (xbetter<COST>(oc, best) || (oc == best && od < bd)) { best = oc; bd = od; }
       if (xbetter<COST>(worst, ow)) worst = ow;
-    }
+    };
+    if (lanes > 32) fold(__shfl_xor(best, 32), __shfl_xor(worst, 32), __shfl_xor(bd, 32), __shfl_xor(nanw, 32));
+    if (lanes > 16) fold(__shfl_xor(best, 16), __shfl_xor(worst, 16), __shfl_xor(bd, 16), __shfl_xor(nanw, 16));
+    if (lanes > 8) fold(dpp_f64<0x140>(best), dpp_f64<0x140>(worst), dpp_i32<0x140>(bd), dpp_i32<0x140>(nanw));     // row_mirror
+    if (lanes > 4) fold(dpp_f64<0x141>(best), dpp_f64<0x141>(worst), dpp_i32<0x141>(bd), dpp_i32<0x141>(nanw));     // row_half_mirror
+    if (lanes > 2) fold(dpp_f64<0x4E>(best), dpp_f64<0x4E>(worst), dpp_i32<0x4E>(bd), dpp_i32<0x4E>(nanw));         // quad_perm [2,3,0,1]
+    if (lanes > 1) fold(dpp_f64<0xB1>(best), dpp_f64<0xB1>(worst), dpp_i32<0xB1>(bd), dpp_i32<0xB1>(nanw));         // quad_perm [1,0,3,2]
     // advance the chains (Algorithms.h:92) with the operands requested at the top of the step
     if (x + 1 < z.zw) {
 #pragma unroll
