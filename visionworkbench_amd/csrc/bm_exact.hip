@@ -191,7 +191,16 @@ bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__
     const double* lead = base + kx;
     auto put = [&](int x) __attribute__((always_inline)) { o[x] = (COST == XCOST_PREC) ? 1.0 / r[0] : r[0]; };
     int x = 0;
-    for (; x + 4 < z.zw; x += 4) {                      // four steps' operands requested together: the chain itself is serial
+    // A lane streams its own row (lanes = rows): 16 steps' operands — one 128-byte line of each stream — are requested together,
+    // so a line is consumed while it sits in the L1 instead of being fetched once per step; the chain itself is serial.
+    for (; x + 16 < z.zw; x += 16) {
+      double l[16], t[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { l[i] = lead[x + i]; t[i] = base[x + i]; }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { put(x + i); r[0] += l[i] - t[i]; }
+    }
+    for (; x + 4 < z.zw; x += 4) {
       double l[4], t[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { l[i] = lead[x + i]; t[i] = base[x + i]; }
