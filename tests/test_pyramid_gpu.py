@@ -159,7 +159,7 @@ def test_disparity_filter_thresholds_and_shapes(vw, oracle, cleanup):
     wide / tall neighbourhoods, images smaller than a 32 x 8 tile and not a multiple of it."""
     rng = np.random.default_rng(70)
     fn = vw.disparity_cleanup_using_thresh if cleanup else vw.rm_outliers_using_thresh
-    for (h, w), hk in [((5, 7), (2, 1)), ((40, 33), (7, 3)), ((9, 130), (1, 6)), ((64, 64), (4, 4))]:
+    for (h, w), hk in [((5, 7), (2, 1)), ((40, 33), (7, 3)), ((9, 130), (1, 6)), ((64, 64), (4, 4)), ((30, 40), (45, 40))]:   # the last: no LDS tile
         d = _random_disparity(rng, h, w)
         for pthr, rthr in [(0.5, 0.4), (2.75, 0.6), (1e12, 0.9), (-1.0, 0.1), (float("nan"), 0.1), (3.0, 0.0), (3.0, 1.5)]:
             g = fn(d, hk[0], hk[1], pthr, rthr)

@@ -188,6 +188,33 @@ rm_outliers_kernel(const int32_t* __restrict__ src, int w, int h, int hh, int hv
   o[0] = r0; o[1] = r1; o[2] = r2;
 }
 
+// The same filter without the LDS tile, for neighbourhoods too large for it (64 KB).
+__global__ void rm_outliers_direct_kernel(const int32_t* __restrict__ src, int w, int h, int hh, int hv, double pthr, double rthr,
+                                   int32_t* __restrict__ dst, int ow, int oh, int ox0, int oy0) {
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y * blockDim.y + threadIdx.y;
+  if (ox >= ow || oy >= oh) return;
+  auto at = [&](int x, int y) -> const int32_t* {
+    x = x < 0 ? 0 : (x >= w ? w - 1 : x);
+    y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+    return src + ((size_t)y * w + x) * 3;
+  };
+  const int x = ox + ox0, y = oy + oy0;
+  const int32_t* c = at(x, y);
+  int32_t r0 = c[0], r1 = c[1], r2 = c[2];
+  if (r2) {
+    int matched = 0, total = 0;
+    for (int yk = -hv; yk <= hv; ++yk)
+      for (int xk = -hh; xk <= hh; ++xk) {
+        const int32_t* n = at(x + xk, y + yk);
+        if (n[2] && fabs((double)(r0 - n[0])) <= pthr && fabs((double)(r1 - n[1])) <= pthr) matched++;
+        total++;
+      }
+    if (((double)matched / (double)total) < rthr) { r0 = r1 = r2 = 0; }
+  }
+  int32_t* o = dst + ((size_t)oy * ow + ox) * 3;
+  o[0] = r0; o[1] = r1; o[2] = r2;
+}
+
 // second pass of disparity_cleanup_using_thresh: functor (1,1,3.0,0.20) over the inner VIEW, which is given here on
 // the domain padded by one pixel (DisparityMap.h:427-441).
 __global__ void cleanup_outer_kernel(const int32_t* __restrict__ inner, int w, int h, int32_t* __restrict__ dst) {
@@ -331,19 +358,22 @@ int vwgpu_launch_disparity_filter(vwgpu_ctx* ctx, const int32_t* src, int w, int
                                   bool cleanup, int32_t* tmp_padded, int32_t* dst) {
   if (hh < 0 || hv < 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "disparity filter: negative half kernel");
   const size_t rm_lds = (size_t)(32 + 2 * hh) * (8 + 2 * hv) * 9;
-  if (rm_lds > 64 * 1024) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "disparity filter: half kernel %d x %d too large", hh, hv);
+  const bool direct = rm_lds > 64 * 1024;
   // fabs((double)int32 difference) <= pthr  <=>  |difference| <= floor(pthr)
   const int never = !(pthr >= 0.0);                                   // negative or NaN: nothing matches
   const unsigned thr = never ? 0u : (pthr >= 4294967295.0 ? 0xffffffffu : (unsigned)std::floor(pthr));
   auto rm_grid = [](int ww, int hh2) { return dim3((unsigned)((ww + 31) / 32), (unsigned)((hh2 + 7) / 8)); };
   if (!cleanup) {
     vwgpu_prof_scope ps(ctx, "rm_outliers");
-    hipLaunchKernelGGL(rm_outliers_kernel, rm_grid(w, h), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr, dst, w, h, 0, 0);
+    if (direct) hipLaunchKernelGGL(rm_outliers_direct_kernel, grid2(w, h), kBlk, 0, ctx->stream, src, w, h, hh, hv, pthr, rthr, dst, w, h, 0, 0);
+    else hipLaunchKernelGGL(rm_outliers_kernel, rm_grid(w, h), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr, dst, w, h, 0, 0);
   } else {
     {
       vwgpu_prof_scope ps(ctx, "rm_outliers");
-      hipLaunchKernelGGL(rm_outliers_kernel, rm_grid(w + 2, h + 2), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr,
-                         tmp_padded, w + 2, h + 2, -1, -1);
+      if (direct) hipLaunchKernelGGL(rm_outliers_direct_kernel, grid2(w + 2, h + 2), kBlk, 0, ctx->stream, src, w, h, hh, hv, pthr, rthr,
+                                     tmp_padded, w + 2, h + 2, -1, -1);
+      else hipLaunchKernelGGL(rm_outliers_kernel, rm_grid(w + 2, h + 2), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr,
+                              tmp_padded, w + 2, h + 2, -1, -1);
     }
     vwgpu_prof_scope ps(ctx, "disparity_cleanup_outer");
     hipLaunchKernelGGL(cleanup_outer_kernel, grid2(w, h), kBlk, 0, ctx->stream, tmp_padded, w, h, dst);
