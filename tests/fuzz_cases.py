@@ -110,3 +110,38 @@ def sgm_cases(n, seed):
         sub = int(rng.choice([0, 1, 2, 3, 4, 5])) if (sx > 0 or sy > 0) else 0
         mem = int(rng.choice([6000, 6000, 1]))
         yield dict(it=it, k=k, cost=cost, search=(sx, sy), left=left, right=right, lm=lm, rm=rm, prev=prev, sub=sub, mem=mem)
+
+
+def pyramid_sgm_cases(n, seed):
+    """pyramid_correlate with VW_CORRELATION_SGM: random scenes (row bands shifted by different amounts), 1-D and 2-D search boxes,
+    census / ternary kernels, L/R thresholds and consistency levels, filter radii, level counts, masks, interior / border tiles."""
+    rng = np.random.default_rng(seed)
+    for it in range(n):
+        H, W = int(rng.integers(60, 200)), int(rng.integers(80, 260))
+        left = np.floor(rng.random((H, W)) * 256).astype(np.float32)
+        right = np.empty_like(left)
+        band = int(rng.integers(20, 90))
+        for y0 in range(0, H, band):
+            right[y0:y0 + band] = np.roll(left[y0:y0 + band], int(rng.integers(-6, 7)), axis=1)
+        if rng.random() < 0.4:
+            right = np.roll(right, int(rng.integers(-1, 2)), axis=0)
+        mx, my = int(rng.integers(1, 10)), int(rng.integers(0, 3))
+        search = (-mx, -my, mx + int(rng.integers(0, 3)), my + 1)
+        k = int(rng.choice([3, 5, 7, 9]))
+        cost = int(rng.choice([3, 4]))
+        thr = float(rng.choice([-1, 1, 2]))
+        mcl = int(rng.choice([0, 0, 1, 2]))
+        filt = int(rng.choice([0, 3, 5]))
+        levels = int(rng.integers(0, 5))
+        lm = rm = None
+        if rng.random() < 0.4:
+            lm = np.full(left.shape, 255, np.uint8)
+            rm = np.full(right.shape, 255, np.uint8)
+            y0, x0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+            lm[y0:y0 + 25, x0:x0 + 40] = 0
+            rm[:, -int(rng.integers(1, 30)):] = 0
+        bbox = None
+        if rng.random() < 0.6:
+            bw, bh = int(rng.integers(24, min(160, W))), int(rng.integers(24, min(120, H)))
+            bbox = (int(rng.integers(0, W - bw + 1)), int(rng.integers(0, H - bh + 1)), bw, bh)
+        yield dict(it=it, left=left, right=right, lm=lm, rm=rm, search=search, k=k, cost=cost, thr=thr, mcl=mcl, filt=filt, levels=levels, bbox=bbox)

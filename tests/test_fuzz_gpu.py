@@ -92,3 +92,19 @@ def test_fuzz_sgm_identical_to_oracle(oracle, n, seed):
         if not (np.array_equal(gi, oi) and (gs is None or np.abs(gs - os_).max() < 1e-5)):
             bad.append((c["it"], int((gi != oi).any(-1).sum())))
     assert not bad, "sgm_cases(seed=%d): %s" % (seed, bad)
+
+
+@pytest.mark.parametrize("n,seed", [(24, 301)])
+def test_fuzz_pyramid_sgm_identical_to_oracle(oracle, n, seed):
+    """The SGM branch of the pyramid: ragged boxes from the previous level, R->L runs, consistency levels, masks, sub-tiles."""
+    bad = []
+    for c in fuzz_cases.pyramid_sgm_cases(n, seed):
+        s = c["search"]
+        g = stereo.pyramid_correlate(c["left"], c["right"], c["lm"], c["rm"], 0, 0.0, BBox2i.from_corners(s[:2], s[2:]), (c["k"], c["k"]), c["cost"],
+                                     consistency_threshold=c["thr"], min_consistency_level=c["mcl"], filter_half_kernel=c["filt"],
+                                     max_pyramid_levels=c["levels"], algorithm=1, bbox=None if c["bbox"] is None else BBox2i(*c["bbox"]))
+        o = oracle.pyramid_correlate_sgm(c["left"], c["right"], c["lm"], c["rm"], s, c["k"], c["cost"], c["thr"], c["mcl"], c["filt"], c["levels"],
+                                         bbox=c["bbox"])
+        if not (np.array_equal(g[..., 2], o[..., 2]) and np.abs(g[..., :2] - o[..., :2]).max() < 1e-5):
+            bad.append(c["it"])
+    assert not bad, "pyramid_sgm_cases(seed=%d) mismatching indices %s" % (seed, bad)
