@@ -15,10 +15,10 @@
 //   SSD       the lane folds B2 (from an LDS table, one read per evaluation) and the disparity index into one 32-bit key
 //             ((B2 + A2max - 2S) << 8 | d: SSD >= 0 bounds the field to 24 bits for kx*ky <= 129) and keeps min / max keys
 //             with v_min3 / v_max3 over disparity pairs; valid <=> min cost != max cost (Correlation.cc:121-133).
-//   NCC       the float64 score is needed only where it can decide.  The lane tracks the two largest fp32 scores
-//             S * fl32(1/sqrt(B2)) (relative error < 2^-22; A2 is a per-pixel constant) and the disparity of the largest:
-//             when the runner-up is more than 2^-20 below, the reference's float64 sequence orders them the same way, so the
-//             recorded disparity is its winner and the pixel is valid.  The other pixels (near ties, flat patches) are queued
+//   NCC       the float64 score is needed only where it can decide.  The lane tracks the two largest keys — the fp32 score
+//             S * fl32(1/sqrt(B2)) (A2 is a per-pixel constant) with the disparity in its low 8 mantissa bits: when the
+//             runner-up's score is more than 2^-13 below, the reference's float64 sequence orders them the same way, so the
+//             winner's disparity is the reference's and the pixel is valid.  The other pixels (near ties, flat patches) are queued
 //             and ncc_full_kernel evaluates the float64 sequence for every disparity of them (Correlation.cc:91-133).
 // Inputs that are not integers in [0,255], or an all-zero window under NCC (1/0), raise the device flag and the float64
 // kernel recomputes the image (the protocol of bm_sad_u8.hip).  One search row (sy == 1).
@@ -240,33 +240,35 @@ bm_corr_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
       }
     }
   } else {
-    // One sweep: the two largest fp32 scores M1 >= M2 of every pixel and the (disparity, S) of the largest.  When M2 stays
-    // below M1 * (1 - 2^-20) the float64 sequence of the reference cannot order the two differently (the fp32 score is good
-    // to 2^-22), so the recorded disparity IS the reference's winner and the pixel is valid (worst < best).  Otherwise — near
-    // ties, flat patches, a single disparity — the pixel is queued for ncc_full_kernel.
-    float M1[TY], M2[TY];
-    u32 C[TY];
+    // One sweep: the two largest keys K1 >= K2 of every pixel, key = fp32 score S * fl32(1/sqrt(B2)) with its low 8 mantissa bits
+    // replaced by 255 - d (scores are >= 0, so the bit patterns order like the values; of equal truncated scores the smaller
+    // disparity has the larger key).  A key's score part is within 2^-15 (truncation) + 2^-22 (fp32 arithmetic) of the exact
+    // score, relatively.  When the runner-up's score part stays below (1 - 2^-13) of the winner's, the reference's float64
+    // sequence cannot order the two differently, so the winner's disparity IS the reference's and the pixel is valid
+    // (worst < best).  Otherwise — near ties, flat patches, a single disparity — the pixel is queued for ncc_full_kernel.
+    u32 K1[TY], K2[TY];
 #pragma unroll
-    for (int y = 0; y < TY; ++y) { M1[y] = -1.0f; M2[y] = -1.0f; C[y] = 0u; }
-    auto take = [&](int y, u32 sv, u32 bv, int d) __attribute__((always_inline)) {
+    for (int y = 0; y < TY; ++y) { K1[y] = 0u; K2[y] = 0u; }
+    auto take = [&](int y, u32 sv, u32 bv, u32 dcode) __attribute__((always_inline)) {
       const float v = (float)sv * __uint_as_float(bv);
-      const u32 pay = (sv << 8) | (u32)d;
-      M2[y] = __builtin_amdgcn_fmed3f(M1[y], M2[y], v);          // second largest so far
-      C[y] = v > M1[y] ? pay : C[y];                              // strict: the first disparity of equal fp32 scores is kept
-      M1[y] = fmaxf(M1[y], v);
+      const u32 key = (__float_as_uint(v) & 0xffffff00u) | dcode;
+      u32 m2;
+      asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m2) : "v"(K1[y]), "v"(K2[y]), "v"(key));   // second largest so far
+      K2[y] = m2;
+      K1[y] = K1[y] > key ? K1[y] : key;
     };
     sweep(
         [&](int d0) __attribute__((always_inline)) {
           quad(d0, [&](int y, const u32* sq, const u32* bq) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < Q; ++q) take(y, sq[q], bq[q], d0 + 4 * q);
+            for (int q = 0; q < Q; ++q) take(y, sq[q], bq[q], (u32)(255 - (d0 + 4 * q)));
           });
         },
         [&](int d0, int nv) __attribute__((always_inline)) {
           quad(d0, [&](int y, const u32* sq, const u32* bq) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < Q; ++q)
-              if (q < nv) take(y, sq[q], bq[q], d0 + 4 * q);
+              if (q < nv) take(y, sq[q], bq[q], (u32)(255 - (d0 + 4 * q)));
           });
         });
     if (x < ow) {
@@ -274,12 +276,13 @@ bm_corr_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
       for (int y = 0; y < TY; ++y) {
         if (y0 + y < oh) {
           const size_t p = (size_t)(y0 + y) * ow + x;
-          if (sx == 1 || M2[y] >= M1[y] * 0.99999905f) {          // 1 - 2^-20 (also: all scores zero); one disparity: best == worst
+          const float m1 = __uint_as_float(K1[y] & 0xffffff00u), m2 = __uint_as_float(K2[y] & 0xffffff00u);
+          if (sx == 1 || m2 >= m1 * 0.99987793f) {                // 1 - 2^-13 (also: all scores zero); one disparity: best == worst
             const u32 i = atomicAdd(full_count, 1u);
             if (i < cap) full_list[i] = (u32)p;
           } else {
             int32_t* o = out + ((ptrdiff_t)(y0 + y) * os + x) * 3;
-            o[0] = (int32_t)(C[y] & 0xffu); o[1] = 0; o[2] = 0x7fffffff;
+            o[0] = (int32_t)(255u - (K1[y] & 0xffu)); o[1] = 0; o[2] = 0x7fffffff;
           }
         }
       }
