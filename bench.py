@@ -254,6 +254,101 @@ def run_config4(args, torch, dist, vwa, core, stereo, synth, partition, rank, wo
         dist.destroy_process_group()
 
 
+def run_config5(args, torch, dist, vwa, core, stereo, synth, partition, rank, world, dev):
+    """BASELINE config 5, the tile loop of tools/correlate (correlate.cc:207-266) at orbital scale: a 32768^2 pair, pyramid_correlate in
+    1024^2 tiles (5 levels, +-64 x +-1 search, L/R check, outlier filters), pulled by 4 tile threads per GPU, each with its own engine
+    context and stream — once with the tool's block-matching defaults (LoG 1.4 prefilter, NCC 11x11) and once with SGM (census 7x7).
+    Rank g owns the tile rows of its row strip; the pyramid halo rows above and below come from the neighbouring ranks by RCCL
+    isend / irecv before the clock starts.  No collective in the timed region.  (parabola_subpixel on NCC results: the config-3 point.)"""
+    import threading
+    W = H = 32768 if not os.environ.get("VWGPU_BENCH_CONFIG5_SIZE") else int(os.environ["VWGPU_BENCH_CONFIG5_SIZE"])
+    TILE, LEVELS, D = 1024, 5, 129
+    if (H // TILE) % world:
+        sys.exit("config 5: --gpus must divide the %d tile rows" % (H // TILE))
+    a, b = partition.row_strip(rank, world, H)
+    lwin = torch.empty((b - a, W), dtype=torch.float32, device=dev)
+    rwin = torch.empty((b - a, W), dtype=torch.float32, device=dev)
+    truth0 = None
+    for r0 in range(a, b, 2048):                                   # the pair is generated in bands (a whole image would need ~30 GB of host arrays)
+        r1 = min(b, r0 + 2048)
+        l, r, t = synth.stereo_pair_rows(W, H, D, r0, r1)
+        lwin[r0 - a:r1 - a] = torch.from_numpy(l).to(dev)
+        rwin[r0 - a:r1 - a] = torch.from_numpy(r[:, 64:64 + W].copy()).to(dev)    # true disparities: 0 +- 48 px inside the +-64 search
+        if truth0 is None: truth0 = t[:TILE, :TILE] - 64
+    first = a
+    how = "none (single rank holds every row)"
+    search = vwa.BBox2i.from_corners((-64, -1), (64, 1))
+    if world > 1:
+        above, below = partition.pyramid_halo_rows(11, LEVELS, -1, 1)
+        hal = max(above, below) + 2 * 3                            # SGM R->L runs reach twice the vertical search extent
+        lwin, first = partition.fetch_strip_window(lwin, rank, world, H, hal, hal)
+        rwin, _ = partition.fetch_strip_window(rwin, rank, world, H, hal, hal)
+        how = "RCCL isend/irecv of %d pyramid halo rows per neighbour" % hal
+    torch.cuda.synchronize(dev)
+    tiles = [(x, y) for y in range(a, b, TILE) for x in range(0, W, TILE)]
+    T = 4
+    ctxs = [vwa.Context(dev.index) for _ in range(T)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(T)]
+    keep = {}
+
+    def loop(kw, only=None):
+        todo = list(tiles if only is None else tiles[:only])
+        lock = threading.Lock()
+        def work(t):
+            with torch.cuda.stream(streams[t]):
+                while True:
+                    with lock:
+                        if not todo: return
+                        x, y = todo.pop()
+                    o = stereo.pyramid_correlate(lwin, rwin, None, None, kw["pf"], kw["pfw"], search, kw["kernel"], kw["cost"], consistency_threshold=2,
+                                                 filter_half_kernel=5, max_pyramid_levels=LEVELS, algorithm=kw["alg"],
+                                                 bbox=vwa.BBox2i(x, y - first, TILE, TILE), ctx=ctxs[t])
+                    if (x, y) == (0, a): keep[kw["name"]] = o
+        th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+        [x.start() for x in th]; [x.join() for x in th]
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    modes = [dict(name="bm", pf=2, pfw=1.4, kernel=(11, 11), cost=2, alg=0), dict(name="sgm", pf=0, pfw=0.0, kernel=(7, 7), cost=3, alg=1)]
+    res = {}
+    for kw in modes:
+        loop(kw, only=2 * T)                                       # warm-up: arenas of every context sized
+        barrier()
+        t0 = time.perf_counter()
+        loop(kw)
+        barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        res[kw["name"]] = float(tmax.item())
+    for c_ in ctxs: c_.close()
+    if rank == 0:
+        npx = W * H
+        ok = {}
+        for name, o in keep.items():
+            g = o.cpu().numpy()
+            ok[name] = float(((np.rint(g[..., 0]) == truth0) & (g[..., 2] != 0)).mean())
+        print(json.dumps({
+            "metric": "disparity Mpix/s, %dx%d pair, pyramid_correlate tile loop (LoG 1.4 + NCC 11x11, 5 levels, +-64 x +-1, L/R check)" % (W, H),
+            "value": npx / res["bm"] / 1e6, "unit": "Mpix/s", "n_gpus": world, "steps": 1, "warmup": 1,
+            "ms_per_step": res["bm"] * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32/f64",
+            "data": "synthetic (SplitMix64 integer-valued float32 noise pair, 256-px blocks shifted by 0+-48)",
+            "config": {"workload": "BASELINE configs[4]: orbital-scale pair through the reference's tile loop; block matching with the correlate "
+                                   "tool's defaults and, separately, SGM (census 7x7)", "tile": TILE, "tiles": (W // TILE) * (H // TILE),
+                       "tile_threads_per_gpu": T, "halo": how,
+                       "sgm": {"Mpix_per_s": npx / res["sgm"] / 1e6, "s_per_pair": res["sgm"]},
+                       "truth_match_rate_first_tile": ok},
+            "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,7 +357,7 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=250.0, dest="settle_ms")   # untimed load before the warm-up steps (clock ramp)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measured points (config 3, SGM block, +-16 px)")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config4"],
+    ap.add_argument("--workload", default="config2", choices=["config2", "config4", "config5"],
                     help="config2 (default, the headline metric): 4096^2 7x7 SAD; config4: 16384^2 census SGM in 8 strips + collar")
     args = ap.parse_args()
 
@@ -283,6 +378,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.workload == "config5":
+        from visionworkbench_amd import partition
+        return run_config5(args, torch, dist, vwa, core, stereo, synth, partition, rank, world, dev)
     if args.workload == "config4":
         from visionworkbench_amd import partition
         return run_config4(args, torch, dist, vwa, core, stereo, synth, partition, rank, world, dev)
