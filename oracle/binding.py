@@ -83,6 +83,7 @@ def lib():
         _LIB.vwo_sgm_p1p2.argtypes = [P, P, P]
         _LIB.vwo_pyramid_correlate_sgm.argtypes = [P, I, I, P, I, I, P, P, I, I, I, I, I, I, F, I, I, I, I, I, I, Z, I, I, I, I, I, P]
         _LIB.vwo_calc_disparity_sgm.argtypes = [I, P, I, I, P, I, I, I, I, I, I, I, I, Z, I, P, I, I, P, I, I, P, I, I, P, P, P, P]
+        _LIB.vwo_calc_disparity_sgm_p.argtypes = [I, P, I, I, P, I, I, I, I, I, I, I, I, Z, I, P, I, I, P, I, I, P, I, I, I, I, P, P, P, P]
     return _LIB
 
 
@@ -381,7 +382,7 @@ class SemiGlobalMatcher:
 
 
 def calc_disparity_sgm(cost_type, left, right, search_volume, kernel, subpixel=SUBPIXEL_LC_BLEND, search_buffer=(2, 2),
-                       memory_limit_mb=6000, left_mask=None, right_mask=None, prev_disparity=None, num_threads=1):
+                       memory_limit_mb=6000, left_mask=None, right_mask=None, prev_disparity=None, num_threads=1, p1=0, p2=0):
     """calc_disparity_sgm on cropped regions: left (lh, lw) float32, right (lh+sy, lw+sx) float32.
     Returns (integer disparity (oh, ow, 3) int32, sub-pixel disparity (oh, ow, 3) float32)."""
     l = np.ascontiguousarray(left, np.float32)
@@ -392,11 +393,11 @@ def calc_disparity_sgm(cost_type, left, right, search_volume, kernel, subpixel=S
     out = np.zeros((l.shape[0], l.shape[1], 3), np.int32)
     sub = np.zeros((l.shape[0], l.shape[1], 3), np.float32)
     ow, oh = ctypes.c_int(), ctypes.c_int()
-    rc = lib().vwo_calc_disparity_sgm(int(cost_type), _p(l), l.shape[1], l.shape[0], _p(r), r.shape[1], r.shape[0],
-                                      search_volume[0], search_volume[1], kernel, int(subpixel), search_buffer[0], search_buffer[1],
-                                      memory_limit_mb, num_threads, None if lm is None else _p(lm), lmw, lmh,
-                                      None if rm is None else _p(rm), rmw, rmh, None if pd is None else _p(pd), pw, ph,
-                                      _p(out), _p(sub), ctypes.byref(ow), ctypes.byref(oh))
+    rc = lib().vwo_calc_disparity_sgm_p(int(cost_type), _p(l), l.shape[1], l.shape[0], _p(r), r.shape[1], r.shape[0],
+                                        search_volume[0], search_volume[1], kernel, int(subpixel), search_buffer[0], search_buffer[1],
+                                        memory_limit_mb, num_threads, None if lm is None else _p(lm), lmw, lmh,
+                                        None if rm is None else _p(rm), rmw, rmh, None if pd is None else _p(pd), pw, ph,
+                                        int(p1), int(p2), _p(out), _p(sub), ctypes.byref(ow), ctypes.byref(oh))
     if rc:
         raise ValueError("vwo_calc_disparity_sgm rc=%d" % rc)
     n = ow.value * oh.value * 3

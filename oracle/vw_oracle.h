@@ -184,6 +184,12 @@ int vwo_calc_disparity_sgm(int cost_type, const float* left, int lw, int lh, con
                            const uint8_t* lmask, int lmw, int lmh, const uint8_t* rmask, int rmw, int rmh,
                            const int32_t* prev, int pw, int ph, int32_t* out_disp, float* out_subpixel, int* ow, int* oh);
 
+/* the same with user penalties (p1 / p2 = 0: the defaults) */
+int vwo_calc_disparity_sgm_p(int cost_type, const float* left, int lw, int lh, const float* right, int rw, int rh,
+                             int sx, int sy, int kernel, int subpixel, int sbx, int sby, size_t memory_limit_mb, int num_threads,
+                             const uint8_t* lmask, int lmw, int lmh, const uint8_t* rmask, int rmw, int rmh,
+                             const int32_t* prev, int pw, int ph, int p1, int p2, int32_t* out_disp, float* out_subpixel, int* ow, int* oh);
+
 #ifdef __cplusplus
 }
 #endif

@@ -672,15 +672,15 @@ int vwo_sgm_read(vwo_sgm* s, int32_t* bounds4, uint64_t* starts, uint8_t* cost, 
 int vwo_sgm_p1p2(vwo_sgm* s, int* p1, int* p2) { *p1 = s->m.p1; *p2 = s->m.p2; return 0; }
 
 // calc_disparity_sgm (SGM.cc:167-229) on already cropped float regions: left lw x lh, right (lw + sx) x (lh + sy).
-int vwo_calc_disparity_sgm(int cost_type, const float* left, int lw, int lh, const float* right, int rw, int rh,
+int vwo_calc_disparity_sgm_p(int cost_type, const float* left, int lw, int lh, const float* right, int rw, int rh,
                            int sx, int sy, int kernel, int subpixel, int sbx, int sby, size_t memory_limit_mb, int num_threads,
                            const uint8_t* lmask, int lmw, int lmh, const uint8_t* rmask, int rmw, int rmh,
-                           const int32_t* prev, int pw, int ph, int32_t* out_disp, float* out_subpixel, int* ow, int* oh) {
+                           const int32_t* prev, int pw, int ph, int p1, int p2, int32_t* out_disp, float* out_subpixel, int* ow, int* oh) {
   if (!left || !right || lw <= 0 || lh <= 0 || rw <= 0 || rh <= 0) return -1;
   std::vector<uint8_t> l8((size_t)lw * lh), r8((size_t)rw * rh);
   vwo_u8_convert(left, lw, lh, l8.data());
   vwo_u8_convert(right, rw, rh, r8.data());
-  vwo_sgm* s = vwo_sgm_create(cost_type, 0, 0, 0, sx, sy, kernel, subpixel, sbx, sby, memory_limit_mb, 0, 0, 5, num_threads);
+  vwo_sgm* s = vwo_sgm_create(cost_type, 0, 0, 0, sx, sy, kernel, subpixel, sbx, sby, memory_limit_mb, p1, p2, 5, num_threads);      // p1 / p2 = 0: the defaults of SGM.cc:106-160
   if (!s) return -2;
   const int hk = (kernel - 1) / 2;
   const int eow = std::min(lw - 1 - hk, rw - 1 - (hk + sx)) - hk + 1, eoh = std::min(lh - 1 - hk, rh - 1 - (hk + sy)) - hk + 1;
@@ -692,6 +692,15 @@ int vwo_calc_disparity_sgm(int cost_type, const float* left, int lw, int lh, con
   }
   vwo_sgm_destroy(s);
   return rc;
+}
+
+
+int vwo_calc_disparity_sgm(int cost_type, const float* left, int lw, int lh, const float* right, int rw, int rh,
+                           int sx, int sy, int kernel, int subpixel, int sbx, int sby, size_t memory_limit_mb, int num_threads,
+                           const uint8_t* lmask, int lmw, int lmh, const uint8_t* rmask, int rmw, int rmh,
+                           const int32_t* prev, int pw, int ph, int32_t* out_disp, float* out_subpixel, int* ow, int* oh) {
+  return vwo_calc_disparity_sgm_p(cost_type, left, lw, lh, right, rw, rh, sx, sy, kernel, subpixel, sbx, sby, memory_limit_mb, num_threads,
+                                  lmask, lmw, lmh, rmask, rmw, rmh, prev, pw, ph, 0, 0, out_disp, out_subpixel, ow, oh);
 }
 
 }  // extern "C"

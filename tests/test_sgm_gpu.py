@@ -248,6 +248,23 @@ def test_register_path_kernel_lane_layouts(vw, oracle, sx, k, w, h):
     assert np.array_equal(gi, oi) and np.abs(gs - os_).max() < 1e-5
 
 
+@pytest.mark.parametrize("p1,p2", [(5, 60), (200, 9000), (1, 65000)])
+def test_user_penalties_incl_u16_wrap(vw, oracle, p1, p2):
+    """User-provided P1 / P2 (SGM.cc:106-160).  With P2 > 7937 the eight path costs of a pixel can exceed 65535: the reference's u16
+    accumulator wraps, and so does the v_pk_add_u16 accumulation of the one-direction-per-launch path kernel."""
+    rng = np.random.default_rng(p2)
+    sx, k, h, w = 40, 5, 30, 90
+    base = rng.integers(0, 256, (h + 8, w + sx + 8)).astype(np.float32)
+    left = np.ascontiguousarray(base[4:4 + h, 4:4 + w])
+    right = np.ascontiguousarray(base[4:4 + h, 1:1 + w + sx])
+    box = _box(w, h)
+    noise = rng.integers(0, 256, right.shape).astype(np.float32)          # an unrelated right image: large path costs everywhere
+    for rr in (right, noise):
+        gi, gs = vw.calc_disparity_sgm(CENSUS, left, rr, box, (sx, 0), (k, k), subpixel_mode=5, with_subpixel=True, p1=p1, p2=p2)
+        oi, os_ = oracle.calc_disparity_sgm(CENSUS, left, rr, (sx, 0), k, subpixel=5, p1=p1, p2=p2)
+        assert np.array_equal(gi, oi) and np.abs(gs - os_).max() < 1e-5
+
+
 @pytest.mark.parametrize("sx,sy,k,w,h", [(4, 0, 7, 40, 30), (8, 0, 7, 60, 48), (3, 1, 5, 20, 16), (16, 0, 7, 100, 80)])
 def test_uniform_path_detected_from_the_boxes(vw, oracle, sx, sy, k, w, h):
     """All-valid masks (the top level of every pyramid): the boxes come out full everywhere and the uniform kernel runs;
