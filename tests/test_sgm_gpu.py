@@ -263,6 +263,24 @@ def test_user_penalties_incl_u16_wrap(vw, oracle, p1, p2):
         gi, gs = vw.calc_disparity_sgm(CENSUS, left, rr, box, (sx, 0), (k, k), subpixel_mode=5, with_subpixel=True, p1=p1, p2=p2)
         oi, os_ = oracle.calc_disparity_sgm(CENSUS, left, rr, (sx, 0), k, subpixel=5, p1=p1, p2=p2)
         assert np.array_equal(gi, oi) and np.abs(gs - os_).max() < 1e-5
+    # the other path kernels: a 2-D search (uniform, LDS-resident vectors) and ragged boxes (masks + a previous level)
+    sy = 2
+    base2 = rng.integers(0, 256, (h + sy + 8, w + 12 + 8)).astype(np.float32)
+    l2, r2 = np.ascontiguousarray(base2[4:4 + h, 4:4 + w]), np.ascontiguousarray(rng.integers(0, 256, (h + sy, w + 12)).astype(np.float32))
+    gi, gs = vw.calc_disparity_sgm(CENSUS, l2, r2, box, (12, sy), (k, k), subpixel_mode=5, with_subpixel=True, p1=p1, p2=p2)
+    oi, os_ = oracle.calc_disparity_sgm(CENSUS, l2, r2, (12, sy), k, subpixel=5, p1=p1, p2=p2)
+    assert np.array_equal(gi, oi) and np.abs(gs - os_).max() < 1e-5
+    oh, ow = h - k + 1, w - k + 1
+    lm = np.full((oh, ow), 255, np.uint8); lm[:3] = 0; lm[:, -4:] = 0
+    rm = np.full((oh + sy, ow + 12), 255, np.uint8); rm[:, :5] = 0
+    prev = np.zeros(((oh + 1) // 2, (ow + 1) // 2, 3), np.int32)
+    prev[..., 0] = rng.integers(0, 7, prev.shape[:2]); prev[..., 1] = rng.integers(0, 2, prev.shape[:2])
+    prev[..., 2] = np.where(rng.random(prev.shape[:2]) < 0.2, 0, np.iinfo(np.int32).max)
+    gi, gs, oi, os_ = None, None, None, None
+    gi, gs = vw.calc_disparity_sgm(CENSUS, l2, r2, box, (12, sy), (k, k), subpixel_mode=5, with_subpixel=True, p1=p1, p2=p2,
+                                   left_mask=lm, right_mask=rm, prev_disparity=prev)
+    oi, os_ = oracle.calc_disparity_sgm(CENSUS, l2, r2, (12, sy), k, subpixel=5, p1=p1, p2=p2, left_mask=lm, right_mask=rm, prev_disparity=prev)
+    assert np.array_equal(gi, oi) and np.abs(gs - os_).max() < 1e-5
 
 
 @pytest.mark.parametrize("sx,sy,k,w,h", [(4, 0, 7, 40, 30), (8, 0, 7, 60, 48), (3, 1, 5, 20, 16), (16, 0, 7, 100, 80)])

@@ -412,7 +412,14 @@ __device__ __forceinline__ unsigned wave_shl1(unsigned v, unsigned edge) {      
   return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xF, 0xF, false);
 }
 
-__device__ __forceinline__ void accum_add_u16(uint16_t* accum, unsigned long long e, unsigned v) {
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 as_us2(unsigned v) { return __builtin_bit_cast(us2, v); }
+__device__ __forceinline__ unsigned as_u32(us2 v) { return __builtin_bit_cast(unsigned, v); }
+// `plain`: the launch holds ONE direction (DirSet::n == 1 — the caller separates the directions when 8 * (255 + max(P1, P2)) could
+// overflow 16 bits), so every pixel lies on exactly one line and the sum is a plain u16 read-modify-write that wraps around like the
+// reference's `+=`; the packed 32-bit atomics would carry an overflowing low half into its neighbour.
+__device__ __forceinline__ void accum_add_u16(uint16_t* accum, unsigned long long e, unsigned v, bool plain = false) {
+  if (plain) { accum[e] = (uint16_t)(accum[e] + v); return; }
   atomicAdd(reinterpret_cast<unsigned*>(accum) + (e >> 1), v << ((e & 1) * 16));
 }
 
@@ -487,7 +494,7 @@ path_kernel(SgmGeom g, DirSet D,
       for (int i = lane; i < nd; i += 64) {
         const unsigned v = cost_at(i);
         prev_out[i] = (uint16_t)v;
-        accum_add_u16(accum, st + i, v);
+        accum_add_u16(accum, st + i, v, D.n == 1);
       }
     } else {
       int grad = cur - last_val; grad = grad < 0 ? -grad : grad;
@@ -526,7 +533,7 @@ path_kernel(SgmGeom g, DirSet D,
         res = subs16(res, min_prior);
         // prev_out is still being read by nobody (scatter finished at the barrier): reuse it for this pixel's vector
         prev_out[i] = (uint16_t)res;
-        accum_add_u16(accum, st + i, res);
+        accum_add_u16(accum, st + i, res, D.n == 1);
       }
       lds_barrier();
       for (int i = lane; i < np; i += 64) {
@@ -685,7 +692,9 @@ path_inplace_kernel(SgmGeom g, DirSet D,
       const unsigned next = wave_shl1(mine, 0u);
       const unsigned long long e = st + (unsigned)(lane + 64 * k);
       const bool low = (e & 1ull) == 0;
-      if (on && (low || lane == 0)) {
+      if (D.n == 1) {                                   // one direction per launch: plain u16 sums (see accum_add_u16)
+        if (on) accum[e] = (uint16_t)(accum[e] + mine);
+      } else if (on && (low || lane == 0)) {
         const unsigned v = low ? (mine | (lane < 63 ? next << 16 : 0u)) : (mine << 16);
         atomicAdd(reinterpret_cast<unsigned*>(accum) + (e >> 1), v);
       }
@@ -835,7 +844,9 @@ path_uniform_kernel(SgmGeom g, DirSet D, int K, int stride,
         if (w < nlive) {
           unsigned v = la[j];
           if (2 * w + 1 >= num_disp) v &= 0xffffu;              // the odd tail shares its dword with a dead slot
-          atomicAdd(ga + pbase * q32 + j + (long long)k * (delta - 1) * q32, v);
+          unsigned* a = ga + pbase * q32 + j + (long long)k * (delta - 1) * q32;
+          if (D.n == 1) *a = as_u32(as_us2(*a) + as_us2(v));    // one direction per launch: u16 wrap-around per element
+          else atomicAdd(a, v);
         }
       }
     }
@@ -847,9 +858,6 @@ path_uniform_kernel(SgmGeom g, DirSet D, int K, int stride,
 // whole recurrence runs on v_pk_{min,add,sub}_u16 with clamping (= the reference's saturating SSE ops, SGM.cc:936-984).
 // The left / right neighbour pairs come from the adjacent dwords through v_alignbit; because the 1-D adjacency already
 // contains the centre, the clamped neighbours at both ends of the range are represented by 0xffff guards (they never win).
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ us2 as_us2(unsigned v) { return __builtin_bit_cast(us2, v); }
-__device__ __forceinline__ unsigned as_u32(us2 v) { return __builtin_bit_cast(unsigned, v); }
 
 // ---- register-resident scan lines ---------------------------------------------------------------------------------------
 // The kernel above spends ~95 issue slots per pixel step (LDS neighbour exchange with two wave barriers, a staged chunk of costs,
