@@ -296,3 +296,22 @@ def test_corr_timeout_estimate(vw, oracle):
     # wall clock; so does the engine: the tile completes
     g2 = vw.pyramid_correlate(left, right, None, None, 0, 0.0, _box(search), (7, 7), 0, 5, 1e-5, -1, 0, 5, 5)
     assert (g2[..., 2] != 0).mean() > 0.5
+
+
+@pytest.mark.parametrize("k", [(15, 15), (25, 25), (5, 23)])
+def test_large_and_oblong_kernels(vw, oracle, k):
+    """Kernels beyond the instantiated sizes (ASP users run up to 25 x 25): run-time window loops of the zone kernel, the exact-order
+    kernels under LoG, levels 0 and 3."""
+    from visionworkbench_amd.core import BBox2i
+    rng = np.random.default_rng(3)
+    H, W = 220, 300
+    left = np.floor(rng.random((H, W)) * 256).astype(np.float32)
+    right = np.roll(left, 4, axis=1)
+    right[100:] = np.roll(left[100:], -3, axis=1)
+    s = (-8, -2, 9, 3)
+    for cost in (0, 2):
+        for pf, pfw in ((0, 0.0), (2, 1.4)):
+            for levels in (0, 3):
+                g = vw.pyramid_correlate(left, right, None, None, pf, pfw, BBox2i.from_corners(s[:2], s[2:]), k, cost, 0, 0.0, 2, 0, 3, levels)
+                o = oracle.pyramid_correlate(left, right, None, None, pf, pfw, s, k, cost, 0, 0.0, 2, 3, levels)
+                assert np.array_equal(g, o), (k, cost, pf, levels)
