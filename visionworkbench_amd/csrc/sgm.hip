@@ -269,23 +269,48 @@ __global__ void row_scan_kernel(const B4* __restrict__ bounds, int ocols, const 
 
 // ---- cost fill --------------------------------------------------------------------------------------------------------
 
-// one wavefront per output pixel, lanes over the pixel's disparities (get_hamming_distance_costs, SGM.cc:40-75)
-__global__ void cost_kernel(const uint64_t* __restrict__ lc, int lcw, const uint64_t* __restrict__ rc, int rcw,
-                            const B4* __restrict__ bounds, const unsigned long long* __restrict__ starts, int ocols, size_t npix,
-                            int off_c, int off_r, uint8_t* __restrict__ cost) {
-  const size_t p = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (p >= npix) return;
+// One wavefront per COST_PPW consecutive output pixels, lanes over a pixel's disparities (get_hamming_distance_costs, SGM.cc:40-75).
+// A pixel is three dependent memory round trips (record -> left census word / vector start -> right census words) and a handful
+// of instructions: the records of all COST_PPW pixels are requested together, then their first 64 right words, before the first
+// popcount (one pixel per wave was pure latency: 0.7 ms per 1024^2 SGM tile).
+constexpr int COST_PPW = 4;
+__global__ void __launch_bounds__(256)
+cost_kernel(const uint64_t* __restrict__ lc, int lcw, const uint64_t* __restrict__ rc, int rcw,
+            const B4* __restrict__ bounds, const unsigned long long* __restrict__ starts, int ocols, size_t npix,
+            int off_c, int off_r, uint8_t* __restrict__ cost) {
+  const size_t p0 = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * COST_PPW;
+  if (p0 >= npix) return;
   const int lane = threadIdx.x & 63;
-  const int r = (int)(p / ocols), c = (int)(p - (size_t)r * ocols);
-  const B4 b = bounds[p];
-  const int wd = b.x1 - b.x0 + 1, n = wd * (b.y1 - b.y0 + 1);
-  if (n <= 0) return;
-  const int bc = c + off_c, br = r + off_r;           // (min_col - half_kernel, min_row - half_kernel) offsets
-  const uint64_t lv = lc[(size_t)br * lcw + bc];
-  uint8_t* o = cost + starts[p];
-  for (int i = lane; i < n; i += 64) {
-    const int qy = i / wd, qx = i - qy * wd;
-    o[i] = (uint8_t)__popcll(lv ^ rc[(size_t)(br + b.y0 + qy) * rcw + bc + b.x0 + qx]);
+  B4 bq[COST_PPW];
+  unsigned long long sq[COST_PPW];
+  int rr[COST_PPW], cc[COST_PPW];
+#pragma unroll
+  for (int q = 0; q < COST_PPW; ++q) {
+    const size_t p = p0 + q < npix ? p0 + q : npix - 1;
+    bq[q] = bounds[p]; sq[q] = starts[p];
+    rr[q] = (int)(p / ocols); cc[q] = (int)(p - (size_t)rr[q] * ocols);
+  }
+  uint64_t lv[COST_PPW], r0[COST_PPW];
+  int wd[COST_PPW], n[COST_PPW];
+#pragma unroll
+  for (int q = 0; q < COST_PPW; ++q) {
+    const int bc = cc[q] + off_c, br = rr[q] + off_r;       // (min_col - half_kernel, min_row - half_kernel) offsets
+    wd[q] = bq[q].x1 - bq[q].x0 + 1; n[q] = wd[q] * (bq[q].y1 - bq[q].y0 + 1);
+    lv[q] = lc[(size_t)br * lcw + bc];
+    const int i = min(lane, max(n[q] - 1, 0));
+    const int qy = n[q] > 0 ? i / wd[q] : 0, qx = n[q] > 0 ? i - qy * wd[q] : 0;
+    r0[q] = n[q] > 0 ? rc[(size_t)(br + bq[q].y0 + qy) * rcw + bc + bq[q].x0 + qx] : 0ull;
+  }
+#pragma unroll
+  for (int q = 0; q < COST_PPW; ++q) {
+    if (p0 + q >= npix || n[q] <= 0) continue;              // wave-uniform
+    uint8_t* o = cost + sq[q];
+    if (lane < n[q]) o[lane] = (uint8_t)__popcll(lv[q] ^ r0[q]);
+    const int bc = cc[q] + off_c, br = rr[q] + off_r;
+    for (int i = lane + 64; i < n[q]; i += 64) {
+      const int qy = i / wd[q], qx = i - qy * wd[q];
+      o[i] = (uint8_t)__popcll(lv[q] ^ rc[(size_t)(br + bq[q].y0 + qy) * rcw + bc + bq[q].x0 + qx]);
+    }
   }
 }
 
@@ -1494,7 +1519,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
                            min_col - hk, min_row - hk, reinterpret_cast<uint32_t*>(cost));
     }
     else
-      hipLaunchKernelGGL(cost_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, st, lc, lcw, rcen, rcw, bounds, starts, g.ocols, npix,
+      hipLaunchKernelGGL(cost_kernel, dim3((unsigned)((npix + 4 * COST_PPW - 1) / (4 * COST_PPW))), dim3(256), 0, st, lc, lcw, rcen, rcw, bounds, starts, g.ocols, npix,
                          min_col - hk, min_row - hk, cost);
   }
   // 8 directions, in the reference's order (SGM.cc:2488-2610)
