@@ -1503,7 +1503,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   uint16_t* accum = reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->sgm_main.base) + 2 * guard + vwgpu_align_up((size_t)main_buf, 256));
   // 0: one direction per launch, plain store / read-modify-write (default); 1: all directions in one launch, 64-bit atomics
   static const int paths_mode = getenv("VWGPU_SGM_PATHS") ? atoi(getenv("VWGPU_SGM_PATHS")) : 0;
-  const bool dir_paths = uniform && g.num_dy == 1 && paths_mode == 0;      // the first direction initialises the volume
+  const bool dir_paths = uniform && g.num_dy == 1 && paths_mode != 1;      // the first direction initialises the volume
   if (!dir_paths) VWGPU_HIP(ctx, hipMemsetAsync(accum, 0, (size_t)main_buf * 2, st));
   {
     vwgpu_prof_scope ps(ctx, "sgm_cost");
@@ -1592,10 +1592,9 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
         switch (pe) { case 1: VWGPU_PATH_REG(1); break; case 2: VWGPU_PATH_REG(2); break; default: VWGPU_PATH_REG(4); break; }
 #undef VWGPU_PATH_REG
       } else if (uniform) {
-#define VWGPU_PATH_U(E) do { if (one_d) hipLaunchKernelGGL((path_uniform_kernel<E, true>), dim3(lines), dim3(64), ulds, st, g, D, K, ustride, \
-                               l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2); \
-                             else hipLaunchKernelGGL((path_uniform_kernel<E, false>), dim3(lines), dim3(64), ulds, st, g, D, K, ustride, \
-                               l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2); } while (0)
+        // (2-D searches only: one search row is served by path_uniform_reg_kernel above)
+#define VWGPU_PATH_U(E) hipLaunchKernelGGL((path_uniform_kernel<E, false>), dim3(lines), dim3(64), ulds, st, g, D, K, ustride, \
+                               l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2)
         switch (ept) {
           case 1: VWGPU_PATH_U(1); break; case 2: VWGPU_PATH_U(2); break; case 3: VWGPU_PATH_U(3); break; case 4: VWGPU_PATH_U(4); break;
           case 5: VWGPU_PATH_U(5); break; case 6: VWGPU_PATH_U(6); break; case 7: VWGPU_PATH_U(7); break; default: VWGPU_PATH_U(8); break;
