@@ -365,6 +365,26 @@ int vwgpu_calc_disparity_sgm(vwgpu_ctx* ctx, const vwgpu_sgm_params* params,
                              const int32_t* prev_disparity, int pw, int ph,
                              int32_t* out_disp, float* out_subpixel, size_t cap_pixels, int* ow, int* oh);
 
+/* ---- multi-GPU: halo rows of a row-sharded source (csrc/halo.hip) ---------------------------------------------------------
+ * The reference has no distributed mode; its tiles are independent (CorrelationView.cc:89-97, CorrelationView.h:123-133), so one
+ * process per GPU can own a strip of tile rows.  When the SOURCE image is sharded the same way, rank g holds rows
+ * [g*rows/world, (g+1)*rows/world) and its tiles additionally read `halo_above` / `halo_below` rows of the neighbours
+ * (half_kernel * 2^levels + search + collar).  These calls fetch them with RCCL point-to-point transfers (librccl.so is opened
+ * at run time; VWGPU_ERR_NOIMPL when it is absent).  The unique id is produced on one rank and handed to the others by the host
+ * application (file, MPI, torch store ...), exactly as ncclGetUniqueId / ncclCommInitRank expect. */
+typedef struct vwgpu_comm vwgpu_comm;
+#define VWGPU_COMM_ID_BYTES 128
+int vwgpu_comm_unique_id(void* id128);
+int vwgpu_comm_create(vwgpu_ctx* ctx, const void* id128, int rank, int world, vwgpu_comm** comm);
+int vwgpu_comm_destroy(vwgpu_comm* comm);
+/* rows owned by `rank` and the rows its window spans (clipped to the image); pure host arithmetic, no context */
+int vwgpu_halo_plan(int rank, int world, int rows_total, int halo_above, int halo_below, int* owned_a, int* owned_b, int* need_a,
+                    int* need_b);
+/* d_owned: the rank's rows (owned_b - owned_a) x cols, contiguous; d_window: (need_b - need_a) x cols, receives own rows + halos;
+ * asynchronous on the context's stream; every rank of the communicator must make the call.  *first_row = need_a. */
+int vwgpu_fetch_strip_window_dev(vwgpu_ctx* ctx, vwgpu_comm* comm, const void* d_owned, int cols, int elem_bytes, int rows_total,
+                                 int halo_above, int halo_below, void* d_window, int* first_row);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include <vw/FileIO.h>
+#include <vw/Halo.h>
 #include <vw/Stereo.h>
 
 #include "../../oracle/vw_oracle.h"
@@ -512,6 +513,21 @@ static void test_disk_views_and_block_write() {
   std::remove(lf.c_str()); std::remove(rf.c_str()); std::remove(df.c_str());
 }
 
+// vw/Halo.h: the strip plan of a row-sharded source and a one-rank RCCL communicator (more ranks need more GPUs).
+static void test_strip_plan_and_comm() {
+  using namespace vw::engine;
+  const StripPlan p = strip_plan(1, 3, 1000, 20, 30);
+  EXPECT_TRUE(p.owned_a == 333 && p.owned_b == 666 && p.need_a == 313 && p.need_b == 696);
+  const StripPlan q = strip_plan(2, 3, 1000, 20, 30);
+  EXPECT_TRUE(q.owned_b == 1000 && q.need_b == 1000);
+  EXPECT_THROW(strip_plan(3, 3, 1000, 0, 0), ArgumentErr);
+  int above = 0, below = 0;
+  pyramid_halo_rows(11, 5, -1, 1, 0, above, below);             // 5 * 32 + 2 * 2 + 8 (+1 for the search row above / below)
+  EXPECT_TRUE(above == 173 && below == 173);
+  StripComm comm(StripComm::unique_id(), 0, 1);
+  EXPECT_TRUE(comm.rank() == 0 && comm.world() == 1);
+}
+
 int main() {
   static_assert(sizeof(PixelMask<Vector2i>) == 12, "layout");
   EXPECT_TRUE(BBox2i(0, 0, 129, 0).empty() && BBox2i(0, 0, 129, 0).width() == 0);
@@ -540,6 +556,7 @@ int main() {
   test_collar_and_lr_disp_diff();
   test_fast_box_sum();
   test_disk_views_and_block_write();
+  test_strip_plan_and_comm();
   // tile threads spread over the visible GPUs (one context per thread x GPU); on a 1-GPU box this is device 0 for all
   EXPECT_TRUE(!vw::engine::devices().empty());
   std::printf("%d checks, %d failures\n", g_checks, g_fail);

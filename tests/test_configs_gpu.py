@@ -127,3 +127,26 @@ def test_config5_sgm_tile_of_a_32768_wide_pair(oracle, pair32768):
     o = oracle.pyramid_correlate_sgm(left, right, None, None, search, 7, 3, 2.0, 0, 5, 5, bbox=bbox)
     assert np.array_equal(g[..., 2], o[..., 2]), int((g[..., 2] != o[..., 2]).sum())
     assert np.abs(g - o).max() < 1e-5
+
+
+def test_engine_rccl_communicator_single_rank():
+    """csrc/halo.hip on the GPU box: librccl.so opens at run time, a one-rank communicator initialises, and the strip window of a
+    one-rank 'sharded' image is the image (the multi-rank plan is covered on the CPU: tests/test_host_logic.py and the gloo tests of
+    the torch.distributed mirror; the driver's multi-GPU runs exercise the exchange itself)."""
+    import torch
+    import visionworkbench_amd as vwa
+    from visionworkbench_amd import partition
+    ctx = vwa.Context(0)
+    uid = partition.EngineComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = partition.EngineComm(ctx, uid, 0, 1)
+    img = torch.arange(37 * 50, dtype=torch.float32, device="cuda").reshape(37, 50)
+    win, first = comm.fetch_strip_window(img, 37, 5, 9)
+    torch.cuda.synchronize()
+    assert first == 0 and torch.equal(win, img)
+    u8 = (torch.arange(12 * 7, device="cuda") % 251).to(torch.uint8).reshape(12, 7)
+    win, first = comm.fetch_strip_window(u8, 12, 0, 0)
+    torch.cuda.synchronize()
+    assert first == 0 and torch.equal(win, u8)
+    comm.close()
+    ctx.close()

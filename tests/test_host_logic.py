@@ -84,3 +84,18 @@ def test_no_context_functions_validate_arguments():
     assert lib.vwgpu_abi_version() == 1
     with pytest.raises(Exception):
         stereo.subdivide_regions(np.zeros((4, 4), np.int32), (7, 7))
+
+
+def test_halo_plan_matches_the_python_partition():
+    """vwgpu_halo_plan (csrc/halo.hip, what the RCCL exchange of the C ABI works from) = the bounds fetch_strip_window uses."""
+    from visionworkbench_amd import partition
+    for world in (1, 2, 3, 8):
+        for rows in (0, 7, 1000, 32768):
+            for above, below in ((0, 0), (3, 9), (173, 173), (5000, 1)):
+                for rank in range(world):
+                    a, b = partition.row_strip(rank, world, rows)
+                    want = (a, b, max(0, a - above), min(rows, b + below))
+                    assert partition.halo_plan(rank, world, rows, above, below) == want
+    import pytest
+    with pytest.raises(ValueError):
+        partition.halo_plan(2, 2, 10, 0, 0)

@@ -26,6 +26,7 @@ SYMBOLS = [
     "vwgpu_disparity_blob_filter_dev", "vwgpu_disparity_blob_filter",
     "vwgpu_pyramid_correlate_dev", "vwgpu_pyramid_correlate",
     "vwgpu_calc_disparity_sgm_dev", "vwgpu_calc_disparity_sgm",
+    "vwgpu_comm_unique_id", "vwgpu_comm_create", "vwgpu_comm_destroy", "vwgpu_halo_plan", "vwgpu_fetch_strip_window_dev",
 ]
 
 
@@ -103,6 +104,12 @@ def load():
     bm = [P, I, P, I, I, PD, P, I, I, PD, I, I, I, I, P, PD]
     lib.vwgpu_calc_disparity_dev.argtypes = bm
     lib.vwgpu_calc_disparity.argtypes = bm
+    IP = ctypes.POINTER(ctypes.c_int)
+    lib.vwgpu_comm_unique_id.argtypes = [P]
+    lib.vwgpu_comm_create.argtypes = [P, P, I, I, ctypes.POINTER(P)]
+    lib.vwgpu_comm_destroy.argtypes = [P]
+    lib.vwgpu_halo_plan.argtypes = [I, I, I, I, I, IP, IP, IP, IP]
+    lib.vwgpu_fetch_strip_window_dev.argtypes = [P, P, P, I, I, I, I, I, P, IP]
     bs = [P, P, I, I, PD, I, I, P, PD]
     lib.vwgpu_fast_box_sum_dev.argtypes = bs
     lib.vwgpu_fast_box_sum.argtypes = bs

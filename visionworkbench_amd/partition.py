@@ -114,3 +114,61 @@ def fetch_strip_window(owned, rank, world, rows_total, halo_above, halo_below, g
         bounds.append((a, b, max(0, a - halo_above), min(rows_total, b + halo_below)))
     a, b, na, nb = bounds[rank]
     return exchange_halo(owned, a, b, na, nb, rank, world, bounds, group=group), na
+
+
+# ---- the same exchange through the engine's C ABI (csrc/halo.hip: RCCL send / recv, librccl.so opened at run time) -------------
+# For C++ hosts that do not link torch; the torch.distributed functions above are what bench.py and the gloo tests drive.
+
+def halo_plan(rank, world, rows_total, halo_above, halo_below):
+    """(owned_a, owned_b, need_a, need_b) of `rank` as vwgpu_halo_plan computes them (pure host arithmetic)."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    v = [ctypes.c_int() for _ in range(4)]
+    rc = lib.vwgpu_halo_plan(int(rank), int(world), int(rows_total), int(halo_above), int(halo_below), *[ctypes.byref(x) for x in v])
+    if rc:
+        raise ValueError("vwgpu_halo_plan: bad strip request")
+    return tuple(x.value for x in v)
+
+
+class EngineComm:
+    """vwgpu_comm: an RCCL communicator owned by the engine (one per process / GPU)."""
+
+    def __init__(self, ctx, unique_id, rank, world):
+        import ctypes
+        self._ctx = ctx
+        self._h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        ctx.check(ctx._lib.vwgpu_comm_create(ctx._h, buf, int(rank), int(world), ctypes.byref(self._h)))
+        self.rank, self.world = int(rank), int(world)
+
+    @staticmethod
+    def unique_id():
+        """128 bytes from ncclGetUniqueId; produced on one rank and handed to the others by the host application."""
+        import ctypes
+        from . import _lib
+        buf = ctypes.create_string_buffer(128)
+        rc = _lib.load().vwgpu_comm_unique_id(buf)
+        if rc:
+            raise RuntimeError("vwgpu_comm_unique_id failed (librccl.so not found?): rc=%d" % rc)
+        return buf.raw
+
+    def fetch_strip_window(self, owned, rows_total, halo_above, halo_below):
+        """owned: this rank's rows (row_strip) of a row-sharded image, a contiguous CUDA tensor.  Returns (window, first row)."""
+        import ctypes
+        import torch
+        a, b, na, nb = halo_plan(self.rank, self.world, rows_total, halo_above, halo_below)
+        if owned.shape[0] != b - a or not owned.is_contiguous():
+            raise ValueError("owned must hold rows [%d, %d) contiguously" % (a, b))
+        win = torch.empty((nb - na, owned.shape[1]), dtype=owned.dtype, device=owned.device)
+        first = ctypes.c_int()
+        self._ctx.set_stream(torch.cuda.current_stream(owned.device).cuda_stream)
+        self._ctx.check(self._ctx._lib.vwgpu_fetch_strip_window_dev(self._ctx._h, self._h, owned.data_ptr(), owned.shape[1], owned.element_size(),
+                                                                     int(rows_total), int(halo_above), int(halo_below), win.data_ptr(),
+                                                                     ctypes.byref(first)))
+        return win, first.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._ctx._lib.vwgpu_comm_destroy(self._h)
+            self._h = None
