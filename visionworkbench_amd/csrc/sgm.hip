@@ -1509,14 +1509,15 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     vwgpu_prof_scope ps(ctx, "sgm_cost");
     if (uniform)
     {
-      const int qd = ustride / 16;                          // 16-disparity groups per pixel (<= 32 for 512 disparities)
-      const dim3 blk(qd, std::max(1, 256 / qd)), grd((g.ocols + blk.y - 1) / blk.y, g.orows);
-      if (g.num_dy == 1)
+      if (g.num_dy == 1) {
         hipLaunchKernelGGL(cost_row_kernel, dim3((g.ocols + 255) / 256, g.orows), dim3(256), (size_t)(256 + num_disp) * 8, st, lc, lcw, rcen, rcw,
                            g.ocols, (int)num_disp, ustride, min_col - hk, min_row - hk, cost);
-      else
+      } else {
+        const int qd = ustride / 16;                        // 16-disparity groups per pixel (2-D searches: stride % 16 == 0, 1 .. 32 groups)
+        const dim3 blk(qd, std::max(1, 256 / qd)), grd((g.ocols + blk.y - 1) / blk.y, g.orows);
         hipLaunchKernelGGL(cost_uniform16_kernel<false>, grd, blk, 0, st, lc, lcw, rcen, rcw, g.ocols, g.orows, g.num_dx, (int)num_disp, ustride,
                            min_col - hk, min_row - hk, reinterpret_cast<uint32_t*>(cost));
+      }
     }
     else
       hipLaunchKernelGGL(cost_kernel, dim3((unsigned)((npix + 4 * COST_PPW - 1) / (4 * COST_PPW))), dim3(256), 0, st, lc, lcw, rcen, rcw, bounds, starts, g.ocols, npix,
