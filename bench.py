@@ -531,7 +531,10 @@ def main():
         else:
             res["cpu_baseline"] = None
         if world == 1 and not args.no_extra:
-            res["extra"] = extra_points(ctx, torch, stereo, core, vwa, synth, l_strip, r_strip, left, right)
+            try:                                  # the headline line must not depend on the side measurements
+                res["extra"] = extra_points(ctx, torch, stereo, core, vwa, synth, l_strip, r_strip, left, right)
+            except Exception as e:  # noqa: BLE001
+                res["extra"] = [{"name": "extra points failed", "error": "%s: %s" % (type(e).__name__, str(e)[:300])}]
         print(json.dumps(res))
     if world > 1:
         dist.barrier()
