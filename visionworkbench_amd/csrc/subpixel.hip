@@ -103,21 +103,27 @@ parabola_kernel(const float* __restrict__ disp, int w, int h, ptrdiff_t dstride_
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int b = 0; b < 3; ++b) s9[a][b] = 0u;
-    auto pack_row = [&](const float* p, int n, unsigned* w, int nw) __attribute__((always_inline)) {
+    // The rasters are bytes here (f32_to_u8_raster_kernel, pitches lrw / rrw in bytes): nw + 1 aligned dwords and one
+    // v_alignbyte per dword give the packed bytes starting at any x — 9 loads and 7 ALU ops per row pair of the window instead of
+    // 24 float loads and 24 conversions (the float form ran into the L1: 21 GB through it for a 4096^2 image).
+    auto pack_row = [&](const uint8_t* p, int n, unsigned* w, int nw) __attribute__((always_inline)) {
+      (void)n;
+      const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);
+      const unsigned* a = reinterpret_cast<const unsigned*>(p - sh);
+      unsigned raw[NB + 1];
 #pragma unroll
-      for (int j = 0; j < nw; ++j) {
-        unsigned v = 0;
+      for (int j = 0; j <= nw; ++j) raw[j] = a[j];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (4 * j + e < n) v = __builtin_amdgcn_cvt_pk_u8_f32(p[4 * j + e], e, v);
-        w[j] = v;
-      }
+      for (int j = 0; j < nw; ++j) w[j] = __builtin_amdgcn_alignbyte(raw[j + 1], raw[j], sh);
     };
+    const uint8_t* lbase8 = reinterpret_cast<const uint8_t*>(lras) + (ptrdiff_t)y * lrw + x;
+    const uint8_t* rras8 = reinterpret_cast<const uint8_t*>(rras);
     unsigned la[NW], lb[NW], lc[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) { la[j] = 0u; lb[j] = 0u; }
-    pack_row(lbase, K, lc, NW);
-    const float* rrow = rras + (ptrdiff_t)(y + Dy - 1 - range_miny) * rrw + (x + Dx - 1 - range_minx);
+    pack_row(lbase8, K, lc, NW);
+    lc[NW - 1] &= LAST;
+    const uint8_t* rrow = rras8 + (ptrdiff_t)(y + Dy - 1 - range_miny) * rrw + (x + Dx - 1 - range_minx);
     for (int q = -1; q <= ky; ++q) {
       unsigned rb[NB];
       pack_row(rrow, K + 2, rb, NB);
@@ -150,7 +156,7 @@ parabola_kernel(const float* __restrict__ disp, int w, int h, ptrdiff_t dstride_
 #pragma unroll
       for (int j = 0; j < NW; ++j) { la[j] = lb[j]; lb[j] = lc[j]; }
       if (q + 2 < ky) {
-        pack_row(lbase + (ptrdiff_t)(q + 2) * lrw, K, lc, NW);
+        pack_row(lbase8 + (ptrdiff_t)(q + 2) * lrw, K, lc, NW);
         lc[NW - 1] &= LAST;
       }
       rrow += rrw;
@@ -298,6 +304,22 @@ int vwgpu_launch_disparity_range(vwgpu_ctx* ctx, const float* disp3f, int w, int
   hipLaunchKernelGGL(disparity_range_kernel, grd, blk, 0, ctx->stream, disp3f, w, h, stride_px, d_out4);
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
+}
+
+// float raster (integers in [0,255]) -> bytes, 4 pixels per thread; the pitch is a multiple of 4 with room for the kernel's
+// aligned over-reads
+__global__ void f32_to_u8_raster_kernel(const float* __restrict__ src, int w, int h, uint8_t* __restrict__ dst, int pitch) {
+  const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x4 >= pitch || y >= h) return;
+  const float* s = src + (size_t)y * w;
+  unsigned v = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v = __builtin_amdgcn_cvt_pk_u8_f32(x4 + e < w ? s[x4 + e] : 0.0f, e, v);
+  *reinterpret_cast<unsigned*>(dst + (size_t)y * pitch + x4) = v;
+}
+int vwgpu_parabola_u8_pitch(int w) { return (w + 3) / 4 * 4 + 32; }
+void vwgpu_launch_f32_to_u8_raster(vwgpu_ctx* ctx, const float* src, int w, int h, uint8_t* dst, int pitch) {
+  hipLaunchKernelGGL(f32_to_u8_raster_kernel, dim3((pitch / 4 + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, ctx->stream, src, w, h, dst, pitch);
 }
 
 int vwgpu_launch_parabola(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t dstride_px,

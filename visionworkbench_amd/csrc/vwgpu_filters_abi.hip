@@ -248,7 +248,10 @@ int vwgpu_parabola_subpixel_dev(vwgpu_ctx* ctx, const float* d_disp, int w, int 
   const int lrw = w + 2 * hx, lrh = h + 2 * hy;
   const int rrw = lrw + (int)rsx, rrh = lrh + (int)rsy;
   const size_t lb = vwgpu_align_up((size_t)lrw * lrh * 4, 256), rb = vwgpu_align_up((size_t)rrw * rrh * 4, 256);
-  const size_t sb = vwgpu_align_up(std::max({(size_t)lrw * lrh, (size_t)rrw * rrh, (size_t)w * h, (size_t)rw * rh}) * 4, 256);
+  // integers in [0,255]: the kernel reads byte copies of the two rasters (built in the scratch area once the crops are done)
+  const int lp8 = vwgpu_parabola_u8_pitch(lrw), rp8 = vwgpu_parabola_u8_pitch(rrw);
+  const size_t l8b = vwgpu_align_up((size_t)lp8 * lrh + 64, 256), r8b = vwgpu_align_up((size_t)rp8 * rrh + 64, 256);
+  const size_t sb = std::max(vwgpu_align_up(std::max({(size_t)lrw * lrh, (size_t)rrw * rrh, (size_t)w * h, (size_t)rw * rh}) * 4, 256), l8b + r8b);
   rc = vwgpu_arena_reserve(ctx, &ctx->filt, lb + rb + sb);
   if (rc) return rc;
   char* base = static_cast<char*>(ctx->filt.base);
@@ -259,6 +262,15 @@ int vwgpu_parabola_subpixel_dev(vwgpu_ctx* ctx, const float* d_disp, int w, int 
   if (rc) return rc;
   rc = vwgpu_prefilter_region(ctx, d_right, rw, rh, rstride, mode, width, -hx + (int)rminx, -hy + (int)rminy, rrw, rrh, rras, scratch);
   if (rc) return rc;
+  if (integer_class == 2 && kx >= 3 && kx <= 15 && (kx & 1)) {                   // the sizes parabola_kernel<K, 2> is instantiated for
+    uint8_t* l8 = reinterpret_cast<uint8_t*>(scratch);
+    uint8_t* r8 = l8 + l8b;
+    vwgpu_launch_f32_to_u8_raster(ctx, lras, lrw, lrh, l8, lp8);
+    vwgpu_launch_f32_to_u8_raster(ctx, rras, rrw, rrh, r8, rp8);
+    return vwgpu_launch_parabola(ctx, d_disp, w, h, dstride, reinterpret_cast<const float*>(l8), lp8, reinterpret_cast<const float*>(r8), rp8,
+                                 (int)rminx, (int)rminy, kx, ky, d_out, ostride, 2);
+  }
+  if (integer_class == 2) integer_class = 1;                                      // other kernel sizes: the run-time loop on the float rasters
   return vwgpu_launch_parabola(ctx, d_disp, w, h, dstride, lras, lrw, rras, rrw, (int)rminx, (int)rminy, kx, ky, d_out, ostride, integer_class);
 }
 

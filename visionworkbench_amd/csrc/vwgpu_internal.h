@@ -170,6 +170,8 @@ extern "C" int vwgpu_generate_gaussian_kernel(double sigma, int size, float* tap
 
 // subpixel.hip
 int vwgpu_launch_disparity_range(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t stride_px, int* d_out4);
+int vwgpu_parabola_u8_pitch(int w);
+void vwgpu_launch_f32_to_u8_raster(vwgpu_ctx* ctx, const float* src, int w, int h, uint8_t* dst, int pitch);
 int vwgpu_launch_parabola(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t dstride_px,
                           const float* lras, int lrw, const float* rras, int rrw, int range_minx, int range_miny,
                           int kx, int ky, float* out3f, ptrdiff_t ostride_px, int integer_class = 0);
