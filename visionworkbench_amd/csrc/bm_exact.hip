@@ -515,8 +515,8 @@ void vwgpu_launch_float_grain(vwgpu_ctx* ctx, int n, const float* const* img, co
       ++m;
     }
     if (m == 0) continue;
-    // workgroups per image: ~64 K pixels each (8 loads in flight per thread), at least GRAIN_BLOCKS, at most 512
-    const unsigned blocks = (unsigned)std::min<size_t>(512, std::max<size_t>(GRAIN_BLOCKS, largest >> 16));
+    // workgroups per image: ~16 K pixels each (8 loads in flight per thread), at least GRAIN_BLOCKS, at most 2048
+    const unsigned blocks = (unsigned)std::min<size_t>(2048, std::max<size_t>(GRAIN_BLOCKS, largest >> 14));
     vwgpu_prof_scope ps(ctx, "float_grain");
     hipLaunchKernelGGL(float_grain_kernel, dim3(blocks, (unsigned)m), dim3(256), 0, ctx->stream, jobs);
   }
