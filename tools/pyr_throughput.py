@@ -11,7 +11,8 @@ W, tile = 4096, 1024
 L, R, _ = synth.stereo_pair(W, W, 129, 1)
 Lg, Rg = torch.from_numpy(L).cuda(), torch.from_numpy(R[:, 64:64 + W].copy()).cuda()
 tiles = [(x, y) for y in range(0, W, tile) for x in range(0, W, tile)]
-cases = [("SAD 7x7, integer imagery", 0, 0, 7), ("NCC 11x11, integer imagery", 0, 2, 11), ("LoG 1.4 + SAD 7x7", 2, 0, 7)]
+cases = [("SAD 7x7, integer imagery", 0, 0, 7), ("NCC 11x11, integer imagery", 0, 2, 11), ("LoG 1.4 + SAD 7x7", 2, 0, 7),
+         ("LoG 1.4 + NCC 11x11", 2, 2, 11)]
 threads = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
 torch.cuda.synchronize()
 for name, pf, cost, k in cases:
