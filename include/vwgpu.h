@@ -290,7 +290,7 @@ typedef struct vwgpu_pyramid_params {
   int min_consistency_level;     /* accepted for signature parity; block matching checks at level 0 only */
   int filter_half_kernel;        /* 0: no clean-up filtering */
   int max_pyramid_levels;
-  int algorithm;                 /* 0 = VW_CORRELATION_BM, 1 = VW_CORRELATION_SGM; MGM variants answer VWGPU_ERR_NOIMPL */
+  int algorithm;                 /* 0 = VW_CORRELATION_BM, 1 = _SGM, 2 = _MGM (use_mgm at every level), 3 = _FINAL_MGM (at level 0 only; CorrelationView.cc:365-366) */
   int blob_filter_area;          /* 0 = off; level i erases blobs of <= area / 2^i valid pixels */
   /* SGM only (CorrelationView.h:211-214): */
   int sgm_subpixel_mode;         /* vwgpu_sgm_subpixel; the reference's default is LC_BLEND */
@@ -334,7 +334,7 @@ typedef enum vwgpu_sgm_subpixel {      /* SemiGlobalMatcher::SgmSubpixelMode, sr
  * (src/vw/Stereo/SGM.h:108-147, 360-375). */
 typedef struct vwgpu_sgm_params {
   int cost_type;                 /* VWGPU_CENSUS_TRANSFORM or VWGPU_TERNARY_CENSUS_TRANSFORM (others: NOIMPL, like the reference) */
-  int use_mgm;                   /* must be 0 (MGM is not implemented) */
+  int use_mgm;                   /* != 0: accum_mgm_multithread (SGM.cc:2619-2700) instead of the eight independent path sweeps */
   int kernel_size;               /* 3, 5, 7 or 9 */
   int subpixel_mode;             /* vwgpu_sgm_subpixel */
   int search_buffer_x, search_buffer_y;

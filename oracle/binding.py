@@ -64,6 +64,8 @@ def lib():
         _LIB.vwo_disparity_blob_filter.argtypes = [P, I, I, I]
         _LIB.vwo_set_blob_filter_area.argtypes = [I]
         _LIB.vwo_set_blob_filter_area.restype = None
+        _LIB.vwo_set_sgm_algorithm.argtypes = [I]
+        _LIB.vwo_set_sgm_algorithm.restype = None
         _LIB.vwo_cross_corr_consistency_check_diff.argtypes = [P, I, I, P, I, I, F, P, I, I, I, I]
         _LIB.vwo_set_lr_disp_diff.argtypes = [P, I, I, I, I]
         _LIB.vwo_set_lr_disp_diff.restype = None
@@ -84,6 +86,7 @@ def lib():
         _LIB.vwo_pyramid_correlate_sgm.argtypes = [P, I, I, P, I, I, P, P, I, I, I, I, I, I, F, I, I, I, I, I, I, Z, I, I, I, I, I, P]
         _LIB.vwo_calc_disparity_sgm.argtypes = [I, P, I, I, P, I, I, I, I, I, I, I, I, Z, I, P, I, I, P, I, I, P, I, I, P, P, P, P]
         _LIB.vwo_calc_disparity_sgm_p.argtypes = [I, P, I, I, P, I, I, I, I, I, I, I, I, Z, I, P, I, I, P, I, I, P, I, I, I, I, P, P, P, P]
+        _LIB.vwo_calc_disparity_sgm_x.argtypes = [I, I, P, I, I, P, I, I, I, I, I, I, I, I, Z, I, P, I, I, P, I, I, P, I, I, I, I, P, P, P, P]
     return _LIB
 
 
@@ -329,8 +332,8 @@ class SemiGlobalMatcher:
     memory_limit_mb, p1, p2, ternary_census_threshold) — src/vw/Stereo/SGM.h:108-121."""
 
     def __init__(self, cost_type, min_dx, min_dy, max_dx, max_dy, kernel=5, subpixel=SUBPIXEL_LC_BLEND, search_buffer=(2, 2),
-                 memory_limit_mb=6000, p1=0, p2=0, ternary_thr=5, num_threads=1):
-        self._h = lib().vwo_sgm_create(int(cost_type), 0, min_dx, min_dy, max_dx, max_dy, kernel, int(subpixel),
+                 memory_limit_mb=6000, p1=0, p2=0, ternary_thr=5, num_threads=1, use_mgm=False):
+        self._h = lib().vwo_sgm_create(int(cost_type), int(bool(use_mgm)), min_dx, min_dy, max_dx, max_dy, kernel, int(subpixel),
                                        search_buffer[0], search_buffer[1], memory_limit_mb, p1, p2, ternary_thr, num_threads)
         if not self._h:
             raise ValueError("vwo_sgm_create: unsupported cost type / kernel size")
@@ -382,7 +385,8 @@ class SemiGlobalMatcher:
 
 
 def calc_disparity_sgm(cost_type, left, right, search_volume, kernel, subpixel=SUBPIXEL_LC_BLEND, search_buffer=(2, 2),
-                       memory_limit_mb=6000, left_mask=None, right_mask=None, prev_disparity=None, num_threads=1, p1=0, p2=0):
+                       memory_limit_mb=6000, left_mask=None, right_mask=None, prev_disparity=None, num_threads=1, p1=0, p2=0,
+                       use_mgm=False):
     """calc_disparity_sgm on cropped regions: left (lh, lw) float32, right (lh+sy, lw+sx) float32.
     Returns (integer disparity (oh, ow, 3) int32, sub-pixel disparity (oh, ow, 3) float32)."""
     l = np.ascontiguousarray(left, np.float32)
@@ -393,7 +397,7 @@ def calc_disparity_sgm(cost_type, left, right, search_volume, kernel, subpixel=S
     out = np.zeros((l.shape[0], l.shape[1], 3), np.int32)
     sub = np.zeros((l.shape[0], l.shape[1], 3), np.float32)
     ow, oh = ctypes.c_int(), ctypes.c_int()
-    rc = lib().vwo_calc_disparity_sgm_p(int(cost_type), _p(l), l.shape[1], l.shape[0], _p(r), r.shape[1], r.shape[0],
+    rc = lib().vwo_calc_disparity_sgm_x(int(cost_type), int(bool(use_mgm)), _p(l), l.shape[1], l.shape[0], _p(r), r.shape[1], r.shape[0],
                                         search_volume[0], search_volume[1], kernel, int(subpixel), search_buffer[0], search_buffer[1],
                                         memory_limit_mb, num_threads, None if lm is None else _p(lm), lmw, lmh,
                                         None if rm is None else _p(rm), rmw, rmh, None if pd is None else _p(pd), pw, ph,
@@ -406,8 +410,9 @@ def calc_disparity_sgm(cost_type, left, right, search_volume, kernel, subpixel=S
 
 def pyramid_correlate_sgm(left, right, left_mask, right_mask, search_region, kernel, cost_type, consistency_threshold=-1.0,
                           min_consistency_level=0, filter_half_kernel=0, max_pyramid_levels=5, subpixel=SUBPIXEL_LC_BLEND,
-                          search_buffer=(2, 2), memory_limit_mb=6000, num_threads=1, bbox=None):
-    """One tile of pyramid_correlate(..., VW_CORRELATION_SGM): returns (h, w, 3) float32 sub-pixel PixelMask<Vector2f>."""
+                          search_buffer=(2, 2), memory_limit_mb=6000, num_threads=1, bbox=None, algorithm=1):
+    """One tile of pyramid_correlate(..., VW_CORRELATION_SGM | _MGM (algorithm=2) | _FINAL_MGM (3)): returns (h, w, 3) float32
+    sub-pixel PixelMask<Vector2f>."""
     l = np.ascontiguousarray(left, np.float32)
     r = np.ascontiguousarray(right, np.float32)
     lm = None if left_mask is None else np.ascontiguousarray(left_mask, np.uint8)
@@ -415,12 +420,14 @@ def pyramid_correlate_sgm(left, right, left_mask, right_mask, search_region, ker
     if bbox is None:
         bbox = (0, 0, l.shape[1], l.shape[0])
     out = np.zeros((bbox[3], bbox[2], 3), np.float32)
+    lib().vwo_set_sgm_algorithm(int(algorithm))
     rc = lib().vwo_pyramid_correlate_sgm(_p(l), l.shape[1], l.shape[0], _p(r), r.shape[1], r.shape[0],
                                          None if lm is None else _p(lm), None if rm is None else _p(rm),
                                          search_region[0], search_region[1], search_region[2], search_region[3], int(kernel), int(cost_type),
                                          float(consistency_threshold), int(min_consistency_level), int(filter_half_kernel),
                                          int(max_pyramid_levels), int(subpixel), search_buffer[0], search_buffer[1], memory_limit_mb,
                                          num_threads, bbox[0], bbox[1], bbox[2], bbox[3], _p(out))
+    lib().vwo_set_sgm_algorithm(1)
     if rc:
         raise ValueError("vwo_pyramid_correlate_sgm rc=%d" % rc)
     return out

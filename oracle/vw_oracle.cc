@@ -884,11 +884,12 @@ int vwo_disparity_blob_filter(int32_t* disp3, int w, int h, int area) {
 }  // extern "C" (reopened below)
 
 static thread_local int g_blob_filter_area = 0;
+static thread_local int g_sgm_algorithm = 1;
 // lr_disp_diff of the NEXT pyramid call on this thread (CorrelationView.h:84: m_lr_disp_diff, m_region_ul)
 static thread_local float* g_lr_diff = nullptr;
 static thread_local int g_lr_cols = 0, g_lr_rows = 0, g_lr_ulx = 0, g_lr_uly = 0;
 
-// algorithm 0 = VW_CORRELATION_BM, 1 = VW_CORRELATION_SGM (MGM variants are not restated)
+// algorithm 0 = VW_CORRELATION_BM, 1 = VW_CORRELATION_SGM, 2 = VW_CORRELATION_MGM, 3 = VW_CORRELATION_FINAL_MGM (MGM at level 0 only)
 static int pyramid_impl(const float* left, int lw, int lh, const float* right, int rw, int rh,
                         const uint8_t* lmask_in, const uint8_t* rmask_in,
                         int prefilter_mode, float prefilter_width,
@@ -1001,10 +1002,11 @@ static int pyramid_impl(const float* left, int lw, int lh, const float* right, i
       int ow = 0, oh = 0;
       std::vector<int32_t> d((size_t)lr.sizex() * lr.sizey() * 3);
       std::vector<float> sub(on_last_level ? d.size() : 0);
-      int rc_ = vwo_calc_disparity_sgm(cost_type, lc.data(), lr.sizex(), lr.sizey(), rc.data(), rr.sizex(), rr.sizey(), sx, sy, kx,
+      const int use_mgm = (algorithm == 2 || (algorithm == 3 && level == 0)) ? 1 : 0;      // CorrelationView.cc:365-366
+      int rc_ = vwo_calc_disparity_sgm_x(cost_type, use_mgm, lc.data(), lr.sizex(), lr.sizey(), rc.data(), rr.sizex(), rr.sizey(), sx, sy, kx,
                                        sgm_subpixel_mode, sgm_sbx, sgm_sby, memory_limit_mb, num_threads,
                                        lmp[level].d.data(), lmp[level].w, lmp[level].h, rmp[level].d.data(), rmp[level].w, rmp[level].h,
-                                       have_prev ? prev_disparity.data() : nullptr, pdw, pdh, d.data(), on_last_level ? sub.data() : nullptr, &ow, &oh);
+                                       have_prev ? prev_disparity.data() : nullptr, pdw, pdh, 0, 0, d.data(), on_last_level ? sub.data() : nullptr, &ow, &oh);
       if (rc_) return rc_;
       if (ow != dw || oh != dh) return -3;
       std::copy(d.begin(), d.begin() + (size_t)dw * dh * 3, disparity.begin());
@@ -1022,11 +1024,11 @@ static int pyramid_impl(const float* left, int lw, int lh, const float* right, i
         std::vector<float> b = crop_ext(Lv.d.data(), Lv.w, Lv.h, lrev, VWO_EDGE_CONSTANT);
         std::vector<int32_t> rl((size_t)rrev.sizex() * rrev.sizey() * 3);
         int row = 0, roh = 0;
-        rc_ = vwo_calc_disparity_sgm(cost_type, a.data(), rrev.sizex(), rrev.sizey(), b.data(), lrev.sizex(), lrev.sizey(), sx, sy, kx,
+        rc_ = vwo_calc_disparity_sgm_x(cost_type, use_mgm, a.data(), rrev.sizex(), rrev.sizey(), b.data(), lrev.sizex(), lrev.sizey(), sx, sy, kx,
                                      sgm_subpixel_mode, sgm_sbx, sgm_sby, memory_limit_mb, num_threads,
                                      right_rl_mask.data(), rrm_w, rrm_h, left_rl_mask.data(), lrm_w, lrm_h,
                                      have_prev && !prev_disparity_rl.empty() ? prev_disparity_rl.data() : nullptr, prlw, prlh,
-                                     rl.data(), nullptr, &row, &roh);
+                                     0, 0, rl.data(), nullptr, &row, &roh);
         if (rc_) return rc_;
         rl.resize((size_t)row * roh * 3);
         for (size_t i = 0; i < (size_t)row * roh; ++i) { rl[3*i] -= sx; rl[3*i+1] -= sy; }
@@ -1156,9 +1158,12 @@ int vwo_pyramid_correlate_sgm(const float* left, int lw, int lh, const float* ri
                               int bx, int by, int bw, int bh, float* out3f) {
   return pyramid_impl(left, lw, lh, right, rw, rh, lmask, rmask, 0, 0.0f, sminx, sminy, smaxx, smaxy, kernel, kernel,
                       cost_type, 0, 0.0, consistency_threshold, filter_half_kernel, max_pyramid_levels,
-                      bx, by, bw, bh, out3f, 1, min_consistency_level, sgm_subpixel_mode, sgm_sbx, sgm_sby, memory_limit_mb, num_threads,
+                      bx, by, bw, bh, out3f, g_sgm_algorithm, min_consistency_level, sgm_subpixel_mode, sgm_sbx, sgm_sby, memory_limit_mb, num_threads,
                       g_blob_filter_area);
 }
+
+// algorithm of the following vwo_pyramid_correlate_sgm calls of this thread: 1 = VW_CORRELATION_SGM (default), 2 = _MGM, 3 = _FINAL_MGM
+void vwo_set_sgm_algorithm(int algorithm) { g_sgm_algorithm = algorithm >= 1 && algorithm <= 3 ? algorithm : 1; }
 
 // blob_filter_area of the NEXT vwo_pyramid_correlate / _sgm call on this thread (keeps the long signatures stable)
 void vwo_set_blob_filter_area(int area) { g_blob_filter_area = area; }

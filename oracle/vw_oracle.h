@@ -136,6 +136,9 @@ int vwo_pyramid_correlate_sgm(const float* left, int lw, int lh, const float* ri
                               float consistency_threshold, int min_consistency_level, int filter_half_kernel, int max_pyramid_levels,
                               int sgm_subpixel_mode, int sgm_sbx, int sgm_sby, size_t memory_limit_mb, int num_threads,
                               int bx, int by, int bw, int bh, float* out3f);
+/* algorithm of the following vwo_pyramid_correlate_sgm calls of this thread: 1 = VW_CORRELATION_SGM (default), 2 = VW_CORRELATION_MGM,
+ * 3 = VW_CORRELATION_FINAL_MGM (src/vw/Stereo/CorrelationView.cc:365-366) */
+void vwo_set_sgm_algorithm(int algorithm);
 
 /* disparity_blob_filter (CorrelationView.cc:242-271): zero every valid pixel of an 8-connected component of valid pixels
  * with at most `area` pixels; vwo_blob_sizes = the size of each pixel's component (0 for invalid pixels), the quantity
@@ -186,6 +189,12 @@ int vwo_calc_disparity_sgm(int cost_type, const float* left, int lw, int lh, con
 
 /* the same with user penalties (p1 / p2 = 0: the defaults) */
 int vwo_calc_disparity_sgm_p(int cost_type, const float* left, int lw, int lh, const float* right, int rw, int rh,
+                             int sx, int sy, int kernel, int subpixel, int sbx, int sby, size_t memory_limit_mb, int num_threads,
+                             const uint8_t* lmask, int lmw, int lmh, const uint8_t* rmask, int rmw, int rmh,
+                             const int32_t* prev, int pw, int ph, int p1, int p2, int32_t* out_disp, float* out_subpixel, int* ow, int* oh);
+
+/* the same with use_mgm (accum_mgm_multithread, SGM.cc:2619-2700) */
+int vwo_calc_disparity_sgm_x(int cost_type, int use_mgm, const float* left, int lw, int lh, const float* right, int rw, int rh,
                              int sx, int sy, int kernel, int subpixel, int sbx, int sby, size_t memory_limit_mb, int num_threads,
                              const uint8_t* lmask, int lmw, int lmh, const uint8_t* rmask, int rmw, int rmh,
                              const int32_t* prev, int pw, int ph, int p1, int p2, int32_t* out_disp, float* out_subpixel, int* ow, int* oh);

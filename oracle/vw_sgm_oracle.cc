@@ -18,7 +18,10 @@
 //   select_best_disparity               SGM.cc:1159-1284, create_disparity_view :1286-1408
 //   create_disparity_view_subpixel      SGM.cc:1497-1614, compute_subpixel_offset :1445-1479, fits :1411-1436,
 //                                       ParabolaFit2d::find_peak SGMAssist.h:99-135
-// MGM (use_mgm) is out of scope and returns an error.
+//   accum_mgm_multithread (use_mgm)     SGM.cc:2619-2700: eight SmoothPathAccumTask passes (SGMAssist.h:835-1239), each pixel the
+//                                       mean of TWO evaluate_path results (path predecessor + perpendicular predecessor);
+//                                       MultiAccumRowBuffer :236-543 (line buffers, added to the sums line by line);
+//                                       get_path_pixel_diff SGM.cc:2715-2721; small-buffer size for MGM :703-713
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -126,6 +129,7 @@ struct IBox {                                      // vw::BBox2i as used by the 
 };
 
 struct Matcher {
+  bool use_mgm = false;
   int cost_type, min_dx, min_dy, max_dx, max_dy, kernel, subpixel, sbx, sby, ternary_thr, num_threads;
   size_t memory_limit_mb;
   AccumCostType p1, p2;
@@ -186,7 +190,13 @@ struct Matcher {
     const int line_size = (int)(std::sqrt((double)(ocols * ocols + orows * orows)) + 1);      // OneLineBuffer::one_buf_size
     size_t one_buf = (size_t)line_size * num_disp;
     if (one_buf > main_buf_size) one_buf = main_buf_size;
-    const size_t small_buf = one_buf * num_threads;
+    size_t small_buf = one_buf * num_threads;
+    if (use_mgm) {                                             // :709-713: four vertical and four horizontal one-path line buffers
+      size_t vert = (size_t)orows * num_disp, horiz = (size_t)ocols * num_disp;      // MultiAccumRowBuffer::multi_buf_size
+      if (vert > main_buf_size) vert = main_buf_size;
+      if (horiz > main_buf_size) horiz = main_buf_size;
+      small_buf = 4 * vert + 4 * horiz;
+    }
     const double MB = 1024.0 * 1024.0;
     const double total = (double)n * (3.0 / MB) + (double)small_buf * (2.0 / MB);
     return !(total > (double)memory_limit_mb);
@@ -415,6 +425,62 @@ struct Matcher {
     for (int i = 0; i < H - 1; ++i) pass_line(L, W - 1, i, -1, -1, line, full_prior);
   }
 
+
+  // accum_mgm_multithread (:2619-2700).  One SmoothPathAccumTask per direction (SGMAssist.h:911-1236): pixels are visited in
+  // raster order of the task's trip; a pixel with both predecessors inside (the task's own border test) gets
+  // (evaluate_path(path predecessor) + evaluate_path(perpendicular predecessor)) / 2, every other pixel its local costs.
+  // Both evaluations use ONE intensity difference, get_path_pixel_diff(col, row, dir) = |I(col,row) - I(col-dir_x, row-dir_y)|
+  // (:2715-2721) — with the task's dir pointing AT the path predecessor that is the pixel on the far side, not the predecessor.
+  // The line buffers of MultiAccumRowBuffer only bound the memory: a direction's values are kept here in a full volume `vol`
+  // and added to the sums (u16 wrap-around) once per pixel, which is what add_lead_buffer_to_accum does line by line.
+  // Pixels without disparities are skipped (get_num_disp == 0 -> continue) but can still serve as (empty) predecessors.
+  struct MgmDir { int ax, ay, bx, by; int need_c_lo, need_c_hi, need_r_lo, need_r_hi; int order; };
+  void mgm_pass(U8Img const& L, MgmDir const& D, std::vector<AccumCostType>& vol, std::vector<AccumCostType>& full_prior,
+                std::vector<AccumCostType>& tmp) {
+    const int W = ocols, H = orows, lastc = W - 1, lastr = H - 1;
+    auto visit = [&](int col, int row) {
+      const int nd = ndisp(col, row);
+      if (nd == 0) return;
+      const size_t st = starts[(size_t)row * W + col];
+      const CostType* local = cost.data() + st;
+      AccumCostType* out = vol.data() + st;
+      const bool ok = (!D.need_c_lo || col > 0) && (!D.need_c_hi || col < lastc) && (!D.need_r_lo || row > 0) && (!D.need_r_hi || row < lastr);
+      if (ok) {
+        // the reference indexes the image unchecked; with min_disp = 0 (calc_disparity_sgm) and kernel >= 3 the far-side pixel
+        // is always inside the image.  Clamped here so that other callers stay defined.
+        const int fc = std::min(std::max(col - D.ax + min_col, 0), L.w - 1), fr = std::min(std::max(row - D.ay + min_row, 0), L.h - 1);
+        const int diff = std::abs((int)L(col + min_col, row + min_row) - (int)L(fc, fr));
+        const int ca = col + D.ax, ra = row + D.ay, cb = col + D.bx, rb = row + D.by;
+        evaluate_path(col, row, ca, ra, vol.data() + starts[(size_t)ra * W + ca], full_prior.data(), local, out, diff);
+        evaluate_path(col, row, cb, rb, vol.data() + starts[(size_t)rb * W + cb], full_prior.data(), local, tmp.data(), diff);
+        for (int d = 0; d < nd; ++d) out[d] = (AccumCostType)(((int)out[d] + (int)tmp[d]) / 2);
+      } else {
+        for (int d = 0; d < nd; ++d) out[d] = local[d];
+      }
+      AccumCostType* dst = accum.data() + st;
+      for (int d = 0; d < nd; ++d) dst[d] = (AccumCostType)(dst[d] + out[d]);
+    };
+    switch (D.order) {
+      case 0: for (int r = 0; r < H; ++r) for (int c = 0; c < W; ++c) visit(c, r); break;             // rows down, columns right
+      case 1: for (int r = lastr; r >= 0; --r) for (int c = lastc; c >= 0; --c) visit(c, r); break;   // rows up, columns left
+      case 2: for (int c = 0; c < W; ++c) for (int r = lastr; r >= 0; --r) visit(c, r); break;        // columns right, rows up
+      default: for (int c = lastc; c >= 0; --c) for (int r = 0; r < H; ++r) visit(c, r); break;       // columns left, rows down
+    }
+  }
+  void accumulate_mgm(U8Img const& L) {
+    std::vector<AccumCostType> vol(main_buf_size), full_prior(num_disp, bad_val()), tmp(num_disp);
+    //                         path pred  perp pred   col>0 col<last row>0 row<last  trip
+    const MgmDir dirs[8] = {{-1,  0,  0, -1,   1, 0, 1, 0,  0},      // L   (SGMAssist.h:911-955)
+                            { 1,  0,  0,  1,   0, 1, 0, 1,  1},      // R   (:998-1033)
+                            {-1, -1,  1, -1,   1, 1, 1, 0,  0},      // TL  (:958-996)
+                            { 1,  1, -1,  1,   1, 1, 0, 1,  1},      // BR  (:1035-1071)
+                            { 0, -1,  1,  0,   0, 1, 1, 0,  3},      // T   (:1147-1182)
+                            { 0,  1, -1,  0,   1, 0, 0, 1,  2},      // B   (:1073-1108)
+                            { 1, -1,  1,  1,   0, 1, 1, 1,  3},      // TR  (:1184-1219)
+                            {-1,  1, -1, -1,   1, 0, 1, 1,  2}};     // BL  (:1110-1145)
+    for (const MgmDir& d : dirs) mgm_pass(L, d, vol, full_prior, tmp);
+  }
+
   // select_best_disparity (:1159-1284); smooths accum_vec in place when several minima tie
   void select_best(AccumCostType* accum_vec, Bounds const& b, int& min_index, std::vector<AccumCostType>& buffer) const {
     const int height = b.v[3] - b.v[1] + 1, width = b.v[2] - b.v[0] + 1, n = height * width;
@@ -582,7 +648,7 @@ struct Matcher {
     cost.assign(main_buf_size, 0);
     accum.assign(main_buf_size, 0);
     compute_costs(L, R);
-    accumulate(L);
+    if (use_mgm) accumulate_mgm(L); else accumulate(L);
     return 0;
   }
 };
@@ -622,11 +688,11 @@ int vwo_hamming_distance(uint64_t a, uint64_t b) { return hamming(a, b); }
 
 vwo_sgm* vwo_sgm_create(int cost_type, int use_mgm, int min_dx, int min_dy, int max_dx, int max_dy, int kernel, int subpixel,
                         int sbx, int sby, size_t memory_limit_mb, int p1, int p2, int ternary_thr, int num_threads) {
-  if (use_mgm) return nullptr;
   if (cost_type != COST_CENSUS && cost_type != COST_TERNARY) return nullptr;       // SGM.cc:1886-1890 (NoImplErr)
   if (kernel != 3 && kernel != 5 && kernel != 7 && kernel != 9) return nullptr;    // :1877-1884
   vwo_sgm* s = new vwo_sgm;
   Matcher& m = s->m;
+  m.use_mgm = use_mgm != 0;
   m.cost_type = cost_type; m.min_dx = min_dx; m.min_dy = min_dy; m.max_dx = max_dx; m.max_dy = max_dy; m.kernel = kernel;
   m.subpixel = subpixel; m.sbx = sbx; m.sby = sby; m.memory_limit_mb = memory_limit_mb; m.ternary_thr = ternary_thr;
   m.num_threads = num_threads > 0 ? num_threads : 1;
@@ -672,7 +738,7 @@ int vwo_sgm_read(vwo_sgm* s, int32_t* bounds4, uint64_t* starts, uint8_t* cost, 
 int vwo_sgm_p1p2(vwo_sgm* s, int* p1, int* p2) { *p1 = s->m.p1; *p2 = s->m.p2; return 0; }
 
 // calc_disparity_sgm (SGM.cc:167-229) on already cropped float regions: left lw x lh, right (lw + sx) x (lh + sy).
-int vwo_calc_disparity_sgm_p(int cost_type, const float* left, int lw, int lh, const float* right, int rw, int rh,
+int vwo_calc_disparity_sgm_x(int cost_type, int use_mgm, const float* left, int lw, int lh, const float* right, int rw, int rh,
                            int sx, int sy, int kernel, int subpixel, int sbx, int sby, size_t memory_limit_mb, int num_threads,
                            const uint8_t* lmask, int lmw, int lmh, const uint8_t* rmask, int rmw, int rmh,
                            const int32_t* prev, int pw, int ph, int p1, int p2, int32_t* out_disp, float* out_subpixel, int* ow, int* oh) {
@@ -680,7 +746,7 @@ int vwo_calc_disparity_sgm_p(int cost_type, const float* left, int lw, int lh, c
   std::vector<uint8_t> l8((size_t)lw * lh), r8((size_t)rw * rh);
   vwo_u8_convert(left, lw, lh, l8.data());
   vwo_u8_convert(right, rw, rh, r8.data());
-  vwo_sgm* s = vwo_sgm_create(cost_type, 0, 0, 0, sx, sy, kernel, subpixel, sbx, sby, memory_limit_mb, p1, p2, 5, num_threads);      // p1 / p2 = 0: the defaults of SGM.cc:106-160
+  vwo_sgm* s = vwo_sgm_create(cost_type, use_mgm, 0, 0, sx, sy, kernel, subpixel, sbx, sby, memory_limit_mb, p1, p2, 5, num_threads);      // p1 / p2 = 0: the defaults of SGM.cc:106-160
   if (!s) return -2;
   const int hk = (kernel - 1) / 2;
   const int eow = std::min(lw - 1 - hk, rw - 1 - (hk + sx)) - hk + 1, eoh = std::min(lh - 1 - hk, rh - 1 - (hk + sy)) - hk + 1;
@@ -693,7 +759,13 @@ int vwo_calc_disparity_sgm_p(int cost_type, const float* left, int lw, int lh, c
   vwo_sgm_destroy(s);
   return rc;
 }
-
+int vwo_calc_disparity_sgm_p(int cost_type, const float* left, int lw, int lh, const float* right, int rw, int rh,
+                           int sx, int sy, int kernel, int subpixel, int sbx, int sby, size_t memory_limit_mb, int num_threads,
+                           const uint8_t* lmask, int lmw, int lmh, const uint8_t* rmask, int rmw, int rmh,
+                           const int32_t* prev, int pw, int ph, int p1, int p2, int32_t* out_disp, float* out_subpixel, int* ow, int* oh) {
+  return vwo_calc_disparity_sgm_x(cost_type, 0, left, lw, lh, right, rw, rh, sx, sy, kernel, subpixel, sbx, sby, memory_limit_mb, num_threads,
+                                  lmask, lmw, lmh, rmask, rmw, rmh, prev, pw, ph, p1, p2, out_disp, out_subpixel, ow, oh);
+}
 
 int vwo_calc_disparity_sgm(int cost_type, const float* left, int lw, int lh, const float* right, int rw, int rh,
                            int sx, int sy, int kernel, int subpixel, int sbx, int sby, size_t memory_limit_mb, int num_threads,

@@ -34,12 +34,12 @@ def _pair(rng, h, w, sx, sy, shift=(3, 2), smooth=False, scale=255.0):
     return np.ascontiguousarray(left), np.ascontiguousarray(right)
 
 
-def _both(vw, oracle, cost, left, right, search, k, sub, sb=(2, 2), mem=6000, lm=None, rm=None, prev=None):
+def _both(vw, oracle, cost, left, right, search, k, sub, sb=(2, 2), mem=6000, lm=None, rm=None, prev=None, mgm=False, p1=0, p2=0):
     h, w = left.shape
-    gi, gs = vw.calc_disparity_sgm(cost, left, right, _box(w, h), search, (k, k), subpixel_mode=sub, search_buffer=sb,
-                                   memory_limit_mb=mem, left_mask=lm, right_mask=rm, prev_disparity=prev, with_subpixel=True)
+    gi, gs = vw.calc_disparity_sgm(cost, left, right, _box(w, h), search, (k, k), use_mgm=mgm, subpixel_mode=sub, search_buffer=sb,
+                                   memory_limit_mb=mem, left_mask=lm, right_mask=rm, prev_disparity=prev, with_subpixel=True, p1=p1, p2=p2)
     oi, os_ = oracle.calc_disparity_sgm(cost, left, right, search, k, subpixel=sub, search_buffer=sb, memory_limit_mb=mem,
-                                        left_mask=lm, right_mask=rm, prev_disparity=prev)
+                                        left_mask=lm, right_mask=rm, prev_disparity=prev, use_mgm=mgm, p1=p1, p2=p2)
     return gi, gs, oi, os_
 
 
@@ -150,7 +150,7 @@ def test_torch_device_entry_and_errors(vw, oracle):
     with pytest.raises(NoImplErr):
         vw.calc_disparity_sgm(CENSUS, left, right, _box(50, 40), (5, 3), (11, 11))    # census sizes 3..9 only
     with pytest.raises(NoImplErr):
-        vw.calc_disparity_sgm(CENSUS, left, right, _box(50, 40), (5, 3), (5, 5), use_mgm=True)
+        vw.calc_disparity_sgm(0, left, right, _box(50, 40), (5, 3), (5, 5), use_mgm=True)   # block cost with MGM
     with pytest.raises(ArgumentErr):
         vw.calc_disparity_sgm(CENSUS, left, right, _box(51, 40), (5, 3), (5, 5))
 
@@ -191,7 +191,9 @@ def test_pyramid_sgm_masks_and_subtile(vw, oracle):
     with pytest.raises(NoImplErr):
         vw.pyramid_correlate(left, right, None, None, 0, 0.0, box, (5, 5), 0, algorithm=1)        # block cost with SGM
     with pytest.raises(NoImplErr):
-        vw.pyramid_correlate(left, right, None, None, 0, 0.0, box, (5, 5), CENSUS, algorithm=2)   # MGM
+        vw.pyramid_correlate(left, right, None, None, 0, 0.0, box, (5, 5), 0, algorithm=2)        # block cost with MGM
+    with pytest.raises(NoImplErr):
+        vw.pyramid_correlate(left, right, None, None, 0, 0.0, box, (5, 5), CENSUS, algorithm=4)   # VW_CORRELATION_OTHER
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -308,4 +310,81 @@ def test_pyramid_sgm_large_tile(vw, oracle):
     g = vw.pyramid_correlate(L, R, None, None, 0, 0.0, BBox2i.from_corners((-64, -1), (64, 1)), (7, 7), CENSUS, consistency_threshold=2,
                              filter_half_kernel=5, max_pyramid_levels=5, algorithm=1, bbox=BBox2i(*bb))
     o = oracle.pyramid_correlate_sgm(L, R, None, None, (-64, -1, 64, 1), 7, CENSUS, 2, 0, 5, 5, bbox=bb)
+    assert np.array_equal(g[..., 2], o[..., 2]) and np.abs(g[..., :2] - o[..., :2]).max() < 1e-5
+
+
+# ---- MGM (use_mgm; accum_mgm_multithread, SGM.cc:2619-2700) ----------------------------------------------------------------------
+# The reference's tests hold no MGM vector (TestSGM.cxx:47 runs use_mgm = false), so the oracle's accumulate_mgm is a restatement
+# that nothing pins: these tests show that the GPU fronts and the oracle's raster loops compute the same function.
+
+@pytest.mark.parametrize("cost,k,sx,sy,w,h", [(CENSUS, 5, 9, 0, 83, 60), (CENSUS, 3, 6, 4, 64, 48), (TERNARY, 7, 12, 2, 90, 41), (CENSUS, 9, 40, 0, 120, 33),
+                                              (CENSUS, 5, 129, 0, 200, 24), (CENSUS, 5, 3, 3, 12, 70), (CENSUS, 3, 2, 0, 3, 3), (CENSUS, 3, 2, 1, 40, 3)])
+def test_mgm_identical_to_oracle(vw, oracle, cost, k, sx, sy, w, h):
+    """Every direction's front order (anti-diagonals, rows, columns), wide / tall / one-pixel outputs, 1-D and 2-D searches."""
+    rng = np.random.default_rng(17 * sx + sy + k)
+    left, right = _pair(rng, h, w, sx, sy, shift=(min(3, sx), min(2, sy)), smooth=(k == 5))
+    gi, gs, oi, os_ = _both(vw, oracle, cost, left, right, (sx, sy), k, 5, mgm=True)
+    assert gi.shape == oi.shape == (h - k + 1, w - k + 1, 3)
+    assert np.array_equal(gi, oi)
+    assert np.abs(gs - os_).max() < 1e-5
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_mgm_ragged_boxes_masks_and_previous_level(vw, oracle, seed):
+    """Masks with empty borders and a previous level with untrusted holes: pixels without disparities are skipped but still serve as
+    (empty) predecessors; ragged vectors on every front.  mem = 1 forces the MGM small-buffer term through the conservation levels."""
+    rng = np.random.default_rng(300 + seed)
+    V = np.iinfo(np.int32).max
+    k = int(rng.choice([3, 5, 7]))
+    sx, sy = int(rng.integers(2, 14)), int(rng.integers(0, 5))
+    h, w = int(rng.integers(36, 60)), int(rng.integers(40, 80))
+    base = rng.integers(0, 256, (h + sy + 8, w + sx + 8)).astype(np.float32)
+    left = np.ascontiguousarray(base[4:4 + h, 4:4 + w])
+    right = np.ascontiguousarray(base[4 - min(2, sy):4 - min(2, sy) + h + sy, 1:1 + w + sx])
+    oh, ow = h - k + 1, w - k + 1
+    lm = np.full((oh, ow), 255, np.uint8)
+    lm[:int(rng.integers(0, 4))] = 0
+    lm[:, :int(rng.integers(0, 4))] = 0
+    lm[10:14, 12:30] = 0
+    rm = np.full((oh + sy + 2, ow + sx + 1), 255, np.uint8)
+    rm[:, :int(rng.integers(0, sx + 2))] = 0
+    rm[-int(rng.integers(1, 4)):] = 0
+    ph, pw = (oh + 1) // 2 + int(rng.integers(-2, 3)), (ow + 1) // 2 + int(rng.integers(-2, 3))
+    prev = np.zeros((ph, pw, 3), np.int32)
+    prev[..., 0] = rng.integers(0, sx // 2 + 1, (ph, pw))
+    prev[..., 1] = rng.integers(0, sy // 2 + 1, (ph, pw))
+    prev[..., 2] = np.where(rng.random((ph, pw)) < 0.3, 0, V)
+    for mem in (6000, 1):
+        gi, gs, oi, os_ = _both(vw, oracle, CENSUS, left, right, (sx, sy), k, 5, lm=lm, rm=rm, prev=prev, mgm=True, mem=mem)
+        assert np.array_equal(gi, oi), mem
+        assert np.abs(gs - os_).max() < 1e-5
+
+
+@pytest.mark.parametrize("p1,p2", [(5, 60), (200, 9000), (1, 65000)])
+def test_mgm_user_penalties(vw, oracle, p1, p2):
+    """P2 > 7937: the eight directions can no longer share packed 16-bit atomics and run one at a time, the u16 sums wrap like the reference's."""
+    rng = np.random.default_rng(p2 + 1)
+    sx, sy, k, h, w = 20, 1, 5, 30, 70
+    left, right = _pair(rng, h, w, sx, sy)
+    noise = rng.integers(0, 256, right.shape).astype(np.float32)
+    for rr in (right, noise):
+        gi, gs, oi, os_ = _both(vw, oracle, CENSUS, left, rr, (sx, sy), k, 5, mgm=True, p1=p1, p2=p2)
+        assert np.array_equal(gi, oi) and np.abs(gs - os_).max() < 1e-5
+
+
+@pytest.mark.parametrize("algorithm", [2, 3])
+def test_pyramid_mgm_and_final_mgm(vw, oracle, algorithm):
+    """VW_CORRELATION_MGM: every level with use_mgm; VW_CORRELATION_FINAL_MGM: level 0 only (CorrelationView.cc:365-366)."""
+    from visionworkbench_amd.core import BBox2i
+    rng = np.random.default_rng(40 + algorithm)
+    base = rng.integers(0, 256, (260, 340)).astype(np.float32)
+    k = np.ones(3) / 3
+    base = np.apply_along_axis(lambda m: np.convolve(m, k, mode="same"), 1, base).astype(np.float32)
+    left = np.ascontiguousarray(base[10:210, 20:300])
+    right = np.ascontiguousarray(base[8:208, 14:294])
+    search = (-8, -4, 8, 4)
+    box = BBox2i.from_corners(search[:2], search[2:])
+    g = vw.pyramid_correlate(left, right, None, None, 0, 0.0, box, (5, 5), CENSUS, consistency_threshold=2, min_consistency_level=0,
+                             filter_half_kernel=3, max_pyramid_levels=2, algorithm=algorithm, bbox=BBox2i(16, 8, 220, 160))
+    o = oracle.pyramid_correlate_sgm(left, right, None, None, search, 5, CENSUS, 2, 0, 3, 2, bbox=(16, 8, 220, 160), algorithm=algorithm)
     assert np.array_equal(g[..., 2], o[..., 2]) and np.abs(g[..., :2] - o[..., :2]).max() < 1e-5

@@ -16,7 +16,7 @@
 //                                                          R->L run, sub-pixel view; blob filter (:242-271), lr_disp_diff
 // Inputs whose box sums would round (prefiltered imagery, mean-filled nodata, deep levels with SSD / NCC) are matched in
 // the reference's own summation order (bm_exact.hip); the class of every level is measured on the device.
-// Not covered: the MGM variants (VW_CORRELATION_MGM / _FINAL_MGM answer NoImplErr); collar_size is applied by the caller
+// VW_CORRELATION_MGM runs every level with use_mgm, _FINAL_MGM only level 0 (:365-366).  collar_size is applied by the caller
 // (PyramidCorrelationView::rasterize, CorrelationView.h:123-133: a larger tile is rasterised and cropped).
 #include <chrono>
 #include <climits>
@@ -675,6 +675,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
       hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(lr.dx(), lr.dy()), kBlk, 0, st, Lv.p, Lv.w, Lv.w, Lv.h, lr.x0, lr.y0, tmp_a, lr.dx(), lr.dy());
       hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(rr.dx(), rr.dy()), kBlk, 0, st, Rv.p, Rv.w, Rv.w, Rv.h, rr.x0, rr.y0, tmp_b, rr.dx(), rr.dy());
       const bool have_prev = level < L;
+      SP.use_mgm = (P->algorithm == 2 || (P->algorithm == 3 && level == 0)) ? 1 : 0;      // CorrelationView.cc:365-366
       int ow = 0, oh = 0;
       rc = vwgpu_sgm_impl(ctx, &SP, tmp_a, lr.dx(), lr.dy(), lr.dx(), tmp_b, rr.dx(), rr.dy(), rr.dx(), sx, sy,
                           lmp[level].p, lmp[level].w, lmp[level].h, rmp[level].p, rmp[level].w, rmp[level].h,
@@ -1012,9 +1013,9 @@ static int check_pyramid_args(vwgpu_ctx* ctx, const void* l, int lw, int lh, con
                       P->search_min_x, P->search_min_y, P->search_max_x, P->search_max_y);
   if (P->algorithm == 0 && (P->cost_type < VWGPU_ABSOLUTE_DIFFERENCE || P->cost_type > VWGPU_CROSS_CORRELATION))
     return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: cost type %d is not a block-matching cost", P->cost_type);
-  if (P->algorithm != 0 && P->algorithm != 1)
-    return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: VW_CORRELATION_BM and VW_CORRELATION_SGM are implemented (algorithm %d is MGM)", P->algorithm);
-  if (P->algorithm == 1) {
+  if (P->algorithm < 0 || P->algorithm > 3)
+    return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: algorithm %d is none of VW_CORRELATION_BM / _SGM / _MGM / _FINAL_MGM", P->algorithm);
+  if (P->algorithm != 0) {
     if (P->cost_type != VWGPU_CENSUS_TRANSFORM && P->cost_type != VWGPU_TERNARY_CENSUS_TRANSFORM)
       return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "With SGM/MGM, only the census transform cost mode gives good results.");
     if (P->kernel_x != P->kernel_y || (P->kernel_x != 3 && P->kernel_x != 5 && P->kernel_x != 7 && P->kernel_x != 9))

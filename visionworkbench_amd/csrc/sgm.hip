@@ -574,6 +574,130 @@ path_kernel(SgmGeom g, DirSet D,
   }
 }
 
+// ---- MGM (accum_mgm_multithread, SGM.cc:2619-2700; SmoothPathAccumTask, SGMAssist.h:835-1239) ---------------------------------
+// Every pixel of a pass takes the mean of TWO evaluate_path results — from its path predecessor A and from a second, "perpendicular"
+// predecessor B — so a pass is no longer a set of independent scan lines but a 2-D recurrence.  Its parallel structure is the FRONT:
+//   L  (A = left,  B = above)       depends on the previous anti-diagonal  c + r              -> W + H - 1 fronts of <= min(W, H) pixels
+//   R, T, B likewise on the mirrored anti-diagonals
+//   TL (A = (c-1, r-1), B = (c+1, r-1)) depends on the previous ROW       -> H fronts of W pixels;      BR: rows upwards
+//   BL (A = (c-1, r+1), B = (c-1, r-1)) depends on the previous COLUMN    -> W fronts of H pixels;      TR: columns leftwards
+// One launch per front, one wavefront per pixel of the front and direction (blockIdx.y): the launch boundary is the only
+// synchronisation, so nothing here can spin.  A direction's values live in a volume of their own (`vols`, laid out like the
+// sums), because both predecessors are read from it; they are added to the sums as they are produced (add_lead_buffer_to_accum,
+// SGMAssist.h:357-388, does that line by line).
+// Both evaluations of a pixel use ONE intensity difference, get_path_pixel_diff (SGM.cc:2715-2721) = |I(c, r) - I(c - ax, r - ay)|:
+// with (ax, ay) pointing at the path predecessor that is the pixel on the FAR side of the path.
+struct MgmDirs {
+  int n;
+  int ax[4], ay[4], bx[4], by[4];
+  int need[4];                    // the task's border test: bit 0 col > 0, bit 1 col < last, bit 2 row > 0, bit 3 row < last
+  int kind[4];                    // 0 anti-diagonal fronts, 1 row fronts, 2 column fronts
+  int flipx[4], flipy[4];         // fronts counted from the right / from the bottom
+};
+
+__global__ void __launch_bounds__(64)
+mgm_front_kernel(SgmGeom g, MgmDirs D, int front, const uint8_t* __restrict__ left, int lw, int lh, int min_col, int min_row,
+                 const B4* __restrict__ bounds, const unsigned long long* __restrict__ starts, const uint8_t* __restrict__ cost,
+                 uint16_t* __restrict__ vols, size_t vol_elems, uint16_t* __restrict__ accum, unsigned p1, unsigned p2) {
+  extern __shared__ uint16_t sm[];
+  const int num_disp = g.num_dx * g.num_dy;
+  uint16_t* full_prior = sm;                 // num_disp: the predecessor's vector over the whole search range, BAD_VAL elsewhere
+  uint16_t* first = sm + num_disp;           // num_disp: result of the first evaluation
+  const int lane = threadIdx.x, q = blockIdx.y, W = g.ocols, H = g.orows;
+  int c, r;
+  if (D.kind[q] == 0) {
+    const int cc = max(0, front - (H - 1)) + (int)blockIdx.x, rr = front - cc;
+    if (cc >= W || rr < 0) return;
+    c = D.flipx[q] ? W - 1 - cc : cc; r = D.flipy[q] ? H - 1 - rr : rr;
+  } else if (D.kind[q] == 1) {
+    if (front >= H || (int)blockIdx.x >= W) return;
+    c = blockIdx.x; r = D.flipy[q] ? H - 1 - front : front;
+  } else {
+    if (front >= W || (int)blockIdx.x >= H) return;
+    r = blockIdx.x; c = D.flipx[q] ? W - 1 - front : front;
+  }
+  const size_t p = (size_t)r * W + c;
+  const B4 b = bounds[p];
+  const int wd = b.x1 - b.x0 + 1, nd = wd * (b.y1 - b.y0 + 1);
+  if (nd <= 0) return;                                         // get_num_disp() == 0: skipped (SGMAssist.h:904-909)
+  const unsigned long long st = starts[p];
+  uint16_t* vol = vols + (size_t)q * vol_elems;
+  const bool plain = D.n == 1;
+  const int need = D.need[q];
+  const bool ok = (!(need & 1) || c > 0) && (!(need & 2) || c < W - 1) && (!(need & 4) || r > 0) && (!(need & 8) || r < H - 1);
+  if (!ok) {                                                   // "Just init to the local cost"
+    for (int i = lane; i < nd; i += 64) {
+      const unsigned v = cost[st + i];
+      vol[st + i] = (uint16_t)v;
+      accum_add_u16(accum, st + i, v, plain);
+    }
+    return;
+  }
+  const unsigned BAD = (255u + p2) & 0xffffu;
+  for (int i = lane; i < num_disp; i += 64) full_prior[i] = (uint16_t)BAD;
+  // the reference indexes the image unchecked; the far-side pixel is inside it whenever the kernel is >= 3 (calc_disparity_sgm
+  // always searches from 0).  Clamped like the oracle so that the read is defined for any geometry.
+  const int fc = min(max(c - D.ax[q] + min_col, 0), lw - 1), fr = min(max(r - D.ay[q] + min_row, 0), lh - 1);
+  int grad = (int)left[(size_t)(r + min_row) * lw + (c + min_col)] - (int)left[(size_t)fr * lw + fc];
+  grad = grad < 0 ? -grad : grad;
+  unsigned p2_mod = p2;
+  if (grad > 0) p2_mod /= (unsigned)grad;
+  if (p2_mod < p1) p2_mod = p1;
+  const float inv_wd = __builtin_amdgcn_rcpf((float)wd);
+  lds_barrier();
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int cp = c + (pass ? D.bx[q] : D.ax[q]), rp = r + (pass ? D.by[q] : D.ay[q]);
+    const size_t pp = (size_t)rp * W + cp;
+    const B4 bp = bounds[pp];
+    const uint16_t* prior = vol + starts[pp];
+    const int wp = bp.x1 - bp.x0 + 1, np = wp * (bp.y1 - bp.y0 + 1);            // 0 for a skipped predecessor: an empty vector
+    const float inv_wp = __builtin_amdgcn_rcpf((float)max(wp, 1));
+    unsigned mn = BAD;
+    for (int i = lane; i < np; i += 64) {
+      int qy, qx;
+      divmod_f(i, wp, inv_wp, qy, qx);
+      const unsigned v = prior[i];
+      mn = min(mn, v);
+      full_prior[(bp.y0 + qy - g.min_dy) * g.num_dx + (bp.x0 + qx - g.min_dx)] = (uint16_t)v;
+    }
+    const unsigned min_prior = wave_min_u32(mn);
+    const unsigned dJ = (min_prior + p2_mod) & 0xffffu;
+    lds_barrier();
+    for (int i = lane; i < nd; i += 64) {
+      int qy, qx;
+      divmod_f(i, wd, inv_wd, qy, qx);
+      const int dx = b.x0 + qx, dy = b.y0 + qy;
+      const int xo = dx - g.min_dx, yo = dy - g.min_dy;
+      const int xl = dx - 1 < g.min_dx ? xo : xo - 1, xm = dx + 1 > g.max_dx ? xo : xo + 1;
+      const int yl = (dy - 1 < g.min_dy ? yo : yo - 1) * g.num_dx, ym = (dy + 1 > g.max_dy ? yo : yo + 1) * g.num_dx, yc = yo * g.num_dx;
+      unsigned m = full_prior[yl + xo];
+      m = min(m, (unsigned)full_prior[yc + xl]); m = min(m, (unsigned)full_prior[yc + xm]); m = min(m, (unsigned)full_prior[ym + xo]);
+      m = min(m, (unsigned)full_prior[yl + xl]); m = min(m, (unsigned)full_prior[yl + xm]);
+      m = min(m, (unsigned)full_prior[ym + xl]); m = min(m, (unsigned)full_prior[ym + xm]);
+      unsigned res = adds16(m, p1);
+      res = min(res, min((unsigned)full_prior[yc + xo], dJ));
+      res = adds16(res, (unsigned)cost[st + i]);
+      res = subs16(res, min_prior);
+      if (pass == 0) first[i] = (uint16_t)res;
+      else {
+        const unsigned v = ((unsigned)first[i] + res) >> 1;    // "(a + b) / 2" in int (SGMAssist.h:945-946)
+        vol[st + i] = (uint16_t)v;
+        accum_add_u16(accum, st + i, v, plain);
+      }
+    }
+    lds_barrier();
+    if (pass == 0) {
+      for (int i = lane; i < np; i += 64) {
+        int qy, qx;
+        divmod_f(i, wp, inv_wp, qy, qx);
+        full_prior[(bp.y0 + qy - g.min_dy) * g.num_dx + (bp.x0 + qx - g.min_dx)] = (uint16_t)BAD;
+      }
+      lds_barrier();
+    }
+  }
+}
+
 // The ragged recurrence for num_disp <= 64 * R, in place.  The full-range buffer always holds the PREVIOUS pixel's vector at
 // its box cells and BAD_VAL elsewhere, so a step is: read the neighbours of every cell of the current box into registers,
 // barrier, write the new values at the current box's cells, put BAD_VAL back into the cells of the previous box that the
@@ -1472,7 +1596,13 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     unsigned long long one_buf = (unsigned long long)line_size * (unsigned long long)num_disp;
     if (one_buf > main_buf) one_buf = main_buf;
     const double MB = 1024.0 * 1024.0;
-    const double total = (double)n * (3.0 / MB) + (double)(one_buf * threads) * (2.0 / MB);
+    unsigned long long small_buf = one_buf * threads;
+    if (P->use_mgm) {                                        // four vertical + four horizontal one-path line buffers (SGM.cc:707-713)
+      const unsigned long long vert = std::min((unsigned long long)g.orows * (unsigned long long)num_disp, main_buf);
+      const unsigned long long horiz = std::min((unsigned long long)g.ocols * (unsigned long long)num_disp, main_buf);
+      small_buf = 4 * vert + 4 * horiz;
+    }
+    const double total = (double)n * (3.0 / MB) + (double)small_buf * (2.0 / MB);
     if (!(total > (double)P->memory_limit_mb)) { ok = true; break; }
   }
   if (!ok) {   // "Unable to compute valid search ranges for SGM input": an all-invalid disparity (SGM.cc:2428-2434)
@@ -1497,13 +1627,19 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   // The register-resident path kernel fetches two chunks of steps ahead without looking at the end of its line: up to 16 steps
   // past either end, i.e. 16 rows + 16 pixels before / behind a volume.  Guard zones keep those (unused) reads inside the arena.
   const size_t guard = uniform ? vwgpu_align_up((size_t)2 * VWGPU_PATH_KC * ((size_t)g.ocols + 1) * ustride * 2, 256) : 0;
-  rc = vwgpu_arena_reserve(ctx, &ctx->sgm_main, (size_t)main_buf * 3 + 1024 + 3 * guard);
+  // MGM keeps the values of the directions in flight in volumes of their own (mgm_front_kernel): four when the directions of a
+  // launch may share packed 16-bit atomics, else one
+  const bool together_u16 = 8 * (255 + std::max(p1, p2)) < 65536;
+  const int mgm_vols = P->use_mgm ? (together_u16 ? 4 : 1) : 0;
+  const size_t vol_bytes = vwgpu_align_up((size_t)main_buf * 2, 256);
+  rc = vwgpu_arena_reserve(ctx, &ctx->sgm_main, (size_t)main_buf * 3 + 1024 + 3 * guard + (size_t)mgm_vols * vol_bytes + 512);
   if (rc) return rc;
   uint8_t* cost = static_cast<uint8_t*>(ctx->sgm_main.base) + guard;
   uint16_t* accum = reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->sgm_main.base) + 2 * guard + vwgpu_align_up((size_t)main_buf, 256));
+  uint16_t* mgm_vol = reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->sgm_main.base) + 3 * guard + vwgpu_align_up((size_t)main_buf, 256) + vol_bytes);
   // 0: one direction per launch, plain store / read-modify-write (default); 1: all directions in one launch, 64-bit atomics
   static const int paths_mode = getenv("VWGPU_SGM_PATHS") ? atoi(getenv("VWGPU_SGM_PATHS")) : 0;
-  const bool dir_paths = uniform && g.num_dy == 1 && paths_mode != 1;      // the first direction initialises the volume
+  const bool dir_paths = uniform && g.num_dy == 1 && paths_mode != 1 && !P->use_mgm;      // the first direction initialises the volume
   if (!dir_paths) VWGPU_HIP(ctx, hipMemsetAsync(accum, 0, (size_t)main_buf * 2, st));
   {
     vwgpu_prof_scope ps(ctx, "sgm_cost");
@@ -1541,7 +1677,37 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     K = std::max(4, std::min(K, 32));
     const size_t ulds = ((size_t)ept * 64 + 256) * sizeof(uint16_t) + (size_t)K * ustride * 3 + K + 16;
     const bool one_d = g.num_dy == 1;
-    if (dir_paths) {
+    if (P->use_mgm) {
+      // accum_mgm_multithread: one launch per front (see mgm_front_kernel).  The four axis directions share their W + H - 1
+      // anti-diagonal steps, the four diagonal ones their max(W, H) row / column steps: (W + H - 1) + max(W, H) launches in all
+      // when the sums can take packed atomics, else each direction on its own.
+      vwgpu_prof_scope ps(ctx, "sgm_mgm_paths");
+      struct MD { int ax, ay, bx, by, need, kind, flipx, flipy; };
+      //                    A (path)  B (perp.)  border test        fronts
+      const MD md[8] = {{-1,  0,  0, -1, 1 | 4,      0, 0, 0},      // L   SGMAssist.h:911-955
+                        { 1,  0,  0,  1, 2 | 8,      0, 1, 1},      // R   :998-1033
+                        { 0, -1,  1,  0, 2 | 4,      0, 1, 0},      // T   :1147-1182
+                        { 0,  1, -1,  0, 1 | 8,      0, 0, 1},      // B   :1073-1108
+                        {-1, -1,  1, -1, 1 | 2 | 4,  1, 0, 0},      // TL  :958-996
+                        { 1,  1, -1,  1, 1 | 2 | 8,  1, 0, 1},      // BR  :1035-1071
+                        {-1,  1, -1, -1, 1 | 4 | 8,  2, 0, 0},      // BL  :1110-1145
+                        { 1, -1,  1,  1, 2 | 4 | 8,  2, 1, 0}};     // TR  :1184-1219
+      const int per = mgm_vols;                                     // directions per launch
+      for (int first = 0; first < 8; first += per) {
+        MgmDirs M;
+        M.n = per;
+        int fronts = 0, width = 0;
+        for (int q = 0; q < per; ++q) {
+          const MD& d = md[first + q];
+          M.ax[q] = d.ax; M.ay[q] = d.ay; M.bx[q] = d.bx; M.by[q] = d.by; M.need[q] = d.need; M.kind[q] = d.kind; M.flipx[q] = d.flipx; M.flipy[q] = d.flipy;
+          fronts = std::max(fronts, d.kind == 0 ? W + H - 1 : d.kind == 1 ? H : W);
+          width = std::max(width, d.kind == 0 ? std::min(W, H) : d.kind == 1 ? W : H);
+        }
+        for (int f = 0; f < fronts; ++f)
+          hipLaunchKernelGGL(mgm_front_kernel, dim3(width, per), dim3(64), lds, st, g, M, f, l8, lw, lh, min_col, min_row, bounds, starts, cost,
+                             mgm_vol, vol_bytes / 2, accum, (unsigned)p1, (unsigned)p2);
+      }
+    } else if (dir_paths) {
       // One direction per launch: every pixel lies on exactly one line of a launch, so the path costs are accumulated with plain
       // loads and stores, and the first direction stores (no memset).  (Tried: bands of rows with the directions pipelined over
       // them, so that a band's vectors are revisited while they sit in the memory-side cache — lines of a few hundred steps pay

@@ -9,7 +9,6 @@ int check_sgm(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const void* l, int lw, 
   ctx->err.clear();
   if (!P || !l || !r || !out || !ow || !oh || lw <= 0 || lh <= 0 || rw <= 0 || rh <= 0 || sx < 0 || sy < 0)
     return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity_sgm: null pointer, empty image or negative search volume");
-  if (P->use_mgm) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity_sgm: MGM is not implemented");
   if (P->cost_type != VWGPU_CENSUS_TRANSFORM && P->cost_type != VWGPU_TERNARY_CENSUS_TRANSFORM)
     return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "With SGM/MGM, only the census transform cost mode gives good results.");
   if (P->kernel_size != 3 && P->kernel_size != 5 && P->kernel_size != 7 && P->kernel_size != 9)

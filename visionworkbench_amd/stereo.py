@@ -297,7 +297,7 @@ def pyramid_correlate(left, right, left_mask, right_mask, prefilter_mode, prefil
     left / right: (rows, cols) float32; masks: (rows, cols) uint8 or None; search_region: BBox2i (half open).
     Returns (bbox rows, bbox cols, 3) float32 PixelMask<Vector2f> {dx, dy, valid}.
     algorithm 0 = VW_CORRELATION_BM (integer disparities cast to float), 1 = VW_CORRELATION_SGM (census costs only; the
-    result is the matcher's sub-pixel view, CorrelationView.cc:862-875); MGM variants raise NoImplErr.  collar_size is
+    result is the matcher's sub-pixel view, CorrelationView.cc:862-875), 2 = VW_CORRELATION_MGM, 3 = _FINAL_MGM (MGM at level 0 only).  collar_size is
     the tile rasteriser's business (CorrelationView.h:128-132): pass the collared bbox.
     lr_disp_diff (optional, modified in place): (rows, cols, 2) float32 PixelMask<float> image covering the image pixels from
     region_ul on; the level-0 consistency check stores the L-R / R-L discrepancy of the pixels it keeps there and pixels

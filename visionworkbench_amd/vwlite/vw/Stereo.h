@@ -361,7 +361,7 @@ calc_disparity_sgm(CostFunctionType cost_type,
                                                 prev_disparity ? prev_disparity->cols() : 0, prev_disparity ? prev_disparity->rows() : 0,
                                                 disp.data(), sub.data(), cap, &ow, &oh));
   } catch (NoImplErr const&) {
-    throw;                                                           // MAD cost / MGM / census size: as the reference's NoImplErr
+    throw;                                                           // MAD cost / census size: as the reference's NoImplErr
   } catch (std::exception const& e) {                                // SGM.cc:221-226
     vw_throw(ArgumentErr() << "Failed to compute the correlation. See the online documentation (next_steps.html) for how to "
                            << "handle failures.\nDetailed error message: " << e.what() << "\n");
@@ -479,8 +479,8 @@ template <class ViewT> ImageViewRef<uint8> mask_ref(ImageViewBase<ViewT> const& 
 }  // namespace detail
 
 /// pyramid_correlate — the reference's argument list (CorrelationView.h:195-230), verbatim; the image / mask arguments
-/// accept any view (the reference takes ImageViewRef handles, which convert from any view as well).  VW_CORRELATION_BM and
-/// VW_CORRELATION_SGM are implemented, the MGM variants answer NoImplErr when a tile is requested.  write_debug_images is
+/// accept any view (the reference takes ImageViewRef handles, which convert from any view as well).  All four algorithms
+/// are implemented (VW_CORRELATION_MGM: use_mgm at every level, _FINAL_MGM: at level 0 only).  write_debug_images is
 /// accepted and ignored (the reference's debug dumps are TIFF files written next to the process).
 template <class Image1T, class Image2T, class Mask1T, class Mask2T>
 PyramidCorrelationView
