@@ -583,54 +583,54 @@ path_kernel(SgmGeom g, DirSet D,
 //   BL (A = (c-1, r+1), B = (c-1, r-1)) depends on the previous COLUMN    -> W fronts of H pixels;      TR: columns leftwards
 // One launch per front, one wavefront per pixel of the front and direction (blockIdx.y): the launch boundary is the only
 // synchronisation, so nothing here can spin.  A direction's values live in a volume of their own (`vols`, laid out like the
-// sums), because both predecessors are read from it; they are added to the sums as they are produced (add_lead_buffer_to_accum,
-// SGMAssist.h:357-388, does that line by line).
+// sums), because both predecessors are read from it; mgm_sum_kernel adds the volumes to the sums afterwards with the u16
+// wrap-around of the reference's `+=` (add_lead_buffer_to_accum, SGMAssist.h:357-388, does that line by line).
 // Both evaluations of a pixel use ONE intensity difference, get_path_pixel_diff (SGM.cc:2715-2721) = |I(c, r) - I(c - ax, r - ay)|:
 // with (ax, ay) pointing at the path predecessor that is the pixel on the FAR side of the path.
 struct MgmDirs {
   int n;
-  int ax[4], ay[4], bx[4], by[4];
-  int need[4];                    // the task's border test: bit 0 col > 0, bit 1 col < last, bit 2 row > 0, bit 3 row < last
-  int kind[4];                    // 0 anti-diagonal fronts, 1 row fronts, 2 column fronts
-  int flipx[4], flipy[4];         // fronts counted from the right / from the bottom
+  int ax[8], ay[8], bx[8], by[8];
+  int need[8];                    // the task's border test: bit 0 col > 0, bit 1 col < last, bit 2 row > 0, bit 3 row < last
+  int kind[8];                    // 0 anti-diagonal fronts, 1 row fronts, 2 column fronts
+  int flipx[8], flipy[8];         // fronts counted from the right / from the bottom
 };
+// pixel of (front, index in the front) for direction q; false when the front has no such pixel
+__device__ __forceinline__ bool mgm_front_pixel(const MgmDirs& D, int q, int front, int i, int W, int H, int& c, int& r) {
+  if (D.kind[q] == 0) {
+    const int cc = max(0, front - (H - 1)) + i, rr = front - cc;
+    if (cc >= W || rr < 0) return false;
+    c = D.flipx[q] ? W - 1 - cc : cc; r = D.flipy[q] ? H - 1 - rr : rr;
+  } else if (D.kind[q] == 1) {
+    if (front >= H || i >= W) return false;
+    c = i; r = D.flipy[q] ? H - 1 - front : front;
+  } else {
+    if (front >= W || i >= H) return false;
+    r = i; c = D.flipx[q] ? W - 1 - front : front;
+  }
+  return true;
+}
 
 __global__ void __launch_bounds__(64)
 mgm_front_kernel(SgmGeom g, MgmDirs D, int front, const uint8_t* __restrict__ left, int lw, int lh, int min_col, int min_row,
                  const B4* __restrict__ bounds, const unsigned long long* __restrict__ starts, const uint8_t* __restrict__ cost,
-                 uint16_t* __restrict__ vols, size_t vol_elems, uint16_t* __restrict__ accum, unsigned p1, unsigned p2) {
+                 uint16_t* __restrict__ vols, size_t vol_elems, unsigned p1, unsigned p2) {
   extern __shared__ uint16_t sm[];
   const int num_disp = g.num_dx * g.num_dy;
   uint16_t* full_prior = sm;                 // num_disp: the predecessor's vector over the whole search range, BAD_VAL elsewhere
   uint16_t* first = sm + num_disp;           // num_disp: result of the first evaluation
   const int lane = threadIdx.x, q = blockIdx.y, W = g.ocols, H = g.orows;
   int c, r;
-  if (D.kind[q] == 0) {
-    const int cc = max(0, front - (H - 1)) + (int)blockIdx.x, rr = front - cc;
-    if (cc >= W || rr < 0) return;
-    c = D.flipx[q] ? W - 1 - cc : cc; r = D.flipy[q] ? H - 1 - rr : rr;
-  } else if (D.kind[q] == 1) {
-    if (front >= H || (int)blockIdx.x >= W) return;
-    c = blockIdx.x; r = D.flipy[q] ? H - 1 - front : front;
-  } else {
-    if (front >= W || (int)blockIdx.x >= H) return;
-    r = blockIdx.x; c = D.flipx[q] ? W - 1 - front : front;
-  }
+  if (!mgm_front_pixel(D, q, front, (int)blockIdx.x, W, H, c, r)) return;
   const size_t p = (size_t)r * W + c;
   const B4 b = bounds[p];
   const int wd = b.x1 - b.x0 + 1, nd = wd * (b.y1 - b.y0 + 1);
   if (nd <= 0) return;                                         // get_num_disp() == 0: skipped (SGMAssist.h:904-909)
   const unsigned long long st = starts[p];
   uint16_t* vol = vols + (size_t)q * vol_elems;
-  const bool plain = D.n == 1;
   const int need = D.need[q];
   const bool ok = (!(need & 1) || c > 0) && (!(need & 2) || c < W - 1) && (!(need & 4) || r > 0) && (!(need & 8) || r < H - 1);
   if (!ok) {                                                   // "Just init to the local cost"
-    for (int i = lane; i < nd; i += 64) {
-      const unsigned v = cost[st + i];
-      vol[st + i] = (uint16_t)v;
-      accum_add_u16(accum, st + i, v, plain);
-    }
+    for (int i = lane; i < nd; i += 64) vol[st + i] = (uint16_t)cost[st + i];
     return;
   }
   const unsigned BAD = (255u + p2) & 0xffffu;
@@ -680,11 +680,7 @@ mgm_front_kernel(SgmGeom g, MgmDirs D, int front, const uint8_t* __restrict__ le
       res = adds16(res, (unsigned)cost[st + i]);
       res = subs16(res, min_prior);
       if (pass == 0) first[i] = (uint16_t)res;
-      else {
-        const unsigned v = ((unsigned)first[i] + res) >> 1;    // "(a + b) / 2" in int (SGMAssist.h:945-946)
-        vol[st + i] = (uint16_t)v;
-        accum_add_u16(accum, st + i, v, plain);
-      }
+      else vol[st + i] = (uint16_t)(((unsigned)first[i] + res) >> 1);      // "(a + b) / 2" in int (SGMAssist.h:945-946)
     }
     lds_barrier();
     if (pass == 0) {
@@ -1246,6 +1242,105 @@ __global__ void uniform_starts_kernel(unsigned long long* __restrict__ starts, s
   if (p < npix) starts[p] = p * stride;
 }
 
+// MGM front for full boxes on ONE search row (the layout of path_uniform_reg_kernel: lane l owns the EPT disparity pairs l * EPT ..,
+// dead halves / pairs hold 0xffff so that they never win a minimum).  Both predecessor vectors, the costs and the two grey values
+// are requested together — one memory round trip per front instead of the chain box -> start -> vector -> LDS of the general
+// kernel — and the two evaluations run in registers (neighbours d - 1 / d + 1 through wave shifts, as there).
+template <int EPT>
+__global__ void __launch_bounds__(64)
+mgm_front_uniform_kernel(SgmGeom g, MgmDirs D, int front, int stride, const uint8_t* __restrict__ left, int lw, int lh, int min_col, int min_row,
+                         const uint8_t* __restrict__ cost, uint16_t* __restrict__ vols, size_t vol_elems, unsigned p1, unsigned p2) {
+  constexpr int NW = CostWords<EPT>::N;
+  const int num_disp = g.num_dx, npairs = (num_disp + 1) / 2, q32 = stride / 2;
+  const int tid = threadIdx.x, q = blockIdx.y, W = g.ocols, H = g.orows;
+  int c, r;
+  if (!mgm_front_pixel(D, q, front, (int)blockIdx.x, W, H, c, r)) return;
+  const int ax = D.ax[q], ay = D.ay[q], bx = D.bx[q], by = D.by[q], need = D.need[q];
+  const bool ok = (!(need & 1) || c > 0) && (!(need & 2) || c < W - 1) && (!(need & 4) || r > 0) && (!(need & 8) || r < H - 1);
+  const bool in = tid * EPT + EPT <= q32;
+  const size_t p = (size_t)r * W + c;
+  unsigned* vol = reinterpret_cast<unsigned*>(vols + (size_t)q * vol_elems);
+  unsigned cw[NW];
+  load_cost_words<EPT>(cost + p * stride + (in ? tid * EPT * 2 : 0), true, cw);
+  unsigned out[EPT];
+  if (!ok) {                                                   // "Just init to the local cost"
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) out[e] = cost_pair<EPT>(cw, e);
+  } else {
+    const size_t pa = (size_t)(r + ay) * W + (c + ax), pb = (size_t)(r + by) * W + (c + bx);
+    const unsigned loff = in ? (unsigned)(tid * EPT) : 0u;
+    unsigned va[EPT], vb[EPT], dead[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) { va[e] = vol[pa * q32 + loff + e]; vb[e] = vol[pb * q32 + loff + e]; }
+    const int fc = min(max(c - ax + min_col, 0), lw - 1), fr = min(max(r - ay + min_row, 0), lh - 1);
+    int grad = (int)left[(size_t)(r + min_row) * lw + (c + min_col)] - (int)left[(size_t)fr * lw + fc];
+    grad = grad < 0 ? -grad : grad;
+    unsigned p2_mod = p2 / (unsigned)max(grad, 1);
+    if (p2_mod < p1) p2_mod = p1;
+    const unsigned BAD = (255u + p2) & 0xffffu;
+    const us2 p1p1 = as_us2(p1 | (p1 << 16));
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int j = tid * EPT + e;
+      dead[e] = j >= npairs ? 0xffffffffu : ((2 * j + 1 >= num_disp) ? 0xffff0000u : 0u);
+    }
+    auto evaluate = [&](const unsigned (&pv)[EPT], unsigned (&res)[EPT]) __attribute__((always_inline)) {
+      unsigned pr[EPT];
+      us2 mn2 = as_us2(0xffffffffu);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) { pr[e] = pv[e] | dead[e]; mn2 = __builtin_elementwise_min(mn2, as_us2(pr[e])); }
+      const unsigned mnu = as_u32(mn2);
+      const unsigned min_prior = min(wave_min_u32(min(mnu & 0xffffu, mnu >> 16)), BAD);
+      const unsigned dj = (min_prior + p2_mod) & 0xffffu;
+      const us2 dJ = as_us2(dj | (dj << 16)), mp = as_us2(min_prior | (min_prior << 16));
+      const unsigned pm = wave_shr1(pr[EPT - 1], 0xffffffffu), pn = wave_shl1(pr[0], 0xffffffffu);
+      unsigned al[EPT + 1];                                         // al[e] = (d_2j-1, d_2j) of pair e; al[e+1] = (d_2j+1, d_2j+2)
+      al[0] = __builtin_amdgcn_alignbit(pr[0], pm, 16);
+#pragma unroll
+      for (int e = 1; e < EPT; ++e) al[e] = __builtin_amdgcn_alignbit(pr[e], pr[e - 1], 16);
+      al[EPT] = __builtin_amdgcn_alignbit(pn, pr[EPT - 1], 16);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const us2 ctr = as_us2(pr[e]);
+        us2 m = __builtin_elementwise_min(__builtin_elementwise_min(as_us2(al[e]), as_us2(al[e + 1])), ctr);
+        us2 v = __builtin_elementwise_add_sat(m, p1p1);
+        v = __builtin_elementwise_min(v, __builtin_elementwise_min(ctr, dJ));
+        v = __builtin_elementwise_add_sat(v, as_us2(cost_pair<EPT>(cw, e)));
+        v = __builtin_elementwise_sub_sat(v, mp);
+        res[e] = as_u32(v);
+      }
+    };
+    unsigned ra[EPT], rb[EPT];
+    evaluate(va, ra);
+    evaluate(vb, rb);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) out[e] = (ra[e] & rb[e]) + (((ra[e] ^ rb[e]) >> 1) & 0x7fff7fffu);      // (a + b) / 2 per u16 half, no carry
+  }
+  if (in) {
+    unsigned* o = vol + p * q32 + tid * EPT;
+    if constexpr (EPT == 2) *reinterpret_cast<uint2*>(o) = make_uint2(out[0], out[1]);
+    else if constexpr (EPT == 4) *reinterpret_cast<uint4*>(o) = make_uint4(out[0], out[1], out[2], out[3]);
+    else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) o[e] = out[e];
+    }
+  }
+}
+
+// sums (u16, wrapping like the reference's `+=`) of n direction volumes: accum = (add ? accum : 0) + vol_0 + .. + vol_{n-1}
+__global__ void __launch_bounds__(256)
+mgm_sum_kernel(uint4* __restrict__ accum, const uint4* __restrict__ vols, size_t vol_words, size_t words, int n, int add) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) {
+    uint4 a = add ? accum[i] : make_uint4(0u, 0u, 0u, 0u);
+    for (int k = 0; k < n; ++k) {
+      const uint4 v = vols[(size_t)k * vol_words + i];
+      a.x = as_u32(as_us2(a.x) + as_us2(v.x)); a.y = as_u32(as_us2(a.y) + as_us2(v.y));
+      a.z = as_u32(as_us2(a.z) + as_us2(v.z)); a.w = as_u32(as_us2(a.w) + as_us2(v.w));
+    }
+    accum[i] = a;
+  }
+}
+
 // ---- winner take all --------------------------------------------------------------------------------------------------
 
 // One wavefront per pixel, WTA_PPW consecutive pixels per wavefront: their records (box, vector start) and the first 128
@@ -1627,11 +1722,11 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   // The register-resident path kernel fetches two chunks of steps ahead without looking at the end of its line: up to 16 steps
   // past either end, i.e. 16 rows + 16 pixels before / behind a volume.  Guard zones keep those (unused) reads inside the arena.
   const size_t guard = uniform ? vwgpu_align_up((size_t)2 * VWGPU_PATH_KC * ((size_t)g.ocols + 1) * ustride * 2, 256) : 0;
-  // MGM keeps the values of the directions in flight in volumes of their own (mgm_front_kernel): four when the directions of a
-  // launch may share packed 16-bit atomics, else one
-  const bool together_u16 = 8 * (255 + std::max(p1, p2)) < 65536;
-  const int mgm_vols = P->use_mgm ? (together_u16 ? 4 : 1) : 0;
+  // MGM keeps the values of the directions in flight in volumes of their own (mgm_front_kernel): all eight, unless that takes
+  // more than 24 GB (then four, two or one at a time: more launches, same result)
   const size_t vol_bytes = vwgpu_align_up((size_t)main_buf * 2, 256);
+  int mgm_vols = 0;
+  if (P->use_mgm) for (mgm_vols = 8; mgm_vols > 1 && (size_t)mgm_vols * vol_bytes > ((size_t)24 << 30); mgm_vols /= 2) {}
   rc = vwgpu_arena_reserve(ctx, &ctx->sgm_main, (size_t)main_buf * 3 + 1024 + 3 * guard + (size_t)mgm_vols * vol_bytes + 512);
   if (rc) return rc;
   uint8_t* cost = static_cast<uint8_t*>(ctx->sgm_main.base) + guard;
@@ -1640,7 +1735,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   // 0: one direction per launch, plain store / read-modify-write (default); 1: all directions in one launch, 64-bit atomics
   static const int paths_mode = getenv("VWGPU_SGM_PATHS") ? atoi(getenv("VWGPU_SGM_PATHS")) : 0;
   const bool dir_paths = uniform && g.num_dy == 1 && paths_mode != 1 && !P->use_mgm;      // the first direction initialises the volume
-  if (!dir_paths) VWGPU_HIP(ctx, hipMemsetAsync(accum, 0, (size_t)main_buf * 2, st));
+  if (!dir_paths && !P->use_mgm) VWGPU_HIP(ctx, hipMemsetAsync(accum, 0, (size_t)main_buf * 2, st));      // (MGM: mgm_sum_kernel stores)
   {
     vwgpu_prof_scope ps(ctx, "sgm_cost");
     if (uniform)
@@ -1678,21 +1773,25 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     const size_t ulds = ((size_t)ept * 64 + 256) * sizeof(uint16_t) + (size_t)K * ustride * 3 + K + 16;
     const bool one_d = g.num_dy == 1;
     if (P->use_mgm) {
-      // accum_mgm_multithread: one launch per front (see mgm_front_kernel).  The four axis directions share their W + H - 1
-      // anti-diagonal steps, the four diagonal ones their max(W, H) row / column steps: (W + H - 1) + max(W, H) launches in all
-      // when the sums can take packed atomics, else each direction on its own.
+      // accum_mgm_multithread: one launch per front (see mgm_front_kernel) for all directions whose volumes fit: the axis
+      // directions have W + H - 1 anti-diagonal fronts, the diagonal ones max(W, H) row / column fronts, so eight directions
+      // together take W + H - 1 launches; then one pass adds the volumes to the sums.
       vwgpu_prof_scope ps(ctx, "sgm_mgm_paths");
       struct MD { int ax, ay, bx, by, need, kind, flipx, flipy; };
       //                    A (path)  B (perp.)  border test        fronts
       const MD md[8] = {{-1,  0,  0, -1, 1 | 4,      0, 0, 0},      // L   SGMAssist.h:911-955
-                        { 1,  0,  0,  1, 2 | 8,      0, 1, 1},      // R   :998-1033
-                        { 0, -1,  1,  0, 2 | 4,      0, 1, 0},      // T   :1147-1182
-                        { 0,  1, -1,  0, 1 | 8,      0, 0, 1},      // B   :1073-1108
                         {-1, -1,  1, -1, 1 | 2 | 4,  1, 0, 0},      // TL  :958-996
+                        { 1,  0,  0,  1, 2 | 8,      0, 1, 1},      // R   :998-1033
                         { 1,  1, -1,  1, 1 | 2 | 8,  1, 0, 1},      // BR  :1035-1071
+                        { 0, -1,  1,  0, 2 | 4,      0, 1, 0},      // T   :1147-1182
                         {-1,  1, -1, -1, 1 | 4 | 8,  2, 0, 0},      // BL  :1110-1145
+                        { 0,  1, -1,  0, 1 | 8,      0, 0, 1},      // B   :1073-1108
                         { 1, -1,  1,  1, 2 | 4 | 8,  2, 1, 0}};     // TR  :1184-1219
       const int per = mgm_vols;                                     // directions per launch
+      int pe = (int)(((num_disp + 1) / 2 + 63) / 64);
+      if (pe == 3) pe = 4;
+      const bool reg_fronts = uniform && one_d && pe <= 4;
+      const size_t words = (vol_bytes + 15) / 16;
       for (int first = 0; first < 8; first += per) {
         MgmDirs M;
         M.n = per;
@@ -1703,9 +1802,17 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
           fronts = std::max(fronts, d.kind == 0 ? W + H - 1 : d.kind == 1 ? H : W);
           width = std::max(width, d.kind == 0 ? std::min(W, H) : d.kind == 1 ? W : H);
         }
-        for (int f = 0; f < fronts; ++f)
-          hipLaunchKernelGGL(mgm_front_kernel, dim3(width, per), dim3(64), lds, st, g, M, f, l8, lw, lh, min_col, min_row, bounds, starts, cost,
-                             mgm_vol, vol_bytes / 2, accum, (unsigned)p1, (unsigned)p2);
+        for (int f = 0; f < fronts; ++f) {
+#define VWGPU_MGM_U(E) hipLaunchKernelGGL((mgm_front_uniform_kernel<E>), dim3(width, per), dim3(64), 0, st, g, M, f, ustride, l8, lw, lh, min_col, min_row, \
+                                          cost, mgm_vol, vol_bytes / 2, (unsigned)p1, (unsigned)p2)
+          if (reg_fronts) { switch (pe) { case 1: VWGPU_MGM_U(1); break; case 2: VWGPU_MGM_U(2); break; default: VWGPU_MGM_U(4); break; } }
+          else
+            hipLaunchKernelGGL(mgm_front_kernel, dim3(width, per), dim3(64), lds, st, g, M, f, l8, lw, lh, min_col, min_row, bounds, starts, cost,
+                               mgm_vol, vol_bytes / 2, (unsigned)p1, (unsigned)p2);
+#undef VWGPU_MGM_U
+        }
+        hipLaunchKernelGGL(mgm_sum_kernel, dim3((unsigned)std::min<size_t>((words + 255) / 256, 8192)), dim3(256), 0, st, reinterpret_cast<uint4*>(accum),
+                           reinterpret_cast<const uint4*>(mgm_vol), vol_bytes / 16, words, per, first > 0 ? 1 : 0);
       }
     } else if (dir_paths) {
       // One direction per launch: every pixel lies on exactly one line of a launch, so the path costs are accumulated with plain
