@@ -223,10 +223,10 @@ static void test_collar_and_lr_disp_diff() {
   fill(lmask, uint8(255)); fill(rmask, uint8(255));
   const BBox2i search_volume(Vector2i(-18, -7), Vector2i(18, 7));
   const int collar = 24;
-  for (int algo = 0; algo < 2; ++algo) {
+  for (int algo = 0; algo < 4; ++algo) {                        // VW_CORRELATION_BM, _SGM, _MGM, _FINAL_MGM
     PyramidCorrelationView view = pyramid_correlate(left, right, lmask, rmask, PREFILTER_NONE, 0.0f, search_volume, Vector2i(7, 7),
                                                     algo ? CENSUS_TRANSFORM : ABSOLUTE_DIFFERENCE, 0, 0.0, 2, 0, 3, 3,
-                                                    algo ? VW_CORRELATION_SGM : VW_CORRELATION_BM, collar);
+                                                    (CorrelationAlgorithm)algo, collar);
     const BBox2i tiles[3] = {BBox2i(0, 0, 100, 80), BBox2i(100, 80, 120, 90), BBox2i(220, 120, 80, 80)};   // corner, interior, far corner
     for (BBox2i const& b : tiles) {
       ImageView<PixelMask<Vector2f>> got(b.width(), b.height());
@@ -234,6 +234,7 @@ static void test_collar_and_lr_disp_diff() {
       BBox2i big = b; big.expand(collar);
       ImageView<PixelMask<Vector2f>> want(big.width(), big.height());
       int rc;
+      vwo_set_sgm_algorithm(algo ? algo : 1);
       if (algo) rc = vwo_pyramid_correlate_sgm(&left(0, 0).v(), 300, 200, &right(0, 0).v(), 300, 200, lmask.data(), rmask.data(), -18, -7, 18, 7, 7,
                                                (int)CENSUS_TRANSFORM, 2.0f, 0, 3, 3, 5, 2, 2, 6000, 1, big.min().x(), big.min().y(), big.width(), big.height(),
                                                reinterpret_cast<float*>(want.data()));
@@ -249,6 +250,7 @@ static void test_collar_and_lr_disp_diff() {
       EXPECT_EQ(0, bad);
     }
   }
+  vwo_set_sgm_algorithm(1);
   // the discrepancy image is filled tile by tile by the worker threads, each writing its own pixels only
   ImageView<PixelMask<float>> diff(300, 200), diff1(300, 200);
   PyramidCorrelationView v4 = pyramid_correlate(left, right, lmask, rmask, PREFILTER_NONE, 0.0f, search_volume, Vector2i(7, 7), ABSOLUTE_DIFFERENCE,

@@ -79,32 +79,33 @@ def test_round1_fuzz_finding_ssd_ties_in_mean_filled_border(oracle):
         assert np.array_equal(g, o), int((g != o).any(-1).sum())
 
 
-@pytest.mark.parametrize("n,seed", [(120, 301)])
-def test_fuzz_sgm_identical_to_oracle(oracle, n, seed):
+@pytest.mark.parametrize("n,seed,mgm", [(120, 301, False), (120, 302, True)])
+def test_fuzz_sgm_identical_to_oracle(oracle, n, seed, mgm):
     bad = []
     for c in fuzz_cases.sgm_cases(n, seed):
         h, w = c["left"].shape
         gi, gs = stereo.calc_disparity_sgm(c["cost"], c["left"], c["right"], BBox2i(0, 0, w, h), c["search"], (c["k"], c["k"]),
                                            subpixel_mode=c["sub"], search_buffer=(2, 2), memory_limit_mb=c["mem"], left_mask=c["lm"],
-                                           right_mask=c["rm"], prev_disparity=c["prev"], with_subpixel=True)
+                                           right_mask=c["rm"], prev_disparity=c["prev"], with_subpixel=True, use_mgm=mgm)
         oi, os_ = oracle.calc_disparity_sgm(c["cost"], c["left"], c["right"], c["search"], c["k"], subpixel=c["sub"], search_buffer=(2, 2),
-                                            memory_limit_mb=c["mem"], left_mask=c["lm"], right_mask=c["rm"], prev_disparity=c["prev"])
+                                            memory_limit_mb=c["mem"], left_mask=c["lm"], right_mask=c["rm"], prev_disparity=c["prev"], use_mgm=mgm)
         if not (np.array_equal(gi, oi) and (gs is None or np.abs(gs - os_).max() < 1e-5)):
             bad.append((c["it"], int((gi != oi).any(-1).sum())))
-    assert not bad, "sgm_cases(seed=%d): %s" % (seed, bad)
+    assert not bad, "sgm_cases(seed=%d, mgm=%s): %s" % (seed, mgm, bad)
 
 
-@pytest.mark.parametrize("n,seed", [(24, 301)])
-def test_fuzz_pyramid_sgm_identical_to_oracle(oracle, n, seed):
-    """The SGM branch of the pyramid: ragged boxes from the previous level, R->L runs, consistency levels, masks, sub-tiles."""
+@pytest.mark.parametrize("n,seed,algorithm", [(24, 301, 1), (24, 302, 2), (24, 303, 3)])
+def test_fuzz_pyramid_sgm_identical_to_oracle(oracle, n, seed, algorithm):
+    """The SGM branch of the pyramid: ragged boxes from the previous level, R->L runs, consistency levels, masks, sub-tiles;
+    algorithm 2 / 3 = VW_CORRELATION_MGM / _FINAL_MGM."""
     bad = []
     for c in fuzz_cases.pyramid_sgm_cases(n, seed):
         s = c["search"]
         g = stereo.pyramid_correlate(c["left"], c["right"], c["lm"], c["rm"], 0, 0.0, BBox2i.from_corners(s[:2], s[2:]), (c["k"], c["k"]), c["cost"],
                                      consistency_threshold=c["thr"], min_consistency_level=c["mcl"], filter_half_kernel=c["filt"],
-                                     max_pyramid_levels=c["levels"], algorithm=1, bbox=None if c["bbox"] is None else BBox2i(*c["bbox"]))
+                                     max_pyramid_levels=c["levels"], algorithm=algorithm, bbox=None if c["bbox"] is None else BBox2i(*c["bbox"]))
         o = oracle.pyramid_correlate_sgm(c["left"], c["right"], c["lm"], c["rm"], s, c["k"], c["cost"], c["thr"], c["mcl"], c["filt"], c["levels"],
-                                         bbox=c["bbox"])
+                                         bbox=c["bbox"], algorithm=algorithm)
         if not (np.array_equal(g[..., 2], o[..., 2]) and np.abs(g[..., :2] - o[..., :2]).max() < 1e-5):
             bad.append(c["it"])
-    assert not bad, "pyramid_sgm_cases(seed=%d) mismatching indices %s" % (seed, bad)
+    assert not bad, "pyramid_sgm_cases(seed=%d, algorithm=%d) mismatching indices %s" % (seed, algorithm, bad)
