@@ -616,81 +616,80 @@ mgm_front_kernel(SgmGeom g, MgmDirs D, int front, const uint8_t* __restrict__ le
                  uint16_t* __restrict__ vols, size_t vol_elems, unsigned p1, unsigned p2) {
   extern __shared__ uint16_t sm[];
   const int num_disp = g.num_dx * g.num_dy;
-  uint16_t* full_prior = sm;                 // num_disp: the predecessor's vector over the whole search range, BAD_VAL elsewhere
-  uint16_t* first = sm + num_disp;           // num_disp: result of the first evaluation
+  // the two predecessors' vectors over the whole search range, BAD_VAL elsewhere (evaluate_path's full_prior_buffer, SGM.cc:1013-1150)
+  uint16_t* fp_a = sm;
+  uint16_t* fp_b = sm + num_disp;
   const int lane = threadIdx.x, q = blockIdx.y, W = g.ocols, H = g.orows;
   int c, r;
   if (!mgm_front_pixel(D, q, front, (int)blockIdx.x, W, H, c, r)) return;
-  const size_t p = (size_t)r * W + c;
-  const B4 b = bounds[p];
-  const int wd = b.x1 - b.x0 + 1, nd = wd * (b.y1 - b.y0 + 1);
-  if (nd <= 0) return;                                         // get_num_disp() == 0: skipped (SGMAssist.h:904-909)
-  const unsigned long long st = starts[p];
-  uint16_t* vol = vols + (size_t)q * vol_elems;
   const int need = D.need[q];
   const bool ok = (!(need & 1) || c > 0) && (!(need & 2) || c < W - 1) && (!(need & 4) || r > 0) && (!(need & 8) || r < H - 1);
-  if (!ok) {                                                   // "Just init to the local cost"
-    for (int i = lane; i < nd; i += 64) vol[st + i] = (uint16_t)cost[st + i];
-    return;
-  }
-  const unsigned BAD = (255u + p2) & 0xffffu;
-  for (int i = lane; i < num_disp; i += 64) full_prior[i] = (uint16_t)BAD;
+  // every record of the step is addressed by the coordinates alone: one memory round trip for the three boxes, the three vector
+  // starts and the two grey values, a second one for the first 128 elements of both predecessor vectors and of the costs
+  const size_t p = (size_t)r * W + c;
+  const size_t pa = ok ? (size_t)(r + D.ay[q]) * W + (c + D.ax[q]) : p, pb = ok ? (size_t)(r + D.by[q]) * W + (c + D.bx[q]) : p;
+  const B4 b = bounds[p], ba = bounds[pa], bb = bounds[pb];
+  const unsigned long long st = starts[p], sta = starts[pa], stb = starts[pb];
   // the reference indexes the image unchecked; the far-side pixel is inside it whenever the kernel is >= 3 (calc_disparity_sgm
   // always searches from 0).  Clamped like the oracle so that the read is defined for any geometry.
   const int fc = min(max(c - D.ax[q] + min_col, 0), lw - 1), fr = min(max(r - D.ay[q] + min_row, 0), lh - 1);
   int grad = (int)left[(size_t)(r + min_row) * lw + (c + min_col)] - (int)left[(size_t)fr * lw + fc];
+  const int wd = b.x1 - b.x0 + 1, nd = wd * (b.y1 - b.y0 + 1);
+  if (nd <= 0) return;                                         // get_num_disp() == 0: skipped (SGMAssist.h:904-909)
+  uint16_t* vol = vols + (size_t)q * vol_elems;
+  const unsigned c0 = lane < nd ? cost[st + lane] : 0u, c1 = lane + 64 < nd ? cost[st + lane + 64] : 0u;
+  if (!ok) {                                                   // "Just init to the local cost"
+    for (int i = lane; i < nd; i += 64) vol[st + i] = (uint16_t)(i < 64 ? c0 : i < 128 ? c1 : (unsigned)cost[st + i]);
+    return;
+  }
+  const unsigned BAD = (255u + p2) & 0xffffu;
+  const int wa = ba.x1 - ba.x0 + 1, na = wa * (ba.y1 - ba.y0 + 1);              // 0 for a skipped predecessor: an empty vector
+  const int wb = bb.x1 - bb.x0 + 1, nb = wb * (bb.y1 - bb.y0 + 1);
+  const uint16_t* pra = vol + sta;
+  const uint16_t* prb = vol + stb;
+  const unsigned a0 = lane < na ? pra[lane] : BAD, a1 = lane + 64 < na ? pra[lane + 64] : BAD;
+  const unsigned b0 = lane < nb ? prb[lane] : BAD, b1 = lane + 64 < nb ? prb[lane + 64] : BAD;
+  for (int i = lane; i < num_disp; i += 64) { fp_a[i] = (uint16_t)BAD; fp_b[i] = (uint16_t)BAD; }
   grad = grad < 0 ? -grad : grad;
   unsigned p2_mod = p2;
   if (grad > 0) p2_mod /= (unsigned)grad;
   if (p2_mod < p1) p2_mod = p1;
-  const float inv_wd = __builtin_amdgcn_rcpf((float)wd);
   lds_barrier();
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    const int cp = c + (pass ? D.bx[q] : D.ax[q]), rp = r + (pass ? D.by[q] : D.ay[q]);
-    const size_t pp = (size_t)rp * W + cp;
-    const B4 bp = bounds[pp];
-    const uint16_t* prior = vol + starts[pp];
-    const int wp = bp.x1 - bp.x0 + 1, np = wp * (bp.y1 - bp.y0 + 1);            // 0 for a skipped predecessor: an empty vector
+  auto scatter = [&](uint16_t* fp, const B4& bp, int wp, int np, const uint16_t* prior, unsigned v0, unsigned v1) __attribute__((always_inline)) {
     const float inv_wp = __builtin_amdgcn_rcpf((float)max(wp, 1));
     unsigned mn = BAD;
     for (int i = lane; i < np; i += 64) {
       int qy, qx;
       divmod_f(i, wp, inv_wp, qy, qx);
-      const unsigned v = prior[i];
+      const unsigned v = i < 64 ? v0 : i < 128 ? v1 : (unsigned)prior[i];
       mn = min(mn, v);
-      full_prior[(bp.y0 + qy - g.min_dy) * g.num_dx + (bp.x0 + qx - g.min_dx)] = (uint16_t)v;
+      fp[(bp.y0 + qy - g.min_dy) * g.num_dx + (bp.x0 + qx - g.min_dx)] = (uint16_t)v;
     }
-    const unsigned min_prior = wave_min_u32(mn);
-    const unsigned dJ = (min_prior + p2_mod) & 0xffffu;
-    lds_barrier();
-    for (int i = lane; i < nd; i += 64) {
-      int qy, qx;
-      divmod_f(i, wd, inv_wd, qy, qx);
-      const int dx = b.x0 + qx, dy = b.y0 + qy;
-      const int xo = dx - g.min_dx, yo = dy - g.min_dy;
-      const int xl = dx - 1 < g.min_dx ? xo : xo - 1, xm = dx + 1 > g.max_dx ? xo : xo + 1;
-      const int yl = (dy - 1 < g.min_dy ? yo : yo - 1) * g.num_dx, ym = (dy + 1 > g.max_dy ? yo : yo + 1) * g.num_dx, yc = yo * g.num_dx;
-      unsigned m = full_prior[yl + xo];
-      m = min(m, (unsigned)full_prior[yc + xl]); m = min(m, (unsigned)full_prior[yc + xm]); m = min(m, (unsigned)full_prior[ym + xo]);
-      m = min(m, (unsigned)full_prior[yl + xl]); m = min(m, (unsigned)full_prior[yl + xm]);
-      m = min(m, (unsigned)full_prior[ym + xl]); m = min(m, (unsigned)full_prior[ym + xm]);
+    return wave_min_u32(mn);
+  };
+  const unsigned min_a = scatter(fp_a, ba, wa, na, pra, a0, a1), min_b = scatter(fp_b, bb, wb, nb, prb, b0, b1);
+  const unsigned dj_a = (min_a + p2_mod) & 0xffffu, dj_b = (min_b + p2_mod) & 0xffffu;
+  const float inv_wd = __builtin_amdgcn_rcpf((float)wd);
+  lds_barrier();
+  for (int i = lane; i < nd; i += 64) {
+    int qy, qx;
+    divmod_f(i, wd, inv_wd, qy, qx);
+    const int dx = b.x0 + qx, dy = b.y0 + qy;
+    const int xo = dx - g.min_dx, yo = dy - g.min_dy;
+    const int xl = dx - 1 < g.min_dx ? xo : xo - 1, xm = dx + 1 > g.max_dx ? xo : xo + 1;
+    const int yl = (dy - 1 < g.min_dy ? yo : yo - 1) * g.num_dx, ym = (dy + 1 > g.max_dy ? yo : yo + 1) * g.num_dx, yc = yo * g.num_dx;
+    const unsigned lc = i < 64 ? c0 : i < 128 ? c1 : (unsigned)cost[st + i];
+    auto eval = [&](const uint16_t* fp, unsigned min_prior, unsigned dJ) __attribute__((always_inline)) {
+      unsigned m = fp[yl + xo];
+      m = min(m, (unsigned)fp[yc + xl]); m = min(m, (unsigned)fp[yc + xm]); m = min(m, (unsigned)fp[ym + xo]);
+      m = min(m, (unsigned)fp[yl + xl]); m = min(m, (unsigned)fp[yl + xm]);
+      m = min(m, (unsigned)fp[ym + xl]); m = min(m, (unsigned)fp[ym + xm]);
       unsigned res = adds16(m, p1);
-      res = min(res, min((unsigned)full_prior[yc + xo], dJ));
-      res = adds16(res, (unsigned)cost[st + i]);
-      res = subs16(res, min_prior);
-      if (pass == 0) first[i] = (uint16_t)res;
-      else vol[st + i] = (uint16_t)(((unsigned)first[i] + res) >> 1);      // "(a + b) / 2" in int (SGMAssist.h:945-946)
-    }
-    lds_barrier();
-    if (pass == 0) {
-      for (int i = lane; i < np; i += 64) {
-        int qy, qx;
-        divmod_f(i, wp, inv_wp, qy, qx);
-        full_prior[(bp.y0 + qy - g.min_dy) * g.num_dx + (bp.x0 + qx - g.min_dx)] = (uint16_t)BAD;
-      }
-      lds_barrier();
-    }
+      res = min(res, min((unsigned)fp[yc + xo], dJ));
+      res = adds16(res, lc);
+      return subs16(res, min_prior);
+    };
+    vol[st + i] = (uint16_t)((eval(fp_a, min_a, dj_a) + eval(fp_b, min_b, dj_b)) >> 1);      // "(a + b) / 2" in int (SGMAssist.h:945-946)
   }
 }
 
