@@ -141,6 +141,15 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right):
     e = out[-1]
     if e["hot_us"]:
         e["min_model_frac"] = round(npx * 536 / (e["hot_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    # (3b) the same matcher with use_mgm (accum_mgm_multithread): 1024^2, one launch per front of the 2-D recurrence.  Bytes: 8 directions x
+    # (2 reads + 1 write) x 2 B per cell + the sum pass (8 reads + 1 write) x 2 B = 66 B per cell, + costs and images
+    n = 1024
+    lm_, rm_ = lt[:n, :n].contiguous(), rt[:n, :n + 128].contiguous()
+    mgm = lambda: stereo.calc_disparity_sgm(3, lm_, rm_, vwa.BBox2i(0, 0, n, n), (128, 0), (7, 7), use_mgm=True, with_subpixel=True, memory_limit_mb=200000, ctx=ctx)
+    wall, kern = measure(ctx, torch, mgm, 3, warm=1)
+    npx = (n - 6) * (n - 6)
+    entry("MGM (use_mgm) 1024^2, census 7x7, 129 disparities", npx * (20 + (66 + 3) * 129), "direction volumes: (20 + 69 D) B/px (DESIGN.md 4.6b)", wall, kern,
+          {k for k in kern if k.startswith("sgm")}, npx, fronts=2 * n - 13, note="launch bound: one launch per front")
     # (4) the tile loop of config 5 (tools/correlate.cc:207-266): pyramid_correlate over the 4096^2 pair in 1024^2 tiles, pulled by
     # 4 tile threads, each with its own engine context and stream — the way block_write_image runs the reference's view
     import threading
