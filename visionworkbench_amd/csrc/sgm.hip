@@ -1137,10 +1137,8 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
     const unsigned pen = (unsigned)__builtin_amdgcn_readlane((int)penv, s & 63);
     const unsigned dj = (min_prior + pen) & 0xffffu;
     const us2 dJ = as_us2(dj | (dj << 16)), mp = as_us2(min_prior | (min_prior << 16));
-#ifndef VWGPU_EXP_NODPP
     wave_shr1_keep(pm, r[EPT - 1]);
     wave_shl1_keep(pn, r[0]);
-#endif
     unsigned al[EPT + 1];                                           // al[e] = (d_2j-1, d_2j) of pair e; al[e+1] = (d_2j+1, d_2j+2)
     al[0] = __builtin_amdgcn_alignbit(r[0], pm, 16);
 #pragma unroll
@@ -1185,11 +1183,7 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
     }
     astore += astore_step;
     const unsigned mnu = as_u32(mn2);
-#ifdef VWGPU_EXP_NOREDUCE
-    min_prior = (unsigned)__builtin_amdgcn_readlane((int)min(mnu & 0xffffu, mnu >> 16), 5);
-#else
     min_prior = wave_min_u32_fused(min(mnu & 0xffffu, mnu >> 16));
-#endif
   };
   auto fetch = [&](unsigned (&buf)[KC][NW], unsigned (&abuf)[KC][EPT]) __attribute__((always_inline)) {
 #pragma unroll
@@ -1801,12 +1795,22 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
           fronts = std::max(fronts, d.kind == 0 ? W + H - 1 : d.kind == 1 ? H : W);
           width = std::max(width, d.kind == 0 ? std::min(W, H) : d.kind == 1 ? W : H);
         }
+        (void)width;
         for (int f = 0; f < fronts; ++f) {
-#define VWGPU_MGM_U(E) hipLaunchKernelGGL((mgm_front_uniform_kernel<E>), dim3(width, per), dim3(64), 0, st, g, M, f, ustride, l8, lw, lh, min_col, min_row, \
+          // pixels of this front in the longest direction of the launch (an anti-diagonal grows and shrinks; rows / columns end)
+          int fw = 0;
+          for (int q = 0; q < per; ++q) {
+            const MD& d = md[first + q];
+            if (d.kind == 0) fw = std::max(fw, std::min(std::min(f, W + H - 2 - f), std::min(W, H) - 1) + 1);
+            else if (d.kind == 1) { if (f < H) fw = std::max(fw, W); }
+            else if (f < W) fw = std::max(fw, H);
+          }
+          if (fw <= 0) continue;
+#define VWGPU_MGM_U(E) hipLaunchKernelGGL((mgm_front_uniform_kernel<E>), dim3(fw, per), dim3(64), 0, st, g, M, f, ustride, l8, lw, lh, min_col, min_row, \
                                           cost, mgm_vol, vol_bytes / 2, (unsigned)p1, (unsigned)p2)
           if (reg_fronts) { switch (pe) { case 1: VWGPU_MGM_U(1); break; case 2: VWGPU_MGM_U(2); break; default: VWGPU_MGM_U(4); break; } }
           else
-            hipLaunchKernelGGL(mgm_front_kernel, dim3(width, per), dim3(64), lds, st, g, M, f, l8, lw, lh, min_col, min_row, bounds, starts, cost,
+            hipLaunchKernelGGL(mgm_front_kernel, dim3(fw, per), dim3(64), lds, st, g, M, f, l8, lw, lh, min_col, min_row, bounds, starts, cost,
                                mgm_vol, vol_bytes / 2, (unsigned)p1, (unsigned)p2);
 #undef VWGPU_MGM_U
         }
