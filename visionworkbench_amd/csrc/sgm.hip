@@ -1240,14 +1240,16 @@ __global__ void uniform_starts_kernel(unsigned long long* __restrict__ starts, s
 // are requested together — one memory round trip per front instead of the chain box -> start -> vector -> LDS of the general
 // kernel — and the two evaluations run in registers (neighbours d - 1 / d + 1 through wave shifts, as there).
 template <int EPT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 mgm_front_uniform_kernel(SgmGeom g, MgmDirs D, int front, int stride, const uint8_t* __restrict__ left, int lw, int lh, int min_col, int min_row,
                          const uint8_t* __restrict__ cost, uint16_t* __restrict__ vols, size_t vol_elems, unsigned p1, unsigned p2) {
   constexpr int NW = CostWords<EPT>::N;
   const int num_disp = g.num_dx, npairs = (num_disp + 1) / 2, q32 = stride / 2;
-  const int tid = threadIdx.x, q = blockIdx.y, W = g.ocols, H = g.orows;
+  // four independent wavefronts (pixels) per workgroup: a front of 2048 pixels x 8 directions is 16 K wavefronts, and the
+  // dispatcher starts workgroups, not waves
+  const int tid = threadIdx.x & 63, q = blockIdx.y, W = g.ocols, H = g.orows;
   int c, r;
-  if (!mgm_front_pixel(D, q, front, (int)blockIdx.x, W, H, c, r)) return;
+  if (!mgm_front_pixel(D, q, front, (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), W, H, c, r)) return;
   const int ax = D.ax[q], ay = D.ay[q], bx = D.bx[q], by = D.by[q], need = D.need[q];
   const bool ok = (!(need & 1) || c > 0) && (!(need & 2) || c < W - 1) && (!(need & 4) || r > 0) && (!(need & 8) || r < H - 1);
   const bool in = tid * EPT + EPT <= q32;
@@ -1806,7 +1808,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
             else if (f < W) fw = std::max(fw, H);
           }
           if (fw <= 0) continue;
-#define VWGPU_MGM_U(E) hipLaunchKernelGGL((mgm_front_uniform_kernel<E>), dim3(fw, per), dim3(64), 0, st, g, M, f, ustride, l8, lw, lh, min_col, min_row, \
+#define VWGPU_MGM_U(E) hipLaunchKernelGGL((mgm_front_uniform_kernel<E>), dim3((fw + 3) / 4, per), dim3(256), 0, st, g, M, f, ustride, l8, lw, lh, min_col, min_row, \
                                           cost, mgm_vol, vol_bytes / 2, (unsigned)p1, (unsigned)p2)
           if (reg_fronts) { switch (pe) { case 1: VWGPU_MGM_U(1); break; case 2: VWGPU_MGM_U(2); break; default: VWGPU_MGM_U(4); break; } }
           else
