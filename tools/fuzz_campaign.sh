@@ -1,0 +1,15 @@
+# Long randomised parity run on the GPU box (the generators of tests/fuzz_cases.py with a fresh seed).  usage: SEED=9191 bash tools/fuzz_campaign.sh
+SEED=${SEED:-9191}
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+L=gpurun_out/fuzz_campaign_$SEED.log; : > $L
+run() { t0=$(date +%s); echo "\$ $*" >> $L; timeout 900 "$@" 2>&1 | grep -E "cases|MISMATCH|ERROR|Traceback" | tail -5 >> $L; echo "  ($(( $(date +%s) - t0 )) s)" >> $L; }
+run python tools/fuzz_pyramid_vs_oracle.py 8000 $SEED 0.6 0,1,2
+run python tools/fuzz_sgm_vs_oracle.py 4000 $SEED
+run python tools/fuzz_sgm_vs_oracle.py 4000 $SEED mgm
+run python tools/fuzz_pyramid_sgm_vs_oracle.py 1500 $SEED 1
+run python tools/fuzz_pyramid_sgm_vs_oracle.py 1000 $SEED 2
+run python tools/fuzz_pyramid_sgm_vs_oracle.py 1000 $SEED 3
+run python tools/fuzz_fast_vs_generic.py 3000 $SEED 0
+run python tools/fuzz_fast_vs_generic.py 3000 $SEED 1
+run python tools/fuzz_fast_vs_generic.py 3000 $SEED 2
+cat $L
