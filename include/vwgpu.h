@@ -365,6 +365,16 @@ int vwgpu_calc_disparity_sgm(vwgpu_ctx* ctx, const vwgpu_sgm_params* params,
                              const int32_t* prev_disparity, int pw, int ph,
                              int32_t* out_disp, float* out_subpixel, size_t cap_pixels, int* ow, int* oh);
 
+/* Host-side view of the launch schedule of the MGM passes (use_mgm; accum_mgm_multithread, src/vw/Stereo/SGM.cc:2619-2700): the
+ * raster loops of the eight SmoothPathAccumTask passes (src/vw/Stereo/SGMAssist.h:911-1236) are walked as FRONTS, sets of pixels whose
+ * two predecessors lie in the previous front (csrc/mgm_schedule.h).  Direction 0 L, 1 TL, 2 R, 3 BR, 4 T, 5 BL, 6 B, 7 TR.
+ * vwgpu_mgm_front_count: number of fronts of a direction on a cols x rows output (< 0: bad arguments).
+ * vwgpu_mgm_front_pixel: pixel `index` of front `front`: returns 1 and fills c_r = {c, r}, preds = {c + ax, r + ay, c + bx, r + by}
+ *   (path predecessor, second predecessor) and *uses_preds (the task's border test: 0 = the pixel keeps its local costs);
+ *   0 when the front has no such pixel, < 0 on bad arguments.  No context, no device work: this is what the launcher enumerates. */
+int vwgpu_mgm_front_count(int cols, int rows, int direction);
+int vwgpu_mgm_front_pixel(int cols, int rows, int direction, int front, int index, int* c_r, int* preds, int* uses_preds);
+
 /* ---- multi-GPU: halo rows of a row-sharded source (csrc/halo.hip) ---------------------------------------------------------
  * The reference has no distributed mode; its tiles are independent (CorrelationView.cc:89-97, CorrelationView.h:123-133), so one
  * process per GPU can own a strip of tile rows.  When the SOURCE image is sharded the same way, rank g holds rows

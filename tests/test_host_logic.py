@@ -99,3 +99,66 @@ def test_halo_plan_matches_the_python_partition():
     import pytest
     with pytest.raises(ValueError):
         partition.halo_plan(2, 2, 10, 0, 0)
+
+
+# The eight SmoothPathAccumTask passes as the reference writes them (src/vw/Stereo/SGMAssist.h:911-1236), re-typed here from its text:
+# (path predecessor, second predecessor, border test of the task, raster loops of the task).  Index = the engine's direction number.
+_MGM_TASKS = [
+    ("L",  (-1, 0), (0, -1), lambda c, r, lc, lr: r > 0 and c > 0,                 "rows_down_cols_right"),    # task_L  :911-955
+    ("TL", (-1, -1), (1, -1), lambda c, r, lc, lr: r > 0 and c > 0 and c < lc,      "rows_down_cols_right"),    # task_TL :958-996
+    ("R",  (1, 0), (0, 1),  lambda c, r, lc, lr: r < lr and c < lc,                "rows_up_cols_left"),       # task_R  :998-1033
+    ("BR", (1, 1), (-1, 1), lambda c, r, lc, lr: r < lr and c > 0 and c < lc,      "rows_up_cols_left"),       # task_BR :1035-1071
+    ("T",  (0, -1), (1, 0), lambda c, r, lc, lr: r > 0 and c < lc,                 "cols_left_rows_down"),     # task_T  :1147-1182
+    ("BL", (-1, 1), (-1, -1), lambda c, r, lc, lr: r > 0 and r < lr and c > 0,      "cols_right_rows_up"),      # task_BL :1110-1145
+    ("B",  (0, 1), (-1, 0), lambda c, r, lc, lr: r < lr and c > 0,                 "cols_right_rows_up"),      # task_B  :1073-1108
+    ("TR", (1, -1), (1, 1), lambda c, r, lc, lr: r > 0 and r < lr and c < lc,      "cols_left_rows_down"),     # task_TR :1184-1219
+]
+
+
+def _raster(order, W, H):
+    if order == "rows_down_cols_right":
+        return [(c, r) for r in range(H) for c in range(W)]
+    if order == "rows_up_cols_left":
+        return [(c, r) for r in range(H - 1, -1, -1) for c in range(W - 1, -1, -1)]
+    if order == "cols_right_rows_up":
+        return [(c, r) for c in range(W) for r in range(H - 1, -1, -1)]
+    return [(c, r) for c in range(W - 1, -1, -1) for r in range(H)]
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (1, 7), (6, 1), (2, 2), (5, 3), (4, 9), (13, 13), (31, 8)])
+def test_mgm_front_schedule_respects_the_tasks_of_the_reference(W, H):
+    """vwgpu_mgm_front_pixel = what the MGM launcher enumerates (csrc/mgm_schedule.h).  For every direction: the fronts visit every pixel
+    exactly once; predecessors and border test are the task's; a pixel that uses its predecessors finds both in the PREVIOUS front
+    (so one launch per front is a valid order), and both precede it in the task's own raster loops (so the reference computes the same)."""
+    lib = _lib.load()
+    cr, pr, use = (ctypes.c_int * 2)(), (ctypes.c_int * 4)(), ctypes.c_int()
+    assert lib.vwgpu_mgm_front_count(0, 4, 0) < 0 and lib.vwgpu_mgm_front_count(4, 4, 8) < 0
+    for d, (name, A, B, test, order) in enumerate(_MGM_TASKS):
+        nf = lib.vwgpu_mgm_front_count(W, H, d)
+        assert nf == (W + H - 1 if name in "LRTB" else H if name in ("TL", "BR") else W), name
+        front_of, uses = {}, {}
+        for f in range(nf):
+            i = 0
+            while True:
+                rc = lib.vwgpu_mgm_front_pixel(W, H, d, f, i, cr, pr, ctypes.byref(use))
+                assert rc >= 0
+                if rc == 0:
+                    break
+                c, r = cr[0], cr[1]
+                assert 0 <= c < W and 0 <= r < H and (c, r) not in front_of, (name, c, r)
+                front_of[(c, r)] = f
+                uses[(c, r)] = bool(use.value)
+                assert (pr[0] - c, pr[1] - r) == A and (pr[2] - c, pr[3] - r) == B, name
+                assert bool(use.value) == bool(test(c, r, W - 1, H - 1)), (name, c, r)
+                i += 1
+            assert lib.vwgpu_mgm_front_pixel(W, H, d, f, i + 1, cr, pr, ctypes.byref(use)) == 0
+        assert len(front_of) == W * H, name
+        assert lib.vwgpu_mgm_front_pixel(W, H, d, nf, 0, cr, pr, ctypes.byref(use)) == 0
+        position = {p: k for k, p in enumerate(_raster(order, W, H))}
+        for (c, r), f in front_of.items():
+            if not uses[(c, r)]:
+                continue
+            for dx, dy in (A, B):
+                q = (c + dx, r + dy)
+                assert q in front_of and front_of[q] == f - 1, (name, (c, r), q)
+                assert position[q] < position[(c, r)], (name, (c, r), q)

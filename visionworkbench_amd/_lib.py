@@ -25,7 +25,7 @@ SYMBOLS = [
     "vwgpu_subdivide_regions",
     "vwgpu_disparity_blob_filter_dev", "vwgpu_disparity_blob_filter",
     "vwgpu_pyramid_correlate_dev", "vwgpu_pyramid_correlate",
-    "vwgpu_calc_disparity_sgm_dev", "vwgpu_calc_disparity_sgm",
+    "vwgpu_calc_disparity_sgm_dev", "vwgpu_calc_disparity_sgm", "vwgpu_mgm_front_count", "vwgpu_mgm_front_pixel",
     "vwgpu_comm_unique_id", "vwgpu_comm_create", "vwgpu_comm_destroy", "vwgpu_halo_plan", "vwgpu_fetch_strip_window_dev",
 ]
 
@@ -109,6 +109,8 @@ def load():
     lib.vwgpu_comm_create.argtypes = [P, P, I, I, ctypes.POINTER(P)]
     lib.vwgpu_comm_destroy.argtypes = [P]
     lib.vwgpu_halo_plan.argtypes = [I, I, I, I, I, IP, IP, IP, IP]
+    lib.vwgpu_mgm_front_count.argtypes = [I, I, I]
+    lib.vwgpu_mgm_front_pixel.argtypes = [I, I, I, I, I, P, P, IP]
     lib.vwgpu_fetch_strip_window_dev.argtypes = [P, P, P, I, I, I, I, I, P, IP]
     bs = [P, P, I, I, PD, I, I, P, PD]
     lib.vwgpu_fast_box_sum_dev.argtypes = bs

@@ -26,6 +26,7 @@
 
 #include <cstdlib>
 #include "vwgpu_internal.h"
+#include "mgm_schedule.h"
 #include <type_traits>
 
 namespace {
@@ -594,20 +595,9 @@ struct MgmDirs {
   int kind[8];                    // 0 anti-diagonal fronts, 1 row fronts, 2 column fronts
   int flipx[8], flipy[8];         // fronts counted from the right / from the bottom
 };
-// pixel of (front, index in the front) for direction q; false when the front has no such pixel
+// pixel of (front, index in the front) for direction q; false when the front has no such pixel (mgm_schedule.h)
 __device__ __forceinline__ bool mgm_front_pixel(const MgmDirs& D, int q, int front, int i, int W, int H, int& c, int& r) {
-  if (D.kind[q] == 0) {
-    const int cc = max(0, front - (H - 1)) + i, rr = front - cc;
-    if (cc >= W || rr < 0) return false;
-    c = D.flipx[q] ? W - 1 - cc : cc; r = D.flipy[q] ? H - 1 - rr : rr;
-  } else if (D.kind[q] == 1) {
-    if (front >= H || i >= W) return false;
-    c = i; r = D.flipy[q] ? H - 1 - front : front;
-  } else {
-    if (front >= W || i >= H) return false;
-    r = i; c = D.flipx[q] ? W - 1 - front : front;
-  }
-  return true;
+  return vwgpu::mgm_front_pixel(D.kind[q], D.flipx[q], D.flipy[q], front, i, W, H, c, r);
 }
 
 __global__ void __launch_bounds__(64)
@@ -623,7 +613,7 @@ mgm_front_kernel(SgmGeom g, MgmDirs D, int front, const uint8_t* __restrict__ le
   int c, r;
   if (!mgm_front_pixel(D, q, front, (int)blockIdx.x, W, H, c, r)) return;
   const int need = D.need[q];
-  const bool ok = (!(need & 1) || c > 0) && (!(need & 2) || c < W - 1) && (!(need & 4) || r > 0) && (!(need & 8) || r < H - 1);
+  const bool ok = vwgpu::mgm_uses_predecessors(need, c, r, W, H);
   // every record of the step is addressed by the coordinates alone: one memory round trip for the three boxes, the three vector
   // starts and the two grey values, a second one for the first 128 elements of both predecessor vectors and of the costs
   const size_t p = (size_t)r * W + c;
@@ -1251,7 +1241,7 @@ mgm_front_uniform_kernel(SgmGeom g, MgmDirs D, int front, int stride, const uint
   int c, r;
   if (!mgm_front_pixel(D, q, front, (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), W, H, c, r)) return;
   const int ax = D.ax[q], ay = D.ay[q], bx = D.bx[q], by = D.by[q], need = D.need[q];
-  const bool ok = (!(need & 1) || c > 0) && (!(need & 2) || c < W - 1) && (!(need & 4) || r > 0) && (!(need & 8) || r < H - 1);
+  const bool ok = vwgpu::mgm_uses_predecessors(need, c, r, W, H);
   const bool in = tid * EPT + EPT <= q32;
   const size_t p = (size_t)r * W + c;
   unsigned* vol = reinterpret_cast<unsigned*>(vols + (size_t)q * vol_elems);
@@ -1772,16 +1762,8 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       // directions have W + H - 1 anti-diagonal fronts, the diagonal ones max(W, H) row / column fronts, so eight directions
       // together take W + H - 1 launches; then one pass adds the volumes to the sums.
       vwgpu_prof_scope ps(ctx, "sgm_mgm_paths");
-      struct MD { int ax, ay, bx, by, need, kind, flipx, flipy; };
-      //                    A (path)  B (perp.)  border test        fronts
-      const MD md[8] = {{-1,  0,  0, -1, 1 | 4,      0, 0, 0},      // L   SGMAssist.h:911-955
-                        {-1, -1,  1, -1, 1 | 2 | 4,  1, 0, 0},      // TL  :958-996
-                        { 1,  0,  0,  1, 2 | 8,      0, 1, 1},      // R   :998-1033
-                        { 1,  1, -1,  1, 1 | 2 | 8,  1, 0, 1},      // BR  :1035-1071
-                        { 0, -1,  1,  0, 2 | 4,      0, 1, 0},      // T   :1147-1182
-                        {-1,  1, -1, -1, 1 | 4 | 8,  2, 0, 0},      // BL  :1110-1145
-                        { 0,  1, -1,  0, 1 | 8,      0, 0, 1},      // B   :1073-1108
-                        { 1, -1,  1,  1, 2 | 4 | 8,  2, 1, 0}};     // TR  :1184-1219
+      typedef vwgpu::MgmDir MD;
+      const MD* md = vwgpu::kMgmDirs;                               // L, TL, R, BR, T, BL, B, TR (mgm_schedule.h)
       const int per = mgm_vols;                                     // directions per launch
       int pe = (int)(((num_disp + 1) / 2 + 63) / 64);
       if (pe == 3) pe = 4;
@@ -1790,23 +1772,15 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       for (int first = 0; first < 8; first += per) {
         MgmDirs M;
         M.n = per;
-        int fronts = 0, width = 0;
+        int fronts = 0;
         for (int q = 0; q < per; ++q) {
           const MD& d = md[first + q];
           M.ax[q] = d.ax; M.ay[q] = d.ay; M.bx[q] = d.bx; M.by[q] = d.by; M.need[q] = d.need; M.kind[q] = d.kind; M.flipx[q] = d.flipx; M.flipy[q] = d.flipy;
-          fronts = std::max(fronts, d.kind == 0 ? W + H - 1 : d.kind == 1 ? H : W);
-          width = std::max(width, d.kind == 0 ? std::min(W, H) : d.kind == 1 ? W : H);
+          fronts = std::max(fronts, vwgpu::mgm_front_count(d.kind, W, H));
         }
-        (void)width;
         for (int f = 0; f < fronts; ++f) {
-          // pixels of this front in the longest direction of the launch (an anti-diagonal grows and shrinks; rows / columns end)
-          int fw = 0;
-          for (int q = 0; q < per; ++q) {
-            const MD& d = md[first + q];
-            if (d.kind == 0) fw = std::max(fw, std::min(std::min(f, W + H - 2 - f), std::min(W, H) - 1) + 1);
-            else if (d.kind == 1) { if (f < H) fw = std::max(fw, W); }
-            else if (f < W) fw = std::max(fw, H);
-          }
+          int fw = 0;                                                // pixels of this front in the longest direction of the launch
+          for (int q = 0; q < per; ++q) fw = std::max(fw, vwgpu::mgm_front_width(md[first + q].kind, f, W, H));
           if (fw <= 0) continue;
 #define VWGPU_MGM_U(E) hipLaunchKernelGGL((mgm_front_uniform_kernel<E>), dim3((fw + 3) / 4, per), dim3(256), 0, st, g, M, f, ustride, l8, lw, lh, min_col, min_row, \
                                           cost, mgm_vol, vol_bytes / 2, (unsigned)p1, (unsigned)p2)

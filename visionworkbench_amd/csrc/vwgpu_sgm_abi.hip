@@ -1,6 +1,7 @@
 // vwgpu_sgm_abi.hip — extern "C" entry points of the SGM family (include/vwgpu.h); argument checks mirror
 // calc_disparity_sgm's asserts (src/vw/Stereo/SGM.cc:183-193) and compute_disparity_costs' NoImplErr cases (:1874-1893).
 #include "vwgpu_internal.h"
+#include "mgm_schedule.h"
 
 namespace {
 int check_sgm(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const void* l, int lw, int lh, const void* r, int rw, int rh, int sx, int sy,
@@ -24,6 +25,23 @@ int check_sgm(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const void* l, int lw, 
 }  // namespace
 
 extern "C" {
+
+int vwgpu_mgm_front_count(int cols, int rows, int direction) {
+  if (cols <= 0 || rows <= 0 || direction < 0 || direction > 7) return VWGPU_ERR_ARGUMENT;
+  return vwgpu::mgm_front_count(vwgpu::kMgmDirs[direction].kind, cols, rows);
+}
+
+int vwgpu_mgm_front_pixel(int cols, int rows, int direction, int front, int index, int* c_r, int* preds, int* uses_preds) {
+  if (cols <= 0 || rows <= 0 || direction < 0 || direction > 7 || !c_r || !preds || !uses_preds) return VWGPU_ERR_ARGUMENT;
+  const vwgpu::MgmDir& d = vwgpu::kMgmDirs[direction];
+  int c = 0, r = 0;
+  if (index >= vwgpu::mgm_front_width(d.kind, front, cols, rows)) return 0;          // what the launcher sizes the grid with
+  if (!vwgpu::mgm_front_pixel(d.kind, d.flipx, d.flipy, front, index, cols, rows, c, r)) return 0;
+  c_r[0] = c; c_r[1] = r;
+  preds[0] = c + d.ax; preds[1] = r + d.ay; preds[2] = c + d.bx; preds[3] = r + d.by;
+  *uses_preds = vwgpu::mgm_uses_predecessors(d.need, c, r, cols, rows) ? 1 : 0;
+  return 1;
+}
 
 int vwgpu_calc_disparity_sgm_dev(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* d_left, int lw, int lh, ptrdiff_t ls,
                                  const float* d_right, int rw, int rh, ptrdiff_t rs, int sx, int sy,
