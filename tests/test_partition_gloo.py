@@ -138,7 +138,7 @@ def _tile_worker(rank, world, port, sgm, collar, q):
         # tile + collar semantics: correlate the collared box, keep its centre (the box may leave the image: edge extension)
         big = (x - collar, y - collar - l0, tw + 2 * collar, th + 2 * collar)
         if sgm:
-            t = oracle.pyramid_correlate_sgm(lwin, rwin, None, None, search, k, 3, 2.0, 0, 3, levels, bbox=big)
+            t = oracle.pyramid_correlate_sgm(lwin, rwin, None, None, search, k, 3, 2.0, 0, 3, levels, bbox=big, algorithm=int(sgm))
         else:
             t = oracle.pyramid_correlate(lwin, rwin, None, None, 0, 0.0, search, (k, k), 0, 0, 0.0, 2.0, 3, levels, bbox=big)
         parts.append(((x, y, tw, th), t[collar:collar + th, collar:collar + tw].copy()))
@@ -154,9 +154,10 @@ def _tile_worker(rank, world, port, sgm, collar, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sgm,collar", [(False, 0), (True, 16)])
+@pytest.mark.parametrize("sgm,collar", [(0, 0), (1, 16), (3, 16)])
 def test_sharded_source_pyramid_tiles_and_sgm_collar(oracle, sgm, collar):
-    """World 2: the reassembled tiles equal the same (collared) tiles computed from the whole pair."""
+    """World 2: the reassembled tiles equal the same (collared) tiles computed from the whole pair.  sgm = the CorrelationAlgorithm
+    (0 block matching, 1 SGM, 3 FINAL_MGM: the 2-D recurrence of MGM couples a tile no further than its collared box either)."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -177,7 +178,7 @@ def test_sharded_source_pyramid_tiles_and_sgm_collar(oracle, sgm, collar):
         for (x, y, tw, th) in partition.strip_tiles(rank, world, h, w, tile=96):
             big = (x - collar, y - collar, tw + 2 * collar, th + 2 * collar)
             if sgm:
-                t = oracle.pyramid_correlate_sgm(left, right, None, None, search, k, 3, 2.0, 0, 3, levels, bbox=big)
+                t = oracle.pyramid_correlate_sgm(left, right, None, None, search, k, 3, 2.0, 0, 3, levels, bbox=big, algorithm=int(sgm))
             else:
                 t = oracle.pyramid_correlate(left, right, None, None, 0, 0.0, search, (k, k), 0, 0, 0.0, 2.0, 3, levels, bbox=big)
             want[y:y + th, x:x + tw] = t[collar:collar + th, collar:collar + tw]
