@@ -380,6 +380,8 @@ cost_row_kernel(const uint64_t* __restrict__ lc, int lcw, const uint64_t* __rest
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the global
 // loads that were just issued as a prefetch for the NEXT step of the scan-line recurrence.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// for LDS data a wavefront exchanges with itself only: its own LDS operations complete in order, the compiler must not move them
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ unsigned adds16(unsigned a, unsigned b) { return min(a + b, 65535u); }
 __device__ __forceinline__ unsigned subs16(unsigned a, unsigned b) { return max(a, b) - b; }
@@ -600,18 +602,22 @@ __device__ __forceinline__ bool mgm_front_pixel(const MgmDirs& D, int q, int fro
   return vwgpu::mgm_front_pixel(D.kind[q], D.flipx[q], D.flipy[q], front, i, W, H, c, r);
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 mgm_front_kernel(SgmGeom g, MgmDirs D, int front, const uint8_t* __restrict__ left, int lw, int lh, int min_col, int min_row,
                  const B4* __restrict__ bounds, const unsigned long long* __restrict__ starts, const uint8_t* __restrict__ cost,
                  uint16_t* __restrict__ vols, size_t vol_elems, unsigned p1, unsigned p2) {
   extern __shared__ uint16_t sm[];
   const int num_disp = g.num_dx * g.num_dy;
+  // One pixel per WAVEFRONT; a workgroup holds one or four independent wavefronts (the dispatcher starts workgroups, and a front of a
+  // 1100-pixel tile in 8 directions is 8800 of them).  A wave only ever reads the LDS cells it wrote itself, so the phases are
+  // separated by s_waitcnt alone (wave_lds_sync) — no workgroup barrier, and a wave may return early.
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), wpw = (int)blockDim.x >> 6;
   // the two predecessors' vectors over the whole search range, BAD_VAL elsewhere (evaluate_path's full_prior_buffer, SGM.cc:1013-1150)
-  uint16_t* fp_a = sm;
-  uint16_t* fp_b = sm + num_disp;
-  const int lane = threadIdx.x, q = blockIdx.y, W = g.ocols, H = g.orows;
+  uint16_t* fp_a = sm + (size_t)wave * 2 * num_disp;
+  uint16_t* fp_b = fp_a + num_disp;
+  const int lane = threadIdx.x & 63, q = blockIdx.y, W = g.ocols, H = g.orows;
   int c, r;
-  if (!mgm_front_pixel(D, q, front, (int)blockIdx.x, W, H, c, r)) return;
+  if (!mgm_front_pixel(D, q, front, (int)blockIdx.x * wpw + wave, W, H, c, r)) return;
   const int need = D.need[q];
   const bool ok = vwgpu::mgm_uses_predecessors(need, c, r, W, H);
   // every record of the step is addressed by the coordinates alone: one memory round trip for the three boxes, the three vector
@@ -644,7 +650,7 @@ mgm_front_kernel(SgmGeom g, MgmDirs D, int front, const uint8_t* __restrict__ le
   unsigned p2_mod = p2;
   if (grad > 0) p2_mod /= (unsigned)grad;
   if (p2_mod < p1) p2_mod = p1;
-  lds_barrier();
+  wave_lds_sync();
   auto scatter = [&](uint16_t* fp, const B4& bp, int wp, int np, const uint16_t* prior, unsigned v0, unsigned v1) __attribute__((always_inline)) {
     const float inv_wp = __builtin_amdgcn_rcpf((float)max(wp, 1));
     unsigned mn = BAD;
@@ -660,7 +666,7 @@ mgm_front_kernel(SgmGeom g, MgmDirs D, int front, const uint8_t* __restrict__ le
   const unsigned min_a = scatter(fp_a, ba, wa, na, pra, a0, a1), min_b = scatter(fp_b, bb, wb, nb, prb, b0, b1);
   const unsigned dj_a = (min_a + p2_mod) & 0xffffu, dj_b = (min_b + p2_mod) & 0xffffu;
   const float inv_wd = __builtin_amdgcn_rcpf((float)wd);
-  lds_barrier();
+  wave_lds_sync();
   for (int i = lane; i < nd; i += 64) {
     int qy, qx;
     divmod_f(i, wd, inv_wd, qy, qx);
@@ -1786,8 +1792,11 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
                                           cost, mgm_vol, vol_bytes / 2, (unsigned)p1, (unsigned)p2)
           if (reg_fronts) { switch (pe) { case 1: VWGPU_MGM_U(1); break; case 2: VWGPU_MGM_U(2); break; default: VWGPU_MGM_U(4); break; } }
           else
-            hipLaunchKernelGGL(mgm_front_kernel, dim3(fw, per), dim3(64), lds, st, g, M, f, l8, lw, lh, min_col, min_row, bounds, starts, cost,
-                               mgm_vol, vol_bytes / 2, (unsigned)p1, (unsigned)p2);
+          {
+            const int wpw = 4 * lds <= 48 * 1024 ? 4 : 1;              // wavefronts (pixels) per workgroup
+            hipLaunchKernelGGL(mgm_front_kernel, dim3((fw + wpw - 1) / wpw, per), dim3(64 * wpw), lds * wpw, st, g, M, f, l8, lw, lh, min_col, min_row,
+                               bounds, starts, cost, mgm_vol, vol_bytes / 2, (unsigned)p1, (unsigned)p2);
+          }
 #undef VWGPU_MGM_U
         }
         hipLaunchKernelGGL(mgm_sum_kernel, dim3((unsigned)std::min<size_t>((words + 255) / 256, 8192)), dim3(256), 0, st, reinterpret_cast<uint4*>(accum),
