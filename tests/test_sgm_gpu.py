@@ -318,9 +318,11 @@ def test_pyramid_sgm_large_tile(vw, oracle):
 # that nothing pins: these tests show that the GPU fronts and the oracle's raster loops compute the same function.
 
 @pytest.mark.parametrize("cost,k,sx,sy,w,h", [(CENSUS, 5, 9, 0, 83, 60), (CENSUS, 3, 6, 4, 64, 48), (TERNARY, 7, 12, 2, 90, 41), (CENSUS, 9, 40, 0, 120, 33),
-                                              (CENSUS, 5, 129, 0, 200, 24), (CENSUS, 5, 3, 3, 12, 70), (CENSUS, 3, 2, 0, 3, 3), (CENSUS, 3, 2, 1, 40, 3)])
+                                              (CENSUS, 5, 129, 0, 200, 24), (CENSUS, 5, 3, 3, 12, 70), (CENSUS, 3, 2, 0, 3, 3), (CENSUS, 3, 2, 1, 40, 3),
+                                              (CENSUS, 5, 62, 60, 44, 30), (CENSUS, 3, 300, 0, 330, 12)])
 def test_mgm_identical_to_oracle(vw, oracle, cost, k, sx, sy, w, h):
-    """Every direction's front order (anti-diagonals, rows, columns), wide / tall / one-pixel outputs, 1-D and 2-D searches."""
+    """Every direction's front order (anti-diagonals, rows, columns), wide / tall / one-pixel outputs, 1-D and 2-D searches; 63 x 61 = 3843
+    disparities (one wavefront per workgroup, vectors longer than the prefetched 128 elements) and 301 on one row (4 pairs per lane)."""
     rng = np.random.default_rng(17 * sx + sy + k)
     left, right = _pair(rng, h, w, sx, sy, shift=(min(3, sx), min(2, sy)), smooth=(k == 5))
     gi, gs, oi, os_ = _both(vw, oracle, cost, left, right, (sx, sy), k, 5, mgm=True)
