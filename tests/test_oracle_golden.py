@@ -417,6 +417,18 @@ def test_sgm_constant_offset(oracle):
     assert (np.abs(sub[..., 0] - 6) < 1).all() and (np.abs(sub[..., 1] - 5) < 1).all()
 
 
+def test_mgm_constant_offset_on_the_reference_fixture(oracle):
+    """The same scene with use_mgm = true.  The reference never runs this branch in its tests (TestSGM.cxx:47 sets use_mgm = false), so
+    this is no golden vector — but its own image pair has one true answer, (2, 1) everywhere, and the restated accum_mgm_multithread must
+    find it as the plain eight-path accumulation does."""
+    left, right = _sgm_fixture()
+    res, sub = oracle.calc_disparity_sgm(oracle.CENSUS_TRANSFORM, left.astype(np.float32), right.astype(np.float32), (9, 9), 3,
+                                         subpixel=oracle.SUBPIXEL_LC_BLEND, search_buffer=(4, 4), memory_limit_mb=1024, use_mgm=True)
+    assert res.shape == (398, 398, 3)
+    assert ((res[..., 0] - 4 == 2) & (res[..., 1] - 4 == 1)).mean() > 0.99
+    assert (np.abs(sub[..., 0] - 6) < 1).all() and (np.abs(sub[..., 1] - 5) < 1).all()
+
+
 def test_sgm_parameters_and_errors(oracle):
     """set_parameters defaults (SGM.cc:105-160) and the NoImplErr cases of compute_disparity_costs (:1877-1890)."""
     table = {(3, 3): (3, 70), (3, 5): (15, 750), (3, 7): (30, 1500), (3, 9): (20, 1000),

@@ -43,11 +43,12 @@ def _both(vw, oracle, cost, left, right, search, k, sub, sb=(2, 2), mem=6000, lm
     return gi, gs, oi, os_
 
 
-def test_reference_fixture_constant_offset(vw, oracle):
-    """TestSGM.cxx:28-75 on the reference's own images."""
+@pytest.mark.parametrize("mgm", [False, True])
+def test_reference_fixture_constant_offset(vw, oracle, mgm):
+    """TestSGM.cxx:28-75 on the reference's own images (the reference's test runs use_mgm = false only)."""
     d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sgm_fixture.npz"))
     left, right = d["left"].astype(np.float32), d["right"].astype(np.float32)
-    gi, gs, oi, os_ = _both(vw, oracle, CENSUS, left, right, (9, 9), 3, 5, sb=(4, 4), mem=1024)
+    gi, gs, oi, os_ = _both(vw, oracle, CENSUS, left, right, (9, 9), 3, 5, sb=(4, 4), mem=1024, mgm=mgm)
     assert gi.shape == (398, 398, 3)
     assert ((gi[..., 0] - 4 == 2) & (gi[..., 1] - 4 == 1)).mean() > 0.99
     assert np.array_equal(gi, oi)
