@@ -375,6 +375,8 @@ def main():
                     help="config2 (default, the headline metric): 4096^2 7x7 SAD; config4: 16384^2 census SGM in 8 strips + collar")
     args = ap.parse_args()
 
+    # the host driver supports dmabuf IPC only: without this RCCL's peer mappings fail (hipIpcGetMemHandle: invalid argument)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import visionworkbench_amd as vwa
