@@ -91,8 +91,18 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *       the result is bit-exact for any input.  1 = pipelined callers that queue many calls without a host round trip: the
  *       call never waits — packed kernels first, the float64 kernel behind a device flag — and vwgpu_last_path() reports
  *       afterwards which family produced the result (bench.py asserts VWGPU_PATH_SAD_U8).
- *   VWGPU_OPT_DEVICE_COUNT (read only): HIP devices visible to the process. */
-typedef enum vwgpu_option { VWGPU_OPT_DEFER_EXACTNESS = 1, VWGPU_OPT_DEVICE_COUNT = 2 } vwgpu_option;
+ *   VWGPU_OPT_DEVICE_COUNT (read only): HIP devices visible to the process.
+ *   The remaining options never change a result (they choose between kernels / schedules that return identical bits, and are
+ *   what tests and tools use to reach every variant); values outside the stated range are rejected with VWGPU_ERR_ARGUMENT:
+ *   VWGPU_OPT_SAD_GROUPS       packed-u8 SAD matcher flavour: 0 = chosen by the launcher's cost model (default), 1 = one wave
+ *       group per tile, 2 = two wave groups per tile.
+ *   VWGPU_OPT_EXACT_SCRATCH_MB scratch budget of the exact-order path in MiB (16 .. 65536, default 4096): column-sum volumes
+ *       beyond it are swept in row bands / zone groups / disparity groups.
+ *   VWGPU_OPT_TRACE            bit 0: host-side timeline of a pyramid tile on stderr, bit 1: the zone shapes of a level. */
+typedef enum vwgpu_option {
+  VWGPU_OPT_DEFER_EXACTNESS = 1, VWGPU_OPT_DEVICE_COUNT = 2, VWGPU_OPT_SAD_GROUPS = 3, VWGPU_OPT_EXACT_SCRATCH_MB = 4,
+  VWGPU_OPT_TRACE = 5
+} vwgpu_option;
 int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value);
 int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value);
 

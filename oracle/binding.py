@@ -21,7 +21,7 @@ __all__ = ["build", "lib", "fast_box_sum", "cost_image", "calc_disparity", "calc
            "EDGE_CONSTANT", "EDGE_ZERO", "PREFILTER_NONE", "PREFILTER_MEANSUB", "PREFILTER_LOG",
            "subdivide_regions", "prefilter_region", "parabola_subpixel", "pyramid_correlate", "disparity_filter",
            "disparity_mask", "u8_convert", "census_transform", "hamming_distance", "SemiGlobalMatcher", "calc_disparity_sgm",
-           "pyramid_correlate_sgm", "blob_sizes", "disparity_blob_filter", "set_blob_filter_area", "cross_corr_consistency_check_diff", "set_lr_disp_diff", "CENSUS_TRANSFORM", "TERNARY_CENSUS_TRANSFORM", "SUBPIXEL_NONE", "SUBPIXEL_PARABOLA", "SUBPIXEL_LINEAR",
+           "pyramid_correlate_sgm", "set_sgm_host_threads", "blob_sizes", "disparity_blob_filter", "set_blob_filter_area", "cross_corr_consistency_check_diff", "set_lr_disp_diff", "CENSUS_TRANSFORM", "TERNARY_CENSUS_TRANSFORM", "SUBPIXEL_NONE", "SUBPIXEL_PARABOLA", "SUBPIXEL_LINEAR",
            "SUBPIXEL_POLY4", "SUBPIXEL_COSINE", "SUBPIXEL_LC_BLEND"]
 
 
@@ -406,6 +406,11 @@ def calc_disparity_sgm(cost_type, left, right, search_volume, kernel, subpixel=S
         raise ValueError("vwo_calc_disparity_sgm rc=%d" % rc)
     n = ow.value * oh.value * 3
     return (out.reshape(-1)[:n].reshape(oh.value, ow.value, 3).copy(), sub.reshape(-1)[:n].reshape(oh.value, ow.value, 3).copy())
+
+
+def set_sgm_host_threads(n):
+    """Host threads for the SGM oracle's path lines / cost rows (run time only; identical results)."""
+    lib().vwo_set_sgm_host_threads(int(n))
 
 
 def pyramid_correlate_sgm(left, right, left_mask, right_mask, search_region, kernel, cost_type, consistency_threshold=-1.0,

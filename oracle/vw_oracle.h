@@ -139,6 +139,9 @@ int vwo_pyramid_correlate_sgm(const float* left, int lw, int lh, const float* ri
 /* algorithm of the following vwo_pyramid_correlate_sgm calls of this thread: 1 = VW_CORRELATION_SGM (default), 2 = VW_CORRELATION_MGM,
  * 3 = VW_CORRELATION_FINAL_MGM (src/vw/Stereo/CorrelationView.cc:365-366) */
 void vwo_set_sgm_algorithm(int algorithm);
+/* Host threads the SGM oracle may use for the lines of a path direction and the rows of the cost fill (process wide; the
+ * results do not depend on it — the reference runs its PixelPassTasks on a pool as well, SGM.cc:2462-2612). */
+void vwo_set_sgm_host_threads(int n);
 
 /* disparity_blob_filter (CorrelationView.cc:242-271): zero every valid pixel of an 8-connected component of valid pixels
  * with at most `area` pixels; vwo_blob_sizes = the size of each pixel's component (0 for invalid pixels), the quantity

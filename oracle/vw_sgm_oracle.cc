@@ -23,15 +23,19 @@
 //                                       MultiAccumRowBuffer :236-543 (line buffers, added to the sums line by line);
 //                                       get_path_pixel_diff SGM.cc:2715-2721; small-buffer size for MGM :703-713
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "vw_oracle.h"
 
 namespace {
+
+int g_host_threads = 1;                  // vwo_set_sgm_host_threads: run-time only, results do not depend on it
 
 typedef uint8_t CostType;
 typedef uint16_t AccumCostType;
@@ -325,17 +329,17 @@ struct Matcher {
     census_image(L, kernel, tern, ternary_thr, lc, lw, lh);
     census_image(R, kernel, tern, ternary_thr, rc, rw, rh);
     const int hk = (kernel - 1) / 2;
-    size_t ci = 0;
-    for (int r = min_row; r <= max_row; ++r) {
-      const int br = r - hk;
+    for_lines(max_row - min_row + 1, [&](int ri, int) {
+      const int r = min_row + ri, br = r - hk;
       for (int c = min_col; c <= max_col; ++c) {
         const int bc = c - hk;
         Bounds const& b = bounds[(size_t)(r - min_row) * ocols + (c - min_col)];
+        size_t ci = starts[(size_t)(r - min_row) * ocols + (c - min_col)];
         for (int dy = b.v[1]; dy <= b.v[3]; ++dy)
           for (int dx = b.v[0]; dx <= b.v[2]; ++dx)
             cost[ci++] = (CostType)hamming(lc[(size_t)br * lw + bc], rc[(size_t)(br + dy) * rw + bc + dx]);
       }
-    }
+    });
   }
 
   static AccumCostType adds(AccumCostType a, AccumCostType b) { unsigned s = (unsigned)a + b; return s > 65535u ? 65535 : (AccumCostType)s; }
@@ -408,21 +412,33 @@ struct Matcher {
     }
   }
 
+  // The lines of ONE direction never share a pixel, so they may run on any number of host threads with identical results (the
+  // reference does the same with its PixelPassTask pool, SGM.cc:2462-2612); g_host_threads only shortens the oracle's run time.
+  template <class F> static void for_lines(int n, F&& body) {
+    const int T = std::max(1, std::min(g_host_threads, n));
+    if (T == 1) { for (int i = 0; i < n; ++i) body(i, 0); return; }
+    std::atomic<int> next(0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; ++t) pool.emplace_back([&, t]() { for (int i = next.fetch_add(16); i < n; i = next.fetch_add(16)) for (int j = i; j < std::min(n, i + 16); ++j) body(j, t); });
+    for (auto& th : pool) th.join();
+  }
   void accumulate(U8Img const& L) {                            // :2462-2612
-    std::vector<AccumCostType> line, full_prior(num_disp);
-    const int W = ocols, H = orows;
-    for (int i = 0; i < W; ++i) pass_line(L, i, 0, 0, 1, line, full_prior);           // B
-    for (int i = 0; i < W; ++i) pass_line(L, i, H - 1, 0, -1, line, full_prior);      // T
-    for (int i = 0; i < H; ++i) pass_line(L, 0, i, 1, 0, line, full_prior);           // R
-    for (int i = 0; i < H; ++i) pass_line(L, W - 1, i, -1, 0, line, full_prior);      // L
-    for (int i = 0; i < W; ++i) pass_line(L, i, 0, 1, 1, line, full_prior);           // BR
-    for (int i = 1; i < H; ++i) pass_line(L, 0, i, 1, 1, line, full_prior);
-    for (int i = 0; i < W; ++i) pass_line(L, i, 0, -1, 1, line, full_prior);          // BL
-    for (int i = 1; i < H; ++i) pass_line(L, W - 1, i, -1, 1, line, full_prior);
-    for (int i = 0; i < W; ++i) pass_line(L, i, H - 1, 1, -1, line, full_prior);      // TR
-    for (int i = 0; i < H - 1; ++i) pass_line(L, 0, i, 1, -1, line, full_prior);
-    for (int i = 0; i < W; ++i) pass_line(L, i, H - 1, -1, -1, line, full_prior);     // TL
-    for (int i = 0; i < H - 1; ++i) pass_line(L, W - 1, i, -1, -1, line, full_prior);
+    const int W = ocols, H = orows, T = std::max(1, g_host_threads);
+    std::vector<std::vector<AccumCostType>> line(T), full_prior(T, std::vector<AccumCostType>(num_disp));
+#define VWO_LINES(n, c0, r0, dc, dr) for_lines((n), [&](int i, int t) { (void)i; pass_line(L, (c0), (r0), (dc), (dr), line[t], full_prior[t]); })
+    VWO_LINES(W, i, 0, 0, 1);                 // B
+    VWO_LINES(W, i, H - 1, 0, -1);            // T
+    VWO_LINES(H, 0, i, 1, 0);                 // R
+    VWO_LINES(H, W - 1, i, -1, 0);            // L
+    VWO_LINES(W, i, 0, 1, 1);                 // BR
+    VWO_LINES(H - 1, 0, i + 1, 1, 1);
+    VWO_LINES(W, i, 0, -1, 1);                // BL
+    VWO_LINES(H - 1, W - 1, i + 1, -1, 1);
+    VWO_LINES(W, i, H - 1, 1, -1);            // TR
+    VWO_LINES(H - 1, 0, i, 1, -1);
+    VWO_LINES(W, i, H - 1, -1, -1);           // TL
+    VWO_LINES(H - 1, W - 1, i, -1, -1);
+#undef VWO_LINES
   }
 
 
@@ -700,6 +716,7 @@ vwo_sgm* vwo_sgm_create(int cost_type, int use_mgm, int min_dx, int min_dy, int 
   return s;
 }
 void vwo_sgm_destroy(vwo_sgm* s) { delete s; }
+void vwo_set_sgm_host_threads(int n) { g_host_threads = n > 0 ? n : 1; }
 
 int vwo_sgm_output_size(vwo_sgm* s, int* ow, int* oh) { *ow = s->m.ocols; *oh = s->m.orows; return 0; }
 

@@ -27,15 +27,21 @@ def ctx(torch_cuda):
     c.close()
 
 
+@pytest.fixture(autouse=True)
+def _default_options(ctx):
+    """Variant-pinning options (same results, other kernels / schedules) never leak from one test into the next."""
+    yield
+    ctx.set_option(core.OPT_SAD_GROUPS, 0)
+    ctx.set_option(core.OPT_EXACT_SCRATCH_MB, 4096)
+
+
 @pytest.fixture(params=["auto", "one-group"])
-def sad_variant(request, monkeypatch):
+def sad_variant(request, ctx):
     """Small images run the packed-u8 matcher with two wave groups per tile (the launcher's choice for grids that do not
-    fill the chip); VWGPU_SAD_SPLIT=0 forces the one-group kernel the full-size case uses, so both see every case."""
-    if request.param == "one-group":
-        monkeypatch.setenv("VWGPU_SAD_SPLIT", "0")
-    else:
-        monkeypatch.delenv("VWGPU_SAD_SPLIT", raising=False)
-    return request.param
+    fill the chip); OPT_SAD_GROUPS = 1 pins the one-group kernel the full-size case uses, so both see every case."""
+    ctx.set_option(core.OPT_SAD_GROUPS, 1 if request.param == "one-group" else 0)
+    yield request.param
+    ctx.set_option(core.OPT_SAD_GROUPS, 0)
 
 
 def _gpu(ctx, cost, left, right, kernel, search, path=core.PATH_NONE, device=True):
@@ -279,14 +285,11 @@ def test_full_size_config2_sampled_parity(ctx, oracle):
 @pytest.mark.parametrize("rows,variant", [(1028, None), (517, None), (1028, "0"), (2051, "1")])
 def test_row_strip_sizes_sampled_parity(ctx, oracle, monkeypatch, rows, variant):
     """The strips a 4096^2 pair is cut into on 4 and 8 GPUs (and the tile-height / wave-group variants the launcher picks
-    for them: 16-row two-group tiles for 1/4, 8-row two-group tiles for 1/8; the env pins the other flavour): full-width
+    for them: 16-row two-group tiles for 1/4, 8-row two-group tiles for 1/8; OPT_SAD_GROUPS pins the other flavour): full-width
     strip on the GPU, the oracle on sampled padded crops, bit for bit."""
     import torch
     from visionworkbench_amd import stereo
-    if variant is None:
-        monkeypatch.delenv("VWGPU_SAD_SPLIT", raising=False)
-    else:
-        monkeypatch.setenv("VWGPU_SAD_SPLIT", variant)
+    ctx.set_option(core.OPT_SAD_GROUPS, {None: 0, "0": 1, "1": 2}[variant])
     W = 4096
     left, right, _ = synth.stereo_pair(W, rows, 129, 1)
     lt, rt = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()

@@ -4,7 +4,7 @@
   config 3  4096^2, 11x11 NCC + parabola      the whole 4086^2 integer image bit for bit, then the whole sub-pixel image
   config 4  16384-wide census-SGM strips      SGM is global along every scan line (no crop reproduces a strip), so the
                                               oracle runs strips it can finish in seconds — 16384 columns x 129
-                                              disparities, the kernel and row length of the config — and a 2048-wide,
+                                              disparities, the kernel and row length of the config: 32 and 512 rows — and a 2048-wide,
                                               256-row strip; the full 16384 x 2048 strip is checked against ground truth
   config 5  1024^2 tiles of a 32768-wide pair pyramid_correlate BM-NCC (5 levels, L/R check, filters) and SGM + sub-pixel
 The oracle legs run on the host cores of the GPU box (tile threads as the reference runs them)."""
@@ -71,9 +71,11 @@ def test_config3_ncc_then_parabola_full_image(ctx, oracle, pair4096):
     assert np.array_equal(sub, ref), float(np.abs(sub - ref).max())       # integer imagery: every sum is exact
 
 
-@pytest.mark.parametrize("w,rows", [(16384, 38), (2048, 262)])
+@pytest.mark.parametrize("w,rows", [(16384, 38), (2048, 262), (16384, 518)])
 def test_config4_sgm_strips_identical(oracle, w, rows):
-    """census 7x7, 129 disparities, 8 paths, LC-blend sub-pixel on strips as wide as config 4's rows."""
+    """census 7x7, 129 disparities, 8 paths, LC-blend sub-pixel on strips as wide as config 4's rows; the 512-row one is a
+    quarter of a GPU's share of the config, with the oracle's path lines on all host threads (8.4 M pixels x 129 disparities)."""
+    oracle.set_sgm_host_threads(NCPU)
     left, right, truth = synth.stereo_pair(w, rows, 129, 1)
     gi, gs = stereo.calc_disparity_sgm(3, left, right, BBox2i(0, 0, w, rows), (128, 0), (7, 7), with_subpixel=True)
     oi, os_ = oracle.calc_disparity_sgm(3, left, right, (128, 0), 7)

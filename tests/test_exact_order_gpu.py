@@ -22,6 +22,14 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(autouse=True)
+def _default_options(ctx):
+    """Variant-pinning options (same results, other kernels / schedules) never leak from one test into the next."""
+    yield
+    ctx.set_option(core.OPT_SAD_GROUPS, 0)
+    ctx.set_option(core.OPT_EXACT_SCRATCH_MB, 4096)
+
+
 def wide_range(rng, h, w, decades=14, signed=True):
     """float32 texture whose magnitudes span `decades` powers of ten: box sums of such data round all the time."""
     v = rng.random((h, w)) * 10.0 ** (rng.random((h, w)) * decades - decades / 2)
@@ -58,7 +66,7 @@ def test_fast_box_sum_golden_and_order(ctx, oracle):
 
 
 def test_fast_box_sum_row_bands(ctx, oracle, monkeypatch):
-    monkeypatch.setenv("VWGPU_EXACT_SCRATCH_MB", "16")      # 16 MB of column sums = bands of ~1000 rows at 2048 columns
+    ctx.set_option(core.OPT_EXACT_SCRATCH_MB, 16)      # 16 MB of column sums = bands of ~1000 rows at 2048 columns
     rng = np.random.default_rng(6)
     img = wide_range(rng, 2300, 2048, decades=10)
     got = stereo.fast_box_sum(img, (7, 7), ctx=ctx)
@@ -136,8 +144,76 @@ def test_nan_and_inf_costs_follow_the_compare_chain(ctx, oracle, cost):
     assert np.array_equal(got, want), int((got != want).any(-1).sum())
 
 
+@pytest.mark.parametrize("cost", [ABS, SQ, NCC])
+@pytest.mark.parametrize("h,w,kernel,search,shift,log", [
+    (70, 90, (7, 7), (129, 5), (64, 2), False),     # 645 disparities: two groups (512 + 133); 27 MB of column sums per group
+    (20, 48, (7, 7), (300, 5), (150, 3), False),    # 1500 disparities: three groups
+    (16, 40, (5, 5), (513, 1), (200, 0), False),    # a last group of ONE disparity
+    (26, 64, (7, 7), (129, 5), (64, 2), True),      # LoG-filtered imagery (values next to zero), the verdict's example
+    (22, 50, (9, 9), (300, 5), (100, 1), True),
+])
+def test_search_volumes_beyond_512_disparities(ctx, oracle, cost, h, w, kernel, search, shift, log):
+    """best_of_search_convolution loops over ANY search volume (Correlation.cc:64-66): zones of more than 512 disparities are swept
+    in disparity groups with the compare-chain state carried between them — still the reference's order, never the tile-local sums."""
+    from visionworkbench_amd import filters
+    rng = np.random.default_rng(h * 31 + w + cost)
+    if log:
+        left = np.floor(rng.random((h, w)) * 256).astype(np.float32)
+        right = np.floor(rng.random((h + search[1] - 1, w + search[0] - 1)) * 256).astype(np.float32)
+        right[shift[1]:shift[1] + h, shift[0]:shift[0] + w] = left
+        left = filters.prefilter_image(left, 1, 1.4, ctx=ctx)           # LaplacianOfGaussian(1.4), PreFilter.h:76-95
+        right = filters.prefilter_image(right, 1, 1.4, ctx=ctx)
+    else:
+        left, right = _pair(rng, h, w, search[0], search[1], shift, decades=14)
+    want = oracle.calc_disparity(cost, left, right, kernel, search)
+    got = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), search, kernel, ctx=ctx)
+    assert ctx.last_path() == core.PATH_EXACT_ORDER
+    assert np.array_equal(got, want), int((got != want).any(-1).sum())
+    ctx.set_option(core.OPT_EXACT_SCRATCH_MB, 16)                       # row bands inside every disparity group
+    got = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), search, kernel, ctx=ctx)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("cost", [ABS, SQ, NCC])
+def test_nan_costs_across_disparity_groups(ctx, oracle, cost):
+    """The chain state handed from group to group can hold a NaN `worst` (or a NaN `best` when disparity 0 is NaN): the
+    next group replays the chain from that state (Correlation.cc:91-117)."""
+    rng = np.random.default_rng(500 + cost)
+    h, w, search = 18, 44, (260, 3)
+    left = (rng.random((h, w)) * 10.0 ** (rng.random((h, w)) * 8 - 4)).astype(np.float32)
+    right = (rng.random((h + 2, w + 259)) * 10.0 ** (rng.random((h + 2, w + 259)) * 8 - 4)).astype(np.float32)
+    right[1:1 + h, 100:100 + w] = left
+    right[0, 3] = np.nan            # NaN cost at the very first disparities of a few pixels (best = NaN forever)
+    right[8, 130] = np.nan          # NaN costs in the first group only
+    right[12, 290] = np.nan         # NaN costs that straddle the group boundary (index 512 = (dx 252, dy 1))
+    right[17, 200] = np.inf
+    left[5, 30] = np.nan            # a pixel window with NaN at every disparity
+    want = oracle.calc_disparity(cost, left, right, (7, 7), search)
+    got = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), search, (7, 7), ctx=ctx)
+    assert ctx.last_path() == core.PATH_EXACT_ORDER
+    assert np.array_equal(got, want), int((got != want).any(-1).sum())
+
+
+def test_search_volume_beyond_65535(ctx, oracle):
+    """The 16-bit index fields belong to the packed kernels only; the float64 and exact-order paths index with ints."""
+    rng = np.random.default_rng(65536)
+    h, w, search = 9, 12, (300, 220)                # 66 000 disparities
+    left = np.floor(rng.random((h, w)) * 256).astype(np.float32)
+    right = np.floor(rng.random((h + 219, w + 299)) * 256).astype(np.float32)
+    right[201:201 + h, 280:280 + w] = left
+    want = oracle.calc_disparity(ABS, left, right, (3, 3), search)
+    got = stereo.calc_disparity(ABS, left, right, vwa.bounding_box(left), search, (3, 3), ctx=ctx)
+    assert np.array_equal(got, want)
+    assert np.all(got[..., 0] == 280) and np.all(got[..., 1] == 201)
+    left2, right2 = left + np.float32(0.1), right + np.float32(0.1)      # not order free: disparity groups
+    want = oracle.calc_disparity(SQ, left2, right2, (3, 3), search)
+    got = stereo.calc_disparity(SQ, left2, right2, vwa.bounding_box(left2), search, (3, 3), ctx=ctx)
+    assert ctx.last_path() == core.PATH_EXACT_ORDER
+    assert np.array_equal(got, want)
+
+
 def test_whole_raster_in_row_bands(ctx, oracle, monkeypatch):
-    monkeypatch.setenv("VWGPU_EXACT_SCRATCH_MB", "16")
+    ctx.set_option(core.OPT_EXACT_SCRATCH_MB, 16)
     rng = np.random.default_rng(9)
     left, right = _pair(rng, 300, 500, 33, 1, (16, 0), decades=12)
     want = oracle.calc_disparity(SQ, left, right, (7, 7), (33, 1))

@@ -26,12 +26,20 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(autouse=True)
+def _default_options(ctx):
+    """Variant-pinning options (same results, other kernels / schedules) never leak from one test into the next."""
+    yield
+    ctx.set_option(core.OPT_SAD_GROUPS, 0)
+    ctx.set_option(core.OPT_EXACT_SCRATCH_MB, 4096)
+
+
 @pytest.mark.parametrize("cost,n,seed", [(0, 120, 101), (1, 60, 102), (2, 60, 103)])
 def test_fuzz_fast_paths_equal_generic(ctx, monkeypatch, cost, n, seed):
     import torch
     bad = []
     for c in fuzz_cases.bm_cases(n, seed, cost):
-        monkeypatch.setenv("VWGPU_SAD_SPLIT", c["split"])
+        ctx.set_option(core.OPT_SAD_GROUPS, 1 + int(c["split"]))
         lt, rt = torch.from_numpy(c["left"]).cuda(), torch.from_numpy(c["right"]).cuda()
         ctx.force_path(core.PATH_NONE)
         a = stereo.calc_disparity(cost, lt, rt, vwa.bounding_box(c["left"]), c["search"], c["kernel"], ctx=ctx).cpu().numpy()

@@ -16,7 +16,7 @@ COST = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ctx = vwa.Context(0)
 bad = 0
 for c in fuzz_cases.bm_cases(N, SEED, COST):
-    os.environ["VWGPU_SAD_SPLIT"] = c["split"]
+    ctx.set_option(core.OPT_SAD_GROUPS, 1 + int(c["split"]))
     lt, rt = torch.from_numpy(c["left"]).cuda(), torch.from_numpy(c["right"]).cuda()
     ctx.force_path(core.PATH_NONE)
     a = stereo.calc_disparity(COST, lt, rt, vwa.bounding_box(c["left"]), c["search"], c["kernel"], ctx=ctx).cpu().numpy()

@@ -1,5 +1,4 @@
-"""SSD / NCC matchers at 4096^2 x 129 disparities: register-blocked kernel (bm_corr_u8) vs the lane-per-column one (bm_dot_u8,
-VWGPU_NO_CORR_U8=1), per-kernel times from HIP events.  GPU box only."""
+"""SSD / NCC matchers at 4096^2 x 129 disparities: register-blocked kernel (bm_corr_u8), per-kernel times from HIP events.  GPU box only."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -11,9 +10,7 @@ Lg, Rg = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
 box = BBox2i(0, 0, W, W)
 ctx = core.default_context(0)
 ctx.set_option(core.OPT_DEFER_EXACTNESS, 1)
-for env in ("", "1"):
-    if env: os.environ["VWGPU_NO_CORR_U8"] = env
-    else: os.environ.pop("VWGPU_NO_CORR_U8", None)
+for env in ("",):
     for cost, k in [(1, 7), (2, 7), (1, 11), (2, 11), (2, 5)]:
         fn = lambda: stereo.calc_disparity(cost, Lg, Rg, box, (129, 1), (k, k), ctx=ctx)
         a = fn(); torch.cuda.synchronize()

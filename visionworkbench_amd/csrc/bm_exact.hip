@@ -36,6 +36,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "vwgpu_internal.h"
@@ -51,11 +52,17 @@ struct XZone {
   int zw, zh;                       // output size; crop = (zw + kx - 1) x (zh + ky - 1)
   int sx, sy;
   int out_off, out_stride, addx, addy;
+  int d0, dn;                       // this pass serves the disparities [d0, d0 + dn) of the zone's sx * sy (dn <= 512; D = dn below)
+  int carry_mode;                   // bit 0: continue the compare chain from the zone's carry records, bit 1: leave it there (more groups follow)
+  long long carry;                  // offset (records) of the zone's carry records, one per output pixel
   int lanes_log2;                   // lanes per unit = 1 << lanes_log2  (>= min(D, 64), power of two)
   int nchunk;                       // ceil(D / 64)
   long long vol;                    // offset (doubles) of the column-sum volume [rows][cw][dp]
   long long lprec, rprec;           // NCC: offsets (doubles) of the zone's precision images; box modes: lprec = output offset
 };
+
+// State of the reference's compare chain (Correlation.cc:91-117) after the disparities of the groups served so far.
+struct XCarry { double best, worst; int idx, pad; };
 
 template <int COST>
 __device__ __forceinline__ double xelem(float a, float b) {
@@ -86,10 +93,10 @@ bmx_col_kernel(const float* __restrict__ A, int aw, int ah, ptrdiff_t as, const 
   const int lanes = 1 << z.lanes_log2;
   const int col = it.y + ((int)threadIdx.x >> z.lanes_log2);
   const int d = it.z * 64 + ((int)threadIdx.x & (lanes - 1));
-  const int D = z.sx * z.sy;
+  const int D = z.dn;
   if (col >= cw || d >= D) return;
   const int dp = z.nchunk == 1 ? lanes : z.nchunk * 64;
-  const int dy = BOX ? 0 : d / z.sx, dx = BOX ? 0 : d - dy * z.sx;
+  const int dy = BOX ? 0 : (z.d0 + d) / z.sx, dx = BOX ? 0 : (z.d0 + d) - dy * z.sx;
   const float* ac = A + xclamp(z.ax + col, aw);
   const float* bc = BOX ? nullptr : B + xclamp(z.bx + col + dx, bw);
   auto elem = [&](int y) __attribute__((always_inline)) -> double {
@@ -141,10 +148,13 @@ __device__ __forceinline__ double dpp_f64(double v) {
 // ---- pass 2: row chains + winner -----------------------------------------------------------------------------------
 // items[i] = {zone, first row}; one wave per item, 64 / lanes rows per wave.  NCH = 64-disparity chunks a lane can hold
 // (instantiated for 1, 3 and XMAX_CHUNKS; the launcher picks by the largest zone).
-template <int COST, int NCH>
+// CARRY: the zone has more than 512 disparities and is served in disparity groups, one launch pair per group: the chain state of
+// every pixel is read from / left in XCarry records between the groups (Correlation.cc:64-119 loops over any search volume).
+template <int COST, int NCH, bool CARRY = false>
 __global__ void __launch_bounds__(256)
 bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__ items, const double* __restrict__ vol,
-               int y_begin, int y_end, const double* __restrict__ prec, int32_t* __restrict__ out, double* __restrict__ outd) {
+               int y_begin, int y_end, const double* __restrict__ prec, int32_t* __restrict__ out, double* __restrict__ outd,
+               XCarry* __restrict__ carry = nullptr) {
   constexpr bool BOX = (COST == XCOST_BOX || COST == XCOST_PREC);
   constexpr bool NCC = (COST == VWGPU_CROSS_CORRELATION);
   __shared__ double park[4][NCH][64];           // costs of a NaN pixel, for the verbatim replay
@@ -158,7 +168,7 @@ bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__
   const int y = it.y + g;
   const int ylim = y_end < z.zh ? y_end : z.zh;
   const bool row_ok = y < ylim;
-  const int D = z.sx * z.sy;
+  const int D = z.dn;
   const int dp = z.nchunk == 1 ? lanes : z.nchunk * 64;
   const int nch = z.nchunk;
   const double* base = vol + z.vol + (size_t)(row_ok ? y - y_begin : 0) * cw * dp;
@@ -177,7 +187,7 @@ bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__
     if (act[k]) {
       for (int i = 0; i < kx; ++i) r[k] += base[(size_t)i * dp + dk[k]];       // Algorithms.h:84: accumulate from 0
       if (NCC) {
-        const int dy = dk[k] / z.sx, dx = dk[k] - dy * z.sx;
+        const int dy = (z.d0 + dk[k]) / z.sx, dx = (z.d0 + dk[k]) - dy * z.sx;
         rp[k] = prec + z.rprec + (size_t)(y + dy) * rpw + dx;
       }
     }
@@ -298,6 +308,18 @@ bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__
 #pragma unroll
     for (int k = 0; k < NCH; ++k) crp[k] = nrp[k];
     clp = nlp;
+    // Disparity groups: the chain continues from the state the earlier groups left.  Without NaNs it is a (value, index) minimum
+    // and a maximum, so the states merge (an earlier group wins ties: its indices are smaller); with a NaN in this group's costs
+    // or in the carried state the chain is order dependent and is replayed verbatim from the carried state.
+    XCarry cin{0.0, 0.0, 0, 0};
+    bool cont = false;                                  // this pixel's chain has a carried state
+    if (CARRY) {
+      cont = (z.carry_mode & 1) != 0;
+      if (cont && row_ok) {
+        cin = carry[z.carry + (size_t)y * z.zw + x];
+        if (cin.best != cin.best || cin.worst != cin.worst) nanw = 1;
+      }
+    }
     if (__any(nanw)) {                                  // wave-uniform: some pixel of this step has a NaN cost
 #pragma unroll
       for (int k = 0; k < NCH; ++k)
@@ -305,15 +327,15 @@ bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       if (nanw && dl == 0 && row_ok) {                  // Correlation.cc:91-117, verbatim
-        double b2 = 0.0, w2 = 0.0;
-        int i2 = 0;
+        double b2 = cin.best, w2 = cin.worst;
+        int i2 = cin.idx;
         for (int d = 0; d < D; ++d) {
           const double v = nch == 1 ? park[wave][0][g * lanes + d] : park[wave][d >> 6][d & 63];
-          if (d == 0) { b2 = w2 = v; }
-          else if (xbetter<COST>(v, b2)) { b2 = v; i2 = d; }
+          if (d == 0 && !cont) { b2 = w2 = v; i2 = 0; }
+          else if (xbetter<COST>(v, b2)) { b2 = v; i2 = (CARRY ? z.d0 : 0) + d; }
           else if (!xbetter<COST>(v, w2)) { w2 = v; }
         }
-        best = b2; worst = w2; bd = i2;
+        best = b2; worst = w2; bd = i2 - (CARRY ? z.d0 : 0);
       }
       __builtin_amdgcn_wave_barrier();
       if (lanes > 1) {                                  // hand the replayed result to the lane that buffers this step
@@ -322,6 +344,23 @@ bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__
         const int d3 = __shfl(bd, src);
         if (nanw) { best = b3; worst = w3; bd = d3; }
       }
+    }
+    if (CARRY) {
+      int gd = z.d0 + bd;                               // index in the zone's whole search volume
+      if (cont && !nanw) {
+        if (!xbetter<COST>(best, cin.best)) { best = cin.best; gd = cin.idx; }
+        if (xbetter<COST>(worst, cin.worst)) worst = cin.worst;
+      }
+      if (row_ok && dl == 0) {
+        if (z.carry_mode & 2) {
+          carry[z.carry + (size_t)y * z.zw + x] = XCarry{best, worst, gd, 0};
+        } else {
+          const int dy = gd / z.sx, dx = gd - dy * z.sx;
+          int32_t* o = out + ((size_t)z.out_off + (size_t)y * z.out_stride + x) * 3;
+          o[0] = dx + z.addx; o[1] = dy + z.addy; o[2] = (best == worst) ? 0 : 0x7fffffff;
+        }
+      }
+      continue;
     }
     const int slot = x & (lanes - 1);
     if (dl == slot) { res_d = bd; res_v = (best == worst) ? 0 : 0x7fffffff; }   // Correlation.cc:121-133
@@ -404,11 +443,7 @@ int lanes_log2_for(int D) {
   return l;
 }
 
-size_t exact_scratch_budget() {
-  const char* e = getenv("VWGPU_EXACT_SCRATCH_MB");
-  const long mb = e ? atol(e) : 4096;
-  return (size_t)(mb < 16 ? 16 : mb) << 20;
-}
+size_t exact_scratch_budget(const vwgpu_ctx* ctx) { return (size_t)ctx->exact_scratch_mb << 20; }     // VWGPU_OPT_EXACT_SCRATCH_MB
 
 struct Tables {
   std::vector<XZone> zones;
@@ -419,7 +454,9 @@ struct Tables {
 
 // appends one zone; rows = the number of volume rows to reserve for it
 void add_zone(Tables& t, XZone z, int kx, int rows, bool box) {
-  const int D = box ? 1 : z.sx * z.sy;
+  if (box) { z.d0 = 0; z.dn = 1; }
+  else if (z.dn == 0) { z.d0 = 0; z.dn = z.sx * z.sy; }
+  const int D = z.dn;
   z.lanes_log2 = lanes_log2_for(D);
   z.nchunk = (D + 63) / 64;
   const int lanes = 1 << z.lanes_log2;
@@ -455,12 +492,23 @@ int upload(vwgpu_ctx* ctx, const Tables& t, char*& cursor, char* end, DevTables*
   const size_t zb = vwgpu_align_up(t.zones.size() * sizeof(XZone), 256), cb = vwgpu_align_up(t.col_items.size() * sizeof(int4), 256),
                rb = vwgpu_align_up(t.row_items.size() * sizeof(int2), 256);
   if (cursor + zb + cb + rb > end) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "bm_exact: table arena too small");
-  VWGPU_HIP(ctx, hipMemcpyAsync(cursor, t.zones.data(), t.zones.size() * sizeof(XZone), hipMemcpyHostToDevice, ctx->stream));
-  d->zones = reinterpret_cast<const XZone*>(cursor); cursor += zb;
-  VWGPU_HIP(ctx, hipMemcpyAsync(cursor, t.col_items.data(), t.col_items.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-  d->col = reinterpret_cast<const int4*>(cursor); cursor += cb;
-  VWGPU_HIP(ctx, hipMemcpyAsync(cursor, t.row_items.data(), t.row_items.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
-  d->row = reinterpret_cast<const int2*>(cursor); cursor += rb;
+  // The host vectors are rebuilt for the next band / go out of scope while the stream still runs: the tables cross PCIe from a
+  // piece of the pinned ring (one asynchronous copy); tables too large for the ring are copied from the vectors and waited for.
+  if (char* h = static_cast<char*>(vwgpu_host_ring(ctx, zb + cb + rb))) {
+    memcpy(h, t.zones.data(), t.zones.size() * sizeof(XZone));
+    memcpy(h + zb, t.col_items.data(), t.col_items.size() * sizeof(int4));
+    memcpy(h + zb + cb, t.row_items.data(), t.row_items.size() * sizeof(int2));
+    VWGPU_HIP(ctx, hipMemcpyAsync(cursor, h, zb + cb + rb, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    VWGPU_HIP(ctx, hipMemcpyAsync(cursor, t.zones.data(), t.zones.size() * sizeof(XZone), hipMemcpyHostToDevice, ctx->stream));
+    VWGPU_HIP(ctx, hipMemcpyAsync(cursor + zb, t.col_items.data(), t.col_items.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+    VWGPU_HIP(ctx, hipMemcpyAsync(cursor + zb + cb, t.row_items.data(), t.row_items.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  d->zones = reinterpret_cast<const XZone*>(cursor);
+  d->col = reinterpret_cast<const int4*>(cursor + zb);
+  d->row = reinterpret_cast<const int2*>(cursor + zb + cb);
+  cursor += zb + cb + rb;
   return VWGPU_OK;
 }
 
@@ -472,7 +520,7 @@ size_t table_bytes(const Tables& t) {
 template <int COST>
 void launch_pair(vwgpu_ctx* ctx, const char* n1, const char* n2, const float* A, int aw, int ah, ptrdiff_t as,
                  const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky, const Tables& t, const DevTables& d, double* vol,
-                 int y_begin, int y_end, double* state, const double* prec, int32_t* out, double* outd) {
+                 int y_begin, int y_end, double* state, const double* prec, int32_t* out, double* outd, XCarry* carry = nullptr) {
   if (!t.col_items.empty()) {
     vwgpu_prof_scope ps(ctx, n1);
     hipLaunchKernelGGL((bmx_col_kernel<COST>), dim3((unsigned)t.col_items.size()), dim3(256), 0, ctx->stream,
@@ -485,7 +533,9 @@ void launch_pair(vwgpu_ctx* ctx, const char* n1, const char* n2, const float* A,
     int nch = 1;
     for (const XZone& z : t.zones) nch = std::max(nch, z.nchunk);
     const dim3 grd((unsigned)(t.row_items.size() / 4)), blk(256);
-    if (nch == 1)
+    if (carry)
+      hipLaunchKernelGGL((bmx_row_kernel<COST, XMAX_CHUNKS, true>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd, carry);
+    else if (nch == 1)
       hipLaunchKernelGGL((bmx_row_kernel<COST, 1>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd);
     else if (nch <= 3)
       hipLaunchKernelGGL((bmx_row_kernel<COST, 3>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd);
@@ -496,7 +546,8 @@ void launch_pair(vwgpu_ctx* ctx, const char* n1, const char* n2, const float* A,
 
 }  // namespace
 
-bool vwgpu_bm_exact_supported(int sx, int sy) { return (long long)sx * sy <= 64LL * XMAX_CHUNKS; }
+// Any search volume: zones of more than 512 disparities are swept in disparity groups with the compare-chain state carried in HBM.
+bool vwgpu_bm_exact_supported(int sx, int sy) { return sx > 0 && sy > 0 && (long long)sx * sy <= INT_MAX; }
 
 // The order-freeness test.  Every pixel of both images is an integer multiple of g = 2^lo and smaller than 2^(hi+1); then
 // every cost element is a multiple of g (SAD) or g^2 (SSD / NCC: the float product rounds to a coarser multiple) and
@@ -557,9 +608,11 @@ int vwgpu_float_grain(vwgpu_ctx* ctx, const float* a, int aw, int ah, ptrdiff_t 
 }
 
 // One group of zones (its column-sum volumes fit the scratch budget, or it is a single zone swept in row bands).
+// dgroup != nullptr: the single zone is served for the disparities [d0, d0 + dn) only, chain state in `carry` (see XCarry).
+struct DGroup { int d0, dn, carry_mode; XCarry* carry; };
 static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, ptrdiff_t as,
                      const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky,
-                     const vwgpu_zone_task* zones, int n, int32_t* out) {
+                     const vwgpu_zone_task* zones, int n, int32_t* out, const DGroup* dgroup = nullptr) {
   const bool ncc = cost_type == VWGPU_CROSS_CORRELATION;
   Tables match, boxa, boxb;
   size_t prec_doubles = 0;
@@ -568,6 +621,7 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
     XZone z{};
     z.ax = s.ax; z.ay = s.ay; z.bx = s.bx; z.by = s.by; z.zw = s.zw; z.zh = s.zh; z.sx = s.sx; z.sy = s.sy;
     z.out_off = s.out_off; z.out_stride = s.out_stride; z.addx = s.addx; z.addy = s.addy;
+    if (dgroup) { z.d0 = dgroup->d0; z.dn = dgroup->dn; z.carry_mode = dgroup->carry_mode; z.carry = 0; }
     if (ncc) {
       // NCCCost ctor over the zone's own crops (CostFunctions.h:214-219): box sums restart at the crop origin
       z.lprec = (long long)prec_doubles; prec_doubles += (size_t)s.zw * s.zh;
@@ -582,7 +636,7 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
   if (match.zones.empty()) return VWGPU_OK;
 
   // band mode: a single zone whose volume exceeds the budget is swept in row bands
-  const size_t budget = exact_scratch_budget();
+  const size_t budget = exact_scratch_budget(ctx);
   int band = INT_MAX;
   size_t state_doubles = 0;
   if (match.vol_doubles * 8 > budget && match.zones.size() == 1) {
@@ -625,11 +679,11 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
     if ((rc = upload(ctx, match, cur, end, &d))) return rc;
     switch (cost_type) {
       case VWGPU_CROSS_CORRELATION:
-        launch_pair<VWGPU_CROSS_CORRELATION>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr); break;
+        launch_pair<VWGPU_CROSS_CORRELATION>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr, dgroup ? dgroup->carry : nullptr); break;
       case VWGPU_SQUARED_DIFFERENCE:
-        launch_pair<VWGPU_SQUARED_DIFFERENCE>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr); break;
+        launch_pair<VWGPU_SQUARED_DIFFERENCE>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr, dgroup ? dgroup->carry : nullptr); break;
       default:
-        launch_pair<VWGPU_ABSOLUTE_DIFFERENCE>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr); break;
+        launch_pair<VWGPU_ABSOLUTE_DIFFERENCE>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr, dgroup ? dgroup->carry : nullptr); break;
     }
   }
   VWGPU_HIP(ctx, hipGetLastError());
@@ -637,18 +691,35 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
 }
 
 // All zones in the reference's summation order.  A / B dense or strided images (clamped reads).  Zones are processed in
-// groups whose column-sum volumes fit the scratch budget (VWGPU_EXACT_SCRATCH_MB, default 4096).
+// groups whose column-sum volumes fit the scratch budget (VWGPU_OPT_EXACT_SCRATCH_MB, default 4096).
 int vwgpu_launch_bm_exact(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, ptrdiff_t as,
                           const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky,
                           const vwgpu_zone_task* zones, int n, int32_t* out) {
-  const size_t budget = exact_scratch_budget();
+  const size_t budget = exact_scratch_budget(ctx);
   std::vector<vwgpu_zone_task> group;
   size_t bytes = 0;
   for (int i = 0; i < n; ++i) {
     const vwgpu_zone_task& s = zones[i];
     if (s.zw <= 0 || s.zh <= 0 || s.sx <= 0 || s.sy <= 0) continue;
     if (!vwgpu_bm_exact_supported(s.sx, s.sy))
-      return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "bm_exact: %d x %d disparities exceed %d per zone", s.sx, s.sy, 64 * XMAX_CHUNKS);
+      return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "bm_exact: %d x %d disparities exceed the index range", s.sx, s.sy);
+    if ((long long)s.sx * s.sy > 64LL * XMAX_CHUNKS) {
+      // more disparities than a lane can hold: groups of 512 in index order, one launch pair each, compare-chain state in HBM
+      if (!group.empty()) {
+        int rc = run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, group.data(), (int)group.size(), out);
+        if (rc) return rc;
+        group.clear(); bytes = 0;
+      }
+      int rc = vwgpu_arena_reserve(ctx, &ctx->xcarry, (size_t)s.zw * s.zh * sizeof(XCarry) + 256);
+      if (rc) return rc;
+      const int D = s.sx * s.sy, G = 64 * XMAX_CHUNKS;
+      for (int d0 = 0; d0 < D; d0 += G) {
+        DGroup dg{d0, std::min(G, D - d0), (d0 > 0 ? 1 : 0) | (d0 + G < D ? 2 : 0), static_cast<XCarry*>(ctx->xcarry.base)};
+        rc = run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, &s, 1, out, &dg);
+        if (rc) return rc;
+      }
+      continue;
+    }
     const int D = s.sx * s.sy, nchunk = (D + 63) / 64, dp = nchunk == 1 ? (1 << lanes_log2_for(D)) : nchunk * 64;
     const size_t need = (size_t)s.zh * (s.zw + kx - 1) * dp * 8;
     if (!group.empty() && bytes + need > budget) {
@@ -669,7 +740,7 @@ int vwgpu_launch_box_sum_exact(vwgpu_ctx* ctx, const float* img, int w, int h, p
   XZone z{};
   z.zw = w - kx + 1; z.zh = h - ky + 1; z.sx = z.sy = 1; z.lprec = 0;
   add_zone(t, z, kx, z.zh, true);
-  const size_t budget = exact_scratch_budget();
+  const size_t budget = exact_scratch_budget(ctx);
   int band = INT_MAX;
   size_t state_doubles = 0;
   if (t.vol_doubles * 8 > budget) {

@@ -523,11 +523,10 @@ const Launch* find_launch(int kx, int ky) {
 //   rounds   sequential staging / output phases: ceil(n / resident) for one group, n for two; ~4.5 row-units each
 // 4096^2: 16-row tiles, one group (4 per CU).  1/4 strip: 16-row tiles, two groups (exactly one per CU; 8-row tiles would
 // put a third tile on a few CUs).  1/8 strip: 8-row tiles, two groups.
-const Launch* pick_launch(int kx, int ky, int ow, int oh, int num_cu, bool* split) {
+const Launch* pick_launch(int kx, int ky, int ow, int oh, int num_cu, int groups, bool* split) {
   const Launch* best = nullptr;
   double best_cost = 0.0;
   *split = false;
-  const char* force = getenv("VWGPU_SAD_SPLIT");    // testing aid: "0" / "1" pin the matcher flavour
   for (const Launch& l : kLaunch) {
     if (l.kx != kx || l.ky != ky) continue;
     const long long wgs = (long long)((ow + l.twb - 1) / l.twb) * ((oh + l.ty - 1) / l.ty);
@@ -535,7 +534,7 @@ const Launch* pick_launch(int kx, int ky, int ow, int oh, int num_cu, bool* spli
     const int resident = (l.ty <= 8 && l.kx <= 8) ? 3 : 2;
     for (int sp = 0; sp < 2; ++sp) {
       if (sp && !l.split_fn) continue;
-      if (force && l.split_fn && (force[0] == '1') != (sp == 1)) continue;
+      if (groups && l.split_fn && (groups == 2) != (sp == 1)) continue;       // VWGPU_OPT_SAD_GROUPS pins the flavour (same results)
       const double steps = sp ? l.nr * 0.55 * n : (n < 2.0 ? l.nr * 0.74 : l.nr * 0.5 * n);
       const double rounds = sp ? n : (double)(((long long)n + resident - 1) / resident);
       const double cost = steps + 4.5 * rounds;
@@ -575,7 +574,7 @@ int vwgpu_launch_bm_sad_u8(vwgpu_ctx* ctx,
   (void)rw; (void)rh;
   const int ow = lw - kx + 1, oh = lh - ky + 1;
   bool split = false;
-  const Launch* l = pick_launch(kx, ky, ow, oh, ctx->num_cu, &split);
+  const Launch* l = pick_launch(kx, ky, ow, oh, ctx->num_cu, ctx->sad_groups, &split);
   if (!l) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "no packed-u8 kernel for %dx%d", kx, ky);
   const int rcw = lw + sx - 1, rch = lh + sy - 1;
   const int gx = (ow + l->twb - 1) / l->twb, gy = (oh + l->ty - 1) / l->ty;

@@ -636,7 +636,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   // (std::time: whole seconds), so a seconds_per_op calibrated for the CPU cannot make the GPU quit after milliseconds.
   double estim = 0.0, prev_estim = 0.0;
   const auto t_start = std::chrono::steady_clock::now();
-  const bool dbg_time = getenv("VWGPU_DEBUG_TIMING") != nullptr;     // development aid: host-side timeline of a tile on stderr
+  const bool dbg_time = (ctx->trace & 1) != 0;     // development aid: host-side timeline of a tile on stderr
   auto stamp = [&](const char* what, int level) {
     if (dbg_time) fprintf(stderr, "  [%8.1f us] level %d %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(), level, what);
   };
@@ -741,7 +741,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
       stamp("zone tables built", level);
       bool exact = exact_level[level] != 0;
       for (vwgpu_zone_task const& z : t1) exact = exact && vwgpu_bm_exact_supported(z.sx, z.sy);
-      if (getenv("VWGPU_DEBUG_ZONES")) {           // development aid: the shape of a level's work
+      if (ctx->trace & 2) {           // development aid: the shape of a level's work
         size_t px = 0, ev = 0; int maxd = 0, maxw = 0, maxh = 0;
         for (vwgpu_zone_task const& z : t1) { px += (size_t)z.zw * z.zh; ev += (size_t)z.zw * z.zh * z.sx * z.sy; maxd = std::max(maxd, z.sx * z.sy); maxw = std::max(maxw, z.zw); maxh = std::max(maxh, z.zh); }
         fprintf(stderr, "level %d: %zu zones, %zu px, %zu evaluations, max D %d, max zone %d x %d, exact %d\n", level, t1.size(), px, ev, maxd, maxw, maxh, (int)exact);

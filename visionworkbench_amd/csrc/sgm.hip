@@ -1723,9 +1723,8 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   uint8_t* cost = static_cast<uint8_t*>(ctx->sgm_main.base) + guard;
   uint16_t* accum = reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->sgm_main.base) + 2 * guard + vwgpu_align_up((size_t)main_buf, 256));
   uint16_t* mgm_vol = reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->sgm_main.base) + 3 * guard + vwgpu_align_up((size_t)main_buf, 256) + vol_bytes);
-  // 0: one direction per launch, plain store / read-modify-write (default); 1: all directions in one launch, 64-bit atomics
-  static const int paths_mode = getenv("VWGPU_SGM_PATHS") ? atoi(getenv("VWGPU_SGM_PATHS")) : 0;
-  const bool dir_paths = uniform && g.num_dy == 1 && paths_mode != 1 && !P->use_mgm;      // the first direction initialises the volume
+  // one direction per launch, plain store / read-modify-write
+  const bool dir_paths = uniform && g.num_dy == 1 && !P->use_mgm;      // the first direction initialises the volume
   if (!dir_paths && !P->use_mgm) VWGPU_HIP(ctx, hipMemsetAsync(accum, 0, (size_t)main_buf * 2, st));      // (MGM: mgm_sum_kernel stores)
   {
     vwgpu_prof_scope ps(ctx, "sgm_cost");
@@ -1810,7 +1809,6 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       vwgpu_prof_scope ps(ctx, "sgm_paths");
       int pe = (int)(((num_disp + 1) / 2 + 63) / 64);
       if (pe == 3) pe = 4;                                            // a lane's pairs must not straddle the end of the vector (stride % 8 == 0: 4 divides stride / 2)
-      static const int acc_probe = getenv("VWGPU_SGM_ACC") ? atoi(getenv("VWGPU_SGM_ACC")) : 0;   // timing experiments only: 2 store, 3 none
       // dirs[]: 0 T->B, 1 B->T, 2 L->R, 3 R->L, 4 TL->BR, 5 TR->BL, 6 BL->TR, 7 BR->TL
       const int order[8] = {2, 3, 0, 1, 4, 5, 6, 7};
       for (int q = 0; q < 8; ++q) {
@@ -1822,11 +1820,10 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
         const int nlines = d.n_first + d.n_second;
         S.line0[1] = nlines;
         if (nlines <= 0) continue;
-        const int acc = acc_probe ? acc_probe : (q == 0 ? ACC_STORE : ACC_RMW);
+        const int acc = q == 0 ? ACC_STORE : ACC_RMW;
 #define VWGPU_PATH_DIR1(E, A) hipLaunchKernelGGL((path_uniform_reg_kernel<E, A, VWGPU_PATH_KC>), dim3(nlines), dim3(64), 0, st, g, S, ustride, l8, lw, \
                                  min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2)
-#define VWGPU_PATH_DIR(E) do { if (acc == ACC_STORE) VWGPU_PATH_DIR1(E, ACC_STORE); else if (acc == ACC_NONE) VWGPU_PATH_DIR1(E, ACC_NONE); \
-                               else VWGPU_PATH_DIR1(E, ACC_RMW); } while (0)
+#define VWGPU_PATH_DIR(E) do { if (acc == ACC_STORE) VWGPU_PATH_DIR1(E, ACC_STORE); else VWGPU_PATH_DIR1(E, ACC_RMW); } while (0)
         switch (pe) { case 1: VWGPU_PATH_DIR(1); break; case 2: VWGPU_PATH_DIR(2); break; default: VWGPU_PATH_DIR(4); break; }
 #undef VWGPU_PATH_DIR
 #undef VWGPU_PATH_DIR1
@@ -1846,14 +1843,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       D.line0[D.n] = lines;
       if (lines <= 0) continue;
       vwgpu_prof_scope ps(ctx, together ? "sgm_paths" : "sgm_path");
-      if (uniform && one_d && paths_mode == 1) {                     // every direction on the whole image in one launch, 64-bit atomics
-        int pe = (int)(((num_disp + 1) / 2 + 63) / 64);
-        if (pe == 3) pe = 4;
-#define VWGPU_PATH_REG(E) hipLaunchKernelGGL((path_uniform_reg_kernel<E, ACC_ATOMIC, VWGPU_PATH_KC>), dim3(lines), dim3(64), 0, st, g, D, ustride, l8, lw, \
-                                 min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2)
-        switch (pe) { case 1: VWGPU_PATH_REG(1); break; case 2: VWGPU_PATH_REG(2); break; default: VWGPU_PATH_REG(4); break; }
-#undef VWGPU_PATH_REG
-      } else if (uniform) {
+      if (uniform) {
         // (2-D searches only: one search row is served by path_uniform_reg_kernel above)
 #define VWGPU_PATH_U(E) hipLaunchKernelGGL((path_uniform_kernel<E, false>), dim3(lines), dim3(64), ulds, st, g, D, K, ustride, \
                                l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2)

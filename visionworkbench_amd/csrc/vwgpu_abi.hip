@@ -134,6 +134,7 @@ void vwgpu_destroy(vwgpu_ctx* ctx) {
   for (auto& lr : ctx->leaf_rects) if (lr.d_rects) (void)hipFree(lr.d_rects);
   if (ctx->xvol.base) (void)hipFree(ctx->xvol.base);
   if (ctx->xtab.base) (void)hipFree(ctx->xtab.base);
+  if (ctx->xcarry.base) (void)hipFree(ctx->xcarry.base);
   if (ctx->staging.base) (void)hipFree(ctx->staging.base);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -176,7 +177,11 @@ int vwgpu_force_path(vwgpu_ctx* ctx, int path) {
 int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value) {
   if (!ctx) return VWGPU_ERR_ARGUMENT;
   if (option == VWGPU_OPT_DEFER_EXACTNESS) { ctx->defer_exact = value != 0; return VWGPU_OK; }
-  return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "vwgpu_set_option: unknown or read-only option %d", option);
+  // the options below select between variants that return identical results; out-of-range values are refused
+  if (option == VWGPU_OPT_SAD_GROUPS && value >= 0 && value <= 2) { ctx->sad_groups = value; return VWGPU_OK; }
+  if (option == VWGPU_OPT_EXACT_SCRATCH_MB && value >= 16 && value <= 65536) { ctx->exact_scratch_mb = value; return VWGPU_OK; }
+  if (option == VWGPU_OPT_TRACE && value >= 0 && value <= 3) { ctx->trace = value; return VWGPU_OK; }
+  return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "vwgpu_set_option: unknown or read-only option %d, or value %d out of range", option, value);
 }
 
 int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value) {
@@ -189,6 +194,9 @@ int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value) {
   }
   if (!ctx) return VWGPU_ERR_ARGUMENT;
   if (option == VWGPU_OPT_DEFER_EXACTNESS) { *value = ctx->defer_exact ? 1 : 0; return VWGPU_OK; }
+  if (option == VWGPU_OPT_SAD_GROUPS) { *value = ctx->sad_groups; return VWGPU_OK; }
+  if (option == VWGPU_OPT_EXACT_SCRATCH_MB) { *value = ctx->exact_scratch_mb; return VWGPU_OK; }
+  if (option == VWGPU_OPT_TRACE) { *value = ctx->trace; return VWGPU_OK; }
   return VWGPU_ERR_ARGUMENT;
 }
 
@@ -255,8 +263,8 @@ static int check_bm_args(vwgpu_ctx* ctx, int cost_type, const void* l, int lw, i
                       lw + sx - 1, lh + sy - 1);
   if (ls < lw || rs < rw || (os != 0 && os < lw - kx + 1))
     return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity: row stride smaller than row width");
-  if ((long long)sx * sy > 65535)
-    return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: search volume %dx%d exceeds 65535 disparities", sx, sy);
+  if ((long long)sx * sy > INT32_MAX)        // (the reference's disparity index is an int as well, Correlation.cc:64-66)
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity: search volume %dx%d exceeds the index range", sx, sy);
   return VWGPU_OK;
 }
 
@@ -273,7 +281,7 @@ static int calc_disparity_classified(vwgpu_ctx* ctx, int cost_type, const float*
     int lo = gr.lo, hi = gr.hi, nonfinite = gr.nonfinite;
     int rc = gr.known ? VWGPU_OK : vwgpu_float_grain(ctx, d_left, lw, lh, ls, d_right, lw + sx - 1, lh + sy - 1, rs, &lo, &hi, &nonfinite);
     if (rc) return rc;
-    if (vwgpu_bm_exact_supported(sx, sy)) exact = !vwgpu_sums_order_free(cost_type, kx, ky, lo, hi, nonfinite);
+    exact = !vwgpu_sums_order_free(cost_type, kx, ky, lo, hi, nonfinite);      // never the tile-local sums on data whose roundings depend on the order
     // integers below 2^16 (16-bit imagery): the packed-u16 SAD kernel; it checks the sign itself and raises its flag
     if (!exact && !nonfinite && lo != INT_MAX && lo >= 0 && hi <= 15 && vwgpu_bm_sad_u16_supported(cost_type, kx, ky, sx, sy)) {   // (nonfinite bit 1 = negative pixels)
       int* d_flag = nullptr;
@@ -295,7 +303,7 @@ static int calc_disparity_classified(vwgpu_ctx* ctx, int cost_type, const float*
   }
   if (exact) {
     if (!vwgpu_bm_exact_supported(sx, sy))
-      return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: the exact-order path serves up to 512 disparities (%d x %d asked)", sx, sy);
+      return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: %d x %d disparities exceed the index range of the exact-order path", sx, sy);
     ctx->last_path = VWGPU_PATH_EXACT_ORDER;
     vwgpu_zone_task z{0, 0, 0, 0, lw - kx + 1, lh - ky + 1, sx, sy, 0, (int)os, 0, 0};
     return vwgpu_launch_bm_exact(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, &z, 1, d_out);
@@ -315,7 +323,7 @@ int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
   if (os > INT32_MAX) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity: output stride too large");
 
   const bool sad_ok = vwgpu_bm_sad_u8_supported(cost_type, kx, ky, sx, sy);
-  const bool corr_ok = !sad_ok && vwgpu_bm_corr_u8_supported(cost_type, kx, ky, sx, sy) && !getenv("VWGPU_NO_CORR_U8");
+  const bool corr_ok = !sad_ok && vwgpu_bm_corr_u8_supported(cost_type, kx, ky, sx, sy);
   const bool dot_ok = !sad_ok && (corr_ok || vwgpu_bm_dot_u8_supported(cost_type, kx, ky, sx, sy));
   if (ctx->forced_path == VWGPU_PATH_SAD_U8 && !sad_ok)
     return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: no packed-u8 path for cost %d kernel %dx%d search %dx%d",

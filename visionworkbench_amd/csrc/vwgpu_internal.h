@@ -50,6 +50,7 @@ struct vwgpu_ctx {
   vwgpu_arena sgm_main;  // SGM: ragged cost (u8) + accumulated cost (u16) buffers
   vwgpu_arena xvol;      // exact-order path: column-sum volumes, band state, per-zone NCC precision images (bm_exact.hip)
   vwgpu_arena xtab;      // exact-order path: zone / work-item tables of one call
+  vwgpu_arena xcarry;    // exact-order path: compare-chain state per pixel between the disparity groups of a zone with > 512 disparities
   // Pinned host memory for the small tables that cross PCIe inside a call (zone / tile tables up, leaf extents down): a copy from or
   // to pageable memory is staged by the runtime and blocks the calling thread.  A ring: vwgpu_host_ring() hands out the next
   // piece and wraps around; a piece stays untouched for at least `cap / 2` bytes of later requests (callers synchronise the
@@ -60,6 +61,9 @@ struct vwgpu_ctx {
   std::vector<LeafRects> leaf_rects;   // zone scheduler: device copies of the leaf boxes of the level sizes seen so far
   bool measure_first = false; // the previous calc_disparity was refused by the packed-u8 kernels: measure the input class first
   bool defer_exact = false;   // VWGPU_OPT_DEFER_EXACTNESS: calc_disparity_dev never waits for the input-class flags
+  int sad_groups = 0;         // VWGPU_OPT_SAD_GROUPS
+  int exact_scratch_mb = 4096;// VWGPU_OPT_EXACT_SCRATCH_MB
+  int trace = 0;              // VWGPU_OPT_TRACE
   int num_cu = 256;
 };
 
