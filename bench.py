@@ -6,10 +6,14 @@ Workload (BASELINE config 2): 4096x4096 synthetic stereo pair, 7x7 SAD, +-64 px 
 already resident in HBM, output (PixelMask<Vector2i>, 12 B/px) left in HBM.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  N > 1: launched by torch.distributed.run, one rank per GPU.  The pair is split into N row strips
-  (output rows [g*oh/N, (g+1)*oh/N) on rank g, input strip + ky-1 halo rows resident on that GPU);
-  block matching needs no exchange step, so there is no data-path collective.  Total work is fixed:
-  scaling = "strong".
+  N > 1: one rank per GPU.  Either launched by torch.distributed.run (RANK / WORLD_SIZE in the environment), or typed as
+  above: bench.py then re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+  --master-addr 127.0.0.1 --master-port <free port>`.  The pair is split into N row strips (output rows
+  [g*oh/N, (g+1)*oh/N) on rank g); the SOURCE images are row-sharded over the GPUs and the ky-1 (+sy-1) halo rows of a
+  strip are fetched from the neighbouring rank before the clock starts — through the engine's C ABI
+  (vwgpu_fetch_strip_window_dev: RCCL send / recv, csrc/halo.hip), with the torch.distributed mirror as the stated
+  fallback; the choice is made collectively (an all-reduced flag), never per rank.  Block matching needs no exchange
+  step inside the timed region: no data-path collective.  Total work is fixed: scaling = "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with three extra objects:
   roofline     HBM roofline of the hot path's kernels: algorithmic bytes / HIP-event time
@@ -44,6 +48,118 @@ def algorithmic_bytes(lw, lh, kx, ky, sx, sy):
     return 4 * lw * lh + 4 * (lw + sx - 1) * (lh + sy - 1) + 12 * (lw - kx + 1) * (lh - ky + 1)
 
 
+def maybe_self_launch(gpus):
+    """`python bench.py --gpus N` typed as is (no RANK in the environment): become the launcher of N ranks on this node."""
+    if gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver supports dmabuf IPC only (RCCL peer mappings)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
+class HaloFetcher:
+    """Halo rows of a row-sharded source image.  First choice: the engine's own RCCL exchange behind the C ABI
+    (partition.EngineComm -> vwgpu_fetch_strip_window_dev; the 128-byte unique id is made on rank 0 and broadcast over the
+    process group).  Fallback: the torch.distributed mirror (partition.fetch_strip_window).  Every decision is COLLECTIVE —
+    a flag all-reduced with MIN over the ranks — so that no rank takes one path while its neighbour waits in the other."""
+
+    def __init__(self, torch, dist, vwa, partition, rank, world, dev):
+        self.torch, self.dist, self.partition, self.rank, self.world, self.dev = torch, dist, partition, rank, world, dev
+        self.comm = self.ctx = None
+        self.how = "none (single rank holds every row)"
+        if world == 1:
+            return
+        err = ""
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            try:
+                uid = torch.tensor(list(partition.EngineComm.unique_id()), dtype=torch.uint8, device=dev)
+            except Exception as e:  # noqa: BLE001
+                err = "unique id: %s" % (str(e)[:80],)
+        if self.agree(not err):
+            dist.broadcast(uid, 0)
+            try:
+                self.ctx = vwa.Context(dev.index)
+                self.comm = partition.EngineComm(self.ctx, bytes(uid.cpu().numpy().tobytes()), rank, world)
+            except Exception as e:  # noqa: BLE001
+                err = "communicator: %s" % (str(e)[:80],)
+                self.comm = None
+            if not self.agree(self.comm is not None):
+                if self.comm is not None:
+                    self.comm.close()
+                self.comm = None
+        self.how = ("engine C ABI: vwgpu_fetch_strip_window_dev (RCCL send/recv, csrc/halo.hip)" if self.comm is not None else
+                    "torch.distributed isend/irecv (engine RCCL communicator unavailable%s)" % ((": " + err) if err else " on some rank"))
+
+    def agree(self, ok):
+        if self.world == 1:
+            return bool(ok)
+        t = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def fetch(self, owned, rows_total, above, below):
+        """owned = rows row_strip(rank, world, rows_total) of the image (contiguous, on the GPU) -> (window, first row)."""
+        if self.world == 1:
+            return owned, 0
+        if self.comm is not None:
+            win = first = None
+            try:
+                win, first = self.comm.fetch_strip_window(owned.contiguous(), rows_total, above, below)
+                self.torch.cuda.synchronize(self.dev)
+            except Exception as e:  # noqa: BLE001
+                win = None
+                self.how = "torch.distributed isend/irecv (engine exchange failed: %s)" % (str(e)[:80],)
+            if self.agree(win is not None):
+                return win, first
+            self.comm.close()
+            self.comm = None
+            if not self.how.startswith("torch"):
+                self.how = "torch.distributed isend/irecv (engine exchange failed on another rank)"
+        return self.partition.fetch_strip_window(owned, self.rank, self.world, rows_total, above, below)
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+        if self.ctx is not None:
+            self.ctx.close()
+        self.comm = self.ctx = None
+
+
+def threaded_tiles(fn, jobs, threads, budget_s):
+    """Runs fn(job) over `jobs` on a pool of `threads` host threads the way the reference's block rasteriser runs tiles
+    (src/vw/Image/ImageIO.h:228-251: tasks pulled from a queue, one tile each), and stops handing out tiles once budget_s
+    seconds of wall time have passed.  Returns (jobs finished, wall seconds).  (The oracle is C behind ctypes: no GIL.)"""
+    import threading
+    lock = threading.Lock()
+    state = {"next": 0, "done": 0}
+    t0 = time.perf_counter()
+
+    def work():
+        while True:
+            with lock:
+                i = state["next"]
+                if i >= len(jobs) or (i >= threads and time.perf_counter() - t0 > budget_s):
+                    return
+                state["next"] = i + 1
+            fn(jobs[i])
+            with lock:
+                state["done"] += 1
+
+    th = [threading.Thread(target=work) for _ in range(threads)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    return state["done"], time.perf_counter() - t0
+
+
 def cpu_baseline(left, right, budget_s=12.0):
     """The restated reference timed the way the reference runs a big image: the output is split into tiles, T worker
     threads pull tiles from a queue and each tile calls single-threaded calc_disparity on its padded crop
@@ -70,10 +186,53 @@ def cpu_baseline(left, right, budget_s=12.0):
         _, d = oracle.calc_disparity_tiled(0, left, right, KERNEL, SEARCH, tile=tile, threads=cores, max_tiles=tiles)
         done += d
     dt = time.perf_counter() - t0
-    return {"value": done / dt / 1e6, "unit": "Mpix/s", "cores": cores, "kind": "port",
+    return {"value": done / dt / 1e6, "unit": "Mpix/s", "cores": cores, "kind": "port", "tile": tile,
+            "tile_note": "256-px tiles = the library default (src/vw/Core/Settings.cc:183), SURVEY 8d's stated alternative to the 1024-px tiles of "
+                         "tools/correlate.cc:266: a 4096^2 image is only 16 tiles of 1024^2, which would leave most of the host's cores idle",
             "sample": "%d x (%d of %d 256x256 output tiles of the same 4096^2 / 7x7 SAD / 129x1 pair) on %d threads, "
                       "%.1f s wall, %.0f core-seconds" % (reps, tiles, ntiles_total, cores, dt, dt * cores),
             "single_thread_ns_per_pixel_disparity": ns_per_op}
+
+
+def cpu_baseline_sgm(synth, cost_type, k, D, budget_s=12.0):
+    """The SGM oracle the way the reference runs a big pair: 1024^2 output tiles (tools/correlate.cc:266), one tile per task on T
+    host threads, each tile single-threaded inside.  Bounded: every thread takes at least one tile, no new tile after budget_s."""
+    import oracle
+    cores = os.cpu_count() or 1
+    T = max(1, min(cores, 32))                                            # ~0.45 GB of cost + path sums per tile in flight
+    n = 1024 + k - 1
+    left, right, _ = synth.stereo_pair(n, n, D, 1)
+    oracle.set_sgm_host_threads(1)
+    jobs = list(range(4 * T))
+    if cost_type == 0:
+        fn = lambda j: oracle.calc_disparity_sgm(0, left, right, (D - 1, 0), k, allow_block_cost=True)
+    else:
+        fn = lambda j: oracle.calc_disparity_sgm(cost_type, left, right, (D - 1, 0), k)
+    done, dt = threaded_tiles(fn, jobs, T, budget_s)
+    return {"value": done * 1024 * 1024 / dt / 1e6, "unit": "Mpix/s", "cores": T, "kind": "port", "tile": 1024,
+            "sample": "%d tiles of 1024^2 (+ kernel rim) of the same kind of pair, %d disparities, one tile per task on %d host threads (of %d), %.1f s wall"
+                      % (done, D, T, cores, dt)}
+
+
+def cpu_baseline_pyramid(left, right, modes, search, levels, budget_s=8.0):
+    """oracle pyramid_correlate over 1024^2 tiles of the given pair on T host threads (tools/correlate.cc:207-266 + ImageIO.h:228-251)."""
+    import oracle
+    cores = os.cpu_count() or 1
+    H, W = left.shape
+    tiles = [(x, y, 1024, 1024) for y in range(0, H - 1023, 1024) for x in range(0, W - 1023, 1024)]
+    T = max(1, min(cores, 64))
+    out = {}
+    for m in modes:
+        if m["alg"] == 0:
+            fn = lambda bb, m=m: oracle.pyramid_correlate(left, right, None, None, m["pf"], m["pfw"], search, m["kernel"], m["cost"], 0, 0.0, 2.0, 5, levels, bbox=bb)
+        else:
+            fn = lambda bb, m=m: oracle.pyramid_correlate_sgm(left, right, None, None, search, m["kernel"][0], m["cost"], 2.0, 0, 5, levels, bbox=bb, algorithm=m["alg"])
+        jobs = [tiles[i % len(tiles)] for i in range(8 * T)]
+        done, dt = threaded_tiles(fn, jobs, T, budget_s)
+        out[m["name"]] = {"value": done * 1024 * 1024 / dt / 1e6, "unit": "Mpix/s", "cores": T, "kind": "port", "tile": 1024,
+                          "sample": "%d tiles of 1024^2 of a %dx%d pair through the oracle's pyramid_correlate, one tile per task on %d host threads (of %d), "
+                                    "%.1f s wall" % (done, W, H, T, cores, dt)}
+    return out
 
 
 def measure(ctx, torch, fn, reps, warm=2):
@@ -202,27 +361,36 @@ def run_config4(args, torch, dist, vwa, core, stereo, synth, partition, rank, wo
     lwin = torch.from_numpy(left).to(dev)
     rwin = torch.from_numpy(right).to(dev)
     first = a
-    how = "none (single rank holds every row)"
+    fetcher = HaloFetcher(torch, dist, vwa, partition, rank, world, dev)
     if world > 1:
-        lwin, first = partition.fetch_strip_window(lwin, rank, world, H, halo, halo)
-        rwin, _ = partition.fetch_strip_window(rwin, rank, world, H, halo, halo)
-        how = "RCCL isend/irecv of %d collar + %d half-kernel rows per neighbour" % (collar, k // 2)
+        lwin, first = fetcher.fetch(lwin, H, halo, halo)
+        rwin, _ = fetcher.fetch(rwin, H, halo, halo)
+    how = fetcher.how if world == 1 else "%s: %d collar + %d half-kernel rows per neighbour" % (fetcher.how, collar, k // 2)
+    fetcher.close()
     torch.cuda.synchronize(dev)
     ctx = vwa.Context(dev.index)
     rows_per = H // nstrips
     mine = [s for s in range(nstrips) if a <= s * rows_per < b]
+    hk = k // 2
+    cost_type = 3 if args.cost == "census" else 0                        # 0 = ABSOLUTE_DIFFERENCE: the MAD block cost (opt-in, see --cost)
+
+    def strip_rows(s_):
+        """(first / last+1 centre row the strip keeps, first / last+1 input row of strip + collar + half kernel): a strip keeps the
+        centre rows of [y0, y1) that have a full window, [hk, H - hk) — the kept rows of all strips partition the valid rows."""
+        y0, y1 = s_ * rows_per, (s_ + 1) * rows_per
+        ka, kb = max(y0, hk), min(y1, H - hk)
+        return ka, kb, max(0, ka - hk - collar), min(H, kb + hk + collar)
 
     def step():
         outs = []
         for s_ in mine:
-            y0, y1 = s_ * rows_per, (s_ + 1) * rows_per                 # output rows of the strip (image coordinates of the window centre)
-            ra, rb = max(0, y0 - halo), min(H, y1 + halo)                # input rows of strip + collar + half kernel
+            ka, kb, ra, rb = strip_rows(s_)
             l = lwin[ra - first:rb - first]
             r = rwin[ra - first:rb - first]
-            d = stereo.calc_disparity_sgm(3, l, r, vwa.BBox2i(0, 0, W, rb - ra), (D - 1, 0), (k, k), with_subpixel=True,
-                                          memory_limit_mb=200000, ctx=ctx)[0]
-            top = max(0, y0 - ra - k // 2)                               # output row j of the call is centred on input row ra + j + k/2
-            outs.append(d[top:top + (y1 - y0)])                          # the strip's centre rows (fewer at the image borders)
+            d = stereo.calc_disparity_sgm(cost_type, l, r, vwa.BBox2i(0, 0, W, rb - ra), (D - 1, 0), (k, k), with_subpixel=True,
+                                          memory_limit_mb=200000, allow_block_cost=(cost_type == 0), ctx=ctx)[0]
+            top = ka - (ra + hk)                                         # output row j of the call is centred on input row ra + hk + j
+            outs.append(d[top:top + (kb - ka)])
         return outs
 
     def barrier():
@@ -244,25 +412,32 @@ def run_config4(args, torch, dist, vwa, core, stereo, synth, partition, rank, wo
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    npx = (W - k + 1) * H
+    npx = (W - k + 1) * (H - k + 1)                                      # the kept rows of all strips: every pixel with a full window, once
     got = out[0]
-    c0 = max(mine[0] * rows_per, k // 2)                                 # centre row of the first kept output row
-    tr = truth[c0 - a:c0 - a + got.shape[0], 3:3 + W - 6]
-    ok = float((got[:tr.shape[0], :, 0].cpu().numpy() == tr).mean()) if got.shape[0] else 0.0
+    ka, kb, _, _ = strip_rows(mine[0])
+    assert got.shape[0] == kb - ka
+    tr = truth[ka - a:kb - a, hk:hk + W - k + 1]
+    ok = float((got[..., 0].cpu().numpy() == tr).mean())
     if rank == 0:
         per_px = 20 + 11 * D
+        cpu = None if args.no_cpu_baseline else cpu_baseline_sgm(synth, cost_type, k, D)
         print(json.dumps({
-            "metric": "disparity Mpix/s, 16384x16384 pair, census 7x7 SGM, 129 disparities, 8 row strips + collar",
+            "metric": "disparity Mpix/s, 16384x16384 pair, %s SGM, 129 disparities, 8 row strips + collar" % ("census 7x7" if cost_type == 3 else "7x7 MAD block cost"),
             "value": npx * steps / dt / 1e6, "unit": "Mpix/s", "n_gpus": world, "steps": steps, "warmup": 1,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8/u16",
             "data": "synthetic (SplitMix64 integer-valued float32 noise pair, 256-px blocks shifted by 64+-48)",
-            "config": {"workload": "BASELINE configs[3] (census SGM: the reference's SGM refuses SAD costs, SURVEY F3), tile + collar semantics",
+            "config": {"workload": "BASELINE configs[3], tile + collar semantics; cost = %s" % (
+                           "census 7x7 (what the reference's SGM accepts, SURVEY F3)" if cost_type == 3 else
+                           "7x7 mean-abs-difference block cost = the config as written; reference code path present but unreachable upstream "
+                           "(SGM.cc:1651-1738 behind the throw at :1887-1892), enabled here by an explicit opt-in"),
                        "strips": nstrips, "strip_rows": rows_per, "collar_rows": collar, "halo": how,
                        "integer_match_rate_vs_truth_first_strip": ok},
             "roofline": {"bound": "hbm", "achieved": npx * per_px * steps / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": npx * per_px * steps / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "bytes_model": "materialised volume (20 + 11 D) B per pixel, SURVEY 8d", "kernel": "calc_disparity_sgm (wall)"},
-            "cpu_baseline": None}))
+                         "min_model_frac": npx * (20 + 4 * D) * steps / dt / 1e9 / HBM_PEAK_GBS,
+                         "bytes_model": "materialised volume (20 + 11 D) B per pixel, SURVEY 8d (min_model_frac: its minimum model, 20 + 4 D)",
+                         "kernel": "calc_disparity_sgm (wall)"},
+            "cpu_baseline": cpu}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -292,12 +467,15 @@ def run_config5(args, torch, dist, vwa, core, stereo, synth, partition, rank, wo
     first = a
     how = "none (single rank holds every row)"
     search = vwa.BBox2i.from_corners((-64, -1), (64, 1))
+    fetcher = HaloFetcher(torch, dist, vwa, partition, rank, world, dev)
+    how = fetcher.how
     if world > 1:
         above, below = partition.pyramid_halo_rows(11, LEVELS, -1, 1)
         hal = max(above, below) + 2 * 3                            # SGM R->L runs reach twice the vertical search extent
-        lwin, first = partition.fetch_strip_window(lwin, rank, world, H, hal, hal)
-        rwin, _ = partition.fetch_strip_window(rwin, rank, world, H, hal, hal)
-        how = "RCCL isend/irecv of %d pyramid halo rows per neighbour" % hal
+        lwin, first = fetcher.fetch(lwin, H, hal, hal)
+        rwin, _ = fetcher.fetch(rwin, H, hal, hal)
+        how = "%s: %d pyramid halo rows per neighbour" % (fetcher.how, hal)
+    fetcher.close()
     torch.cuda.synchronize(dev)
     tiles = [(x, y) for y in range(a, b, TILE) for x in range(0, W, TILE)]
     T = 4
@@ -306,7 +484,7 @@ def run_config5(args, torch, dist, vwa, core, stereo, synth, partition, rank, wo
     keep = {}
 
     def loop(kw, only=None):
-        todo = list(tiles if only is None else tiles[:only])
+        todo = list(tiles if only is None else tiles[-only:])      # (the timed loop pops from the end: warm up with the tiles it starts with)
         lock = threading.Lock()
         def work(t):
             with torch.cuda.stream(streams[t]):
@@ -347,17 +525,36 @@ def run_config5(args, torch, dist, vwa, core, stereo, synth, partition, rank, wo
         for name, o in keep.items():
             g = o.cpu().numpy()
             ok[name] = float(((np.rint(g[..., 0]) == truth0) & (g[..., 2] != 0)).mean())
+        # Byte model of one tile (summed over the levels): the pyramid build reads 4 N_src and writes N_src per image and
+        # level ( ~ (4/3) 5 N per image), every level's matcher moves the BM bytes of its size (4 L + 4 R + 12 out; the top level over the
+        # whole search, level 0 twice: L->R and R->L for the consistency check), every level's disparity is read and written once more by
+        # the clean-up chain (24 B/px).  SGM adds the materialised volume of its per-pixel boxes: (3 x 25 + 2 x 8 x 25) B/px at 5 x 5 boxes.
+        nl = [TILE * TILE / 4 ** l for l in range(LEVELS + 1)]
+        bm_tile = 2 * (4.0 / 3.0) * 5 * nl[0] + sum((20 + 24) * n for n in nl) + 20 * nl[0]
+        sgm_tile = bm_tile + sum(11 * 25 * n for n in nl) + 11 * 25 * nl[0]
+        ntiles = (W // TILE) * (H // TILE)
+        cpu = None
+        if not args.no_cpu_baseline:
+            l0, r0, _ = synth.stereo_pair_rows(W, H, D, 0, 2 * TILE)
+            cpu = cpu_baseline_pyramid(np.ascontiguousarray(l0[:, :8 * TILE]), np.ascontiguousarray(r0[:, 64:64 + 8 * TILE]), modes, (-64, -1, 65, 2), LEVELS)
         print(json.dumps({
             "metric": "disparity Mpix/s, %dx%d pair, pyramid_correlate tile loop (LoG 1.4 + NCC 11x11, 5 levels, +-64 x +-1, L/R check)" % (W, H),
             "value": npx / res["bm"] / 1e6, "unit": "Mpix/s", "n_gpus": world, "steps": 1, "warmup": 1,
             "ms_per_step": res["bm"] * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32/f64",
             "data": "synthetic (SplitMix64 integer-valued float32 noise pair, 256-px blocks shifted by 0+-48)",
             "config": {"workload": "BASELINE configs[4]: orbital-scale pair through the reference's tile loop; block matching with the correlate "
-                                   "tool's defaults and, separately, SGM (census 7x7)", "tile": TILE, "tiles": (W // TILE) * (H // TILE),
+                                   "tool's defaults and, separately, SGM (census 7x7)", "tile": TILE, "tiles": ntiles,
                        "tile_threads_per_gpu": T, "halo": how,
-                       "sgm": {"Mpix_per_s": npx / res["sgm"] / 1e6, "s_per_pair": res["sgm"]},
+                       "sgm": {"Mpix_per_s": npx / res["sgm"] / 1e6, "s_per_pair": res["sgm"],
+                               "roofline_frac": ntiles * sgm_tile / res["sgm"] / 1e9 / HBM_PEAK_GBS,
+                               "cpu_baseline": None if cpu is None else cpu["sgm"]},
                        "truth_match_rate_first_tile": ok},
-            "roofline": None, "cpu_baseline": None}))
+            "roofline": {"bound": "hbm", "achieved": ntiles * bm_tile / res["bm"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ntiles * bm_tile / res["bm"] / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "pyramid_correlate tile loop (wall)",
+                         "algorithmic_bytes_per_tile": int(bm_tile),
+                         "bytes_model": "SURVEY 8d summed over the levels of a tile: pyramid build + BM bytes per level (level 0 twice) + clean-up chain; "
+                                        "the loop is launch / latency bound (about 100 dependent launches per tile), not byte bound"},
+            "cpu_baseline": None if cpu is None else cpu["bm"]}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -371,23 +568,32 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=250.0, dest="settle_ms")   # untimed load before the warm-up steps (clock ramp)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measured points (config 3, SGM block, +-16 px)")
+    ap.add_argument("--cost", default="census", choices=["census", "mad"],
+                    help="config4 only: census (what the reference's SGM accepts) or mad = the 7x7 mean-abs-difference block cost of the config as "
+                         "written (SGM.cc:1651-1738; unreachable upstream, explicit opt-in here)")
     ap.add_argument("--workload", default="config2", choices=["config2", "config4", "config5"],
                     help="config2 (default, the headline metric): 4096^2 7x7 SAD; config4: 16384^2 census SGM in 8 strips + collar")
     args = ap.parse_args()
 
+    maybe_self_launch(args.gpus)              # `python bench.py --gpus N` as typed: re-executes under torch.distributed.run (never returns)
     # the host driver supports dmabuf IPC only: without this RCCL's peer mappings fail (hipIpcGetMemHandle: invalid argument)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: rank %d: --gpus %d but WORLD_SIZE is %d (launch with --nproc-per-node %d, or type `python bench.py --gpus %d` "
+                 "and let bench.py launch its ranks)" % (rank, args.gpus, world, args.gpus, args.gpus))
     import torch
     import torch.distributed as dist
     import visionworkbench_amd as vwa
     from visionworkbench_amd import core, stereo, synth
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+        # (the product has no CPU path; tests/test_bench_contract.py drives the launcher up to this line on a GPU-less host)
+        print("bench.py: rank %d of %d (local rank %d): no GPU visible to this rank (%d device(s)) - nothing to measure"
+              % (rank, world, local, torch.cuda.device_count() if torch.cuda.is_available() else 0), file=sys.stderr)
+        sys.exit(3)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -412,27 +618,33 @@ def main():
     halo = "none (single strip)"
     l_strip = r_strip = None
     if world > 1:
-        # The source pair is row-sharded across the GPUs (disjoint rows per HBM); the ky-1 (+sy-1) halo rows a strip's
-        # windows read come from the neighbour over RCCL point-to-point (one xGMI link per neighbour pair) — set-up, not
-        # part of the timed region (inputs are resident when the clock starts).  Falls back to host-provided halos if
-        # the P2P path is unavailable, and says so in the JSON line.
+        # The source pair is row-sharded across the GPUs (rank g holds rows row_strip(g, N, rows) of each image, disjoint per HBM);
+        # the ky-1 (+sy-1) halo rows a strip's windows read come from the neighbouring rank over RCCL point-to-point (one xGMI
+        # link per neighbour pair) through the engine's C ABI — set-up, not part of the timed region (inputs are resident when
+        # the clock starts).  Whether the fetched rows are used is decided by ALL ranks together (all-reduced flags): engine
+        # exchange -> torch.distributed exchange -> host-provided halo rows, and the JSON line says which.
+        fetcher = HaloFetcher(torch, dist, vwa, partition, rank, world, dev)
+        hal = ky - 1 + sy - 1
+        ok, why = True, ""
         try:
-            lbnd = partition.sharded_bounds(world, left.shape[0], oh, 0, ky - 1)
-            rbnd = partition.sharded_bounds(world, right.shape[0], oh, 0, ky - 1 + sy - 1)
-            a, b, na, nb = lbnd[rank]
-            l_strip = partition.exchange_halo(torch.from_numpy(left[a:b].copy()).to(dev), a, b, na, nb, rank, world, lbnd)
-            a, b, na, nb = rbnd[rank]
-            r_strip = partition.exchange_halo(torch.from_numpy(right[a:b].copy()).to(dev), a, b, na, nb, rank, world, rbnd)
+            a, b = partition.row_strip(rank, world, left.shape[0])
+            lwin, lfirst = fetcher.fetch(torch.from_numpy(left[a:b].copy()).to(dev), left.shape[0], hal, hal)
+            a, b = partition.row_strip(rank, world, right.shape[0])
+            rwin, rfirst = fetcher.fetch(torch.from_numpy(right[a:b].copy()).to(dev), right.shape[0], hal, hal)
             torch.cuda.synchronize(dev)
-            l_strip = l_strip[:lb - la].contiguous()
-            r_strip = r_strip[:rb - ra].contiguous()
-            ok = bool(torch.equal(l_strip.cpu(), torch.from_numpy(left[la:lb])) and torch.equal(r_strip.cpu(), torch.from_numpy(right[ra:rb])))
-            if not ok:
-                raise RuntimeError("halo exchange returned wrong rows")
-            halo = "RCCL isend/irecv of %d (+%d) rows between neighbouring strips" % (ky - 1, sy - 1)
-        except Exception as e:  # noqa: BLE001
-            halo = "host-provided halo rows (RCCL P2P unavailable: %s)" % (str(e)[:80],)
+            l_strip = lwin[la - lfirst:lb - lfirst].contiguous()
+            r_strip = rwin[ra - rfirst:rb - rfirst].contiguous()
+            if not (l_strip.shape[0] == lb - la and r_strip.shape[0] == rb - ra and
+                    torch.equal(l_strip.cpu(), torch.from_numpy(left[la:lb])) and torch.equal(r_strip.cpu(), torch.from_numpy(right[ra:rb]))):
+                ok, why = False, "the exchange returned wrong rows"
+        except Exception as e:  # noqa: BLE001  (collective calls inside fetch() are matched on every rank: see HaloFetcher)
+            ok, why = False, str(e)[:80]
+        if fetcher.agree(ok):
+            halo = "%s: %d (+%d) rows between neighbouring strips" % (fetcher.how, ky - 1, sy - 1)
+        else:
+            halo = "host-provided halo rows (halo exchange unusable on some rank%s)" % ((": " + why) if why else "")
             l_strip = r_strip = None
+        fetcher.close()
     if l_strip is None:
         l_strip = torch.from_numpy(left[la:lb]).to(dev)
         r_strip = torch.from_numpy(right[ra:rb]).to(dev)
@@ -536,13 +748,15 @@ def main():
                                  "(256 CU x 64 lane-ops/clk x 2.4 GHz): evaluations per VOP3 issue slot — the kernel "
                                  "is VALU-issue bound (~4.25 slots per evaluation at best), see DESIGN.md"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # rank 0, for every N: the same leg (the other ranks wait at the final barrier)
             res["cpu_baseline"] = cpu_baseline(left, right)
-            # the checker: one full-image pass of the oracle against the result of the timed work, every pixel
+            # the checker: one full-image pass of the oracle against the result of the timed work — every pixel of this rank's strip
             import oracle
             want, _ = oracle.calc_disparity_tiled(0, left, right, KERNEL, SEARCH, tile=256, threads=os.cpu_count() or 1)
-            same = bool(np.array_equal(out.cpu().numpy(), want))
+            same = bool(np.array_equal(out.cpu().numpy(), want[r0:r1]))
             res["cpu_baseline"]["result_identical_to_oracle"] = same
+            res["cpu_baseline"]["rows_checked"] = [int(r0), int(r1)]
             assert same, "the timed result differs from the CPU oracle"
         else:
             res["cpu_baseline"] = None

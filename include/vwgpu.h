@@ -343,7 +343,7 @@ typedef enum vwgpu_sgm_subpixel {      /* SemiGlobalMatcher::SgmSubpixelMode, sr
 /* The arguments of vw::stereo::calc_disparity_sgm / SemiGlobalMatcher::set_parameters that are not images
  * (src/vw/Stereo/SGM.h:108-147, 360-375). */
 typedef struct vwgpu_sgm_params {
-  int cost_type;                 /* VWGPU_CENSUS_TRANSFORM or VWGPU_TERNARY_CENSUS_TRANSFORM (others: NOIMPL, like the reference) */
+  int cost_type;                 /* VWGPU_CENSUS_TRANSFORM or VWGPU_TERNARY_CENSUS_TRANSFORM (others: NOIMPL, like the reference; see allow_block_cost) */
   int use_mgm;                   /* != 0: accum_mgm_multithread (SGM.cc:2619-2700) instead of the eight independent path sweeps */
   int kernel_size;               /* 3, 5, 7 or 9 */
   int subpixel_mode;             /* vwgpu_sgm_subpixel */
@@ -352,6 +352,10 @@ typedef struct vwgpu_sgm_params {
   int p1, p2;                    /* 0 = the reference's defaults for the cost type / kernel size */
   int ternary_census_threshold;  /* the reference's default is 5 */
   int num_threads;               /* only enters the memory-cap formula (line buffers per thread); >= 1 */
+  int allow_block_cost;          /* 0 (default): costs other than census return VWGPU_ERR_NOIMPL, as compute_disparity_costs throws
+                                  * (SGM.cc:1887-1892).  1: VWGPU_ABSOLUTE_DIFFERENCE / VWGPU_SQUARED_DIFFERENCE run the code behind that
+                                  * throw — fill_costs_block's mean-abs-difference block cost (:1651-1738, p1 = 3, p2 = 250 by default),
+                                  * odd kernel sizes 1 .. 15.  A reference code path that is unreachable upstream: explicit opt-in only. */
 } vwgpu_sgm_params;
 
 /* Replaces vw::stereo::calc_disparity_sgm (src/vw/Stereo/SGM.cc:167-229) on already cropped regions:

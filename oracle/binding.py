@@ -386,7 +386,7 @@ class SemiGlobalMatcher:
 
 def calc_disparity_sgm(cost_type, left, right, search_volume, kernel, subpixel=SUBPIXEL_LC_BLEND, search_buffer=(2, 2),
                        memory_limit_mb=6000, left_mask=None, right_mask=None, prev_disparity=None, num_threads=1, p1=0, p2=0,
-                       use_mgm=False):
+                       use_mgm=False, allow_block_cost=False):
     """calc_disparity_sgm on cropped regions: left (lh, lw) float32, right (lh+sy, lw+sx) float32.
     Returns (integer disparity (oh, ow, 3) int32, sub-pixel disparity (oh, ow, 3) float32)."""
     l = np.ascontiguousarray(left, np.float32)
@@ -397,6 +397,8 @@ def calc_disparity_sgm(cost_type, left, right, search_volume, kernel, subpixel=S
     out = np.zeros((l.shape[0], l.shape[1], 3), np.int32)
     sub = np.zeros((l.shape[0], l.shape[1], 3), np.float32)
     ow, oh = ctypes.c_int(), ctypes.c_int()
+    # cost types 0 / 1 = the MAD block cost (SGM.cc:1651-1738), refused like the reference's throw (:1887-1892) unless opted in
+    lib().vwo_set_sgm_allow_block_cost(int(bool(allow_block_cost)))
     rc = lib().vwo_calc_disparity_sgm_x(int(cost_type), int(bool(use_mgm)), _p(l), l.shape[1], l.shape[0], _p(r), r.shape[1], r.shape[0],
                                         search_volume[0], search_volume[1], kernel, int(subpixel), search_buffer[0], search_buffer[1],
                                         memory_limit_mb, num_threads, None if lm is None else _p(lm), lmw, lmh,

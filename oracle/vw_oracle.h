@@ -142,6 +142,9 @@ void vwo_set_sgm_algorithm(int algorithm);
 /* Host threads the SGM oracle may use for the lines of a path direction and the rows of the cost fill (process wide; the
  * results do not depend on it — the reference runs its PixelPassTasks on a pool as well, SGM.cc:2462-2612). */
 void vwo_set_sgm_host_threads(int n);
+/* Opt-in (process wide) to cost types 0 / 1 = the mean-abs-difference block cost of fill_costs_block / get_cost_block
+ * (SGM.cc:1651-1738, defaults p1 = 3, p2 = 250 :128-131,156-158), which the reference keeps behind a NoImplErr (:1887-1892). */
+void vwo_set_sgm_allow_block_cost(int on);
 
 /* disparity_blob_filter (CorrelationView.cc:242-271): zero every valid pixel of an 8-connected component of valid pixels
  * with at most `area` pixels; vwo_blob_sizes = the size of each pixel's component (0 for invalid pixels), the quantity

@@ -35,6 +35,7 @@
 
 namespace {
 
+bool g_allow_block_cost = false;         // vwo_set_sgm_allow_block_cost: the MAD block cost the reference keeps behind a throw (SGM.cc:1887-1892)
 int g_host_threads = 1;                  // vwo_set_sgm_host_threads: run-time only, results do not depend on it
 
 typedef uint8_t CostType;
@@ -323,7 +324,33 @@ struct Matcher {
     return result;
   }
 
+  // get_cost_block, "Mean of abs differences" branch (SGM.cc:1651-1709): int sum of |L - R| over the kernel, integer division by
+  // the pixel count, saturated to 255; the single-pixel kernel returns the plain difference.
+  CostType cost_block(U8Img const& L, U8Img const& R, int lx, int ly, int rx, int ry) const {
+    if (kernel == 1) return (CostType)std::abs(L(lx, ly) - R(rx, ry));
+    const int hk = (kernel - 1) / 2, count = kernel * kernel;
+    int sum = 0;
+    for (int j = -hk; j <= hk; ++j)
+      for (int i = -hk; i <= hk; ++i) sum += std::abs(L(lx + i, ly + j) - R(rx + i, ry + j));
+    sum /= count;
+    return (CostType)(sum > 255 ? 255 : sum);
+  }
+  // fill_costs_block (SGM.cc:1711-1738): unreachable upstream (compute_disparity_costs throws first, :1887-1892); run here only
+  // after vwo_set_sgm_allow_block_cost(1)
+  void compute_costs_block(U8Img const& L, U8Img const& R) {
+    for_lines(max_row - min_row + 1, [&](int ri, int) {
+      const int r = min_row + ri;
+      for (int c = min_col; c <= max_col; ++c) {
+        Bounds const& b = bounds[(size_t)(r - min_row) * ocols + (c - min_col)];
+        size_t ci = starts[(size_t)(r - min_row) * ocols + (c - min_col)];
+        for (int dy = b.v[1]; dy <= b.v[3]; ++dy)
+          for (int dx = b.v[0]; dx <= b.v[2]; ++dx) cost[ci++] = cost_block(L, R, c, r, c + dx, r + dy);
+      }
+    });
+  }
+
   void compute_costs(U8Img const& L, U8Img const& R) {         // :1740-1893, :40-75
+    if (cost_type != COST_CENSUS && cost_type != COST_TERNARY) { compute_costs_block(L, R); return; }
     std::vector<uint64_t> lc, rc; int lw, lh, rw, rh;
     const bool tern = cost_type == COST_TERNARY;
     census_image(L, kernel, tern, ternary_thr, lc, lw, lh);
@@ -704,8 +731,11 @@ int vwo_hamming_distance(uint64_t a, uint64_t b) { return hamming(a, b); }
 
 vwo_sgm* vwo_sgm_create(int cost_type, int use_mgm, int min_dx, int min_dy, int max_dx, int max_dy, int kernel, int subpixel,
                         int sbx, int sby, size_t memory_limit_mb, int p1, int p2, int ternary_thr, int num_threads) {
-  if (cost_type != COST_CENSUS && cost_type != COST_TERNARY) return nullptr;       // SGM.cc:1886-1890 (NoImplErr)
-  if (kernel != 3 && kernel != 5 && kernel != 7 && kernel != 9) return nullptr;    // :1877-1884
+  const bool census = cost_type == COST_CENSUS || cost_type == COST_TERNARY;
+  // SGM.cc:1886-1890 (NoImplErr) unless the caller opted in to the block cost; cost type 2 (the NCC flavour of get_cost_block) is not restated
+  if (!census && !(g_allow_block_cost && (cost_type == 0 || cost_type == 1))) return nullptr;
+  if (census && kernel != 3 && kernel != 5 && kernel != 7 && kernel != 9) return nullptr;    // :1877-1884
+  if (!census && (kernel < 1 || kernel % 2 == 0)) return nullptr;
   vwo_sgm* s = new vwo_sgm;
   Matcher& m = s->m;
   m.use_mgm = use_mgm != 0;
@@ -717,6 +747,7 @@ vwo_sgm* vwo_sgm_create(int cost_type, int use_mgm, int min_dx, int min_dy, int 
 }
 void vwo_sgm_destroy(vwo_sgm* s) { delete s; }
 void vwo_set_sgm_host_threads(int n) { g_host_threads = n > 0 ? n : 1; }
+void vwo_set_sgm_allow_block_cost(int on) { g_allow_block_cost = on != 0; }
 
 int vwo_sgm_output_size(vwo_sgm* s, int* ow, int* oh) { *ow = s->m.ocols; *oh = s->m.orows; return 0; }
 

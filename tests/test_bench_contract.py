@@ -73,6 +73,37 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert not any(ln.strip().startswith("{") for ln in p.stdout.splitlines())        # no JSON line from a CPU path
 
 
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as typed (no RANK in the environment) must re-execute itself under torch.distributed.run: both ranks
+    come up with RANK / WORLD_SIZE / LOCAL_RANK set and — on this GPU-less host — stop at the 'no GPU visible' line, each for itself."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert p.returncode != 0
+    err = p.stderr
+    assert "rank 0 of 2 (local rank 0): no GPU visible" in err and "rank 1 of 2 (local rank 1): no GPU visible" in err, err[-2000:]
+    assert "must be launched with" not in err
+    assert not any(ln.strip().startswith("{") for ln in p.stdout.splitlines())
+    # a launch whose world size contradicts --gpus is refused with a message that says how to launch
+    env2 = dict(env, RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env2)
+    assert p.returncode != 0 and "WORLD_SIZE is 4" in p.stderr
+
+
+def test_halo_fetcher_decisions_are_collective():
+    """bench.py's HaloFetcher: world 2 over gloo on the CPU (the engine communicator cannot exist without a GPU, so both ranks must
+    agree on the torch.distributed exchange and return the right rows)."""
+    script = os.path.join(ROOT, "tests", "_halo_fetcher_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29613", script], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.stdout.count("halo fetcher ok") == 2, p.stdout
+
+
 def test_oracle_is_only_the_checker_in_bench():
     src = open(os.path.join(ROOT, "bench.py")).read()
     uses = [m.start() for m in re.finditer(r"\boracle\b", src)]

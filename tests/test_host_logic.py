@@ -58,8 +58,8 @@ def test_struct_layouts_match_the_header():
     assert P.lr_disp_diff.offset % 8 == 0 and P.lr_disp_diff_stride.offset % 8 == 0
     S = _lib.SgmParams
     assert [f[0] for f in S._fields_] == ["cost_type", "use_mgm", "kernel_size", "subpixel_mode", "search_buffer_x", "search_buffer_y",
-                                          "memory_limit_mb", "p1", "p2", "ternary_census_threshold", "num_threads"]
-    assert S.memory_limit_mb.offset == 24 and ctypes.sizeof(S) == 48
+                                          "memory_limit_mb", "p1", "p2", "ternary_census_threshold", "num_threads", "allow_block_cost"]
+    assert S.memory_limit_mb.offset == 24 and S.allow_block_cost.offset == 48 and ctypes.sizeof(S) == 56
     # the header spells the same field order
     import os
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "vwgpu.h")).read()

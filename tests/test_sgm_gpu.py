@@ -34,12 +34,13 @@ def _pair(rng, h, w, sx, sy, shift=(3, 2), smooth=False, scale=255.0):
     return np.ascontiguousarray(left), np.ascontiguousarray(right)
 
 
-def _both(vw, oracle, cost, left, right, search, k, sub, sb=(2, 2), mem=6000, lm=None, rm=None, prev=None, mgm=False, p1=0, p2=0):
+def _both(vw, oracle, cost, left, right, search, k, sub, sb=(2, 2), mem=6000, lm=None, rm=None, prev=None, mgm=False, p1=0, p2=0, block=False):
     h, w = left.shape
     gi, gs = vw.calc_disparity_sgm(cost, left, right, _box(w, h), search, (k, k), use_mgm=mgm, subpixel_mode=sub, search_buffer=sb,
-                                   memory_limit_mb=mem, left_mask=lm, right_mask=rm, prev_disparity=prev, with_subpixel=True, p1=p1, p2=p2)
+                                   memory_limit_mb=mem, left_mask=lm, right_mask=rm, prev_disparity=prev, with_subpixel=True, p1=p1, p2=p2,
+                                   allow_block_cost=block)
     oi, os_ = oracle.calc_disparity_sgm(cost, left, right, search, k, subpixel=sub, search_buffer=sb, memory_limit_mb=mem,
-                                        left_mask=lm, right_mask=rm, prev_disparity=prev, use_mgm=mgm, p1=p1, p2=p2)
+                                        left_mask=lm, right_mask=rm, prev_disparity=prev, use_mgm=mgm, p1=p1, p2=p2, allow_block_cost=block)
     return gi, gs, oi, os_
 
 
@@ -154,6 +155,72 @@ def test_torch_device_entry_and_errors(vw, oracle):
         vw.calc_disparity_sgm(0, left, right, _box(50, 40), (5, 3), (5, 5), use_mgm=True)   # block cost with MGM
     with pytest.raises(ArgumentErr):
         vw.calc_disparity_sgm(CENSUS, left, right, _box(51, 40), (5, 3), (5, 5))
+
+
+# ---- the mean-abs-difference block cost (fill_costs_block, SGM.cc:1651-1738): behind the reference's throw, opt-in here ------
+
+@pytest.mark.parametrize("cost", [0, 1])
+@pytest.mark.parametrize("k,sx,w,h", [(7, 128, 300, 40), (3, 33, 530, 20), (5, 64, 257, 23), (9, 40, 100, 30), (11, 17, 70, 30),
+                                      (13, 20, 80, 36), (1, 12, 60, 20), (15, 9, 64, 40)])
+def test_block_cost_one_search_row(vw, oracle, cost, k, sx, w, h):
+    """BASELINE configs[3] as written (a SAD-class cost into SGM): uniform one-row searches take the packed qsad kernel for kernels
+    3 .. 11 and the general kernel otherwise; ABSOLUTE_DIFFERENCE and SQUARED_DIFFERENCE both mean "mean of abs differences"."""
+    rng = np.random.default_rng(100 * k + sx + cost)
+    left, right = _pair(rng, h, w, sx, 0, shift=(sx // 3, 0), smooth=(k == 5))
+    gi, gs, oi, os_ = _both(vw, oracle, cost, left, right, (sx, 0), k, 5, block=True)
+    assert gi.shape == oi.shape == (h - k + 1, w - k + 1, 3)
+    assert np.array_equal(gi, oi), int((gi != oi).any(-1).sum())
+    assert np.abs(gs - os_).max() < 1e-5
+    assert (gi[..., 0] == sx // 3).mean() > 0.8
+
+
+def test_block_cost_extreme_values_and_division(vw, oracle):
+    """Costs of 0 and 255 (black against white), pad bytes of the packed kernel next to 255-valued pixels, a flat pair."""
+    rng = np.random.default_rng(4)
+    left = (rng.random((30, 140)) > 0.5).astype(np.float32) * 255.0
+    right = np.concatenate([255.0 - left[:, :20], left, (rng.random((30, 60)) > 0.5).astype(np.float32) * 255.0], axis=1).astype(np.float32)
+    for k in (3, 5, 7, 9, 11):
+        gi, gs, oi, os_ = _both(vw, oracle, 0, left, right, (80, 0), k, 5, block=True)
+        assert np.array_equal(gi, oi), k
+    flat = np.full((20, 90), 77.0, np.float32); flat[0, 0] = 0; flat[-1, -1] = 255
+    rflat = np.full((20, 120), 77.0, np.float32); rflat[0, 0] = 0; rflat[-1, -1] = 255
+    gi, gs, oi, os_ = _both(vw, oracle, 0, flat, rflat, (30, 0), 7, 5, block=True)
+    assert np.array_equal(gi, oi)
+
+
+def test_block_cost_ragged_boxes_two_d_and_mgm(vw, oracle):
+    rng = np.random.default_rng(12)
+    left, right = _pair(rng, 64, 96, 12, 12)
+    k = 5
+    oh, ow = 64 - k + 1, 96 - k + 1
+    lm = np.full((oh, ow), 255, np.uint8)
+    lm[10:20, 10:30] = 0
+    rm = np.full((oh + 12, ow + 12), 255, np.uint8)
+    rm[:, -9:] = 0
+    prev = np.zeros(((oh + 1) // 2, (ow + 1) // 2, 3), np.int32)
+    prev[..., 0], prev[..., 1], prev[..., 2] = 2, 1, np.iinfo(np.int32).max
+    prev[5:12, 8:20, 2] = 0
+    gi, gs, oi, os_ = _both(vw, oracle, 0, left, right, (12, 12), k, 5, lm=lm, rm=rm, prev=prev, block=True)
+    assert np.array_equal(gi, oi) and np.abs(gs - os_).max() < 1e-5
+    gi, gs, oi, os_ = _both(vw, oracle, 0, left, right, (12, 12), k, 5, block=True)              # uniform 2-D search
+    assert np.array_equal(gi, oi)
+    gi, gs, oi, os_ = _both(vw, oracle, 0, left, right, (12, 12), k, 5, lm=lm, mgm=True, block=True, p1=5, p2=90)
+    assert np.array_equal(gi, oi)
+
+
+def test_block_cost_needs_the_opt_in(vw, oracle):
+    from visionworkbench_amd.core import ArgumentErr, NoImplErr
+    rng = np.random.default_rng(13)
+    left, right = _pair(rng, 40, 50, 5, 3)
+    for cost in (0, 1, 2):
+        with pytest.raises(NoImplErr):
+            vw.calc_disparity_sgm(cost, left, right, _box(50, 40), (5, 3), (5, 5))                 # SGM.cc:1887-1892
+    with pytest.raises(NoImplErr):
+        vw.calc_disparity_sgm(2, left, right, _box(50, 40), (5, 3), (5, 5), allow_block_cost=True)  # the NCC flavour is not restated
+    with pytest.raises(ArgumentErr):
+        vw.calc_disparity_sgm(0, left, right, _box(50, 40), (5, 3), (17, 17), allow_block_cost=True)
+    with pytest.raises(ValueError):
+        oracle.calc_disparity_sgm(0, left, right, (5, 3), 5)
 
 
 # ---- pyramid_correlate with VW_CORRELATION_SGM ------------------------------------------------------------------------

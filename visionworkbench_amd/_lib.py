@@ -36,6 +36,7 @@ class SgmParams(ctypes.Structure):
         ("cost_type", ctypes.c_int), ("use_mgm", ctypes.c_int), ("kernel_size", ctypes.c_int), ("subpixel_mode", ctypes.c_int),
         ("search_buffer_x", ctypes.c_int), ("search_buffer_y", ctypes.c_int), ("memory_limit_mb", ctypes.c_size_t),
         ("p1", ctypes.c_int), ("p2", ctypes.c_int), ("ternary_census_threshold", ctypes.c_int), ("num_threads", ctypes.c_int),
+        ("allow_block_cost", ctypes.c_int),
     ]
 
 

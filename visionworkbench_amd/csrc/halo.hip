@@ -6,8 +6,9 @@
 // node (one process per GPU), a rank's tiles need the rows of its strip plus half_kernel * 2^levels + search (+ collar) rows above
 // and below, which live on the neighbouring ranks.  One point-to-point transfer per neighbour that owns needed rows, all of a
 // call inside one ncclGroupStart / ncclGroupEnd on the context's stream — xGMI is point-to-point, a ring or tree collective
-// would only add hops.  The Python mirror (visionworkbench_amd/partition.py, torch.distributed) has the same plan and is what the
-// gloo tests and bench.py drive; this is the same exchange for C++ hosts that do not link torch.
+// would only add hops.  bench.py --gpus N drives THIS exchange (partition.EngineComm; the unique id travels over the process group
+// that launched the ranks), C++ hosts through vw::engine::StripComm; the torch.distributed mirror in visionworkbench_amd/partition.py
+// has the same plan, runs on gloo in the CPU tests and is bench.py's stated fallback.
 //
 // librccl.so is opened at run time (dlopen): a single-GPU installation does not need it, and libvwgpu.so does not link it.
 #include <dlfcn.h>
@@ -15,6 +16,7 @@
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "vwgpu_internal.h"
 
@@ -131,6 +133,40 @@ int vwgpu_fetch_strip_window_dev(vwgpu_ctx* ctx, vwgpu_comm* comm, const void* d
   char* win = static_cast<char*>(d_window);
   const char* own = static_cast<const char*>(d_owned);
   VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  // Every rank must describe the same image and halos, or the byte counts of a send and its receive differ and a rank waits
+  // for ever.  The request is compared with every neighbour it is about to talk to first: a 32-byte header each way, one
+  // group — ranks whose headers differ fail on BOTH sides, after the exchange of headers has completed.
+  if (world > 1) {
+    rc = vwgpu_arena_reserve(ctx, &ctx->misc, 4096);
+    if (rc) return rc;
+    long long* hdr = reinterpret_cast<long long*>(static_cast<char*>(ctx->misc.base) + 1024);     // [0..3] mine, [4 + 4 p ..] rank p's
+    if ((size_t)(4 + 4 * world) * sizeof(long long) > 3072) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "vwgpu_fetch_strip_window_dev: more than 95 ranks");
+    const long long mine[4] = {rows_total, halo_above, halo_below, (long long)cols * elem_bytes};
+    VWGPU_HIP(ctx, hipMemcpyAsync(hdr, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<int> peers;
+    for (int p = 0; p < world; ++p) {
+      if (p == rank) continue;
+      int pa, pb, pna, pnb;
+      vwgpu_halo_plan(p, world, rows_total, halo_above, halo_below, &pa, &pb, &pna, &pnb);
+      if (std::max(na, pa) < std::min(nb, pb) || std::max(pna, a) < std::min(pnb, b)) peers.push_back(p);
+    }
+    int hrc = r.GroupStart();
+    for (int p : peers) {
+      if (hrc == 0) hrc = r.Recv(hdr + 4 + 4 * p, sizeof mine, 0, p, comm->comm, ctx->stream);
+      if (hrc == 0) hrc = r.Send(hdr, sizeof mine, 0, p, comm->comm, ctx->stream);
+    }
+    const int herc = r.GroupEnd();
+    if (hrc == 0) hrc = herc;
+    if (hrc != 0) return vwgpu_fail(ctx, VWGPU_ERR_HIP, "RCCL halo header exchange failed: %s", r.GetErrorString ? r.GetErrorString(hrc) : "?");
+    std::vector<long long> got((size_t)4 * world);
+    VWGPU_HIP(ctx, hipMemcpyAsync(got.data(), hdr + 4, got.size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int p : peers)
+      if (memcmp(&got[(size_t)4 * p], mine, sizeof mine) != 0)
+        return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "vwgpu_fetch_strip_window_dev: rank %d asked for (rows %lld, halos %lld / %lld, %lld bytes per row), rank %d for "
+                          "(%d, %d / %d, %lld): every rank must pass the same image and halos", p, got[(size_t)4 * p], got[(size_t)4 * p + 1],
+                          got[(size_t)4 * p + 2], got[(size_t)4 * p + 3], rank, rows_total, halo_above, halo_below, (long long)cols * elem_bytes);
+  }
   // my own rows
   if (b > a) VWGPU_HIP(ctx, hipMemcpyAsync(win + (size_t)(a - na) * rowb, own, (size_t)(b - a) * rowb, hipMemcpyDeviceToDevice, ctx->stream));
   int nrc = r.GroupStart();

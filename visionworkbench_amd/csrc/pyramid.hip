@@ -628,6 +628,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   SP.cost_type = P->cost_type; SP.use_mgm = 0; SP.kernel_size = kx; SP.subpixel_mode = P->sgm_subpixel_mode;
   SP.search_buffer_x = P->sgm_search_buffer_x; SP.search_buffer_y = P->sgm_search_buffer_y; SP.memory_limit_mb = P->memory_limit_mb;
   SP.p1 = 0; SP.p2 = 0; SP.ternary_census_threshold = 5; SP.num_threads = P->sgm_num_threads > 0 ? P->sgm_num_threads : 1;
+  SP.allow_block_cost = 0;        // (the pyramid view only ever hands census costs to SGM, CorrelationView.cc:391-403)
   std::vector<vwgpu::LeafExtent> leaf_ext;
   std::vector<SearchZone> zones;
   zones.push_back(SearchZone{IBox(0, 0, lmp[L].w, lmp[L].h), IBox(0, 0, search.width() / up + 1, search.height() / up + 1)});

@@ -375,6 +375,134 @@ cost_row_kernel(const uint64_t* __restrict__ lc, int lcw, const uint64_t* __rest
   }
 }
 
+// ---- the mean-abs-difference block cost (opt-in) ------------------------------------------------------------------------
+// get_cost_block / fill_costs_block (src/vw/Stereo/SGM.cc:1651-1738, "Mean of abs differences" branch): cost = min(255,
+// (sum over the k x k window of |L - R|) / (k * k)) on the u8 images, integer division.  The reference keeps this path behind a
+// NoImplErr (:1887-1892); vwgpu_sgm_params.allow_block_cost opts in (BASELINE configs[3] names a SAD cost into SGM).
+// Exact division of n < 2^16 by the window's pixel count: __umulhi(n, 2^32 / c + 1) (checked exhaustively by the launcher).
+//
+// General form: one wavefront per pixel, lane = disparity of the pixel's box (any bounds: masks, previous level, 2-D searches).
+__global__ void __launch_bounds__(256)
+cost_block_kernel(const uint8_t* __restrict__ l8, int lw, const uint8_t* __restrict__ r8, int rw, const B4* __restrict__ bounds,
+                  const unsigned long long* __restrict__ starts, int ocols, size_t npix, int min_col, int min_row, int kernel, unsigned magic,
+                  uint8_t* __restrict__ cost) {
+  const size_t p = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= npix) return;
+  const int lane = threadIdx.x & 63;
+  const B4 b = bounds[p];
+  const int wd = b.x1 - b.x0 + 1, n = wd * (b.y1 - b.y0 + 1);
+  if (n <= 0) return;
+  const int r = (int)(p / ocols), c = (int)(p - (size_t)r * ocols);
+  const int hk = (kernel - 1) / 2;
+  const uint8_t* lp = l8 + (size_t)(r + min_row - hk) * lw + (c + min_col - hk);
+  uint8_t* o = cost + starts[p];
+  for (int i = lane; i < n; i += 64) {
+    const int qy = i / wd, qx = i - qy * wd;
+    const uint8_t* rp = r8 + (size_t)(r + min_row - hk + b.y0 + qy) * rw + (c + min_col - hk + b.x0 + qx);
+    unsigned sum = 0;
+    for (int j = 0; j < kernel; ++j)
+      for (int k = 0; k < kernel; ++k) sum += (unsigned)abs((int)lp[(size_t)j * lw + k] - (int)rp[(size_t)j * rw + k]);
+    const unsigned q = kernel == 1 ? sum : __umulhi(sum, magic);
+    o[i] = (uint8_t)min(q, 255u);
+  }
+}
+
+__host__ __device__ inline int block_row_dwords(int num_disp, int nw) { const int n = (256 + num_disp + 4 * nw + 8) / 4 + 1; return (n + 15) / 32 * 32 + 16; }
+
+// Uniform layout, one search row (config 4's single-level strips): a workgroup owns 256 consecutive pixels of a row.  The K right
+// rows its windows can reach are staged in LDS as dwords at EVERY byte offset (four pre-shifted copies), the lane's K x K left
+// window lives in registers as NW = ceil(K / 4) dwords per row with the bytes beyond K cleared, and four consecutive disparities
+// are one chain of v_qsad_pk_u16_u8 down the rows: slot i = sum over (row, word) of SAD4(R[x + d + i + 4n ..], L[4n ..]).
+// The cleared left bytes pick up |0 - R| = R at the window positions K .. 4 NW - 1: that excess is the column sum of the right rows
+// there — formed once per workgroup — and is subtracted; then the exact division and one 8-byte store per 8 disparities.
+template <int K>
+__global__ void __launch_bounds__(256)
+cost_block_row_kernel(const uint8_t* __restrict__ l8, int lw, int lh, const uint8_t* __restrict__ r8, int rw, int rh, int ocols, int num_disp, int stride,
+                      int min_col, int min_row, unsigned magic, uint8_t* __restrict__ cost) {
+  constexpr int NW = (K + 3) / 4, HK = (K - 1) / 2, PAD = 4 * NW - K;
+  extern __shared__ unsigned lds_u32[];
+  const int tid = threadIdx.x, c0 = blockIdx.x * 256, r = blockIdx.y;
+  const int rlw = block_row_dwords(num_disp, NW);                       // dwords per staged row (% 32 == 16: the four copies a wave reads fall on disjoint banks)
+  unsigned* shifted = lds_u32;                                           // [K][4][rlw]: dword i of copy t = bytes 4 i + t .. 4 i + t + 3 of the row
+  unsigned* colsum = shifted + K * 4 * rlw;                              // [4 * rlw]: sum of the K rows' bytes at each column
+  unsigned* base = colsum + 4 * rlw;                                     // [K][rlw + 1]: the rows as aligned dwords
+  const int x0 = c0 + min_col - HK;                                      // image column of byte 0 of the staged rows (may be < 0 never: min_col >= HK)
+  for (int j = 0; j < K; ++j) {
+    const uint8_t* row = r8 + (size_t)min(r + min_row - HK + j, rh - 1) * rw;
+    for (int i = tid; i < rlw + 1; i += 256) {
+      unsigned w = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) w |= (unsigned)row[min(x0 + 4 * i + b, rw - 1)] << (8 * b);
+      base[j * (rlw + 1) + i] = w;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < K * rlw; i += 256) {
+    const int j = i / rlw, w = i - j * rlw;
+    const unsigned lo = base[j * (rlw + 1) + w], hi = base[j * (rlw + 1) + w + 1];
+    shifted[(j * 4 + 0) * rlw + w] = lo;
+    shifted[(j * 4 + 1) * rlw + w] = __builtin_amdgcn_alignbyte(hi, lo, 1);
+    shifted[(j * 4 + 2) * rlw + w] = __builtin_amdgcn_alignbyte(hi, lo, 2);
+    shifted[(j * 4 + 3) * rlw + w] = __builtin_amdgcn_alignbyte(hi, lo, 3);
+  }
+  for (int i = tid; i < 4 * rlw; i += 256) {
+    unsigned sum = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) sum += (base[j * (rlw + 1) + (i >> 2)] >> (8 * (i & 3))) & 0xffu;
+    colsum[i] = sum;
+  }
+  // the lane's left window
+  const int c = c0 + tid;
+  unsigned lwin[K][NW];
+  {
+    const int lx = min(c, ocols - 1) + min_col - HK;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const uint8_t* row = l8 + (size_t)min(r + min_row - HK + j, lh - 1) * lw;
+#pragma unroll
+      for (int n = 0; n < NW; ++n) {
+        unsigned w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (4 * n + b < K) w |= (unsigned)row[min(lx + 4 * n + b, lw - 1)] << (8 * b);
+        lwin[j][n] = w;
+      }
+    }
+  }
+  __syncthreads();
+  if (c >= ocols) return;
+  const int t = tid & 3, w0 = tid >> 2;
+  uint2* o = reinterpret_cast<uint2*>(cost + ((size_t)r * ocols + c) * stride);
+  for (int d8 = 0; d8 < stride; d8 += 8) {
+    unsigned out[2] = {0u, 0u};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int d = d8 + 4 * h;                                          // disparities d .. d + 3: right bytes from tid + d
+      if (d >= num_disp) continue;                                       // dead slots of the stride stay zero
+      unsigned long long acc = 0ull;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const unsigned* sr = shifted + (j * 4 + t) * rlw + w0 + (d >> 2);
+        unsigned w[NW + 1];
+#pragma unroll
+        for (int n = 0; n <= NW; ++n) w[n] = sr[n];
+#pragma unroll
+        for (int n = 0; n < NW; ++n)
+          acc = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)w[n + 1] << 32) | w[n], lwin[j][n], acc);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned sum = (unsigned)(acc >> (16 * i)) & 0xffffu;
+#pragma unroll
+        for (int q = 0; q < PAD; ++q) sum -= colsum[tid + d + i + K + q];
+        const unsigned v = d + i < num_disp ? min(__umulhi(sum, magic), 255u) : 0u;
+        out[h] |= v << (8 * i);
+      }
+    }
+    o[d8 >> 3] = make_uint2(out[0], out[1]);
+  }
+}
+
 // ---- path aggregation -------------------------------------------------------------------------------------------------
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the global
@@ -1571,6 +1699,11 @@ struct Bump {
 };
 
 void default_p1p2(int cost_type, int kernel, int& p1, int& p2) {     // SGM.cc:105-160
+  if (cost_type != VWGPU_CENSUS_TRANSFORM && cost_type != VWGPU_TERNARY_CENSUS_TRANSFORM) {     // "default: // MAD" (:128-131, :156-158)
+    if (p1 <= 0) p1 = 3;
+    if (p2 <= 0) p2 = 250;
+    return;
+  }
   const bool tern = cost_type == VWGPU_TERNARY_CENSUS_TRANSFORM;
   if (p1 <= 0) p1 = tern ? (kernel == 3 ? 12 : kernel == 5 ? 30 : kernel == 7 ? 40 : kernel == 9 ? 40 : 30)
                          : (kernel == 3 ? 3 : kernel == 5 ? 15 : kernel == 7 ? 30 : kernel == 9 ? 20 : 3);
@@ -1644,7 +1777,8 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     hipLaunchKernelGGL(u8_convert_kernel, dim3((lw + 255) / 256, lh), dim3(256), 0, st, left, ls, lw, lh, mm, l8);
     hipLaunchKernelGGL(u8_convert_kernel, dim3((rw + 255) / 256, rh), dim3(256), 0, st, right, rs, rw, rh, mm + 2, r8);
   }
-  {
+  const bool block_cost = P->cost_type != VWGPU_CENSUS_TRANSFORM && P->cost_type != VWGPU_TERNARY_CENSUS_TRANSFORM;   // opt-in checked by the ABI layer
+  if (!block_cost) {
     vwgpu_prof_scope ps(ctx, "sgm_census");
     const int tern = P->cost_type == VWGPU_TERNARY_CENSUS_TRANSFORM;
     hipLaunchKernelGGL(census_kernel, dim3((lcw + 63) / 64, (lch + 3) / 4), dim3(64, 4), 0, st, l8, lw, lh, kernel, tern, P->ternary_census_threshold, lc);
@@ -1726,7 +1860,28 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   // one direction per launch, plain store / read-modify-write
   const bool dir_paths = uniform && g.num_dy == 1 && !P->use_mgm;      // the first direction initialises the volume
   if (!dir_paths && !P->use_mgm) VWGPU_HIP(ctx, hipMemsetAsync(accum, 0, (size_t)main_buf * 2, st));      // (MGM: mgm_sum_kernel stores)
-  {
+  if (block_cost) {
+    // fill_costs_block (SGM.cc:1711-1738).  Exact n / count for every n the sums can reach: multiply-high by 2^32 / count + 1.
+    vwgpu_prof_scope ps(ctx, "sgm_cost");
+    const unsigned count = (unsigned)(kernel * kernel), magic = (unsigned)((1ull << 32) / count + 1);
+    for (unsigned n = 0; n <= 255u * count; ++n)
+      if ((unsigned)(((unsigned long long)n * magic) >> 32) != n / count) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "calc_disparity_sgm: division constant");
+    const bool fast = uniform && g.num_dy == 1 && (kernel == 3 || kernel == 5 || kernel == 7 || kernel == 9 || kernel == 11);
+    if (fast) {
+      const int nw = (kernel + 3) / 4, rlw = block_row_dwords((int)num_disp, nw);
+      const size_t lds = ((size_t)kernel * 4 * rlw + 4 * rlw + (size_t)kernel * (rlw + 1)) * sizeof(unsigned);
+      const dim3 grd((g.ocols + 255) / 256, g.orows);
+#define VWGPU_BLOCK_ROW(KK) hipLaunchKernelGGL(cost_block_row_kernel<KK>, grd, dim3(256), lds, st, l8, lw, lh, r8, rw, rh, g.ocols, (int)num_disp, ustride, \
+                                               min_col, min_row, magic, cost)
+      switch (kernel) { case 3: VWGPU_BLOCK_ROW(3); break; case 5: VWGPU_BLOCK_ROW(5); break; case 7: VWGPU_BLOCK_ROW(7); break;
+                        case 9: VWGPU_BLOCK_ROW(9); break; default: VWGPU_BLOCK_ROW(11); break; }
+#undef VWGPU_BLOCK_ROW
+    } else {
+      if (uniform) VWGPU_HIP(ctx, hipMemsetAsync(cost, 0, (size_t)main_buf, st));       // the dead slots of the stride
+      hipLaunchKernelGGL(cost_block_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, st, l8, lw, r8, rw, bounds, starts, g.ocols, npix, min_col, min_row,
+                         kernel, magic, cost);
+    }
+  } else {
     vwgpu_prof_scope ps(ctx, "sgm_cost");
     if (uniform)
     {

@@ -10,10 +10,16 @@ int check_sgm(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const void* l, int lw, 
   ctx->err.clear();
   if (!P || !l || !r || !out || !ow || !oh || lw <= 0 || lh <= 0 || rw <= 0 || rh <= 0 || sx < 0 || sy < 0)
     return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity_sgm: null pointer, empty image or negative search volume");
-  if (P->cost_type != VWGPU_CENSUS_TRANSFORM && P->cost_type != VWGPU_TERNARY_CENSUS_TRANSFORM)
+  const bool census = P->cost_type == VWGPU_CENSUS_TRANSFORM || P->cost_type == VWGPU_TERNARY_CENSUS_TRANSFORM;
+  // The reference throws for every other cost (SGM.cc:1887-1892) and so does this, unless the caller opts in to the code behind
+  // that throw: fill_costs_block's mean-abs-difference cost (:1651-1738) for ABSOLUTE_DIFFERENCE / SQUARED_DIFFERENCE (both take
+  // the "Mean of abs differences" branch; the NCC flavour of get_cost_block, cost type 2, is not restated).
+  if (!census && !(P->allow_block_cost == 1 && (P->cost_type == VWGPU_ABSOLUTE_DIFFERENCE || P->cost_type == VWGPU_SQUARED_DIFFERENCE)))
     return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "With SGM/MGM, only the census transform cost mode gives good results.");
-  if (P->kernel_size != 3 && P->kernel_size != 5 && P->kernel_size != 7 && P->kernel_size != 9)
+  if (census && P->kernel_size != 3 && P->kernel_size != 5 && P->kernel_size != 7 && P->kernel_size != 9)
     return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "Census transforms are only available in size 3, 5, 7, and 9.");
+  if (!census && (P->kernel_size < 1 || P->kernel_size % 2 != 1 || P->kernel_size > 15))
+    return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity_sgm: the block cost takes odd kernel sizes 1 .. 15");
   if (P->kernel_size > lw || P->kernel_size > lh)
     return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity_sgm: Kernel size too large of active region.");
   if (P->subpixel_mode < VWGPU_SUBPIXEL_NONE || P->subpixel_mode > VWGPU_SUBPIXEL_LC_BLEND)

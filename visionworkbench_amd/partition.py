@@ -117,7 +117,8 @@ def fetch_strip_window(owned, rank, world, rows_total, halo_above, halo_below, g
 
 
 # ---- the same exchange through the engine's C ABI (csrc/halo.hip: RCCL send / recv, librccl.so opened at run time) -------------
-# For C++ hosts that do not link torch; the torch.distributed functions above are what bench.py and the gloo tests drive.
+# What bench.py --gpus N drives (the unique id travels over the process group that launched the ranks); C++ hosts that do not
+# link torch use vw::engine::StripComm.  The torch.distributed functions above are the gloo-testable mirror and the fallback.
 
 def halo_plan(rank, world, rows_total, halo_above, halo_below):
     """(owned_a, owned_b, need_a, need_b) of `rank` as vwgpu_halo_plan computes them (pure host arithmetic)."""
@@ -172,3 +173,15 @@ class EngineComm:
         if getattr(self, "_h", None):
             self._ctx._lib.vwgpu_comm_destroy(self._h)
             self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown: the library may be gone)
+            pass

@@ -368,8 +368,12 @@ SUBPIXEL_NONE, SUBPIXEL_PARABOLA, SUBPIXEL_LINEAR, SUBPIXEL_POLY4, SUBPIXEL_COSI
 def calc_disparity_sgm(cost_type, left_in, right_in, left_region, search_volume, kernel_size, use_mgm=False,
                        subpixel_mode=SUBPIXEL_LC_BLEND, search_buffer=(2, 2), memory_limit_mb=6000,
                        left_mask=None, right_mask=None, prev_disparity=None, p1=0, p2=0, ternary_census_threshold=5,
-                       num_threads=1, with_subpixel=False, ctx=None):
+                       num_threads=1, with_subpixel=False, allow_block_cost=False, ctx=None):
     """vw::stereo::calc_disparity_sgm (src/vw/Stereo/SGM.h:360-375, SGM.cc:167-229).
+
+    allow_block_cost (not an argument of the reference's function): cost types ABSOLUTE_DIFFERENCE / SQUARED_DIFFERENCE raise
+    NoImplErr exactly as compute_disparity_costs throws (SGM.cc:1887-1892) unless this is True, which runs the code behind that
+    throw — fill_costs_block's mean-abs-difference block cost (SGM.cc:1651-1738; p1 = 3, p2 = 250 by default).
 
     left_in / right_in: (rows, cols) float32; left_region: BBox2i inside the left image; search_volume = (sx, sy) is
     INCLUSIVE like the reference's (the right crop is left_region grown by search_volume, so (sx+1) x (sy+1) disparities
@@ -393,7 +397,7 @@ def calc_disparity_sgm(cost_type, left_in, right_in, left_region, search_volume,
         raise ArgumentErr("calc_disparity_sgm: Kernel size too large of active region.")
     rx1, ry1 = min(x1 + sx, right_in.shape[1]), min(y1 + sy, right_in.shape[0])
     P = SgmParams(int(cost_type), int(bool(use_mgm)), kx, int(subpixel_mode), int(search_buffer[0]), int(search_buffer[1]),
-                  int(memory_limit_mb), int(p1), int(p2), int(ternary_census_threshold), int(num_threads))
+                  int(memory_limit_mb), int(p1), int(p2), int(ternary_census_threshold), int(num_threads), int(bool(allow_block_cost)))
     ctx = _ctx_for(left_in, ctx)
     lib = ctx._lib
     ow, oh = ctypes.c_int(), ctypes.c_int()

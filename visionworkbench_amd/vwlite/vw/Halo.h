@@ -45,8 +45,12 @@ public:
     if (vwgpu_comm_unique_id(id.data()) != VWGPU_OK) vw_throw(LogicErr() << "engine::StripComm: librccl.so is not available");
     return id;
   }
+  /// device < 0: devices()[rank % ndev] — one process per GPU, rank r on the r-th device of the list (NOT the calling thread's
+  /// default device, which is the first one on every rank's main thread: RCCL refuses two ranks on one GPU).
   StripComm(std::vector<char> const& id, int rank, int world, int device = -1) : m_rank(rank), m_world(world) {
     VW_ASSERT((int)id.size() == VWGPU_COMM_ID_BYTES, ArgumentErr() << "engine::StripComm: the unique id has 128 bytes");
+    VW_ASSERT(world >= 1 && rank >= 0 && rank < world, ArgumentErr() << "engine::StripComm: rank " << rank << " of " << world);
+    if (device < 0) { std::vector<int> d = devices(); device = d[(size_t)rank % d.size()]; }
     m_ctx = thread_context(device);
     check(m_ctx, vwgpu_comm_create(m_ctx, id.data(), rank, world, &m_comm));
   }
@@ -56,6 +60,8 @@ public:
   int rank() const { return m_rank; }
   int world() const { return m_world; }
   /// d_owned: this rank's rows, contiguous, in device memory; d_window: room for (need_b - need_a) x cols elements.
+  /// Every rank calls this with the SAME (cols, elem_bytes, rows_total, halo_above, halo_below); the engine compares the requests
+  /// of neighbouring ranks before moving rows and throws ArgumentErr on both sides of a mismatch.
   /// Asynchronous on the calling thread's context stream; returns the first row of the window.
   int fetch_strip_window(const void* d_owned, int cols, int elem_bytes, int rows_total, int halo_above, int halo_below, void* d_window) {
     int first = 0;
