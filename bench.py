@@ -262,7 +262,7 @@ def measure(ctx, torch, fn, reps, warm=2):
     return wall, {k: v / reps * 1e3 for k, v in per.items()}
 
 
-def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right):
+def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right, with_cpu=True):
     """The other measured points of the path (see the module docstring).  Bounded: a few dozen calls in total."""
     out = []
 
@@ -275,16 +275,31 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right):
         e.update(kw)
         out.append(e)
 
+    cores = os.cpu_count() or 1
+
+    def cpu(fn, jobs, threads, px_per_job, what, budget_s=4.0):
+        """A bounded CPU leg beside a GPU point: the oracle on `threads` host threads, one tile per task (see threaded_tiles)."""
+        if not with_cpu:
+            return None
+        done, dt = threaded_tiles(fn, jobs, threads, budget_s)
+        return {"value": done * px_per_job / dt / 1e6, "unit": "Mpix/s", "cores": threads, "kind": "port",
+                "sample": "%d x %s on %d host threads (of %d), %.1f s wall" % (done, what, threads, cores, dt)}
+
+    import oracle
     bb = vwa.bounding_box(left)
     # (1) the headline kernel at +-16 px: 33 disparities
     r33 = rt[:, 48:48 + W + 32].contiguous()
     wall, kern = measure(ctx, torch, lambda: stereo.calc_disparity(0, lt, r33, bb, (33, 1), KERNEL, ctx=ctx), 40)
     entry("4096^2, 7x7 SAD, search 33x1 (+-16 px)", algorithmic_bytes(W, H, 7, 7, 33, 1), "4LW + 4RW + 12 out (SURVEY 8d)", wall, kern,
-          {"bm_sad_u8"}, (W - 6) * (H - 6), path=ctx.last_path())
+          {"bm_sad_u8"}, (W - 6) * (H - 6), path=ctx.last_path(),
+          cpu_baseline=cpu(lambda j: oracle.calc_disparity(0, left[j:j + 262, :1030], right[j:j + 262, 48:48 + 1030 + 32], KERNEL, (33, 1)),
+                           [256 * (i % 15) for i in range(16 * cores)], cores, 256 * 1024, "256 x 1024-px output tile, 7x7 SAD, 33 disparities"))
     # (2) BASELINE config 3: 11x11 NCC over 129x1, then parabola_subpixel on the result
     wall, kern = measure(ctx, torch, lambda: stereo.calc_disparity(2, lt, rt, bb, SEARCH, (11, 11), ctx=ctx), 10)
     entry("config 3a: 4096^2, 11x11 NCC, search 129x1", algorithmic_bytes(W, H, 11, 11, 129, 1), "4LW + 4RW + 12 out (SURVEY 8d)", wall, kern,
-          {"bm_corr_u8", "ncc_full", "bm_dot_u8"}, (W - 10) * (H - 10), path=ctx.last_path())
+          {"bm_corr_u8", "ncc_full", "bm_dot_u8"}, (W - 10) * (H - 10), path=ctx.last_path(),
+          cpu_baseline=cpu(lambda j: oracle.calc_disparity(2, left[j:j + 266, :266], right[j:j + 266, :266 + 128], (11, 11), SEARCH),
+                           [256 * (i % 15) for i in range(8 * cores)], cores, 256 * 256, "256^2 output tile (the library's default tile), 11x11 NCC, 129 disparities"))
     d = stereo.calc_disparity(2, lt, rt, bb, SEARCH, (11, 11), ctx=ctx)
     disp = torch.zeros((H, W, 3), dtype=torch.float32, device=lt.device)
     disp[5:5 + H - 10, 5:5 + W - 10, :2] = d[..., :2].float()
@@ -292,7 +307,9 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right):
     wall, kern = measure(ctx, torch, lambda: stereo.parabola_subpixel(disp, lt, rt, 0, 0.0, (11, 11), ctx=ctx), 10)
     pb = 4 * W * H + 4 * (W + 128) * H + 12 * W * H + 12 * W * H
     entry("config 3b: parabola_subpixel 11x11 on the 4096^2 NCC result", pb, "4LW + 4RW + 12 disparity in + 12 out (SURVEY 8d)", wall, kern,
-          {k for k in kern if k.startswith("parabola") or k in ("disparity_range", "float_grain", "edge_extend_sub")}, W * H)
+          {k for k in kern if k.startswith("parabola") or k in ("disparity_range", "float_grain", "edge_extend_sub")}, W * H,
+          cpu_baseline=cpu(lambda j, dh=disp[:512, :512].cpu().numpy(): oracle.parabola_subpixel(dh, left[:512, :512], right[:512, :512 + 128], 0, 0.0, (11, 11)),
+                           list(range(4 * cores)), cores, 512 * 512, "512^2 crop of the same NCC result through parabola_subpixel 11x11"))
     # (3) SGM building block of config 4: 2048^2, census 7x7, 129 disparities, 8 paths, LC-blend sub-pixel
     n = 2048
     ls, rs_ = lt[:n, :n].contiguous(), rt[:n, :n + 128].contiguous()
@@ -301,7 +318,8 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right):
     npx = (n - 6) * (n - 6)
     entry("config 4 building block: SGM 2048^2, census 7x7, 129 disparities", npx * (20 + 11 * 129),
           "materialised volume (20 + 11 D) B/px (SURVEY 8d; the minimum model is 20 + 4 D = 536 B/px)", wall, kern,
-          {k for k in kern if k.startswith("sgm")}, npx, min_model_frac=None)
+          {k for k in kern if k.startswith("sgm")}, npx, min_model_frac=None,
+          cpu_baseline=cpu_baseline_sgm(synth, 3, 7, 129, budget_s=5.0) if with_cpu else None)
     e = out[-1]
     if e["hot_us"]:
         e["min_model_frac"] = round(npx * 536 / (e["hot_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
@@ -313,7 +331,9 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right):
     wall, kern = measure(ctx, torch, mgm, 3, warm=1)
     npx = (n - 6) * (n - 6)
     entry("MGM (use_mgm) 1024^2, census 7x7, 129 disparities", npx * (20 + (66 + 3) * 129), "direction volumes: (20 + 69 D) B/px (DESIGN.md 4.6b)", wall, kern,
-          {k for k in kern if k.startswith("sgm")}, npx, fronts=2 * n - 13, note="launch bound: one launch per front")
+          {k for k in kern if k.startswith("sgm")}, npx, fronts=2 * n - 13,
+          cpu_baseline=cpu(lambda j, a=left[:518, :518].copy(), b=right[:518, :518 + 128].copy(): oracle.calc_disparity_sgm(3, a, b, (128, 0), 7, use_mgm=True),
+                           list(range(2 * min(cores, 32))), min(cores, 32), 512 * 512, "512^2 tile, census 7x7, 129 disparities, use_mgm"))
     # (4) the tile loop of config 5 (tools/correlate.cc:207-266): pyramid_correlate over the 4096^2 pair in 1024^2 tiles, pulled by
     # 4 tile threads, each with its own engine context and stream — the way block_write_image runs the reference's view
     import threading
@@ -337,10 +357,18 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right):
             torch.cuda.synchronize(lt.device); dt_ = time.perf_counter() - t0
             if rep > 0: best = dt_ if best is None else min(best, dt_)
         for c_ in ctxs: c_.close()
+        nl = [1024 * 1024 / 4 ** l for l in range(6)]
+        tile_bytes = 2 * (4.0 / 3.0) * 5 * nl[0] + sum((20 + 24) * n for n in nl) + 20 * nl[0]       # the config-5 byte model (run_config5)
+        cb = None
+        if with_cpu:
+            cb = cpu_baseline_pyramid(left, np.ascontiguousarray(right[:, 64:64 + W]), [dict(name="bm", pf=pf, pfw=pw, kernel=(kk, kk), cost=cost, alg=0)],
+                                      (-64, -1, 65, 2), 5, budget_s=4.0)["bm"]
         out.append({"name": "config 5 building block: pyramid_correlate tile loop, 4096^2 in 16 tiles of 1024^2, %s, +-64 x +-1, 5 levels, L/R check, "
                             "4 tile threads" % label, "wall_ms_per_pair": round(best * 1e3, 2), "ms_per_tile": round(best * 1e3 / len(tiles), 3),
-                    "Mpix_per_s": round(W * H / best / 1e6, 1), "roofline_frac": None,
-                    "note": "throughput of the threaded tile loop; per-kernel times of one tile: tools/pyr_profile.py"})
+                    "Mpix_per_s": round(W * H / best / 1e6, 1), "algorithmic_bytes": int(tile_bytes * len(tiles)),
+                    "bytes_model": "SURVEY 8d summed over the levels of a tile (pyramid build + BM bytes per level, level 0 twice + clean-up chain)",
+                    "roofline_frac": round(tile_bytes * len(tiles) / best / 1e9 / HBM_PEAK_GBS, 5), "cpu_baseline": cb,
+                    "note": "throughput of the threaded tile loop (launch / latency bound, not byte bound); per-kernel times of one tile: tools/pyr_profile.py"})
     return out
 
 
@@ -762,7 +790,7 @@ def main():
             res["cpu_baseline"] = None
         if world == 1 and not args.no_extra:
             try:                                  # the headline line must not depend on the side measurements
-                res["extra"] = extra_points(ctx, torch, stereo, core, vwa, synth, l_strip, r_strip, left, right)
+                res["extra"] = extra_points(ctx, torch, stereo, core, vwa, synth, l_strip, r_strip, left, right, with_cpu=not args.no_cpu_baseline)
             except Exception as e:  # noqa: BLE001
                 res["extra"] = [{"name": "extra points failed", "error": "%s: %s" % (type(e).__name__, str(e)[:300])}]
         print(json.dumps(res))

@@ -324,6 +324,11 @@ public:
   ImageView<PixelMask<Vector2f>> m_subpixel;   // filled by calc_disparity_sgm
 };
 
+/// Opt-in to the code the reference keeps behind a throw: with the flag set, calc_disparity_sgm with ABSOLUTE_DIFFERENCE /
+/// SQUARED_DIFFERENCE runs fill_costs_block's mean-abs-difference cost (SGM.cc:1651-1738, p1 = 3, p2 = 250) instead of throwing
+/// NoImplErr like compute_disparity_costs (SGM.cc:1887-1892).  Process wide, off by default; not part of the reference's API.
+inline bool& sgm_allow_block_cost() { static bool flag = false; return flag; }
+
 /// calc_disparity_sgm — the reference's signature (SGM.h:360-375); std::shared_ptr stands in for boost::shared_ptr.
 inline ImageView<PixelMask<Vector2i>>
 calc_disparity_sgm(CostFunctionType cost_type,
@@ -347,6 +352,7 @@ calc_disparity_sgm(CostFunctionType cost_type,
   p.cost_type = (int)cost_type; p.use_mgm = use_mgm ? 1 : 0; p.kernel_size = kernel_size[0]; p.subpixel_mode = (int)subpixel_mode;
   p.search_buffer_x = search_buffer[0]; p.search_buffer_y = search_buffer[1]; p.memory_limit_mb = memory_limit_mb;
   p.p1 = 0; p.p2 = 0; p.ternary_census_threshold = 5; p.num_threads = 1;
+  p.allow_block_cost = sgm_allow_block_cost() ? 1 : 0;
   const size_t cap = (size_t)l.cols() * l.rows();
   std::vector<int32_t> disp(cap * 3);
   std::vector<float> sub(cap * 3);
