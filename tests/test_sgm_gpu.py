@@ -166,7 +166,10 @@ def test_block_cost_one_search_row(vw, oracle, cost, k, sx, w, h):
     """BASELINE configs[3] as written (a SAD-class cost into SGM): uniform one-row searches take the packed qsad kernel for kernels
     3 .. 11 and the general kernel otherwise; ABSOLUTE_DIFFERENCE and SQUARED_DIFFERENCE both mean "mean of abs differences"."""
     rng = np.random.default_rng(100 * k + sx + cost)
-    left, right = _pair(rng, h, w, sx, 0, shift=(sx // 3, 0), smooth=(k == 5))
+    left = np.floor(rng.random((h, w)) * 256).astype(np.float32)
+    right = np.floor(rng.random((h, w + sx)) * 256).astype(np.float32)
+    right[:, sx // 3:sx // 3 + w] = left                                     # left(x, y) = right(x + sx / 3, y)
+    left[0, 0], left[-1, -1] = 0.0, 255.0                                    # u8_convert stretches [min, max] to [0, 255]: keep the values
     gi, gs, oi, os_ = _both(vw, oracle, cost, left, right, (sx, 0), k, 5, block=True)
     assert gi.shape == oi.shape == (h - k + 1, w - k + 1, 3)
     assert np.array_equal(gi, oi), int((gi != oi).any(-1).sum())
