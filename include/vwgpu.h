@@ -98,10 +98,14 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *       group per tile, 2 = two wave groups per tile.
  *   VWGPU_OPT_EXACT_SCRATCH_MB scratch budget of the exact-order path in MiB (16 .. 65536, default 4096): column-sum volumes
  *       beyond it are swept in row bands / zone groups / disparity groups.
- *   VWGPU_OPT_TRACE            bit 0: host-side timeline of a pyramid tile on stderr, bit 1: the zone shapes of a level. */
+ *   VWGPU_OPT_TRACE            bit 0: host-side timeline of a pyramid tile on stderr, bit 1: the zone shapes of a level.
+ *   VWGPU_OPT_SGM_SWEEP        SGM path aggregation of full-range one-row searches (<= 256 disparities): 0 = one direction per launch
+ *       (default: eight passes over the u16 sums, bandwidth bound), 1 = two concurrent fused raster sweeps of four directions each
+ *       (a fifth of the HBM traffic, the same sums; slower on MI355X because a sweep is W + 2 H dependent pixel steps), 2 .. 15 = the
+ *       sweeps with that many rows per workgroup (tuning). */
 typedef enum vwgpu_option {
   VWGPU_OPT_DEFER_EXACTNESS = 1, VWGPU_OPT_DEVICE_COUNT = 2, VWGPU_OPT_SAD_GROUPS = 3, VWGPU_OPT_EXACT_SCRATCH_MB = 4,
-  VWGPU_OPT_TRACE = 5
+  VWGPU_OPT_TRACE = 5, VWGPU_OPT_SGM_SWEEP = 6
 } vwgpu_option;
 int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value);
 int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value);

@@ -157,6 +157,54 @@ def test_torch_device_entry_and_errors(vw, oracle):
         vw.calc_disparity_sgm(CENSUS, left, right, _box(51, 40), (5, 3), (5, 5))
 
 
+# ---- the fused raster sweeps (VWGPU_OPT_SGM_SWEEP; csrc/sgm.hip sweep_uniform_kernel): another schedule, the same sums -------------
+
+@pytest.mark.parametrize("sweep", [1, 2, 5])
+@pytest.mark.parametrize("k,sx,w,h,cost", [(7, 128, 300, 40, CENSUS), (5, 16, 64, 20, CENSUS), (3, 60, 1000, 90, TERNARY), (9, 130, 257, 70, CENSUS),
+                                           (5, 255, 300, 33, CENSUS), (7, 95, 100, 300, TERNARY), (7, 8, 41, 25, CENSUS)])
+def test_fused_sweeps_identical_to_oracle(vw, oracle, sweep, k, sx, w, h, cost):
+    """Two concurrent sweeps of four directions each, one wavefront per row, vectors handed from row to row through LDS rings and
+    from workgroup to workgroup through HBM (1 = as many rows per workgroup as fit, 2 / 5 = pinned: more hand-offs): identical
+    integer disparities, sub-pixel values within 1e-5, for 1 .. 8 disparity pairs per lane and rows that end inside a workgroup."""
+    from visionworkbench_amd import core
+    ctx = core.default_context(0)
+    rng = np.random.default_rng(7 * k + sx + sweep)
+    left = np.floor(rng.random((h, w)) * 256).astype(np.float32)
+    right = np.floor(rng.random((h, w + sx)) * 256).astype(np.float32)
+    right[:, sx // 3:sx // 3 + w] = left
+    ctx.set_option(core.OPT_SGM_SWEEP, sweep)
+    try:
+        gi, gs = vw.calc_disparity_sgm(cost, left, right, _box(w, h), (sx, 0), (k, k), with_subpixel=True, ctx=ctx)
+    finally:
+        ctx.set_option(core.OPT_SGM_SWEEP, 0)
+    oi, os_ = oracle.calc_disparity_sgm(cost, left, right, (sx, 0), k)
+    assert np.array_equal(gi, oi), int((gi != oi).any(-1).sum())
+    assert np.abs(gs - os_).max() < 1e-5
+
+
+def test_fused_sweeps_flat_image_and_user_penalties(vw, oracle):
+    """Ties everywhere (the packed winner-take-all hands the pixel to the smoothing kernel, which must find the SUM of the two sweeps'
+    volumes), and penalties large enough for the u16 sums to wrap."""
+    from visionworkbench_amd import core
+    ctx = core.default_context(0)
+    flat = np.full((30, 90), 77.0, np.float32); flat[0, 0] = 0; flat[-1, -1] = 255
+    rflat = np.full((30, 130), 77.0, np.float32); rflat[0, 0] = 0; rflat[-1, -1] = 255
+    rng = np.random.default_rng(3)
+    left = np.floor(rng.random((40, 120)) * 256).astype(np.float32)
+    right = np.floor(rng.random((40, 160)) * 256).astype(np.float32)
+    right[:, 20:140] = left
+    ctx.set_option(core.OPT_SGM_SWEEP, 1)
+    try:
+        gi, gs = vw.calc_disparity_sgm(CENSUS, flat, rflat, _box(90, 30), (40, 0), (5, 5), with_subpixel=True, ctx=ctx)
+        g2 = vw.calc_disparity_sgm(CENSUS, left, right, _box(120, 40), (40, 0), (7, 7), p1=2000, p2=60000, ctx=ctx)
+    finally:
+        ctx.set_option(core.OPT_SGM_SWEEP, 0)
+    oi, os_ = oracle.calc_disparity_sgm(CENSUS, flat, rflat, (40, 0), 5)
+    assert np.array_equal(gi, oi) and np.abs(gs - os_).max() < 1e-5
+    o2, _ = oracle.calc_disparity_sgm(CENSUS, left, right, (40, 0), 7, p1=2000, p2=60000)
+    assert np.array_equal(g2, o2)
+
+
 # ---- the mean-abs-difference block cost (fill_costs_block, SGM.cc:1651-1738): behind the reference's throw, opt-in here ------
 
 @pytest.mark.parametrize("cost", [0, 1])

@@ -1,0 +1,20 @@
+"""Timing experiments on the fused SGM sweeps with the tools build (gpurun_exp/libvwgpu_dbg.so, -DVWGPU_SWEEP_DEBUG; results are wrong
+with any switch set).  VWGPU_LIBRARY must point at that build.  GPU box only."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from visionworkbench_amd import stereo, synth, core
+from visionworkbench_amd.core import BBox2i
+ctx = core.default_context(0)
+W = H = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+L, R, _ = synth.stereo_pair(W, H, 129, 1)
+Lg, Rg = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+f = lambda: stereo.calc_disparity_sgm(3, Lg, Rg, BBox2i(0, 0, W, H), (128, 0), (7, 7), with_subpixel=True, memory_limit_mb=200000, ctx=ctx)
+for nw in (1,):
+    ctx.set_option(core.OPT_SGM_SWEEP, nw)
+    for dbg in (0, 3, 7, 15):
+        os.environ["VWGPU_SWEEP_DBG"] = str(dbg)
+        f(); torch.cuda.synchronize()
+        ctx.profile_enable(True); ctx.profile_reset(); f(); f(); torch.cuda.synchronize(); rec = ctx.profile_read(4096); ctx.profile_enable(False)
+        t = [m for n, m in rec if n == "sgm_paths"]
+        print("rows/wg %2d dbg %2d (1 no boundary stores, 2 feeder trusts, 4 rows do not wait, 8 no sum stores): sgm_paths %s ms" % (nw, dbg, " ".join("%.2f" % x for x in t)), flush=True)

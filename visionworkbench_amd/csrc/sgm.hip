@@ -1353,6 +1353,423 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
   }
 }
 
+
+// ---- fused raster sweeps (round 3) ------------------------------------------------------------------------------------------
+// One direction per launch touches the u16 sums eight times (27.7 GB per 2048^2 x 129 call, measured).  Here the eight directions
+// run as TWO sweeps over the image that proceed CONCURRENTLY:
+//   forward  (rows top -> bottom, pixels left -> right):  L->R, T->B, TL->BR, TR->BL
+//   backward (rows bottom -> top, pixels right -> left):  R->L, B->T, BR->TL, BL->TR
+// Every pixel is visited once per sweep; the four path vectors of the visit are summed in registers and stored once, into a
+// volume per sweep (the winner-take-all kernels read both): cost read twice (2 x 1 B), sums written twice, read once (3 x 2 B
+// per disparity) instead of 8 x (1 + 2 + 2) B.
+//
+// Mapping: one wavefront per image ROW and sweep, marching along the row.  The four directions of a pixel are the four DPP ROWS
+// of the wavefront (16 lanes each: row 0 = along the row, rows 1..3 = from above, from above-left, from above-right), lane j of a
+// row owns Q consecutive disparity pairs, so ONE packed-u16 evaluation (the arithmetic of path_uniform_reg_kernel) serves all four
+// directions: the d-1 / d+1 neighbours are `row_shr:1` / `row_shl:1` moves (a row's first / last lane keeps its 0xffff guard), the
+// four minima are one four-stage row reduction, the thresholds are per-lane values.  A step is ~110 vector instructions, and the
+// step time IS the run time: row y must stay two pixels behind row y-1 (it needs the vectors of (x, y-1), (x-1, y-1), (x+1, y-1)),
+// so all rows of the image are in flight at once, skewed, and a sweep takes W + 2 H pixel steps.
+// The "from above" vectors travel through an LDS ring per row (producer wave = row y-1, consumer wave = row y of the same
+// workgroup, progress counters in LDS, no barrier).  A workgroup holds NW consecutive rows; its first row takes the vectors of the
+// previous workgroup's last row from HBM: that row stores every 32-bit word as (word, epoch) in one 64-bit coherent store, and a
+// FEEDER wave of the consuming workgroup polls the entries with coherent loads (an entry is complete when every word carries this
+// launch's epoch — no fence, no cache invalidation) and refills an LDS ring for row wave 0.  Workgroups take their (sweep, block)
+// from a ticket counter, so a block's predecessor has always started before it: nothing can wait on work that is not yet scheduled.
+// A line's first pixel starts from r = 0, min_prior = 0 (see path_uniform_reg_kernel): the general step then yields the plain cost.
+//
+// Measured (MI355X, 2048^2 x 129): identical sums, a fifth of the HBM traffic — and 8.0 ms against 5.5 ms for the eight
+// per-direction launches.  The pixel step of a row wave takes ~1 us (130 vector + ~100 other instructions, a dependent chain, 13
+// co-resident rows of a workgroup sharing 4 SIMDs), and the sweep needs W + 2 H of them in sequence, while the per-direction kernel
+// keeps 2048 .. 4101 independent lines in flight and is bandwidth bound.  So the sweeps are an OPTION (VWGPU_OPT_SGM_SWEEP), not
+// the default schedule.
+#ifndef VWGPU_SWEEP_KC
+#define VWGPU_SWEEP_KC 8
+#endif
+constexpr int SWEEP_RING = 8, SWEEP_FRING = 16, SWEEP_FB = 8, SWEEP_KC = VWGPU_SWEEP_KC;
+
+struct SweepParams {
+  SgmGeom g;
+  int stride, lw, min_col, min_row, nblk, nw;
+  unsigned p1, p2, epoch;
+  const uint8_t* left;
+  const uint8_t* cost;
+  uint16_t* out0;
+  uint16_t* out1;
+  unsigned* sync;                    // [0] ticket counter
+  unsigned long long* bnd;           // boundary rows: [sweep][block][pixel][3 vectors + minima] of (word, epoch)
+#ifdef VWGPU_SWEEP_DEBUG
+  int dbg;                           // tools build only (timing experiments, wrong results): 1 no boundary stores, 2 feeder trusts every word, 4 rows do not wait, 8 no sum stores
+#endif
+};
+
+typedef __attribute__((address_space(3))) unsigned lds_uint;
+#ifdef VWGPU_SWEEP_DEBUG
+__device__ unsigned long long sweep_trace[2 * 2048 * 8];          // tools build: [sweep][block][event] timestamps (s_memrealtime, 100 MHz)
+#define SWEEP_STAMP(ev) do { if (tid == 0 && blk < 2048) sweep_trace[((size_t)pass * 2048 + blk) * 8 + (ev)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SWEEP_STAMP(ev) do {} while (0)
+#endif
+
+__device__ __forceinline__ unsigned long long ld_coherent(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_coherent(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// lane j of a DPP row <- lane j -+ 1 of the same row; the row's first / last lane keeps dst (bound_ctrl off): its guard
+__device__ __forceinline__ void row_shr1_keep(unsigned& dst, unsigned src) {
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(dst) : "v"(src));
+}
+__device__ __forceinline__ void row_shl1_keep(unsigned& dst, unsigned src) {
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(dst) : "v"(src));
+}
+// minimum over each DPP row of 16 lanes; every lane of a row ends up with its row's minimum
+__device__ __forceinline__ unsigned row_min_u32(unsigned v) {
+  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1"
+               : "+v"(v));
+  return v;
+}
+template <int N> struct __attribute__((packed, aligned(4))) SweepWords { unsigned v[N]; };
+
+template <int Q>
+__global__ void __launch_bounds__(1024)
+sweep_uniform_kernel(SweepParams A) {
+  constexpr int RING = SWEEP_RING, FRING = SWEEP_FRING, KC = SWEEP_KC;
+  constexpr int VQ = 16 * Q;                                       // dwords of a vector in a slot: every lane of a row addresses its own Q
+  constexpr int SLOT = 3 * VQ + 4;                                 // from above, from above-left, from above-right + their three minima
+  constexpr int NWORDS = 3 * VQ + 4;                              // (the pad word is tagged too)
+  constexpr int FB = (NWORDS + 63) / 64 <= 4 ? SWEEP_FB : SWEEP_FB / 2;   // entries the feeder requests at once: 32 / 28 loads in flight per lane
+  constexpr int NWC = (Q + 1) / 2;                                 // dwords that hold a lane's 2 Q cost bytes (from a dword-aligned address)
+  extern __shared__ unsigned lds_u32[];
+  lds_uint* const sm = (lds_uint*)lds_u32;                         // every LDS access through address-space-3 pointers: ds_* instructions, lgkmcnt only
+  const int tid = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int NW = A.nw;                                             // row waves 0 .. NW-1; wave NW is the feeder
+  const int W = A.g.ocols, H = A.g.orows, stride = A.stride, q32 = stride / 2;
+  const size_t ENT = SLOT;                                         // 64-bit words of a boundary entry (same order as a slot)
+  volatile lds_uint* done = sm + 1;                                // [i]: pixels completed by row wave i; [NW]: entries delivered by the feeder
+  lds_uint* rings = sm + 32;
+  if (threadIdx.x == 0) sm[0] = atomicAdd(&A.sync[0], 1u);
+  if (threadIdx.x >= 1 && threadIdx.x < 32) sm[threadIdx.x] = 0u;
+  __syncthreads();
+  const unsigned ticket = sm[0];
+  const int pass = (int)(ticket & 1u), blk = (int)(ticket >> 1);
+  const unsigned epoch = A.epoch;
+
+  if (wv == NW) {                                                  // ---- feeder: boundary row of the previous block -> LDS ring of row wave 0
+    if (blk == 0) return;
+    constexpr int PER = (NWORDS + 63) / 64;
+    const unsigned long long* src = A.bnd + ((size_t)(pass * A.nblk + blk - 1) * W) * ENT;
+    lds_uint* ring = rings + NW * RING * SLOT;
+    int e = 0;
+    unsigned cons = 0;
+    while (e < W) {
+      const int B = min(FB, W - e);
+      const int needc = e + B - FRING + 2;                         // row wave 0 must be done with the slots about to be overwritten
+      while ((int)cons < needc) {
+#ifdef VWGPU_SWEEP_DEBUG
+        if (A.dbg & 4) break;
+#endif
+        cons = done[0];
+        if ((int)cons < needc) __builtin_amdgcn_s_sleep(2);
+      }
+      unsigned long long wd[FB][PER];
+#pragma unroll
+      for (int b = 0; b < FB; ++b) {
+        const unsigned long long* ent = src + (size_t)min(e + b, W - 1) * ENT;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) wd[b][k] = ld_coherent(ent + min(k * 64 + tid, NWORDS - 1));
+      }
+      int k = 0;                                                   // entries e .. e + k - 1 are complete
+#pragma unroll
+      for (int b = 0; b < FB; ++b) {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) ok = ok && (unsigned)(wd[b][q] >> 32) == epoch;
+#ifdef VWGPU_SWEEP_DEBUG
+        if (A.dbg & 2) ok = true;
+#endif
+        if (__all(ok) && b < B && k == b) k = b + 1;
+      }
+#pragma unroll
+      for (int b = 0; b < FB; ++b) {
+        if (b < k) {                                               // wave-uniform
+          lds_uint* slot = ring + ((e + b) & (FRING - 1)) * SLOT;
+#pragma unroll
+          for (int q = 0; q < PER; ++q)
+            if (q * 64 + tid < NWORDS) slot[q * 64 + tid] = (unsigned)wd[b][q];
+        }
+      }
+      if (k) {
+        if (e == 0) SWEEP_STAMP(4);
+        asm volatile("" ::: "memory");                             // LDS executes a wave's accesses in order: data, then the counter
+        done[NW] = (unsigned)(e + k);
+        e += k;
+      } else {
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    SWEEP_STAMP(5);
+    return;
+  }
+
+  // ---- a row wave
+  const int yy = blk * NW + wv;                                    // row in sweep order
+  if (yy >= H) return;
+  const int sgn = pass ? -1 : 1;
+  const int y = pass ? H - 1 - yy : yy;
+  const bool has_above = yy > 0;
+  const int mode = yy + 1 >= H ? 0 : (wv < NW - 1 ? 1 : 2);      // where this row's vectors go: nowhere / LDS ring / HBM boundary row
+  const int aidx = wv > 0 ? wv - 1 : NW;
+  const int AMASK = (wv > 0 ? RING : FRING) - 1;
+  const lds_uint* aring = rings + aidx * RING * SLOT;
+  volatile lds_uint* adone = done + aidx;
+  lds_uint* oring = rings + wv * RING * SLOT;
+  unsigned long long* bdst = A.bnd + ((size_t)(pass * A.nblk + blk) * W) * ENT;
+
+  const int row = tid >> 4, j = tid & 15;                          // DPP row = direction: 0 along the row, 1 from above, 2 above-left, 3 above-right
+  const int dl = row == 2 ? -1 : (row == 3 ? 1 : 0);              // pixel of the row above this direction continues from
+  const int voff = (row > 0 ? (row - 1) * VQ : 0) + j * Q;        // the lane's dwords inside a slot / boundary entry
+  const int moff = 3 * VQ + (row > 0 ? row - 1 : 0);              // the direction's minimum inside a slot
+  const int num_disp = A.g.num_dx, npairs = (num_disp + 1) / 2;
+  unsigned dead[Q], r[Q];
+#pragma unroll
+  for (int e = 0; e < Q; ++e) {
+    const int p = j * Q + e;
+    dead[e] = p >= npairs ? 0xffffffffu : ((2 * p + 1 >= num_disp) ? 0xffff0000u : 0u);
+    r[e] = dead[e];
+  }
+  unsigned mp = 0;                                                 // min_prior of the lane's direction
+  const bool st_full = row == 0 && j * Q + Q <= q32, st_part = row == 0 && j * Q < q32 && !st_full;
+  const long long p0 = (long long)y * W + (pass ? W - 1 : 0);     // the row's first pixel in sweep order
+  const unsigned cb0 = (unsigned)(2 * Q * j);
+  const uint8_t* cfetch = A.cost + p0 * stride + (cb0 & ~3u);
+  const unsigned csh = (cb0 & 2u) * 8u;                            // odd Q: every other lane's bytes start in the middle of a dword
+  const long long cstep = (long long)sgn * stride;
+  unsigned* ostore = reinterpret_cast<unsigned*>(pass ? A.out1 : A.out0) + p0 * q32 + j * Q;
+  const long long ostep = (long long)sgn * q32;
+  const us2 p1p1 = as_us2(A.p1 | (A.p1 << 16));
+  const unsigned p1 = A.p1, p2 = A.p2;
+  const uint8_t* rowp = A.left + (size_t)(y + A.min_row) * A.lw + A.min_col;
+  const uint8_t* rowa = has_above ? rowp - (long long)sgn * A.lw : rowp;
+  const uint8_t* prow = row == 0 ? rowp : rowa;                    // the row of the lane's predecessor pixel
+
+  // grey values of a block of 16 steps (lane j of every row <-> step s0 + j) and of the direction's predecessor, fetched a block ahead
+  int gc, gp;
+  auto grey = [&](int s0) __attribute__((always_inline)) {
+    const int xs = min(s0 + j, W - 1);
+    const int x = pass ? W - 1 - xs : xs;
+    const int xl = xs > 0 ? x - sgn : x, xr = xs < W - 1 ? x + sgn : x;
+    gc = rowp[x];
+    gp = prow[row == 1 ? x : (row == 3 ? xr : xl)];
+  };
+  grey(0);
+  unsigned penl = 0;
+  auto refresh = [&](int s0) __attribute__((always_inline)) {      // s0 % 16 == 0
+    int grad = gc - gp; grad = grad < 0 ? -grad : grad;
+    unsigned v = p2 / (unsigned)max(grad, 1);
+    if (v < p1) v = p1;
+    penl = v & 0xffffu;
+    grey(min(s0 + 16, W - 1) & ~15);
+  };
+  unsigned pm = 0xffffffffu, pn = 0xffffffffu;
+  unsigned avail = 0, cavail = 0;
+  const int bp_pen = (tid & 48) << 2, bp_x32 = (tid ^ 32) << 2;
+
+  // The sum of a pixel's four directions crosses the DPP rows through the LDS crossbar (ds_swizzle lane ^ 16, ds_bpermute lane ^ 32):
+  // two dependent round trips.  They are issued for the PREVIOUS pixel at the start of a step, next to the poll of the row above,
+  // and consumed after the evaluation — off every critical path; the pixel's sum is stored one step late (flush after the loop).
+  unsigned rs[Q];                                                  // the previous pixel's four vectors (one per DPP row)
+  unsigned sw[Q];                                                  // ... and their lane ^ 16 partners, in flight
+  bool have_prev = false;
+  auto sum_issue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < Q; ++e) sw[e] = (unsigned)__builtin_amdgcn_ds_swizzle((int)rs[e], 0x401f);
+  };
+  unsigned sa[Q], sb[Q];                                           // half sums, and their lane ^ 32 partners in flight
+  auto sum_mid = [&]() __attribute__((always_inline)) {            // after the step's first LDS wait: the swizzles have arrived
+#pragma unroll
+    for (int e = 0; e < Q; ++e) {
+      sa[e] = as_u32(as_us2(rs[e]) + as_us2(sw[e]));               // u16 wrap-around, the reference's +=
+      sb[e] = (unsigned)__builtin_amdgcn_ds_bpermute(bp_x32, (int)sa[e]);
+    }
+  };
+  auto sum_finish = [&]() __attribute__((always_inline)) {
+    unsigned o[Q];
+#pragma unroll
+    for (int e = 0; e < Q; ++e) o[e] = as_u32(as_us2(sa[e]) + as_us2(sb[e]));
+#ifdef VWGPU_SWEEP_DEBUG
+    if (A.dbg & 8) {} else
+#endif
+    if (st_full) {
+      SweepWords<Q> w;
+#pragma unroll
+      for (int e = 0; e < Q; ++e) w.v[e] = o[e];
+      *reinterpret_cast<SweepWords<Q>*>(ostore) = w;
+    } else if (st_part) {                                          // the lane whose pairs straddle the end of the pixel's vector
+#pragma unroll
+      for (int e = 0; e < Q; ++e)
+        if (j * Q + e < q32) ostore[e] = o[e];
+    }
+    ostore += ostep;
+  };
+
+  auto step = [&](const unsigned (&cw)[NWC], int xx) __attribute__((always_inline)) {
+    // (0) crossbar requests that need nothing from this step: the previous pixel's partial sums, this pixel's threshold
+    if (have_prev) sum_issue();
+    const unsigned pen = (unsigned)__builtin_amdgcn_ds_bpermute(bp_pen + ((xx & 15) << 2), (int)penl);
+    // (1) the vectors this pixel continues: row 0 keeps its own, rows 1 .. 3 take them from the row above
+    if (has_above) {                                               // wave-uniform
+      const int need = min(xx + 2, W);
+      const int sl = ((xx + dl) & AMASK) * SLOT;
+      unsigned t[Q], tm = 0;
+      for (;;) {
+        // the counter first, then the slots (LDS serves a wave's requests in order): if the counter is high enough, so are the slots
+        const unsigned got = avail >= (unsigned)need ? avail : *adone;
+        asm volatile("" ::: "memory");
+        if (row > 0) {
+#pragma unroll
+          for (int e = 0; e < Q; ++e) t[e] = aring[sl + voff + e];
+          tm = aring[sl + moff];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        avail = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+#ifdef VWGPU_SWEEP_DEBUG
+        if (A.dbg & 4) break;
+#endif
+        if (avail >= (unsigned)need) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (row > 0) {
+#pragma unroll
+        for (int e = 0; e < Q; ++e) r[e] = t[e];
+        mp = tm;
+      }
+      if (xx == 0 || xx + 1 == W) {                                // the diagonal lines that start at this pixel
+        if ((row == 2 && xx == 0) || (row == 3 && xx + 1 == W)) {
+#pragma unroll
+          for (int e = 0; e < Q; ++e) r[e] = dead[e];
+          mp = 0;
+        }
+      }
+    } else if (row > 0) {                                          // first row of the sweep: every "from above" line starts here
+#pragma unroll
+      for (int e = 0; e < Q; ++e) r[e] = dead[e];
+      mp = 0;
+    }
+    if (have_prev) sum_mid();
+    // (2) thresholds of the lane's direction
+    const unsigned dj = (mp + pen) & 0xffffu;
+    const us2 dJ = as_us2(dj | (dj << 16)), mpp = as_us2(mp | (mp << 16));
+    // (3) the cost pairs of the lane
+    unsigned cs[NWC];
+#pragma unroll
+    for (int n = 0; n < NWC; ++n) cs[n] = (Q & 1) ? __builtin_amdgcn_alignbit(n + 1 < NWC ? cw[n + 1] : 0u, cw[n], csh) : cw[n];
+    // (4) one evaluation for the four directions (SGM.cc:936-984,1013-1060 on packed u16 pairs)
+    row_shr1_keep(pm, r[Q - 1]);
+    row_shl1_keep(pn, r[0]);
+    unsigned al[Q + 1];
+    al[0] = __builtin_amdgcn_alignbit(r[0], pm, 16);
+#pragma unroll
+    for (int e = 1; e < Q; ++e) al[e] = __builtin_amdgcn_alignbit(r[e], r[e - 1], 16);
+    al[Q] = __builtin_amdgcn_alignbit(pn, r[Q - 1], 16);
+    us2 mn2 = as_us2(0xffffffffu);
+#pragma unroll
+    for (int e = 0; e < Q; ++e) {
+      const us2 ctr = as_us2(r[e]);
+      us2 m = __builtin_elementwise_min(__builtin_elementwise_min(as_us2(al[e]), as_us2(al[e + 1])), ctr);
+      us2 v = __builtin_elementwise_add_sat(m, p1p1);
+      v = __builtin_elementwise_min(v, __builtin_elementwise_min(ctr, dJ));
+      v = __builtin_elementwise_add_sat(v, as_us2(__builtin_amdgcn_perm(0u, cs[e >> 1], (e & 1) ? 0x0c030c02u : 0x0c010c00u)));
+      v = __builtin_elementwise_sub_sat(v, mpp);
+      r[e] = as_u32(v) | dead[e];
+      mn2 = e == 0 ? as_us2(r[e]) : __builtin_elementwise_min(mn2, as_us2(r[e]));
+    }
+    const unsigned mnu = as_u32(mn2);
+    const unsigned nm = row_min_u32(min(mnu & 0xffffu, mnu >> 16));  // every lane: the minimum of its direction
+    // (5) hand the three "from above" vectors on — before anything else: the row below is waiting for them
+    if (mode == 1) {                                               // to the row below, through this wave's LDS ring
+      const int needc = xx - RING + 2;
+      while ((int)cavail < needc) {
+#ifdef VWGPU_SWEEP_DEBUG
+        if (A.dbg & 4) break;
+#endif
+        cavail = done[wv + 1];
+        if ((int)cavail < needc) __builtin_amdgcn_s_sleep(1);
+      }
+      lds_uint* slot = oring + (xx & (RING - 1)) * SLOT;
+      if (row > 0) {
+#pragma unroll
+        for (int e = 0; e < Q; ++e) slot[voff + e] = r[e];
+        if (j == 0) slot[moff] = nm;
+      }
+    } else if (mode == 2
+#ifdef VWGPU_SWEEP_DEBUG
+               && !(A.dbg & 1)
+#endif
+               ) {                                                 // to the next block, through HBM: every word with this launch's epoch
+      unsigned long long* ent = bdst + (size_t)xx * ENT;
+      const unsigned long long tag = (unsigned long long)epoch << 32;
+      if (row > 0) {
+#pragma unroll
+        for (int e = 0; e < Q; ++e) st_coherent(ent + voff + e, tag | r[e]);
+        if (j < 2) st_coherent(ent + moff + (j ? 4 - row : 0), tag | nm);   // (lane 1 of row 1 tags the entry's pad word: the feeder reads word pairs)
+      }
+    }
+    // progress of this row: the row below reads it before it takes the slots, the row above (or the feeder) before it reuses them —
+    // every row publishes it, also the ones whose vectors go to HBM or nowhere
+    asm volatile("" ::: "memory");                                 // LDS executes a wave's accesses in order: slot data, then the counter
+    done[wv] = (unsigned)(xx + 1);
+    // (6) the previous pixel's sum leaves; this pixel's vectors wait for the next step
+    if (have_prev) sum_finish();
+#pragma unroll
+    for (int e = 0; e < Q; ++e) rs[e] = r[e];
+    have_prev = true;
+    if (row == 0) mp = nm;                                         // (rows 1 .. 3 reload theirs)
+  };
+
+  // The cost words of the next KC steps wait in registers: the loop is unrolled KC times so that step k of a round uses cq[k] and
+  // refills it for the round after.
+  unsigned cq[KC][NWC];
+  auto load_cost = [&](unsigned (&w)[NWC]) __attribute__((always_inline)) {
+    // one dword per load on purpose: a dwordx3 lands in a register triple that the loop-carried cq[k][n] cannot be, and the copies
+    // out of the triple sit right behind the load — every round waited for the load it had just issued
+#pragma unroll
+    for (int n = 0; n < NWC; ++n) {
+      unsigned off = 4u * n;
+      asm("" : "+v"(off));                                         // (keeps the vectoriser from seeing three adjacent loads)
+      w[n] = *reinterpret_cast<const unsigned*>(cfetch + off);
+    }
+    cfetch += cstep;                                               // runs up to 2 KC steps past the row: guard zones (host side)
+  };
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    load_cost(cq[k]);
+    // pinned in this order: the waits of the loop count the loads issued AFTER the one a step needs, on every path into the loop
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (wv == 0) SWEEP_STAMP(0);
+  if (mode != 1) SWEEP_STAMP(2);
+  for (int x0 = 0; x0 < W; x0 += KC) {
+    if ((x0 & 15) == 0) refresh(x0);
+    if (x0 == KC) { if (wv == 0) SWEEP_STAMP(6); if (mode != 1) SWEEP_STAMP(7); }
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      if (x0 + k < W) step(cq[k], x0 + k);
+      load_cost(cq[k]);                                            // after the step's last use of cq[k]: the refill lands in the same registers
+    }
+  }
+  sum_issue();                                                     // the row's last pixel
+  sum_mid();
+  sum_finish();
+  if (wv == 0) SWEEP_STAMP(1);
+  if (mode != 1) SWEEP_STAMP(3);
+}
+
 // starts of the uniform layout: pixel p's vectors begin at p * stride
 __global__ void uniform_starts_kernel(unsigned long long* __restrict__ starts, size_t npix, unsigned long long stride) {
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1564,8 +1981,9 @@ wta_kernel(const B4* __restrict__ bounds, const unsigned long long* __restrict__
 // Pixels whose minimum is not unique need the reference's smoothing loop: they are marked in `todo` and left to wta_kernel.
 constexpr int WTAU_PPW = 8;
 __global__ void __launch_bounds__(256)
-wta_uniform_kernel(size_t npix, int num_disp, int stride, int min_dx, int row_dy, const uint16_t* __restrict__ accum,
+wta_uniform_kernel(size_t npix, int num_disp, int stride, int min_dx, int row_dy, uint16_t* __restrict__ accum, uint16_t* __restrict__ accum2,
                    int32_t* __restrict__ disp, uint8_t* __restrict__ todo, int* __restrict__ any_todo) {
+  // accum2 != nullptr: the sums of the backward sweep (sweep_uniform_kernel); a pixel's vector is accum + accum2 (u16 wrap-around)
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t p0 = ((size_t)blockIdx.x * 4 + wv) * WTAU_PPW;
   if (p0 >= npix) return;
@@ -1577,6 +1995,11 @@ wta_uniform_kernel(size_t npix, int num_disp, int stride, int min_dx, int row_dy
     const unsigned* v32 = reinterpret_cast<const unsigned*>(accum + p * (size_t)stride);
     va[q] = lane < npairs ? v32[lane] : 0xffffffffu;
     vb[q] = lane + 64 < npairs ? v32[lane + 64] : 0xffffffffu;
+    if (accum2) {
+      const unsigned* w32 = reinterpret_cast<const unsigned*>(accum2 + p * (size_t)stride);
+      if (lane < npairs) va[q] = as_u32(as_us2(va[q]) + as_us2(w32[lane]));
+      if (lane + 64 < npairs) vb[q] = as_u32(as_us2(vb[q]) + as_us2(w32[lane + 64]));
+    }
   }
   bool flagged = false;
 #pragma unroll
@@ -1599,6 +2022,12 @@ wta_uniform_kernel(size_t npix, int num_disp, int stride, int min_dx, int row_dy
     if (cnt > 1) {
       if (lane == 0) todo[p] = 1;
       flagged = true;
+      if (accum2) {        // the general kernel (tie smoothing, write-back) and the sub-pixel kernel find the whole vector in accum
+        unsigned* v32 = reinterpret_cast<unsigned*>(accum + p * (size_t)stride);
+        unsigned* w32 = reinterpret_cast<unsigned*>(accum2 + p * (size_t)stride);
+        if (lane < npairs) { v32[lane] = va[q]; w32[lane] = 0u; }
+        if (lane + 64 < npairs) { v32[lane + 64] = vb[q]; w32[lane + 64] = 0u; }
+      }
     } else if (lane == 0) {
       todo[p] = 0;
       int32_t* o = disp + p * 3;
@@ -1656,7 +2085,8 @@ __device__ bool sp_parabola(const double* z, double& dx, double& dy) {
 }
 
 __global__ void subpixel_kernel(int mode, const B4* __restrict__ bounds, const unsigned long long* __restrict__ starts, size_t npix,
-                                const uint16_t* __restrict__ accum, const int32_t* __restrict__ idisp, float* __restrict__ out) {
+                                const uint16_t* __restrict__ accum, const uint16_t* __restrict__ accum2, const int32_t* __restrict__ idisp,
+                                float* __restrict__ out) {
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npix) return;
   const int32_t* ip = idisp + p * 3;
@@ -1673,16 +2103,18 @@ __global__ void subpixel_kernel(int mode, const B4* __restrict__ bounds, const u
   if (dx == b.x1) { xr = 0; rb = true; }
   if (dy == b.y0) { yu = 0; tb = true; }
   if (dy == b.y1) { yd = 0; bb = true; }
-  const uint16_t* a = accum + starts[p];
+  const uint16_t* a1 = accum + starts[p];
+  const uint16_t* a2 = accum2 ? accum2 + starts[p] : nullptr;     // the backward sweep's sums (sweep_uniform_kernel)
+  auto a = [&](int i) __attribute__((always_inline)) -> unsigned { return a2 ? (unsigned)(uint16_t)(a1[i] + a2[i]) : (unsigned)a1[i]; };
   double ddx = 0, ddy = 0;
   bool valid = true;
   if (mode == 1) {
-    const double z[9] = {(double)a[mi + xl + yu], (double)a[mi + yu], (double)a[mi + xr + yu], (double)a[mi + xl], (double)a[mi],
-                         (double)a[mi + xr], (double)a[mi + xl + yd], (double)a[mi + yd], (double)a[mi + xr + yd]};
+    const double z[9] = {(double)a(mi + xl + yu), (double)a(mi + yu), (double)a(mi + xr + yu), (double)a(mi + xl), (double)a(mi),
+                         (double)a(mi + xr), (double)a(mi + xl + yd), (double)a(mi + yd), (double)a(mi + xr + yd)};
     valid = sp_parabola(z, ddx, ddy);
   } else {
-    ddx = sp_offset(mode, a[mi + xl], a[mi], a[mi + xr], lb, rb);
-    ddy = sp_offset(mode, a[mi + yu], a[mi], a[mi + yd], tb, bb);
+    ddx = sp_offset(mode, a(mi + xl), a(mi), a(mi + xr), lb, rb);
+    ddy = sp_offset(mode, a(mi + yu), a(mi), a(mi + yd), tb, bb);
   }
   if (valid) { o[0] = (float)((double)dx + ddx); o[1] = (float)((double)dy + ddy); } else { o[0] = (float)dx; o[1] = (float)dy; }
   o[2] = 1.0f;
@@ -1852,11 +2284,26 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   const size_t vol_bytes = vwgpu_align_up((size_t)main_buf * 2, 256);
   int mgm_vols = 0;
   if (P->use_mgm) for (mgm_vols = 8; mgm_vols > 1 && (size_t)mgm_vols * vol_bytes > ((size_t)24 << 30); mgm_vols /= 2) {}
-  rc = vwgpu_arena_reserve(ctx, &ctx->sgm_main, (size_t)main_buf * 3 + 1024 + 3 * guard + (size_t)mgm_vols * vol_bytes + 512);
+  // fused raster sweeps (sweep_uniform_kernel): full boxes on one search row, up to 256 disparities (the packed winner-take-all kernel
+  // adds the two sweeps' volumes), enough LDS for at least two rows per workgroup
+  int sweep_nw = 0, sweep_q = 0;
+  if (uniform && g.num_dy == 1 && !P->use_mgm && num_disp <= 256 && ctx->sgm_sweep >= 1) {      // opt-in: see the kernel's header for the trade
+    sweep_q = (int)(((num_disp + 1) / 2 + 15) / 16);               // disparity pairs per lane of a 16-lane row: 1 .. 8
+    if (sweep_q == 7) sweep_q = 8;
+    const size_t slot = (size_t)(3 * 16 * sweep_q + 4) * 4;
+    // rows per workgroup: as many as the LDS takes (13 at 129 disparities) unless VWGPU_OPT_SGM_SWEEP pins the count (2 .. 15):
+    // every workgroup boundary costs a hand-off through HBM (5 .. 8 us measured), every row of a workgroup shares its CU
+    const size_t budget = 120 * 1024 - 128 - SWEEP_FRING * slot;
+    sweep_nw = (int)std::min<size_t>(ctx->sgm_sweep >= 2 ? ctx->sgm_sweep : 15, budget / (SWEEP_RING * slot));
+    if (sweep_nw < 2 || g.ocols < 4) sweep_nw = 0;
+  }
+  const size_t accum2_bytes = sweep_nw ? vol_bytes + guard : 0;
+  rc = vwgpu_arena_reserve(ctx, &ctx->sgm_main, (size_t)main_buf * 3 + 1024 + 3 * guard + (size_t)mgm_vols * vol_bytes + accum2_bytes + 512);
   if (rc) return rc;
   uint8_t* cost = static_cast<uint8_t*>(ctx->sgm_main.base) + guard;
   uint16_t* accum = reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->sgm_main.base) + 2 * guard + vwgpu_align_up((size_t)main_buf, 256));
   uint16_t* mgm_vol = reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->sgm_main.base) + 3 * guard + vwgpu_align_up((size_t)main_buf, 256) + vol_bytes);
+  uint16_t* accum2 = sweep_nw ? reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->sgm_main.base) + 3 * guard + vwgpu_align_up((size_t)main_buf, 256) + vol_bytes) : nullptr;
   // one direction per launch, plain store / read-modify-write
   const bool dir_paths = uniform && g.num_dy == 1 && !P->use_mgm;      // the first direction initialises the volume
   if (!dir_paths && !P->use_mgm) VWGPU_HIP(ctx, hipMemsetAsync(accum, 0, (size_t)main_buf * 2, st));      // (MGM: mgm_sum_kernel stores)
@@ -1956,6 +2403,50 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
         hipLaunchKernelGGL(mgm_sum_kernel, dim3((unsigned)std::min<size_t>((words + 255) / 256, 8192)), dim3(256), 0, st, reinterpret_cast<uint4*>(accum),
                            reinterpret_cast<const uint4*>(mgm_vol), vol_bytes / 16, words, per, first > 0 ? 1 : 0);
       }
+    } else if (sweep_nw) {
+      // two concurrent raster sweeps, four directions each: the sums are written once per sweep (sweep_uniform_kernel)
+      vwgpu_prof_scope ps(ctx, "sgm_paths");
+      const int nblk = (g.orows + sweep_nw - 1) / sweep_nw;
+      const size_t slot_dwords = (size_t)3 * 16 * sweep_q + 4;
+      const size_t bnd_bytes = (size_t)2 * nblk * g.ocols * slot_dwords * 8 + 256;
+      if (ctx->sgm_bnd.cap < bnd_bytes || ctx->sgm_epoch == 0xffffffffu) {       // fresh memory (or the epochs are used up): no word may carry a future epoch
+        rc = vwgpu_arena_reserve(ctx, &ctx->sgm_bnd, bnd_bytes);
+        if (rc) return rc;
+        VWGPU_HIP(ctx, hipMemsetAsync(ctx->sgm_bnd.base, 0, ctx->sgm_bnd.cap, st));
+        ctx->sgm_epoch = 0;
+      }
+      SweepParams SA;
+      SA.g = g; SA.stride = ustride; SA.lw = lw; SA.min_col = min_col; SA.min_row = min_row; SA.nblk = nblk; SA.nw = sweep_nw;
+      SA.p1 = (unsigned)p1; SA.p2 = (unsigned)p2; SA.epoch = ++ctx->sgm_epoch;
+      SA.left = l8; SA.cost = cost; SA.out0 = accum; SA.out1 = accum2;
+#ifdef VWGPU_SWEEP_DEBUG
+      SA.dbg = getenv("VWGPU_SWEEP_DBG") ? atoi(getenv("VWGPU_SWEEP_DBG")) : 0;
+#endif
+      SA.sync = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->sgm_bnd.base));
+      SA.bnd = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->sgm_bnd.base) + 256);
+      VWGPU_HIP(ctx, hipMemsetAsync(SA.sync, 0, 256, st));
+      const size_t lds = (32 + ((size_t)sweep_nw * SWEEP_RING + SWEEP_FRING) * slot_dwords) * 4;
+      const dim3 grd((unsigned)(2 * nblk)), blk((unsigned)((sweep_nw + 1) * 64));
+#define VWGPU_SWEEP(QQ) do { VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_uniform_kernel<QQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                             hipLaunchKernelGGL(sweep_uniform_kernel<QQ>, grd, blk, lds, st, SA); } while (0)
+      switch (sweep_q) {
+        case 1: VWGPU_SWEEP(1); break; case 2: VWGPU_SWEEP(2); break; case 3: VWGPU_SWEEP(3); break; case 4: VWGPU_SWEEP(4); break;
+        case 5: VWGPU_SWEEP(5); break; case 6: VWGPU_SWEEP(6); break; default: VWGPU_SWEEP(8); break;
+      }
+#undef VWGPU_SWEEP
+#ifdef VWGPU_SWEEP_DEBUG
+      if (getenv("VWGPU_SWEEP_TRACE")) {
+        std::vector<unsigned long long> tr((size_t)2 * 2048 * 8);
+        VWGPU_HIP(ctx, hipStreamSynchronize(st));
+        VWGPU_HIP(ctx, hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(sweep_trace), tr.size() * 8));
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < nblk; ++b) for (int q = 0; q < 2; ++q) if (tr[((size_t)q * 2048 + b) * 8]) t0 = std::min(t0, tr[((size_t)q * 2048 + b) * 8]);
+        for (int b = 0; b < std::min(nblk, 2048); b += std::max(1, nblk / 24))
+          fprintf(stderr, "blk %4d fwd: w0 start %8.2f step8 %8.2f end %8.2f | last row start %8.2f step8 %8.2f end %8.2f | feeder first %8.2f last %8.2f us\n", b,
+                  (tr[b * 8 + 0] - t0) * 0.01, (tr[b * 8 + 6] - t0) * 0.01, (tr[b * 8 + 1] - t0) * 0.01, (tr[b * 8 + 2] - t0) * 0.01, (tr[b * 8 + 7] - t0) * 0.01,
+                  (tr[b * 8 + 3] - t0) * 0.01, (tr[b * 8 + 4] - t0) * 0.01, (tr[b * 8 + 5] - t0) * 0.01);
+      }
+#endif
     } else if (dir_paths) {
       // One direction per launch: every pixel lies on exactly one line of a launch, so the path costs are accumulated with plain
       // loads and stores, and the first direction stores (no memset).  (Tried: bands of rows with the directions pipelined over
@@ -2031,7 +2522,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       int* flag = reinterpret_cast<int*>(mm + 6);
       VWGPU_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int), st));
       hipLaunchKernelGGL(wta_uniform_kernel, dim3((unsigned)((npix + 4 * WTAU_PPW - 1) / (4 * WTAU_PPW))), dim3(256), 0, st, npix, (int)num_disp, ustride,
-                         g.min_dx, g.min_dy, accum, out_disp, full_search, flag);
+                         g.min_dx, g.min_dy, accum, accum2, out_disp, full_search, flag);
       todo = full_search; any_todo = flag;
     }
     hipLaunchKernelGGL(wta_kernel, dim3((unsigned)((npix + 4 * WTA_PPW - 1) / (4 * WTA_PPW))), dim3(256), lds, st, bounds, starts, npix, (int)num_disp, accum, out_disp,
@@ -2039,7 +2530,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   }
   if (out_sub) {
     vwgpu_prof_scope ps(ctx, "sgm_subpixel");
-    hipLaunchKernelGGL(subpixel_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, P->subpixel_mode, bounds, starts, npix, accum, out_disp, out_sub);
+    hipLaunchKernelGGL(subpixel_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, P->subpixel_mode, bounds, starts, npix, accum, accum2, out_disp, out_sub);
   }
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;

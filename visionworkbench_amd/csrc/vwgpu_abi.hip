@@ -131,6 +131,7 @@ void vwgpu_destroy(vwgpu_ctx* ctx) {
   if (ctx->host_ring) (void)hipHostFree(ctx->host_ring);
   if (ctx->sgm.base) (void)hipFree(ctx->sgm.base);
   if (ctx->sgm_main.base) (void)hipFree(ctx->sgm_main.base);
+  if (ctx->sgm_bnd.base) (void)hipFree(ctx->sgm_bnd.base);
   for (auto& lr : ctx->leaf_rects) if (lr.d_rects) (void)hipFree(lr.d_rects);
   if (ctx->xvol.base) (void)hipFree(ctx->xvol.base);
   if (ctx->xtab.base) (void)hipFree(ctx->xtab.base);
@@ -181,6 +182,7 @@ int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value) {
   if (option == VWGPU_OPT_SAD_GROUPS && value >= 0 && value <= 2) { ctx->sad_groups = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_EXACT_SCRATCH_MB && value >= 16 && value <= 65536) { ctx->exact_scratch_mb = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_TRACE && value >= 0 && value <= 3) { ctx->trace = value; return VWGPU_OK; }
+  if (option == VWGPU_OPT_SGM_SWEEP && value >= 0 && value <= 15) { ctx->sgm_sweep = value; return VWGPU_OK; }
   return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "vwgpu_set_option: unknown or read-only option %d, or value %d out of range", option, value);
 }
 
@@ -197,6 +199,7 @@ int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value) {
   if (option == VWGPU_OPT_SAD_GROUPS) { *value = ctx->sad_groups; return VWGPU_OK; }
   if (option == VWGPU_OPT_EXACT_SCRATCH_MB) { *value = ctx->exact_scratch_mb; return VWGPU_OK; }
   if (option == VWGPU_OPT_TRACE) { *value = ctx->trace; return VWGPU_OK; }
+  if (option == VWGPU_OPT_SGM_SWEEP) { *value = ctx->sgm_sweep; return VWGPU_OK; }
   return VWGPU_ERR_ARGUMENT;
 }
 
