@@ -2311,7 +2311,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     // fill_costs_block (SGM.cc:1711-1738).  Exact n / count for every n the sums can reach: multiply-high by 2^32 / count + 1.
     vwgpu_prof_scope ps(ctx, "sgm_cost");
     const unsigned count = (unsigned)(kernel * kernel), magic = (unsigned)((1ull << 32) / count + 1);
-    for (unsigned n = 0; n <= 255u * count; ++n)
+    for (unsigned n = 0; count > 1 && n <= 255u * count; ++n)         // (a single-pixel kernel returns the plain difference, SGM.cc:1658-1662)
       if ((unsigned)(((unsigned long long)n * magic) >> 32) != n / count) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "calc_disparity_sgm: division constant");
     const bool fast = uniform && g.num_dy == 1 && (kernel == 3 || kernel == 5 || kernel == 7 || kernel == 9 || kernel == 11);
     if (fast) {
