@@ -102,10 +102,13 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *   VWGPU_OPT_SGM_SWEEP        SGM path aggregation of full-range one-row searches (<= 256 disparities): 0 = one direction per launch
  *       (default: eight passes over the u16 sums, bandwidth bound), 1 = two concurrent fused raster sweeps of four directions each
  *       (a fifth of the HBM traffic, the same sums; slower on MI355X because a sweep is W + 2 H dependent pixel steps), 2 .. 15 = the
- *       sweeps with that many rows per workgroup (tuning). */
+ *       sweeps with that many rows per workgroup (tuning).
+ *   VWGPU_OPT_EXACT_LDS        exact-order matching of zones whose working set fits the LDS of one wavefront (bmx_zone_lds_kernel):
+ *       0 = never (default: the two HBM passes for every zone — measured faster), 1 = for the zone lists of a pyramid level,
+ *       2 = also for single-zone calls (calc_disparity on a small raster). */
 typedef enum vwgpu_option {
   VWGPU_OPT_DEFER_EXACTNESS = 1, VWGPU_OPT_DEVICE_COUNT = 2, VWGPU_OPT_SAD_GROUPS = 3, VWGPU_OPT_EXACT_SCRATCH_MB = 4,
-  VWGPU_OPT_TRACE = 5, VWGPU_OPT_SGM_SWEEP = 6
+  VWGPU_OPT_TRACE = 5, VWGPU_OPT_SGM_SWEEP = 6, VWGPU_OPT_EXACT_LDS = 7
 } vwgpu_option;
 int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value);
 int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value);

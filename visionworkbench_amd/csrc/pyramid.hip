@@ -24,6 +24,8 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "vwgpu_internal.h"
@@ -746,6 +748,14 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         size_t px = 0, ev = 0; int maxd = 0, maxw = 0, maxh = 0;
         for (vwgpu_zone_task const& z : t1) { px += (size_t)z.zw * z.zh; ev += (size_t)z.zw * z.zh * z.sx * z.sy; maxd = std::max(maxd, z.sx * z.sy); maxw = std::max(maxw, z.zw); maxh = std::max(maxh, z.zh); }
         fprintf(stderr, "level %d: %zu zones, %zu px, %zu evaluations, max D %d, max zone %d x %d, exact %d\n", level, t1.size(), px, ev, maxd, maxw, maxh, (int)exact);
+        // histogram of zone shapes: (width bucket, height bucket, disparities bucket) -> zones, evaluations
+        std::map<std::string, std::pair<size_t, size_t>> hist;
+        for (vwgpu_zone_task const& z : t1) {
+          char key[96];
+          snprintf(key, sizeof key, "w<=%d h<=%d sx<=%d sy<=%d", (z.zw + 15) / 16 * 16, (z.zh + 15) / 16 * 16, (z.sx + 3) / 4 * 4, (z.sy + 3) / 4 * 4);
+          hist[key].first += 1; hist[key].second += (size_t)z.zw * z.zh * z.sx * z.sy;
+        }
+        for (auto const& kv : hist) fprintf(stderr, "    %-34s %6zu zones %12zu evaluations\n", kv.first.c_str(), kv.second.first, kv.second.second);
       }
       if (lr_active && rl_pixels) { if ((rc = vwgpu_arena_reserve(ctx, &ctx->zrl, rl_pixels * 12))) return rc; }
       if (exact) rc = vwgpu_launch_bm_exact(ctx, P->cost_type, Lv.p, Lv.w, Lv.h, Lv.w, Rv.p, Rv.w, Rv.h, Rv.w, kx, ky, t1.data(), (int)t1.size(), disp);
