@@ -450,6 +450,29 @@ def test_mgm_identical_to_oracle(vw, oracle, cost, k, sx, sy, w, h):
     assert np.abs(gs - os_).max() < 1e-5
 
 
+@pytest.mark.parametrize("opt", [0, 1, 2, 5])
+@pytest.mark.parametrize("k,sx,w,h,cost", [(7, 128, 150, 40, CENSUS), (5, 16, 40, 130, CENSUS), (3, 60, 300, 25, TERNARY), (9, 200, 64, 64, CENSUS),
+                                           (5, 250, 90, 31, CENSUS), (7, 9, 21, 200, TERNARY), (5, 30, 10, 10, CENSUS)])
+def test_mgm_sweeps_and_fronts_identical_to_oracle(vw, oracle, opt, k, sx, w, h, cost):
+    """use_mgm on full-range one-row searches: the eight passes as four concurrent sweeps in the frames (x, y), (-x, -y), (y, -x), (-y, x)
+    (VWGPU_OPT_MGM_SWEEP 0; 2 / 5 = pinned lines per workgroup: hand-offs through HBM every few lines, and the ticket deal when the row
+    and column sweeps have different block counts) and as one launch per front (1): wide, tall and tiny outputs, 1 .. 8 pairs per lane."""
+    from visionworkbench_amd import core
+    ctx = core.default_context(0)
+    rng = np.random.default_rng(11 * k + sx + opt)
+    left = np.floor(rng.random((h, w)) * 256).astype(np.float32)
+    right = np.floor(rng.random((h, w + sx)) * 256).astype(np.float32)
+    right[:, sx // 3:sx // 3 + w] = left
+    ctx.set_option(core.OPT_MGM_SWEEP, opt)
+    try:
+        gi, gs = vw.calc_disparity_sgm(cost, left, right, _box(w, h), (sx, 0), (k, k), use_mgm=True, with_subpixel=True, ctx=ctx)
+    finally:
+        ctx.set_option(core.OPT_MGM_SWEEP, 0)
+    oi, os_ = oracle.calc_disparity_sgm(cost, left, right, (sx, 0), k, use_mgm=True)
+    assert np.array_equal(gi, oi), int((gi != oi).any(-1).sum())
+    assert np.abs(gs - os_).max() < 1e-5
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_mgm_ragged_boxes_masks_and_previous_level(vw, oracle, seed):
     """Masks with empty borders and a previous level with untrusted holes: pixels without disparities are skipped but still serve as

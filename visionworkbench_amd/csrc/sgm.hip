@@ -1436,6 +1436,74 @@ __device__ __forceinline__ unsigned row_min_u32(unsigned v) {
 }
 template <int N> struct __attribute__((packed, aligned(4))) SweepWords { unsigned v[N]; };
 
+
+// The feeder wave of a sweep workgroup: the boundary row of the previous block (W entries of NWORDS tagged words) -> the LDS ring of
+// row wave 0.  An entry is complete when every word carries this launch's epoch.
+template <int SLOT, int NWORDS>
+__device__ __forceinline__ void sweep_feeder(const unsigned long long* __restrict__ src, int W, lds_uint* ring, volatile lds_uint* done, int NW,
+                                             unsigned epoch, int tid
+#ifdef VWGPU_SWEEP_DEBUG
+                                             , int dbg, int pass, int blk
+#endif
+                                             ) {
+  constexpr int FRING = SWEEP_FRING, PER = (NWORDS + 63) / 64;
+  constexpr int FB = PER <= 4 ? SWEEP_FB : SWEEP_FB / 2;            // entries requested at once: 32 / 28 loads in flight per lane
+  const size_t ENT = SLOT;
+  int e = 0;
+  unsigned cons = 0;
+  while (e < W) {
+    const int B = min(FB, W - e);
+    const int needc = e + B - FRING + 2;                           // row wave 0 must be done with the slots about to be overwritten
+    while ((int)cons < needc) {
+#ifdef VWGPU_SWEEP_DEBUG
+      if (dbg & 4) break;
+#endif
+      cons = done[0];
+      if ((int)cons < needc) __builtin_amdgcn_s_sleep(2);
+    }
+    unsigned long long wd[FB][PER];
+#pragma unroll
+    for (int b = 0; b < FB; ++b) {
+      const unsigned long long* ent = src + (size_t)min(e + b, W - 1) * ENT;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) wd[b][k] = ld_coherent(ent + min(k * 64 + tid, NWORDS - 1));
+    }
+    int k = 0;                                                     // entries e .. e + k - 1 are complete
+#pragma unroll
+    for (int b = 0; b < FB; ++b) {
+      bool ok = true;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) ok = ok && (unsigned)(wd[b][q] >> 32) == epoch;
+#ifdef VWGPU_SWEEP_DEBUG
+      if (dbg & 2) ok = true;
+#endif
+      if (__all(ok) && b < B && k == b) k = b + 1;
+    }
+#pragma unroll
+    for (int b = 0; b < FB; ++b) {
+      if (b < k) {                                                 // wave-uniform
+        lds_uint* slot = ring + ((e + b) & (FRING - 1)) * SLOT;
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+          if (q * 64 + tid < NWORDS) slot[q * 64 + tid] = (unsigned)wd[b][q];
+      }
+    }
+    if (k) {
+#ifdef VWGPU_SWEEP_DEBUG
+      if (e == 0 && tid == 0 && blk < 2048) sweep_trace[((size_t)pass * 2048 + blk) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+#endif
+      asm volatile("" ::: "memory");                               // LDS executes a wave's accesses in order: data, then the counter
+      done[NW] = (unsigned)(e + k);
+      e += k;
+    } else {
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+#ifdef VWGPU_SWEEP_DEBUG
+  if (tid == 0 && blk < 2048) sweep_trace[((size_t)pass * 2048 + blk) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
 template <int Q>
 __global__ void __launch_bounds__(1024)
 sweep_uniform_kernel(SweepParams A) {
@@ -1443,7 +1511,6 @@ sweep_uniform_kernel(SweepParams A) {
   constexpr int VQ = 16 * Q;                                       // dwords of a vector in a slot: every lane of a row addresses its own Q
   constexpr int SLOT = 3 * VQ + 4;                                 // from above, from above-left, from above-right + their three minima
   constexpr int NWORDS = 3 * VQ + 4;                              // (the pad word is tagged too)
-  constexpr int FB = (NWORDS + 63) / 64 <= 4 ? SWEEP_FB : SWEEP_FB / 2;   // entries the feeder requests at once: 32 / 28 loads in flight per lane
   constexpr int NWC = (Q + 1) / 2;                                 // dwords that hold a lane's 2 Q cost bytes (from a dword-aligned address)
   extern __shared__ unsigned lds_u32[];
   lds_uint* const sm = (lds_uint*)lds_u32;                         // every LDS access through address-space-3 pointers: ds_* instructions, lgkmcnt only
@@ -1461,59 +1528,11 @@ sweep_uniform_kernel(SweepParams A) {
   const unsigned epoch = A.epoch;
 
   if (wv == NW) {                                                  // ---- feeder: boundary row of the previous block -> LDS ring of row wave 0
-    if (blk == 0) return;
-    constexpr int PER = (NWORDS + 63) / 64;
-    const unsigned long long* src = A.bnd + ((size_t)(pass * A.nblk + blk - 1) * W) * ENT;
-    lds_uint* ring = rings + NW * RING * SLOT;
-    int e = 0;
-    unsigned cons = 0;
-    while (e < W) {
-      const int B = min(FB, W - e);
-      const int needc = e + B - FRING + 2;                         // row wave 0 must be done with the slots about to be overwritten
-      while ((int)cons < needc) {
+    if (blk > 0) sweep_feeder<SLOT, NWORDS>(A.bnd + ((size_t)(pass * A.nblk + blk - 1) * W) * ENT, W, rings + NW * RING * SLOT, done, NW, epoch, tid
 #ifdef VWGPU_SWEEP_DEBUG
-        if (A.dbg & 4) break;
+                                            , A.dbg, pass, blk
 #endif
-        cons = done[0];
-        if ((int)cons < needc) __builtin_amdgcn_s_sleep(2);
-      }
-      unsigned long long wd[FB][PER];
-#pragma unroll
-      for (int b = 0; b < FB; ++b) {
-        const unsigned long long* ent = src + (size_t)min(e + b, W - 1) * ENT;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) wd[b][k] = ld_coherent(ent + min(k * 64 + tid, NWORDS - 1));
-      }
-      int k = 0;                                                   // entries e .. e + k - 1 are complete
-#pragma unroll
-      for (int b = 0; b < FB; ++b) {
-        bool ok = true;
-#pragma unroll
-        for (int q = 0; q < PER; ++q) ok = ok && (unsigned)(wd[b][q] >> 32) == epoch;
-#ifdef VWGPU_SWEEP_DEBUG
-        if (A.dbg & 2) ok = true;
-#endif
-        if (__all(ok) && b < B && k == b) k = b + 1;
-      }
-#pragma unroll
-      for (int b = 0; b < FB; ++b) {
-        if (b < k) {                                               // wave-uniform
-          lds_uint* slot = ring + ((e + b) & (FRING - 1)) * SLOT;
-#pragma unroll
-          for (int q = 0; q < PER; ++q)
-            if (q * 64 + tid < NWORDS) slot[q * 64 + tid] = (unsigned)wd[b][q];
-        }
-      }
-      if (k) {
-        if (e == 0) SWEEP_STAMP(4);
-        asm volatile("" ::: "memory");                             // LDS executes a wave's accesses in order: data, then the counter
-        done[NW] = (unsigned)(e + k);
-        e += k;
-      } else {
-        __builtin_amdgcn_s_sleep(8);
-      }
-    }
-    SWEEP_STAMP(5);
+                                            );
     return;
   }
 
@@ -1768,6 +1787,277 @@ sweep_uniform_kernel(SweepParams A) {
   sum_finish();
   if (wv == 0) SWEEP_STAMP(1);
   if (mode != 1) SWEEP_STAMP(3);
+}
+
+
+// ---- MGM as four concurrent sweeps (round 3) ----------------------------------------------------------------------------------------
+// accum_mgm_multithread (SGM.cc:2619-2700): eight passes in which a pixel takes the mean of TWO evaluate_path results of the pass's
+// own values, from a path predecessor A and a second predecessor B (mgm_schedule.h).  One launch per front made that 2035 launches
+// for a 1024^2 image (5.5 us each).  In a suitable frame (u = marching axis, v = line index) every pass is one of two shapes:
+//     axis      A = (u-1, v), B = (u, v-1)         L in (x, y), R in (-x, -y), T in (y, -x), B in (-y, x)
+//     diagonal  A = (u-1, v-1), B = (u+1, v-1)     TL           BR             TR            BL          (same frames)
+// so the eight passes are FOUR sweeps of the sweep_uniform_kernel kind — one wavefront per line v marching along u, two pixels
+// behind the line before it, vectors handed on through LDS rings (and through tagged HBM rows between workgroups) — that run
+// concurrently, each carrying one axis and one diagonal pass in the four DPP rows of its wavefronts:
+//     row 0  axis pass from A (the wavefront's own previous pixel)      row 2  diagonal pass from A (line v-1, pixel u-1)
+//     row 1  axis pass from B (line v-1, pixel u)                       row 3  diagonal pass from B (line v-1, pixel u+1)
+// One packed evaluation per pixel serves the four, the means are taken between DPP rows (ds_swizzle lane ^ 16), the pass values go
+// to the per-direction volumes that mgm_sum_kernel adds to the sums.  Border tests (SGMAssist.h:911-1219) in frame coordinates:
+// axis u > 0 and v > 0, diagonal 0 < u < U-1 and v > 0; a pixel that fails it keeps its local costs (both predecessors "none").
+struct MgmSweepParams {
+  SgmGeom g;
+  int stride, lw, lh, min_col, min_row, nw;
+  int nblk[4], blk0[5];              // blocks of NW lines per sweep; blk0 = prefix sums (tickets are dealt round robin over the sweeps)
+  unsigned p1, p2, epoch;
+  const uint8_t* left;
+  const uint8_t* cost;
+  uint16_t* vols;                    // per-direction volumes, kMgmDirs order: L, TL, R, BR, T, BL, B, TR
+  size_t vol_stride;                 // u16 elements between two volumes
+  unsigned* sync;
+  unsigned long long* bnd;           // boundary rows of all sweeps, block-major: entry = 2 vectors + 2 minima of (word, epoch)
+  size_t bnd_off[4];                 // first entry of each sweep's boundary rows
+};
+
+template <int Q>
+__global__ void __launch_bounds__(1024)
+mgm_sweep_kernel(MgmSweepParams A) {
+  constexpr int RING = SWEEP_RING, FRING = SWEEP_FRING, KC = SWEEP_KC;
+  constexpr int VQ = 16 * Q, SLOT = 2 * VQ + 4, NWORDS = SLOT, NWC = (Q + 1) / 2;
+  extern __shared__ unsigned lds_u32[];
+  lds_uint* const sm = (lds_uint*)lds_u32;
+  const int tid = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int NW = A.nw;
+  const int W = A.g.ocols, H = A.g.orows, stride = A.stride, q32 = stride / 2;
+  const size_t ENT = SLOT;
+  volatile lds_uint* done = sm + 1;
+  lds_uint* rings = sm + 32;
+  if (threadIdx.x == 0) sm[0] = atomicAdd(&A.sync[0], 1u);
+  if (threadIdx.x >= 1 && threadIdx.x < 32) sm[threadIdx.x] = 0u;
+  __syncthreads();
+  // tickets -> (sweep, block): round robin over the sweeps while they have blocks left, so that every sweep's blocks start in order
+  int sweep = 0, blk = 0;
+  {
+    int t = (int)sm[0];
+    const int m = min(min(A.nblk[0], A.nblk[1]), min(A.nblk[2], A.nblk[3]));      // all four sweeps alive: rounds of four tickets
+    if (t < 4 * m) { sweep = t & 3; blk = t >> 2; }
+    else {                                                          // the two longer sweeps (more lines) share the rest, round robin
+      t -= 4 * m;
+      int alive[4], n = 0;
+      for (int q = 0; q < 4; ++q) if (A.nblk[q] > m) alive[n++] = q;
+      sweep = alive[t % n]; blk = m + t / n;                        // (equal line counts among the survivors: same-shape frames come in pairs)
+    }
+  }
+  const unsigned epoch = A.epoch;
+  // frames: 0 (u, v) = (x, y); 1 (-x, -y); 2 (y, -x); 3 (-y, x)
+  const bool transposed = sweep >= 2;
+  const int U = transposed ? H : W, V = transposed ? W : H;
+  unsigned long long* bnd = A.bnd + A.bnd_off[sweep] * ENT;
+  if (wv == NW) {
+    if (blk > 0) sweep_feeder<SLOT, NWORDS>(bnd + (size_t)(blk - 1) * U * ENT, U, rings + NW * RING * SLOT, done, NW, epoch, tid
+#ifdef VWGPU_SWEEP_DEBUG
+                                            , 0, 0, 4096
+#endif
+                                            );
+    return;
+  }
+  const int vv = blk * NW + wv;                                    // line in sweep order
+  if (vv >= V) return;
+  const bool has_above = vv > 0;
+  const int mode = vv + 1 >= V ? 0 : (wv < NW - 1 ? 1 : 2);
+  const int aidx = wv > 0 ? wv - 1 : NW;
+  const int AMASK = (wv > 0 ? RING : FRING) - 1;
+  const lds_uint* aring = rings + aidx * RING * SLOT;
+  volatile lds_uint* adone = done + aidx;
+  lds_uint* oring = rings + wv * RING * SLOT;
+  unsigned long long* bdst = bnd + (size_t)blk * U * ENT;
+
+  // image coordinates of (u, v): x = x0 + u * xu, y = y0 + u * yu
+  int x0, y0, xu, yu, axis_dir, diag_dir;
+  if (sweep == 0) { x0 = 0; y0 = vv; xu = 1; yu = 0; axis_dir = 0; diag_dir = 1; }                    // L, TL
+  else if (sweep == 1) { x0 = W - 1; y0 = H - 1 - vv; xu = -1; yu = 0; axis_dir = 2; diag_dir = 3; }  // R, BR
+  else if (sweep == 2) { x0 = W - 1 - vv; y0 = 0; xu = 0; yu = 1; axis_dir = 4; diag_dir = 7; }       // T, TR
+  else { x0 = vv; y0 = H - 1; xu = 0; yu = -1; axis_dir = 6; diag_dir = 5; }                          // B, BL
+  // the far-side pixel of the intensity difference: (col - ax, row - ay) of the pass's path predecessor (SGM.cc:2715-2721)
+  const int row = tid >> 4, j = tid & 15;
+  const bool diag = row >= 2;
+  const vwgpu::MgmDir md = vwgpu::kMgmDirs[diag ? diag_dir : axis_dir];
+  const int dl = row == 2 ? -1 : (row == 3 ? 1 : 0);
+  const int voff = (diag ? VQ : 0) + j * Q;
+  const int moff = 2 * VQ + (diag ? 1 : 0);
+  const int num_disp = A.g.num_dx, npairs = (num_disp + 1) / 2;
+  unsigned dead[Q], r[Q];
+#pragma unroll
+  for (int e = 0; e < Q; ++e) {
+    const int p = j * Q + e;
+    dead[e] = p >= npairs ? 0xffffffffu : ((2 * p + 1 >= num_disp) ? 0xffff0000u : 0u);
+    r[e] = dead[e];
+  }
+  unsigned mp = 0;
+  const bool writer = row == 0 || row == 2;                        // the lanes that hold a pass's values for the volumes / the ring
+  const bool st_full = writer && j * Q + Q <= q32, st_part = writer && j * Q < q32 && !st_full;
+  const long long p0 = (long long)y0 * W + x0;
+  const long long pstep = (long long)yu * W + xu;                   // pixels per marching step
+  const unsigned cb0 = (unsigned)(2 * Q * j);
+  const uint8_t* cfetch = A.cost + p0 * stride + (cb0 & ~3u);
+  const unsigned csh = (cb0 & 2u) * 8u;
+  const long long cstep = pstep * stride;
+  unsigned* ostore = reinterpret_cast<unsigned*>(A.vols + (size_t)(diag ? diag_dir : axis_dir) * A.vol_stride) + p0 * q32 + j * Q;
+  const long long ostep = pstep * q32;
+  const us2 p1p1 = as_us2(A.p1 | (A.p1 << 16));
+  const unsigned p1 = A.p1, p2 = A.p2;
+
+  int gc, gp;
+  auto grey = [&](int s0) __attribute__((always_inline)) {
+    const int us = min(s0 + j, U - 1);
+    const int col = x0 + us * xu, rw_ = y0 + us * yu;
+    const int fc = min(max(col - md.ax + A.min_col, 0), A.lw - 1), fr = min(max(rw_ - md.ay + A.min_row, 0), A.lh - 1);
+    gc = A.left[(size_t)(rw_ + A.min_row) * A.lw + col + A.min_col];
+    gp = A.left[(size_t)fr * A.lw + fc];
+  };
+  grey(0);
+  unsigned penl = 0;
+  auto refresh = [&](int s0) __attribute__((always_inline)) {
+    int grad = gc - gp; grad = grad < 0 ? -grad : grad;
+    unsigned v = p2 / (unsigned)max(grad, 1);
+    if (v < p1) v = p1;
+    penl = v & 0xffffu;
+    grey(min(s0 + 16, U - 1) & ~15);
+  };
+  unsigned pm = 0xffffffffu, pn = 0xffffffffu;
+  unsigned avail = 0, cavail = 0;
+  const int bp_pen = (tid & 48) << 2;
+
+  auto step = [&](const unsigned (&cw)[NWC], int uu) __attribute__((always_inline)) {
+    const unsigned pen = (unsigned)__builtin_amdgcn_ds_bpermute(bp_pen + ((uu & 15) << 2), (int)penl);
+    // (1) the vectors the four evaluations start from
+    if (has_above) {
+      const int need = min(uu + 2, U);
+      const int sl = ((uu + dl) & AMASK) * SLOT;
+      unsigned t[Q], tm = 0;
+      for (;;) {
+        const unsigned got = avail >= (unsigned)need ? avail : *adone;
+        asm volatile("" ::: "memory");
+        if (row > 0) {
+#pragma unroll
+          for (int e = 0; e < Q; ++e) t[e] = aring[sl + voff + e];
+          tm = aring[sl + moff];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        avail = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+        if (avail >= (unsigned)need) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (row > 0) {
+#pragma unroll
+        for (int e = 0; e < Q; ++e) r[e] = t[e];
+        mp = tm;
+      }
+    }
+    // the pass's border test: a pixel that fails it keeps its local costs — both evaluations start from "none"
+    const bool uses = has_above && (diag ? (uu > 0 && uu + 1 < U) : uu > 0);
+    if (!uses) {
+#pragma unroll
+      for (int e = 0; e < Q; ++e) r[e] = dead[e];
+      mp = 0;
+    }
+    const unsigned dj = (mp + pen) & 0xffffu;
+    const us2 dJ = as_us2(dj | (dj << 16)), mpp = as_us2(mp | (mp << 16));
+    unsigned cs[NWC];
+#pragma unroll
+    for (int n = 0; n < NWC; ++n) cs[n] = (Q & 1) ? __builtin_amdgcn_alignbit(n + 1 < NWC ? cw[n + 1] : 0u, cw[n], csh) : cw[n];
+    // (2) evaluate_path for the four (pass, predecessor) pairs
+    row_shr1_keep(pm, r[Q - 1]);
+    row_shl1_keep(pn, r[0]);
+    unsigned al[Q + 1];
+    al[0] = __builtin_amdgcn_alignbit(r[0], pm, 16);
+#pragma unroll
+    for (int e = 1; e < Q; ++e) al[e] = __builtin_amdgcn_alignbit(r[e], r[e - 1], 16);
+    al[Q] = __builtin_amdgcn_alignbit(pn, r[Q - 1], 16);
+    unsigned ev[Q];
+#pragma unroll
+    for (int e = 0; e < Q; ++e) {
+      const us2 ctr = as_us2(r[e]);
+      us2 m = __builtin_elementwise_min(__builtin_elementwise_min(as_us2(al[e]), as_us2(al[e + 1])), ctr);
+      us2 v = __builtin_elementwise_add_sat(m, p1p1);
+      v = __builtin_elementwise_min(v, __builtin_elementwise_min(ctr, dJ));
+      v = __builtin_elementwise_add_sat(v, as_us2(__builtin_amdgcn_perm(0u, cs[e >> 1], (e & 1) ? 0x0c030c02u : 0x0c010c00u)));
+      v = __builtin_elementwise_sub_sat(v, mpp);
+      ev[e] = as_u32(v);
+    }
+    // (3) the mean of a pass's two evaluations: (a + b) / 2 per u16 without the 17th bit — (a & b) + ((a ^ b) >> 1)
+    us2 mn2 = as_us2(0xffffffffu);
+#pragma unroll
+    for (int e = 0; e < Q; ++e) {
+      const unsigned o = (unsigned)__builtin_amdgcn_ds_swizzle((int)ev[e], 0x401f);                   // lane ^ 16: the pass's other evaluation
+      const us2 x1 = as_us2(ev[e] ^ o);
+      const us2 half = x1 >> (us2)(1);
+      r[e] = as_u32(as_us2(ev[e] & o) + half) | dead[e];
+      mn2 = e == 0 ? as_us2(r[e]) : __builtin_elementwise_min(mn2, as_us2(r[e]));
+    }
+    const unsigned mnu = as_u32(mn2);
+    const unsigned nm = row_min_u32(min(mnu & 0xffffu, mnu >> 16));
+    // (4) hand the two passes' vectors to the next line
+    if (mode == 1) {
+      const int needc = uu - RING + 2;
+      while ((int)cavail < needc) {
+        cavail = done[wv + 1];
+        if ((int)cavail < needc) __builtin_amdgcn_s_sleep(1);
+      }
+      lds_uint* slot = oring + (uu & (RING - 1)) * SLOT;
+      if (writer) {
+#pragma unroll
+        for (int e = 0; e < Q; ++e) slot[voff + e] = r[e];
+        if (j == 0) slot[moff] = nm;
+      }
+    } else if (mode == 2) {
+      unsigned long long* ent = bdst + (size_t)uu * ENT;
+      const unsigned long long tag = (unsigned long long)epoch << 32;
+      if (writer) {
+#pragma unroll
+        for (int e = 0; e < Q; ++e) st_coherent(ent + voff + e, tag | r[e]);
+        if (j < 2) st_coherent(ent + moff + (j ? (diag ? 2 : 2) : 0), tag | nm);      // lanes 1 tag the entry's two pad words
+      }
+    }
+    asm volatile("" ::: "memory");
+    done[wv] = (unsigned)(uu + 1);
+    // (5) the passes' values of this pixel -> their volumes
+    if (st_full) {
+      SweepWords<Q> w;
+#pragma unroll
+      for (int e = 0; e < Q; ++e) w.v[e] = r[e];
+      *reinterpret_cast<SweepWords<Q>*>(ostore) = w;
+    } else if (st_part) {
+#pragma unroll
+      for (int e = 0; e < Q; ++e)
+        if (j * Q + e < q32) ostore[e] = r[e];
+    }
+    ostore += ostep;
+    mp = nm;                                                       // row 0 continues from it; rows 1 .. 3 reload theirs
+  };
+
+  unsigned cq[KC][NWC];
+  auto load_cost = [&](unsigned (&w)[NWC]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int n = 0; n < NWC; ++n) {
+      unsigned off = 4u * n;
+      asm("" : "+v"(off));
+      w[n] = *reinterpret_cast<const unsigned*>(cfetch + off);
+    }
+    cfetch += cstep;
+  };
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    load_cost(cq[k]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int u0 = 0; u0 < U; u0 += KC) {
+    if ((u0 & 15) == 0) refresh(u0);
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      if (u0 + k < U) step(cq[k], u0 + k);
+      load_cost(cq[k]);
+    }
+  }
 }
 
 // starts of the uniform layout: pixel p's vectors begin at p * stride
@@ -2364,7 +2654,54 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     K = std::max(4, std::min(K, 32));
     const size_t ulds = ((size_t)ept * 64 + 256) * sizeof(uint16_t) + (size_t)K * ustride * 3 + K + 16;
     const bool one_d = g.num_dy == 1;
-    if (P->use_mgm) {
+    int mgm_q = 0, mgm_nw = 0;
+    if (P->use_mgm && uniform && one_d && num_disp <= 256 && mgm_vols == 8 && ctx->mgm_sweep != 1 && g.ocols >= 4 && g.orows >= 4) {
+      mgm_q = (int)(((num_disp + 1) / 2 + 15) / 16);
+      if (mgm_q == 7) mgm_q = 8;
+      const size_t slot = (size_t)(2 * 16 * mgm_q + 4) * 4;
+      mgm_nw = (int)std::min<size_t>(ctx->mgm_sweep >= 2 ? ctx->mgm_sweep : 15, (120 * 1024 - 128 - SWEEP_FRING * slot) / (SWEEP_RING * slot));
+      if (mgm_nw < 2) mgm_nw = 0;
+    }
+    if (mgm_nw) {
+      // the eight passes as four concurrent sweeps (mgm_sweep_kernel), then one pass adds the volumes to the sums
+      vwgpu_prof_scope ps(ctx, "sgm_mgm_paths");
+      MgmSweepParams MA;
+      MA.g = g; MA.stride = ustride; MA.lw = lw; MA.lh = lh; MA.min_col = min_col; MA.min_row = min_row; MA.nw = mgm_nw;
+      const size_t slot_dwords = (size_t)2 * 16 * mgm_q + 4;
+      size_t entries = 0;
+      int total = 0;
+      for (int q = 0; q < 4; ++q) {
+        const int lines = q < 2 ? H : W, len = q < 2 ? W : H;
+        MA.nblk[q] = (lines + mgm_nw - 1) / mgm_nw;
+        MA.blk0[q] = total; total += MA.nblk[q];
+        MA.bnd_off[q] = entries; entries += (size_t)MA.nblk[q] * len;
+      }
+      MA.blk0[4] = total;
+      const size_t bnd_bytes = entries * slot_dwords * 8 + 256;
+      if (ctx->sgm_bnd.cap < bnd_bytes || ctx->sgm_epoch == 0xffffffffu) {
+        rc = vwgpu_arena_reserve(ctx, &ctx->sgm_bnd, bnd_bytes);
+        if (rc) return rc;
+        VWGPU_HIP(ctx, hipMemsetAsync(ctx->sgm_bnd.base, 0, ctx->sgm_bnd.cap, st));
+        ctx->sgm_epoch = 0;
+      }
+      MA.p1 = (unsigned)p1; MA.p2 = (unsigned)p2; MA.epoch = ++ctx->sgm_epoch;
+      MA.left = l8; MA.cost = cost; MA.vols = mgm_vol; MA.vol_stride = vol_bytes / 2;
+      MA.sync = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->sgm_bnd.base));
+      MA.bnd = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->sgm_bnd.base) + 256);
+      VWGPU_HIP(ctx, hipMemsetAsync(MA.sync, 0, 256, st));
+      const size_t mlds = (32 + ((size_t)mgm_nw * SWEEP_RING + SWEEP_FRING) * slot_dwords) * 4;
+      const dim3 grd((unsigned)total), blk((unsigned)((mgm_nw + 1) * 64));
+#define VWGPU_MSWEEP(QQ) do { VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(mgm_sweep_kernel<QQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds)); \
+                              hipLaunchKernelGGL(mgm_sweep_kernel<QQ>, grd, blk, mlds, st, MA); } while (0)
+      switch (mgm_q) {
+        case 1: VWGPU_MSWEEP(1); break; case 2: VWGPU_MSWEEP(2); break; case 3: VWGPU_MSWEEP(3); break; case 4: VWGPU_MSWEEP(4); break;
+        case 5: VWGPU_MSWEEP(5); break; case 6: VWGPU_MSWEEP(6); break; default: VWGPU_MSWEEP(8); break;
+      }
+#undef VWGPU_MSWEEP
+      const size_t words = (vol_bytes + 15) / 16;
+      hipLaunchKernelGGL(mgm_sum_kernel, dim3((unsigned)std::min<size_t>((words + 255) / 256, 8192)), dim3(256), 0, st, reinterpret_cast<uint4*>(accum),
+                         reinterpret_cast<const uint4*>(mgm_vol), vol_bytes / 16, words, 8, 0);
+    } else if (P->use_mgm) {
       // accum_mgm_multithread: one launch per front (see mgm_front_kernel) for all directions whose volumes fit: the axis
       // directions have W + H - 1 anti-diagonal fronts, the diagonal ones max(W, H) row / column fronts, so eight directions
       // together take W + H - 1 launches; then one pass adds the volumes to the sums.
