@@ -235,25 +235,42 @@ bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__
     rps[k] = (NCC && act[k]) ? rp[k] : prec;
   }
   const double* lps = NCC ? (row_ok ? lp : prec) : nullptr;
-  double pl[NCH], pt[NCH], crp[NCH], nrp[NCH];
-  double clp = 0.0, nlp = 0.0;
+  // Round 3: the operands of a step are requested PF steps ahead (a ring of PF register sets, the step loop unrolled PF times).  One
+  // step ahead left a chain step at the latency of a memory round trip — 1.1 us per step at any chunk count, 0.46 ms for a 256-step
+  // chain (tools/time_exact_zone.py) — and the longest chains of a level ARE the time of the launch.  (4 / 3 / 2 sets for 1 / 3 / 8
+  // chunks per lane: what the register file takes.)
+  constexpr int PF = NCH <= 1 ? 4 : (NCH <= 3 ? 3 : 2);
+  double pl[PF][NCH], pt[PF][NCH], crp[NCH], nrp[PF][NCH];
+  double clp = 0.0, nlp[PF];
+  auto request = [&](int u, int t) __attribute__((always_inline)) {     // the operands that END step t (clamped: requests past the row re-read its end)
+    const int tc = min(t, z.zw - 1);
+    const size_t li = (size_t)min(tc + kx, cw - 1) * dp, ti = (size_t)tc * dp;
+    const int xn = min(tc + 1, z.zw - 1);
 #pragma unroll
-  for (int k = 0; k < NCH; ++k) { pl[k] = pt[k] = crp[k] = nrp[k] = 0.0; if (NCC && k < nch) crp[k] = rps[k][0]; }
+    for (int k = 0; k < NCH; ++k)
+      if (k < nch) {                                    // wave-uniform
+        pl[u][k] = base[li + off[k]]; pt[u][k] = base[ti + off[k]];
+        if (NCC) nrp[u][k] = rps[k][xn];
+      }
+    if (NCC) nlp[u] = lps[xn];
+  };
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) { crp[k] = 0.0; if (NCC && k < nch) crp[k] = rps[k][0]; }
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) pl[u][k] = pt[u][k] = nrp[u][k] = 0.0;
+    nlp[u] = 0.0;
+    request(u, u);
+  }
   if (NCC) clp = lps[0];
 
   int res_d = 0, res_v = 0;                             // buffered result of the step x with (x & (lanes-1)) == dl
-  for (int x = 0; x < z.zw; ++x) {
-    {
-      const size_t li = (size_t)min(x + kx, cw - 1) * dp, ti = (size_t)x * dp;
-      const int xn = min(x + 1, z.zw - 1);
+  for (int x0 = 0; x0 < z.zw; x0 += PF)
 #pragma unroll
-      for (int k = 0; k < NCH; ++k)
-        if (k < nch) {                                  // wave-uniform
-          pl[k] = base[li + off[k]]; pt[k] = base[ti + off[k]];
-          if (NCC) nrp[k] = rps[k][xn];
-        }
-      if (NCC) nlp = lps[xn];
-    }
+  for (int u = 0; u < PF; ++u) {
+    const int x = x0 + u;
+    if (x >= z.zw) break;
     // this lane's candidates, in disparity order
     double c[NCH];
     double best = SENT_BEST, worst = SENT_WORST;
@@ -303,11 +320,12 @@ bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__
     if (x + 1 < z.zw) {
 #pragma unroll
       for (int k = 0; k < NCH; ++k)
-        if (k < nch && act[k]) r[k] += pl[k] - pt[k];
+        if (k < nch && act[k]) r[k] += pl[u][k] - pt[u][k];
     }
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) crp[k] = nrp[k];
-    clp = nlp;
+    for (int k = 0; k < NCH; ++k) crp[k] = nrp[u][k];
+    clp = nlp[u];
+    request(u, x + PF);                                 // this register set again PF steps from now
     // Disparity groups: the chain continues from the state the earlier groups left.  Without NaNs it is a (value, index) minimum
     // and a maximum, so the states merge (an earlier group wins ties: its indices are smaller); with a NaN in this group's costs
     // or in the carried state the chain is order dependent and is replayed verbatim from the carried state.
