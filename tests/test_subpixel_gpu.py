@@ -71,6 +71,21 @@ def test_integer_imagery_is_bit_exact(ctx, oracle, kernel, scale, offset):
     assert (got[5:9, 20:40] == 0).all()
 
 
+def test_tall_window_on_large_integers_does_not_wrap(ctx, oracle):
+    """15 x 69 pixels of 20-bit integers: 1035 abs-diffs of up to 2^21 exceed 32 bits — the integer form must hand the call to the
+    float64 sums (exact on integers of this size)."""
+    left, right, _ = synth.stereo_pair(120, 110, 9, 1, block=32, seeds=(51, 52, 53), smooth=True)
+    left, right = left * np.float32(4000.0), right * np.float32(4000.0)
+    right = np.ascontiguousarray(right[:110, :120 + 8])
+    disp = np.zeros((110, 120, 3), np.float32)
+    disp[..., 0] = 4.0
+    disp[..., 2] = 1.0
+    want = oracle.parabola_subpixel(disp, left, right, 0, 0.0, (15, 69))
+    got = _run(ctx, disp, left, right, 0, 0.0, (15, 69))
+    assert np.array_equal(got[..., 2], want[..., 2])
+    assert np.abs(got - want).max() < 1e-5
+
+
 @pytest.mark.parametrize("mode,width", [(2, 1.4), (1, 3.0), (0, 0.0)])
 def test_prefiltered_and_float_imagery_within_tolerance(ctx, oracle, mode, width):
     yy, xx = np.mgrid[0:60, 0:110].astype(np.float64)

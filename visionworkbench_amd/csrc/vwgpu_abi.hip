@@ -149,6 +149,7 @@ int vwgpu_set_stream(vwgpu_ctx* ctx, void* hip_stream) {
   (void)hipStreamSynchronize(ctx->stream);
   ctx->stream = s;
   ctx->stream_is_own = false;
+  ctx->measure_first = false;       // the launch order of the next call must not depend on what another stream's caller fed last
   return VWGPU_OK;
 }
 
@@ -172,6 +173,7 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx) { return ctx ? ctx->err.c_str
 int vwgpu_force_path(vwgpu_ctx* ctx, int path) {
   if (!ctx || path < VWGPU_PATH_NONE || path > VWGPU_PATH_SAD_U16) return VWGPU_ERR_ARGUMENT;
   ctx->forced_path = path;
+  ctx->measure_first = false;
   return VWGPU_OK;
 }
 

@@ -239,6 +239,9 @@ int vwgpu_parabola_subpixel_dev(vwgpu_ctx* ctx, const float* d_disp, int w, int 
   int integer_class = 0;
   if (mode == VWGPU_PREFILTER_NONE && !(grain[2] & 1) && (grain[0] == INT_MAX || (grain[0] >= 0 && grain[1] <= 20)))
     integer_class = ((grain[0] == INT_MAX || grain[1] <= 7) && !(grain[2] & 2)) ? 2 : 1;     // bytes need non-negative pixels
+  // class 1 sums |a - b| < 2^(hi + 2) over kx * ky pixels in 32-bit unsigned integers: the window must not be able to wrap them
+  // (e.g. 15 x 69 pixels of 2^21-sized data would); otherwise the float64 sums
+  if (integer_class == 1 && grain[0] != INT_MAX && ((long long)kx * ky << (grain[1] + 2)) >= (1LL << 32)) integer_class = 0;
   const long long rminx = (long long)r4[0] - 1, rminy = (long long)r4[1] - 1;
   const long long rsx = (long long)r4[2] + 1 - r4[0] + 2, rsy = (long long)r4[3] + 1 - r4[1] + 2;
   if (rsx > 8192 || rsy > 8192 || rminx < -(1 << 20) || rminx > (1 << 20) || rminy < -(1 << 20) || rminy > (1 << 20))

@@ -37,6 +37,11 @@ def calc_disparity(cost_type, left_in, right_in, left_region, search_volume, ker
     image.  search_volume = (sx, sy) >= 1, kernel_size = (kx, ky) odd.  The right image must cover
     left_region grown by search_volume - 1 on the max side (the reference crops it so, :356-359).
     Returns (rows-ky+1, cols-kx+1, 3) int32 = PixelMask<Vector2i> {dx, dy, valid (INT32_MAX|0)}.
+
+    Device tensors: the call is queued on the current torch stream, but by default it WAITS for the input-class flags of the data
+    (one small device-to-host copy: packed integer kernels, the float64 tile kernel or the reference's summation order are chosen
+    from the data, so that the result is bit-exact for any input).  Callers that queue many calls set
+    ctx.set_option(core.OPT_DEFER_EXACTNESS, 1): no host round trip, ctx.last_path() reports afterwards.
     """
     kx, ky = int(kernel_size[0]), int(kernel_size[1])
     sx, sy = int(search_volume[0]), int(search_volume[1])
