@@ -18,20 +18,20 @@
 //   pass 1  bmx_col_kernel   thread <-> (zone, column, disparity), serial in y: writes col_sum(x, y, d) into the
 //                            zone's volume [row][column][disparity] (disparity fastest: lanes <-> disparities, so the
 //                            right-image reads and the volume writes are coalesced, the left pixel is a broadcast);
-//   pass 2  bmx_row_kernel   wave <-> (zone, 64 / lanes rows), lane <-> disparity, serial in x: the row recurrence
-//                            from coalesced volume reads, NCC scaling, then the winner across the disparity lanes
-//                            (lexicographic (cost, index) minimum == "strict compare, first wins"; the worst cost is
-//                            the plain extremum); a pixel whose costs contain a NaN is replayed by ONE lane with the
-//                            reference's compare chain verbatim (Correlation.cc:91-117), from costs parked in LDS.
+//   pass 2a bmx_rowsum_kernel  wave <-> (zone, 64 / lanes rows), lane <-> disparity, serial in x: the row recurrence from
+//                            coalesced volume reads, written back in place — nothing but the two additions of a chain step;
+//   pass 2b bmx_select_kernel  lane <-> pixel, no chain: NCC scaling and the reference's compare chain verbatim over the
+//                            disparities in index order (Correlation.cc:91-117; a NaN cost needs no special case).
+//   (Until round 3 pass 2 was ONE kernel that also scaled and reduced across the disparity lanes inside every chain step.)
 //
 // A "zone" is one calc_disparity problem: a SearchParam zone of a pyramid level (CorrelationView.cc:596-700; crops
 // with clamped coordinates = the ConstantEdgeExtension crops the reference hands over) or a whole raster.  NCC side
 // cars (CostFunctions.h:214-219: 1.0 / fast_box_sum(square(crop))) go through the same two passes with one
 // "disparity" per zone crop; vwgpu_fast_box_sum exports that form (Algorithms.h:41-43).
 //
-// HBM traffic: 8 B written + 8 B read per (pixel, disparity) — the price of the reference's order; the volume of a
+// HBM traffic: 8 B written + 8 B read per (pixel, disparity) for the column sums, the same again for the row sums — the price of the reference's order; the volume of a
 // whole-raster call is processed in row bands (column-chain state carried between bands) so that it stays within a
-// scratch budget.  Roofline: HBM bound by design (16 B per evaluation); it is the correctness path, not the headline.
+// scratch budget.  Roofline: HBM bound by design (32 B per evaluation); it is the correctness path, not the headline.
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -145,21 +145,66 @@ __device__ __forceinline__ double dpp_f64(double v) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// ---- pass 2: row chains + winner -----------------------------------------------------------------------------------
-// items[i] = {zone, first row}; one wave per item, 64 / lanes rows per wave.  NCH = 64-disparity chunks a lane can hold
-// (instantiated for 1, 3 and XMAX_CHUNKS; the launcher picks by the largest zone).
-// CARRY: the zone has more than 512 disparities and is served in disparity groups, one launch pair per group: the chain state of
-// every pixel is read from / left in XCarry records between the groups (Correlation.cc:64-119 loops over any search volume).
-template <int COST, int NCH, bool CARRY = false>
+// ---- pass 2 of the box sums (fast_box_sum, NCC precision images): the row chain of ONE image, the sum itself is the result ----------
+// items[i] = {zone, first row}; one wave per item, a lane per row.  (The matchers' pass 2: bmx_rowsum_kernel + bmx_select_kernel.)
+template <int COST>
 __global__ void __launch_bounds__(256)
-bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__ items, const double* __restrict__ vol,
-               int y_begin, int y_end, const double* __restrict__ prec, int32_t* __restrict__ out, double* __restrict__ outd,
-               XCarry* __restrict__ carry = nullptr) {
-  constexpr bool BOX = (COST == XCOST_BOX || COST == XCOST_PREC);
-  constexpr bool NCC = (COST == VWGPU_CROSS_CORRELATION);
-  __shared__ double park[4][NCH][64];           // costs of a NaN pixel, for the verbatim replay
+bmx_box_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__ items, const double* __restrict__ vol,
+                   int y_begin, int y_end, double* __restrict__ outd) {
+  static_assert(COST == XCOST_BOX || COST == XCOST_PREC, "box sums only");
   const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
   const int2 it = items[blockIdx.x * 4 + wave];
+  if (it.x < 0) return;
+  const XZone z = zones[it.x];                          // lanes_log2 == 0, one "disparity": a lane per row
+  const int cw = z.zw + kx - 1;
+  const int y = it.y + lane;
+  const int ylim = y_end < z.zh ? y_end : z.zh;
+  if (y >= ylim) return;
+  const double* base = vol + z.vol + (size_t)(y - y_begin) * cw;
+  double r = 0.0;
+  for (int i = 0; i < kx; ++i) r += base[i];            // Algorithms.h:84: accumulate from 0
+  double* o = outd + z.lprec + (size_t)y * z.zw;
+  const double* lead = base + kx;
+  auto put = [&](int x) __attribute__((always_inline)) { o[x] = (COST == XCOST_PREC) ? 1.0 / r : r; };
+  int x = 0;
+  // A lane streams its own row: 16 steps' operands — one 128-byte line of each stream — are requested together, so a line is
+  // consumed while it sits in the L1 instead of being fetched once per step; the chain itself is serial.
+  for (; x + 16 < z.zw; x += 16) {
+    double l[16], t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { l[i] = lead[x + i]; t[i] = base[x + i]; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { put(x + i); r += l[i] - t[i]; }
+  }
+  for (; x + 4 < z.zw; x += 4) {
+    double l[4], t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { l[i] = lead[x + i]; t[i] = base[x + i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { put(x + i); r += l[i] - t[i]; }
+  }
+  for (; x < z.zw; ++x) {
+    put(x);
+    if (x + 1 < z.zw) r += lead[x] - base[x];
+  }
+}
+
+// ---- pass 2 of the matchers (round 3): the row chains alone, then a parallel selection ------------------------------------------
+// Until round 3 one kernel ran the row chain AND, inside every chain step, the NCC scaling and the winner across the disparity
+// lanes (two f64 butterflies, a NaN replay): ~300 dependent instructions per step, 1.1 us, so a 256-pixel zone row took 0.46 ms and
+// the longest chains of a level were the time of its launch (tools/time_exact_zone.py).  The recurrence itself is two additions:
+//   bmx_rowsum_kernel   lane <-> disparity, serial in x: row_sum(x+1) = row_sum(x) + (col_sum(x+kx) - col_sum(x))  (Algorithms.h:84,92),
+//                       operands requested PF steps ahead, the row sum written IN PLACE over col_sum(x) (read for the last time in
+//                       that very step);
+//   bmx_select_kernel   lane <-> pixel: the costs of all disparities in index order through the reference's compare chain VERBATIM
+//                       (Correlation.cc:91-117; NaN behaviour for free), NCC scaling (CostFunctions.h:227-231) on the way; zones of
+//                       more than 512 disparities continue the chain from / leave it in the XCarry records of their pixels.
+// items[i] = {zone, first row, 64-disparity chunk, -}: one wave per item (64 / lanes rows of a zone that searches fewer than 64
+// disparities, one chunk of 64 otherwise — every chain is a lane of its own, whatever the zone's search volume).
+__global__ void __launch_bounds__(256)
+bmx_rowsum_kernel(int kx, const XZone* __restrict__ zones, const int4* __restrict__ items, double* __restrict__ vol, int y_begin, int y_end) {
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int4 it = items[blockIdx.x * 4 + wave];
   if (it.x < 0) return;
   const XZone z = zones[it.x];
   const int cw = z.zw + kx - 1;
@@ -167,232 +212,111 @@ bmx_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__
   const int g = lane >> z.lanes_log2, dl = lane & (lanes - 1);
   const int y = it.y + g;
   const int ylim = y_end < z.zh ? y_end : z.zh;
-  const bool row_ok = y < ylim;
-  const int D = z.dn;
   const int dp = z.nchunk == 1 ? lanes : z.nchunk * 64;
-  const int nch = z.nchunk;
-  const double* base = vol + z.vol + (size_t)(row_ok ? y - y_begin : 0) * cw * dp;
-
-  double r[NCH];
-  int dk[NCH];
-  const double* rp[NCH];
-  bool act[NCH];
-  const int rpw = z.zw + z.sx - 1;
-#pragma unroll
-  for (int k = 0; k < NCH; ++k) {
-    dk[k] = k * 64 + dl;
-    act[k] = row_ok && k < nch && dk[k] < D;
-    r[k] = 0.0;
-    rp[k] = nullptr;
-    if (act[k]) {
-      for (int i = 0; i < kx; ++i) r[k] += base[(size_t)i * dp + dk[k]];       // Algorithms.h:84: accumulate from 0
-      if (NCC) {
-        const int dy = (z.d0 + dk[k]) / z.sx, dx = (z.d0 + dk[k]) - dy * z.sx;
-        rp[k] = prec + z.rprec + (size_t)(y + dy) * rpw + dx;
-      }
-    }
-  }
-  const double* lp = NCC ? prec + z.lprec + (size_t)(row_ok ? y : 0) * z.zw : nullptr;
-  const double SENT_BEST = NCC ? -INFINITY : INFINITY, SENT_WORST = NCC ? INFINITY : -INFINITY;
-
-  if (BOX) {                                            // one chain per lane (lanes == 1, dp == 1): the sum itself is the result
-    if (!act[0]) return;
-    double* o = outd + z.lprec + (size_t)y * z.zw;
-    const double* lead = base + kx;
-    auto put = [&](int x) __attribute__((always_inline)) { o[x] = (COST == XCOST_PREC) ? 1.0 / r[0] : r[0]; };
-    int x = 0;
-    // A lane streams its own row (lanes = rows): 16 steps' operands — one 128-byte line of each stream — are requested together,
-    // so a line is consumed while it sits in the L1 instead of being fetched once per step; the chain itself is serial.
-    for (; x + 16 < z.zw; x += 16) {
-      double l[16], t[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { l[i] = lead[x + i]; t[i] = base[x + i]; }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { put(x + i); r[0] += l[i] - t[i]; }
-    }
-    for (; x + 4 < z.zw; x += 4) {
-      double l[4], t[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { l[i] = lead[x + i]; t[i] = base[x + i]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { put(x + i); r[0] += l[i] - t[i]; }
-    }
-    for (; x < z.zw; ++x) {
-      put(x);
-      if (x + 1 < z.zw) r[0] += lead[x] - base[x];
-    }
-    return;
-  }
-  // The operands of a step — the two column sums that advance each chain and, for NCC, the precisions — are requested one step
-  // ahead, unconditionally (idle lanes / chunks read a valid dummy address, the last step re-reads clamped indices): loaded and
-  // consumed in the same step they cost a memory round trip per step; a load under a lane condition makes the compiler drain
-  // every outstanding request (s_waitcnt vmcnt(0)) before the next use.
-  int off[NCH];
-  const double* rps[NCH];
-#pragma unroll
-  for (int k = 0; k < NCH; ++k) {
-    off[k] = act[k] ? dk[k] : 0;
-    rps[k] = (NCC && act[k]) ? rp[k] : prec;
-  }
-  const double* lps = NCC ? (row_ok ? lp : prec) : nullptr;
-  // Round 3: the operands of a step are requested PF steps ahead (a ring of PF register sets, the step loop unrolled PF times).  One
-  // step ahead left a chain step at the latency of a memory round trip — 1.1 us per step at any chunk count, 0.46 ms for a 256-step
-  // chain (tools/time_exact_zone.py) — and the longest chains of a level ARE the time of the launch.  (4 / 3 / 2 sets for 1 / 3 / 8
-  // chunks per lane: what the register file takes.)
-  constexpr int PF = NCH <= 1 ? 4 : (NCH <= 3 ? 3 : 2);
-  double pl[PF][NCH], pt[PF][NCH], crp[NCH], nrp[PF][NCH];
-  double clp = 0.0, nlp[PF];
-  auto request = [&](int u, int t) __attribute__((always_inline)) {     // the operands that END step t (clamped: requests past the row re-read its end)
+  const int dk = it.z * 64 + dl;
+  if (y >= ylim || dk >= z.dn) return;
+  double* base = vol + z.vol + (size_t)(y - y_begin) * cw * dp + dk;
+  double r = 0.0;
+  for (int i = 0; i < kx; ++i) r += base[(size_t)i * dp];          // Algorithms.h:84: accumulate from 0
+  // requests in flight per chain: the volumes of a level are far larger than the L2, a request is ~2 us away
+  constexpr int PF = 12;
+  double pl[PF], pt[PF];
+  auto request = [&](int u, int t) __attribute__((always_inline)) {     // the operands that END step t (requests past the row re-read its end)
     const int tc = min(t, z.zw - 1);
-    const size_t li = (size_t)min(tc + kx, cw - 1) * dp, ti = (size_t)tc * dp;
-    const int xn = min(tc + 1, z.zw - 1);
-#pragma unroll
-    for (int k = 0; k < NCH; ++k)
-      if (k < nch) {                                    // wave-uniform
-        pl[u][k] = base[li + off[k]]; pt[u][k] = base[ti + off[k]];
-        if (NCC) nrp[u][k] = rps[k][xn];
-      }
-    if (NCC) nlp[u] = lps[xn];
+    pl[u] = base[(size_t)min(tc + kx, cw - 1) * dp];
+    pt[u] = base[(size_t)tc * dp];
   };
 #pragma unroll
-  for (int k = 0; k < NCH; ++k) { crp[k] = 0.0; if (NCC && k < nch) crp[k] = rps[k][0]; }
-#pragma unroll
-  for (int u = 0; u < PF; ++u) {
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) pl[u][k] = pt[u][k] = nrp[u][k] = 0.0;
-    nlp[u] = 0.0;
-    request(u, u);
-  }
-  if (NCC) clp = lps[0];
-
-  int res_d = 0, res_v = 0;                             // buffered result of the step x with (x & (lanes-1)) == dl
+  for (int u = 0; u < PF; ++u) request(u, u);
   for (int x0 = 0; x0 < z.zw; x0 += PF)
 #pragma unroll
-  for (int u = 0; u < PF; ++u) {
-    const int x = x0 + u;
-    if (x >= z.zw) break;
-    // this lane's candidates, in disparity order
-    double c[NCH];
-    double best = SENT_BEST, worst = SENT_WORST;
-    int bd = INT_MAX;
-    bool nan = false;
-    const double lpx = clp;
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      c[k] = 0.0;
-      if (k < nch && act[k]) {
-        double v = r[k];
-        if (NCC) v *= sqrt(lpx * crp[k]);               // CostFunctions.h:227-231
-        c[k] = v;
-        nan |= (v != v);
-        if (xbetter<COST>(v, best) || (v == best && dk[k] < bd)) { best = v; bd = dk[k]; }
-        if (xbetter<COST>(worst, v)) worst = v;
+    for (int u = 0; u < PF; ++u) {
+      const int x = x0 + u;
+      if (x < z.zw) {                                  // (wave-uniform; no `break`: the loop must unroll, pl / pt are registers)
+        base[(size_t)x * dp] = r;                      // in place: col_sum(x) was requested PF steps ago and is not needed again
+        r += pl[u] - pt[u];                            // Algorithms.h:92 (the value after the last pixel is not used)
+        // requests of step x + PF read col_sum(x + PF) and col_sum(x + PF + kx): columns this wave has not overwritten yet
+        request(u, x + PF);
       }
     }
-    // winner across the disparity lanes of the row's group
-    int nanw = nan ? 1 : 0;
-    // Winner across the group's lanes in two butterflies: first the extreme VALUES (v_max_f64 / v_min_f64: one instruction per
-    // stage), then the smallest disparity among the lanes that hold the best value — "strict compare, first wins" without carrying
-    // (value, index) pairs and a lexicographic select through every stage (that form was ~150 of the ~320 VALU instructions of a
-    // pixel step).  -0.0 and +0.0 compare equal, as in the reference's chain; NaN costs take the replay below.
-    // Partners 32 and 16 lanes away through ds_bpermute, the four nearest stages as DPP moves (quad permutes, row_half_mirror,
-    // row_mirror: inside an aligned group of 2 / 4 / 8 / 16 lanes they pair the same halves).
-    auto fold_v = [&](double ob, double ow, int on) __attribute__((always_inline)) {
-      nanw |= on;
-      best = NCC ? fmax(best, ob) : fmin(best, ob);
-      worst = NCC ? fmin(worst, ow) : fmax(worst, ow);
-    };
-    const double lbest = best;                            // this lane's best value; bd = its (smallest) disparity
-    if (lanes > 32) fold_v(__shfl_xor(best, 32), __shfl_xor(worst, 32), __shfl_xor(nanw, 32));
-    if (lanes > 16) fold_v(__shfl_xor(best, 16), __shfl_xor(worst, 16), __shfl_xor(nanw, 16));
-    if (lanes > 8) fold_v(dpp_f64<0x140>(best), dpp_f64<0x140>(worst), dpp_i32<0x140>(nanw));     // row_mirror
-    if (lanes > 4) fold_v(dpp_f64<0x141>(best), dpp_f64<0x141>(worst), dpp_i32<0x141>(nanw));     // row_half_mirror
-    if (lanes > 2) fold_v(dpp_f64<0x4E>(best), dpp_f64<0x4E>(worst), dpp_i32<0x4E>(nanw));         // quad_perm [2,3,0,1]
-    if (lanes > 1) fold_v(dpp_f64<0xB1>(best), dpp_f64<0xB1>(worst), dpp_i32<0xB1>(nanw));         // quad_perm [1,0,3,2]
-    bd = (lbest == best) ? bd : INT_MAX;                   // lanes without a candidate hold the sentinel: never equal, or bd = INT_MAX
-    if (lanes > 32) bd = min(bd, __shfl_xor(bd, 32));
-    if (lanes > 16) bd = min(bd, __shfl_xor(bd, 16));
-    if (lanes > 8) bd = min(bd, dpp_i32<0x140>(bd));
-    if (lanes > 4) bd = min(bd, dpp_i32<0x141>(bd));
-    if (lanes > 2) bd = min(bd, dpp_i32<0x4E>(bd));
-    if (lanes > 1) bd = min(bd, dpp_i32<0xB1>(bd));
-    // advance the chains (Algorithms.h:92) with the operands requested at the top of the step
-    if (x + 1 < z.zw) {
-#pragma unroll
-      for (int k = 0; k < NCH; ++k)
-        if (k < nch && act[k]) r[k] += pl[u][k] - pt[u][k];
-    }
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) crp[k] = nrp[u][k];
-    clp = nlp[u];
-    request(u, x + PF);                                 // this register set again PF steps from now
-    // Disparity groups: the chain continues from the state the earlier groups left.  Without NaNs it is a (value, index) minimum
-    // and a maximum, so the states merge (an earlier group wins ties: its indices are smaller); with a NaN in this group's costs
-    // or in the carried state the chain is order dependent and is replayed verbatim from the carried state.
-    XCarry cin{0.0, 0.0, 0, 0};
-    bool cont = false;                                  // this pixel's chain has a carried state
-    if (CARRY) {
-      cont = (z.carry_mode & 1) != 0;
-      if (cont && row_ok) {
-        cin = carry[z.carry + (size_t)y * z.zw + x];
-        if (cin.best != cin.best || cin.worst != cin.worst) nanw = 1;
-      }
-    }
-    if (__any(nanw)) {                                  // wave-uniform: some pixel of this step has a NaN cost
-#pragma unroll
-      for (int k = 0; k < NCH; ++k)
-        if (k < nch) park[wave][k][lane] = c[k];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (nanw && dl == 0 && row_ok) {                  // Correlation.cc:91-117, verbatim
-        double b2 = cin.best, w2 = cin.worst;
-        int i2 = cin.idx;
-        for (int d = 0; d < D; ++d) {
-          const double v = nch == 1 ? park[wave][0][g * lanes + d] : park[wave][d >> 6][d & 63];
-          if (d == 0 && !cont) { b2 = w2 = v; i2 = 0; }
-          else if (xbetter<COST>(v, b2)) { b2 = v; i2 = (CARRY ? z.d0 : 0) + d; }
-          else if (!xbetter<COST>(v, w2)) { w2 = v; }
-        }
-        best = b2; worst = w2; bd = i2 - (CARRY ? z.d0 : 0);
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (lanes > 1) {                                  // hand the replayed result to the lane that buffers this step
-        const int src = g * lanes;
-        const double b3 = __shfl(best, src), w3 = __shfl(worst, src);
-        const int d3 = __shfl(bd, src);
-        if (nanw) { best = b3; worst = w3; bd = d3; }
-      }
-    }
-    if (CARRY) {
-      int gd = z.d0 + bd;                               // index in the zone's whole search volume
-      if (cont && !nanw) {
-        if (!xbetter<COST>(best, cin.best)) { best = cin.best; gd = cin.idx; }
-        if (xbetter<COST>(worst, cin.worst)) worst = cin.worst;
-      }
-      if (row_ok && dl == 0) {
-        if (z.carry_mode & 2) {
-          carry[z.carry + (size_t)y * z.zw + x] = XCarry{best, worst, gd, 0};
-        } else {
-          const int dy = gd / z.sx, dx = gd - dy * z.sx;
-          int32_t* o = out + ((size_t)z.out_off + (size_t)y * z.out_stride + x) * 3;
-          o[0] = dx + z.addx; o[1] = dy + z.addy; o[2] = (best == worst) ? 0 : 0x7fffffff;
-        }
-      }
-      continue;
-    }
-    const int slot = x & (lanes - 1);
-    if (dl == slot) { res_d = bd; res_v = (best == worst) ? 0 : 0x7fffffff; }   // Correlation.cc:121-133
-    if (slot == lanes - 1 || x == z.zw - 1) {
-      const int xb = x - slot;
-      if (row_ok && dl <= slot) {
-        const int dy = res_d / z.sx, dx = res_d - dy * z.sx;
-        int32_t* o = out + ((size_t)z.out_off + (size_t)y * z.out_stride + xb + dl) * 3;
-        o[0] = dx + z.addx; o[1] = dy + z.addy; o[2] = res_v;
-      }
-    }
-  }
 }
 
+// items[i] = {zone, y0 | x-chunk << 20}: a wave serves 64 pixels — (64 >> xlog) rows x (1 << xlog) columns, xlog = log2 of the zone's
+// width rounded up to a power of two (at most 64 columns per chunk).
+template <int COST, bool CARRY>
+__global__ void __launch_bounds__(256)
+bmx_select_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__ items, const double* __restrict__ vol, int y_begin, int y_end,
+                  const double* __restrict__ prec, int32_t* __restrict__ out, XCarry* __restrict__ carry) {
+  constexpr bool NCC = (COST == VWGPU_CROSS_CORRELATION);
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int2 it = items[blockIdx.x * 4 + wave];
+  if (it.x < 0) return;
+  const XZone z = zones[it.x];
+  const int cw = z.zw + kx - 1;
+  const int lanes = 1 << z.lanes_log2;
+  const int dp = z.nchunk == 1 ? lanes : z.nchunk * 64;
+  int xlog = 0;
+  while ((1 << xlog) < z.zw && xlog < 6) ++xlog;
+  const int x = (it.y >> 20) * 64 + (lane & ((1 << xlog) - 1));
+  const int y = (it.y & 0xfffff) + (lane >> xlog);
+  const int ylim = y_end < z.zh ? y_end : z.zh;
+  const bool ok = x < z.zw && y < ylim;
+  if (!ok) return;
+  const double* v = vol + z.vol + ((size_t)(y - y_begin) * cw + x) * dp;
+  const int rpw = z.zw + z.sx - 1;
+  const double lp = NCC ? prec[z.lprec + (size_t)y * z.zw + x] : 0.0;
+  const double* rpb = NCC ? prec + z.rprec + (size_t)y * rpw + x : nullptr;
+  double best = 0.0, worst = 0.0;
+  int idx = 0;
+  bool first = true;                                    // no value seen yet: the chain starts with `best = worst = v` (Correlation.cc:93-96)
+  if (CARRY && (z.carry_mode & 1)) {
+    const XCarry c = carry[z.carry + (size_t)y * z.zw + x];
+    best = c.best; worst = c.worst; idx = c.idx; first = false;
+  }
+  int dy = z.d0 / z.sx, dx = z.d0 - dy * z.sx;          // the group's first disparity
+  const int D = z.dn;
+  auto take = [&](double c, int d) __attribute__((always_inline)) {
+    if (first) { best = worst = c; idx = d; first = false; }
+    else if (xbetter<COST>(c, best)) { best = c; idx = d; }
+    else if (!xbetter<COST>(c, worst)) { worst = c; }
+  };
+  int d = 0;
+  // A lane streams its own pixel's vector: consecutive lanes are dp * 8 bytes apart, so one request touches 64 cache lines whatever
+  // its width — eight disparities (two 32-byte requests) are asked for together and a line is used up in two visits instead of 16.
+  struct __attribute__((packed, aligned(8))) D4 { double v[4]; };
+  for (; d + 8 <= D; d += 8) {
+    const D4 a = *reinterpret_cast<const D4*>(v + d), b = *reinterpret_cast<const D4*>(v + d + 4);
+    double c[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      c[i] = i < 4 ? a.v[i] : b.v[i - 4];
+      if (NCC) {
+        q[i] = rpb[(size_t)dy * rpw + dx];
+        if (++dx == z.sx) { dx = 0; ++dy; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (NCC) c[i] *= sqrt(lp * q[i]);                 // CostFunctions.h:227-231
+      take(c[i], z.d0 + d + i);
+    }
+  }
+  for (; d < D; ++d) {
+    double c = v[d];
+    if (NCC) {
+      c *= sqrt(lp * rpb[(size_t)dy * rpw + dx]);
+      if (++dx == z.sx) { dx = 0; ++dy; }
+    }
+    take(c, z.d0 + d);
+  }
+  if (CARRY && (z.carry_mode & 2)) {
+    carry[z.carry + (size_t)y * z.zw + x] = XCarry{best, worst, idx, 0};
+  } else {
+    const int qy = idx / z.sx, qx = idx - qy * z.sx;
+    int32_t* o = out + ((size_t)z.out_off + (size_t)y * z.out_stride + x) * 3;
+    o[0] = qx + z.addx; o[1] = qy + z.addy; o[2] = (best == worst) ? 0 : 0x7fffffff;       // Correlation.cc:121-133
+  }
+}
 
 // ---- small zones: the whole recurrence in LDS, one wavefront per zone (round 3) ---------------------------------------------------
 // A pyramid level is ~2000 zones of ~32 x 32 pixels with ~5 x 5 disparities each (CorrelationView.cc:596-700).  Through the two
@@ -613,6 +537,8 @@ struct Tables {
   std::vector<XZone> zones;
   std::vector<int4> col_items;
   std::vector<int2> row_items;
+  std::vector<int2> sel_items;      // bmx_select_kernel: {zone, first row | x-chunk << 20}
+  std::vector<int4> rs_items;       // bmx_rowsum_kernel: {zone, first row, chunk, -}
   size_t vol_doubles = 0;
 };
 
@@ -634,13 +560,23 @@ void add_zone(Tables& t, XZone z, int kx, int rows, bool box) {
 void build_items(Tables& t, int kx, int y_begin, int y_end) {
   t.col_items.clear();
   t.row_items.clear();
+  t.sel_items.clear();
+  t.rs_items.clear();
   for (size_t i = 0; i < t.zones.size(); ++i) {
     const XZone& z = t.zones[i];
     const int lanes = 1 << z.lanes_log2, cpw = 256 / lanes, cw = z.zw + kx - 1, rpw = 64 / lanes;
     for (int c = 0; c < z.nchunk; ++c)
       for (int x0 = 0; x0 < cw; x0 += cpw) t.col_items.push_back(make_int4((int)i, x0, c, 0));
     const int y1 = std::min(y_end, z.zh);
-    for (int y0 = std::max(y_begin, 0); y0 < y1; y0 += rpw) t.row_items.push_back(make_int2((int)i, y0));
+    for (int y0 = std::max(y_begin, 0); y0 < y1; y0 += rpw) {
+      t.row_items.push_back(make_int2((int)i, y0));
+      for (int c = 0; c < z.nchunk; ++c) t.rs_items.push_back(make_int4((int)i, y0, c, 0));
+    }
+    int xlog = 0;
+    while ((1 << xlog) < z.zw && xlog < 6) ++xlog;
+    const int rps = 64 >> xlog, nxc = (z.zw + 63) / 64;
+    for (int y0 = std::max(y_begin, 0); y0 < y1; y0 += rps)
+      for (int xc = 0; xc < nxc; ++xc) t.sel_items.push_back(make_int2((int)i, y0 | (xc << 20)));
   }
   // Longest chains first: a row item is a serial recurrence of zw steps, and the zones arrive sorted by ascending search volume —
   // the 512-wide level-0 zones would start last and finish alone (LoG + NCC tile: 5.57 -> 5.32 ms of bmx_row).
@@ -648,37 +584,50 @@ void build_items(Tables& t, int kx, int y_begin, int y_end) {
       return (long long)t.zones[a.x].zw * t.zones[a.x].nchunk > (long long)t.zones[b.x].zw * t.zones[b.x].nchunk;
     });
   while (t.row_items.size() % 4) t.row_items.push_back(make_int2(-1, 0));
+  while (t.sel_items.size() % 4) t.sel_items.push_back(make_int2(-1, 0));
+  // longest chains first, as the row items
+  std::stable_sort(t.rs_items.begin(), t.rs_items.end(), [&](const int4& a, const int4& b) { return t.zones[a.x].zw > t.zones[b.x].zw; });
+  while (t.rs_items.size() % 4) t.rs_items.push_back(make_int4(-1, 0, 0, 0));
 }
 
-struct DevTables { const XZone* zones; const int4* col; const int2* row; };
+struct DevTables { const XZone* zones; const int4* col; const int2* row; const int2* sel; const int4* rs; };
 
 int upload(vwgpu_ctx* ctx, const Tables& t, char*& cursor, char* end, DevTables* d) {
   const size_t zb = vwgpu_align_up(t.zones.size() * sizeof(XZone), 256), cb = vwgpu_align_up(t.col_items.size() * sizeof(int4), 256),
-               rb = vwgpu_align_up(t.row_items.size() * sizeof(int2), 256);
-  if (cursor + zb + cb + rb > end) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "bm_exact: table arena too small");
+               rb = vwgpu_align_up(t.row_items.size() * sizeof(int2), 256), sb = vwgpu_align_up(t.sel_items.size() * sizeof(int2), 256),
+               qb = vwgpu_align_up(t.rs_items.size() * sizeof(int4), 256);
+  const size_t all = zb + cb + rb + sb + qb;
+  if (cursor + all > end) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "bm_exact: table arena too small");
   // The host vectors are rebuilt for the next band / go out of scope while the stream still runs: the tables cross PCIe from a
   // piece of the pinned ring (one asynchronous copy); tables too large for the ring are copied from the vectors and waited for.
-  if (char* h = static_cast<char*>(vwgpu_host_ring(ctx, zb + cb + rb))) {
+  if (char* h = static_cast<char*>(vwgpu_host_ring(ctx, all))) {
     memcpy(h, t.zones.data(), t.zones.size() * sizeof(XZone));
     memcpy(h + zb, t.col_items.data(), t.col_items.size() * sizeof(int4));
     memcpy(h + zb + cb, t.row_items.data(), t.row_items.size() * sizeof(int2));
-    VWGPU_HIP(ctx, hipMemcpyAsync(cursor, h, zb + cb + rb, hipMemcpyHostToDevice, ctx->stream));
+    memcpy(h + zb + cb + rb, t.sel_items.data(), t.sel_items.size() * sizeof(int2));
+    memcpy(h + zb + cb + rb + sb, t.rs_items.data(), t.rs_items.size() * sizeof(int4));
+    VWGPU_HIP(ctx, hipMemcpyAsync(cursor, h, all, hipMemcpyHostToDevice, ctx->stream));
   } else {
     VWGPU_HIP(ctx, hipMemcpyAsync(cursor, t.zones.data(), t.zones.size() * sizeof(XZone), hipMemcpyHostToDevice, ctx->stream));
     VWGPU_HIP(ctx, hipMemcpyAsync(cursor + zb, t.col_items.data(), t.col_items.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
     VWGPU_HIP(ctx, hipMemcpyAsync(cursor + zb + cb, t.row_items.data(), t.row_items.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    VWGPU_HIP(ctx, hipMemcpyAsync(cursor + zb + cb + rb, t.sel_items.data(), t.sel_items.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    VWGPU_HIP(ctx, hipMemcpyAsync(cursor + zb + cb + rb + sb, t.rs_items.data(), t.rs_items.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
     VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   d->zones = reinterpret_cast<const XZone*>(cursor);
   d->col = reinterpret_cast<const int4*>(cursor + zb);
   d->row = reinterpret_cast<const int2*>(cursor + zb + cb);
-  cursor += zb + cb + rb;
+  d->sel = reinterpret_cast<const int2*>(cursor + zb + cb + rb);
+  d->rs = reinterpret_cast<const int4*>(cursor + zb + cb + rb + sb);
+  cursor += all;
   return VWGPU_OK;
 }
 
 size_t table_bytes(const Tables& t) {
   return vwgpu_align_up(t.zones.size() * sizeof(XZone), 256) + vwgpu_align_up(t.col_items.size() * sizeof(int4), 256) +
-         vwgpu_align_up(t.row_items.size() * sizeof(int2), 256);
+         vwgpu_align_up(t.row_items.size() * sizeof(int2), 256) + vwgpu_align_up(t.sel_items.size() * sizeof(int2), 256) +
+         vwgpu_align_up(t.rs_items.size() * sizeof(int4), 256);
 }
 
 template <int COST>
@@ -691,20 +640,21 @@ void launch_pair(vwgpu_ctx* ctx, const char* n1, const char* n2, const float* A,
                        A, aw, ah, as, B, bw, bh, bs, kx, ky, d.zones, d.col, vol, y_begin, y_end, state);
   }
   if (!t.row_items.empty()) {
-    vwgpu_prof_scope ps(ctx, n2);
-    // (one launch for all zones: launches per chunk class — leaner kernels for small searches — serialise the longest serial chains
-    // of the classes: 2.3 -> 3.9 ms on a LoG + NCC tile)
-    int nch = 1;
-    for (const XZone& z : t.zones) nch = std::max(nch, z.nchunk);
+    constexpr bool BOX = (COST == XCOST_BOX || COST == XCOST_PREC);
     const dim3 grd((unsigned)(t.row_items.size() / 4)), blk(256);
-    if (carry)
-      hipLaunchKernelGGL((bmx_row_kernel<COST, XMAX_CHUNKS, true>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd, carry);
-    else if (nch == 1)
-      hipLaunchKernelGGL((bmx_row_kernel<COST, 1>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd);
-    else if (nch <= 3)
-      hipLaunchKernelGGL((bmx_row_kernel<COST, 3>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd);
-    else
-      hipLaunchKernelGGL((bmx_row_kernel<COST, XMAX_CHUNKS>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd);
+    if constexpr (BOX) {
+      vwgpu_prof_scope ps(ctx, n2);
+      hipLaunchKernelGGL((bmx_box_row_kernel<COST>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, outd);
+    } else {
+      {
+        vwgpu_prof_scope ps(ctx, n2);
+        hipLaunchKernelGGL(bmx_rowsum_kernel, dim3((unsigned)(t.rs_items.size() / 4)), blk, 0, ctx->stream, kx, d.zones, d.rs, vol, y_begin, y_end);
+      }
+      vwgpu_prof_scope ps(ctx, "bmx_select");
+      const dim3 sgrd((unsigned)(t.sel_items.size() / 4));
+      if (carry) hipLaunchKernelGGL((bmx_select_kernel<COST, true>), sgrd, blk, 0, ctx->stream, kx, d.zones, d.sel, vol, y_begin, y_end, prec, out, carry);
+      else hipLaunchKernelGGL((bmx_select_kernel<COST, false>), sgrd, blk, 0, ctx->stream, kx, d.zones, d.sel, vol, y_begin, y_end, prec, out, carry);
+    }
   }
 }
 
