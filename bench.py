@@ -774,7 +774,10 @@ def main():
                          "issue_bound_frac": (evals / (t_hot_us * 1e-6)) / (LANES * FCLK_HZ) if t_hot_us > 0 else None,
                          "note": "rank-0 strip; issue_bound_frac = (pixel x disparity evaluations per second) / "
                                  "(256 CU x 64 lane-ops/clk x 2.4 GHz): evaluations per VOP3 issue slot — the kernel "
-                                 "is VALU-issue bound (~4.25 slots per evaluation at best), see DESIGN.md"},
+                                 "is VALU-issue bound (~4.25 slots per evaluation at best), see DESIGN.md.  north_star's 0.70 of the HBM "
+                                 "roofline is out of reach for +-64-px SAD on this ISA: every abs-diff of the cost volume is unique and SAD4-class "
+                                 "instructions deliver 4 per issue slot, which puts the floor of the formulation near 234 us per 4096^2 launch "
+                                 "(frac 0.18); the +-16-px point in `extra` shows the same kernel where the arithmetic shrinks 4x"},
         }
         if not args.no_cpu_baseline:
             # rank 0, for every N: the same leg (the other ranks wait at the final barrier)
