@@ -106,11 +106,14 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *   VWGPU_OPT_EXACT_LDS        exact-order matching of zones whose working set fits the LDS of one wavefront (bmx_zone_lds_kernel):
  *       0 = never (default: the two HBM passes for every zone — measured faster), 1 = for the zone lists of a pyramid level,
  *       2 = also for single-zone calls (calc_disparity on a small raster).
+ *   VWGPU_OPT_EXACT_SPLIT      pass 2 of the exact-order matchers: 0 = chosen by the longest chain of the call (the recurrence alone + a
+ *       parallel selection for chains of 1024 pixels and more, one fused kernel for the zone lists of a pyramid level), 1 = always
+ *       the split form, 2 = always the fused form.
  *   VWGPU_OPT_MGM_SWEEP        use_mgm on full-range one-row searches (<= 256 disparities): 0 = the eight passes as four concurrent
  *       sweeps (default), 1 = one launch per front (the round-2 schedule), 2 .. 15 = the sweeps with that many lines per workgroup. */
 typedef enum vwgpu_option {
   VWGPU_OPT_DEFER_EXACTNESS = 1, VWGPU_OPT_DEVICE_COUNT = 2, VWGPU_OPT_SAD_GROUPS = 3, VWGPU_OPT_EXACT_SCRATCH_MB = 4,
-  VWGPU_OPT_TRACE = 5, VWGPU_OPT_SGM_SWEEP = 6, VWGPU_OPT_EXACT_LDS = 7, VWGPU_OPT_MGM_SWEEP = 8
+  VWGPU_OPT_TRACE = 5, VWGPU_OPT_SGM_SWEEP = 6, VWGPU_OPT_EXACT_LDS = 7, VWGPU_OPT_MGM_SWEEP = 8, VWGPU_OPT_EXACT_SPLIT = 9
 } vwgpu_option;
 int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value);
 int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value);

@@ -22,10 +22,14 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(autouse=True)
-def _default_options(ctx):
-    """Variant-pinning options (same results, other kernels / schedules) never leak from one test into the next."""
+@pytest.fixture(autouse=True, params=["split", "fused"])
+def _default_options(request, ctx):
+    """Every test of this module runs with both forms of pass 2 (OPT_EXACT_SPLIT: the recurrence alone + a parallel selection, and
+    the fused kernel — the automatic choice goes by the longest chain of a call).  Variant-pinning options (same results, other
+    kernels / schedules) never leak from one test into the next."""
+    ctx.set_option(core.OPT_EXACT_SPLIT, 1 if request.param == "split" else 2)
     yield
+    ctx.set_option(core.OPT_EXACT_SPLIT, 0)
     ctx.set_option(core.OPT_SAD_GROUPS, 0)
     ctx.set_option(core.OPT_EXACT_SCRATCH_MB, 4096)
     ctx.set_option(core.OPT_EXACT_LDS, 0)

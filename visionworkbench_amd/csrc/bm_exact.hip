@@ -189,6 +189,230 @@ bmx_box_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restri
   }
 }
 
+// ---- pass 2 of the matchers, fused form (round 2): row chains, NCC scaling and the winner across the disparity lanes in ONE kernel ----
+// Kept for zone lists whose longest chain is short (the ~1000 zones of a pyramid level): there the three kernels of the split form move
+// the level's volumes three times and cost two more launches per level and direction — the tile loop is launch bound (LoG + NCC tile loop
+// 327 -> 291 Mpix/s with the split form everywhere).  A chain step here is ~300 dependent instructions (1.1 us): long chains — whole
+// rasters, zones as wide as a whole tile — take bmx_rowsum_kernel + bmx_select_kernel below.
+// items[i] = {zone, first row}; one wave per item, 64 / lanes rows per wave.  NCH = 64-disparity chunks a lane can hold (instantiated
+// for 1, 3 and XMAX_CHUNKS; the launcher picks by the largest zone).  CARRY: a disparity group of a zone with more than 512 disparities.
+template <int COST, int NCH, bool CARRY = false>
+__global__ void __launch_bounds__(256)
+bmx_row_fused_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__ items, const double* __restrict__ vol,
+               int y_begin, int y_end, const double* __restrict__ prec, int32_t* __restrict__ out, double* __restrict__ outd,
+               XCarry* __restrict__ carry = nullptr) {
+  constexpr bool BOX = (COST == XCOST_BOX || COST == XCOST_PREC);
+  constexpr bool NCC = (COST == VWGPU_CROSS_CORRELATION);
+  __shared__ double park[4][NCH][64];           // costs of a NaN pixel, for the verbatim replay
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int2 it = items[blockIdx.x * 4 + wave];
+  if (it.x < 0) return;
+  const XZone z = zones[it.x];
+  const int cw = z.zw + kx - 1;
+  const int lanes = 1 << z.lanes_log2;
+  const int g = lane >> z.lanes_log2, dl = lane & (lanes - 1);
+  const int y = it.y + g;
+  const int ylim = y_end < z.zh ? y_end : z.zh;
+  const bool row_ok = y < ylim;
+  const int D = z.dn;
+  const int dp = z.nchunk == 1 ? lanes : z.nchunk * 64;
+  const int nch = z.nchunk;
+  const double* base = vol + z.vol + (size_t)(row_ok ? y - y_begin : 0) * cw * dp;
+
+  double r[NCH];
+  int dk[NCH];
+  const double* rp[NCH];
+  bool act[NCH];
+  const int rpw = z.zw + z.sx - 1;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    dk[k] = k * 64 + dl;
+    act[k] = row_ok && k < nch && dk[k] < D;
+    r[k] = 0.0;
+    rp[k] = nullptr;
+    if (act[k]) {
+      for (int i = 0; i < kx; ++i) r[k] += base[(size_t)i * dp + dk[k]];       // Algorithms.h:84: accumulate from 0
+      if (NCC) {
+        const int dy = (z.d0 + dk[k]) / z.sx, dx = (z.d0 + dk[k]) - dy * z.sx;
+        rp[k] = prec + z.rprec + (size_t)(y + dy) * rpw + dx;
+      }
+    }
+  }
+  const double* lp = NCC ? prec + z.lprec + (size_t)(row_ok ? y : 0) * z.zw : nullptr;
+  const double SENT_BEST = NCC ? -INFINITY : INFINITY, SENT_WORST = NCC ? INFINITY : -INFINITY;
+
+  static_assert(!BOX, "box sums: bmx_box_row_kernel");
+  // The operands of a step — the two column sums that advance each chain and, for NCC, the precisions — are requested one step
+  // ahead, unconditionally (idle lanes / chunks read a valid dummy address, the last step re-reads clamped indices): loaded and
+  // consumed in the same step they cost a memory round trip per step; a load under a lane condition makes the compiler drain
+  // every outstanding request (s_waitcnt vmcnt(0)) before the next use.
+  int off[NCH];
+  const double* rps[NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    off[k] = act[k] ? dk[k] : 0;
+    rps[k] = (NCC && act[k]) ? rp[k] : prec;
+  }
+  const double* lps = NCC ? (row_ok ? lp : prec) : nullptr;
+  // Round 3: the operands of a step are requested PF steps ahead (a ring of PF register sets, the step loop unrolled PF times).  One
+  // step ahead left a chain step at the latency of a memory round trip — 1.1 us per step at any chunk count, 0.46 ms for a 256-step
+  // chain (tools/time_exact_zone.py) — and the longest chains of a level ARE the time of the launch.  (4 / 3 / 2 sets for 1 / 3 / 8
+  // chunks per lane: what the register file takes.)
+  constexpr int PF = NCH <= 1 ? 4 : (NCH <= 3 ? 3 : 2);
+  double pl[PF][NCH], pt[PF][NCH], crp[NCH], nrp[PF][NCH];
+  double clp = 0.0, nlp[PF];
+  auto request = [&](int u, int t) __attribute__((always_inline)) {     // the operands that END step t (clamped: requests past the row re-read its end)
+    const int tc = min(t, z.zw - 1);
+    const size_t li = (size_t)min(tc + kx, cw - 1) * dp, ti = (size_t)tc * dp;
+    const int xn = min(tc + 1, z.zw - 1);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+      if (k < nch) {                                    // wave-uniform
+        pl[u][k] = base[li + off[k]]; pt[u][k] = base[ti + off[k]];
+        if (NCC) nrp[u][k] = rps[k][xn];
+      }
+    if (NCC) nlp[u] = lps[xn];
+  };
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) { crp[k] = 0.0; if (NCC && k < nch) crp[k] = rps[k][0]; }
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) pl[u][k] = pt[u][k] = nrp[u][k] = 0.0;
+    nlp[u] = 0.0;
+    request(u, u);
+  }
+  if (NCC) clp = lps[0];
+
+  int res_d = 0, res_v = 0;                             // buffered result of the step x with (x & (lanes-1)) == dl
+  for (int x0 = 0; x0 < z.zw; x0 += PF)
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int x = x0 + u;
+    if (x >= z.zw) break;
+    // this lane's candidates, in disparity order
+    double c[NCH];
+    double best = SENT_BEST, worst = SENT_WORST;
+    int bd = INT_MAX;
+    bool nan = false;
+    const double lpx = clp;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      c[k] = 0.0;
+      if (k < nch && act[k]) {
+        double v = r[k];
+        if (NCC) v *= sqrt(lpx * crp[k]);               // CostFunctions.h:227-231
+        c[k] = v;
+        nan |= (v != v);
+        if (xbetter<COST>(v, best) || (v == best && dk[k] < bd)) { best = v; bd = dk[k]; }
+        if (xbetter<COST>(worst, v)) worst = v;
+      }
+    }
+    // winner across the disparity lanes of the row's group
+    int nanw = nan ? 1 : 0;
+    // Winner across the group's lanes in two butterflies: first the extreme VALUES (v_max_f64 / v_min_f64: one instruction per
+    // stage), then the smallest disparity among the lanes that hold the best value — "strict compare, first wins" without carrying
+    // (value, index) pairs and a lexicographic select through every stage (that form was ~150 of the ~320 VALU instructions of a
+    // pixel step).  -0.0 and +0.0 compare equal, as in the reference's chain; NaN costs take the replay below.
+    // Partners 32 and 16 lanes away through ds_bpermute, the four nearest stages as DPP moves (quad permutes, row_half_mirror,
+    // row_mirror: inside an aligned group of 2 / 4 / 8 / 16 lanes they pair the same halves).
+    auto fold_v = [&](double ob, double ow, int on) __attribute__((always_inline)) {
+      nanw |= on;
+      best = NCC ? fmax(best, ob) : fmin(best, ob);
+      worst = NCC ? fmin(worst, ow) : fmax(worst, ow);
+    };
+    const double lbest = best;                            // this lane's best value; bd = its (smallest) disparity
+    if (lanes > 32) fold_v(__shfl_xor(best, 32), __shfl_xor(worst, 32), __shfl_xor(nanw, 32));
+    if (lanes > 16) fold_v(__shfl_xor(best, 16), __shfl_xor(worst, 16), __shfl_xor(nanw, 16));
+    if (lanes > 8) fold_v(dpp_f64<0x140>(best), dpp_f64<0x140>(worst), dpp_i32<0x140>(nanw));     // row_mirror
+    if (lanes > 4) fold_v(dpp_f64<0x141>(best), dpp_f64<0x141>(worst), dpp_i32<0x141>(nanw));     // row_half_mirror
+    if (lanes > 2) fold_v(dpp_f64<0x4E>(best), dpp_f64<0x4E>(worst), dpp_i32<0x4E>(nanw));         // quad_perm [2,3,0,1]
+    if (lanes > 1) fold_v(dpp_f64<0xB1>(best), dpp_f64<0xB1>(worst), dpp_i32<0xB1>(nanw));         // quad_perm [1,0,3,2]
+    bd = (lbest == best) ? bd : INT_MAX;                   // lanes without a candidate hold the sentinel: never equal, or bd = INT_MAX
+    if (lanes > 32) bd = min(bd, __shfl_xor(bd, 32));
+    if (lanes > 16) bd = min(bd, __shfl_xor(bd, 16));
+    if (lanes > 8) bd = min(bd, dpp_i32<0x140>(bd));
+    if (lanes > 4) bd = min(bd, dpp_i32<0x141>(bd));
+    if (lanes > 2) bd = min(bd, dpp_i32<0x4E>(bd));
+    if (lanes > 1) bd = min(bd, dpp_i32<0xB1>(bd));
+    // advance the chains (Algorithms.h:92) with the operands requested at the top of the step
+    if (x + 1 < z.zw) {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+        if (k < nch && act[k]) r[k] += pl[u][k] - pt[u][k];
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) crp[k] = nrp[u][k];
+    clp = nlp[u];
+    request(u, x + PF);                                 // this register set again PF steps from now
+    // Disparity groups: the chain continues from the state the earlier groups left.  Without NaNs it is a (value, index) minimum
+    // and a maximum, so the states merge (an earlier group wins ties: its indices are smaller); with a NaN in this group's costs
+    // or in the carried state the chain is order dependent and is replayed verbatim from the carried state.
+    XCarry cin{0.0, 0.0, 0, 0};
+    bool cont = false;                                  // this pixel's chain has a carried state
+    if (CARRY) {
+      cont = (z.carry_mode & 1) != 0;
+      if (cont && row_ok) {
+        cin = carry[z.carry + (size_t)y * z.zw + x];
+        if (cin.best != cin.best || cin.worst != cin.worst) nanw = 1;
+      }
+    }
+    if (__any(nanw)) {                                  // wave-uniform: some pixel of this step has a NaN cost
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+        if (k < nch) park[wave][k][lane] = c[k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (nanw && dl == 0 && row_ok) {                  // Correlation.cc:91-117, verbatim
+        double b2 = cin.best, w2 = cin.worst;
+        int i2 = cin.idx;
+        for (int d = 0; d < D; ++d) {
+          const double v = nch == 1 ? park[wave][0][g * lanes + d] : park[wave][d >> 6][d & 63];
+          if (d == 0 && !cont) { b2 = w2 = v; i2 = 0; }
+          else if (xbetter<COST>(v, b2)) { b2 = v; i2 = (CARRY ? z.d0 : 0) + d; }
+          else if (!xbetter<COST>(v, w2)) { w2 = v; }
+        }
+        best = b2; worst = w2; bd = i2 - (CARRY ? z.d0 : 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lanes > 1) {                                  // hand the replayed result to the lane that buffers this step
+        const int src = g * lanes;
+        const double b3 = __shfl(best, src), w3 = __shfl(worst, src);
+        const int d3 = __shfl(bd, src);
+        if (nanw) { best = b3; worst = w3; bd = d3; }
+      }
+    }
+    if (CARRY) {
+      int gd = z.d0 + bd;                               // index in the zone's whole search volume
+      if (cont && !nanw) {
+        if (!xbetter<COST>(best, cin.best)) { best = cin.best; gd = cin.idx; }
+        if (xbetter<COST>(worst, cin.worst)) worst = cin.worst;
+      }
+      if (row_ok && dl == 0) {
+        if (z.carry_mode & 2) {
+          carry[z.carry + (size_t)y * z.zw + x] = XCarry{best, worst, gd, 0};
+        } else {
+          const int dy = gd / z.sx, dx = gd - dy * z.sx;
+          int32_t* o = out + ((size_t)z.out_off + (size_t)y * z.out_stride + x) * 3;
+          o[0] = dx + z.addx; o[1] = dy + z.addy; o[2] = (best == worst) ? 0 : 0x7fffffff;
+        }
+      }
+      continue;
+    }
+    const int slot = x & (lanes - 1);
+    if (dl == slot) { res_d = bd; res_v = (best == worst) ? 0 : 0x7fffffff; }   // Correlation.cc:121-133
+    if (slot == lanes - 1 || x == z.zw - 1) {
+      const int xb = x - slot;
+      if (row_ok && dl <= slot) {
+        const int dy = res_d / z.sx, dx = res_d - dy * z.sx;
+        int32_t* o = out + ((size_t)z.out_off + (size_t)y * z.out_stride + xb + dl) * 3;
+        o[0] = dx + z.addx; o[1] = dy + z.addy; o[2] = res_v;
+      }
+    }
+  }
+}
+
+
 // ---- pass 2 of the matchers (round 3): the row chains alone, then a parallel selection ------------------------------------------
 // Until round 3 one kernel ran the row chain AND, inside every chain step, the NCC scaling and the winner across the disparity
 // lanes (two f64 butterflies, a NaN replay): ~300 dependent instructions per step, 1.1 us, so a 256-pixel zone row took 0.46 ms and
@@ -646,14 +870,30 @@ void launch_pair(vwgpu_ctx* ctx, const char* n1, const char* n2, const float* A,
       vwgpu_prof_scope ps(ctx, n2);
       hipLaunchKernelGGL((bmx_box_row_kernel<COST>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, outd);
     } else {
-      {
+      int nch = 1, longest = 0;
+      for (const XZone& z : t.zones) { nch = std::max(nch, z.nchunk); longest = std::max(longest, z.zw); }
+      // long chains: the recurrence alone, then a parallel selection; short chains (zone lists of a pyramid level): one fused kernel
+      const bool split = ctx->exact_split == 1 || (ctx->exact_split == 0 && longest >= 1024);
+      if (split) {
+        {
+          vwgpu_prof_scope ps(ctx, n2);
+          hipLaunchKernelGGL(bmx_rowsum_kernel, dim3((unsigned)(t.rs_items.size() / 4)), blk, 0, ctx->stream, kx, d.zones, d.rs, vol, y_begin, y_end);
+        }
+        vwgpu_prof_scope ps(ctx, "bmx_select");
+        const dim3 sgrd((unsigned)(t.sel_items.size() / 4));
+        if (carry) hipLaunchKernelGGL((bmx_select_kernel<COST, true>), sgrd, blk, 0, ctx->stream, kx, d.zones, d.sel, vol, y_begin, y_end, prec, out, carry);
+        else hipLaunchKernelGGL((bmx_select_kernel<COST, false>), sgrd, blk, 0, ctx->stream, kx, d.zones, d.sel, vol, y_begin, y_end, prec, out, carry);
+      } else {
         vwgpu_prof_scope ps(ctx, n2);
-        hipLaunchKernelGGL(bmx_rowsum_kernel, dim3((unsigned)(t.rs_items.size() / 4)), blk, 0, ctx->stream, kx, d.zones, d.rs, vol, y_begin, y_end);
+        if (carry)
+          hipLaunchKernelGGL((bmx_row_fused_kernel<COST, XMAX_CHUNKS, true>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd, carry);
+        else if (nch == 1)
+          hipLaunchKernelGGL((bmx_row_fused_kernel<COST, 1>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd);
+        else if (nch <= 3)
+          hipLaunchKernelGGL((bmx_row_fused_kernel<COST, 3>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd);
+        else
+          hipLaunchKernelGGL((bmx_row_fused_kernel<COST, XMAX_CHUNKS>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd);
       }
-      vwgpu_prof_scope ps(ctx, "bmx_select");
-      const dim3 sgrd((unsigned)(t.sel_items.size() / 4));
-      if (carry) hipLaunchKernelGGL((bmx_select_kernel<COST, true>), sgrd, blk, 0, ctx->stream, kx, d.zones, d.sel, vol, y_begin, y_end, prec, out, carry);
-      else hipLaunchKernelGGL((bmx_select_kernel<COST, false>), sgrd, blk, 0, ctx->stream, kx, d.zones, d.sel, vol, y_begin, y_end, prec, out, carry);
     }
   }
 }

@@ -67,6 +67,7 @@ struct vwgpu_ctx {
   bool defer_exact = false;   // VWGPU_OPT_DEFER_EXACTNESS: calc_disparity_dev never waits for the input-class flags
   int sad_groups = 0;         // VWGPU_OPT_SAD_GROUPS
   int exact_scratch_mb = 4096;// VWGPU_OPT_EXACT_SCRATCH_MB
+  int exact_split = 0;        // VWGPU_OPT_EXACT_SPLIT: 0 by the longest chain, 1 always the split pass 2, 2 always the fused one
   int exact_lds = 0;          // VWGPU_OPT_EXACT_LDS: 0 never (default), 1 small zones of a multi-zone call in LDS, 2 also single-zone calls
   int trace = 0;              // VWGPU_OPT_TRACE
   int num_cu = 256;
