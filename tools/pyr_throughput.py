@@ -14,10 +14,13 @@ tiles = [(x, y) for y in range(0, W, tile) for x in range(0, W, tile)]
 cases = [("SAD 7x7, integer imagery", 0, 0, 7), ("NCC 11x11, integer imagery", 0, 2, 11), ("LoG 1.4 + SAD 7x7", 2, 0, 7),
          ("LoG 1.4 + NCC 11x11", 2, 2, 11)]
 threads = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+import os
+SPLIT = int(os.environ.get("PYR_EXACT_SPLIT", "0"))      # tool-side switch -> core.OPT_EXACT_SPLIT of every context
 torch.cuda.synchronize()
 for name, pf, cost, k in cases:
     # device time of one tile's kernels, for reference
     ctx0 = core.default_context(0)
+    ctx0.set_option(core.OPT_EXACT_SPLIT, SPLIT)
     run0 = lambda c, x, y: stereo.pyramid_correlate(Lg, Rg, None, None, pf, 1.4 if pf else 0.0, BBox2i.from_corners((-64, -1), (64, 1)), (k, k), cost,
                                                     consistency_threshold=2, filter_half_kernel=5, max_pyramid_levels=5, bbox=BBox2i(x, y, tile, tile), ctx=c)
     run0(ctx0, 1024, 1024); torch.cuda.synchronize()
@@ -26,6 +29,7 @@ for name, pf, cost, k in cases:
     line = "%-28s kernels %.2f ms/tile |" % (name, kern)
     for T in threads:
         ctxs = [core.Context(0) for _ in range(T)]
+        for c in ctxs: c.set_option(core.OPT_EXACT_SPLIT, SPLIT)
         for c in ctxs: run0(c, 0, 0)                        # arenas warm
         torch.cuda.synchronize()
         todo = list(tiles) * 6

@@ -22,11 +22,27 @@ int vwgpu_fail(vwgpu_ctx* ctx, int status, const char* fmt, ...) {
 
 int vwgpu_arena_reserve(vwgpu_ctx* ctx, vwgpu_arena* a, size_t bytes) {
   if (bytes <= a->cap) return VWGPU_OK;
-  // Kernels already queued may still use the old block: drain before freeing it.
-  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (a->base) { (void)hipFree(a->base); a->base = nullptr; a->cap = 0; }
-  const size_t want = vwgpu_align_up(bytes + bytes / 4, 1 << 20);
-  VWGPU_HIP(ctx, hipMalloc(&a->base, want));
+  // Growth is geometric and the outgrown block is NOT freed here: hipFree waits for the whole device — every stream of every tile
+  // thread — and a tile loop that meets its tiles once (the reference's block_write_image) grows its arenas all through the first
+  // dozens of tiles (LoG + NCC tiles on 4 threads: 7.0 ms per tile with the free-and-reallocate of round 2, measured in round 3).
+  // Kernels already queued keep using the old block; it goes to the context's graveyard and is released with the context (or when
+  // an allocation fails).  The garbage of a geometric series is at most the size of the live block.
+  const size_t want = vwgpu_align_up(std::max(bytes + bytes / 4, std::min(2 * a->cap, a->cap + ((size_t)4 << 30))), 1 << 20);   // doubling, by at most 4 GB
+  void* fresh = nullptr;
+  hipError_t e = hipMalloc(&fresh, want);
+  if (e != hipSuccess) {                                 // out of memory: give the garbage back and try once more
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void* g : ctx->graveyard) (void)hipFree(g);
+    ctx->graveyard.clear();
+    if (a->base) { (void)hipFree(a->base); a->base = nullptr; a->cap = 0; }
+    VWGPU_HIP(ctx, hipMalloc(&fresh, vwgpu_align_up(bytes + bytes / 4, 1 << 20)));
+    a->base = fresh;
+    a->cap = vwgpu_align_up(bytes + bytes / 4, 1 << 20);
+    return VWGPU_OK;
+  }
+  if (a->base) ctx->graveyard.push_back(a->base);
+  a->base = fresh;
   a->cap = want;
   return VWGPU_OK;
 }
@@ -137,6 +153,7 @@ void vwgpu_destroy(vwgpu_ctx* ctx) {
   if (ctx->xtab.base) (void)hipFree(ctx->xtab.base);
   if (ctx->xcarry.base) (void)hipFree(ctx->xcarry.base);
   if (ctx->staging.base) (void)hipFree(ctx->staging.base);
+  for (void* g : ctx->graveyard) (void)hipFree(g);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }

@@ -32,6 +32,7 @@ struct vwgpu_ctx {
   bool profiling = false;
   std::vector<vwgpu_prof_rec> prof;
   std::vector<hipEvent_t> event_pool;
+  std::vector<void*> graveyard;   // outgrown arena blocks (vwgpu_arena_reserve): released with the context
   vwgpu_arena scratch;   // kernel scratch (NCC precision images)
   vwgpu_arena flags;     // two alternating "input not representable" flags of the packed-u8 path
   bool flags_init = false;
