@@ -781,7 +781,9 @@ void add_zone(Tables& t, XZone z, int kx, int rows, bool box) {
   t.zones.push_back(z);
 }
 
-void build_items(Tables& t, int kx, int y_begin, int y_end) {
+// split_from: zones at least this wide take the split pass 2 (rowsum + select items), narrower ones the fused kernel (row items);
+// box tables pass INT_MAX (their pass 2 is bmx_box_row_kernel over the row items).
+void build_items(Tables& t, int kx, int y_begin, int y_end, int split_from = INT_MAX) {
   t.col_items.clear();
   t.row_items.clear();
   t.sel_items.clear();
@@ -792,10 +794,12 @@ void build_items(Tables& t, int kx, int y_begin, int y_end) {
     for (int c = 0; c < z.nchunk; ++c)
       for (int x0 = 0; x0 < cw; x0 += cpw) t.col_items.push_back(make_int4((int)i, x0, c, 0));
     const int y1 = std::min(y_end, z.zh);
-    for (int y0 = std::max(y_begin, 0); y0 < y1; y0 += rpw) {
-      t.row_items.push_back(make_int2((int)i, y0));
-      for (int c = 0; c < z.nchunk; ++c) t.rs_items.push_back(make_int4((int)i, y0, c, 0));
+    if (z.zw < split_from) {
+      for (int y0 = std::max(y_begin, 0); y0 < y1; y0 += rpw) t.row_items.push_back(make_int2((int)i, y0));
+      continue;
     }
+    for (int y0 = std::max(y_begin, 0); y0 < y1; y0 += rpw)
+      for (int c = 0; c < z.nchunk; ++c) t.rs_items.push_back(make_int4((int)i, y0, c, 0));
     int xlog = 0;
     while ((1 << xlog) < z.zw && xlog < 6) ++xlog;
     const int rps = 64 >> xlog, nxc = (z.zw + 63) / 64;
@@ -863,18 +867,16 @@ void launch_pair(vwgpu_ctx* ctx, const char* n1, const char* n2, const float* A,
     hipLaunchKernelGGL((bmx_col_kernel<COST>), dim3((unsigned)t.col_items.size()), dim3(256), 0, ctx->stream,
                        A, aw, ah, as, B, bw, bh, bs, kx, ky, d.zones, d.col, vol, y_begin, y_end, state);
   }
-  if (!t.row_items.empty()) {
+  if (!t.row_items.empty() || !t.rs_items.empty()) {
     constexpr bool BOX = (COST == XCOST_BOX || COST == XCOST_PREC);
     const dim3 grd((unsigned)(t.row_items.size() / 4)), blk(256);
     if constexpr (BOX) {
       vwgpu_prof_scope ps(ctx, n2);
       hipLaunchKernelGGL((bmx_box_row_kernel<COST>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, outd);
     } else {
-      int nch = 1, longest = 0;
-      for (const XZone& z : t.zones) { nch = std::max(nch, z.nchunk); longest = std::max(longest, z.zw); }
-      // long chains: the recurrence alone, then a parallel selection; short chains (zone lists of a pyramid level): one fused kernel
-      const bool split = ctx->exact_split == 1 || (ctx->exact_split == 0 && longest >= 1024);
-      if (split) {
+      // Long chains (wide zones, whole rasters): the recurrence alone, then a parallel selection.  Short chains — most zones of a
+      // pyramid level — keep the fused kernel: one pass over their volumes, and its register budget is set by THEIR chunk counts.
+      if (!t.rs_items.empty()) {
         {
           vwgpu_prof_scope ps(ctx, n2);
           hipLaunchKernelGGL(bmx_rowsum_kernel, dim3((unsigned)(t.rs_items.size() / 4)), blk, 0, ctx->stream, kx, d.zones, d.rs, vol, y_begin, y_end);
@@ -883,7 +885,10 @@ void launch_pair(vwgpu_ctx* ctx, const char* n1, const char* n2, const float* A,
         const dim3 sgrd((unsigned)(t.sel_items.size() / 4));
         if (carry) hipLaunchKernelGGL((bmx_select_kernel<COST, true>), sgrd, blk, 0, ctx->stream, kx, d.zones, d.sel, vol, y_begin, y_end, prec, out, carry);
         else hipLaunchKernelGGL((bmx_select_kernel<COST, false>), sgrd, blk, 0, ctx->stream, kx, d.zones, d.sel, vol, y_begin, y_end, prec, out, carry);
-      } else {
+      }
+      if (!t.row_items.empty()) {
+        int nch = 1;
+        for (const int2& it : t.row_items) if (it.x >= 0) nch = std::max(nch, t.zones[it.x].nchunk);
         vwgpu_prof_scope ps(ctx, n2);
         if (carry)
           hipLaunchKernelGGL((bmx_row_fused_kernel<COST, XMAX_CHUNKS, true>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd, carry);
@@ -1008,7 +1013,11 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
   double* state = state_doubles ? vol + vol_need : nullptr;
   double* prec = vol + vol_need + state_doubles;
 
-  build_items(match, kx, 0, band);
+  // zones at least this wide take the split pass 2 (VWGPU_OPT_EXACT_SPLIT: 0 = 1024 pixels — whole rasters; the zones of a pyramid tile stay
+  // with the fused kernel: with a 128-pixel threshold the selection pass over a level's wide zones cost more than their chains had, LoG + NCC
+  // tile loop 3.18 -> 3.40 ms per tile; 1 = all; 2 = none)
+  const int split_from = ctx->exact_split == 1 ? 0 : (ctx->exact_split == 2 ? INT_MAX : 1024);
+  build_items(match, kx, 0, band, split_from);
   build_items(boxa, kx, 0, INT_MAX);
   build_items(boxb, kx, 0, INT_MAX);
   // tables of every launch of this call live side by side (uploads are stream ordered)
@@ -1029,7 +1038,7 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
   const int nbands = band == INT_MAX ? 1 : (zh0 + band - 1) / band;
   for (int b = 0; b < nbands; ++b) {
     const int yb = band == INT_MAX ? 0 : b * band, ye = band == INT_MAX ? INT_MAX : yb + band;
-    if (band != INT_MAX) build_items(match, kx, yb, ye);
+    if (band != INT_MAX) build_items(match, kx, yb, ye, split_from);
     if ((rc = upload(ctx, match, cur, end, &d))) return rc;
     switch (cost_type) {
       case VWGPU_CROSS_CORRELATION:
