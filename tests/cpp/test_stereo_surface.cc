@@ -438,6 +438,22 @@ static void test_sgm_constant_offset() {
                                   SemiGlobalMatcher::SUBPIXEL_LC_BLEND, Vector2i(4, 4), 1024, matcher_ptr), NoImplErr);
   EXPECT_THROW(calc_disparity_sgm(CENSUS_TRANSFORM, left, right, BBox2i(0, 0, 401, 400), Vector2i(9, 9), Vector2i(3, 3), false,
                                   SemiGlobalMatcher::SUBPIXEL_LC_BLEND, Vector2i(4, 4), 1024, matcher_ptr), ArgumentErr);
+  // the block cost behind the reference's throw (SGM.cc:1651-1738, :1887-1892): explicit opt-in, identical to the oracle
+  sgm_allow_block_cost() = true;
+  vwo_set_sgm_allow_block_cost(1);
+  SemiGlobalMatcher::DisparityImage mad =
+      calc_disparity_sgm(ABSOLUTE_DIFFERENCE, left, right, BBox2i(0, 0, left.cols(), left.rows()), Vector2i(disp_x_range, disp_y_range),
+                         Vector2i(kernel_size, kernel_size), false, SemiGlobalMatcher::SUBPIXEL_LC_BLEND, Vector2i(4, 4), 1024, matcher_ptr);
+  EXPECT_EQ(0, vwo_calc_disparity_sgm(0, &left(0, 0).v(), 400, 400, &right(0, 0).v(), right.cols(), right.rows(), disp_x_range, disp_y_range,
+                                      kernel_size, 5, 4, 4, 1024, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, want.data(), 0, &ow, &oh));
+  bad = 0;
+  for (int r = 0; r < oh; ++r) for (int c = 0; c < ow; ++c) {
+    const int32_t* w3 = &want[((size_t)r * ow + c) * 3];
+    if (mad(c, r)[0] != w3[0] || mad(c, r)[1] != w3[1] || mad(c, r).valid() != w3[2]) ++bad;
+  }
+  EXPECT_EQ(0, bad);
+  sgm_allow_block_cost() = false;
+  vwo_set_sgm_allow_block_cost(0);
 }
 
 // --- block_rasterize: the tile loop of tools/correlate (src/vw/tools/correlate.cc:207-266), 4 worker threads --------------
