@@ -300,6 +300,15 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right, with
           {"bm_corr_u8", "ncc_full", "bm_dot_u8"}, (W - 10) * (H - 10), path=ctx.last_path(),
           cpu_baseline=cpu(lambda j: oracle.calc_disparity(2, left[j:j + 266, :266], right[j:j + 266, :266 + 128], (11, 11), SEARCH),
                            [256 * (i % 15) for i in range(8 * cores)], cores, 256 * 256, "256^2 output tile (the library's default tile), 11x11 NCC, 129 disparities"))
+    # (2b) the same call on 12-bit imagery (pixels * 16 + 7: integers in [7, 4087]): v_dot2_u32_u16 pairs instead of v_dot4_u32_u8 quads
+    l12, r12 = lt * 16.0 + 7.0, rt * 16.0 + 7.0
+    left12, right12 = left * np.float32(16.0) + np.float32(7.0), right * np.float32(16.0) + np.float32(7.0)
+    wall, kern = measure(ctx, torch, lambda: stereo.calc_disparity(2, l12, r12, bb, SEARCH, (11, 11), ctx=ctx), 10)
+    entry("config 3a on 12-bit imagery: 4096^2, 11x11 NCC, search 129x1", algorithmic_bytes(W, H, 11, 11, 129, 1), "4LW + 4RW + 12 out (SURVEY 8d)", wall, kern,
+          {"bm_corr_u16", "ncc_full"}, (W - 10) * (H - 10), path=ctx.last_path(),
+          cpu_baseline=cpu(lambda j: oracle.calc_disparity(2, left12[j:j + 266, :266], right12[j:j + 266, :266 + 128], (11, 11), SEARCH),
+                           [256 * (i % 15) for i in range(8 * cores)], cores, 256 * 256, "256^2 output tile (the library's default tile), 11x11 NCC, 129 disparities"))
+    del l12, r12
     d = stereo.calc_disparity(2, lt, rt, bb, SEARCH, (11, 11), ctx=ctx)
     disp = torch.zeros((H, W, 3), dtype=torch.float32, device=lt.device)
     disp[5:5 + H - 10, 5:5 + W - 10, :2] = d[..., :2].float()

@@ -60,7 +60,8 @@ typedef enum vwgpu_path {
   VWGPU_PATH_SAD_U8 = 2,       /* integer-valued inputs in [0,255]: packed u8 SAD (v_qsad_pk_u16_u8)      */
   VWGPU_PATH_DOT_U8 = 3,       /* integer-valued inputs in [0,255]: SSD / NCC on v_dot4_u32_u8            */
   VWGPU_PATH_EXACT_ORDER = 4,  /* inputs whose box sums round: the reference's serial summation order     */
-  VWGPU_PATH_SAD_U16 = 5       /* integer-valued inputs in [0,65535]: SAD on v_sad_u16 pixel pairs        */
+  VWGPU_PATH_SAD_U16 = 5,      /* integer-valued inputs in [0,65535]: SAD on v_sad_u16 pixel pairs        */
+  VWGPU_PATH_DOT_U16 = 6       /* integer-valued inputs in [0,4095]: SSD / NCC on v_dot2_u32_u16          */
 } vwgpu_path;
 
 /* ---- context ------------------------------------------------------------------------------------- */

@@ -6,20 +6,23 @@ import numpy as np
 KERNELS_SAD = [(3, 3), (5, 5), (7, 7), (7, 5), (9, 9), (11, 11)]
 
 
-def bm_cases(n, seed, cost):
-    """calc_disparity: random sizes / kernels / 1-D and 2-D searches, shifted copies + flat patches (validity)."""
+def bm_cases(n, seed, cost, scale=256):
+    """calc_disparity: random sizes / kernels / 1-D and 2-D searches, shifted copies + flat patches (validity).  `scale` = 4096: 12-bit
+    imagery (the packed-u16 kernels; SSD / NCC windows are then mostly the instantiated squares)."""
     rng = np.random.default_rng(seed)
     for it in range(n):
         kx, ky = KERNELS_SAD[rng.integers(len(KERNELS_SAD))]
         if cost:
             kx, ky = int(rng.integers(1, 9)) * 2 - 1, int(rng.integers(1, 9)) * 2 - 1
+            if scale != 256 and np.random.default_rng([seed, 7000003 + it]).random() < 0.8:
+                kx = ky = min(max(kx, 3), 11)
         sx = int(rng.integers(1, 140))
         sy = int(rng.choice([1, 1, 1, 2, 3])) if cost == 0 else 1
         w = int(rng.integers(kx, 2600))
         h = int(rng.integers(ky, 200))
         lo = 1 if cost == 2 else 0                     # NCC: no all-zero windows (1/0 is the float64 kernel's business)
-        left = np.floor(rng.random((h, w)) * (256 - lo)).astype(np.float32) + lo
-        right = np.floor(rng.random((h + sy - 1, w + sx - 1)) * (256 - lo)).astype(np.float32) + lo
+        left = np.floor(rng.random((h, w)) * (scale - lo)).astype(np.float32) + lo
+        right = np.floor(rng.random((h + sy - 1, w + sx - 1)) * (scale - lo)).astype(np.float32) + lo
         d = int(rng.integers(0, sx))
         right[:h, d:d + w] = np.where(rng.random((h, w)) < 0.7, left, right[:h, d:d + w])
         if rng.random() < 0.5:

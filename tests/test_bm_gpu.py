@@ -436,3 +436,89 @@ def test_u16_path_random_cross_check(ctx):
         b = stereo.calc_disparity(ABS, lt, rt, vwa.bounding_box(left), (sx, 1), (kx, ky), ctx=ctx).cpu().numpy()
         ctx.force_path(core.PATH_NONE)
         assert np.array_equal(a, b), (it, kx, ky, sx, w, h, int((a != b).any(-1).sum()))
+
+
+# ---- packed SSD / NCC for 11- / 12-bit imagery (v_dot2_u32_u16) --------------------------------------------------------------
+
+@pytest.mark.parametrize("cost", [SQ, NCC])
+@pytest.mark.parametrize("w,h,kernel,sx", [(300, 70, (7, 7), 129), (97, 40, (5, 5), 9), (640, 33, (11, 11), 64), (258, 50, (3, 3), 1),
+                                           (1100, 60, (9, 9), 33), (64, 16, (7, 7), 2), (520, 45, (11, 11), 129)])
+def test_u12_corr_path_bit_exact(ctx, oracle, cost, w, h, kernel, sx):
+    """Integer-valued pixels in [0,4095]: float32 products / squared differences are exact, the v_dot2_u32_u16 kernel returns
+    the oracle's bits — shifted copies, saturated patches (ties, validity), both ends of the range."""
+    rng = np.random.default_rng(w * 11 + sx + cost)
+    left = np.floor(rng.random((h, w)) * 4096).astype(np.float32)
+    right = np.floor(rng.random((h, w + sx - 1)) * 4096).astype(np.float32)
+    d = int(rng.integers(0, sx))
+    right[:, d:d + w] = np.where(rng.random((h, w)) < 0.7, left, right[:, d:d + w])
+    left[3:12, 10:40] = 4095.0
+    right[2:14, 5:60 + sx] = 4095.0
+    left[0, 0] = 0.0
+    got, path = _gpu(ctx, cost, left, right, kernel, (sx, 1))
+    # (one disparity under NCC: best == worst everywhere, every pixel would be queued for the float64 sequence — the float64 kernel takes the image)
+    assert path == (core.PATH_GENERIC_F64 if (cost == NCC and sx == 1) else core.PATH_DOT_U16)
+    want = oracle.calc_disparity(cost, left, right, kernel, (sx, 1))
+    assert np.array_equal(got, want), int((got != want).any(-1).sum())
+    # one pixel at 4096: a product may round in float32, the float64 kernel serves the image
+    left[5, 7] = 4096.0
+    got, path = _gpu(ctx, cost, left, right, kernel, (sx, 1))
+    assert path == core.PATH_GENERIC_F64
+    assert np.array_equal(got, oracle.calc_disparity(cost, left, right, kernel, (sx, 1)))
+    # fractional pixels: not this path either
+    left[5, 7] = 100.5
+    got, path = _gpu(ctx, cost, left, right, kernel, (sx, 1))
+    assert path in (core.PATH_GENERIC_F64, core.PATH_EXACT_ORDER)
+    assert np.array_equal(got, oracle.calc_disparity(cost, left, right, kernel, (sx, 1)))
+
+
+def test_u12_corr_zero_windows_and_flat_images(ctx, oracle):
+    """An all-zero window under NCC (1/0 in the reference) and images that are mostly flat (every score ties): the packed kernel
+    hands the image over, the result is the oracle's either way."""
+    rng = np.random.default_rng(4)
+    left = np.floor(rng.random((40, 200)) * 4096).astype(np.float32)
+    right = np.floor(rng.random((40, 232)) * 4096).astype(np.float32)
+    right[10:30, 50:120] = 0.0
+    for cost in (SQ, NCC):
+        got, path = _gpu(ctx, cost, left, right, (7, 7), (33, 1))
+        assert path == (core.PATH_DOT_U16 if cost == SQ else core.PATH_GENERIC_F64)
+        assert np.array_equal(got, oracle.calc_disparity(cost, left, right, (7, 7), (33, 1)))
+    flat_l = np.full((40, 200), 1000.0, np.float32)
+    flat_r = np.full((40, 232), 1000.0, np.float32)
+    flat_l[20, 100] = 1001.0
+    for cost in (SQ, NCC):
+        got, _ = _gpu(ctx, cost, flat_l, flat_r, (7, 7), (33, 1))
+        assert np.array_equal(got, oracle.calc_disparity(cost, flat_l, flat_r, (7, 7), (33, 1)))
+
+
+def test_u12_corr_path_random_cross_check(ctx):
+    """Seeded random sizes / searches: packed-u16 SSD / NCC vs the float64 kernel (pinned to the oracle above)."""
+    import torch
+    from visionworkbench_amd import stereo
+    rng = np.random.default_rng(77)
+    kernels = [(3, 3), (5, 5), (7, 7), (9, 9), (11, 11)]
+    ran = 0
+    for it in range(80):
+        kx, ky = kernels[rng.integers(len(kernels))]
+        cost = int(rng.choice([SQ, NCC]))
+        sx = int(rng.integers(1, 200))
+        w, h = int(rng.integers(kx, 1500)), int(rng.integers(ky, 120))
+        scale = float(rng.choice([4096, 2048, 300, 40]))
+        left = np.floor(rng.random((h, w)) * scale).astype(np.float32) + (1.0 if cost == NCC else 0.0)
+        right = np.floor(rng.random((h, w + sx - 1)) * scale).astype(np.float32) + (1.0 if cost == NCC else 0.0)
+        left, right = np.minimum(left, 4095.0), np.minimum(right, 4095.0)
+        d = int(rng.integers(0, sx))
+        right[:, d:d + w] = np.where(rng.random((h, w)) < 0.6, left, right[:, d:d + w])
+        lt, rt = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+        ctx.force_path(core.PATH_DOT_U16)
+        try:
+            a = stereo.calc_disparity(cost, lt, rt, vwa.bounding_box(left), (sx, 1), (kx, ky), ctx=ctx).cpu().numpy()
+            assert ctx.last_path() == core.PATH_DOT_U16
+        except vwa.NoImplErr:                                     # search too wide for the kernel's LDS tile
+            ctx.force_path(core.PATH_NONE)
+            continue
+        ctx.force_path(core.PATH_GENERIC_F64)
+        b = stereo.calc_disparity(cost, lt, rt, vwa.bounding_box(left), (sx, 1), (kx, ky), ctx=ctx).cpu().numpy()
+        ctx.force_path(core.PATH_NONE)
+        assert np.array_equal(a, b), (it, cost, kx, ky, sx, w, h, int((a != b).any(-1).sum()))
+        ran += 1
+    assert ran >= 50

@@ -34,11 +34,13 @@ def _default_options(ctx):
     ctx.set_option(core.OPT_EXACT_SCRATCH_MB, 4096)
 
 
-@pytest.mark.parametrize("cost,n,seed", [(0, 120, 101), (1, 60, 102), (2, 60, 103)])
-def test_fuzz_fast_paths_equal_generic(ctx, monkeypatch, cost, n, seed):
+@pytest.mark.parametrize("cost,n,seed,scale", [(0, 120, 101, 256), (1, 60, 102, 256), (2, 60, 103, 256),
+                                               (0, 40, 104, 65536), (1, 60, 105, 4096), (2, 60, 106, 4096)])
+def test_fuzz_fast_paths_equal_generic(ctx, monkeypatch, cost, n, seed, scale):
+    """Packed kernels (u8; 16-bit SAD; 12-bit SSD / NCC) against the float64 kernel on seeded random cases."""
     import torch
     bad = []
-    for c in fuzz_cases.bm_cases(n, seed, cost):
+    for c in fuzz_cases.bm_cases(n, seed, cost, scale):
         ctx.set_option(core.OPT_SAD_GROUPS, 1 + int(c["split"]))
         lt, rt = torch.from_numpy(c["left"]).cuda(), torch.from_numpy(c["right"]).cuda()
         ctx.force_path(core.PATH_NONE)

@@ -420,11 +420,18 @@ int vwgpu_launch_bm_corr_u8(vwgpu_ctx* ctx, int cost_type, const float* left, in
     hipLaunchKernelGGL(l->fn, dim3((ow + CTW - 1) / CTW, (oh + l->ty - 1) / l->ty), dim3(CTHREADS), shmem, ctx->stream,
                        left, ls, lw, lh, right, rs, rcw, rch, g, out, os, ow, oh, flag_set, flag_clear, a2, b2, b2w, full_list, full_count, cap);
   }
-  if (ncc) {
-    vwgpu_prof_scope ps(ctx, "ncc_full");
-    hipLaunchKernelGGL(ncc_full_kernel, dim3(2048), dim3(256), 0, ctx->stream, left, ls, right, rs, kx, ky, sx, a2, b2, b2w,
-                       out, os, ow, flag_set, full_list, full_count, cap);
-  }
+  VWGPU_HIP(ctx, hipGetLastError());
+  if (ncc) return vwgpu_launch_ncc_full(ctx, left, ls, right, rs, kx, ky, sx, a2, b2, b2w, out, os, ow, flag_set, full_list, full_count, cap);
+  return VWGPU_OK;
+}
+
+// The float64 sequence for the queued pixels of an integer NCC matcher (bm_corr_u8.hip, bm_corr_u16.hip: products and window sums below 2^32).
+int vwgpu_launch_ncc_full(vwgpu_ctx* ctx, const float* left, ptrdiff_t ls, const float* right, ptrdiff_t rs, int kx, int ky, int sx,
+                          const uint32_t* a2, const uint32_t* b2, int b2w, int32_t* out, ptrdiff_t os, int ow, int* flag,
+                          const uint32_t* full_list, const uint32_t* full_count, uint32_t cap) {
+  vwgpu_prof_scope ps(ctx, "ncc_full");
+  hipLaunchKernelGGL(ncc_full_kernel, dim3(2048), dim3(256), 0, ctx->stream, left, ls, right, rs, kx, ky, sx, a2, b2, b2w,
+                     out, os, ow, flag, full_list, full_count, cap);
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }

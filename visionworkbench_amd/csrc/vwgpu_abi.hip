@@ -188,7 +188,7 @@ int vwgpu_synchronize(vwgpu_ctx* ctx) {
 const char* vwgpu_last_error(const vwgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
 
 int vwgpu_force_path(vwgpu_ctx* ctx, int path) {
-  if (!ctx || path < VWGPU_PATH_NONE || path > VWGPU_PATH_SAD_U16) return VWGPU_ERR_ARGUMENT;
+  if (!ctx || path < VWGPU_PATH_NONE || path > VWGPU_PATH_DOT_U16) return VWGPU_ERR_ARGUMENT;
   ctx->forced_path = path;
   ctx->measure_first = false;
   return VWGPU_OK;
@@ -231,7 +231,7 @@ int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value) {
 int vwgpu_last_path(const vwgpu_ctx* cctx) {
   vwgpu_ctx* ctx = const_cast<vwgpu_ctx*>(cctx);
   if (!ctx) return VWGPU_PATH_NONE;
-  if ((ctx->last_path == VWGPU_PATH_SAD_U8 || ctx->last_path == VWGPU_PATH_DOT_U8 || ctx->last_path == VWGPU_PATH_SAD_U16) && ctx->last_flag) {
+  if ((ctx->last_path == VWGPU_PATH_SAD_U8 || ctx->last_path == VWGPU_PATH_DOT_U8 || ctx->last_path == VWGPU_PATH_SAD_U16 || ctx->last_path == VWGPU_PATH_DOT_U16) && ctx->last_flag) {
     // The fast path reports non-representable input through a device flag; the generic kernel then ran.
     int flag = 0;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return VWGPU_PATH_NONE;
@@ -320,6 +320,24 @@ static int calc_disparity_classified(vwgpu_ctx* ctx, int cost_type, const float*
       VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
       if (!flag) { ctx->last_path = VWGPU_PATH_SAD_U16; return VWGPU_OK; }
     }
+    // integers below 2^12 (11- / 12-bit imagery): float32 products and squared differences are exact, SSD / NCC on v_dot2_u32_u16
+    if (!exact && !nonfinite && lo != INT_MAX && lo >= 0 && hi <= 11 && vwgpu_bm_corr_u16_supported(cost_type, kx, ky, sx, sy)) {
+      int* d_flag = nullptr;
+      rc = vwgpu_launch_bm_corr_u16(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
+      if (rc) return rc;
+      int flag = 0;
+      VWGPU_HIP(ctx, hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+      VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (!flag) { ctx->last_path = VWGPU_PATH_DOT_U16; return VWGPU_OK; }
+    }
+  } else if (ctx->forced_path == VWGPU_PATH_DOT_U16) {
+    if (!vwgpu_bm_corr_u16_supported(cost_type, kx, ky, sx, sy))
+      return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: no packed-u16 SSD / NCC path for cost %d kernel %dx%d search %dx%d", cost_type, kx, ky, sx, sy);
+    int* d_flag = nullptr;
+    int rc = vwgpu_launch_bm_corr_u16(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
+    ctx->last_path = VWGPU_PATH_DOT_U16;
+    ctx->last_flag = d_flag;
+    return rc;
   } else if (ctx->forced_path == VWGPU_PATH_SAD_U16) {
     if (!vwgpu_bm_sad_u16_supported(cost_type, kx, ky, sx, sy))
       return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: no packed-u16 path for cost %d kernel %dx%d search %dx%d", cost_type, kx, ky, sx, sy);

@@ -137,6 +137,14 @@ bool vwgpu_bm_corr_u8_supported(int cost_type, int kx, int ky, int sx, int sy);
 int vwgpu_launch_bm_corr_u8(vwgpu_ctx* ctx, int cost_type, const float* left, int lw, int lh, ptrdiff_t ls,
                             const float* right, int rw, int rh, ptrdiff_t rs, int kx, int ky, int sx, int sy,
                             int32_t* out, ptrdiff_t os, int** d_fallback_flag);
+int vwgpu_launch_ncc_full(vwgpu_ctx* ctx, const float* left, ptrdiff_t ls, const float* right, ptrdiff_t rs, int kx, int ky, int sx,
+                          const uint32_t* a2, const uint32_t* b2, int b2w, int32_t* out, ptrdiff_t os, int ow, int* flag,
+                          const uint32_t* full_list, const uint32_t* full_count, uint32_t cap);
+// bm_corr_u16.hip: SSD / NCC for integer-valued imagery in [0,4095] (v_dot2_u32_u16 on pixel pairs); same fallback-flag protocol
+bool vwgpu_bm_corr_u16_supported(int cost_type, int kx, int ky, int sx, int sy);
+int vwgpu_launch_bm_corr_u16(vwgpu_ctx* ctx, int cost_type, const float* left, int lw, int lh, ptrdiff_t ls,
+                             const float* right, int rw, int rh, ptrdiff_t rs, int kx, int ky, int sx, int sy,
+                             int32_t* out, ptrdiff_t os, int** d_fallback_flag);
 
 // bm_exact.hip: the reference's own summation order (serial column / row chains of fast_box_sum) for inputs whose
 // partial sums are not exactly representable; see the file header.
