@@ -22,12 +22,12 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(autouse=True, params=["split", "fused"])
+@pytest.fixture(autouse=True, params=["split", "fused", "tiled"])
 def _default_options(request, ctx):
-    """Every test of this module runs with both forms of pass 2 (OPT_EXACT_SPLIT: the recurrence alone + a parallel selection, and
-    the fused kernel — the automatic choice goes by the longest chain of a call).  Variant-pinning options (same results, other
+    """Every test of this module runs with all three forms of pass 2 (OPT_EXACT_SPLIT: the recurrence alone + a parallel selection, the
+    fused kernel, and the tiled kernel that transposes a row's sums through LDS).  Variant-pinning options (same results, other
     kernels / schedules) never leak from one test into the next."""
-    ctx.set_option(core.OPT_EXACT_SPLIT, 1 if request.param == "split" else 2)
+    ctx.set_option(core.OPT_EXACT_SPLIT, {"split": 1, "fused": 2, "tiled": 3}[request.param])
     yield
     ctx.set_option(core.OPT_EXACT_SPLIT, 0)
     ctx.set_option(core.OPT_SAD_GROUPS, 0)

@@ -12,7 +12,11 @@ cases = [(0, 0, 7), (2, 0, 7), (1, 0, 7), (0, 2, 11), (2, 2, 11), (0, 1, 7)]
 L, R, _ = synth.stereo_pair(W, W, 129, 1)
 Lg, Rg = torch.from_numpy(L).cuda(), torch.from_numpy(R[:, 64:64 + W].copy()).cuda()
 ctx = core.default_context(0)
+import os
+ctx.set_option(core.OPT_EXACT_SPLIT, int(os.environ.get("PYR_EXACT_SPLIT", "0")))      # tool-side switch
+ONLY = os.environ.get("PYR_ONLY", "")
 for pf, cost, k in cases:
+    if ONLY and ONLY != "%d,%d,%d" % (pf, cost, k): continue
     args = dict(consistency_threshold=2, filter_half_kernel=5, max_pyramid_levels=5, bbox=BBox2i(256, 256, tile, tile))
     run = lambda: stereo.pyramid_correlate(Lg, Rg, None, None, pf, 1.4 if pf else 0.0, BBox2i.from_corners((-64, -1), (64, 1)), (k, k), cost, **args)
     run(); torch.cuda.synchronize()

@@ -55,11 +55,33 @@ struct XZone {
   int d0, dn;                       // this pass serves the disparities [d0, d0 + dn) of the zone's sx * sy (dn <= 512; D = dn below)
   int carry_mode;                   // bit 0: continue the compare chain from the zone's carry records, bit 1: leave it there (more groups follow)
   long long carry;                  // offset (records) of the zone's carry records, one per output pixel
+  long long part;                   // bmx_rowsel_kernel: offset (records) of the zone's group records [group][row][x]
+  int img;                          // box-sum zones: 0 = the crop is taken from image A, 1 = from image B (one launch serves both NCC side cars)
+  int tiled;                        // volume layout: 0 = [row][column][disparity], 1 = [row][group of XTL disparities][column][XTL] (bmx_rowsel_kernel)
   int lanes_log2;                   // lanes per unit = 1 << lanes_log2  (>= min(D, 64), power of two)
   int nchunk;                       // ceil(D / 64)
   long long vol;                    // offset (doubles) of the column-sum volume [rows][cw][dp]
   long long lprec, rprec;           // NCC: offsets (doubles) of the zone's precision images; box modes: lprec = output offset
 };
+
+// The two volume layouts.  Zones that go through bmx_rowsel_kernel keep the XTL disparities of a group next to each other for every column, so
+// that a row chain of a group streams through consecutive 128-byte lines (with the disparity-fastest layout a chain step of 16 lanes was one
+// 128-byte line out of every dp * 8 bytes: more than half of that kernel's time was waiting for them).
+constexpr int XTL = 16;
+struct XLayout {
+  int xs;                           // doubles between two columns of a (row, disparity)
+  size_t rs;                        // doubles between two rows
+  int tiled, cw;
+  __host__ __device__ size_t off(int d) const { return tiled ? (size_t)(d / XTL) * cw * XTL + (d % XTL) : (size_t)d; }
+};
+__host__ __device__ inline XLayout xlayout(const XZone& z, int cw, int dp) {
+  XLayout l;
+  l.tiled = z.tiled; l.cw = cw;
+  const int ngrp = (z.dn + XTL - 1) / XTL;
+  l.xs = z.tiled ? XTL : dp;
+  l.rs = z.tiled ? (size_t)ngrp * XTL * cw : (size_t)cw * dp;
+  return l;
+}
 
 // State of the reference's compare chain (Correlation.cc:91-117) after the disparities of the groups served so far.
 struct XCarry { double best, worst; int idx, pad; };
@@ -91,12 +113,15 @@ bmx_col_kernel(const float* __restrict__ A, int aw, int ah, ptrdiff_t as, const 
   const XZone z = zones[it.x];
   const int cw = z.zw + kx - 1;
   const int lanes = 1 << z.lanes_log2;
-  const int col = it.y + ((int)threadIdx.x >> z.lanes_log2);
-  const int d = it.z * 64 + ((int)threadIdx.x & (lanes - 1));
+  // (tiled volumes: a wavefront is 4 columns x the XTL disparities of a group = 512 consecutive bytes of a volume row)
+  const int col = it.y + (z.tiled ? (int)threadIdx.x / XTL : ((int)threadIdx.x >> z.lanes_log2));
+  const int d = z.tiled ? it.z * XTL + (int)threadIdx.x % XTL : it.z * 64 + ((int)threadIdx.x & (lanes - 1));
   const int D = z.dn;
   if (col >= cw || d >= D) return;
   const int dp = z.nchunk == 1 ? lanes : z.nchunk * 64;
+  const XLayout lay = xlayout(z, cw, dp);
   const int dy = BOX ? 0 : (z.d0 + d) / z.sx, dx = BOX ? 0 : (z.d0 + d) - dy * z.sx;
+  if (BOX && z.img) { A = B; aw = bw; ah = bh; as = bs; }
   const float* ac = A + xclamp(z.ax + col, aw);
   const float* bc = BOX ? nullptr : B + xclamp(z.bx + col + dx, bw);
   auto elem = [&](int y) __attribute__((always_inline)) -> double {
@@ -112,15 +137,15 @@ bmx_col_kernel(const float* __restrict__ A, int aw, int ah, ptrdiff_t as, const 
   } else {
     cs = state[(size_t)col * dp + d];
   }
-  double* v = vol + z.vol + (size_t)col * dp + d;
-  const size_t rstride = (size_t)cw * dp;
+  double* v = vol + z.vol + (size_t)col * lay.xs + lay.off(d);
+  const size_t rstride = lay.rs;
   int y = y0;
-  for (; y + 4 <= y1 && y + 4 < z.zh; y += 4) {         // four rows' pixels requested together: the chain itself is serial
-    double in[4], out[4];
+  for (; y + 8 <= y1 && y + 8 < z.zh; y += 8) {         // eight rows' pixels requested together: the chain itself is serial
+    double in[8], out[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { in[i] = elem(y + ky + i); out[i] = elem(y + i); }
+    for (int i = 0; i < 8; ++i) { in[i] = elem(y + ky + i); out[i] = elem(y + i); }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
       v[(size_t)(y + i - y0) * rstride] = cs;
       cs += in[i];                                      // Algorithms.h:100-103: two statements, this order
       cs -= out[i];
@@ -152,40 +177,39 @@ __global__ void __launch_bounds__(256)
 bmx_box_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__ items, const double* __restrict__ vol,
                    int y_begin, int y_end, double* __restrict__ outd) {
   static_assert(COST == XCOST_BOX || COST == XCOST_PREC, "box sums only");
+  // The chain of a row is two additions per pixel; the reciprocal of the precision images (a division, ~25 instructions) and the store do
+  // not belong into it.  16 steps' sums go to LDS, then the 64 x 16 block is finished by all lanes along the rows: independent divisions,
+  // 128-byte stores (a lane per row wrote 8 bytes out of every row).
+  __shared__ double R[4][64 * 17];
   const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
   const int2 it = items[blockIdx.x * 4 + wave];
   if (it.x < 0) return;
   const XZone z = zones[it.x];                          // lanes_log2 == 0, one "disparity": a lane per row
   const int cw = z.zw + kx - 1;
-  const int y = it.y + lane;
   const int ylim = y_end < z.zh ? y_end : z.zh;
-  if (y >= ylim) return;
-  const double* base = vol + z.vol + (size_t)(y - y_begin) * cw;
+  const int y = it.y + lane;
+  const bool act = y < ylim;                            // idle lanes walk the item's first row
+  const double* base = vol + z.vol + (size_t)((act ? y : it.y) - y_begin) * cw;
   double r = 0.0;
   for (int i = 0; i < kx; ++i) r += base[i];            // Algorithms.h:84: accumulate from 0
-  double* o = outd + z.lprec + (size_t)y * z.zw;
-  const double* lead = base + kx;
-  auto put = [&](int x) __attribute__((always_inline)) { o[x] = (COST == XCOST_PREC) ? 1.0 / r : r; };
-  int x = 0;
-  // A lane streams its own row: 16 steps' operands — one 128-byte line of each stream — are requested together, so a line is
-  // consumed while it sits in the L1 instead of being fetched once per step; the chain itself is serial.
-  for (; x + 16 < z.zw; x += 16) {
+  double* Rw = R[wave];
+  double* o = outd + z.lprec;
+  for (int x0 = 0; x0 < z.zw; x0 += 16) {
+    // A lane streams its own row: 16 steps' operands — one 128-byte line of each stream — are requested together
     double l[16], t[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { l[i] = lead[x + i]; t[i] = base[x + i]; }
+    for (int i = 0; i < 16; ++i) { l[i] = base[min(x0 + i + kx, cw - 1)]; t[i] = base[min(x0 + i, cw - 1)]; }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { put(x + i); r += l[i] - t[i]; }
-  }
-  for (; x + 4 < z.zw; x += 4) {
-    double l[4], t[4];
+    for (int i = 0; i < 16; ++i) { Rw[lane * 17 + i] = r; r += l[i] - t[i]; }       // Algorithms.h:92 (sums past the row's end are not used)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wavefront's own LDS writes, then reads by other lanes
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { l[i] = lead[x + i]; t[i] = base[x + i]; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { put(x + i); r += l[i] - t[i]; }
-  }
-  for (; x < z.zw; ++x) {
-    put(x);
-    if (x + 1 < z.zw) r += lead[x] - base[x];
+    for (int k = 0; k < 16; ++k) {
+      const int i = lane + 64 * k, row = i >> 4, col = i & 15;
+      const int yy = it.y + row, xx = x0 + col;
+      const double v = Rw[row * 17 + col];
+      if (yy < ylim && xx < z.zw) o[(size_t)yy * z.zw + xx] = (COST == XCOST_PREC) ? 1.0 / v : v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next block overwrites
   }
 }
 
@@ -200,13 +224,14 @@ template <int COST, int NCH, bool CARRY = false>
 __global__ void __launch_bounds__(256)
 bmx_row_fused_kernel(int kx, const XZone* __restrict__ zones, const int2* __restrict__ items, const double* __restrict__ vol,
                int y_begin, int y_end, const double* __restrict__ prec, int32_t* __restrict__ out, double* __restrict__ outd,
-               XCarry* __restrict__ carry = nullptr) {
+               XCarry* __restrict__ carry = nullptr, const int* __restrict__ zone_flag = nullptr) {
   constexpr bool BOX = (COST == XCOST_BOX || COST == XCOST_PREC);
   constexpr bool NCC = (COST == VWGPU_CROSS_CORRELATION);
   __shared__ double park[4][NCH][64];           // costs of a NaN pixel, for the verbatim replay
   const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
   const int2 it = items[blockIdx.x * 4 + wave];
   if (it.x < 0) return;
+  if (zone_flag && !zone_flag[it.x]) return;    // the pass after bmx_merge_kernel: only the zones it flagged
   const XZone z = zones[it.x];
   const int cw = z.zw + kx - 1;
   const int lanes = 1 << z.lanes_log2;
@@ -217,7 +242,8 @@ bmx_row_fused_kernel(int kx, const XZone* __restrict__ zones, const int2* __rest
   const int D = z.dn;
   const int dp = z.nchunk == 1 ? lanes : z.nchunk * 64;
   const int nch = z.nchunk;
-  const double* base = vol + z.vol + (size_t)(row_ok ? y - y_begin : 0) * cw * dp;
+  const XLayout lay = xlayout(z, cw, dp);
+  const double* base = vol + z.vol + (size_t)(row_ok ? y - y_begin : 0) * lay.rs;
 
   double r[NCH];
   int dk[NCH];
@@ -231,7 +257,7 @@ bmx_row_fused_kernel(int kx, const XZone* __restrict__ zones, const int2* __rest
     r[k] = 0.0;
     rp[k] = nullptr;
     if (act[k]) {
-      for (int i = 0; i < kx; ++i) r[k] += base[(size_t)i * dp + dk[k]];       // Algorithms.h:84: accumulate from 0
+      for (int i = 0; i < kx; ++i) r[k] += base[(size_t)i * lay.xs + lay.off(dk[k])];       // Algorithms.h:84: accumulate from 0
       if (NCC) {
         const int dy = (z.d0 + dk[k]) / z.sx, dx = (z.d0 + dk[k]) - dy * z.sx;
         rp[k] = prec + z.rprec + (size_t)(y + dy) * rpw + dx;
@@ -246,11 +272,11 @@ bmx_row_fused_kernel(int kx, const XZone* __restrict__ zones, const int2* __rest
   // ahead, unconditionally (idle lanes / chunks read a valid dummy address, the last step re-reads clamped indices): loaded and
   // consumed in the same step they cost a memory round trip per step; a load under a lane condition makes the compiler drain
   // every outstanding request (s_waitcnt vmcnt(0)) before the next use.
-  int off[NCH];
+  size_t off[NCH];
   const double* rps[NCH];
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
-    off[k] = act[k] ? dk[k] : 0;
+    off[k] = act[k] ? lay.off(dk[k]) : 0;
     rps[k] = (NCC && act[k]) ? rp[k] : prec;
   }
   const double* lps = NCC ? (row_ok ? lp : prec) : nullptr;
@@ -263,7 +289,7 @@ bmx_row_fused_kernel(int kx, const XZone* __restrict__ zones, const int2* __rest
   double clp = 0.0, nlp[PF];
   auto request = [&](int u, int t) __attribute__((always_inline)) {     // the operands that END step t (clamped: requests past the row re-read its end)
     const int tc = min(t, z.zw - 1);
-    const size_t li = (size_t)min(tc + kx, cw - 1) * dp, ti = (size_t)tc * dp;
+    const size_t li = (size_t)min(tc + kx, cw - 1) * lay.xs, ti = (size_t)tc * lay.xs;
     const int xn = min(tc + 1, z.zw - 1);
 #pragma unroll
     for (int k = 0; k < NCH; ++k)
@@ -542,6 +568,224 @@ bmx_select_kernel(int kx, const XZone* __restrict__ zones, const int2* __restric
   }
 }
 
+// ---- pass 2 of the matchers, tiled form (round 3): row chains and selection in ONE kernel, transposed through LDS ----------------
+// The fused kernel above reads the volume once but selects ACROSS the disparity lanes inside every chain step (~300 dependent
+// instructions per step: it is instruction bound, 130 G evaluations/s); the split form is cheap per evaluation but moves the volume three
+// times.  Here one wavefront owns (zone, 2 rows, a group of 32 disparities) and walks the rows in chunks of 32 pixels:
+//   chains   lane <-> (row, disparity): 32 steps of row_sum(x+1) = row_sum(x) + (col_sum(x+kx) - col_sum(x)), every operand of the
+//            chunk requested up front (Algorithms.h:84,92); every row sum goes to LDS, T[chain][step]; the chain's state is a register
+//   select   lane <-> (row, pixel): the 32 costs of its pixel from LDS (conflict free: consecutive lanes, consecutive words), NCC
+//            scaling, the reference's compare chain VERBATIM over the group (Correlation.cc:91-117).
+// A zone of up to 32 disparities is finished by that wavefront.  Wider searches: the groups of a pixel run in parallel (a wavefront that
+// walked all of them in turn was the critical path of a level: 16 chunks x 7 groups x 9 us for a 512-pixel zone with 216 disparities)
+// and leave (best, worst, index, "saw a NaN") per group; bmx_merge_kernel folds them in index order.  Without NaN costs the chain is a
+// (value, first index) minimum and a maximum, which fold exactly; a pixel with a NaN cost (NCC over an all-zero window: 0 * inf) is
+// order dependent, so its zone is flagged and the fused kernel above recomputes the flagged zones from the same volume.
+// 8 B of HBM traffic per evaluation (the column sums, once) + 1.5 B for the group records, ~40 instruction slots instead of ~300.
+constexpr int TL_X = XTL, TL_PITCH = TL_X + 1;       // pixels per chunk = disparities per group; 64 / TL_X rows per wavefront
+constexpr int TL_R = 64 / TL_X, TL_LOG = 4;
+static_assert((1 << TL_LOG) == TL_X, "TL_X is a power of two");
+// KX > 0: the window width is a compile-time constant and the column sums of a chunk live in a register window of TL_X + KX values — the
+// last KX of a chunk are the first KX of the next one, so every column sum is requested exactly once (KX == 0, any width: lead and trail of
+// every step are requested separately; the halo of a chunk is then read twice, 27 lines per 16 steps at 11 x 11).
+template <int COST, bool CARRY, int KX>
+__global__ void __launch_bounds__(64)
+bmx_rowsel_kernel(int kx, const XZone* __restrict__ zones, const int4* __restrict__ items, const double* __restrict__ vol, int y_begin, int y_end,
+                  const double* __restrict__ prec, int32_t* __restrict__ out, XCarry* __restrict__ carry, XCarry* __restrict__ part) {
+  constexpr bool NCC = (COST == VWGPU_CROSS_CORRELATION);
+  __shared__ double T[64 * TL_PITCH];                   // [chain][step]
+  const int lane = (int)threadIdx.x;
+  const int4 it = items[blockIdx.x];
+  const XZone z = zones[it.x];
+  const int cw = z.zw + kx - 1;
+  const int lanes = 1 << z.lanes_log2;
+  const int dp = z.nchunk == 1 ? lanes : z.nchunk * 64;
+  const int D = z.dn;
+  const int ylim = y_end < z.zh ? y_end : z.zh;
+  const int g = lane >> TL_LOG, dl = lane & (TL_X - 1);              // row of the pair; disparity of the group (chains) / pixel of the chunk (select)
+  const int y = it.y + g;
+  const bool row_ok = y < ylim;
+  const int dg = it.z;
+  const bool single = D <= TL_X;                          // the whole search in this group: the result is final
+  const int d = dg * TL_X + dl;
+  const bool act = row_ok && d < D;
+  // idle lanes walk a valid chain whose sums nobody reads
+  const XLayout lay = xlayout(z, cw, dp);
+  const double* base = vol + z.vol + (size_t)((row_ok ? y : it.y) - y_begin) * lay.rs + lay.off(act ? d : dg * TL_X);
+  const int xs = XTL;                                   // (z.tiled: the only zones this kernel serves)
+  const int jn = min(TL_X, D - dg * TL_X);
+  const int rpw = z.zw + z.sx - 1;
+  const int dfirst = z.d0 + dg * TL_X;                    // the group's first disparity in the zone's search volume
+  const int dy0 = dfirst / z.sx, dx0 = dfirst - dy0 * z.sx;
+  const int prows = (y_end < z.zh ? y_end : z.zh) - y_begin;     // rows of this band: the group records are [group][row of the band][x]
+  constexpr int NV = KX > 0 ? TL_X + KX : 1;
+  double v[NV];                                         // KX > 0: v[i] = col_sum(x0 + i) of this chain
+  double r = 0.0;
+  if (KX > 0) {
+#pragma unroll
+    for (int i = 0; i < KX; ++i) v[TL_X + i] = base[(size_t)i * xs];
+#pragma unroll
+    for (int i = 0; i < KX; ++i) r += v[TL_X + i];     // Algorithms.h:84: accumulate from 0
+  } else {
+    for (int i = 0; i < kx; ++i) r += base[(size_t)i * xs];
+  }
+  // The column sums of chunk k + 1 are requested while chunk k is selected (a level's tiled pass is ~9000 wavefronts, 10 per CU on average:
+  // there are not enough of them to hide a memory round trip per chunk behind each other).
+  double vn[KX > 0 ? TL_X : 1];
+  auto request_chunk = [&](int xc) __attribute__((always_inline)) {       // col_sum(xc + KX + u), u < TL_X, into vn
+    if (xc + KX + TL_X <= cw) {                         // wave-uniform: constant offsets, no address arithmetic per request
+      const double* pb = base + (size_t)(xc + KX) * XTL;
+#pragma unroll
+      for (int u = 0; u < TL_X; ++u) vn[u] = pb[u * XTL];
+    } else {
+#pragma unroll
+      for (int u = 0; u < TL_X; ++u) vn[u] = base[(size_t)min(xc + KX + u, cw - 1) * XTL];     // (past the row's end: sums nobody uses)
+    }
+  };
+  if (KX > 0) request_chunk(0);
+  for (int x0 = 0; x0 < z.zw; x0 += TL_X) {
+    // ---- chains: every operand of the chunk's steps is in registers before the first step ----
+    // (xs == XTL here: tiled volumes only)
+    double pl[TL_X], pt[TL_X];
+    if (KX > 0) {
+#pragma unroll
+      for (int i = 0; i < KX; ++i) v[i] = v[TL_X + i];
+#pragma unroll
+      for (int u = 0; u < TL_X; ++u) v[KX + u] = vn[u];
+      request_chunk(x0 + TL_X);
+#pragma unroll
+      for (int u = 0; u < TL_X; ++u) { pl[u] = v[KX + u]; pt[u] = v[u]; }
+    } else if (x0 + kx + TL_X <= cw) {
+      const double* pb = base + (size_t)x0 * XTL;
+#pragma unroll
+      for (int u = 0; u < TL_X; ++u) { pl[u] = pb[(size_t)(u + kx) * XTL]; pt[u] = pb[u * XTL]; }
+    } else {
+#pragma unroll
+      for (int u = 0; u < TL_X; ++u) {                  // the operands that END step u (clamped at the row's end: those sums are not used)
+        const int tc = min(x0 + u, z.zw - 1);
+        pl[u] = base[(size_t)min(tc + kx, cw - 1) * XTL];
+        pt[u] = base[(size_t)tc * XTL];
+      }
+    }
+    const int x = x0 + dl;
+    const bool pok = row_ok && x < z.zw;
+    const double lp = (NCC && pok) ? prec[z.lprec + (size_t)y * z.zw + x] : 0.0;
+    const double* rpb = NCC ? prec + z.rprec + (pok ? (size_t)y * rpw + x : 0) : nullptr;
+    double* trow = T + lane * TL_PITCH;
+#pragma unroll
+    for (int u = 0; u < TL_X; ++u) {
+      trow[u] = r;                                      // (steps past the row's end write sums nobody reads)
+      r += pl[u] - pt[u];                               // Algorithms.h:92
+    }
+    double q[TL_X];                                     // (requested once the chain operands are dead: together they would be 280 registers)
+    const bool full = jn == TL_X;                       // wave-uniform
+    if (NCC) {
+      if (full && dx0 + TL_X <= z.sx) {                 // the group stays on one search row
+        const double* qb = rpb + (size_t)dy0 * rpw + dx0;
+#pragma unroll
+        for (int i = 0; i < TL_X; ++i) q[i] = qb[i];
+      } else {
+        int dy = dy0, dx = dx0;
+#pragma unroll
+        for (int i = 0; i < TL_X; ++i) {
+          q[i] = rpb[(size_t)dy * rpw + dx];
+          if (i + 1 < jn) { if (++dx == z.sx) { dx = 0; ++dy; } }     // never past the group's last disparity (the read stays inside the image)
+        }
+      }
+    }
+    __syncthreads();
+    // ---- select: lane <-> pixel (row g, x0 + dl); the group's costs in index order ----
+    double best = 0.0, worst = 0.0;
+    int idx = 0;
+    bool first = true;                                  // no value seen yet: the chain starts with `best = worst = v` (Correlation.cc:93-96)
+    bool nan = false;
+    if (CARRY && single && (z.carry_mode & 1) && pok) {
+      const XCarry c = carry[z.carry + (size_t)y * z.zw + x];
+      best = c.best; worst = c.worst; idx = c.idx; first = false;
+    }
+    const double* tcol = T + (g * TL_X) * TL_PITCH + dl;
+    double c[TL_X];
+#pragma unroll
+    for (int i = 0; i < TL_X; ++i) c[i] = tcol[i * TL_PITCH];
+    auto take = [&](int i) __attribute__((always_inline)) {
+      double v = c[i];
+      if (NCC) v *= sqrt(lp * q[i]);                    // CostFunctions.h:227-231
+      nan |= (v != v);
+      // Correlation.cc:91-117 as selects (a branch per comparison cost more than the comparisons)
+      const bool b = first || xbetter<COST>(v, best);
+      const bool w = first || (!b && !xbetter<COST>(v, worst));
+      best = b ? v : best;
+      idx = b ? dfirst + i : idx;
+      worst = w ? v : worst;
+      first = false;
+    };
+    if (full) {
+#pragma unroll
+      for (int i = 0; i < TL_X; ++i) take(i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < TL_X; ++i)
+        if (i < jn) take(i);                            // wave-uniform
+    }
+    __syncthreads();                                    // T is rewritten by the next chunk's chains
+    if (pok) {
+      if (!single) {
+        part[z.part + ((size_t)dg * prows + (y - y_begin)) * z.zw + x] = XCarry{best, worst, idx, nan ? 1 : 0};
+      } else if (CARRY && (z.carry_mode & 2)) {
+        carry[z.carry + (size_t)y * z.zw + x] = XCarry{best, worst, idx, 0};
+      } else {
+        const int qy = idx / z.sx, qx = idx - qy * z.sx;
+        int32_t* o = out + ((size_t)z.out_off + (size_t)y * z.out_stride + x) * 3;
+        o[0] = qx + z.addx; o[1] = qy + z.addy; o[2] = (best == worst) ? 0 : 0x7fffffff;       // Correlation.cc:121-133
+      }
+    }
+  }
+}
+
+// Folds the group records of bmx_rowsel_kernel in index order.  items[i] = {zone, y0 | x-chunk << 20} as bmx_select_kernel's (zones of
+// more than 32 disparities only).  A NaN in any record (or in the carried state) flags the zone: the fused kernel recomputes it.
+template <int COST, bool CARRY>
+__global__ void __launch_bounds__(256)
+bmx_merge_kernel(const XZone* __restrict__ zones, const int2* __restrict__ items, int y_begin, int y_end, const XCarry* __restrict__ part,
+                 int32_t* __restrict__ out, XCarry* __restrict__ carry, int* __restrict__ zone_flag) {
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int2 it = items[blockIdx.x * 4 + wave];
+  if (it.x < 0) return;
+  const XZone z = zones[it.x];
+  int xlog = 0;
+  while ((1 << xlog) < z.zw && xlog < 6) ++xlog;
+  const int x = (it.y >> 20) * 64 + (lane & ((1 << xlog) - 1));
+  const int y = (it.y & 0xfffff) + (lane >> xlog);
+  const int ylim = y_end < z.zh ? y_end : z.zh;
+  if (x >= z.zw || y >= ylim) return;
+  const int prows = ylim - y_begin;
+  const int ngrp = (z.dn + TL_X - 1) / TL_X;
+  const XCarry* p = part + z.part + (size_t)(y - y_begin) * z.zw + x;
+  const size_t gstride = (size_t)prows * z.zw;
+  XCarry s = p[0];
+  int nan = s.pad;
+  if (CARRY && (z.carry_mode & 1)) {
+    const XCarry c = carry[z.carry + (size_t)y * z.zw + x];
+    nan |= (c.best != c.best || c.worst != c.worst) ? 1 : 0;
+    if (!xbetter<COST>(s.best, c.best)) { s.best = c.best; s.idx = c.idx; }       // the earlier disparities win ties
+    if (xbetter<COST>(s.worst, c.worst)) s.worst = c.worst;
+  }
+  for (int k = 1; k < ngrp; ++k) {
+    const XCarry n = p[(size_t)k * gstride];
+    nan |= n.pad;
+    if (xbetter<COST>(n.best, s.best)) { s.best = n.best; s.idx = n.idx; }
+    if (!xbetter<COST>(n.worst, s.worst)) s.worst = n.worst;
+  }
+  if (nan) { zone_flag[it.x] = 1; return; }             // (every writer stores the same value)
+  if (CARRY && (z.carry_mode & 2)) {
+    carry[z.carry + (size_t)y * z.zw + x] = XCarry{s.best, s.worst, s.idx, 0};
+  } else {
+    const int qy = s.idx / z.sx, qx = s.idx - qy * z.sx;
+    int32_t* o = out + ((size_t)z.out_off + (size_t)y * z.out_stride + x) * 3;
+    o[0] = qx + z.addx; o[1] = qy + z.addy; o[2] = (s.best == s.worst) ? 0 : 0x7fffffff;   // Correlation.cc:121-133
+  }
+}
+
 // ---- small zones: the whole recurrence in LDS, one wavefront per zone (round 3) ---------------------------------------------------
 // A pyramid level is ~2000 zones of ~32 x 32 pixels with ~5 x 5 disparities each (CorrelationView.cc:596-700).  Through the two
 // HBM passes above every (pixel, disparity) costs 16 B of traffic and the chains are 32 steps long — LoG + NCC, the `correlate`
@@ -755,6 +999,12 @@ int lanes_log2_for(int D) {
   return l;
 }
 
+// doubles per (row, column) of a matcher's volume: enough for either layout (the tiled one rounds the disparities up to groups of XTL)
+int dp_alloc(int D) {
+  const int nchunk = (D + 63) / 64, dp = nchunk == 1 ? (1 << lanes_log2_for(D)) : nchunk * 64;
+  return std::max(dp, (D + XTL - 1) / XTL * XTL);
+}
+
 size_t exact_scratch_budget(const vwgpu_ctx* ctx) { return (size_t)ctx->exact_scratch_mb << 20; }     // VWGPU_OPT_EXACT_SCRATCH_MB
 
 struct Tables {
@@ -763,6 +1013,9 @@ struct Tables {
   std::vector<int2> row_items;
   std::vector<int2> sel_items;      // bmx_select_kernel: {zone, first row | x-chunk << 20}
   std::vector<int4> rs_items;       // bmx_rowsum_kernel: {zone, first row, chunk, -}
+  std::vector<int4> tl_items;       // bmx_rowsel_kernel: {zone, first row of a pair, group of 32 disparities, -}
+  std::vector<int2> mg_items;       // bmx_merge_kernel: {zone, first row | x-chunk << 20}, zones of more than 32 disparities
+  size_t part_records = 0;          // group records of those zones
   size_t vol_doubles = 0;
 };
 
@@ -777,23 +1030,50 @@ void add_zone(Tables& t, XZone z, int kx, int rows, bool box) {
   const int dp = z.nchunk == 1 ? lanes : z.nchunk * 64;
   const int cw = z.zw + kx - 1;
   z.vol = (long long)t.vol_doubles;
-  t.vol_doubles += (size_t)rows * cw * dp;
+  t.vol_doubles += (size_t)rows * cw * (box ? dp : dp_alloc(D));
   t.zones.push_back(z);
 }
 
 // split_from: zones at least this wide take the split pass 2 (rowsum + select items), narrower ones the fused kernel (row items);
 // box tables pass INT_MAX (their pass 2 is bmx_box_row_kernel over the row items).
-void build_items(Tables& t, int kx, int y_begin, int y_end, int split_from = INT_MAX) {
+// (zones that take the tiled form get the offsets of their group records here: the table is uploaded afterwards)
+void build_items(Tables& t, int kx, int y_begin, int y_end, int split_from = INT_MAX, int tiled_from = INT_MAX, int tiled_to = INT_MAX) {
   t.col_items.clear();
   t.row_items.clear();
   t.sel_items.clear();
   t.rs_items.clear();
+  t.tl_items.clear();
+  t.mg_items.clear();
+  t.part_records = 0;
   for (size_t i = 0; i < t.zones.size(); ++i) {
-    const XZone& z = t.zones[i];
+    XZone& z = t.zones[i];
     const int lanes = 1 << z.lanes_log2, cpw = 256 / lanes, cw = z.zw + kx - 1, rpw = 64 / lanes;
-    for (int c = 0; c < z.nchunk; ++c)
-      for (int x0 = 0; x0 < cw; x0 += cpw) t.col_items.push_back(make_int4((int)i, x0, c, 0));
+    z.tiled = (z.zw >= tiled_from && z.zw < tiled_to) ? 1 : 0;
+    if (z.tiled) {
+      for (int c = 0; c < (z.dn + XTL - 1) / XTL; ++c)
+        for (int x0 = 0; x0 < cw; x0 += 256 / XTL) t.col_items.push_back(make_int4((int)i, x0, c, 0));
+    } else {
+      for (int c = 0; c < z.nchunk; ++c)
+        for (int x0 = 0; x0 < cw; x0 += cpw) t.col_items.push_back(make_int4((int)i, x0, c, 0));
+    }
     const int y1 = std::min(y_end, z.zh);
+    if (z.tiled) {
+      const int ngrp = (z.dn + TL_X - 1) / TL_X, yb = std::max(y_begin, 0);
+      for (int y0 = yb; y0 < y1; y0 += TL_R)
+        for (int dg = 0; dg < ngrp; ++dg) t.tl_items.push_back(make_int4((int)i, y0, dg, 0));
+      // the fused kernel's items: it recomputes the zones bmx_merge_kernel flags (a NaN cost), and only those
+      for (int y0 = yb; y0 < y1; y0 += rpw) t.row_items.push_back(make_int2((int)i, y0));
+      if (ngrp > 1) {
+        z.part = (long long)t.part_records;
+        t.part_records += (size_t)ngrp * (y1 - yb) * z.zw;
+        int xlog = 0;
+        while ((1 << xlog) < z.zw && xlog < 6) ++xlog;
+        const int rps = 64 >> xlog, nxc = (z.zw + 63) / 64;
+        for (int y0 = yb; y0 < y1; y0 += rps)
+          for (int xc = 0; xc < nxc; ++xc) t.mg_items.push_back(make_int2((int)i, y0 | (xc << 20)));
+      }
+      continue;
+    }
     if (z.zw < split_from) {
       for (int y0 = std::max(y_begin, 0); y0 < y1; y0 += rpw) t.row_items.push_back(make_int2((int)i, y0));
       continue;
@@ -806,6 +1086,9 @@ void build_items(Tables& t, int kx, int y_begin, int y_end, int split_from = INT
     for (int y0 = std::max(y_begin, 0); y0 < y1; y0 += rps)
       for (int xc = 0; xc < nxc; ++xc) t.sel_items.push_back(make_int2((int)i, y0 | (xc << 20)));
   }
+  // tallest zones first: a column chain is zh serial steps (the zones arrive sorted by ascending search volume: the level's largest zone,
+  // 256 rows, would start last and finish alone)
+  std::stable_sort(t.col_items.begin(), t.col_items.end(), [&](const int4& a, const int4& b) { return t.zones[a.x].zh > t.zones[b.x].zh; });
   // Longest chains first: a row item is a serial recurrence of zw steps, and the zones arrive sorted by ascending search volume —
   // the 512-wide level-0 zones would start last and finish alone (LoG + NCC tile: 5.57 -> 5.32 ms of bmx_row).
   std::stable_sort(t.row_items.begin(), t.row_items.end(), [&](const int2& a, const int2& b) {
@@ -816,58 +1099,67 @@ void build_items(Tables& t, int kx, int y_begin, int y_end, int split_from = INT
   // longest chains first, as the row items
   std::stable_sort(t.rs_items.begin(), t.rs_items.end(), [&](const int4& a, const int4& b) { return t.zones[a.x].zw > t.zones[b.x].zw; });
   while (t.rs_items.size() % 4) t.rs_items.push_back(make_int4(-1, 0, 0, 0));
+  // longest rows first
+  std::stable_sort(t.tl_items.begin(), t.tl_items.end(), [&](const int4& a, const int4& b) { return t.zones[a.x].zw > t.zones[b.x].zw; });
+  while (t.mg_items.size() % 4) t.mg_items.push_back(make_int2(-1, 0));
 }
 
-struct DevTables { const XZone* zones; const int4* col; const int2* row; const int2* sel; const int4* rs; };
+struct DevTables { const XZone* zones; const int4* col; const int2* row; const int2* sel; const int4* rs; const int4* tl; const int2* mg; int* flags; };
+
+// the pieces of one table set, in upload order (the last one, the zone flags of bmx_merge_kernel, is a block of zeros)
+struct TablePieces {
+  const void* src[8];
+  size_t bytes[8], off[8], all;
+  std::vector<int> zeros;
+  explicit TablePieces(const Tables& t) : zeros(t.mg_items.empty() ? 0 : t.zones.size(), 0) {
+    const void* p[8] = {t.zones.data(), t.col_items.data(), t.row_items.data(), t.sel_items.data(), t.rs_items.data(), t.tl_items.data(),
+                        t.mg_items.data(), zeros.data()};
+    const size_t n[8] = {t.zones.size() * sizeof(XZone), t.col_items.size() * sizeof(int4), t.row_items.size() * sizeof(int2),
+                         t.sel_items.size() * sizeof(int2), t.rs_items.size() * sizeof(int4), t.tl_items.size() * sizeof(int4),
+                         t.mg_items.size() * sizeof(int2), zeros.size() * sizeof(int)};
+    all = 0;
+    for (int i = 0; i < 8; ++i) { src[i] = p[i]; bytes[i] = n[i]; off[i] = all; all += vwgpu_align_up(n[i], 256); }
+  }
+};
 
 int upload(vwgpu_ctx* ctx, const Tables& t, char*& cursor, char* end, DevTables* d) {
-  const size_t zb = vwgpu_align_up(t.zones.size() * sizeof(XZone), 256), cb = vwgpu_align_up(t.col_items.size() * sizeof(int4), 256),
-               rb = vwgpu_align_up(t.row_items.size() * sizeof(int2), 256), sb = vwgpu_align_up(t.sel_items.size() * sizeof(int2), 256),
-               qb = vwgpu_align_up(t.rs_items.size() * sizeof(int4), 256);
-  const size_t all = zb + cb + rb + sb + qb;
-  if (cursor + all > end) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "bm_exact: table arena too small");
+  const TablePieces tp(t);
+  if (cursor + tp.all > end) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "bm_exact: table arena too small");
   // The host vectors are rebuilt for the next band / go out of scope while the stream still runs: the tables cross PCIe from a
   // piece of the pinned ring (one asynchronous copy); tables too large for the ring are copied from the vectors and waited for.
-  if (char* h = static_cast<char*>(vwgpu_host_ring(ctx, all))) {
-    memcpy(h, t.zones.data(), t.zones.size() * sizeof(XZone));
-    memcpy(h + zb, t.col_items.data(), t.col_items.size() * sizeof(int4));
-    memcpy(h + zb + cb, t.row_items.data(), t.row_items.size() * sizeof(int2));
-    memcpy(h + zb + cb + rb, t.sel_items.data(), t.sel_items.size() * sizeof(int2));
-    memcpy(h + zb + cb + rb + sb, t.rs_items.data(), t.rs_items.size() * sizeof(int4));
-    VWGPU_HIP(ctx, hipMemcpyAsync(cursor, h, all, hipMemcpyHostToDevice, ctx->stream));
+  if (char* h = static_cast<char*>(vwgpu_host_ring(ctx, tp.all))) {
+    for (int i = 0; i < 8; ++i)
+      if (tp.bytes[i]) memcpy(h + tp.off[i], tp.src[i], tp.bytes[i]);
+    VWGPU_HIP(ctx, hipMemcpyAsync(cursor, h, tp.all, hipMemcpyHostToDevice, ctx->stream));
   } else {
-    VWGPU_HIP(ctx, hipMemcpyAsync(cursor, t.zones.data(), t.zones.size() * sizeof(XZone), hipMemcpyHostToDevice, ctx->stream));
-    VWGPU_HIP(ctx, hipMemcpyAsync(cursor + zb, t.col_items.data(), t.col_items.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-    VWGPU_HIP(ctx, hipMemcpyAsync(cursor + zb + cb, t.row_items.data(), t.row_items.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
-    VWGPU_HIP(ctx, hipMemcpyAsync(cursor + zb + cb + rb, t.sel_items.data(), t.sel_items.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
-    VWGPU_HIP(ctx, hipMemcpyAsync(cursor + zb + cb + rb + sb, t.rs_items.data(), t.rs_items.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+    for (int i = 0; i < 8; ++i)
+      if (tp.bytes[i]) VWGPU_HIP(ctx, hipMemcpyAsync(cursor + tp.off[i], tp.src[i], tp.bytes[i], hipMemcpyHostToDevice, ctx->stream));
     VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  d->zones = reinterpret_cast<const XZone*>(cursor);
-  d->col = reinterpret_cast<const int4*>(cursor + zb);
-  d->row = reinterpret_cast<const int2*>(cursor + zb + cb);
-  d->sel = reinterpret_cast<const int2*>(cursor + zb + cb + rb);
-  d->rs = reinterpret_cast<const int4*>(cursor + zb + cb + rb + sb);
-  cursor += all;
+  d->zones = reinterpret_cast<const XZone*>(cursor + tp.off[0]);
+  d->col = reinterpret_cast<const int4*>(cursor + tp.off[1]);
+  d->row = reinterpret_cast<const int2*>(cursor + tp.off[2]);
+  d->sel = reinterpret_cast<const int2*>(cursor + tp.off[3]);
+  d->rs = reinterpret_cast<const int4*>(cursor + tp.off[4]);
+  d->tl = reinterpret_cast<const int4*>(cursor + tp.off[5]);
+  d->mg = reinterpret_cast<const int2*>(cursor + tp.off[6]);
+  d->flags = reinterpret_cast<int*>(cursor + tp.off[7]);
+  cursor += tp.all;
   return VWGPU_OK;
 }
 
-size_t table_bytes(const Tables& t) {
-  return vwgpu_align_up(t.zones.size() * sizeof(XZone), 256) + vwgpu_align_up(t.col_items.size() * sizeof(int4), 256) +
-         vwgpu_align_up(t.row_items.size() * sizeof(int2), 256) + vwgpu_align_up(t.sel_items.size() * sizeof(int2), 256) +
-         vwgpu_align_up(t.rs_items.size() * sizeof(int4), 256);
-}
+size_t table_bytes(const Tables& t) { return TablePieces(t).all; }
 
 template <int COST>
 void launch_pair(vwgpu_ctx* ctx, const char* n1, const char* n2, const float* A, int aw, int ah, ptrdiff_t as,
                  const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky, const Tables& t, const DevTables& d, double* vol,
-                 int y_begin, int y_end, double* state, const double* prec, int32_t* out, double* outd, XCarry* carry = nullptr) {
+                 int y_begin, int y_end, double* state, const double* prec, int32_t* out, double* outd, XCarry* carry = nullptr, XCarry* part = nullptr) {
   if (!t.col_items.empty()) {
     vwgpu_prof_scope ps(ctx, n1);
     hipLaunchKernelGGL((bmx_col_kernel<COST>), dim3((unsigned)t.col_items.size()), dim3(256), 0, ctx->stream,
                        A, aw, ah, as, B, bw, bh, bs, kx, ky, d.zones, d.col, vol, y_begin, y_end, state);
   }
-  if (!t.row_items.empty() || !t.rs_items.empty()) {
+  if (!t.row_items.empty() || !t.rs_items.empty() || !t.tl_items.empty()) {
     constexpr bool BOX = (COST == XCOST_BOX || COST == XCOST_PREC);
     const dim3 grd((unsigned)(t.row_items.size() / 4)), blk(256);
     if constexpr (BOX) {
@@ -886,18 +1178,44 @@ void launch_pair(vwgpu_ctx* ctx, const char* n1, const char* n2, const float* A,
         if (carry) hipLaunchKernelGGL((bmx_select_kernel<COST, true>), sgrd, blk, 0, ctx->stream, kx, d.zones, d.sel, vol, y_begin, y_end, prec, out, carry);
         else hipLaunchKernelGGL((bmx_select_kernel<COST, false>), sgrd, blk, 0, ctx->stream, kx, d.zones, d.sel, vol, y_begin, y_end, prec, out, carry);
       }
+      const bool tiled = !t.tl_items.empty();           // then the row items are the redo pass over the zones bmx_merge_kernel flags
+      if (tiled) {
+        {
+          vwgpu_prof_scope ps(ctx, "bmx_rowsel");
+          const dim3 tgrd((unsigned)t.tl_items.size());
+#define VWGPU_RS(K) do { if (carry) hipLaunchKernelGGL((bmx_rowsel_kernel<COST, true, K>), tgrd, dim3(64), 0, ctx->stream, kx, d.zones, d.tl, vol, y_begin, y_end, prec, out, carry, part); \
+                         else hipLaunchKernelGGL((bmx_rowsel_kernel<COST, false, K>), tgrd, dim3(64), 0, ctx->stream, kx, d.zones, d.tl, vol, y_begin, y_end, prec, out, carry, part); } while (0)
+          switch (kx) {
+            case 3: VWGPU_RS(3); break;
+            case 5: VWGPU_RS(5); break;
+            case 7: VWGPU_RS(7); break;
+            case 9: VWGPU_RS(9); break;
+            case 11: VWGPU_RS(11); break;
+            case 13: VWGPU_RS(13); break;
+            case 15: VWGPU_RS(15); break;
+            default: VWGPU_RS(0); break;
+          }
+#undef VWGPU_RS
+        }
+        if (t.mg_items.empty()) return;                  // no zone searches more than 32 disparities: every result is final
+        vwgpu_prof_scope ps(ctx, "bmx_merge");
+        const dim3 mgrd((unsigned)(t.mg_items.size() / 4));
+        if (carry) hipLaunchKernelGGL((bmx_merge_kernel<COST, true>), mgrd, blk, 0, ctx->stream, d.zones, d.mg, y_begin, y_end, part, out, carry, d.flags);
+        else hipLaunchKernelGGL((bmx_merge_kernel<COST, false>), mgrd, blk, 0, ctx->stream, d.zones, d.mg, y_begin, y_end, part, out, carry, d.flags);
+      }
+      const int* zflag = tiled ? d.flags : nullptr;
       if (!t.row_items.empty()) {
         int nch = 1;
         for (const int2& it : t.row_items) if (it.x >= 0) nch = std::max(nch, t.zones[it.x].nchunk);
         vwgpu_prof_scope ps(ctx, n2);
         if (carry)
-          hipLaunchKernelGGL((bmx_row_fused_kernel<COST, XMAX_CHUNKS, true>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd, carry);
+          hipLaunchKernelGGL((bmx_row_fused_kernel<COST, XMAX_CHUNKS, true>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd, carry, zflag);
         else if (nch == 1)
-          hipLaunchKernelGGL((bmx_row_fused_kernel<COST, 1>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd);
+          hipLaunchKernelGGL((bmx_row_fused_kernel<COST, 1>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd, static_cast<XCarry*>(nullptr), zflag);
         else if (nch <= 3)
-          hipLaunchKernelGGL((bmx_row_fused_kernel<COST, 3>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd);
+          hipLaunchKernelGGL((bmx_row_fused_kernel<COST, 3>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd, static_cast<XCarry*>(nullptr), zflag);
         else
-          hipLaunchKernelGGL((bmx_row_fused_kernel<COST, XMAX_CHUNKS>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd);
+          hipLaunchKernelGGL((bmx_row_fused_kernel<COST, XMAX_CHUNKS>), grd, blk, 0, ctx->stream, kx, d.zones, d.row, vol, y_begin, y_end, prec, out, outd, static_cast<XCarry*>(nullptr), zflag);
       }
     }
   }
@@ -973,7 +1291,7 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
                      const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky,
                      const vwgpu_zone_task* zones, int n, int32_t* out, const DGroup* dgroup = nullptr) {
   const bool ncc = cost_type == VWGPU_CROSS_CORRELATION;
-  Tables match, boxa, boxb;
+  Tables match, box;                                  // box: the NCC precision images of every zone, left and right crops in one table
   size_t prec_doubles = 0;
   for (int i = 0; i < n; ++i) {
     const vwgpu_zone_task& s = zones[i];
@@ -985,10 +1303,10 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
       // NCCCost ctor over the zone's own crops (CostFunctions.h:214-219): box sums restart at the crop origin
       z.lprec = (long long)prec_doubles; prec_doubles += (size_t)s.zw * s.zh;
       z.rprec = (long long)prec_doubles; prec_doubles += (size_t)(s.zw + s.sx - 1) * (s.zh + s.sy - 1);
-      XZone a{}; a.ax = s.ax; a.ay = s.ay; a.zw = s.zw; a.zh = s.zh; a.sx = a.sy = 1; a.lprec = z.lprec;
-      add_zone(boxa, a, kx, a.zh, true);
-      XZone b{}; b.ax = s.bx; b.ay = s.by; b.zw = s.zw + s.sx - 1; b.zh = s.zh + s.sy - 1; b.sx = b.sy = 1; b.lprec = z.rprec;
-      add_zone(boxb, b, kx, b.zh, true);
+      XZone a{}; a.ax = s.ax; a.ay = s.ay; a.zw = s.zw; a.zh = s.zh; a.sx = a.sy = 1; a.lprec = z.lprec; a.img = 0;
+      add_zone(box, a, kx, a.zh, true);
+      XZone b{}; b.ax = s.bx; b.ay = s.by; b.zw = s.zw + s.sx - 1; b.zh = s.zh + s.sy - 1; b.sx = b.sy = 1; b.lprec = z.rprec; b.img = 1;
+      add_zone(box, b, kx, b.zh, true);
     }
     add_zone(match, z, kx, z.zh, false);
   }
@@ -1000,28 +1318,29 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
   size_t state_doubles = 0;
   if (match.vol_doubles * 8 > budget && match.zones.size() == 1) {
     XZone& z = match.zones[0];
-    const int lanes = 1 << z.lanes_log2, dp = z.nchunk == 1 ? lanes : z.nchunk * 64, cw = z.zw + kx - 1;
+    const int dp = dp_alloc(z.dn), cw = z.zw + kx - 1;
     const size_t row = (size_t)cw * dp * 8;
     band = (int)std::max<size_t>(1, budget / row);
     if (band >= z.zh) band = INT_MAX;
     else { match.vol_doubles = (size_t)band * cw * dp; state_doubles = (size_t)cw * dp; }
   }
-  const size_t vol_need = std::max(match.vol_doubles, std::max(boxa.vol_doubles, boxb.vol_doubles));
-  int rc = vwgpu_arena_reserve(ctx, &ctx->xvol, (vol_need + state_doubles + prec_doubles) * 8 + 1024);
+  // zones at least this wide take the split pass 2, narrower ones the tiled kernel (VWGPU_OPT_EXACT_SPLIT: 0 = 1024 pixels — whole rasters
+  // run the recurrence alone + a parallel selection; 1 = split, 2 = fused, 3 = tiled for every zone)
+  const int split_from = ctx->exact_split == 1 ? 0 : (ctx->exact_split == 2 || ctx->exact_split == 3 ? INT_MAX : 1024);
+  const int tiled_from = ctx->exact_split == 1 || ctx->exact_split == 2 ? INT_MAX : 0;
+  const int tiled_to = ctx->exact_split == 3 ? INT_MAX : split_from;      // tiled: tiled_from <= width < tiled_to
+  build_items(match, kx, 0, band, split_from, tiled_from, tiled_to);
+  build_items(box, kx, 0, INT_MAX);
+  const size_t vol_need = std::max(match.vol_doubles, box.vol_doubles);
+  const size_t part_doubles = match.part_records * (sizeof(XCarry) / sizeof(double));      // (the first band is the tallest)
+  int rc = vwgpu_arena_reserve(ctx, &ctx->xvol, (vol_need + state_doubles + prec_doubles + part_doubles) * 8 + 1024);
   if (rc) return rc;
   double* vol = static_cast<double*>(ctx->xvol.base);
   double* state = state_doubles ? vol + vol_need : nullptr;
   double* prec = vol + vol_need + state_doubles;
-
-  // zones at least this wide take the split pass 2 (VWGPU_OPT_EXACT_SPLIT: 0 = 1024 pixels — whole rasters; the zones of a pyramid tile stay
-  // with the fused kernel: with a 128-pixel threshold the selection pass over a level's wide zones cost more than their chains had, LoG + NCC
-  // tile loop 3.18 -> 3.40 ms per tile; 1 = all; 2 = none)
-  const int split_from = ctx->exact_split == 1 ? 0 : (ctx->exact_split == 2 ? INT_MAX : 1024);
-  build_items(match, kx, 0, band, split_from);
-  build_items(boxa, kx, 0, INT_MAX);
-  build_items(boxb, kx, 0, INT_MAX);
+  XCarry* part = reinterpret_cast<XCarry*>(prec + prec_doubles);
   // tables of every launch of this call live side by side (uploads are stream ordered)
-  size_t tb = table_bytes(match) + table_bytes(boxa) + table_bytes(boxb) + 4096;
+  size_t tb = table_bytes(match) + table_bytes(box) + 4096;
   if (band != INT_MAX) tb += (size_t)((match.zones[0].zh + band - 1) / band) * (table_bytes(match) + 1024);
   rc = vwgpu_arena_reserve(ctx, &ctx->xtab, tb);
   if (rc) return rc;
@@ -1029,24 +1348,22 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
   char* end = cur + ctx->xtab.cap;
   DevTables d;
   if (ncc) {
-    if ((rc = upload(ctx, boxa, cur, end, &d))) return rc;
-    launch_pair<XCOST_PREC>(ctx, "bmx_prec_col", "bmx_prec_row", A, aw, ah, as, nullptr, 0, 0, 0, kx, ky, boxa, d, vol, 0, INT_MAX, nullptr, nullptr, nullptr, prec);
-    if ((rc = upload(ctx, boxb, cur, end, &d))) return rc;
-    launch_pair<XCOST_PREC>(ctx, "bmx_prec_col", "bmx_prec_row", B, bw, bh, bs, nullptr, 0, 0, 0, kx, ky, boxb, d, vol, 0, INT_MAX, nullptr, nullptr, nullptr, prec);
+    if ((rc = upload(ctx, box, cur, end, &d))) return rc;
+    launch_pair<XCOST_PREC>(ctx, "bmx_prec_col", "bmx_prec_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, box, d, vol, 0, INT_MAX, nullptr, nullptr, nullptr, prec);
   }
   const int zh0 = match.zones[0].zh;
   const int nbands = band == INT_MAX ? 1 : (zh0 + band - 1) / band;
   for (int b = 0; b < nbands; ++b) {
     const int yb = band == INT_MAX ? 0 : b * band, ye = band == INT_MAX ? INT_MAX : yb + band;
-    if (band != INT_MAX) build_items(match, kx, yb, ye, split_from);
+    if (band != INT_MAX) build_items(match, kx, yb, ye, split_from, tiled_from, tiled_to);
     if ((rc = upload(ctx, match, cur, end, &d))) return rc;
     switch (cost_type) {
       case VWGPU_CROSS_CORRELATION:
-        launch_pair<VWGPU_CROSS_CORRELATION>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr, dgroup ? dgroup->carry : nullptr); break;
+        launch_pair<VWGPU_CROSS_CORRELATION>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr, dgroup ? dgroup->carry : nullptr, part); break;
       case VWGPU_SQUARED_DIFFERENCE:
-        launch_pair<VWGPU_SQUARED_DIFFERENCE>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr, dgroup ? dgroup->carry : nullptr); break;
+        launch_pair<VWGPU_SQUARED_DIFFERENCE>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr, dgroup ? dgroup->carry : nullptr, part); break;
       default:
-        launch_pair<VWGPU_ABSOLUTE_DIFFERENCE>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr, dgroup ? dgroup->carry : nullptr); break;
+        launch_pair<VWGPU_ABSOLUTE_DIFFERENCE>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr, dgroup ? dgroup->carry : nullptr, part); break;
     }
   }
   VWGPU_HIP(ctx, hipGetLastError());
@@ -1124,8 +1441,7 @@ int vwgpu_launch_bm_exact(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
       }
       continue;
     }
-    const int D = s.sx * s.sy, nchunk = (D + 63) / 64, dp = nchunk == 1 ? (1 << lanes_log2_for(D)) : nchunk * 64;
-    const size_t need = (size_t)s.zh * (s.zw + kx - 1) * dp * 8;
+    const size_t need = (size_t)s.zh * (s.zw + kx - 1) * dp_alloc(s.sx * s.sy) * 8;
     if (!group.empty() && bytes + need > budget) {
       int rc = run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, group.data(), (int)group.size(), out);
       if (rc) return rc;

@@ -204,7 +204,7 @@ int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value) {
   if (option == VWGPU_OPT_SGM_SWEEP && value >= 0 && value <= 15) { ctx->sgm_sweep = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_EXACT_LDS && value >= 0 && value <= 2) { ctx->exact_lds = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_MGM_SWEEP && value >= 0 && value <= 15) { ctx->mgm_sweep = value; return VWGPU_OK; }
-  if (option == VWGPU_OPT_EXACT_SPLIT && value >= 0 && value <= 2) { ctx->exact_split = value; return VWGPU_OK; }
+  if (option == VWGPU_OPT_EXACT_SPLIT && value >= 0 && value <= 3) { ctx->exact_split = value; return VWGPU_OK; }
   return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "vwgpu_set_option: unknown or read-only option %d, or value %d out of range", option, value);
 }
 
