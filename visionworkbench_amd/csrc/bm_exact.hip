@@ -103,7 +103,10 @@ __device__ __forceinline__ int xclamp(int v, int n) { return v < 0 ? 0 : (v >= n
 // ---- pass 1: column chains -----------------------------------------------------------------------------------------
 // items[i] = {zone, first column, disparity chunk, -}.  Rows [y_begin, y_end) of every zone are produced (clipped to
 // the zone); y_begin > 0 resumes the chains from `state` (single-zone band mode), and `state` receives them at the end.
-template <int COST>
+// KY > 0: the window height is a compile-time constant and the chain advances in batches of KY rows — the elements that leave the window
+// during a batch are the ones that entered it during the previous batch, so every cost element is formed once (KY == 0, any height: the
+// entering and the leaving element of every row are both formed from their pixels).
+template <int COST, int KY>
 __global__ void __launch_bounds__(256)
 bmx_col_kernel(const float* __restrict__ A, int aw, int ah, ptrdiff_t as, const float* __restrict__ B, int bw, int bh, ptrdiff_t bs,
                int kx, int ky, const XZone* __restrict__ zones, const int4* __restrict__ items, double* __restrict__ vol,
@@ -131,16 +134,41 @@ bmx_col_kernel(const float* __restrict__ A, int aw, int ah, ptrdiff_t as, const 
   };
   const int y0 = y_begin < 0 ? 0 : y_begin, y1 = y_end < z.zh ? y_end : z.zh;
   double cs;
+  double prev[KY > 0 ? KY : 1];                          // KY > 0: the elements of rows y .. y + KY - 1 (they leave the window next)
+  if (KY > 0) {
+#pragma unroll
+    for (int i = 0; i < KY; ++i) prev[i] = elem(y0 + i);
+  }
   if (y0 == 0) {
     cs = 0.0;                                           // std::valarray<AccumT> col_sum(cols): zero-initialised
-    for (int j = 0; j < ky; ++j) cs += elem(j);         // Algorithms.h:62-75
+    if (KY > 0) {
+#pragma unroll
+      for (int j = 0; j < KY; ++j) cs += prev[j];       // Algorithms.h:62-75
+    } else {
+      for (int j = 0; j < ky; ++j) cs += elem(j);
+    }
   } else {
     cs = state[(size_t)col * dp + d];
   }
   double* v = vol + z.vol + (size_t)col * lay.xs + lay.off(d);
   const size_t rstride = lay.rs;
   int y = y0;
-  for (; y + 8 <= y1 && y + 8 < z.zh; y += 8) {         // eight rows' pixels requested together: the chain itself is serial
+  if (KY > 0) {
+    for (; y + KY <= y1 && y + KY < z.zh; y += KY) {    // KY rows' pixels requested together: the chain itself is serial
+      double in[KY > 0 ? KY : 1];
+#pragma unroll
+      for (int i = 0; i < KY; ++i) in[i] = elem(y + KY + i);
+#pragma unroll
+      for (int i = 0; i < KY; ++i) {
+        v[(size_t)(y + i - y0) * rstride] = cs;
+        cs += in[i];                                    // Algorithms.h:100-103: two statements, this order
+        cs -= prev[i];
+      }
+#pragma unroll
+      for (int i = 0; i < KY; ++i) prev[i] = in[i];
+    }
+  }
+  for (; KY == 0 && y + 8 <= y1 && y + 8 < z.zh; y += 8) {         // eight rows' pixels requested together: the chain itself is serial
     double in[8], out[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { in[i] = elem(y + ky + i); out[i] = elem(y + i); }
@@ -1156,8 +1184,19 @@ void launch_pair(vwgpu_ctx* ctx, const char* n1, const char* n2, const float* A,
                  int y_begin, int y_end, double* state, const double* prec, int32_t* out, double* outd, XCarry* carry = nullptr, XCarry* part = nullptr) {
   if (!t.col_items.empty()) {
     vwgpu_prof_scope ps(ctx, n1);
-    hipLaunchKernelGGL((bmx_col_kernel<COST>), dim3((unsigned)t.col_items.size()), dim3(256), 0, ctx->stream,
-                       A, aw, ah, as, B, bw, bh, bs, kx, ky, d.zones, d.col, vol, y_begin, y_end, state);
+#define VWGPU_CK(K) hipLaunchKernelGGL((bmx_col_kernel<COST, K>), dim3((unsigned)t.col_items.size()), dim3(256), 0, ctx->stream, \
+                                      A, aw, ah, as, B, bw, bh, bs, kx, ky, d.zones, d.col, vol, y_begin, y_end, state)
+    switch (ky) {
+      case 3: VWGPU_CK(3); break;
+      case 5: VWGPU_CK(5); break;
+      case 7: VWGPU_CK(7); break;
+      case 9: VWGPU_CK(9); break;
+      case 11: VWGPU_CK(11); break;
+      case 13: VWGPU_CK(13); break;
+      case 15: VWGPU_CK(15); break;
+      default: VWGPU_CK(0); break;
+    }
+#undef VWGPU_CK
   }
   if (!t.row_items.empty() || !t.rs_items.empty() || !t.tl_items.empty()) {
     constexpr bool BOX = (COST == XCOST_BOX || COST == XCOST_PREC);
