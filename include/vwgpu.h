@@ -107,9 +107,10 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *   VWGPU_OPT_EXACT_LDS        exact-order matching of zones whose working set fits the LDS of one wavefront (bmx_zone_lds_kernel):
  *       0 = never (default: the two HBM passes for every zone — measured faster), 1 = for the zone lists of a pyramid level,
  *       2 = also for single-zone calls (calc_disparity on a small raster).
- *   VWGPU_OPT_EXACT_SPLIT      pass 2 of the exact-order matchers: 0 = chosen by the longest chain of the call (the recurrence alone + a
- *       parallel selection for zones of 1024 pixels and more (whole rasters), the fused kernel for narrower ones), 1 = always
- *       the split form, 2 = always the fused form, 3 = always the tiled form (row sums transposed through LDS).
+ *   VWGPU_OPT_EXACT_SPLIT      pass 2 of the exact-order matchers: 0 = chosen by the width of a zone (the recurrence alone + a parallel
+ *       selection for zones of 1024 pixels and more (whole rasters), the tiled form — row sums transposed through LDS — for narrower
+ *       ones), 1 = always the split form, 2 = always the fused form (selection across the disparity lanes inside the chain), 3 = always
+ *       the tiled form.  Same results in every form.
  *   VWGPU_OPT_MGM_SWEEP        use_mgm on full-range one-row searches (<= 256 disparities): 0 = the eight passes as four concurrent
  *       sweeps (default), 1 = one launch per front (the round-2 schedule), 2 .. 15 = the sweeps with that many lines per workgroup. */
 typedef enum vwgpu_option {
