@@ -12,4 +12,7 @@ run python tools/fuzz_pyramid_sgm_vs_oracle.py 1000 $SEED 3
 run python tools/fuzz_fast_vs_generic.py 3000 $SEED 0
 run python tools/fuzz_fast_vs_generic.py 3000 $SEED 1
 run python tools/fuzz_fast_vs_generic.py 3000 $SEED 2
+run python tools/fuzz_fast_vs_generic.py 1500 $SEED 0 65536
+run python tools/fuzz_fast_vs_generic.py 2000 $SEED 1 4096
+run python tools/fuzz_fast_vs_generic.py 2000 $SEED 2 4096
 cat $L
