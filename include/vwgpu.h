@@ -111,11 +111,14 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *       selection for zones of 1024 pixels and more (whole rasters), the tiled form — row sums transposed through LDS — for narrower
  *       ones), 1 = always the split form, 2 = always the fused form (selection across the disparity lanes inside the chain), 3 = always
  *       the tiled form.  Same results in every form.
+ *   VWGPU_OPT_CORR_MFMA        SSD / NCC on byte imagery: 0 = the v_dot4_u32_u8 kernels (default), 1 = the products on the matrix cores
+ *       (v_mfma_i32_16x16x32_i8; same results, measured slower: 1.13 - 1.20 ms against 0.69 - 0.94 ms at 4096^2 x 129).
  *   VWGPU_OPT_MGM_SWEEP        use_mgm on full-range one-row searches (<= 256 disparities): 0 = the eight passes as four concurrent
  *       sweeps (default), 1 = one launch per front (the round-2 schedule), 2 .. 15 = the sweeps with that many lines per workgroup. */
 typedef enum vwgpu_option {
   VWGPU_OPT_DEFER_EXACTNESS = 1, VWGPU_OPT_DEVICE_COUNT = 2, VWGPU_OPT_SAD_GROUPS = 3, VWGPU_OPT_EXACT_SCRATCH_MB = 4,
-  VWGPU_OPT_TRACE = 5, VWGPU_OPT_SGM_SWEEP = 6, VWGPU_OPT_EXACT_LDS = 7, VWGPU_OPT_MGM_SWEEP = 8, VWGPU_OPT_EXACT_SPLIT = 9
+  VWGPU_OPT_TRACE = 5, VWGPU_OPT_SGM_SWEEP = 6, VWGPU_OPT_EXACT_LDS = 7, VWGPU_OPT_MGM_SWEEP = 8, VWGPU_OPT_EXACT_SPLIT = 9,
+  VWGPU_OPT_CORR_MFMA = 10
 } vwgpu_option;
 int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value);
 int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value);
