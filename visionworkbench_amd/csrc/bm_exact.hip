@@ -1269,9 +1269,10 @@ bool vwgpu_bm_exact_supported(int sx, int sy) { return sx > 0 && sy > 0 && (long
 // every cost element is a multiple of g (SAD) or g^2 (SSD / NCC: the float product rounds to a coarser multiple) and
 // every intermediate value of the reference's chains — at most 2 * kx * ky elements in magnitude — is exactly
 // representable in float64 iff it stays below 2^53 units, in which case ANY summation order returns the same bits.
-bool vwgpu_sums_order_free(int cost_type, int kx, int ky, int lo, int hi, int nonfinite) {
-  if (nonfinite & 1) return false;
-  if (lo == INT_MAX) return true;                       // all-zero images
+// mantissa bits the largest intermediate value of the chains can need (INT_MAX: a non-finite pixel; 0: all-zero images)
+int vwgpu_sums_bits(int cost_type, int kx, int ky, int lo, int hi, int nonfinite) {
+  if (nonfinite & 1) return INT_MAX;
+  if (lo == INT_MAX) return 0;
   int lg = 0;
   while ((1LL << lg) < (long long)kx * ky) ++lg;
   const long long E = (long long)hi + 1;                // |pixel| < 2^E
@@ -1279,7 +1280,10 @@ bool vwgpu_sums_order_free(int cost_type, int kx, int ky, int lo, int hi, int no
   if (cost_type == VWGPU_ABSOLUTE_DIFFERENCE) bits = (E + 1) + lg + 1 - lo;              // |a-b| < 2^(E+1)
   else if (cost_type == VWGPU_SQUARED_DIFFERENCE) bits = 2 * (E + 1) + 1 + lg + 1 - 2LL * lo;
   else bits = 2 * E + 1 + lg + 1 - 2LL * lo;
-  return bits <= 53;
+  return (int)std::min<long long>(bits, INT_MAX - 1);
+}
+bool vwgpu_sums_order_free(int cost_type, int kx, int ky, int lo, int hi, int nonfinite) {
+  return vwgpu_sums_bits(cost_type, kx, ky, lo, hi, nonfinite) <= 53;
 }
 
 // Measures images[i] into d_cells[i] (3 ints each, initialised by the caller with {INT_MAX, INT_MIN, 0}); several images may

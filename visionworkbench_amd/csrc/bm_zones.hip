@@ -31,11 +31,11 @@ namespace {
 constexpr int ZT = 32;            // output tile side
 constexpr int ZTHREADS = 256;
 
-template <int COST>
-__device__ __forceinline__ double zcost(float a, float b) {
-  if (COST == VWGPU_CROSS_CORRELATION) return (double)(a * b);
-  if (COST == VWGPU_SQUARED_DIFFERENCE) { float d = a - b; return (double)(d * d); }
-  return (double)fabsf(a - b);
+template <int COST, typename ACC = double>
+__device__ __forceinline__ ACC zcost(float a, float b) {
+  if (COST == VWGPU_CROSS_CORRELATION) return (ACC)(a * b);
+  if (COST == VWGPU_SQUARED_DIFFERENCE) { float d = a - b; return (ACC)(d * d); }
+  return (ACC)fabsf(a - b);
 }
 template <int COST>
 __device__ __forceinline__ bool zbetter(double c, double q) {
@@ -82,7 +82,10 @@ zone_precision_kernel(const float* __restrict__ img, int w, int h, int kx, int k
 
 // KS > 0: a square KS x KS window known at compile time — the horizontal and vertical window sums are unrolled (with run-time
 // sizes the loop overhead outweighed the sums, as PMC showed for bm_generic).  KS == 0: any kx, ky.
-template <int COST, int KS>
+// ACC: the type of the window sums.  float64 is the reference's; float32 is taken when every intermediate value is exactly representable in 24
+// bits as well (vwgpu_sums_bits <= 24: byte imagery under SAD) — then both give the same numbers, the LDS planes are half as large and the sums
+// full-rate.  The compare chain runs on doubles either way.
+template <int COST, int KS, typename ACC>
 __global__ void __launch_bounds__(ZTHREADS)
 bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __restrict__ B, int bw, int bh,
                 int kx, int ky, const vwgpu_zone_task* __restrict__ zones, const int2* __restrict__ tiles,
@@ -91,7 +94,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
   const int PW = ZT + kx - 1, PH = ZT + ky - 1, RW = PW + sxc - 1;
   float* Lp = reinterpret_cast<float*>(smem);                    // PH x PW
   float* Rp = Lp + PH * PW;                                      // PH x RW
-  double* H = reinterpret_cast<double*>(smem + (((size_t)(PH * PW + PH * RW) * 4 + 7) & ~size_t(7)));   // 2 x PH x ZT
+  ACC* H = reinterpret_cast<ACC*>(smem + (((size_t)(PH * PW + PH * RW) * 4 + 7) & ~size_t(7)));   // 2 x PH x ZT
 
   const int2 tl = tiles[blockIdx.x];
   const vwgpu_zone_task z = zones[tl.x];
@@ -129,7 +132,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
       }
       __syncthreads();
       for (int d = 0; d < nd; ++d) {
-        double* Hc = H + hb * (PH * ZT);
+        ACC* Hc = H + hb * (PH * ZT);
         if (KS > 0) {
           // Four adjacent columns per thread: KS + 3 cost elements are formed once and the window slides (s' = s - e[j] + e[j + KS]),
           // 2 (KS + 3) LDS reads and 3 KS + ... adds for four sums instead of 8 KS reads and 4 KS adds.  The slide is exact here:
@@ -139,14 +142,14 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
             if (q < tw) {
               const float* lp = Lp + r * PW + q;
               const float* rp = Rp + r * RW + q + d;
-              double e[KS > 0 ? KS + 3 : 1];
+              ACC e[KS > 0 ? KS + 3 : 1];
 #pragma unroll
-              for (int a = 0; a < KS + 3; ++a) e[a] = zcost<COST>(lp[a], rp[a]);
-              double s0 = 0.0;
+              for (int a = 0; a < KS + 3; ++a) e[a] = zcost<COST, ACC>(lp[a], rp[a]);
+              ACC s0 = 0;
 #pragma unroll
               for (int a = 0; a < KS; ++a) s0 += e[a];
-              const double s1 = s0 - e[0] + e[KS], s2 = s1 - e[1] + e[KS + 1], s3 = s2 - e[2] + e[KS + 2];
-              double* h = Hc + r * ZT + q;
+              const ACC s1 = s0 - e[0] + e[KS], s2 = s1 - e[1] + e[KS + 1], s3 = s2 - e[2] + e[KS + 2];
+              ACC* h = Hc + r * ZT + q;
               h[0] = s0; h[1] = s1; h[2] = s2; h[3] = s3;
             }
           }
@@ -156,8 +159,8 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
           if (q < tw) {
             const float* lp = Lp + r * PW + q;
             const float* rp = Rp + r * RW + q + d;
-            double s = 0.0;
-            for (int a = 0; a < kx; ++a) s += zcost<COST>(lp[a], rp[a]);
+            ACC s = 0;
+            for (int a = 0; a < kx; ++a) s += zcost<COST, ACC>(lp[a], rp[a]);
             Hc[r * ZT + q] = s;
           }
         }
@@ -166,9 +169,9 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
         if (c < tw) {
           const int dx = dx0 + d;
           const bool first = (dx == 0 && dy == 0);
-          double vs[4] = {0.0, 0.0, 0.0, 0.0};
+          ACC vs[4] = {0, 0, 0, 0};
           if (KS > 0) {                                           // the same slide down the rows (rows beyond th hold stale planes: unused)
-            double h[KS > 0 ? KS + 3 : 1];
+            ACC h[KS > 0 ? KS + 3 : 1];
 #pragma unroll
             for (int b = 0; b < KS + 3; ++b) h[b] = Hc[min(y0 + b, PH - 1) * ZT + c];
 #pragma unroll
@@ -179,10 +182,11 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
           for (int m = 0; m < 4; ++m) {
             const int y = y0 + m;
             if (y < th) {
-              double s = vs[m];
+              ACC sa = vs[m];
               if (KS == 0) {
-                for (int b = 0; b < ky; ++b) s += Hc[(y + b) * ZT + c];
+                for (int b = 0; b < ky; ++b) sa += Hc[(y + b) * ZT + c];
               }
+              double s = (double)sa;
               if (COST == VWGPU_CROSS_CORRELATION)
                 s *= sqrt(lprec[m] * pb.p[(size_t)(z.by + oy + y + dy - pb.y0) * pb.w + (z.bx + ox + c + dx - pb.x0)]);
               if (first) { best[m] = worst[m] = s; }
@@ -280,7 +284,9 @@ bool vwgpu_bm_zones_supported(int kx, int ky) {
 }
 
 int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
-                          int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out) {
+                          int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out, int f32_sums) {
+  if (cost_type == VWGPU_CROSS_CORRELATION) f32_sums = 0;        // (its sums are scaled in float64 anyway)
+  const size_t accb = f32_sums ? 4 : 8;
   if (n <= 0) return VWGPU_OK;
   if (!vwgpu_bm_zones_supported(kx, ky)) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "bm_zones: kernel %dx%d too large", kx, ky);
   std::vector<int2> tiles;
@@ -297,10 +303,10 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     bx1 = std::max(bx1, z.bx + z.zw + z.sx - 1); by1 = std::max(by1, z.by + z.zh + z.sy - 1);
   }
   const size_t PW = ZT + kx - 1, PH = ZT + ky - 1;
-  const size_t fixed = PH * PW * 4 + 2 * PH * ZT * 8 + 16;
+  const size_t fixed = PH * PW * 4 + 2 * PH * ZT * accb + 16;
   int sxc = (int)std::min<size_t>((size_t)max_sx, ((64 * 1024 - fixed) / (PH * 4)) - PW + 1);
   if (sxc < 1) sxc = 1;
-  const size_t lds = (((PH * PW + PH * (PW + sxc - 1)) * 4 + 7) & ~size_t(7)) + 2 * PH * ZT * 8;
+  const size_t lds = (((PH * PW + PH * (PW + sxc - 1)) * 4 + 7) & ~size_t(7)) + 2 * PH * ZT * accb;
 
   PrecView pa{nullptr, 0, 0, 0, 0}, pb{nullptr, 0, 0, 0, 0};
   if (cost_type == VWGPU_CROSS_CORRELATION) {
@@ -322,7 +328,8 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
   if (rc) return rc;
   vwgpu_prof_scope ps(ctx, "bm_zones");
   const dim3 grd((unsigned)tiles.size()), blk(ZTHREADS);
-#define VW_ZN(C, K) hipLaunchKernelGGL((bm_zones_kernel<C, K>), grd, blk, lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, dt, sxc, pa, pb, out)
+#define VW_ZN(C, K) do { if (f32_sums) hipLaunchKernelGGL((bm_zones_kernel<C, K, float>), grd, blk, lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, dt, sxc, pa, pb, out); \
+                         else hipLaunchKernelGGL((bm_zones_kernel<C, K, double>), grd, blk, lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, dt, sxc, pa, pb, out); } while (0)
 #define VW_ZN_K(C) do { switch (kx == ky ? kx : 0) { case 3: VW_ZN(C, 3); break; case 5: VW_ZN(C, 5); break; case 7: VW_ZN(C, 7); break; \
                                                      case 9: VW_ZN(C, 9); break; case 11: VW_ZN(C, 11); break; case 13: VW_ZN(C, 13); break; \
                                                      default: VW_ZN(C, 0); break; } } while (0)

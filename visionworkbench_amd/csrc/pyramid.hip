@@ -580,7 +580,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
 
   // Class of every level: when the box sums of a level could round, its zones are matched in the reference's own
   // summation order (bm_exact.hip); integer imagery and most float imagery are order free and take the tile kernels.
-  std::vector<char> exact_level(L + 1, 0);
+  std::vector<char> exact_level(L + 1, 0), f32_level(L + 1, 0);      // f32_level: the window sums are exact in float32 as well (bm_zones.hip)
   if (!use_sgm) {
     int* d_cells = A.take<int>(4 * (size_t)(L + 1));
     if (!d_cells) return fail_mem();
@@ -595,8 +595,10 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     }
     VWGPU_HIP(ctx, hipMemcpyAsync(cells.data(), d_cells, cells.size() * sizeof(int), hipMemcpyDeviceToHost, st));
     VWGPU_HIP(ctx, hipStreamSynchronize(st));
-    for (int i = 0; i <= L; ++i)
+    for (int i = 0; i <= L; ++i) {
       exact_level[i] = !vwgpu_sums_order_free(P->cost_type, kx, ky, cells[4 * i], cells[4 * i + 1], cells[4 * i + 2]);
+      f32_level[i] = vwgpu_sums_bits(P->cost_type, kx, ky, cells[4 * i], cells[4 * i + 1], cells[4 * i + 2]) <= 24;      // (byte imagery under SAD)
+    }
   }
 
   // level loop
@@ -759,12 +761,12 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
       }
       if (lr_active && rl_pixels) { if ((rc = vwgpu_arena_reserve(ctx, &ctx->zrl, rl_pixels * 12))) return rc; }
       if (exact) rc = vwgpu_launch_bm_exact(ctx, P->cost_type, Lv.p, Lv.w, Lv.h, Lv.w, Rv.p, Rv.w, Rv.h, Rv.w, kx, ky, t1.data(), (int)t1.size(), disp);
-      else rc = vwgpu_launch_bm_zones(ctx, P->cost_type, Lv.p, Lv.w, Lv.h, Rv.p, Rv.w, Rv.h, kx, ky, t1.data(), (int)t1.size(), disp);
+      else rc = vwgpu_launch_bm_zones(ctx, P->cost_type, Lv.p, Lv.w, Lv.h, Rv.p, Rv.w, Rv.h, kx, ky, t1.data(), (int)t1.size(), disp, f32_level[level]);
       if (rc) return rc;
       if (lr_active) {
         int32_t* rlbuf = static_cast<int32_t*>(ctx->zrl.base);
         if (exact) rc = vwgpu_launch_bm_exact(ctx, P->cost_type, Rv.p, Rv.w, Rv.h, Rv.w, Lv.p, Lv.w, Lv.h, Lv.w, kx, ky, t2.data(), (int)t2.size(), rlbuf);
-        else rc = vwgpu_launch_bm_zones(ctx, P->cost_type, Rv.p, Rv.w, Rv.h, Lv.p, Lv.w, Lv.h, kx, ky, t2.data(), (int)t2.size(), rlbuf);
+        else rc = vwgpu_launch_bm_zones(ctx, P->cost_type, Rv.p, Rv.w, Rv.h, Lv.p, Lv.w, Lv.h, kx, ky, t2.data(), (int)t2.size(), rlbuf, f32_level[level]);
         if (rc) return rc;
         if ((rc = vwgpu_launch_zone_lr(ctx, t3.data(), (int)t3.size(), disp, rlbuf, P->consistency_threshold, lr_diff, lr_stride))) return rc;
       }

@@ -158,6 +158,7 @@ int vwgpu_launch_bm_corr_u16(vwgpu_ctx* ctx, int cost_type, const float* left, i
 struct vwgpu_zone_task;
 bool vwgpu_bm_exact_supported(int sx, int sy);
 bool vwgpu_sums_order_free(int cost_type, int kx, int ky, int lo, int hi, int nonfinite);
+int vwgpu_sums_bits(int cost_type, int kx, int ky, int lo, int hi, int nonfinite);      // <= 53: any order in float64; <= 24: in float32 too
 int vwgpu_float_grain(vwgpu_ctx* ctx, const float* a, int aw, int ah, ptrdiff_t as, const float* b, int bw, int bh, ptrdiff_t bs,
                       int* lo, int* hi, int* nonfinite);
 void vwgpu_launch_float_grain(vwgpu_ctx* ctx, int n, const float* const* img, const int* w, const int* h, const ptrdiff_t* stride, int* const* d_cells);
@@ -214,7 +215,7 @@ struct vwgpu_zone_task {
 };
 bool vwgpu_bm_zones_supported(int kx, int ky);
 int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
-                          int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out);
+                          int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out, int f32_sums = 0);   // f32_sums: vwgpu_sums_bits <= 24 for BOTH images
 // lr tasks: ax = pixel offset of the zone's R->L image, (bx, by) = its size, (sx, sy) = the zone's origin in the diff image
 int vwgpu_launch_zone_lr(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, int32_t* l2r, const int32_t* r2l, float thr,
                          float* diff2, ptrdiff_t dstride);
