@@ -1178,18 +1178,23 @@ __device__ __forceinline__ void wave_shl1_keep(unsigned& dst, unsigned src) {
 //   ACC_STORE   plain store: the first direction of a call initialises the volume (no memset);
 //   ACC_RMW     load (fetched a chunk ahead, like the costs) + v_pk_add_u16 + store: race-free when the launch holds ONE direction,
 //               because then every pixel lies on exactly one line.  u16 wrap-around per element, as the reference's `+=`;
+//   ACC_RMW_WTA ACC_RMW for the LAST direction of a call: the pixel's sums are final in the step's registers, so the winner is taken there — a
+//               unique minimum writes the disparity, a tie marks the pixel for wta_kernel (the smoothing loop of the reference) — instead of a
+//               ninth pass over the volume (wta_uniform_kernel: 0.52 of the 6.9 ms at 2048^2 x 129);
 //   ACC_NONE    timing experiments only.
 // No load of the step loop sits under a condition: a lane outside the pixel's vector reads lane 0's bytes, and the fetch pointers
 // stop advancing at the last pixel of the line — with conditional loads the compiler falls back to s_waitcnt vmcnt(0) in front
 // of every chunk, i.e. no prefetch at all (measured: 770 clk per step).
-enum { ACC_ATOMIC = 1, ACC_STORE = 2, ACC_NONE = 3, ACC_RMW = 4 };
+enum { ACC_ATOMIC = 1, ACC_STORE = 2, ACC_NONE = 3, ACC_RMW = 4, ACC_RMW_WTA = 5 };
 #ifndef VWGPU_PATH_KC
 #define VWGPU_PATH_KC 8
 #endif
 template <int EPT, int ACC, int KC>
 __global__ void __launch_bounds__(64)
 path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
-                        const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2) {
+                        const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2,
+                        int32_t* __restrict__ disp = nullptr, uint8_t* __restrict__ todo = nullptr, int* __restrict__ any_todo = nullptr) {
+  constexpr bool RMW = (ACC == ACC_RMW || ACC == ACC_RMW_WTA);
   constexpr int NW = CostWords<EPT>::N;
   const int num_disp = g.num_dx;                                                     // num_dy == 1
   const int npairs = (num_disp + 1) / 2;
@@ -1228,11 +1233,16 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
     r[e] = dead[e];                                      // no predecessor: r = 0 in the live elements (see above)
   }
   const bool in = tid * EPT + EPT <= q32;               // the lane's dwords / cost bytes lie inside the pixel's vector
+  bool live0[EPT], live1[EPT];                          // ACC_RMW_WTA: the halves of the lane's pairs that are disparities of the search
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) { live0[e] = 2 * (tid * EPT + e) < num_disp; live1[e] = 2 * (tid * EPT + e) + 1 < num_disp; }
+  bool flagged = false;
   int last_val = 0;
   unsigned min_prior = 0;
   // uniform (scalar) running pointers + a 32-bit lane offset for the loads; a per-lane pointer with a per-lane stride for the stores
   const long long delta = (long long)dr * g.ocols + dc;
   const long long pbase = (long long)r0 * g.ocols + c0;
+  long long pcur = pbase;                               // ACC_RMW_WTA: the pixel of the current step
   const unsigned loff_c = in ? (unsigned)(tid * EPT * 2) : 0u, loff_a = in ? (unsigned)(tid * EPT) : 0u;
   const uint8_t* cfetch = cost + pbase * stride;                    // cost vector of the next step to fetch
   const long long cstep = delta * stride;
@@ -1295,7 +1305,32 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
     } else if constexpr (ACC != ACC_NONE) {
       unsigned o[EPT];
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) o[e] = ACC == ACC_RMW ? as_u32(as_us2(aw[e]) + as_us2(r[e])) : r[e];
+      for (int e = 0; e < EPT; ++e) o[e] = RMW ? as_u32(as_us2(aw[e]) + as_us2(r[e])) : r[e];
+      if constexpr (ACC == ACC_RMW_WTA) {
+        // keys (value << 16 | index) of the lane's live elements; the wave minimum is the winner, ties on its value go to wta_kernel
+        unsigned k = 0xffffffffu;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const unsigned j2 = (unsigned)(tid * EPT + e) * 2u;
+          const unsigned k0 = live0[e] ? ((o[e] << 16) | j2) : 0xffffffffu, k1 = live1[e] ? ((o[e] & 0xffff0000u) | (j2 + 1u)) : 0xffffffffu;
+          k = min(k, min(k0, k1));
+        }
+        const unsigned key = wave_min_u32_fused(k), mv = key >> 16;
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+          cnt += __popcll(__ballot(live0[e] && (o[e] & 0xffffu) == mv)) + __popcll(__ballot(live1[e] && (o[e] >> 16) == mv));
+        if (tid == 0) {
+          if (cnt > 1) { todo[pcur] = 1; }
+          else {
+            todo[pcur] = 0;
+            int32_t* w3 = disp + pcur * 3;
+            w3[0] = (int)(key & 0xffffu) + g.min_dx; w3[1] = g.min_dy; w3[2] = 0x7fffffff;
+          }
+        }
+        flagged |= cnt > 1;
+        pcur += delta;
+      }
       if (in) {                                                      // (a shared dump slot for the other lanes: 8.5 ms instead of 5)
         if constexpr (EPT == 2) *reinterpret_cast<uint2*>(astore) = make_uint2(o[0], o[1]);
         else if constexpr (EPT == 4) *reinterpret_cast<uint4*>(astore) = make_uint4(o[0], o[1], o[2], o[3]);
@@ -1313,7 +1348,7 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
       load_cost_words<EPT>(cfetch + loff_c, true, buf[k]);
-      if constexpr (ACC == ACC_RMW) {
+      if constexpr (RMW) {
         const unsigned* a = afetch + loff_a;
         if constexpr (EPT == 2) { const uint2 v = *reinterpret_cast<const uint2*>(a); abuf[k][0] = v.x; abuf[k][1] = v.y; }
         else if constexpr (EPT == 4) { const uint4 v = *reinterpret_cast<const uint4*>(a); abuf[k][0] = v.x; abuf[k][1] = v.y; abuf[k][2] = v.z; abuf[k][3] = v.w; }
@@ -1350,6 +1385,9 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
     fetch(cb, ab);
     steps(ca, aa, ch * KC, std::true_type());
     steps(cb, ab, (ch + 1) * KC, std::true_type());
+  }
+  if constexpr (ACC == ACC_RMW_WTA) {
+    if (flagged && tid == 0) atomicOr(any_todo, 1);
   }
 }
 
@@ -2596,6 +2634,10 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   uint16_t* accum2 = sweep_nw ? reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->sgm_main.base) + 3 * guard + vwgpu_align_up((size_t)main_buf, 256) + vol_bytes) : nullptr;
   // one direction per launch, plain store / read-modify-write
   const bool dir_paths = uniform && g.num_dy == 1 && !P->use_mgm;      // the first direction initialises the volume
+  // the last direction of that schedule also takes the winners (ACC_RMW_WTA)
+  int* const wta_flag = reinterpret_cast<int*>(mm + 6);
+  const bool wta_in_paths = dir_paths && num_disp <= 256;
+  bool wta_done = false;
   if (!dir_paths && !P->use_mgm) VWGPU_HIP(ctx, hipMemsetAsync(accum, 0, (size_t)main_buf * 2, st));      // (MGM: mgm_sum_kernel stores)
   if (block_cost) {
     // fill_costs_block (SGM.cc:1711-1738).  Exact n / count for every n the sums can reach: multiply-high by 2^32 / count + 1.
@@ -2794,6 +2836,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       if (pe == 3) pe = 4;                                            // a lane's pairs must not straddle the end of the vector (stride % 8 == 0: 4 divides stride / 2)
       // dirs[]: 0 T->B, 1 B->T, 2 L->R, 3 R->L, 4 TL->BR, 5 TR->BL, 6 BL->TR, 7 BR->TL
       const int order[8] = {2, 3, 0, 1, 4, 5, 6, 7};
+      if (wta_in_paths) VWGPU_HIP(ctx, hipMemsetAsync(wta_flag, 0, sizeof(int), st));
       for (int q = 0; q < 8; ++q) {
         const Dir& d = dirs[order[q]];
         DirSet S;
@@ -2803,11 +2846,14 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
         const int nlines = d.n_first + d.n_second;
         S.line0[1] = nlines;
         if (nlines <= 0) continue;
-        const int acc = q == 0 ? ACC_STORE : ACC_RMW;
+        // the last direction takes the winners on the way (every pixel lies on exactly one of its lines)
+        const int acc = q == 0 ? ACC_STORE : ((q == 7 && wta_in_paths) ? ACC_RMW_WTA : ACC_RMW);
 #define VWGPU_PATH_DIR1(E, A) hipLaunchKernelGGL((path_uniform_reg_kernel<E, A, VWGPU_PATH_KC>), dim3(nlines), dim3(64), 0, st, g, S, ustride, l8, lw, \
-                                 min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2)
-#define VWGPU_PATH_DIR(E) do { if (acc == ACC_STORE) VWGPU_PATH_DIR1(E, ACC_STORE); else VWGPU_PATH_DIR1(E, ACC_RMW); } while (0)
+                                 min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2, out_disp, full_search, wta_flag)
+#define VWGPU_PATH_DIR(E) do { if (acc == ACC_STORE) VWGPU_PATH_DIR1(E, ACC_STORE); else if (acc == ACC_RMW_WTA) VWGPU_PATH_DIR1(E, ACC_RMW_WTA); \
+                               else VWGPU_PATH_DIR1(E, ACC_RMW); } while (0)
         switch (pe) { case 1: VWGPU_PATH_DIR(1); break; case 2: VWGPU_PATH_DIR(2); break; default: VWGPU_PATH_DIR(4); break; }
+        if (acc == ACC_RMW_WTA) wta_done = true;
 #undef VWGPU_PATH_DIR
 #undef VWGPU_PATH_DIR1
       }
@@ -2855,7 +2901,9 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     const size_t lds = (size_t)4 * 2 * num_disp * sizeof(uint16_t);
     const uint8_t* todo = nullptr;
     const int* any_todo = nullptr;
-    if (uniform && g.num_dy == 1 && num_disp <= 256) {      // unique minima straight from the packed vectors; ties go to the general kernel
+    if (wta_done) {                                         // the last direction took the unique minima; ties go to the general kernel
+      todo = full_search; any_todo = wta_flag;
+    } else if (uniform && g.num_dy == 1 && num_disp <= 256) {      // unique minima straight from the packed vectors; ties go to the general kernel
       int* flag = reinterpret_cast<int*>(mm + 6);
       VWGPU_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int), st));
       hipLaunchKernelGGL(wta_uniform_kernel, dim3((unsigned)((npix + 4 * WTAU_PPW - 1) / (4 * WTAU_PPW))), dim3(256), 0, st, npix, (int)num_disp, ustride,
