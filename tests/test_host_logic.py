@@ -2,6 +2,7 @@
 generator, argument validation (status codes + messages before any device work), and the ctypes struct layouts.  Runs in the
 CPU suite; the zone scheduler and the taps are compared with the oracle's restatement of the reference."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -162,3 +163,16 @@ def test_mgm_front_schedule_respects_the_tasks_of_the_reference(W, H):
                 q = (c + dx, r + dy)
                 assert q in front_of and front_of[q] == f - 1, (name, (c, r), q)
                 assert position[q] < position[(c, r)], (name, (c, r), q)
+
+
+def test_python_constants_match_the_header():
+    """The option / path / error numbers of visionworkbench_amd.core are the enumerators of include/vwgpu.h."""
+    import re
+    from visionworkbench_amd import core
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "vwgpu.h")).read()
+    enums = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(VWGPU_(?:OPT|PATH)_[A-Z0-9_]+)\s*=\s*(-?\d+)", hdr)}
+    assert len([k for k in enums if k.startswith("VWGPU_OPT_")]) >= 10 and len([k for k in enums if k.startswith("VWGPU_PATH_")]) >= 7
+    for name, value in enums.items():
+        py = name[len("VWGPU_"):]
+        assert hasattr(core, py), "visionworkbench_amd.core lacks %s" % py
+        assert getattr(core, py) == value, (name, value, getattr(core, py))
