@@ -20,6 +20,10 @@ for rep in range(3):
     search = BBox2i.from_corners((-64, -1), (64, 1))
     stereo.pyramid_correlate(Lg, Rc, None, None, 2, 1.4, search, (7, 7), 0, consistency_threshold=2, filter_half_kernel=5,
                              max_pyramid_levels=5, bbox=BBox2i(1024, 1024, 1024, 1024))          # BM pyramid tile, LoG prefilter
+    stereo.pyramid_correlate(Lg, Rc, None, None, 2, 1.4, search, (11, 11), 2, consistency_threshold=2, filter_half_kernel=5,
+                             max_pyramid_levels=5, bbox=BBox2i(1024, 1024, 1024, 1024))          # the correlate tool's defaults: LoG + NCC 11x11 (exact-order kernels)
+    stereo.pyramid_correlate(Lg, Rc, None, None, 0, 0.0, search, (7, 7), 0, consistency_threshold=2, filter_half_kernel=5,
+                             max_pyramid_levels=5, bbox=BBox2i(1024, 1024, 1024, 1024))          # integer imagery, SAD (float32 window sums)
     stereo.pyramid_correlate(Lg, Rc, None, None, 0, 0.0, search, (7, 7), 3, consistency_threshold=2, filter_half_kernel=5,
                              max_pyramid_levels=5, algorithm=1, bbox=BBox2i(1024, 1024, 1024, 1024))   # SGM pyramid tile
     stereo.calc_disparity_sgm(3, Lg[:2048, :2048].contiguous(), Rg[:2048, :2048 + 128].contiguous(), BBox2i(0, 0, 2048, 2048), (128, 0), (7, 7),
