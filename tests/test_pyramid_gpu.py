@@ -315,3 +315,44 @@ def test_large_and_oblong_kernels(vw, oracle, k):
                 g = vw.pyramid_correlate(left, right, None, None, pf, pfw, BBox2i.from_corners(s[:2], s[2:]), k, cost, 0, 0.0, 2, 0, 3, levels)
                 o = oracle.pyramid_correlate(left, right, None, None, pf, pfw, s, k, cost, 0, 0.0, 2, 3, levels)
                 assert np.array_equal(g, o), (k, cost, pf, levels)
+
+
+def test_concurrent_tile_threads_return_the_single_thread_result():
+    """The reference pulls tiles with a thread pool (ImageIO.h:228-251): four host threads, a context and a stream each, the correlate tool's
+    defaults (LoG + NCC: the exact-order kernels, their tables, flags and scratch arenas) and integer SAD — every tile, every time, the bits of
+    the single-threaded run."""
+    import threading
+    import torch
+    from visionworkbench_amd import core, stereo, synth
+    from visionworkbench_amd.core import BBox2i
+    W, T = 1536, 512
+    L, R, _ = synth.stereo_pair(W, W, 129, 1)
+    Lg, Rg = torch.from_numpy(L).cuda(), torch.from_numpy(R[:, 64:64 + W].copy()).cuda()
+    tiles = [(x, y) for y in range(0, W, T) for x in range(0, W, T)]
+    for pf, cost, k in [(2, 2, 11), (0, 0, 7)]:
+        run = lambda c, x, y: stereo.pyramid_correlate(Lg, Rg, None, None, pf, 1.4 if pf else 0.0, BBox2i.from_corners((-64, -1), (64, 1)), (k, k), cost,
+                                                       consistency_threshold=2, filter_half_kernel=5, max_pyramid_levels=5, bbox=BBox2i(x, y, T, T), ctx=c)
+        ref_ctx = core.Context(0)
+        want = {t: run(ref_ctx, *t).cpu().numpy() for t in tiles}
+        ref_ctx.close()
+        todo = list(tiles) * 3
+        lock = threading.Lock()
+        bad = []
+        ctxs = [core.Context(0) for _ in range(4)]
+        streams = [torch.cuda.Stream() for _ in range(4)]
+        def work(c, st):
+            with torch.cuda.stream(st):
+                while True:
+                    with lock:
+                        if not todo:
+                            return
+                        t = todo.pop()
+                    got = run(c, *t).cpu().numpy()
+                    if not np.array_equal(got, want[t]):
+                        with lock:
+                            bad.append(t)
+        th = [threading.Thread(target=work, args=(c, st)) for c, st in zip(ctxs, streams)]
+        for t in th: t.start()
+        for t in th: t.join()
+        for c in ctxs: c.close()
+        assert not bad, (pf, cost, k, bad)
