@@ -980,7 +980,6 @@ float_grain_kernel(GrainJobs jobs) {
   const ptrdiff_t stride = (ptrdiff_t)jobs.stride[j];
   int lo = INT_MAX, hi = INT_MIN, bad = 0;
   const int cols_per_row = (w + 255) / 256;                     // column chunks of 256 pixels
-  const long long nchunks = (long long)cols_per_row * h;
   auto take = [&](unsigned u) __attribute__((always_inline)) {
     const int e = (int)((u >> 23) & 0xffu);
     unsigned m = u & 0x7fffffu;
@@ -993,19 +992,22 @@ float_grain_kernel(GrainJobs jobs) {
     lo = min(lo, base + (__ffs((int)m) - 1));
     hi = max(hi, base + (31 - __clz((int)m)));
   };
-  // eight loads in flight per thread (out-of-range chunks read pixel 0 of the image, which is harmless to count twice)
-  for (long long c0 = blockIdx.x; c0 < nchunks; c0 += 8LL * gridDim.x) {
-    unsigned u[8];
+  // A workgroup walks rows blockIdx.x, blockIdx.x + gridDim.x, ...; eight 256-pixel chunks of a row are in flight per thread (out-of-range
+  // chunks read pixel 0 of the row, which is harmless to count twice).  (Flat chunk indices needed a 64-bit division per request: the kernel
+  // was bound by those — 84 us for two 4096^2 images.)
+  for (int y = blockIdx.x; y < h; y += gridDim.x) {
+    const float* row = img + (ptrdiff_t)y * stride;
+    for (int xc = 0; xc < cols_per_row; xc += 8) {
+      unsigned u[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const long long c = c0 + (long long)k * gridDim.x;
-      const int y = c < nchunks ? (int)(c / cols_per_row) : 0;
-      int x = c < nchunks ? (int)(c % cols_per_row) * 256 + (int)threadIdx.x : 0;
-      if (x >= w) x = 0;
-      u[k] = __float_as_uint(img[(ptrdiff_t)y * stride + x]);
+      for (int k = 0; k < 8; ++k) {
+        int x = (xc + k) * 256 + (int)threadIdx.x;
+        if (x >= w) x = 0;
+        u[k] = __float_as_uint(row[x]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) take(u[k]);
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) take(u[k]);
   }
   for (int o = 32; o > 0; o >>= 1) {
     lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); bad |= __shfl_xor(bad, o);
@@ -1015,9 +1017,17 @@ float_grain_kernel(GrainJobs jobs) {
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int i = 1; i < 4; ++i) { lo = min(lo, part[i][0]); hi = max(hi, part[i][1]); bad |= part[i][2]; }
+    // Same-address atomics serialise at the L2 (thousands of workgroups x 3 of them were most of this kernel's time): a workgroup whose
+    // values cannot move the cell — it only ever moves one way, so a stale read errs on the side of an atomic — skips them.
     int* cell = jobs.cell[j];
-    if (lo != INT_MAX) { atomicMin(&cell[0], lo); atomicMax(&cell[1], hi); }
-    if (bad) atomicOr(&cell[2], bad);
+    const int c0 = __hip_atomic_load(&cell[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int c1 = __hip_atomic_load(&cell[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int c2 = __hip_atomic_load(&cell[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lo != INT_MAX) {
+      if (lo < c0) atomicMin(&cell[0], lo);
+      if (hi > c1) atomicMax(&cell[1], hi);
+    }
+    if (bad & ~c2) atomicOr(&cell[2], bad);
   }
 }
 
