@@ -359,7 +359,7 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right, with
                     stereo.pyramid_correlate(lt, rc, None, None, pf, pw, search, (kk, kk), cost, consistency_threshold=2, filter_half_kernel=5,
                                              max_pyramid_levels=5, bbox=tiles[i], ctx=ctxs[t])
         best = None
-        for rep in range(3):
+        for rep in range(7):                                   # one warm-up pass, then the fastest of six (a pass is 10 - 40 ms: host noise shows)
             torch.cuda.synchronize(lt.device); t0 = time.perf_counter()
             th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
             [x.start() for x in th]; [x.join() for x in th]
