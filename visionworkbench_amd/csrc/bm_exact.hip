@@ -599,12 +599,12 @@ bmx_select_kernel(int kx, const XZone* __restrict__ zones, const int2* __restric
 // ---- pass 2 of the matchers, tiled form (round 3): row chains and selection in ONE kernel, transposed through LDS ----------------
 // The fused kernel above reads the volume once but selects ACROSS the disparity lanes inside every chain step (~300 dependent
 // instructions per step: it is instruction bound, 130 G evaluations/s); the split form is cheap per evaluation but moves the volume three
-// times.  Here one wavefront owns (zone, 2 rows, a group of 32 disparities) and walks the rows in chunks of 32 pixels:
-//   chains   lane <-> (row, disparity): 32 steps of row_sum(x+1) = row_sum(x) + (col_sum(x+kx) - col_sum(x)), every operand of the
+// times.  Here one wavefront owns (zone, 4 rows, a group of 16 disparities) and walks the rows in chunks of 16 pixels:
+//   chains   lane <-> (row, disparity): 16 steps of row_sum(x+1) = row_sum(x) + (col_sum(x+kx) - col_sum(x)), every operand of the
 //            chunk requested up front (Algorithms.h:84,92); every row sum goes to LDS, T[chain][step]; the chain's state is a register
-//   select   lane <-> (row, pixel): the 32 costs of its pixel from LDS (conflict free: consecutive lanes, consecutive words), NCC
+//   select   lane <-> (row, pixel): the 16 costs of its pixel from LDS (conflict free: consecutive lanes, consecutive words), NCC
 //            scaling, the reference's compare chain VERBATIM over the group (Correlation.cc:91-117).
-// A zone of up to 32 disparities is finished by that wavefront.  Wider searches: the groups of a pixel run in parallel (a wavefront that
+// A zone of up to 16 disparities is finished by that wavefront.  Wider searches: the groups of a pixel run in parallel (a wavefront that
 // walked all of them in turn was the critical path of a level: 16 chunks x 7 groups x 9 us for a 512-pixel zone with 216 disparities)
 // and leave (best, worst, index, "saw a NaN") per group; bmx_merge_kernel folds them in index order.  Without NaN costs the chain is a
 // (value, first index) minimum and a maximum, which fold exactly; a pixel with a NaN cost (NCC over an all-zero window: 0 * inf) is
@@ -771,7 +771,7 @@ bmx_rowsel_kernel(int kx, const XZone* __restrict__ zones, const int4* __restric
 }
 
 // Folds the group records of bmx_rowsel_kernel in index order.  items[i] = {zone, y0 | x-chunk << 20} as bmx_select_kernel's (zones of
-// more than 32 disparities only).  A NaN in any record (or in the carried state) flags the zone: the fused kernel recomputes it.
+// more than 16 disparities only).  A NaN in any record (or in the carried state) flags the zone: the fused kernel recomputes it.
 template <int COST, bool CARRY>
 __global__ void __launch_bounds__(256)
 bmx_merge_kernel(const XZone* __restrict__ zones, const int2* __restrict__ items, int y_begin, int y_end, const XCarry* __restrict__ part,
@@ -1051,8 +1051,8 @@ struct Tables {
   std::vector<int2> row_items;
   std::vector<int2> sel_items;      // bmx_select_kernel: {zone, first row | x-chunk << 20}
   std::vector<int4> rs_items;       // bmx_rowsum_kernel: {zone, first row, chunk, -}
-  std::vector<int4> tl_items;       // bmx_rowsel_kernel: {zone, first row of a pair, group of 32 disparities, -}
-  std::vector<int2> mg_items;       // bmx_merge_kernel: {zone, first row | x-chunk << 20}, zones of more than 32 disparities
+  std::vector<int4> tl_items;       // bmx_rowsel_kernel: {zone, first of 4 rows, group of 16 disparities, -}
+  std::vector<int2> mg_items;       // bmx_merge_kernel: {zone, first row | x-chunk << 20}, zones of more than 16 disparities
   size_t part_records = 0;          // group records of those zones
   size_t vol_doubles = 0;
 };
@@ -1246,7 +1246,7 @@ void launch_pair(vwgpu_ctx* ctx, const char* n1, const char* n2, const float* A,
           }
 #undef VWGPU_RS
         }
-        if (t.mg_items.empty()) return;                  // no zone searches more than 32 disparities: every result is final
+        if (t.mg_items.empty()) return;                  // no zone searches more than 16 disparities: every result is final
         vwgpu_prof_scope ps(ctx, "bmx_merge");
         const dim3 mgrd((unsigned)(t.mg_items.size() / 4));
         if (carry) hipLaunchKernelGGL((bmx_merge_kernel<COST, true>), mgrd, blk, 0, ctx->stream, d.zones, d.mg, y_begin, y_end, part, out, carry, d.flags);
