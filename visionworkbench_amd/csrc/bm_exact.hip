@@ -22,16 +22,19 @@
 //                            coalesced volume reads, written back in place — nothing but the two additions of a chain step;
 //   pass 2b bmx_select_kernel  lane <-> pixel, no chain: NCC scaling and the reference's compare chain verbatim over the
 //                            disparities in index order (Correlation.cc:91-117; a NaN cost needs no special case).
-//   (Until round 3 pass 2 was ONE kernel that also scaled and reduced across the disparity lanes inside every chain step.)
+//   (Until round 3 pass 2 was ONE kernel that also scaled and reduced across the disparity lanes inside every chain step: it is still
+//   here, bmx_row_fused_kernel.  The DEFAULT for zones narrower than 1024 pixels — every zone of a pyramid tile — is a third form,
+//   bmx_rowsel_kernel + bmx_merge_kernel: row chains and selection in one kernel, transposed through LDS; 2a / 2b serve whole rasters.)
 //
 // A "zone" is one calc_disparity problem: a SearchParam zone of a pyramid level (CorrelationView.cc:596-700; crops
 // with clamped coordinates = the ConstantEdgeExtension crops the reference hands over) or a whole raster.  NCC side
 // cars (CostFunctions.h:214-219: 1.0 / fast_box_sum(square(crop))) go through the same two passes with one
 // "disparity" per zone crop; vwgpu_fast_box_sum exports that form (Algorithms.h:41-43).
 //
-// HBM traffic: 8 B written + 8 B read per (pixel, disparity) for the column sums, the same again for the row sums — the price of the reference's order; the volume of a
-// whole-raster call is processed in row bands (column-chain state carried between bands) so that it stays within a
-// scratch budget.  Roofline: HBM bound by design (32 B per evaluation); it is the correctness path, not the headline.
+// HBM traffic: 8 B written + 8 B read per (pixel, disparity) for the column sums (+ 1.5 B of group records in the tiled form; the same again
+// for the row sums in the split form) — the price of the reference's order; the volume of a whole-raster call is processed in row bands
+// (column-chain state carried between bands) so that it stays within a scratch budget.  Roofline: HBM bound by the byte count (16 - 32 B per
+// evaluation), in fact bound by the wave-cycles of latency-bound wavefronts; it is the correctness path, not the headline.
 #include <algorithm>
 #include <climits>
 #include <cmath>
