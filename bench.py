@@ -110,6 +110,16 @@ class HaloFetcher:
         """owned = rows row_strip(rank, world, rows_total) of the image (contiguous, on the GPU) -> (window, first row)."""
         if self.world == 1:
             return owned, 0
+        # The request is agreed on BEFORE anyone enters an exchange (ADVICE r3): if the ranks were handed different images or halos,
+        # every rank learns it from the same all-reduced pair and raises — none is left waiting for a neighbour that took another way.
+        hdr = self.torch.tensor([int(rows_total), int(above), int(below), int(owned.shape[1]) * owned.element_size()],
+                                dtype=self.torch.int64, device=self.dev)
+        lo, hi = hdr.clone(), hdr.clone()
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
+        if not bool((lo == hi).all().item()):
+            raise ValueError("HaloFetcher.fetch: the ranks disagree about (rows, halo above, halo below, bytes per row): min %s max %s"
+                             % (lo.tolist(), hi.tolist()))
         if self.comm is not None:
             win = first = None
             try:

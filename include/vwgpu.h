@@ -61,7 +61,10 @@ typedef enum vwgpu_path {
   VWGPU_PATH_DOT_U8 = 3,       /* integer-valued inputs in [0,255]: SSD / NCC on v_dot4_u32_u8            */
   VWGPU_PATH_EXACT_ORDER = 4,  /* inputs whose box sums round: the reference's serial summation order     */
   VWGPU_PATH_SAD_U16 = 5,      /* integer-valued inputs in [0,65535]: SAD on v_sad_u16 pixel pairs        */
-  VWGPU_PATH_DOT_U16 = 6       /* integer-valued inputs in [0,4095]: SSD / NCC on v_dot2_u32_u16          */
+  VWGPU_PATH_DOT_U16 = 6,      /* integer-valued inputs in [0,4095]: SSD / NCC on v_dot2_u32_u16          */
+  VWGPU_PATH_REFUSED = 7       /* vwgpu_last_path only: a packed kernel queued WITHOUT waiting for its verdict
+                                  (vwgpu_force_path, VWGPU_OPT_DEFER_EXACTNESS) met input outside its domain; that
+                                  call produced NO result — repeat it with automatic dispatch                   */
 } vwgpu_path;
 
 /* ---- context ------------------------------------------------------------------------------------- */
@@ -89,9 +92,12 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *       the packed kernels, other inputs the float64 kernel when every box-sum partial is exactly representable (then any
  *       summation order returns the reference's bits), and the reference's own serial summation order otherwise
  *       (VWGPU_PATH_EXACT_ORDER).  The classes are measured on the device; by default (0) the call waits for them, so that
- *       the result is bit-exact for any input.  1 = pipelined callers that queue many calls without a host round trip: the
- *       call never waits — packed kernels first, the float64 kernel behind a device flag — and vwgpu_last_path() reports
- *       afterwards which family produced the result (bench.py asserts VWGPU_PATH_SAD_U8).
+ *       the result is bit-exact for any input.  1 = pipelined callers that queue many calls on byte imagery without a host
+ *       round trip: where a packed-u8 kernel exists for the configuration the call is that ONE launch and never waits.  The
+ *       option cannot change a result, it can only withhold one: input outside the kernel's domain raises a device flag,
+ *       nothing else is computed, vwgpu_last_path() answers VWGPU_PATH_REFUSED for that call (its output buffer is
+ *       undefined) and the caller repeats it with the option off.  bench.py asserts VWGPU_PATH_SAD_U8 after its timed steps.
+ *       Configurations without a packed-u8 kernel behave as with 0.
  *   VWGPU_OPT_DEVICE_COUNT (read only): HIP devices visible to the process.
  *   The remaining options never change a result (they choose between kernels / schedules that return identical bits, and are
  *   what tests and tools use to reach every variant); values outside the stated range are rejected with VWGPU_ERR_ARGUMENT:
@@ -114,11 +120,15 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *   VWGPU_OPT_CORR_MFMA        SSD / NCC on byte imagery: 0 = the v_dot4_u32_u8 kernels (default), 1 = the products on the matrix cores
  *       (v_mfma_i32_16x16x32_i8; same results, measured slower: 1.13 - 1.20 ms against 0.69 - 0.94 ms at 4096^2 x 129).
  *   VWGPU_OPT_MGM_SWEEP        use_mgm on full-range one-row searches (<= 256 disparities): 0 = the eight passes as four concurrent
- *       sweeps (default), 1 = one launch per front (the round-2 schedule), 2 .. 15 = the sweeps with that many lines per workgroup. */
+ *       sweeps (default), 1 = one launch per front (the round-2 schedule), 2 .. 15 = the sweeps with that many lines per workgroup.
+ *   VWGPU_OPT_HOST_RING_KB     size in KiB (16 .. 1048576, default 16384) of the pinned host ring through which zone / work-item tables
+ *       reach the device; pieces larger than a quarter of it are copied from pageable memory and waited for.  A small ring makes the
+ *       library wait for the device more often, nothing else (tests use it to wrap the ring on small rasters).
+ *   VWGPU_OPT_HOST_RING_WRAPS  (read only) how often the ring cursor has changed halves so far. */
 typedef enum vwgpu_option {
   VWGPU_OPT_DEFER_EXACTNESS = 1, VWGPU_OPT_DEVICE_COUNT = 2, VWGPU_OPT_SAD_GROUPS = 3, VWGPU_OPT_EXACT_SCRATCH_MB = 4,
   VWGPU_OPT_TRACE = 5, VWGPU_OPT_SGM_SWEEP = 6, VWGPU_OPT_EXACT_LDS = 7, VWGPU_OPT_MGM_SWEEP = 8, VWGPU_OPT_EXACT_SPLIT = 9,
-  VWGPU_OPT_CORR_MFMA = 10
+  VWGPU_OPT_CORR_MFMA = 10, VWGPU_OPT_HOST_RING_KB = 11, VWGPU_OPT_HOST_RING_WRAPS = 12
 } vwgpu_option;
 int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value);
 int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value);
@@ -150,9 +160,10 @@ int vwgpu_profile_read(vwgpu_ctx* ctx, const char** names, float* ms, int cap);
  *
  * Semantics kept from the reference: raster order dy-outer/dx-inner, strict comparison, first wins;
  * a pixel is invalid iff its best and worst cost are equal (so search_volume (1,1) is all-invalid).
- * Bit-exact against the reference for any float input: inputs whose box sums could round take the kernels that
- * follow fast_box_sum's serial summation order (VWGPU_PATH_EXACT_ORDER; up to 512 disparities per call, beyond that
- * the float64 kernel with tile-local sums serves them).  See VWGPU_OPT_DEFER_EXACTNESS for the asynchronous variant. */
+ * Bit-exact against the reference for any float input and any search volume: inputs whose box sums could round take the
+ * kernels that follow fast_box_sum's serial summation order (VWGPU_PATH_EXACT_ORDER; more than 512 disparities are swept in
+ * groups of 512 with the compare-chain state carried from group to group).  See VWGPU_OPT_DEFER_EXACTNESS for the
+ * asynchronous variant (which either returns the same bits or reports that it returned none). */
 int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
                              const float* d_left, int lw, int lh, ptrdiff_t lstride,
                              const float* d_right, int rw, int rh, ptrdiff_t rstride,
@@ -421,8 +432,14 @@ int vwgpu_comm_destroy(vwgpu_comm* comm);
 /* rows owned by `rank` and the rows its window spans (clipped to the image); pure host arithmetic, no context */
 int vwgpu_halo_plan(int rank, int world, int rows_total, int halo_above, int halo_below, int* owned_a, int* owned_b, int* need_a,
                     int* need_b);
+/* The verdict of the request check below from a table of gathered headers {rows_total, halo_above, halo_below, bytes per row} x world:
+ * 1 = every rank asked for the same image and halos, 0 = not (rank_a / rank_b: the first differing pair).  Pure host arithmetic. */
+int vwgpu_halo_headers_agree(const long long* headers, int world, int* rank_a, int* rank_b);
 /* d_owned: the rank's rows (owned_b - owned_a) x cols, contiguous; d_window: (need_b - need_a) x cols, receives own rows + halos;
- * asynchronous on the context's stream; every rank of the communicator must make the call.  *first_row = need_a. */
+ * every rank of the communicator must make the call.  The requests of all ranks are compared first — one 32-byte all-gather over
+ * the communicator and one host round trip — and either EVERY rank enters the data exchange or every rank returns
+ * VWGPU_ERR_ARGUMENT; the exchange itself (one send / recv per neighbour that owns needed rows) is queued on the context's stream
+ * and the call returns without waiting for it.  *first_row = need_a. */
 int vwgpu_fetch_strip_window_dev(vwgpu_ctx* ctx, vwgpu_comm* comm, const void* d_owned, int cols, int elem_bytes, int rows_total,
                                  int halo_above, int halo_below, void* d_window, int* first_row);
 

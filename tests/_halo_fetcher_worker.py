@@ -29,6 +29,11 @@ win, first = f.fetch(torch.from_numpy(img[a:b].copy()), 101, 9, 4)
 na, nb = max(0, a - 9), min(101, b + 4)
 assert first == na and np.array_equal(win.numpy(), img[na:nb])
 assert f.agree(True) and not f.agree(rank == 0)                                  # one dissenting rank decides for all
+try:                                                                             # ranks that were handed different halos: EVERY rank raises,
+    f.fetch(torch.from_numpy(img[a:b].copy()), 101, 9 if rank == 0 else 8, 4)    # before anyone posts a send or a receive
+    raise SystemExit("a disagreeing request went through on rank %d" % rank)
+except ValueError as e:
+    assert "disagree" in str(e)
 f.close()
 dist.barrier()
 print("halo fetcher ok")

@@ -100,8 +100,12 @@ def test_halo_fetcher_decisions_are_collective():
     agree on the torch.distributed exchange and return the right rows)."""
     script = os.path.join(ROOT, "tests", "_halo_fetcher_worker.py")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    import socket
+    with socket.socket() as sock:                   # a free port, as bench.py's own launcher picks one (a fixed one can collide on a shared host)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29613", script], capture_output=True, text=True, timeout=600, env=env)
+                        "--master-port", str(port), script], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     assert p.stdout.count("halo fetcher ok") == 2, p.stdout
 

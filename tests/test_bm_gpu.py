@@ -181,18 +181,42 @@ def test_non_integer_input_falls_back_to_generic(ctx, oracle):
         g2, p = _gpu(ctx, ABS, l2, r2, (5, 5), (9, 1))
         assert p in (core.PATH_GENERIC_F64, core.PATH_EXACT_ORDER) or (bad == 256.0 and p == core.PATH_SAD_U16)
         assert np.array_equal(g2, oracle.calc_disparity(ABS, l2, r2, (5, 5), (9, 1)))
-    # pipelined callers (VWGPU_OPT_DEFER_EXACTNESS): no host round trip, the flag is read by vwgpu_last_path afterwards
-    ctx.set_option(core.OPT_DEFER_EXACTNESS, 1)
+
+
+def test_deferred_mode_returns_the_reference_bits_or_says_it_returned_none(ctx, oracle):
+    """VWGPU_OPT_DEFER_EXACTNESS = 1 (pipelined callers, ONE launch per call, no host round trip): byte imagery is served by the
+    packed kernel; anything else — a stray non-integer, float textures, LoG-filtered imagery, pixels over 14 decades (classes whose
+    box sums round, src/vw/Stereo/Algorithms.h:43-129) — must never be answered by tile-local sums: vwgpu_last_path() says
+    PATH_REFUSED and the same call with the option off returns the oracle's bits."""
+    from visionworkbench_amd import filters
+    l8, r8, _ = synth.stereo_pair(200, 60, 17)
+    rng = np.random.default_rng(77)
+    decades = (rng.random((60, 216)).astype(np.float32) * np.float32(10.0) ** rng.integers(-7, 8, (60, 216)).astype(np.float32)).astype(np.float32)
+    cases = [("bytes", l8, r8, core.PATH_SAD_U8)]
+    l2 = l8.copy(); l2[3, 5] = 0.5
+    cases.append(("one half-integer pixel", l2, r8, core.PATH_REFUSED))
+    cases.append(("LoG filtered", filters.prefilter_image(l8, 2, 1.4, ctx=ctx), filters.prefilter_image(r8, 2, 1.4, ctx=ctx), core.PATH_REFUSED))
+    cases.append(("14 decades", decades[:, :200].copy(), decades, core.PATH_REFUSED))
+    cases.append(("16-bit integers", l8 * 200.0, r8 * 200.0, core.PATH_REFUSED))
+    for name, left, right, want_path in cases:
+        want = oracle.calc_disparity(ABS, left, right, (7, 7), (17, 1))
+        ctx.set_option(core.OPT_DEFER_EXACTNESS, 1)
+        try:
+            got, p = _gpu(ctx, ABS, left, right, (7, 7), (17, 1))
+        finally:
+            ctx.set_option(core.OPT_DEFER_EXACTNESS, 0)
+        assert p == want_path, (name, p)
+        if p != core.PATH_REFUSED:
+            assert np.array_equal(got, want), name
+        got, p = _gpu(ctx, ABS, left, right, (7, 7), (17, 1))          # the repeat the header prescribes
+        assert p != core.PATH_REFUSED and np.array_equal(got, want), (name, p)
+    # a forced packed path on data outside its domain reports the same way
+    ctx.force_path(core.PATH_SAD_U8)
     try:
-        l2, r2, _ = synth.stereo_pair(64, 24, 9)
-        _, p = _gpu(ctx, ABS, l2, r2, (5, 5), (9, 1))
-        assert p == core.PATH_SAD_U8
-        l2[3, 5] = 0.5
-        g2, p = _gpu(ctx, ABS, l2, r2, (5, 5), (9, 1))
-        assert p == core.PATH_GENERIC_F64
-        assert np.array_equal(g2, oracle.calc_disparity(ABS, l2, r2, (5, 5), (9, 1)))
+        _, p = _gpu(ctx, ABS, l2, r8, (7, 7), (17, 1), path=core.PATH_SAD_U8)
     finally:
-        ctx.set_option(core.OPT_DEFER_EXACTNESS, 0)
+        ctx.force_path(core.PATH_NONE)
+    assert p == core.PATH_REFUSED
 
 
 def test_strided_region_crop(ctx, oracle, sad_variant):

@@ -1,5 +1,6 @@
-"""Parity evidence AT the sizes BASELINE.json names (configs 2-5), through the C ABI, against the CPU oracle.
+"""Parity evidence AT the sizes BASELINE.json names (configs 1-5), through the C ABI, against the CPU oracle.
 
+  config 1  512^2, 5x5 SAD, 33x1              BASELINE configs[0] literally (the reference's own CPU-runnable case)
   config 2  4096^2, 7x7 SAD, 129x1            the whole 4090^2 disparity image, bit for bit
   config 3  4096^2, 11x11 NCC + parabola      the whole 4086^2 integer image bit for bit, then the whole sub-pixel image
   config 4  16384-wide census-SGM strips      SGM is global along every scan line (no crop reproduces a strip), so the
@@ -33,6 +34,20 @@ def ctx():
 @pytest.fixture(scope="module")
 def pair4096():
     return synth.stereo_pair(4096, 4096, 129, 1)
+
+
+def test_config1_literal(ctx, oracle):
+    """BASELINE.json configs[0]: 512 x 512 synthetic pair, 5x5 SAD, +-16 px (33 x 1) — every pixel against the single-threaded oracle
+    (best_of_search_convolution on the whole raster, src/vw/Stereo/Correlation.cc:33-137), device and host entry points."""
+    import torch
+    left, right, truth = synth.stereo_pair(512, 512, 33, 1)
+    want = oracle.calc_disparity(0, left, right, (5, 5), (33, 1))
+    got = stereo.calc_disparity(0, torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda(), vwa.bounding_box(left), (33, 1), (5, 5), ctx=ctx)
+    torch.cuda.synchronize()
+    assert ctx.last_path() == core.PATH_SAD_U8
+    assert want.shape == (508, 508, 3) and np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(stereo.calc_disparity(0, left, right, vwa.bounding_box(left), (33, 1), (5, 5), ctx=ctx), want)
+    assert (want[..., 2] == core.VALID_I32).mean() > 0.999 and (want[..., 0] == truth[:508, :508]).mean() > 0.9
 
 
 def test_config2_full_image_identical(ctx, oracle, pair4096):

@@ -224,6 +224,28 @@ def test_search_volume_beyond_65535(ctx, oracle):
     assert np.array_equal(got, want)
 
 
+def test_table_ring_wraps_while_the_device_is_behind(oracle):
+    """The disparity-group loop queues one table upload per 512 disparities and never synchronises: with a 64 KiB pinned ring
+    the 40 groups of this call change ring halves a dozen times while earlier uploads are still pending — the ring must wait for
+    the copies that read a half before it rewrites it.  Same result as with the default ring, which never wraps here."""
+    rng = np.random.default_rng(4242)
+    h, w, search = 40, 70, (255, 80)                # 20 400 disparities = 40 groups; NCC: two table sets per group
+    left, right = _pair(rng, h, w, search[0], search[1], (101, 33), decades=10)
+    want = oracle.calc_disparity(NCC, left, right, (5, 5), search)
+    c = vwa.Context(0)
+    try:
+        c.set_option(core.OPT_HOST_RING_KB, 64)
+        got = stereo.calc_disparity(NCC, left, right, vwa.bounding_box(left), search, (5, 5), ctx=c)
+        assert c.last_path() == core.PATH_EXACT_ORDER
+        wraps = c.get_option(core.OPT_HOST_RING_WRAPS)
+        assert np.array_equal(got, want), int((got != want).any(-1).sum())
+        assert wraps >= 4, wraps
+        c.set_option(core.OPT_HOST_RING_KB, 16384)                       # (re-allocates the ring)
+        assert np.array_equal(stereo.calc_disparity(NCC, left, right, vwa.bounding_box(left), search, (5, 5), ctx=c), want)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("cost", [ABS, SQ, NCC])
 @pytest.mark.parametrize("h,w,kernel,search,shift", [
     (38, 38, (7, 7), (5, 5), (2, 3)),          # the typical level-0 zone of a pyramid tile: 32 x 32 outputs, 5 x 5 disparities

@@ -102,6 +102,31 @@ def test_halo_plan_matches_the_python_partition():
         partition.halo_plan(2, 2, 10, 0, 0)
 
 
+def test_halo_request_check_is_collective():
+    """csrc/halo.hip gathers the request header of EVERY rank (one all-gather) and each rank judges the same table
+    (vwgpu_halo_headers_agree), so the ranks cannot disagree about entering the data exchange.  Three ranks, rank 0 differs:
+    with the round-3 pairwise check rank 0 and rank 1 failed while rank 2 (whose header matched rank 1's) went on to wait for a
+    rank 1 that had already returned; with the gathered table every rank — rank 2 included — reaches the same "no"."""
+    import ctypes
+    from visionworkbench_amd import _lib
+    lib = _lib.load()
+
+    def verdict(headers):
+        flat = [v for h in headers for v in h]
+        arr = (ctypes.c_longlong * len(flat))(*flat)
+        a, b = ctypes.c_int(-1), ctypes.c_int(-1)
+        return lib.vwgpu_halo_headers_agree(arr, len(headers), ctypes.byref(a), ctypes.byref(b)), a.value, b.value
+
+    same = (4096, 3, 3, 4096 * 4)
+    assert verdict([same, same, same])[0] == 1
+    assert verdict([same])[0] == 1
+    world = [(4096, 0, 3, 4096 * 4), same, same]                  # rank 0 passed another halo
+    # what each rank sees after the all-gather is the same table: every rank returns the same verdict and names the same pair
+    per_rank = [verdict(list(world)) for _rank in range(3)]
+    assert per_rank[0] == per_rank[1] == per_rank[2] == (0, 0, 1)
+    assert verdict([same, same, (4096, 3, 3, 4096 * 8)]) == (0, 0, 2)     # bytes per row differ on the last rank
+
+
 # The eight SmoothPathAccumTask passes as the reference writes them (src/vw/Stereo/SGMAssist.h:911-1236), re-typed here from its text:
 # (path predecessor, second predecessor, border test of the task, raster loops of the task).  Index = the engine's direction number.
 _MGM_TASKS = [

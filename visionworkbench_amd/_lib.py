@@ -26,7 +26,7 @@ SYMBOLS = [
     "vwgpu_disparity_blob_filter_dev", "vwgpu_disparity_blob_filter",
     "vwgpu_pyramid_correlate_dev", "vwgpu_pyramid_correlate",
     "vwgpu_calc_disparity_sgm_dev", "vwgpu_calc_disparity_sgm", "vwgpu_mgm_front_count", "vwgpu_mgm_front_pixel",
-    "vwgpu_comm_unique_id", "vwgpu_comm_create", "vwgpu_comm_destroy", "vwgpu_halo_plan", "vwgpu_fetch_strip_window_dev",
+    "vwgpu_comm_unique_id", "vwgpu_comm_create", "vwgpu_comm_destroy", "vwgpu_halo_plan", "vwgpu_halo_headers_agree", "vwgpu_fetch_strip_window_dev",
 ]
 
 
@@ -110,6 +110,7 @@ def load():
     lib.vwgpu_comm_create.argtypes = [P, P, I, I, ctypes.POINTER(P)]
     lib.vwgpu_comm_destroy.argtypes = [P]
     lib.vwgpu_halo_plan.argtypes = [I, I, I, I, I, IP, IP, IP, IP]
+    lib.vwgpu_halo_headers_agree.argtypes = [ctypes.POINTER(ctypes.c_longlong), I, IP, IP]
     lib.vwgpu_mgm_front_count.argtypes = [I, I, I]
     lib.vwgpu_mgm_front_pixel.argtypes = [I, I, I, I, I, P, P, IP]
     lib.vwgpu_fetch_strip_window_dev.argtypes = [P, P, P, I, I, I, I, I, P, IP]

@@ -37,8 +37,10 @@
 //             one 8/16-byte LDS read per row.
 //   validity  invalid <=> all sx*sy costs equal.  Instead of tracking the worst cost everywhere, four cost pairs are
 //             compared during the first sweep (one bit per lane and row: "some pixel of the row had equal costs in every
-//             probe"); only workgroups with a surviving row (never on textured data, always on flat data) do work in
-//             the second launch (FIX = true), which recomputes packed best / worst and invalidates.
+//             probe"); only a workgroup with a surviving row (never on textured data, always on flat data) runs the
+//             second sweep — in the same launch, after its epilogue — which recomputes packed best / worst costs and
+//             invalidates.  (Rounds 1-3 ran that sweep as a second launch behind a per-tile flag: 6.4 us per call for
+//             starting and retiring a grid that had nothing to do.)
 //   output    a lane's 4 pixels are 12 consecutive dwords, i.e. 48-byte strided stores; each wave transposes its row
 //             through LDS and writes three coalesced 1 KiB pieces instead.
 //   grids     1-D grid, tile = XCD-banded raster order; grids too small for two waves per SIMD run the two-wave-group
@@ -107,21 +109,21 @@ __device__ __forceinline__ void divmod_small(int idx, int d, float inv, int& quo
   quo = qq; rem = rr;
 }
 
-// FIX = false: the matcher (first sweep: keys + equality probe; raises need_fix[workgroup] if some pixel may be
-//               invalid).  FIX = true: the validity fix-up launched right after it; workgroups whose need_fix
-//               entry is clear return at once, the others recompute packed best/worst costs and invalidate
-//               pixels with best == worst (Correlation.cc:121-133).
+// One launch: the matcher sweep (keys + equality probe), the epilogue, and — only in workgroups where some pixel may be
+// invalid — the validity sweep: packed best / worst costs recomputed, pixels with best == worst invalidated
+// (Correlation.cc:121-133).
 // SPLIT: for grids too small to give every SIMD two waves (a 1/8 row strip of the 4096^2 case is 256 eight-row tiles):
 //        the workgroup has TWO wave groups on the same tile.  Both hold the LEFT windows; wave w of group 0 and wave w
 //        of group 1 cover the same pixels and sit on the same SIMD, draw the step items of a phase from a shared LDS
 //        counter (the arbiter favours the older wave, so a fixed split would leave one group waiting), and the partial
-//        keys are merged through LDS at the end of the tile — a key minimum is order independent.
-template <int KX, int KY, int TY, bool FIX, bool SPLIT>
+//        keys are merged through LDS at the end of the tile — a key minimum is order independent.  (The validity sweep
+//        is not split: group 0 walks its items alone, group 1 only helps to build the word groups.)
+template <int KX, int KY, int TY, bool SPLIT>
 __global__ void __launch_bounds__((SPLIT ? 2 : 1) * (KX <= 8 ? 256 : 128), (SPLIT ? 1 : (TY <= 8 && KX <= 8 ? 3 : 2)))
 bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
                  const float* __restrict__ R, ptrdiff_t rs, int rcw, int rch,
                  int sx, int sy, int ne, int32_t* __restrict__ out, ptrdiff_t os, int ow, int oh,
-                 int* __restrict__ flag_set, int* __restrict__ flag_clear, int* __restrict__ need_fix,
+                 int* __restrict__ flag_set, int* __restrict__ flag_clear,
                  int gxt, int ntiles) {
   typedef Cfg<KX, KY, TY> C;
   constexpr int NW = C::NW, EW = C::EW, NR = C::NR;
@@ -130,7 +132,6 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   const int bpitch = ne + NW + 1;                   // dwords per row of the RIGHT u8 base tile
   u32* base = lds + (size_t)NR * ne * EW;           // [NR][bpitch]
   u32* item_ctr = base + (size_t)NR * bpitch;       // SPLIT: one work item counter per wave pair
-  static_assert(!(FIX && SPLIT), "the fix-up sweep is not split");
 
   constexpr int PT = C::THREADS;                    // threads that map to pixels
   constexpr int NT = SPLIT ? 2 * PT : PT;           // threads of the workgroup
@@ -149,11 +150,7 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   const int y0 = (wg / gxt) * TY;
   const int q = x0 + 4 * ltid;                      // first of the lane's 4 output pixels
   u32 bad_acc = 0;                                  // non-zero: some input pixel is not an integer in [0,255]
-  if (FIX) {
-    if (need_fix[wg] == 0) return;                  // workgroup-uniform
-  } else if (wg == 0 && tid == 0) {
-    *flag_clear = 0;                                // the NEXT call's flag
-  }
+  if (wg == 0 && tid == 0) *flag_clear = 0;         // the NEXT call's flag
 
   // ---- LEFT: float tile -> u8 in LDS (borrowing the entry array) -> per-lane register windows ----
   // Both tiles are staged before anything else is live in registers (the LEFT tile borrows the entry array).
@@ -171,13 +168,9 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   }
 
   u32 K[TY][4];                                     // best key per pixel: cost << 16 | disparity index
-  u32 MN[TY][2], MX[TY][2];                         // packed best / worst cost (fix-up kernel only)
+  u32 MN[TY][2], MX[TY][2];                         // packed best / worst cost (validity sweep only)
 #pragma unroll
-  for (int y = 0; y < TY; ++y) {
-    K[y][0] = K[y][1] = K[y][2] = K[y][3] = 0xffffffffu;
-    MN[y][0] = MN[y][1] = 0xffffffffu;
-    MX[y][0] = MX[y][1] = 0u;
-  }
+  for (int y = 0; y < TY; ++y) K[y][0] = K[y][1] = K[y][2] = K[y][3] = 0xffffffffu;
   // bit y: "in every probed step pair, some in-image pixel of this lane's row y had two equal costs".  A superset of
   // the rows that hold an invalid pixel (all costs equal), kept per row rather than per pixel: one min tree and one
   // bit per row is all the bookkeeping a probe costs.  On noise one pixel pair is equal with p ~ 7e-4, so a row of 4
@@ -190,11 +183,13 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   typedef std::true_type T;
   typedef std::false_type F;
 
-  {
-    constexpr bool MAXSWEEP = FIX;
+  // MAXSWEEP = false: the matcher sweep (keys K, equality probe).  MAXSWEEP = true: the validity sweep (packed MN / MX).
+  auto sweep = [&](auto max_tag) __attribute__((always_inline)) {
+    constexpr bool MAXSWEEP = decltype(max_tag)::value;
     for (int dy = 0; dy < sy; ++dy) {
       __syncthreads();                              // everyone is done with the previous base tile / windows
-      if (dy > 0) stage_u8_rows<NR>(R, rs, rcw, rch, x0, y0 + dy, bpitch, bpitch, base, tid, NT, bad_acc);
+      // (the validity sweep finds the base tile of the last dy: with more than one search row it stages row 0 again)
+      if (dy > 0 || (MAXSWEEP && sy > 1)) stage_u8_rows<NR>(R, rs, rcw, rch, x0, y0 + dy, bpitch, bpitch, base, tid, NT, bad_acc);
       for (int t = 0; t < 4; ++t) {
         const int a_last = (sx + 2 - t) >> 2;       // last step with any valid slot
         __syncthreads();                            // base staged / previous phase's readers done
@@ -360,6 +355,7 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
         const int nitems = n1 + npair + n4;
         int seq = 0;
         auto next_item = [&]() __attribute__((always_inline)) -> int {
+          if (MAXSWEEP) return grp == 0 ? seq++ : 0x7fffffff;      // not split: group 1 takes nothing
           if (!SPLIT) return seq++;
           int lane, v = 0;
           asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
@@ -376,20 +372,9 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
         eq_checks += nprobe;
       }
     }
-  }
+  };
+  sweep(F{});
 
-  if (FIX) {
-#pragma unroll
-    for (int y = 0; y < TY; ++y) {
-      const u32 same0 = MN[y][0] ^ MX[y][0], same1 = MN[y][1] ^ MX[y][1];
-      const bool inv[4] = {(same0 & 0xffffu) == 0, (same0 >> 16) == 0, (same1 & 0xffffu) == 0, (same1 >> 16) == 0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        if (inv[s] && y0 + y < oh && q + s < ow)
-          out[((ptrdiff_t)(y0 + y) * os + q + s) * 3 + 2] = 0;   // best == worst (Correlation.cc:121-133)
-    }
-    return;
-  }
   if (bad_acc != 0u) atomicOr(flag_set, 1);
   // ---- SPLIT: merge the two wave groups.  Group 0 finishes rows [0,TY/2), group 1 rows [TY/2,TY): each hands the
   // other its partial keys of the other's rows (and its equality bits) through the entry array, free by now.
@@ -428,7 +413,6 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   for (int y = 0; y < TY; ++y)
     if (y0 + y >= oh || q >= ow || !row_mine(y)) cand &= ~(1u << y);
   const int any = __syncthreads_or(cand != 0u);     // never set on textured imagery; also: the entry array is free now
-  if (tid == 0) need_fix[wg] = any;
 
   // ---- epilogue: decode keys, store {dx, dy, VALID} in the PixelMask<Vector2i> layout ----------------------------
   // A lane owns 4 pixels = 12 consecutive dwords, so direct stores would be 48-byte strided (measured: 80 us of the
@@ -478,14 +462,36 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
       }
     }
   }
+
+  // ---- validity sweep (workgroup-uniform; never taken on textured imagery): the same steps with packed best / worst
+  // costs instead of keys, then best == worst => invalid (Correlation.cc:121-133).  The epilogue's stores above are
+  // complete before the barrier at the head of the sweep, the zeros below land after them.
+  if (!any) return;
+#pragma unroll
+  for (int y = 0; y < TY; ++y) {
+    MN[y][0] = MN[y][1] = 0xffffffffu;
+    MX[y][0] = MX[y][1] = 0u;
+  }
+  sweep(T{});
+  if (grp == 0) {
+#pragma unroll
+    for (int y = 0; y < TY; ++y) {
+      const u32 same0 = MN[y][0] ^ MX[y][0], same1 = MN[y][1] ^ MX[y][1];
+      const bool inv[4] = {(same0 & 0xffffu) == 0, (same0 >> 16) == 0, (same1 & 0xffffu) == 0, (same1 >> 16) == 0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        if (inv[s] && y0 + y < oh && q + s < ow)
+          out[((ptrdiff_t)(y0 + y) * os + q + s) * 3 + 2] = 0;
+    }
+  }
 }
 
 typedef void (*KernelFn)(const float*, ptrdiff_t, int, int, const float*, ptrdiff_t, int, int, int, int, int,
-                         int32_t*, ptrdiff_t, int, int, int*, int*, int*, int, int);
+                         int32_t*, ptrdiff_t, int, int, int*, int*, int, int);
 struct Launch {
   int kx, ky, ty;
   int threads, twb, nr, ew, nw;
-  KernelFn fn, fix_fn;
+  KernelFn fn;
   KernelFn split_fn;         // the two-wave-group matcher for small grids (nullptr: not instantiated for this size)
 };
 
@@ -493,8 +499,8 @@ template <int KX, int KY, int TY, bool WITH_SPLIT = false>
 constexpr Launch make_launch() {
   typedef Cfg<KX, KY, TY> C;
   return Launch{KX, KY, TY, C::THREADS, C::TWB, C::NR, C::EW, C::NW,
-                bm_sad_u8_kernel<KX, KY, TY, false, false>, bm_sad_u8_kernel<KX, KY, TY, true, false>,
-                WITH_SPLIT ? bm_sad_u8_kernel<KX, KY, TY, false, WITH_SPLIT> : nullptr};
+                bm_sad_u8_kernel<KX, KY, TY, false>,
+                WITH_SPLIT ? bm_sad_u8_kernel<KX, KY, TY, WITH_SPLIT> : nullptr};
 }
 
 // Instantiated kernel sizes.  Others fall back to the generic path.
@@ -582,39 +588,21 @@ int vwgpu_launch_bm_sad_u8(vwgpu_ctx* ctx,
 
   // Two alternating device flags: call n raises flags[n&1] on unsuitable input and clears flags[(n+1)&1]
   // for the next call, so no memset launch is needed (stream order makes this race free).
-  int rc = vwgpu_arena_reserve(ctx, &ctx->flags, 256 + (size_t)gx * gy * sizeof(int));
+  int *flag_set = nullptr, *flag_clear = nullptr;
+  int rc = vwgpu_next_flags(ctx, 0, &flag_set, &flag_clear, nullptr);
   if (rc) return rc;
-  int* flags = static_cast<int*>(ctx->flags.base);
-  if (ctx->flags_base_seen != ctx->flags.base) { ctx->flags_init = false; ctx->flags_base_seen = ctx->flags.base; ctx->last_flag = nullptr; }
-  if (!ctx->flags_init) {
-    VWGPU_HIP(ctx, hipMemsetAsync(flags, 0, 256, ctx->stream));
-    ctx->flags_init = true;
-  }
-  int* flag_set = flags + (ctx->flag_parity & 1);
-  int* flag_clear = flags + ((ctx->flag_parity + 1) & 1);
-  ctx->flag_parity ^= 1;
-  int* need_fix = flags + 64;                       // one int per workgroup, written by every matcher launch
   *d_fallback_flag = flag_set;
   const size_t shmem = lds_bytes(*l, sx) + (split ? 64 : 0);   // + the item counters of the split variant
   const KernelFn main_fn = split ? l->split_fn : l->fn;
   const unsigned grid1 = (unsigned)((gx * gy + 7) / 8 * 8);   // one tile per workgroup, see the XCD note in the kernel
-  if (shmem > 64 * 1024) {
+  if (shmem > 64 * 1024)
     VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(main_fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(l->fix_fn),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  }
   {
     vwgpu_prof_scope ps(ctx, "bm_sad_u8");
     hipLaunchKernelGGL(main_fn, dim3(grid1), dim3(split ? 2 * l->threads : l->threads), shmem, ctx->stream,
                        left, ls, lw, lh, right, rs, rcw, rch, sx, sy, ne, out, os, ow, oh,
-                       flag_set, flag_clear, need_fix, gx, gx * gy);
-  }
-  {
-    vwgpu_prof_scope ps(ctx, "bm_sad_u8_validity_fix");
-    hipLaunchKernelGGL(l->fix_fn, dim3(grid1), dim3(l->threads), shmem, ctx->stream,
-                       left, ls, lw, lh, right, rs, rcw, rch, sx, sy, ne, out, os, ow, oh,
-                       flag_set, flag_clear, need_fix, gx, gx * gy);
+                       flag_set, flag_clear, gx, gx * gy);
   }
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;

@@ -31,6 +31,7 @@ struct Rccl {
   int (*CommDestroy)(NcclComm) = nullptr;
   int (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
   int (*Recv)(void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
@@ -51,9 +52,9 @@ Rccl& rccl() {
 #define VW_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.so, name))
     VW_SYM(GetUniqueId, "ncclGetUniqueId"); VW_SYM(CommInitRank, "ncclCommInitRank"); VW_SYM(CommDestroy, "ncclCommDestroy");
     VW_SYM(Send, "ncclSend"); VW_SYM(Recv, "ncclRecv"); VW_SYM(GroupStart, "ncclGroupStart"); VW_SYM(GroupEnd, "ncclGroupEnd");
-    VW_SYM(GetErrorString, "ncclGetErrorString");
+    VW_SYM(GetErrorString, "ncclGetErrorString"); VW_SYM(AllGather, "ncclAllGather");
 #undef VW_SYM
-    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Send && r.Recv && r.GroupStart && r.GroupEnd;
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Send && r.Recv && r.GroupStart && r.GroupEnd && r.AllGather;
   });
   return r;
 }
@@ -82,6 +83,20 @@ int vwgpu_halo_plan(int rank, int world, int rows_total, int halo_above, int hal
   if (need_a) *need_a = std::max(0, a - halo_above);
   if (need_b) *need_b = std::min(rows_total, b + halo_below);
   return VWGPU_OK;
+}
+
+/* The verdict every rank reaches from the SAME table of gathered request headers (4 values per rank: rows_total, halo_above,
+ * halo_below, bytes per row): 1 = all ranks asked for the same image and halos; 0 = they did not, and *rank_a / *rank_b name the
+ * first pair that differs.  Pure host arithmetic (tests/test_host_logic.py drives it with three ranks). */
+int vwgpu_halo_headers_agree(const long long* headers, int world, int* rank_a, int* rank_b) {
+  if (!headers || world < 1) return 0;
+  for (int p = 1; p < world; ++p)
+    if (memcmp(headers + 4 * (size_t)p, headers, 4 * sizeof(long long)) != 0) {
+      if (rank_a) *rank_a = 0;
+      if (rank_b) *rank_b = p;
+      return 0;
+    }
+  return 1;
 }
 
 int vwgpu_comm_unique_id(void* id128) {
@@ -134,8 +149,12 @@ int vwgpu_fetch_strip_window_dev(vwgpu_ctx* ctx, vwgpu_comm* comm, const void* d
   const char* own = static_cast<const char*>(d_owned);
   VWGPU_HIP(ctx, hipSetDevice(ctx->device));
   // Every rank must describe the same image and halos, or the byte counts of a send and its receive differ and a rank waits
-  // for ever.  The request is compared with every neighbour it is about to talk to first: a 32-byte header each way, one
-  // group — ranks whose headers differ fail on BOTH sides, after the exchange of headers has completed.
+  // for ever.  The decision is COLLECTIVE and does not depend on the arguments it checks: every rank contributes its 32-byte
+  // request to one all-gather over the whole communicator (a peer set computed from a rank's own halos differs between ranks that
+  // disagree — rank A posts nothing while rank B waits for it; and a pairwise check lets a third rank, whose header matches B's,
+  // walk into the data exchange with a B that has already returned: round-3 findings).  All ranks then hold the same table, reach
+  // the same verdict (vwgpu_halo_headers_agree) and either all enter the data exchange or all return the error.
+  // (One small host round trip per fetch: the call is synchronous up to here; the data exchange below is queued.)
   if (world > 1) {
     rc = vwgpu_arena_reserve(ctx, &ctx->misc, 4096);
     if (rc) return rc;
@@ -143,29 +162,17 @@ int vwgpu_fetch_strip_window_dev(vwgpu_ctx* ctx, vwgpu_comm* comm, const void* d
     if ((size_t)(4 + 4 * world) * sizeof(long long) > 3072) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "vwgpu_fetch_strip_window_dev: more than 95 ranks");
     const long long mine[4] = {rows_total, halo_above, halo_below, (long long)cols * elem_bytes};
     VWGPU_HIP(ctx, hipMemcpyAsync(hdr, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
-    std::vector<int> peers;
-    for (int p = 0; p < world; ++p) {
-      if (p == rank) continue;
-      int pa, pb, pna, pnb;
-      vwgpu_halo_plan(p, world, rows_total, halo_above, halo_below, &pa, &pb, &pna, &pnb);
-      if (std::max(na, pa) < std::min(nb, pb) || std::max(pna, a) < std::min(pnb, b)) peers.push_back(p);
-    }
-    int hrc = r.GroupStart();
-    for (int p : peers) {
-      if (hrc == 0) hrc = r.Recv(hdr + 4 + 4 * p, sizeof mine, 0, p, comm->comm, ctx->stream);
-      if (hrc == 0) hrc = r.Send(hdr, sizeof mine, 0, p, comm->comm, ctx->stream);
-    }
-    const int herc = r.GroupEnd();
-    if (hrc == 0) hrc = herc;
-    if (hrc != 0) return vwgpu_fail(ctx, VWGPU_ERR_HIP, "RCCL halo header exchange failed: %s", r.GetErrorString ? r.GetErrorString(hrc) : "?");
+    const int hrc = r.AllGather(hdr, hdr + 4, sizeof mine, /*ncclChar*/ 0, comm->comm, ctx->stream);
+    if (hrc != 0) return vwgpu_fail(ctx, VWGPU_ERR_HIP, "RCCL halo header all-gather failed: %s", r.GetErrorString ? r.GetErrorString(hrc) : "?");
     std::vector<long long> got((size_t)4 * world);
     VWGPU_HIP(ctx, hipMemcpyAsync(got.data(), hdr + 4, got.size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int p : peers)
-      if (memcmp(&got[(size_t)4 * p], mine, sizeof mine) != 0)
-        return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "vwgpu_fetch_strip_window_dev: rank %d asked for (rows %lld, halos %lld / %lld, %lld bytes per row), rank %d for "
-                          "(%d, %d / %d, %lld): every rank must pass the same image and halos", p, got[(size_t)4 * p], got[(size_t)4 * p + 1],
-                          got[(size_t)4 * p + 2], got[(size_t)4 * p + 3], rank, rows_total, halo_above, halo_below, (long long)cols * elem_bytes);
+    int ra = 0, rb = 0;
+    if (!vwgpu_halo_headers_agree(got.data(), world, &ra, &rb))
+      return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "vwgpu_fetch_strip_window_dev: rank %d asked for (rows %lld, halos %lld / %lld, %lld bytes per row), rank %d for "
+                        "(%lld, %lld / %lld, %lld): every rank must pass the same image and halos (this is rank %d; no rank exchanged data)",
+                        rb, got[(size_t)4 * rb], got[(size_t)4 * rb + 1], got[(size_t)4 * rb + 2], got[(size_t)4 * rb + 3],
+                        ra, got[(size_t)4 * ra], got[(size_t)4 * ra + 1], got[(size_t)4 * ra + 2], got[(size_t)4 * ra + 3], rank);
   }
   // my own rows
   if (b > a) VWGPU_HIP(ctx, hipMemcpyAsync(win + (size_t)(a - na) * rowb, own, (size_t)(b - a) * rowb, hipMemcpyDeviceToDevice, ctx->stream));

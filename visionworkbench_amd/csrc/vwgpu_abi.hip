@@ -47,19 +47,37 @@ int vwgpu_arena_reserve(vwgpu_ctx* ctx, vwgpu_arena* a, size_t bytes) {
   return VWGPU_OK;
 }
 
+// The pinned ring is two halves.  Pieces are handed out in address order; when the cursor leaves a half, an event recorded on the
+// stream marks "every copy that reads this half has been queued before here", and the cursor enters the other half only after the
+// event recorded when IT was last left has completed.  So a piece is never rewritten while a copy that reads it is still pending,
+// however far the host runs ahead of the device (the disparity-group loop of bm_exact.hip queues hundreds of table uploads
+// without a synchronisation; before this the ring relied on callers synchronising "at least once per pyramid level").
 void* vwgpu_host_ring(vwgpu_ctx* ctx, size_t bytes) {
-  constexpr size_t CAP = 16u << 20;
+  const size_t CAP = (size_t)ctx->host_ring_kb << 10;
   if (!ctx->host_ring) {
     void* p = nullptr;
     if (hipHostMalloc(&p, CAP, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    ctx->host_ring = static_cast<char*>(p); ctx->host_cap = CAP; ctx->host_pos = 0;
+    ctx->host_ring = static_cast<char*>(p); ctx->host_cap = CAP; ctx->host_pos = 0; ctx->host_half = 0;
+    ctx->ring_event_set[0] = ctx->ring_event_set[1] = false;
+    for (int i = 0; i < 2; ++i)
+      if (!ctx->ring_event[i] && hipEventCreateWithFlags(&ctx->ring_event[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   }
   bytes = vwgpu_align_up(bytes, 256);
-  if (bytes > ctx->host_cap / 4) return nullptr;
-  if (ctx->host_pos + bytes > ctx->host_cap) ctx->host_pos = 0;
-  void* out = ctx->host_ring + ctx->host_pos;
-  ctx->host_pos += bytes;
-  return out;
+  if (bytes == 0 || bytes > ctx->host_cap / 4) return nullptr;
+  const size_t half = ctx->host_cap / 2;
+  size_t pos = ctx->host_pos;
+  if (pos < half && pos + bytes > half) pos = half;           // a piece never straddles the halves
+  if (pos + bytes > ctx->host_cap) pos = 0;
+  const int h = pos >= half ? 1 : 0;
+  if (h != ctx->host_half) {
+    if (hipEventRecord(ctx->ring_event[ctx->host_half], ctx->stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    ctx->ring_event_set[ctx->host_half] = true;
+    if (ctx->ring_event_set[h] && hipEventSynchronize(ctx->ring_event[h]) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    ctx->host_half = h;
+    ++ctx->ring_wraps;
+  }
+  ctx->host_pos = pos + bytes;
+  return ctx->host_ring + pos;
 }
 
 vwgpu_prof_scope::vwgpu_prof_scope(vwgpu_ctx* c, const char* name) : ctx(c) {
@@ -145,6 +163,7 @@ void vwgpu_destroy(vwgpu_ctx* ctx) {
   if (ctx->zrl.base) (void)hipFree(ctx->zrl.base);
   if (ctx->zext.base) (void)hipFree(ctx->zext.base);
   if (ctx->host_ring) (void)hipHostFree(ctx->host_ring);
+  for (int i = 0; i < 2; ++i) if (ctx->ring_event[i]) (void)hipEventDestroy(ctx->ring_event[i]);
   if (ctx->sgm.base) (void)hipFree(ctx->sgm.base);
   if (ctx->sgm_main.base) (void)hipFree(ctx->sgm_main.base);
   if (ctx->sgm_bnd.base) (void)hipFree(ctx->sgm_bnd.base);
@@ -206,6 +225,15 @@ int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value) {
   if (option == VWGPU_OPT_MGM_SWEEP && value >= 0 && value <= 15) { ctx->mgm_sweep = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_EXACT_SPLIT && value >= 0 && value <= 3) { ctx->exact_split = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_CORR_MFMA && (value == 0 || value == 1)) { ctx->corr_mfma = value; return VWGPU_OK; }
+  if (option == VWGPU_OPT_HOST_RING_KB && value >= 16 && value <= (1 << 20)) {
+    if (value != ctx->host_ring_kb && ctx->host_ring) {            // pending copies read the old ring
+      VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipHostFree(ctx->host_ring);
+      ctx->host_ring = nullptr; ctx->host_cap = ctx->host_pos = 0;
+    }
+    ctx->host_ring_kb = value;
+    return VWGPU_OK;
+  }
   return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "vwgpu_set_option: unknown or read-only option %d, or value %d out of range", option, value);
 }
 
@@ -227,6 +255,8 @@ int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value) {
   if (option == VWGPU_OPT_MGM_SWEEP) { *value = ctx->mgm_sweep; return VWGPU_OK; }
   if (option == VWGPU_OPT_EXACT_SPLIT) { *value = ctx->exact_split; return VWGPU_OK; }
   if (option == VWGPU_OPT_CORR_MFMA) { *value = ctx->corr_mfma; return VWGPU_OK; }
+  if (option == VWGPU_OPT_HOST_RING_KB) { *value = ctx->host_ring_kb; return VWGPU_OK; }
+  if (option == VWGPU_OPT_HOST_RING_WRAPS) { *value = (int)(ctx->ring_wraps & 0x7fffffff); return VWGPU_OK; }
   return VWGPU_ERR_ARGUMENT;
 }
 
@@ -234,11 +264,12 @@ int vwgpu_last_path(const vwgpu_ctx* cctx) {
   vwgpu_ctx* ctx = const_cast<vwgpu_ctx*>(cctx);
   if (!ctx) return VWGPU_PATH_NONE;
   if ((ctx->last_path == VWGPU_PATH_SAD_U8 || ctx->last_path == VWGPU_PATH_DOT_U8 || ctx->last_path == VWGPU_PATH_SAD_U16 || ctx->last_path == VWGPU_PATH_DOT_U16) && ctx->last_flag) {
-    // The fast path reports non-representable input through a device flag; the generic kernel then ran.
+    // A packed kernel was queued without waiting for its verdict (a forced path, or VWGPU_OPT_DEFER_EXACTNESS): it reports input
+    // outside its domain through a device flag, and NOTHING recomputed the image then — the call has no result.
     int flag = 0;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return VWGPU_PATH_NONE;
     if (hipMemcpy(&flag, ctx->last_flag, sizeof flag, hipMemcpyDeviceToHost) != hipSuccess) return VWGPU_PATH_NONE;
-    return flag ? VWGPU_PATH_GENERIC_F64 : ctx->last_path;
+    return flag ? VWGPU_PATH_REFUSED : ctx->last_path;
   }
   return ctx->last_path;
 }
@@ -405,10 +436,10 @@ int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
   ctx->last_path = sad_ok ? VWGPU_PATH_SAD_U8 : VWGPU_PATH_DOT_U8;
   ctx->last_flag = d_flag;
   if (ctx->forced_path != VWGPU_PATH_NONE) return VWGPU_OK;       // caller inspects vwgpu_last_path()
-  if (ctx->defer_exact)
-    // pipelined callers: no host round trip; the float64 kernel recomputes the image if the flag is up (its blocks
-    // return at once otherwise) and vwgpu_last_path() tells afterwards
-    return vwgpu_launch_bm_generic_flag(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, d_flag);
+  // Pipelined callers: ONE launch and no host round trip.  Nothing runs behind the flag (rounds 1-3 queued the float64 tile kernel
+  // there, which is not the reference's arithmetic on data whose sums round): input outside the packed kernel's domain leaves
+  // the call without a result, vwgpu_last_path() says VWGPU_PATH_REFUSED, and the caller repeats it with the option off.
+  if (ctx->defer_exact) return VWGPU_OK;
   int flag = 0;
   VWGPU_HIP(ctx, hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
   VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -57,11 +57,15 @@ struct vwgpu_ctx {
   vwgpu_arena xtab;      // exact-order path: zone / work-item tables of one call
   vwgpu_arena xcarry;    // exact-order path: compare-chain state per pixel between the disparity groups of a zone with > 512 disparities
   // Pinned host memory for the small tables that cross PCIe inside a call (zone / tile tables up, leaf extents down): a copy from or
-  // to pageable memory is staged by the runtime and blocks the calling thread.  A ring: vwgpu_host_ring() hands out the next
-  // piece and wraps around; a piece stays untouched for at least `cap / 2` bytes of later requests (callers synchronise the
-  // stream at least once per pyramid level, long before that).
+  // to pageable memory is staged by the runtime and blocks the calling thread.  A ring of two halves: vwgpu_host_ring() hands out the
+  // next piece and waits, before it re-enters a half, for the event that marks the last copy queued from that half.
   char* host_ring = nullptr;
   size_t host_cap = 0, host_pos = 0;
+  int host_half = 0;
+  hipEvent_t ring_event[2] = {nullptr, nullptr};
+  bool ring_event_set[2] = {false, false};
+  int host_ring_kb = 16384;   // VWGPU_OPT_HOST_RING_KB
+  unsigned long long ring_wraps = 0;   // half crossings so far (VWGPU_OPT_HOST_RING_WRAPS, read only: tests)
   struct LeafRects { int w, h; size_t n; void* d_rects; };
   std::vector<LeafRects> leaf_rects;   // zone scheduler: device copies of the leaf boxes of the level sizes seen so far
   bool measure_first = false; // the previous calc_disparity was refused by the packed-u8 kernels: measure the input class first

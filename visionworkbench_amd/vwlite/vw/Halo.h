@@ -60,9 +60,9 @@ public:
   int rank() const { return m_rank; }
   int world() const { return m_world; }
   /// d_owned: this rank's rows, contiguous, in device memory; d_window: room for (need_b - need_a) x cols elements.
-  /// Every rank calls this with the SAME (cols, elem_bytes, rows_total, halo_above, halo_below); the engine compares the requests
-  /// of neighbouring ranks before moving rows and throws ArgumentErr on both sides of a mismatch.
-  /// Asynchronous on the calling thread's context stream; returns the first row of the window.
+  /// Every rank calls this with the SAME (cols, elem_bytes, rows_total, halo_above, halo_below); the engine gathers the requests of
+  /// ALL ranks first (one 32-byte all-gather and one host round trip) and throws ArgumentErr on every rank if any two differ — no
+  /// rank moves rows then.  The row exchange itself is queued on the calling thread's context stream; returns the first row of the window.
   int fetch_strip_window(const void* d_owned, int cols, int elem_bytes, int rows_total, int halo_above, int halo_below, void* d_window) {
     int first = 0;
     check(m_ctx, vwgpu_fetch_strip_window_dev(m_ctx, m_comm, d_owned, cols, elem_bytes, rows_total, halo_above, halo_below, d_window, &first));
