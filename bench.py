@@ -698,8 +698,9 @@ def main():
     region = vwa.BBox2i(0, 0, W, r1 - r0 + ky - 1)
     ctx = vwa.Context(local)
     # K steps are queued back to back: the engine must not wait for the input-class flags of each call (a host round trip
-    # per step).  It runs the packed kernels, keeps the float64 kernel behind the device flag, and vwgpu_last_path() says
-    # afterwards which family produced the result — asserted below, together with the result itself.
+    # per step).  With VWGPU_OPT_DEFER_EXACTNESS a step is ONE launch — the packed matcher, validity sweep included — and
+    # vwgpu_last_path() says afterwards whether the kernel accepted the data (PATH_REFUSED: no result) — asserted below,
+    # together with the result itself.
     ctx.set_option(core.OPT_DEFER_EXACTNESS, 1)
 
     def step():
@@ -724,10 +725,11 @@ def main():
         out = step()
     barrier()
     path = ctx.last_path()
+    assert path != core.PATH_REFUSED, "the packed kernel refused the synthetic pair (not byte imagery?)"
 
     # Kernel durations come from HIP events the engine records on its own stream, live inside the timed region — on every
-    # 4th step only: an event pair around each of a step's three launches costs ~10 us of dispatch serialisation per
-    # launch, which would otherwise be charged to `value`.
+    # 4th step only: an event pair around a launch costs ~10 us of dispatch serialisation, which would otherwise be
+    # charged to `value`.
     ctx.profile_reset()
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -28,7 +28,11 @@
 extern "C" {
 #endif
 
-#define VWGPU_ABI_VERSION 1
+/* 2 (round 4): struct vwgpu_sgm_params carries allow_block_cost (appended in round 3 without a bump: a host compiled against
+ *     version 1 passes a struct that is 8 bytes shorter), VWGPU_PATH_REFUSED replaces the silent float64 fallback of
+ *     VWGPU_OPT_DEFER_EXACTNESS, vwgpu_trim, vwgpu_halo_headers_agree, the host-ring options.
+ * A host checks vwgpu_abi_version() == VWGPU_ABI_VERSION once after loading the library (vw::engine does, vw/Engine.h). */
+#define VWGPU_ABI_VERSION 2
 
 typedef struct vwgpu_ctx vwgpu_ctx;
 
@@ -80,8 +84,15 @@ void vwgpu_destroy(vwgpu_ctx* ctx);
 int vwgpu_set_stream(vwgpu_ctx* ctx, void* hip_stream);
 /* Back to the context's own (non-blocking) stream. */
 int vwgpu_reset_stream(vwgpu_ctx* ctx);
-/* Blocks until everything queued on the context's stream is done. */
+/* Blocks until everything queued on the context's stream is done (and releases the scratch blocks the context has outgrown). */
 int vwgpu_synchronize(vwgpu_ctx* ctx);
+/* Memory policy: a context keeps one grow-only scratch arena per purpose (pyramids, SGM volumes, exact-order column sums, ...), sized by
+ * the largest call it has served — steady-state calls do no hipMalloc / hipFree, which would stall every stream of the device.  A long-lived
+ * tile thread therefore holds the high-water mark of every arena until vwgpu_destroy.  vwgpu_trim gives the memory back in between:
+ * it waits for the context's stream, then frees every arena (and the outgrown blocks); the next call allocates what it needs again.
+ * Call it when a thread changes workload (e.g. after the one config-4-sized SGM strip of a session) or before another context needs
+ * the memory; *freed_bytes (optional) receives the amount released. */
+int vwgpu_trim(vwgpu_ctx* ctx, size_t* freed_bytes);
 
 const char* vwgpu_strerror(int status);
 /* Detail text of the last failing call on this context ("" if none). */
@@ -105,7 +116,15 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *       group per tile, 2 = two wave groups per tile.
  *   VWGPU_OPT_EXACT_SCRATCH_MB scratch budget of the exact-order path in MiB (16 .. 65536, default 4096): column-sum volumes
  *       beyond it are swept in row bands / zone groups / disparity groups.
- *   VWGPU_OPT_TRACE            bit 0: host-side timeline of a pyramid tile on stderr, bit 1: the zone shapes of a level.
+ *   VWGPU_OPT_TRACE            bit 0: host-side timeline of a pyramid tile on stderr, bit 1: the zone shapes of a level, bit 2: certification
+ *       statistics of every tile (one host round trip per tile; VWGPU_OPT_CERT_PERMILLE reads the running total).
+ *   VWGPU_OPT_CERTIFY          pyramid levels whose box sums could round (prefiltered imagery, float imagery, deep levels under SSD / NCC): 1
+ *       (default) = the tile-parallel kernels match every zone first and CERTIFY each pixel — best cost ahead of the runner-up by more
+ *       than twice a rigorous bound on the difference between any-order float64 sums and fast_box_sum's serial running sums
+ *       (src/vw/Stereo/Algorithms.h:43-129) — and only zones that hold an uncertified pixel are redone by the exact-order kernels;
+ *       0 = every zone of such a level goes to the exact-order kernels (the round-3 schedule).  Same results either way.
+ *   VWGPU_OPT_ZONE_SXC         horizontal disparities per staged right patch: 0 (default) = 16, n = at most n (1 .. 4096; the LDS budget caps it).
+ *   VWGPU_OPT_CERT_PERMILLE    (read only) per mille of the pixels in certified tiles since VWGPU_OPT_TRACE was last set with bit 2; -1 = none.
  *   VWGPU_OPT_SGM_SWEEP        SGM path aggregation of full-range one-row searches (<= 256 disparities): 0 = one direction per launch
  *       (default: eight passes over the u16 sums, bandwidth bound), 1 = two concurrent fused raster sweeps of four directions each
  *       (a fifth of the HBM traffic, the same sums; slower on MI355X because a sweep is W + 2 H dependent pixel steps), 2 .. 15 = the
@@ -128,7 +147,8 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
 typedef enum vwgpu_option {
   VWGPU_OPT_DEFER_EXACTNESS = 1, VWGPU_OPT_DEVICE_COUNT = 2, VWGPU_OPT_SAD_GROUPS = 3, VWGPU_OPT_EXACT_SCRATCH_MB = 4,
   VWGPU_OPT_TRACE = 5, VWGPU_OPT_SGM_SWEEP = 6, VWGPU_OPT_EXACT_LDS = 7, VWGPU_OPT_MGM_SWEEP = 8, VWGPU_OPT_EXACT_SPLIT = 9,
-  VWGPU_OPT_CORR_MFMA = 10, VWGPU_OPT_HOST_RING_KB = 11, VWGPU_OPT_HOST_RING_WRAPS = 12
+  VWGPU_OPT_CORR_MFMA = 10, VWGPU_OPT_HOST_RING_KB = 11, VWGPU_OPT_HOST_RING_WRAPS = 12, VWGPU_OPT_CERTIFY = 13,
+  VWGPU_OPT_CERT_PERMILLE = 14, VWGPU_OPT_ZONE_SXC = 15
 } vwgpu_option;
 int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value);
 int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value);

@@ -219,6 +219,24 @@ def test_deferred_mode_returns_the_reference_bits_or_says_it_returned_none(ctx, 
     assert p == core.PATH_REFUSED
 
 
+def test_trim_gives_the_arenas_back(oracle):
+    """vwgpu_trim (memory policy in include/vwgpu.h): the scratch arenas go back to the device and the next call simply allocates again."""
+    from visionworkbench_amd import stereo
+    left, right, _ = synth.stereo_pair(300, 90, 17)
+    c = vwa.Context(0)
+    try:
+        want = oracle.calc_disparity(NCC, left, right, (7, 7), (17, 1))
+        assert np.array_equal(stereo.calc_disparity(NCC, left, right, vwa.bounding_box(left), (17, 1), (7, 7), ctx=c), want)
+        freed = c.trim()
+        assert freed >= left.nbytes + right.nbytes          # at least the staging copies of the host-pointer entry
+        assert c.trim() == 0
+        assert np.array_equal(stereo.calc_disparity(NCC, left, right, vwa.bounding_box(left), (17, 1), (7, 7), ctx=c), want)
+        assert np.array_equal(stereo.calc_disparity(ABS, left, right, vwa.bounding_box(left), (17, 1), (7, 7), ctx=c),
+                              oracle.calc_disparity(ABS, left, right, (7, 7), (17, 1)))
+    finally:
+        c.close()
+
+
 def test_strided_region_crop(ctx, oracle, sad_variant):
     """calc_disparity with a left_region inside a larger image (Correlation.cc:356-359 crops)."""
     import torch

@@ -1,0 +1,91 @@
+"""Certified tile-parallel matching of pyramid levels whose box sums round (csrc/bm_zones.hip, VWGPU_OPT_CERTIFY).
+
+The reference's box sums are serial running sums (src/vw/Stereo/Algorithms.h:43-129); on prefiltered or float imagery their roundings depend
+on the raster position.  The engine matches such levels with the tile-parallel float64 kernels, proves per pixel that the winner leads the
+runner-up by more than twice a bound on the difference between the two summation orders, and redoes only the zones that hold an unproven
+pixel in the reference's own order.  Everything here must be IDENTICAL to the oracle with the option on (default) and off (round-3 schedule),
+and the option must actually certify most of a textured scene."""
+import numpy as np
+import pytest
+
+import scenes
+import visionworkbench_amd as vwa
+from visionworkbench_amd import core, stereo
+from visionworkbench_amd.core import BBox2i
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked tests need a GPU"
+    c = vwa.Context(0)
+    yield c
+    c.close()
+
+
+def _both(ctx, oracle, left, right, lm, rm, pf, pfw, search, kernel, cost, thr, filt, levels):
+    box = BBox2i.from_corners(search[:2], search[2:])
+    out = {}
+    for certify in (1, 0):
+        ctx.set_option(core.OPT_CERTIFY, certify)
+        ctx.set_option(core.OPT_TRACE, 4)             # certification statistics (resets the running total)
+        try:
+            out[certify] = stereo.pyramid_correlate(left, right, lm, rm, pf, pfw, box, kernel, cost, 0, 0.0, thr, 0, filt, levels, ctx=ctx)
+            permille = ctx.get_option(core.OPT_CERT_PERMILLE)
+        finally:
+            ctx.set_option(core.OPT_TRACE, 0)
+            ctx.set_option(core.OPT_CERTIFY, 1)
+        if certify:
+            share = permille
+    want = oracle.pyramid_correlate(left, right, lm, rm, pf, pfw, search, kernel, cost, 0, 0.0, thr, filt, levels)
+    assert np.array_equal(out[0], want), ("exact-order schedule", int((out[0] != want).any(-1).sum()))
+    assert np.array_equal(out[1], want), ("certified schedule", int((out[1] != want).any(-1).sum()))
+    return share
+
+
+@pytest.mark.parametrize("cost,kernel", [(2, (11, 11)), (1, (7, 7)), (0, (7, 7))])
+def test_log_filtered_scene_is_mostly_certified(ctx, oracle, cost, kernel):
+    """The `correlate` tool's defaults (LoG 1.4, tools/correlate.cc:85,210) on the reference's test scene: identical tiles, and most pixels
+    proven by the tile-parallel pass (SAD on this scene is order free: nothing to certify, the share reads -1)."""
+    left, right, scale, trans, search = scenes.pyramid_scene("u8")
+    share = _both(ctx, oracle, left, right, None, None, 2, float(np.float32(1.4)), search, kernel, cost, 2, 5, 5)
+    assert share == -1 or share >= 700, share
+
+
+@pytest.mark.parametrize("cost", [0, 1, 2])
+def test_float_textures_with_masks(ctx, oracle, cost):
+    """Float textures, mean-filled nodata areas (exact cost ties there: the rounding order of the running sums decides — those zones must
+    go to the exact-order kernels) and a consistency check."""
+    rng = np.random.default_rng(808 + cost)
+    H, W = 220, 300
+    left = (rng.random((H, W)) * 200.0).astype(np.float32)
+    right = np.roll(left, 6, axis=1)
+    right[:, :6] = (rng.random((H, 6)) * 200.0).astype(np.float32)
+    lm = np.full((H, W), 255, np.uint8); lm[50:120, 40:130] = 0
+    rm = np.full((H, W), 255, np.uint8); rm[:, -30:] = 0
+    share = _both(ctx, oracle, left, right, lm, rm, 0, 0.0, (-10, -2, 11, 3), (7, 7), cost, 2, 3, 3)
+    assert share == -1 or share >= 300, share
+
+
+def test_repeated_texture_near_ties_go_to_the_exact_kernels(ctx, oracle):
+    """A right image that repeats the left texture with a period inside the search range: two disparities whose NCC costs are equal in
+    exact arithmetic and differ only by the rounding history of the running sums.  No certificate exists for those pixels."""
+    rng = np.random.default_rng(99)
+    H, W, P = 160, 240, 7
+    base = (rng.random((H, W + 64)) * 90.0 + 5.0).astype(np.float32)
+    left = base[:, :W].copy()
+    right = base[:, :W].copy()
+    right[:, P:] = np.where(rng.random((H, W - P)) < 0.5, right[:, P:], left[:, :W - P])       # half the pixels: the texture shifted by P as well
+    _both(ctx, oracle, left, right, None, None, 0, 0.0, (-9, -1, 10, 2), (5, 5), 2, -1, 0, 2)
+
+
+@pytest.mark.parametrize("cost", [1, 2])
+def test_wide_range_floats(ctx, oracle, cost):
+    """Magnitudes over 9 decades: the error bound is as large as the largest pixel allows, few pixels certify — still the oracle's tile."""
+    rng = np.random.default_rng(5 + cost)
+    H, W = 160, 200
+    v = (rng.random((H, W)) * 10.0 ** (rng.random((H, W)) * 9 - 4.5)).astype(np.float32)
+    right = np.roll(v, 4, axis=1)
+    _both(ctx, oracle, v, right, None, None, 0, 0.0, (-8, -2, 9, 3), (7, 7), cost, 2, 3, 3)

@@ -62,19 +62,27 @@ def _pyramid_pair(oracle, c):
     return g, o
 
 
-@pytest.mark.parametrize("n,seed,float_p,prefilters,costs", [
-    (70, 201, 0.0, (0,), (0, 0, 1)),            # the round-1 generator: integer scenes, SAD / SSD
-    (40, 202, 0.0, (0,), (2,)),                 # NCC
-    (50, 203, 1.0, (0,), (0, 1, 2)),            # float textures: order-dependent running sums
-    (50, 204, 0.0, (1, 2), (0, 1, 2)),          # mean-subtracted / LoG prefilters (tools/correlate.cc default)
+@pytest.mark.parametrize("n,seed,float_p,prefilters,costs,certify", [
+    (70, 201, 0.0, (0,), (0, 0, 1), 1),            # the round-1 generator: integer scenes, SAD / SSD
+    (40, 202, 0.0, (0,), (2,), 1),                 # NCC
+    (50, 203, 1.0, (0,), (0, 1, 2), 1),            # float textures: order-dependent running sums (certified pixels + redone zones)
+    (50, 204, 0.0, (1, 2), (0, 1, 2), 1),          # mean-subtracted / LoG prefilters (tools/correlate.cc default)
+    (25, 203, 1.0, (0,), (0, 1, 2), 0),            # the same classes with VWGPU_OPT_CERTIFY = 0: every zone through the exact-order kernels
+    (25, 204, 0.0, (1, 2), (0, 1, 2), 0),
 ])
-def test_fuzz_pyramid_identical_to_oracle(oracle, n, seed, float_p, prefilters, costs):
+def test_fuzz_pyramid_identical_to_oracle(oracle, n, seed, float_p, prefilters, costs, certify):
+    from visionworkbench_amd import core
+    ctx = core.default_context(0)
+    ctx.set_option(core.OPT_CERTIFY, certify)
     bad = []
-    for c in fuzz_cases.pyramid_cases(n, seed, prefilters=prefilters, costs=costs, float_scene=float_p):
-        g, o = _pyramid_pair(oracle, c)
-        if not np.array_equal(g, o):
-            bad.append((c["it"], int((g != o).any(-1).sum())))
-    assert not bad, "pyramid_cases(seed=%d, float=%g, prefilters=%s, costs=%s): (index, differing pixels) %s" % (seed, float_p, prefilters, costs, bad)
+    try:
+        for c in fuzz_cases.pyramid_cases(n, seed, prefilters=prefilters, costs=costs, float_scene=float_p):
+            g, o = _pyramid_pair(oracle, c)
+            if not np.array_equal(g, o):
+                bad.append((c["it"], int((g != o).any(-1).sum())))
+    finally:
+        ctx.set_option(core.OPT_CERTIFY, 1)
+    assert not bad, "pyramid_cases(seed=%d, float=%g, prefilters=%s, costs=%s, certify=%d): (index, differing pixels) %s" % (seed, float_p, prefilters, costs, certify, bad)
 
 
 def test_round1_fuzz_finding_ssd_ties_in_mean_filled_border(oracle):

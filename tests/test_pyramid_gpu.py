@@ -38,10 +38,7 @@ def test_reference_scene_identical_to_oracle(vw, oracle, channel, cost, thr):
     left, right, scale, trans, search = scenes.pyramid_scene(channel)
     g, o = _run_both(vw, oracle, left, right, None, None, 0, 0.0, search, (7, 7), cost, thr, 5, 5)
     assert g.shape == o.shape == left.shape + (3,)
-    if cost == 2:      # NCC scores are float64 on both sides but summed in a different order: allow rare near-ties
-        assert (g != o).any(axis=2).mean() < 2e-3
-    else:
-        assert np.array_equal(g, o)
+    assert np.array_equal(g, o), int((g != o).any(axis=2).sum())      # (NCC included: levels whose sums round are certified or matched in the reference's order)
     c, a = scenes.pyramid_score(g, scale, trans)
     assert c > (.87 if cost == 2 else .90) and a > .99           # TestPyramidCorrelationView.cxx thresholds
 

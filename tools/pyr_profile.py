@@ -15,6 +15,7 @@ ctx = core.default_context(0)
 import os
 ctx.set_option(core.OPT_EXACT_SPLIT, int(os.environ.get("PYR_EXACT_SPLIT", "0")))      # tool-side switch
 ONLY = os.environ.get("PYR_ONLY", "")
+ctx.set_option(core.OPT_ZONE_SXC, int(os.environ.get("PYR_ZONE_SXC", "0")))
 for pf, cost, k in cases:
     if ONLY and ONLY != "%d,%d,%d" % (pf, cost, k): continue
     args = dict(consistency_threshold=2, filter_half_kernel=5, max_pyramid_levels=5, bbox=BBox2i(256, 256, tile, tile))
@@ -32,3 +33,6 @@ for pf, cost, k in cases:
           (pf, cost, k, k, tile, wall * 1e3, sum(v[1] for v in agg.values()), float((out[..., 2] != 0).float().mean())))
     for n, (c, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
         print("   %-28s launches %6d  device %.3f ms" % (n, c, ms))
+    if os.environ.get("PYR_LAUNCHES"):              # every launch of the matchers in stream order (coarsest level first)
+        print("   launches (us): " + " ".join("%s=%.0f" % (n.replace("bm_zones", "z").replace("bmx_", "x"), ms * 1e3) for n, ms in rec
+                                               if n.startswith("bm_zones") or n.startswith("bmx_") or n == "zone_precision"))

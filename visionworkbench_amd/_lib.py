@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("VWGPU_LIBRARY") or os.path.join(_HERE, "lib", "libvwg
 _LIB = None
 
 SYMBOLS = [
-    "vwgpu_abi_version", "vwgpu_create", "vwgpu_destroy", "vwgpu_set_stream", "vwgpu_reset_stream", "vwgpu_synchronize",
+    "vwgpu_abi_version", "vwgpu_create", "vwgpu_destroy", "vwgpu_set_stream", "vwgpu_reset_stream", "vwgpu_synchronize", "vwgpu_trim",
     "vwgpu_strerror", "vwgpu_last_error", "vwgpu_force_path", "vwgpu_last_path", "vwgpu_set_option", "vwgpu_get_option",
     "vwgpu_profile_enable", "vwgpu_profile_reset", "vwgpu_profile_read",
     "vwgpu_calc_disparity_dev", "vwgpu_calc_disparity", "vwgpu_fast_box_sum_dev", "vwgpu_fast_box_sum",
@@ -91,6 +91,7 @@ def load():
     lib.vwgpu_set_stream.argtypes = [P, P]
     lib.vwgpu_reset_stream.argtypes = [P]
     lib.vwgpu_synchronize.argtypes = [P]
+    lib.vwgpu_trim.argtypes = [P, ctypes.POINTER(ctypes.c_size_t)]
     lib.vwgpu_strerror.argtypes = [I]
     lib.vwgpu_strerror.restype = ctypes.c_char_p
     lib.vwgpu_last_error.argtypes = [P]

@@ -65,7 +65,10 @@ struct XZone {
   int nchunk;                       // ceil(D / 64)
   long long vol;                    // offset (doubles) of the column-sum volume [rows][cw][dp]
   long long lprec, rprec;           // NCC: offsets (doubles) of the zone's precision images; box modes: lprec = output offset
+  long long gate;                   // 0, or the device address of an int: every work item of the zone leaves at once while it is 0 (the zones a
+                                    // certified tile-parallel pass did NOT flag, bm_zones.hip)
 };
+__device__ __forceinline__ bool xgated_off(const XZone& z) { return z.gate != 0 && *reinterpret_cast<const int*>(z.gate) == 0; }
 
 // The two volume layouts.  Zones that go through bmx_rowsel_kernel keep the XTL disparities of a group next to each other for every column, so
 // that a row chain of a group streams through consecutive 128-byte lines (with the disparity-fastest layout a chain step of 16 lanes was one
@@ -117,6 +120,7 @@ bmx_col_kernel(const float* __restrict__ A, int aw, int ah, ptrdiff_t as, const 
   constexpr bool BOX = (COST == XCOST_BOX || COST == XCOST_PREC);
   const int4 it = items[blockIdx.x];
   const XZone z = zones[it.x];
+  if (xgated_off(z)) return;
   const int cw = z.zw + kx - 1;
   const int lanes = 1 << z.lanes_log2;
   // (tiled volumes: a wavefront is 4 columns x the XTL disparities of a group = 512 consecutive bytes of a volume row)
@@ -216,6 +220,7 @@ bmx_box_row_kernel(int kx, const XZone* __restrict__ zones, const int2* __restri
   const int2 it = items[blockIdx.x * 4 + wave];
   if (it.x < 0) return;
   const XZone z = zones[it.x];                          // lanes_log2 == 0, one "disparity": a lane per row
+  if (xgated_off(z)) return;
   const int cw = z.zw + kx - 1;
   const int ylim = y_end < z.zh ? y_end : z.zh;
   const int y = it.y + lane;
@@ -264,6 +269,7 @@ bmx_row_fused_kernel(int kx, const XZone* __restrict__ zones, const int2* __rest
   if (it.x < 0) return;
   if (zone_flag && !zone_flag[it.x]) return;    // the pass after bmx_merge_kernel: only the zones it flagged
   const XZone z = zones[it.x];
+  if (xgated_off(z)) return;
   const int cw = z.zw + kx - 1;
   const int lanes = 1 << z.lanes_log2;
   const int g = lane >> z.lanes_log2, dl = lane & (lanes - 1);
@@ -488,6 +494,7 @@ bmx_rowsum_kernel(int kx, const XZone* __restrict__ zones, const int4* __restric
   const int4 it = items[blockIdx.x * 4 + wave];
   if (it.x < 0) return;
   const XZone z = zones[it.x];
+  if (xgated_off(z)) return;
   const int cw = z.zw + kx - 1;
   const int lanes = 1 << z.lanes_log2;
   const int g = lane >> z.lanes_log2, dl = lane & (lanes - 1);
@@ -533,6 +540,7 @@ bmx_select_kernel(int kx, const XZone* __restrict__ zones, const int2* __restric
   const int2 it = items[blockIdx.x * 4 + wave];
   if (it.x < 0) return;
   const XZone z = zones[it.x];
+  if (xgated_off(z)) return;
   const int cw = z.zw + kx - 1;
   const int lanes = 1 << z.lanes_log2;
   const int dp = z.nchunk == 1 ? lanes : z.nchunk * 64;
@@ -628,6 +636,7 @@ bmx_rowsel_kernel(int kx, const XZone* __restrict__ zones, const int4* __restric
   const int lane = (int)threadIdx.x;
   const int4 it = items[blockIdx.x];
   const XZone z = zones[it.x];
+  if (xgated_off(z)) return;
   const int cw = z.zw + kx - 1;
   const int lanes = 1 << z.lanes_log2;
   const int dp = z.nchunk == 1 ? lanes : z.nchunk * 64;
@@ -783,6 +792,7 @@ bmx_merge_kernel(const XZone* __restrict__ zones, const int2* __restrict__ items
   const int2 it = items[blockIdx.x * 4 + wave];
   if (it.x < 0) return;
   const XZone z = zones[it.x];
+  if (xgated_off(z)) return;
   int xlog = 0;
   while ((1 << xlog) < z.zw && xlog < 6) ++xlog;
   const int x = (it.y >> 20) * 64 + (lane & ((1 << xlog) - 1));
@@ -1345,7 +1355,7 @@ int vwgpu_float_grain(vwgpu_ctx* ctx, const float* a, int aw, int ah, ptrdiff_t 
 struct DGroup { int d0, dn, carry_mode; XCarry* carry; };
 static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, ptrdiff_t as,
                      const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky,
-                     const vwgpu_zone_task* zones, int n, int32_t* out, const DGroup* dgroup = nullptr) {
+                     const vwgpu_zone_task* zones, int n, int32_t* out, const DGroup* dgroup = nullptr, const int* const* gates = nullptr) {
   const bool ncc = cost_type == VWGPU_CROSS_CORRELATION;
   Tables match, box;                                  // box: the NCC precision images of every zone, left and right crops in one table
   size_t prec_doubles = 0;
@@ -1354,14 +1364,15 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
     XZone z{};
     z.ax = s.ax; z.ay = s.ay; z.bx = s.bx; z.by = s.by; z.zw = s.zw; z.zh = s.zh; z.sx = s.sx; z.sy = s.sy;
     z.out_off = s.out_off; z.out_stride = s.out_stride; z.addx = s.addx; z.addy = s.addy;
+    z.gate = gates ? (long long)reinterpret_cast<uintptr_t>(gates[i]) : 0;
     if (dgroup) { z.d0 = dgroup->d0; z.dn = dgroup->dn; z.carry_mode = dgroup->carry_mode; z.carry = 0; }
     if (ncc) {
       // NCCCost ctor over the zone's own crops (CostFunctions.h:214-219): box sums restart at the crop origin
       z.lprec = (long long)prec_doubles; prec_doubles += (size_t)s.zw * s.zh;
       z.rprec = (long long)prec_doubles; prec_doubles += (size_t)(s.zw + s.sx - 1) * (s.zh + s.sy - 1);
-      XZone a{}; a.ax = s.ax; a.ay = s.ay; a.zw = s.zw; a.zh = s.zh; a.sx = a.sy = 1; a.lprec = z.lprec; a.img = 0;
+      XZone a{}; a.ax = s.ax; a.ay = s.ay; a.zw = s.zw; a.zh = s.zh; a.sx = a.sy = 1; a.lprec = z.lprec; a.img = 0; a.gate = z.gate;
       add_zone(box, a, kx, a.zh, true);
-      XZone b{}; b.ax = s.bx; b.ay = s.by; b.zw = s.zw + s.sx - 1; b.zh = s.zh + s.sy - 1; b.sx = b.sy = 1; b.lprec = z.rprec; b.img = 1;
+      XZone b{}; b.ax = s.bx; b.ay = s.by; b.zw = s.zw + s.sx - 1; b.zh = s.zh + s.sy - 1; b.sx = b.sy = 1; b.lprec = z.rprec; b.img = 1; b.gate = z.gate;
       add_zone(box, b, kx, b.zh, true);
     }
     add_zone(match, z, kx, z.zh, false);
@@ -1430,16 +1441,18 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
 // groups whose column-sum volumes fit the scratch budget (VWGPU_OPT_EXACT_SCRATCH_MB, default 4096).
 int vwgpu_launch_bm_exact(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, ptrdiff_t as,
                           const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky,
-                          const vwgpu_zone_task* zones, int n, int32_t* out) {
+                          const vwgpu_zone_task* zones, int n, int32_t* out, const int* d_gate) {
   const size_t budget = exact_scratch_budget(ctx);
   std::vector<vwgpu_zone_task> group;
+  std::vector<const int*> group_gate;                 // d_gate != nullptr: zone i works only if d_gate[i] != 0 (decided on the device)
+  auto gates_of = [&]() -> const int* const* { return d_gate ? group_gate.data() : nullptr; };
   size_t bytes = 0;
   // zones whose working set fits the LDS of a wavefront: one launch, no HBM volume (bmx_zone_lds_kernel)
   std::vector<LZone> small;
   std::vector<char> is_small((size_t)std::max(n, 0), 0);
   size_t small_lds = 0;
   const bool ncc = cost_type == VWGPU_CROSS_CORRELATION;
-  if (ctx->exact_lds == 2 || (ctx->exact_lds == 1 && n > 1))       // opt-in (VWGPU_OPT_EXACT_LDS): measured slower than the HBM passes, see below
+  if (!d_gate && (ctx->exact_lds == 2 || (ctx->exact_lds == 1 && n > 1)))       // opt-in (VWGPU_OPT_EXACT_LDS): measured slower than the HBM passes, see below
     for (int i = 0; i < n; ++i) {
       const vwgpu_zone_task& s = zones[i];
       size_t b = 0;
@@ -1483,31 +1496,33 @@ int vwgpu_launch_bm_exact(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     if ((long long)s.sx * s.sy > 64LL * XMAX_CHUNKS) {
       // more disparities than a lane can hold: groups of 512 in index order, one launch pair each, compare-chain state in HBM
       if (!group.empty()) {
-        int rc = run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, group.data(), (int)group.size(), out);
+        int rc = run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, group.data(), (int)group.size(), out, nullptr, gates_of());
         if (rc) return rc;
-        group.clear(); bytes = 0;
+        group.clear(); group_gate.clear(); bytes = 0;
       }
       int rc = vwgpu_arena_reserve(ctx, &ctx->xcarry, (size_t)s.zw * s.zh * sizeof(XCarry) + 256);
       if (rc) return rc;
       const int D = s.sx * s.sy, G = 64 * XMAX_CHUNKS;
       for (int d0 = 0; d0 < D; d0 += G) {
         DGroup dg{d0, std::min(G, D - d0), (d0 > 0 ? 1 : 0) | (d0 + G < D ? 2 : 0), static_cast<XCarry*>(ctx->xcarry.base)};
-        rc = run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, &s, 1, out, &dg);
+        const int* one_gate = d_gate ? d_gate + i : nullptr;
+        rc = run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, &s, 1, out, &dg, d_gate ? &one_gate : nullptr);
         if (rc) return rc;
       }
       continue;
     }
     const size_t need = (size_t)s.zh * (s.zw + kx - 1) * dp_alloc(s.sx * s.sy) * 8;
     if (!group.empty() && bytes + need > budget) {
-      int rc = run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, group.data(), (int)group.size(), out);
+      int rc = run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, group.data(), (int)group.size(), out, nullptr, gates_of());
       if (rc) return rc;
-      group.clear(); bytes = 0;
+      group.clear(); group_gate.clear(); bytes = 0;
     }
     group.push_back(s);
+    if (d_gate) group_gate.push_back(d_gate + i);
     bytes += need;
   }
   if (group.empty()) return VWGPU_OK;
-  return run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, group.data(), (int)group.size(), out);
+  return run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, group.data(), (int)group.size(), out, nullptr, gates_of());
 }
 
 // fast_box_sum<double>(image, kernel) (Algorithms.h:41-43) in the reference's order.  d_out: (w-kx+1) x (h-ky+1) doubles, dense.

@@ -54,6 +54,20 @@
 #include "vwgpu_internal.h"
 #include "u8_tile.h"
 
+#ifdef VWGPU_TILE_STAMPS
+// Tools build only (make stamps -> tools/build/libvwgpu_stamps.so; tools/sad_timeline.py): every workgroup leaves a record of 16 u64 —
+// wall clock (100 MHz) and shader clock at its start and end, wall clock after staging / after each byte phase / after the epilogue,
+// and where it ran (XCC, SE, CU).  The product library does not contain any of this.
+__device__ unsigned long long* g_sad_stamps = nullptr;
+extern "C" int vwgpu_debug_set_sad_stamps(void* d_buf) {
+  unsigned long long* p = static_cast<unsigned long long*>(d_buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_sad_stamps), &p, sizeof p) == hipSuccess ? 0 : -3;
+}
+#define VWGPU_STAMP(k) do { if (g_sad_stamps && tid == 0) g_sad_stamps[(size_t)wg * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define VWGPU_STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 using namespace vwgpu_u8;
@@ -151,11 +165,19 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   const int q = x0 + 4 * ltid;                      // first of the lane's 4 output pixels
   u32 bad_acc = 0;                                  // non-zero: some input pixel is not an integer in [0,255]
   if (wg == 0 && tid == 0) *flag_clear = 0;         // the NEXT call's flag
+#ifdef VWGPU_TILE_STAMPS
+  if (g_sad_stamps && tid == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* rec = g_sad_stamps + (size_t)wg * 16;
+    rec[0] = wall_clock64(); rec[1] = clock64(); rec[2] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 
   // ---- LEFT: float tile -> u8 in LDS (borrowing the entry array) -> per-lane register windows ----
   // Both tiles are staged before anything else is live in registers (the LEFT tile borrows the entry array).
-  stage_u8_rows<NR>(L, ls, lw, lh, x0, y0, C::LBW, C::LBW, ent, tid, NT, bad_acc);
-  stage_u8_rows<NR>(R, rs, rcw, rch, x0, y0, bpitch, bpitch, base, tid, NT, bad_acc);
+  stage_u8_rows2<NR>(L, ls, lw, lh, C::LBW, C::LBW, ent, R, rs, rcw, rch, bpitch, bpitch, base, x0, y0, tid, NT, bad_acc);
   __syncthreads();
   u64 win[NR][NW];                                  // win[r][n] = bytes L[q+4n .. q+4n+7]
 #pragma unroll
@@ -167,6 +189,7 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
     for (int n = 0; n < NW; ++n) win[r][n] = (u64)a[n] | ((u64)a[n + 1] << 32);
   }
 
+  VWGPU_STAMP(3);
   u32 K[TY][4];                                     // best key per pixel: cost << 16 | disparity index
   u32 MN[TY][2], MX[TY][2];                         // packed best / worst cost (validity sweep only)
 #pragma unroll
@@ -370,6 +393,7 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
         for (; i < n1 + npair; i = next_item()) step(n1 + 2 * (i - n1), F{}, T{}, F{});
         for (; i < nitems; i = next_item()) step(a4 + (i - n1 - npair), T{}, F{}, F{});
         eq_checks += nprobe;
+        if (!MAXSWEEP && dy == 0) VWGPU_STAMP(4 + t);
       }
     }
   };
@@ -463,6 +487,9 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
     }
   }
 
+#ifdef VWGPU_TILE_STAMPS
+  if (g_sad_stamps && tid == 0) { g_sad_stamps[(size_t)wg * 16 + 8] = wall_clock64(); g_sad_stamps[(size_t)wg * 16 + 9] = clock64(); }
+#endif
   // ---- validity sweep (workgroup-uniform; never taken on textured imagery): the same steps with packed best / worst
   // costs instead of keys, then best == worst => invalid (Correlation.cc:121-133).  The epilogue's stores above are
   // complete before the barrier at the head of the sweep, the zeros below land after them.

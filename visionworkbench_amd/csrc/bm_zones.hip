@@ -1,9 +1,9 @@
-// bm_zones.hip — all search zones of one pyramid level in ONE launch.
+// bm_zones.hip — all search zones of one pyramid level in ONE launch sequence.
 //
 // PyramidCorrelationView::prerasterize runs calc_disparity once per SearchParam zone
 // (src/vw/Stereo/CorrelationView.cc:596-700); at level 0 of a 1024^2 tile that is ~2000 zones of ~32x32 pixels with
 // ~5x5 disparities each — as separate launches they cost ~600 ms of launch latency.  Here a zone is a row of a device
-// table and a workgroup serves one 32x32 output tile of one zone:
+// table and a workgroup serves a WORK ITEM: one 32x32 output tile of one zone and a run of its disparities:
 //   * the tile's left patch and (per dy, per chunk of dx) right patch are staged in LDS with coordinates CLAMPED into
 //     the level image — exactly the ConstantEdgeExtension crops the reference hands to calc_disparity when a padded
 //     zone sticks out of the level image (CorrelationView.cc:607-616,660-668);
@@ -15,21 +15,48 @@
 //     (Correlation.cc:91-133), dy outer / dx inner like the reference;
 //   * NCC: cost *= sqrt(precA * precB) with the 1/box-sum(img^2) images (CostFunctions.h:214-231) precomputed over the
 //     (clamped) union of all zone origins of the level.
+// Work items (round 4).  Rounds 1-3 gave a tile ALL its disparities and issued the tiles in zone order — the zones arrive sorted by
+// ascending search volume, so the few tiles that search 200+ disparities started LAST and the launch waited for them: PMC on the
+// level-0 launch of a 1024^2 tile showed 1.7 resident waves per SIMD on average and a launch 2.4x (NCC) to 4x (SAD) longer than its
+// work spread evenly (profiles/r04_zones_pmc_*.md).  Now a tile whose search is longer than a cap — a third of the level's work per
+// resident workgroup — is cut into runs of disparities in index order, the items are issued longest first, and the runs of a
+// tile leave (best, worst, first index) records that zones_merge_kernel folds in index order: the compare chain of
+// Correlation.cc:91-117 is a (value, first index) minimum plus an extremum as long as no cost is NaN, and both fold exactly.  A
+// tile with a non-finite cost is order dependent: the merge flags it and the tile is redone as ONE item by the launch queued behind
+// the merge (every other workgroup of that launch leaves at once).
+// Certification (round 4, levels whose box sums could round).  The tile-parallel sums differ from the reference's serial running sums by
+// at most eps (derived in vwgpu_launch_bm_zones from the level's largest exponent and the chain lengths of the zone); a pixel whose best
+// cost beats its runner-up by more than 2 eps provably has the reference's disparity AND validity.  With `cert` the kernels track the
+// runner-up (NCC: also the largest right precision), and a pixel that cannot be certified raises its ZONE's flag: bm_exact.hip then
+// redoes exactly the flagged zones in the reference's order.  Default results stay bit-identical to the oracle.
 // A second tiny kernel applies the per-zone L/R consistency check (Correlate.cc:1441-1502) and the
 // `+= zone.disparity_range().min()` offset (CorrelationView.cc:696-697) for every zone at once.
-//
-// Roofline: LDS-bandwidth bound (~2*kx 4-byte + ky 8-byte LDS reads per pixel*disparity); the point of this kernel is
-// launch count, the level-0 work of a refined pyramid is only ~25 disparities per pixel.
 #include <algorithm>
+#include <climits>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
 #include "vwgpu_internal.h"
 
+#ifdef VWGPU_TILE_STAMPS
+// Tools build only (make stamps; tools/zones_timeline.py): every workgroup of the zone matcher leaves {start, end (100 MHz wall clock), where it
+// ran, its item's evaluations} in a buffer set through vwgpu_debug_set_zone_stamps.  Not in the product library.
+__device__ unsigned long long* g_zone_stamps = nullptr;
+__device__ unsigned int g_zone_stamp_count = 0;
+extern "C" int vwgpu_debug_set_zone_stamps(void* d_buf) {
+  unsigned long long* p = static_cast<unsigned long long*>(d_buf);
+  unsigned int zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_zone_stamp_count), &zero, sizeof zero) != hipSuccess) return -3;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_zone_stamps), &p, sizeof p) == hipSuccess ? 0 : -3;
+}
+#endif
+
 namespace {
 
-constexpr int ZT = 32;            // output tile side
+constexpr int ZT = 32;            // output tile side of the per-zone L/R kernel
 constexpr int ZTHREADS = 256;
+// (the matcher kernels take the tile side as a template parameter; only 32 x 32 outputs on 256 threads is instantiated, see the launcher)
 
 template <int COST, typename ACC = double>
 __device__ __forceinline__ ACC zcost(float a, float b) {
@@ -80,29 +107,73 @@ zone_precision_kernel(const float* __restrict__ img, int w, int h, int kx, int k
   prec[(size_t)j * pw + i] = 1.0 / s;
 }
 
+// A work item: disparities [i0, i0 + n) (index = dy * sx + dx, the reference's loop order) of one 32 x 32 tile of one zone.
+struct ZItem {
+  int zone, txy;        // zone row; tile x | tile y << 16
+  int i0, n;
+  int slot;             // >= 0: the tile is cut into several items, this one leaves its records in partial slot `slot`; -1: the tile's only item
+  int gate;             // >= 0: run only if redo[gate] != 0 (the redo launch behind the merge); -1: always
+  int pad0, pad1;
+};
+struct ZMergeItem { int zone, txy, slot0, nitems, gate, pad0, pad1, pad2; };
+// records of the partial slots, one plane of 1024 pixels per slot and field
+struct ZPart { double* best; double* worst; int* idx; double* second; double* rpmax; int* bad; int* redo; };
+// certification constants of a zone: bounds on |tile-parallel sum - reference running sum| (see vwgpu_launch_bm_zones)
+struct ZCert { double eps_s, eps_ll, eps_rr, pad; };
+struct ZCertArgs { const ZCert* zc; int* zflag; unsigned long long* stats; };      // zc == nullptr: no certification
+
+// "can this pixel's result be proven equal to the reference's?"  best / second / worst / rpmax: what the chain has seen over ALL D
+// disparities of the pixel (second = the best cost among the disparities other than the winner; equal costs => second == best).
+template <int COST>
+__device__ __forceinline__ bool zcertified(const ZCert& zc, int D, bool bad, double best, double second, double worst, double lprec, double rpmax) {
+  if (bad) return false;                                     // a non-finite cost: the reference's chain is order dependent there
+  if (D == 1) return true;                                   // best == worst in any arithmetic: invalid, like the reference
+  double eps;
+  if (COST == VWGPU_CROSS_CORRELATION) {
+    // cost = S_lr * sqrt((1 / S_ll) * (1 / S_rr)), every S off by at most its eps, 1/x and sqrt propagated to first order with a factor 2
+    const double dl = 2.0 * zc.eps_ll * lprec, dr = 2.0 * zc.eps_rr * rpmax;
+    if (!(lprec > 0.0) || !(rpmax > 0.0) || !(dl <= 0x1p-10) || !(dr <= 0x1p-10)) return false;
+    const double cmax = fmax(fabs(best), fabs(worst));
+    eps = 2.0 * (cmax * (dl + dr + 0x1p-49) + zc.eps_s * sqrt(lprec * rpmax));
+  } else {
+    eps = zc.eps_s;
+  }
+  const double gap = COST == VWGPU_CROSS_CORRELATION ? best - second : second - best;
+  return gap > 2.0 * eps;                                    // (false for NaN)
+}
+
 // KS > 0: a square KS x KS window known at compile time — the horizontal and vertical window sums are unrolled (with run-time
 // sizes the loop overhead outweighed the sums, as PMC showed for bm_generic).  KS == 0: any kx, ky.
 // ACC: the type of the window sums.  float64 is the reference's; float32 is taken when every intermediate value is exactly representable in 24
 // bits as well (vwgpu_sums_bits <= 24: byte imagery under SAD) — then both give the same numbers, the LDS planes are half as large and the sums
 // full-rate.  The compare chain runs on doubles either way.
-template <int COST, int KS, typename ACC>
-__global__ void __launch_bounds__(ZTHREADS)
+// CERT: track the runner-up (and the largest right precision) and certify / flag, see the file header.
+template <int COST, int KS, typename ACC, bool CERT, int ZS>
+__global__ void __launch_bounds__(ZS * ZS / 4)
 bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __restrict__ B, int bw, int bh,
-                int kx, int ky, const vwgpu_zone_task* __restrict__ zones, const int2* __restrict__ tiles,
-                int sxc, PrecView pa, PrecView pb, int32_t* __restrict__ out) {
+                int kx, int ky, const vwgpu_zone_task* __restrict__ zones, const ZItem* __restrict__ items,
+                int sxc, PrecView pa, PrecView pb, int32_t* __restrict__ out, ZPart P, ZCertArgs C) {
   extern __shared__ char smem[];
+  // tile side, threads, columns per horizontal item (float64 sums: four — eight need 36 registers for the elements alone and cost a
+  // resident workgroup per CU), items per row
+  constexpr int ZT = ZS, ZTHREADS = ZS * ZS / 4, HW = sizeof(ACC) == 4 ? 8 : 4, QL = ZS / HW;
+  const ZItem it = items[blockIdx.x];
+  if (it.gate >= 0 && P.redo[it.gate] == 0) return;               // redo launch: only the tiles the merge flagged
+#ifdef VWGPU_TILE_STAMPS
+  unsigned long long stamp_t0 = 0;
+  if (g_zone_stamps && threadIdx.x == 0) stamp_t0 = wall_clock64();
+#endif
   const int PW = ZT + kx - 1, PH = ZT + ky - 1, RW = PW + sxc - 1;
   float* Lp = reinterpret_cast<float*>(smem);                    // PH x PW
   float* Rp = Lp + PH * PW;                                      // PH x RW
   ACC* H = reinterpret_cast<ACC*>(smem + (((size_t)(PH * PW + PH * RW) * 4 + 7) & ~size_t(7)));   // 2 x PH x ZT
 
-  const int2 tl = tiles[blockIdx.x];
-  const vwgpu_zone_task z = zones[tl.x];
-  const int ox = (tl.y & 0xffff) * ZT, oy = (tl.y >> 16) * ZT;
+  const vwgpu_zone_task z = zones[it.zone];
+  const int ox = (it.txy & 0xffff) * ZT, oy = (it.txy >> 16) * ZT;
   const int tw = min(ZT, z.zw - ox), th = min(ZT, z.zh - oy);
   const int pw = tw + kx - 1, ph = th + ky - 1;
   const int t = threadIdx.x;
-  const int c = t & 31, y0 = (t >> 5) * 4;
+  const int c = t % ZT, y0 = (t / ZT) * 4;
 
   for (int i = t; i < ph * pw; i += ZTHREADS) {
     const int r = i / pw, q = i - r * pw;
@@ -110,52 +181,72 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
     int yy = z.ay + oy + r; yy = yy < 0 ? 0 : (yy >= ah ? ah - 1 : yy);
     Lp[r * PW + q] = A[(size_t)yy * aw + xx];
   }
-  double best[4], worst[4], lprec[4];
-  int bdx[4], bdy[4];
+  double best[4], worst[4], lprec[4], second[4], rpmax[4];
+  int bidx[4];
+  bool bad = false;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    best[m] = worst[m] = 0.0; bdx[m] = bdy[m] = 0; lprec[m] = 0.0;
+    best[m] = worst[m] = 0.0; bidx[m] = 0; lprec[m] = 0.0; second[m] = 0.0; rpmax[m] = 0.0;
     if (COST == VWGPU_CROSS_CORRELATION && c < tw && y0 + m < th)
       lprec[m] = pa.p[(size_t)(z.ay + oy + y0 + m - pa.y0) * pa.w + (z.ax + ox + c - pa.x0)];
   }
   int hb = 0;
-  for (int dy = 0; dy < z.sy; ++dy) {
-    for (int dx0 = 0; dx0 < z.sx; dx0 += sxc) {
-      const int nd = min(sxc, z.sx - dx0);
-      const int rwid = pw + nd - 1;
-      __syncthreads();                                            // everyone done with the previous right patch
-      for (int i = t; i < ph * rwid; i += ZTHREADS) {
-        const int r = i / rwid, q = i - r * rwid;
-        int xx = z.bx + ox + dx0 + q; xx = xx < 0 ? 0 : (xx >= bw ? bw - 1 : xx);
-        int yy = z.by + oy + dy + r; yy = yy < 0 ? 0 : (yy >= bh ? bh - 1 : yy);
-        Rp[r * RW + q] = B[(size_t)yy * bw + xx];
+  const int iend = it.i0 + it.n;
+  // (Tried and dropped, round 4: requesting the right patch of the next run of dx while this run is matched, and four instead of three
+  // resident workgroups per CU through a 128-register cap.  tools/zones_timeline.py: with four residents every workgroup advanced at
+  // 260 instead of 400 evaluations per microsecond — the launch is bound by the VALU instructions per evaluation, not by latency.)
+  for (int i0 = it.i0; i0 < iend;) {
+    const int dy = i0 / z.sx, dx0 = i0 - dy * z.sx;
+    const int nd = min(min(sxc, z.sx - dx0), iend - i0);          // a run of dx inside one search row
+    const int rwid = pw + nd - 1;
+    __syncthreads();                                              // everyone done with the previous right patch
+    for (int i = t; i < ph * rwid; i += ZTHREADS) {
+      const int r = i / rwid, q = i - r * rwid;
+      int xx = z.bx + ox + dx0 + q; xx = xx < 0 ? 0 : (xx >= bw ? bw - 1 : xx);
+      int yy = z.by + oy + dy + r; yy = yy < 0 ? 0 : (yy >= bh ? bh - 1 : yy);
+      Rp[r * RW + q] = B[(size_t)yy * bw + xx];
+    }
+    __syncthreads();
+    // NCC: the right precisions of a disparity are requested before its horizontal pass and consumed after it (a load issued where it is
+    // used put a memory round trip on the critical path of every disparity)
+    const double* prow[4] = {nullptr, nullptr, nullptr, nullptr};
+    double rpn[4] = {0.0, 0.0, 0.0, 0.0};
+    if (COST == VWGPU_CROSS_CORRELATION && c < tw) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (y0 + m < th) prow[m] = pb.p + (size_t)(z.by + oy + y0 + m + dy - pb.y0) * pb.w + (z.bx + ox + c + dx0 - pb.x0);
+    }
+    for (int d = 0; d < nd; ++d) {
+      ACC* Hc = H + hb * (PH * ZT);
+      if (COST == VWGPU_CROSS_CORRELATION) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) rpn[m] = prow[m] ? prow[m][d] : 0.0;
       }
-      __syncthreads();
-      for (int d = 0; d < nd; ++d) {
-        ACC* Hc = H + hb * (PH * ZT);
-        if (KS > 0) {
-          // Four adjacent columns per thread: KS + 3 cost elements are formed once and the window slides (s' = s - e[j] + e[j + KS]),
-          // 2 (KS + 3) LDS reads and 3 KS + ... adds for four sums instead of 8 KS reads and 4 KS adds.  The slide is exact here:
-          // this kernel only runs on data whose running sums are exactly representable (vwgpu_sums_order_free).
-          for (int i = t; i < ph * (ZT / 4); i += ZTHREADS) {
-            const int r = i >> 3, q = (i & 7) * 4;
-            if (q < tw) {
-              const float* lp = Lp + r * PW + q;
-              const float* rp = Rp + r * RW + q + d;
-              ACC e[KS > 0 ? KS + 3 : 1];
+      if (KS > 0) {
+        // HW adjacent columns per thread: KS + HW - 1 cost elements are formed once and the window slides (s' = s - e[j] + e[j + KS]).
+        // With float32 sums HW = 8: 2 (KS + 7) LDS reads and KS + 13 adds for eight sums, and the ph x ZT / 8 items of a disparity are
+        // ONE round of the workgroup (with four columns per item a 32 x 32 tile is 1.3 rounds: two of the four waves run twice and the
+        // others wait at the barrier).  On order-free data the slide is exact; with CERT its roundings are part of eps.
+        for (int i = t; i < ph * QL; i += ZTHREADS) {
+          const int r = i / QL, q = (i % QL) * HW;
+          if (q < tw) {
+            const float* lp = Lp + r * PW + q;
+            const float* rp = Rp + r * RW + q + d;
+            ACC e[KS > 0 ? KS + HW - 1 : 1];
 #pragma unroll
-              for (int a = 0; a < KS + 3; ++a) e[a] = zcost<COST, ACC>(lp[a], rp[a]);
-              ACC s0 = 0;
+            for (int a = 0; a < KS + HW - 1; ++a) e[a] = zcost<COST, ACC>(lp[a], rp[a]);
+            ACC sacc = 0;
 #pragma unroll
-              for (int a = 0; a < KS; ++a) s0 += e[a];
-              const ACC s1 = s0 - e[0] + e[KS], s2 = s1 - e[1] + e[KS + 1], s3 = s2 - e[2] + e[KS + 2];
-              ACC* h = Hc + r * ZT + q;
-              h[0] = s0; h[1] = s1; h[2] = s2; h[3] = s3;
-            }
+            for (int a = 0; a < KS; ++a) sacc += e[a];
+            ACC* h = Hc + r * ZT + q;
+            h[0] = sacc;
+#pragma unroll
+            for (int j = 1; j < HW; ++j) { sacc = sacc - e[j - 1] + e[j - 1 + KS]; h[j] = sacc; }
           }
-        } else {
+        }
+      } else {
         for (int i = t; i < ph * ZT; i += ZTHREADS) {             // horizontal sums
-          const int r = i >> 5, q = i & 31;
+          const int r = i / ZT, q = i % ZT;
           if (q < tw) {
             const float* lp = Lp + r * PW + q;
             const float* rp = Rp + r * RW + q + d;
@@ -164,50 +255,165 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
             Hc[r * ZT + q] = s;
           }
         }
-        }
-        __syncthreads();
-        if (c < tw) {
-          const int dx = dx0 + d;
-          const bool first = (dx == 0 && dy == 0);
-          ACC vs[4] = {0, 0, 0, 0};
-          if (KS > 0) {                                           // the same slide down the rows (rows beyond th hold stale planes: unused)
-            ACC h[KS > 0 ? KS + 3 : 1];
-#pragma unroll
-            for (int b = 0; b < KS + 3; ++b) h[b] = Hc[min(y0 + b, PH - 1) * ZT + c];
-#pragma unroll
-            for (int b = 0; b < KS; ++b) vs[0] += h[b];
-            vs[1] = vs[0] - h[0] + h[KS]; vs[2] = vs[1] - h[1] + h[KS + 1]; vs[3] = vs[2] - h[2] + h[KS + 2];
-          }
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const int y = y0 + m;
-            if (y < th) {
-              ACC sa = vs[m];
-              if (KS == 0) {
-                for (int b = 0; b < ky; ++b) sa += Hc[(y + b) * ZT + c];
-              }
-              double s = (double)sa;
-              if (COST == VWGPU_CROSS_CORRELATION)
-                s *= sqrt(lprec[m] * pb.p[(size_t)(z.by + oy + y + dy - pb.y0) * pb.w + (z.bx + ox + c + dx - pb.x0)]);
-              if (first) { best[m] = worst[m] = s; }
-              else if (zbetter<COST>(s, best[m])) { best[m] = s; bdx[m] = dx; bdy[m] = dy; }
-              else if (!zbetter<COST>(s, worst[m])) { worst[m] = s; }
-            }
-          }
-        }
-        hb ^= 1;                                                  // next disparity writes the other plane
       }
+      __syncthreads();
+      if (c < tw) {
+        const int di = i0 + d;
+        const bool first = (di == it.i0);
+        ACC vs[4] = {0, 0, 0, 0};
+        if (KS > 0) {                                           // the same slide down the rows (rows beyond th hold stale planes: unused)
+          ACC h[KS > 0 ? KS + 3 : 1];
+#pragma unroll
+          for (int b = 0; b < KS + 3; ++b) h[b] = Hc[min(y0 + b, PH - 1) * ZT + c];
+#pragma unroll
+          for (int b = 0; b < KS; ++b) vs[0] += h[b];
+          vs[1] = vs[0] - h[0] + h[KS]; vs[2] = vs[1] - h[1] + h[KS + 1]; vs[3] = vs[2] - h[2] + h[KS + 2];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int y = y0 + m;
+          if (y < th) {
+            ACC sa = vs[m];
+            if (KS == 0) {
+              for (int b = 0; b < ky; ++b) sa += Hc[(y + b) * ZT + c];
+            }
+            double s = (double)sa;
+            if (COST == VWGPU_CROSS_CORRELATION) {
+              const double rp = rpn[m];
+              s *= sqrt(lprec[m] * rp);
+              if (CERT) rpmax[m] = fmax(rpmax[m], rp);
+            }
+            if (CERT || it.slot >= 0) bad = bad || !(fabs(s) <= 1.7976931348623157e308);
+            // Correlation.cc:91-117 as selects (a branch per comparison costs more than the comparisons): the first disparity sets
+            // best = worst; a strictly better cost takes best and the index; otherwise a cost that is not better than worst takes worst
+            // (a NaN cost compares false both times: it never wins and becomes `worst`, as in the reference)
+            const bool cb = zbetter<COST>(s, best[m]), cw = zbetter<COST>(s, worst[m]);
+            const bool ub = first || cb, uw = first || (!cb && !cw);
+            if (CERT) {
+              const bool cs = zbetter<COST>(s, second[m]);
+              const double sent = COST == VWGPU_CROSS_CORRELATION ? -INFINITY : INFINITY;
+              second[m] = first ? sent : (cb ? best[m] : (cs ? s : second[m]));
+            }
+            best[m] = ub ? s : best[m];
+            bidx[m] = ub ? di : bidx[m];
+            worst[m] = uw ? s : worst[m];
+          }
+        }
+      }
+      hb ^= 1;                                                  // next disparity writes the other plane
+    }
+    i0 += nd;
+  }
+#ifdef VWGPU_TILE_STAMPS
+  if (g_zone_stamps && threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned k = atomicAdd(&g_zone_stamp_count, 1u);
+    if (k < (1u << 18)) {
+      unsigned long long* rec = g_zone_stamps + (size_t)k * 4;
+      rec[0] = stamp_t0; rec[1] = wall_clock64(); rec[2] = ((unsigned long long)xcc << 32) | hw;
+      rec[3] = ((unsigned long long)blockIdx.x << 32) | (unsigned)(it.n * tw * th);
     }
   }
+#endif
+  if (it.slot >= 0) {                                           // one of several runs of this tile: leave the records to zones_merge_kernel
+    const size_t base = (size_t)it.slot * (ZT * ZT);
+    if (c < tw) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int y = y0 + m;
+        if (y < th) {
+          const size_t o = base + (size_t)y * ZT + c;
+          P.best[o] = best[m]; P.worst[o] = worst[m]; P.idx[o] = bidx[m];
+          if (CERT) { P.second[o] = second[m]; if (COST == VWGPU_CROSS_CORRELATION) P.rpmax[o] = rpmax[m]; }
+        }
+      }
+    }
+    if (__syncthreads_or(bad ? 1 : 0) && t == 0) P.bad[it.slot] = 1;     // (the slot flags are zeroed with the tables)
+    return;
+  }
+  bool uncert = false;
   if (c < tw) {
+    const int D = z.sx * z.sy;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int y = y0 + m;
       if (y < th) {
         int32_t* o = out + ((size_t)z.out_off + (size_t)(oy + y) * z.out_stride + ox + c) * 3;
-        o[0] = bdx[m] + z.addx; o[1] = bdy[m] + z.addy;
+        const int by_ = bidx[m] / z.sx, bx_ = bidx[m] - by_ * z.sx;
+        o[0] = bx_ + z.addx; o[1] = by_ + z.addy;
         o[2] = (best[m] == worst[m]) ? 0 : 0x7fffffff;
+        if (CERT && !zcertified<COST>(C.zc[it.zone], D, bad, best[m], second[m], worst[m], lprec[m], rpmax[m])) uncert = true;
       }
+    }
+  }
+  if (CERT) {
+    const int any = __syncthreads_or(uncert ? 1 : 0);
+    if (t == 0) {
+      if (any) C.zflag[it.zone] = 1;
+      if (C.stats) { atomicAdd(&C.stats[any ? 1 : 0], (unsigned long long)(tw * th)); }
+    }
+  }
+}
+
+// Folds the runs of a tile in index order (see the file header): (value, first index) minimum, extremum, runner-up, largest right precision.
+template <int COST, bool CERT, int ZS>
+__global__ void __launch_bounds__(ZS * ZS / 4)
+zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* __restrict__ items, PrecView pa,
+                   int32_t* __restrict__ out, ZPart P, ZCertArgs C) {
+  constexpr int ZT = ZS;
+  const ZMergeItem it = items[blockIdx.x];
+  const vwgpu_zone_task z = zones[it.zone];
+  const int ox = (it.txy & 0xffff) * ZT, oy = (it.txy >> 16) * ZT;
+  const int tw = min(ZT, z.zw - ox), th = min(ZT, z.zh - oy);
+  const int t = threadIdx.x;
+  const int c = t % ZT, y0 = (t / ZT) * 4;
+  bool bad = false;
+  for (int k = 0; k < it.nitems; ++k) bad = bad || P.bad[it.slot0 + k] != 0;      // workgroup-uniform
+  if (bad && !CERT) {                                           // order dependent: the redo launch recomputes the tile as one item
+    if (t == 0) P.redo[it.gate] = 1;
+    return;
+  }
+  bool uncert = false;
+  if (c < tw) {
+    const int D = z.sx * z.sy;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int y = y0 + m;
+      if (y >= th) continue;
+      double best = 0.0, worst = 0.0, second = 0.0, rpmax = 0.0;
+      int bi = 0;
+      for (int k = 0; k < it.nitems; ++k) {
+        const size_t o = (size_t)(it.slot0 + k) * (ZT * ZT) + (size_t)y * ZT + c;
+        const double b = P.best[o], w = P.worst[o];
+        const double sc = CERT ? P.second[o] : 0.0;
+        if (k == 0) { best = b; worst = w; bi = P.idx[o]; second = sc; }
+        else {
+          if (zbetter<COST>(b, best)) {                         // strictly better: ties stay with the earlier run (first wins)
+            if (CERT) second = zbetter<COST>(sc, best) ? sc : best;
+            best = b; bi = P.idx[o];
+          } else if (CERT && zbetter<COST>(b, second)) second = b;
+          if (!zbetter<COST>(w, worst)) worst = w;
+        }
+        if (CERT && COST == VWGPU_CROSS_CORRELATION) rpmax = fmax(rpmax, P.rpmax[o]);
+      }
+      int32_t* o3 = out + ((size_t)z.out_off + (size_t)(oy + y) * z.out_stride + ox + c) * 3;
+      const int by_ = bi / z.sx, bx_ = bi - by_ * z.sx;
+      o3[0] = bx_ + z.addx; o3[1] = by_ + z.addy;
+      o3[2] = (best == worst) ? 0 : 0x7fffffff;
+      if (CERT) {
+        double lprec = 0.0;
+        if (COST == VWGPU_CROSS_CORRELATION) lprec = pa.p[(size_t)(z.ay + oy + y - pa.y0) * pa.w + (z.ax + ox + c - pa.x0)];
+        if (!zcertified<COST>(C.zc[it.zone], D, bad, best, second, worst, lprec, rpmax)) uncert = true;
+      }
+    }
+  }
+  if (CERT) {
+    const int any = __syncthreads_or(uncert ? 1 : 0);
+    if (t == 0) {
+      if (any) C.zflag[it.zone] = 1;
+      if (C.stats) { atomicAdd(&C.stats[any ? 1 : 0], (unsigned long long)(tw * th)); }
     }
   }
 }
@@ -242,27 +448,43 @@ __global__ void zone_lr_kernel(const vwgpu_zone_task* __restrict__ zones, const 
   }
 }
 
-int upload_tables(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, std::vector<int2> const& tiles,
-                  const vwgpu_zone_task** d_zones, const int2** d_tiles) {
-  const size_t zb = vwgpu_align_up((size_t)n * sizeof(vwgpu_zone_task), 256), tb = tiles.size() * sizeof(int2);
-  // the previous launch may still be reading the table: alternate between two halves of the arena
-  const size_t half = vwgpu_align_up(zb + tb, 4096);
+// Tables of one launch sequence, side by side in one half of the ztab arena (the previous sequence may still be reading the other half):
+// pieces[i] = {host pointer, bytes}; d[i] receives the device address.  One asynchronous copy from the pinned ring when they fit.
+int upload_pieces(vwgpu_ctx* ctx, const void* const* src, const size_t* bytes, int n, char** d, size_t zero_tail, char** d_zero) {
+  size_t off[8], all = 0;
+  for (int i = 0; i < n; ++i) { off[i] = all; all += vwgpu_align_up(bytes[i], 256); }
+  const size_t zoff = all;
+  all += vwgpu_align_up(zero_tail, 256);
+  const size_t half = vwgpu_align_up(all, 4096);
   if (ctx->ztab.cap < 2 * half) {
     int rc = vwgpu_arena_reserve(ctx, &ctx->ztab, 2 * half + (1 << 20));
     if (rc) return rc;
   }
   ctx->ztab_parity ^= 1;
   char* base = static_cast<char*>(ctx->ztab.base) + (ctx->ztab_parity ? ctx->ztab.cap / 2 : 0);
-  if (char* h = static_cast<char*>(vwgpu_host_ring(ctx, zb + tb))) {   // one asynchronous copy from pinned memory
-    memcpy(h, zones, (size_t)n * sizeof(vwgpu_zone_task));
-    memcpy(h + zb, tiles.data(), tb);
-    VWGPU_HIP(ctx, hipMemcpyAsync(base, h, zb + tb, hipMemcpyHostToDevice, ctx->stream));
+  if (char* h = static_cast<char*>(vwgpu_host_ring(ctx, zoff))) {
+    for (int i = 0; i < n; ++i) if (bytes[i]) memcpy(h + off[i], src[i], bytes[i]);
+    VWGPU_HIP(ctx, hipMemcpyAsync(base, h, zoff, hipMemcpyHostToDevice, ctx->stream));
   } else {
-    VWGPU_HIP(ctx, hipMemcpyAsync(base, zones, (size_t)n * sizeof(vwgpu_zone_task), hipMemcpyHostToDevice, ctx->stream));
-    VWGPU_HIP(ctx, hipMemcpyAsync(base + zb, tiles.data(), tb, hipMemcpyHostToDevice, ctx->stream));
+    for (int i = 0; i < n; ++i)
+      if (bytes[i]) VWGPU_HIP(ctx, hipMemcpyAsync(base + off[i], src[i], bytes[i], hipMemcpyHostToDevice, ctx->stream));
+    VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the host vectors go out of scope
   }
-  *d_zones = reinterpret_cast<const vwgpu_zone_task*>(base);
-  *d_tiles = reinterpret_cast<const int2*>(base + zb);
+  if (zero_tail) VWGPU_HIP(ctx, hipMemsetAsync(base + zoff, 0, zero_tail, ctx->stream));
+  for (int i = 0; i < n; ++i) d[i] = base + off[i];
+  if (d_zero) *d_zero = base + zoff;
+  return VWGPU_OK;
+}
+
+int upload_tables(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, std::vector<int2> const& tiles,
+                  const vwgpu_zone_task** d_zones, const int2** d_tiles) {
+  const void* src[2] = {zones, tiles.data()};
+  const size_t bytes[2] = {(size_t)n * sizeof(vwgpu_zone_task), tiles.size() * sizeof(int2)};
+  char* d[2];
+  int rc = upload_pieces(ctx, src, bytes, 2, d, 0, nullptr);
+  if (rc) return rc;
+  *d_zones = reinterpret_cast<const vwgpu_zone_task*>(d[0]);
+  *d_tiles = reinterpret_cast<const int2*>(d[1]);
   return VWGPU_OK;
 }
 
@@ -275,6 +497,16 @@ void build_tiles(const vwgpu_zone_task* zones, int n, std::vector<int2>& tiles) 
   }
 }
 
+// bound on |any-order float64 sum - the reference's running sum| of a kx x ky window over a W x H output region, in units of the
+// largest element magnitude: the reference's column chain (Algorithms.h:62-75,100-103) makes 2 roundings per row step on values below
+// (ky + 1) elements, its row chain (:84-92) 2 per column step on values below kx ky + 2 ky elements, the inherited column errors
+// telescope along a row, and the tile-parallel sums (kx + 5 and ky + 5 additions of at most kx ky elements) are a lower-order term:
+//   ref <= u [kx ky^2 + 2 kx H (ky + 1) + kx ky (kx - 1) + W ky (kx + 2)],  tile <= u (kx + 2)(ky + 2)(kx + ky + 9)
+// both below u (kx + 2)(ky + 2)(2 kx + 2 ky + 2 W + 2 H + 9); the constant 8 leaves a factor > 3 for the second-order terms.
+double sum_error_units(int kx, int ky, int W, int H) {
+  return 8.0 * (kx + 2.0) * (ky + 2.0) * ((double)kx + ky + W + H + 5.0) * 0x1p-53;
+}
+
 }  // namespace
 
 bool vwgpu_bm_zones_supported(int kx, int ky) {
@@ -283,63 +515,227 @@ bool vwgpu_bm_zones_supported(int kx, int ky) {
   return (PH * PW + PH * (PW + 7)) * 4 + 2 * PH * ZT * 8 + 16 <= 64 * 1024;
 }
 
+// cert_hi: INT_MIN = no certification (the level is order free: any summation order returns the reference's bits).  Otherwise the
+// largest binary exponent of the level's pixels (|pixel| < 2^(cert_hi + 1), all finite): the kernels certify every pixel against the
+// error bound above and raise d_zflag[zone] (n ints, zeroed here) for zones with a pixel they cannot certify; the caller redoes those
+// zones in the reference's order (vwgpu_launch_bm_exact with the same flags as its gate).
+namespace {
+// the work of one tile size of a launch sequence
+struct ZPlan {
+  int zs = 32;                                   // tile side
+  int sxc = 1;                                   // dx per right patch
+  size_t lds = 0;
+  std::vector<ZItem> items, redo;
+  std::vector<ZMergeItem> merges;
+  int nslots = 0;
+  ZPart P{};
+  const ZItem* d_items = nullptr; const ZItem* d_redo = nullptr; const ZMergeItem* d_merges = nullptr;
+};
+size_t zones_lds_fixed(int zs, int kx, int ky, size_t accb) { return (size_t)(zs + ky - 1) * (zs + kx - 1) * 4 + 2 * (size_t)(zs + ky - 1) * zs * accb + 16; }
+}  // namespace
+
 int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
-                          int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out, int f32_sums) {
-  if (cost_type == VWGPU_CROSS_CORRELATION) f32_sums = 0;        // (its sums are scaled in float64 anyway)
+                          int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out, int f32_sums, int cert_hi, int* d_zflag,
+                          unsigned long long* d_stats) {
+  const bool cert = cert_hi != INT_MIN;
+  if (cost_type == VWGPU_CROSS_CORRELATION || cert) f32_sums = 0;        // (NCC sums are scaled in float64 anyway)
   const size_t accb = f32_sums ? 4 : 8;
   if (n <= 0) return VWGPU_OK;
   if (!vwgpu_bm_zones_supported(kx, ky)) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "bm_zones: kernel %dx%d too large", kx, ky);
-  std::vector<int2> tiles;
-  build_tiles(zones, n, tiles);
-  if (tiles.empty()) return VWGPU_OK;
+  if (cert && !d_zflag) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "bm_zones: certification without zone flags");
+  const bool ncc = cost_type == VWGPU_CROSS_CORRELATION;
   int max_sx = 1;
   int ax0 = INT32_MAX, ay0 = INT32_MAX, ax1 = INT32_MIN, ay1 = INT32_MIN, bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = INT32_MIN, by1 = INT32_MIN;
+  double total = 0.0;                                            // evaluations of the level
   for (int i = 0; i < n; ++i) {
     const vwgpu_zone_task& z = zones[i];
-    if (z.zw <= 0 || z.zh <= 0) continue;
+    if (z.zw <= 0 || z.zh <= 0 || z.sx <= 0 || z.sy <= 0) continue;
+    if ((long long)z.sx * z.sy > INT32_MAX) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "bm_zones: search volume exceeds the index range");
     max_sx = std::max(max_sx, z.sx);
+    total += (double)z.zw * z.zh * z.sx * z.sy;
     ax0 = std::min(ax0, z.ax); ay0 = std::min(ay0, z.ay); ax1 = std::max(ax1, z.ax + z.zw); ay1 = std::max(ay1, z.ay + z.zh);
     bx0 = std::min(bx0, z.bx); by0 = std::min(by0, z.by);
     bx1 = std::max(bx1, z.bx + z.zw + z.sx - 1); by1 = std::max(by1, z.by + z.zh + z.sy - 1);
   }
-  const size_t PW = ZT + kx - 1, PH = ZT + ky - 1;
-  const size_t fixed = PH * PW * 4 + 2 * PH * ZT * accb + 16;
-  int sxc = (int)std::min<size_t>((size_t)max_sx, ((64 * 1024 - fixed) / (PH * 4)) - PW + 1);
-  if (sxc < 1) sxc = 1;
-  const size_t lds = (((PH * PW + PH * (PW + sxc - 1)) * 4 + 7) & ~size_t(7)) + 2 * PH * ZT * accb;
+  if (total == 0.0) return VWGPU_OK;
+
+  ZPlan plan[2];
+  plan[0].zs = 32; plan[1].zs = 16;
+  for (ZPlan& pl : plan) {
+    const size_t PW = pl.zs + kx - 1, PH = pl.zs + ky - 1;
+    const size_t fixed = zones_lds_fixed(pl.zs, kx, ky, accb);
+    const size_t budget = pl.zs == 32 ? 64 * 1024 : 20 * 1024;     // a wavefront-sized tile keeps its right patch short: more of them fit a CU
+    long long room = (long long)((budget - std::min(budget, fixed)) / (PH * 4)) - (long long)PW + 1;
+    room = std::min<long long>(room, ctx->zone_sxc > 0 ? ctx->zone_sxc : 16);      // (measured: 16 dx per patch keep four workgroups on a CU; longer patches three)
+    pl.sxc = (int)std::max<long long>(1, std::min<long long>(max_sx, room));
+    pl.lds = (((PH * PW + PH * (PW + pl.sxc - 1)) * 4 + 7) & ~size_t(7)) + 2 * PH * pl.zs * accb;
+  }
+
+  // Work items.  A tile is cut when its evaluations exceed `cap` = a third of the level's work per resident workgroup (so that the longest
+  // item cannot hold the launch much longer than an even spread would take), never below 16 disparities of a full tile (the left patch,
+  // the records and the merge are per item).  Items are issued longest first.
+  // Tile size per zone: 16 x 16 tiles when they cover the zone with less padded work than 32 x 32 tiles (a 16-tile costs ~1.4x per pixel:
+  // its patches carry more halo) — the 16 x 16 leaves of the quad tree and the thin zones.
+  const int resident = std::max(1, (int)std::min<size_t>(8, (160 * 1024) / (plan[0].lds + 512))) * ctx->num_cu;
+  const double cap = std::max(16.0 * 32 * 32, total / (3.0 * resident));
+  for (int i = 0; i < n; ++i) {
+    const vwgpu_zone_task& z = zones[i];
+    if (z.zw <= 0 || z.zh <= 0 || z.sx <= 0 || z.sy <= 0) continue;
+    // (Round 4 also built 16 x 16 tiles on one wavefront for the 16 x 16 leaves of the quad tree — on a 32 x 32 tile a quarter of the lanes
+    // have pixels there.  Measured on 1024^2 pyramid tiles: every zone on 16-tiles = the same time (their patches carry 2.6x halo and a
+    // wavefront per workgroup exposes every LDS round trip); both sizes in one level = two launches with a tail each, slower.  Dropped.)
+    const bool small = false;
+    ZPlan& pl = small ? plan[1] : plan[0];
+    const int ZS = pl.zs;
+    const int nx = (z.zw + ZS - 1) / ZS, ny = (z.zh + ZS - 1) / ZS;
+    const long long D = (long long)z.sx * z.sy;
+    for (int ty = 0; ty < ny; ++ty)
+      for (int tx = 0; tx < nx; ++tx) {
+        const int tw = std::min(ZS, z.zw - tx * ZS), th = std::min(ZS, z.zh - ty * ZS);
+        const double px = (double)tw * th;
+        int pieces = (int)std::min<double>((double)D, std::ceil(px * (double)D / cap));
+        if (pieces < 1) pieces = 1;
+        const int txy = tx | (ty << 16);
+        if (pieces == 1) {
+          pl.items.push_back(ZItem{i, txy, 0, (int)D, -1, -1, (int)(px * (double)D), 0});
+          continue;
+        }
+        const int per = (int)((D + pieces - 1) / pieces);
+        const int gate = (int)pl.merges.size();
+        pl.merges.push_back(ZMergeItem{i, txy, pl.nslots, 0, gate, 0, 0, 0});
+        for (long long i0 = 0; i0 < D; i0 += per) {
+          const int cnt = (int)std::min<long long>(per, D - i0);
+          pl.items.push_back(ZItem{i, txy, (int)i0, cnt, pl.nslots++, -1, (int)(px * cnt), 0});
+          pl.merges.back().nitems++;
+        }
+        pl.redo.push_back(ZItem{i, txy, 0, (int)D, -1, gate, 0, 0});
+      }
+  }
+  for (ZPlan& pl : plan)                                        // longest first (pad0 = the item's evaluations; stable: equal items keep the zone order)
+    std::stable_sort(pl.items.begin(), pl.items.end(), [](const ZItem& a, const ZItem& b) { return a.pad0 > b.pad0; });
+  if (plan[0].items.empty() && plan[1].items.empty()) return VWGPU_OK;
 
   PrecView pa{nullptr, 0, 0, 0, 0}, pb{nullptr, 0, 0, 0, 0};
-  if (cost_type == VWGPU_CROSS_CORRELATION) {
+  // partial records of the cut tiles behind the precision images in the scratch arena
+  const size_t rec_bytes = 8 + 8 + 4 + (cert ? 8 : 0) + (cert && ncc ? 8 : 0);
+  size_t part_bytes = 1024;
+  for (ZPlan& pl : plan) part_bytes += vwgpu_align_up((size_t)pl.nslots * pl.zs * pl.zs * rec_bytes + 64, 256);
+  size_t na = 0, nb = 0;
+  if (ncc) {
     pa.x0 = ax0; pa.y0 = ay0; pa.w = ax1 - ax0; pa.h = ay1 - ay0;
     pb.x0 = bx0; pb.y0 = by0; pb.w = bx1 - bx0; pb.h = by1 - by0;
-    const size_t na = vwgpu_align_up((size_t)pa.w * pa.h * 8, 256), nb = vwgpu_align_up((size_t)pb.w * pb.h * 8, 256);
-    int rc = vwgpu_arena_reserve(ctx, &ctx->scratch, na + nb);
-    if (rc) return rc;
-    double* da = static_cast<double*>(ctx->scratch.base);
-    double* db = reinterpret_cast<double*>(static_cast<char*>(ctx->scratch.base) + na);
+    na = vwgpu_align_up((size_t)pa.w * pa.h * 8, 256); nb = vwgpu_align_up((size_t)pb.w * pb.h * 8, 256);
+  }
+  int rc = vwgpu_arena_reserve(ctx, &ctx->scratch, na + nb + part_bytes);
+  if (rc) return rc;
+  char* sbase = static_cast<char*>(ctx->scratch.base);
+  if (ncc) {
+    double* da = reinterpret_cast<double*>(sbase);
+    double* db = reinterpret_cast<double*>(sbase + na);
     vwgpu_prof_scope ps(ctx, "zone_precision");
     const size_t zp_lds = ((size_t)(64 + kx - 1) * (4 + ky - 1) + (size_t)(4 + ky - 1) * 64) * sizeof(double);
     hipLaunchKernelGGL(zone_precision_kernel, dim3((pa.w + 63) / 64, (pa.h + 3) / 4), dim3(64, 4), zp_lds, ctx->stream, A, aw, ah, kx, ky, da, pa.x0, pa.y0, pa.w, pa.h);
     hipLaunchKernelGGL(zone_precision_kernel, dim3((pb.w + 63) / 64, (pb.h + 3) / 4), dim3(64, 4), zp_lds, ctx->stream, B, bw, bh, kx, ky, db, pb.x0, pb.y0, pb.w, pb.h);
     pa.p = da; pb.p = db;
   }
-  const vwgpu_zone_task* dz; const int2* dt;
-  int rc = upload_tables(ctx, zones, n, tiles, &dz, &dt);
-  if (rc) return rc;
-  vwgpu_prof_scope ps(ctx, "bm_zones");
-  const dim3 grd((unsigned)tiles.size()), blk(ZTHREADS);
-#define VW_ZN(C, K) do { if (f32_sums) hipLaunchKernelGGL((bm_zones_kernel<C, K, float>), grd, blk, lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, dt, sxc, pa, pb, out); \
-                         else hipLaunchKernelGGL((bm_zones_kernel<C, K, double>), grd, blk, lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, dt, sxc, pa, pb, out); } while (0)
-#define VW_ZN_K(C) do { switch (kx == ky ? kx : 0) { case 3: VW_ZN(C, 3); break; case 5: VW_ZN(C, 5); break; case 7: VW_ZN(C, 7); break; \
-                                                     case 9: VW_ZN(C, 9); break; case 11: VW_ZN(C, 11); break; case 13: VW_ZN(C, 13); break; \
-                                                     default: VW_ZN(C, 0); break; } } while (0)
-  switch (cost_type) {
-    case VWGPU_CROSS_CORRELATION: VW_ZN_K(VWGPU_CROSS_CORRELATION); break;
-    case VWGPU_SQUARED_DIFFERENCE: VW_ZN_K(VWGPU_SQUARED_DIFFERENCE); break;
-    default: VW_ZN_K(VWGPU_ABSOLUTE_DIFFERENCE); break;
+  {
+    char* q = sbase + na + nb;
+    for (ZPlan& pl : plan) {
+      const size_t slot_px = (size_t)pl.nslots * pl.zs * pl.zs;
+      char* q0 = q;
+      pl.P.best = reinterpret_cast<double*>(q); q += slot_px * 8;
+      pl.P.worst = reinterpret_cast<double*>(q); q += slot_px * 8;
+      if (cert) { pl.P.second = reinterpret_cast<double*>(q); q += slot_px * 8; }
+      if (cert && ncc) { pl.P.rpmax = reinterpret_cast<double*>(q); q += slot_px * 8; }
+      pl.P.idx = reinterpret_cast<int*>(q);
+      q = q0 + vwgpu_align_up(slot_px * rec_bytes + 64, 256);
+    }
   }
+
+  // certification constants per zone
+  std::vector<ZCert> zc;
+  if (cert) {
+    zc.resize((size_t)n);
+    const double e_el = cost_type == VWGPU_ABSOLUTE_DIFFERENCE ? std::ldexp(1.0, cert_hi + 2)          // |a - b| < 2^(hi + 2)
+                        : cost_type == VWGPU_SQUARED_DIFFERENCE ? std::ldexp(1.0, 2 * cert_hi + 4)     // (a - b)^2
+                        : std::ldexp(1.0, 2 * cert_hi + 2);                                            // |a b|, a^2
+    for (int i = 0; i < n; ++i) {
+      const vwgpu_zone_task& z = zones[i];
+      zc[i].eps_s = sum_error_units(kx, ky, z.zw, z.zh) * e_el;
+      zc[i].eps_ll = zc[i].eps_s;
+      zc[i].eps_rr = sum_error_units(kx, ky, z.zw + z.sx - 1, z.zh + z.sy - 1) * e_el;
+      zc[i].pad = 0.0;
+    }
+  }
+  const void* src[8] = {zones, zc.data(), plan[0].items.data(), plan[0].merges.data(), plan[0].redo.data(),
+                        plan[1].items.data(), plan[1].merges.data(), plan[1].redo.data()};
+  const size_t bytes[8] = {(size_t)n * sizeof(vwgpu_zone_task), zc.size() * sizeof(ZCert),
+                           plan[0].items.size() * sizeof(ZItem), plan[0].merges.size() * sizeof(ZMergeItem), plan[0].redo.size() * sizeof(ZItem),
+                           plan[1].items.size() * sizeof(ZItem), plan[1].merges.size() * sizeof(ZMergeItem), plan[1].redo.size() * sizeof(ZItem)};
+  char* d[8]; char* dzero = nullptr;
+  // zeroed tail: per tile size the slot flags, then the redo flags of the cut tiles
+  const size_t nflags = (size_t)plan[0].nslots + plan[0].merges.size() + plan[1].nslots + plan[1].merges.size();
+  rc = upload_pieces(ctx, src, bytes, 8, d, nflags * sizeof(int), &dzero);
+  if (rc) return rc;
+  const vwgpu_zone_task* dz = reinterpret_cast<const vwgpu_zone_task*>(d[0]);
+  {
+    int* f = reinterpret_cast<int*>(dzero);
+    for (int k = 0; k < 2; ++k) {
+      plan[k].d_items = reinterpret_cast<const ZItem*>(d[2 + 3 * k]);
+      plan[k].d_merges = reinterpret_cast<const ZMergeItem*>(d[3 + 3 * k]);
+      plan[k].d_redo = reinterpret_cast<const ZItem*>(d[4 + 3 * k]);
+      plan[k].P.bad = f; f += plan[k].nslots;
+      plan[k].P.redo = f; f += plan[k].merges.size();
+    }
+  }
+  ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats};
+  if (cert) VWGPU_HIP(ctx, hipMemsetAsync(d_zflag, 0, (size_t)n * sizeof(int), ctx->stream));
+
+#define VW_ZN4(C_, K_, A_, T_, S_) hipLaunchKernelGGL((bm_zones_kernel<C_, K_, A_, T_, S_>), grd, dim3(S_ * S_ / 4), pl.lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, tab, pl.sxc, pa, pb, out, pl.P, C)
+#define VW_ZN3(C_, K_, A_, T_) VW_ZN4(C_, K_, A_, T_, 32)
+#define VW_ZN(C_, K_) do { if (cert) VW_ZN3(C_, K_, double, true); else if (f32_sums) VW_ZN3(C_, K_, float, false); else VW_ZN3(C_, K_, double, false); } while (0)
+#define VW_ZN_K(C_) do { switch (kx == ky ? kx : 0) { case 3: VW_ZN(C_, 3); break; case 5: VW_ZN(C_, 5); break; case 7: VW_ZN(C_, 7); break; \
+                                                     case 9: VW_ZN(C_, 9); break; case 11: VW_ZN(C_, 11); break; case 13: VW_ZN(C_, 13); break; \
+                                                     default: VW_ZN(C_, 0); break; } } while (0)
+#define VW_ZN_C() do { switch (cost_type) { case VWGPU_CROSS_CORRELATION: VW_ZN_K(VWGPU_CROSS_CORRELATION); break; \
+                                            case VWGPU_SQUARED_DIFFERENCE: VW_ZN_K(VWGPU_SQUARED_DIFFERENCE); break; \
+                                            default: VW_ZN_K(VWGPU_ABSOLUTE_DIFFERENCE); break; } } while (0)
+#define VW_MG2(C_, T_) hipLaunchKernelGGL((zones_merge_kernel<C_, T_, 32>), mgrd, dim3(256), 0, ctx->stream, dz, pl.d_merges, pa, out, pl.P, C)
+#define VW_MG(C_) do { if (cert) VW_MG2(C_, true); else VW_MG2(C_, false); } while (0)
+  for (ZPlan& pl : plan) {                                      // the 32-tiles hold the long items: first
+    if (pl.items.empty()) continue;
+    vwgpu_prof_scope ps(ctx, "bm_zones");
+    const dim3 grd((unsigned)pl.items.size());
+    const ZItem* tab = pl.d_items;
+    VW_ZN_C();
+  }
+  for (ZPlan& pl : plan) {
+    if (pl.merges.empty()) continue;
+    {
+      vwgpu_prof_scope ps(ctx, "bm_zones_merge");
+      const dim3 mgrd((unsigned)pl.merges.size());
+      switch (cost_type) {
+        case VWGPU_CROSS_CORRELATION: VW_MG(VWGPU_CROSS_CORRELATION); break;
+        case VWGPU_SQUARED_DIFFERENCE: VW_MG(VWGPU_SQUARED_DIFFERENCE); break;
+        default: VW_MG(VWGPU_ABSOLUTE_DIFFERENCE); break;
+      }
+    }
+    // Non-finite costs (NCC over an all-zero window: 0 * inf) make the chain order dependent: the flagged tiles again, as one item each.
+    // Order-free SAD / SSD levels hold finite costs only; with certification a non-finite cost flags the zone instead.
+    if (ncc && !cert) {
+      vwgpu_prof_scope ps(ctx, "bm_zones_redo");
+      const dim3 grd((unsigned)pl.redo.size());
+      const ZItem* tab = pl.d_redo;
+      VW_ZN_C();
+    }
+  }
+#undef VW_MG
+#undef VW_MG2
+#undef VW_ZN_C
 #undef VW_ZN_K
 #undef VW_ZN
+#undef VW_ZN3
+#undef VW_ZN4
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }

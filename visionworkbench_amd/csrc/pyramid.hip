@@ -581,6 +581,10 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   // Class of every level: when the box sums of a level could round, its zones are matched in the reference's own
   // summation order (bm_exact.hip); integer imagery and most float imagery are order free and take the tile kernels.
   std::vector<char> exact_level(L + 1, 0), f32_level(L + 1, 0);      // f32_level: the window sums are exact in float32 as well (bm_zones.hip)
+  // cert_hi[level] != INT_MIN: the level is not order free but finite — its zones go through the tile kernels first, which certify every pixel
+  // against a bound on the difference to the reference's running sums (bm_zones.hip) and flag the zones that hold a pixel they cannot
+  // certify; only those are redone in the reference's order (VWGPU_OPT_CERTIFY = 0: every zone of such a level, as in round 3)
+  std::vector<int> cert_hi(L + 1, INT_MIN);
   if (!use_sgm) {
     int* d_cells = A.take<int>(4 * (size_t)(L + 1));
     if (!d_cells) return fail_mem();
@@ -598,9 +602,19 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     for (int i = 0; i <= L; ++i) {
       exact_level[i] = !vwgpu_sums_order_free(P->cost_type, kx, ky, cells[4 * i], cells[4 * i + 1], cells[4 * i + 2]);
       f32_level[i] = vwgpu_sums_bits(P->cost_type, kx, ky, cells[4 * i], cells[4 * i + 1], cells[4 * i + 2]) <= 24;      // (byte imagery under SAD)
+      if (exact_level[i] && ctx->certify && (cells[4 * i + 2] & 1) == 0 && cells[4 * i] != INT_MAX      // (bit 0: a non-finite pixel; bit 1 only says "negative pixels")
+          && cells[4 * i + 1] < 60 && cells[4 * i + 1] > -60)
+        cert_hi[i] = cells[4 * i + 1];
     }
   }
 
+  // certification statistics (VWGPU_OPT_TRACE bit 2): pixels in certified tiles / in tiles that flagged their zone
+  unsigned long long* d_cert_stats = nullptr;
+  if (ctx->trace & 4) {
+    d_cert_stats = A.take<unsigned long long>(4);
+    if (!d_cert_stats) return fail_mem();
+    VWGPU_HIP(ctx, hipMemsetAsync(d_cert_stats, 0, 32, st));
+  }
   // level loop
   int32_t* disp = A.take<int32_t>((size_t)bw * bh * 3);
   int32_t* disp2 = A.take<int32_t>((size_t)bw * bh * 3);
@@ -760,14 +774,24 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         for (auto const& kv : hist) fprintf(stderr, "    %-34s %6zu zones %12zu evaluations\n", kv.first.c_str(), kv.second.first, kv.second.second);
       }
       if (lr_active && rl_pixels) { if ((rc = vwgpu_arena_reserve(ctx, &ctx->zrl, rl_pixels * 12))) return rc; }
-      if (exact) rc = vwgpu_launch_bm_exact(ctx, P->cost_type, Lv.p, Lv.w, Lv.h, Lv.w, Rv.p, Rv.w, Rv.h, Rv.w, kx, ky, t1.data(), (int)t1.size(), disp);
-      else rc = vwgpu_launch_bm_zones(ctx, P->cost_type, Lv.p, Lv.w, Lv.h, Rv.p, Rv.w, Rv.h, kx, ky, t1.data(), (int)t1.size(), disp, f32_level[level]);
-      if (rc) return rc;
+      // One matching pass over a zone list: the tile kernels when the level is order free; the tile kernels WITH certification plus the
+      // exact-order kernels gated by the zone flags when it is finite but not order free; the exact-order kernels alone otherwise.
+      auto match = [&](const float* a, int aw_, int ah_, const float* b, int bw_, int bh_, std::vector<vwgpu_zone_task> const& tz, int32_t* dst) -> int {
+        if (tz.empty()) return VWGPU_OK;
+        if (!exact) return vwgpu_launch_bm_zones(ctx, P->cost_type, a, aw_, ah_, b, bw_, bh_, kx, ky, tz.data(), (int)tz.size(), dst, f32_level[level]);
+        if (cert_hi[level] != INT_MIN) {
+          int* zflag = A.take<int>(tz.size());
+          if (!zflag) return fail_mem();
+          int rc2 = vwgpu_launch_bm_zones(ctx, P->cost_type, a, aw_, ah_, b, bw_, bh_, kx, ky, tz.data(), (int)tz.size(), dst, 0, cert_hi[level], zflag, d_cert_stats);
+          if (rc2) return rc2;
+          return vwgpu_launch_bm_exact(ctx, P->cost_type, a, aw_, ah_, aw_, b, bw_, bh_, bw_, kx, ky, tz.data(), (int)tz.size(), dst, zflag);
+        }
+        return vwgpu_launch_bm_exact(ctx, P->cost_type, a, aw_, ah_, aw_, b, bw_, bh_, bw_, kx, ky, tz.data(), (int)tz.size(), dst);
+      };
+      if ((rc = match(Lv.p, Lv.w, Lv.h, Rv.p, Rv.w, Rv.h, t1, disp))) return rc;
       if (lr_active) {
         int32_t* rlbuf = static_cast<int32_t*>(ctx->zrl.base);
-        if (exact) rc = vwgpu_launch_bm_exact(ctx, P->cost_type, Rv.p, Rv.w, Rv.h, Rv.w, Lv.p, Lv.w, Lv.h, Lv.w, kx, ky, t2.data(), (int)t2.size(), rlbuf);
-        else rc = vwgpu_launch_bm_zones(ctx, P->cost_type, Rv.p, Rv.w, Rv.h, Lv.p, Lv.w, Lv.h, kx, ky, t2.data(), (int)t2.size(), rlbuf, f32_level[level]);
-        if (rc) return rc;
+        if ((rc = match(Rv.p, Rv.w, Rv.h, Lv.p, Lv.w, Lv.h, t2, rlbuf))) return rc;
         if ((rc = vwgpu_launch_zone_lr(ctx, t3.data(), (int)t3.size(), disp, rlbuf, P->consistency_threshold, lr_diff, lr_stride))) return rc;
       }
     } else if (!use_sgm)
@@ -902,6 +926,14 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   else
     hipLaunchKernelGGL(finish_kernel, grid2(bw, bh), kBlk, 0, st, disp, bw, bh, search.x0, search.y0, out, os);
   VWGPU_HIP(ctx, hipGetLastError());
+  if (d_cert_stats) {
+    unsigned long long got[4] = {0, 0, 0, 0};
+    VWGPU_HIP(ctx, hipMemcpyAsync(got, d_cert_stats, sizeof got, hipMemcpyDeviceToHost, st));
+    VWGPU_HIP(ctx, hipStreamSynchronize(st));
+    ctx->cert_px[0] += got[0]; ctx->cert_px[1] += got[1];
+    fprintf(stderr, "certification: %llu pixels in certified tiles, %llu in tiles that sent their zone to the exact-order kernels (%.2f %%)\n",
+            got[0], got[1], got[0] + got[1] ? 100.0 * (double)got[1] / (double)(got[0] + got[1]) : 0.0);
+  }
   return VWGPU_OK;
 }
 

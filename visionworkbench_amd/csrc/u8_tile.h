@@ -69,7 +69,45 @@ __device__ __forceinline__ void patch_right_edge(const float* __restrict__ img, 
 // latency.  Columns beyond the first `nthreads` groups (the search margin) are spread evenly over the workgroup.
 // Groups straddling the right image edge (at most one per row) are patched by a scalar tail loop.
 template <int NROWS>
-__device__ __forceinline__ void stage_u8_rows(const float* __restrict__ img, ptrdiff_t stride, int w, int h,
+struct U8MainLoads { float4 v[NROWS]; };
+
+// main part of a tile: group g = tid of every row.  `issue` requests the NROWS loads, `finish` converts and stores them.
+template <int NROWS>
+__device__ __forceinline__ void stage_u8_main_issue(const float* __restrict__ img, ptrdiff_t stride, int w, int h, int x0, int y0, int ndw,
+                                                    int tid, U8MainLoads<NROWS>& ld) {
+  const bool vec4 = ((reinterpret_cast<uintptr_t>(img) & 15) == 0) && ((stride & 3) == 0);
+  if (tid < ndw) {
+    const int x = x0 + 4 * tid;
+    const bool colin = x + 3 < w;
+    const int off = colin ? x : 0;
+#pragma unroll
+    for (int r = 0; r < NROWS; ++r) {
+      const float* rowp = (y0 + r < h) ? img + (ptrdiff_t)(y0 + r) * stride : img;   // uniform
+      if (vec4) ld.v[r] = *reinterpret_cast<const float4*>(rowp + off);
+      else ld.v[r] = make_float4(rowp[off], rowp[off + (colin ? 1 : 0)], rowp[off + (colin ? 2 : 0)], rowp[off + (colin ? 3 : 0)]);
+    }
+  }
+}
+template <int NROWS>
+__device__ __forceinline__ void stage_u8_main_finish(int w, int h, int x0, int y0, int ndw, int dst_pitch_dw, u32* __restrict__ dst, int tid,
+                                                     const U8MainLoads<NROWS>& ld, u32& acc) {
+  if (tid < ndw) {
+    const int g = tid, x = x0 + 4 * g;
+    const bool colin = x + 3 < w;
+#pragma unroll
+    for (int r = 0; r < NROWS; ++r) {
+      u32 a = 0;
+      const u32 p = pack4_check(ld.v[r], a);
+      const bool inb = colin && (y0 + r < h);
+      if (inb) acc |= a;
+      if (colin || x >= w) dst[r * dst_pitch_dw + g] = inb ? p : 0u;   // a straddling group belongs to patch_right_edge
+    }
+  }
+}
+
+// remainder columns [nthreads, ndw): NROWS * rem items spread over all threads, 4 in flight per thread; then the straddling groups
+template <int NROWS>
+__device__ __forceinline__ void stage_u8_rest(const float* __restrict__ img, ptrdiff_t stride, int w, int h,
                                               int x0, int y0, int ndw, int dst_pitch_dw,
                                               u32* __restrict__ dst, int tid, int nthreads, u32& acc) {
   const bool vec4 = ((reinterpret_cast<uintptr_t>(img) & 15) == 0) && ((stride & 3) == 0);
@@ -77,27 +115,6 @@ __device__ __forceinline__ void stage_u8_rows(const float* __restrict__ img, ptr
     if (vec4) return *reinterpret_cast<const float4*>(rowp + off);
     return make_float4(rowp[off], rowp[off + (full ? 1 : 0)], rowp[off + (full ? 2 : 0)], rowp[off + (full ? 3 : 0)]);
   };
-  // main part: group g = tid, every row
-  if (tid < ndw) {
-    const int g = tid, x = x0 + 4 * g;
-    const bool colin = x + 3 < w;
-    const int off = colin ? x : 0;
-    float4 v[NROWS];
-#pragma unroll
-    for (int r = 0; r < NROWS; ++r) {
-      const float* rowp = (y0 + r < h) ? img + (ptrdiff_t)(y0 + r) * stride : img;   // uniform
-      v[r] = load4(rowp, off, colin);
-    }
-#pragma unroll
-    for (int r = 0; r < NROWS; ++r) {
-      u32 a = 0;
-      const u32 p = pack4_check(v[r], a);
-      const bool inb = colin && (y0 + r < h);
-      if (inb) acc |= a;
-      if (colin || x >= w) dst[r * dst_pitch_dw + g] = inb ? p : 0u;   // a straddling group belongs to patch_right_edge
-    }
-  }
-  // remainder columns [nthreads, ndw): NROWS * rem items spread over all threads, 4 in flight per thread
   const int rem = ndw - nthreads;
   if (rem > 0) {
     const int total = NROWS * rem;
@@ -127,6 +144,32 @@ __device__ __forceinline__ void stage_u8_rows(const float* __restrict__ img, ptr
     }
   }
   patch_right_edge<NROWS>(img, stride, w, h, x0, y0, ndw, dst_pitch_dw, dst, tid, nthreads, acc);
+}
+
+template <int NROWS>
+__device__ __forceinline__ void stage_u8_rows(const float* __restrict__ img, ptrdiff_t stride, int w, int h,
+                                              int x0, int y0, int ndw, int dst_pitch_dw,
+                                              u32* __restrict__ dst, int tid, int nthreads, u32& acc) {
+  U8MainLoads<NROWS> ld;
+  stage_u8_main_issue<NROWS>(img, stride, w, h, x0, y0, ndw, tid, ld);
+  stage_u8_main_finish<NROWS>(w, h, x0, y0, ndw, dst_pitch_dw, dst, tid, ld, acc);
+  stage_u8_rest<NROWS>(img, stride, w, h, x0, y0, ndw, dst_pitch_dw, dst, tid, nthreads, acc);
+}
+
+// Two tiles (the LEFT and RIGHT windows of a matcher) with the main loads of BOTH in flight before the first conversion: a
+// workgroup that stages one image after the other pays the memory latency twice (the 8-row strips of a multi-GPU run are latency-,
+// not bandwidth-bound: 256 workgroups x 122 KB in 8.8 us).
+template <int NROWS>
+__device__ __forceinline__ void stage_u8_rows2(const float* __restrict__ A, ptrdiff_t as, int aw, int ah, int andw, int apitch, u32* __restrict__ adst,
+                                               const float* __restrict__ B, ptrdiff_t bs, int bw, int bh, int bndw, int bpitch, u32* __restrict__ bdst,
+                                               int x0, int y0, int tid, int nthreads, u32& acc) {
+  U8MainLoads<NROWS> la, lb;
+  stage_u8_main_issue<NROWS>(A, as, aw, ah, x0, y0, andw, tid, la);
+  stage_u8_main_issue<NROWS>(B, bs, bw, bh, x0, y0, bndw, tid, lb);
+  stage_u8_main_finish<NROWS>(aw, ah, x0, y0, andw, apitch, adst, tid, la, acc);
+  stage_u8_main_finish<NROWS>(bw, bh, x0, y0, bndw, bpitch, bdst, tid, lb, acc);
+  stage_u8_rest<NROWS>(A, as, aw, ah, x0, y0, andw, apitch, adst, tid, nthreads, acc);
+  stage_u8_rest<NROWS>(B, bs, bw, bh, x0, y0, bndw, bpitch, bdst, tid, nthreads, acc);
 }
 
 }  // namespace vwgpu_u8

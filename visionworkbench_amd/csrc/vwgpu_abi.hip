@@ -34,14 +34,14 @@ int vwgpu_arena_reserve(vwgpu_ctx* ctx, vwgpu_arena* a, size_t bytes) {
     (void)hipGetLastError();
     (void)hipStreamSynchronize(ctx->stream);
     for (void* g : ctx->graveyard) (void)hipFree(g);
-    ctx->graveyard.clear();
+    ctx->graveyard.clear(); ctx->graveyard_bytes = 0;
     if (a->base) { (void)hipFree(a->base); a->base = nullptr; a->cap = 0; }
     VWGPU_HIP(ctx, hipMalloc(&fresh, vwgpu_align_up(bytes + bytes / 4, 1 << 20)));
     a->base = fresh;
     a->cap = vwgpu_align_up(bytes + bytes / 4, 1 << 20);
     return VWGPU_OK;
   }
-  if (a->base) ctx->graveyard.push_back(a->base);
+  if (a->base) { ctx->graveyard.push_back(a->base); ctx->graveyard_bytes += a->cap; }
   a->base = fresh;
   a->cap = want;
   return VWGPU_OK;
@@ -149,32 +149,44 @@ int vwgpu_create(vwgpu_ctx** out, int device) {
   return VWGPU_OK;
 }
 
+// Every device arena of a context.  The stream must be idle: nothing queued may still use the blocks.
+static size_t free_arenas(vwgpu_ctx* ctx) {
+  size_t freed = ctx->graveyard_bytes;
+  vwgpu_arena* all[] = {&ctx->scratch, &ctx->flags, &ctx->filt, &ctx->misc, &ctx->pyr, &ctx->ztab, &ctx->zrl, &ctx->zext, &ctx->sgm,
+                        &ctx->sgm_main, &ctx->sgm_bnd, &ctx->xvol, &ctx->xtab, &ctx->xcarry, &ctx->staging};
+  for (vwgpu_arena* a : all) {
+    if (a->base) { (void)hipFree(a->base); freed += a->cap; }
+    a->base = nullptr; a->cap = 0;
+  }
+  for (auto& lr : ctx->leaf_rects) if (lr.d_rects) (void)hipFree(lr.d_rects);
+  ctx->leaf_rects.clear();
+  for (void* g : ctx->graveyard) (void)hipFree(g);
+  ctx->graveyard.clear(); ctx->graveyard_bytes = 0;
+  // state that pointed into the arenas
+  ctx->flags_init = false; ctx->flags_base_seen = nullptr; ctx->last_flag = nullptr;
+  ctx->sgm_epoch = 0;                               // (sgm_bnd is zero-initialised on its next reservation)
+  return freed;
+}
+
 void vwgpu_destroy(vwgpu_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   prof_clear(ctx);
-  if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
-  if (ctx->flags.base) (void)hipFree(ctx->flags.base);
-  if (ctx->filt.base) (void)hipFree(ctx->filt.base);
-  if (ctx->misc.base) (void)hipFree(ctx->misc.base);
-  if (ctx->pyr.base) (void)hipFree(ctx->pyr.base);
-  if (ctx->ztab.base) (void)hipFree(ctx->ztab.base);
-  if (ctx->zrl.base) (void)hipFree(ctx->zrl.base);
-  if (ctx->zext.base) (void)hipFree(ctx->zext.base);
+  (void)free_arenas(ctx);
   if (ctx->host_ring) (void)hipHostFree(ctx->host_ring);
   for (int i = 0; i < 2; ++i) if (ctx->ring_event[i]) (void)hipEventDestroy(ctx->ring_event[i]);
-  if (ctx->sgm.base) (void)hipFree(ctx->sgm.base);
-  if (ctx->sgm_main.base) (void)hipFree(ctx->sgm_main.base);
-  if (ctx->sgm_bnd.base) (void)hipFree(ctx->sgm_bnd.base);
-  for (auto& lr : ctx->leaf_rects) if (lr.d_rects) (void)hipFree(lr.d_rects);
-  if (ctx->xvol.base) (void)hipFree(ctx->xvol.base);
-  if (ctx->xtab.base) (void)hipFree(ctx->xtab.base);
-  if (ctx->xcarry.base) (void)hipFree(ctx->xcarry.base);
-  if (ctx->staging.base) (void)hipFree(ctx->staging.base);
-  for (void* g : ctx->graveyard) (void)hipFree(g);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
+}
+
+int vwgpu_trim(vwgpu_ctx* ctx, size_t* freed_bytes) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t freed = free_arenas(ctx);
+  if (freed_bytes) *freed_bytes = freed;
+  return VWGPU_OK;
 }
 
 int vwgpu_set_stream(vwgpu_ctx* ctx, void* hip_stream) {
@@ -201,6 +213,11 @@ int vwgpu_reset_stream(vwgpu_ctx* ctx) {
 int vwgpu_synchronize(vwgpu_ctx* ctx) {
   if (!ctx) return VWGPU_ERR_ARGUMENT;
   VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // a safe point: nothing queued can still use the blocks the arenas have outgrown (they used to stay until vwgpu_destroy)
+  if (!ctx->graveyard.empty()) {
+    for (void* g : ctx->graveyard) (void)hipFree(g);
+    ctx->graveyard.clear(); ctx->graveyard_bytes = 0;
+  }
   return VWGPU_OK;
 }
 
@@ -219,7 +236,9 @@ int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value) {
   // the options below select between variants that return identical results; out-of-range values are refused
   if (option == VWGPU_OPT_SAD_GROUPS && value >= 0 && value <= 2) { ctx->sad_groups = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_EXACT_SCRATCH_MB && value >= 16 && value <= 65536) { ctx->exact_scratch_mb = value; return VWGPU_OK; }
-  if (option == VWGPU_OPT_TRACE && value >= 0 && value <= 3) { ctx->trace = value; return VWGPU_OK; }
+  if (option == VWGPU_OPT_TRACE && value >= 0 && value <= 7) { ctx->trace = value; ctx->cert_px[0] = ctx->cert_px[1] = 0; return VWGPU_OK; }
+  if (option == VWGPU_OPT_CERTIFY && (value == 0 || value == 1)) { ctx->certify = value; return VWGPU_OK; }
+  if (option == VWGPU_OPT_ZONE_SXC && value >= 0 && value <= 4096) { ctx->zone_sxc = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_SGM_SWEEP && value >= 0 && value <= 15) { ctx->sgm_sweep = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_EXACT_LDS && value >= 0 && value <= 2) { ctx->exact_lds = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_MGM_SWEEP && value >= 0 && value <= 15) { ctx->mgm_sweep = value; return VWGPU_OK; }
@@ -256,6 +275,13 @@ int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value) {
   if (option == VWGPU_OPT_EXACT_SPLIT) { *value = ctx->exact_split; return VWGPU_OK; }
   if (option == VWGPU_OPT_CORR_MFMA) { *value = ctx->corr_mfma; return VWGPU_OK; }
   if (option == VWGPU_OPT_HOST_RING_KB) { *value = ctx->host_ring_kb; return VWGPU_OK; }
+  if (option == VWGPU_OPT_CERTIFY) { *value = ctx->certify; return VWGPU_OK; }
+  if (option == VWGPU_OPT_ZONE_SXC) { *value = ctx->zone_sxc; return VWGPU_OK; }
+  if (option == VWGPU_OPT_CERT_PERMILLE) {          // share of the pixels (per mille) that were certified since VWGPU_OPT_TRACE was last set; -1: none counted
+    const unsigned long long all = ctx->cert_px[0] + ctx->cert_px[1];
+    *value = all ? (int)((ctx->cert_px[0] * 1000ull) / all) : -1;
+    return VWGPU_OK;
+  }
   if (option == VWGPU_OPT_HOST_RING_WRAPS) { *value = (int)(ctx->ring_wraps & 0x7fffffff); return VWGPU_OK; }
   return VWGPU_ERR_ARGUMENT;
 }

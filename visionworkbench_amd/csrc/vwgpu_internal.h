@@ -32,7 +32,8 @@ struct vwgpu_ctx {
   bool profiling = false;
   std::vector<vwgpu_prof_rec> prof;
   std::vector<hipEvent_t> event_pool;
-  std::vector<void*> graveyard;   // outgrown arena blocks (vwgpu_arena_reserve): released with the context
+  std::vector<void*> graveyard;   // outgrown arena blocks (vwgpu_arena_reserve): released by vwgpu_synchronize / vwgpu_trim / with the context
+  size_t graveyard_bytes = 0;
   vwgpu_arena scratch;   // kernel scratch (NCC precision images)
   vwgpu_arena flags;     // two alternating "input not representable" flags of the packed-u8 path
   bool flags_init = false;
@@ -76,6 +77,9 @@ struct vwgpu_ctx {
   int corr_mfma = 0;          // VWGPU_OPT_CORR_MFMA: 1 = SSD / NCC on bytes take the matrix-core kernel where instantiated (measured slower), 0 = the v_dot4 kernels
   int exact_lds = 0;          // VWGPU_OPT_EXACT_LDS: 0 never (default), 1 small zones of a multi-zone call in LDS, 2 also single-zone calls
   int trace = 0;              // VWGPU_OPT_TRACE
+  int certify = 1;            // VWGPU_OPT_CERTIFY
+  int zone_sxc = 0;           // VWGPU_OPT_ZONE_SXC: 0 = 16 dx per right patch, else at most this many
+  unsigned long long cert_px[2] = {0, 0};   // with VWGPU_OPT_TRACE bit 2: pixels in certified tiles / in flagged tiles so far (VWGPU_OPT_CERT_PERMILLE)
   int num_cu = 256;
 };
 
@@ -168,7 +172,7 @@ int vwgpu_float_grain(vwgpu_ctx* ctx, const float* a, int aw, int ah, ptrdiff_t 
 void vwgpu_launch_float_grain(vwgpu_ctx* ctx, int n, const float* const* img, const int* w, const int* h, const ptrdiff_t* stride, int* const* d_cells);
 int vwgpu_launch_bm_exact(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, ptrdiff_t as,
                           const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky,
-                          const vwgpu_zone_task* zones, int n, int32_t* out);
+                          const vwgpu_zone_task* zones, int n, int32_t* out, const int* d_gate = nullptr);   // d_gate[i] == 0 (device): zone i is skipped
 int vwgpu_launch_box_sum_exact(vwgpu_ctx* ctx, const float* img, int w, int h, ptrdiff_t stride, int kx, int ky, double* d_out);
 
 int vwgpu_launch_lr_check(vwgpu_ctx* ctx, int32_t* l2r, int lw, int lh, ptrdiff_t ls,
@@ -218,8 +222,11 @@ struct vwgpu_zone_task {
   int addx, addy;      // added to the winning disparity index of every pixel
 };
 bool vwgpu_bm_zones_supported(int kx, int ky);
+// f32_sums: vwgpu_sums_bits <= 24 for BOTH images.  cert_hi != INT_MIN: certify against the reference's summation order (bm_zones.hip),
+// d_zflag[n] receives the zones that need vwgpu_launch_bm_exact; d_stats (optional): {pixels in certified tiles, in flagged tiles}
 int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
-                          int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out, int f32_sums = 0);   // f32_sums: vwgpu_sums_bits <= 24 for BOTH images
+                          int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out, int f32_sums = 0,
+                          int cert_hi = (-2147483647 - 1), int* d_zflag = nullptr, unsigned long long* d_stats = nullptr);
 // lr tasks: ax = pixel offset of the zone's R->L image, (bx, by) = its size, (sx, sy) = the zone's origin in the diff image
 int vwgpu_launch_zone_lr(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, int32_t* l2r, const int32_t* r2l, float thr,
                          float* diff2, ptrdiff_t dstride);

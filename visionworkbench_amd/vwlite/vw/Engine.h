@@ -80,6 +80,8 @@ inline vwgpu_ctx* thread_context(int device = -1) {
   if (device < 0) device = thread_device();
   vwgpu_ctx*& ctx = tc.by_device[device];
   if (!ctx) {
+    if (vwgpu_abi_version() != VWGPU_ABI_VERSION)     // e.g. vwgpu_sgm_params grew between versions 1 and 2: never pass structs across a mismatch
+      vw_throw(LogicErr() << "libvwgpu.so speaks ABI version " << vwgpu_abi_version() << ", these headers were written for " << VWGPU_ABI_VERSION);
     int rc = vwgpu_create(&ctx, device);
     if (rc != VWGPU_OK) {
       ctx = nullptr;
