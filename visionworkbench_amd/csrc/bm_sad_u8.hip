@@ -177,7 +177,10 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
 
   // ---- LEFT: float tile -> u8 in LDS (borrowing the entry array) -> per-lane register windows ----
   // Both tiles are staged before anything else is live in registers (the LEFT tile borrows the entry array).
-  stage_u8_rows2<NR>(L, ls, lw, lh, C::LBW, C::LBW, ent, R, rs, rcw, rch, bpitch, bpitch, base, x0, y0, tid, NT, bad_acc);
+  // (both images' main loads in flight before the first conversion — one memory latency instead of two — was tried for the
+  // latency-bound 1/8 strips in round 4: nothing there, 2 us slower at 4096^2; the tiles are staged one after the other)
+  stage_u8_rows<NR>(L, ls, lw, lh, x0, y0, C::LBW, C::LBW, ent, tid, NT, bad_acc);
+  stage_u8_rows<NR>(R, rs, rcw, rch, x0, y0, bpitch, bpitch, base, tid, NT, bad_acc);
   __syncthreads();
   u64 win[NR][NW];                                  // win[r][n] = bytes L[q+4n .. q+4n+7]
 #pragma unroll

@@ -156,20 +156,4 @@ __device__ __forceinline__ void stage_u8_rows(const float* __restrict__ img, ptr
   stage_u8_rest<NROWS>(img, stride, w, h, x0, y0, ndw, dst_pitch_dw, dst, tid, nthreads, acc);
 }
 
-// Two tiles (the LEFT and RIGHT windows of a matcher) with the main loads of BOTH in flight before the first conversion: a
-// workgroup that stages one image after the other pays the memory latency twice (the 8-row strips of a multi-GPU run are latency-,
-// not bandwidth-bound: 256 workgroups x 122 KB in 8.8 us).
-template <int NROWS>
-__device__ __forceinline__ void stage_u8_rows2(const float* __restrict__ A, ptrdiff_t as, int aw, int ah, int andw, int apitch, u32* __restrict__ adst,
-                                               const float* __restrict__ B, ptrdiff_t bs, int bw, int bh, int bndw, int bpitch, u32* __restrict__ bdst,
-                                               int x0, int y0, int tid, int nthreads, u32& acc) {
-  U8MainLoads<NROWS> la, lb;
-  stage_u8_main_issue<NROWS>(A, as, aw, ah, x0, y0, andw, tid, la);
-  stage_u8_main_issue<NROWS>(B, bs, bw, bh, x0, y0, bndw, tid, lb);
-  stage_u8_main_finish<NROWS>(aw, ah, x0, y0, andw, apitch, adst, tid, la, acc);
-  stage_u8_main_finish<NROWS>(bw, bh, x0, y0, bndw, bpitch, bdst, tid, lb, acc);
-  stage_u8_rest<NROWS>(A, as, aw, ah, x0, y0, andw, apitch, adst, tid, nthreads, acc);
-  stage_u8_rest<NROWS>(B, bs, bw, bh, x0, y0, bndw, bpitch, bdst, tid, nthreads, acc);
-}
-
 }  // namespace vwgpu_u8
