@@ -607,6 +607,66 @@ def run_config5(args, torch, dist, vwa, core, stereo, synth, partition, rank, wo
         dist.destroy_process_group()
 
 
+def measure_traffic():
+    """HBM bytes per launch of the headline kernel from the PMC counters, measured NOW: two rocprofv3 passes of this very command (short:
+    8 steps, no CPU leg, no extras), one per counter — FETCH_SIZE and WRITE_SIZE do not fit one pass — read back from the rocpd database.
+    gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts the 128-byte requests of wide
+    coalesced reads at 64 bytes -> x2; WRITE_SIZE as is; both in KiB.  Returns (bytes per launch or None, how it was obtained)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="vwgpu_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "8", "--warmup", "2", "--settle-ms", "30", "--no-cpu-baseline", "--no-extra", "--no-traffic"]
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+            if p.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, p.returncode)
+            cur = sqlite3.connect(dbs[0]).cursor()
+            row = cur.execute("select count(*), avg(value) from counters_collection where counter_name = ? and kernel_name like '%bm_sad_u8_kernel%'",
+                              (counter,)).fetchone()
+            if not row or not row[0]:
+                return None, "no %s samples of bm_sad_u8_kernel in the profile" % counter
+            got[counter] = (int(row[0]), float(row[1]))
+        except Exception as e:  # noqa: BLE001  (the headline line must not depend on the profiler)
+            return None, "PMC pass failed: %s" % (str(e)[:80],)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    total = int(got["FETCH_SIZE"][1] * 1024 * 2 + got["WRITE_SIZE"][1] * 1024)
+    return total, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `bench.py --steps 8` "
+                   "(%d / %d launches): FETCH_SIZE %.0f KiB x 2 (gfx950 correction) + WRITE_SIZE %.0f KiB"
+                   % (got["FETCH_SIZE"][0], got["WRITE_SIZE"][0], got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]))
+
+
+def sub_workload(name, extra_args, env_extra, keys, timeout=900):
+    """One of the other workloads of this file (config 4, config 5) as a child process on the same GPU, its JSON line condensed into an
+    `extra` entry — so that the driver's run times them too, at sizes that keep the default command within minutes."""
+    import subprocess
+    env = dict(os.environ)
+    env.update(env_extra)
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra_args, env=env, capture_output=True, text=True, timeout=timeout)
+    line = next((ln for ln in reversed(p.stdout.splitlines()) if ln.startswith("{")), None)
+    if p.returncode != 0 or line is None:
+        return {"name": name, "error": "child exited %d: %s" % (p.returncode, p.stderr[-200:])}
+    d = json.loads(line)
+    out = {"name": name, "command": "python bench.py " + " ".join(extra_args) + ("  (" + " ".join("%s=%s" % kv for kv in env_extra.items()) + ")" if env_extra else ""),
+           "child_wall_s": round(time.perf_counter() - t0, 1)}
+    for k in keys:
+        if k in d:
+            out[k] = d[k]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -614,7 +674,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--settle-ms", type=float, default=250.0, dest="settle_ms")   # untimed load before the warm-up steps (clock ramp)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the extra measured points (config 3, SGM block, +-16 px)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra measured points (config 3, SGM block, +-16 px, config 4 / 5 runs)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--cost", default="census", choices=["census", "mad"],
                     help="config4 only: census (what the reference's SGM accepts) or mad = the 7x7 mean-abs-difference block cost of the config as "
                          "written (SGM.cc:1651-1738; unreachable upstream, explicit opt-in here)")
@@ -764,14 +825,19 @@ def main():
         achieved = strip_bytes / (t_hot_us * 1e-6) / 1e9 if t_hot_us > 0 else 0.0
         evals = (r1 - r0) * ow * sx * sy
         traffic = traffic_src = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                traffic = tj.get("hbm_bytes_per_launch")
-                traffic_src = "profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run" % tj.get("round", "r01")
-            except Exception:
-                traffic = None
+        if world == 1 and not args.no_traffic:
+            traffic, traffic_src = measure_traffic()
+        if traffic is None:
+            why = traffic_src
+            tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tfile):
+                try:
+                    tj = json.load(open(tfile))
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, NOT measured in this run%s" % (
+                        tj.get("round", "r01"), (" (" + why + ")") if why else "")
+                except Exception:
+                    traffic = None
         res = {
             "metric": "disparity Mpix/s, 4096x4096 pair, 7x7 SAD, +-64-px search",
             "value": ow * oh * args.steps / dt / 1e6,
@@ -795,10 +861,12 @@ def main():
                          "issue_bound_frac": (evals / (t_hot_us * 1e-6)) / (LANES * FCLK_HZ) if t_hot_us > 0 else None,
                          "note": "rank-0 strip; issue_bound_frac = (pixel x disparity evaluations per second) / "
                                  "(256 CU x 64 lane-ops/clk x 2.4 GHz): evaluations per VOP3 issue slot — the kernel "
-                                 "is VALU-issue bound (~4.25 slots per evaluation at best), see DESIGN.md.  north_star's 0.70 of the HBM "
-                                 "roofline is out of reach for +-64-px SAD on this ISA: every abs-diff of the cost volume is unique and SAD4-class "
-                                 "instructions deliver 4 per issue slot, which puts the floor of the formulation near 234 us per 4096^2 launch "
-                                 "(frac 0.18); the +-16-px point in `extra` shows the same kernel where the arithmetic shrinks 4x"},
+                                 "is VALU-issue bound (~4.25 slots per evaluation at best), see DESIGN.md 4.1.  north_star's 0.70 of the HBM "
+                                 "roofline is out of reach for +-64-px SAD on this ISA: the cost volume has W H D unique abs-diffs, but a 7-wide "
+                                 "window is 4 + 3 bytes — SAD4-class instructions (4 abs-diffs per issue slot, summed) cannot share row partials "
+                                 "between neighbouring pixels of an odd window — which puts the floor of the formulation near 234 us per 4096^2 launch "
+                                 "(frac 0.18); the +-16-px point in `extra` shows the same kernel where the arithmetic shrinks 4x.  One launch per "
+                                 "step since round 4 (validity sweep folded into the matcher)"},
         }
         if not args.no_cpu_baseline:
             # rank 0, for every N: the same leg (the other ranks wait at the final barrier)
@@ -815,6 +883,14 @@ def main():
         if world == 1 and not args.no_extra:
             try:                                  # the headline line must not depend on the side measurements
                 res["extra"] = extra_points(ctx, torch, stereo, core, vwa, synth, l_strip, r_strip, left, right, with_cpu=not args.no_cpu_baseline)
+                # BASELINE configs[3] and configs[4] themselves on this GPU: config 4 at full size (one pair = 0.45 s), config 5 on an
+                # 8192^2 pair (64 tiles of 1024^2 instead of 1024) — the same code as `bench.py --workload config4 / config5`
+                ckeys = ["metric", "value", "unit", "ms_per_step", "roofline", "config"]
+                res["extra"].append(sub_workload("BASELINE configs[3] on one GPU: 16384^2 pair, census 7x7 SGM, 8 strips + collar (full size)",
+                                                 ["--workload", "config4", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], {}, ckeys))
+                res["extra"].append(sub_workload("BASELINE configs[4] on one GPU, reduced to an 8192^2 pair (64 tiles): pyramid_correlate tile loop, "
+                                                 "LoG 1.4 + NCC 11x11 and census SGM",
+                                                 ["--workload", "config5", "--no-cpu-baseline"], {"VWGPU_BENCH_CONFIG5_SIZE": "8192"}, ckeys))
             except Exception as e:  # noqa: BLE001
                 res["extra"] = [{"name": "extra points failed", "error": "%s: %s" % (type(e).__name__, str(e)[:300])}]
         print(json.dumps(res))

@@ -14,7 +14,7 @@ for tag in main fetch write sq; do
   # the stats pass runs long enough for the clocks to settle (its average must agree with bench.py's HIP events); the
   # counter passes serialise every dispatch, a dozen launches are plenty
   if [ $tag = main ]; then n="--steps 200 --warmup 20"; else n="--steps 12 --warmup 3"; fi
-  rocprofv3 --kernel-trace $extra -d gpurun_out/prof/${TAG}_$tag -o ${TAG}_$tag -- python bench.py $n --no-cpu-baseline --no-extra > gpurun_out/prof/${TAG}_$tag.log 2>&1
+  rocprofv3 --kernel-trace $extra -d gpurun_out/prof/${TAG}_$tag -o ${TAG}_$tag -- python bench.py $n --no-cpu-baseline --no-extra --no-traffic > gpurun_out/prof/${TAG}_$tag.log 2>&1
   db=$(find gpurun_out/prof/${TAG}_$tag -name "*.db" | head -1)
   python tools/rocprof_summary.py "$db" gpurun_out/${TAG}_$tag.md >/dev/null 2>&1 || echo "summary $tag failed"
   tail -1 gpurun_out/prof/${TAG}_$tag.log | cut -c1-200
