@@ -496,7 +496,7 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   // ---- validity sweep (workgroup-uniform; never taken on textured imagery): the same steps with packed best / worst
   // costs instead of keys, then best == worst => invalid (Correlation.cc:121-133).  The epilogue's stores above are
   // complete before the barrier at the head of the sweep, the zeros below land after them.
-  if (!any) return;
+  if (__builtin_expect(!any, 1)) return;
 #pragma unroll
   for (int y = 0; y < TY; ++y) {
     MN[y][0] = MN[y][1] = 0xffffffffu;
