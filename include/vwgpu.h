@@ -30,7 +30,8 @@ extern "C" {
 
 /* 2 (round 4): struct vwgpu_sgm_params carries allow_block_cost (appended in round 3 without a bump: a host compiled against
  *     version 1 passes a struct that is 8 bytes shorter), VWGPU_PATH_REFUSED replaces the silent float64 fallback of
- *     VWGPU_OPT_DEFER_EXACTNESS, vwgpu_trim, vwgpu_halo_headers_agree, the host-ring options.
+ *     VWGPU_OPT_DEFER_EXACTNESS, vwgpu_trim, vwgpu_halo_headers_agree, the host-ring and certification options; options 7
+ *     (VWGPU_OPT_EXACT_LDS) and 10 (VWGPU_OPT_CORR_MFMA) are gone with the two slower kernel variants they selected.
  * A host checks vwgpu_abi_version() == VWGPU_ABI_VERSION once after loading the library (vw::engine does, vw/Engine.h). */
 #define VWGPU_ABI_VERSION 2
 
@@ -129,15 +130,10 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *       (default: eight passes over the u16 sums, bandwidth bound), 1 = two concurrent fused raster sweeps of four directions each
  *       (a fifth of the HBM traffic, the same sums; slower on MI355X because a sweep is W + 2 H dependent pixel steps), 2 .. 15 = the
  *       sweeps with that many rows per workgroup (tuning).
- *   VWGPU_OPT_EXACT_LDS        exact-order matching of zones whose working set fits the LDS of one wavefront (bmx_zone_lds_kernel):
- *       0 = never (default: the two HBM passes for every zone — measured faster), 1 = for the zone lists of a pyramid level,
- *       2 = also for single-zone calls (calc_disparity on a small raster).
  *   VWGPU_OPT_EXACT_SPLIT      pass 2 of the exact-order matchers: 0 = chosen by the width of a zone (the recurrence alone + a parallel
  *       selection for zones of 1024 pixels and more (whole rasters), the tiled form — row sums transposed through LDS — for narrower
  *       ones), 1 = always the split form, 2 = always the fused form (selection across the disparity lanes inside the chain), 3 = always
  *       the tiled form.  Same results in every form.
- *   VWGPU_OPT_CORR_MFMA        SSD / NCC on byte imagery: 0 = the v_dot4_u32_u8 kernels (default), 1 = the products on the matrix cores
- *       (v_mfma_i32_16x16x32_i8; same results, measured slower: 1.13 - 1.20 ms against 0.69 - 0.94 ms at 4096^2 x 129).
  *   VWGPU_OPT_MGM_SWEEP        use_mgm on full-range one-row searches (<= 256 disparities): 0 = the eight passes as four concurrent
  *       sweeps (default), 1 = one launch per front (the round-2 schedule), 2 .. 15 = the sweeps with that many lines per workgroup.
  *   VWGPU_OPT_HOST_RING_KB     size in KiB (16 .. 1048576, default 16384) of the pinned host ring through which zone / work-item tables
@@ -146,8 +142,8 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *   VWGPU_OPT_HOST_RING_WRAPS  (read only) how often the ring cursor has changed halves so far. */
 typedef enum vwgpu_option {
   VWGPU_OPT_DEFER_EXACTNESS = 1, VWGPU_OPT_DEVICE_COUNT = 2, VWGPU_OPT_SAD_GROUPS = 3, VWGPU_OPT_EXACT_SCRATCH_MB = 4,
-  VWGPU_OPT_TRACE = 5, VWGPU_OPT_SGM_SWEEP = 6, VWGPU_OPT_EXACT_LDS = 7, VWGPU_OPT_MGM_SWEEP = 8, VWGPU_OPT_EXACT_SPLIT = 9,
-  VWGPU_OPT_CORR_MFMA = 10, VWGPU_OPT_HOST_RING_KB = 11, VWGPU_OPT_HOST_RING_WRAPS = 12, VWGPU_OPT_CERTIFY = 13,
+  VWGPU_OPT_TRACE = 5, VWGPU_OPT_SGM_SWEEP = 6, /* 7: removed in ABI 2 */ VWGPU_OPT_MGM_SWEEP = 8, VWGPU_OPT_EXACT_SPLIT = 9,
+  /* 10: removed in ABI 2 */ VWGPU_OPT_HOST_RING_KB = 11, VWGPU_OPT_HOST_RING_WRAPS = 12, VWGPU_OPT_CERTIFY = 13,
   VWGPU_OPT_CERT_PERMILLE = 14, VWGPU_OPT_ZONE_SXC = 15
 } vwgpu_option;
 int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value);

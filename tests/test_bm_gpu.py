@@ -27,13 +27,10 @@ def ctx(torch_cuda):
     c.close()
 
 
-@pytest.fixture(autouse=True, params=["dot4", "mfma"])
-def _default_options(request, ctx):
-    """Every test of this module runs with both SSD / NCC byte kernels (OPT_CORR_MFMA: v_dot4 chains — the default — / products on the matrix cores).
-    Variant-pinning options (same results, other kernels / schedules) never leak from one test into the next."""
-    ctx.set_option(core.OPT_CORR_MFMA, 1 if request.param == "mfma" else 0)
+@pytest.fixture(autouse=True)
+def _default_options(ctx):
+    """Variant-pinning options (same results, other kernels / schedules) never leak from one test into the next."""
     yield
-    ctx.set_option(core.OPT_CORR_MFMA, 0)
     ctx.set_option(core.OPT_SAD_GROUPS, 0)
     ctx.set_option(core.OPT_EXACT_SCRATCH_MB, 4096)
 

@@ -32,7 +32,6 @@ def _default_options(request, ctx):
     ctx.set_option(core.OPT_EXACT_SPLIT, 0)
     ctx.set_option(core.OPT_SAD_GROUPS, 0)
     ctx.set_option(core.OPT_EXACT_SCRATCH_MB, 4096)
-    ctx.set_option(core.OPT_EXACT_LDS, 0)
 
 
 def wide_range(rng, h, w, decades=14, signed=True):
@@ -253,28 +252,23 @@ def test_table_ring_wraps_while_the_device_is_behind(oracle):
     (64, 30, (11, 11), (3, 4), (1, 2)),        # 54 output rows
     (25, 33, (3, 9), (27, 8), (13, 4)),        # 216 disparities
     (12, 12, (11, 11), (9, 1), (4, 0)),        # 2 x 2 outputs
-    (70, 40, (5, 5), (4, 3), (1, 1)),          # 66 output rows: does not fit one wavefront -> the two HBM passes, same answer
+    (70, 40, (5, 5), (4, 3), (1, 1)),          # 66 output rows
 ])
-def test_small_zone_in_lds(ctx, oracle, cost, h, w, kernel, search, shift):
-    """bmx_zone_lds_kernel (one wavefront owns a zone, the whole recurrence in LDS) on single-zone calls (OPT_EXACT_LDS = 2): the
-    reference's summation order and compare chain, wide-range data with NaN / Inf pixels and all-zero NCC windows."""
+def test_small_zones_in_reference_order(ctx, oracle, cost, h, w, kernel, search, shift):
+    """Zone-sized rasters (what a pyramid level hands to calc_disparity) through the exact-order kernels: the reference's summation
+    order and compare chain, wide-range data with NaN / Inf pixels and all-zero NCC windows."""
     rng = np.random.default_rng(h * 100 + w + cost)
     left, right = _pair(rng, h, w, search[0], search[1], shift, decades=14)
     left[h // 2, w // 3] = np.nan
     right[h // 3, w // 2] = np.inf
     left[:kernel[1], :kernel[0]] = 0.0
     want = oracle.calc_disparity(cost, left, right, kernel, search)
-    ctx.set_option(core.OPT_EXACT_LDS, 2)
     ctx.force_path(core.PATH_EXACT_ORDER)
     try:
         got = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), search, kernel, ctx=ctx)
-        ctx.set_option(core.OPT_EXACT_LDS, 0)
-        hbm = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), search, kernel, ctx=ctx)
     finally:
         ctx.force_path(core.PATH_NONE)
-        ctx.set_option(core.OPT_EXACT_LDS, 0)
     assert np.array_equal(got, want), int((got != want).any(-1).sum())
-    assert np.array_equal(hbm, want)
 
 
 def test_whole_raster_in_row_bands(ctx, oracle, monkeypatch):
@@ -285,22 +279,6 @@ def test_whole_raster_in_row_bands(ctx, oracle, monkeypatch):
     got = stereo.calc_disparity(SQ, left, right, vwa.bounding_box(left), (33, 1), (7, 7), ctx=ctx)
     assert ctx.last_path() == core.PATH_EXACT_ORDER
     assert np.array_equal(got, want)
-
-
-@pytest.mark.parametrize("cost", [ABS, NCC])
-def test_pyramid_zone_lists_through_the_lds_kernel(ctx, oracle, cost):
-    """OPT_EXACT_LDS = 1: the small zones of every level of a pyramid tile in LDS, the others through HBM — same tile."""
-    from visionworkbench_amd.core import BBox2i
-    rng = np.random.default_rng(61 + cost)
-    H, W = 180, 240
-    left = wide_range(rng, H, W, decades=9, signed=False)
-    right = np.roll(left, 5, axis=1)
-    right[:, :5] = wide_range(rng, H, 5, decades=9, signed=False)
-    search = (-8, -2, 9, 3)
-    ctx.set_option(core.OPT_EXACT_LDS, 1)
-    g = stereo.pyramid_correlate(left, right, None, None, 0, 0.0, BBox2i.from_corners(search[:2], search[2:]), (7, 7), cost, 0, 0.0, 2, 0, 3, 3, ctx=ctx)
-    o = oracle.pyramid_correlate(left, right, None, None, 0, 0.0, search, (7, 7), cost, 0, 0.0, 2, 3, 3)
-    assert np.array_equal(g, o), int((g != o).any(-1).sum())
 
 
 @pytest.mark.parametrize("cost", [ABS, SQ, NCC])

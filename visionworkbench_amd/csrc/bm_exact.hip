@@ -827,150 +827,9 @@ bmx_merge_kernel(const XZone* __restrict__ zones, const int2* __restrict__ items
   }
 }
 
-// ---- small zones: the whole recurrence in LDS, one wavefront per zone (round 3) ---------------------------------------------------
-// A pyramid level is ~2000 zones of ~32 x 32 pixels with ~5 x 5 disparities each (CorrelationView.cc:596-700).  Through the two
-// HBM passes above every (pixel, disparity) costs 16 B of traffic and the chains are 32 steps long — LoG + NCC, the `correlate`
-// tool's default, spent 5.6 ms per 1024^2 tile there.  A zone's working set is small: both float patches (clamped crops), the column
-// sums of ONE disparity, the NCC precision images and the compare-chain state of its pixels are ~50 .. 70 KB.  So one wavefront
-// owns a zone and literally runs best_of_search_convolution on it (Correlation.cc:64-133), disparity after disparity:
-//     pass 1  lane <-> column: the column chain down the rows (Algorithms.h:62-75,100-103) into LDS
-//     pass 2  lane <-> row:    the row chain along the columns (:84,:92), the NCC scaling (CostFunctions.h:227-231) and the
-//                              reference's compare chain VERBATIM on the pixel's (best, worst, index) in LDS — NaN behaviour included
-// The order of every floating-point operation is the reference's; nothing crosses HBM but the patches in and the disparities out.
-// Measured (1024^2 tile of the synthetic pair, LoG + NCC 11x11, tools/lds_zone_ab.py): NOT a gain as it stands — 0.45 ms per level-0
-// launch for the ~1000 zones that fit (15 % of the evaluations), while the HBM passes do not get faster without them: their time is
-// the serial chains of the few 128^2 / 256^2 zones, and here a 16 x 16 zone that searches 264 disparities is one wavefront for
-// 0.5 ms.  Kept as an option (VWGPU_OPT_EXACT_LDS) with its tests; the default remains the two HBM passes for every zone.
-struct LZone {
-  int ax, ay, bx, by, zw, zh, sx, sy, out_off, out_stride, addx, addy;
-};
-struct LLayout {                     // dword offsets into the workgroup's LDS
-  int pa, pb, cs, best, worst, idx, lprec, rprec, total;
-  int apitch, bpitch, cpitch, spitch, lpitch, rpitch;     // row pitches (floats / doubles) padded against bank conflicts
-};
-__host__ __device__ inline LLayout lzone_layout(int zw, int zh, int sx, int sy, int kx, int ky, bool ncc) {
-  LLayout l;
-  const int cw = zw + kx - 1, ch = zh + ky - 1, bwp = cw + sx - 1, bhp = ch + sy - 1;
-  const int pw = ncc ? bwp : cw;                             // widest set of column chains (the right precision image's)
-  const int prows = ncc ? zh + sy - 1 : zh;
-  auto odd = [](int v) { return v | 1; };
-  l.apitch = odd(cw); l.bpitch = odd(bwp); l.cpitch = odd(pw); l.spitch = odd(zw); l.lpitch = odd(zw); l.rpitch = odd(zw + sx - 1);
-  int o = 0;
-  l.pa = o; o += l.apitch * ch;
-  l.pb = o; o += l.bpitch * bhp;
-  o = (o + 1) & ~1;
-  l.cs = o; o += 2 * l.cpitch * prows;
-  l.best = o; o += 2 * l.spitch * zh;
-  l.worst = o; o += 2 * l.spitch * zh;
-  l.idx = o; o += l.spitch * zh;
-  o = (o + 1) & ~1;
-  l.lprec = o; if (ncc) o += 2 * l.lpitch * zh;
-  l.rprec = o; if (ncc) o += 2 * l.rpitch * (zh + sy - 1);
-  l.total = o;
-  return l;
-}
-
-template <int COST>
-__global__ void __launch_bounds__(64)
-bmx_zone_lds_kernel(const float* __restrict__ A, int aw, int ah, ptrdiff_t as, const float* __restrict__ B, int bw, int bh, ptrdiff_t bs,
-                    int kx, int ky, const LZone* __restrict__ zones, int32_t* __restrict__ out) {
-  constexpr bool NCC = COST == VWGPU_CROSS_CORRELATION;
-  extern __shared__ __attribute__((aligned(8))) unsigned zl[];
-  const LZone z = zones[blockIdx.x];
-  const int lane = threadIdx.x;
-  const int cw = z.zw + kx - 1, ch = z.zh + ky - 1, bwp = cw + z.sx - 1, bhp = ch + z.sy - 1;
-  const LLayout l = lzone_layout(z.zw, z.zh, z.sx, z.sy, kx, ky, NCC);
-  float* pa = reinterpret_cast<float*>(zl + l.pa);
-  float* pb = reinterpret_cast<float*>(zl + l.pb);
-  double* cs = reinterpret_cast<double*>(zl + l.cs);
-  double* bestv = reinterpret_cast<double*>(zl + l.best);
-  double* worstv = reinterpret_cast<double*>(zl + l.worst);
-  int* idxv = reinterpret_cast<int*>(zl + l.idx);
-  double* lprec = reinterpret_cast<double*>(zl + l.lprec);
-  double* rprec = reinterpret_cast<double*>(zl + l.rprec);
-  // the two patches: the zone's crops with clamped coordinates (ConstantEdgeExtension, as the tile kernels take them)
-  for (int i = lane; i < cw * ch; i += 64) {
-    const int y = i / cw, c = i - y * cw;
-    pa[y * l.apitch + c] = A[(ptrdiff_t)xclamp(z.ay + y, ah) * as + xclamp(z.ax + c, aw)];
-  }
-  for (int i = lane; i < bwp * bhp; i += 64) {
-    const int y = i / bwp, c = i - y * bwp;
-    pb[y * l.bpitch + c] = B[(ptrdiff_t)xclamp(z.by + y, bh) * bs + xclamp(z.bx + c, bw)];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-  // one box-sum image: columns [0, ow + kx - 1) x rows [0, oh + ky - 1) of `elem` -> f(x, y, row_sum) for the ow x oh outputs
-  auto box = [&](int ow, int oh, auto elem, auto sink) __attribute__((always_inline)) {
-    const int pw = ow + kx - 1;
-    if (lane < pw) {                                              // Algorithms.h:62-75, 100-103
-      double c = 0.0;
-      for (int j = 0; j < ky; ++j) c += elem(lane, j);
-      for (int y = 0; y < oh; ++y) {
-        cs[y * l.cpitch + lane] = c;
-        if (y + 1 < oh) {
-          c += elem(lane, y + ky);
-          c -= elem(lane, y);
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (lane < oh) {                                              // Algorithms.h:84, 92
-      const double* row = cs + lane * l.cpitch;
-      double r = 0.0;
-      for (int i = 0; i < kx; ++i) r += row[i];
-      for (int x = 0; x < ow; ++x) {
-        sink(x, lane, r);
-        if (x + 1 < ow) r += row[x + kx] - row[x];
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  };
-
-  if (NCC) {                                                       // NCCCost's constructor over the zone's own crops (CostFunctions.h:214-219)
-    box(z.zw, z.zh, [&](int c, int y) { const float a = pa[y * l.apitch + c]; return (double)(a * a); },
-        [&](int x, int y, double r) { lprec[y * l.lpitch + x] = 1.0 / r; });
-    box(z.zw + z.sx - 1, z.zh + z.sy - 1, [&](int c, int y) { const float b = pb[y * l.bpitch + c]; return (double)(b * b); },
-        [&](int x, int y, double r) { rprec[y * l.rpitch + x] = 1.0 / r; });
-  }
-  int d = 0;
-  for (int dy = 0; dy < z.sy; ++dy)
-    for (int dx = 0; dx < z.sx; ++dx, ++d) {                      // Correlation.cc:64-119: dy outer, dx inner
-      box(z.zw, z.zh,
-          [&](int c, int y) { return xelem<COST>(pa[y * l.apitch + c], pb[(y + dy) * l.bpitch + c + dx]); },
-          [&](int x, int y, double r) {
-            double v = r;
-            if (NCC) v *= sqrt(lprec[y * l.lpitch + x] * rprec[(y + dy) * l.rpitch + x + dx]);      // CostFunctions.h:227-231
-            const int s = y * l.spitch + x;
-            if (d == 0) { bestv[s] = v; worstv[s] = v; idxv[s] = 0; }                               // Correlation.cc:91-117, verbatim
-            else if (xbetter<COST>(v, bestv[s])) { bestv[s] = v; idxv[s] = d; }
-            else if (!xbetter<COST>(v, worstv[s])) { worstv[s] = v; }
-          });
-    }
-  if (lane < z.zh) {                                               // Correlation.cc:121-133
-    for (int x = 0; x < z.zw; ++x) {
-      const int s = lane * l.spitch + x;
-      const int i = idxv[s], qy = i / z.sx, qx = i - qy * z.sx;
-      int32_t* o = out + ((size_t)z.out_off + (size_t)lane * z.out_stride + x) * 3;
-      o[0] = qx + z.addx; o[1] = qy + z.addy; o[2] = (bestv[s] == worstv[s]) ? 0 : 0x7fffffff;
-    }
-  }
-}
-
-constexpr size_t kLZoneLdsMax = 78 * 1024;      // two zones per CU
-bool lzone_fits(const vwgpu_zone_task& s, int kx, int ky, bool ncc, size_t* bytes) {
-  const int cw = s.zw + kx - 1;
-  const int pw = ncc ? cw + s.sx - 1 : cw, prows = ncc ? s.zh + s.sy - 1 : s.zh;
-  if (pw > 64 || prows > 64 || s.zw < 1 || s.zh < 1) return false;
-  const LLayout l = lzone_layout(s.zw, s.zh, s.sx, s.sy, kx, ky, ncc);
-  *bytes = (size_t)l.total * 4;
-  return *bytes <= kLZoneLdsMax;
-}
+// (Rounds 3-4: bmx_zone_lds_kernel — one wavefront running best_of_search_convolution on a zone with everything in LDS — was an
+// opt-in here.  Identical results, slower on the tile loop (15 % of a level's evaluations are in zones that fit, and a 16 x 16 zone that
+// searches 264 disparities is one wavefront for 0.5 ms): removed from the product in round 4, tools/experiments/ keeps the source.)
 
 // ---- order-freeness of an image: lowest set bit and magnitude of its pixels ------------------------------------------
 // cell[0] = min over non-zero pixels of the exponent of the lowest set mantissa bit, cell[1] = max exponent,
@@ -1447,49 +1306,8 @@ int vwgpu_launch_bm_exact(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
   std::vector<const int*> group_gate;                 // d_gate != nullptr: zone i works only if d_gate[i] != 0 (decided on the device)
   auto gates_of = [&]() -> const int* const* { return d_gate ? group_gate.data() : nullptr; };
   size_t bytes = 0;
-  // zones whose working set fits the LDS of a wavefront: one launch, no HBM volume (bmx_zone_lds_kernel)
-  std::vector<LZone> small;
-  std::vector<char> is_small((size_t)std::max(n, 0), 0);
-  size_t small_lds = 0;
-  const bool ncc = cost_type == VWGPU_CROSS_CORRELATION;
-  if (!d_gate && (ctx->exact_lds == 2 || (ctx->exact_lds == 1 && n > 1)))       // opt-in (VWGPU_OPT_EXACT_LDS): measured slower than the HBM passes, see below
-    for (int i = 0; i < n; ++i) {
-      const vwgpu_zone_task& s = zones[i];
-      size_t b = 0;
-      if (s.zw <= 0 || s.zh <= 0 || s.sx <= 0 || s.sy <= 0 || !vwgpu_bm_exact_supported(s.sx, s.sy) || !lzone_fits(s, kx, ky, ncc, &b)) continue;
-      is_small[i] = 1;
-      small_lds = std::max(small_lds, b);
-      small.push_back(LZone{s.ax, s.ay, s.bx, s.by, s.zw, s.zh, s.sx, s.sy, s.out_off, s.out_stride, s.addx, s.addy});
-    }
-  if (!small.empty()) {
-    // the longest zones first (work ~ pixels x disparities)
-    std::stable_sort(small.begin(), small.end(), [](const LZone& a, const LZone& b) {
-        return (long long)a.zw * a.zh * a.sx * a.sy > (long long)b.zw * b.zh * b.sx * b.sy; });
-    const size_t tb = vwgpu_align_up(small.size() * sizeof(LZone), 256);
-    int rc = vwgpu_arena_reserve(ctx, &ctx->xtab, tb + 4096);
-    if (rc) return rc;
-    // (the tables of the HBM path are uploaded to the same arena afterwards: stream order keeps them apart — this launch reads
-    // its table before the next upload runs)
-    if (char* h = static_cast<char*>(vwgpu_host_ring(ctx, tb))) {
-      memcpy(h, small.data(), small.size() * sizeof(LZone));
-      VWGPU_HIP(ctx, hipMemcpyAsync(ctx->xtab.base, h, small.size() * sizeof(LZone), hipMemcpyHostToDevice, ctx->stream));
-    } else {
-      VWGPU_HIP(ctx, hipMemcpyAsync(ctx->xtab.base, small.data(), small.size() * sizeof(LZone), hipMemcpyHostToDevice, ctx->stream));
-      VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    const LZone* dz = static_cast<const LZone*>(ctx->xtab.base);
-    vwgpu_prof_scope ps(ctx, "bmx_zone_lds");
-#define VWGPU_LZ(C) do { VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(bmx_zone_lds_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLZoneLdsMax)); \
-                         hipLaunchKernelGGL((bmx_zone_lds_kernel<C>), dim3((unsigned)small.size()), dim3(64), small_lds, ctx->stream, A, aw, ah, as, B, bw, bh, bs, kx, ky, dz, out); } while (0)
-    if (cost_type == VWGPU_CROSS_CORRELATION) VWGPU_LZ(VWGPU_CROSS_CORRELATION);
-    else if (cost_type == VWGPU_SQUARED_DIFFERENCE) VWGPU_LZ(VWGPU_SQUARED_DIFFERENCE);
-    else VWGPU_LZ(VWGPU_ABSOLUTE_DIFFERENCE);
-#undef VWGPU_LZ
-    if ((int)small.size() == n) { VWGPU_HIP(ctx, hipGetLastError()); return VWGPU_OK; }
-  }
   for (int i = 0; i < n; ++i) {
     const vwgpu_zone_task& s = zones[i];
-    if (is_small[i]) continue;
     if (s.zw <= 0 || s.zh <= 0 || s.sx <= 0 || s.sy <= 0) continue;
     if (!vwgpu_bm_exact_supported(s.sx, s.sy))
       return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "bm_exact: %d x %d disparities exceed the index range", s.sx, s.sy);

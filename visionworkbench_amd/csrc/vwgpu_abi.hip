@@ -240,10 +240,8 @@ int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value) {
   if (option == VWGPU_OPT_CERTIFY && (value == 0 || value == 1)) { ctx->certify = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_ZONE_SXC && value >= 0 && value <= 4096) { ctx->zone_sxc = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_SGM_SWEEP && value >= 0 && value <= 15) { ctx->sgm_sweep = value; return VWGPU_OK; }
-  if (option == VWGPU_OPT_EXACT_LDS && value >= 0 && value <= 2) { ctx->exact_lds = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_MGM_SWEEP && value >= 0 && value <= 15) { ctx->mgm_sweep = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_EXACT_SPLIT && value >= 0 && value <= 3) { ctx->exact_split = value; return VWGPU_OK; }
-  if (option == VWGPU_OPT_CORR_MFMA && (value == 0 || value == 1)) { ctx->corr_mfma = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_HOST_RING_KB && value >= 16 && value <= (1 << 20)) {
     if (value != ctx->host_ring_kb && ctx->host_ring) {            // pending copies read the old ring
       VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -270,10 +268,8 @@ int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value) {
   if (option == VWGPU_OPT_EXACT_SCRATCH_MB) { *value = ctx->exact_scratch_mb; return VWGPU_OK; }
   if (option == VWGPU_OPT_TRACE) { *value = ctx->trace; return VWGPU_OK; }
   if (option == VWGPU_OPT_SGM_SWEEP) { *value = ctx->sgm_sweep; return VWGPU_OK; }
-  if (option == VWGPU_OPT_EXACT_LDS) { *value = ctx->exact_lds; return VWGPU_OK; }
   if (option == VWGPU_OPT_MGM_SWEEP) { *value = ctx->mgm_sweep; return VWGPU_OK; }
   if (option == VWGPU_OPT_EXACT_SPLIT) { *value = ctx->exact_split; return VWGPU_OK; }
-  if (option == VWGPU_OPT_CORR_MFMA) { *value = ctx->corr_mfma; return VWGPU_OK; }
   if (option == VWGPU_OPT_HOST_RING_KB) { *value = ctx->host_ring_kb; return VWGPU_OK; }
   if (option == VWGPU_OPT_CERTIFY) { *value = ctx->certify; return VWGPU_OK; }
   if (option == VWGPU_OPT_ZONE_SXC) { *value = ctx->zone_sxc; return VWGPU_OK; }
@@ -428,9 +424,8 @@ int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
   if (os > INT32_MAX) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "calc_disparity: output stride too large");
 
   const bool sad_ok = vwgpu_bm_sad_u8_supported(cost_type, kx, ky, sx, sy);
-  const bool mfma_ok = !sad_ok && ctx->corr_mfma == 1 && vwgpu_bm_mfma_u8_supported(cost_type, kx, ky, sx, sy);      // opt-in: measured slower (bm_mfma_u8.hip)
-  const bool corr_ok = !sad_ok && !mfma_ok && vwgpu_bm_corr_u8_supported(cost_type, kx, ky, sx, sy);
-  const bool dot_ok = !sad_ok && (mfma_ok || corr_ok || vwgpu_bm_dot_u8_supported(cost_type, kx, ky, sx, sy));
+  const bool corr_ok = !sad_ok && vwgpu_bm_corr_u8_supported(cost_type, kx, ky, sx, sy);
+  const bool dot_ok = !sad_ok && (corr_ok || vwgpu_bm_dot_u8_supported(cost_type, kx, ky, sx, sy));
   if (ctx->forced_path == VWGPU_PATH_SAD_U8 && !sad_ok)
     return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "calc_disparity: no packed-u8 path for cost %d kernel %dx%d search %dx%d",
                       cost_type, kx, ky, sx, sy);
@@ -455,7 +450,6 @@ int vwgpu_calc_disparity_dev(vwgpu_ctx* ctx, int cost_type,
   // Integer-valued inputs in [0,255]: the packed kernels; they check the domain while converting and raise a device flag.
   int* d_flag = nullptr;
   if (sad_ok) rc = vwgpu_launch_bm_sad_u8(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
-  else if (mfma_ok) rc = vwgpu_launch_bm_mfma_u8(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
   else if (corr_ok) rc = vwgpu_launch_bm_corr_u8(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
   else rc = vwgpu_launch_bm_dot_u8(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, sx, sy, d_out, os, &d_flag);
   if (rc) return rc;

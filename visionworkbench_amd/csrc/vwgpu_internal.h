@@ -74,8 +74,6 @@ struct vwgpu_ctx {
   int sad_groups = 0;         // VWGPU_OPT_SAD_GROUPS
   int exact_scratch_mb = 4096;// VWGPU_OPT_EXACT_SCRATCH_MB
   int exact_split = 0;        // VWGPU_OPT_EXACT_SPLIT: 0 by the longest chain, 1 always the split pass 2, 2 always the fused one
-  int corr_mfma = 0;          // VWGPU_OPT_CORR_MFMA: 1 = SSD / NCC on bytes take the matrix-core kernel where instantiated (measured slower), 0 = the v_dot4 kernels
-  int exact_lds = 0;          // VWGPU_OPT_EXACT_LDS: 0 never (default), 1 small zones of a multi-zone call in LDS, 2 also single-zone calls
   int trace = 0;              // VWGPU_OPT_TRACE
   int certify = 1;            // VWGPU_OPT_CERTIFY
   int zone_sxc = 0;           // VWGPU_OPT_ZONE_SXC: 0 = 16 dx per right patch, else at most this many
@@ -149,12 +147,6 @@ int vwgpu_launch_bm_corr_u8(vwgpu_ctx* ctx, int cost_type, const float* left, in
 int vwgpu_launch_ncc_full(vwgpu_ctx* ctx, const float* left, ptrdiff_t ls, const float* right, ptrdiff_t rs, int kx, int ky, int sx,
                           const uint32_t* a2, const uint32_t* b2, int b2w, int32_t* out, ptrdiff_t os, int ow, int* flag,
                           const uint32_t* full_list, const uint32_t* full_count, uint32_t cap);
-// bm_mfma_u8.hip: the same matchers with the products on the matrix cores (v_mfma_i32_16x16x32_i8); same results, measured slower than
-// the v_dot4 kernels: opt-in (VWGPU_OPT_CORR_MFMA = 1)
-bool vwgpu_bm_mfma_u8_supported(int cost_type, int kx, int ky, int sx, int sy);
-int vwgpu_launch_bm_mfma_u8(vwgpu_ctx* ctx, int cost_type, const float* left, int lw, int lh, ptrdiff_t ls,
-                            const float* right, int rw, int rh, ptrdiff_t rs, int kx, int ky, int sx, int sy,
-                            int32_t* out, ptrdiff_t os, int** d_fallback_flag);
 // bm_corr_u16.hip: SSD / NCC for integer-valued imagery in [0,4095] (v_dot2_u32_u16 on pixel pairs); same fallback-flag protocol
 bool vwgpu_bm_corr_u16_supported(int cost_type, int kx, int ky, int sx, int sy);
 int vwgpu_launch_bm_corr_u16(vwgpu_ctx* ctx, int cost_type, const float* left, int lw, int lh, ptrdiff_t ls,
