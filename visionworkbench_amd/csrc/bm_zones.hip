@@ -134,12 +134,23 @@ __device__ __forceinline__ bool zcertified(const ZCert& zc, int D, bool bad, dou
     const double dl = 2.0 * zc.eps_ll * lprec, dr = 2.0 * zc.eps_rr * rpmax;
     if (!(lprec > 0.0) || !(rpmax > 0.0) || !(dl <= 0x1p-10) || !(dr <= 0x1p-10)) return false;
     const double cmax = fmax(fabs(best), fabs(worst));
-    eps = 2.0 * (cmax * (dl + dr + 0x1p-49) + zc.eps_s * sqrt(lprec * rpmax));
+    eps = 2.0 * (cmax * (dl + dr + 0x1p-49 + 0x1p-36) + zc.eps_s * sqrt(lprec * rpmax));      // 2^-36: zsqrt_cert
   } else {
     eps = zc.eps_s;
   }
   const double gap = COST == VWGPU_CROSS_CORRELATION ? best - second : second - best;
   return gap > 2.0 * eps;                                    // (false for NaN)
+}
+
+// sqrt for the certified kernels: the seed of v_rsq_f64 and ONE Goldschmidt step (the first of the three the exact sequence takes).  The
+// certificate only needs a cost within a known distance of the reference's: zcertified charges 2^-36 relative for this (a seed good to
+// 2^-19 already gives 2^-37 after the step; the hardware seed is far better).  0, negative, infinite and subnormal arguments give NaN or
+// inf: a non-finite cost, no certificate.
+__device__ __forceinline__ double zsqrt_cert(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  return __builtin_fma(g, r, g);
 }
 
 // KS > 0: a square KS x KS window known at compile time — the horizontal and vertical window sums are unrolled (with run-time
@@ -149,7 +160,7 @@ __device__ __forceinline__ bool zcertified(const ZCert& zc, int D, bool bad, dou
 // full-rate.  The compare chain runs on doubles either way.
 // CERT: track the runner-up (and the largest right precision) and certify / flag, see the file header.
 template <int COST, int KS, typename ACC, bool CERT, int ZS>
-__global__ void __launch_bounds__(ZS * ZS / 4)
+__global__ void __launch_bounds__(ZS * ZS / 4, 4)
 bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __restrict__ B, int bw, int bh,
                 int kx, int ky, const vwgpu_zone_task* __restrict__ zones, const ZItem* __restrict__ items,
                 int sxc, PrecView pa, PrecView pb, int32_t* __restrict__ out, ZPart P, ZCertArgs C) {
@@ -163,10 +174,14 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
   unsigned long long stamp_t0 = 0;
   if (g_zone_stamps && threadIdx.x == 0) stamp_t0 = wall_clock64();
 #endif
-  const int PW = ZT + kx - 1, PH = ZT + ky - 1, RW = PW + sxc - 1;
+  // LDS pitches: ODD row pitches for the two float patches and ZT + 1 for the sum planes.  A horizontal item is lane <-> (row, group of
+  // HW columns): with the natural pitches (42 floats at 11 x 11, 32 sums) the rows of a half wave fell on the same banks — four-way
+  // conflicts on every patch read, eight-way on the plane writes (PMC round 4: 40 % of the LDS-active cycles were conflict cycles).
+  const int PW = (ZT + kx - 1) | 1, PH = ZT + ky - 1, RW = (ZT + kx - 1 + sxc - 1) | 1;
+  constexpr int HP = ZT + 1;
   float* Lp = reinterpret_cast<float*>(smem);                    // PH x PW
   float* Rp = Lp + PH * PW;                                      // PH x RW
-  ACC* H = reinterpret_cast<ACC*>(smem + (((size_t)(PH * PW + PH * RW) * 4 + 7) & ~size_t(7)));   // 2 x PH x ZT
+  ACC* H = reinterpret_cast<ACC*>(smem + (((size_t)(PH * PW + PH * RW) * 4 + 7) & ~size_t(7)));   // 2 x PH x HP
 
   const vwgpu_zone_task z = zones[it.zone];
   const int ox = (it.txy & 0xffff) * ZT, oy = (it.txy >> 16) * ZT;
@@ -184,9 +199,12 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
   double best[4], worst[4], lprec[4], second[4], rpmax[4];
   int bidx[4];
   bool bad = false;
+  double fsum = 0.0;                                            // CERT: every cost of the thread added up — non-finite iff one of them was
+  constexpr double kBestInit = COST == VWGPU_CROSS_CORRELATION ? -INFINITY : INFINITY;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     best[m] = worst[m] = 0.0; bidx[m] = 0; lprec[m] = 0.0; second[m] = 0.0; rpmax[m] = 0.0;
+    if (CERT) { best[m] = second[m] = kBestInit; worst[m] = -kBestInit; }
     if (COST == VWGPU_CROSS_CORRELATION && c < tw && y0 + m < th)
       lprec[m] = pa.p[(size_t)(z.ay + oy + y0 + m - pa.y0) * pa.w + (z.ax + ox + c - pa.x0)];
   }
@@ -217,7 +235,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
         if (y0 + m < th) prow[m] = pb.p + (size_t)(z.by + oy + y0 + m + dy - pb.y0) * pb.w + (z.bx + ox + c + dx0 - pb.x0);
     }
     for (int d = 0; d < nd; ++d) {
-      ACC* Hc = H + hb * (PH * ZT);
+      ACC* Hc = H + hb * (PH * HP);
       if (COST == VWGPU_CROSS_CORRELATION) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) rpn[m] = prow[m] ? prow[m][d] : 0.0;
@@ -238,7 +256,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
             ACC sacc = 0;
 #pragma unroll
             for (int a = 0; a < KS; ++a) sacc += e[a];
-            ACC* h = Hc + r * ZT + q;
+            ACC* h = Hc + r * HP + q;
             h[0] = sacc;
 #pragma unroll
             for (int j = 1; j < HW; ++j) { sacc = sacc - e[j - 1] + e[j - 1 + KS]; h[j] = sacc; }
@@ -252,7 +270,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
             const float* rp = Rp + r * RW + q + d;
             ACC s = 0;
             for (int a = 0; a < kx; ++a) s += zcost<COST, ACC>(lp[a], rp[a]);
-            Hc[r * ZT + q] = s;
+            Hc[r * HP + q] = s;
           }
         }
       }
@@ -264,7 +282,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
         if (KS > 0) {                                           // the same slide down the rows (rows beyond th hold stale planes: unused)
           ACC h[KS > 0 ? KS + 3 : 1];
 #pragma unroll
-          for (int b = 0; b < KS + 3; ++b) h[b] = Hc[min(y0 + b, PH - 1) * ZT + c];
+          for (int b = 0; b < KS + 3; ++b) h[b] = Hc[min(y0 + b, PH - 1) * HP + c];
 #pragma unroll
           for (int b = 0; b < KS; ++b) vs[0] += h[b];
           vs[1] = vs[0] - h[0] + h[KS]; vs[2] = vs[1] - h[1] + h[KS + 1]; vs[3] = vs[2] - h[2] + h[KS + 2];
@@ -275,28 +293,46 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
           if (y < th) {
             ACC sa = vs[m];
             if (KS == 0) {
-              for (int b = 0; b < ky; ++b) sa += Hc[(y + b) * ZT + c];
+              for (int b = 0; b < ky; ++b) sa += Hc[(y + b) * HP + c];
             }
             double s = (double)sa;
+            if (CERT) {
+              // Certified pass: the chain of Correlation.cc:91-117 reduced to what a certificate needs — minimum with its first index,
+              // runner-up (= min over the others: min(second, max(s, best)) before best moves; equal costs give second == best),
+              // maximum, largest right precision — as min / max instructions instead of compare-and-select pairs (20 -> 8 per
+              // evaluation).  A NaN cost is ignored by min / max and caught by fsum; such a pixel has no certificate anyway.
+              if (COST == VWGPU_CROSS_CORRELATION) {
+                const double rp = rpn[m];
+                rpmax[m] = fmax(rpmax[m], rp);
+                s *= zsqrt_cert(lprec[m] * rp);
+              }
+              fsum += s;
+              const bool cb = zbetter<COST>(s, best[m]);
+              if (COST == VWGPU_CROSS_CORRELATION) {
+                second[m] = fmax(second[m], fmin(s, best[m]));
+                best[m] = fmax(best[m], s);
+                worst[m] = fmin(worst[m], s);
+              } else {
+                second[m] = fmin(second[m], fmax(s, best[m]));
+                best[m] = fmin(best[m], s);
+                worst[m] = fmax(worst[m], s);
+              }
+              bidx[m] = cb ? di : bidx[m];
+            } else {
             if (COST == VWGPU_CROSS_CORRELATION) {
               const double rp = rpn[m];
               s *= sqrt(lprec[m] * rp);
-              if (CERT) rpmax[m] = fmax(rpmax[m], rp);
             }
-            if (CERT || it.slot >= 0) bad = bad || !(fabs(s) <= 1.7976931348623157e308);
+            if (it.slot >= 0) bad = bad || !(fabs(s) <= 1.7976931348623157e308);
             // Correlation.cc:91-117 as selects (a branch per comparison costs more than the comparisons): the first disparity sets
             // best = worst; a strictly better cost takes best and the index; otherwise a cost that is not better than worst takes worst
             // (a NaN cost compares false both times: it never wins and becomes `worst`, as in the reference)
             const bool cb = zbetter<COST>(s, best[m]), cw = zbetter<COST>(s, worst[m]);
             const bool ub = first || cb, uw = first || (!cb && !cw);
-            if (CERT) {
-              const bool cs = zbetter<COST>(s, second[m]);
-              const double sent = COST == VWGPU_CROSS_CORRELATION ? -INFINITY : INFINITY;
-              second[m] = first ? sent : (cb ? best[m] : (cs ? s : second[m]));
-            }
             best[m] = ub ? s : best[m];
             bidx[m] = ub ? di : bidx[m];
             worst[m] = uw ? s : worst[m];
+            }
           }
         }
       }
@@ -304,6 +340,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
     }
     i0 += nd;
   }
+  if (CERT) bad = !(fabs(fsum) <= 1.7976931348623157e308);
 #ifdef VWGPU_TILE_STAMPS
   if (g_zone_stamps && threadIdx.x == 0) {
     unsigned hw, xcc;
@@ -511,8 +548,8 @@ double sum_error_units(int kx, int ky, int W, int H) {
 
 bool vwgpu_bm_zones_supported(int kx, int ky) {
   // LDS: left patch + right patch with at least 8 disparities per chunk + two sum planes within 64 KB
-  const size_t PW = ZT + kx - 1, PH = ZT + ky - 1;
-  return (PH * PW + PH * (PW + 7)) * 4 + 2 * PH * ZT * 8 + 16 <= 64 * 1024;
+  const size_t PW = (ZT + kx - 1) | 1, PH = ZT + ky - 1;
+  return (PH * PW + PH * (PW + 8)) * 4 + 2 * PH * (ZT + 1) * 8 + 16 <= 64 * 1024;
 }
 
 // cert_hi: INT_MIN = no certification (the level is order free: any summation order returns the reference's bits).  Otherwise the
@@ -531,7 +568,7 @@ struct ZPlan {
   ZPart P{};
   const ZItem* d_items = nullptr; const ZItem* d_redo = nullptr; const ZMergeItem* d_merges = nullptr;
 };
-size_t zones_lds_fixed(int zs, int kx, int ky, size_t accb) { return (size_t)(zs + ky - 1) * (zs + kx - 1) * 4 + 2 * (size_t)(zs + ky - 1) * zs * accb + 16; }
+size_t zones_lds_fixed(int zs, int kx, int ky, size_t accb) { return (size_t)(zs + ky - 1) * ((zs + kx - 1) | 1) * 4 + 2 * (size_t)(zs + ky - 1) * (zs + 1) * accb + 16; }
 }  // namespace
 
 int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
@@ -565,10 +602,11 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     const size_t PW = pl.zs + kx - 1, PH = pl.zs + ky - 1;
     const size_t fixed = zones_lds_fixed(pl.zs, kx, ky, accb);
     const size_t budget = pl.zs == 32 ? 64 * 1024 : 20 * 1024;     // a wavefront-sized tile keeps its right patch short: more of them fit a CU
-    long long room = (long long)((budget - std::min(budget, fixed)) / (PH * 4)) - (long long)PW + 1;
+    long long room = (long long)((budget - std::min(budget, fixed)) / (PH * 4)) - (long long)PW;            // (the right pitch is rounded up to odd)
     room = std::min<long long>(room, ctx->zone_sxc > 0 ? ctx->zone_sxc : 16);      // (measured: 16 dx per patch keep four workgroups on a CU; longer patches three)
     pl.sxc = (int)std::max<long long>(1, std::min<long long>(max_sx, room));
-    pl.lds = (((PH * PW + PH * (PW + pl.sxc - 1)) * 4 + 7) & ~size_t(7)) + 2 * PH * pl.zs * accb;
+    const size_t LPW = PW | 1, RPW = (PW + pl.sxc - 1) | 1;
+    pl.lds = (((PH * LPW + PH * RPW) * 4 + 7) & ~size_t(7)) + 2 * PH * (pl.zs + 1) * accb;
   }
 
   // Work items.  A tile is cut when its evaluations exceed `cap` = a third of the level's work per resident workgroup (so that the longest
