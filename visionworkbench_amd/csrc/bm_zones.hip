@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -190,11 +191,18 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
   const int t = threadIdx.x;
   const int c = t % ZT, y0 = (t / ZT) * 4;
 
-  for (int i = t; i < ph * pw; i += ZTHREADS) {
-    const int r = i / pw, q = i - r * pw;
-    int xx = z.ax + ox + q; xx = xx < 0 ? 0 : (xx >= aw ? aw - 1 : xx);
-    int yy = z.ay + oy + r; yy = yy < 0 ? 0 : (yy >= ah ? ah - 1 : yy);
-    Lp[r * PW + q] = A[(size_t)yy * aw + xx];
+  // staging: thread <-> (column t % 32, rows t / 32, + ZTHREADS / 32, ...) — no division by the run-time patch width (a flat index
+  // cost a 40-instruction division per element: two thirds of the instructions of a 16 x 16 zone with a dozen disparities)
+  constexpr int SROWS = ZTHREADS / 32;
+  {
+    const int q0 = t & 31, r0 = t >> 5;
+    for (int q = q0; q < pw; q += 32) {
+      int xx = z.ax + ox + q; xx = xx < 0 ? 0 : (xx >= aw ? aw - 1 : xx);
+      for (int r = r0; r < ph; r += SROWS) {
+        int yy = z.ay + oy + r; yy = yy < 0 ? 0 : (yy >= ah ? ah - 1 : yy);
+        Lp[r * PW + q] = A[(size_t)yy * aw + xx];
+      }
+    }
   }
   double best[4], worst[4], lprec[4], second[4], rpmax[4];
   int bidx[4];
@@ -218,11 +226,15 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
     const int nd = min(min(sxc, z.sx - dx0), iend - i0);          // a run of dx inside one search row
     const int rwid = pw + nd - 1;
     __syncthreads();                                              // everyone done with the previous right patch
-    for (int i = t; i < ph * rwid; i += ZTHREADS) {
-      const int r = i / rwid, q = i - r * rwid;
-      int xx = z.bx + ox + dx0 + q; xx = xx < 0 ? 0 : (xx >= bw ? bw - 1 : xx);
-      int yy = z.by + oy + dy + r; yy = yy < 0 ? 0 : (yy >= bh ? bh - 1 : yy);
-      Rp[r * RW + q] = B[(size_t)yy * bw + xx];
+    {
+      const int q0 = t & 31, r0 = t >> 5;
+      for (int q = q0; q < rwid; q += 32) {
+        int xx = z.bx + ox + dx0 + q; xx = xx < 0 ? 0 : (xx >= bw ? bw - 1 : xx);
+        for (int r = r0; r < ph; r += SROWS) {
+          int yy = z.by + oy + dy + r; yy = yy < 0 ? 0 : (yy >= bh ? bh - 1 : yy);
+          Rp[r * RW + q] = B[(size_t)yy * bw + xx];
+        }
+      }
     }
     __syncthreads();
     // NCC: the right precisions of a disparity are requested before its horizontal pass and consumed after it (a load issued where it is
@@ -622,7 +634,11 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     // (Round 4 also built 16 x 16 tiles on one wavefront for the 16 x 16 leaves of the quad tree — on a 32 x 32 tile a quarter of the lanes
     // have pixels there.  Measured on 1024^2 pyramid tiles: every zone on 16-tiles = the same time (their patches carry 2.6x halo and a
     // wavefront per workgroup exposes every LDS round trip); both sizes in one level = two launches with a tail each, slower.  Dropped.)
+#ifdef VWGPU_ZONES16
+    const bool small = getenv("VWGPU_ZONES16") != nullptr;      // tools build: every zone on 16 x 16 tiles
+#else
     const bool small = false;
+#endif
     ZPlan& pl = small ? plan[1] : plan[0];
     const int ZS = pl.zs;
     const int nx = (z.zw + ZS - 1) / ZS, ny = (z.zh + ZS - 1) / ZS;
@@ -730,7 +746,11 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
   if (cert) VWGPU_HIP(ctx, hipMemsetAsync(d_zflag, 0, (size_t)n * sizeof(int), ctx->stream));
 
 #define VW_ZN4(C_, K_, A_, T_, S_) hipLaunchKernelGGL((bm_zones_kernel<C_, K_, A_, T_, S_>), grd, dim3(S_ * S_ / 4), pl.lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, tab, pl.sxc, pa, pb, out, pl.P, C)
+#ifdef VWGPU_ZONES16
+#define VW_ZN3(C_, K_, A_, T_) do { if (pl.zs == 32) VW_ZN4(C_, K_, A_, T_, 32); else VW_ZN4(C_, K_, A_, T_, 16); } while (0)
+#else
 #define VW_ZN3(C_, K_, A_, T_) VW_ZN4(C_, K_, A_, T_, 32)
+#endif
 #define VW_ZN(C_, K_) do { if (cert) VW_ZN3(C_, K_, double, true); else if (f32_sums) VW_ZN3(C_, K_, float, false); else VW_ZN3(C_, K_, double, false); } while (0)
 #define VW_ZN_K(C_) do { switch (kx == ky ? kx : 0) { case 3: VW_ZN(C_, 3); break; case 5: VW_ZN(C_, 5); break; case 7: VW_ZN(C_, 7); break; \
                                                      case 9: VW_ZN(C_, 9); break; case 11: VW_ZN(C_, 11); break; case 13: VW_ZN(C_, 13); break; \
@@ -738,7 +758,12 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
 #define VW_ZN_C() do { switch (cost_type) { case VWGPU_CROSS_CORRELATION: VW_ZN_K(VWGPU_CROSS_CORRELATION); break; \
                                             case VWGPU_SQUARED_DIFFERENCE: VW_ZN_K(VWGPU_SQUARED_DIFFERENCE); break; \
                                             default: VW_ZN_K(VWGPU_ABSOLUTE_DIFFERENCE); break; } } while (0)
+#ifdef VWGPU_ZONES16
+#define VW_MG2(C_, T_) do { if (pl.zs == 32) hipLaunchKernelGGL((zones_merge_kernel<C_, T_, 32>), mgrd, dim3(256), 0, ctx->stream, dz, pl.d_merges, pa, out, pl.P, C); \
+                            else hipLaunchKernelGGL((zones_merge_kernel<C_, T_, 16>), mgrd, dim3(64), 0, ctx->stream, dz, pl.d_merges, pa, out, pl.P, C); } while (0)
+#else
 #define VW_MG2(C_, T_) hipLaunchKernelGGL((zones_merge_kernel<C_, T_, 32>), mgrd, dim3(256), 0, ctx->stream, dz, pl.d_merges, pa, out, pl.P, C)
+#endif
 #define VW_MG(C_) do { if (cert) VW_MG2(C_, true); else VW_MG2(C_, false); } while (0)
   for (ZPlan& pl : plan) {                                      // the 32-tiles hold the long items: first
     if (pl.items.empty()) continue;
