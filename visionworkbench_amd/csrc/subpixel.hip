@@ -14,52 +14,124 @@
 //
 // Roofline: 9*kx*ky abs-diffs per pixel against 36 B of compulsory traffic per pixel (disparity in, two images,
 // disparity out) — VALU / L1 bound; the windows of neighbouring pixels overlap and are served by the vector L1.
+#include <algorithm>
 #include <climits>
 
 #include "vwgpu_internal.h"
 
 namespace {
 
-// get_disparity_range over ALL pixels (invalid ones included, src/vw/Stereo/DisparityMap.h:52-66) of the disparity
-// truncated to int (the PixelMask<Vector2f> -> PixelMask<Vector2i> conversion of ParabolaSubpixelView.cc:283).
-__global__ void disparity_range_kernel(const float* __restrict__ d, int w, int h, ptrdiff_t stride_px, int* __restrict__ out4) {
-  int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
-  // four pixels of a row requested together (two dependent-free loads each; one pixel at a time the kernel waited out a memory round trip
-  // per pixel: 90 us for 4096^2); a pixel beyond the row repeats the thread's first one
-  const int xs = gridDim.x * blockDim.x, xf = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int y = blockIdx.y * blockDim.y + threadIdx.y; y < h; y += gridDim.y * blockDim.y) {
-    const float* row = d + (ptrdiff_t)y * stride_px * 3;
-    for (int x = xf; x < w; x += 4 * xs) {
-      float vx[4], vy[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int xx = x + k * xs < w ? x + k * xs : x;
-        vx[k] = row[(ptrdiff_t)xx * 3]; vy[k] = row[(ptrdiff_t)xx * 3 + 1];
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int dx = (int)vx[k], dy = (int)vy[k];
-        mnx = min(mnx, dx); mxx = max(mxx, dx); mny = min(mny, dy); mxy = max(mxy, dy);
-      }
-    }
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    mnx = min(mnx, __shfl_xor(mnx, o)); mny = min(mny, __shfl_xor(mny, o));
-    mxx = max(mxx, __shfl_xor(mxx, o)); mxy = max(mxy, __shfl_xor(mxy, o));
-  }
-  // one set of atomics per workgroup, and few workgroups: atomics on the same four words serialise at the L2 (65 k of them
-  // were 0.76 ms for a 4096^2 image — ten times the time of reading it)
+// get_disparity_range over ALL pixels (invalid ones included, src/vw/Stereo/DisparityMap.h:52-66) of the disparity truncated to int
+// (the PixelMask<Vector2f> -> PixelMask<Vector2i> conversion of ParabolaSubpixelView.cc:283): parabola_prepass_kernel, blockIdx.z = 0.
+
+// The class of the imagery in the SAME launch as the disparity range (blockIdx.z = 1, 2: the left / the right image): lowest set mantissa
+// bit, largest exponent, "non-finite" (bit 0) and "negative" (bit 1) over all pixels, as float_grain_kernel (bm_exact.hip) measures them —
+// cell[0] = min over non-zero pixels of the exponent of the lowest set bit, cell[1] = max exponent, cell[2] = flags.  Separate launches
+// of the two measurements took 82 + 50 us at 4096^2 (each well under the HBM rate); together they overlap.
+__device__ __forceinline__ void grain_take(float v, int& lo, int& hi, int& bad) {
+  const unsigned u = __float_as_uint(v);
+  const int e = (int)((u >> 23) & 0xffu);
+  unsigned m = u & 0x7fffffu;
+  if (e == 0xff) { bad |= 1; return; }
+  if (e == 0 && m == 0) return;
+  if (u >> 31) bad |= 2;
+  int base;
+  if (e == 0) base = -149; else { m |= 0x800000u; base = e - 127 - 23; }
+  lo = min(lo, base + (__ffs((int)m) - 1));
+  hi = max(hi, base + (31 - __clz((int)m)));
+}
+__global__ void __launch_bounds__(256)
+parabola_prepass_kernel(const float* __restrict__ d, int w, int h, ptrdiff_t stride_px, int* __restrict__ out4,
+                        const float* __restrict__ L, int lw, int lh, ptrdiff_t ls, const float* __restrict__ R, int rw, int rh, ptrdiff_t rs,
+                        int* __restrict__ cell) {
   __shared__ int part[4][4];
   const int t = threadIdx.y * blockDim.x + threadIdx.x;
-  if ((t & 63) == 0) { part[t >> 6][0] = mnx; part[t >> 6][1] = mny; part[t >> 6][2] = mxx; part[t >> 6][3] = mxy; }
+  const int xs = gridDim.x * blockDim.x, xf = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.z == 0) {
+    // A row of the disparity is 3 w floats {dx, dy, valid, dx, ...}: four pixels = three float4 (dx at elements 0, 3, 6, 9, dy at 1, 4, 7,
+    // 10), two such groups in flight per thread where the rows are 16-byte aligned; pixel by pixel otherwise.
+    int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
+    const bool vec = ((reinterpret_cast<uintptr_t>(d) & 15) == 0) && (stride_px % 4 == 0);
+    const int n12 = vec ? w / 4 : 0;                            // whole groups of four pixels
+    auto tx = [&](float v) __attribute__((always_inline)) { const int iv = (int)v; mnx = min(mnx, iv); mxx = max(mxx, iv); };
+    auto ty = [&](float v) __attribute__((always_inline)) { const int iv = (int)v; mny = min(mny, iv); mxy = max(mxy, iv); };
+    // (the loads in flight are two ROWS of the thread's column group — a 4096-wide row is one group per thread of the 1024-wide grid row)
+    const int ys = gridDim.y * blockDim.y;
+    for (int y = blockIdx.y * blockDim.y + threadIdx.y; y < h; y += 2 * ys) {
+      const int y1 = y + ys < h ? y + ys : y;
+      const float* row = d + (ptrdiff_t)y * stride_px * 3;
+      const float* rowb = d + (ptrdiff_t)y1 * stride_px * 3;
+      const float4* row4 = reinterpret_cast<const float4*>(row);
+      const float4* rowb4 = reinterpret_cast<const float4*>(rowb);
+      for (int j = xf; j < n12; j += xs) {
+        const float4 a0 = row4[3 * j], a1 = row4[3 * j + 1], a2 = row4[3 * j + 2];
+        const float4 b0 = rowb4[3 * j], b1 = rowb4[3 * j + 1], b2 = rowb4[3 * j + 2];
+        tx(a0.x); ty(a0.y); tx(a0.w); ty(a1.x); tx(a1.z); ty(a1.w); tx(a2.y); ty(a2.z);
+        tx(b0.x); ty(b0.y); tx(b0.w); ty(b1.x); tx(b1.z); ty(b1.w); tx(b2.y); ty(b2.z);
+      }
+      for (int x = 4 * n12 + xf; x < w; x += xs) {
+        tx(row[(ptrdiff_t)x * 3]); ty(row[(ptrdiff_t)x * 3 + 1]); tx(rowb[(ptrdiff_t)x * 3]); ty(rowb[(ptrdiff_t)x * 3 + 1]);
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      mnx = min(mnx, __shfl_xor(mnx, o)); mny = min(mny, __shfl_xor(mny, o));
+      mxx = max(mxx, __shfl_xor(mxx, o)); mxy = max(mxy, __shfl_xor(mxy, o));
+    }
+    // one set of atomics per workgroup, and few workgroups: atomics on the same four words serialise at the L2
+    if ((t & 63) == 0) { part[t >> 6][0] = mnx; part[t >> 6][1] = mny; part[t >> 6][2] = mxx; part[t >> 6][3] = mxy; }
+    __syncthreads();
+    if (t == 0) {
+      for (int k = 1; k < 4; ++k) { mnx = min(mnx, part[k][0]); mny = min(mny, part[k][1]); mxx = max(mxx, part[k][2]); mxy = max(mxy, part[k][3]); }
+      // Same-address atomics serialise at the L2 (~12 ns each: the 10 k of this launch were most of its time): a workgroup whose values
+      // cannot move a word — the words only ever move one way, so a stale read errs on the side of an atomic — skips it.
+      if (mnx < __hip_atomic_load(out4 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(out4 + 0, mnx);
+      if (mny < __hip_atomic_load(out4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(out4 + 1, mny);
+      if (mxx > __hip_atomic_load(out4 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out4 + 2, mxx);
+      if (mxy > __hip_atomic_load(out4 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out4 + 3, mxy);
+    }
+    return;
+  }
+  if (!cell) return;
+  const float* img = blockIdx.z == 1 ? L : R;
+  const int iw = blockIdx.z == 1 ? lw : rw, ih = blockIdx.z == 1 ? lh : rh;
+  const ptrdiff_t is = blockIdx.z == 1 ? ls : rs;
+  int lo = INT_MAX, hi = INT_MIN, bad = 0;
+  const bool vec = ((reinterpret_cast<uintptr_t>(img) & 15) == 0) && (is % 4 == 0);
+  const int n4 = iw / 4;
+  const int ys = gridDim.y * blockDim.y;
+  for (int y = blockIdx.y * blockDim.y + threadIdx.y; y < ih; y += 4 * ys) {
+    const float* rows[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rows[k] = img + (ptrdiff_t)(y + k * ys < ih ? y + k * ys : y) * is;      // four rows in flight
+    if (vec) {
+      for (int i = xf; i < n4; i += xs) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = reinterpret_cast<const float4*>(rows[k])[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { grain_take(v[k].x, lo, hi, bad); grain_take(v[k].y, lo, hi, bad); grain_take(v[k].z, lo, hi, bad); grain_take(v[k].w, lo, hi, bad); }
+      }
+      for (int x = 4 * n4 + xf; x < iw; x += xs)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) grain_take(rows[k][x], lo, hi, bad);
+    } else {
+      for (int x = xf; x < iw; x += xs)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) grain_take(rows[k][x], lo, hi, bad);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); bad |= __shfl_xor(bad, o); }
+  if ((t & 63) == 0) { part[t >> 6][0] = lo; part[t >> 6][1] = hi; part[t >> 6][2] = bad; }
   __syncthreads();
   if (t == 0) {
-    for (int k = 1; k < 4; ++k) { mnx = min(mnx, part[k][0]); mny = min(mny, part[k][1]); mxx = max(mxx, part[k][2]); mxy = max(mxy, part[k][3]); }
-    atomicMin(out4 + 0, mnx); atomicMin(out4 + 1, mny); atomicMax(out4 + 2, mxx); atomicMax(out4 + 3, mxy);
+    for (int k = 1; k < 4; ++k) { lo = min(lo, part[k][0]); hi = max(hi, part[k][1]); bad |= part[k][2]; }
+    if (lo != INT_MAX) {
+      if (lo < __hip_atomic_load(&cell[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&cell[0], lo);
+      if (hi > __hip_atomic_load(&cell[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cell[1], hi);
+    }
+    if (bad & ~__hip_atomic_load(&cell[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&cell[2], bad);
   }
 }
-
-__global__ void range_init_kernel(int* out4) { out4[0] = out4[1] = INT_MAX; out4[2] = out4[3] = INT_MIN; }
 
 // KX > 0: the window width is a compile-time constant and the nine costs are formed in one sweep over the (ky + 2) rows of
 // the right neighbourhood: every right value is loaded once (kx + 2 per row) and every left value once (three rows kept in
@@ -310,30 +382,44 @@ parabola_kernel(const float* __restrict__ disp, int w, int h, ptrdiff_t dstride_
 
 }  // namespace
 
-int vwgpu_launch_disparity_range(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t stride_px, int* d_out4) {
-  hipLaunchKernelGGL(range_init_kernel, dim3(1), dim3(1), 0, ctx->stream, d_out4);
-  dim3 blk(64, 4), grd(std::min((w + 63) / 64, 16), std::min((h + 3) / 4, 64));   // <= 1024 workgroups, 4 atomics each
-  vwgpu_prof_scope ps(ctx, "disparity_range");
-  hipLaunchKernelGGL(disparity_range_kernel, grd, blk, 0, ctx->stream, disp3f, w, h, stride_px, d_out4);
+// Disparity range and (d_cell != nullptr) the class of both images in one launch.  d_out4: 4 ints; d_cell: 3 ints, initialised here.
+int vwgpu_launch_parabola_prepass(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t stride_px, int* d_out4,
+                                  const float* L, int lw, int lh, ptrdiff_t ls, const float* R, int rw, int rh, ptrdiff_t rs, int* d_cell) {
+  const int init[8] = {INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MAX, INT_MIN, 0, 0};
+  if (d_cell && d_cell != d_out4 + 4) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "parabola prepass: the cell follows the range");
+  VWGPU_HIP(ctx, hipMemcpyAsync(d_out4, init, d_cell ? sizeof init : 4 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  const int mw = std::max(w, std::max(lw, rw)), mh = std::max(h, std::max(lh, rh));
+  dim3 blk(64, 4), grd(std::min((mw + 63) / 64, 16), std::min((mh + 3) / 4, 64), d_cell ? 3 : 1);
+  vwgpu_prof_scope ps(ctx, "parabola_prepass");
+  hipLaunchKernelGGL(parabola_prepass_kernel, grd, blk, 0, ctx->stream, disp3f, w, h, stride_px, d_out4, L, lw, lh, ls, R, rw, rh, rs, d_cell);
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }
 
-// float raster (integers in [0,255]) -> bytes, 4 pixels per thread; the pitch is a multiple of 4 with room for the kernel's
-// aligned over-reads
-__global__ void f32_to_u8_raster_kernel(const float* __restrict__ src, int w, int h, uint8_t* __restrict__ dst, int pitch) {
+// Byte raster of the region [x0, x0 + bw) x [y0, y0 + bh) of a float image of integers in [0,255], constant edge extension — the crop
+// the reference's prerasterize takes (ParabolaSubpixelView.cc:302-327) written as bytes directly (the float crop + its conversion
+// were two passes: 8 + 5 B per pixel instead of 4 + 1).
+__global__ void f32_ext_to_u8_raster_kernel(const float* __restrict__ src, ptrdiff_t stride, int w, int h, int x0, int y0, int bw, int bh,
+                                            uint8_t* __restrict__ dst, int pitch) {
   const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x4 >= pitch || y >= h) return;
-  const float* s = src + (size_t)y * w;
+  if (x4 >= pitch || y >= bh) return;
+  int sy = y0 + y; sy = sy < 0 ? 0 : (sy >= h ? h - 1 : sy);
+  const float* s = src + (ptrdiff_t)sy * stride;
   unsigned v = 0;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v = __builtin_amdgcn_cvt_pk_u8_f32(x4 + e < w ? s[x4 + e] : 0.0f, e, v);
+  for (int e = 0; e < 4; ++e) {
+    int sx = x0 + x4 + e; sx = sx < 0 ? 0 : (sx >= w ? w - 1 : sx);
+    v = __builtin_amdgcn_cvt_pk_u8_f32(x4 + e < bw ? s[sx] : 0.0f, e, v);
+  }
   *reinterpret_cast<unsigned*>(dst + (size_t)y * pitch + x4) = v;
 }
-int vwgpu_parabola_u8_pitch(int w) { return (w + 3) / 4 * 4 + 32; }
-void vwgpu_launch_f32_to_u8_raster(vwgpu_ctx* ctx, const float* src, int w, int h, uint8_t* dst, int pitch) {
-  hipLaunchKernelGGL(f32_to_u8_raster_kernel, dim3((pitch / 4 + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, ctx->stream, src, w, h, dst, pitch);
+void vwgpu_launch_f32_ext_to_u8_raster(vwgpu_ctx* ctx, const float* src, ptrdiff_t stride, int w, int h, int x0, int y0, int bw, int bh,
+                                       uint8_t* dst, int pitch) {
+  vwgpu_prof_scope ps(ctx, "parabola_u8_raster");
+  hipLaunchKernelGGL(f32_ext_to_u8_raster_kernel, dim3((pitch / 4 + 63) / 64, (bh + 3) / 4), dim3(64, 4), 0, ctx->stream, src, stride, w, h, x0, y0, bw, bh, dst, pitch);
 }
+
+int vwgpu_parabola_u8_pitch(int w) { return (w + 3) / 4 * 4 + 32; }
 
 int vwgpu_launch_parabola(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t dstride_px,
                           const float* lras, int lrw, const float* rras, int rrw, int range_minx, int range_miny,

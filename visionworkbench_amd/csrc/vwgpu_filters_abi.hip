@@ -218,20 +218,13 @@ int vwgpu_parabola_subpixel_dev(vwgpu_ctx* ctx, const float* d_disp, int w, int 
   int rc = vwgpu_arena_reserve(ctx, &ctx->misc, 256);
   if (rc) return rc;
   int* d_range = static_cast<int*>(ctx->misc.base);
-  rc = vwgpu_launch_disparity_range(ctx, d_disp, w, h, dstride, d_range);
-  if (rc) return rc;
-  // class of the imagery, measured in the same round trip: small integers take the integer SAD form of the kernel
-  int* d_grain = d_range + 8;
+  // class of the imagery, measured in the same launch and the same round trip: small integers take the integer SAD form of the kernel
+  int* d_grain = d_range + 4;
   int grain[3] = {INT_MAX, INT_MIN, 0};
-  if (mode == VWGPU_PREFILTER_NONE) {
-    VWGPU_HIP(ctx, hipMemcpyAsync(d_grain, grain, sizeof grain, hipMemcpyHostToDevice, ctx->stream));
-    const float* imgs[2] = {d_left, d_right};
-    const int ws[2] = {w, rw}, hs[2] = {h, rh};
-    const ptrdiff_t ss[2] = {lstride, rstride};
-    int* cells[2] = {d_grain, d_grain};
-    vwgpu_launch_float_grain(ctx, 2, imgs, ws, hs, ss, cells);
-    VWGPU_HIP(ctx, hipMemcpyAsync(grain, d_grain, sizeof grain, hipMemcpyDeviceToHost, ctx->stream));
-  }
+  rc = vwgpu_launch_parabola_prepass(ctx, d_disp, w, h, dstride, d_range, d_left, w, h, lstride, d_right, rw, rh, rstride,
+                                     mode == VWGPU_PREFILTER_NONE ? d_grain : nullptr);
+  if (rc) return rc;
+  if (mode == VWGPU_PREFILTER_NONE) VWGPU_HIP(ctx, hipMemcpyAsync(grain, d_grain, sizeof grain, hipMemcpyDeviceToHost, ctx->stream));
   int r4[4];
   VWGPU_HIP(ctx, hipMemcpyAsync(r4, d_range, sizeof r4, hipMemcpyDeviceToHost, ctx->stream));
   VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));              // the ROI sizes depend on the data
@@ -261,18 +254,19 @@ int vwgpu_parabola_subpixel_dev(vwgpu_ctx* ctx, const float* d_disp, int w, int 
   float* lras = reinterpret_cast<float*>(base);
   float* rras = reinterpret_cast<float*>(base + lb);
   float* scratch = reinterpret_cast<float*>(base + lb + rb);
+  if (integer_class == 2 && kx >= 3 && kx <= 15 && (kx & 1)) {                   // the sizes parabola_kernel<K, 2> is instantiated for
+    // integers in [0,255] (PREFILTER_NONE): the byte rasters straight from the images, edge extension included
+    uint8_t* l8 = reinterpret_cast<uint8_t*>(scratch);
+    uint8_t* r8 = l8 + l8b;
+    vwgpu_launch_f32_ext_to_u8_raster(ctx, d_left, lstride, w, h, -hx, -hy, lrw, lrh, l8, lp8);
+    vwgpu_launch_f32_ext_to_u8_raster(ctx, d_right, rstride, rw, rh, -hx + (int)rminx, -hy + (int)rminy, rrw, rrh, r8, rp8);
+    return vwgpu_launch_parabola(ctx, d_disp, w, h, dstride, reinterpret_cast<const float*>(l8), lp8, reinterpret_cast<const float*>(r8), rp8,
+                                 (int)rminx, (int)rminy, kx, ky, d_out, ostride, 2);
+  }
   rc = vwgpu_prefilter_region(ctx, d_left, w, h, lstride, mode, width, -hx, -hy, lrw, lrh, lras, scratch);
   if (rc) return rc;
   rc = vwgpu_prefilter_region(ctx, d_right, rw, rh, rstride, mode, width, -hx + (int)rminx, -hy + (int)rminy, rrw, rrh, rras, scratch);
   if (rc) return rc;
-  if (integer_class == 2 && kx >= 3 && kx <= 15 && (kx & 1)) {                   // the sizes parabola_kernel<K, 2> is instantiated for
-    uint8_t* l8 = reinterpret_cast<uint8_t*>(scratch);
-    uint8_t* r8 = l8 + l8b;
-    vwgpu_launch_f32_to_u8_raster(ctx, lras, lrw, lrh, l8, lp8);
-    vwgpu_launch_f32_to_u8_raster(ctx, rras, rrw, rrh, r8, rp8);
-    return vwgpu_launch_parabola(ctx, d_disp, w, h, dstride, reinterpret_cast<const float*>(l8), lp8, reinterpret_cast<const float*>(r8), rp8,
-                                 (int)rminx, (int)rminy, kx, ky, d_out, ostride, 2);
-  }
   if (integer_class == 2) integer_class = 1;                                      // other kernel sizes: the run-time loop on the float rasters
   return vwgpu_launch_parabola(ctx, d_disp, w, h, dstride, lras, lrw, rras, rrw, (int)rminx, (int)rminy, kx, ky, d_out, ostride, integer_class);
 }

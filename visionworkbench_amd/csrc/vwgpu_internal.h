@@ -196,9 +196,11 @@ int vwgpu_prefilter_region(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdi
 extern "C" int vwgpu_generate_gaussian_kernel(double sigma, int size, float* taps, int cap);
 
 // subpixel.hip
-int vwgpu_launch_disparity_range(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t stride_px, int* d_out4);
+int vwgpu_launch_parabola_prepass(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t stride_px, int* d_out4,
+                                  const float* L, int lw, int lh, ptrdiff_t ls, const float* R, int rw, int rh, ptrdiff_t rs, int* d_cell);
+void vwgpu_launch_f32_ext_to_u8_raster(vwgpu_ctx* ctx, const float* src, ptrdiff_t stride, int w, int h, int x0, int y0, int bw, int bh,
+                                       uint8_t* dst, int pitch);
 int vwgpu_parabola_u8_pitch(int w);
-void vwgpu_launch_f32_to_u8_raster(vwgpu_ctx* ctx, const float* src, int w, int h, uint8_t* dst, int pitch);
 int vwgpu_launch_parabola(vwgpu_ctx* ctx, const float* disp3f, int w, int h, ptrdiff_t dstride_px,
                           const float* lras, int lrw, const float* rras, int rrw, int range_minx, int range_miny,
                           int kx, int ky, float* out3f, ptrdiff_t ostride_px, int integer_class = 0);
