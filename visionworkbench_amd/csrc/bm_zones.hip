@@ -77,10 +77,16 @@ struct PrecView {           // 1 / box-sum(img^2) over origins [x0, x0+w) x [y0,
 // prec(x, y) = 1.0 / sum_{ky x kx} img(clamp)^2 for window origins (x0 + i, y0 + j).  A 64 x 4 output tile: the squares of its
 // (64 + kx - 1) x (4 + ky - 1) pixels go to LDS once, then row sums and column sums (the direct form read kx * ky floats per output
 // through the L1: 0.3 ms per 1024^2 NCC tile).  Only used on data whose box sums are exact in any order (vwgpu_sums_order_free).
+struct ZPrecJob { const float* img; int w, h; double* prec; int x0, y0, pw, ph; };
+struct ZPrecJobs { ZPrecJob j[2]; };           // blockIdx.z: the left and the right image of a pass in one launch
 __global__ void __launch_bounds__(256)
-zone_precision_kernel(const float* __restrict__ img, int w, int h, int kx, int ky,
-                      double* __restrict__ prec, int x0, int y0, int pw, int ph) {
+zone_precision_kernel(ZPrecJobs jobs, int kx, int ky) {
   extern __shared__ double zp_sm[];
+  const ZPrecJob J = jobs.j[blockIdx.z];
+  const float* __restrict__ img = J.img;
+  double* __restrict__ prec = J.prec;
+  const int w = J.w, h = J.h, x0 = J.x0, y0 = J.y0, pw = J.pw, ph = J.ph;
+  if ((int)blockIdx.x * 64 >= pw || (int)blockIdx.y * 4 >= ph) return;
   const int tw = 64 + kx - 1, th = 4 + ky - 1;
   double* sq = zp_sm;                 // th x tw squares
   double* hs = zp_sm + (size_t)th * tw;   // th x 64 row sums
@@ -688,8 +694,10 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     double* db = reinterpret_cast<double*>(sbase + na);
     vwgpu_prof_scope ps(ctx, "zone_precision");
     const size_t zp_lds = ((size_t)(64 + kx - 1) * (4 + ky - 1) + (size_t)(4 + ky - 1) * 64) * sizeof(double);
-    hipLaunchKernelGGL(zone_precision_kernel, dim3((pa.w + 63) / 64, (pa.h + 3) / 4), dim3(64, 4), zp_lds, ctx->stream, A, aw, ah, kx, ky, da, pa.x0, pa.y0, pa.w, pa.h);
-    hipLaunchKernelGGL(zone_precision_kernel, dim3((pb.w + 63) / 64, (pb.h + 3) / 4), dim3(64, 4), zp_lds, ctx->stream, B, bw, bh, kx, ky, db, pb.x0, pb.y0, pb.w, pb.h);
+    ZPrecJobs zj;
+    zj.j[0] = ZPrecJob{A, aw, ah, da, pa.x0, pa.y0, pa.w, pa.h};
+    zj.j[1] = ZPrecJob{B, bw, bh, db, pb.x0, pb.y0, pb.w, pb.h};
+    hipLaunchKernelGGL(zone_precision_kernel, dim3((std::max(pa.w, pb.w) + 63) / 64, (std::max(pa.h, pb.h) + 3) / 4, 2), dim3(64, 4), zp_lds, ctx->stream, zj, kx, ky);
     pa.p = da; pb.p = db;
   }
   {

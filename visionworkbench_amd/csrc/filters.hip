@@ -15,6 +15,8 @@
 //
 // Roofline: all of these are HBM bound.  Pyramid level: reads 4 B per source pixel once (tile + small halo through
 // LDS), writes 1 B per source pixel (4 B per output) -> 5 B/source pixel; prefilter: 4 B in + 4 B out per pixel.
+#include <algorithm>
+
 #include "vwgpu_internal.h"
 
 namespace {
@@ -39,11 +41,18 @@ __device__ __forceinline__ float ext_load(const float* __restrict__ src, ptrdiff
   return src[(ptrdiff_t)y * stride + x];
 }
 
+struct ImgJobs { vwgpu_img_job j[VWGPU_MAX_IMG_JOBS]; };
+
 template <int EDGE>
 __global__ void __launch_bounds__(256)
-sepconv_kernel(const float* __restrict__ src, ptrdiff_t stride, int w, int h, Taps t, int step,
-               float* __restrict__ dst, ptrdiff_t dstride, int ow, int oh, int sw, int sh, int offx, int offy) {
+sepconv_kernel(ImgJobs jobs, Taps t, int step, int sw, int sh) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const vwgpu_img_job J = jobs.j[blockIdx.z];
+  const float* __restrict__ src = static_cast<const float*>(J.src);
+  float* __restrict__ dst = static_cast<float*>(J.dst);
+  const ptrdiff_t stride = J.stride, dstride = J.dstride;
+  const int w = J.w, h = J.h, ow = J.ow, oh = J.oh, offx = J.offx, offy = J.offy;
+  if ((int)blockIdx.x * TW >= ow || (int)blockIdx.y * TH >= oh) return;       // (the grid is the largest job's)
   float* tile = smem;                       // [sh][sw]   edge-extended source
   float* work = smem + (size_t)sh * sw;     // [sh][TW]   horizontal pass (float, like the reference's `work`)
   const int tid = threadIdx.x;
@@ -92,8 +101,12 @@ struct Kernel2D {
 };
 
 template <int EDGE>
-__global__ void conv2d_kernel(const float* __restrict__ src, ptrdiff_t stride, int w, int h, Kernel2D kk,
-                              float* __restrict__ dst, ptrdiff_t dstride, int ow, int oh, int offx, int offy) {
+__global__ void conv2d_kernel(ImgJobs jobs, Kernel2D kk) {
+  const vwgpu_img_job J = jobs.j[blockIdx.z];
+  const float* __restrict__ src = static_cast<const float*>(J.src);
+  float* __restrict__ dst = static_cast<float*>(J.dst);
+  const ptrdiff_t stride = J.stride, dstride = J.dstride;
+  const int w = J.w, h = J.h, ow = J.ow, oh = J.oh, offx = J.offx, offy = J.offy;
   const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y * blockDim.y + threadIdx.y;
   if (ox >= ow || oy >= oh) return;
   const int x = ox + offx, y = oy + offy;          // source position of this output (may be outside the image)
@@ -114,8 +127,12 @@ __global__ void ext_sub_kernel(const float* __restrict__ a, ptrdiff_t as, int w,
   dst[(ptrdiff_t)oy * ds + ox] = b ? v - b[(ptrdiff_t)oy * bs + ox] : v;
 }
 
-__global__ void mask_by_two_kernel(const uint8_t* __restrict__ src, ptrdiff_t stride, int w, int h,
-                                   uint8_t* __restrict__ dst, ptrdiff_t dstride, int ow, int oh) {
+__global__ void mask_by_two_kernel(ImgJobs jobs) {
+  const vwgpu_img_job J = jobs.j[blockIdx.z];
+  const uint8_t* __restrict__ src = static_cast<const uint8_t*>(J.src);
+  uint8_t* __restrict__ dst = static_cast<uint8_t*>(J.dst);
+  const ptrdiff_t stride = J.stride, dstride = J.dstride;
+  const int w = J.w, h = J.h, ow = J.ow, oh = J.oh;
   const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y * blockDim.y + threadIdx.y;
   if (ox >= ow || oy >= oh) return;
   const int x = 2 * ox, y = 2 * oy;
@@ -124,8 +141,13 @@ __global__ void mask_by_two_kernel(const uint8_t* __restrict__ src, ptrdiff_t st
   dst[(ptrdiff_t)oy * dstride + ox] = count > 1 ? 255 : 0;
 }
 
-__global__ void subtract_kernel(const float* __restrict__ a, ptrdiff_t as, const float* __restrict__ b, ptrdiff_t bs,
-                                int w, int h, float* __restrict__ dst, ptrdiff_t ds) {
+__global__ void subtract_kernel(ImgJobs jobs) {
+  const vwgpu_img_job J = jobs.j[blockIdx.z];
+  const float* __restrict__ a = static_cast<const float*>(J.src);
+  const float* __restrict__ b = J.b;
+  float* __restrict__ dst = static_cast<float*>(J.dst);
+  const ptrdiff_t as = J.stride, bs = J.bs, ds = J.dstride;
+  const int w = J.w, h = J.h;
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= w || y >= h) return;
   dst[(ptrdiff_t)y * ds + x] = a[(ptrdiff_t)y * as + x] - b[(ptrdiff_t)y * bs + x];
@@ -144,9 +166,18 @@ int vwgpu_launch_sepconv(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff
                                      1 + (w - 1) / step, 1 + (h - 1) / step, 0, 0);
 }
 
-int vwgpu_launch_sepconv_region(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
-                                const float* xk, int nx, int cx, const float* yk, int ny, int cy,
-                                int edge, int step, float* dst, ptrdiff_t dstride, int ow, int oh, int offx, int offy) {
+namespace {
+int pack_jobs(vwgpu_ctx* ctx, const vwgpu_img_job* jobs, int n, ImgJobs& out, int& mw, int& mh) {
+  if (n < 1 || n > VWGPU_MAX_IMG_JOBS) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "filter launch: %d image jobs", n);
+  mw = mh = 0;
+  for (int i = 0; i < n; ++i) { out.j[i] = jobs[i]; mw = std::max(mw, jobs[i].ow); mh = std::max(mh, jobs[i].oh); }
+  for (int i = n; i < VWGPU_MAX_IMG_JOBS; ++i) out.j[i] = jobs[0];
+  return VWGPU_OK;
+}
+}  // namespace
+
+int vwgpu_launch_sepconv_jobs(vwgpu_ctx* ctx, const vwgpu_img_job* jobs, int n, const float* xk, int nx, int cx, const float* yk, int ny, int cy,
+                              int edge, int step) {
   if (nx > MAXT || ny > MAXT) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "separable convolution: more than %d taps", MAXT);
   Taps t;
   t.nx = nx; t.ny = ny; t.cx = cx; t.cy = cy;
@@ -155,14 +186,22 @@ int vwgpu_launch_sepconv_region(vwgpu_ctx* ctx, const float* src, int w, int h, 
   const int sw = (TW - 1) * step + 1 + (nx ? nx - 1 : 0), sh = (TH - 1) * step + 1 + (ny ? ny - 1 : 0);
   const size_t shmem = ((size_t)sh * sw + (size_t)sh * TW) * sizeof(float);
   if (shmem > 64 * 1024) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "separable convolution: kernel %dx%d step %d needs %zu B of LDS", nx, ny, step, shmem);
-  dim3 grd((ow + TW - 1) / TW, (oh + TH - 1) / TH), blk(256);
+  ImgJobs J; int mw, mh;
+  int rc = pack_jobs(ctx, jobs, n, J, mw, mh);
+  if (rc) return rc;
+  dim3 grd((mw + TW - 1) / TW, (mh + TH - 1) / TH, n), blk(256);
   vwgpu_prof_scope ps(ctx, step > 1 ? "sepconv_decimate" : "sepconv");
-  if (edge == 1)
-    hipLaunchKernelGGL(sepconv_kernel<1>, grd, blk, shmem, ctx->stream, src, stride, w, h, t, step, dst, dstride, ow, oh, sw, sh, offx, offy);
-  else
-    hipLaunchKernelGGL(sepconv_kernel<0>, grd, blk, shmem, ctx->stream, src, stride, w, h, t, step, dst, dstride, ow, oh, sw, sh, offx, offy);
+  if (edge == 1) hipLaunchKernelGGL(sepconv_kernel<1>, grd, blk, shmem, ctx->stream, J, t, step, sw, sh);
+  else hipLaunchKernelGGL(sepconv_kernel<0>, grd, blk, shmem, ctx->stream, J, t, step, sw, sh);
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
+}
+
+int vwgpu_launch_sepconv_region(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
+                                const float* xk, int nx, int cx, const float* yk, int ny, int cy,
+                                int edge, int step, float* dst, ptrdiff_t dstride, int ow, int oh, int offx, int offy) {
+  const vwgpu_img_job j{src, stride, w, h, dst, dstride, ow, oh, offx, offy, nullptr, 0};
+  return vwgpu_launch_sepconv_jobs(ctx, &j, 1, xk, nx, cx, yk, ny, cy, edge, step);
 }
 
 int vwgpu_launch_conv2d(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
@@ -170,38 +209,61 @@ int vwgpu_launch_conv2d(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_
   return vwgpu_launch_conv2d_region(ctx, src, w, h, stride, k, kw, kh, ci, cj, edge, dst, dstride, w, h, 0, 0);
 }
 
-int vwgpu_launch_conv2d_region(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
-                               const float* k, int kw, int kh, int ci, int cj, int edge, float* dst, ptrdiff_t dstride,
-                               int ow, int oh, int offx, int offy) {
+int vwgpu_launch_conv2d_jobs(vwgpu_ctx* ctx, const vwgpu_img_job* jobs, int n, const float* k, int kw, int kh, int ci, int cj, int edge) {
   if (kw * kh > 49) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "2-D convolution: kernel %dx%d larger than 49 taps", kw, kh);
   Kernel2D kk;
   kk.kw = kw; kk.kh = kh; kk.ci = ci; kk.cj = cj;
   for (int i = 0; i < kw * kh; ++i) kk.k[i] = k[i];
-  dim3 blk(64, 4), grd((ow + 63) / 64, (oh + 3) / 4);
+  ImgJobs J; int mw, mh;
+  int rc = pack_jobs(ctx, jobs, n, J, mw, mh);
+  if (rc) return rc;
+  dim3 blk(64, 4), grd((mw + 63) / 64, (mh + 3) / 4, n);
   vwgpu_prof_scope ps(ctx, "conv2d");
-  if (edge == 1) hipLaunchKernelGGL(conv2d_kernel<1>, grd, blk, 0, ctx->stream, src, stride, w, h, kk, dst, dstride, ow, oh, offx, offy);
-  else hipLaunchKernelGGL(conv2d_kernel<0>, grd, blk, 0, ctx->stream, src, stride, w, h, kk, dst, dstride, ow, oh, offx, offy);
+  if (edge == 1) hipLaunchKernelGGL(conv2d_kernel<1>, grd, blk, 0, ctx->stream, J, kk);
+  else hipLaunchKernelGGL(conv2d_kernel<0>, grd, blk, 0, ctx->stream, J, kk);
+  VWGPU_HIP(ctx, hipGetLastError());
+  return VWGPU_OK;
+}
+
+int vwgpu_launch_conv2d_region(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
+                               const float* k, int kw, int kh, int ci, int cj, int edge, float* dst, ptrdiff_t dstride,
+                               int ow, int oh, int offx, int offy) {
+  const vwgpu_img_job j{src, stride, w, h, dst, dstride, ow, oh, offx, offy, nullptr, 0};
+  return vwgpu_launch_conv2d_jobs(ctx, &j, 1, k, kw, kh, ci, cj, edge);
+}
+
+int vwgpu_launch_mask_by_two_jobs(vwgpu_ctx* ctx, const vwgpu_img_job* jobs, int n) {
+  ImgJobs J; int mw, mh;
+  int rc = pack_jobs(ctx, jobs, n, J, mw, mh);
+  if (rc) return rc;
+  dim3 blk(64, 4), grd((mw + 63) / 64, (mh + 3) / 4, n);
+  vwgpu_prof_scope ps(ctx, "mask_by_two");
+  hipLaunchKernelGGL(mask_by_two_kernel, grd, blk, 0, ctx->stream, J);
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }
 
 int vwgpu_launch_mask_by_two(vwgpu_ctx* ctx, const uint8_t* src, int w, int h, ptrdiff_t stride,
                              uint8_t* dst, ptrdiff_t dstride) {
-  const int ow = 1 + (w - 1) / 2, oh = 1 + (h - 1) / 2;
-  dim3 blk(64, 4), grd((ow + 63) / 64, (oh + 3) / 4);
-  vwgpu_prof_scope ps(ctx, "mask_by_two");
-  hipLaunchKernelGGL(mask_by_two_kernel, grd, blk, 0, ctx->stream, src, stride, w, h, dst, dstride, ow, oh);
+  const vwgpu_img_job j{src, stride, w, h, dst, dstride, 1 + (w - 1) / 2, 1 + (h - 1) / 2, 0, 0, nullptr, 0};
+  return vwgpu_launch_mask_by_two_jobs(ctx, &j, 1);
+}
+
+int vwgpu_launch_subtract_jobs(vwgpu_ctx* ctx, const vwgpu_img_job* jobs, int n) {
+  ImgJobs J; int mw, mh;
+  int rc = pack_jobs(ctx, jobs, n, J, mw, mh);
+  if (rc) return rc;
+  dim3 blk(64, 4), grd((mw + 63) / 64, (mh + 3) / 4, n);
+  vwgpu_prof_scope ps(ctx, "subtract");
+  hipLaunchKernelGGL(subtract_kernel, grd, blk, 0, ctx->stream, J);
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }
 
 int vwgpu_launch_subtract(vwgpu_ctx* ctx, const float* a, ptrdiff_t as, const float* b, ptrdiff_t bs, int w, int h,
                           float* dst, ptrdiff_t ds) {
-  dim3 blk(64, 4), grd((w + 63) / 64, (h + 3) / 4);
-  vwgpu_prof_scope ps(ctx, "subtract");
-  hipLaunchKernelGGL(subtract_kernel, grd, blk, 0, ctx->stream, a, as, b, bs, w, h, dst, ds);
-  VWGPU_HIP(ctx, hipGetLastError());
-  return VWGPU_OK;
+  const vwgpu_img_job j{a, as, w, h, dst, ds, w, h, 0, 0, b, bs};
+  return vwgpu_launch_subtract_jobs(ctx, &j, 1);
 }
 
 int vwgpu_launch_ext_sub(vwgpu_ctx* ctx, const float* a, ptrdiff_t as, int w, int h, const float* b, ptrdiff_t bs,

@@ -38,6 +38,25 @@ using vwgpu::SearchZone;
 
 // ---- small kernels ----------------------------------------------------------------------------------------------
 
+// The six base crops of a tile (two float images, four mask crops) in ONE launch: job = blockIdx.z.
+struct CropJob { const void* src; ptrdiff_t stride; int w, h, x0, y0; void* dst; int dw, dh; int is_float, edge; };
+struct CropJobs { CropJob j[6]; };
+__global__ void crop_jobs_kernel(CropJobs jobs) {
+  const CropJob J = jobs.j[blockIdx.z];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= J.dw || y >= J.dh) return;
+  int sx = J.x0 + x, sy = J.y0 + y;
+  const bool outside = sx < 0 || sy < 0 || sx >= J.w || sy >= J.h;
+  sx = sx < 0 ? 0 : (sx >= J.w ? J.w - 1 : sx);
+  sy = sy < 0 ? 0 : (sy >= J.h ? J.h - 1 : sy);
+  if (J.is_float) {
+    static_cast<float*>(J.dst)[(size_t)y * J.dw + x] = (J.edge == 1 && outside) ? 0.0f : static_cast<const float*>(J.src)[(ptrdiff_t)sy * J.stride + sx];
+  } else {
+    const uint8_t v = (J.edge == 1 && outside) ? (uint8_t)0 : (J.src ? static_cast<const uint8_t*>(J.src)[(ptrdiff_t)sy * J.stride + sx] : (uint8_t)255);
+    static_cast<uint8_t*>(J.dst)[(size_t)y * J.dw + x] = v;
+  }
+}
+
 // dst(x,y) = src(ext(x0+x, y0+y)); EDGE 0 = clamp, 1 = zero.  src == nullptr means "an all-255 mask".
 template <class T, int EDGE>
 __global__ void crop_ext_kernel(const T* __restrict__ src, ptrdiff_t stride, int w, int h, int x0, int y0,
@@ -499,12 +518,16 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   if (!lp[0].p || !rp[0].p || !lmx || !rmx || !lmp[0].p || !rmp[0].p || !d_acc) return fail_mem();
   {
     vwgpu_prof_scope ps(ctx, "pyramid_base_crops");
-    hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(lp[0].w, lp[0].h), kBlk, 0, st, left, ls, lw, lh, lg.x0, lg.y0, lp[0].p, lp[0].w, lp[0].h);
-    hipLaunchKernelGGL((crop_ext_kernel<float, 0>), grid2(rp[0].w, rp[0].h), kBlk, 0, st, right, rs, rw, rh, rg.x0, rg.y0, rp[0].p, rp[0].w, rp[0].h);
-    hipLaunchKernelGGL((crop_ext_kernel<uint8_t, 0>), grid2(lp[0].w, lp[0].h), kBlk, 0, st, lmask, lms, lw, lh, lg.x0, lg.y0, lmx, lp[0].w, lp[0].h);
-    hipLaunchKernelGGL((crop_ext_kernel<uint8_t, 0>), grid2(rp[0].w, rp[0].h), kBlk, 0, st, rmask, rms, rw, rh, rg.x0, rg.y0, rmx, rp[0].w, rp[0].h);
-    hipLaunchKernelGGL((crop_ext_kernel<uint8_t, 1>), grid2(bw, bh), kBlk, 0, st, lmask, lms, lw, lh, bbox.x0, bbox.y0, lmp[0].p, bw, bh);
-    hipLaunchKernelGGL((crop_ext_kernel<uint8_t, 1>), grid2(rmp[0].w, rmp[0].h), kBlk, 0, st, rmask, rms, rw, rh, rmb.x0, rmb.y0, rmp[0].p, rmp[0].w, rmp[0].h);
+    CropJobs cj;
+    cj.j[0] = CropJob{left, ls, lw, lh, lg.x0, lg.y0, lp[0].p, lp[0].w, lp[0].h, 1, 0};
+    cj.j[1] = CropJob{right, rs, rw, rh, rg.x0, rg.y0, rp[0].p, rp[0].w, rp[0].h, 1, 0};
+    cj.j[2] = CropJob{lmask, lms, lw, lh, lg.x0, lg.y0, lmx, lp[0].w, lp[0].h, 0, 0};
+    cj.j[3] = CropJob{rmask, rms, rw, rh, rg.x0, rg.y0, rmx, rp[0].w, rp[0].h, 0, 0};
+    cj.j[4] = CropJob{lmask, lms, lw, lh, bbox.x0, bbox.y0, lmp[0].p, bw, bh, 0, 1};
+    cj.j[5] = CropJob{rmask, rms, rw, rh, rmb.x0, rmb.y0, rmp[0].p, rmp[0].w, rmp[0].h, 0, 1};
+    const int cmw = std::max(std::max(lp[0].w, rp[0].w), std::max(bw, rmp[0].w)), cmh = std::max(std::max(lp[0].h, rp[0].h), std::max(bh, rmp[0].h));
+    dim3 cgrd((cmw + 63) / 64, (cmh + 3) / 4, 6);
+    hipLaunchKernelGGL(crop_jobs_kernel, cgrd, kBlk, 0, st, cj);
   }
   // nodata mean fill (:130-149)
   {
@@ -558,24 +581,30 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     lmp[i].w = 1 + (lmp[i - 1].w - 1) / 2; lmp[i].h = 1 + (lmp[i - 1].h - 1) / 2; lmp[i].p = A.take<uint8_t>((size_t)lmp[i].w * lmp[i].h);
     rmp[i].w = 1 + (rmp[i - 1].w - 1) / 2; rmp[i].h = 1 + (rmp[i - 1].h - 1) / 2; rmp[i].p = A.take<uint8_t>((size_t)rmp[i].w * rmp[i].h);
     if (!lp[i].p || !rp[i].p || !lmp[i].p || !rmp[i].p) return fail_mem();
-    if ((rc = vwgpu_launch_sepconv(ctx, lp[i - 1].p, lp[i - 1].w, lp[i - 1].h, lp[i - 1].w, k5, 5, 2, k5, 5, 2, 0, 2, lp[i].p, lp[i].w))) return rc;
-    if ((rc = vwgpu_launch_sepconv(ctx, rp[i - 1].p, rp[i - 1].w, rp[i - 1].h, rp[i - 1].w, k5, 5, 2, k5, 5, 2, 0, 2, rp[i].p, rp[i].w))) return rc;
-    if ((rc = vwgpu_launch_mask_by_two(ctx, lmp[i - 1].p, lmp[i - 1].w, lmp[i - 1].h, lmp[i - 1].w, lmp[i].p, lmp[i].w))) return rc;
-    if ((rc = vwgpu_launch_mask_by_two(ctx, rmp[i - 1].p, rmp[i - 1].w, rmp[i - 1].h, rmp[i - 1].w, rmp[i].p, rmp[i].w))) return rc;
+    // both images of the level in one launch, both masks in another (four launches of ~12 us on these sizes otherwise)
+    const vwgpu_img_job sj[2] = {{lp[i - 1].p, lp[i - 1].w, lp[i - 1].w, lp[i - 1].h, lp[i].p, lp[i].w, lp[i].w, lp[i].h, 0, 0, nullptr, 0},
+                                 {rp[i - 1].p, rp[i - 1].w, rp[i - 1].w, rp[i - 1].h, rp[i].p, rp[i].w, rp[i].w, rp[i].h, 0, 0, nullptr, 0}};
+    if ((rc = vwgpu_launch_sepconv_jobs(ctx, sj, 2, k5, 5, 2, k5, 5, 2, 0, 2))) return rc;
+    const vwgpu_img_job mj[2] = {{lmp[i - 1].p, lmp[i - 1].w, lmp[i - 1].w, lmp[i - 1].h, lmp[i].p, lmp[i].w, lmp[i].w, lmp[i].h, 0, 0, nullptr, 0},
+                                 {rmp[i - 1].p, rmp[i - 1].w, rmp[i - 1].w, rmp[i - 1].h, rmp[i].p, rmp[i].w, rmp[i].w, rmp[i].h, 0, 0, nullptr, 0}};
+    if ((rc = vwgpu_launch_mask_by_two_jobs(ctx, mj, 2))) return rc;
   }
   // prefilter every level (:232-236); levels stay unfiltered sources of the next level, so filter into copies
   const bool use_sgm = P->algorithm != 0;
   // SGM/MGM run without a prefilter (CorrelationView.h:96-97)
   const bool filtered = !use_sgm && (P->prefilter_mode == VWGPU_PREFILTER_LOG || P->prefilter_mode == VWGPU_PREFILTER_MEANSUB);
   if (filtered) {
+    // every level of both images through the same two launches (gaussian, then laplacian / subtraction)
+    std::vector<const float*> fs; std::vector<float*> fd; std::vector<int> fw, fh;
     for (int i = 0; i <= L; ++i) {
       float* lf = A.take<float>((size_t)lp[i].w * lp[i].h);
       float* rf = A.take<float>((size_t)rp[i].w * rp[i].h);
       if (!lf || !rf) return fail_mem();
-      if ((rc = vwgpu_prefilter_image_dev(ctx, lp[i].p, lp[i].w, lp[i].h, lp[i].w, P->prefilter_mode, P->prefilter_width, lf, lp[i].w))) return rc;
-      if ((rc = vwgpu_prefilter_image_dev(ctx, rp[i].p, rp[i].w, rp[i].h, rp[i].w, P->prefilter_mode, P->prefilter_width, rf, rp[i].w))) return rc;
+      fs.push_back(lp[i].p); fd.push_back(lf); fw.push_back(lp[i].w); fh.push_back(lp[i].h);
+      fs.push_back(rp[i].p); fd.push_back(rf); fw.push_back(rp[i].w); fh.push_back(rp[i].h);
       lp[i].p = lf; rp[i].p = rf;
     }
+    if ((rc = vwgpu_prefilter_images_dev(ctx, (int)fs.size(), fs.data(), fw.data(), fh.data(), P->prefilter_mode, P->prefilter_width, fd.data()))) return rc;
   }
 
   // Class of every level: when the box sums of a level could round, its zones are matched in the reference's own

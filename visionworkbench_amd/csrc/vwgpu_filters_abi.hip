@@ -183,6 +183,48 @@ int vwgpu_prefilter_image_dev(vwgpu_ctx* ctx, const float* d_src, int w, int h, 
   return vwgpu_launch_conv2d(ctx, g, w, h, w, lap, 3, 3, 1, 1, 0, d_dst, dstride);
 }
 
+}  // extern "C"
+
+// prefilter_image for several dense images in two launches (the pyramid of a tile: both images of every level, CorrelationView.cc:232-236)
+int vwgpu_prefilter_images_dev(vwgpu_ctx* ctx, int n, const float* const* srcs, const int* ws, const int* hs, int mode, float width, float* const* dsts) {
+  if (n <= 0) return VWGPU_OK;
+  if (mode != VWGPU_PREFILTER_LOG && mode != VWGPU_PREFILTER_MEANSUB) {
+    for (int i = 0; i < n; ++i)
+      if (srcs[i] != dsts[i]) VWGPU_HIP(ctx, hipMemcpyAsync(dsts[i], srcs[i], (size_t)ws[i] * hs[i] * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return VWGPU_OK;
+  }
+  float taps[1024];
+  const int nt = vwgpu_generate_gaussian_kernel((double)width, 0, taps, 1024);
+  if (nt < 0) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "prefilter_image: prefilter width %g too large", (double)width);
+  const float lap[9] = {0, 1, 0, 1, -4, 1, 0, 1, 0};                               // Filter.h:320-335
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) total += vwgpu_align_up((size_t)ws[i] * hs[i] * sizeof(float), 256);
+  int rc = nt ? vwgpu_arena_reserve(ctx, &ctx->filt, total) : VWGPU_OK;
+  if (rc) return rc;
+  for (int i0 = 0; i0 < n; i0 += VWGPU_MAX_IMG_JOBS) {
+    const int m = std::min(VWGPU_MAX_IMG_JOBS, n - i0);
+    vwgpu_img_job a[VWGPU_MAX_IMG_JOBS], b[VWGPU_MAX_IMG_JOBS];
+    char* g = static_cast<char*>(ctx->filt.base);
+    for (int i = 0; i < i0; ++i) g += vwgpu_align_up((size_t)ws[i] * hs[i] * sizeof(float), 256);
+    for (int k = 0; k < m; ++k) {
+      const int i = i0 + k, w = ws[i], h = hs[i];
+      float* gi = reinterpret_cast<float*>(g);
+      g += vwgpu_align_up((size_t)w * h * sizeof(float), 256);
+      if (nt == 0) gi = const_cast<float*>(srcs[i]);                           // sigma == 0: gaussian_filter is the identity
+      a[k] = vwgpu_img_job{srcs[i], w, w, h, gi, w, w, h, 0, 0, nullptr, 0};    // gaussian_filter(image, kernel_width)
+      if (mode == VWGPU_PREFILTER_MEANSUB) b[k] = vwgpu_img_job{srcs[i], w, w, h, dsts[i], w, w, h, 0, 0, gi, w};     // image - gaussian (PreFilter.h:73)
+      else b[k] = vwgpu_img_job{gi, w, w, h, dsts[i], w, w, h, 0, 0, nullptr, 0};                                      // laplacian_filter(gaussian)
+    }
+    if (nt && (rc = vwgpu_launch_sepconv_jobs(ctx, a, m, taps, nt, (nt - 1) / 2, taps, nt, (nt - 1) / 2, 0, 1))) return rc;
+    if (mode == VWGPU_PREFILTER_MEANSUB) rc = vwgpu_launch_subtract_jobs(ctx, b, m);
+    else rc = vwgpu_launch_conv2d_jobs(ctx, b, m, lap, 3, 3, 1, 1, 0);
+    if (rc) return rc;
+  }
+  return VWGPU_OK;
+}
+
+extern "C" {
+
 int vwgpu_prefilter_image(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
                           int mode, float width, float* dst, ptrdiff_t dstride) {
   int rc = check_image(ctx, "prefilter_image", src, w, h, stride, dst);

@@ -174,6 +174,21 @@ int vwgpu_launch_lr_check_diff(vwgpu_ctx* ctx, int32_t* l2r, int lw, int lh, ptr
                                float* diff2, ptrdiff_t dstride, int ulx, int uly);
 
 // filters.hip
+// One launch serves up to VWGPU_MAX_IMG_JOBS images (blockIdx.z = job): the pyramid of a tile is ~60 filter launches of 10-20 us on small
+// images, launch bound — the left and right image of a level, or all twelve level images of a prefilter, go through ONE launch.
+constexpr int VWGPU_MAX_IMG_JOBS = 12;
+struct vwgpu_img_job {
+  const void* src; ptrdiff_t stride; int w, h;        // source image
+  void* dst; ptrdiff_t dstride; int ow, oh;           // destination and output size
+  int offx, offy;                                     // source position of output (0, 0)
+  const float* b; ptrdiff_t bs;                       // second operand (subtract / edge_extend_sub), or nullptr
+};
+int vwgpu_launch_sepconv_jobs(vwgpu_ctx* ctx, const vwgpu_img_job* jobs, int n, const float* xk, int nx, int cx, const float* yk, int ny, int cy,
+                              int edge, int step);
+int vwgpu_launch_conv2d_jobs(vwgpu_ctx* ctx, const vwgpu_img_job* jobs, int n, const float* k, int kw, int kh, int ci, int cj, int edge);
+int vwgpu_launch_mask_by_two_jobs(vwgpu_ctx* ctx, const vwgpu_img_job* jobs, int n);
+int vwgpu_launch_subtract_jobs(vwgpu_ctx* ctx, const vwgpu_img_job* jobs, int n);
+int vwgpu_prefilter_images_dev(vwgpu_ctx* ctx, int n, const float* const* srcs, const int* ws, const int* hs, int mode, float width, float* const* dsts);
 int vwgpu_launch_sepconv(vwgpu_ctx* ctx, const float* src, int w, int h, ptrdiff_t stride,
                          const float* xk, int nx, int cx, const float* yk, int ny, int cy,
                          int edge, int step, float* dst, ptrdiff_t dstride);
