@@ -127,7 +127,7 @@ struct ZMergeItem { int zone, txy, slot0, nitems, gate, pad0, pad1, pad2; };
 struct ZPart { double* best; double* worst; int* idx; double* second; double* rpmax; int* bad; int* redo; };
 // certification constants of a zone: bounds on |tile-parallel sum - reference running sum| (see vwgpu_launch_bm_zones)
 struct ZCert { double eps_s, eps_ll, eps_rr, pad; };
-struct ZCertArgs { const ZCert* zc; int* zflag; unsigned long long* stats; };      // zc == nullptr: no certification
+struct ZCertArgs { const ZCert* zc; int* zflag; unsigned long long* stats; int* any; };      // zc == nullptr: no certification; any: "some zone was flagged"
 
 // "can this pixel's result be proven equal to the reference's?"  best / second / worst / rpmax: what the chain has seen over ALL D
 // disparities of the pixel (second = the best cost among the disparities other than the winner; equal costs => second == best).
@@ -406,7 +406,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
   if (CERT) {
     const int any = __syncthreads_or(uncert ? 1 : 0);
     if (t == 0) {
-      if (any) C.zflag[it.zone] = 1;
+      if (any) { C.zflag[it.zone] = 1; if (C.any) *C.any = 1; }
       if (C.stats) { atomicAdd(&C.stats[any ? 1 : 0], (unsigned long long)(tw * th)); }
     }
   }
@@ -467,7 +467,7 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
   if (CERT) {
     const int any = __syncthreads_or(uncert ? 1 : 0);
     if (t == 0) {
-      if (any) C.zflag[it.zone] = 1;
+      if (any) { C.zflag[it.zone] = 1; if (C.any) *C.any = 1; }
       if (C.stats) { atomicAdd(&C.stats[any ? 1 : 0], (unsigned long long)(tw * th)); }
     }
   }
@@ -591,7 +591,7 @@ size_t zones_lds_fixed(int zs, int kx, int ky, size_t accb) { return (size_t)(zs
 
 int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
                           int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out, int f32_sums, int cert_hi, int* d_zflag,
-                          unsigned long long* d_stats) {
+                          unsigned long long* d_stats, int* d_any) {
   const bool cert = cert_hi != INT_MIN;
   if (cost_type == VWGPU_CROSS_CORRELATION || cert) f32_sums = 0;        // (NCC sums are scaled in float64 anyway)
   const size_t accb = f32_sums ? 4 : 8;
@@ -750,7 +750,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
       plan[k].P.redo = f; f += plan[k].merges.size();
     }
   }
-  ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats};
+  ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats, d_any};
   if (cert) VWGPU_HIP(ctx, hipMemsetAsync(d_zflag, 0, (size_t)n * sizeof(int), ctx->stream));
 
 #define VW_ZN4(C_, K_, A_, T_, S_) hipLaunchKernelGGL((bm_zones_kernel<C_, K_, A_, T_, S_>), grd, dim3(S_ * S_ / 4), pl.lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, tab, pl.sxc, pa, pb, out, pl.P, C)

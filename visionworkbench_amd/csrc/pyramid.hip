@@ -805,24 +805,45 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
       if (lr_active && rl_pixels) { if ((rc = vwgpu_arena_reserve(ctx, &ctx->zrl, rl_pixels * 12))) return rc; }
       // One matching pass over a zone list: the tile kernels when the level is order free; the tile kernels WITH certification plus the
       // exact-order kernels gated by the zone flags when it is finite but not order free; the exact-order kernels alone otherwise.
+      // The exact-order launches behind a certified pass are queued only if some zone was flagged: the two directions' "any zone
+      // flagged" words come back in one small copy (one more host round trip per certified level, hidden by the other tile threads;
+      // twelve gated launches of ~6 us that find nothing to do are not — measured 0.25 ms of a 2 ms LoG + NCC tile).
+      struct Pending { const float* a; int aw, ah; const float* b; int bw, bh; const std::vector<vwgpu_zone_task>* tz; int32_t* dst; int* zflag; };
+      std::vector<Pending> pending;
+      int* d_any = nullptr;
       auto match = [&](const float* a, int aw_, int ah_, const float* b, int bw_, int bh_, std::vector<vwgpu_zone_task> const& tz, int32_t* dst) -> int {
         if (tz.empty()) return VWGPU_OK;
         if (!exact) return vwgpu_launch_bm_zones(ctx, P->cost_type, a, aw_, ah_, b, bw_, bh_, kx, ky, tz.data(), (int)tz.size(), dst, f32_level[level]);
         if (cert_hi[level] != INT_MIN) {
+          if (!d_any) {
+            d_any = A.take<int>(64);
+            if (!d_any) return fail_mem();
+            VWGPU_HIP(ctx, hipMemsetAsync(d_any, 0, 2 * sizeof(int), st));
+          }
           int* zflag = A.take<int>(tz.size());
           if (!zflag) return fail_mem();
-          int rc2 = vwgpu_launch_bm_zones(ctx, P->cost_type, a, aw_, ah_, b, bw_, bh_, kx, ky, tz.data(), (int)tz.size(), dst, 0, cert_hi[level], zflag, d_cert_stats);
+          int rc2 = vwgpu_launch_bm_zones(ctx, P->cost_type, a, aw_, ah_, b, bw_, bh_, kx, ky, tz.data(), (int)tz.size(), dst, 0, cert_hi[level], zflag, d_cert_stats,
+                                          d_any + pending.size());
           if (rc2) return rc2;
-          return vwgpu_launch_bm_exact(ctx, P->cost_type, a, aw_, ah_, aw_, b, bw_, bh_, bw_, kx, ky, tz.data(), (int)tz.size(), dst, zflag);
+          pending.push_back(Pending{a, aw_, ah_, b, bw_, bh_, &tz, dst, zflag});
+          return VWGPU_OK;
         }
         return vwgpu_launch_bm_exact(ctx, P->cost_type, a, aw_, ah_, aw_, b, bw_, bh_, bw_, kx, ky, tz.data(), (int)tz.size(), dst);
       };
+      int32_t* rlbuf = static_cast<int32_t*>(ctx->zrl.base);
       if ((rc = match(Lv.p, Lv.w, Lv.h, Rv.p, Rv.w, Rv.h, t1, disp))) return rc;
-      if (lr_active) {
-        int32_t* rlbuf = static_cast<int32_t*>(ctx->zrl.base);
-        if ((rc = match(Rv.p, Rv.w, Rv.h, Lv.p, Lv.w, Lv.h, t2, rlbuf))) return rc;
-        if ((rc = vwgpu_launch_zone_lr(ctx, t3.data(), (int)t3.size(), disp, rlbuf, P->consistency_threshold, lr_diff, lr_stride))) return rc;
+      if (lr_active && (rc = match(Rv.p, Rv.w, Rv.h, Lv.p, Lv.w, Lv.h, t2, rlbuf))) return rc;
+      if (!pending.empty()) {
+        int any[2] = {0, 0};
+        VWGPU_HIP(ctx, hipMemcpyAsync(any, d_any, sizeof any, hipMemcpyDeviceToHost, st));
+        VWGPU_HIP(ctx, hipStreamSynchronize(st));
+        for (size_t k = 0; k < pending.size(); ++k) {
+          if (!any[k]) continue;
+          const Pending& q = pending[k];
+          if ((rc = vwgpu_launch_bm_exact(ctx, P->cost_type, q.a, q.aw, q.ah, q.aw, q.b, q.bw, q.bh, q.bw, kx, ky, q.tz->data(), (int)q.tz->size(), q.dst, q.zflag))) return rc;
+        }
       }
+      if (lr_active && (rc = vwgpu_launch_zone_lr(ctx, t3.data(), (int)t3.size(), disp, rlbuf, P->consistency_threshold, lr_diff, lr_stride))) return rc;
     } else if (!use_sgm)
     for (SearchZone const& z : zones) {
       const IBox lr(z.region.x0 + rox - hkx, z.region.y0 + roy - hky, z.region.x1 + rox + hkx, z.region.y1 + roy + hky);

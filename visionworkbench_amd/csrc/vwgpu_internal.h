@@ -235,7 +235,8 @@ bool vwgpu_bm_zones_supported(int kx, int ky);
 // d_zflag[n] receives the zones that need vwgpu_launch_bm_exact; d_stats (optional): {pixels in certified tiles, in flagged tiles}
 int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
                           int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out, int f32_sums = 0,
-                          int cert_hi = (-2147483647 - 1), int* d_zflag = nullptr, unsigned long long* d_stats = nullptr);
+                          int cert_hi = (-2147483647 - 1), int* d_zflag = nullptr, unsigned long long* d_stats = nullptr,
+                          int* d_any = nullptr);      // d_any (optional, zeroed by the caller): set to 1 when some zone was flagged
 // lr tasks: ax = pixel offset of the zone's R->L image, (bx, by) = its size, (sx, sy) = the zone's origin in the diff image
 int vwgpu_launch_zone_lr(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, int32_t* l2r, const int32_t* r2l, float thr,
                          float* diff2, ptrdiff_t dstride);
