@@ -16,6 +16,7 @@ import os
 ctx.set_option(core.OPT_EXACT_SPLIT, int(os.environ.get("PYR_EXACT_SPLIT", "0")))      # tool-side switch
 ONLY = os.environ.get("PYR_ONLY", "")
 ctx.set_option(core.OPT_ZONE_SXC, int(os.environ.get("PYR_ZONE_SXC", "0")))
+TRACE = int(os.environ.get("PYR_TRACE", "0"))                     # 2: the shape of every level's work on stderr, 4: certification counts
 for pf, cost, k in cases:
     if ONLY and ONLY != "%d,%d,%d" % (pf, cost, k): continue
     args = dict(consistency_threshold=2, filter_half_kernel=5, max_pyramid_levels=5, bbox=BBox2i(256, 256, tile, tile))
@@ -23,7 +24,9 @@ for pf, cost, k in cases:
     run(); torch.cuda.synchronize()
     t0 = time.perf_counter(); out = run(); torch.cuda.synchronize(); wall = time.perf_counter() - t0
     ctx.profile_enable(True); ctx.profile_reset()
+    ctx.set_option(core.OPT_TRACE, TRACE)
     run(); torch.cuda.synchronize()
+    ctx.set_option(core.OPT_TRACE, 0)
     rec = ctx.profile_read(1 << 16)
     ctx.profile_enable(False)
     agg = collections.OrderedDict()

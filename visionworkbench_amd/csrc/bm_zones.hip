@@ -45,6 +45,11 @@
 // ran, its item's evaluations} in a buffer set through vwgpu_debug_set_zone_stamps.  Not in the product library.
 __device__ unsigned long long* g_zone_stamps = nullptr;
 __device__ unsigned int g_zone_stamp_count = 0;
+// knock-out experiments (tools/zones_knockout.py): bits switch parts of the big launches (> 2000 workgroups) off — wrong results, honest timing
+__device__ int g_zone_knock = 0;
+extern "C" int vwgpu_debug_set_zone_knock(int bits) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_zone_knock), &bits, sizeof bits) == hipSuccess ? 0 : -3;
+}
 extern "C" int vwgpu_debug_set_zone_stamps(void* d_buf) {
   unsigned long long* p = static_cast<unsigned long long*>(d_buf);
   unsigned int zero = 0;
@@ -76,11 +81,12 @@ struct PrecView {           // 1 / box-sum(img^2) over origins [x0, x0+w) x [y0,
 
 // prec(x, y) = 1.0 / sum_{ky x kx} img(clamp)^2 for window origins (x0 + i, y0 + j).  A 64 x 4 output tile: the squares of its
 // (64 + kx - 1) x (4 + ky - 1) pixels go to LDS once, then row sums and column sums (the direct form read kx * ky floats per output
-// through the L1: 0.3 ms per 1024^2 NCC tile).  Only used on data whose box sums are exact in any order (vwgpu_sums_order_free).
+// through the L1: 0.3 ms per 1024^2 NCC tile).  Used on data whose box sums are exact in any order (vwgpu_sums_order_free) and, as
+// sqrt(1 / S) (root != 0), by the certified pass, whose error bound covers the order of the sums.
 struct ZPrecJob { const float* img; int w, h; double* prec; int x0, y0, pw, ph; };
 struct ZPrecJobs { ZPrecJob j[2]; };           // blockIdx.z: the left and the right image of a pass in one launch
 __global__ void __launch_bounds__(256)
-zone_precision_kernel(ZPrecJobs jobs, int kx, int ky) {
+zone_precision_kernel(ZPrecJobs jobs, int kx, int ky, int root) {
   extern __shared__ double zp_sm[];
   const ZPrecJob J = jobs.j[blockIdx.z];
   const float* __restrict__ img = J.img;
@@ -111,7 +117,7 @@ zone_precision_kernel(ZPrecJobs jobs, int kx, int ky) {
   if (i >= pw || j >= ph) return;
   double s = 0.0;
   for (int b = 0; b < ky; ++b) s += hs[(threadIdx.y + b) * 64 + threadIdx.x];
-  prec[(size_t)j * pw + i] = 1.0 / s;
+  prec[(size_t)j * pw + i] = root ? sqrt(1.0 / s) : 1.0 / s;           // root: the certified kernels multiply by sqrt(1 / S), see there
 }
 
 // A work item: disparities [i0, i0 + n) (index = dy * sx + dx, the reference's loop order) of one 32 x 32 tile of one zone.
@@ -129,19 +135,22 @@ struct ZPart { double* best; double* worst; int* idx; double* second; double* rp
 struct ZCert { double eps_s, eps_ll, eps_rr, pad; };
 struct ZCertArgs { const ZCert* zc; int* zflag; unsigned long long* stats; int* any; };      // zc == nullptr: no certification; any: "some zone was flagged"
 
-// "can this pixel's result be proven equal to the reference's?"  best / second / worst / rpmax: what the chain has seen over ALL D
-// disparities of the pixel (second = the best cost among the disparities other than the winner; equal costs => second == best).
+// "can this pixel's result be proven equal to the reference's?"  best / second / rpmax: what the chain has seen over ALL D disparities of
+// the pixel (second = the best cost among the disparities other than the winner; equal costs => second == best).  A certified pixel with
+// D >= 2 is valid (best > second >= worst in the reference's arithmetic too), so the chain keeps no `worst`; D == 1 is invalid by
+// definition (best == worst in any arithmetic).
 template <int COST>
-__device__ __forceinline__ bool zcertified(const ZCert& zc, int D, bool bad, double best, double second, double worst, double lprec, double rpmax) {
+__device__ __forceinline__ bool zcertified(const ZCert& zc, int D, bool bad, double best, double second, double lprec, double rpmax) {
   if (bad) return false;                                     // a non-finite cost: the reference's chain is order dependent there
-  if (D == 1) return true;                                   // best == worst in any arithmetic: invalid, like the reference
+  if (D == 1) return true;
   double eps;
   if (COST == VWGPU_CROSS_CORRELATION) {
-    // cost = S_lr * sqrt((1 / S_ll) * (1 / S_rr)), every S off by at most its eps, 1/x and sqrt propagated to first order with a factor 2
+    // cost = S_lr * sqrt((1 / S_ll) * (1 / S_rr)), every S off by at most its eps, 1/x and sqrt propagated to first order with a factor 2.
+    // |cost| <= 1 for every disparity (Cauchy-Schwarz: the three sums run over the same window positions), up to the roundings.
     const double dl = 2.0 * zc.eps_ll * lprec, dr = 2.0 * zc.eps_rr * rpmax;
     if (!(lprec > 0.0) || !(rpmax > 0.0) || !(dl <= 0x1p-10) || !(dr <= 0x1p-10)) return false;
-    const double cmax = fmax(fabs(best), fabs(worst));
-    eps = 2.0 * (cmax * (dl + dr + 0x1p-49 + 0x1p-36) + zc.eps_s * sqrt(lprec * rpmax));      // 2^-36: zsqrt_cert
+    const double cmax = fmax(1.0 + 0x1p-20, fmax(fabs(best), fabs(second)));
+    eps = 2.0 * (cmax * (dl + dr + 0x1p-49) + zc.eps_s * sqrt(lprec * rpmax));      // 2^-49: the roundings of either way to the cost
   } else {
     eps = zc.eps_s;
   }
@@ -149,17 +158,55 @@ __device__ __forceinline__ bool zcertified(const ZCert& zc, int D, bool bad, dou
   return gap > 2.0 * eps;                                    // (false for NaN)
 }
 
-// sqrt for the certified kernels: the seed of v_rsq_f64 and ONE Goldschmidt step (the first of the three the exact sequence takes).  The
-// certificate only needs a cost within a known distance of the reference's: zcertified charges 2^-36 relative for this (a seed good to
-// 2^-19 already gives 2^-37 after the step; the hardware seed is far better).  0, negative, infinite and subnormal arguments give NaN or
-// inf: a non-finite cost, no certificate.
-__device__ __forceinline__ double zsqrt_cert(double x) {
-  const double y = __builtin_amdgcn_rsq(x);
-  const double g = x * y, h = 0.5 * y;
-  const double r = __builtin_fma(-h, g, 0.5);
-  return __builtin_fma(g, r, g);
+// The certified pass scores NCC as S_lr * sr * sl with sl = sqrt(1 / S_ll), sr = sqrt(1 / S_rr) from the precision images (the reference:
+// S_lr * sqrt((1 / S_ll) * (1 / S_rr)), CostFunctions.h:207-236 — a square root sequence per evaluation): the same number up to a
+// handful of roundings on either side (2^-49 in zcertified).  sl is the same for all disparities of a pixel, so the chain runs on
+// S_lr * sr and sl scales its records afterwards.  zcertified takes precisions: the callers square the roots.
+// min / max of the chain as the bare instructions: fmin / fmax spell a canonicalisation (v_max_f64 x, x, x) in front of every operand that
+// comes round the loop — five of the 21 instructions of an evaluation.  A NaN operand is ignored (IEEE mode: the other one is returned).
+__device__ __forceinline__ double zmin_raw(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double zmax_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+typedef float zfloat2 __attribute__((ext_vector_type(2)));
+
+// N window sums of KS elements from KS + N - 1 elements e[]: w[j] = e[j] + ... + e[j + KS - 1].  Not as a slide (w' = w - e_old + e_new: one
+// chain of KS + 2 N dependent float64 additions, and four wavefronts per SIMD do not cover the latency of such a chain — knock-out
+// timing, tools/zones_knockout.py) but as the elements every window shares, summed as a tree, plus a run of prefix sums on either side:
+// three independent chains of depth <= N.  On order-free data any order gives the same bits; with CERT the roundings are part of eps.
+template <int n, typename ACC>
+__device__ __forceinline__ ACC ztree_sum(const ACC* e) {
+  if constexpr (n == 1) return e[0];
+  else if constexpr (n == 2) return e[0] + e[1];
+  else return ztree_sum<n / 2, ACC>(e) + ztree_sum<n - n / 2, ACC>(e + n / 2);
+}
+template <int KS, int N, typename ACC>
+__device__ __forceinline__ void zwindow_sums(const ACC* e, ACC* w) {
+  if constexpr (KS >= N) {
+    const ACC core = ztree_sum<KS - N + 1, ACC>(e + N - 1);      // e[N - 1 .. KS - 1]: in every window
+    ACC left[N], right[N];                                      // left[j] = e[j] + ... + e[N - 2], right[j] = e[KS] + ... + e[KS + j - 1]
+    left[N - 2] = e[N - 2];
+#pragma unroll
+    for (int j = N - 3; j >= 0; --j) left[j] = e[j] + left[j + 1];
+    right[1] = e[KS];
+#pragma unroll
+    for (int j = 2; j < N; ++j) right[j] = right[j - 1] + e[KS + j - 1];
+    w[0] = left[0] + core;
+#pragma unroll
+    for (int j = 1; j < N - 1; ++j) w[j] = (left[j] + core) + right[j];
+    w[N - 1] = core + right[N - 1];
+  } else {
+    ACC sacc = e[0];
+#pragma unroll
+    for (int a = 1; a < KS; ++a) sacc += e[a];
+    w[0] = sacc;
+#pragma unroll
+    for (int j = 1; j < N; ++j) { sacc = sacc - e[j - 1] + e[j - 1 + KS]; w[j] = sacc; }
+  }
 }
 
+#ifndef VWGPU_TILE_STAMPS
+#define ZKNOCK(bit) false
+#endif
 // KS > 0: a square KS x KS window known at compile time — the horizontal and vertical window sums are unrolled (with run-time
 // sizes the loop overhead outweighed the sums, as PMC showed for bm_generic).  KS == 0: any kx, ky.
 // ACC: the type of the window sums.  float64 is the reference's; float32 is taken when every intermediate value is exactly representable in 24
@@ -174,17 +221,20 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
   extern __shared__ char smem[];
   // tile side, threads, columns per horizontal item (float64 sums: four — eight need 36 registers for the elements alone and cost a
   // resident workgroup per CU), items per row
-  constexpr int ZT = ZS, ZTHREADS = ZS * ZS / 4, HW = sizeof(ACC) == 4 ? 8 : 4, QL = ZS / HW;
+  constexpr int ZT = ZS, ZTHREADS = ZS * ZS / 4, HW = 8, QL = ZS / HW;
   const ZItem it = items[blockIdx.x];
   if (it.gate >= 0 && P.redo[it.gate] == 0) return;               // redo launch: only the tiles the merge flagged
 #ifdef VWGPU_TILE_STAMPS
+  const int knock = gridDim.x > 2000 ? g_zone_knock : 0;
+#define ZKNOCK(bit) (knock & (bit))
   unsigned long long stamp_t0 = 0;
   if (g_zone_stamps && threadIdx.x == 0) stamp_t0 = wall_clock64();
 #endif
   // LDS pitches: ODD row pitches for the two float patches and ZT + 1 for the sum planes.  A horizontal item is lane <-> (row, group of
   // HW columns): with the natural pitches (42 floats at 11 x 11, 32 sums) the rows of a half wave fell on the same banks — four-way
   // conflicts on every patch read, eight-way on the plane writes (PMC round 4: 40 % of the LDS-active cycles were conflict cycles).
-  const int PW = (ZT + kx - 1) | 1, PH = ZT + ky - 1, RW = (ZT + kx - 1 + sxc - 1) | 1;
+  // (compile-time for a compile-time window: the row offsets of the vertical pass become immediate offsets of the LDS reads)
+  const int PW = KS > 0 ? ((ZT + KS - 1) | 1) : ((ZT + kx - 1) | 1), PH = KS > 0 ? ZT + KS - 1 : ZT + ky - 1, RW = (ZT + kx - 1 + sxc - 1) | 1;
   constexpr int HP = ZT + 1;
   float* Lp = reinterpret_cast<float*>(smem);                    // PH x PW
   float* Rp = Lp + PH * PW;                                      // PH x RW
@@ -213,7 +263,6 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
   double best[4], worst[4], lprec[4], second[4], rpmax[4];
   int bidx[4];
   bool bad = false;
-  double fsum = 0.0;                                            // CERT: every cost of the thread added up — non-finite iff one of them was
   constexpr double kBestInit = COST == VWGPU_CROSS_CORRELATION ? -INFINITY : INFINITY;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -256,7 +305,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
       ACC* Hc = H + hb * (PH * HP);
       if (COST == VWGPU_CROSS_CORRELATION) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) rpn[m] = prow[m] ? prow[m][d] : 0.0;
+        for (int m = 0; m < 4; ++m) rpn[m] = (prow[m] && !ZKNOCK(32)) ? prow[m][d] : 0.0;
       }
       if (KS > 0) {
         // HW adjacent columns per thread: KS + HW - 1 cost elements are formed once and the window slides (s' = s - e[j] + e[j + KS]).
@@ -269,15 +318,30 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
             const float* lp = Lp + r * PW + q;
             const float* rp = Rp + r * RW + q + d;
             ACC e[KS > 0 ? KS + HW - 1 : 1];
+            if (COST == VWGPU_CROSS_CORRELATION && (KS + HW - 1) % 2 == 0) {      // two float products per instruction (v_pk_mul_f32)
 #pragma unroll
-            for (int a = 0; a < KS + HW - 1; ++a) e[a] = zcost<COST, ACC>(lp[a], rp[a]);
-            ACC sacc = 0;
+              for (int a = 0; a < KS + HW - 1; a += 2) {
+                zfloat2 l2 = {lp[a], lp[a + 1]}, r2 = {rp[a], rp[a + 1]};
+                if (ZKNOCK(1)) { l2.x = __int_as_float(i + a); l2.y = __int_as_float(i - a); r2 = l2; }
+                const zfloat2 p2 = l2 * r2;
+                e[a] = (ACC)p2.x; e[a + 1] = (ACC)p2.y;
+              }
+            } else {
 #pragma unroll
-            for (int a = 0; a < KS; ++a) sacc += e[a];
+              for (int a = 0; a < KS + HW - 1; ++a) e[a] = zcost<COST, ACC>(lp[a], rp[a]);
+            }
+            ACC wsum[HW];
+            zwindow_sums<KS, HW, ACC>(e, wsum);
             ACC* h = Hc + r * HP + q;
-            h[0] = sacc;
+            if (ZKNOCK(2)) {
+              ACC tot = 0;
 #pragma unroll
-            for (int j = 1; j < HW; ++j) { sacc = sacc - e[j - 1] + e[j - 1 + KS]; h[j] = sacc; }
+              for (int j = 0; j < HW; ++j) tot += wsum[j];
+              if (tot == (ACC)12345.678) h[0] = tot;
+            } else {
+#pragma unroll
+              for (int j = 0; j < HW; ++j) h[j] = wsum[j];
+            }
           }
         }
       } else {
@@ -292,18 +356,18 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
           }
         }
       }
-      __syncthreads();
+      if (!ZKNOCK(16)) __syncthreads();
       if (c < tw) {
         const int di = i0 + d;
         const bool first = (di == it.i0);
+        int div = di;
+        if (CERT) asm volatile("" : "+v"(div));                   // one copy to a vector register per disparity instead of one per select
         ACC vs[4] = {0, 0, 0, 0};
         if (KS > 0) {                                           // the same slide down the rows (rows beyond th hold stale planes: unused)
           ACC h[KS > 0 ? KS + 3 : 1];
 #pragma unroll
-          for (int b = 0; b < KS + 3; ++b) h[b] = Hc[min(y0 + b, PH - 1) * HP + c];
-#pragma unroll
-          for (int b = 0; b < KS; ++b) vs[0] += h[b];
-          vs[1] = vs[0] - h[0] + h[KS]; vs[2] = vs[1] - h[1] + h[KS + 1]; vs[3] = vs[2] - h[2] + h[KS + 2];
+          for (int b = 0; b < KS + 3; ++b) h[b] = ZKNOCK(4) ? (ACC)(t + b + d) : Hc[(y0 + b) * HP + c];          // y0 + b <= ZT - 4 + KS + 2 = PH - 1
+          zwindow_sums<KS, 4, ACC>(h, vs);
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -314,28 +378,27 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
               for (int b = 0; b < ky; ++b) sa += Hc[(y + b) * HP + c];
             }
             double s = (double)sa;
-            if (CERT) {
-              // Certified pass: the chain of Correlation.cc:91-117 reduced to what a certificate needs — minimum with its first index,
-              // runner-up (= min over the others: min(second, max(s, best)) before best moves; equal costs give second == best),
-              // maximum, largest right precision — as min / max instructions instead of compare-and-select pairs (20 -> 8 per
-              // evaluation).  A NaN cost is ignored by min / max and caught by fsum; such a pixel has no certificate anyway.
+            if (CERT && ZKNOCK(8)) { best[m] += s; }
+            else if (CERT) {
+              // Certified pass: the chain of Correlation.cc:91-117 reduced to what a certificate needs — the minimum with its first index, the
+              // runner-up (= min over the others: min(second, max(s, best)) before best moves; equal costs give second == best) and, NCC,
+              // the largest right factor — as min / max instructions instead of compare-and-select pairs: 5 (NCC 7) instructions per
+              // evaluation, 20 before.  Non-finite costs: the level holds finite pixels below 2^60 (cert_hi), so S_lr is finite; an
+              // infinite right factor shows in rpmax, an infinite cost in best — both end without a certificate.
               if (COST == VWGPU_CROSS_CORRELATION) {
-                const double rp = rpn[m];
-                rpmax[m] = fmax(rpmax[m], rp);
-                s *= zsqrt_cert(lprec[m] * rp);
+                const double rp = rpn[m];                                  // sqrt(1 / S_rr); the left factor scales the records afterwards
+                rpmax[m] = zmax_raw(rpmax[m], rp);
+                s *= rp;
               }
-              fsum += s;
               const bool cb = zbetter<COST>(s, best[m]);
               if (COST == VWGPU_CROSS_CORRELATION) {
-                second[m] = fmax(second[m], fmin(s, best[m]));
-                best[m] = fmax(best[m], s);
-                worst[m] = fmin(worst[m], s);
+                second[m] = zmax_raw(second[m], zmin_raw(s, best[m]));
+                best[m] = zmax_raw(best[m], s);
               } else {
-                second[m] = fmin(second[m], fmax(s, best[m]));
-                best[m] = fmin(best[m], s);
-                worst[m] = fmax(worst[m], s);
+                second[m] = zmin_raw(second[m], zmax_raw(s, best[m]));
+                best[m] = zmin_raw(best[m], s);
               }
-              bidx[m] = cb ? di : bidx[m];
+              bidx[m] = cb ? div : bidx[m];
             } else {
             if (COST == VWGPU_CROSS_CORRELATION) {
               const double rp = rpn[m];
@@ -358,7 +421,6 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
     }
     i0 += nd;
   }
-  if (CERT) bad = !(fabs(fsum) <= 1.7976931348623157e308);
 #ifdef VWGPU_TILE_STAMPS
   if (g_zone_stamps && threadIdx.x == 0) {
     unsigned hw, xcc;
@@ -380,8 +442,13 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
         const int y = y0 + m;
         if (y < th) {
           const size_t o = base + (size_t)y * ZT + c;
-          P.best[o] = best[m]; P.worst[o] = worst[m]; P.idx[o] = bidx[m];
-          if (CERT) { P.second[o] = second[m]; if (COST == VWGPU_CROSS_CORRELATION) P.rpmax[o] = rpmax[m]; }
+          P.best[o] = best[m]; P.idx[o] = bidx[m];
+          if (CERT) {
+            P.second[o] = second[m]; if (COST == VWGPU_CROSS_CORRELATION) P.rpmax[o] = rpmax[m];
+            bad = bad || !(fabs(best[m]) <= 1.7976931348623157e308);
+          } else {
+            P.worst[o] = worst[m];
+          }
         }
       }
     }
@@ -398,8 +465,14 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
         int32_t* o = out + ((size_t)z.out_off + (size_t)(oy + y) * z.out_stride + ox + c) * 3;
         const int by_ = bidx[m] / z.sx, bx_ = bidx[m] - by_ * z.sx;
         o[0] = bx_ + z.addx; o[1] = by_ + z.addy;
-        o[2] = (best[m] == worst[m]) ? 0 : 0x7fffffff;
-        if (CERT && !zcertified<COST>(C.zc[it.zone], D, bad, best[m], second[m], worst[m], lprec[m], rpmax[m])) uncert = true;
+        if (CERT) {
+          const bool ncc = COST == VWGPU_CROSS_CORRELATION;         // NCC: lprec / rpmax hold square roots of precisions here
+          const double sl = ncc ? lprec[m] : 1.0;
+          o[2] = D == 1 ? 0 : 0x7fffffff;                           // (what a certificate implies; an uncertified zone is matched again)
+          if (!zcertified<COST>(C.zc[it.zone], D, !(fabs(best[m]) <= 1.7976931348623157e308), best[m] * sl, second[m] * sl, sl * sl, rpmax[m] * rpmax[m])) uncert = true;
+        } else {
+          o[2] = (best[m] == worst[m]) ? 0 : 0x7fffffff;
+        }
       }
     }
   }
@@ -441,7 +514,7 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
       int bi = 0;
       for (int k = 0; k < it.nitems; ++k) {
         const size_t o = (size_t)(it.slot0 + k) * (ZT * ZT) + (size_t)y * ZT + c;
-        const double b = P.best[o], w = P.worst[o];
+        const double b = P.best[o], w = CERT ? 0.0 : P.worst[o];
         const double sc = CERT ? P.second[o] : 0.0;
         if (k == 0) { best = b; worst = w; bi = P.idx[o]; second = sc; }
         else {
@@ -449,18 +522,19 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
             if (CERT) second = zbetter<COST>(sc, best) ? sc : best;
             best = b; bi = P.idx[o];
           } else if (CERT && zbetter<COST>(b, second)) second = b;
-          if (!zbetter<COST>(w, worst)) worst = w;
+          if (!CERT && !zbetter<COST>(w, worst)) worst = w;
         }
         if (CERT && COST == VWGPU_CROSS_CORRELATION) rpmax = fmax(rpmax, P.rpmax[o]);
       }
       int32_t* o3 = out + ((size_t)z.out_off + (size_t)(oy + y) * z.out_stride + ox + c) * 3;
       const int by_ = bi / z.sx, bx_ = bi - by_ * z.sx;
       o3[0] = bx_ + z.addx; o3[1] = by_ + z.addy;
-      o3[2] = (best == worst) ? 0 : 0x7fffffff;
+      o3[2] = CERT ? (D == 1 ? 0 : 0x7fffffff) : ((best == worst) ? 0 : 0x7fffffff);
       if (CERT) {
         double lprec = 0.0;
         if (COST == VWGPU_CROSS_CORRELATION) lprec = pa.p[(size_t)(z.ay + oy + y - pa.y0) * pa.w + (z.ax + ox + c - pa.x0)];
-        if (!zcertified<COST>(C.zc[it.zone], D, bad, best, second, worst, lprec, rpmax)) uncert = true;
+        const double sl = COST == VWGPU_CROSS_CORRELATION ? lprec : 1.0;       // (square roots of precisions, as in bm_zones_kernel)
+        if (!zcertified<COST>(C.zc[it.zone], D, bad, best * sl, second * sl, sl * sl, rpmax * rpmax)) uncert = true;
       }
     }
   }
@@ -697,7 +771,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     ZPrecJobs zj;
     zj.j[0] = ZPrecJob{A, aw, ah, da, pa.x0, pa.y0, pa.w, pa.h};
     zj.j[1] = ZPrecJob{B, bw, bh, db, pb.x0, pb.y0, pb.w, pb.h};
-    hipLaunchKernelGGL(zone_precision_kernel, dim3((std::max(pa.w, pb.w) + 63) / 64, (std::max(pa.h, pb.h) + 3) / 4, 2), dim3(64, 4), zp_lds, ctx->stream, zj, kx, ky);
+    hipLaunchKernelGGL(zone_precision_kernel, dim3((std::max(pa.w, pb.w) + 63) / 64, (std::max(pa.h, pb.h) + 3) / 4, 2), dim3(64, 4), zp_lds, ctx->stream, zj, kx, ky, cert ? 1 : 0);
     pa.p = da; pb.p = db;
   }
   {
