@@ -38,4 +38,4 @@ for pf, cost, k in cases:
         print("   %-28s launches %6d  device %.3f ms" % (n, c, ms))
     if os.environ.get("PYR_LAUNCHES"):              # every launch of the matchers in stream order (coarsest level first)
         print("   launches (us): " + " ".join("%s=%.0f" % (n.replace("bm_zones", "z").replace("bmx_", "x"), ms * 1e3) for n, ms in rec
-                                               if n.startswith("bm_zones") or n.startswith("bmx_") or n == "zone_precision"))
+                                               if os.environ["PYR_LAUNCHES"] == "all" or n.startswith("bm_zones") or n.startswith("bmx_") or n == "zone_precision"))

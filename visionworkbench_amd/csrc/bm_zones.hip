@@ -133,7 +133,35 @@ struct ZMergeItem { int zone, txy, slot0, nitems, gate, pad0, pad1, pad2; };
 struct ZPart { double* best; double* worst; int* idx; double* second; double* rpmax; int* bad; int* redo; };
 // certification constants of a zone: bounds on |tile-parallel sum - reference running sum| (see vwgpu_launch_bm_zones)
 struct ZCert { double eps_s, eps_ll, eps_rr, pad; };
-struct ZCertArgs { const ZCert* zc; int* zflag; unsigned long long* stats; int* any; };      // zc == nullptr: no certification; any: "some zone was flagged"
+struct ZCertArgs { const ZCert* zc; int* zflag; unsigned long long* stats; int* any; const int* need; const unsigned char* cells; };      // zc == nullptr: no certification; any: "some zone was flagged"
+// need != nullptr (the R->L pass of a level with the L/R check): eight ints per zone from zone_need_kernel — the rectangle of the zone the
+// check will read, and where the zone's 16 x 16-pixel cell flags start.  The tiles are laid from the rectangle's corner and stop at its
+// far side, and a tile none of whose cells holds a position the check reads is skipped; the rest of the zone is not matched (every pixel
+// of these kernels is independent of the others, so the pixels that are matched get the same result).
+struct ZGeom { int ox, oy, tw, th; };
+template <int ZT>
+__device__ __forceinline__ bool ztile_geometry(const vwgpu_zone_task& z, int zone, int txy, const int* need, const unsigned char* cells, ZGeom& g) {
+  int x0 = 0, y0 = 0, x1 = z.zw, y1 = z.zh;
+  int cell0 = -1;
+  if (need) {
+    const int4 b = reinterpret_cast<const int4*>(need)[2 * zone];   // {zw - x0, zh - y0, x1, y1} as maxima, all 0 = nothing needed
+    if (b.z <= 0) return false;
+    x0 = z.zw - b.x; y0 = z.zh - b.y; x1 = b.z; y1 = b.w;
+    const int4 e = reinterpret_cast<const int4*>(need)[2 * zone + 1];      // {first cell, 1 = every cell, -, -}
+    if (e.y == 0) cell0 = e.x;
+  }
+  g.ox = x0 + (txy & 0xffff) * ZT; g.oy = y0 + (txy >> 16) * ZT;
+  if (g.ox >= x1 || g.oy >= y1) return false;
+  g.tw = min(ZT, x1 - g.ox); g.th = min(ZT, y1 - g.oy);
+  if (cell0 >= 0) {
+    const int ncx = (z.zw + 15) >> 4;
+    bool any = false;
+    for (int cy = g.oy >> 4; cy <= (g.oy + g.th - 1) >> 4; ++cy)
+      for (int cx = g.ox >> 4; cx <= (g.ox + g.tw - 1) >> 4; ++cx) any = any || cells[cell0 + cy * ncx + cx] != 0;
+    if (!any) return false;
+  }
+  return true;
+}
 
 // "can this pixel's result be proven equal to the reference's?"  best / second / rpmax: what the chain has seen over ALL D disparities of
 // the pixel (second = the best cost among the disparities other than the winner; equal costs => second == best).  A certified pixel with
@@ -241,8 +269,9 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
   ACC* H = reinterpret_cast<ACC*>(smem + (((size_t)(PH * PW + PH * RW) * 4 + 7) & ~size_t(7)));   // 2 x PH x HP
 
   const vwgpu_zone_task z = zones[it.zone];
-  const int ox = (it.txy & 0xffff) * ZT, oy = (it.txy >> 16) * ZT;
-  const int tw = min(ZT, z.zw - ox), th = min(ZT, z.zh - oy);
+  ZGeom geom;
+  if (!ztile_geometry<ZT>(z, it.zone, it.txy, C.need, C.cells, geom)) return;          // (workgroup-uniform)
+  const int ox = geom.ox, oy = geom.oy, tw = geom.tw, th = geom.th;
   const int pw = tw + kx - 1, ph = th + ky - 1;
   const int t = threadIdx.x;
   const int c = t % ZT, y0 = (t / ZT) * 4;
@@ -493,8 +522,9 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
   constexpr int ZT = ZS;
   const ZMergeItem it = items[blockIdx.x];
   const vwgpu_zone_task z = zones[it.zone];
-  const int ox = (it.txy & 0xffff) * ZT, oy = (it.txy >> 16) * ZT;
-  const int tw = min(ZT, z.zw - ox), th = min(ZT, z.zh - oy);
+  ZGeom geom;
+  if (!ztile_geometry<ZT>(z, it.zone, it.txy, C.need, C.cells, geom)) return;
+  const int ox = geom.ox, oy = geom.oy, tw = geom.tw, th = geom.th;
   const int t = threadIdx.x;
   const int c = t % ZT, y0 = (t / ZT) * 4;
   bool bad = false;
@@ -575,6 +605,42 @@ __global__ void zone_lr_kernel(const vwgpu_zone_task* __restrict__ zones, const 
     p[0] = dx + z.addx; p[1] = dy + z.addy;
     if (!keep) p[2] = 0;
   }
+}
+
+// Which part of its R->L image will a zone's L/R check read?  zone_lr_kernel looks at (c + dx, r + dy) for every valid pixel (c, r) of the
+// L->R result: per zone the bounding rectangle of those positions as four maxima over a zeroed record — {w - x, h - y, x + 1, y + 1}
+// (w x h = the R->L image) — and a flag per 16 x 16 cell of the R->L image that holds one (z.ay = the zone's first cell).  A zone whose
+// L->R result is not final yet (flagged by the certified pass: the exact-order kernels will match it again) asks for everything.
+// Same tasks and tiles as zone_lr_kernel.
+__global__ void zone_need_kernel(const vwgpu_zone_task* __restrict__ zones, const int2* __restrict__ tiles, const int32_t* __restrict__ l2r,
+                                 const int* __restrict__ zflag, int* __restrict__ need, unsigned char* __restrict__ cells) {
+  __shared__ int acc[4];
+  const int2 tl = tiles[blockIdx.x];
+  const vwgpu_zone_task z = zones[tl.x];
+  int* rec = need + 8 * tl.x;
+  if (zflag && zflag[tl.x]) {
+    if (threadIdx.x == 0) { atomicMax(rec + 0, z.bx); atomicMax(rec + 1, z.by); atomicMax(rec + 2, z.bx); atomicMax(rec + 3, z.by); rec[5] = 1; }
+    return;
+  }
+  if (threadIdx.x < 4) acc[threadIdx.x] = 0;
+  if (threadIdx.x == 0) rec[4] = z.ay;
+  __syncthreads();
+  const int ox = (tl.y & 0xffff) * ZT, oy = (tl.y >> 16) * ZT;
+  const int c = ox + (threadIdx.x & 31);
+  const int ncx = (z.bx + 15) >> 4;
+  int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  if (c < z.zw)
+    for (int r = oy + (threadIdx.x >> 5); r < min(oy + ZT, z.zh); r += ZTHREADS / 32) {
+      const int32_t* p = l2r + ((size_t)z.out_off + (size_t)r * z.out_stride + c) * 3;
+      if (p[2] == 0) continue;
+      const int x = c + p[0], y = r + p[1];
+      if (x < 0 || x >= z.bx || y < 0 || y >= z.by) continue;
+      a0 = max(a0, z.bx - x); a1 = max(a1, z.by - y); a2 = max(a2, x + 1); a3 = max(a3, y + 1);
+      cells[z.ay + (y >> 4) * ncx + (x >> 4)] = 1;
+    }
+  if (a2 > 0) { atomicMax(&acc[0], a0); atomicMax(&acc[1], a1); atomicMax(&acc[2], a2); atomicMax(&acc[3], a3); }
+  __syncthreads();
+  if (threadIdx.x < 4 && acc[threadIdx.x] > 0) atomicMax(rec + threadIdx.x, acc[threadIdx.x]);
 }
 
 // Tables of one launch sequence, side by side in one half of the ztab arena (the previous sequence may still be reading the other half):
@@ -665,7 +731,7 @@ size_t zones_lds_fixed(int zs, int kx, int ky, size_t accb) { return (size_t)(zs
 
 int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
                           int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out, int f32_sums, int cert_hi, int* d_zflag,
-                          unsigned long long* d_stats, int* d_any) {
+                          unsigned long long* d_stats, int* d_any, const int* d_need, const unsigned char* d_cells) {
   const bool cert = cert_hi != INT_MIN;
   if (cost_type == VWGPU_CROSS_CORRELATION || cert) f32_sums = 0;        // (NCC sums are scaled in float64 anyway)
   const size_t accb = f32_sums ? 4 : 8;
@@ -824,7 +890,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
       plan[k].P.redo = f; f += plan[k].merges.size();
     }
   }
-  ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats, d_any};
+  ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats, d_any, d_need, d_cells};
   if (cert) VWGPU_HIP(ctx, hipMemsetAsync(d_zflag, 0, (size_t)n * sizeof(int), ctx->stream));
 
 #define VW_ZN4(C_, K_, A_, T_, S_) hipLaunchKernelGGL((bm_zones_kernel<C_, K_, A_, T_, S_>), grd, dim3(S_ * S_ / 4), pl.lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, tab, pl.sxc, pa, pb, out, pl.P, C)
@@ -881,6 +947,32 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
 #undef VW_ZN
 #undef VW_ZN3
 #undef VW_ZN4
+  VWGPU_HIP(ctx, hipGetLastError());
+  return VWGPU_OK;
+}
+
+size_t vwgpu_zone_need_cells(vwgpu_zone_task* zones, int n) {
+  size_t cells = 0;
+  for (int i = 0; i < n; ++i) {
+    zones[i].ay = (int)cells;
+    cells += (size_t)((zones[i].bx + 15) >> 4) * ((zones[i].by + 15) >> 4);
+  }
+  return cells;
+}
+
+int vwgpu_launch_zone_need(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, const int32_t* l2r, const int* d_zflag, int* d_need,
+                           unsigned char* d_cells, size_t ncells) {
+  if (n <= 0) return VWGPU_OK;
+  VWGPU_HIP(ctx, hipMemsetAsync(d_need, 0, (size_t)n * 8 * sizeof(int), ctx->stream));
+  VWGPU_HIP(ctx, hipMemsetAsync(d_cells, 0, ncells, ctx->stream));
+  std::vector<int2> tiles;
+  build_tiles(zones, n, tiles);
+  if (tiles.empty()) return VWGPU_OK;
+  const vwgpu_zone_task* dz; const int2* dt;
+  int rc = upload_tables(ctx, zones, n, tiles, &dz, &dt);
+  if (rc) return rc;
+  vwgpu_prof_scope ps(ctx, "zone_lr_need");
+  hipLaunchKernelGGL(zone_need_kernel, dim3((unsigned)tiles.size()), dim3(ZTHREADS), 0, ctx->stream, dz, dt, l2r, d_zflag, d_need, d_cells);
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }

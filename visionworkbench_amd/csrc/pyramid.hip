@@ -811,9 +811,12 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
       struct Pending { const float* a; int aw, ah; const float* b; int bw, bh; const std::vector<vwgpu_zone_task>* tz; int32_t* dst; int* zflag; };
       std::vector<Pending> pending;
       int* d_any = nullptr;
-      auto match = [&](const float* a, int aw_, int ah_, const float* b, int bw_, int bh_, std::vector<vwgpu_zone_task> const& tz, int32_t* dst) -> int {
+      const unsigned char* need_cells = nullptr;
+      auto match = [&](const float* a, int aw_, int ah_, const float* b, int bw_, int bh_, std::vector<vwgpu_zone_task> const& tz, int32_t* dst,
+                       const int* need) -> int {
         if (tz.empty()) return VWGPU_OK;
-        if (!exact) return vwgpu_launch_bm_zones(ctx, P->cost_type, a, aw_, ah_, b, bw_, bh_, kx, ky, tz.data(), (int)tz.size(), dst, f32_level[level]);
+        if (!exact) return vwgpu_launch_bm_zones(ctx, P->cost_type, a, aw_, ah_, b, bw_, bh_, kx, ky, tz.data(), (int)tz.size(), dst, f32_level[level],
+                                                 INT_MIN, nullptr, nullptr, nullptr, need, need ? need_cells : nullptr);
         if (cert_hi[level] != INT_MIN) {
           if (!d_any) {
             d_any = A.take<int>(64);
@@ -823,7 +826,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
           int* zflag = A.take<int>(tz.size());
           if (!zflag) return fail_mem();
           int rc2 = vwgpu_launch_bm_zones(ctx, P->cost_type, a, aw_, ah_, b, bw_, bh_, kx, ky, tz.data(), (int)tz.size(), dst, 0, cert_hi[level], zflag, d_cert_stats,
-                                          d_any + pending.size());
+                                          d_any + pending.size(), need, need ? need_cells : nullptr);
           if (rc2) return rc2;
           pending.push_back(Pending{a, aw_, ah_, b, bw_, bh_, &tz, dst, zflag});
           return VWGPU_OK;
@@ -831,8 +834,22 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         return vwgpu_launch_bm_exact(ctx, P->cost_type, a, aw_, ah_, aw_, b, bw_, bh_, bw_, kx, ky, tz.data(), (int)tz.size(), dst);
       };
       int32_t* rlbuf = static_cast<int32_t*>(ctx->zrl.base);
-      if ((rc = match(Lv.p, Lv.w, Lv.h, Rv.p, Rv.w, Rv.h, t1, disp))) return rc;
-      if (lr_active && (rc = match(Rv.p, Rv.w, Rv.h, Lv.p, Lv.w, Lv.h, t2, rlbuf))) return rc;
+      if ((rc = match(Lv.p, Lv.w, Lv.h, Rv.p, Rv.w, Rv.h, t1, disp, nullptr))) return rc;
+      if (lr_active && !t2.empty()) {
+        // The R->L pass only has to cover what the L/R check will look at: the positions the L->R disparities point to — about the zone
+        // itself instead of the zone widened by its search range (3x the pixels for a 16 x 16 leaf with 32 disparities).  Only where the
+        // tile kernels match (their pixels are independent of each other); the exact-order kernels need the whole zone for their sums.
+        int* need = nullptr;
+        if (!exact || cert_hi[level] != INT_MIN) {
+          const size_t ncells = vwgpu_zone_need_cells(t3.data(), (int)t3.size());
+          need = A.take<int>(8 * t3.size());
+          unsigned char* cells = A.take<unsigned char>(ncells + 16);
+          if (!need || !cells) return fail_mem();
+          if ((rc = vwgpu_launch_zone_need(ctx, t3.data(), (int)t3.size(), disp, pending.empty() ? nullptr : pending[0].zflag, need, cells, ncells))) return rc;
+          need_cells = cells;
+        }
+        if ((rc = match(Rv.p, Rv.w, Rv.h, Lv.p, Lv.w, Lv.h, t2, rlbuf, need))) return rc;
+      }
       if (!pending.empty()) {
         int any[2] = {0, 0};
         VWGPU_HIP(ctx, hipMemcpyAsync(any, d_any, sizeof any, hipMemcpyDeviceToHost, st));
