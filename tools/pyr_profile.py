@@ -22,7 +22,9 @@ for pf, cost, k in cases:
     args = dict(consistency_threshold=2, filter_half_kernel=5, max_pyramid_levels=5, bbox=BBox2i(256, 256, tile, tile))
     run = lambda: stereo.pyramid_correlate(Lg, Rg, None, None, pf, 1.4 if pf else 0.0, BBox2i.from_corners((-64, -1), (64, 1)), (k, k), cost, **args)
     run(); torch.cuda.synchronize()
+    if os.environ.get("PYR_TRACE_PLAIN"): ctx.set_option(core.OPT_TRACE, int(os.environ["PYR_TRACE_PLAIN"]))    # the host timeline without the profiler's events
     t0 = time.perf_counter(); out = run(); torch.cuda.synchronize(); wall = time.perf_counter() - t0
+    ctx.set_option(core.OPT_TRACE, 0)
     ctx.profile_enable(True); ctx.profile_reset()
     ctx.set_option(core.OPT_TRACE, TRACE)
     run(); torch.cuda.synchronize()
