@@ -28,6 +28,7 @@ t0 = st[:, 0].astype(np.float64); t1 = st[:, 1].astype(np.float64)
 base = t0.min()
 s_us, e_us = (t0 - base) / 100.0, (t1 - base) / 100.0
 ev = (st[:, 3] & np.uint64(0xffffffff)).astype(np.float64)
+shader_clk = (st[:, 3] >> np.uint64(32)).astype(np.float64)
 # launches = clusters of start times: a new launch begins after every workgroup of the previous one has ended
 order = np.argsort(s_us)
 launches, cur, cur_end = [], [order[0]], e_us[order[0]]
@@ -55,6 +56,8 @@ for li, idx in enumerate(launches):
           (li, len(idx), b - a, life.sum(), life.sum() / (b - a), ev[idx].sum() / 1e6))
     print("   life us p5/50/95/max: %.1f %.1f %.1f %.1f | evaluations per item p5/50/95/max: %.0f %.0f %.0f %.0f | evals per us of life p5/50/95: %.0f %.0f %.0f" %
           (*np.percentile(life, [5, 50, 95]), life.max(), *np.percentile(ev[idx], [5, 50, 95]), ev[idx].max(), *np.percentile(rate, [5, 50, 95])))
+    mhz = shader_clk[idx] / np.maximum(life, 1e-3)
+    print("   shader clock over a workgroup's life: p5 %.0f  median %.0f  p95 %.0f MHz" % tuple(np.percentile(mhz, [5, 50, 95])))
     print("   resident workgroups over the span (40 samples): " + " ".join(str(r) for r in res))
     print("   workgroups per CU: min %d max %d (%d CUs)" % (min(percu), max(percu), len(percu)))
     starts = np.sort(s_us[idx]) - a

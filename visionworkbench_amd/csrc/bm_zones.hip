@@ -255,8 +255,8 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
 #ifdef VWGPU_TILE_STAMPS
   const int knock = gridDim.x > 2000 ? g_zone_knock : 0;
 #define ZKNOCK(bit) (knock & (bit))
-  unsigned long long stamp_t0 = 0;
-  if (g_zone_stamps && threadIdx.x == 0) stamp_t0 = wall_clock64();
+  unsigned long long stamp_t0 = 0, stamp_c0 = 0;
+  if (g_zone_stamps && threadIdx.x == 0) { stamp_t0 = wall_clock64(); stamp_c0 = clock64(); }
 #endif
   // LDS pitches: ODD row pitches for the two float patches and ZT + 1 for the sum planes.  A horizontal item is lane <-> (row, group of
   // HW columns): with the natural pitches (42 floats at 11 x 11, 32 sums) the rows of a half wave fell on the same banks — four-way
@@ -350,8 +350,13 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
             if (COST == VWGPU_CROSS_CORRELATION && (KS + HW - 1) % 2 == 0) {      // two float products per instruction (v_pk_mul_f32)
 #pragma unroll
               for (int a = 0; a < KS + HW - 1; a += 2) {
-                zfloat2 l2 = {lp[a], lp[a + 1]}, r2 = {rp[a], rp[a + 1]};
-                if (ZKNOCK(1)) { l2.x = __int_as_float(i + a); l2.y = __int_as_float(i - a); r2 = l2; }
+#ifdef VWGPU_TILE_STAMPS
+                zfloat2 l2, r2;
+                if (ZKNOCK(1)) { l2.x = (float)(i + a); l2.y = (float)(i - a); r2 = l2; asm volatile("" : "+v"(l2.x), "+v"(r2.y)); }
+                else { l2 = zfloat2{lp[a], lp[a + 1]}; r2 = zfloat2{rp[a], rp[a + 1]}; }
+#else
+                const zfloat2 l2 = {lp[a], lp[a + 1]}, r2 = {rp[a], rp[a + 1]};
+#endif
                 const zfloat2 p2 = l2 * r2;
                 e[a] = (ACC)p2.x; e[a + 1] = (ACC)p2.y;
               }
@@ -395,7 +400,11 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
         if (KS > 0) {                                           // the same slide down the rows (rows beyond th hold stale planes: unused)
           ACC h[KS > 0 ? KS + 3 : 1];
 #pragma unroll
-          for (int b = 0; b < KS + 3; ++b) h[b] = ZKNOCK(4) ? (ACC)(t + b + d) : Hc[(y0 + b) * HP + c];          // y0 + b <= ZT - 4 + KS + 2 = PH - 1
+#ifdef VWGPU_TILE_STAMPS
+          for (int b = 0; b < KS + 3; ++b) { if (ZKNOCK(4)) { h[b] = (ACC)(t + b + d); asm volatile("" : "+v"(h[b])); } else h[b] = Hc[(y0 + b) * HP + c]; }
+#else
+          for (int b = 0; b < KS + 3; ++b) h[b] = Hc[(y0 + b) * HP + c];          // y0 + b <= ZT - 4 + KS + 2 = PH - 1
+#endif
           zwindow_sums<KS, 4, ACC>(h, vs);
         }
 #pragma unroll
@@ -459,7 +468,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
     if (k < (1u << 18)) {
       unsigned long long* rec = g_zone_stamps + (size_t)k * 4;
       rec[0] = stamp_t0; rec[1] = wall_clock64(); rec[2] = ((unsigned long long)xcc << 32) | hw;
-      rec[3] = ((unsigned long long)blockIdx.x << 32) | (unsigned)(it.n * tw * th);
+      rec[3] = ((unsigned long long)(unsigned)(clock64() - stamp_c0) << 32) | (unsigned)(it.n * tw * th);      // shader clocks of the item | its evaluations
     }
   }
 #endif
@@ -794,6 +803,9 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
       for (int tx = 0; tx < nx; ++tx) {
         const int tw = std::min(ZS, z.zw - tx * ZS), th = std::min(ZS, z.zh - ty * ZS);
         const double px = (double)tw * th;
+        // (Tried: three tiles in ten cut four times finer, so that short items fill the end of the launch, where a third of the wave slots
+        // stand empty for a third of the span — tools/zones_timeline.py.  The matcher launches got 10 % shorter and the merges of the
+        // extra records took it back: 28 bytes per pixel and run, written and read.)
         int pieces = (int)std::min<double>((double)D, std::ceil(px * (double)D / cap));
         if (pieces < 1) pieces = 1;
         const int txy = tx | (ty << 16);
