@@ -163,6 +163,33 @@ def test_disparity_filter_thresholds_and_shapes(vw, oracle, cleanup):
             assert np.array_equal(g, oracle.disparity_filter(d, hk[0], hk[1], pthr, rthr, cleanup)), (h, w, hk, pthr, rthr)
 
 
+@pytest.mark.parametrize("cleanup", [0, 1])
+def test_disparity_filter_packed_form_limits(vw, oracle, cleanup):
+    """The filter's packed 16-bit form serves tiles whose valid disparities are below 2^13 with a threshold below 2^13; everything else
+    takes the int32 form in the same launch: values at and beyond the limit (in a corner of the image only, so that both forms run),
+    int32 extremes (the difference wraps around like the reference's), garbage under invalid pixels, thresholds around 2^13."""
+    rng = np.random.default_rng(71)
+    fn = vw.disparity_cleanup_using_thresh if cleanup else vw.rm_outliers_using_thresh
+    V = np.iinfo(np.int32).max
+    for case in range(4):
+        d = _random_disparity(rng, 70, 150)
+        if case == 0:
+            d[:12, :40, 0] += rng.choice([8180, 8192, -8180, -8192, 20000], (12, 40))
+        elif case == 1:
+            d[30:, 100:, 1] = rng.choice([V, -V - 1, V - 3, 0, 5], d[30:, 100:, 1].shape)
+        elif case == 2:
+            inval = d[..., 2] == 0
+            d[..., 0][inval] = rng.integers(-2**31, 2**31 - 1, inval.sum())
+            d[..., 1][inval] = rng.integers(-2**31, 2**31 - 1, inval.sum())
+        else:
+            d[..., 0] = rng.integers(-8191, 8192, d.shape[:2]); d[..., 1] = rng.integers(-8191, 8192, d.shape[:2])
+            d[40:, :, 1] = rng.integers(-9000, 9000, d[40:, :, 1].shape)
+        for pthr in (3.0, 8191.0, 8192.0, 40000.0):
+            for hk in ((5, 5), (2, 3)):
+                g = fn(d, hk[0], hk[1], pthr, 0.3)
+                assert np.array_equal(g, oracle.disparity_filter(d, hk[0], hk[1], pthr, 0.3, cleanup)), (case, pthr, hk)
+
+
 def test_disparity_mask_identical(vw, oracle):
     rng = np.random.default_rng(8)
     d = _random_disparity(rng, 50, 70)

@@ -621,9 +621,19 @@ __global__ void zone_lr_kernel(const vwgpu_zone_task* __restrict__ zones, const 
 // (w x h = the R->L image) — and a flag per 16 x 16 cell of the R->L image that holds one (z.ay = the zone's first cell).  A zone whose
 // L->R result is not final yet (flagged by the certified pass: the exact-order kernels will match it again) asks for everything.
 // Same tasks and tiles as zone_lr_kernel.
+// maximum over the 64 lanes of a wavefront with DPP moves only (the pattern of sgm.hip's wave_min_u32)
+__device__ __forceinline__ unsigned zwave_max_u32(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __global__ void zone_need_kernel(const vwgpu_zone_task* __restrict__ zones, const int2* __restrict__ tiles, const int32_t* __restrict__ l2r,
                                  const int* __restrict__ zflag, int* __restrict__ need, unsigned char* __restrict__ cells) {
-  __shared__ int acc[4];
   const int2 tl = tiles[blockIdx.x];
   const vwgpu_zone_task z = zones[tl.x];
   int* rec = need + 8 * tl.x;
@@ -631,9 +641,7 @@ __global__ void zone_need_kernel(const vwgpu_zone_task* __restrict__ zones, cons
     if (threadIdx.x == 0) { atomicMax(rec + 0, z.bx); atomicMax(rec + 1, z.by); atomicMax(rec + 2, z.bx); atomicMax(rec + 3, z.by); rec[5] = 1; }
     return;
   }
-  if (threadIdx.x < 4) acc[threadIdx.x] = 0;
   if (threadIdx.x == 0) rec[4] = z.ay;
-  __syncthreads();
   const int ox = (tl.y & 0xffff) * ZT, oy = (tl.y >> 16) * ZT;
   const int c = ox + (threadIdx.x & 31);
   const int ncx = (z.bx + 15) >> 4;
@@ -647,9 +655,9 @@ __global__ void zone_need_kernel(const vwgpu_zone_task* __restrict__ zones, cons
       a0 = max(a0, z.bx - x); a1 = max(a1, z.by - y); a2 = max(a2, x + 1); a3 = max(a3, y + 1);
       cells[z.ay + (y >> 4) * ncx + (x >> 4)] = 1;
     }
-  if (a2 > 0) { atomicMax(&acc[0], a0); atomicMax(&acc[1], a1); atomicMax(&acc[2], a2); atomicMax(&acc[3], a3); }
-  __syncthreads();
-  if (threadIdx.x < 4 && acc[threadIdx.x] > 0) atomicMax(rec + threadIdx.x, acc[threadIdx.x]);
+  // (a shared-memory atomic per thread and value serialised 1024 updates per workgroup: 2 us of a 4 us workgroup)
+  a0 = (int)zwave_max_u32((unsigned)a0); a1 = (int)zwave_max_u32((unsigned)a1); a2 = (int)zwave_max_u32((unsigned)a2); a3 = (int)zwave_max_u32((unsigned)a3);
+  if ((threadIdx.x & 63) == 0 && a2 > 0) { atomicMax(rec + 0, a0); atomicMax(rec + 1, a1); atomicMax(rec + 2, a2); atomicMax(rec + 3, a3); }
 }
 
 // Tables of one launch sequence, side by side in one half of the ztab arena (the previous sequence may still be reading the other half):

@@ -164,25 +164,40 @@ __global__ void add_offset_kernel(int32_t* __restrict__ d, ptrdiff_t stride_px, 
 // neighbourhood rim are staged in LDS once (the direct version read 121 x 12 B per pixel through the L1: 0.3 ms per 1024^2 level).
 // `fabs((double)(a - b)) <= pthr` on int32 differences is the unsigned compare |a - b| <= floor(pthr) (thr; `never` for a
 // negative or NaN threshold); the match ratio is compared in float64 as the reference does.
+// Packed form: when every valid disparity of the tile is below 2^13 in magnitude and thr < 2^13 (always, in a pyramid) the tile is
+// ALSO staged as one dword per pixel — (dx + 2^14) | (dy + 2^14) << 16, 0xffffffff for an invalid pixel — and a neighbour is one LDS
+// read and four instructions: t = n + (thr - c) per half (v_pk_add_u16: |n - c| <= thr  <=>  t <= 2 thr as unsigned 16-bit values —
+// a negative n - c + thr wraps to more than 2^15, and the invalid code gives 65535 - (c + 2^14) + thr, between 2^15 and 2^16: it
+// never passes), max with 2 thr per half, compare with the splat, add the carry.  The three-array form took
+// ten instructions and three LDS reads per neighbour: 160 us of an 870 us SAD tile went into this filter.
+// HH > 0: hh == hv == HH known at compile time (the loops unroll: the small levels of a pyramid are latency bound here).
+template <int HH>
 __global__ void __launch_bounds__(256)
 rm_outliers_kernel(const int32_t* __restrict__ src, int w, int h, int hh, int hv, unsigned thr, int never, double rthr,
                    int32_t* __restrict__ dst, int ow, int oh, int ox0, int oy0) {
   extern __shared__ int32_t rm_sm[];
+  if (HH > 0) { hh = HH; hv = HH; }
   const int tw = 32 + 2 * hh, th = 8 + 2 * hv, tn = tw * th;
   int32_t* sx = rm_sm;
   int32_t* sy = rm_sm + tn;
-  uint8_t* sv = reinterpret_cast<uint8_t*>(rm_sm + 2 * tn);
+  unsigned* pk = reinterpret_cast<unsigned*>(rm_sm + 2 * tn);
+  uint8_t* sv = reinterpret_cast<uint8_t*>(rm_sm + 3 * tn);
   const int tid = threadIdx.y * 32 + threadIdx.x;
   const int bx = blockIdx.x * 32 + ox0 - hh, by = blockIdx.y * 8 + oy0 - hv;      // source coordinates of the tile's corner
+  bool big = thr >= 8192u;
   for (int i = tid; i < tn; i += 256) {
     const int ty = i / tw, tx = i - ty * tw;
     int x = bx + tx, y = by + ty;
     x = x < 0 ? 0 : (x >= w ? w - 1 : x);
     y = y < 0 ? 0 : (y >= h ? h - 1 : y);
     const int32_t* c = src + ((size_t)y * w + x) * 3;
-    sx[i] = c[0]; sy[i] = c[1]; sv[i] = c[2] != 0;
+    const int32_t d0 = c[0], d1 = c[1];
+    const bool v = c[2] != 0;
+    sx[i] = d0; sy[i] = d1; sv[i] = v;
+    if (v) big = big || d0 <= -8192 || d0 >= 8192 || d1 <= -8192 || d1 >= 8192;
+    pk[i] = v ? ((unsigned)(d0 + 16384) & 0xffffu) | ((unsigned)(d1 + 16384) << 16) : 0xffffffffu;
   }
-  __syncthreads();
+  const bool wide = __syncthreads_or(big ? 1 : 0) != 0;         // (also the barrier behind the staging)
   const int ox = blockIdx.x * 32 + threadIdx.x, oy = blockIdx.y * 8 + threadIdx.y;
   if (ox >= ow || oy >= oh) return;
   const int ci = (threadIdx.y + hv) * tw + threadIdx.x + hh;
@@ -192,7 +207,29 @@ rm_outliers_kernel(const int32_t* __restrict__ src, int w, int h, int hh, int hv
     const int x = min(max(ox + ox0, 0), w - 1), y = min(max(oy + oy0, 0), h - 1);
     r2 = src[((size_t)y * w + x) * 3 + 2];
     int matched = 0;
-    if (!never)
+    if (!never && !wide) {
+      typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+      const unsigned cb = ((thr - (unsigned)(r0 + 16384)) & 0xffffu) | ((thr - (unsigned)(r1 + 16384)) << 16);      // thr - c per half (mod 2^16)
+      const unsigned lim = (2u * thr) | ((2u * thr) << 16);
+      auto one = [&](unsigned n) __attribute__((always_inline)) {
+        const us2_t t = __builtin_bit_cast(us2_t, n) + __builtin_bit_cast(us2_t, cb);
+        const us2_t m = __builtin_elementwise_max(t, __builtin_bit_cast(us2_t, lim));
+        matched += __builtin_bit_cast(unsigned, m) == lim ? 1 : 0;
+      };
+      if (HH > 0) {
+#pragma unroll
+        for (int yk = 0; yk <= 2 * HH; ++yk) {
+          const unsigned* row = pk + (threadIdx.y + yk) * tw + threadIdx.x;
+#pragma unroll
+          for (int xk = 0; xk <= 2 * HH; ++xk) one(row[xk]);
+        }
+      } else {
+        for (int yk = 0; yk <= 2 * hv; ++yk) {
+          const unsigned* row = pk + (threadIdx.y + yk) * tw + threadIdx.x;
+          for (int xk = 0; xk <= 2 * hh; ++xk) one(row[xk]);
+        }
+      }
+    } else if (!never) {
       for (int yk = 0; yk <= 2 * hv; ++yk) {
         const int row = (threadIdx.y + yk) * tw + threadIdx.x;
         for (int xk = 0; xk <= 2 * hh; ++xk) {
@@ -202,6 +239,7 @@ rm_outliers_kernel(const int32_t* __restrict__ src, int w, int h, int hh, int hv
           matched += (sv[i] && a0 <= thr && a1 <= thr) ? 1 : 0;
         }
       }
+    }
     const int total = (2 * hh + 1) * (2 * hv + 1);
     if (((double)matched / (double)total) < rthr) { r0 = r1 = r2 = 0; }
   }
@@ -378,7 +416,7 @@ struct DevMask { uint8_t* p = nullptr; int w = 0, h = 0; };
 int vwgpu_launch_disparity_filter(vwgpu_ctx* ctx, const int32_t* src, int w, int h, int hh, int hv, double pthr, double rthr,
                                   bool cleanup, int32_t* tmp_padded, int32_t* dst) {
   if (hh < 0 || hv < 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "disparity filter: negative half kernel");
-  const size_t rm_lds = (size_t)(32 + 2 * hh) * (8 + 2 * hv) * 9;
+  const size_t rm_lds = (size_t)(32 + 2 * hh) * (8 + 2 * hv) * 13;
   const bool direct = rm_lds > 64 * 1024;
   // fabs((double)int32 difference) <= pthr  <=>  |difference| <= floor(pthr)
   const int never = !(pthr >= 0.0);                                   // negative or NaN: nothing matches
@@ -387,13 +425,16 @@ int vwgpu_launch_disparity_filter(vwgpu_ctx* ctx, const int32_t* src, int w, int
   if (!cleanup) {
     vwgpu_prof_scope ps(ctx, "rm_outliers");
     if (direct) hipLaunchKernelGGL(rm_outliers_direct_kernel, grid2(w, h), kBlk, 0, ctx->stream, src, w, h, hh, hv, pthr, rthr, dst, w, h, 0, 0);
-    else hipLaunchKernelGGL(rm_outliers_kernel, rm_grid(w, h), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr, dst, w, h, 0, 0);
+    else if (hh == 5 && hv == 5) hipLaunchKernelGGL(rm_outliers_kernel<5>, rm_grid(w, h), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr, dst, w, h, 0, 0);
+    else hipLaunchKernelGGL(rm_outliers_kernel<0>, rm_grid(w, h), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr, dst, w, h, 0, 0);
   } else {
     {
       vwgpu_prof_scope ps(ctx, "rm_outliers");
       if (direct) hipLaunchKernelGGL(rm_outliers_direct_kernel, grid2(w + 2, h + 2), kBlk, 0, ctx->stream, src, w, h, hh, hv, pthr, rthr,
                                      tmp_padded, w + 2, h + 2, -1, -1);
-      else hipLaunchKernelGGL(rm_outliers_kernel, rm_grid(w + 2, h + 2), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr,
+      else if (hh == 5 && hv == 5) hipLaunchKernelGGL(rm_outliers_kernel<5>, rm_grid(w + 2, h + 2), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr,
+                                                      tmp_padded, w + 2, h + 2, -1, -1);
+      else hipLaunchKernelGGL(rm_outliers_kernel<0>, rm_grid(w + 2, h + 2), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr,
                               tmp_padded, w + 2, h + 2, -1, -1);
     }
     vwgpu_prof_scope ps(ctx, "disparity_cleanup_outer");
