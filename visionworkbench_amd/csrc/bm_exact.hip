@@ -867,7 +867,11 @@ float_grain_kernel(GrainJobs jobs) {
   // A workgroup walks rows blockIdx.x, blockIdx.x + gridDim.x, ...; eight 256-pixel chunks of a row are in flight per thread (out-of-range
   // chunks read pixel 0 of the row, which is harmless to count twice).  (Flat chunk indices needed a 64-bit division per request: the kernel
   // was bound by those — 84 us for two 4096^2 images.)
-  for (int y = blockIdx.x; y < h; y += gridDim.x) {
+  // workgroups of this image: ~16 K pixels each but no more than eight rows (a row is a dependent round trip) — the launch is sized for
+  // the largest image of the batch; a 32 x 32 pyramid level gets five workgroups and sets of atomics, not eighty
+  const int nb = (int)min((size_t)gridDim.x, max((size_t)(h + 7) / 8, ((size_t)w * (size_t)h) >> 14));
+  if ((int)blockIdx.x >= nb) return;
+  for (int y = blockIdx.x; y < h; y += nb) {
     const float* row = img + (ptrdiff_t)y * stride;
     for (int xc = 0; xc < cols_per_row; xc += 8) {
       unsigned u[8];

@@ -655,7 +655,7 @@ zone_need_kernel(const vwgpu_zone_task* __restrict__ zones, const int2* __restri
     if (whole) { rec[0] = z.bx; rec[1] = z.by; rec[2] = z.bx; rec[3] = z.by; }
   }
   const int ncx = (z.bx + 15) >> 4, ncells = ncx * ((z.by + 15) >> 4);
-  const bool local = ncells <= LCELLS;
+  const bool local = whole && ncells <= LCELLS;                 // (a small zone's few workgroups store their flags directly)
   if (local) {
     for (int i = threadIdx.x; i < (ncells + 3) / 4; i += ZTHREADS) lc32[i] = 0u;
     __syncthreads();
@@ -671,20 +671,14 @@ zone_need_kernel(const vwgpu_zone_task* __restrict__ zones, const int2* __restri
       if (x < 0 || x >= z.bx || y < 0 || y >= z.by) continue;
       a0 = max(a0, z.bx - x); a1 = max(a1, z.by - y); a2 = max(a2, x + 1); a3 = max(a3, y + 1);
       const int ci = (y >> 4) * ncx + (x >> 4);
-      if (local) lc[ci] = 1; else if (cells[z.ay + ci] == 0) cells[z.ay + ci] = 1;
+      if (local) lc[ci] = 1; else cells[z.ay + ci] = 1;
     }
   if (!whole) { a0 = (int)zwave_max_u32((unsigned)a0); a1 = (int)zwave_max_u32((unsigned)a1); a2 = (int)zwave_max_u32((unsigned)a2); a3 = (int)zwave_max_u32((unsigned)a3); }
-  if (!whole && (threadIdx.x & 63) == 0 && a2 > 0) {            // (only where it raises the record)
-    const volatile int* seen = rec;
-    if (a0 > seen[0]) atomicMax(rec + 0, a0);
-    if (a1 > seen[1]) atomicMax(rec + 1, a1);
-    if (a2 > seen[2]) atomicMax(rec + 2, a2);
-    if (a3 > seen[3]) atomicMax(rec + 3, a3);
-  }
+  if (!whole && (threadIdx.x & 63) == 0 && a2 > 0) { atomicMax(rec + 0, a0); atomicMax(rec + 1, a1); atomicMax(rec + 2, a2); atomicMax(rec + 3, a3); }
   if (local) {
     __syncthreads();
     for (int i = threadIdx.x; i < ncells; i += ZTHREADS)
-      if (lc[i] && cells[z.ay + i] == 0) cells[z.ay + i] = 1;
+      if (lc[i]) cells[z.ay + i] = 1;
   }
 }
 

@@ -414,7 +414,7 @@ struct DevMask { uint8_t* p = nullptr; int w = 0, h = 0; };
 }  // namespace
 
 int vwgpu_launch_disparity_filter(vwgpu_ctx* ctx, const int32_t* src, int w, int h, int hh, int hv, double pthr, double rthr,
-                                  bool cleanup, int32_t* tmp_padded, int32_t* dst) {
+                                  bool cleanup, int32_t* tmp_padded, int32_t* dst, bool inner_only) {
   if (hh < 0 || hv < 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "disparity filter: negative half kernel");
   const size_t rm_lds = (size_t)(32 + 2 * hh) * (8 + 2 * hv) * 13;
   const bool direct = rm_lds > 64 * 1024;
@@ -437,8 +437,10 @@ int vwgpu_launch_disparity_filter(vwgpu_ctx* ctx, const int32_t* src, int w, int
       else hipLaunchKernelGGL(rm_outliers_kernel<0>, rm_grid(w + 2, h + 2), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr,
                               tmp_padded, w + 2, h + 2, -1, -1);
     }
-    vwgpu_prof_scope ps(ctx, "disparity_cleanup_outer");
-    hipLaunchKernelGGL(cleanup_outer_kernel, grid2(w, h), kBlk, 0, ctx->stream, tmp_padded, w, h, dst);
+    if (!inner_only) {                                              // (inner_only: the caller applies the second pass itself, see zone_extent_fused_kernel)
+      vwgpu_prof_scope ps(ctx, "disparity_cleanup_outer");
+      hipLaunchKernelGGL(cleanup_outer_kernel, grid2(w, h), kBlk, 0, ctx->stream, tmp_padded, w, h, dst);
+    }
   }
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
@@ -483,6 +485,56 @@ zone_extent_kernel(const int32_t* __restrict__ disp, int w, int h, const int4* _
     const int32_t* p = disp + ((size_t)y * w + x) * 3;
     if (!p[2]) continue;
     const int dx = p[0], dy = p[1];
+    anya = 1; loxa = min(loxa, dx); hixa = max(hixa, dx); loya = min(loya, dy); hiya = max(hiya, dy);
+    if (x >= r.x && x < r.z && y >= r.y && y < r.w) {
+      any = 1; lox = min(lox, dx); hix = max(hix, dx); loy = min(loy, dy); hiy = max(hiy, dy);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    any |= __shfl_xor(any, o); anya |= __shfl_xor(anya, o);
+    lox = min(lox, __shfl_xor(lox, o)); loy = min(loy, __shfl_xor(loy, o));
+    hix = max(hix, __shfl_xor(hix, o)); hiy = max(hiy, __shfl_xor(hiy, o));
+    loxa = min(loxa, __shfl_xor(loxa, o)); loya = min(loya, __shfl_xor(loya, o));
+    hixa = max(hixa, __shfl_xor(hixa, o)); hiya = max(hiya, __shfl_xor(hiya, o));
+  }
+  if (threadIdx.x == 0) {
+    int32_t* o = out + (size_t)leaf * 10;
+    o[0] = any; o[1] = lox; o[2] = loy; o[3] = hix; o[4] = hiy;
+    o[5] = anya; o[6] = loxa; o[7] = loya; o[8] = hixa; o[9] = hiya;
+  }
+}
+
+// The same measurement for an intermediate level of the block-matching branch, straight from the first pass of the clean-up filter: the
+// level's finished disparity image — second pass of disparity_cleanup_using_thresh (cleanup_outer_kernel), then disparity_mask
+// (disparity_mask_kernel) — is read by nothing but this scheduler, so the two point-wise passes are applied to the pixels a leaf looks
+// at as they are read, and the image itself is never written (two launches per level less; the small levels are launch bound).
+__global__ void __launch_bounds__(64)
+zone_extent_fused_kernel(const int32_t* __restrict__ inner, int w, int h, const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
+                         int m2w, int m2h, const int4* __restrict__ rects, int n, int32_t* __restrict__ out) {
+  const int leaf = blockIdx.x;
+  if (leaf >= n) return;
+  const int4 r = rects[leaf];                       // x0, y0, x1, y1
+  const int ax0 = max(r.x - 1, 0), ay0 = max(r.y - 1, 0), ax1 = min(r.z + 1, w), ay1 = min(r.w + 1, h);
+  const int aw = ax1 - ax0, count = aw * (ay1 - ay0);
+  const int pw = w + 2;
+  int any = 0, lox = INT_MAX, loy = INT_MAX, hix = INT_MIN, hiy = INT_MIN;
+  int anya = 0, loxa = INT_MAX, loya = INT_MAX, hixa = INT_MIN, hiya = INT_MIN;
+  for (int i = threadIdx.x; i < count; i += 64) {
+    const int yy = i / aw, x = ax0 + (i - yy * aw), y = ay0 + yy;
+    const int32_t* c = inner + ((size_t)(y + 1) * pw + (x + 1)) * 3;
+    const int dx = c[0], dy = c[1];
+    if (!c[2]) continue;
+    int matched = 0;                                 // cleanup_outer_kernel
+    for (int yk = -1; yk <= 1; ++yk)
+      for (int xk = -1; xk <= 1; ++xk) {
+        const int32_t* q = inner + ((size_t)(y + 1 + yk) * pw + (x + 1 + xk)) * 3;
+        if (q[2] && fabs((double)(dx - q[0])) <= 3.0 && fabs((double)(dy - q[1])) <= 3.0) matched++;
+      }
+    if (((double)matched / 9.0) < 0.20) continue;
+    if (m1[(size_t)y * w + x] == 0) continue;        // disparity_mask_kernel
+    const int tx = x + dx, ty = y + dy;
+    if (tx < 0 || tx >= m2w || ty < 0 || ty >= m2h || m2[(size_t)ty * m2w + tx] == 0) continue;
     anya = 1; loxa = min(loxa, dx); hixa = max(hixa, dx); loya = min(loya, dy); hiya = max(hiya, dy);
     if (x >= r.x && x < r.z && y >= r.y && y < r.w) {
       any = 1; lox = min(lox, dx); hix = max(hix, dx); loy = min(loy, dy); hiy = max(hiy, dy);
@@ -656,25 +708,26 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   // certify; only those are redone in the reference's order (VWGPU_OPT_CERTIFY = 0: every zone of such a level, as in round 3)
   std::vector<int> cert_hi(L + 1, INT_MIN);
   if (!use_sgm) {
-    int* d_cells = A.take<int>(4 * (size_t)(L + 1));
+    constexpr int CS = 16;                                          // a cache line per level: same-line atomics queue up at the L2
+    int* d_cells = A.take<int>(CS * (size_t)(L + 1));
     if (!d_cells) return fail_mem();
-    std::vector<int> cells(4 * (size_t)(L + 1));
-    for (int i = 0; i <= L; ++i) { cells[4 * i] = INT_MAX; cells[4 * i + 1] = INT_MIN; cells[4 * i + 2] = 0; cells[4 * i + 3] = 0; }
+    std::vector<int> cells(CS * (size_t)(L + 1), 0);
+    for (int i = 0; i <= L; ++i) { cells[CS * i] = INT_MAX; cells[CS * i + 1] = INT_MIN; cells[CS * i + 2] = 0; cells[CS * i + 3] = 0; }
     VWGPU_HIP(ctx, hipMemcpyAsync(d_cells, cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice, st));
     {
       std::vector<const float*> gi; std::vector<int> gw, gh; std::vector<ptrdiff_t> gs; std::vector<int*> gc;
       for (int i = 0; i <= L; ++i)
-        for (DevImg const* im : {&lp[i], &rp[i]}) { gi.push_back(im->p); gw.push_back(im->w); gh.push_back(im->h); gs.push_back(im->w); gc.push_back(d_cells + 4 * i); }
+        for (DevImg const* im : {&lp[i], &rp[i]}) { gi.push_back(im->p); gw.push_back(im->w); gh.push_back(im->h); gs.push_back(im->w); gc.push_back(d_cells + CS * i); }
       vwgpu_launch_float_grain(ctx, (int)gi.size(), gi.data(), gw.data(), gh.data(), gs.data(), gc.data());
     }
     VWGPU_HIP(ctx, hipMemcpyAsync(cells.data(), d_cells, cells.size() * sizeof(int), hipMemcpyDeviceToHost, st));
     VWGPU_HIP(ctx, hipStreamSynchronize(st));
     for (int i = 0; i <= L; ++i) {
-      exact_level[i] = !vwgpu_sums_order_free(P->cost_type, kx, ky, cells[4 * i], cells[4 * i + 1], cells[4 * i + 2]);
-      f32_level[i] = vwgpu_sums_bits(P->cost_type, kx, ky, cells[4 * i], cells[4 * i + 1], cells[4 * i + 2]) <= 24;      // (byte imagery under SAD)
-      if (exact_level[i] && ctx->certify && (cells[4 * i + 2] & 1) == 0 && cells[4 * i] != INT_MAX      // (bit 0: a non-finite pixel; bit 1 only says "negative pixels")
-          && cells[4 * i + 1] < 60 && cells[4 * i + 1] > -60)
-        cert_hi[i] = cells[4 * i + 1];
+      exact_level[i] = !vwgpu_sums_order_free(P->cost_type, kx, ky, cells[CS * i], cells[CS * i + 1], cells[CS * i + 2]);
+      f32_level[i] = vwgpu_sums_bits(P->cost_type, kx, ky, cells[CS * i], cells[CS * i + 1], cells[CS * i + 2]) <= 24;      // (byte imagery under SAD)
+      if (exact_level[i] && ctx->certify && (cells[CS * i + 2] & 1) == 0 && cells[CS * i] != INT_MAX      // (bit 0: a non-finite pixel; bit 1 only says "negative pixels")
+          && cells[CS * i + 1] < 60 && cells[CS * i + 1] > -60)
+        cert_hi[i] = cells[CS * i + 1];
     }
   }
 
@@ -958,12 +1011,16 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     ctx->forced_path = saved_force;
     stamp("matchers queued", level);
     // clean-up filters (:702-744)
+    // (an intermediate block-matching level: the second filter pass and the mask are applied by the zone scheduler's kernel as it reads)
+    const bool fused_extents = !last && !use_sgm && P->filter_half_kernel > 0 && P->blob_filter_area <= 0;
     if (P->filter_half_kernel > 0) {
-      rc = vwgpu_launch_disparity_filter(ctx, disp, dw, dh, P->filter_half_kernel, P->filter_half_kernel, 3.0, 0.5, !last, padded, disp2);
+      rc = vwgpu_launch_disparity_filter(ctx, disp, dw, dh, P->filter_half_kernel, P->filter_half_kernel, 3.0, 0.5, !last, padded, disp2, fused_extents);
       if (rc) return rc;
-      std::swap(disp, disp2);
-      rc = vwgpu_launch_disparity_mask(ctx, disp, dw, dh, lmp[level].p, rmp[level].p, rmp[level].w, rmp[level].h);
-      if (rc) return rc;
+      if (!fused_extents) {
+        std::swap(disp, disp2);
+        rc = vwgpu_launch_disparity_mask(ctx, disp, dw, dh, lmp[level].p, rmp[level].p, rmp[level].w, rmp[level].h);
+        if (rc) return rc;
+      }
       if (!last && check_rl && use_sgm) {           // the R->L result seeds the next level's R->L run (:722-730)
         rc = vwgpu_launch_disparity_filter(ctx, rl_a, rlw, rlh, P->filter_half_kernel, P->filter_half_kernel, 3.0, 0.5, true, rl_pad, rl_b);
         if (rc) return rc;
@@ -1009,7 +1066,11 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
       int32_t* d_ext = static_cast<int32_t*>(ctx->zext.base);
       {
         vwgpu_prof_scope ps(ctx, "zone_extents");
-        hipLaunchKernelGGL(zone_extent_kernel, dim3((unsigned)nleaf), dim3(64), 0, st, disp, dw, dh, d_rects, (int)nleaf, d_ext);
+        if (fused_extents)
+          hipLaunchKernelGGL(zone_extent_fused_kernel, dim3((unsigned)nleaf), dim3(64), 0, st, padded, dw, dh, lmp[level].p, rmp[level].p, rmp[level].w, rmp[level].h,
+                             d_rects, (int)nleaf, d_ext);
+        else
+          hipLaunchKernelGGL(zone_extent_kernel, dim3((unsigned)nleaf), dim3(64), 0, st, disp, dw, dh, d_rects, (int)nleaf, d_ext);
       }
       const vwgpu::LeafExtent* h_ext = static_cast<const vwgpu::LeafExtent*>(vwgpu_host_ring(ctx, ext_bytes));
       if (!h_ext) { leaf_ext.resize(nleaf); h_ext = leaf_ext.data(); }

@@ -250,7 +250,7 @@ int vwgpu_launch_zone_lr(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, in
 
 // pyramid.hip
 int vwgpu_launch_disparity_filter(vwgpu_ctx* ctx, const int32_t* src, int w, int h, int hh, int hv, double pthr, double rthr,
-                                  bool cleanup, int32_t* tmp_padded, int32_t* dst);
+                                  bool cleanup, int32_t* tmp_padded, int32_t* dst, bool inner_only = false);      // inner_only: stop after the first pass (tmp_padded)
 int vwgpu_launch_blob_filter(vwgpu_ctx* ctx, int32_t* d, int w, int h, int area, int* scratch);
 int vwgpu_launch_disparity_mask(vwgpu_ctx* ctx, int32_t* d, int w, int h, const uint8_t* m1, const uint8_t* m2, int m2w, int m2h);
 int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t ls,
