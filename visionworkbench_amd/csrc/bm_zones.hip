@@ -833,6 +833,8 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
       for (int tx = 0; tx < nx; ++tx) {
         const int tw = std::min(ZS, z.zw - tx * ZS), th = std::min(ZS, z.zh - ty * ZS);
         const double px = (double)tw * th;
+        // (Tried: runs of unequal length, 1.35 ... 0.65 or 1.6 ... 0.4 of the mean, so that the short ones — issued last — fill the end of
+        // the launch with the same number of records: -1.5 % on the NCC launches, +7 % on SAD (tools/zones_ab.py medians).)
         // (Tried: three tiles in ten cut four times finer, so that short items fill the end of the launch, where a third of the wave slots
         // stand empty for a third of the span — tools/zones_timeline.py.  The matcher launches got 10 % shorter and the merges of the
         // extra records took it back: 28 bytes per pixel and run, written and read.)
