@@ -43,7 +43,9 @@ def test_default_bench_line_contract():
     us = r["avg_us_per_launch"]["bm_sad_u8"]
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9) / r["achieved"] < 1e-6
     assert r["algorithmic_bytes_per_launch"] == 4 * 4096 * 4096 + 4 * 4224 * 4096 + 12 * 4090 * 4090
-    assert us * 1e-3 <= d["ms_per_step"]                                   # the kernel fits inside the step
+    # the kernel fits inside the step — a step is ONE launch since round 4, and the sampled steps (every 4th) carry the two event records
+    # around the kernel (~1.5 us), so the event average may exceed the all-steps wall average by that much
+    assert us * 1e-3 <= d["ms_per_step"] * 1.01
     assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
