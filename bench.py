@@ -866,7 +866,8 @@ def main():
                                  "window is 4 + 3 bytes — SAD4-class instructions (4 abs-diffs per issue slot, summed) cannot share row partials "
                                  "between neighbouring pixels of an odd window — which puts the floor of the formulation near 234 us per 4096^2 launch "
                                  "(frac 0.18); the +-16-px point in `extra` shows the same kernel where the arithmetic shrinks 4x.  One launch per "
-                                 "step since round 4 (validity sweep folded into the matcher)"},
+                                 "step since round 4 (validity sweep folded into the matcher); avg_us_per_launch comes from HIP events around the "
+                                 "kernel on every 4th step, whose two event records cost ~1.5 us that the other steps do not pay"},
         }
         if not args.no_cpu_baseline:
             # rank 0, for every N: the same leg (the other ranks wait at the final barrier)
