@@ -235,6 +235,7 @@ __device__ __forceinline__ void zwindow_sums(const ACC* e, ACC* w) {
 #ifndef VWGPU_TILE_STAMPS
 #define ZKNOCK(bit) false
 #endif
+
 // KS > 0: a square KS x KS window known at compile time — the horizontal and vertical window sums are unrolled (with run-time
 // sizes the loop overhead outweighed the sums, as PMC showed for bm_generic).  KS == 0: any kx, ky.
 // ACC: the type of the window sums.  float64 is the reference's; float32 is taken when every intermediate value is exactly representable in 24
@@ -323,30 +324,46 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
     __syncthreads();
     // NCC: the right precisions of a disparity are requested before its horizontal pass and consumed after it (a load issued where it is
     // used put a memory round trip on the critical path of every disparity)
-    const double* prow[4] = {nullptr, nullptr, nullptr, nullptr};
+    // (Scalar instructions count: a wavefront issues one instruction of any kind per turn of its SIMD, and with four wavefronts per SIMD
+    // the launch advances at about total instructions x 4.6 clk.  A third of the disparity loop were exec-mask regions, branches and waits —
+    // so nothing inside it sits under a per-row or per-lane condition that can be avoided: lanes and rows without a pixel load the first
+    // precision of the image, run the chain on whatever their plane rows hold, and are dropped in the epilogue.)
+    const double* prow[4] = {pb.p, pb.p, pb.p, pb.p};
     double rpn[4] = {0.0, 0.0, 0.0, 0.0};
-    if (COST == VWGPU_CROSS_CORRELATION && c < tw) {
+    if (COST == VWGPU_CROSS_CORRELATION) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
-        if (y0 + m < th) prow[m] = pb.p + (size_t)(z.by + oy + y0 + m + dy - pb.y0) * pb.w + (z.bx + ox + c + dx0 - pb.x0);
+      for (int m = 0; m < 4; ++m) {
+        const bool in = c < tw && y0 + m < th;
+        const size_t off = (size_t)(z.by + oy + y0 + m + dy - pb.y0) * pb.w + (z.bx + ox + c + dx0 - pb.x0);
+        prow[m] = pb.p + (in ? off : 0);
+      }
     }
     for (int d = 0; d < nd; ++d) {
       ACC* Hc = H + hb * (PH * HP);
       if (COST == VWGPU_CROSS_CORRELATION) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) rpn[m] = (prow[m] && !ZKNOCK(32)) ? prow[m][d] : 0.0;
+        for (int m = 0; m < 4; ++m) rpn[m] = ZKNOCK(32) ? 0.0 : prow[m][d];      // (d < 16: inside the image's 256-byte-aligned block even for a 1 x 1 zone)
       }
       if (KS > 0) {
         // HW adjacent columns per thread: KS + HW - 1 cost elements are formed once and the window slides (s' = s - e[j] + e[j + KS]).
         // With float32 sums HW = 8: 2 (KS + 7) LDS reads and KS + 13 adds for eight sums, and the ph x ZT / 8 items of a disparity are
         // ONE round of the workgroup (with four columns per item a 32 x 32 tile is 1.3 rounds: two of the four waves run twice and the
         // others wait at the barrier).  On order-free data the slide is exact; with CERT its roundings are part of eps.
-        for (int i = t; i < ph * QL; i += ZTHREADS) {
+        // ((ZT + KS - 1) x QL items <= ZTHREADS for every compile-time window: one item per thread, no loop)
+        static_assert(KS == 0 || (ZT + KS - 1) * QL <= ZTHREADS, "one horizontal item per thread");
+        {
+          const int i = t;
           const int r = i / QL, q = (i % QL) * HW;
-          if (q < tw) {
+          if (i < ph * QL && q < tw) {
             const float* lp = Lp + r * PW + q;
             const float* rp = Rp + r * RW + q + d;
             ACC e[KS > 0 ? KS + HW - 1 : 1];
+            // (Tried: every patch read of the item behind ONE wait — an empty asm statement that takes all the values, the compiler then
+            // places a single s_waitcnt instead of eight — and the same for the plane reads of the vertical pass: 5 % SLOWER; the early
+            // products overlap the later reads inside the wavefront.)
+            float lv[KS > 0 ? KS + HW - 1 : 1], rv[KS > 0 ? KS + HW - 1 : 1];
+#pragma unroll
+            for (int a = 0; a < KS + HW - 1; ++a) { lv[a] = lp[a]; rv[a] = rp[a]; }
             if (COST == VWGPU_CROSS_CORRELATION && (KS + HW - 1) % 2 == 0) {      // two float products per instruction (v_pk_mul_f32)
 #pragma unroll
               for (int a = 0; a < KS + HW - 1; a += 2) {
@@ -355,18 +372,22 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
                 if (ZKNOCK(1)) { l2.x = (float)(i + a); l2.y = (float)(i - a); r2 = l2; asm volatile("" : "+v"(l2.x), "+v"(r2.y)); }
                 else { l2 = zfloat2{lp[a], lp[a + 1]}; r2 = zfloat2{rp[a], rp[a + 1]}; }
 #else
-                const zfloat2 l2 = {lp[a], lp[a + 1]}, r2 = {rp[a], rp[a + 1]};
+                const zfloat2 l2 = {lv[a], lv[a + 1]}, r2 = {rv[a], rv[a + 1]};
 #endif
                 const zfloat2 p2 = l2 * r2;
                 e[a] = (ACC)p2.x; e[a + 1] = (ACC)p2.y;
               }
             } else {
 #pragma unroll
-              for (int a = 0; a < KS + HW - 1; ++a) e[a] = zcost<COST, ACC>(lp[a], rp[a]);
+              for (int a = 0; a < KS + HW - 1; ++a) e[a] = zcost<COST, ACC>(lv[a], rv[a]);
             }
             ACC wsum[HW];
             zwindow_sums<KS, HW, ACC>(e, wsum);
-            ACC* h = Hc + r * HP + q;
+            // one address register + immediate offsets (the compiler re-derived base + constant per store); through an address-space-3
+            // pointer, so that the laundered address still selects ds_* instructions
+            typedef __attribute__((address_space(3))) ACC lds_acc;
+            lds_acc* h = (lds_acc*)(Hc + r * HP + q);
+            asm volatile("" : "+v"(h));
             if (ZKNOCK(2)) {
               ACC tot = 0;
 #pragma unroll
@@ -391,7 +412,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
         }
       }
       if (!ZKNOCK(16)) __syncthreads();
-      if (c < tw) {
+      if (KS > 0 || c < tw) {                                     // (compile-time window: every lane and row runs, see above)
         const int di = i0 + d;
         const bool first = (di == it.i0);
         int div = di;
@@ -399,18 +420,22 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
         ACC vs[4] = {0, 0, 0, 0};
         if (KS > 0) {                                           // the same slide down the rows (rows beyond th hold stale planes: unused)
           ACC h[KS > 0 ? KS + 3 : 1];
-#pragma unroll
 #ifdef VWGPU_TILE_STAMPS
+#pragma unroll
           for (int b = 0; b < KS + 3; ++b) { if (ZKNOCK(4)) { h[b] = (ACC)(t + b + d); asm volatile("" : "+v"(h[b])); } else h[b] = Hc[(y0 + b) * HP + c]; }
 #else
-          for (int b = 0; b < KS + 3; ++b) h[b] = Hc[(y0 + b) * HP + c];          // y0 + b <= ZT - 4 + KS + 2 = PH - 1
+          typedef __attribute__((address_space(3))) ACC lds_acc;
+          const lds_acc* hv = (const lds_acc*)(Hc + y0 * HP + c);
+          asm volatile("" : "+v"(hv));
+#pragma unroll
+          for (int b = 0; b < KS + 3; ++b) h[b] = hv[b * HP];                     // y0 + b <= ZT - 4 + KS + 2 = PH - 1
 #endif
           zwindow_sums<KS, 4, ACC>(h, vs);
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const int y = y0 + m;
-          if (y < th) {
+          if (KS > 0 || y < th) {
             ACC sa = vs[m];
             if (KS == 0) {
               for (int b = 0; b < ky; ++b) sa += Hc[(y + b) * HP + c];
@@ -442,7 +467,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
               const double rp = rpn[m];
               s *= sqrt(lprec[m] * rp);
             }
-            if (it.slot >= 0) bad = bad || !(fabs(s) <= 1.7976931348623157e308);
+            if (it.slot >= 0) bad = bad || (c < tw && y < th && !(fabs(s) <= 1.7976931348623157e308));
             // Correlation.cc:91-117 as selects (a branch per comparison costs more than the comparisons): the first disparity sets
             // best = worst; a strictly better cost takes best and the index; otherwise a cost that is not better than worst takes worst
             // (a NaN cost compares false both times: it never wins and becomes `worst`, as in the reference)
