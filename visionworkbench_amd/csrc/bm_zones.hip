@@ -324,10 +324,11 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
     __syncthreads();
     // NCC: the right precisions of a disparity are requested before its horizontal pass and consumed after it (a load issued where it is
     // used put a memory round trip on the critical path of every disparity)
-    // (Scalar instructions count: a wavefront issues one instruction of any kind per turn of its SIMD, and with four wavefronts per SIMD
-    // the launch advances at about total instructions x 4.6 clk.  A third of the disparity loop were exec-mask regions, branches and waits —
-    // so nothing inside it sits under a per-row or per-lane condition that can be avoided: lanes and rows without a pixel load the first
-    // precision of the image, run the chain on whatever their plane rows hold, and are dropped in the epilogue.)
+    // (Nothing inside the disparity loop sits under a per-row or per-lane condition that can be avoided: twelve exec-mask regions — four
+    // row tests, four guarded precision loads, the lane tests, a one-trip loop — were a third of the loop's instructions, 13 saveexec /
+    // 12 restores / 14 branches, and 14 % of a level-0 launch.  Lanes and rows without a pixel load the first precision of the image,
+    // run the chain on whatever their plane rows hold, and are dropped in the epilogue.  Fewer s_waitcnt or address instructions did
+    // not pay the same way, see below.)
     const double* prow[4] = {pb.p, pb.p, pb.p, pb.p};
     double rpn[4] = {0.0, 0.0, 0.0, 0.0};
     if (COST == VWGPU_CROSS_CORRELATION) {
