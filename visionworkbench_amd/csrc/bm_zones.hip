@@ -194,6 +194,8 @@ __device__ __forceinline__ bool zcertified(const ZCert& zc, int D, bool bad, dou
 // comes round the loop — five of the 21 instructions of an evaluation.  A NaN operand is ignored (IEEE mode: the other one is returned).
 __device__ __forceinline__ double zmin_raw(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double zmax_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float zmin_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float zmax_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 typedef float zfloat2 __attribute__((ext_vector_type(2)));
 
@@ -301,6 +303,10 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
     if (COST == VWGPU_CROSS_CORRELATION && c < tw && y0 + m < th)
       lprec[m] = pa.p[(size_t)(z.ay + oy + y0 + m - pa.y0) * pa.w + (z.ax + ox + c - pa.x0)];
   }
+  ACC bestA[4], worstA[4];                                        // the lean chain of the order-free SAD / SSD levels
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { bestA[m] = (ACC)INFINITY; worstA[m] = -(ACC)INFINITY; }
+  constexpr bool LEAN = !CERT && COST != VWGPU_CROSS_CORRELATION;
   int hb = 0;
   const int iend = it.i0 + it.n;
   // (Tried and dropped, round 4: requesting the right patch of the next run of dx while this run is matched, and four instead of three
@@ -417,7 +423,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
         const int di = i0 + d;
         const bool first = (di == it.i0);
         int div = di;
-        if (CERT) asm volatile("" : "+v"(div));                   // one copy to a vector register per disparity instead of one per select
+        if (CERT || COST != VWGPU_CROSS_CORRELATION) asm volatile("" : "+v"(div));      // one copy to a vector register per disparity instead of one per select
         ACC vs[4] = {0, 0, 0, 0};
         if (KS > 0) {                                           // the same slide down the rows (rows beyond th hold stale planes: unused)
           ACC h[KS > 0 ? KS + 3 : 1];
@@ -463,6 +469,14 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
                 best[m] = zmin_raw(best[m], s);
               }
               bidx[m] = cb ? div : bidx[m];
+            } else if (COST != VWGPU_CROSS_CORRELATION) {
+              // Order-free SAD / SSD level: the costs are finite (the level's pixels are), and on finite costs the chain of
+              // Correlation.cc:91-117 IS (minimum, its first index, maximum) — a cost that becomes the new best is below the first cost,
+              // which `worst` starts from, so it never is the maximum.  In the type of the sums (float32 when they are exact there).
+              const bool cb = sa < bestA[m];
+              bestA[m] = zmin_raw(bestA[m], sa);
+              worstA[m] = zmax_raw(worstA[m], sa);
+              bidx[m] = cb ? div : bidx[m];
             } else {
             if (COST == VWGPU_CROSS_CORRELATION) {
               const double rp = rpn[m];
@@ -498,6 +512,10 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
     }
   }
 #endif
+  if (LEAN) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { best[m] = (double)bestA[m]; worst[m] = (double)worstA[m]; }
+  }
   if (it.slot >= 0) {                                           // one of several runs of this tile: leave the records to zones_merge_kernel
     const size_t base = (size_t)it.slot * (ZT * ZT);
     if (c < tw) {
@@ -775,7 +793,8 @@ bool vwgpu_bm_zones_supported(int kx, int ky) {
   return (PH * PW + PH * (PW + 8)) * 4 + 2 * PH * (ZT + 1) * 8 + 16 <= 64 * 1024;
 }
 
-// cert_hi: INT_MIN = no certification (the level is order free: any summation order returns the reference's bits).  Otherwise the
+// cert_hi: INT_MIN = no certification (the level is order free: any summation order returns the reference's bits — which includes "every
+// pixel finite", vwgpu_sums_bits: the SAD / SSD chain relies on finite costs).  Otherwise the
 // largest binary exponent of the level's pixels (|pixel| < 2^(cert_hi + 1), all finite): the kernels certify every pixel against the
 // error bound above and raise d_zflag[zone] (n ints, zeroed here) for zones with a pixel they cannot certify; the caller redoes those
 // zones in the reference's order (vwgpu_launch_bm_exact with the same flags as its gate).
