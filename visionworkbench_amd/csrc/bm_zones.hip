@@ -580,11 +580,55 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
   const int ox = geom.ox, oy = geom.oy, tw = geom.tw, th = geom.th;
   const int t = threadIdx.x;
   const int c = t % ZT, y0 = (t / ZT) * 4;
-  bool bad = false;
-  for (int k = 0; k < it.nitems; ++k) bad = bad || P.bad[it.slot0 + k] != 0;      // workgroup-uniform
+  // the slot flags of the runs: one load per lane instead of a chain of dependent scalar loads
+  const bool bad = __syncthreads_or(t < it.nitems && P.bad[it.slot0 + t] != 0) != 0;
   if (bad && !CERT) {                                           // order dependent: the redo launch recomputes the tile as one item
     if (t == 0) P.redo[it.gate] = 1;
     return;
+  }
+  // Every record plane is a full ZT x ZT block, so the loads need no bounds: all four rows of a lane are read for run k + 1 while run k is
+  // folded, and the fold is selects (the branchy form waited out a memory round trip per run and row: 25 us for a few hundred tiles).
+  struct Rec { double b, x, rp; int idx; };
+  const size_t px0 = (size_t)y0 * ZT + c;
+  auto load = [&](int k, int m) __attribute__((always_inline)) {
+    const size_t o = (size_t)(it.slot0 + k) * (ZT * ZT) + px0 + (size_t)m * ZT;
+    Rec r;
+    r.b = P.best[o]; r.x = CERT ? P.second[o] : P.worst[o]; r.idx = P.idx[o];
+    r.rp = (CERT && COST == VWGPU_CROSS_CORRELATION) ? P.rpmax[o] : 0.0;
+    return r;
+  };
+  double best[4], other[4], rpmax[4];
+  int bi[4];
+  Rec nxt[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) nxt[m] = load(0, m);
+  for (int k = 0; k < it.nitems; ++k) {
+    Rec cur[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) cur[m] = nxt[m];
+    if (k + 1 < it.nitems) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) nxt[m] = load(k + 1, m);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const double b = cur[m].b, x = cur[m].x;
+      if (k == 0) { best[m] = b; other[m] = x; bi[m] = cur[m].idx; rpmax[m] = cur[m].rp; }
+      else {
+        const bool better = zbetter<COST>(b, best[m]);          // strictly better: ties stay with the earlier run (first wins)
+        if (CERT) {
+          // runner-up of the union: the run's own runner-up or the old best when the run wins, else the run's best if it beats the old runner-up
+          const double when_better = zbetter<COST>(x, best[m]) ? x : best[m];
+          const double when_not = zbetter<COST>(b, other[m]) ? b : other[m];
+          other[m] = better ? when_better : when_not;
+          rpmax[m] = fmax(rpmax[m], cur[m].rp);
+        } else {
+          other[m] = !zbetter<COST>(x, other[m]) ? x : other[m];      // the extremum (a NaN never gets here: bad tiles left above)
+        }
+        bi[m] = better ? cur[m].idx : bi[m];
+        best[m] = better ? b : best[m];
+      }
+    }
   }
   bool uncert = false;
   if (c < tw) {
@@ -593,31 +637,15 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
     for (int m = 0; m < 4; ++m) {
       const int y = y0 + m;
       if (y >= th) continue;
-      double best = 0.0, worst = 0.0, second = 0.0, rpmax = 0.0;
-      int bi = 0;
-      for (int k = 0; k < it.nitems; ++k) {
-        const size_t o = (size_t)(it.slot0 + k) * (ZT * ZT) + (size_t)y * ZT + c;
-        const double b = P.best[o], w = CERT ? 0.0 : P.worst[o];
-        const double sc = CERT ? P.second[o] : 0.0;
-        if (k == 0) { best = b; worst = w; bi = P.idx[o]; second = sc; }
-        else {
-          if (zbetter<COST>(b, best)) {                         // strictly better: ties stay with the earlier run (first wins)
-            if (CERT) second = zbetter<COST>(sc, best) ? sc : best;
-            best = b; bi = P.idx[o];
-          } else if (CERT && zbetter<COST>(b, second)) second = b;
-          if (!CERT && !zbetter<COST>(w, worst)) worst = w;
-        }
-        if (CERT && COST == VWGPU_CROSS_CORRELATION) rpmax = fmax(rpmax, P.rpmax[o]);
-      }
       int32_t* o3 = out + ((size_t)z.out_off + (size_t)(oy + y) * z.out_stride + ox + c) * 3;
-      const int by_ = bi / z.sx, bx_ = bi - by_ * z.sx;
+      const int by_ = bi[m] / z.sx, bx_ = bi[m] - by_ * z.sx;
       o3[0] = bx_ + z.addx; o3[1] = by_ + z.addy;
-      o3[2] = CERT ? (D == 1 ? 0 : 0x7fffffff) : ((best == worst) ? 0 : 0x7fffffff);
+      o3[2] = CERT ? (D == 1 ? 0 : 0x7fffffff) : ((best[m] == other[m]) ? 0 : 0x7fffffff);
       if (CERT) {
         double lprec = 0.0;
         if (COST == VWGPU_CROSS_CORRELATION) lprec = pa.p[(size_t)(z.ay + oy + y - pa.y0) * pa.w + (z.ax + ox + c - pa.x0)];
         const double sl = COST == VWGPU_CROSS_CORRELATION ? lprec : 1.0;       // (square roots of precisions, as in bm_zones_kernel)
-        if (!zcertified<COST>(C.zc[it.zone], D, bad, best * sl, second * sl, sl * sl, rpmax * rpmax)) uncert = true;
+        if (!zcertified<COST>(C.zc[it.zone], D, bad, best[m] * sl, other[m] * sl, sl * sl, rpmax[m] * rpmax[m])) uncert = true;
       }
     }
   }
@@ -858,7 +886,10 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
   // its patches carry more halo) — the 16 x 16 leaves of the quad tree and the thin zones.
   plan[0].items.reserve((size_t)n * 2 + 64);
   const int resident = std::max(1, (int)std::min<size_t>(8, (160 * 1024) / (plan[0].lds + 512))) * ctx->num_cu;
-  const double cap = std::max(16.0 * 32 * 32, total / (3.0 * resident));
+  // (a level that cannot fill the GPU with 16-disparity runs — the coarse levels of a tile: one zone of a few dozen tiles — is cut down to
+  // 4-disparity runs: its launch is as long as its longest item)
+  const double min_run = std::min(16.0, std::max(4.0, total / (1024.0 * resident)));
+  const double cap = std::max(min_run * 32 * 32, total / (3.0 * resident));
   for (int i = 0; i < n; ++i) {
     const vwgpu_zone_task& z = zones[i];
     if (z.zw <= 0 || z.zh <= 0 || z.sx <= 0 || z.sy <= 0) continue;
