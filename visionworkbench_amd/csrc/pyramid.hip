@@ -953,10 +953,29 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         int any[2] = {0, 0};
         VWGPU_HIP(ctx, hipMemcpyAsync(any, d_any, sizeof any, hipMemcpyDeviceToHost, st));
         VWGPU_HIP(ctx, hipStreamSynchronize(st));
+        // The flagged zones of a pass as a list of their own (their flags come back in a second small copy, only when there are any): the
+        // exact-order launches are then sized by the flagged zones — gated launches over all 2000 zones of a border tile spent 0.1 ms
+        // each on workgroups that read a zero and left (18 launches, 2 ms for 3 % of the tile's pixels).
+        std::vector<int> hflag;
         for (size_t k = 0; k < pending.size(); ++k) {
           if (!any[k]) continue;
           const Pending& q = pending[k];
-          if ((rc = vwgpu_launch_bm_exact(ctx, P->cost_type, q.a, q.aw, q.ah, q.aw, q.b, q.bw, q.bh, q.bw, kx, ky, q.tz->data(), (int)q.tz->size(), q.dst, q.zflag))) return rc;
+          hflag.resize(q.tz->size());
+          VWGPU_HIP(ctx, hipMemcpyAsync(hflag.data(), q.zflag, hflag.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+          VWGPU_HIP(ctx, hipStreamSynchronize(st));
+          std::vector<vwgpu_zone_task> redo;
+          for (size_t i = 0; i < hflag.size(); ++i) if (hflag[i]) redo.push_back((*q.tz)[i]);
+          if (redo.empty()) continue;
+          if (ctx->trace & 4) {
+            size_t px = 0, ev = 0;
+            for (auto const& zt : redo) { px += (size_t)zt.zw * zt.zh; ev += (size_t)zt.zw * zt.zh * zt.sx * zt.sy; }
+            fprintf(stderr, "  level %d pass %zu: %zu of %zu zones to the exact-order kernels, %zu px, %zu evaluations; largest:", level, k, redo.size(), q.tz->size(), px, ev);
+            std::vector<vwgpu_zone_task> big(redo);
+            std::sort(big.begin(), big.end(), [](vwgpu_zone_task const& a2, vwgpu_zone_task const& b2) { return (size_t)a2.zw * a2.zh * a2.sx * a2.sy > (size_t)b2.zw * b2.zh * b2.sx * b2.sy; });
+            for (size_t i = 0; i < std::min<size_t>(4, big.size()); ++i) fprintf(stderr, " %dx%d x %dx%d", big[i].zw, big[i].zh, big[i].sx, big[i].sy);
+            fprintf(stderr, "\n");
+          }
+          if ((rc = vwgpu_launch_bm_exact(ctx, P->cost_type, q.a, q.aw, q.ah, q.aw, q.b, q.bw, q.bh, q.bw, kx, ky, redo.data(), (int)redo.size(), q.dst))) return rc;
         }
       }
       if (lr_active && (rc = vwgpu_launch_zone_lr(ctx, t3.data(), (int)t3.size(), disp, rlbuf, P->consistency_threshold, lr_diff, lr_stride))) return rc;
