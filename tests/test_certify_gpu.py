@@ -89,3 +89,33 @@ def test_wide_range_floats(ctx, oracle, cost):
     v = (rng.random((H, W)) * 10.0 ** (rng.random((H, W)) * 9 - 4.5)).astype(np.float32)
     right = np.roll(v, 4, axis=1)
     _both(ctx, oracle, v, right, None, None, 0, 0.0, (-8, -2, 9, 3), (7, 7), cost, 2, 3, 3)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_search_across_the_image_borders(ctx, oracle, case):
+    """A search range that reaches beyond both sides of the right image.  Out there the crop is mean-filled nodata: under a LoG or mean
+    prefilter its windows are all-zero (NCC: 0 * inf = NaN costs — a NaN first candidate is the reference's winner whatever follows) or
+    bit-identical copies (exact ties).  No certificate can order those candidates; the "cannot matter" certificate (bm_zones.hip, ZEdge)
+    proves instead that whichever of them the reference picks, the pixel is erased by the mask pass (L->R) or fails the consistency check
+    (R->L), and that no neighbour's clean-up count can see it.  Costs, prefilters, clean-up kernels (0 = no filter and NO mask pass: the
+    certificate must stay off), consistency thresholds, levels and nodata masks vary; the tile must equal the oracle's in every case."""
+    rng = np.random.default_rng(4100 + case)
+    H, W = int(rng.integers(150, 230)), int(rng.integers(200, 320))
+    shift = int(rng.integers(-9, 10))
+    base = (rng.random((H, W + 64)) * 180.0 + 20.0).astype(np.float32)
+    base = (base + np.roll(base, 1, axis=1) + np.roll(base, 1, axis=0)) / np.float32(3.0)           # some correlation between neighbours
+    left = base[:, 32:32 + W].copy()
+    right = base[:, 32 - shift:32 - shift + W].copy()
+    cost = case % 3
+    kernel = [(7, 7), (5, 5), (11, 11)][cost]
+    pf, pfw = [(2, float(np.float32(1.4))), (1, float(np.float32(3.0))), (2, float(np.float32(1.4))), (0, 0.0)][case % 4]
+    filt = [5, 3, 1, 0, 5, 2][case % 6]
+    thr = [2, 0, -1, 7.5, 2, 1][(case // 2) % 6]
+    levels = [3, 2, 0, 4][case % 4]
+    reach = int(rng.integers(12, 30))
+    search = (-reach, -2, reach + 1, 3)
+    lm = rm = None
+    if case % 5 == 3:
+        lm = np.full((H, W), 255, np.uint8); lm[20:60, :25] = 0
+        rm = np.full((H, W), 255, np.uint8); rm[:, -18:] = 0; rm[100:130, 5:40] = 0
+    _both(ctx, oracle, left, right, lm, rm, pf, pfw, search, kernel, cost, thr, filt, levels)

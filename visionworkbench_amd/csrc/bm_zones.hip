@@ -117,7 +117,12 @@ zone_precision_kernel(ZPrecJobs jobs, int kx, int ky, int root) {
   if (i >= pw || j >= ph) return;
   double s = 0.0;
   for (int b = 0; b < ky; ++b) s += hs[(threadIdx.y + b) * 64 + threadIdx.x];
-  prec[(size_t)j * pw + i] = root ? sqrt(1.0 / s) : 1.0 / s;           // root: the certified kernels multiply by sqrt(1 / S), see there
+  // root: the certified kernels multiply by sqrt(1 / S), see there; root == 2 (passes with the "cannot matter" certificate): NaN for an
+  // all-zero window — such a candidate's cost is NaN in the reference (0 * inf) and never wins unless it is the first one; the chain's
+  // min / max instructions skip a NaN the same way, and the first candidate is looked at separately (ZEdge)
+  double pr = root ? sqrt(1.0 / s) : 1.0 / s;
+  if (root == 2 && !(pr <= 1.7976931348623157e308)) pr = __builtin_nan("");
+  prec[(size_t)j * pw + i] = pr;
 }
 
 // A work item: disparities [i0, i0 + n) (index = dy * sx + dx, the reference's loop order) of one 32 x 32 tile of one zone.
@@ -130,10 +135,25 @@ struct ZItem {
 };
 struct ZMergeItem { int zone, txy, slot0, nitems, gate, pad0, pad1, pad2; };
 // records of the partial slots, one plane of 1024 pixels per slot and field
-struct ZPart { double* best; double* worst; int* idx; double* second; double* rpmax; int* bad; int* redo; };
+struct ZPart { double* best; double* worst; int* idx; double* second; double* rpmax; int* bad; int* redo; double* bnf; };
 // certification constants of a zone: bounds on |tile-parallel sum - reference running sum| (see vwgpu_launch_bm_zones)
 struct ZCert { double eps_s, eps_ll, eps_rr, pad; };
-struct ZCertArgs { const ZCert* zc; int* zflag; unsigned long long* stats; int* any; const int* need; const unsigned char* cells; };      // zc == nullptr: no certification; any: "some zone was flagged"
+struct ZCertArgs { const ZCert* zc; int* zflag; unsigned long long* stats; int* any; const int* need; const unsigned char* cells;
+                   int edge_m, edge_k, edge_lo, edge_hi; };     // zc == nullptr: no certification; any: "some zone was flagged"; edge_*: see ZEdge
+// The "cannot matter" certificate (EDGE kernels; edge_m > 0).  A candidate (pixel, disparity) whose partner lies edge_m or more columns
+// outside the other image — partner column = origin of its window in the other image - edge_k, outside [edge_lo, edge_hi] — is FAR
+// (edge_m > 0 switches the certificate on; the caller folds the margin into the two bounds).  Far windows are clamped copies of the border column: whole runs of them have bit-identical data, their costs tie exactly
+// in any arithmetic that treats them alike and in the reference's running sums only almost — no certificate can order them.  But when
+// the best cost is far and leads the best NOT-far cost (`bnf`) by more than 2 eps, the reference's winner is SOME far candidate, and
+// every one of them meets the same end: an L->R pixel that points edge_m = filter half kernel + 4 columns outside the right image is
+// never within 3 px of a neighbour that points inside (the two clean-up passes count nothing else) and is then erased by
+// disparity_mask (DisparityMap.h:132-155); an R->L pixel that points floor(threshold) + 2 columns outside the left image is
+// inconsistent with every left pixel of the check (cross_corr_consistency_check), its only reader.  Which far candidate won cannot be seen
+// in the output.  pyramid.hip says when the premises hold (a mask pass follows; no lr_disp_diff image requested).
+struct ZEdge {
+  int lo, hi, base;                                             // partner column of (lane's pixel, dx index i) = base + i
+  __device__ __forceinline__ bool notfar(int i) const { return (unsigned)(base + i - lo) <= (unsigned)(hi - lo); }
+};
 // need != nullptr (the R->L pass of a level with the L/R check): eight ints per zone from zone_need_kernel — the rectangle of the zone the
 // check will read, and where the zone's 16 x 16-pixel cell flags start.  The tiles are laid from the rectangle's corner and stop at its
 // far side, and a tile none of whose cells holds a position the check reads is skipped; the rest of the zone is not matched (every pixel
@@ -244,7 +264,7 @@ __device__ __forceinline__ void zwindow_sums(const ACC* e, ACC* w) {
 // bits as well (vwgpu_sums_bits <= 24: byte imagery under SAD) — then both give the same numbers, the LDS planes are half as large and the sums
 // full-rate.  The compare chain runs on doubles either way.
 // CERT: track the runner-up (and the largest right precision) and certify / flag, see the file header.
-template <int COST, int KS, typename ACC, bool CERT, int ZS>
+template <int COST, int KS, typename ACC, bool CERT, int ZS, bool EDGE = false>
 __global__ void __launch_bounds__(ZS * ZS / 4, 4)
 bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __restrict__ B, int bw, int bh,
                 int kx, int ky, const vwgpu_zone_task* __restrict__ zones, const ZItem* __restrict__ items,
@@ -303,6 +323,10 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
     if (COST == VWGPU_CROSS_CORRELATION && c < tw && y0 + m < th)
       lprec[m] = pa.p[(size_t)(z.ay + oy + y0 + m - pa.y0) * pa.w + (z.ax + ox + c - pa.x0)];
   }
+  bool fnan[4] = {false, false, false, false};                    // EDGE: the FIRST candidate of the search has a NaN cost (then it is the reference's winner)
+  double bnf[4];                                                  // EDGE: the best cost among the candidates that are not far (ZEdge)
+#pragma unroll
+  for (int m = 0; m < 4; ++m) bnf[m] = kBestInit;
   ACC bestA[4], worstA[4];                                        // the lean chain of the order-free SAD / SSD levels
 #pragma unroll
   for (int m = 0; m < 4; ++m) { bestA[m] = (ACC)INFINITY; worstA[m] = -(ACC)INFINITY; }
@@ -335,6 +359,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
     // 12 restores / 14 branches, and 14 % of a level-0 launch.  Lanes and rows without a pixel load the first precision of the image,
     // run the chain on whatever their plane rows hold, and are dropped in the epilogue.  Fewer s_waitcnt or address instructions did
     // not pay the same way, see below.)
+    const ZEdge edge{C.edge_lo, C.edge_hi, z.bx + ox + c + dx0 - C.edge_k};
     const double* prow[4] = {pb.p, pb.p, pb.p, pb.p};
     double rpn[4] = {0.0, 0.0, 0.0, 0.0};
     if (COST == VWGPU_CROSS_CORRELATION) {
@@ -424,6 +449,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
         const bool first = (di == it.i0);
         int div = di;
         if (CERT || COST != VWGPU_CROSS_CORRELATION) asm volatile("" : "+v"(div));      // one copy to a vector register per disparity instead of one per select
+        const bool nfar = EDGE ? edge.notfar(d) : true;
         ACC vs[4] = {0, 0, 0, 0};
         if (KS > 0) {                                           // the same slide down the rows (rows beyond th hold stale planes: unused)
           ACC h[KS > 0 ? KS + 3 : 1];
@@ -461,6 +487,11 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
                 s *= rp;
               }
               const bool cb = zbetter<COST>(s, best[m]);
+              if (EDGE && di == 0) fnan[m] = !(s == s);           // (workgroup-uniform test: the first disparity of the search)
+              if (EDGE) {
+                const double snf = nfar ? s : kBestInit;
+                bnf[m] = COST == VWGPU_CROSS_CORRELATION ? zmax_raw(bnf[m], snf) : zmin_raw(bnf[m], snf);
+              }
               if (COST == VWGPU_CROSS_CORRELATION) {
                 second[m] = zmax_raw(second[m], zmin_raw(s, best[m]));
                 best[m] = zmax_raw(best[m], s);
@@ -524,9 +555,10 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
         const int y = y0 + m;
         if (y < th) {
           const size_t o = base + (size_t)y * ZT + c;
-          P.best[o] = best[m]; P.idx[o] = bidx[m];
+          P.best[o] = best[m]; P.idx[o] = (EDGE && fnan[m]) ? (bidx[m] | (int)0x80000000) : bidx[m];      // (bit 31: the run starts the search with a NaN)
           if (CERT) {
             P.second[o] = second[m]; if (COST == VWGPU_CROSS_CORRELATION) P.rpmax[o] = rpmax[m];
+            if (EDGE) P.bnf[o] = bnf[m];
             bad = bad || !(fabs(best[m]) <= 1.7976931348623157e308);
           } else {
             P.worst[o] = worst[m];
@@ -545,13 +577,22 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
       const int y = y0 + m;
       if (y < th) {
         int32_t* o = out + ((size_t)z.out_off + (size_t)(oy + y) * z.out_stride + ox + c) * 3;
-        const int by_ = bidx[m] / z.sx, bx_ = bidx[m] - by_ * z.sx;
+        const int bsel = (EDGE && fnan[m]) ? 0 : bidx[m];          // (a NaN first candidate is the reference's winner)
+        const int by_ = bsel / z.sx, bx_ = bsel - by_ * z.sx;
         o[0] = bx_ + z.addx; o[1] = by_ + z.addy;
         if (CERT) {
           const bool ncc = COST == VWGPU_CROSS_CORRELATION;         // NCC: lprec / rpmax hold square roots of precisions here
           const double sl = ncc ? lprec[m] : 1.0;
           o[2] = D == 1 ? 0 : 0x7fffffff;                           // (what a certificate implies; an uncertified zone is matched again)
-          if (!zcertified<COST>(C.zc[it.zone], D, !(fabs(best[m]) <= 1.7976931348623157e308), best[m] * sl, second[m] * sl, sl * sl, rpmax[m] * rpmax[m])) uncert = true;
+          const bool badpx = !(fabs(best[m]) <= 1.7976931348623157e308);
+          bool okpx = zcertified<COST>(C.zc[it.zone], D, badpx, best[m] * sl, second[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
+          if (EDGE) {
+            const ZEdge e1{C.edge_lo, C.edge_hi, z.bx + ox + c - C.edge_k};
+            if (fnan[m]) okpx = !e1.notfar(0);                    // the reference's winner is candidate 0, whatever follows: fine iff that one is far
+            else if (!okpx && !badpx && !e1.notfar(bx_))          // the best is far and ahead of everything that is not
+              okpx = bnf[m] == kBestInit || zcertified<COST>(C.zc[it.zone], D, false, best[m] * sl, bnf[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
+          }
+          if (!okpx) uncert = true;
         } else {
           o[2] = (best[m] == worst[m]) ? 0 : 0x7fffffff;
         }
@@ -588,17 +629,20 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
   }
   // Every record plane is a full ZT x ZT block, so the loads need no bounds: all four rows of a lane are read for run k + 1 while run k is
   // folded, and the fold is selects (the branchy form waited out a memory round trip per run and row: 25 us for a few hundred tiles).
-  struct Rec { double b, x, rp; int idx; };
+  struct Rec { double b, x, rp, nf; int idx; };
+  const bool edge = CERT && C.edge_m > 0;                        // (workgroup-uniform) the runs carry their best not-far cost, see ZEdge
   const size_t px0 = (size_t)y0 * ZT + c;
   auto load = [&](int k, int m) __attribute__((always_inline)) {
     const size_t o = (size_t)(it.slot0 + k) * (ZT * ZT) + px0 + (size_t)m * ZT;
     Rec r;
     r.b = P.best[o]; r.x = CERT ? P.second[o] : P.worst[o]; r.idx = P.idx[o];
     r.rp = (CERT && COST == VWGPU_CROSS_CORRELATION) ? P.rpmax[o] : 0.0;
+    r.nf = edge ? P.bnf[o] : 0.0;
     return r;
   };
-  double best[4], other[4], rpmax[4];
+  double best[4], other[4], rpmax[4], bnf[4];
   int bi[4];
+  bool fn[4] = {false, false, false, false};                     // run 0 started the search with a NaN cost (bit 31 of its index record)
   Rec nxt[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) nxt[m] = load(0, m);
@@ -613,7 +657,7 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const double b = cur[m].b, x = cur[m].x;
-      if (k == 0) { best[m] = b; other[m] = x; bi[m] = cur[m].idx; rpmax[m] = cur[m].rp; }
+      if (k == 0) { best[m] = b; other[m] = x; bi[m] = cur[m].idx & 0x7fffffff; fn[m] = cur[m].idx < 0; rpmax[m] = cur[m].rp; bnf[m] = cur[m].nf; }
       else {
         const bool better = zbetter<COST>(b, best[m]);          // strictly better: ties stay with the earlier run (first wins)
         if (CERT) {
@@ -622,10 +666,11 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
           const double when_not = zbetter<COST>(b, other[m]) ? b : other[m];
           other[m] = better ? when_better : when_not;
           rpmax[m] = fmax(rpmax[m], cur[m].rp);
+          bnf[m] = zbetter<COST>(cur[m].nf, bnf[m]) ? cur[m].nf : bnf[m];
         } else {
           other[m] = !zbetter<COST>(x, other[m]) ? x : other[m];      // the extremum (a NaN never gets here: bad tiles left above)
         }
-        bi[m] = better ? cur[m].idx : bi[m];
+        bi[m] = better ? (cur[m].idx & 0x7fffffff) : bi[m];
         best[m] = better ? b : best[m];
       }
     }
@@ -638,14 +683,23 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
       const int y = y0 + m;
       if (y >= th) continue;
       int32_t* o3 = out + ((size_t)z.out_off + (size_t)(oy + y) * z.out_stride + ox + c) * 3;
-      const int by_ = bi[m] / z.sx, bx_ = bi[m] - by_ * z.sx;
+      const int bsel = fn[m] ? 0 : bi[m];                        // (a NaN first candidate is the reference's winner)
+      const int by_ = bsel / z.sx, bx_ = bsel - by_ * z.sx;
       o3[0] = bx_ + z.addx; o3[1] = by_ + z.addy;
       o3[2] = CERT ? (D == 1 ? 0 : 0x7fffffff) : ((best[m] == other[m]) ? 0 : 0x7fffffff);
       if (CERT) {
         double lprec = 0.0;
         if (COST == VWGPU_CROSS_CORRELATION) lprec = pa.p[(size_t)(z.ay + oy + y - pa.y0) * pa.w + (z.ax + ox + c - pa.x0)];
         const double sl = COST == VWGPU_CROSS_CORRELATION ? lprec : 1.0;       // (square roots of precisions, as in bm_zones_kernel)
-        if (!zcertified<COST>(C.zc[it.zone], D, bad, best[m] * sl, other[m] * sl, sl * sl, rpmax[m] * rpmax[m])) uncert = true;
+        bool okpx = zcertified<COST>(C.zc[it.zone], D, bad, best[m] * sl, other[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
+        if (edge) {                                                // the "cannot matter" certificate, as in bm_zones_kernel
+          constexpr double kInit = COST == VWGPU_CROSS_CORRELATION ? -INFINITY : INFINITY;
+          const ZEdge e1{C.edge_lo, C.edge_hi, z.bx + ox + c - C.edge_k};
+          if (fn[m]) okpx = !e1.notfar(0);
+          else if (!okpx && !bad && fabs(best[m]) <= 1.7976931348623157e308 && !e1.notfar(bx_))
+            okpx = bnf[m] == kInit || zcertified<COST>(C.zc[it.zone], D, false, best[m] * sl, bnf[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
+        }
+        if (!okpx) uncert = true;
       }
     }
   }
@@ -843,7 +897,8 @@ size_t zones_lds_fixed(int zs, int kx, int ky, size_t accb) { return (size_t)(zs
 
 int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
                           int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out, int f32_sums, int cert_hi, int* d_zflag,
-                          unsigned long long* d_stats, int* d_any, const int* d_need, const unsigned char* d_cells) {
+                          unsigned long long* d_stats, int* d_any, const int* d_need, const unsigned char* d_cells,
+                          int edge_m, int edge_k, int edge_lo, int edge_hi) {
   const bool cert = cert_hi != INT_MIN;
   if (cost_type == VWGPU_CROSS_CORRELATION || cert) f32_sums = 0;        // (NCC sums are scaled in float64 anyway)
   const size_t accb = f32_sums ? 4 : 8;
@@ -954,7 +1009,17 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
 
   PrecView pa{nullptr, 0, 0, 0, 0}, pb{nullptr, 0, 0, 0, 0};
   // partial records of the cut tiles behind the precision images in the scratch arena
-  const size_t rec_bytes = 8 + 8 + 4 + (cert ? 8 : 0) + (cert && ncc ? 8 : 0);
+  // the "cannot matter" certificate (ZEdge) only where a zone of the pass has far candidates at all: its kernels cost 4 instructions per evaluation more
+  bool edge = false;
+  if (cert && edge_m > 0)
+    for (int i = 0; i < n && !edge; ++i) {
+      const vwgpu_zone_task& z = zones[i];
+      if (z.zw <= 0 || z.zh <= 0 || z.sx <= 0 || z.sy <= 0) continue;
+      const long long lo = (long long)z.bx - edge_k, hi = lo + z.zw - 1 + z.sx - 1;        // partner columns of the zone's candidates
+      edge = lo < (long long)edge_lo || hi > (long long)edge_hi;
+    }
+  if (!edge) edge_m = 0;
+  const size_t rec_bytes = 8 + 8 + 4 + (cert ? 8 : 0) + (cert && ncc ? 8 : 0) + (edge ? 8 : 0);
   size_t part_bytes = 1024;
   for (ZPlan& pl : plan) part_bytes += vwgpu_align_up((size_t)pl.nslots * pl.zs * pl.zs * rec_bytes + 64, 256);
   size_t na = 0, nb = 0;
@@ -974,7 +1039,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     ZPrecJobs zj;
     zj.j[0] = ZPrecJob{A, aw, ah, da, pa.x0, pa.y0, pa.w, pa.h};
     zj.j[1] = ZPrecJob{B, bw, bh, db, pb.x0, pb.y0, pb.w, pb.h};
-    hipLaunchKernelGGL(zone_precision_kernel, dim3((std::max(pa.w, pb.w) + 63) / 64, (std::max(pa.h, pb.h) + 3) / 4, 2), dim3(64, 4), zp_lds, ctx->stream, zj, kx, ky, cert ? 1 : 0);
+    hipLaunchKernelGGL(zone_precision_kernel, dim3((std::max(pa.w, pb.w) + 63) / 64, (std::max(pa.h, pb.h) + 3) / 4, 2), dim3(64, 4), zp_lds, ctx->stream, zj, kx, ky, cert ? (edge ? 2 : 1) : 0);
     pa.p = da; pb.p = db;
   }
   {
@@ -986,6 +1051,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
       pl.P.worst = reinterpret_cast<double*>(q); q += slot_px * 8;
       if (cert) { pl.P.second = reinterpret_cast<double*>(q); q += slot_px * 8; }
       if (cert && ncc) { pl.P.rpmax = reinterpret_cast<double*>(q); q += slot_px * 8; }
+      if (edge) { pl.P.bnf = reinterpret_cast<double*>(q); q += slot_px * 8; }
       pl.P.idx = reinterpret_cast<int*>(q);
       q = q0 + vwgpu_align_up(slot_px * rec_bytes + 64, 256);
     }
@@ -1027,10 +1093,11 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
       plan[k].P.redo = f; f += plan[k].merges.size();
     }
   }
-  ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats, d_any, d_need, d_cells};
+  ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats, d_any, d_need, d_cells, edge_m, edge_k, edge_lo, edge_hi};
   if (cert) VWGPU_HIP(ctx, hipMemsetAsync(d_zflag, 0, (size_t)n * sizeof(int), ctx->stream));
 
-#define VW_ZN4(C_, K_, A_, T_, S_) hipLaunchKernelGGL((bm_zones_kernel<C_, K_, A_, T_, S_>), grd, dim3(S_ * S_ / 4), pl.lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, tab, pl.sxc, pa, pb, out, pl.P, C)
+#define VW_ZN5(C_, K_, A_, T_, S_, E_) hipLaunchKernelGGL((bm_zones_kernel<C_, K_, A_, T_, S_, E_>), grd, dim3(S_ * S_ / 4), pl.lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, tab, pl.sxc, pa, pb, out, pl.P, C)
+#define VW_ZN4(C_, K_, A_, T_, S_) do { if (T_ && edge) VW_ZN5(C_, K_, A_, T_, S_, T_); else VW_ZN5(C_, K_, A_, T_, S_, false); } while (0)
 #ifdef VWGPU_ZONES16
 #define VW_ZN3(C_, K_, A_, T_) do { if (pl.zs == 32) VW_ZN4(C_, K_, A_, T_, 32); else VW_ZN4(C_, K_, A_, T_, 16); } while (0)
 #else
@@ -1084,6 +1151,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
 #undef VW_ZN
 #undef VW_ZN3
 #undef VW_ZN4
+#undef VW_ZN5
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }

@@ -911,8 +911,20 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
       std::vector<Pending> pending;
       int* d_any = nullptr;
       const unsigned char* need_cells = nullptr;
+      // The "cannot matter" certificate of the certified passes (bm_zones.hip, ZEdge) and its premises.  L->R: a mask pass follows the
+      // clean-up filter (both sit behind filter_half_kernel > 0, CorrelationView.cc:702-744) and erases a pixel that points outside the
+      // right image; the filters before it compare disparities within 3 px over +- half kernel, hence the margin; no lr_disp_diff image
+      // (its entries keep the discrepancy of pixels the filters removed).  R->L: read by the L/R check alone.
+      const int edge_k = rox - hkx;
+      const int edge_m_lr = (P->filter_half_kernel > 0 && !(last && lr_diff)) ? P->filter_half_kernel + 4 : 0;
+      const int edge_m_rl = (P->consistency_threshold >= 0 && P->consistency_threshold < 1e6) ? (int)std::floor(P->consistency_threshold) + 2 : 0;
+      // columns of the right mask of this level that can be non-zero: the part of the crop inside the right image, halved per level the way
+      // subsample_mask_by_two does (a column is kept when one of its two source columns is)
+      const int rv0 = std::max(0, -rmb.x0) >> level, rv1 = (std::min(rmp[0].w, rw - rmb.x0) + (1 << level) - 1) >> level;
+      const int lr_lo = rv0 - edge_m_lr + 1, lr_hi = rv1 + edge_m_lr - 2;
+      const int rl_lo = -edge_m_rl + 1, rl_hi = dw + edge_m_rl - 2;           // the left pixels of the check lie in the tile: [0, dw)
       auto match = [&](const float* a, int aw_, int ah_, const float* b, int bw_, int bh_, std::vector<vwgpu_zone_task> const& tz, int32_t* dst,
-                       const int* need) -> int {
+                       const int* need, int edge_m, int edge_lo, int edge_hi) -> int {
         if (tz.empty()) return VWGPU_OK;
         if (!exact) return vwgpu_launch_bm_zones(ctx, P->cost_type, a, aw_, ah_, b, bw_, bh_, kx, ky, tz.data(), (int)tz.size(), dst, f32_level[level],
                                                  INT_MIN, nullptr, nullptr, nullptr, need, need ? need_cells : nullptr);
@@ -925,7 +937,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
           int* zflag = A.take<int>(tz.size());
           if (!zflag) return fail_mem();
           int rc2 = vwgpu_launch_bm_zones(ctx, P->cost_type, a, aw_, ah_, b, bw_, bh_, kx, ky, tz.data(), (int)tz.size(), dst, 0, cert_hi[level], zflag, d_cert_stats,
-                                          d_any + pending.size(), need, need ? need_cells : nullptr);
+                                          d_any + pending.size(), need, need ? need_cells : nullptr, edge_m, edge_k, edge_lo, edge_hi);
           if (rc2) return rc2;
           pending.push_back(Pending{a, aw_, ah_, b, bw_, bh_, &tz, dst, zflag});
           return VWGPU_OK;
@@ -933,7 +945,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         return vwgpu_launch_bm_exact(ctx, P->cost_type, a, aw_, ah_, aw_, b, bw_, bh_, bw_, kx, ky, tz.data(), (int)tz.size(), dst);
       };
       int32_t* rlbuf = static_cast<int32_t*>(ctx->zrl.base);
-      if ((rc = match(Lv.p, Lv.w, Lv.h, Rv.p, Rv.w, Rv.h, t1, disp, nullptr))) return rc;
+      if ((rc = match(Lv.p, Lv.w, Lv.h, Rv.p, Rv.w, Rv.h, t1, disp, nullptr, edge_m_lr, lr_lo, lr_hi))) return rc;
       if (lr_active && !t2.empty()) {
         // The R->L pass only has to cover what the L/R check will look at: the positions the L->R disparities point to — about the zone
         // itself instead of the zone widened by its search range (3x the pixels for a 16 x 16 leaf with 32 disparities).  Only where the
@@ -947,7 +959,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
           if ((rc = vwgpu_launch_zone_need(ctx, t3.data(), (int)t3.size(), disp, pending.empty() ? nullptr : pending[0].zflag, need, cells, ncells))) return rc;
           need_cells = cells;
         }
-        if ((rc = match(Rv.p, Rv.w, Rv.h, Lv.p, Lv.w, Lv.h, t2, rlbuf, need))) return rc;
+        if ((rc = match(Rv.p, Rv.w, Rv.h, Lv.p, Lv.w, Lv.h, t2, rlbuf, need, edge_m_rl, rl_lo, rl_hi))) return rc;
       }
       if (!pending.empty()) {
         int any[2] = {0, 0};
