@@ -622,8 +622,13 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     dim3 cgrd((cmw + 63) / 64, (cmh + 3) / 4, 6);
     hipLaunchKernelGGL(crop_jobs_kernel, cgrd, kBlk, 0, st, cj);
   }
-  // nodata mean fill (:130-149)
-  {
+  // nodata mean fill (:130-149).  Without a user mask the mask of an image crop is all-valid (it is edge-extended like the image — only the
+  // bbox crops lmp / rmp are zero outside the image): its mean is not needed and nothing is filled; when that is true of both images the two
+  // reductions, the read-back and its host round trip are skipped altogether.
+  const bool l_all = !lmask, r_all = !rmask;
+  if (l_all && r_all) {
+    acc[0] = acc[1] = acc[2] = acc[3] = 1.0;
+  } else {
     constexpr int NB = 256;                         // workgroups per image
     double* d_part = A.take<double>(2 * 2 * NB);
     int* d_cell = A.take<int>(8);
@@ -663,8 +668,8 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     VWGPU_HIP(ctx, hipGetLastError());
     return VWGPU_OK;
   }
-  hipLaunchKernelGGL(fill_masked_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, lp[0].p, lmx, nl, (float)(acc[0] / acc[1]));
-  hipLaunchKernelGGL(fill_masked_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, rp[0].p, rmx, nr, (float)(acc[2] / acc[3]));
+  if (!l_all) hipLaunchKernelGGL(fill_masked_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, lp[0].p, lmx, nl, (float)(acc[0] / acc[1]));
+  if (!r_all) hipLaunchKernelGGL(fill_masked_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, rp[0].p, rmx, nr, (float)(acc[2] / acc[3]));
 
   // smoothing + decimation chain and mask decimation (:205-216)
   const float k5[5] = {(float)(1.0 / 16.0), (float)(4.0 / 16.0), (float)(6.0 / 16.0), (float)(4.0 / 16.0), (float)(1.0 / 16.0)};
