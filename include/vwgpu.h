@@ -122,7 +122,10 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *   VWGPU_OPT_CERTIFY          pyramid levels whose box sums could round (prefiltered imagery, float imagery, deep levels under SSD / NCC): 1
  *       (default) = the tile-parallel kernels match every zone first and CERTIFY each pixel — best cost ahead of the runner-up by more
  *       than twice a rigorous bound on the difference between any-order float64 sums and fast_box_sum's serial running sums
- *       (src/vw/Stereo/Algorithms.h:43-129) — and only zones that hold an uncertified pixel are redone by the exact-order kernels;
+ *       (src/vw/Stereo/Algorithms.h:43-129) — and only zones that hold an uncertified pixel are redone by the exact-order kernels.
+ *       A second certificate covers candidates whose partner lies far outside the other image (tiles at the side of a pair: NaN or exactly
+ *       tied costs in the margin that no bound can order): when only such candidates can win, the pixel is erased by the mask pass (L->R)
+ *       or fails the consistency check (R->L) whichever of them the reference picks, so the tile is the reference's without knowing which.
  *       0 = every zone of such a level goes to the exact-order kernels (the round-3 schedule).  Same results either way.
  *   VWGPU_OPT_ZONE_SXC         horizontal disparities per staged right patch: 0 (default) = 16, n = at most n (1 .. 4096; the LDS budget caps it).
  *   VWGPU_OPT_CERT_PERMILLE    (read only) per mille of the pixels in certified tiles since VWGPU_OPT_TRACE was last set with bit 2; -1 = none.
