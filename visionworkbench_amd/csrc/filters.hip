@@ -53,6 +53,21 @@ sepconv_kernel(ImgJobs jobs, Taps t, int step, int sw, int sh) {
   const ptrdiff_t stride = J.stride, dstride = J.dstride;
   const int w = J.w, h = J.h, ow = J.ow, oh = J.oh, offx = J.offx, offy = J.offy;
   if ((int)blockIdx.x * TW >= ow || (int)blockIdx.y * TH >= oh) return;       // (the grid is the largest job's)
+  if (J.bs == VWGPU_JOB_MASK_BY_TWO) {
+    // a mask job riding in the launch of a pyramid level's images (subsample_mask_by_two, CorrelationView.cc:38-63; mask_by_two_kernel):
+    // a launch of its own was 6 us of pure latency per level
+    const uint8_t* __restrict__ msrc = static_cast<const uint8_t*>(J.src);
+    uint8_t* __restrict__ mdst = static_cast<uint8_t*>(J.dst);
+    for (int i = threadIdx.x; i < TH * TW; i += 256) {
+      const int oy = blockIdx.y * TH + i / TW, ox = blockIdx.x * TW + (i % TW);
+      if (ox >= ow || oy >= oh) continue;
+      const int x = 2 * ox, y = 2 * oy;
+      auto at = [&](int xx, int yy) -> int { return (xx < w && yy < h) ? (msrc[(ptrdiff_t)yy * stride + xx] != 0) : 0; };
+      const int count = at(x, y) + at(x + 1, y) + at(x, y + 1) + at(x + 1, y + 1);
+      mdst[(ptrdiff_t)oy * dstride + ox] = count > 1 ? 255 : 0;
+    }
+    return;
+  }
   float* tile = smem;                       // [sh][sw]   edge-extended source
   float* work = smem + (size_t)sh * sw;     // [sh][TW]   horizontal pass (float, like the reference's `work`)
   const int tid = threadIdx.x;

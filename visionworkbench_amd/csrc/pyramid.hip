@@ -680,12 +680,11 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     rmp[i].w = 1 + (rmp[i - 1].w - 1) / 2; rmp[i].h = 1 + (rmp[i - 1].h - 1) / 2; rmp[i].p = A.take<uint8_t>((size_t)rmp[i].w * rmp[i].h);
     if (!lp[i].p || !rp[i].p || !lmp[i].p || !rmp[i].p) return fail_mem();
     // both images of the level in one launch, both masks in another (four launches of ~12 us on these sizes otherwise)
-    const vwgpu_img_job sj[2] = {{lp[i - 1].p, lp[i - 1].w, lp[i - 1].w, lp[i - 1].h, lp[i].p, lp[i].w, lp[i].w, lp[i].h, 0, 0, nullptr, 0},
-                                 {rp[i - 1].p, rp[i - 1].w, rp[i - 1].w, rp[i - 1].h, rp[i].p, rp[i].w, rp[i].w, rp[i].h, 0, 0, nullptr, 0}};
-    if ((rc = vwgpu_launch_sepconv_jobs(ctx, sj, 2, k5, 5, 2, k5, 5, 2, 0, 2))) return rc;
-    const vwgpu_img_job mj[2] = {{lmp[i - 1].p, lmp[i - 1].w, lmp[i - 1].w, lmp[i - 1].h, lmp[i].p, lmp[i].w, lmp[i].w, lmp[i].h, 0, 0, nullptr, 0},
-                                 {rmp[i - 1].p, rmp[i - 1].w, rmp[i - 1].w, rmp[i - 1].h, rmp[i].p, rmp[i].w, rmp[i].w, rmp[i].h, 0, 0, nullptr, 0}};
-    if ((rc = vwgpu_launch_mask_by_two_jobs(ctx, mj, 2))) return rc;
+    const vwgpu_img_job sj[4] = {{lp[i - 1].p, lp[i - 1].w, lp[i - 1].w, lp[i - 1].h, lp[i].p, lp[i].w, lp[i].w, lp[i].h, 0, 0, nullptr, 0},
+                                 {rp[i - 1].p, rp[i - 1].w, rp[i - 1].w, rp[i - 1].h, rp[i].p, rp[i].w, rp[i].w, rp[i].h, 0, 0, nullptr, 0},
+                                 {lmp[i - 1].p, lmp[i - 1].w, lmp[i - 1].w, lmp[i - 1].h, lmp[i].p, lmp[i].w, lmp[i].w, lmp[i].h, 0, 0, nullptr, VWGPU_JOB_MASK_BY_TWO},
+                                 {rmp[i - 1].p, rmp[i - 1].w, rmp[i - 1].w, rmp[i - 1].h, rmp[i].p, rmp[i].w, rmp[i].w, rmp[i].h, 0, 0, nullptr, VWGPU_JOB_MASK_BY_TWO}};
+    if ((rc = vwgpu_launch_sepconv_jobs(ctx, sj, 4, k5, 5, 2, k5, 5, 2, 0, 2))) return rc;      // both images and both masks of the level in one launch
   }
   // prefilter every level (:232-236); levels stay unfiltered sources of the next level, so filter into copies
   const bool use_sgm = P->algorithm != 0;

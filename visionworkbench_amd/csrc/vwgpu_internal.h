@@ -183,6 +183,8 @@ struct vwgpu_img_job {
   int offx, offy;                                     // source position of output (0, 0)
   const float* b; ptrdiff_t bs;                       // second operand (subtract / edge_extend_sub), or nullptr
 };
+// a job of vwgpu_launch_sepconv_jobs with bs == VWGPU_JOB_MASK_BY_TWO is a uint8 mask halved by subsample_mask_by_two instead of an image
+constexpr ptrdiff_t VWGPU_JOB_MASK_BY_TWO = -7;
 int vwgpu_launch_sepconv_jobs(vwgpu_ctx* ctx, const vwgpu_img_job* jobs, int n, const float* xk, int nx, int cx, const float* yk, int ny, int cy,
                               int edge, int step);
 int vwgpu_launch_conv2d_jobs(vwgpu_ctx* ctx, const vwgpu_img_job* jobs, int n, const float* k, int kw, int kh, int ci, int cj, int edge);
