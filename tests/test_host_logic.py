@@ -201,3 +201,55 @@ def test_python_constants_match_the_header():
         py = name[len("VWGPU_"):]
         assert hasattr(core, py), "visionworkbench_amd.core lacks %s" % py
         assert getattr(core, py) == value, (name, value, getattr(core, py))
+
+
+def test_mask_pyramid_is_zero_outside_the_halved_image_bounds(oracle):
+    """A premise of the "cannot matter" certificate (csrc/bm_zones.hip ZEdge, csrc/pyramid.hip): a right-mask crop that is zero left of column
+    v0 and from column v1 on (the part of the crop outside the image) stays zero, at pyramid level k of subsample_mask_by_two
+    (CorrelationView.cc:38-63), left of v0 >> k and from ceil(v1 / 2^k) on — whatever the mask holds in between."""
+    rng = np.random.default_rng(31)
+    for _ in range(60):
+        h, w = int(rng.integers(3, 70)), int(rng.integers(8, 150))
+        v0 = int(rng.integers(0, w // 2)); v1 = int(rng.integers(max(v0 + 1, w // 2), w + 1))
+        m = np.where(rng.random((h, w)) < 0.85, 255, 0).astype(np.uint8)
+        m[:, :v0] = 0; m[:, v1:] = 0
+        for level in range(1, 6):
+            m = oracle.subsample_mask_by_two(m)
+            if m.shape[0] < 1 or m.shape[1] < 1: break
+            lo, hi = v0 >> level, (v1 + (1 << level) - 1) >> level
+            assert not m[:, :lo].any(), (h, w, v0, v1, level)
+            assert not m[:, hi:].any(), (h, w, v0, v1, level)
+
+
+@pytest.mark.parametrize("cleanup", [0, 1])
+def test_far_pointing_pixels_cannot_be_seen_after_filter_and_mask(oracle, cleanup):
+    """The other premise of that certificate, on the oracle's own clean-up filter and mask pass (DisparityMap.h:357-441, :132-155): change
+    the disparities (and the validity) of pixels that point half kernel + 4 or more columns outside the right mask's non-zero part to OTHER such
+    values — the filtered, masked image does not change, for any neighbours."""
+    rng = np.random.default_rng(77 + cleanup)
+    V = np.iinfo(np.int32).max
+    for trial in range(40):
+        h, w = int(rng.integers(20, 60)), int(rng.integers(30, 90))
+        hk = int(rng.choice([1, 2, 3, 5])); M = hk + 4
+        m2w = w + int(rng.integers(10, 40)); v0 = int(rng.integers(0, 12)); v1 = m2w - int(rng.integers(0, 12))
+        rmask = np.where(rng.random((h + 6, m2w)) < 0.95, 255, 0).astype(np.uint8); rmask[:, :v0] = 0; rmask[:, v1:] = 0
+        lmask = np.where(rng.random((h, w)) < 0.95, 255, 0).astype(np.uint8)
+        x = np.arange(w)[None, :].repeat(h, 0)
+        d = np.zeros((h, w, 3), np.int32)
+        d[..., 0] = rng.integers(-6, 14, (h, w)); d[..., 1] = rng.integers(-1, 3, (h, w))
+        d[..., 2] = np.where(rng.random((h, w)) < 0.1, 0, V)
+        far = rng.random((h, w)) < 0.25
+        def far_values():
+            left_side = rng.random((h, w)) < 0.5
+            part = np.where(left_side, v0 - M - rng.integers(0, 20, (h, w)), v1 - 1 + M + rng.integers(0, 20, (h, w)))
+            return (part - x).astype(np.int32)
+        a, b = d.copy(), d.copy()
+        a[..., 0][far] = far_values()[far]; b[..., 0][far] = far_values()[far]
+        b[..., 1][far] = rng.integers(-3, 4, (h, w))[far]
+        b[..., 2][far] = np.where(rng.random((h, w)) < 0.3, 0, V)[far]
+        a[..., 2][far] = V
+        outs = []
+        for v in (a, b):
+            f = oracle.disparity_filter(v, hk, hk, 3.0, 0.5, cleanup)
+            outs.append(oracle.disparity_mask(f, lmask, rmask))
+        assert np.array_equal(outs[0], outs[1]), (trial, hk, int((outs[0] != outs[1]).any(-1).sum()))
