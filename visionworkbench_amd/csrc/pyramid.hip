@@ -309,6 +309,23 @@ __global__ void disparity_mask_kernel(int32_t* __restrict__ d, int w, int h, con
   if (!keep) { p[0] = 0; p[1] = 0; p[2] = 0; }
 }
 
+// disparity_mask_kernel + finish_kernel in one pass, for the last level of a block-matching tile when nothing else reads the masked image
+__global__ void finish_masked_kernel(const int32_t* __restrict__ d, int w, int h, const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
+                                     int m2w, int m2h, int ax, int ay, float* __restrict__ out, ptrdiff_t ostride_px) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= w || j >= h) return;
+  const int32_t* p = d + ((size_t)j * w + i) * 3;
+  int p0 = p[0], p1 = p[1], p2 = p[2];
+  bool keep = m1[(size_t)j * w + i] != 0 && p2 != 0;
+  if (keep) {
+    const int x = i + p0, y = j + p1;
+    keep = !(x < 0 || x >= m2w || y < 0 || y >= m2h || m2[(size_t)y * m2w + x] == 0);
+  }
+  if (!keep) { p0 = 0; p1 = 0; p2 = 0; }
+  float* o = out + ((ptrdiff_t)j * ostride_px + i) * 3;
+  o[0] = (float)(p0 + ax); o[1] = (float)(p1 + ay); o[2] = p2 ? 1.0f : 0.0f;
+}
+
 // out = PixelMask<Vector2f>(disparity + search.min)  (CorrelationView.cc:879-881)
 __global__ void finish_kernel(const int32_t* __restrict__ d, int w, int h, int ax, int ay, float* __restrict__ out, ptrdiff_t ostride_px) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -794,6 +811,7 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   };
   const int saved_force = ctx->forced_path;
   int dw = 0, dh = 0;
+  bool fused_finish = false;
   for (int level = L; level >= 0; --level) {
     const bool last = (level == 0);
     const int scaling = 1 << level;
@@ -1048,13 +1066,17 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     // clean-up filters (:702-744)
     // (an intermediate block-matching level: the second filter pass and the mask are applied by the zone scheduler's kernel as it reads)
     const bool fused_extents = !last && !use_sgm && P->filter_half_kernel > 0 && P->blob_filter_area <= 0;
+    // (the last level: the mask is applied by the kernel that writes the tile when nothing else reads the masked image)
+    fused_finish = last && !use_sgm && P->filter_half_kernel > 0 && P->blob_filter_area <= 0 && !lr_diff;
     if (P->filter_half_kernel > 0) {
       rc = vwgpu_launch_disparity_filter(ctx, disp, dw, dh, P->filter_half_kernel, P->filter_half_kernel, 3.0, 0.5, !last, padded, disp2, fused_extents);
       if (rc) return rc;
       if (!fused_extents) {
         std::swap(disp, disp2);
-        rc = vwgpu_launch_disparity_mask(ctx, disp, dw, dh, lmp[level].p, rmp[level].p, rmp[level].w, rmp[level].h);
-        if (rc) return rc;
+        if (!fused_finish) {
+          rc = vwgpu_launch_disparity_mask(ctx, disp, dw, dh, lmp[level].p, rmp[level].p, rmp[level].w, rmp[level].h);
+          if (rc) return rc;
+        }
       }
       if (!last && check_rl && use_sgm) {           // the R->L result seeds the next level's R->L run (:722-730)
         rc = vwgpu_launch_disparity_filter(ctx, rl_a, rlw, rlh, P->filter_half_kernel, P->filter_half_kernel, 3.0, 0.5, true, rl_pad, rl_b);
@@ -1132,6 +1154,8 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   if (lr_diff) hipLaunchKernelGGL(lr_diff_invalidate_kernel, grid2(bw, bh), kBlk, 0, st, disp, bw, bh, lr_diff, lr_stride, lr_ulx, lr_uly);
   if (use_sgm)
     hipLaunchKernelGGL(finish_sgm_kernel, grid2(bw, bh), kBlk, 0, st, disp, sub, bw, bh, (float)search.x0, (float)search.y0, out, os);
+  else if (fused_finish)
+    hipLaunchKernelGGL(finish_masked_kernel, grid2(bw, bh), kBlk, 0, st, disp, bw, bh, lmp[0].p, rmp[0].p, rmp[0].w, rmp[0].h, search.x0, search.y0, out, os);
   else
     hipLaunchKernelGGL(finish_kernel, grid2(bw, bh), kBlk, 0, st, disp, bw, bh, search.x0, search.y0, out, os);
   VWGPU_HIP(ctx, hipGetLastError());
