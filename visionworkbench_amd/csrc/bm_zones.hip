@@ -822,9 +822,13 @@ int upload_pieces(vwgpu_ctx* ctx, const void* const* src, const size_t* bytes, i
   }
   ctx->ztab_parity ^= 1;
   char* base = static_cast<char*>(ctx->ztab.base) + (ctx->ztab_parity ? ctx->ztab.cap / 2 : 0);
-  if (char* h = static_cast<char*>(vwgpu_host_ring(ctx, zoff))) {
+  // a small zeroed tail travels as zeros in the same copy (a fill of its own is one more 5 us launch per launch sequence)
+  const bool tail_in_copy = zero_tail > 0 && zero_tail <= 64 * 1024;
+  if (char* h = static_cast<char*>(vwgpu_host_ring(ctx, tail_in_copy ? zoff + zero_tail : zoff))) {
     for (int i = 0; i < n; ++i) if (bytes[i]) memcpy(h + off[i], src[i], bytes[i]);
-    VWGPU_HIP(ctx, hipMemcpyAsync(base, h, zoff, hipMemcpyHostToDevice, ctx->stream));
+    if (tail_in_copy) memset(h + zoff, 0, zero_tail);
+    VWGPU_HIP(ctx, hipMemcpyAsync(base, h, tail_in_copy ? zoff + zero_tail : zoff, hipMemcpyHostToDevice, ctx->stream));
+    if (tail_in_copy) zero_tail = 0;
   } else {
     for (int i = 0; i < n; ++i)
       if (bytes[i]) VWGPU_HIP(ctx, hipMemcpyAsync(base + off[i], src[i], bytes[i], hipMemcpyHostToDevice, ctx->stream));
@@ -878,7 +882,7 @@ bool vwgpu_bm_zones_supported(int kx, int ky) {
 // cert_hi: INT_MIN = no certification (the level is order free: any summation order returns the reference's bits — which includes "every
 // pixel finite", vwgpu_sums_bits: the SAD / SSD chain relies on finite costs).  Otherwise the
 // largest binary exponent of the level's pixels (|pixel| < 2^(cert_hi + 1), all finite): the kernels certify every pixel against the
-// error bound above and raise d_zflag[zone] (n ints, zeroed here) for zones with a pixel they cannot certify; the caller redoes those
+// error bound above and raise d_zflag[zone] (n ints, zeroed by the CALLER) for zones with a pixel they cannot certify; the caller redoes those
 // zones in the reference's order (vwgpu_launch_bm_exact with the same flags as its gate).
 namespace {
 // the work of one tile size of a launch sequence
@@ -1094,7 +1098,6 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     }
   }
   ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats, d_any, d_need, d_cells, edge_m, edge_k, edge_lo, edge_hi};
-  if (cert) VWGPU_HIP(ctx, hipMemsetAsync(d_zflag, 0, (size_t)n * sizeof(int), ctx->stream));
 
 #define VW_ZN5(C_, K_, A_, T_, S_, E_) hipLaunchKernelGGL((bm_zones_kernel<C_, K_, A_, T_, S_, E_>), grd, dim3(S_ * S_ / 4), pl.lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, tab, pl.sxc, pa, pb, out, pl.P, C)
 #define VW_ZN4(C_, K_, A_, T_, S_) do { if (T_ && edge) VW_ZN5(C_, K_, A_, T_, S_, T_); else VW_ZN5(C_, K_, A_, T_, S_, false); } while (0)
@@ -1168,8 +1171,12 @@ size_t vwgpu_zone_need_cells(vwgpu_zone_task* zones, int n) {
 int vwgpu_launch_zone_need(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, const int32_t* l2r, const int* d_zflag, int* d_need,
                            unsigned char* d_cells, size_t ncells) {
   if (n <= 0) return VWGPU_OK;
-  VWGPU_HIP(ctx, hipMemsetAsync(d_need, 0, (size_t)n * 8 * sizeof(int), ctx->stream));
-  VWGPU_HIP(ctx, hipMemsetAsync(d_cells, 0, ncells, ctx->stream));
+  if (d_cells == reinterpret_cast<unsigned char*>(d_need + (size_t)8 * n)) {       // one block: one fill
+    VWGPU_HIP(ctx, hipMemsetAsync(d_need, 0, (size_t)n * 8 * sizeof(int) + ncells, ctx->stream));
+  } else {
+    VWGPU_HIP(ctx, hipMemsetAsync(d_need, 0, (size_t)n * 8 * sizeof(int), ctx->stream));
+    VWGPU_HIP(ctx, hipMemsetAsync(d_cells, 0, ncells, ctx->stream));
+  }
   std::vector<int2> tiles;
   build_tiles(zones, n, tiles);
   if (tiles.empty()) return VWGPU_OK;

@@ -951,13 +951,13 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         if (!exact) return vwgpu_launch_bm_zones(ctx, P->cost_type, a, aw_, ah_, b, bw_, bh_, kx, ky, tz.data(), (int)tz.size(), dst, f32_level[level],
                                                  INT_MIN, nullptr, nullptr, nullptr, need, need ? need_cells : nullptr);
         if (cert_hi[level] != INT_MIN) {
-          if (!d_any) {
-            d_any = A.take<int>(64);
+          if (!d_any) {                                            // the two "any zone flagged" words and the zone flags of both passes: one block, one fill
+            const size_t nflag = 64 + t1.size() + t2.size();
+            d_any = A.take<int>(nflag);
             if (!d_any) return fail_mem();
-            VWGPU_HIP(ctx, hipMemsetAsync(d_any, 0, 2 * sizeof(int), st));
+            VWGPU_HIP(ctx, hipMemsetAsync(d_any, 0, nflag * sizeof(int), st));
           }
-          int* zflag = A.take<int>(tz.size());
-          if (!zflag) return fail_mem();
+          int* zflag = d_any + 64 + (pending.empty() ? 0 : t1.size());
           int rc2 = vwgpu_launch_bm_zones(ctx, P->cost_type, a, aw_, ah_, b, bw_, bh_, kx, ky, tz.data(), (int)tz.size(), dst, 0, cert_hi[level], zflag, d_cert_stats,
                                           d_any + pending.size(), need, need ? need_cells : nullptr, edge_m, edge_k, edge_lo, edge_hi);
           if (rc2) return rc2;
@@ -975,9 +975,9 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
         int* need = nullptr;
         if (!exact || cert_hi[level] != INT_MIN) {
           const size_t ncells = vwgpu_zone_need_cells(t3.data(), (int)t3.size());
-          need = A.take<int>(8 * t3.size());
-          unsigned char* cells = A.take<unsigned char>(ncells + 16);
-          if (!need || !cells) return fail_mem();
+          need = A.take<int>(8 * t3.size() + (ncells + 16 + 3) / 4);      // records, then the cell flags: one block, one fill
+          if (!need) return fail_mem();
+          unsigned char* cells = reinterpret_cast<unsigned char*>(need + 8 * t3.size());
           if ((rc = vwgpu_launch_zone_need(ctx, t3.data(), (int)t3.size(), disp, pending.empty() ? nullptr : pending[0].zflag, need, cells, ncells))) return rc;
           need_cells = cells;
         }

@@ -234,7 +234,7 @@ struct vwgpu_zone_task {
 };
 bool vwgpu_bm_zones_supported(int kx, int ky);
 // f32_sums: vwgpu_sums_bits <= 24 for BOTH images.  cert_hi != INT_MIN: certify against the reference's summation order (bm_zones.hip),
-// d_zflag[n] receives the zones that need vwgpu_launch_bm_exact; d_stats (optional): {pixels in certified tiles, in flagged tiles}
+// d_zflag[n] (zeroed by the caller) receives the zones that need vwgpu_launch_bm_exact; d_stats (optional): {pixels in certified tiles, in flagged tiles}
 int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
                           int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out, int f32_sums = 0,
                           int cert_hi = (-2147483647 - 1), int* d_zflag = nullptr, unsigned long long* d_stats = nullptr,
