@@ -1,18 +1,12 @@
-# Is the threaded tile loop GPU bound?  Sum of the kernel durations (rocprofv3 --kernel-trace) against the wall time of the same run.  GPU box only.
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-cd $R
-export PYR_ONLY="${PYR_ONLY:-LoG 1.4 + NCC}"
-rocprofv3 --kernel-trace --stats -d /tmp/ptl -o ptl -- python tools/pyr_throughput.py ${THREADS:-4} > /tmp/ptl.log 2>&1
-grep -v amdgpu /tmp/ptl.log | grep "ms/tile"
-db=$(find /tmp/ptl -name "*.db" | head -1)
-python tools/rocprof_summary.py "$db" gpurun_out/tile_loop_kernels.md > /dev/null 2>&1
-python - <<'PY'
-import re
-tot = 0.0; rows = []
-for line in open("gpurun_out/tile_loop_kernels.md"):
-    m = re.match(r"\| (.+?) \| (\d+) \| ([\d.]+) \| ([\d.]+) \| ([\d.]+) \|", line)
-    if m: rows.append((m.group(1), int(m.group(2)), float(m.group(3)))); tot += float(m.group(3))
-print("sum of kernel durations: %.1f ms over the whole process" % (tot / 1e3))
-for n, c, t in rows[:12]: print("  %-50s %6d calls %9.1f ms" % (n[:50], c, t / 1e3))
-PY
+# rocprofv3 kernel trace of the four-thread pyramid tile loops (tools/pyr_throughput.py): per-kernel totals and how busy the GPU was.
+# usage: TAG=r04k bash tools/prof_tile_loop.sh   (GPU box)
+TAG=${TAG:-r04k}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+for c in "SAD 7x7, integer" "LoG 1.4 + NCC"; do
+  tag=$(echo "$c" | tr -dc 'A-Za-z' | cut -c1-6)
+  rm -rf /tmp/ktr_$tag
+  PYR_ONLY="$c" timeout 300 rocprofv3 --kernel-trace -d /tmp/ktr_$tag -o ktr -- python tools/pyr_throughput.py 4 > /tmp/ktr_$tag.log 2>&1
+  db=$(find /tmp/ktr_$tag -name "*.db" | head -1)
+  { echo "## $c — four tile threads, 96 tiles of the 4096^2 pair (rocprofv3 --kernel-trace; the tracer slows the host side)"; grep thr /tmp/ktr_$tag.log; python tools/trace_overlap.py "$db" 0.3; echo; } >> gpurun_out/${TAG}_tile_loop_kernels.md
+done
+cat gpurun_out/${TAG}_tile_loop_kernels.md
