@@ -6,7 +6,8 @@
   config 4  16384-wide census-SGM strips      SGM is global along every scan line (no crop reproduces a strip), so the
                                               oracle runs strips it can finish in seconds — 16384 columns x 129
                                               disparities, the kernel and row length of the config: 32 and 512 rows — and a 2048-wide,
-                                              256-row strip; the full 16384 x 2048 strip is checked against ground truth
+                                              256-row strip; the full 16384 x 2048 strip is checked against ground truth and, with the
+                                              oracle's path lines on all host threads (minutes), pixel for pixel
   config 5  1024^2 tiles of a 32768-wide pair pyramid_correlate BM-NCC (5 levels, L/R check, filters) and SGM + sub-pixel
 The oracle legs run on the host cores of the GPU box (tile threads as the reference runs them)."""
 import os
@@ -112,6 +113,24 @@ def test_config4_full_strip_ground_truth():
     valid = gi[..., 2] != 0
     assert valid.mean() > 0.99
     assert (gi[..., 0] == t)[valid].mean() > 0.93      # the rest: occlusion seams between blocks of different shift
+
+
+def test_config4_full_strip_identical(oracle):
+    """One GPU's share of BASELINE configs[3] — a 16384 x 2048-row strip (+ the 7x7 kernel rim), census 7x7, 129 disparities, 8 paths,
+    LC-blend sub-pixel — against the oracle on ALL host threads (its path lines and cost rows are threaded; 33.5 M pixels x 129
+    disparities: minutes of host time, which is why the other strip tests stop at 518 rows).  Every integer disparity identical, sub-pixel
+    values within 1e-5 (VERDICT r4 "What's weak" 3).  Both sides get the same memory limit: the volume is 13 GB, above the reference's
+    default cap of 6000 MB (SGM.cc:502-672)."""
+    oracle.set_sgm_host_threads(NCPU)
+    w, rows = 16384, 2048 + 6
+    left, right, truth = synth.stereo_pair(w, rows, 129, 1)
+    gi, gs = stereo.calc_disparity_sgm(3, left, right, BBox2i(0, 0, w, rows), (128, 0), (7, 7), with_subpixel=True, memory_limit_mb=20000)
+    oi, os_ = oracle.calc_disparity_sgm(3, left, right, (128, 0), 7, memory_limit_mb=20000)
+    assert gi.shape == oi.shape == (2048, w - 6, 3)
+    assert np.array_equal(gi, oi), int((gi != oi).any(-1).sum())
+    assert np.abs(gs - os_).max() < 1e-5
+    valid = gi[..., 2] != 0
+    assert valid.mean() > 0.99 and (gi[..., 0] == truth[3:3 + 2048, 3:3 + w - 6])[valid].mean() > 0.93
 
 
 @pytest.fixture(scope="module")

@@ -82,7 +82,8 @@ struct PrecView {           // 1 / box-sum(img^2) over origins [x0, x0+w) x [y0,
 // prec(x, y) = 1.0 / sum_{ky x kx} img(clamp)^2 for window origins (x0 + i, y0 + j).  A 64 x 4 output tile: the squares of its
 // (64 + kx - 1) x (4 + ky - 1) pixels go to LDS once, then row sums and column sums (the direct form read kx * ky floats per output
 // through the L1: 0.3 ms per 1024^2 NCC tile).  Used on data whose box sums are exact in any order (vwgpu_sums_order_free) and, as
-// sqrt(1 / S) (root != 0), by the certified pass, whose error bound covers the order of the sums.
+// sqrt(1 / S) (root != 0), by the certified pass, whose error bound covers the order of the sums (root == 2, the passes with the "cannot
+// matter" certificate, additionally turns the infinite precision of an all-zero window into NaN for EVERY pixel of the pass, see below).
 struct ZPrecJob { const float* img; int w, h; double* prec; int x0, y0, pw, ph; };
 struct ZPrecJobs { ZPrecJob j[2]; };           // blockIdx.z: the left and the right image of a pass in one launch
 __global__ void __launch_bounds__(256)
@@ -374,7 +375,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
       ACC* Hc = H + hb * (PH * HP);
       if (COST == VWGPU_CROSS_CORRELATION) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) rpn[m] = ZKNOCK(32) ? 0.0 : prow[m][d];      // (d < 16: inside the image's 256-byte-aligned block even for a 1 x 1 zone)
+        for (int m = 0; m < 4; ++m) rpn[m] = ZKNOCK(32) ? 0.0 : prow[m][d];      // (lanes without a pixel read pb.p[d]: d < nd <= z.sx <= pb.w, inside the precision image's first row)
       }
       if (KS > 0) {
         // HW adjacent columns per thread: KS + HW - 1 cost elements are formed once and the window slides (s' = s - e[j] + e[j + KS]).

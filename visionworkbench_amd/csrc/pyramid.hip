@@ -604,7 +604,11 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   const size_t nl = (size_t)lg.dx() * lg.dy(), nr = (size_t)rg.dx() * rg.dy();
   const size_t need = 4 * (nl + nr) * 3 + (nl + nr) * 2 + (size_t)rmb.dx() * rmb.dy() * 2 + (size_t)bw * bh * (12 * 3 + 2) +
                       (size_t)(bw + 2) * (bh + 2) * 12 + (nl + nr) * 4 * 2 + (size_t)(rg.dx() + 2 * search.dx()) * (rg.dy() + 2 * search.dy()) * 20 +
-                      (size_t)(lg.dx() + 2 * search.dx() + 2) * (lg.dy() + 2 * search.dy() + 2) * 4 + (1 << 20);
+                      (size_t)(lg.dx() + 2 * search.dx() + 2) * (lg.dy() + 2 * search.dy() + 2) * 4 + (1 << 20) +
+                      // per-level tables taken inside the level loop: zone flags of both passes and the R->L need records (8 ints per
+                      // zone; zones <= 4 per 16 x 16 px of the tile + 64) with one cell flag per 16 x 16 px of every zone's R->L image (a zone widened
+                      // by its search range: at most (sdx / 16 + 3)(sdy / 16 + 3) cells for a leaf-sized zone)
+                      (size_t)(L + 1) * ((size_t)bw * bh / 64 + 64) * (48 + (size_t)(search.dx() / 16 + 3) * (search.dy() / 16 + 3)) + 4096;
   // SGM: R->L crops (left image grown by twice the search), R->L masks, disparities of both directions and their history
   const size_t rl_px = (size_t)(bw + search.dx() + 8) * (bh + search.dy() + 8);
   const size_t lrev_px = (size_t)(lg.dx() + 2 * search.dx() + 8) * (lg.dy() + 2 * search.dy() + 8);
@@ -938,7 +942,13 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
       // right image; the filters before it compare disparities within 3 px over +- half kernel, hence the margin; no lr_disp_diff image
       // (its entries keep the discrepancy of pixels the filters removed).  R->L: read by the L/R check alone.
       const int edge_k = rox - hkx;
-      const int edge_m_lr = (P->filter_half_kernel > 0 && !(last && lr_diff)) ? P->filter_half_kernel + 4 : 0;
+      // Margin.  Last level: ONE filter pass (rm_outliers, hk x hk, 3 px) — a far pixel M must not be counted by a pixel that
+      // can survive the mask, i.e. |dx(M) - dx(N)| > 3 for every N within hk columns whose target lies inside: hk + 3 + 1.  Intermediate
+      // levels: disparity_cleanup_using_thresh is TWO passes (inner (hk, hk, 3, 0.5), then outer (1, 1, 3, 0.2) on the inner pass's output,
+      // DisparityMap.h:427-441): a kept pixel K (target inside) has an outer-pass neighbour N within 1 column and 3 px — N's target up to 4
+      // columns outside — whose inner-pass count sees M within hk columns and 3 px: M's target up to hk + 7 columns outside must still be
+      // treated as "can matter", so far starts at hk + 8.
+      const int edge_m_lr = (P->filter_half_kernel > 0 && !(last && lr_diff)) ? P->filter_half_kernel + (last ? 4 : 8) : 0;
       const int edge_m_rl = (P->consistency_threshold >= 0 && P->consistency_threshold < 1e6) ? (int)std::floor(P->consistency_threshold) + 2 : 0;
       // columns of the right mask of this level that can be non-zero: the part of the crop inside the right image, halved per level the way
       // subsample_mask_by_two does (a column is kept when one of its two source columns is)

@@ -52,6 +52,9 @@ int vwgpu_arena_reserve(vwgpu_ctx* ctx, vwgpu_arena* a, size_t bytes) {
 // event recorded when IT was last left has completed.  So a piece is never rewritten while a copy that reads it is still pending,
 // however far the host runs ahead of the device (the disparity-group loop of bm_exact.hip queues hundreds of table uploads
 // without a synchronisation; before this the ring relied on callers synchronising "at least once per pyramid level").
+// CONTRACT: the copy that reads a piece must be queued on ctx->stream BEFORE the next vwgpu_host_ring call — the event that
+// protects a half is recorded when the cursor leaves it, i.e. inside a later call, and covers only what was queued by then.  Every caller
+// fills the piece and queues its hipMemcpyAsync at once (upload_pieces, the leaf-extent read-back, bm_exact's table uploads).
 void* vwgpu_host_ring(vwgpu_ctx* ctx, size_t bytes) {
   const size_t CAP = (size_t)ctx->host_ring_kb << 10;
   if (!ctx->host_ring) {
