@@ -224,8 +224,9 @@ def cpu_baseline_sgm(synth, cost_type, k, D, budget_s=12.0):
                       % (done, D, T, cores, dt)}
 
 
-def cpu_baseline_pyramid(left, right, modes, search, levels, budget_s=8.0):
-    """oracle pyramid_correlate over 1024^2 tiles of the given pair on T host threads (tools/correlate.cc:207-266 + ImageIO.h:228-251)."""
+def cpu_baseline_pyramid(left, right, modes, search, levels, budget_s=8.0, keep=None):
+    """oracle pyramid_correlate over 1024^2 tiles of the given pair on T host threads (tools/correlate.cc:207-266 + ImageIO.h:228-251).
+    keep (a dict): receives {(mode name, tile bbox): the oracle's tile} for the tiles that were computed — the checker of the GPU tile loop."""
     import oracle
     cores = os.cpu_count() or 1
     H, W = left.shape
@@ -234,9 +235,14 @@ def cpu_baseline_pyramid(left, right, modes, search, levels, budget_s=8.0):
     out = {}
     for m in modes:
         if m["alg"] == 0:
-            fn = lambda bb, m=m: oracle.pyramid_correlate(left, right, None, None, m["pf"], m["pfw"], search, m["kernel"], m["cost"], 0, 0.0, 2.0, 5, levels, bbox=bb)
+            run = lambda bb, m=m: oracle.pyramid_correlate(left, right, None, None, m["pf"], m["pfw"], search, m["kernel"], m["cost"], 0, 0.0, 2.0, 5, levels, bbox=bb)
         else:
-            fn = lambda bb, m=m: oracle.pyramid_correlate_sgm(left, right, None, None, search, m["kernel"][0], m["cost"], 2.0, 0, 5, levels, bbox=bb, algorithm=m["alg"])
+            run = lambda bb, m=m: oracle.pyramid_correlate_sgm(left, right, None, None, search, m["kernel"][0], m["cost"], 2.0, 0, 5, levels, bbox=bb, algorithm=m["alg"])
+
+        def fn(bb, m=m, run=run):
+            o = run(bb)
+            if keep is not None:
+                keep.setdefault((m["name"], bb), o)
         jobs = [tiles[i % len(tiles)] for i in range(8 * T)]
         done, dt = threaded_tiles(fn, jobs, T, budget_s)
         out[m["name"]] = {"value": done * 1024 * 1024 / dt / 1e6, "unit": "Mpix/s", "cores": T, "kind": "port", "tile": 1024,
@@ -329,6 +335,63 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right, with
           {k for k in kern if k.startswith("parabola") or k in ("disparity_range", "float_grain", "edge_extend_sub")}, W * H,
           cpu_baseline=cpu(lambda j, dh=disp[:512, :512].cpu().numpy(): oracle.parabola_subpixel(dh, left[:512, :512], right[:512, :512 + 128], 0, 0.0, (11, 11)),
                            list(range(4 * cores)), cores, 512 * 512, "512^2 crop of the same NCC result through parabola_subpixel 11x11"))
+    # (2c) SURVEY 8(d): "one non-integer (float texture) input per config and report mismatch rate".  The float twin of the pair (pixel * 0.37 +
+    # uniform noise in [0, 1), independent per image — tests/fuzz_cases.py:47) through the same calc_disparity calls as configs 2 and 3a: which
+    # kernel family served it, Mpix/s, roofline fraction, and the whole image against the oracle (single-threaded over the whole raster, as
+    # best_of_search_convolution runs it: on such data the running sums' roundings depend on the raster position, Correlation.cc:33-137).
+    rng = np.random.default_rng(20260926)
+    left_f = (left * np.float32(0.37) + rng.random(left.shape, dtype=np.float32)).astype(np.float32)
+    right_f = (right * np.float32(0.37) + rng.random(right.shape, dtype=np.float32)).astype(np.float32)
+    lf, rf = torch.from_numpy(left_f).to(lt.device), torch.from_numpy(right_f).to(lt.device)
+    want_f = {}
+    oth = []
+    if with_cpu:
+        import threading
+        for c_, kk_ in ((0, KERNEL), (2, (11, 11))):
+            th_ = threading.Thread(target=lambda c_=c_, kk_=kk_: want_f.__setitem__(c_, oracle.calc_disparity(c_, left_f, right_f, kk_, SEARCH)))
+            th_.start(); oth.append(th_)
+    fl = []
+    for c_, kk_, nm in ((0, KERNEL, "config 2"), (2, (11, 11), "config 3a")):
+        wall, kern = measure(ctx, torch, lambda: stereo.calc_disparity(c_, lf, rf, bb, SEARCH, kk_, ctx=ctx), 5, warm=1)
+        fl.append((c_, kk_, stereo.calc_disparity(c_, lf, rf, bb, SEARCH, kk_, ctx=ctx)))
+        entry("%s on a FLOAT texture (pixel * 0.37 + uniform noise): 4096^2, %dx%d %s, search 129x1" % (nm, kk_[0], kk_[1], "SAD" if c_ == 0 else "NCC"),
+              algorithmic_bytes(W, H, kk_[0], kk_[1], 129, 1), "4LW + 4RW + 12 out (SURVEY 8d)", wall, kern, set(kern), (W - kk_[0] + 1) * (H - kk_[1] + 1),
+              path=ctx.last_path())
+    for th_ in oth:
+        th_.join()
+    for (c_, kk_, got_), e in zip(fl, out[-2:]):
+        if c_ in want_f:
+            g = got_.cpu().numpy()
+            bad = int((g != want_f[c_]).any(-1).sum())
+            e["identical_to_oracle"] = bad == 0
+            e["mismatch_rate"] = bad / float(g.shape[0] * g.shape[1])
+            e["oracle_check"] = "every pixel of the %d x %d image against oracle.calc_disparity over the whole raster (one host thread)" % (g.shape[1], g.shape[0])
+            assert bad == 0, "float-texture %s: %d pixels differ from the oracle" % (e["name"], bad)
+    del lf, rf, fl
+    # (2d) SURVEY 8(d)'s second column: END TO END — the host-pointer entry of the C ABI (vwgpu_calc_disparity: H2D of both images, the
+    # matcher, D2H of the disparity image, one synchronisation), on pageable numpy arrays and on page-locked ones
+    def e2e(l_, r_, o_):
+        rc_ = ctx._lib.vwgpu_calc_disparity(ctx._h, 0, l_, W, H, W, r_, right.shape[1], right.shape[0], right.shape[1], KERNEL[0], KERNEL[1], SEARCH[0], SEARCH[1], o_, 0)
+        ctx.check(rc_)
+    ow_, oh_ = W - KERNEL[0] + 1, H - KERNEL[1] + 1
+    res_e2e = {}
+    out_np = np.empty((oh_, ow_, 3), np.int32)
+    pl_, pr_ = torch.from_numpy(left).pin_memory(), torch.from_numpy(right).pin_memory()
+    po_ = torch.empty((oh_, ow_, 3), dtype=torch.int32).pin_memory()
+    for kind, args_ in (("pageable", (left.ctypes.data, right.ctypes.data, out_np.ctypes.data)), ("pinned", (pl_.data_ptr(), pr_.data_ptr(), po_.data_ptr()))):
+        e2e(*args_)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            e2e(*args_)
+        dt_ = (time.perf_counter() - t0) / 3
+        res_e2e[kind] = {"ms_per_call": round(dt_ * 1e3, 3), "Mpix_per_s": round(ow_ * oh_ / dt_ / 1e6, 1)}
+    assert np.array_equal(out_np, po_.numpy())
+    moved = 4 * W * H + 4 * right.shape[0] * right.shape[1] + 12 * ow_ * oh_
+    out.append({"name": "headline END TO END: vwgpu_calc_disparity on host pointers (H2D + matcher + D2H), 4096^2, 7x7 SAD, search 129x1",
+                "bytes_over_pcie": int(moved), "pageable": res_e2e["pageable"], "pinned": res_e2e["pinned"],
+                "pcie_GBs_pinned": round(moved / (res_e2e["pinned"]["ms_per_call"] * 1e-3) / 1e9, 1),
+                "note": "never `value`: the device-resident column is the headline (inputs in HBM when the clock starts)"})
+    del pl_, pr_, po_
     # (3) SGM building block of config 4: 2048^2, census 7x7, 129 disparities, 8 paths, LC-blend sub-pixel
     n = 2048
     ls, rs_ = lt[:n, :n].contiguous(), rt[:n, :n + 128].contiguous()
@@ -363,11 +426,12 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right, with
         T = 4
         ctxs = [vwa.Context(lt.device.index) for _ in range(T)]
         streams = [torch.cuda.Stream(device=lt.device) for _ in range(T)]
+        outs = [None] * len(tiles)
         def work(t):
             with torch.cuda.stream(streams[t]):
                 for i in range(t, len(tiles), T):
-                    stereo.pyramid_correlate(lt, rc, None, None, pf, pw, search, (kk, kk), cost, consistency_threshold=2, filter_half_kernel=5,
-                                             max_pyramid_levels=5, bbox=tiles[i], ctx=ctxs[t])
+                    outs[i] = stereo.pyramid_correlate(lt, rc, None, None, pf, pw, search, (kk, kk), cost, consistency_threshold=2, filter_half_kernel=5,
+                                                       max_pyramid_levels=5, bbox=tiles[i], ctx=ctxs[t])
         best = None
         for rep in range(7):                                   # one warm-up pass, then the fastest of six (a pass is 10 - 40 ms: host noise shows)
             torch.cuda.synchronize(lt.device); t0 = time.perf_counter()
@@ -378,15 +442,25 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right, with
         for c_ in ctxs: c_.close()
         nl = [1024 * 1024 / 4 ** l for l in range(6)]
         tile_bytes = 2 * (4.0 / 3.0) * 5 * nl[0] + sum((20 + 24) * n for n in nl) + 20 * nl[0]       # the config-5 byte model (run_config5)
-        cb = None
+        cb = ident = None
         if with_cpu:
+            # the oracle leg is also the checker: every tile it computes is compared with the tile of the LAST timed pass, pixel for pixel
+            kept = {}
             cb = cpu_baseline_pyramid(left, np.ascontiguousarray(right[:, 64:64 + W]), [dict(name="bm", pf=pf, pfw=pw, kernel=(kk, kk), cost=cost, alg=0)],
-                                      (-64, -1, 65, 2), 5, budget_s=4.0)["bm"]
+                                      (-64, -1, 64, 1), 5, budget_s=4.0, keep=kept)["bm"]
+            same = 0
+            for (_, bbt), want in kept.items():
+                i = next(k for k, tb in enumerate(tiles) if (tb.min[0], tb.min[1]) == (bbt[0], bbt[1]))
+                same += int(np.array_equal(outs[i].cpu().numpy(), want))
+            ident = "%d / %d" % (same, len(kept))
+            assert same == len(kept), "tile loop (%s): %s tiles identical to the oracle" % (label, ident)
+        del outs
         out.append({"name": "config 5 building block: pyramid_correlate tile loop, 4096^2 in 16 tiles of 1024^2, %s, +-64 x +-1, 5 levels, L/R check, "
                             "4 tile threads" % label, "wall_ms_per_pair": round(best * 1e3, 2), "ms_per_tile": round(best * 1e3 / len(tiles), 3),
                     "Mpix_per_s": round(W * H / best / 1e6, 1), "algorithmic_bytes": int(tile_bytes * len(tiles)),
                     "bytes_model": "SURVEY 8d summed over the levels of a tile (pyramid build + BM bytes per level, level 0 twice + clean-up chain)",
                     "roofline_frac": round(tile_bytes * len(tiles) / best / 1e9 / HBM_PEAK_GBS, 5), "cpu_baseline": cb,
+                    "tiles_identical_to_oracle": ident,
                     "note": "throughput of the threaded tile loop (launch / latency bound, not byte bound); per-kernel times of one tile: tools/pyr_profile.py"})
     return out
 

@@ -81,7 +81,7 @@ def _run(ctx, oracle, left, right, pf, pfw, kernel, cost, names, min_share):
         assert np.array_equal(g0, w), (n, "exact-order schedule", int((g0 != w).any(-1).sum()))
         assert np.array_equal(g1, w), (n, "certified schedule", int((g1 != w).any(-1).sum()))
         # the certificate engaged (share == -1: no level of the tile was certified at all) and proved most of the tile
-        assert share >= min_share, (n, "certified share (per mille)", share)
+        assert share >= min_share or (min_share is None and share == -1), (n, "certified share (per mille)", share)
 
 
 @pytest.mark.parametrize("name", list(TILES))
@@ -92,8 +92,9 @@ def test_log_ncc_tiles_of_the_bench_pair(ctx, oracle, pair, name):
 
 @pytest.mark.parametrize("cost,kernel", [(0, (7, 7)), (1, (7, 7))])
 def test_float_texture_tiles(ctx, oracle, float_pair, cost, kernel):
-    """The same three kinds of tile on a float texture (non-integer left / right, no prefilter) with SAD and SSD."""
-    _run(ctx, oracle, float_pair[0], float_pair[1], 0, 0.0, kernel, cost, ["interior", "left border", "corner"], 900)
+    """The same three kinds of tile on a float texture (non-integer left / right, no prefilter) with SAD and SSD.  (SAD: 31 significant bits
+    per pixel + 6 for the 49 addends fit float64 — the level is order free, nothing to certify, the share reads -1; SSD squares them.)"""
+    _run(ctx, oracle, float_pair[0], float_pair[1], 0, 0.0, kernel, cost, ["interior", "left border", "corner"], None if cost == 0 else 900)
 
 
 def test_float_texture_ncc_meansub_tile(ctx, oracle, float_pair):
