@@ -67,9 +67,14 @@ typedef enum vwgpu_path {
   VWGPU_PATH_EXACT_ORDER = 4,  /* inputs whose box sums round: the reference's serial summation order     */
   VWGPU_PATH_SAD_U16 = 5,      /* integer-valued inputs in [0,65535]: SAD on v_sad_u16 pixel pairs        */
   VWGPU_PATH_DOT_U16 = 6,      /* integer-valued inputs in [0,4095]: SSD / NCC on v_dot2_u32_u16          */
-  VWGPU_PATH_REFUSED = 7       /* vwgpu_last_path only: a packed kernel queued WITHOUT waiting for its verdict
+  VWGPU_PATH_REFUSED = 7,      /* vwgpu_last_path only: a packed kernel queued WITHOUT waiting for its verdict
                                   (vwgpu_force_path, VWGPU_OPT_DEFER_EXACTNESS) met input outside its domain; that
                                   call produced NO result — repeat it with automatic dispatch                   */
+  VWGPU_PATH_CERTIFIED = 8     /* vwgpu_last_path only: inputs whose box sums round, matched by the tile-parallel
+                                  kernels with every pixel PROVEN equal to the reference's serial summation order
+                                  (winner ahead of the runner-up by more than twice a bound on the difference of the
+                                  two orders); a call with a pixel that cannot be proven is redone in the reference's
+                                  order and reports VWGPU_PATH_EXACT_ORDER.  VWGPU_OPT_CERTIFY = 0 turns it off      */
 } vwgpu_path;
 
 /* ---- context ------------------------------------------------------------------------------------- */

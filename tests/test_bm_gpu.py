@@ -167,7 +167,7 @@ def test_non_integer_input_falls_back_to_generic(ctx, oracle):
     left = synth.noise_f32(41, 48, 120, 0.0, 1.0)
     right = np.concatenate([synth.noise_f32(42, 48, 8), left, synth.noise_f32(43, 48, 8)], axis=1)
     got, path = _gpu(ctx, ABS, left, right, (7, 7), (17, 1))
-    assert path in (core.PATH_GENERIC_F64, core.PATH_EXACT_ORDER)
+    assert path in (core.PATH_GENERIC_F64, core.PATH_EXACT_ORDER, core.PATH_CERTIFIED)
     want = oracle.calc_disparity(ABS, left, right, (7, 7), (17, 1))
     assert (got[..., 0] == 8).mean() > 0.99
     assert np.array_equal(got, want)
@@ -176,7 +176,7 @@ def test_non_integer_input_falls_back_to_generic(ctx, oracle):
         l2, r2, _ = synth.stereo_pair(64, 24, 9)
         l2[3, 5] = bad
         g2, p = _gpu(ctx, ABS, l2, r2, (5, 5), (9, 1))
-        assert p in (core.PATH_GENERIC_F64, core.PATH_EXACT_ORDER) or (bad == 256.0 and p == core.PATH_SAD_U16)
+        assert p in (core.PATH_GENERIC_F64, core.PATH_EXACT_ORDER, core.PATH_CERTIFIED) or (bad == 256.0 and p == core.PATH_SAD_U16)
         assert np.array_equal(g2, oracle.calc_disparity(ABS, l2, r2, (5, 5), (9, 1)))
 
 
@@ -509,7 +509,7 @@ def test_u12_corr_path_bit_exact(ctx, oracle, cost, w, h, kernel, sx):
     # fractional pixels: not this path either
     left[5, 7] = 100.5
     got, path = _gpu(ctx, cost, left, right, kernel, (sx, 1))
-    assert path in (core.PATH_GENERIC_F64, core.PATH_EXACT_ORDER)
+    assert path in (core.PATH_GENERIC_F64, core.PATH_EXACT_ORDER, core.PATH_CERTIFIED)
     assert np.array_equal(got, oracle.calc_disparity(cost, left, right, kernel, (sx, 1)))
 
 

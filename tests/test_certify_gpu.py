@@ -119,3 +119,72 @@ def test_search_across_the_image_borders(ctx, oracle, case):
         lm = np.full((H, W), 255, np.uint8); lm[20:60, :25] = 0
         rm = np.full((H, W), 255, np.uint8); rm[:, -18:] = 0; rm[100:130, 5:40] = 0
     _both(ctx, oracle, left, right, lm, rm, pf, pfw, search, kernel, cost, thr, filt, levels)
+
+
+# ---- single-level calc_disparity (round 5): the whole raster as the one zone of the certified pass (csrc/vwgpu_abi.hip) -----------------
+
+def _float_scene(rng, h, w, sx, sy, decades=0.0):
+    """Non-integer left / right rasters with a shifted copy + independent noise, magnitudes over `decades` powers of ten."""
+    base = rng.random((h + sy - 1, w + sx - 1)) * 200.0
+    if decades:
+        base = base * 10.0 ** (rng.random(base.shape) * decades - decades / 2)
+    right = base.astype(np.float32)
+    d = (int(rng.integers(0, sx)), int(rng.integers(0, sy)))
+    left = (right[d[1]:d[1] + h, d[0]:d[0] + w] + rng.random((h, w)).astype(np.float32) * np.float32(0.5)).astype(np.float32)
+    return left, right
+
+
+@pytest.mark.parametrize("cost,kernel,search", [(0, (7, 7), (33, 1)), (1, (7, 7), (40, 3)), (2, (11, 11), (65, 1)), (1, (5, 9), (9, 9)), (2, (3, 3), (20, 2))])
+def test_single_level_float_raster_is_certified(ctx, oracle, cost, kernel, search):
+    """calc_disparity on a float raster whose box sums round: served by the certified tile-parallel pass (VWGPU_PATH_CERTIFIED), identical
+    to the oracle's whole-raster running sums; the same call with VWGPU_OPT_CERTIFY = 0 goes to the exact-order kernels: same image."""
+    import torch
+    rng = np.random.default_rng(7000 + cost * 10 + kernel[0])
+    left, right = _float_scene(rng, 150, 260, search[0], search[1], decades=3.0)
+    want = oracle.calc_disparity(cost, left, right, kernel, search)
+    got = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), search, kernel, ctx=ctx)
+    path = ctx.last_path()
+    assert np.array_equal(got, want), (path, int((got != want).any(-1).sum()))
+    assert path in (core.PATH_CERTIFIED, core.PATH_GENERIC_F64), path          # (GENERIC_F64: the data happened to be order free)
+    ctx.set_option(core.OPT_CERTIFY, 0)
+    try:
+        got0 = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), search, kernel, ctx=ctx)
+        assert ctx.last_path() in (core.PATH_EXACT_ORDER, core.PATH_GENERIC_F64)
+    finally:
+        ctx.set_option(core.OPT_CERTIFY, 1)
+    assert np.array_equal(got0, want)
+    # a region of a larger device image (row strides != widths), as vw::stereo::calc_disparity crops its inputs (Correlation.cc:353-359)
+    big_l = torch.zeros((left.shape[0] + 9, left.shape[1] + 13), dtype=torch.float32, device="cuda")
+    big_r = torch.zeros((right.shape[0] + 9, right.shape[1] + 13 + 5), dtype=torch.float32, device="cuda")
+    big_l[4:4 + left.shape[0], 6:6 + left.shape[1]] = torch.from_numpy(left).cuda()
+    big_r[4:4 + right.shape[0], 6:6 + right.shape[1]] = torch.from_numpy(right).cuda()
+    got_d = stereo.calc_disparity(cost, big_l, big_r, BBox2i(6, 4, left.shape[1], left.shape[0]), search, kernel, ctx=ctx)
+    torch.cuda.synchronize()
+    assert np.array_equal(got_d.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("cost", [0, 1, 2])
+def test_single_level_exact_ties_fall_back_to_the_reference_order(ctx, oracle, cost):
+    """A flat patch inside a float texture: inside it every disparity has the same cost in exact arithmetic and the running sums' rounding
+    residue decides — no certificate exists, the call must be redone in the reference's order (VWGPU_PATH_EXACT_ORDER) and match."""
+    rng = np.random.default_rng(7100 + cost)
+    left, right = _float_scene(rng, 120, 200, 17, 1, decades=6.0)
+    left[40:80, 60:140] = np.float32(3.3)
+    right[40:80, 50:170] = np.float32(3.3)
+    want = oracle.calc_disparity(cost, left, right, (7, 7), (17, 1))
+    got = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), (17, 1), (7, 7), ctx=ctx)
+    assert ctx.last_path() == core.PATH_EXACT_ORDER
+    assert np.array_equal(got, want), int((got != want).any(-1).sum())
+
+
+def test_single_level_order_free_float_raster(ctx, oracle):
+    """Order-free float data (here: quarter-integers) takes the tile-parallel kernels without a certificate — any order returns the bits."""
+    rng = np.random.default_rng(7200)
+    right = (np.floor(rng.random((100, 300)) * 1024) / 4).astype(np.float32)
+    left = right[:, 11:11 + 240].copy()
+    left[30:50, 100:130] += np.float32(0.25)
+    for cost, kernel in ((0, (7, 7)), (1, (9, 5)), (2, (11, 11))):
+        want = oracle.calc_disparity(cost, left, right, kernel, (61, 1))
+        got = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), (61, 1), kernel, ctx=ctx)
+        assert ctx.last_path() == core.PATH_GENERIC_F64
+        assert np.array_equal(got, want), (cost, int((got != want).any(-1).sum()))

@@ -22,13 +22,17 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(autouse=True, params=["split", "fused", "tiled"])
+@pytest.fixture(autouse=True, params=["split", "fused", "tiled", "certified"])
 def _default_options(request, ctx):
     """Every test of this module runs with all three forms of pass 2 (OPT_EXACT_SPLIT: the recurrence alone + a parallel selection, the
-    fused kernel, and the tiled kernel that transposes a row's sums through LDS).  Variant-pinning options (same results, other
-    kernels / schedules) never leak from one test into the next."""
-    ctx.set_option(core.OPT_EXACT_SPLIT, {"split": 1, "fused": 2, "tiled": 3}[request.param])
+    fused kernel, and the tiled kernel that transposes a row's sums through LDS) with VWGPU_OPT_CERTIFY off — every call on rounding data
+    goes to the exact-order kernels — and once more with the default dispatch: the certified tile-parallel pass first
+    (VWGPU_PATH_CERTIFIED), the exact-order kernels only for calls with an unproven pixel.  Variant-pinning options (same results,
+    other kernels / schedules) never leak from one test into the next."""
+    ctx.set_option(core.OPT_EXACT_SPLIT, {"split": 1, "fused": 2, "tiled": 3, "certified": 0}[request.param])
+    ctx.set_option(core.OPT_CERTIFY, 1 if request.param == "certified" else 0)
     yield
+    ctx.set_option(core.OPT_CERTIFY, 1)
     ctx.set_option(core.OPT_EXACT_SPLIT, 0)
     ctx.set_option(core.OPT_SAD_GROUPS, 0)
     ctx.set_option(core.OPT_EXACT_SCRATCH_MB, 4096)
@@ -99,7 +103,7 @@ def test_calc_disparity_in_reference_order(ctx, oracle, cost, h, w, kernel, sear
     left, right = _pair(rng, h, w, search[0], search[1], shift, decades=14)
     want = oracle.calc_disparity(cost, left, right, kernel, search)
     got = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), search, kernel, ctx=ctx)
-    assert ctx.last_path() == core.PATH_EXACT_ORDER
+    assert ctx.last_path() in (core.PATH_EXACT_ORDER, core.PATH_CERTIFIED)
     assert np.array_equal(got, want), int((got != want).any(-1).sum())
     got_d = stereo.calc_disparity(cost, torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda(), vwa.bounding_box(left), search, kernel, ctx=ctx)
     assert np.array_equal(got_d.cpu().numpy(), want)
@@ -119,7 +123,7 @@ def test_order_free_floats_keep_the_fast_kernels(ctx, oracle):
     right = np.concatenate([synth.noise_f32(42, 48, 8), left, synth.noise_f32(43, 48, 8)], axis=1)
     for cost in (ABS, SQ, NCC):
         got = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), (17, 1), (7, 7), ctx=ctx)
-        assert ctx.last_path() in (core.PATH_GENERIC_F64, core.PATH_EXACT_ORDER)
+        assert ctx.last_path() in (core.PATH_GENERIC_F64, core.PATH_EXACT_ORDER, core.PATH_CERTIFIED)
         assert np.array_equal(got, oracle.calc_disparity(cost, left, right, (7, 7), (17, 1)))
     i16 = np.floor(synth.noise_f32(44, 40, 100, 0.0, 32767.0)).astype(np.float32)
     r16 = np.concatenate([i16[:, 5:], np.floor(synth.noise_f32(45, 40, 21, 0.0, 32767.0))], axis=1).astype(np.float32)
@@ -172,7 +176,7 @@ def test_search_volumes_beyond_512_disparities(ctx, oracle, cost, h, w, kernel, 
     want = oracle.calc_disparity(cost, left, right, kernel, search)
     got = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), search, kernel, ctx=ctx)
     # (LoG + SAD of 8-bit imagery is order free — every partial sum fits 53 bits — and may take the tile kernel: same bits)
-    assert ctx.last_path() == core.PATH_EXACT_ORDER or (log and cost == ABS and ctx.last_path() == core.PATH_GENERIC_F64)
+    assert ctx.last_path() in (core.PATH_EXACT_ORDER, core.PATH_CERTIFIED) or (log and cost == ABS and ctx.last_path() == core.PATH_GENERIC_F64)
     assert np.array_equal(got, want), int((got != want).any(-1).sum())
     ctx.force_path(core.PATH_EXACT_ORDER)
     try:
@@ -219,7 +223,7 @@ def test_search_volume_beyond_65535(ctx, oracle):
     left2, right2 = left + np.float32(0.1), right + np.float32(0.1)      # not order free: disparity groups
     want = oracle.calc_disparity(SQ, left2, right2, (3, 3), search)
     got = stereo.calc_disparity(SQ, left2, right2, vwa.bounding_box(left2), search, (3, 3), ctx=ctx)
-    assert ctx.last_path() == core.PATH_EXACT_ORDER
+    assert ctx.last_path() in (core.PATH_EXACT_ORDER, core.PATH_CERTIFIED)
     assert np.array_equal(got, want)
 
 
@@ -234,6 +238,7 @@ def test_table_ring_wraps_while_the_device_is_behind(oracle):
     c = vwa.Context(0)
     try:
         c.set_option(core.OPT_HOST_RING_KB, 64)
+        c.set_option(core.OPT_CERTIFY, 0)                                # (the exact-order kernels are what queues the tables)
         got = stereo.calc_disparity(NCC, left, right, vwa.bounding_box(left), search, (5, 5), ctx=c)
         assert c.last_path() == core.PATH_EXACT_ORDER
         wraps = c.get_option(core.OPT_HOST_RING_WRAPS)
@@ -277,7 +282,7 @@ def test_whole_raster_in_row_bands(ctx, oracle, monkeypatch):
     left, right = _pair(rng, 300, 500, 33, 1, (16, 0), decades=12)
     want = oracle.calc_disparity(SQ, left, right, (7, 7), (33, 1))
     got = stereo.calc_disparity(SQ, left, right, vwa.bounding_box(left), (33, 1), (7, 7), ctx=ctx)
-    assert ctx.last_path() == core.PATH_EXACT_ORDER
+    assert ctx.last_path() in (core.PATH_EXACT_ORDER, core.PATH_CERTIFIED)
     assert np.array_equal(got, want)
 
 

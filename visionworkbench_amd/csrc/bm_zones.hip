@@ -84,7 +84,7 @@ struct PrecView {           // 1 / box-sum(img^2) over origins [x0, x0+w) x [y0,
 // through the L1: 0.3 ms per 1024^2 NCC tile).  Used on data whose box sums are exact in any order (vwgpu_sums_order_free) and, as
 // sqrt(1 / S) (root != 0), by the certified pass, whose error bound covers the order of the sums (root == 2, the passes with the "cannot
 // matter" certificate, additionally turns the infinite precision of an all-zero window into NaN for EVERY pixel of the pass, see below).
-struct ZPrecJob { const float* img; int w, h; double* prec; int x0, y0, pw, ph; };
+struct ZPrecJob { const float* img; int w, h; ptrdiff_t pitch; double* prec; int x0, y0, pw, ph; };
 struct ZPrecJobs { ZPrecJob j[2]; };           // blockIdx.z: the left and the right image of a pass in one launch
 __global__ void __launch_bounds__(256)
 zone_precision_kernel(ZPrecJobs jobs, int kx, int ky, int root) {
@@ -93,6 +93,7 @@ zone_precision_kernel(ZPrecJobs jobs, int kx, int ky, int root) {
   const float* __restrict__ img = J.img;
   double* __restrict__ prec = J.prec;
   const int w = J.w, h = J.h, x0 = J.x0, y0 = J.y0, pw = J.pw, ph = J.ph;
+  const ptrdiff_t pitch = J.pitch;
   if ((int)blockIdx.x * 64 >= pw || (int)blockIdx.y * 4 >= ph) return;
   const int tw = 64 + kx - 1, th = 4 + ky - 1;
   double* sq = zp_sm;                 // th x tw squares
@@ -103,7 +104,7 @@ zone_precision_kernel(ZPrecJobs jobs, int kx, int ky, int root) {
     const int r = i / tw, c = i - r * tw;
     int xx = x0 + bx + c; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
     int yy = y0 + by + r; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
-    const float v = img[(size_t)yy * w + xx];
+    const float v = img[(ptrdiff_t)yy * pitch + xx];
     sq[i] = (double)(v * v);
   }
   __syncthreads();
@@ -267,7 +268,7 @@ __device__ __forceinline__ void zwindow_sums(const ACC* e, ACC* w) {
 // CERT: track the runner-up (and the largest right precision) and certify / flag, see the file header.
 template <int COST, int KS, typename ACC, bool CERT, int ZS, bool EDGE = false>
 __global__ void __launch_bounds__(ZS * ZS / 4, 4)
-bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __restrict__ B, int bw, int bh,
+bm_zones_kernel(const float* __restrict__ A, int aw, int ah, int ap, const float* __restrict__ B, int bw, int bh, int bp,
                 int kx, int ky, const vwgpu_zone_task* __restrict__ zones, const ZItem* __restrict__ items,
                 int sxc, PrecView pa, PrecView pb, int32_t* __restrict__ out, ZPart P, ZCertArgs C) {
   extern __shared__ char smem[];
@@ -309,7 +310,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
       int xx = z.ax + ox + q; xx = xx < 0 ? 0 : (xx >= aw ? aw - 1 : xx);
       for (int r = r0; r < ph; r += SROWS) {
         int yy = z.ay + oy + r; yy = yy < 0 ? 0 : (yy >= ah ? ah - 1 : yy);
-        Lp[r * PW + q] = A[(size_t)yy * aw + xx];
+        Lp[r * PW + q] = A[(size_t)yy * ap + xx];
       }
     }
   }
@@ -348,7 +349,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, const float* __rest
         int xx = z.bx + ox + dx0 + q; xx = xx < 0 ? 0 : (xx >= bw ? bw - 1 : xx);
         for (int r = r0; r < ph; r += SROWS) {
           int yy = z.by + oy + dy + r; yy = yy < 0 ? 0 : (yy >= bh ? bh - 1 : yy);
-          Rp[r * RW + q] = B[(size_t)yy * bw + xx];
+          Rp[r * RW + q] = B[(size_t)yy * bp + xx];
         }
       }
     }
@@ -903,8 +904,12 @@ size_t zones_lds_fixed(int zs, int kx, int ky, size_t accb) { return (size_t)(zs
 int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
                           int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out, int f32_sums, int cert_hi, int* d_zflag,
                           unsigned long long* d_stats, int* d_any, const int* d_need, const unsigned char* d_cells,
-                          int edge_m, int edge_k, int edge_lo, int edge_hi) {
+                          int edge_m, int edge_k, int edge_lo, int edge_hi, ptrdiff_t as, ptrdiff_t bs) {
   const bool cert = cert_hi != INT_MIN;
+  if (as == 0) as = aw;
+  if (bs == 0) bs = bw;
+  if (as > INT32_MAX || bs > INT32_MAX) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "bm_zones: row stride too large");
+  const int ap = (int)as, bp = (int)bs;
   if (cost_type == VWGPU_CROSS_CORRELATION || cert) f32_sums = 0;        // (NCC sums are scaled in float64 anyway)
   const size_t accb = f32_sums ? 4 : 8;
   if (n <= 0) return VWGPU_OK;
@@ -1042,8 +1047,8 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     vwgpu_prof_scope ps(ctx, "zone_precision");
     const size_t zp_lds = ((size_t)(64 + kx - 1) * (4 + ky - 1) + (size_t)(4 + ky - 1) * 64) * sizeof(double);
     ZPrecJobs zj;
-    zj.j[0] = ZPrecJob{A, aw, ah, da, pa.x0, pa.y0, pa.w, pa.h};
-    zj.j[1] = ZPrecJob{B, bw, bh, db, pb.x0, pb.y0, pb.w, pb.h};
+    zj.j[0] = ZPrecJob{A, aw, ah, ap, da, pa.x0, pa.y0, pa.w, pa.h};
+    zj.j[1] = ZPrecJob{B, bw, bh, bp, db, pb.x0, pb.y0, pb.w, pb.h};
     hipLaunchKernelGGL(zone_precision_kernel, dim3((std::max(pa.w, pb.w) + 63) / 64, (std::max(pa.h, pb.h) + 3) / 4, 2), dim3(64, 4), zp_lds, ctx->stream, zj, kx, ky, cert ? (edge ? 2 : 1) : 0);
     pa.p = da; pb.p = db;
   }
@@ -1100,7 +1105,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
   }
   ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats, d_any, d_need, d_cells, edge_m, edge_k, edge_lo, edge_hi};
 
-#define VW_ZN5(C_, K_, A_, T_, S_, E_) hipLaunchKernelGGL((bm_zones_kernel<C_, K_, A_, T_, S_, E_>), grd, dim3(S_ * S_ / 4), pl.lds, ctx->stream, A, aw, ah, B, bw, bh, kx, ky, dz, tab, pl.sxc, pa, pb, out, pl.P, C)
+#define VW_ZN5(C_, K_, A_, T_, S_, E_) hipLaunchKernelGGL((bm_zones_kernel<C_, K_, A_, T_, S_, E_>), grd, dim3(S_ * S_ / 4), pl.lds, ctx->stream, A, aw, ah, ap, B, bw, bh, bp, kx, ky, dz, tab, pl.sxc, pa, pb, out, pl.P, C)
 #define VW_ZN4(C_, K_, A_, T_, S_) do { if (T_ && edge) VW_ZN5(C_, K_, A_, T_, S_, T_); else VW_ZN5(C_, K_, A_, T_, S_, false); } while (0)
 #ifdef VWGPU_ZONES16
 #define VW_ZN3(C_, K_, A_, T_) do { if (pl.zs == 32) VW_ZN4(C_, K_, A_, T_, 32); else VW_ZN4(C_, K_, A_, T_, 16); } while (0)

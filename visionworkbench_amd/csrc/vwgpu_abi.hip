@@ -363,10 +363,12 @@ static int calc_disparity_classified(vwgpu_ctx* ctx, int cost_type, const float*
                                      int32_t* d_out, ptrdiff_t os, Grain gr = Grain()) {
   bool exact = ctx->forced_path == VWGPU_PATH_EXACT_ORDER;
   ctx->last_flag = nullptr;
+  int g_lo = INT_MAX, g_hi = INT_MIN, g_nonfinite = 1;
   if (ctx->forced_path == VWGPU_PATH_NONE) {
     int lo = gr.lo, hi = gr.hi, nonfinite = gr.nonfinite;
     int rc = gr.known ? VWGPU_OK : vwgpu_float_grain(ctx, d_left, lw, lh, ls, d_right, lw + sx - 1, lh + sy - 1, rs, &lo, &hi, &nonfinite);
     if (rc) return rc;
+    g_lo = lo; g_hi = hi; g_nonfinite = nonfinite;
     exact = !vwgpu_sums_order_free(cost_type, kx, ky, lo, hi, nonfinite);      // never the tile-local sums on data whose roundings depend on the order
     // integers below 2^16 (16-bit imagery): the packed-u16 SAD kernel; it checks the sign itself and raises its flag
     if (!exact && !nonfinite && lo != INT_MAX && lo >= 0 && hi <= 15 && vwgpu_bm_sad_u16_supported(cost_type, kx, ky, sx, sy)) {   // (nonfinite bit 1 = negative pixels)
@@ -404,6 +406,43 @@ static int calc_disparity_classified(vwgpu_ctx* ctx, int cost_type, const float*
     ctx->last_path = VWGPU_PATH_SAD_U16;
     ctx->last_flag = d_flag;
     return rc;
+  }
+  // Float imagery outside the packed classes, automatic dispatch: the tile-parallel zone matcher (bm_zones.hip) with the whole raster as its
+  // one zone — the kernel family the pyramid levels run on, several times faster than bm_generic's column-sum tiles and than the
+  // exact-order passes.  Order-free data: any summation order returns the reference's bits.  Data whose sums round (finite, |pixel| <
+  // 2^60): the CERTIFIED pass — every pixel's winner must lead its runner-up by more than twice the bound on |tile-parallel sum -
+  // reference running sum| (chain lengths W + H of the whole raster); a single unproven pixel sends the call to the reference's order.
+  if (ctx->forced_path == VWGPU_PATH_NONE && vwgpu_bm_zones_supported(kx, ky) && lw - kx + 1 <= 65535 * 32 && lh - ky + 1 <= 65535 * 32 &&
+      os <= INT32_MAX && (long long)sx * sy <= INT32_MAX) {
+    vwgpu_zone_task z{0, 0, 0, 0, lw - kx + 1, lh - ky + 1, sx, sy, 0, (int)os, 0, 0};
+    const int rcw = lw + sx - 1, rch = lh + sy - 1;               // the part of the right raster the search can reach (no clamped reads)
+    if (!exact) {                                                  // (order free implies finite)
+      ctx->last_path = VWGPU_PATH_GENERIC_F64;
+      return vwgpu_launch_bm_zones(ctx, cost_type, d_left, lw, lh, d_right, rcw, rch, kx, ky, &z, 1, d_out,
+                                   vwgpu_sums_bits(cost_type, kx, ky, g_lo, g_hi, g_nonfinite) <= 24 ? 1 : 0, INT_MIN, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                   0, 0, 0, 0, ls, rs);
+    }
+    if (exact && ctx->certify && (g_nonfinite & 1) == 0 && g_lo != INT_MAX && g_hi < 60 && g_hi > -60 && vwgpu_bm_exact_supported(sx, sy)) {
+      int rc = vwgpu_arena_reserve(ctx, &ctx->misc, 256);
+      if (rc) return rc;
+      int* d_word = static_cast<int*>(ctx->misc.base);            // [0] any zone flagged, [1] the zone's flag
+      VWGPU_HIP(ctx, hipMemsetAsync(d_word, 0, 2 * sizeof(int), ctx->stream));
+      unsigned long long* d_stats = nullptr;
+      if (ctx->trace & 4) {
+        d_stats = reinterpret_cast<unsigned long long*>(d_word + 16);
+        VWGPU_HIP(ctx, hipMemsetAsync(d_stats, 0, 16, ctx->stream));
+      }
+      rc = vwgpu_launch_bm_zones(ctx, cost_type, d_left, lw, lh, d_right, rcw, rch, kx, ky, &z, 1, d_out, 0, g_hi, d_word + 1, d_stats, d_word, nullptr, nullptr,
+                                 0, 0, 0, 0, ls, rs);
+      if (rc) return rc;
+      int any = 0;
+      VWGPU_HIP(ctx, hipMemcpyAsync(&any, d_word, sizeof any, hipMemcpyDeviceToHost, ctx->stream));
+      unsigned long long got[2] = {0, 0};
+      if (d_stats) VWGPU_HIP(ctx, hipMemcpyAsync(got, d_stats, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
+      VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (d_stats) { ctx->cert_px[0] += got[0]; ctx->cert_px[1] += got[1]; }
+      if (!any) { ctx->last_path = VWGPU_PATH_CERTIFIED; return VWGPU_OK; }
+    }
   }
   if (exact) {
     if (!vwgpu_bm_exact_supported(sx, sy))

@@ -240,7 +240,8 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
                           int cert_hi = (-2147483647 - 1), int* d_zflag = nullptr, unsigned long long* d_stats = nullptr,
                           int* d_any = nullptr,       // d_any (optional, zeroed by the caller): set to 1 when some zone was flagged
                           const int* d_need = nullptr, const unsigned char* d_cells = nullptr,      // (optional) what to match of every zone, from vwgpu_launch_zone_need
-                          int edge_m = 0, int edge_k = 0, int edge_lo = 0, int edge_hi = 0);      // certified passes: edge_m > 0 turns the "cannot matter" certificate on (bm_zones.hip, ZEdge)
+                          int edge_m = 0, int edge_k = 0, int edge_lo = 0, int edge_hi = 0,      // certified passes: edge_m > 0 turns the "cannot matter" certificate on (bm_zones.hip, ZEdge)
+                          ptrdiff_t as = 0, ptrdiff_t bs = 0);                                     // row strides of A / B in floats (0: the widths)
 // The part of every zone's R->L image that its L/R check (vwgpu_launch_zone_lr, same tasks) will read, from the finished L->R result:
 // a rectangle per zone (d_need, 8 ints per zone) and a flag per 16 x 16 cell (d_cells; vwgpu_zone_need_cells numbers the cells into the
 // tasks' `ay` slot and returns their count).  d_zflag (optional): L->R zones still to be matched again ask for the whole image.
