@@ -134,6 +134,10 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *       0 = every zone of such a level goes to the exact-order kernels (the round-3 schedule).  Same results either way.
  *   VWGPU_OPT_ZONE_SXC         horizontal disparities per staged right patch: 0 (default) = 16, n = at most n (1 .. 4096; the LDS budget caps it).
  *   VWGPU_OPT_CERT_PERMILLE    (read only) per mille of the pixels in certified tiles since VWGPU_OPT_TRACE was last set with bit 2; -1 = none.
+ *   VWGPU_OPT_CERT_F32         1 (default): the certified pass is two tiers in one launch — float32 window sums and compare chain first,
+ *       proven against the reference's order AND their own float32 roundings; a 32 x 32 tile with a pixel that tier cannot prove runs again
+ *       in float64, and only what float64 cannot prove goes to the exact-order kernels.  0: float64 only (the round-4 schedule).  Same results.
+ *   VWGPU_OPT_CERT_F64_PERMILLE (read only) per mille of the counted pixels that lay in tiles the fp32 tier passed on to float64; -1 = none.
  *   VWGPU_OPT_SGM_SWEEP        SGM path aggregation of full-range one-row searches (<= 256 disparities): 0 = one direction per launch
  *       (default: eight passes over the u16 sums, bandwidth bound), 1 = two concurrent fused raster sweeps of four directions each
  *       (a fifth of the HBM traffic, the same sums; slower on MI355X because a sweep is W + 2 H dependent pixel steps), 2 .. 15 = the
@@ -152,7 +156,7 @@ typedef enum vwgpu_option {
   VWGPU_OPT_DEFER_EXACTNESS = 1, VWGPU_OPT_DEVICE_COUNT = 2, VWGPU_OPT_SAD_GROUPS = 3, VWGPU_OPT_EXACT_SCRATCH_MB = 4,
   VWGPU_OPT_TRACE = 5, VWGPU_OPT_SGM_SWEEP = 6, /* 7: removed in ABI 2 */ VWGPU_OPT_MGM_SWEEP = 8, VWGPU_OPT_EXACT_SPLIT = 9,
   /* 10: removed in ABI 2 */ VWGPU_OPT_HOST_RING_KB = 11, VWGPU_OPT_HOST_RING_WRAPS = 12, VWGPU_OPT_CERTIFY = 13,
-  VWGPU_OPT_CERT_PERMILLE = 14, VWGPU_OPT_ZONE_SXC = 15
+  VWGPU_OPT_CERT_PERMILLE = 14, VWGPU_OPT_ZONE_SXC = 15, VWGPU_OPT_CERT_F32 = 16, VWGPU_OPT_CERT_F64_PERMILLE = 17
 } vwgpu_option;
 int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value);
 int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value);

@@ -16,6 +16,7 @@ import os
 ctx.set_option(core.OPT_EXACT_SPLIT, int(os.environ.get("PYR_EXACT_SPLIT", "0")))      # tool-side switch
 ONLY = os.environ.get("PYR_ONLY", "")
 ctx.set_option(core.OPT_ZONE_SXC, int(os.environ.get("PYR_ZONE_SXC", "0")))
+ctx.set_option(core.OPT_CERT_F32, int(os.environ.get("PYR_CERT_F32", "1")))                 # 0: the certified pass in float64 only (round 4)
 TRACE = int(os.environ.get("PYR_TRACE", "0"))                     # 2: the shape of every level's work on stderr, 4: certification counts
 for pf, cost, k in cases:
     if ONLY and ONLY != "%d,%d,%d" % (pf, cost, k): continue

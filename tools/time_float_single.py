@@ -45,6 +45,10 @@ def run(label, cost, k, reps=3):
 
 for cost, k in ((0, 7), (1, 7), (2, 11)):
     a = run("default", cost, k)
+    ctx.set_option(core.OPT_CERT_F32, 0)
+    a64 = run("fp32 tier off", cost, k)
+    ctx.set_option(core.OPT_CERT_F32, 1)
+    assert torch.equal(a, a64)
     ctx.set_option(core.OPT_CERTIFY, 0)
     b = run("certify off", cost, k, reps=1)
     ctx.set_option(core.OPT_CERTIFY, 1)

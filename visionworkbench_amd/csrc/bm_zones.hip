@@ -75,8 +75,8 @@ __device__ __forceinline__ bool zbetter(double c, double q) {
   return COST == VWGPU_CROSS_CORRELATION ? (c > q) : (c < q);
 }
 
-struct PrecView {           // 1 / box-sum(img^2) over origins [x0, x0+w) x [y0, y0+h)
-  const double* p; int x0, y0, w, h;
+struct PrecView {           // 1 / box-sum(img^2) over origins [x0, x0+w) x [y0, y0+h); pf: the same image rounded to float32 (fp32 tier), or null
+  const double* p; int x0, y0, w, h; const float* pf;
 };
 
 // prec(x, y) = 1.0 / sum_{ky x kx} img(clamp)^2 for window origins (x0 + i, y0 + j).  A 64 x 4 output tile: the squares of its
@@ -84,7 +84,7 @@ struct PrecView {           // 1 / box-sum(img^2) over origins [x0, x0+w) x [y0,
 // through the L1: 0.3 ms per 1024^2 NCC tile).  Used on data whose box sums are exact in any order (vwgpu_sums_order_free) and, as
 // sqrt(1 / S) (root != 0), by the certified pass, whose error bound covers the order of the sums (root == 2, the passes with the "cannot
 // matter" certificate, additionally turns the infinite precision of an all-zero window into NaN for EVERY pixel of the pass, see below).
-struct ZPrecJob { const float* img; int w, h; ptrdiff_t pitch; double* prec; int x0, y0, pw, ph; };
+struct ZPrecJob { const float* img; int w, h; ptrdiff_t pitch; double* prec; int x0, y0, pw, ph; float* prec32; };
 struct ZPrecJobs { ZPrecJob j[2]; };           // blockIdx.z: the left and the right image of a pass in one launch
 __global__ void __launch_bounds__(256)
 zone_precision_kernel(ZPrecJobs jobs, int kx, int ky, int root) {
@@ -125,6 +125,7 @@ zone_precision_kernel(ZPrecJobs jobs, int kx, int ky, int root) {
   double pr = root ? sqrt(1.0 / s) : 1.0 / s;
   if (root == 2 && !(pr <= 1.7976931348623157e308)) pr = __builtin_nan("");
   prec[(size_t)j * pw + i] = pr;
+  if (J.prec32) J.prec32[(size_t)j * pw + i] = (float)pr;
 }
 
 // A work item: disparities [i0, i0 + n) (index = dy * sx + dx, the reference's loop order) of one 32 x 32 tile of one zone.
@@ -139,7 +140,7 @@ struct ZMergeItem { int zone, txy, slot0, nitems, gate, pad0, pad1, pad2; };
 // records of the partial slots, one plane of 1024 pixels per slot and field
 struct ZPart { double* best; double* worst; int* idx; double* second; double* rpmax; int* bad; int* redo; double* bnf; };
 // certification constants of a zone: bounds on |tile-parallel sum - reference running sum| (see vwgpu_launch_bm_zones)
-struct ZCert { double eps_s, eps_ll, eps_rr, pad; };
+struct ZCert { double eps_s, eps_ll, eps_rr, eps32; };      // eps32: bound on |float32 tile sum - exact sum| of the fp32 tier, see vwgpu_launch_bm_zones
 struct ZCertArgs { const ZCert* zc; int* zflag; unsigned long long* stats; int* any; const int* need; const unsigned char* cells;
                    int edge_m, edge_k, edge_lo, edge_hi; };     // zc == nullptr: no certification; any: "some zone was flagged"; edge_*: see ZEdge
 // The "cannot matter" certificate (EDGE kernels; edge_m > 0).  A candidate (pixel, disparity) whose partner lies edge_m or more columns
@@ -189,7 +190,16 @@ __device__ __forceinline__ bool ztile_geometry(const vwgpu_zone_task& z, int zon
 // the pixel (second = the best cost among the disparities other than the winner; equal costs => second == best).  A certified pixel with
 // D >= 2 is valid (best > second >= worst in the reference's arithmetic too), so the chain keeps no `worst`; D == 1 is invalid by
 // definition (best == worst in any arithmetic).
-template <int COST>
+// T32 (the fp32 tier): the window sums were formed in float32 — the SAME float cost elements as the reference's (CostFunctions.h:72-141
+// forms them in float), summed in another order AND another precision.  Two bounds on |float32 sum - exact sum|, u = 2^-24:
+//   absolute  zc.eps32 = 2 (2 K + 24) kx ky u E   (E bounds an element, K = max(kx, ky)): the sliding form of zwindow_sums subtracts, so an
+//             operation's rounding scales with the running value (<= kx ky E), not with the window it ends in; (2 K + 24) counts the
+//             operations on a result's path through both passes (initial K adds + 2 per slide step, the ky inherited row errors folded in);
+//   relative  REL32 (the tree form of zwindow_sums, no subtraction: KS >= 9 here): depth <= 22 additions on any element's path, so
+//             |error| <= 22 u sum|e|; SAD / SSD elements are >= 0 (sum|e| = the sum itself), NCC: sum|a b| <= sqrt(S_ll S_rr)
+//             (Cauchy-Schwarz) = 1 in cost units.  2^-18 = 64 u leaves a factor ~3; NCC adds the float32 roundings of the right factor and
+//             of the product (3 u) inside the same constant.
+template <int COST, bool T32 = false, bool REL32 = false>
 __device__ __forceinline__ bool zcertified(const ZCert& zc, int D, bool bad, double best, double second, double lprec, double rpmax) {
   if (bad) return false;                                     // a non-finite cost: the reference's chain is order dependent there
   if (D == 1) return true;
@@ -200,9 +210,19 @@ __device__ __forceinline__ bool zcertified(const ZCert& zc, int D, bool bad, dou
     const double dl = 2.0 * zc.eps_ll * lprec, dr = 2.0 * zc.eps_rr * rpmax;
     if (!(lprec > 0.0) || !(rpmax > 0.0) || !(dl <= 0x1p-10) || !(dr <= 0x1p-10)) return false;
     const double cmax = fmax(1.0 + 0x1p-20, fmax(fabs(best), fabs(second)));
-    eps = 2.0 * (cmax * (dl + dr + 0x1p-49) + zc.eps_s * sqrt(lprec * rpmax));      // 2^-49: the roundings of either way to the cost
+    double s32 = 0.0;                                        // the fp32 tier's own error, in cost units
+    if (T32) {
+      s32 = zc.eps32 * sqrt(lprec * rpmax) + 0x1p-21 * cmax;   // absolute form (+ 8 u: right factor and product in float32)
+      if (REL32) s32 = fmin(s32, 0x1p-18 * cmax);
+    }
+    eps = 2.0 * (cmax * (dl + dr + 0x1p-49) + zc.eps_s * sqrt(lprec * rpmax) + s32);      // 2^-49: the roundings of either way to the cost
   } else {
     eps = zc.eps_s;
+    if (T32) {
+      double s32 = zc.eps32;
+      if (REL32) s32 = fmin(s32, 0x1p-18 * fmax(fabs(best), fabs(second)));
+      eps += s32;
+    }
   }
   const double gap = COST == VWGPU_CROSS_CORRELATION ? best - second : second - best;
   return gap > 2.0 * eps;                                    // (false for NaN)
@@ -266,17 +286,31 @@ __device__ __forceinline__ void zwindow_sums(const ACC* e, ACC* w) {
 // bits as well (vwgpu_sums_bits <= 24: byte imagery under SAD) — then both give the same numbers, the LDS planes are half as large and the sums
 // full-rate.  The compare chain runs on doubles either way.
 // CERT: track the runner-up (and the largest right precision) and certify / flag, see the file header.
-template <int COST, int KS, typename ACC, bool CERT, int ZS, bool EDGE = false>
-__global__ void __launch_bounds__(ZS * ZS / 4, 4)
-bm_zones_kernel(const float* __restrict__ A, int aw, int ah, int ap, const float* __restrict__ B, int bw, int bh, int bp,
-                int kx, int ky, const vwgpu_zone_task* __restrict__ zones, const ZItem* __restrict__ items,
-                int sxc, PrecView pa, PrecView pb, int32_t* __restrict__ out, ZPart P, ZCertArgs C) {
-  extern __shared__ char smem[];
+// what every item of a launch shares
+struct ZLaunch {
+  const float* A; int aw, ah, ap; const float* B; int bw, bh, bp;
+  int kx, ky, sxc; PrecView pa, pb; int32_t* out; ZPart P; ZCertArgs C;
+};
+
+// One work item.  Returns (CERT, an item that finishes its tile): true when some pixel of the tile could not be certified — the caller
+// decides what happens then (the fp32 tier runs the item again in float64; the float64 tier flags the zone).  Every thread of the workgroup
+// runs this function; the value is per thread (fold it with __syncthreads_or).
+// ACC = float with CERT is the FP32 TIER (T32): window sums, compare chain and NCC right factors in float32 — simple float32
+// instructions issue at twice the rate of float64 ones (profiles/r04_ubench_valu.txt, r04_ubench_f64.txt) and the sum planes are half as
+// large — certified against BOTH the reference's summation order and its own float32 roundings (zcertified<T32>).
+template <int COST, int KS, typename ACC, bool CERT, int ZS, bool EDGE>
+__device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, const vwgpu_zone_task& z, const ZGeom& geom, char* smem) {
+  const float* __restrict__ A = G.A; const float* __restrict__ B = G.B;
+  const int aw = G.aw, ah = G.ah, ap = G.ap, bw = G.bw, bh = G.bh, bp = G.bp, kx = G.kx, ky = G.ky, sxc = G.sxc;
+  const PrecView pa = G.pa, pb = G.pb;
+  int32_t* __restrict__ out = G.out;
+  const ZPart& P = G.P; const ZCertArgs& C = G.C;
   // tile side, threads, columns per horizontal item (float64 sums: four — eight need 36 registers for the elements alone and cost a
   // resident workgroup per CU), items per row
   constexpr int ZT = ZS, ZTHREADS = ZS * ZS / 4, HW = 8, QL = ZS / HW;
-  const ZItem it = items[blockIdx.x];
-  if (it.gate >= 0 && P.redo[it.gate] == 0) return;               // redo launch: only the tiles the merge flagged
+  constexpr bool T32 = CERT && sizeof(ACC) == 4;
+  constexpr bool REL32 = T32 && KS >= 9;                          // the tree form of zwindow_sums in both passes (no subtraction), see zcertified
+  typedef typename std::conditional<T32, float, double>::type CT; // type of the compare chain and of the NCC right factors
 #ifdef VWGPU_TILE_STAMPS
   const int knock = gridDim.x > 2000 ? g_zone_knock : 0;
 #define ZKNOCK(bit) (knock & (bit))
@@ -293,9 +327,6 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, int ap, const float
   float* Rp = Lp + PH * PW;                                      // PH x RW
   ACC* H = reinterpret_cast<ACC*>(smem + (((size_t)(PH * PW + PH * RW) * 4 + 7) & ~size_t(7)));   // 2 x PH x HP
 
-  const vwgpu_zone_task z = zones[it.zone];
-  ZGeom geom;
-  if (!ztile_geometry<ZT>(z, it.zone, it.txy, C.need, C.cells, geom)) return;          // (workgroup-uniform)
   const int ox = geom.ox, oy = geom.oy, tw = geom.tw, th = geom.th;
   const int pw = tw + kx - 1, ph = th + ky - 1;
   const int t = threadIdx.x;
@@ -314,19 +345,20 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, int ap, const float
       }
     }
   }
-  double best[4], worst[4], lprec[4], second[4], rpmax[4];
+  CT best[4], worst[4], second[4], rpmax[4];
+  double lprec[4];
   int bidx[4];
   bool bad = false;
-  constexpr double kBestInit = COST == VWGPU_CROSS_CORRELATION ? -INFINITY : INFINITY;
+  constexpr CT kBestInit = COST == VWGPU_CROSS_CORRELATION ? -INFINITY : INFINITY;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    best[m] = worst[m] = 0.0; bidx[m] = 0; lprec[m] = 0.0; second[m] = 0.0; rpmax[m] = 0.0;
+    best[m] = worst[m] = 0; bidx[m] = 0; lprec[m] = 0.0; second[m] = 0; rpmax[m] = 0;
     if (CERT) { best[m] = second[m] = kBestInit; worst[m] = -kBestInit; }
     if (COST == VWGPU_CROSS_CORRELATION && c < tw && y0 + m < th)
       lprec[m] = pa.p[(size_t)(z.ay + oy + y0 + m - pa.y0) * pa.w + (z.ax + ox + c - pa.x0)];
   }
   bool fnan[4] = {false, false, false, false};                    // EDGE: the FIRST candidate of the search has a NaN cost (then it is the reference's winner)
-  double bnf[4];                                                  // EDGE: the best cost among the candidates that are not far (ZEdge)
+  CT bnf[4];                                                      // EDGE: the best cost among the candidates that are not far (ZEdge)
 #pragma unroll
   for (int m = 0; m < 4; ++m) bnf[m] = kBestInit;
   ACC bestA[4], worstA[4];                                        // the lean chain of the order-free SAD / SSD levels
@@ -362,21 +394,23 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, int ap, const float
     // run the chain on whatever their plane rows hold, and are dropped in the epilogue.  Fewer s_waitcnt or address instructions did
     // not pay the same way, see below.)
     const ZEdge edge{C.edge_lo, C.edge_hi, z.bx + ox + c + dx0 - C.edge_k};
-    const double* prow[4] = {pb.p, pb.p, pb.p, pb.p};
-    double rpn[4] = {0.0, 0.0, 0.0, 0.0};
+    const CT* pbase;
+    if constexpr (T32) pbase = pb.pf; else pbase = pb.p;
+    const CT* prow[4] = {pbase, pbase, pbase, pbase};
+    CT rpn[4] = {0, 0, 0, 0};
     if (COST == VWGPU_CROSS_CORRELATION) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const bool in = c < tw && y0 + m < th;
         const size_t off = (size_t)(z.by + oy + y0 + m + dy - pb.y0) * pb.w + (z.bx + ox + c + dx0 - pb.x0);
-        prow[m] = pb.p + (in ? off : 0);
+        prow[m] = pbase + (in ? off : 0);
       }
     }
     for (int d = 0; d < nd; ++d) {
       ACC* Hc = H + hb * (PH * HP);
       if (COST == VWGPU_CROSS_CORRELATION) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) rpn[m] = ZKNOCK(32) ? 0.0 : prow[m][d];      // (lanes without a pixel read pb.p[d]: d < nd <= z.sx <= pb.w, inside the precision image's first row)
+        for (int m = 0; m < 4; ++m) rpn[m] = ZKNOCK(32) ? (CT)0 : prow[m][d];      // (lanes without a pixel read pb.p[d]: d < nd <= z.sx <= pb.w, inside the precision image's first row)
       }
       if (KS > 0) {
         // HW adjacent columns per thread: KS + HW - 1 cost elements are formed once and the window slides (s' = s - e[j] + e[j + KS]).
@@ -475,7 +509,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, int ap, const float
             if (KS == 0) {
               for (int b = 0; b < ky; ++b) sa += Hc[(y + b) * HP + c];
             }
-            double s = (double)sa;
+            CT s = (CT)sa;
             if (CERT && ZKNOCK(8)) { best[m] += s; }
             else if (CERT) {
               // Certified pass: the chain of Correlation.cc:91-117 reduced to what a certificate needs — the minimum with its first index, the
@@ -484,14 +518,14 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, int ap, const float
               // evaluation, 20 before.  Non-finite costs: the level holds finite pixels below 2^60 (cert_hi), so S_lr is finite; an
               // infinite right factor shows in rpmax, an infinite cost in best — both end without a certificate.
               if (COST == VWGPU_CROSS_CORRELATION) {
-                const double rp = rpn[m];                                  // sqrt(1 / S_rr); the left factor scales the records afterwards
+                const CT rp = rpn[m];                                      // sqrt(1 / S_rr); the left factor scales the records afterwards
                 rpmax[m] = zmax_raw(rpmax[m], rp);
                 s *= rp;
               }
-              const bool cb = zbetter<COST>(s, best[m]);
+              const bool cb = COST == VWGPU_CROSS_CORRELATION ? (s > best[m]) : (s < best[m]);
               if (EDGE && di == 0) fnan[m] = !(s == s);           // (workgroup-uniform test: the first disparity of the search)
               if (EDGE) {
-                const double snf = nfar ? s : kBestInit;
+                const CT snf = nfar ? s : kBestInit;
                 bnf[m] = COST == VWGPU_CROSS_CORRELATION ? zmax_raw(bnf[m], snf) : zmin_raw(bnf[m], snf);
               }
               if (COST == VWGPU_CROSS_CORRELATION) {
@@ -510,7 +544,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, int ap, const float
               bestA[m] = zmin_raw(bestA[m], sa);
               worstA[m] = zmax_raw(worstA[m], sa);
               bidx[m] = cb ? div : bidx[m];
-            } else {
+            } else if constexpr (!T32) {
             if (COST == VWGPU_CROSS_CORRELATION) {
               const double rp = rpn[m];
               s *= sqrt(lprec[m] * rp);
@@ -547,7 +581,7 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, int ap, const float
 #endif
   if (LEAN) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) { best[m] = (double)bestA[m]; worst[m] = (double)worstA[m]; }
+    for (int m = 0; m < 4; ++m) { best[m] = (CT)bestA[m]; worst[m] = (CT)worstA[m]; }
   }
   if (it.slot >= 0) {                                           // one of several runs of this tile: leave the records to zones_merge_kernel
     const size_t base = (size_t)it.slot * (ZT * ZT);
@@ -557,19 +591,19 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, int ap, const float
         const int y = y0 + m;
         if (y < th) {
           const size_t o = base + (size_t)y * ZT + c;
-          P.best[o] = best[m]; P.idx[o] = (EDGE && fnan[m]) ? (bidx[m] | (int)0x80000000) : bidx[m];      // (bit 31: the run starts the search with a NaN)
+          P.best[o] = (double)best[m]; P.idx[o] = (EDGE && fnan[m]) ? (bidx[m] | (int)0x80000000) : bidx[m];      // (bit 31: the run starts the search with a NaN)
           if (CERT) {
-            P.second[o] = second[m]; if (COST == VWGPU_CROSS_CORRELATION) P.rpmax[o] = rpmax[m];
-            if (EDGE) P.bnf[o] = bnf[m];
-            bad = bad || !(fabs(best[m]) <= 1.7976931348623157e308);
+            P.second[o] = (double)second[m]; if (COST == VWGPU_CROSS_CORRELATION) P.rpmax[o] = (double)rpmax[m];
+            if (EDGE) P.bnf[o] = (double)bnf[m];
+            bad = bad || !(fabs((double)best[m]) <= 1.7976931348623157e308);
           } else {
-            P.worst[o] = worst[m];
+            P.worst[o] = (double)worst[m];
           }
         }
       }
     }
     if (__syncthreads_or(bad ? 1 : 0) && t == 0) P.bad[it.slot] = 1;     // (the slot flags are zeroed with the tables)
-    return;
+    return false;
   }
   bool uncert = false;
   if (c < tw) {
@@ -585,14 +619,15 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, int ap, const float
         if (CERT) {
           const bool ncc = COST == VWGPU_CROSS_CORRELATION;         // NCC: lprec / rpmax hold square roots of precisions here
           const double sl = ncc ? lprec[m] : 1.0;
+          const double bd = (double)best[m], sd = (double)second[m], rq = (double)rpmax[m], nfd = (double)bnf[m];
           o[2] = D == 1 ? 0 : 0x7fffffff;                           // (what a certificate implies; an uncertified zone is matched again)
-          const bool badpx = !(fabs(best[m]) <= 1.7976931348623157e308);
-          bool okpx = zcertified<COST>(C.zc[it.zone], D, badpx, best[m] * sl, second[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
+          const bool badpx = !(fabs(bd) <= 1.7976931348623157e308);
+          bool okpx = zcertified<COST, T32, REL32>(C.zc[it.zone], D, badpx, bd * sl, sd * sl, sl * sl, rq * rq);
           if (EDGE) {
             const ZEdge e1{C.edge_lo, C.edge_hi, z.bx + ox + c - C.edge_k};
             if (fnan[m]) okpx = !e1.notfar(0);                    // the reference's winner is candidate 0, whatever follows: fine iff that one is far
             else if (!okpx && !badpx && !e1.notfar(bx_))          // the best is far and ahead of everything that is not
-              okpx = bnf[m] == kBestInit || zcertified<COST>(C.zc[it.zone], D, false, best[m] * sl, bnf[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
+              okpx = bnf[m] == kBestInit || zcertified<COST, T32, REL32>(C.zc[it.zone], D, false, bd * sl, nfd * sl, sl * sl, rq * rq);
           }
           if (!okpx) uncert = true;
         } else {
@@ -601,17 +636,49 @@ bm_zones_kernel(const float* __restrict__ A, int aw, int ah, int ap, const float
       }
     }
   }
-  if (CERT) {
+  return uncert;
+}
+
+// T32: the certified pass as two tiers in ONE launch — every item runs in float32 first; a tile with a pixel the fp32 tier cannot prove
+// runs again in float64 (same workgroup, same LDS), and only what THAT cannot prove flags the zone for the reference's order.  (Cut tiles:
+// the runs leave float32 records, zones_merge_kernel<T32> certifies them and sends an unproven tile to the float64 redo launch.)
+template <int COST, int KS, typename ACC, bool CERT, int ZS, bool EDGE, bool T32>
+__global__ void __launch_bounds__(ZS * ZS / 4, 4)
+bm_zones_kernel(ZLaunch G, const vwgpu_zone_task* __restrict__ zones, const ZItem* __restrict__ items) {
+  extern __shared__ char smem[];
+  static_assert(!T32 || (CERT && sizeof(ACC) == 8), "T32 wraps the float64 certified kernel");
+  const ZItem it = items[blockIdx.x];
+  if (it.gate >= 0 && G.P.redo[it.gate] == 0) return;             // redo launch: only the tiles the merge flagged
+  const vwgpu_zone_task z = zones[it.zone];
+  ZGeom geom;
+  if (!ztile_geometry<ZS>(z, it.zone, it.txy, G.C.need, G.C.cells, geom)) return;          // (workgroup-uniform)
+  bool uncert;
+  int tier = 0;
+  if constexpr (T32) {
+    uncert = zmatch_item<COST, KS, float, true, ZS, EDGE>(G, it, z, geom, smem);
+    if (it.slot < 0 && __syncthreads_or(uncert ? 1 : 0)) {        // (__syncthreads_or is also the barrier between the two uses of the LDS)
+      tier = 1;
+      uncert = zmatch_item<COST, KS, double, true, ZS, EDGE>(G, it, z, geom, smem);
+    }
+  } else {
+    uncert = zmatch_item<COST, KS, ACC, CERT, ZS, EDGE>(G, it, z, geom, smem);
+  }
+  if (CERT && it.slot < 0) {
     const int any = __syncthreads_or(uncert ? 1 : 0);
-    if (t == 0) {
-      if (any) { C.zflag[it.zone] = 1; if (C.any) *C.any = 1; }
-      if (C.stats) { atomicAdd(&C.stats[any ? 1 : 0], (unsigned long long)(tw * th)); }
+    if (threadIdx.x == 0) {
+      if (any) { G.C.zflag[it.zone] = 1; if (G.C.any) *G.C.any = 1; }
+      if (G.C.stats) {
+        atomicAdd(&G.C.stats[any ? 1 : 0], (unsigned long long)(geom.tw * geom.th));
+        if (tier) atomicAdd(&G.C.stats[2], (unsigned long long)(geom.tw * geom.th));      // pixels of tiles the fp32 tier passed on
+      }
     }
   }
 }
 
 // Folds the runs of a tile in index order (see the file header): (value, first index) minimum, extremum, runner-up, largest right precision.
-template <int COST, bool CERT, int ZS>
+// T32: the records come from the fp32 tier — certified with its own error term (REL32 as in zmatch_item); a tile with an unproven pixel
+// goes to the float64 redo launch (P.redo) instead of flagging its zone.
+template <int COST, bool CERT, int ZS, bool T32 = false, bool REL32 = false>
 __global__ void __launch_bounds__(ZS * ZS / 4)
 zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* __restrict__ items, PrecView pa,
                    int32_t* __restrict__ out, ZPart P, ZCertArgs C) {
@@ -693,13 +760,13 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
         double lprec = 0.0;
         if (COST == VWGPU_CROSS_CORRELATION) lprec = pa.p[(size_t)(z.ay + oy + y - pa.y0) * pa.w + (z.ax + ox + c - pa.x0)];
         const double sl = COST == VWGPU_CROSS_CORRELATION ? lprec : 1.0;       // (square roots of precisions, as in bm_zones_kernel)
-        bool okpx = zcertified<COST>(C.zc[it.zone], D, bad, best[m] * sl, other[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
+        bool okpx = zcertified<COST, T32, REL32>(C.zc[it.zone], D, bad, best[m] * sl, other[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
         if (edge) {                                                // the "cannot matter" certificate, as in bm_zones_kernel
           constexpr double kInit = COST == VWGPU_CROSS_CORRELATION ? -INFINITY : INFINITY;
           const ZEdge e1{C.edge_lo, C.edge_hi, z.bx + ox + c - C.edge_k};
           if (fn[m]) okpx = !e1.notfar(0);
           else if (!okpx && !bad && fabs(best[m]) <= 1.7976931348623157e308 && !e1.notfar(bx_))
-            okpx = bnf[m] == kInit || zcertified<COST>(C.zc[it.zone], D, false, best[m] * sl, bnf[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
+            okpx = bnf[m] == kInit || zcertified<COST, T32, REL32>(C.zc[it.zone], D, false, best[m] * sl, bnf[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
         }
         if (!okpx) uncert = true;
       }
@@ -708,8 +775,13 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
   if (CERT) {
     const int any = __syncthreads_or(uncert ? 1 : 0);
     if (t == 0) {
-      if (any) { C.zflag[it.zone] = 1; if (C.any) *C.any = 1; }
-      if (C.stats) { atomicAdd(&C.stats[any ? 1 : 0], (unsigned long long)(tw * th)); }
+      if (T32) {
+        if (any) { P.redo[it.gate] = 1; if (C.stats) atomicAdd(&C.stats[2], (unsigned long long)(tw * th)); }      // the float64 redo launch decides (and counts) the tile
+        else if (C.stats) atomicAdd(&C.stats[0], (unsigned long long)(tw * th));
+      } else {
+        if (any) { C.zflag[it.zone] = 1; if (C.any) *C.any = 1; }
+        if (C.stats) { atomicAdd(&C.stats[any ? 1 : 0], (unsigned long long)(tw * th)); }
+      }
     }
   }
 }
@@ -906,6 +978,8 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
                           unsigned long long* d_stats, int* d_any, const int* d_need, const unsigned char* d_cells,
                           int edge_m, int edge_k, int edge_lo, int edge_hi, ptrdiff_t as, ptrdiff_t bs) {
   const bool cert = cert_hi != INT_MIN;
+  // the fp32 tier of the certified pass (VWGPU_OPT_CERT_F32, default on): compile-time square windows only
+  const bool t32 = cert && ctx->cert_f32 && kx == ky && kx >= 3 && kx <= 13;
   if (as == 0) as = aw;
   if (bs == 0) bs = bw;
   if (as > INT32_MAX || bs > INT32_MAX) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "bm_zones: row stride too large");
@@ -1017,7 +1091,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
   }
   if (plan[0].items.empty() && plan[1].items.empty()) return VWGPU_OK;
 
-  PrecView pa{nullptr, 0, 0, 0, 0}, pb{nullptr, 0, 0, 0, 0};
+  PrecView pa{nullptr, 0, 0, 0, 0, nullptr}, pb{nullptr, 0, 0, 0, 0, nullptr};
   // partial records of the cut tiles behind the precision images in the scratch arena
   // the "cannot matter" certificate (ZEdge) only where a zone of the pass has far candidates at all: its kernels cost 4 instructions per evaluation more
   bool edge = false;
@@ -1032,28 +1106,30 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
   const size_t rec_bytes = 8 + 8 + 4 + (cert ? 8 : 0) + (cert && ncc ? 8 : 0) + (edge ? 8 : 0);
   size_t part_bytes = 1024;
   for (ZPlan& pl : plan) part_bytes += vwgpu_align_up((size_t)pl.nslots * pl.zs * pl.zs * rec_bytes + 64, 256);
-  size_t na = 0, nb = 0;
+  size_t na = 0, nb = 0, nb32 = 0;
   if (ncc) {
     pa.x0 = ax0; pa.y0 = ay0; pa.w = ax1 - ax0; pa.h = ay1 - ay0;
     pb.x0 = bx0; pb.y0 = by0; pb.w = bx1 - bx0; pb.h = by1 - by0;
     na = vwgpu_align_up((size_t)pa.w * pa.h * 8, 256); nb = vwgpu_align_up((size_t)pb.w * pb.h * 8, 256);
+    if (t32) nb32 = vwgpu_align_up((size_t)pb.w * pb.h * 4, 256);      // the right factors once more in float32 (the chain of the fp32 tier reads them per evaluation)
   }
-  int rc = vwgpu_arena_reserve(ctx, &ctx->scratch, na + nb + part_bytes);
+  int rc = vwgpu_arena_reserve(ctx, &ctx->scratch, na + nb + nb32 + part_bytes);
   if (rc) return rc;
   char* sbase = static_cast<char*>(ctx->scratch.base);
   if (ncc) {
     double* da = reinterpret_cast<double*>(sbase);
     double* db = reinterpret_cast<double*>(sbase + na);
+    float* db32 = t32 ? reinterpret_cast<float*>(sbase + na + nb) : nullptr;
     vwgpu_prof_scope ps(ctx, "zone_precision");
     const size_t zp_lds = ((size_t)(64 + kx - 1) * (4 + ky - 1) + (size_t)(4 + ky - 1) * 64) * sizeof(double);
     ZPrecJobs zj;
-    zj.j[0] = ZPrecJob{A, aw, ah, ap, da, pa.x0, pa.y0, pa.w, pa.h};
-    zj.j[1] = ZPrecJob{B, bw, bh, bp, db, pb.x0, pb.y0, pb.w, pb.h};
+    zj.j[0] = ZPrecJob{A, aw, ah, ap, da, pa.x0, pa.y0, pa.w, pa.h, nullptr};
+    zj.j[1] = ZPrecJob{B, bw, bh, bp, db, pb.x0, pb.y0, pb.w, pb.h, db32};
     hipLaunchKernelGGL(zone_precision_kernel, dim3((std::max(pa.w, pb.w) + 63) / 64, (std::max(pa.h, pb.h) + 3) / 4, 2), dim3(64, 4), zp_lds, ctx->stream, zj, kx, ky, cert ? (edge ? 2 : 1) : 0);
-    pa.p = da; pb.p = db;
+    pa.p = da; pb.p = db; pb.pf = db32;
   }
   {
-    char* q = sbase + na + nb;
+    char* q = sbase + na + nb + nb32;
     for (ZPlan& pl : plan) {
       const size_t slot_px = (size_t)pl.nslots * pl.zs * pl.zs;
       char* q0 = q;
@@ -1079,7 +1155,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
       zc[i].eps_s = sum_error_units(kx, ky, z.zw, z.zh) * e_el;
       zc[i].eps_ll = zc[i].eps_s;
       zc[i].eps_rr = sum_error_units(kx, ky, z.zw + z.sx - 1, z.zh + z.sy - 1) * e_el;
-      zc[i].pad = 0.0;
+      zc[i].eps32 = 2.0 * (2.0 * std::max(kx, ky) + 24.0) * kx * ky * 0x1p-24 * e_el;      // the fp32 tier's absolute bound, see zcertified
     }
   }
   const void* src[8] = {zones, zc.data(), plan[0].items.data(), plan[0].merges.data(), plan[0].redo.data(),
@@ -1105,7 +1181,9 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
   }
   ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats, d_any, d_need, d_cells, edge_m, edge_k, edge_lo, edge_hi};
 
-#define VW_ZN5(C_, K_, A_, T_, S_, E_) hipLaunchKernelGGL((bm_zones_kernel<C_, K_, A_, T_, S_, E_>), grd, dim3(S_ * S_ / 4), pl.lds, ctx->stream, A, aw, ah, ap, B, bw, bh, bp, kx, ky, dz, tab, pl.sxc, pa, pb, out, pl.P, C)
+#define VW_ZN6(C_, K_, A_, T_, S_, E_, T32_) hipLaunchKernelGGL((bm_zones_kernel<C_, K_, A_, T_, S_, E_, T32_>), grd, dim3(S_ * S_ / 4), pl.lds, ctx->stream, \
+                                                               ZLaunch{A, aw, ah, ap, B, bw, bh, bp, kx, ky, pl.sxc, pa, pb, out, pl.P, C}, dz, tab)
+#define VW_ZN5(C_, K_, A_, T_, S_, E_) do { if (T_ && (K_) > 0 && use32) VW_ZN6(C_, K_, A_, T_, S_, E_, (T_ && (K_) > 0)); else VW_ZN6(C_, K_, A_, T_, S_, E_, false); } while (0)
 #define VW_ZN4(C_, K_, A_, T_, S_) do { if (T_ && edge) VW_ZN5(C_, K_, A_, T_, S_, T_); else VW_ZN5(C_, K_, A_, T_, S_, false); } while (0)
 #ifdef VWGPU_ZONES16
 #define VW_ZN3(C_, K_, A_, T_) do { if (pl.zs == 32) VW_ZN4(C_, K_, A_, T_, 32); else VW_ZN4(C_, K_, A_, T_, 16); } while (0)
@@ -1125,7 +1203,9 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
 #else
 #define VW_MG2(C_, T_) hipLaunchKernelGGL((zones_merge_kernel<C_, T_, 32>), mgrd, dim3(256), 0, ctx->stream, dz, pl.d_merges, pa, out, pl.P, C)
 #endif
-#define VW_MG(C_) do { if (cert) VW_MG2(C_, true); else VW_MG2(C_, false); } while (0)
+#define VW_MG32(C_, R_) hipLaunchKernelGGL((zones_merge_kernel<C_, true, 32, true, R_>), mgrd, dim3(256), 0, ctx->stream, dz, pl.d_merges, pa, out, pl.P, C)
+#define VW_MG(C_) do { if (t32 && kx >= 9) VW_MG32(C_, true); else if (t32) VW_MG32(C_, false); else if (cert) VW_MG2(C_, true); else VW_MG2(C_, false); } while (0)
+  bool use32 = t32;
   for (ZPlan& pl : plan) {                                      // the 32-tiles hold the long items: first
     if (pl.items.empty()) continue;
     vwgpu_prof_scope ps(ctx, "bm_zones");
@@ -1146,7 +1226,9 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     }
     // Non-finite costs (NCC over an all-zero window: 0 * inf) make the chain order dependent: the flagged tiles again, as one item each.
     // Order-free SAD / SSD levels hold finite costs only; with certification a non-finite cost flags the zone instead.
-    if (ncc && !cert) {
+    // The fp32 tier: the cut tiles whose merged float32 records leave a pixel unproven, again as one float64 item each.
+    if ((ncc && !cert) || t32) {
+      use32 = false;
       vwgpu_prof_scope ps(ctx, "bm_zones_redo");
       const dim3 grd((unsigned)pl.redo.size());
       const ZItem* tab = pl.d_redo;
@@ -1161,6 +1243,8 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
 #undef VW_ZN3
 #undef VW_ZN4
 #undef VW_ZN5
+#undef VW_ZN6
+#undef VW_MG32
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }

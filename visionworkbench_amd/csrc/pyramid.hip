@@ -1173,9 +1173,11 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
     unsigned long long got[4] = {0, 0, 0, 0};
     VWGPU_HIP(ctx, hipMemcpyAsync(got, d_cert_stats, sizeof got, hipMemcpyDeviceToHost, st));
     VWGPU_HIP(ctx, hipStreamSynchronize(st));
-    ctx->cert_px[0] += got[0]; ctx->cert_px[1] += got[1];
-    fprintf(stderr, "certification: %llu pixels in certified tiles, %llu in tiles that sent their zone to the exact-order kernels (%.2f %%)\n",
-            got[0], got[1], got[0] + got[1] ? 100.0 * (double)got[1] / (double)(got[0] + got[1]) : 0.0);
+    ctx->cert_px[0] += got[0]; ctx->cert_px[1] += got[1]; ctx->cert_px[2] += got[2];
+    fprintf(stderr, "certification: %llu pixels in certified tiles, %llu in tiles that sent their zone to the exact-order kernels (%.2f %%); %llu in tiles "
+            "the fp32 tier passed on to float64 (%.2f %%)\n",
+            got[0], got[1], got[0] + got[1] ? 100.0 * (double)got[1] / (double)(got[0] + got[1]) : 0.0, got[2],
+            got[0] + got[1] ? 100.0 * (double)got[2] / (double)(got[0] + got[1]) : 0.0);
   }
   return VWGPU_OK;
 }

@@ -239,8 +239,9 @@ int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value) {
   // the options below select between variants that return identical results; out-of-range values are refused
   if (option == VWGPU_OPT_SAD_GROUPS && value >= 0 && value <= 2) { ctx->sad_groups = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_EXACT_SCRATCH_MB && value >= 16 && value <= 65536) { ctx->exact_scratch_mb = value; return VWGPU_OK; }
-  if (option == VWGPU_OPT_TRACE && value >= 0 && value <= 7) { ctx->trace = value; ctx->cert_px[0] = ctx->cert_px[1] = 0; return VWGPU_OK; }
+  if (option == VWGPU_OPT_TRACE && value >= 0 && value <= 7) { ctx->trace = value; ctx->cert_px[0] = ctx->cert_px[1] = ctx->cert_px[2] = 0; return VWGPU_OK; }
   if (option == VWGPU_OPT_CERTIFY && (value == 0 || value == 1)) { ctx->certify = value; return VWGPU_OK; }
+  if (option == VWGPU_OPT_CERT_F32 && (value == 0 || value == 1)) { ctx->cert_f32 = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_ZONE_SXC && value >= 0 && value <= 4096) { ctx->zone_sxc = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_SGM_SWEEP && value >= 0 && value <= 15) { ctx->sgm_sweep = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_MGM_SWEEP && value >= 0 && value <= 15) { ctx->mgm_sweep = value; return VWGPU_OK; }
@@ -279,6 +280,12 @@ int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value) {
   if (option == VWGPU_OPT_CERT_PERMILLE) {          // share of the pixels (per mille) that were certified since VWGPU_OPT_TRACE was last set; -1: none counted
     const unsigned long long all = ctx->cert_px[0] + ctx->cert_px[1];
     *value = all ? (int)((ctx->cert_px[0] * 1000ull) / all) : -1;
+    return VWGPU_OK;
+  }
+  if (option == VWGPU_OPT_CERT_F32) { *value = ctx->cert_f32; return VWGPU_OK; }
+  if (option == VWGPU_OPT_CERT_F64_PERMILLE) {
+    const unsigned long long all = ctx->cert_px[0] + ctx->cert_px[1];
+    *value = all ? (int)((ctx->cert_px[2] * 1000ull) / all) : -1;
     return VWGPU_OK;
   }
   if (option == VWGPU_OPT_HOST_RING_WRAPS) { *value = (int)(ctx->ring_wraps & 0x7fffffff); return VWGPU_OK; }
@@ -429,18 +436,18 @@ static int calc_disparity_classified(vwgpu_ctx* ctx, int cost_type, const float*
       VWGPU_HIP(ctx, hipMemsetAsync(d_word, 0, 2 * sizeof(int), ctx->stream));
       unsigned long long* d_stats = nullptr;
       if (ctx->trace & 4) {
-        d_stats = reinterpret_cast<unsigned long long*>(d_word + 16);
-        VWGPU_HIP(ctx, hipMemsetAsync(d_stats, 0, 16, ctx->stream));
+        d_stats = reinterpret_cast<unsigned long long*>(d_word + 32);
+        VWGPU_HIP(ctx, hipMemsetAsync(d_stats, 0, 32, ctx->stream));
       }
       rc = vwgpu_launch_bm_zones(ctx, cost_type, d_left, lw, lh, d_right, rcw, rch, kx, ky, &z, 1, d_out, 0, g_hi, d_word + 1, d_stats, d_word, nullptr, nullptr,
                                  0, 0, 0, 0, ls, rs);
       if (rc) return rc;
       int any = 0;
       VWGPU_HIP(ctx, hipMemcpyAsync(&any, d_word, sizeof any, hipMemcpyDeviceToHost, ctx->stream));
-      unsigned long long got[2] = {0, 0};
+      unsigned long long got[3] = {0, 0, 0};
       if (d_stats) VWGPU_HIP(ctx, hipMemcpyAsync(got, d_stats, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
       VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (d_stats) { ctx->cert_px[0] += got[0]; ctx->cert_px[1] += got[1]; }
+      if (d_stats) { ctx->cert_px[0] += got[0]; ctx->cert_px[1] += got[1]; ctx->cert_px[2] += got[2]; }
       if (!any) { ctx->last_path = VWGPU_PATH_CERTIFIED; return VWGPU_OK; }
     }
   }

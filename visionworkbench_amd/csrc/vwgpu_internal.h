@@ -76,8 +76,9 @@ struct vwgpu_ctx {
   int exact_split = 0;        // VWGPU_OPT_EXACT_SPLIT: 0 by the longest chain, 1 always the split pass 2, 2 always the fused one
   int trace = 0;              // VWGPU_OPT_TRACE
   int certify = 1;            // VWGPU_OPT_CERTIFY
+  int cert_f32 = 1;           // VWGPU_OPT_CERT_F32: the certified pass runs its fp32 tier first (bm_zones.hip)
   int zone_sxc = 0;           // VWGPU_OPT_ZONE_SXC: 0 = 16 dx per right patch, else at most this many
-  unsigned long long cert_px[2] = {0, 0};   // with VWGPU_OPT_TRACE bit 2: pixels in certified tiles / in flagged tiles so far (VWGPU_OPT_CERT_PERMILLE)
+  unsigned long long cert_px[3] = {0, 0, 0};   // with VWGPU_OPT_TRACE bit 2: pixels in certified tiles / in flagged tiles / in tiles the fp32 tier passed on to float64, so far
   int num_cu = 256;
 };
 
