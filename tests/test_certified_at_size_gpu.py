@@ -98,5 +98,5 @@ def test_float_texture_tiles(ctx, oracle, float_pair, cost, kernel):
 
 
 def test_float_texture_ncc_meansub_tile(ctx, oracle, float_pair):
-    """One SubtractedMean case (PREFILTER_MEANSUB, kernel width 25: src/vw/Stereo/PreFilter.h:52-74), NCC 11x11, corner tile."""
-    _run(ctx, oracle, float_pair[0], float_pair[1], 1, 25.0, (11, 11), 2, ["corner"], 900)
+    """One SubtractedMean case (PREFILTER_MEANSUB, Gaussian sigma 3: src/vw/Stereo/PreFilter.h:52-74), NCC 11x11, corner tile."""
+    _run(ctx, oracle, float_pair[0], float_pair[1], 1, float(np.float32(3.0)), (11, 11), 2, ["corner"], 900)

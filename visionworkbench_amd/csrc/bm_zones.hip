@@ -639,9 +639,11 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
   return uncert;
 }
 
-// T32: the certified pass as two tiers in ONE launch — every item runs in float32 first; a tile with a pixel the fp32 tier cannot prove
-// runs again in float64 (same workgroup, same LDS), and only what THAT cannot prove flags the zone for the reference's order.  (Cut tiles:
-// the runs leave float32 records, zones_merge_kernel<T32> certifies them and sends an unproven tile to the float64 redo launch.)
+// T32: the certified pass as two tiers in ONE launch — an item that finishes its tile runs in float32 first; a tile with a pixel the fp32
+// tier cannot prove runs again in float64 (same workgroup, same LDS), and only what THAT cannot prove flags the zone for the reference's
+// order.  The runs of a CUT tile stay in float64: their records are certified after the merge, and an unproven tile would have to be matched
+// again over ALL its disparities by one workgroup — measured on a LoG + NCC pyramid tile (41 of ~2200 tiles unproven in float32): the redo
+// launches took 0.39 ms, four times what the float32 runs had saved.
 template <int COST, int KS, typename ACC, bool CERT, int ZS, bool EDGE, bool T32>
 __global__ void __launch_bounds__(ZS * ZS / 4, 4)
 bm_zones_kernel(ZLaunch G, const vwgpu_zone_task* __restrict__ zones, const ZItem* __restrict__ items) {
@@ -655,10 +657,14 @@ bm_zones_kernel(ZLaunch G, const vwgpu_zone_task* __restrict__ zones, const ZIte
   bool uncert;
   int tier = 0;
   if constexpr (T32) {
-    uncert = zmatch_item<COST, KS, float, true, ZS, EDGE>(G, it, z, geom, smem);
-    if (it.slot < 0 && __syncthreads_or(uncert ? 1 : 0)) {        // (__syncthreads_or is also the barrier between the two uses of the LDS)
-      tier = 1;
+    if (it.slot >= 0) {                                           // a run of a cut tile: float64 records for zones_merge_kernel (see above)
       uncert = zmatch_item<COST, KS, double, true, ZS, EDGE>(G, it, z, geom, smem);
+    } else {
+      uncert = zmatch_item<COST, KS, float, true, ZS, EDGE>(G, it, z, geom, smem);
+      if (__syncthreads_or(uncert ? 1 : 0)) {                     // (__syncthreads_or is also the barrier between the two uses of the LDS)
+        tier = 1;
+        uncert = zmatch_item<COST, KS, double, true, ZS, EDGE>(G, it, z, geom, smem);
+      }
     }
   } else {
     uncert = zmatch_item<COST, KS, ACC, CERT, ZS, EDGE>(G, it, z, geom, smem);
@@ -676,9 +682,7 @@ bm_zones_kernel(ZLaunch G, const vwgpu_zone_task* __restrict__ zones, const ZIte
 }
 
 // Folds the runs of a tile in index order (see the file header): (value, first index) minimum, extremum, runner-up, largest right precision.
-// T32: the records come from the fp32 tier — certified with its own error term (REL32 as in zmatch_item); a tile with an unproven pixel
-// goes to the float64 redo launch (P.redo) instead of flagging its zone.
-template <int COST, bool CERT, int ZS, bool T32 = false, bool REL32 = false>
+template <int COST, bool CERT, int ZS>
 __global__ void __launch_bounds__(ZS * ZS / 4)
 zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* __restrict__ items, PrecView pa,
                    int32_t* __restrict__ out, ZPart P, ZCertArgs C) {
@@ -760,13 +764,13 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
         double lprec = 0.0;
         if (COST == VWGPU_CROSS_CORRELATION) lprec = pa.p[(size_t)(z.ay + oy + y - pa.y0) * pa.w + (z.ax + ox + c - pa.x0)];
         const double sl = COST == VWGPU_CROSS_CORRELATION ? lprec : 1.0;       // (square roots of precisions, as in bm_zones_kernel)
-        bool okpx = zcertified<COST, T32, REL32>(C.zc[it.zone], D, bad, best[m] * sl, other[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
+        bool okpx = zcertified<COST>(C.zc[it.zone], D, bad, best[m] * sl, other[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
         if (edge) {                                                // the "cannot matter" certificate, as in bm_zones_kernel
           constexpr double kInit = COST == VWGPU_CROSS_CORRELATION ? -INFINITY : INFINITY;
           const ZEdge e1{C.edge_lo, C.edge_hi, z.bx + ox + c - C.edge_k};
           if (fn[m]) okpx = !e1.notfar(0);
           else if (!okpx && !bad && fabs(best[m]) <= 1.7976931348623157e308 && !e1.notfar(bx_))
-            okpx = bnf[m] == kInit || zcertified<COST, T32, REL32>(C.zc[it.zone], D, false, best[m] * sl, bnf[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
+            okpx = bnf[m] == kInit || zcertified<COST>(C.zc[it.zone], D, false, best[m] * sl, bnf[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
         }
         if (!okpx) uncert = true;
       }
@@ -775,13 +779,8 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
   if (CERT) {
     const int any = __syncthreads_or(uncert ? 1 : 0);
     if (t == 0) {
-      if (T32) {
-        if (any) { P.redo[it.gate] = 1; if (C.stats) atomicAdd(&C.stats[2], (unsigned long long)(tw * th)); }      // the float64 redo launch decides (and counts) the tile
-        else if (C.stats) atomicAdd(&C.stats[0], (unsigned long long)(tw * th));
-      } else {
-        if (any) { C.zflag[it.zone] = 1; if (C.any) *C.any = 1; }
-        if (C.stats) { atomicAdd(&C.stats[any ? 1 : 0], (unsigned long long)(tw * th)); }
-      }
+      if (any) { C.zflag[it.zone] = 1; if (C.any) *C.any = 1; }
+      if (C.stats) { atomicAdd(&C.stats[any ? 1 : 0], (unsigned long long)(tw * th)); }
     }
   }
 }
@@ -1203,9 +1202,8 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
 #else
 #define VW_MG2(C_, T_) hipLaunchKernelGGL((zones_merge_kernel<C_, T_, 32>), mgrd, dim3(256), 0, ctx->stream, dz, pl.d_merges, pa, out, pl.P, C)
 #endif
-#define VW_MG32(C_, R_) hipLaunchKernelGGL((zones_merge_kernel<C_, true, 32, true, R_>), mgrd, dim3(256), 0, ctx->stream, dz, pl.d_merges, pa, out, pl.P, C)
-#define VW_MG(C_) do { if (t32 && kx >= 9) VW_MG32(C_, true); else if (t32) VW_MG32(C_, false); else if (cert) VW_MG2(C_, true); else VW_MG2(C_, false); } while (0)
-  bool use32 = t32;
+#define VW_MG(C_) do { if (cert) VW_MG2(C_, true); else VW_MG2(C_, false); } while (0)
+  const bool use32 = t32;
   for (ZPlan& pl : plan) {                                      // the 32-tiles hold the long items: first
     if (pl.items.empty()) continue;
     vwgpu_prof_scope ps(ctx, "bm_zones");
@@ -1226,9 +1224,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     }
     // Non-finite costs (NCC over an all-zero window: 0 * inf) make the chain order dependent: the flagged tiles again, as one item each.
     // Order-free SAD / SSD levels hold finite costs only; with certification a non-finite cost flags the zone instead.
-    // The fp32 tier: the cut tiles whose merged float32 records leave a pixel unproven, again as one float64 item each.
-    if ((ncc && !cert) || t32) {
-      use32 = false;
+    if (ncc && !cert) {
       vwgpu_prof_scope ps(ctx, "bm_zones_redo");
       const dim3 grd((unsigned)pl.redo.size());
       const ZItem* tab = pl.d_redo;
@@ -1244,7 +1240,6 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
 #undef VW_ZN4
 #undef VW_ZN5
 #undef VW_ZN6
-#undef VW_MG32
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
 }
