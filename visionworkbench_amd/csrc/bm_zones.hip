@@ -85,13 +85,14 @@ struct PrecView {           // 1 / box-sum(img^2) over origins [x0, x0+w) x [y0,
 // sqrt(1 / S) (root != 0), by the certified pass, whose error bound covers the order of the sums (root == 2, the passes with the "cannot
 // matter" certificate, additionally turns the infinite precision of an all-zero window into NaN for EVERY pixel of the pass, see below).
 struct ZPrecJob { const float* img; int w, h; ptrdiff_t pitch; double* prec; int x0, y0, pw, ph; float* prec32; };
-struct ZPrecJobs { ZPrecJob j[2]; };           // blockIdx.z: the left and the right image of a pass in one launch
+struct ZPrecJobs { ZPrecJob j[2]; size_t img_tile[2], prec_tile[2]; };      // blockIdx.z & 1: the left / right image of a pass, blockIdx.z >> 1: the image pair of a group
 __global__ void __launch_bounds__(256)
 zone_precision_kernel(ZPrecJobs jobs, int kx, int ky, int root) {
   extern __shared__ double zp_sm[];
-  const ZPrecJob J = jobs.j[blockIdx.z];
-  const float* __restrict__ img = J.img;
-  double* __restrict__ prec = J.prec;
+  const ZPrecJob J = jobs.j[blockIdx.z & 1];
+  const size_t gi = blockIdx.z >> 1;
+  const float* __restrict__ img = J.img + gi * jobs.img_tile[blockIdx.z & 1];
+  double* __restrict__ prec = J.prec + gi * jobs.prec_tile[blockIdx.z & 1];
   const int w = J.w, h = J.h, x0 = J.x0, y0 = J.y0, pw = J.pw, ph = J.ph;
   const ptrdiff_t pitch = J.pitch;
   if ((int)blockIdx.x * 64 >= pw || (int)blockIdx.y * 4 >= ph) return;
@@ -125,7 +126,7 @@ zone_precision_kernel(ZPrecJobs jobs, int kx, int ky, int root) {
   double pr = root ? sqrt(1.0 / s) : 1.0 / s;
   if (root == 2 && !(pr <= 1.7976931348623157e308)) pr = __builtin_nan("");
   prec[(size_t)j * pw + i] = pr;
-  if (J.prec32) J.prec32[(size_t)j * pw + i] = (float)pr;
+  if (J.prec32) J.prec32[gi * jobs.prec_tile[blockIdx.z & 1] + (size_t)j * pw + i] = (float)pr;
 }
 
 // A work item: disparities [i0, i0 + n) (index = dy * sx + dx, the reference's loop order) of one 32 x 32 tile of one zone.
@@ -140,9 +141,9 @@ struct ZMergeItem { int zone, txy, slot0, nitems, gate, pad0, pad1, pad2; };
 // records of the partial slots, one plane of 1024 pixels per slot and field
 struct ZPart { double* best; double* worst; int* idx; double* second; double* rpmax; int* bad; int* redo; double* bnf; };
 // certification constants of a zone: bounds on |tile-parallel sum - reference running sum| (see vwgpu_launch_bm_zones)
-struct ZCert { double eps_s, eps_ll, eps_rr, eps32; };      // eps32: bound on |float32 tile sum - exact sum| of the fp32 tier, see vwgpu_launch_bm_zones
+struct ZCert { double eps_s, eps_ll, eps_rr, eps32; int edge_lo, edge_hi, pad0, pad1; };      // eps32: bound on |float32 tile sum - exact sum| of the fp32 tier, see vwgpu_launch_bm_zones
 struct ZCertArgs { const ZCert* zc; int* zflag; unsigned long long* stats; int* any; const int* need; const unsigned char* cells;
-                   int edge_m, edge_k, edge_lo, edge_hi; };     // zc == nullptr: no certification; any: "some zone was flagged"; edge_*: see ZEdge
+                   int edge_m, edge_k; };     // zc == nullptr: no certification; any[image]: "some zone was flagged"; edge_* (the bounds: per zone, in ZCert): see ZEdge
 // The "cannot matter" certificate (EDGE kernels; edge_m > 0).  A candidate (pixel, disparity) whose partner lies edge_m or more columns
 // outside the other image — partner column = origin of its window in the other image - edge_k, outside [edge_lo, edge_hi] — is FAR
 // (edge_m > 0 switches the certificate on; the caller folds the margin into the two bounds).  Far windows are clamped copies of the border column: whole runs of them have bit-identical data, their costs tie exactly
@@ -290,6 +291,7 @@ __device__ __forceinline__ void zwindow_sums(const ACC* e, ACC* w) {
 struct ZLaunch {
   const float* A; int aw, ah, ap; const float* B; int bw, bh, bp;
   int kx, ky, sxc; PrecView pa, pb; int32_t* out; ZPart P; ZCertArgs C;
+  size_t a_tile, b_tile, pa_tile, pb_tile;      // groups (vwgpu_zone_group): elements between the images / precision images of consecutive image pairs
 };
 
 // One work item.  Returns (CERT, an item that finishes its tile): true when some pixel of the tile could not be certified — the caller
@@ -300,9 +302,13 @@ struct ZLaunch {
 // large — certified against BOTH the reference's summation order and its own float32 roundings (zcertified<T32>).
 template <int COST, int KS, typename ACC, bool CERT, int ZS, bool EDGE>
 __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, const vwgpu_zone_task& z, const ZGeom& geom, char* smem) {
-  const float* __restrict__ A = G.A; const float* __restrict__ B = G.B;
+  const float* __restrict__ A = G.A + (size_t)z.img * G.a_tile; const float* __restrict__ B = G.B + (size_t)z.img * G.b_tile;
   const int aw = G.aw, ah = G.ah, ap = G.ap, bw = G.bw, bh = G.bh, bp = G.bp, kx = G.kx, ky = G.ky, sxc = G.sxc;
-  const PrecView pa = G.pa, pb = G.pb;
+  PrecView pa = G.pa, pb = G.pb;
+  if (COST == VWGPU_CROSS_CORRELATION) {
+    pa.p += (size_t)z.img * G.pa_tile; pb.p += (size_t)z.img * G.pb_tile;
+    if (pb.pf) pb.pf += (size_t)z.img * G.pb_tile;
+  }
   int32_t* __restrict__ out = G.out;
   const ZPart& P = G.P; const ZCertArgs& C = G.C;
   // tile side, threads, columns per horizontal item (float64 sums: four — eight need 36 registers for the elements alone and cost a
@@ -359,6 +365,8 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
   }
   bool fnan[4] = {false, false, false, false};                    // EDGE: the FIRST candidate of the search has a NaN cost (then it is the reference's winner)
   CT bnf[4];                                                      // EDGE: the best cost among the candidates that are not far (ZEdge)
+  int elo = 0, ehi = 0;
+  if (EDGE) { elo = C.zc[it.zone].edge_lo; ehi = C.zc[it.zone].edge_hi; }
 #pragma unroll
   for (int m = 0; m < 4; ++m) bnf[m] = kBestInit;
   ACC bestA[4], worstA[4];                                        // the lean chain of the order-free SAD / SSD levels
@@ -393,7 +401,7 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
     // 12 restores / 14 branches, and 14 % of a level-0 launch.  Lanes and rows without a pixel load the first precision of the image,
     // run the chain on whatever their plane rows hold, and are dropped in the epilogue.  Fewer s_waitcnt or address instructions did
     // not pay the same way, see below.)
-    const ZEdge edge{C.edge_lo, C.edge_hi, z.bx + ox + c + dx0 - C.edge_k};
+    const ZEdge edge{elo, ehi, z.bx + ox + c + dx0 - C.edge_k};
     const CT* pbase;
     if constexpr (T32) pbase = pb.pf; else pbase = pb.p;
     const CT* prow[4] = {pbase, pbase, pbase, pbase};
@@ -624,7 +632,7 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
           const bool badpx = !(fabs(bd) <= 1.7976931348623157e308);
           bool okpx = zcertified<COST, T32, REL32>(C.zc[it.zone], D, badpx, bd * sl, sd * sl, sl * sl, rq * rq);
           if (EDGE) {
-            const ZEdge e1{C.edge_lo, C.edge_hi, z.bx + ox + c - C.edge_k};
+            const ZEdge e1{elo, ehi, z.bx + ox + c - C.edge_k};
             if (fnan[m]) okpx = !e1.notfar(0);                    // the reference's winner is candidate 0, whatever follows: fine iff that one is far
             else if (!okpx && !badpx && !e1.notfar(bx_))          // the best is far and ahead of everything that is not
               okpx = bnf[m] == kBestInit || zcertified<COST, T32, REL32>(C.zc[it.zone], D, false, bd * sl, nfd * sl, sl * sl, rq * rq);
@@ -672,7 +680,7 @@ bm_zones_kernel(ZLaunch G, const vwgpu_zone_task* __restrict__ zones, const ZIte
   if (CERT && it.slot < 0) {
     const int any = __syncthreads_or(uncert ? 1 : 0);
     if (threadIdx.x == 0) {
-      if (any) { G.C.zflag[it.zone] = 1; if (G.C.any) *G.C.any = 1; }
+      if (any) { G.C.zflag[it.zone] = 1; if (G.C.any) G.C.any[z.img] = 1; }
       if (G.C.stats) {
         atomicAdd(&G.C.stats[any ? 1 : 0], (unsigned long long)(geom.tw * geom.th));
         if (tier) atomicAdd(&G.C.stats[2], (unsigned long long)(geom.tw * geom.th));      // pixels of tiles the fp32 tier passed on
@@ -684,11 +692,12 @@ bm_zones_kernel(ZLaunch G, const vwgpu_zone_task* __restrict__ zones, const ZIte
 // Folds the runs of a tile in index order (see the file header): (value, first index) minimum, extremum, runner-up, largest right precision.
 template <int COST, bool CERT, int ZS>
 __global__ void __launch_bounds__(ZS * ZS / 4)
-zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* __restrict__ items, PrecView pa,
+zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* __restrict__ items, PrecView pa, size_t pa_tile,
                    int32_t* __restrict__ out, ZPart P, ZCertArgs C) {
   constexpr int ZT = ZS;
   const ZMergeItem it = items[blockIdx.x];
   const vwgpu_zone_task z = zones[it.zone];
+  if (CERT && COST == VWGPU_CROSS_CORRELATION) pa.p += (size_t)z.img * pa_tile;
   ZGeom geom;
   if (!ztile_geometry<ZT>(z, it.zone, it.txy, C.need, C.cells, geom)) return;
   const int ox = geom.ox, oy = geom.oy, tw = geom.tw, th = geom.th;
@@ -767,7 +776,7 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
         bool okpx = zcertified<COST>(C.zc[it.zone], D, bad, best[m] * sl, other[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
         if (edge) {                                                // the "cannot matter" certificate, as in bm_zones_kernel
           constexpr double kInit = COST == VWGPU_CROSS_CORRELATION ? -INFINITY : INFINITY;
-          const ZEdge e1{C.edge_lo, C.edge_hi, z.bx + ox + c - C.edge_k};
+          const ZEdge e1{C.zc[it.zone].edge_lo, C.zc[it.zone].edge_hi, z.bx + ox + c - C.edge_k};
           if (fn[m]) okpx = !e1.notfar(0);
           else if (!okpx && !bad && fabs(best[m]) <= 1.7976931348623157e308 && !e1.notfar(bx_))
             okpx = bnf[m] == kInit || zcertified<COST>(C.zc[it.zone], D, false, best[m] * sl, bnf[m] * sl, sl * sl, rpmax[m] * rpmax[m]);
@@ -779,7 +788,7 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
   if (CERT) {
     const int any = __syncthreads_or(uncert ? 1 : 0);
     if (t == 0) {
-      if (any) { C.zflag[it.zone] = 1; if (C.any) *C.any = 1; }
+      if (any) { C.zflag[it.zone] = 1; if (C.any) C.any[z.img] = 1; }
       if (C.stats) { atomicAdd(&C.stats[any ? 1 : 0], (unsigned long long)(tw * th)); }
     }
   }
@@ -975,7 +984,14 @@ size_t zones_lds_fixed(int zs, int kx, int ky, size_t accb) { return (size_t)(zs
 int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
                           int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out, int f32_sums, int cert_hi, int* d_zflag,
                           unsigned long long* d_stats, int* d_any, const int* d_need, const unsigned char* d_cells,
-                          int edge_m, int edge_k, int edge_lo, int edge_hi, ptrdiff_t as, ptrdiff_t bs) {
+                          int edge_m, int edge_k, int edge_lo, int edge_hi, ptrdiff_t as, ptrdiff_t bs, const vwgpu_zone_group* grp) {
+  const int n_img = grp ? std::max(1, grp->n_img) : 1;
+  if (grp && grp->cert_hi) {                                      // (a group is certified as a whole or not at all: the caller sorts its image pairs into such groups)
+    cert_hi = INT_MIN;
+    for (int i = 0; i < n_img; ++i) cert_hi = std::max(cert_hi, grp->cert_hi[i]);
+  }
+  for (int i = 0; i < n; ++i)
+    if (zones[i].img < 0 || zones[i].img >= n_img) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "bm_zones: zone %d names image pair %d of %d", i, zones[i].img, n_img);
   const bool cert = cert_hi != INT_MIN;
   // the fp32 tier of the certified pass (VWGPU_OPT_CERT_F32, default on): compile-time square windows only
   const bool t32 = cert && ctx->cert_f32 && kx == ky && kx >= 3 && kx <= 13;
@@ -1099,7 +1115,8 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
       const vwgpu_zone_task& z = zones[i];
       if (z.zw <= 0 || z.zh <= 0 || z.sx <= 0 || z.sy <= 0) continue;
       const long long lo = (long long)z.bx - edge_k, hi = lo + z.zw - 1 + z.sx - 1;        // partner columns of the zone's candidates
-      edge = lo < (long long)edge_lo || hi > (long long)edge_hi;
+      const int elo = grp && grp->edge_lo ? grp->edge_lo[z.img] : edge_lo, ehi = grp && grp->edge_hi ? grp->edge_hi[z.img] : edge_hi;
+      edge = lo < (long long)elo || hi > (long long)ehi;
     }
   if (!edge) edge_m = 0;
   const size_t rec_bytes = 8 + 8 + 4 + (cert ? 8 : 0) + (cert && ncc ? 8 : 0) + (edge ? 8 : 0);
@@ -1112,6 +1129,9 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     na = vwgpu_align_up((size_t)pa.w * pa.h * 8, 256); nb = vwgpu_align_up((size_t)pb.w * pb.h * 8, 256);
     if (t32) nb32 = vwgpu_align_up((size_t)pb.w * pb.h * 4, 256);      // the right factors once more in float32 (the chain of the fp32 tier reads them per evaluation)
   }
+  // (groups: one precision image pair per image pair, all over the common origin rectangle, at a fixed stride)
+  const size_t pa_tile = (size_t)pa.w * pa.h, pb_tile = (size_t)pb.w * pb.h;
+  na *= (size_t)n_img; nb *= (size_t)n_img; nb32 *= (size_t)n_img;
   int rc = vwgpu_arena_reserve(ctx, &ctx->scratch, na + nb + nb32 + part_bytes);
   if (rc) return rc;
   char* sbase = static_cast<char*>(ctx->scratch.base);
@@ -1124,7 +1144,9 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     ZPrecJobs zj;
     zj.j[0] = ZPrecJob{A, aw, ah, ap, da, pa.x0, pa.y0, pa.w, pa.h, nullptr};
     zj.j[1] = ZPrecJob{B, bw, bh, bp, db, pb.x0, pb.y0, pb.w, pb.h, db32};
-    hipLaunchKernelGGL(zone_precision_kernel, dim3((std::max(pa.w, pb.w) + 63) / 64, (std::max(pa.h, pb.h) + 3) / 4, 2), dim3(64, 4), zp_lds, ctx->stream, zj, kx, ky, cert ? (edge ? 2 : 1) : 0);
+    zj.img_tile[0] = grp ? grp->a_stride : 0; zj.img_tile[1] = grp ? grp->b_stride : 0;
+    zj.prec_tile[0] = pa_tile; zj.prec_tile[1] = pb_tile;
+    hipLaunchKernelGGL(zone_precision_kernel, dim3((std::max(pa.w, pb.w) + 63) / 64, (std::max(pa.h, pb.h) + 3) / 4, 2 * n_img), dim3(64, 4), zp_lds, ctx->stream, zj, kx, ky, cert ? (edge ? 2 : 1) : 0);
     pa.p = da; pb.p = db; pb.pf = db32;
   }
   {
@@ -1146,11 +1168,17 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
   std::vector<ZCert> zc;
   if (cert) {
     zc.resize((size_t)n);
-    const double e_el = cost_type == VWGPU_ABSOLUTE_DIFFERENCE ? std::ldexp(1.0, cert_hi + 2)          // |a - b| < 2^(hi + 2)
+    double e_el = cost_type == VWGPU_ABSOLUTE_DIFFERENCE ? std::ldexp(1.0, cert_hi + 2)          // |a - b| < 2^(hi + 2)
                         : cost_type == VWGPU_SQUARED_DIFFERENCE ? std::ldexp(1.0, 2 * cert_hi + 4)     // (a - b)^2
                         : std::ldexp(1.0, 2 * cert_hi + 2);                                            // |a b|, a^2
     for (int i = 0; i < n; ++i) {
       const vwgpu_zone_task& z = zones[i];
+      if (grp && grp->cert_hi) {                                  // the zone's own image pair bounds its elements
+        const int h = grp->cert_hi[z.img];
+        e_el = cost_type == VWGPU_ABSOLUTE_DIFFERENCE ? std::ldexp(1.0, h + 2) : cost_type == VWGPU_SQUARED_DIFFERENCE ? std::ldexp(1.0, 2 * h + 4) : std::ldexp(1.0, 2 * h + 2);
+      }
+      zc[i].edge_lo = grp && grp->edge_lo ? grp->edge_lo[z.img] : edge_lo; zc[i].edge_hi = grp && grp->edge_hi ? grp->edge_hi[z.img] : edge_hi;
+      zc[i].pad0 = zc[i].pad1 = 0;
       zc[i].eps_s = sum_error_units(kx, ky, z.zw, z.zh) * e_el;
       zc[i].eps_ll = zc[i].eps_s;
       zc[i].eps_rr = sum_error_units(kx, ky, z.zw + z.sx - 1, z.zh + z.sy - 1) * e_el;
@@ -1178,10 +1206,11 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
       plan[k].P.redo = f; f += plan[k].merges.size();
     }
   }
-  ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats, d_any, d_need, d_cells, edge_m, edge_k, edge_lo, edge_hi};
+  ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats, d_any, d_need, d_cells, edge_m, edge_k};
+  const size_t a_tile = grp ? grp->a_stride : 0, b_tile = grp ? grp->b_stride : 0;
 
 #define VW_ZN6(C_, K_, A_, T_, S_, E_, T32_) hipLaunchKernelGGL((bm_zones_kernel<C_, K_, A_, T_, S_, E_, T32_>), grd, dim3(S_ * S_ / 4), pl.lds, ctx->stream, \
-                                                               ZLaunch{A, aw, ah, ap, B, bw, bh, bp, kx, ky, pl.sxc, pa, pb, out, pl.P, C}, dz, tab)
+                                                               ZLaunch{A, aw, ah, ap, B, bw, bh, bp, kx, ky, pl.sxc, pa, pb, out, pl.P, C, a_tile, b_tile, pa_tile, pb_tile}, dz, tab)
 #define VW_ZN5(C_, K_, A_, T_, S_, E_) do { if (T_ && (K_) > 0 && use32) VW_ZN6(C_, K_, A_, T_, S_, E_, (T_ && (K_) > 0)); else VW_ZN6(C_, K_, A_, T_, S_, E_, false); } while (0)
 #define VW_ZN4(C_, K_, A_, T_, S_) do { if (T_ && edge) VW_ZN5(C_, K_, A_, T_, S_, T_); else VW_ZN5(C_, K_, A_, T_, S_, false); } while (0)
 #ifdef VWGPU_ZONES16
@@ -1197,10 +1226,10 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
                                             case VWGPU_SQUARED_DIFFERENCE: VW_ZN_K(VWGPU_SQUARED_DIFFERENCE); break; \
                                             default: VW_ZN_K(VWGPU_ABSOLUTE_DIFFERENCE); break; } } while (0)
 #ifdef VWGPU_ZONES16
-#define VW_MG2(C_, T_) do { if (pl.zs == 32) hipLaunchKernelGGL((zones_merge_kernel<C_, T_, 32>), mgrd, dim3(256), 0, ctx->stream, dz, pl.d_merges, pa, out, pl.P, C); \
-                            else hipLaunchKernelGGL((zones_merge_kernel<C_, T_, 16>), mgrd, dim3(64), 0, ctx->stream, dz, pl.d_merges, pa, out, pl.P, C); } while (0)
+#define VW_MG2(C_, T_) do { if (pl.zs == 32) hipLaunchKernelGGL((zones_merge_kernel<C_, T_, 32>), mgrd, dim3(256), 0, ctx->stream, dz, pl.d_merges, pa, pa_tile, out, pl.P, C); \
+                            else hipLaunchKernelGGL((zones_merge_kernel<C_, T_, 16>), mgrd, dim3(64), 0, ctx->stream, dz, pl.d_merges, pa, pa_tile, out, pl.P, C); } while (0)
 #else
-#define VW_MG2(C_, T_) hipLaunchKernelGGL((zones_merge_kernel<C_, T_, 32>), mgrd, dim3(256), 0, ctx->stream, dz, pl.d_merges, pa, out, pl.P, C)
+#define VW_MG2(C_, T_) hipLaunchKernelGGL((zones_merge_kernel<C_, T_, 32>), mgrd, dim3(256), 0, ctx->stream, dz, pl.d_merges, pa, pa_tile, out, pl.P, C)
 #endif
 #define VW_MG(C_) do { if (cert) VW_MG2(C_, true); else VW_MG2(C_, false); } while (0)
   const bool use32 = t32;

@@ -232,6 +232,16 @@ struct vwgpu_zone_task {
   int out_off;         // pixel offset of the zone's first output pixel in the output buffer
   int out_stride;      // pixels
   int addx, addy;      // added to the winning disparity index of every pixel
+  int img = 0;         // zone-matcher groups (vwgpu_zone_group): which image pair of the group the zone belongs to
+};
+// A launch sequence of the zone matcher over several image pairs of EQUAL geometry laid out at a fixed stride (the tiles of a
+// pyramid_correlate group, pyramid.hip): image pair i = (A + i * a_stride, B + i * b_stride); zones name theirs in vwgpu_zone_task::img.
+struct vwgpu_zone_group {
+  int n_img = 1;
+  size_t a_stride = 0, b_stride = 0;       // floats
+  const int* cert_hi = nullptr;            // n_img largest exponents (certified passes; overrides the cert_hi argument)
+  const int* edge_lo = nullptr;            // n_img bounds of the "cannot matter" certificate (override edge_lo / edge_hi)
+  const int* edge_hi = nullptr;
 };
 bool vwgpu_bm_zones_supported(int kx, int ky);
 // f32_sums: vwgpu_sums_bits <= 24 for BOTH images.  cert_hi != INT_MIN: certify against the reference's summation order (bm_zones.hip),
@@ -242,7 +252,8 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
                           int* d_any = nullptr,       // d_any (optional, zeroed by the caller): set to 1 when some zone was flagged
                           const int* d_need = nullptr, const unsigned char* d_cells = nullptr,      // (optional) what to match of every zone, from vwgpu_launch_zone_need
                           int edge_m = 0, int edge_k = 0, int edge_lo = 0, int edge_hi = 0,      // certified passes: edge_m > 0 turns the "cannot matter" certificate on (bm_zones.hip, ZEdge)
-                          ptrdiff_t as = 0, ptrdiff_t bs = 0);                                     // row strides of A / B in floats (0: the widths)
+                          ptrdiff_t as = 0, ptrdiff_t bs = 0,                                      // row strides of A / B in floats (0: the widths)
+                          const vwgpu_zone_group* grp = nullptr);                                  // several image pairs in one launch sequence; d_any then has n_img words
 // The part of every zone's R->L image that its L/R check (vwgpu_launch_zone_lr, same tasks) will read, from the finished L->R result:
 // a rectangle per zone (d_need, 8 ints per zone) and a flag per 16 x 16 cell (d_cells; vwgpu_zone_need_cells numbers the cells into the
 // tasks' `ay` slot and returns their count).  d_zflag (optional): L->R zones still to be matched again ask for the whole image.
