@@ -389,6 +389,27 @@ int vwgpu_pyramid_correlate(vwgpu_ctx* ctx, const float* left, int lw, int lh, p
                             const vwgpu_pyramid_params* params, int bx, int by, int bw, int bh,
                             float* out, ptrdiff_t ostride);
 
+/* Several output tiles of the SAME image pair and parameters in one call (round 5) — what the reference's block rasteriser hands to its tile
+ * threads one by one (src/vw/Image/ImageIO.h:228-251, BlockProcessor.h:52-176; tools/correlate.cc:266 cuts 1024^2 tiles).  Tile t is
+ * [bx[t], bx[t] + bw[t]) x [by[t], by[t] + bh[t]) and goes to outs[t] (bw[t] x bh[t] x 3 floats, row stride ostride[t] pixels; ostride NULL
+ * or 0 = dense).  Runs of consecutive tiles of EQUAL size (at most 16) go through the pyramid level loop TOGETHER: every launch serves the
+ * whole group and one host round trip per level brings back the zone scheduler's tables of all its tiles (a lone tile is ~50 dependent
+ * launches of which the coarse levels are pure latency).  Each tile's result is identical to vwgpu_pyramid_correlate[_dev] on that tile.
+ * Grouping applies to VW_CORRELATION_BM without lr_disp_diff, blob filter and corr_timeout; everything else runs tile by tile inside the
+ * call.  One context = one group at a time; callers that want more in flight use one context per host thread, as for single tiles. */
+int vwgpu_pyramid_correlate_batch_dev(vwgpu_ctx* ctx, const float* d_left, int lw, int lh, ptrdiff_t lstride,
+                                      const float* d_right, int rw, int rh, ptrdiff_t rstride,
+                                      const uint8_t* d_left_mask, ptrdiff_t lmstride,
+                                      const uint8_t* d_right_mask, ptrdiff_t rmstride,
+                                      const vwgpu_pyramid_params* params, int n_tiles, const int* bx, const int* by, const int* bw, const int* bh,
+                                      float* const* d_outs, const ptrdiff_t* ostride);
+int vwgpu_pyramid_correlate_batch(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t lstride,
+                                  const float* right, int rw, int rh, ptrdiff_t rstride,
+                                  const uint8_t* left_mask, ptrdiff_t lmstride,
+                                  const uint8_t* right_mask, ptrdiff_t rmstride,
+                                  const vwgpu_pyramid_params* params, int n_tiles, const int* bx, const int* by, const int* bw, const int* bh,
+                                  float* const* outs, const ptrdiff_t* ostride);
+
 /* ---- semi-global matching ---------------------------------------------------------------------------- */
 
 typedef enum vwgpu_sgm_subpixel {      /* SemiGlobalMatcher::SgmSubpixelMode, src/vw/Stereo/SGM.h:93-99 */

@@ -24,7 +24,7 @@ SYMBOLS = [
     "vwgpu_disparity_mask_dev", "vwgpu_disparity_mask",
     "vwgpu_subdivide_regions",
     "vwgpu_disparity_blob_filter_dev", "vwgpu_disparity_blob_filter",
-    "vwgpu_pyramid_correlate_dev", "vwgpu_pyramid_correlate",
+    "vwgpu_pyramid_correlate_dev", "vwgpu_pyramid_correlate", "vwgpu_pyramid_correlate_batch_dev", "vwgpu_pyramid_correlate_batch",
     "vwgpu_calc_disparity_sgm_dev", "vwgpu_calc_disparity_sgm", "vwgpu_mgm_front_count", "vwgpu_mgm_front_pixel",
     "vwgpu_comm_unique_id", "vwgpu_comm_create", "vwgpu_comm_destroy", "vwgpu_halo_plan", "vwgpu_halo_headers_agree", "vwgpu_fetch_strip_window_dev",
 ]
@@ -153,6 +153,9 @@ def load():
     pc = [P, P, I, I, PD, P, I, I, PD, P, PD, P, PD, ctypes.POINTER(PyramidParams), I, I, I, I, P, PD]
     lib.vwgpu_pyramid_correlate_dev.argtypes = pc
     lib.vwgpu_pyramid_correlate.argtypes = pc
+    pb = [P, P, I, I, PD, P, I, I, PD, P, PD, P, PD, ctypes.POINTER(PyramidParams), I, P, P, P, P, P, P]
+    lib.vwgpu_pyramid_correlate_batch_dev.argtypes = pb
+    lib.vwgpu_pyramid_correlate_batch.argtypes = pb
     IP = ctypes.POINTER(ctypes.c_int)
     sg = [P, ctypes.POINTER(SgmParams), P, I, I, PD, P, I, I, PD, I, I, P, I, I, P, I, I, P, I, I, P, P, ctypes.c_size_t, IP, IP]
     lib.vwgpu_calc_disparity_sgm_dev.argtypes = sg

@@ -174,8 +174,9 @@ __global__ void add_offset_kernel(int32_t* __restrict__ d, ptrdiff_t stride_px, 
 template <int HH>
 __global__ void __launch_bounds__(256)
 rm_outliers_kernel(const int32_t* __restrict__ src, int w, int h, int hh, int hv, unsigned thr, int never, double rthr,
-                   int32_t* __restrict__ dst, int ow, int oh, int ox0, int oy0) {
+                   int32_t* __restrict__ dst, int ow, int oh, int ox0, int oy0, size_t src_tile = 0, size_t dst_tile = 0) {
   extern __shared__ int32_t rm_sm[];
+  src += blockIdx.z * src_tile; dst += blockIdx.z * dst_tile;     // tile groups: blockIdx.z = the tile, its images at a fixed stride (ints)
   if (HH > 0) { hh = HH; hv = HH; }
   const int tw = 32 + 2 * hh, th = 8 + 2 * hv, tn = tw * th;
   int32_t* sx = rm_sm;
@@ -404,6 +405,30 @@ __global__ void lr_diff_invalidate_kernel(const int32_t* __restrict__ d, int w, 
   if (!d[((size_t)y * w + x) * 3 + 2]) diff2[((ptrdiff_t)(y + uly) * dstride + (x + ulx)) * 2 + 1] = 0.0f;
 }
 
+// finish_masked_kernel / finish_kernel / zero_out_kernel for the tiles of a group (blockIdx.z): per-tile images at a fixed stride, per-tile
+// destinations from a table.  mode[t]: 0 = nothing to write, 1 = finish, 2 = mask + finish, 3 = zeros.
+constexpr int VWGPU_MAX_GROUP = 16;
+struct GroupOuts { float* out[VWGPU_MAX_GROUP]; ptrdiff_t os[VWGPU_MAX_GROUP]; int mode[VWGPU_MAX_GROUP]; };
+__global__ void finish_group_kernel(GroupOuts g, const int32_t* __restrict__ d, size_t d_tile, int w, int h, const uint8_t* __restrict__ m1,
+                                    const uint8_t* __restrict__ m2, size_t mask_tile, int m2w, int m2h, int ax, int ay) {
+  const int t = blockIdx.z, mode = g.mode[t];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (mode == 0 || i >= w || j >= h) return;
+  float* o = g.out[t] + ((ptrdiff_t)j * g.os[t] + i) * 3;
+  if (mode == 3) { o[0] = o[1] = o[2] = 0.0f; return; }
+  const int32_t* p = d + t * d_tile + ((size_t)j * w + i) * 3;
+  int p0 = p[0], p1 = p[1], p2 = p[2];
+  if (mode == 2) {
+    bool keep = m1[t * mask_tile + (size_t)j * w + i] != 0 && p2 != 0;
+    if (keep) {
+      const int x = i + p0, y = j + p1;
+      keep = !(x < 0 || x >= m2w || y < 0 || y >= m2h || m2[t * mask_tile + (size_t)y * m2w + x] == 0);
+    }
+    if (!keep) { p0 = 0; p1 = 0; p2 = 0; }
+  }
+  o[0] = (float)(p0 + ax); o[1] = (float)(p1 + ay); o[2] = p2 ? 1.0f : 0.0f;
+}
+
 __global__ void zero_out_kernel(float* __restrict__ out, ptrdiff_t ostride_px, int w, int h) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= w || y >= h) return;
@@ -431,28 +456,32 @@ struct DevMask { uint8_t* p = nullptr; int w = 0, h = 0; };
 }  // namespace
 
 int vwgpu_launch_disparity_filter(vwgpu_ctx* ctx, const int32_t* src, int w, int h, int hh, int hv, double pthr, double rthr,
-                                  bool cleanup, int32_t* tmp_padded, int32_t* dst, bool inner_only) {
+                                  bool cleanup, int32_t* tmp_padded, int32_t* dst, bool inner_only, int tiles, size_t tile_ints) {
+  // tiles > 1 (the tile groups of vwgpu_pyramid_group_impl): the same filter over `tiles` images at a fixed stride of tile_ints ints, for the
+  // source, the padded intermediate and the destination alike — one launch (blockIdx.z); the second pass is the caller's (inner_only)
   if (hh < 0 || hv < 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "disparity filter: negative half kernel");
   const size_t rm_lds = (size_t)(32 + 2 * hh) * (8 + 2 * hv) * 13;
   const bool direct = rm_lds > 64 * 1024;
+  if (tiles > 1 && (direct || (cleanup && !inner_only))) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "disparity filter: this form is not built for tile groups");
+  const size_t ts = tiles > 1 ? tile_ints : 0;
   // fabs((double)int32 difference) <= pthr  <=>  |difference| <= floor(pthr)
   const int never = !(pthr >= 0.0);                                   // negative or NaN: nothing matches
   const unsigned thr = never ? 0u : (pthr >= 4294967295.0 ? 0xffffffffu : (unsigned)std::floor(pthr));
-  auto rm_grid = [](int ww, int hh2) { return dim3((unsigned)((ww + 31) / 32), (unsigned)((hh2 + 7) / 8)); };
+  auto rm_grid = [tiles](int ww, int hh2) { return dim3((unsigned)((ww + 31) / 32), (unsigned)((hh2 + 7) / 8), (unsigned)std::max(tiles, 1)); };
   if (!cleanup) {
     vwgpu_prof_scope ps(ctx, "rm_outliers");
     if (direct) hipLaunchKernelGGL(rm_outliers_direct_kernel, grid2(w, h), kBlk, 0, ctx->stream, src, w, h, hh, hv, pthr, rthr, dst, w, h, 0, 0);
-    else if (hh == 5 && hv == 5) hipLaunchKernelGGL(rm_outliers_kernel<5>, rm_grid(w, h), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr, dst, w, h, 0, 0);
-    else hipLaunchKernelGGL(rm_outliers_kernel<0>, rm_grid(w, h), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr, dst, w, h, 0, 0);
+    else if (hh == 5 && hv == 5) hipLaunchKernelGGL(rm_outliers_kernel<5>, rm_grid(w, h), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr, dst, w, h, 0, 0, ts, ts);
+    else hipLaunchKernelGGL(rm_outliers_kernel<0>, rm_grid(w, h), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr, dst, w, h, 0, 0, ts, ts);
   } else {
     {
       vwgpu_prof_scope ps(ctx, "rm_outliers");
       if (direct) hipLaunchKernelGGL(rm_outliers_direct_kernel, grid2(w + 2, h + 2), kBlk, 0, ctx->stream, src, w, h, hh, hv, pthr, rthr,
                                      tmp_padded, w + 2, h + 2, -1, -1);
       else if (hh == 5 && hv == 5) hipLaunchKernelGGL(rm_outliers_kernel<5>, rm_grid(w + 2, h + 2), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr,
-                                                      tmp_padded, w + 2, h + 2, -1, -1);
+                                                      tmp_padded, w + 2, h + 2, -1, -1, ts, ts);
       else hipLaunchKernelGGL(rm_outliers_kernel<0>, rm_grid(w + 2, h + 2), dim3(32, 8), rm_lds, ctx->stream, src, w, h, hh, hv, thr, never, rthr,
-                              tmp_padded, w + 2, h + 2, -1, -1);
+                              tmp_padded, w + 2, h + 2, -1, -1, ts, ts);
     }
     if (!inner_only) {                                              // (inner_only: the caller applies the second pass itself, see zone_extent_fused_kernel)
       vwgpu_prof_scope ps(ctx, "disparity_cleanup_outer");
@@ -489,9 +518,10 @@ int vwgpu_launch_disparity_mask(vwgpu_ctx* ctx, int32_t* d, int w, int h, const 
 // disparities inside the box and inside the box grown by 1 px (clipped to the image) — what subdivide_regions reads
 // (Correlation.cc:149-171).  out: 10 ints per leaf (vwgpu::LeafExtent).
 __global__ void __launch_bounds__(64)
-zone_extent_kernel(const int32_t* __restrict__ disp, int w, int h, const int4* __restrict__ rects, int n, int32_t* __restrict__ out) {
+zone_extent_kernel(const int32_t* __restrict__ disp, int w, int h, const int4* __restrict__ rects, int n, int32_t* __restrict__ out, size_t disp_tile = 0) {
   const int leaf = blockIdx.x;
   if (leaf >= n) return;
+  disp += blockIdx.y * disp_tile; out += (size_t)blockIdx.y * n * 10;      // tile groups: blockIdx.y = the tile
   const int4 r = rects[leaf];                       // x0, y0, x1, y1
   const int ax0 = max(r.x - 1, 0), ay0 = max(r.y - 1, 0), ax1 = min(r.z + 1, w), ay1 = min(r.w + 1, h);
   const int aw = ax1 - ax0, count = aw * (ay1 - ay0);
@@ -528,9 +558,11 @@ zone_extent_kernel(const int32_t* __restrict__ disp, int w, int h, const int4* _
 // at as they are read, and the image itself is never written (two launches per level less; the small levels are launch bound).
 __global__ void __launch_bounds__(64)
 zone_extent_fused_kernel(const int32_t* __restrict__ inner, int w, int h, const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
-                         int m2w, int m2h, const int4* __restrict__ rects, int n, int32_t* __restrict__ out) {
+                         int m2w, int m2h, const int4* __restrict__ rects, int n, int32_t* __restrict__ out,
+                         size_t inner_tile = 0, size_t mask_tile = 0) {
   const int leaf = blockIdx.x;
   if (leaf >= n) return;
+  inner += blockIdx.y * inner_tile; m1 += blockIdx.y * mask_tile; m2 += blockIdx.y * mask_tile; out += (size_t)blockIdx.y * n * 10;      // tile groups
   const int4 r = rects[leaf];                       // x0, y0, x1, y1
   const int ax0 = max(r.x - 1, 0), ay0 = max(r.y - 1, 0), ax1 = min(r.z + 1, w), ay1 = min(r.w + 1, h);
   const int aw = ax1 - ax0, count = aw * (ay1 - ay0);
@@ -1182,6 +1214,452 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   return VWGPU_OK;
 }
 
+// ---- tile groups (round 5) ------------------------------------------------------------------------------------------
+// vwgpu_pyramid_correlate_batch: several tiles of ONE image pair, of equal size, through the level loop TOGETHER.  The reference runs one
+// tile per thread (src/vw/Image/ImageIO.h:228-251, BlockProcessor.h:52-176); here a tile is ~50 dependent launches of which the coarse levels
+// are pure latency (images of 40 .. 300 pixels), and the device advances only 3 - 4 such chains at once however many tile threads feed it
+// (profiles/r04_ubench_streams.txt).  A group of tiles shares every launch: the tiles' buffers have the same sizes (same bbox size, search
+// range and kernel) and live in per-tile slices of one arena at a FIXED STRIDE, so a kernel finds tile t's image at base + t * slice
+// (blockIdx.z / .y = the tile) and the zone matcher takes the zones of all tiles in one table (vwgpu_zone_group).  One host round trip per
+// level serves the whole group: the leaf extents of all tiles come back together and the zone scheduler (zones.hip) runs per tile on them.
+// Every tile's result is what vwgpu_pyramid_correlate_impl computes for it alone: same kernels, same arithmetic, same zone lists — the tiles
+// never read each other's data.  Eligible: block matching without an lr_disp_diff image, blob filter or time budget; anything else runs
+// tile by tile through vwgpu_pyramid_correlate_impl.
+namespace {
+
+struct GroupLayout {                       // offsets (bytes) inside a tile's slice of the arena; sizes per level
+  std::vector<size_t> lp, rp, lpf, rpf, lmp, rmp;
+  std::vector<int> lpw, lph, rpw, rph, lmw, lmh, rmw, rmh;
+  size_t lmx = 0, rmx = 0, d_acc = 0, d_part = 0, d_cell = 0, d_cells = 0, disp = 0, disp2 = 0, padded = 0;
+  size_t slice = 0;
+};
+
+struct GroupTile {
+  IBox bbox, lg, rg, rmb;
+  bool alive = true;                       // false: a fully masked image (the tile is zeros, CorrelationView.cc:318-327)
+  std::vector<SearchZone> zones;
+  std::vector<char> exact_level, f32_level;
+  std::vector<int> cert_hi;
+};
+
+}  // namespace
+
+bool vwgpu_pyramid_group_eligible(const vwgpu_ctx* ctx, const vwgpu_pyramid_params* P, int n, const int* bw, const int* bh) {
+  if (n < 2 || n > VWGPU_MAX_GROUP) return false;
+  if (P->algorithm != 0 || P->lr_disp_diff || P->blob_filter_area > 0 || P->corr_timeout > 0) return false;
+  if (ctx->forced_path != VWGPU_PATH_NONE || !vwgpu_bm_zones_supported(P->kernel_x, P->kernel_y)) return false;
+  if ((size_t)(32 + 2 * P->filter_half_kernel) * (8 + 2 * P->filter_half_kernel) * 13 > 64 * 1024) return false;      // (the LDS form of the clean-up filter)
+  for (int i = 1; i < n; ++i) if (bw[i] != bw[0] || bh[i] != bh[0]) return false;
+  return bw[0] > 0 && bh[0] > 0;
+}
+
+// All pointers are device pointers (masks may be null).  outs[t]: bw x bh x 3 floats with row stride oss[t] pixels.
+int vwgpu_pyramid_group_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t ls, const float* right, int rw, int rh, ptrdiff_t rs,
+                             const uint8_t* lmask, ptrdiff_t lms, const uint8_t* rmask, ptrdiff_t rms, const vwgpu_pyramid_params* P,
+                             int n, const int* bxs, const int* bys, int bw, int bh, float* const* outs, const ptrdiff_t* oss) {
+  const int kx = P->kernel_x, ky = P->kernel_y;
+  const IBox search(P->search_min_x, P->search_min_y, P->search_max_x, P->search_max_y);
+  hipStream_t st = ctx->stream;
+  // number of levels (CorrelationView.h:99-105, CorrelationView.cc:301-310): the same for every tile of the group
+  const int largest_search = std::max(search.dx(), search.dy());
+  int by_search = (int)(std::floor(std::log(float(largest_search)) / std::log(2.0f)) - 1);
+  by_search = std::max(0, std::min(by_search, P->max_pyramid_levels));
+  int L = (int)std::floor(std::log((double)std::min(bw, bh)) / std::log(2.0f) - std::log((double)std::max(kx, ky)) / std::log(2.0f));
+  L = std::min(L, by_search);
+  if (L < 1) L = 0;
+  const int hkx = kx / 2, hky = ky / 2, up = 1 << L;
+  const bool filtered = P->prefilter_mode == VWGPU_PREFILTER_LOG || P->prefilter_mode == VWGPU_PREFILTER_MEANSUB;
+  constexpr int CS = 16, NB = 256;
+
+  std::vector<GroupTile> T((size_t)n);
+  for (int t = 0; t < n; ++t) {
+    GroupTile& g = T[t];
+    g.bbox = IBox(bxs[t], bys[t], bxs[t] + bw, bys[t] + bh);
+    g.lg = g.bbox; g.lg.x0 -= hkx * up; g.lg.x1 += hkx * up; g.lg.y0 -= hky * up; g.lg.y1 += hky * up;
+    g.rg = IBox(g.lg.x0 + search.x0, g.lg.y0 + search.y0, g.lg.x1 + search.x0 + search.dx(), g.lg.y1 + search.y0 + search.dy());
+    g.rmb = IBox(g.bbox.x0 + search.x0, g.bbox.y0 + search.y0, g.bbox.x1 + search.x0 + search.dx(), g.bbox.y1 + search.y0 + search.dy());
+    g.exact_level.assign(L + 1, 0); g.f32_level.assign(L + 1, 0); g.cert_hi.assign(L + 1, INT_MIN);
+  }
+  // the layout of a tile's slice: the geometry of tile 0 is every tile's
+  GroupLayout Y;
+  {
+    Bump A{nullptr, SIZE_MAX};
+    auto off = [&](void* p) { return (size_t)reinterpret_cast<uintptr_t>(p); };
+    const IBox &lg = T[0].lg, &rg = T[0].rg, &rmb = T[0].rmb;
+    Y.lp.resize(L + 1); Y.rp.resize(L + 1); Y.lpf.resize(L + 1); Y.rpf.resize(L + 1); Y.lmp.resize(L + 1); Y.rmp.resize(L + 1);
+    Y.lpw.resize(L + 1); Y.lph.resize(L + 1); Y.rpw.resize(L + 1); Y.rph.resize(L + 1); Y.lmw.resize(L + 1); Y.lmh.resize(L + 1); Y.rmw.resize(L + 1); Y.rmh.resize(L + 1);
+    Y.lpw[0] = lg.dx(); Y.lph[0] = lg.dy(); Y.rpw[0] = rg.dx(); Y.rph[0] = rg.dy();
+    Y.lmw[0] = bw; Y.lmh[0] = bh; Y.rmw[0] = rmb.dx(); Y.rmh[0] = rmb.dy();
+    const size_t nl = (size_t)lg.dx() * lg.dy(), nr = (size_t)rg.dx() * rg.dy();
+    A.take<char>(256);                                            // (offset 0 stays unused: a null offset means "not there")
+    Y.lp[0] = off(A.take<float>(nl)); Y.rp[0] = off(A.take<float>(nr));
+    Y.lmx = off(A.take<uint8_t>(nl)); Y.rmx = off(A.take<uint8_t>(nr));
+    Y.lmp[0] = off(A.take<uint8_t>((size_t)bw * bh)); Y.rmp[0] = off(A.take<uint8_t>((size_t)rmb.dx() * rmb.dy()));
+    Y.d_acc = off(A.take<double>(4)); Y.d_part = off(A.take<double>(2 * 2 * NB)); Y.d_cell = off(A.take<int>(8));
+    for (int i = 1; i <= L; ++i) {
+      Y.lpw[i] = 1 + (Y.lpw[i - 1] - 1) / 2; Y.lph[i] = 1 + (Y.lph[i - 1] - 1) / 2; Y.rpw[i] = 1 + (Y.rpw[i - 1] - 1) / 2; Y.rph[i] = 1 + (Y.rph[i - 1] - 1) / 2;
+      Y.lmw[i] = 1 + (Y.lmw[i - 1] - 1) / 2; Y.lmh[i] = 1 + (Y.lmh[i - 1] - 1) / 2; Y.rmw[i] = 1 + (Y.rmw[i - 1] - 1) / 2; Y.rmh[i] = 1 + (Y.rmh[i - 1] - 1) / 2;
+      Y.lp[i] = off(A.take<float>((size_t)Y.lpw[i] * Y.lph[i])); Y.rp[i] = off(A.take<float>((size_t)Y.rpw[i] * Y.rph[i]));
+      Y.lmp[i] = off(A.take<uint8_t>((size_t)Y.lmw[i] * Y.lmh[i])); Y.rmp[i] = off(A.take<uint8_t>((size_t)Y.rmw[i] * Y.rmh[i]));
+    }
+    for (int i = 0; i <= L; ++i) {
+      Y.lpf[i] = filtered ? off(A.take<float>((size_t)Y.lpw[i] * Y.lph[i])) : Y.lp[i];
+      Y.rpf[i] = filtered ? off(A.take<float>((size_t)Y.rpw[i] * Y.rph[i])) : Y.rp[i];
+    }
+    Y.d_cells = off(A.take<int>(CS * (size_t)(L + 1)));
+    Y.disp = off(A.take<int32_t>((size_t)bw * bh * 3)); Y.disp2 = off(A.take<int32_t>((size_t)bw * bh * 3));
+    Y.padded = off(A.take<int32_t>((size_t)(bw + 2) * (bh + 2) * 3));
+    Y.slice = vwgpu_align_up(A.off + 256, 768);                  // a multiple of 12 (a disparity pixel), of 8 and of 256
+  }
+  // group-level tables behind the slices: the certified passes' flag words, the R->L need records and cells (bounds as in the single-tile arena)
+  const size_t tables = (size_t)n * ((size_t)(L + 1) * ((size_t)bw * bh / 64 + 64) * (48 + (size_t)(search.dx() / 16 + 3) * (search.dy() / 16 + 3)) + 8192) + (1 << 16);
+  int rc = vwgpu_arena_reserve(ctx, &ctx->pyr, (size_t)n * Y.slice + tables);
+  if (rc) return rc;
+  char* base = static_cast<char*>(ctx->pyr.base);
+  Bump GA{base + (size_t)n * Y.slice, tables};
+  auto fail_mem = [&]() { return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "pyramid_correlate (group): internal arena too small"); };
+  auto at = [&](int t, size_t off) -> char* { return base + (size_t)t * Y.slice + off; };
+  auto fimg = [&](int t, size_t off) { return reinterpret_cast<float*>(at(t, off)); };
+  auto bimg = [&](int t, size_t off) { return reinterpret_cast<uint8_t*>(at(t, off)); };
+  const size_t slice_f = Y.slice / 4, slice_i = Y.slice / 4, slice_px = Y.slice / 12;
+
+  // ---- base crops, nodata mean fill (CorrelationView.cc:67-149) ----
+  for (int t = 0; t < n; ++t) {
+    const GroupTile& g = T[t];
+    vwgpu_prof_scope ps(ctx, "pyramid_base_crops");
+    CropJobs cj;
+    cj.j[0] = CropJob{left, ls, lw, lh, g.lg.x0, g.lg.y0, fimg(t, Y.lp[0]), Y.lpw[0], Y.lph[0], 1, 0};
+    cj.j[1] = CropJob{right, rs, rw, rh, g.rg.x0, g.rg.y0, fimg(t, Y.rp[0]), Y.rpw[0], Y.rph[0], 1, 0};
+    cj.j[2] = CropJob{lmask, lms, lw, lh, g.lg.x0, g.lg.y0, bimg(t, Y.lmx), Y.lpw[0], Y.lph[0], 0, 0};
+    cj.j[3] = CropJob{rmask, rms, rw, rh, g.rg.x0, g.rg.y0, bimg(t, Y.rmx), Y.rpw[0], Y.rph[0], 0, 0};
+    cj.j[4] = CropJob{lmask, lms, lw, lh, g.bbox.x0, g.bbox.y0, bimg(t, Y.lmp[0]), bw, bh, 0, 1};
+    cj.j[5] = CropJob{rmask, rms, rw, rh, g.rmb.x0, g.rmb.y0, bimg(t, Y.rmp[0]), Y.rmw[0], Y.rmh[0], 0, 1};
+    const int cmw = std::max(std::max(Y.lpw[0], Y.rpw[0]), std::max(bw, Y.rmw[0])), cmh = std::max(std::max(Y.lph[0], Y.rph[0]), std::max(bh, Y.rmh[0]));
+    hipLaunchKernelGGL(crop_jobs_kernel, dim3((cmw + 63) / 64, (cmh + 3) / 4, 6), kBlk, 0, st, cj);
+  }
+  const bool l_all = !lmask, r_all = !rmask;
+  const size_t nl = (size_t)Y.lpw[0] * Y.lph[0], nr = (size_t)Y.rpw[0] * Y.rph[0];
+  if (!(l_all && r_all)) {
+    // the reductions of every tile are queued, ONE synchronisation brings all partial sums back (pinned ring; the pageable fallback waits per copy)
+    std::vector<double> part((size_t)n * 4 * NB);
+    std::vector<int> cell((size_t)n * 8);
+    const int init[8] = {INT_MAX, INT_MIN, 0, 0, INT_MAX, INT_MIN, 0, 0};
+    for (int t = 0; t < n; ++t) {
+      double* d_part = reinterpret_cast<double*>(at(t, Y.d_part));
+      int* d_cell = reinterpret_cast<int*>(at(t, Y.d_cell));
+      VWGPU_HIP(ctx, hipMemcpyAsync(d_cell, init, sizeof init, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(masked_mean_kernel, dim3(16, 16), kBlk, 0, st, fimg(t, Y.lp[0]), bimg(t, Y.lmx), Y.lpw[0], Y.lph[0], d_part, d_cell);
+      hipLaunchKernelGGL(masked_mean_kernel, dim3(16, 16), kBlk, 0, st, fimg(t, Y.rp[0]), bimg(t, Y.rmx), Y.rpw[0], Y.rph[0], d_part + 2 * NB, d_cell + 4);
+      VWGPU_HIP(ctx, hipMemcpyAsync(part.data() + (size_t)t * 4 * NB, d_part, 4 * NB * sizeof(double), hipMemcpyDeviceToHost, st));
+      VWGPU_HIP(ctx, hipMemcpyAsync(cell.data() + (size_t)t * 8, d_cell, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+    }
+    VWGPU_HIP(ctx, hipStreamSynchronize(st));
+    std::vector<double> acc((size_t)n * 4, 0.0);
+    std::vector<char> serial((size_t)n * 2, 0);
+    bool any_serial = false;
+    for (int t = 0; t < n; ++t)
+      for (int im = 0; im < 2; ++im) {
+        double s_ = 0.0, n_ = 0.0;
+        for (int b = 0; b < NB; ++b) { s_ += part[(size_t)t * 4 * NB + (im * NB + b) * 2]; n_ += part[(size_t)t * 4 * NB + (im * NB + b) * 2 + 1]; }
+        acc[t * 4 + 2 * im] = s_; acc[t * 4 + 2 * im + 1] = n_;
+        const int lo = cell[t * 8 + 4 * im], hi = cell[t * 8 + 4 * im + 1];
+        int lgn = 0;
+        while ((1LL << lgn) < (long long)n_ + 1) ++lgn;
+        serial[t * 2 + im] = cell[t * 8 + 4 * im + 2] != 0 || (lo != INT_MAX && (long long)hi + 1 + lgn - lo > 53);
+        any_serial = any_serial || serial[t * 2 + im];
+      }
+    if (any_serial) {
+      std::vector<double> got((size_t)n * 4, 0.0);
+      for (int t = 0; t < n; ++t) {
+        double* d_acc = reinterpret_cast<double*>(at(t, Y.d_acc));
+        if (serial[t * 2]) hipLaunchKernelGGL(masked_mean_serial_kernel, dim3(1), dim3(64), 0, st, fimg(t, Y.lp[0]), bimg(t, Y.lmx), Y.lpw[0], Y.lph[0], d_acc);
+        if (serial[t * 2 + 1]) hipLaunchKernelGGL(masked_mean_serial_kernel, dim3(1), dim3(64), 0, st, fimg(t, Y.rp[0]), bimg(t, Y.rmx), Y.rpw[0], Y.rph[0], d_acc + 2);
+        if (serial[t * 2] || serial[t * 2 + 1]) VWGPU_HIP(ctx, hipMemcpyAsync(got.data() + (size_t)t * 4, d_acc, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+      }
+      VWGPU_HIP(ctx, hipStreamSynchronize(st));
+      for (int t = 0; t < n; ++t) {
+        if (serial[t * 2]) { acc[t * 4] = got[t * 4]; acc[t * 4 + 1] = got[t * 4 + 1]; }
+        if (serial[t * 2 + 1]) { acc[t * 4 + 2] = got[t * 4 + 2]; acc[t * 4 + 3] = got[t * 4 + 3]; }
+      }
+    }
+    for (int t = 0; t < n; ++t) {
+      // (without a mask an image's crop mask is all valid: its mean is not needed, as in the single-tile path)
+      if ((!l_all && acc[t * 4 + 1] == 0.0) || (!r_all && acc[t * 4 + 3] == 0.0)) { T[t].alive = false; continue; }
+      if (!l_all) hipLaunchKernelGGL(fill_masked_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, fimg(t, Y.lp[0]), bimg(t, Y.lmx), nl, (float)(acc[t * 4] / acc[t * 4 + 1]));
+      if (!r_all) hipLaunchKernelGGL(fill_masked_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, fimg(t, Y.rp[0]), bimg(t, Y.rmx), nr, (float)(acc[t * 4 + 2] / acc[t * 4 + 3]));
+    }
+  }
+  // ---- smoothing + decimation chain, mask decimation (:205-216): the four jobs of every tile of a level, VWGPU_MAX_IMG_JOBS per launch ----
+  const float k5[5] = {(float)(1.0 / 16.0), (float)(4.0 / 16.0), (float)(6.0 / 16.0), (float)(4.0 / 16.0), (float)(1.0 / 16.0)};
+  for (int i = 1; i <= L; ++i) {
+    std::vector<vwgpu_img_job> jobs;
+    for (int t = 0; t < n; ++t) {
+      jobs.push_back({fimg(t, Y.lp[i - 1]), Y.lpw[i - 1], Y.lpw[i - 1], Y.lph[i - 1], fimg(t, Y.lp[i]), Y.lpw[i], Y.lpw[i], Y.lph[i], 0, 0, nullptr, 0});
+      jobs.push_back({fimg(t, Y.rp[i - 1]), Y.rpw[i - 1], Y.rpw[i - 1], Y.rph[i - 1], fimg(t, Y.rp[i]), Y.rpw[i], Y.rpw[i], Y.rph[i], 0, 0, nullptr, 0});
+      jobs.push_back({bimg(t, Y.lmp[i - 1]), Y.lmw[i - 1], Y.lmw[i - 1], Y.lmh[i - 1], bimg(t, Y.lmp[i]), Y.lmw[i], Y.lmw[i], Y.lmh[i], 0, 0, nullptr, VWGPU_JOB_MASK_BY_TWO});
+      jobs.push_back({bimg(t, Y.rmp[i - 1]), Y.rmw[i - 1], Y.rmw[i - 1], Y.rmh[i - 1], bimg(t, Y.rmp[i]), Y.rmw[i], Y.rmw[i], Y.rmh[i], 0, 0, nullptr, VWGPU_JOB_MASK_BY_TWO});
+    }
+    for (size_t j0 = 0; j0 < jobs.size(); j0 += VWGPU_MAX_IMG_JOBS)
+      if ((rc = vwgpu_launch_sepconv_jobs(ctx, jobs.data() + j0, (int)std::min<size_t>(VWGPU_MAX_IMG_JOBS, jobs.size() - j0), k5, 5, 2, k5, 5, 2, 0, 2))) return rc;
+  }
+  // ---- prefilter every level into copies (:232-236), level by level so that a launch holds images of one size ----
+  if (filtered) {
+    std::vector<const float*> fs; std::vector<float*> fd; std::vector<int> fw, fh;
+    for (int i = 0; i <= L; ++i)
+      for (int t = 0; t < n; ++t) {
+        fs.push_back(fimg(t, Y.lp[i])); fd.push_back(fimg(t, Y.lpf[i])); fw.push_back(Y.lpw[i]); fh.push_back(Y.lph[i]);
+        fs.push_back(fimg(t, Y.rp[i])); fd.push_back(fimg(t, Y.rpf[i])); fw.push_back(Y.rpw[i]); fh.push_back(Y.rph[i]);
+      }
+    if ((rc = vwgpu_prefilter_images_dev(ctx, (int)fs.size(), fs.data(), fw.data(), fh.data(), P->prefilter_mode, P->prefilter_width, fd.data()))) return rc;
+  }
+  // ---- class of every level of every tile: ONE read-back for the group ----
+  {
+    std::vector<int> cells((size_t)n * CS * (L + 1), 0);
+    for (int t = 0; t < n; ++t)
+      for (int i = 0; i <= L; ++i) { int* c = cells.data() + ((size_t)t * (L + 1) + i) * CS; c[0] = INT_MAX; c[1] = INT_MIN; }
+    std::vector<const float*> gi; std::vector<int> gw, gh; std::vector<ptrdiff_t> gs; std::vector<int*> gc;
+    for (int t = 0; t < n; ++t) {
+      int* d_cells = reinterpret_cast<int*>(at(t, Y.d_cells));
+      VWGPU_HIP(ctx, hipMemcpyAsync(d_cells, cells.data() + (size_t)t * (L + 1) * CS, (size_t)(L + 1) * CS * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    for (int i = 0; i <= L; ++i)
+      for (int t = 0; t < n; ++t) {
+        int* d_cells = reinterpret_cast<int*>(at(t, Y.d_cells));
+        gi.push_back(fimg(t, Y.lpf[i])); gw.push_back(Y.lpw[i]); gh.push_back(Y.lph[i]); gs.push_back(Y.lpw[i]); gc.push_back(d_cells + CS * i);
+        gi.push_back(fimg(t, Y.rpf[i])); gw.push_back(Y.rpw[i]); gh.push_back(Y.rph[i]); gs.push_back(Y.rpw[i]); gc.push_back(d_cells + CS * i);
+      }
+    vwgpu_launch_float_grain(ctx, (int)gi.size(), gi.data(), gw.data(), gh.data(), gs.data(), gc.data());
+    for (int t = 0; t < n; ++t)
+      VWGPU_HIP(ctx, hipMemcpyAsync(cells.data() + (size_t)t * (L + 1) * CS, at(t, Y.d_cells), (size_t)(L + 1) * CS * sizeof(int), hipMemcpyDeviceToHost, st));
+    VWGPU_HIP(ctx, hipStreamSynchronize(st));
+    for (int t = 0; t < n; ++t)
+      for (int i = 0; i <= L; ++i) {
+        const int* c = cells.data() + ((size_t)t * (L + 1) + i) * CS;
+        T[t].exact_level[i] = !vwgpu_sums_order_free(P->cost_type, kx, ky, c[0], c[1], c[2]);
+        T[t].f32_level[i] = vwgpu_sums_bits(P->cost_type, kx, ky, c[0], c[1], c[2]) <= 24;
+        if (T[t].exact_level[i] && ctx->certify && (c[2] & 1) == 0 && c[0] != INT_MAX && c[1] < 60 && c[1] > -60) T[t].cert_hi[i] = c[1];
+      }
+  }
+  unsigned long long* d_cert_stats = nullptr;
+  if (ctx->trace & 4) {
+    d_cert_stats = GA.take<unsigned long long>(4);
+    if (!d_cert_stats) return fail_mem();
+    VWGPU_HIP(ctx, hipMemsetAsync(d_cert_stats, 0, 32, st));
+  }
+  for (int t = 0; t < n; ++t)
+    if (T[t].alive) T[t].zones.push_back(SearchZone{IBox(0, 0, Y.lmw[L], Y.lmh[L]), IBox(0, 0, search.width() / up + 1, search.height() / up + 1)});
+
+  // ---- level loop ----
+  size_t disp_off = Y.disp, disp2_off = Y.disp2;                   // (the two disparity buffers of every tile swap together)
+  int dw = 0, dh = 0;
+  for (int level = L; level >= 0; --level) {
+    const bool last = (level == 0);
+    const int scaling = 1 << level;
+    dw = Y.lmw[level]; dh = Y.lmh[level];
+    VWGPU_HIP(ctx, hipMemset2DAsync(at(0, disp_off), Y.slice, 0, (size_t)dw * dh * 12, (size_t)n, st));
+    int32_t* disp0 = reinterpret_cast<int32_t*>(at(0, disp_off));
+    const int rox = up * hkx / scaling, roy = up * hky / scaling;
+    const bool lr_active = P->consistency_threshold >= 0 && last;
+    const int aw_ = Y.lpw[level], ah_ = Y.lph[level], bw_ = Y.rpw[level], bh_ = Y.rph[level];
+    const float* A0 = fimg(0, Y.lpf[level]);
+    const float* B0 = fimg(0, Y.rpf[level]);
+    // zone tasks of every tile, sorted into the kernel classes of this level: 0 = order free with float32 sums, 1 = order free, 2 = certified,
+    // 3 = the reference's order only (a non-finite pixel, or VWGPU_OPT_CERTIFY = 0)
+    std::vector<vwgpu_zone_task> t1[4], t2[4], t3[4];
+    std::vector<int> cls((size_t)n, -1);
+    size_t rl_pixels = 0;
+    for (int t = 0; t < n; ++t) {
+      GroupTile& g = T[t];
+      if (!g.alive) continue;
+      bool exact = g.exact_level[level] != 0;
+      for (SearchZone const& z : g.zones)
+        if (z.range.dx() > 0 && z.range.dy() > 0) exact = exact && vwgpu_bm_exact_supported(z.range.dx(), z.range.dy());      // (as the single-tile path: the tile kernels otherwise)
+      const int c = exact ? (g.cert_hi[level] != INT_MIN ? 2 : 3) : (g.f32_level[level] ? 0 : 1);
+      cls[t] = c;
+      for (SearchZone const& z : g.zones) {
+        const IBox lr(z.region.x0 + rox - hkx, z.region.y0 + roy - hky, z.region.x1 + rox + hkx, z.region.y1 + roy + hky);
+        const IBox rr(lr.x0 + z.range.x0, lr.y0 + z.range.y0, lr.x1 + z.range.x0 + z.range.dx(), lr.y1 + z.range.y0 + z.range.dy());
+        const int zw = z.region.dx(), zh = z.region.dy(), sx = z.range.dx(), sy = z.range.dy();
+        if (zw <= 0 || zh <= 0 || sx <= 0 || sy <= 0) continue;
+        if (zw > 65535 * 32 || zh > 65535 * 32) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: zone too large");
+        const long long out_off = (long long)t * (long long)slice_px + (long long)z.region.y0 * dw + z.region.x0;
+        if (out_off > INT32_MAX) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: tile group too large for the zone tables");
+        vwgpu_zone_task a{lr.x0, lr.y0, rr.x0, rr.y0, zw, zh, sx, sy, (int)out_off, dw, lr_active ? 0 : z.range.x0, lr_active ? 0 : z.range.y0, t};
+        t1[c].push_back(a);
+        if (lr_active) {
+          const int rlw = rr.dx() - kx + 1, rlh = rr.dy() - ky + 1;
+          vwgpu_zone_task b{rr.x0, rr.y0, lr.x0 - sx, lr.y0 - sy, rlw, rlh, sx, sy, (int)rl_pixels, rlw, -sx, -sy, t};
+          t2[c].push_back(b);
+          vwgpu_zone_task cc{(int)rl_pixels, 0, rlw, rlh, zw, zh, 0, 0, a.out_off, dw, z.range.x0, z.range.y0, t};
+          t3[c].push_back(cc);
+          rl_pixels += (size_t)rlw * rlh;
+          if (rl_pixels > (size_t)INT32_MAX / 2) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: tile group too large for the L/R check buffers");
+        }
+      }
+    }
+    if (lr_active && rl_pixels) { if ((rc = vwgpu_arena_reserve(ctx, &ctx->zrl, rl_pixels * 12))) return rc; }
+    int32_t* rlbuf = static_cast<int32_t*>(ctx->zrl.base);
+    // the "cannot matter" certificate (see vwgpu_pyramid_correlate_impl): margins per level, bounds per tile
+    const int edge_k = rox - hkx;
+    const int edge_m_lr = P->filter_half_kernel > 0 ? P->filter_half_kernel + (last ? 4 : 8) : 0;
+    const int edge_m_rl = (P->consistency_threshold >= 0 && P->consistency_threshold < 1e6) ? (int)std::floor(P->consistency_threshold) + 2 : 0;
+    std::vector<int> lr_lo((size_t)n), lr_hi((size_t)n), rl_lo((size_t)n, -edge_m_rl + 1), rl_hi((size_t)n, dw + edge_m_rl - 2), hi_img((size_t)n, INT_MIN);
+    for (int t = 0; t < n; ++t) {
+      const int rv0 = std::max(0, -T[t].rmb.x0) >> level, rv1 = (std::min(Y.rmw[0], rw - T[t].rmb.x0) + (1 << level) - 1) >> level;
+      lr_lo[t] = rv0 - edge_m_lr + 1; lr_hi[t] = rv1 + edge_m_lr - 2;
+      hi_img[t] = T[t].cert_hi[level];
+    }
+    vwgpu_zone_group grp;
+    grp.n_img = n; grp.a_stride = slice_f; grp.b_stride = slice_f;
+    // certified classes: flag words {any per pass and tile: 2 n} + zone flags of both passes, one block, one fill
+    int* d_any = nullptr; int* zflag1 = nullptr; int* zflag2 = nullptr;
+    if (!t1[2].empty()) {
+      const size_t nflag = 64 + 2 * (size_t)n + t1[2].size() + t2[2].size();
+      d_any = GA.take<int>(nflag);
+      if (!d_any) return fail_mem();
+      VWGPU_HIP(ctx, hipMemsetAsync(d_any, 0, nflag * sizeof(int), st));
+      zflag1 = d_any + 64 + 2 * n; zflag2 = zflag1 + t1[2].size();
+    }
+    for (int c = 0; c < 4; ++c) {
+      if (t1[c].empty()) continue;
+      if (c == 3) {                                              // the reference's order: tile by tile (zones of one image pair per call)
+        for (int t = 0; t < n; ++t) {
+          if (cls[t] != 3) continue;
+          std::vector<vwgpu_zone_task> za, zb;
+          for (auto const& z : t1[3]) if (z.img == t) za.push_back(z);
+          for (auto const& z : t2[3]) if (z.img == t) zb.push_back(z);
+          const float* At = A0 + (size_t)t * slice_f; const float* Bt = B0 + (size_t)t * slice_f;
+          if (!za.empty() && (rc = vwgpu_launch_bm_exact(ctx, P->cost_type, At, aw_, ah_, aw_, Bt, bw_, bh_, bw_, kx, ky, za.data(), (int)za.size(), disp0))) return rc;
+          if (!zb.empty() && (rc = vwgpu_launch_bm_exact(ctx, P->cost_type, Bt, bw_, bh_, bw_, At, aw_, ah_, aw_, kx, ky, zb.data(), (int)zb.size(), rlbuf))) return rc;
+        }
+        continue;
+      }
+      const bool cert = c == 2;
+      grp.cert_hi = cert ? hi_img.data() : nullptr;
+      grp.edge_lo = lr_lo.data(); grp.edge_hi = lr_hi.data();
+      rc = vwgpu_launch_bm_zones(ctx, P->cost_type, A0, aw_, ah_, B0, bw_, bh_, kx, ky, t1[c].data(), (int)t1[c].size(), disp0, c == 0 ? 1 : 0,
+                                 cert ? 0 : INT_MIN, cert ? zflag1 : nullptr, cert ? d_cert_stats : nullptr, cert ? d_any : nullptr, nullptr, nullptr,
+                                 cert ? edge_m_lr : 0, edge_k, 0, 0, 0, 0, &grp);
+      if (rc) return rc;
+      if (lr_active && !t2[c].empty()) {
+        const size_t ncells = vwgpu_zone_need_cells(t3[c].data(), (int)t3[c].size());
+        int* need = GA.take<int>(8 * t3[c].size() + (ncells + 16 + 3) / 4);
+        if (!need) return fail_mem();
+        unsigned char* cells = reinterpret_cast<unsigned char*>(need + 8 * t3[c].size());
+        if ((rc = vwgpu_launch_zone_need(ctx, t3[c].data(), (int)t3[c].size(), disp0, cert ? zflag1 : nullptr, need, cells, ncells))) return rc;
+        std::swap(grp.a_stride, grp.b_stride);                    // (equal anyway: the R->L pass matches the right image against the left)
+        grp.edge_lo = rl_lo.data(); grp.edge_hi = rl_hi.data();
+        rc = vwgpu_launch_bm_zones(ctx, P->cost_type, B0, bw_, bh_, A0, aw_, ah_, kx, ky, t2[c].data(), (int)t2[c].size(), rlbuf, c == 0 ? 1 : 0,
+                                   cert ? 0 : INT_MIN, cert ? zflag2 : nullptr, cert ? d_cert_stats : nullptr, cert ? d_any + n : nullptr, need, cells,
+                                   cert ? edge_m_rl : 0, edge_k, 0, 0, 0, 0, &grp);
+        if (rc) return rc;
+      }
+    }
+    if (d_any) {
+      // the flagged zones of the certified passes, per tile: one small read-back for the group, a second one only when some zone was flagged
+      std::vector<int> any(2 * (size_t)n, 0);
+      VWGPU_HIP(ctx, hipMemcpyAsync(any.data(), d_any, any.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+      VWGPU_HIP(ctx, hipStreamSynchronize(st));
+      bool some[2] = {false, false};
+      for (int t = 0; t < n; ++t) { some[0] = some[0] || any[t]; some[1] = some[1] || any[n + t]; }
+      for (int pass = 0; pass < 2; ++pass) {
+        if (!some[pass]) continue;
+        const std::vector<vwgpu_zone_task>& tz = pass ? t2[2] : t1[2];
+        std::vector<int> hflag(tz.size());
+        VWGPU_HIP(ctx, hipMemcpyAsync(hflag.data(), pass ? zflag2 : zflag1, hflag.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+        VWGPU_HIP(ctx, hipStreamSynchronize(st));
+        for (int t = 0; t < n; ++t) {
+          if (!any[pass * n + t]) continue;
+          std::vector<vwgpu_zone_task> redo;
+          for (size_t i = 0; i < tz.size(); ++i) if (hflag[i] && tz[i].img == t) redo.push_back(tz[i]);
+          if (redo.empty()) continue;
+          const float* At = A0 + (size_t)t * slice_f; const float* Bt = B0 + (size_t)t * slice_f;
+          if (pass == 0) rc = vwgpu_launch_bm_exact(ctx, P->cost_type, At, aw_, ah_, aw_, Bt, bw_, bh_, bw_, kx, ky, redo.data(), (int)redo.size(), disp0);
+          else rc = vwgpu_launch_bm_exact(ctx, P->cost_type, Bt, bw_, bh_, bw_, At, aw_, ah_, aw_, kx, ky, redo.data(), (int)redo.size(), rlbuf);
+          if (rc) return rc;
+        }
+      }
+    }
+    if (lr_active)
+      for (int c = 0; c < 4; ++c)
+        if (!t3[c].empty() && (rc = vwgpu_launch_zone_lr(ctx, t3[c].data(), (int)t3[c].size(), disp0, rlbuf, P->consistency_threshold, nullptr, 0))) return rc;
+    // ---- clean-up filters (:702-744) ----
+    int32_t* disp2_0 = reinterpret_cast<int32_t*>(at(0, disp2_off));
+    int32_t* padded0 = reinterpret_cast<int32_t*>(at(0, Y.padded));
+    const bool fused_extents = !last && P->filter_half_kernel > 0;       // second filter pass + mask applied by the zone scheduler's kernel as it reads
+    if (P->filter_half_kernel > 0) {
+      rc = vwgpu_launch_disparity_filter(ctx, disp0, dw, dh, P->filter_half_kernel, P->filter_half_kernel, 3.0, 0.5, !last, padded0, disp2_0, true, n, slice_i);
+      if (rc) return rc;
+      if (last) std::swap(disp_off, disp2_off);
+    }
+    // ---- zone refinement (:754-799): leaf extents of every tile in one launch, one copy, one synchronisation ----
+    if (!last) {
+      const std::vector<vwgpu::IBox>& leaves = vwgpu::cached_leaves(dw, dh);
+      const size_t nleaf = leaves.size();
+      int4* d_rects = nullptr;
+      for (auto& lr : ctx->leaf_rects)
+        if (lr.w == dw && lr.h == dh && lr.n == nleaf) d_rects = static_cast<int4*>(lr.d_rects);
+      if (!d_rects) {
+        void* p = nullptr;
+        VWGPU_HIP(ctx, hipMalloc(&p, std::max<size_t>(nleaf, 1) * sizeof(int4)));
+        VWGPU_HIP(ctx, hipMemcpyAsync(p, leaves.data(), nleaf * sizeof(int4), hipMemcpyHostToDevice, st));
+        VWGPU_HIP(ctx, hipStreamSynchronize(st));
+        if (ctx->leaf_rects.size() >= 64) { (void)hipFree(ctx->leaf_rects.front().d_rects); ctx->leaf_rects.erase(ctx->leaf_rects.begin()); }
+        ctx->leaf_rects.push_back({dw, dh, nleaf, p});
+        d_rects = static_cast<int4*>(p);
+      }
+      const size_t ext_bytes = (size_t)n * nleaf * sizeof(vwgpu::LeafExtent);
+      if ((rc = vwgpu_arena_reserve(ctx, &ctx->zext, ext_bytes + 256))) return rc;
+      int32_t* d_ext = static_cast<int32_t*>(ctx->zext.base);
+      {
+        vwgpu_prof_scope ps(ctx, "zone_extents");
+        if (fused_extents)
+          hipLaunchKernelGGL(zone_extent_fused_kernel, dim3((unsigned)nleaf, (unsigned)n), dim3(64), 0, st, padded0, dw, dh, bimg(0, Y.lmp[level]), bimg(0, Y.rmp[level]),
+                             Y.rmw[level], Y.rmh[level], d_rects, (int)nleaf, d_ext, slice_i, Y.slice);
+        else
+          hipLaunchKernelGGL(zone_extent_kernel, dim3((unsigned)nleaf, (unsigned)n), dim3(64), 0, st, reinterpret_cast<const int32_t*>(at(0, disp_off)), dw, dh, d_rects, (int)nleaf, d_ext, slice_i);
+      }
+      std::vector<vwgpu::LeafExtent> own;
+      const vwgpu::LeafExtent* h_ext = static_cast<const vwgpu::LeafExtent*>(vwgpu_host_ring(ctx, ext_bytes));
+      if (!h_ext) { own.resize((size_t)n * nleaf); h_ext = own.data(); }
+      VWGPU_HIP(ctx, hipMemcpyAsync(const_cast<vwgpu::LeafExtent*>(h_ext), d_ext, ext_bytes, hipMemcpyDeviceToHost, st));
+      VWGPU_HIP(ctx, hipStreamSynchronize(st));
+      const IBox scale_search(0, 0, Y.rpw[level - 1] - Y.lpw[level - 1], Y.rph[level - 1] - Y.lph[level - 1]);
+      const IBox next_size(0, 0, Y.lmw[level - 1], Y.lmh[level - 1]);
+      for (int t = 0; t < n; ++t) {
+        if (!T[t].alive) continue;
+        std::vector<SearchZone>& zones = T[t].zones;
+        zones.clear();
+        vwgpu::subdivide_regions_from_leaves(dw, dh, kx, ky, h_ext + (size_t)t * nleaf, nleaf, zones);
+        for (SearchZone& z : zones) {
+          z.region.scale(2);
+          z.region.clip(next_size);
+          z.range.scale(2);
+          z.range.expand(2);
+          z.range.clip(scale_search);
+          if (z.range.empty()) z.range = IBox(0, 0, search.width(), search.height());
+        }
+      }
+    }
+  }
+  if (dw != bw || dh != bh) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "PyramidCorrelation: Solved disparity doesn't match requested bbox size.");
+  {
+    GroupOuts go;
+    for (int t = 0; t < VWGPU_MAX_GROUP; ++t) { go.out[t] = nullptr; go.os[t] = 0; go.mode[t] = 0; }
+    for (int t = 0; t < n; ++t) { go.out[t] = outs[t]; go.os[t] = oss[t]; go.mode[t] = !T[t].alive ? 3 : (P->filter_half_kernel > 0 ? 2 : 1); }
+    hipLaunchKernelGGL(finish_group_kernel, dim3((bw + 63) / 64, (bh + 3) / 4, (unsigned)n), kBlk, 0, st, go, reinterpret_cast<const int32_t*>(at(0, disp_off)), slice_i, bw, bh,
+                       bimg(0, Y.lmp[0]), bimg(0, Y.rmp[0]), Y.slice, Y.rmw[0], Y.rmh[0], search.x0, search.y0);
+  }
+  VWGPU_HIP(ctx, hipGetLastError());
+  if (d_cert_stats) {
+    unsigned long long got[4] = {0, 0, 0, 0};
+    VWGPU_HIP(ctx, hipMemcpyAsync(got, d_cert_stats, sizeof got, hipMemcpyDeviceToHost, st));
+    VWGPU_HIP(ctx, hipStreamSynchronize(st));
+    ctx->cert_px[0] += got[0]; ctx->cert_px[1] += got[1]; ctx->cert_px[2] += got[2];
+  }
+  return VWGPU_OK;
+}
+
 // ---- extern "C" entry points ------------------------------------------------------------------------------------
 
 extern "C" {
@@ -1339,6 +1817,129 @@ int vwgpu_pyramid_correlate_dev(vwgpu_ctx* ctx, const float* d_left, int lw, int
   VWGPU_HIP(ctx, hipSetDevice(ctx->device));
   return vwgpu_pyramid_correlate_impl(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, d_lmask, lms, d_rmask, rms, P, bx, by, bw, bh, d_out, os,
                                       P->lr_disp_diff);
+}
+
+int vwgpu_pyramid_correlate_batch_dev(vwgpu_ctx* ctx, const float* d_left, int lw, int lh, ptrdiff_t ls,
+                                      const float* d_right, int rw, int rh, ptrdiff_t rs,
+                                      const uint8_t* d_lmask, ptrdiff_t lms, const uint8_t* d_rmask, ptrdiff_t rms,
+                                      const vwgpu_pyramid_params* P, int n_tiles, const int* bx, const int* by, const int* bw, const int* bh,
+                                      float* const* d_outs, const ptrdiff_t* os) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  ctx->err.clear();
+  if (n_tiles < 0 || (n_tiles > 0 && (!bx || !by || !bw || !bh || !d_outs))) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate_batch: null tile table");
+  if (ls == 0) ls = lw;
+  if (rs == 0) rs = rw;
+  if (lms == 0) lms = lw;
+  if (rms == 0) rms = rw;
+  for (int t = 0; t < n_tiles; ++t) {
+    int rc = check_pyramid_args(ctx, d_left, lw, lh, d_right, rw, rh, P, bw[t], bh[t], d_outs[t]);
+    if (rc) return rc;
+    if (os && os[t] != 0 && os[t] < bw[t]) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate: row stride smaller than row width");
+  }
+  if (n_tiles == 0) return VWGPU_OK;
+  if (ls < lw || rs < rw || lms < lw || rms < rw) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate: row stride smaller than row width");
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  // groups: runs of consecutive tiles of equal size, at most VWGPU_MAX_GROUP each; what a group cannot take (SGM / MGM, lr_disp_diff, blob
+  // filter, time budget, a forced kernel family) and lone tiles go through the single-tile entry — same results either way
+  int t0 = 0;
+  while (t0 < n_tiles) {
+    int t1 = t0 + 1;
+    while (t1 < n_tiles && t1 - t0 < VWGPU_MAX_GROUP && bw[t1] == bw[t0] && bh[t1] == bh[t0]) ++t1;
+    const int m = t1 - t0;
+    if (vwgpu_pyramid_group_eligible(ctx, P, m, bw + t0, bh + t0)) {
+      ptrdiff_t oss[VWGPU_MAX_GROUP];
+      for (int t = 0; t < m; ++t) oss[t] = (os && os[t0 + t]) ? os[t0 + t] : bw[t0 + t];
+      int rc = vwgpu_pyramid_group_impl(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, d_lmask, lms, d_rmask, rms, P, m, bx + t0, by + t0, bw[t0], bh[t0], d_outs + t0, oss);
+      if (rc) return rc;
+    } else {
+      for (int t = t0; t < t1; ++t) {
+        if (P->lr_disp_diff && (bx[t] < P->region_ul_x || by[t] < P->region_ul_y || bx[t] + bw[t] > P->region_ul_x + P->lr_disp_diff_cols ||
+                                by[t] + bh[t] > P->region_ul_y + P->lr_disp_diff_rows))
+          return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "The L-R to R-L difference image domain does not contain the current tile.");
+        int rc = vwgpu_pyramid_correlate_impl(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, d_lmask, lms, d_rmask, rms, P, bx[t], by[t], bw[t], bh[t], d_outs[t],
+                                              (os && os[t]) ? os[t] : bw[t], P->lr_disp_diff);
+        if (rc) return rc;
+      }
+    }
+    t0 = t1;
+  }
+  return VWGPU_OK;
+}
+
+int vwgpu_pyramid_correlate_batch(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t ls,
+                                  const float* right, int rw, int rh, ptrdiff_t rs,
+                                  const uint8_t* lmask, ptrdiff_t lms, const uint8_t* rmask, ptrdiff_t rms,
+                                  const vwgpu_pyramid_params* P, int n_tiles, const int* bx, const int* by, const int* bw, const int* bh,
+                                  float* const* outs, const ptrdiff_t* os) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  ctx->err.clear();
+  if (n_tiles < 0 || (n_tiles > 0 && (!bx || !by || !bw || !bh || !outs))) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate_batch: null tile table");
+  if (n_tiles == 0) return VWGPU_OK;
+  // an lr_disp_diff image is staged per tile by the single-tile entry (concurrent tiles must not write back each other's pixels)
+  if (P && P->lr_disp_diff) {
+    for (int t = 0; t < n_tiles; ++t) {
+      int rc = vwgpu_pyramid_correlate(ctx, left, lw, lh, ls, right, rw, rh, rs, lmask, lms, rmask, rms, P, bx[t], by[t], bw[t], bh[t], outs[t], os ? os[t] : 0);
+      if (rc) return rc;
+    }
+    return VWGPU_OK;
+  }
+  for (int t = 0; t < n_tiles; ++t) {
+    int rc = check_pyramid_args(ctx, left, lw, lh, right, rw, rh, P, bw[t], bh[t], outs[t]);
+    if (rc) return rc;
+  }
+  if (ls == 0) ls = lw;
+  if (rs == 0) rs = rw;
+  if (lms == 0) lms = lw;
+  if (rms == 0) rms = rw;
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  // the window of the sources the tiles can touch (see vwgpu_pyramid_correlate): the union over the tiles, one origin for both images and masks
+  const int upb = 1 << std::max(0, std::min(P->max_pyramid_levels, 12));
+  const int sdx = P->search_max_x - P->search_min_x, sdy = P->search_max_y - P->search_min_y;
+  const long long padx = (long long)(P->kernel_x / 2) * upb + 2LL * std::max(sdx, 0) + 8;
+  const long long pady = (long long)(P->kernel_y / 2) * upb + 2LL * std::max(sdy, 0) + 8;
+  long long ux0 = LLONG_MAX, uy0 = LLONG_MAX, ux1 = LLONG_MIN, uy1 = LLONG_MIN;
+  size_t out_bytes = 0;
+  for (int t = 0; t < n_tiles; ++t) {
+    ux0 = std::min<long long>(ux0, bx[t]); uy0 = std::min<long long>(uy0, by[t]);
+    ux1 = std::max<long long>(ux1, (long long)bx[t] + bw[t]); uy1 = std::max<long long>(uy1, (long long)by[t] + bh[t]);
+    out_bytes += vwgpu_align_up((size_t)bw[t] * bh[t] * 12, 256);
+  }
+  const long long wx0 = std::max<long long>(0, ux0 - padx + std::min(P->search_min_x, 0)), wy0 = std::max<long long>(0, uy0 - pady + std::min(P->search_min_y, 0));
+  const long long wx1 = ux1 + padx + std::max(P->search_max_x, 0), wy1 = uy1 + pady + std::max(P->search_max_y, 0);
+  const int ox = (int)std::min<long long>(wx0, std::min(lw, rw)), oy = (int)std::min<long long>(wy0, std::min(lh, rh));
+  const int lww = (int)(std::min<long long>(wx1, lw) - ox), lwh = (int)(std::min<long long>(wy1, lh) - oy);
+  const int rww = (int)(std::min<long long>(wx1, rw) - ox), rwh = (int)(std::min<long long>(wy1, rh) - oy);
+  if (lww <= 0 || lwh <= 0 || rww <= 0 || rwh <= 0) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate: the tiles lie outside the images");
+  const size_t lb = vwgpu_align_up((size_t)lww * lwh * 4, 256), rb = vwgpu_align_up((size_t)rww * rwh * 4, 256);
+  const size_t lmb = vwgpu_align_up((size_t)lww * lwh, 256), rmb = vwgpu_align_up((size_t)rww * rwh, 256);
+  int rc = vwgpu_arena_reserve(ctx, &ctx->staging, lb + rb + lmb + rmb + out_bytes);
+  if (rc) return rc;
+  char* base = static_cast<char*>(ctx->staging.base);
+  float* d_l = reinterpret_cast<float*>(base);
+  float* d_r = reinterpret_cast<float*>(base + lb);
+  uint8_t* d_lm = reinterpret_cast<uint8_t*>(base + lb + rb);
+  uint8_t* d_rm = reinterpret_cast<uint8_t*>(base + lb + rb + lmb);
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_l, (size_t)lww * 4, left + (ptrdiff_t)oy * ls + ox, (size_t)ls * 4, (size_t)lww * 4, lwh, hipMemcpyHostToDevice, ctx->stream));
+  VWGPU_HIP(ctx, hipMemcpy2DAsync(d_r, (size_t)rww * 4, right + (ptrdiff_t)oy * rs + ox, (size_t)rs * 4, (size_t)rww * 4, rwh, hipMemcpyHostToDevice, ctx->stream));
+  if (lmask) VWGPU_HIP(ctx, hipMemcpy2DAsync(d_lm, (size_t)lww, lmask + (ptrdiff_t)oy * lms + ox, (size_t)lms, (size_t)lww, lwh, hipMemcpyHostToDevice, ctx->stream));
+  if (rmask) VWGPU_HIP(ctx, hipMemcpy2DAsync(d_rm, (size_t)rww, rmask + (ptrdiff_t)oy * rms + ox, (size_t)rms, (size_t)rww, rwh, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<int> wbx((size_t)n_tiles), wby((size_t)n_tiles);
+  std::vector<float*> d_outs((size_t)n_tiles);
+  char* q = base + lb + rb + lmb + rmb;
+  for (int t = 0; t < n_tiles; ++t) {
+    wbx[t] = bx[t] - ox; wby[t] = by[t] - oy;
+    d_outs[t] = reinterpret_cast<float*>(q);
+    q += vwgpu_align_up((size_t)bw[t] * bh[t] * 12, 256);
+  }
+  rc = vwgpu_pyramid_correlate_batch_dev(ctx, d_l, lww, lwh, lww, d_r, rww, rwh, rww, lmask ? d_lm : nullptr, lww, rmask ? d_rm : nullptr, rww, P, n_tiles,
+                                         wbx.data(), wby.data(), bw, bh, d_outs.data(), nullptr);
+  if (rc) return rc;
+  for (int t = 0; t < n_tiles; ++t) {
+    const ptrdiff_t o = (os && os[t]) ? os[t] : bw[t];
+    VWGPU_HIP(ctx, hipMemcpy2DAsync(outs[t], (size_t)o * 12, d_outs[t], (size_t)bw[t] * 12, (size_t)bw[t] * 12, bh[t], hipMemcpyDeviceToHost, ctx->stream));
+  }
+  VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VWGPU_OK;
 }
 
 int vwgpu_pyramid_correlate(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t ls,

@@ -266,7 +266,8 @@ int vwgpu_launch_zone_lr(vwgpu_ctx* ctx, const vwgpu_zone_task* zones, int n, in
 
 // pyramid.hip
 int vwgpu_launch_disparity_filter(vwgpu_ctx* ctx, const int32_t* src, int w, int h, int hh, int hv, double pthr, double rthr,
-                                  bool cleanup, int32_t* tmp_padded, int32_t* dst, bool inner_only = false);      // inner_only: stop after the first pass (tmp_padded)
+                                  bool cleanup, int32_t* tmp_padded, int32_t* dst, bool inner_only = false,      // inner_only: stop after the first pass (tmp_padded)
+                                  int tiles = 1, size_t tile_ints = 0);                                        // tile groups: `tiles` images at a stride of tile_ints ints
 int vwgpu_launch_blob_filter(vwgpu_ctx* ctx, int32_t* d, int w, int h, int area, int* scratch);
 int vwgpu_launch_disparity_mask(vwgpu_ctx* ctx, int32_t* d, int w, int h, const uint8_t* m1, const uint8_t* m2, int m2w, int m2h);
 int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t ls,
@@ -274,6 +275,12 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
                                  const uint8_t* lmask, ptrdiff_t lms, const uint8_t* rmask, ptrdiff_t rms,
                                  const vwgpu_pyramid_params* P, int bx, int by, int bw, int bh,
                                  float* out, ptrdiff_t os, float* lr_diff);
+
+// tile groups (pyramid.hip): several equal-sized tiles of one image pair through the level loop together
+bool vwgpu_pyramid_group_eligible(const vwgpu_ctx* ctx, const vwgpu_pyramid_params* P, int n, const int* bw, const int* bh);
+int vwgpu_pyramid_group_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t ls, const float* right, int rw, int rh, ptrdiff_t rs,
+                             const uint8_t* lmask, ptrdiff_t lms, const uint8_t* rmask, ptrdiff_t rms, const vwgpu_pyramid_params* P,
+                             int n, const int* bxs, const int* bys, int bw, int bh, float* const* outs, const ptrdiff_t* oss);
 
 // sgm.hip
 int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left, int lw, int lh, ptrdiff_t ls,

@@ -367,6 +367,64 @@ def pyramid_correlate(left, right, left_mask, right_mask, prefilter_mode, prefil
     return out
 
 
+def pyramid_correlate_batch(left, right, left_mask, right_mask, prefilter_mode, prefilter_width, search_region, kernel_size, cost_type,
+                            bboxes, corr_timeout=0, seconds_per_op=0.0, consistency_threshold=-1.0, min_consistency_level=0,
+                            filter_half_kernel=0, max_pyramid_levels=5, algorithm=0, collar_size=0, sgm_subpixel_mode=5,
+                            sgm_search_buffer=(2, 2), memory_limit_mb=6000, blob_filter_area=0, sgm_num_threads=1, ctx=None):
+    """Several tiles (`bboxes`: a list of BBox2i) of vw::stereo::pyramid_correlate in ONE call: what the reference's block rasteriser hands
+    to its tile threads one at a time (src/vw/Image/ImageIO.h:228-251).  Runs of consecutive tiles of equal size go through the pyramid
+    level loop together (vwgpu_pyramid_correlate_batch[_dev], include/vwgpu.h); every tile's result is identical to pyramid_correlate on
+    that tile.  Returns a list of (rows, cols, 3) float32 PixelMask<Vector2f> images: CUDA tensors for CUDA inputs, numpy arrays otherwise."""
+    from ._lib import PyramidParams
+    if left.ndim != 2 or right.ndim != 2:
+        raise ArgumentErr("pyramid_correlate: images must be 2-D (rows, cols)")
+    lh, lw = left.shape
+    rh, rw = right.shape
+    P = PyramidParams(int(prefilter_mode), float(prefilter_width),
+                      int(search_region.min[0]), int(search_region.min[1]), int(search_region.max[0]), int(search_region.max[1]),
+                      int(kernel_size[0]), int(kernel_size[1]), int(cost_type), int(corr_timeout), float(seconds_per_op),
+                      float(consistency_threshold), int(min_consistency_level), int(filter_half_kernel),
+                      int(max_pyramid_levels), int(algorithm), int(blob_filter_area), int(sgm_subpixel_mode),
+                      int(sgm_search_buffer[0]), int(sgm_search_buffer[1]), int(memory_limit_mb), int(sgm_num_threads),
+                      None, 0, 0, 0, 0, 0)
+    n = len(bboxes)
+    IA = ctypes.c_int * max(n, 1)
+    bx = IA(*[int(b.min[0]) for b in bboxes]); by = IA(*[int(b.min[1]) for b in bboxes])
+    bw = IA(*[int(b.max[0] - b.min[0]) for b in bboxes]); bh = IA(*[int(b.max[1] - b.min[1]) for b in bboxes])
+    ctx = _ctx_for(left, ctx)
+    lib = ctx._lib
+    PA = ctypes.c_void_p * max(n, 1)
+    if _is_tensor(left):
+        if not (left.is_cuda and right.is_cuda) or left.dtype != torch.float32 or right.dtype != torch.float32:
+            raise ArgumentErr("pyramid_correlate: float32 CUDA tensors required (no CPU path)")
+        l, r = left.contiguous(), right.contiguous()
+        lm = left_mask.contiguous() if left_mask is not None else None
+        rm = right_mask.contiguous() if right_mask is not None else None
+        for m, shp in ((lm, l.shape), (rm, r.shape)):
+            if m is not None and (m.dtype != torch.uint8 or tuple(m.shape) != tuple(shp) or not m.is_cuda):
+                raise ArgumentErr("pyramid_correlate: masks must be uint8 CUDA tensors of the image size")
+        outs = [torch.empty((max(bh[t], 0), max(bw[t], 0), 3), dtype=torch.float32, device=l.device) for t in range(n)]
+        ptrs = PA(*[o.data_ptr() for o in outs])
+        ctx.set_stream(torch.cuda.current_stream(l.device).cuda_stream)
+        ctx.check(lib.vwgpu_pyramid_correlate_batch_dev(ctx._h, l.data_ptr(), lw, lh, 0, r.data_ptr(), rw, rh, 0,
+                                                        lm.data_ptr() if lm is not None else None, 0, rm.data_ptr() if rm is not None else None, 0,
+                                                        ctypes.byref(P), n, bx, by, bw, bh, ptrs, None))
+        return outs
+    l = np.ascontiguousarray(left, np.float32)
+    r = np.ascontiguousarray(right, np.float32)
+    lm = np.ascontiguousarray(left_mask, np.uint8) if left_mask is not None else None
+    rm = np.ascontiguousarray(right_mask, np.uint8) if right_mask is not None else None
+    for m, shp in ((lm, l.shape), (rm, r.shape)):
+        if m is not None and tuple(m.shape) != tuple(shp):
+            raise ArgumentErr("pyramid_correlate: masks must have the image size")
+    outs = [np.empty((max(bh[t], 0), max(bw[t], 0), 3), np.float32) for t in range(n)]
+    ptrs = PA(*[o.ctypes.data for o in outs])
+    ctx.check(lib.vwgpu_pyramid_correlate_batch(ctx._h, l.ctypes.data, lw, lh, 0, r.ctypes.data, rw, rh, 0,
+                                                lm.ctypes.data if lm is not None else None, 0, rm.ctypes.data if rm is not None else None, 0,
+                                                ctypes.byref(P), n, bx, by, bw, bh, ptrs, None))
+    return outs
+
+
 SUBPIXEL_NONE, SUBPIXEL_PARABOLA, SUBPIXEL_LINEAR, SUBPIXEL_POLY4, SUBPIXEL_COSINE, SUBPIXEL_LC_BLEND = range(6)
 
 
@@ -445,5 +503,5 @@ def calc_disparity_sgm(cost_type, left_in, right_in, left_region, search_volume,
 
 
 __all__ = ["calc_disparity", "calc_disparity_sgm", "cross_corr_consistency_check", "parabola_subpixel", "rm_outliers_using_thresh",
-           "disparity_cleanup_using_thresh", "disparity_mask", "disparity_blob_filter", "subdivide_regions", "pyramid_correlate",
+           "disparity_cleanup_using_thresh", "disparity_mask", "disparity_blob_filter", "subdivide_regions", "pyramid_correlate", "pyramid_correlate_batch",
            "BBox2i", "CostFunctionType"]
