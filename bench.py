@@ -423,15 +423,19 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right, with
     tiles = [vwa.BBox2i(x, y, 1024, 1024) for y in range(0, H, 1024) for x in range(0, W, 1024)]
     search = vwa.BBox2i.from_corners((-64, -1), (64, 1))
     for label, pf, pw, cost, kk in (("SAD 7x7", 0, 0.0, 0, 7), ("LoG 1.4 + NCC 11x11 (the correlate tool's defaults)", 2, 1.4, 2, 11)):
-        T = 4
+        # the tiles are handed over in GROUPS (vwgpu_pyramid_correlate_batch_dev, round 5): the 4 tiles of a tile row go through the level loop
+        # together — every launch serves the group, one host round trip per level — one group per tile thread
+        T, G = 4, 4
         ctxs = [vwa.Context(lt.device.index) for _ in range(T)]
         streams = [torch.cuda.Stream(device=lt.device) for _ in range(T)]
         outs = [None] * len(tiles)
+        groups = [list(range(i, min(i + G, len(tiles)))) for i in range(0, len(tiles), G)]
         def work(t):
             with torch.cuda.stream(streams[t]):
-                for i in range(t, len(tiles), T):
-                    outs[i] = stereo.pyramid_correlate(lt, rc, None, None, pf, pw, search, (kk, kk), cost, consistency_threshold=2, filter_half_kernel=5,
-                                                       max_pyramid_levels=5, bbox=tiles[i], ctx=ctxs[t])
+                for gi in range(t, len(groups), T):
+                    got_ = stereo.pyramid_correlate_batch(lt, rc, None, None, pf, pw, search, (kk, kk), cost, [tiles[i] for i in groups[gi]], consistency_threshold=2,
+                                                          filter_half_kernel=5, max_pyramid_levels=5, ctx=ctxs[t])
+                    for i, o_ in zip(groups[gi], got_): outs[i] = o_
         best = None
         for rep in range(7):                                   # one warm-up pass, then the fastest of six (a pass is 10 - 40 ms: host noise shows)
             torch.cuda.synchronize(lt.device); t0 = time.perf_counter()
@@ -439,6 +443,15 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right, with
             [x.start() for x in th]; [x.join() for x in th]
             torch.cuda.synchronize(lt.device); dt_ = time.perf_counter() - t0
             if rep > 0: best = dt_ if best is None else min(best, dt_)
+        # launches of one more pass (the kernels the engine brackets with events; fills and copies are not counted)
+        for c_ in ctxs: c_.profile_reset(); c_.profile_enable(True)
+        th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+        [x.start() for x in th]; [x.join() for x in th]
+        torch.cuda.synchronize(lt.device)
+        launches = 0
+        for c_ in ctxs:
+            c_.profile_enable(False)
+            launches += len(c_.profile_read(1 << 16))
         for c_ in ctxs: c_.close()
         nl = [1024 * 1024 / 4 ** l for l in range(6)]
         tile_bytes = 2 * (4.0 / 3.0) * 5 * nl[0] + sum((20 + 24) * n for n in nl) + 20 * nl[0]       # the config-5 byte model (run_config5)
@@ -456,7 +469,9 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right, with
             assert same == len(kept), "tile loop (%s): %s tiles identical to the oracle" % (label, ident)
         del outs
         out.append({"name": "config 5 building block: pyramid_correlate tile loop, 4096^2 in 16 tiles of 1024^2, %s, +-64 x +-1, 5 levels, L/R check, "
-                            "4 tile threads" % label, "wall_ms_per_pair": round(best * 1e3, 2), "ms_per_tile": round(best * 1e3 / len(tiles), 3),
+                            "4 tile threads x groups of 4 tiles (vwgpu_pyramid_correlate_batch_dev)" % label,
+                    "kernel_launches_per_tile": round(launches / len(tiles), 1),
+                    "wall_ms_per_pair": round(best * 1e3, 2), "ms_per_tile": round(best * 1e3 / len(tiles), 3),
                     "Mpix_per_s": round(W * H / best / 1e6, 1), "algorithmic_bytes": int(tile_bytes * len(tiles)),
                     "bytes_model": "SURVEY 8d summed over the levels of a tile (pyramid build + BM bytes per level, level 0 twice + clean-up chain)",
                     "roofline_frac": round(tile_bytes * len(tiles) / best / 1e9 / HBM_PEAK_GBS, 5), "cpu_baseline": cb,
@@ -604,6 +619,8 @@ def run_config5(args, torch, dist, vwa, core, stereo, synth, partition, rank, wo
     streams = [torch.cuda.Stream(device=dev) for _ in range(T)]
     keep = {}
 
+    G = 8                                                          # tiles per group (vwgpu_pyramid_correlate_batch_dev; SGM tiles run one by one inside the call)
+
     def loop(kw, only=None):
         todo = list(tiles if only is None else tiles[-only:])      # (the timed loop pops from the end: warm up with the tiles it starts with)
         lock = threading.Lock()
@@ -612,11 +629,12 @@ def run_config5(args, torch, dist, vwa, core, stereo, synth, partition, rank, wo
                 while True:
                     with lock:
                         if not todo: return
-                        x, y = todo.pop()
-                    o = stereo.pyramid_correlate(lwin, rwin, None, None, kw["pf"], kw["pfw"], search, kw["kernel"], kw["cost"], consistency_threshold=2,
-                                                 filter_half_kernel=5, max_pyramid_levels=LEVELS, algorithm=kw["alg"],
-                                                 bbox=vwa.BBox2i(x, y - first, TILE, TILE), ctx=ctxs[t])
-                    if (x, y) == (0, a): keep[kw["name"]] = o
+                        grp = [todo.pop() for _ in range(min(G if kw["alg"] == 0 else 1, len(todo)))]
+                    got_ = stereo.pyramid_correlate_batch(lwin, rwin, None, None, kw["pf"], kw["pfw"], search, kw["kernel"], kw["cost"],
+                                                          [vwa.BBox2i(x, y - first, TILE, TILE) for x, y in grp], consistency_threshold=2,
+                                                          filter_half_kernel=5, max_pyramid_levels=LEVELS, algorithm=kw["alg"], ctx=ctxs[t])
+                    for (x, y), o in zip(grp, got_):
+                        if (x, y) == (0, a): keep[kw["name"]] = o
         th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
         [x.start() for x in th]; [x.join() for x in th]
 
@@ -629,7 +647,7 @@ def run_config5(args, torch, dist, vwa, core, stereo, synth, partition, rank, wo
     modes = [dict(name="bm", pf=2, pfw=1.4, kernel=(11, 11), cost=2, alg=0), dict(name="sgm", pf=0, pfw=0.0, kernel=(7, 7), cost=3, alg=1)]
     res = {}
     for kw in modes:
-        loop(kw, only=2 * T)                                       # warm-up: arenas of every context sized
+        loop(kw, only=(G if kw["alg"] == 0 else 2) * T)            # warm-up: arenas of every context sized
         barrier()
         t0 = time.perf_counter()
         loop(kw)
@@ -665,7 +683,7 @@ def run_config5(args, torch, dist, vwa, core, stereo, synth, partition, rank, wo
             "data": "synthetic (SplitMix64 integer-valued float32 noise pair, 256-px blocks shifted by 0+-48)",
             "config": {"workload": "BASELINE configs[4]: orbital-scale pair through the reference's tile loop; block matching with the correlate "
                                    "tool's defaults and, separately, SGM (census 7x7)", "tile": TILE, "tiles": ntiles,
-                       "tile_threads_per_gpu": T, "halo": how,
+                       "tile_threads_per_gpu": T, "tiles_per_group": G, "halo": how,
                        "sgm": {"Mpix_per_s": npx / res["sgm"] / 1e6, "s_per_pair": res["sgm"],
                                "roofline_frac": ntiles * sgm_tile / res["sgm"] / 1e9 / HBM_PEAK_GBS,
                                "cpu_baseline": None if cpu is None else cpu["sgm"]},

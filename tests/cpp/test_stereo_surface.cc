@@ -531,6 +531,38 @@ static void test_disk_views_and_block_write() {
   std::remove(lf.c_str()); std::remove(rf.c_str()); std::remove(df.c_str());
 }
 
+// --- tile groups: PyramidCorrelationView::correlate_tiles / rasterize_group (vwgpu_pyramid_correlate_batch) = the tiles one by one ---
+static void test_tile_groups() {
+  ImageView<PixelGray<float>> left, right;
+  pyramid_scene(left, right);
+  ImageView<uint8> lmask(300, 200), rmask(300, 200);
+  fill(lmask, uint8(255)); fill(rmask, uint8(255));
+  for (int r = 60; r < 90; ++r) for (int c = 100; c < 150; ++c) lmask(c, r) = 0;
+  const BBox2i search_volume(Vector2i(-18, -7), Vector2i(18, 7));
+  for (int collar = 0; collar <= 8; collar += 8) {
+    PyramidCorrelationView view = pyramid_correlate(left, right, lmask, rmask, PREFILTER_LOG, 1.4f, search_volume, Vector2i(7, 7),
+                                                    CROSS_CORRELATION, 0, 0.0, 2, 0, 3, 3, VW_CORRELATION_BM, collar);
+    std::vector<BBox2i> boxes;
+    for (int x = 0; x < 300; x += 100) for (int y = 0; y < 200; y += 100) boxes.push_back(BBox2i(x, y, 100, 100));
+    boxes.push_back(BBox2i(40, 30, 77, 55));                              // an odd one: runs alone inside the call
+    std::vector<ImageView<PixelMask<Vector2f>>> got = view.correlate_tiles(boxes);
+    std::vector<ImageView<PixelMask<Vector2f>>> dests;
+    for (BBox2i const& b : boxes) dests.push_back(ImageView<PixelMask<Vector2f>>(b.width(), b.height()));
+    view.rasterize_group(dests, boxes);
+    long bad = 0;
+    for (size_t i = 0; i < boxes.size(); ++i) {
+      ImageView<PixelMask<Vector2f>> one = view.correlate_tile(boxes[i]);
+      ImageView<PixelMask<Vector2f>> ras(boxes[i].width(), boxes[i].height());
+      view.rasterize(ras, boxes[i]);
+      for (int r = 0; r < boxes[i].height(); ++r) for (int c = 0; c < boxes[i].width(); ++c) {
+        if (!(got[i](c, r).child() == one(c, r).child()) || is_valid(got[i](c, r)) != is_valid(one(c, r))) ++bad;
+        if (!(dests[i](c, r).child() == ras(c, r).child()) || is_valid(dests[i](c, r)) != is_valid(ras(c, r))) ++bad;
+      }
+    }
+    EXPECT_EQ(0, bad);
+  }
+}
+
 // vw/Halo.h: the strip plan of a row-sharded source and a one-rank RCCL communicator (more ranks need more GPUs).
 static void test_strip_plan_and_comm() {
   using namespace vw::engine;
@@ -574,6 +606,7 @@ int main() {
   test_collar_and_lr_disp_diff();
   test_fast_box_sum();
   test_disk_views_and_block_write();
+  test_tile_groups();
   test_strip_plan_and_comm();
   // tile threads spread over the visible GPUs (one context per thread x GPU); on a 1-GPU box this is device 0 for all
   EXPECT_TRUE(!vw::engine::devices().empty());

@@ -1271,6 +1271,11 @@ int vwgpu_pyramid_group_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, 
   const bool filtered = P->prefilter_mode == VWGPU_PREFILTER_LOG || P->prefilter_mode == VWGPU_PREFILTER_MEANSUB;
   constexpr int CS = 16, NB = 256;
 
+  const auto t_start = std::chrono::steady_clock::now();
+  const bool dbg_time = (ctx->trace & 1) != 0;     // development aid: host-side timeline of a group on stderr
+  auto stamp = [&](const char* what, int level) {
+    if (dbg_time) fprintf(stderr, "  [%8.1f us] group of %d, level %d: %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(), n, level, what);
+  };
   std::vector<GroupTile> T((size_t)n);
   for (int t = 0; t < n; ++t) {
     GroupTile& g = T[t];
@@ -1431,7 +1436,9 @@ int vwgpu_pyramid_group_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, 
     vwgpu_launch_float_grain(ctx, (int)gi.size(), gi.data(), gw.data(), gh.data(), gs.data(), gc.data());
     for (int t = 0; t < n; ++t)
       VWGPU_HIP(ctx, hipMemcpyAsync(cells.data() + (size_t)t * (L + 1) * CS, at(t, Y.d_cells), (size_t)(L + 1) * CS * sizeof(int), hipMemcpyDeviceToHost, st));
+    stamp("pyramids queued, waiting for the level classes", L);
     VWGPU_HIP(ctx, hipStreamSynchronize(st));
+    stamp("level classes on the host", L);
     for (int t = 0; t < n; ++t)
       for (int i = 0; i <= L; ++i) {
         const int* c = cells.data() + ((size_t)t * (L + 1) + i) * CS;
@@ -1497,6 +1504,7 @@ int vwgpu_pyramid_group_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, 
         }
       }
     }
+    stamp("zone tasks built", level);
     if (lr_active && rl_pixels) { if ((rc = vwgpu_arena_reserve(ctx, &ctx->zrl, rl_pixels * 12))) return rc; }
     int32_t* rlbuf = static_cast<int32_t*>(ctx->zrl.base);
     // the "cannot matter" certificate (see vwgpu_pyramid_correlate_impl): margins per level, bounds per tile
@@ -1555,6 +1563,7 @@ int vwgpu_pyramid_group_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, 
         if (rc) return rc;
       }
     }
+    stamp("matchers queued", level);
     if (d_any) {
       // the flagged zones of the certified passes, per tile: one small read-back for the group, a second one only when some zone was flagged
       std::vector<int> any(2 * (size_t)n, 0);
@@ -1623,7 +1632,9 @@ int vwgpu_pyramid_group_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, 
       const vwgpu::LeafExtent* h_ext = static_cast<const vwgpu::LeafExtent*>(vwgpu_host_ring(ctx, ext_bytes));
       if (!h_ext) { own.resize((size_t)n * nleaf); h_ext = own.data(); }
       VWGPU_HIP(ctx, hipMemcpyAsync(const_cast<vwgpu::LeafExtent*>(h_ext), d_ext, ext_bytes, hipMemcpyDeviceToHost, st));
+      stamp("level queued, waiting", level);
       VWGPU_HIP(ctx, hipStreamSynchronize(st));
+      stamp("leaf extents on the host", level);
       const IBox scale_search(0, 0, Y.rpw[level - 1] - Y.lpw[level - 1], Y.rph[level - 1] - Y.lph[level - 1]);
       const IBox next_size(0, 0, Y.lmw[level - 1], Y.lmh[level - 1]);
       for (int t = 0; t < n; ++t) {
@@ -1640,8 +1651,10 @@ int vwgpu_pyramid_group_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, 
           if (z.range.empty()) z.range = IBox(0, 0, search.width(), search.height());
         }
       }
+      stamp("zones of the next level ready", level);
     }
   }
+  stamp("last level queued", 0);
   if (dw != bw || dh != bh) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "PyramidCorrelation: Solved disparity doesn't match requested bbox size.");
   {
     GroupOuts go;

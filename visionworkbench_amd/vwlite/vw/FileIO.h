@@ -188,6 +188,18 @@ void write_image(std::string const& path, ImageViewBase<ViewT> const& view) {
 /// handed out in raster order to num_threads workers — and every block is written where it belongs as soon as it is done,
 /// so reading (lazy sources pull their windows inside rasterize), correlation on the GPU (one engine context per worker
 /// thread) and writing of different tiles overlap.  The whole image never exists in memory.
+namespace fileio {
+// Views that can rasterise a run of blocks in one go (PyramidCorrelationView::rasterize_group: the blocks go through the engine's pyramid
+// level loop as one group) say so with group_size(); every other view is rasterised block by block.
+template <class V> auto view_group_size(V const& v, int) -> decltype(v.group_size()) { return v.group_size(); }
+template <class V> int32 view_group_size(V const&, long) { return 1; }
+template <class V, class T> auto rasterize_blocks(V const& v, std::vector<ImageView<T>> const& tiles, std::vector<BBox2i> const& blocks, int)
+    -> decltype(v.rasterize_group(tiles, blocks)) { v.rasterize_group(tiles, blocks); }
+template <class V, class T> void rasterize_blocks(V const& v, std::vector<ImageView<T>> const& tiles, std::vector<BBox2i> const& blocks, long) {
+  for (size_t i = 0; i < blocks.size(); ++i) v.rasterize(tiles[i], blocks[i]);
+}
+}  // namespace fileio
+
 template <class ViewT>
 void block_write_image(std::string const& path, ImageViewBase<ViewT> const& view,
                        Vector2i block_size = Vector2i(1024, 1024), int32 num_threads = 0) {
@@ -204,25 +216,34 @@ void block_write_image(std::string const& path, ImageViewBase<ViewT> const& view
   std::atomic<int32> next(0);
   std::exception_ptr error;
   std::mutex error_mutex;
+  // a worker takes a run of up to `group` blocks of one block row at a time (1 for views without rasterize_group)
+  const int32 group = std::max<int32>(1, std::min<int32>(fileio::view_group_size(v, 0), std::max<int32>(1, (nbx * nby + num_threads - 1) / num_threads)));
+  const int32 runs_per_row = (nbx + group - 1) / group;
   auto worker = [&](int32 index) {
     engine::thread_worker_index() = index;        // worker w -> GPU w % ndev (vw/Engine.h)
     try {
       for (;;) {
         const int32 i = next.fetch_add(1);
-        if (i >= nbx * nby) return;
-        BBox2i block((i % nbx) * block_size.x(), (i / nbx) * block_size.y(), block_size.x(), block_size.y());
-        block.crop(BBox2i(0, 0, W, H));
-        ImageView<pixel_type> tile(block.width(), block.height());
-        v.rasterize(tile, block);
-        writer.write(tile, block);
+        if (i >= runs_per_row * nby) return;
+        const int32 row = i / runs_per_row, b0 = (i % runs_per_row) * group, b1 = std::min(nbx, b0 + group);
+        std::vector<BBox2i> blocks;
+        std::vector<ImageView<pixel_type>> tiles;
+        for (int32 b = b0; b < b1; ++b) {
+          BBox2i block(b * block_size.x(), row * block_size.y(), block_size.x(), block_size.y());
+          block.crop(BBox2i(0, 0, W, H));
+          blocks.push_back(block);
+          tiles.push_back(ImageView<pixel_type>(block.width(), block.height()));
+        }
+        fileio::rasterize_blocks(v, tiles, blocks, 0);
+        for (size_t k = 0; k < blocks.size(); ++k) writer.write(tiles[k], blocks[k]);
       }
     } catch (...) {
       std::lock_guard<std::mutex> lock(error_mutex);
       if (!error) error = std::current_exception();
-      next.store(nbx * nby);
+      next.store(runs_per_row * nby);
     }
   };
-  const int32 nt = std::min<int32>(num_threads, nbx * nby);
+  const int32 nt = std::min<int32>(num_threads, runs_per_row * nby);
   if (nt <= 1) worker(engine::thread_worker_index());
   else {
     std::vector<std::thread> pool;

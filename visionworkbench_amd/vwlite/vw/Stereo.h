@@ -461,6 +461,69 @@ public:
                                                reinterpret_cast<float*>(out.data()), 0));
     return out;
   }
+  /// Several tiles in one engine call (vwgpu_pyramid_correlate_batch, include/vwgpu.h): runs of equal-sized tiles go through the pyramid
+  /// level loop together — every launch serves the group, one host round trip per level.  Tile i of the result is what correlate_tile(boxes[i])
+  /// returns.  The reference hands tiles to its threads one by one (ImageIO.h:228-251); block_write_image below hands this view a run of
+  /// blocks of a block row at a time (group_size()).
+  std::vector<ImageView<pixel_type>> correlate_tiles(std::vector<BBox2i> const& boxes) const {
+    const int n = (int)boxes.size();
+    std::vector<ImageView<pixel_type>> out((size_t)n);
+    if (n == 0) return out;
+    std::vector<int> bx((size_t)n), by((size_t)n), bw((size_t)n), bh((size_t)n);
+    std::vector<float*> ptr((size_t)n);
+    BBox2i all;
+    for (int i = 0; i < n; ++i) {
+      VW_ASSERT(!boxes[i].empty(), ArgumentErr() << "PyramidCorrelationView: empty tile in a group.");
+      out[i].set_size(boxes[i].width(), boxes[i].height());
+      bx[i] = boxes[i].min().x(); by[i] = boxes[i].min().y(); bw[i] = boxes[i].width(); bh[i] = boxes[i].height();
+      ptr[i] = reinterpret_cast<float*>(out[i].data());
+      all.grow(boxes[i]);
+    }
+    vwgpu_ctx* ctx = detail::thread_context();
+    int32 ls = 0, rs = 0, lms = 0, rms = 0;
+    const PixelGray<float>* lp = m_left.plain_data(ls);
+    const PixelGray<float>* rp = m_right.plain_data(rs);
+    const uint8* lmp = m_left_mask.plain_data(lms);
+    const uint8* rmp = m_right_mask.plain_data(rms);
+    if (lp && rp && lmp && rmp) {
+      detail::check(ctx, vwgpu_pyramid_correlate_batch(ctx, reinterpret_cast<const float*>(lp), m_left.cols(), m_left.rows(), ls,
+                                                       reinterpret_cast<const float*>(rp), m_right.cols(), m_right.rows(), rs, lmp, lms, rmp, rms, &m_p,
+                                                       n, bx.data(), by.data(), bw.data(), bh.data(), ptr.data(), NULL));
+      return out;
+    }
+    // lazy sources: one window for the group (the union of the tiles grown as in correlate_tile)
+    const int64 up = int64(1) << std::max(0, std::min<int>(m_p.max_pyramid_levels, 12));
+    const int64 sdx = std::max(0, m_p.search_max_x - m_p.search_min_x), sdy = std::max(0, m_p.search_max_y - m_p.search_min_y);
+    const int64 padx = (m_p.kernel_x / 2) * up + 2 * sdx + 8, pady = (m_p.kernel_y / 2) * up + 2 * sdy + 8;
+    const int64 wx0 = std::max<int64>(0, all.min().x() - padx + std::min(m_p.search_min_x, 0));
+    const int64 wy0 = std::max<int64>(0, all.min().y() - pady + std::min(m_p.search_min_y, 0));
+    const int64 wx1 = int64(all.max().x()) + padx + std::max(m_p.search_max_x, 0);
+    const int64 wy1 = int64(all.max().y()) + pady + std::max(m_p.search_max_y, 0);
+    const int32 ox = (int32)std::min<int64>(wx0, std::min(m_left.cols(), m_right.cols()));
+    const int32 oy = (int32)std::min<int64>(wy0, std::min(m_left.rows(), m_right.rows()));
+    const BBox2i lwin(ox, oy, (int32)(std::min<int64>(wx1, m_left.cols()) - ox), (int32)(std::min<int64>(wy1, m_left.rows()) - oy));
+    const BBox2i rwin(ox, oy, (int32)(std::min<int64>(wx1, m_right.cols()) - ox), (int32)(std::min<int64>(wy1, m_right.rows()) - oy));
+    VW_ASSERT(!lwin.empty() && !rwin.empty(), ArgumentErr() << "PyramidCorrelationView: the tiles lie outside the images.");
+    ImageView<PixelGray<float>> l = m_left.prerasterize(lwin), r = m_right.prerasterize(rwin);
+    ImageView<uint8> lm = m_left_mask.prerasterize(lwin), rm = m_right_mask.prerasterize(rwin);
+    vwgpu_pyramid_params p = m_p;
+    p.region_ul_x -= ox; p.region_ul_y -= oy;
+    for (int i = 0; i < n; ++i) { bx[i] -= ox; by[i] -= oy; }
+    detail::check(ctx, vwgpu_pyramid_correlate_batch(ctx, reinterpret_cast<const float*>(l.data()), l.cols(), l.rows(), 0,
+                                                     reinterpret_cast<const float*>(r.data()), r.cols(), r.rows(), 0, lm.data(), 0, rm.data(), 0, &p,
+                                                     n, bx.data(), by.data(), bw.data(), bh.data(), ptr.data(), NULL));
+    return out;
+  }
+  /// How many blocks of a block row block_write_image hands over at a time (rasterize_group).
+  int32 group_size() const { return 8; }
+  /// rasterize() for a run of blocks: collars as in rasterize (CorrelationView.h:123-133), the tiles correlated as one group.
+  template <class DestT> void rasterize_group(std::vector<DestT> const& dests, std::vector<BBox2i> const& boxes) const {
+    std::vector<BBox2i> proc(boxes);
+    if (m_collar_size > 0) for (BBox2i& b : proc) b.expand(m_collar_size);
+    std::vector<ImageView<pixel_type>> tiles = correlate_tiles(proc);
+    for (size_t i = 0; i < boxes.size(); ++i)
+      vw::rasterize(prerasterize_type(tiles[i], -proc[i].min().x(), -proc[i].min().y(), cols(), rows()), dests[i], boxes[i]);
+  }
   /// CorrelationView.cc:876-885: the tile wrapped so that GLOBAL pixel coordinates inside bbox address it.
   prerasterize_type prerasterize(BBox2i const& bbox) const {
     return prerasterize_type(correlate_tile(bbox), -bbox.min().x(), -bbox.min().y(), cols(), rows());
