@@ -148,3 +148,57 @@ def pyramid_sgm_cases(n, seed):
             bw, bh = int(rng.integers(24, min(160, W))), int(rng.integers(24, min(120, H)))
             bbox = (int(rng.integers(0, W - bw + 1)), int(rng.integers(0, H - bh + 1)), bw, bh)
         yield dict(it=it, left=left, right=right, lm=lm, rm=rm, search=search, k=k, cost=cost, thr=thr, mcl=mcl, filt=filt, levels=levels, bbox=bbox)
+
+
+def bm_float_cases(n, seed):
+    """calc_disparity on NON-integer rasters (round 5: the certified single-level path): smooth float textures, wide dynamic ranges, flat
+    patches (exact ties: the call must fall back to the reference's order), LoG-like zero-mean data, negative values; windows from the
+    compile-time squares and odd rectangles; 1-D and 2-D searches.  Sizes the oracle finishes in milliseconds."""
+    rng = np.random.default_rng(seed)
+    for it in range(n):
+        cost = int(rng.integers(0, 3))
+        if rng.random() < 0.7:
+            kx = ky = int(rng.choice([3, 5, 7, 9, 11, 13]))
+        else:
+            kx, ky = int(rng.integers(1, 8)) * 2 - 1, int(rng.integers(1, 8)) * 2 - 1
+        sx = int(rng.integers(1, 70))
+        sy = int(rng.choice([1, 1, 2, 3]))
+        w = int(rng.integers(kx + 1, 420))
+        h = int(rng.integers(ky + 1, 160))
+        kind = int(rng.integers(0, 5))
+        base = rng.random((h + sy - 1, w + sx - 1))
+        if kind == 0:
+            right = (base * 200.0)
+        elif kind == 1:
+            right = base * 10.0 ** (rng.random(base.shape) * rng.choice([2.0, 6.0, 12.0]) - 3.0)
+        elif kind == 2:
+            right = (base - 0.5) * 60.0                                    # zero-mean (what a LoG / mean-subtraction prefilter leaves)
+        elif kind == 3:
+            right = np.floor(base * 256) * 0.37 + rng.random(base.shape)   # the bench's float texture
+        else:
+            right = base * 1e-3
+        right = right.astype(np.float32)
+        d = (int(rng.integers(0, sx)), int(rng.integers(0, sy)))
+        left = right[d[1]:d[1] + h, d[0]:d[0] + w].copy()
+        left += (rng.random((h, w)).astype(np.float32) - np.float32(0.5)) * np.float32(rng.choice([0.0, 0.01, 1.0]))
+        if rng.random() < 0.3:                                             # a flat patch: ties in exact arithmetic
+            y0, x0 = int(rng.integers(0, h)), int(rng.integers(0, w))
+            v = np.float32(rng.choice([0.0, 3.3, 100.25]))
+            left[y0:y0 + 25, x0:x0 + 45] = v
+            right[y0:y0 + 27, x0:x0 + 60 + sx] = v
+        yield dict(it=it, cost=cost, kernel=(kx, ky), search=(sx, sy), left=left, right=right, kind=kind)
+
+
+def batch_cases(n, seed):
+    """pyramid_correlate_batch: the scenes of pyramid_cases cut into grids of tiles (equal tiles + smaller ones at the right / bottom, so
+    that groups and lone tiles both occur), every prefilter and cost, integer and float scenes."""
+    rng = np.random.default_rng([seed, 99])
+    for c in pyramid_cases(n, seed, prefilters=(0, 1, 2), costs=(0, 1, 2), float_scene=0.5):
+        H, W = c["left"].shape
+        tw, th = int(rng.integers(40, 140)), int(rng.integers(40, 120))
+        boxes = [(x, y, min(tw, W - x), min(th, H - y)) for y in range(0, H, th) for x in range(0, W, tw)]
+        boxes = [b for b in boxes if b[2] >= 16 and b[3] >= 16]
+        if len(boxes) > 12:
+            boxes = [boxes[i] for i in sorted(rng.choice(len(boxes), 12, replace=False))]
+        c["boxes"] = boxes
+        yield c

@@ -127,3 +127,36 @@ def test_fuzz_pyramid_sgm_identical_to_oracle(oracle, n, seed, algorithm):
         if not (np.array_equal(g[..., 2], o[..., 2]) and np.abs(g[..., :2] - o[..., :2]).max() < 1e-5):
             bad.append(c["it"])
     assert not bad, "pyramid_sgm_cases(seed=%d, algorithm=%d) mismatching indices %s" % (seed, algorithm, bad)
+
+
+@pytest.mark.parametrize("n,seed", [(90, 501), (90, 502)])
+def test_fuzz_single_level_float_identical_to_oracle(ctx, oracle, n, seed):
+    """calc_disparity on float rasters through the default dispatch (round 5): the zone matcher with the whole raster as one zone — order-free
+    data without, rounding data with the per-pixel certificate (fp32 tier first) and the exact-order fallback — against the oracle's
+    whole-raster running sums."""
+    bad, paths = [], {}
+    for c in fuzz_cases.bm_float_cases(n, seed):
+        got = stereo.calc_disparity(c["cost"], c["left"], c["right"], vwa.bounding_box(c["left"]), c["search"], c["kernel"], ctx=ctx)
+        p = ctx.last_path()
+        paths[p] = paths.get(p, 0) + 1
+        want = oracle.calc_disparity(c["cost"], c["left"], c["right"], c["kernel"], c["search"])
+        if not np.array_equal(got, want):
+            bad.append((c["it"], c["cost"], c["kernel"], c["search"], c["left"].shape, c["kind"], p, int((got != want).any(-1).sum())))
+    assert not bad, "bm_float_cases(seed=%d): %s" % (seed, bad)
+    assert paths.get(core.PATH_CERTIFIED, 0) >= n // 5 and paths.get(core.PATH_EXACT_ORDER, 0) >= 3, paths      # both outcomes of the certificate occur
+
+
+@pytest.mark.parametrize("n,seed", [(30, 601)])
+def test_fuzz_batch_identical_to_oracle(ctx, oracle, n, seed):
+    """pyramid_correlate_batch on random scenes cut into random tile grids: every tile against the oracle's tile."""
+    bad = []
+    for c in fuzz_cases.batch_cases(n, seed):
+        s = c["search"]
+        got = stereo.pyramid_correlate_batch(c["left"], c["right"], c["lm"], c["rm"], c["pf"], c["pfw"], BBox2i.from_corners(s[:2], s[2:]), c["kernel"], c["cost"],
+                                             [BBox2i(*b) for b in c["boxes"]], consistency_threshold=c["thr"], filter_half_kernel=c["filt"],
+                                             max_pyramid_levels=c["levels"], ctx=ctx)
+        for b, g in zip(c["boxes"], got):
+            o = oracle.pyramid_correlate(c["left"], c["right"], c["lm"], c["rm"], c["pf"], c["pfw"], s, c["kernel"], c["cost"], 0, 0.0, c["thr"], c["filt"], c["levels"], bbox=b)
+            if not np.array_equal(g, o):
+                bad.append((c["it"], b, int((g != o).any(-1).sum())))
+    assert not bad, "batch_cases(seed=%d): (index, tile, differing pixels) %s" % (seed, bad)
