@@ -817,6 +817,7 @@ def main():
     (la, lb), (ra, rb) = partition.strip_inputs(rank, world, H, ky, sy)
     halo = "none (single strip)"
     l_strip = r_strip = None
+    rank_info = None
     if world > 1:
         # The source pair is row-sharded across the GPUs (rank g holds rows row_strip(g, N, rows) of each image, disjoint per HBM);
         # the ky-1 (+sy-1) halo rows a strip's windows read come from the neighbouring rank over RCCL point-to-point (one xGMI
@@ -844,6 +845,15 @@ def main():
         else:
             halo = "host-provided halo rows (halo exchange unusable on some rank%s)" % ((": " + why) if why else "")
             l_strip = r_strip = None
+        # a SCALE record must check itself: every rank says which device it drove, how many ranks its RCCL communicator
+        # held, which halo path it took and whether the rows it received equal the rows of the full image — gathered into config.ranks
+        mine = {"rank": rank, "device": torch.cuda.get_device_name(dev), "pci_bus": torch.cuda.get_device_properties(dev).pci_bus_id
+                if hasattr(torch.cuda.get_device_properties(dev), "pci_bus_id") else None,
+                "rccl_ranks_seen": (fetcher.comm.world if (fetcher.comm is not None and hasattr(fetcher.comm, "world")) else (world if fetcher.comm is not None else 0)),
+                "torch_distributed_world": dist.get_world_size(), "halo_path": fetcher.how, "halo_rows_verified": bool(ok),
+                "output_rows": [int(r0), int(r1)]}
+        rank_info = [None] * world
+        dist.all_gather_object(rank_info, mine)
         fetcher.close()
     if l_strip is None:
         l_strip = torch.from_numpy(left[la:lb]).to(dev)
@@ -943,7 +953,7 @@ def main():
             "data": "synthetic (SplitMix64 integer-valued float32 noise pair, 256-px blocks shifted by 64+-48)",
             "config": {"workload": "BASELINE configs[1]: 4096x4096 pair, 7x7 SAD, search_volume 129x1, calc_disparity",
                        "kernel": list(KERNEL), "search_volume": list(SEARCH),
-                       "partition": "%d row strip(s), no collective in the timed region" % world, "halo": halo,
+                       "partition": "%d row strip(s), no collective in the timed region" % world, "halo": halo, "ranks": rank_info,
                        "clock_settle_ms": args.settle_ms,
                        "path": {core.PATH_SAD_U8: "packed-u8 qsad", core.PATH_GENERIC_F64: "generic f64"}.get(path, "?")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

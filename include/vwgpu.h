@@ -156,7 +156,7 @@ typedef enum vwgpu_option {
   VWGPU_OPT_DEFER_EXACTNESS = 1, VWGPU_OPT_DEVICE_COUNT = 2, VWGPU_OPT_SAD_GROUPS = 3, VWGPU_OPT_EXACT_SCRATCH_MB = 4,
   VWGPU_OPT_TRACE = 5, VWGPU_OPT_SGM_SWEEP = 6, /* 7: removed in ABI 2 */ VWGPU_OPT_MGM_SWEEP = 8, VWGPU_OPT_EXACT_SPLIT = 9,
   /* 10: removed in ABI 2 */ VWGPU_OPT_HOST_RING_KB = 11, VWGPU_OPT_HOST_RING_WRAPS = 12, VWGPU_OPT_CERTIFY = 13,
-  VWGPU_OPT_CERT_PERMILLE = 14, VWGPU_OPT_ZONE_SXC = 15, VWGPU_OPT_CERT_F32 = 16, VWGPU_OPT_CERT_F64_PERMILLE = 17
+  VWGPU_OPT_CERT_PERMILLE = 14, VWGPU_OPT_ZONE_SXC = 15, VWGPU_OPT_CERT_F32 = 16, VWGPU_OPT_CERT_F64_PERMILLE = 17, VWGPU_OPT_ZONE_TILE16 = 18
 } vwgpu_option;
 int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value);
 int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value);

@@ -24,8 +24,9 @@ search = vwa.BBox2i.from_corners((-64, -1), (64, 1))
 dev = lt.device
 
 
-def loop(T, G, pf, pw, cost, kk, reps=4):
+def loop(T, G, pf, pw, cost, kk, reps=int(os.environ.get('TLB_REPS', '4'))):
     ctxs = [vwa.Context(dev.index) for _ in range(T)]
+    for c in ctxs: c.set_option(18, int(os.environ.get('TLB_TILE16', '2')))      # VWGPU_OPT_ZONE_TILE16
     streams = [torch.cuda.Stream(device=dev) for _ in range(T)]
     groups = [tiles[i:i + G] for i in range(0, len(tiles), G)]
     outs = {}
@@ -76,6 +77,7 @@ def loop(T, G, pf, pw, cost, kk, reps=4):
 
 
 for label, pf, pw, cost, kk in (("SAD 7x7", 0, 0.0, 0, 7), ("LoG 1.4 + NCC 11x11", 2, 1.4, 2, 11)):
+    if os.environ.get("TLB_ONLY") and not label.startswith(os.environ["TLB_ONLY"]): continue
     ref = None
     combos = [tuple(int(v) for v in a.split("x")) for a in sys.argv[2:]] or [(4, 1), (4, 4), (2, 8), (1, 16), (4, 2), (2, 4), (8, 2), (3, 6)]
     for T, G in combos:

@@ -1050,11 +1050,9 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     // (Round 4 also built 16 x 16 tiles on one wavefront for the 16 x 16 leaves of the quad tree — on a 32 x 32 tile a quarter of the lanes
     // have pixels there.  Measured on 1024^2 pyramid tiles: every zone on 16-tiles = the same time (their patches carry 2.6x halo and a
     // wavefront per workgroup exposes every LDS round trip); both sizes in one level = two launches with a tail each, slower.  Dropped.)
-#ifdef VWGPU_ZONES16
-    const bool small = getenv("VWGPU_ZONES16") != nullptr;      // tools build: every zone on 16 x 16 tiles
-#else
-    const bool small = false;
-#endif
+    // Round 5: with TILE GROUPS a launch holds the zones of several tiles, the tails are shared, and the leaves pay again: zones that fit a
+    // 16 x 16 tile go to the one-wavefront kernels when VWGPU_OPT_ZONE_TILE16 says so (1 = always, 0 = in group launches, 2 = never).
+    const bool small = z.zw <= 16 && z.zh <= 16 && (ctx->zone_tile16 == 1 || (ctx->zone_tile16 == 0 && n_img > 1));
     ZPlan& pl = small ? plan[1] : plan[0];
     const int ZS = pl.zs;
     const int nx = (z.zw + ZS - 1) / ZS, ny = (z.zh + ZS - 1) / ZS;
@@ -1213,11 +1211,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
                                                                ZLaunch{A, aw, ah, ap, B, bw, bh, bp, kx, ky, pl.sxc, pa, pb, out, pl.P, C, a_tile, b_tile, pa_tile, pb_tile}, dz, tab)
 #define VW_ZN5(C_, K_, A_, T_, S_, E_) do { if (T_ && (K_) > 0 && use32) VW_ZN6(C_, K_, A_, T_, S_, E_, (T_ && (K_) > 0)); else VW_ZN6(C_, K_, A_, T_, S_, E_, false); } while (0)
 #define VW_ZN4(C_, K_, A_, T_, S_) do { if (T_ && edge) VW_ZN5(C_, K_, A_, T_, S_, T_); else VW_ZN5(C_, K_, A_, T_, S_, false); } while (0)
-#ifdef VWGPU_ZONES16
 #define VW_ZN3(C_, K_, A_, T_) do { if (pl.zs == 32) VW_ZN4(C_, K_, A_, T_, 32); else VW_ZN4(C_, K_, A_, T_, 16); } while (0)
-#else
-#define VW_ZN3(C_, K_, A_, T_) VW_ZN4(C_, K_, A_, T_, 32)
-#endif
 #define VW_ZN(C_, K_) do { if (cert) VW_ZN3(C_, K_, double, true); else if (f32_sums) VW_ZN3(C_, K_, float, false); else VW_ZN3(C_, K_, double, false); } while (0)
 #define VW_ZN_K(C_) do { switch (kx == ky ? kx : 0) { case 3: VW_ZN(C_, 3); break; case 5: VW_ZN(C_, 5); break; case 7: VW_ZN(C_, 7); break; \
                                                      case 9: VW_ZN(C_, 9); break; case 11: VW_ZN(C_, 11); break; case 13: VW_ZN(C_, 13); break; \
@@ -1225,12 +1219,8 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
 #define VW_ZN_C() do { switch (cost_type) { case VWGPU_CROSS_CORRELATION: VW_ZN_K(VWGPU_CROSS_CORRELATION); break; \
                                             case VWGPU_SQUARED_DIFFERENCE: VW_ZN_K(VWGPU_SQUARED_DIFFERENCE); break; \
                                             default: VW_ZN_K(VWGPU_ABSOLUTE_DIFFERENCE); break; } } while (0)
-#ifdef VWGPU_ZONES16
 #define VW_MG2(C_, T_) do { if (pl.zs == 32) hipLaunchKernelGGL((zones_merge_kernel<C_, T_, 32>), mgrd, dim3(256), 0, ctx->stream, dz, pl.d_merges, pa, pa_tile, out, pl.P, C); \
                             else hipLaunchKernelGGL((zones_merge_kernel<C_, T_, 16>), mgrd, dim3(64), 0, ctx->stream, dz, pl.d_merges, pa, pa_tile, out, pl.P, C); } while (0)
-#else
-#define VW_MG2(C_, T_) hipLaunchKernelGGL((zones_merge_kernel<C_, T_, 32>), mgrd, dim3(256), 0, ctx->stream, dz, pl.d_merges, pa, pa_tile, out, pl.P, C)
-#endif
 #define VW_MG(C_) do { if (cert) VW_MG2(C_, true); else VW_MG2(C_, false); } while (0)
   const bool use32 = t32;
   for (ZPlan& pl : plan) {                                      // the 32-tiles hold the long items: first

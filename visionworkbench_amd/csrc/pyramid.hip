@@ -405,6 +405,14 @@ __global__ void lr_diff_invalidate_kernel(const int32_t* __restrict__ d, int w, 
   if (!d[((size_t)y * w + x) * 3 + 2]) diff2[((ptrdiff_t)(y + uly) * dstride + (x + ulx)) * 2 + 1] = 0.0f;
 }
 
+// Zeroes `count` 16-byte words at the start of every tile's buffer (blockIdx.y = the tile; buffers at a fixed stride).  hipMemset2DAsync over
+// slices ~100 MB apart took 170 us per call (its fill kernel walks the pitch) — as long as the level's matcher launches.
+__global__ void __launch_bounds__(256)
+zero_tiles_kernel(uint4* __restrict__ base, size_t tile_words, size_t count) {
+  uint4* p = base + blockIdx.y * tile_words;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // finish_masked_kernel / finish_kernel / zero_out_kernel for the tiles of a group (blockIdx.z): per-tile images at a fixed stride, per-tile
 // destinations from a table.  mode[t]: 0 = nothing to write, 1 = finish, 2 = mask + finish, 3 = zeros.
 constexpr int VWGPU_MAX_GROUP = 16;
@@ -1463,7 +1471,11 @@ int vwgpu_pyramid_group_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, 
     const bool last = (level == 0);
     const int scaling = 1 << level;
     dw = Y.lmw[level]; dh = Y.lmh[level];
-    VWGPU_HIP(ctx, hipMemset2DAsync(at(0, disp_off), Y.slice, 0, (size_t)dw * dh * 12, (size_t)n, st));
+    {
+      const size_t words = ((size_t)dw * dh * 12 + 15) / 16;      // (the buffers are 256-byte aligned and sized for the largest level; rounding up stays inside)
+      hipLaunchKernelGGL(zero_tiles_kernel, dim3((unsigned)std::min<size_t>(512, (words + 255) / 256), (unsigned)n), dim3(256), 0, st,
+                         reinterpret_cast<uint4*>(at(0, disp_off)), Y.slice / 16, words);
+    }
     int32_t* disp0 = reinterpret_cast<int32_t*>(at(0, disp_off));
     const int rox = up * hkx / scaling, roy = up * hky / scaling;
     const bool lr_active = P->consistency_threshold >= 0 && last;

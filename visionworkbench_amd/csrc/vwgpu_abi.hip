@@ -242,6 +242,7 @@ int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value) {
   if (option == VWGPU_OPT_TRACE && value >= 0 && value <= 7) { ctx->trace = value; ctx->cert_px[0] = ctx->cert_px[1] = ctx->cert_px[2] = 0; return VWGPU_OK; }
   if (option == VWGPU_OPT_CERTIFY && (value == 0 || value == 1)) { ctx->certify = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_CERT_F32 && (value == 0 || value == 1)) { ctx->cert_f32 = value; return VWGPU_OK; }
+  if (option == VWGPU_OPT_ZONE_TILE16 && value >= 0 && value <= 2) { ctx->zone_tile16 = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_ZONE_SXC && value >= 0 && value <= 4096) { ctx->zone_sxc = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_SGM_SWEEP && value >= 0 && value <= 15) { ctx->sgm_sweep = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_MGM_SWEEP && value >= 0 && value <= 15) { ctx->mgm_sweep = value; return VWGPU_OK; }
@@ -283,6 +284,7 @@ int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value) {
     return VWGPU_OK;
   }
   if (option == VWGPU_OPT_CERT_F32) { *value = ctx->cert_f32; return VWGPU_OK; }
+  if (option == VWGPU_OPT_ZONE_TILE16) { *value = ctx->zone_tile16; return VWGPU_OK; }
   if (option == VWGPU_OPT_CERT_F64_PERMILLE) {
     const unsigned long long all = ctx->cert_px[0] + ctx->cert_px[1];
     *value = all ? (int)((ctx->cert_px[2] * 1000ull) / all) : -1;

@@ -76,6 +76,7 @@ struct vwgpu_ctx {
   int exact_split = 0;        // VWGPU_OPT_EXACT_SPLIT: 0 by the longest chain, 1 always the split pass 2, 2 always the fused one
   int trace = 0;              // VWGPU_OPT_TRACE
   int certify = 1;            // VWGPU_OPT_CERTIFY
+  int zone_tile16 = 2;        // VWGPU_OPT_ZONE_TILE16: zones that fit 16 x 16 on the one-wavefront tile kernels: 0 = in tile groups, 1 = always, 2 = never
   int cert_f32 = 1;           // VWGPU_OPT_CERT_F32: the certified pass runs its fp32 tier first (bm_zones.hip)
   int zone_sxc = 0;           // VWGPU_OPT_ZONE_SXC: 0 = 16 dx per right patch, else at most this many
   unsigned long long cert_px[3] = {0, 0, 0};   // with VWGPU_OPT_TRACE bit 2: pixels in certified tiles / in flagged tiles / in tiles the fp32 tier passed on to float64, so far
