@@ -188,3 +188,29 @@ def test_single_level_order_free_float_raster(ctx, oracle):
         got = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), (61, 1), kernel, ctx=ctx)
         assert ctx.last_path() == core.PATH_GENERIC_F64
         assert np.array_equal(got, want), (cost, int((got != want).any(-1).sum()))
+
+
+@pytest.mark.parametrize("f32,tile16", [(0, 2), (1, 1), (0, 1)])
+def test_tier_and_tile_options_return_the_same_image(ctx, oracle, f32, tile16):
+    """VWGPU_OPT_CERT_F32 = 0 (the certified pass in float64 only) and VWGPU_OPT_ZONE_TILE16 = 1 (zones that fit 16 x 16 on the one-wavefront
+    tile kernels) select other kernels for the same arithmetic: pyramid tiles (LoG + NCC, float SSD) and a single-level float raster."""
+    ctx.set_option(core.OPT_CERT_F32, f32)
+    ctx.set_option(core.OPT_ZONE_TILE16, tile16)
+    try:
+        left, right, scale, trans, search = scenes.pyramid_scene("u8")
+        for cost, kernel, pf in ((2, (11, 11), 2), (1, (7, 7), 0), (0, (5, 5), 2)):
+            l, r = left, right
+            if pf == 0:
+                l = (left * np.float32(0.37) + np.float32(0.11)).astype(np.float32); r = (right * np.float32(0.37) + np.float32(0.07)).astype(np.float32)
+            pfw = float(np.float32(1.4)) if pf else 0.0
+            got = stereo.pyramid_correlate(l, r, None, None, pf, pfw, BBox2i.from_corners(search[:2], search[2:]), kernel, cost, 0, 0.0, 2, 0, 5, 5, ctx=ctx)
+            want = oracle.pyramid_correlate(l, r, None, None, pf, pfw, search, kernel, cost, 0, 0.0, 2, 5, 5)
+            assert np.array_equal(got, want), (cost, int((got != want).any(-1).sum()))
+        rng = np.random.default_rng(4242)
+        fl, fr = _float_scene(rng, 130, 250, 41, 2, decades=2.0)
+        for cost, kernel in ((1, (7, 7)), (2, (9, 9))):
+            got = stereo.calc_disparity(cost, fl, fr, vwa.bounding_box(fl), (41, 2), kernel, ctx=ctx)
+            assert np.array_equal(got, oracle.calc_disparity(cost, fl, fr, kernel, (41, 2)))
+    finally:
+        ctx.set_option(core.OPT_CERT_F32, 1)
+        ctx.set_option(core.OPT_ZONE_TILE16, 2)
