@@ -122,3 +122,33 @@ def test_batch_at_benchmark_size(ctx, oracle):
             w = f.result()
             g = g.cpu().numpy()
             assert np.array_equal(g, w), (b, int((g != w).any(-1).sum()))
+
+
+@pytest.mark.parametrize("cost,kernel,pf", [(0, (7, 7), 0), (1, (7, 7), 0), (2, (9, 9), 0), (2, (7, 7), 2)])
+def test_batch_mixed_level_classes(ctx, oracle, cost, kernel, pf):
+    """Tiles of one group in DIFFERENT kernel classes on the same level: the left part of the pair is integer valued (order free, float32-exact
+    under SAD), the middle a float texture (certified), one tile holds a NaN and an Inf (non-finite: the reference's order only).  Every
+    class is one launch sequence over its tiles; the zone flags, "any" words and R->L buffers of the classes must not collide."""
+    left, right = _scene(900 + cost, H=280, W=720)
+    rng = np.random.default_rng(901)
+    noise = rng.random(left.shape).astype(np.float32)
+    left[:, 240:] = (left[:, 240:] * np.float32(0.37) + noise[:, 240:]).astype(np.float32)
+    right[:, 240:] = (right[:, 240:] * np.float32(0.37) + noise[:, 240:][:, ::-1]).astype(np.float32)
+    left[200, 650] = np.nan
+    right[60, 600] = np.inf
+    boxes = _tiles(720, 280, 120, 140)
+    _check(ctx, left, right, None, None, pf, float(np.float32(1.4)) if pf else 0.0, (-10, -2, 11, 3), kernel, cost, boxes, oracle=oracle)
+    ctx.set_option(core.OPT_CERTIFY, 0)                           # certified tiles become exact-only tiles: classes {0 / 1, 3}
+    try:
+        _check(ctx, left, right, None, None, pf, float(np.float32(1.4)) if pf else 0.0, (-10, -2, 11, 3), kernel, cost, boxes)
+    finally:
+        ctx.set_option(core.OPT_CERTIFY, 1)
+
+
+@pytest.mark.parametrize("which", ["left", "right"])
+def test_batch_with_one_mask_only(ctx, oracle, which):
+    left, right = _scene(55)
+    m = np.full(left.shape, 255, np.uint8)
+    m[100:260, 200:420] = 0
+    lm, rm = (m, None) if which == "left" else (None, m)
+    _check(ctx, left, right, lm, rm, 0, 0.0, (-10, -1, 11, 2), (7, 7), 1, _tiles(600, 420, 150, 140), oracle=oracle)

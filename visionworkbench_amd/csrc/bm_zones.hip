@@ -86,6 +86,7 @@ struct PrecView {           // 1 / box-sum(img^2) over origins [x0, x0+w) x [y0,
 // matter" certificate, additionally turns the infinite precision of an all-zero window into NaN for EVERY pixel of the pass, see below).
 struct ZPrecJob { const float* img; int w, h; ptrdiff_t pitch; double* prec; int x0, y0, pw, ph; float* prec32; };
 struct ZPrecJobs { ZPrecJob j[2]; size_t img_tile[2], prec_tile[2]; };      // blockIdx.z & 1: the left / right image of a pass, blockIdx.z >> 1: the image pair of a group
+constexpr int ZP_TH = 16;          // output rows per workgroup (round 5: 4 -> 16: a 4-row tile squares (4 + ky - 1) / 4 = 3.5 x the pixels it needs at 11 x 11)
 __global__ void __launch_bounds__(256)
 zone_precision_kernel(ZPrecJobs jobs, int kx, int ky, int root) {
   extern __shared__ double zp_sm[];
@@ -95,12 +96,12 @@ zone_precision_kernel(ZPrecJobs jobs, int kx, int ky, int root) {
   double* __restrict__ prec = J.prec + gi * jobs.prec_tile[blockIdx.z & 1];
   const int w = J.w, h = J.h, x0 = J.x0, y0 = J.y0, pw = J.pw, ph = J.ph;
   const ptrdiff_t pitch = J.pitch;
-  if ((int)blockIdx.x * 64 >= pw || (int)blockIdx.y * 4 >= ph) return;
-  const int tw = 64 + kx - 1, th = 4 + ky - 1;
+  if ((int)blockIdx.x * 64 >= pw || (int)blockIdx.y * ZP_TH >= ph) return;
+  const int tw = 64 + kx - 1, th = ZP_TH + ky - 1;
   double* sq = zp_sm;                 // th x tw squares
   double* hs = zp_sm + (size_t)th * tw;   // th x 64 row sums
   const int tid = threadIdx.y * 64 + threadIdx.x;
-  const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
+  const int bx = blockIdx.x * 64, by = blockIdx.y * ZP_TH;
   for (int i = tid; i < tw * th; i += 256) {
     const int r = i / tw, c = i - r * tw;
     int xx = x0 + bx + c; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
@@ -116,17 +117,21 @@ zone_precision_kernel(ZPrecJobs jobs, int kx, int ky, int root) {
     hs[i] = s;
   }
   __syncthreads();
-  const int i = bx + threadIdx.x, j = by + threadIdx.y;
-  if (i >= pw || j >= ph) return;
-  double s = 0.0;
-  for (int b = 0; b < ky; ++b) s += hs[(threadIdx.y + b) * 64 + threadIdx.x];
-  // root: the certified kernels multiply by sqrt(1 / S), see there; root == 2 (passes with the "cannot matter" certificate): NaN for an
-  // all-zero window — such a candidate's cost is NaN in the reference (0 * inf) and never wins unless it is the first one; the chain's
-  // min / max instructions skip a NaN the same way, and the first candidate is looked at separately (ZEdge)
-  double pr = root ? sqrt(1.0 / s) : 1.0 / s;
-  if (root == 2 && !(pr <= 1.7976931348623157e308)) pr = __builtin_nan("");
-  prec[(size_t)j * pw + i] = pr;
-  if (J.prec32) J.prec32[gi * jobs.prec_tile[blockIdx.z & 1] + (size_t)j * pw + i] = (float)pr;
+  const int i = bx + threadIdx.x;
+  if (i >= pw) return;
+  for (int jr = threadIdx.y; jr < ZP_TH; jr += 4) {
+    const int j = by + jr;
+    if (j >= ph) break;
+    double s = 0.0;
+    for (int b = 0; b < ky; ++b) s += hs[(jr + b) * 64 + threadIdx.x];
+    // root: the certified kernels multiply by sqrt(1 / S), see there; root == 2 (passes with the "cannot matter" certificate): NaN for an
+    // all-zero window — such a candidate's cost is NaN in the reference (0 * inf) and never wins unless it is the first one; the chain's
+    // min / max instructions skip a NaN the same way, and the first candidate is looked at separately (ZEdge)
+    double pr = root ? sqrt(1.0 / s) : 1.0 / s;
+    if (root == 2 && !(pr <= 1.7976931348623157e308)) pr = __builtin_nan("");
+    prec[(size_t)j * pw + i] = pr;
+    if (J.prec32) J.prec32[gi * jobs.prec_tile[blockIdx.z & 1] + (size_t)j * pw + i] = (float)pr;
+  }
 }
 
 // A work item: disparities [i0, i0 + n) (index = dy * sx + dx, the reference's loop order) of one 32 x 32 tile of one zone.
@@ -336,7 +341,16 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
   const int ox = geom.ox, oy = geom.oy, tw = geom.tw, th = geom.th;
   const int pw = tw + kx - 1, ph = th + ky - 1;
   const int t = threadIdx.x;
-  const int c = t % ZT, y0 = (t / ZT) * 4;
+  // Lane <-> pixels.  Wide tiles: column t % ZT, rows 4 (t / ZT) .. + 3.  NARROW tiles (round 5: at most 16 columns — the 16 x 16 leaves of the
+  // quad tree are 1249 of the ~2000 zones of a level-0 tile): column t % 16, rows 4 (t / 16) .. + 3, so that a 16 x 16 tile is ONE
+  // full wavefront instead of halves of two, and the wavefronts whose rows lie below the tile skip the vertical pass and the chain
+  // altogether (`wave_active`, a scalar branch — not one of the exec-mask regions the loop was cleared of).  The sum planes keep their
+  // layout; the horizontal pass of a narrow tile has two items per row instead of four.
+  const bool narrow = ZT == 32 && tw <= 16;                       // (workgroup-uniform)
+  const int c = narrow ? (t & 15) : t % ZT, y0 = narrow ? (t >> 4) * 4 : (t / ZT) * 4;
+  const int wave_row0 = __builtin_amdgcn_readfirstlane(narrow ? (t >> 6) * 16 : (t >> 6) * (256 / ZT));      // first row of the wavefront's lanes
+  const bool wave_active = wave_row0 < th;
+  const int qsh = narrow ? 1 : (QL == 4 ? 2 : (QL == 2 ? 1 : 0)); // log2 of the horizontal items per row
 
   // staging: thread <-> (column t % 32, rows t / 32, + ZTHREADS / 32, ...) — no division by the run-time patch width (a flat index
   // cost a 40-instruction division per element: two thirds of the instructions of a 16 x 16 zone with a dozen disparities)
@@ -416,7 +430,7 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
     }
     for (int d = 0; d < nd; ++d) {
       ACC* Hc = H + hb * (PH * HP);
-      if (COST == VWGPU_CROSS_CORRELATION) {
+      if (COST == VWGPU_CROSS_CORRELATION && wave_active) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) rpn[m] = ZKNOCK(32) ? (CT)0 : prow[m][d];      // (lanes without a pixel read pb.p[d]: d < nd <= z.sx <= pb.w, inside the precision image's first row)
       }
@@ -429,8 +443,8 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
         static_assert(KS == 0 || (ZT + KS - 1) * QL <= ZTHREADS, "one horizontal item per thread");
         {
           const int i = t;
-          const int r = i / QL, q = (i % QL) * HW;
-          if (i < ph * QL && q < tw) {
+          const int r = i >> qsh, q = (i & ((1 << qsh) - 1)) * HW;
+          if (i < (ph << qsh) && q < tw) {
             const float* lp = Lp + r * PW + q;
             const float* rp = Rp + r * RW + q + d;
             ACC e[KS > 0 ? KS + HW - 1 : 1];
@@ -488,7 +502,7 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
         }
       }
       if (!ZKNOCK(16)) __syncthreads();
-      if (KS > 0 || c < tw) {                                     // (compile-time window: every lane and row runs, see above)
+      if (wave_active && (KS > 0 || c < tw)) {                    // (compile-time window: every lane and row of a wavefront with pixels runs, see above)
         const int di = i0 + d;
         const bool first = (di == it.i0);
         int div = di;
@@ -1138,13 +1152,13 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     double* db = reinterpret_cast<double*>(sbase + na);
     float* db32 = t32 ? reinterpret_cast<float*>(sbase + na + nb) : nullptr;
     vwgpu_prof_scope ps(ctx, "zone_precision");
-    const size_t zp_lds = ((size_t)(64 + kx - 1) * (4 + ky - 1) + (size_t)(4 + ky - 1) * 64) * sizeof(double);
+    const size_t zp_lds = ((size_t)(64 + kx - 1) * (ZP_TH + ky - 1) + (size_t)(ZP_TH + ky - 1) * 64) * sizeof(double);
     ZPrecJobs zj;
     zj.j[0] = ZPrecJob{A, aw, ah, ap, da, pa.x0, pa.y0, pa.w, pa.h, nullptr};
     zj.j[1] = ZPrecJob{B, bw, bh, bp, db, pb.x0, pb.y0, pb.w, pb.h, db32};
     zj.img_tile[0] = grp ? grp->a_stride : 0; zj.img_tile[1] = grp ? grp->b_stride : 0;
     zj.prec_tile[0] = pa_tile; zj.prec_tile[1] = pb_tile;
-    hipLaunchKernelGGL(zone_precision_kernel, dim3((std::max(pa.w, pb.w) + 63) / 64, (std::max(pa.h, pb.h) + 3) / 4, 2 * n_img), dim3(64, 4), zp_lds, ctx->stream, zj, kx, ky, cert ? (edge ? 2 : 1) : 0);
+    hipLaunchKernelGGL(zone_precision_kernel, dim3((std::max(pa.w, pb.w) + 63) / 64, (std::max(pa.h, pb.h) + ZP_TH - 1) / ZP_TH, 2 * n_img), dim3(64, 4), zp_lds, ctx->stream, zj, kx, ky, cert ? (edge ? 2 : 1) : 0);
     pa.p = da; pb.p = db; pb.pf = db32;
   }
   {
