@@ -18,8 +18,12 @@
 // the reference's own summation order (bm_exact.hip); the class of every level is measured on the device.
 // VW_CORRELATION_MGM runs every level with use_mgm, _FINAL_MGM only level 0 (:365-366).  collar_size is applied by the caller
 // (PyramidCorrelationView::rasterize, CorrelationView.h:123-133: a larger tile is rasterised and cropped).
+#include <atomic>
 #include <chrono>
 #include <climits>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -1222,6 +1226,84 @@ int vwgpu_pyramid_correlate_impl(vwgpu_ctx* ctx, const float* left, int lw, int 
   return VWGPU_OK;
 }
 
+// ---- helper threads of a context ----------------------------------------------------------------------------------------
+// The host side of a tile group is per-tile work on tables the device sent back (the zone scheduler's accept / retry / merge walk, the zone
+// task lists of the next level: ~30 000 zones for 16 tiles at level 0, milliseconds on one thread with the device idle).  A context keeps a
+// few helper threads for it: persistent (the zone scheduler caches its trees per thread), parked on a condition variable between jobs.
+namespace {
+struct HostPool {
+  std::vector<std::thread> workers;
+  std::mutex m;
+  std::condition_variable wake, done;
+  void (*fn)(void*, int) = nullptr;
+  void* arg = nullptr;
+  int n = 0;
+  std::atomic<int> next{0};
+  int running = 0;                   // workers still inside the current job
+  unsigned long long job = 0;        // generation counter
+  bool quit = false;
+  void work() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n) return;
+      fn(arg, i);
+    }
+  }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        wake.wait(lk, [&] { return quit || job != seen; });
+        if (quit) return;
+        seen = job;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (--running == 0) done.notify_one();
+      }
+    }
+  }
+};
+}  // namespace
+
+void vwgpu_pool_run(vwgpu_ctx* ctx, int n, void (*fn)(void*, int), void* arg) {
+  if (n <= 0) return;
+  HostPool* P = static_cast<HostPool*>(ctx->host_pool);
+  if (!P && n >= 4) {
+    P = new HostPool();
+    const unsigned hc = std::thread::hardware_concurrency();
+    const int nw = hc >= 32 ? 7 : (hc >= 8 ? 3 : 0);               // + the calling thread
+    for (int i = 0; i < nw; ++i) P->workers.emplace_back([P] { P->loop(); });
+    ctx->host_pool = P;
+  }
+  if (!P || P->workers.empty() || n < 4) { for (int i = 0; i < n; ++i) fn(arg, i); return; }
+  {
+    std::lock_guard<std::mutex> lk(P->m);
+    P->fn = fn; P->arg = arg; P->n = n; P->next.store(0);
+    P->running = (int)P->workers.size();
+    ++P->job;
+  }
+  P->wake.notify_all();
+  P->work();
+  std::unique_lock<std::mutex> lk(P->m);
+  P->done.wait(lk, [&] { return P->running == 0; });
+}
+
+void vwgpu_pool_destroy(vwgpu_ctx* ctx) {
+  HostPool* P = static_cast<HostPool*>(ctx->host_pool);
+  if (!P) return;
+  {
+    std::lock_guard<std::mutex> lk(P->m);
+    P->quit = true;
+  }
+  P->wake.notify_all();
+  for (std::thread& t : P->workers) t.join();
+  delete P;
+  ctx->host_pool = nullptr;
+}
+
 // ---- tile groups (round 5) ------------------------------------------------------------------------------------------
 // vwgpu_pyramid_correlate_batch: several tiles of ONE image pair, of equal size, through the level loop TOGETHER.  The reference runs one
 // tile per thread (src/vw/Image/ImageIO.h:228-251, BlockProcessor.h:52-176); here a tile is ~50 dependent launches of which the coarse levels
@@ -1250,6 +1332,12 @@ struct GroupTile {
   std::vector<int> cert_hi;
 };
 
+}  // namespace
+
+namespace {
+template <class F> void pool_for(vwgpu_ctx* ctx, int n, F& f) {
+  vwgpu_pool_run(ctx, n, [](void* a, int i) { (*static_cast<F*>(a))(i); }, &f);
+}
 }  // namespace
 
 bool vwgpu_pyramid_group_eligible(const vwgpu_ctx* ctx, const vwgpu_pyramid_params* P, int n, const int* bw, const int* bh) {
@@ -1487,34 +1575,59 @@ int vwgpu_pyramid_group_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, 
     std::vector<vwgpu_zone_task> t1[4], t2[4], t3[4];
     std::vector<int> cls((size_t)n, -1);
     size_t rl_pixels = 0;
-    for (int t = 0; t < n; ++t) {
+    // per tile on the helper threads (R->L offsets local to the tile), then strung together per class
+    struct TileTasks { std::vector<vwgpu_zone_task> a, b, c; size_t rl = 0; int err = 0; };
+    std::vector<TileTasks> TT((size_t)n);
+    auto build_tile = [&](int t) {
       GroupTile& g = T[t];
-      if (!g.alive) continue;
+      TileTasks& tt = TT[t];
+      if (!g.alive) return;
       bool exact = g.exact_level[level] != 0;
       for (SearchZone const& z : g.zones)
         if (z.range.dx() > 0 && z.range.dy() > 0) exact = exact && vwgpu_bm_exact_supported(z.range.dx(), z.range.dy());      // (as the single-tile path: the tile kernels otherwise)
-      const int c = exact ? (g.cert_hi[level] != INT_MIN ? 2 : 3) : (g.f32_level[level] ? 0 : 1);
-      cls[t] = c;
+      cls[t] = exact ? (g.cert_hi[level] != INT_MIN ? 2 : 3) : (g.f32_level[level] ? 0 : 1);
+      tt.a.reserve(g.zones.size());
+      if (lr_active) { tt.b.reserve(g.zones.size()); tt.c.reserve(g.zones.size()); }
       for (SearchZone const& z : g.zones) {
         const IBox lr(z.region.x0 + rox - hkx, z.region.y0 + roy - hky, z.region.x1 + rox + hkx, z.region.y1 + roy + hky);
         const IBox rr(lr.x0 + z.range.x0, lr.y0 + z.range.y0, lr.x1 + z.range.x0 + z.range.dx(), lr.y1 + z.range.y0 + z.range.dy());
         const int zw = z.region.dx(), zh = z.region.dy(), sx = z.range.dx(), sy = z.range.dy();
         if (zw <= 0 || zh <= 0 || sx <= 0 || sy <= 0) continue;
-        if (zw > 65535 * 32 || zh > 65535 * 32) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: zone too large");
+        if (zw > 65535 * 32 || zh > 65535 * 32) { tt.err = 1; return; }
         const long long out_off = (long long)t * (long long)slice_px + (long long)z.region.y0 * dw + z.region.x0;
-        if (out_off > INT32_MAX) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: tile group too large for the zone tables");
+        if (out_off > INT32_MAX) { tt.err = 2; return; }
         vwgpu_zone_task a{lr.x0, lr.y0, rr.x0, rr.y0, zw, zh, sx, sy, (int)out_off, dw, lr_active ? 0 : z.range.x0, lr_active ? 0 : z.range.y0, t};
-        t1[c].push_back(a);
+        tt.a.push_back(a);
         if (lr_active) {
           const int rlw = rr.dx() - kx + 1, rlh = rr.dy() - ky + 1;
-          vwgpu_zone_task b{rr.x0, rr.y0, lr.x0 - sx, lr.y0 - sy, rlw, rlh, sx, sy, (int)rl_pixels, rlw, -sx, -sy, t};
-          t2[c].push_back(b);
-          vwgpu_zone_task cc{(int)rl_pixels, 0, rlw, rlh, zw, zh, 0, 0, a.out_off, dw, z.range.x0, z.range.y0, t};
-          t3[c].push_back(cc);
-          rl_pixels += (size_t)rlw * rlh;
-          if (rl_pixels > (size_t)INT32_MAX / 2) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: tile group too large for the L/R check buffers");
+          vwgpu_zone_task b{rr.x0, rr.y0, lr.x0 - sx, lr.y0 - sy, rlw, rlh, sx, sy, (int)tt.rl, rlw, -sx, -sy, t};
+          tt.b.push_back(b);
+          vwgpu_zone_task cc{(int)tt.rl, 0, rlw, rlh, zw, zh, 0, 0, a.out_off, dw, z.range.x0, z.range.y0, t};
+          tt.c.push_back(cc);
+          tt.rl += (size_t)rlw * rlh;
+          if (tt.rl > (size_t)INT32_MAX / 2) { tt.err = 3; return; }
         }
       }
+    };
+    {
+      size_t nz = 0;
+      for (int t = 0; t < n; ++t) nz += T[t].zones.size();
+      if (nz >= 1024) pool_for(ctx, n, build_tile);                 // (waking the helpers costs tens of microseconds: not for the coarse levels)
+      else for (int t = 0; t < n; ++t) build_tile(t);
+    }
+    for (int t = 0; t < n; ++t) {
+      TileTasks& tt = TT[t];
+      if (tt.err == 1) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: zone too large");
+      if (tt.err == 2) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: tile group too large for the zone tables");
+      if (tt.err == 3 || rl_pixels + tt.rl > (size_t)INT32_MAX / 2) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "pyramid_correlate: tile group too large for the L/R check buffers");
+      if (cls[t] < 0) continue;
+      const int c = cls[t], base = (int)rl_pixels;
+      t1[c].insert(t1[c].end(), tt.a.begin(), tt.a.end());
+      for (vwgpu_zone_task& b : tt.b) b.out_off += base;
+      for (vwgpu_zone_task& cc : tt.c) cc.ax += base;
+      t2[c].insert(t2[c].end(), tt.b.begin(), tt.b.end());
+      t3[c].insert(t3[c].end(), tt.c.begin(), tt.c.end());
+      rl_pixels += tt.rl;
     }
     stamp("zone tasks built", level);
     if (lr_active && rl_pixels) { if ((rc = vwgpu_arena_reserve(ctx, &ctx->zrl, rl_pixels * 12))) return rc; }
@@ -1649,8 +1762,8 @@ int vwgpu_pyramid_group_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, 
       stamp("leaf extents on the host", level);
       const IBox scale_search(0, 0, Y.rpw[level - 1] - Y.lpw[level - 1], Y.rph[level - 1] - Y.lph[level - 1]);
       const IBox next_size(0, 0, Y.lmw[level - 1], Y.lmh[level - 1]);
-      for (int t = 0; t < n; ++t) {
-        if (!T[t].alive) continue;
+      auto refine_tile = [&](int t) {                               // (helper threads: the scheduler keeps its tree of boxes per thread)
+        if (!T[t].alive) return;
         std::vector<SearchZone>& zones = T[t].zones;
         zones.clear();
         vwgpu::subdivide_regions_from_leaves(dw, dh, kx, ky, h_ext + (size_t)t * nleaf, nleaf, zones);
@@ -1662,7 +1775,9 @@ int vwgpu_pyramid_group_impl(vwgpu_ctx* ctx, const float* left, int lw, int lh, 
           z.range.clip(scale_search);
           if (z.range.empty()) z.range = IBox(0, 0, search.width(), search.height());
         }
-      }
+      };
+      if (nleaf * (size_t)n >= 2048) pool_for(ctx, n, refine_tile);
+      else for (int t = 0; t < n; ++t) refine_tile(t);
       stamp("zones of the next level ready", level);
     }
   }

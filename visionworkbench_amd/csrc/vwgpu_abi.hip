@@ -176,6 +176,7 @@ void vwgpu_destroy(vwgpu_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   prof_clear(ctx);
+  vwgpu_pool_destroy(ctx);
   (void)free_arenas(ctx);
   if (ctx->host_ring) (void)hipHostFree(ctx->host_ring);
   for (int i = 0; i < 2; ++i) if (ctx->ring_event[i]) (void)hipEventDestroy(ctx->ring_event[i]);

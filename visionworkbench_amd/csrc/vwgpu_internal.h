@@ -81,7 +81,11 @@ struct vwgpu_ctx {
   int zone_sxc = 0;           // VWGPU_OPT_ZONE_SXC: 0 = 16 dx per right patch, else at most this many
   unsigned long long cert_px[3] = {0, 0, 0};   // with VWGPU_OPT_TRACE bit 2: pixels in certified tiles / in flagged tiles / in tiles the fp32 tier passed on to float64, so far
   int num_cu = 256;
+  void* host_pool = nullptr;  // helper threads for the per-tile host work of tile groups (pyramid.hip), created on first use
 };
+// fn(i) for i in [0, n) on the context's helper threads and the calling thread; returns when all are done.  fn must not throw.
+void vwgpu_pool_run(vwgpu_ctx* ctx, int n, void (*fn)(void*, int), void* arg);
+void vwgpu_pool_destroy(vwgpu_ctx* ctx);
 
 int vwgpu_fail(vwgpu_ctx* ctx, int status, const char* fmt, ...);
 int vwgpu_arena_reserve(vwgpu_ctx* ctx, vwgpu_arena* a, size_t bytes);
