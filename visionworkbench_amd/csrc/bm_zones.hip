@@ -320,6 +320,7 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
   // resident workgroup per CU), items per row
   constexpr int ZT = ZS, ZTHREADS = ZS * ZS / 4, HW = 8, QL = ZS / HW;
   constexpr bool T32 = CERT && sizeof(ACC) == 4;
+  constexpr int DP = (KS > 0 && sizeof(ACC) == 4) ? 2 : 1;        // disparities per step: two with float32 sums, see the disparity loop
   constexpr bool REL32 = T32 && KS >= 9;                          // the tree form of zwindow_sums in both passes (no subtraction), see zcertified
   typedef typename std::conditional<T32, float, double>::type CT; // type of the compare chain and of the NCC right factors
 #ifdef VWGPU_TILE_STAMPS
@@ -336,7 +337,7 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
   constexpr int HP = ZT + 1;
   float* Lp = reinterpret_cast<float*>(smem);                    // PH x PW
   float* Rp = Lp + PH * PW;                                      // PH x RW
-  ACC* H = reinterpret_cast<ACC*>(smem + (((size_t)(PH * PW + PH * RW) * 4 + 7) & ~size_t(7)));   // 2 x PH x HP
+  ACC* H = reinterpret_cast<ACC*>(smem + (((size_t)(PH * PW + PH * RW) * 4 + 7) & ~size_t(7)));   // 2 x DP x PH x HP (float32: four planes in the room of two float64 ones)
 
   const int ox = geom.ox, oy = geom.oy, tw = geom.tw, th = geom.th;
   const int pw = tw + kx - 1, ph = th + ky - 1;
@@ -419,7 +420,11 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
     const CT* pbase;
     if constexpr (T32) pbase = pb.pf; else pbase = pb.p;
     const CT* prow[4] = {pbase, pbase, pbase, pbase};
-    CT rpn[4] = {0, 0, 0, 0};
+    CT rpn[DP][4];
+#pragma unroll
+    for (int u = 0; u < DP; ++u)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) rpn[u][m] = 0;
     if (COST == VWGPU_CROSS_CORRELATION) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -428,11 +433,21 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
         prow[m] = pbase + (in ? off : 0);
       }
     }
-    for (int d = 0; d < nd; ++d) {
-      ACC* Hc = H + hb * (PH * HP);
+    // DP disparities per barrier-delimited step (round 5).  A step is a chain of dependent latencies — patch reads, products, window sums,
+    // plane writes, barrier, plane reads, window sums, compare chain — and four resident workgroups per CU do not cover it: the timeline
+    // (tools/zones_timeline.py) shows 2.5 us per step and workgroup where the VALU work is 1.0.  With float32 sums (half the registers) a
+    // step serves TWO disparities: the left values are read once, the right values overlap in all but one, the second disparity's loads and
+    // arithmetic fill the first one's waits, and the barriers halve.  The chain still sees the disparities in index order.
+    for (int d = 0; d < nd; d += DP) {
+      const bool two = DP == 2 && d + 1 < nd;                     // (workgroup-uniform) the step holds a second disparity
+      ACC* const Hb = H + hb * (DP * PH * HP);
       if (COST == VWGPU_CROSS_CORRELATION && wave_active) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) rpn[m] = ZKNOCK(32) ? (CT)0 : prow[m][d];      // (lanes without a pixel read pb.p[d]: d < nd <= z.sx <= pb.w, inside the precision image's first row)
+        for (int u = 0; u < DP; ++u) {
+          const int dd = two ? d + u : d;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) rpn[u][m] = ZKNOCK(32) ? (CT)0 : prow[m][dd];      // (lanes without a pixel read pb.p[dd]: dd < nd <= z.sx <= pb.w, inside the precision image's first row)
+        }
       }
       if (KS > 0) {
         // HW adjacent columns per thread: KS + HW - 1 cost elements are formed once and the window slides (s' = s - e[j] + e[j + KS]).
@@ -447,45 +462,52 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
           if (i < (ph << qsh) && q < tw) {
             const float* lp = Lp + r * PW + q;
             const float* rp = Rp + r * RW + q + d;
-            ACC e[KS > 0 ? KS + HW - 1 : 1];
+            constexpr int NE = KS > 0 ? KS + HW - 1 : 1;
             // (Tried: every patch read of the item behind ONE wait — an empty asm statement that takes all the values, the compiler then
             // places a single s_waitcnt instead of eight — and the same for the plane reads of the vertical pass: 5 % SLOWER; the early
             // products overlap the later reads inside the wavefront.)
-            float lv[KS > 0 ? KS + HW - 1 : 1], rv[KS > 0 ? KS + HW - 1 : 1];
+            float lv[NE], rv[NE + DP - 1];                        // (the right values of disparity d + 1 are those of d, one further; the last one is the patch's next column or, in the very last step of a row of dx, a stale word that `two` keeps unused)
 #pragma unroll
-            for (int a = 0; a < KS + HW - 1; ++a) { lv[a] = lp[a]; rv[a] = rp[a]; }
-            if (COST == VWGPU_CROSS_CORRELATION && (KS + HW - 1) % 2 == 0) {      // two float products per instruction (v_pk_mul_f32)
+            for (int a = 0; a < NE; ++a) lv[a] = lp[a];
 #pragma unroll
-              for (int a = 0; a < KS + HW - 1; a += 2) {
+            for (int a = 0; a < NE + DP - 1; ++a) rv[a] = rp[a];
+#pragma unroll
+            for (int u = 0; u < DP; ++u) {
+              if (u == 1 && !two) break;
+              ACC e[NE];
+              if (COST == VWGPU_CROSS_CORRELATION && NE % 2 == 0) {      // two float products per instruction (v_pk_mul_f32)
+#pragma unroll
+                for (int a = 0; a < NE; a += 2) {
 #ifdef VWGPU_TILE_STAMPS
-                zfloat2 l2, r2;
-                if (ZKNOCK(1)) { l2.x = (float)(i + a); l2.y = (float)(i - a); r2 = l2; asm volatile("" : "+v"(l2.x), "+v"(r2.y)); }
-                else { l2 = zfloat2{lp[a], lp[a + 1]}; r2 = zfloat2{rp[a], rp[a + 1]}; }
+                  zfloat2 l2, r2;
+                  if (ZKNOCK(1)) { l2.x = (float)(i + a); l2.y = (float)(i - a); r2 = l2; asm volatile("" : "+v"(l2.x), "+v"(r2.y)); }
+                  else { l2 = zfloat2{lp[a], lp[a + 1]}; r2 = zfloat2{rp[a + u], rp[a + u + 1]}; }
 #else
-                const zfloat2 l2 = {lv[a], lv[a + 1]}, r2 = {rv[a], rv[a + 1]};
+                  const zfloat2 l2 = {lv[a], lv[a + 1]}, r2 = {rv[a + u], rv[a + u + 1]};
 #endif
-                const zfloat2 p2 = l2 * r2;
-                e[a] = (ACC)p2.x; e[a + 1] = (ACC)p2.y;
+                  const zfloat2 p2 = l2 * r2;
+                  e[a] = (ACC)p2.x; e[a + 1] = (ACC)p2.y;
+                }
+              } else {
+#pragma unroll
+                for (int a = 0; a < NE; ++a) e[a] = zcost<COST, ACC>(lv[a], rv[a + u]);
               }
-            } else {
+              ACC wsum[HW];
+              zwindow_sums<KS, HW, ACC>(e, wsum);
+              // one address register + immediate offsets (the compiler re-derived base + constant per store); through an address-space-3
+              // pointer, so that the laundered address still selects ds_* instructions
+              typedef __attribute__((address_space(3))) ACC lds_acc;
+              lds_acc* h = (lds_acc*)(Hb + u * (PH * HP) + r * HP + q);
+              asm volatile("" : "+v"(h));
+              if (ZKNOCK(2)) {
+                ACC tot = 0;
 #pragma unroll
-              for (int a = 0; a < KS + HW - 1; ++a) e[a] = zcost<COST, ACC>(lv[a], rv[a]);
-            }
-            ACC wsum[HW];
-            zwindow_sums<KS, HW, ACC>(e, wsum);
-            // one address register + immediate offsets (the compiler re-derived base + constant per store); through an address-space-3
-            // pointer, so that the laundered address still selects ds_* instructions
-            typedef __attribute__((address_space(3))) ACC lds_acc;
-            lds_acc* h = (lds_acc*)(Hc + r * HP + q);
-            asm volatile("" : "+v"(h));
-            if (ZKNOCK(2)) {
-              ACC tot = 0;
+                for (int j = 0; j < HW; ++j) tot += wsum[j];
+                if (tot == (ACC)12345.678) h[0] = tot;
+              } else {
 #pragma unroll
-              for (int j = 0; j < HW; ++j) tot += wsum[j];
-              if (tot == (ACC)12345.678) h[0] = tot;
-            } else {
-#pragma unroll
-              for (int j = 0; j < HW; ++j) h[j] = wsum[j];
+                for (int j = 0; j < HW; ++j) h[j] = wsum[j];
+              }
             }
           }
         }
@@ -497,17 +519,21 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
             const float* rp = Rp + r * RW + q + d;
             ACC s = 0;
             for (int a = 0; a < kx; ++a) s += zcost<COST, ACC>(lp[a], rp[a]);
-            Hc[r * HP + q] = s;
+            Hb[r * HP + q] = s;
           }
         }
       }
       if (!ZKNOCK(16)) __syncthreads();
       if (wave_active && (KS > 0 || c < tw)) {                    // (compile-time window: every lane and row of a wavefront with pixels runs, see above)
-        const int di = i0 + d;
+#pragma unroll
+       for (int u = 0; u < DP; ++u) {
+        if (u == 1 && !two) break;
+        ACC* const Hc = Hb + u * (PH * HP);
+        const int di = i0 + d + u;
         const bool first = (di == it.i0);
         int div = di;
         if (CERT || COST != VWGPU_CROSS_CORRELATION) asm volatile("" : "+v"(div));      // one copy to a vector register per disparity instead of one per select
-        const bool nfar = EDGE ? edge.notfar(d) : true;
+        const bool nfar = EDGE ? edge.notfar(d + u) : true;
         ACC vs[4] = {0, 0, 0, 0};
         if (KS > 0) {                                           // the same slide down the rows (rows beyond th hold stale planes: unused)
           ACC h[KS > 0 ? KS + 3 : 1];
@@ -540,7 +566,7 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
               // evaluation, 20 before.  Non-finite costs: the level holds finite pixels below 2^60 (cert_hi), so S_lr is finite; an
               // infinite right factor shows in rpmax, an infinite cost in best — both end without a certificate.
               if (COST == VWGPU_CROSS_CORRELATION) {
-                const CT rp = rpn[m];                                      // sqrt(1 / S_rr); the left factor scales the records afterwards
+                const CT rp = rpn[u][m];                                   // sqrt(1 / S_rr); the left factor scales the records afterwards
                 rpmax[m] = zmax_raw(rpmax[m], rp);
                 s *= rp;
               }
@@ -568,7 +594,7 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
               bidx[m] = cb ? div : bidx[m];
             } else if constexpr (!T32) {
             if (COST == VWGPU_CROSS_CORRELATION) {
-              const double rp = rpn[m];
+              const double rp = rpn[u][m];
               s *= sqrt(lprec[m] * rp);
             }
             if (it.slot >= 0) bad = bad || (c < tw && y < th && !(fabs(s) <= 1.7976931348623157e308));
@@ -583,6 +609,7 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
             }
           }
         }
+       }
       }
       hb ^= 1;                                                  // next disparity writes the other plane
     }
@@ -1014,7 +1041,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
   if (as > INT32_MAX || bs > INT32_MAX) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "bm_zones: row stride too large");
   const int ap = (int)as, bp = (int)bs;
   if (cost_type == VWGPU_CROSS_CORRELATION || cert) f32_sums = 0;        // (NCC sums are scaled in float64 anyway)
-  const size_t accb = f32_sums ? 4 : 8;
+  const size_t accb = 8;                                          // (float32 sums keep four planes — two disparities per step — in the room of two float64 ones)
   if (n <= 0) return VWGPU_OK;
   if (!vwgpu_bm_zones_supported(kx, ky)) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "bm_zones: kernel %dx%d too large", kx, ky);
   if (cert && !d_zflag) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "bm_zones: certification without zone flags");
