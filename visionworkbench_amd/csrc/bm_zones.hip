@@ -320,7 +320,7 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
   // resident workgroup per CU), items per row
   constexpr int ZT = ZS, ZTHREADS = ZS * ZS / 4, HW = 8, QL = ZS / HW;
   constexpr bool T32 = CERT && sizeof(ACC) == 4;
-  constexpr int DP = (KS > 0 && sizeof(ACC) == 4) ? 2 : 1;        // disparities per step: two with float32 sums, see the disparity loop
+  constexpr int DP = (KS > 0 && T32) ? 2 : 1;                     // disparities per step: two in the fp32 tier, see the disparity loop (the lean float32 chain of order-free SAD / SSD levels gains nothing from it and keeps its small LDS footprint: six workgroups per CU)
   constexpr bool REL32 = T32 && KS >= 9;                          // the tree form of zwindow_sums in both passes (no subtraction), see zcertified
   typedef typename std::conditional<T32, float, double>::type CT; // type of the compare chain and of the NCC right factors
 #ifdef VWGPU_TILE_STAMPS
@@ -1041,7 +1041,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
   if (as > INT32_MAX || bs > INT32_MAX) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "bm_zones: row stride too large");
   const int ap = (int)as, bp = (int)bs;
   if (cost_type == VWGPU_CROSS_CORRELATION || cert) f32_sums = 0;        // (NCC sums are scaled in float64 anyway)
-  const size_t accb = 8;                                          // (float32 sums keep four planes — two disparities per step — in the room of two float64 ones)
+  const size_t accb = f32_sums ? 4 : 8;                           // (the fp32 tier keeps four float32 planes — two disparities per step — in the room of the two float64 ones)
   if (n <= 0) return VWGPU_OK;
   if (!vwgpu_bm_zones_supported(kx, ky)) return vwgpu_fail(ctx, VWGPU_ERR_NOIMPL, "bm_zones: kernel %dx%d too large", kx, ky);
   if (cert && !d_zflag) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "bm_zones: certification without zone flags");
