@@ -60,5 +60,10 @@ for li, idx in enumerate(launches):
     print("   shader clock over a workgroup's life: p5 %.0f  median %.0f  p95 %.0f MHz" % tuple(np.percentile(mhz, [5, 50, 95])))
     print("   resident workgroups over the span (40 samples): " + " ".join(str(r) for r in res))
     print("   workgroups per CU: min %d max %d (%d CUs)" % (min(percu), max(percu), len(percu)))
+    pl = ((st[idx, 3] >> np.uint64(52)) & np.uint64(0xfff)).astype(np.float64) / 100.0
+    pr = ((st[idx, 3] >> np.uint64(40)) & np.uint64(0xfff)).astype(np.float64) / 100.0
+    steps = np.maximum(ev[idx] / 1024.0, 1.0)
+    print("   phases (us, p50 / p90): start -> left patch requested %.1f / %.1f | -> first right patch staged %.1f / %.1f | rest of the life (loop) %.1f / %.1f" %
+          (np.percentile(pl, 50), np.percentile(pl, 90), np.percentile(pr, 50), np.percentile(pr, 90), np.percentile(life - pr, 50), np.percentile(life - pr, 90)))
     starts = np.sort(s_us[idx]) - a
     print("   start times: #256 %.1f  #512 %.1f  #1024 %.1f  last %.1f us" % tuple(starts[min(k_, len(starts) - 1)] for k_ in (255, 511, 1023, len(starts) - 1)))

@@ -367,6 +367,10 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
     }
   }
   CT best[4], worst[4], second[4], rpmax[4];
+#ifdef VWGPU_TILE_STAMPS
+  unsigned long long stamp_l = 0, stamp_r1 = 0;                  // tools build: after the left patch is staged / after the first right patch is
+  if (g_zone_stamps && threadIdx.x == 0) stamp_l = wall_clock64();      // (the loads are in flight here; the first barrier waits for them)
+#endif
   double lprec[4];
   int bidx[4];
   bool bad = false;
@@ -409,6 +413,9 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
       }
     }
     __syncthreads();
+#ifdef VWGPU_TILE_STAMPS
+    if (g_zone_stamps && threadIdx.x == 0 && stamp_r1 == 0) stamp_r1 = wall_clock64();
+#endif
     // NCC: the right precisions of a disparity are requested before its horizontal pass and consumed after it (a load issued where it is
     // used put a memory round trip on the critical path of every disparity)
     // (Nothing inside the disparity loop sits under a per-row or per-lane condition that can be avoided: twelve exec-mask regions — four
@@ -624,7 +631,9 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
     if (k < (1u << 18)) {
       unsigned long long* rec = g_zone_stamps + (size_t)k * 4;
       rec[0] = stamp_t0; rec[1] = wall_clock64(); rec[2] = ((unsigned long long)xcc << 32) | hw;
-      rec[3] = ((unsigned long long)(unsigned)(clock64() - stamp_c0) << 32) | (unsigned)(it.n * tw * th);      // shader clocks of the item | its evaluations
+      // (phases: ticks of the 100 MHz clock from the start to "left patch requested" and to "first right patch staged", 12 bits each, in the top of the clock word)
+      const unsigned long long pl_ = min(stamp_l - stamp_t0, 4095ull), pr_ = min(stamp_r1 - stamp_t0, 4095ull);
+      rec[3] = (pl_ << 52) | (pr_ << 40) | (((unsigned long long)(unsigned)(clock64() - stamp_c0) & 0xffffffull) << 32 >> 0) | (unsigned)(it.n * tw * th);
     }
   }
 #endif
