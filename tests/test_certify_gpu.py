@@ -214,3 +214,26 @@ def test_tier_and_tile_options_return_the_same_image(ctx, oracle, f32, tile16):
     finally:
         ctx.set_option(core.OPT_CERT_F32, 1)
         ctx.set_option(core.OPT_ZONE_TILE16, 2)
+
+
+@pytest.mark.parametrize("cost,kernel,search", [(0, (7, 7), (21, 1)), (1, (5, 5), (9, 3)), (2, (11, 11), (33, 2))])
+def test_single_level_partial_redo_of_flagged_tile_rows(ctx, oracle, cost, kernel, search):
+    """A few unprovable pixels in a large float raster: only the tile rows that hold them are redone in the reference's order — the column
+    chains run from the raster's first row (bm_exact.hip, row ranges) — in the middle, at the top, at the bottom of the raster, in two
+    separate bands; and a raster flagged nearly everywhere (the whole call in the reference's order).  Always the oracle's image."""
+    rng = np.random.default_rng(7300 + cost)
+    H, W = 420, 520
+    left, right = _float_scene(rng, H, W, search[0], search[1], decades=4.0)
+    def flat(y0, y1, x0, x1):
+        left[y0:y1, x0:x1] = np.float32(2.7)
+        right[y0:y1 + search[1] - 1, x0:x1 + search[0] + 30] = np.float32(2.7)
+    for bands in ([(200, 230)], [(0, 25)], [(H - 30, H)], [(40, 70), (300, 340)], [(0, H)]):
+        l0, r0 = left.copy(), right.copy()
+        for (a, b) in bands:
+            flat(a, b, 100, 260)
+        want = oracle.calc_disparity(cost, left, right, kernel, search)
+        got = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), search, kernel, ctx=ctx)
+        assert np.array_equal(got, want), (bands, ctx.last_path(), int((got != want).any(-1).sum()))
+        # (SAD on this scene may be order free — every sum representable: then no certificate is needed at all)
+        assert ctx.last_path() == core.PATH_EXACT_ORDER or (cost == 0 and ctx.last_path() == core.PATH_GENERIC_F64), (bands, ctx.last_path())
+        left[:], right[:] = l0, r0

@@ -157,6 +157,7 @@ bmx_col_kernel(const float* __restrict__ A, int aw, int ah, ptrdiff_t as, const 
   } else {
     cs = state[(size_t)col * dp + d];
   }
+  const bool wr = vol != nullptr;                        // nullptr: only advance the chains (rows nobody will read: partial redo of a raster)
   double* v = vol + z.vol + (size_t)col * lay.xs + lay.off(d);
   const size_t rstride = lay.rs;
   int y = y0;
@@ -167,7 +168,7 @@ bmx_col_kernel(const float* __restrict__ A, int aw, int ah, ptrdiff_t as, const 
       for (int i = 0; i < KY; ++i) in[i] = elem(y + KY + i);
 #pragma unroll
       for (int i = 0; i < KY; ++i) {
-        v[(size_t)(y + i - y0) * rstride] = cs;
+        if (wr) v[(size_t)(y + i - y0) * rstride] = cs;
         cs += in[i];                                    // Algorithms.h:100-103: two statements, this order
         cs -= prev[i];
       }
@@ -181,13 +182,13 @@ bmx_col_kernel(const float* __restrict__ A, int aw, int ah, ptrdiff_t as, const 
     for (int i = 0; i < 8; ++i) { in[i] = elem(y + ky + i); out[i] = elem(y + i); }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      v[(size_t)(y + i - y0) * rstride] = cs;
+      if (wr) v[(size_t)(y + i - y0) * rstride] = cs;
       cs += in[i];                                      // Algorithms.h:100-103: two statements, this order
       cs -= out[i];
     }
   }
   for (; y < y1; ++y) {
-    v[(size_t)(y - y0) * rstride] = cs;
+    if (wr) v[(size_t)(y - y0) * rstride] = cs;
     if (y + 1 < z.zh) {
       cs += elem(y + ky);
       cs -= elem(y);
@@ -1067,7 +1068,9 @@ size_t table_bytes(const Tables& t) { return TablePieces(t).all; }
 template <int COST>
 void launch_pair(vwgpu_ctx* ctx, const char* n1, const char* n2, const float* A, int aw, int ah, ptrdiff_t as,
                  const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky, const Tables& t, const DevTables& d, double* vol,
-                 int y_begin, int y_end, double* state, const double* prec, int32_t* out, double* outd, XCarry* carry = nullptr, XCarry* part = nullptr) {
+                 int y_begin, int y_end, double* state, const double* prec, int32_t* out, double* outd, XCarry* carry = nullptr, XCarry* part = nullptr,
+                 bool col_only = false) {
+  if (col_only) vol = nullptr;                          // the column chains advance over [y_begin, y_end) without leaving their sums
   if (!t.col_items.empty()) {
     vwgpu_prof_scope ps(ctx, n1);
 #define VWGPU_CK(K) hipLaunchKernelGGL((bmx_col_kernel<COST, K>), dim3((unsigned)t.col_items.size()), dim3(256), 0, ctx->stream, \
@@ -1084,6 +1087,7 @@ void launch_pair(vwgpu_ctx* ctx, const char* n1, const char* n2, const float* A,
     }
 #undef VWGPU_CK
   }
+  if (col_only) return;
   if (!t.row_items.empty() || !t.rs_items.empty() || !t.tl_items.empty()) {
     constexpr bool BOX = (COST == XCOST_BOX || COST == XCOST_PREC);
     const dim3 grd((unsigned)(t.row_items.size() / 4)), blk(256);
@@ -1218,7 +1222,8 @@ int vwgpu_float_grain(vwgpu_ctx* ctx, const float* a, int aw, int ah, ptrdiff_t 
 struct DGroup { int d0, dn, carry_mode; XCarry* carry; };
 static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, ptrdiff_t as,
                      const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky,
-                     const vwgpu_zone_task* zones, int n, int32_t* out, const DGroup* dgroup = nullptr, const int* const* gates = nullptr) {
+                     const vwgpu_zone_task* zones, int n, int32_t* out, const DGroup* dgroup = nullptr, const int* const* gates = nullptr,
+                     const int* rows = nullptr, int nranges = 0) {
   const bool ncc = cost_type == VWGPU_CROSS_CORRELATION;
   Tables match, box;                                  // box: the NCC precision images of every zone, left and right crops in one table
   size_t prec_doubles = 0;
@@ -1246,12 +1251,18 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
   const size_t budget = exact_scratch_budget(ctx);
   int band = INT_MAX;
   size_t state_doubles = 0;
-  if (match.vol_doubles * 8 > budget && match.zones.size() == 1) {
+  const bool partial = rows && nranges > 0 && match.zones.size() == 1 && !dgroup;      // only some output rows are wanted (a certified raster's flagged tile rows)
+  if ((match.vol_doubles * 8 > budget || partial) && match.zones.size() == 1) {
     XZone& z = match.zones[0];
     const int dp = dp_alloc(z.dn), cw = z.zw + kx - 1;
     const size_t row = (size_t)cw * dp * 8;
     band = (int)std::max<size_t>(1, budget / row);
-    if (band >= z.zh) band = INT_MAX;
+    if (partial) {                                              // bands no taller than the tallest wanted range; the chain state is always carried
+      int tallest = 1;
+      for (int i = 0; i < nranges; ++i) tallest = std::max(tallest, rows[2 * i + 1] - rows[2 * i]);
+      band = std::min(band, tallest);
+      match.vol_doubles = (size_t)band * cw * dp; state_doubles = (size_t)cw * dp;
+    } else if (band >= z.zh) band = INT_MAX;
     else { match.vol_doubles = (size_t)band * cw * dp; state_doubles = (size_t)cw * dp; }
   }
   // zones at least this wide take the split pass 2, narrower ones the tiled kernel (VWGPU_OPT_EXACT_SPLIT: 0 = 1024 pixels — whole rasters
@@ -1271,7 +1282,7 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
   XCarry* part = reinterpret_cast<XCarry*>(prec + prec_doubles);
   // tables of every launch of this call live side by side (uploads are stream ordered)
   size_t tb = table_bytes(match) + table_bytes(box) + 4096;
-  if (band != INT_MAX) tb += (size_t)((match.zones[0].zh + band - 1) / band) * (table_bytes(match) + 1024);
+  if (band != INT_MAX) tb += (size_t)((match.zones[0].zh + band - 1) / band + 2 * (size_t)std::max(nranges, 0) + 2) * (table_bytes(match) + 1024);
   rc = vwgpu_arena_reserve(ctx, &ctx->xtab, tb);
   if (rc) return rc;
   char* cur = static_cast<char*>(ctx->xtab.base);
@@ -1282,18 +1293,34 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
     launch_pair<XCOST_PREC>(ctx, "bmx_prec_col", "bmx_prec_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, box, d, vol, 0, INT_MAX, nullptr, nullptr, nullptr, prec);
   }
   const int zh0 = match.zones[0].zh;
-  const int nbands = band == INT_MAX ? 1 : (zh0 + band - 1) / band;
-  for (int b = 0; b < nbands; ++b) {
-    const int yb = band == INT_MAX ? 0 : b * band, ye = band == INT_MAX ? INT_MAX : yb + band;
+  // the row segments of the call: {first row, last row + 1, column chains only}
+  struct Seg { int yb, ye; bool col_only; };
+  std::vector<Seg> segs;
+  if (partial) {
+    int y = 0;
+    for (int i = 0; i < nranges; ++i) {
+      const int a = std::max(rows[2 * i], y), b = std::min(rows[2 * i + 1], zh0);
+      if (b <= a) continue;
+      if (a > y) segs.push_back(Seg{y, a, true});              // nobody reads these rows: the chains run through them, nothing is stored
+      for (int yb = a; yb < b; yb += band) segs.push_back(Seg{yb, std::min(yb + band, b), false});
+      y = b;
+    }                                                           // (rows below the last wanted range are not visited at all)
+  } else {
+    const int nbands = band == INT_MAX ? 1 : (zh0 + band - 1) / band;
+    for (int b = 0; b < nbands; ++b) segs.push_back(Seg{band == INT_MAX ? 0 : b * band, band == INT_MAX ? INT_MAX : b * band + band, false});
+  }
+  for (const Seg& sg : segs) {
+    const int yb = sg.yb, ye = sg.ye;
+    const bool col_only = sg.col_only;
     if (band != INT_MAX) build_items(match, kx, yb, ye, split_from, tiled_from, tiled_to);
     if ((rc = upload(ctx, match, cur, end, &d))) return rc;
     switch (cost_type) {
       case VWGPU_CROSS_CORRELATION:
-        launch_pair<VWGPU_CROSS_CORRELATION>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr, dgroup ? dgroup->carry : nullptr, part); break;
+        launch_pair<VWGPU_CROSS_CORRELATION>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr, dgroup ? dgroup->carry : nullptr, part, col_only); break;
       case VWGPU_SQUARED_DIFFERENCE:
-        launch_pair<VWGPU_SQUARED_DIFFERENCE>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr, dgroup ? dgroup->carry : nullptr, part); break;
+        launch_pair<VWGPU_SQUARED_DIFFERENCE>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr, dgroup ? dgroup->carry : nullptr, part, col_only); break;
       default:
-        launch_pair<VWGPU_ABSOLUTE_DIFFERENCE>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr, dgroup ? dgroup->carry : nullptr, part); break;
+        launch_pair<VWGPU_ABSOLUTE_DIFFERENCE>(ctx, "bmx_col", "bmx_row", A, aw, ah, as, B, bw, bh, bs, kx, ky, match, d, vol, yb, ye, state, prec, out, nullptr, dgroup ? dgroup->carry : nullptr, part, col_only); break;
     }
   }
   VWGPU_HIP(ctx, hipGetLastError());
@@ -1304,7 +1331,8 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
 // groups whose column-sum volumes fit the scratch budget (VWGPU_OPT_EXACT_SCRATCH_MB, default 4096).
 int vwgpu_launch_bm_exact(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, ptrdiff_t as,
                           const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky,
-                          const vwgpu_zone_task* zones, int n, int32_t* out, const int* d_gate) {
+                          const vwgpu_zone_task* zones, int n, int32_t* out, const int* d_gate, const int* rows, int nranges) {
+  if (n != 1 || d_gate) { rows = nullptr; nranges = 0; }          // row ranges: single-zone calls (a raster whose certified pass flagged some tile rows)
   const size_t budget = exact_scratch_budget(ctx);
   std::vector<vwgpu_zone_task> group;
   std::vector<const int*> group_gate;                 // d_gate != nullptr: zone i works only if d_gate[i] != 0 (decided on the device)
@@ -1344,7 +1372,7 @@ int vwgpu_launch_bm_exact(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     bytes += need;
   }
   if (group.empty()) return VWGPU_OK;
-  return run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, group.data(), (int)group.size(), out, nullptr, gates_of());
+  return run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, group.data(), (int)group.size(), out, nullptr, gates_of(), rows, nranges);
 }
 
 // fast_box_sum<double>(image, kernel) (Algorithms.h:41-43) in the reference's order.  d_out: (w-kx+1) x (h-ky+1) doubles, dense.

@@ -148,7 +148,8 @@ struct ZPart { double* best; double* worst; int* idx; double* second; double* rp
 // certification constants of a zone: bounds on |tile-parallel sum - reference running sum| (see vwgpu_launch_bm_zones)
 struct ZCert { double eps_s, eps_ll, eps_rr, eps32; int edge_lo, edge_hi, pad0, pad1; };      // eps32: bound on |float32 tile sum - exact sum| of the fp32 tier, see vwgpu_launch_bm_zones
 struct ZCertArgs { const ZCert* zc; int* zflag; unsigned long long* stats; int* any; const int* need; const unsigned char* cells;
-                   int edge_m, edge_k; };     // zc == nullptr: no certification; any[image]: "some zone was flagged"; edge_* (the bounds: per zone, in ZCert): see ZEdge
+                   int edge_m, edge_k;        // zc == nullptr: no certification; any[image]: "some zone was flagged"; edge_* (the bounds: per zone, in ZCert): see ZEdge
+                   int* tflag; int tnx; };    // tflag != nullptr (single-zone callers): the 32 x 32 tiles with an unproven pixel, tflag[tile y * tnx + tile x] = 1
 // The "cannot matter" certificate (EDGE kernels; edge_m > 0).  A candidate (pixel, disparity) whose partner lies edge_m or more columns
 // outside the other image — partner column = origin of its window in the other image - edge_k, outside [edge_lo, edge_hi] — is FAR
 // (edge_m > 0 switches the certificate on; the caller folds the margin into the two bounds).  Far windows are clamped copies of the border column: whole runs of them have bit-identical data, their costs tie exactly
@@ -730,7 +731,10 @@ bm_zones_kernel(ZLaunch G, const vwgpu_zone_task* __restrict__ zones, const ZIte
   if (CERT && it.slot < 0) {
     const int any = __syncthreads_or(uncert ? 1 : 0);
     if (threadIdx.x == 0) {
-      if (any) { G.C.zflag[it.zone] = 1; if (G.C.any) G.C.any[z.img] = 1; }
+      if (any) {
+        G.C.zflag[it.zone] = 1; if (G.C.any) G.C.any[z.img] = 1;
+        if (G.C.tflag) G.C.tflag[(it.txy >> 16) * G.C.tnx + (it.txy & 0xffff)] = 1;
+      }
       if (G.C.stats) {
         atomicAdd(&G.C.stats[any ? 1 : 0], (unsigned long long)(geom.tw * geom.th));
         if (tier) atomicAdd(&G.C.stats[2], (unsigned long long)(geom.tw * geom.th));      // pixels of tiles the fp32 tier passed on
@@ -838,7 +842,10 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
   if (CERT) {
     const int any = __syncthreads_or(uncert ? 1 : 0);
     if (t == 0) {
-      if (any) { C.zflag[it.zone] = 1; if (C.any) C.any[z.img] = 1; }
+      if (any) {
+        C.zflag[it.zone] = 1; if (C.any) C.any[z.img] = 1;
+        if (C.tflag) C.tflag[(it.txy >> 16) * C.tnx + (it.txy & 0xffff)] = 1;
+      }
       if (C.stats) { atomicAdd(&C.stats[any ? 1 : 0], (unsigned long long)(tw * th)); }
     }
   }
@@ -1034,7 +1041,7 @@ size_t zones_lds_fixed(int zs, int kx, int ky, size_t accb) { return (size_t)(zs
 int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, const float* B, int bw, int bh,
                           int kx, int ky, const vwgpu_zone_task* zones, int n, int32_t* out, int f32_sums, int cert_hi, int* d_zflag,
                           unsigned long long* d_stats, int* d_any, const int* d_need, const unsigned char* d_cells,
-                          int edge_m, int edge_k, int edge_lo, int edge_hi, ptrdiff_t as, ptrdiff_t bs, const vwgpu_zone_group* grp) {
+                          int edge_m, int edge_k, int edge_lo, int edge_hi, ptrdiff_t as, ptrdiff_t bs, const vwgpu_zone_group* grp, int* d_tflag) {
   const int n_img = grp ? std::max(1, grp->n_img) : 1;
   if (grp && grp->cert_hi) {                                      // (a group is certified as a whole or not at all: the caller sorts its image pairs into such groups)
     cert_hi = INT_MIN;
@@ -1102,7 +1109,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     // wavefront per workgroup exposes every LDS round trip); both sizes in one level = two launches with a tail each, slower.  Dropped.)
     // Round 5: with TILE GROUPS a launch holds the zones of several tiles, the tails are shared, and the leaves pay again: zones that fit a
     // 16 x 16 tile go to the one-wavefront kernels when VWGPU_OPT_ZONE_TILE16 says so (1 = always, 0 = in group launches, 2 = never).
-    const bool small = z.zw <= 16 && z.zh <= 16 && (ctx->zone_tile16 == 1 || (ctx->zone_tile16 == 0 && n_img > 1));
+    const bool small = !d_tflag && z.zw <= 16 && z.zh <= 16 && (ctx->zone_tile16 == 1 || (ctx->zone_tile16 == 0 && n_img > 1));      // (tile flags are per 32 x 32 tile)
     ZPlan& pl = small ? plan[1] : plan[0];
     const int ZS = pl.zs;
     const int nx = (z.zw + ZS - 1) / ZS, ny = (z.zh + ZS - 1) / ZS;
@@ -1254,7 +1261,9 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
       plan[k].P.redo = f; f += plan[k].merges.size();
     }
   }
-  ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats, d_any, d_need, d_cells, edge_m, edge_k};
+  if (d_tflag && (n != 1 || d_need)) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "bm_zones: tile flags are for single-zone calls");
+  ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats, d_any, d_need, d_cells, edge_m, edge_k, d_tflag,
+              d_tflag ? (zones[0].zw + 31) / 32 : 0};
   const size_t a_tile = grp ? grp->a_stride : 0, b_tile = grp ? grp->b_stride : 0;
 
 #define VW_ZN6(C_, K_, A_, T_, S_, E_, T32_) hipLaunchKernelGGL((bm_zones_kernel<C_, K_, A_, T_, S_, E_, T32_>), grd, dim3(S_ * S_ / 4), pl.lds, ctx->stream, \

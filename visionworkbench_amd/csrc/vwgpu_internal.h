@@ -170,7 +170,8 @@ int vwgpu_float_grain(vwgpu_ctx* ctx, const float* a, int aw, int ah, ptrdiff_t 
 void vwgpu_launch_float_grain(vwgpu_ctx* ctx, int n, const float* const* img, const int* w, const int* h, const ptrdiff_t* stride, int* const* d_cells);
 int vwgpu_launch_bm_exact(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int ah, ptrdiff_t as,
                           const float* B, int bw, int bh, ptrdiff_t bs, int kx, int ky,
-                          const vwgpu_zone_task* zones, int n, int32_t* out, const int* d_gate = nullptr);   // d_gate[i] == 0 (device): zone i is skipped
+                          const vwgpu_zone_task* zones, int n, int32_t* out, const int* d_gate = nullptr,   // d_gate[i] == 0 (device): zone i is skipped
+                          const int* rows = nullptr, int nranges = 0);   // one zone only: produce just the output rows [rows[2i], rows[2i+1]) (sorted, disjoint); the column chains still run from row 0
 int vwgpu_launch_box_sum_exact(vwgpu_ctx* ctx, const float* img, int w, int h, ptrdiff_t stride, int kx, int ky, double* d_out);
 
 int vwgpu_launch_lr_check(vwgpu_ctx* ctx, int32_t* l2r, int lw, int lh, ptrdiff_t ls,
@@ -258,7 +259,8 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
                           const int* d_need = nullptr, const unsigned char* d_cells = nullptr,      // (optional) what to match of every zone, from vwgpu_launch_zone_need
                           int edge_m = 0, int edge_k = 0, int edge_lo = 0, int edge_hi = 0,      // certified passes: edge_m > 0 turns the "cannot matter" certificate on (bm_zones.hip, ZEdge)
                           ptrdiff_t as = 0, ptrdiff_t bs = 0,                                      // row strides of A / B in floats (0: the widths)
-                          const vwgpu_zone_group* grp = nullptr);                                  // several image pairs in one launch sequence; d_any then has n_img words
+                          const vwgpu_zone_group* grp = nullptr,                                   // several image pairs in one launch sequence; d_any then has n_img words
+                          int* d_tflag = nullptr);                                                 // single-zone certified calls: one int per 32 x 32 tile of the zone (zeroed by the caller), set for tiles with an unproven pixel
 // The part of every zone's R->L image that its L/R check (vwgpu_launch_zone_lr, same tasks) will read, from the finished L->R result:
 // a rectangle per zone (d_need, 8 ints per zone) and a flag per 16 x 16 cell (d_cells; vwgpu_zone_need_cells numbers the cells into the
 // tasks' `ay` slot and returns their count).  d_zflag (optional): L->R zones still to be matched again ask for the whole image.
