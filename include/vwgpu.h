@@ -32,8 +32,11 @@ extern "C" {
  *     version 1 passes a struct that is 8 bytes shorter), VWGPU_PATH_REFUSED replaces the silent float64 fallback of
  *     VWGPU_OPT_DEFER_EXACTNESS, vwgpu_trim, vwgpu_halo_headers_agree, the host-ring and certification options; options 7
  *     (VWGPU_OPT_EXACT_LDS) and 10 (VWGPU_OPT_CORR_MFMA) are gone with the two slower kernel variants they selected.
+ * 3 (round 5): vwgpu_pyramid_correlate_batch[_dev] (tile groups); vwgpu_last_path() may answer VWGPU_PATH_CERTIFIED (single-level calls on
+ *     float rasters proven equal to the reference's summation order); options VWGPU_OPT_CERT_F32, _CERT_F64_PERMILLE, _ZONE_TILE16.  No struct
+ *     of version 2 changed: a version-2 host keeps working against this library, a version-3 host needs it for the batch entry.
  * A host checks vwgpu_abi_version() == VWGPU_ABI_VERSION once after loading the library (vw::engine does, vw/Engine.h). */
-#define VWGPU_ABI_VERSION 2
+#define VWGPU_ABI_VERSION 3
 
 typedef struct vwgpu_ctx vwgpu_ctx;
 

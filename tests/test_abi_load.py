@@ -30,7 +30,7 @@ def test_header_symbols_exported():
 def test_python_binding_covers_header():
     assert sorted(_lib.SYMBOLS) == _declared_symbols()
     lib = _lib.load()
-    assert lib.vwgpu_abi_version() == 2
+    assert lib.vwgpu_abi_version() == 3
     assert lib.vwgpu_strerror(-1) == b"invalid argument"
 
 

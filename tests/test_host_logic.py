@@ -82,7 +82,7 @@ def test_no_context_functions_validate_arguments():
     assert lib.vwgpu_subdivide_regions(d.ctypes.data, 0, 4, 7, 7, z.ctypes.data, 8) < 0   # empty image
     assert lib.vwgpu_subdivide_regions(None, 4, 4, 7, 7, z.ctypes.data, 8) < 0
     assert lib.vwgpu_strerror(-1) and lib.vwgpu_strerror(-2) and lib.vwgpu_strerror(0)
-    assert lib.vwgpu_abi_version() == 2
+    assert lib.vwgpu_abi_version() == 3
     with pytest.raises(Exception):
         stereo.subdivide_regions(np.zeros((4, 4), np.int32), (7, 7))
 
