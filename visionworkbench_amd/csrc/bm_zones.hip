@@ -357,13 +357,31 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
   // staging: thread <-> (column t % 32, rows t / 32, + ZTHREADS / 32, ...) — no division by the run-time patch width (a flat index
   // cost a 40-instruction division per element: two thirds of the instructions of a 16 x 16 zone with a dozen disparities)
   constexpr int SROWS = ZTHREADS / 32;
+  // (compile-time windows: the rows of a column are requested TOGETHER and stored afterwards — the plain nested loop compiled to one load
+  // per s_waitcnt, five or six dependent memory round trips per patch: the timeline showed 10 - 20 us of an item's 40 - 50 before its loop)
+  constexpr int SRIT = KS > 0 ? (ZT + KS - 1 + SROWS - 1) / SROWS : 1;      // row iterations of a staging thread
   {
     const int q0 = t & 31, r0 = t >> 5;
     for (int q = q0; q < pw; q += 32) {
       int xx = z.ax + ox + q; xx = xx < 0 ? 0 : (xx >= aw ? aw - 1 : xx);
-      for (int r = r0; r < ph; r += SROWS) {
-        int yy = z.ay + oy + r; yy = yy < 0 ? 0 : (yy >= ah ? ah - 1 : yy);
-        Lp[r * PW + q] = A[(size_t)yy * ap + xx];
+      if (KS > 0) {
+        float v[SRIT];
+#pragma unroll
+        for (int k = 0; k < SRIT; ++k) {
+          const int r = r0 + k * SROWS;
+          int yy = z.ay + oy + r; yy = yy < 0 ? 0 : (yy >= ah ? ah - 1 : yy);
+          v[k] = r < ph ? A[(size_t)yy * ap + xx] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < SRIT; ++k) {
+          const int r = r0 + k * SROWS;
+          if (r < ph) Lp[r * PW + q] = v[k];
+        }
+      } else {
+        for (int r = r0; r < ph; r += SROWS) {
+          int yy = z.ay + oy + r; yy = yy < 0 ? 0 : (yy >= ah ? ah - 1 : yy);
+          Lp[r * PW + q] = A[(size_t)yy * ap + xx];
+        }
       }
     }
   }
@@ -407,9 +425,24 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
       const int q0 = t & 31, r0 = t >> 5;
       for (int q = q0; q < rwid; q += 32) {
         int xx = z.bx + ox + dx0 + q; xx = xx < 0 ? 0 : (xx >= bw ? bw - 1 : xx);
-        for (int r = r0; r < ph; r += SROWS) {
-          int yy = z.by + oy + dy + r; yy = yy < 0 ? 0 : (yy >= bh ? bh - 1 : yy);
-          Rp[r * RW + q] = B[(size_t)yy * bp + xx];
+        if (KS > 0) {
+          float v[SRIT];
+#pragma unroll
+          for (int k = 0; k < SRIT; ++k) {
+            const int r = r0 + k * SROWS;
+            int yy = z.by + oy + dy + r; yy = yy < 0 ? 0 : (yy >= bh ? bh - 1 : yy);
+            v[k] = r < ph ? B[(size_t)yy * bp + xx] : 0.0f;
+          }
+#pragma unroll
+          for (int k = 0; k < SRIT; ++k) {
+            const int r = r0 + k * SROWS;
+            if (r < ph) Rp[r * RW + q] = v[k];
+          }
+        } else {
+          for (int r = r0; r < ph; r += SROWS) {
+            int yy = z.by + oy + dy + r; yy = yy < 0 ? 0 : (yy >= bh ? bh - 1 : yy);
+            Rp[r * RW + q] = B[(size_t)yy * bp + xx];
+          }
         }
       }
     }
