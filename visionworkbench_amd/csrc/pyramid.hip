@@ -190,17 +190,29 @@ rm_outliers_kernel(const int32_t* __restrict__ src, int w, int h, int hh, int hv
   const int tid = threadIdx.y * 32 + threadIdx.x;
   const int bx = blockIdx.x * 32 + ox0 - hh, by = blockIdx.y * 8 + oy0 - hv;      // source coordinates of the tile's corner
   bool big = thr >= 8192u;
-  for (int i = tid; i < tn; i += 256) {
-    const int ty = i / tw, tx = i - ty * tw;
-    int x = bx + tx, y = by + ty;
-    x = x < 0 ? 0 : (x >= w ? w - 1 : x);
-    y = y < 0 ? 0 : (y >= h ? h - 1 : y);
-    const int32_t* c = src + ((size_t)y * w + x) * 3;
-    const int32_t d0 = c[0], d1 = c[1];
-    const bool v = c[2] != 0;
-    sx[i] = d0; sy[i] = d1; sv[i] = v;
-    if (v) big = big || d0 <= -8192 || d0 >= 8192 || d1 <= -8192 || d1 >= 8192;
-    pk[i] = v ? ((unsigned)(d0 + 16384) & 0xffffu) | ((unsigned)(d1 + 16384) << 16) : 0xffffffffu;
+  // (three pixels per thread and batch: their nine loads are requested together — the plain loop waited for every pixel's three words)
+  for (int i0 = tid; i0 < tn; i0 += 3 * 256) {
+    int32_t d0[3], d1[3], d2[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int i = i0 + b * 256;
+      const int ty = i / tw, tx = i - ty * tw;
+      int x = bx + tx, y = by + ty;
+      x = x < 0 ? 0 : (x >= w ? w - 1 : x);
+      y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+      const int32_t* c = src + ((size_t)y * w + x) * 3;
+      const bool in = i < tn;
+      d0[b] = in ? c[0] : 0; d1[b] = in ? c[1] : 0; d2[b] = in ? c[2] : 0;
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int i = i0 + b * 256;
+      if (i >= tn) break;
+      const bool v = d2[b] != 0;
+      sx[i] = d0[b]; sy[i] = d1[b]; sv[i] = v;
+      if (v) big = big || d0[b] <= -8192 || d0[b] >= 8192 || d1[b] <= -8192 || d1[b] >= 8192;
+      pk[i] = v ? ((unsigned)(d0[b] + 16384) & 0xffffu) | ((unsigned)(d1[b] + 16384) << 16) : 0xffffffffu;
+    }
   }
   const bool wide = __syncthreads_or(big ? 1 : 0) != 0;         // (also the barrier behind the staging)
   const int ox = blockIdx.x * 32 + threadIdx.x, oy = blockIdx.y * 8 + threadIdx.y;
