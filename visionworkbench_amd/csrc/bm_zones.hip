@@ -134,6 +134,65 @@ zone_precision_kernel(ZPrecJobs jobs, int kx, int ky, int root) {
   }
 }
 
+// The same image for square windows K x K, K = 3 ... 13 (every kernel size the matchers are instantiated for), without the load phase of the
+// kernel above (7.5 clamped scalar loads per thread, each waited for before its square went to LDS: the launch ran at a fifth of its
+// arithmetic).  A WAVEFRONT owns 64 consecutive image columns x ZP_R output rows: a lane requests the ZP_R + K - 1 pixels of its column
+// together (rows are 256 contiguous bytes across the lanes), squares them, forms the ZP_R column sums of K rows in registers and leaves them
+// in the wavefront's own LDS plane; the first 64 - (K - 1) lanes then add K neighbouring column sums.  No workgroup barrier (a wavefront
+// reads only what it wrote itself).  Columns first, rows second — fast_box_sum's own nesting; the kernel above sums rows first: both are K + K
+// additions of at most K^2 elements, the case the error bound of the certified pass is derived for (sum_error_units), and on order-free
+// data every order returns the same bits.
+constexpr int ZP_R = 16;
+template <int K>
+__global__ void __launch_bounds__(256)
+zone_precision_sq_kernel(ZPrecJobs jobs, int root) {
+  __shared__ double vs[4][ZP_R][64];
+  const ZPrecJob J = jobs.j[blockIdx.z & 1];
+  const size_t gi = blockIdx.z >> 1;
+  const float* __restrict__ img = J.img + gi * jobs.img_tile[blockIdx.z & 1];
+  const size_t poff = gi * jobs.prec_tile[blockIdx.z & 1];
+  double* __restrict__ prec = J.prec + poff;
+  float* __restrict__ prec32 = J.prec32 ? J.prec32 + poff : nullptr;
+  const int w = J.w, h = J.h, pw = J.pw, ph = J.ph;
+  const ptrdiff_t pitch = J.pitch;
+  constexpr int OW = 64 - (K - 1), NR = ZP_R + K - 1;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+  const int bx = (int)blockIdx.x * OW, by = ((int)blockIdx.y * 4 + wave) * ZP_R;
+  if (bx >= pw || by >= ph) return;
+  int xx = J.x0 + bx + lane; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+  float px[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    int yy = J.y0 + by + r; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+    px[r] = img[(ptrdiff_t)yy * pitch + xx];
+  }
+  double sq[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) sq[r] = (double)(px[r] * px[r]);              // square(): float product (Math/Functors.h:316-321)
+  double (*V)[64] = vs[wave];
+#pragma unroll
+  for (int j = 0; j < ZP_R; ++j) {
+    double s = 0.0;
+#pragma unroll
+    for (int b = 0; b < K; ++b) s += sq[j + b];
+    V[j][lane] = s;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wavefront's own LDS writes, then reads by other lanes
+  const int i = bx + lane;
+  if (lane >= OW || i >= pw) return;
+#pragma unroll 4
+  for (int j = 0; j < ZP_R; ++j) {
+    if (by + j >= ph) break;
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < K; ++a) s += V[j][lane + a];
+    double pr = root ? sqrt(1.0 / s) : 1.0 / s;             // (root, NaN: see the kernel above)
+    if (root == 2 && !(pr <= 1.7976931348623157e308)) pr = __builtin_nan("");
+    prec[(size_t)(by + j) * pw + i] = pr;
+    if (prec32) prec32[(size_t)(by + j) * pw + i] = (float)pr;
+  }
+}
+
 // A work item: disparities [i0, i0 + n) (index = dy * sx + dx, the reference's loop order) of one 32 x 32 tile of one zone.
 struct ZItem {
   int zone, txy;        // zone row; tile x | tile y << 16
@@ -146,10 +205,10 @@ struct ZMergeItem { int zone, txy, slot0, nitems, gate, pad0, pad1, pad2; };
 // records of the partial slots, one plane of 1024 pixels per slot and field
 struct ZPart { double* best; double* worst; int* idx; double* second; double* rpmax; int* bad; int* redo; double* bnf; };
 // certification constants of a zone: bounds on |tile-parallel sum - reference running sum| (see vwgpu_launch_bm_zones)
-struct ZCert { double eps_s, eps_ll, eps_rr, eps32; int edge_lo, edge_hi, pad0, pad1; };      // eps32: bound on |float32 tile sum - exact sum| of the fp32 tier, see vwgpu_launch_bm_zones
+struct ZCert { double eps_s, eps_ll, eps_rr, eps32; int edge_lo, edge_hi, trow, pad1; };      // eps32: bound on |float32 tile sum - exact sum| of the fp32 tier, see vwgpu_launch_bm_zones
 struct ZCertArgs { const ZCert* zc; int* zflag; unsigned long long* stats; int* any; const int* need; const unsigned char* cells;
                    int edge_m, edge_k;        // zc == nullptr: no certification; any[image]: "some zone was flagged"; edge_* (the bounds: per zone, in ZCert): see ZEdge
-                   int* tflag; int tnx; };    // tflag != nullptr (single-zone callers): the 32 x 32 tiles with an unproven pixel, tflag[tile y * tnx + tile x] = 1
+                   int* tflag; };             // tflag != nullptr: the 32-row bands of a zone that hold an unproven pixel, tflag[ZCert::trow + tile y] = 1 (see vwgpu_zone_row_flags)
 // The "cannot matter" certificate (EDGE kernels; edge_m > 0).  A candidate (pixel, disparity) whose partner lies edge_m or more columns
 // outside the other image — partner column = origin of its window in the other image - edge_k, outside [edge_lo, edge_hi] — is FAR
 // (edge_m > 0 switches the certificate on; the caller folds the margin into the two bounds).  Far windows are clamped copies of the border column: whole runs of them have bit-identical data, their costs tie exactly
@@ -766,7 +825,7 @@ bm_zones_kernel(ZLaunch G, const vwgpu_zone_task* __restrict__ zones, const ZIte
     if (threadIdx.x == 0) {
       if (any) {
         G.C.zflag[it.zone] = 1; if (G.C.any) G.C.any[z.img] = 1;
-        if (G.C.tflag) G.C.tflag[(it.txy >> 16) * G.C.tnx + (it.txy & 0xffff)] = 1;
+        if (G.C.tflag) G.C.tflag[G.C.zc[it.zone].trow + (it.txy >> 16)] = 1;
       }
       if (G.C.stats) {
         atomicAdd(&G.C.stats[any ? 1 : 0], (unsigned long long)(geom.tw * geom.th));
@@ -877,7 +936,7 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
     if (t == 0) {
       if (any) {
         C.zflag[it.zone] = 1; if (C.any) C.any[z.img] = 1;
-        if (C.tflag) C.tflag[(it.txy >> 16) * C.tnx + (it.txy & 0xffff)] = 1;
+        if (C.tflag) C.tflag[C.zc[it.zone].trow + (it.txy >> 16)] = 1;
       }
       if (C.stats) { atomicAdd(&C.stats[any ? 1 : 0], (unsigned long long)(tw * th)); }
     }
@@ -1142,7 +1201,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     // wavefront per workgroup exposes every LDS round trip); both sizes in one level = two launches with a tail each, slower.  Dropped.)
     // Round 5: with TILE GROUPS a launch holds the zones of several tiles, the tails are shared, and the leaves pay again: zones that fit a
     // 16 x 16 tile go to the one-wavefront kernels when VWGPU_OPT_ZONE_TILE16 says so (1 = always, 0 = in group launches, 2 = never).
-    const bool small = !d_tflag && z.zw <= 16 && z.zh <= 16 && (ctx->zone_tile16 == 1 || (ctx->zone_tile16 == 0 && n_img > 1));      // (tile flags are per 32 x 32 tile)
+    const bool small = z.zw <= 16 && z.zh <= 16 && (ctx->zone_tile16 == 1 || (ctx->zone_tile16 == 0 && n_img > 1));
     ZPlan& pl = small ? plan[1] : plan[0];
     const int ZS = pl.zs;
     const int nx = (z.zw + ZS - 1) / ZS, ny = (z.zh + ZS - 1) / ZS;
@@ -1234,7 +1293,15 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     zj.j[1] = ZPrecJob{B, bw, bh, bp, db, pb.x0, pb.y0, pb.w, pb.h, db32};
     zj.img_tile[0] = grp ? grp->a_stride : 0; zj.img_tile[1] = grp ? grp->b_stride : 0;
     zj.prec_tile[0] = pa_tile; zj.prec_tile[1] = pb_tile;
-    hipLaunchKernelGGL(zone_precision_kernel, dim3((std::max(pa.w, pb.w) + 63) / 64, (std::max(pa.h, pb.h) + ZP_TH - 1) / ZP_TH, 2 * n_img), dim3(64, 4), zp_lds, ctx->stream, zj, kx, ky, cert ? (edge ? 2 : 1) : 0);
+    const int root = cert ? (edge ? 2 : 1) : 0, mw = std::max(pa.w, pb.w), mh = std::max(pa.h, pb.h);
+#define VW_ZPSQ(K_) hipLaunchKernelGGL((zone_precision_sq_kernel<K_>), dim3((mw + 64 - K_) / (65 - K_), (mh + 4 * ZP_R - 1) / (4 * ZP_R), 2 * n_img), dim3(256), 0, ctx->stream, zj, root)
+    if (kx != ky) hipLaunchKernelGGL(zone_precision_kernel, dim3((mw + 63) / 64, (mh + ZP_TH - 1) / ZP_TH, 2 * n_img), dim3(64, 4), zp_lds, ctx->stream, zj, kx, ky, root);
+    else switch (kx) {
+      case 3: VW_ZPSQ(3); break;  case 5: VW_ZPSQ(5); break;   case 7: VW_ZPSQ(7); break;
+      case 9: VW_ZPSQ(9); break;  case 11: VW_ZPSQ(11); break; case 13: VW_ZPSQ(13); break;
+      default: hipLaunchKernelGGL(zone_precision_kernel, dim3((mw + 63) / 64, (mh + ZP_TH - 1) / ZP_TH, 2 * n_img), dim3(64, 4), zp_lds, ctx->stream, zj, kx, ky, root);
+    }
+#undef VW_ZPSQ
     pa.p = da; pb.p = db; pb.pf = db32;
   }
   {
@@ -1256,6 +1323,7 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
   std::vector<ZCert> zc;
   if (cert) {
     zc.resize((size_t)n);
+    int trow = 0;                                                   // the zone's first band flag (vwgpu_zone_row_flags: the same walk)
     double e_el = cost_type == VWGPU_ABSOLUTE_DIFFERENCE ? std::ldexp(1.0, cert_hi + 2)          // |a - b| < 2^(hi + 2)
                         : cost_type == VWGPU_SQUARED_DIFFERENCE ? std::ldexp(1.0, 2 * cert_hi + 4)     // (a - b)^2
                         : std::ldexp(1.0, 2 * cert_hi + 2);                                            // |a b|, a^2
@@ -1266,7 +1334,8 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
         e_el = cost_type == VWGPU_ABSOLUTE_DIFFERENCE ? std::ldexp(1.0, h + 2) : cost_type == VWGPU_SQUARED_DIFFERENCE ? std::ldexp(1.0, 2 * h + 4) : std::ldexp(1.0, 2 * h + 2);
       }
       zc[i].edge_lo = grp && grp->edge_lo ? grp->edge_lo[z.img] : edge_lo; zc[i].edge_hi = grp && grp->edge_hi ? grp->edge_hi[z.img] : edge_hi;
-      zc[i].pad0 = zc[i].pad1 = 0;
+      zc[i].trow = trow; zc[i].pad1 = 0;
+      trow += (z.zh + 31) / 32;
       zc[i].eps_s = sum_error_units(kx, ky, z.zw, z.zh) * e_el;
       zc[i].eps_ll = zc[i].eps_s;
       zc[i].eps_rr = sum_error_units(kx, ky, z.zw + z.sx - 1, z.zh + z.sy - 1) * e_el;
@@ -1294,9 +1363,8 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
       plan[k].P.redo = f; f += plan[k].merges.size();
     }
   }
-  if (d_tflag && (n != 1 || d_need)) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "bm_zones: tile flags are for single-zone calls");
-  ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats, d_any, d_need, d_cells, edge_m, edge_k, d_tflag,
-              d_tflag ? (zones[0].zw + 31) / 32 : 0};
+  if (d_tflag && d_need) return vwgpu_fail(ctx, VWGPU_ERR_LOGIC, "bm_zones: band flags are for passes whose tiles start at the zone's origin");
+  ZCertArgs C{cert ? reinterpret_cast<const ZCert*>(d[1]) : nullptr, d_zflag, d_stats, d_any, d_need, d_cells, edge_m, edge_k, d_tflag};
   const size_t a_tile = grp ? grp->a_stride : 0, b_tile = grp ? grp->b_stride : 0;
 
 #define VW_ZN6(C_, K_, A_, T_, S_, E_, T32_) hipLaunchKernelGGL((bm_zones_kernel<C_, K_, A_, T_, S_, E_, T32_>), grd, dim3(S_ * S_ / 4), pl.lds, ctx->stream, \

@@ -434,12 +434,12 @@ static int calc_disparity_classified(vwgpu_ctx* ctx, int cost_type, const float*
                                    0, 0, 0, 0, ls, rs);
     }
     if (exact && ctx->certify && (g_nonfinite & 1) == 0 && g_lo != INT_MAX && g_hi < 60 && g_hi > -60 && vwgpu_bm_exact_supported(sx, sy)) {
-      const int tnx = (z.zw + 31) / 32, tny = (z.zh + 31) / 32;
-      int rc = vwgpu_arena_reserve(ctx, &ctx->misc, 512 + (size_t)tnx * tny * sizeof(int));
+      const int tny = (z.zh + 31) / 32;
+      int rc = vwgpu_arena_reserve(ctx, &ctx->misc, 512 + (size_t)tny * sizeof(int));
       if (rc) return rc;
-      int* d_word = static_cast<int*>(ctx->misc.base);            // [0] any zone flagged, [1] the zone's flag, [128 ...] one flag per 32 x 32 tile
+      int* d_word = static_cast<int*>(ctx->misc.base);            // [0] any zone flagged, [1] the zone's flag, [128 ...] one flag per band of 32 rows
       int* d_tflag = d_word + 128;
-      VWGPU_HIP(ctx, hipMemsetAsync(d_word, 0, 512 + (size_t)tnx * tny * sizeof(int), ctx->stream));
+      VWGPU_HIP(ctx, hipMemsetAsync(d_word, 0, 512 + (size_t)tny * sizeof(int), ctx->stream));
       unsigned long long* d_stats = nullptr;
       if (ctx->trace & 4) {
         d_stats = reinterpret_cast<unsigned long long*>(d_word + 32);
@@ -454,24 +454,16 @@ static int calc_disparity_classified(vwgpu_ctx* ctx, int cost_type, const float*
       VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
       if (d_stats) { ctx->cert_px[0] += got[0]; ctx->cert_px[1] += got[1]; ctx->cert_px[2] += got[2]; }
       if (!any) { ctx->last_path = VWGPU_PATH_CERTIFIED; return VWGPU_OK; }
-      // Some pixel could not be proven.  The reference's order is needed only for the TILE ROWS that hold such a pixel — every other pixel of
-      // the image already has the reference's value — but its chains start at the raster's first row and column: the column chains run from
-      // row 0 down to the last flagged tile row (without storing anything for the rows nobody reads), the row chains and the selection only
-      // over the flagged tile rows (bm_exact.hip, row ranges).  The rows are rewritten whole: certified pixels get the same values again.
+      // Some pixel could not be proven.  The reference's order is needed only for the BANDS of 32 rows that hold such a pixel — every other
+      // pixel of the image already has the reference's value — but its chains start at the raster's first row and column: the column chains
+      // run from row 0 down to the last flagged band (without storing anything for the rows nobody reads), the row chains and the selection
+      // only over the flagged bands (bm_exact.hip, row ranges).  The rows are rewritten whole: certified pixels get the same values again.
       if ((long long)sx * sy <= 512) {
-        std::vector<int> tf((size_t)tnx * tny);
+        std::vector<int> tf((size_t)tny);
         VWGPU_HIP(ctx, hipMemcpyAsync(tf.data(), d_tflag, tf.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
         std::vector<int> rows;
-        int flagged_rows = 0;
-        for (int ty = 0; ty < tny; ++ty) {
-          bool hit = false;
-          for (int tx = 0; tx < tnx && !hit; ++tx) hit = tf[(size_t)ty * tnx + tx] != 0;
-          if (!hit) continue;
-          const int a = ty * 32, b = std::min(z.zh, a + 32);
-          flagged_rows += b - a;
-          if (!rows.empty() && rows.back() == a) rows.back() = b; else { rows.push_back(a); rows.push_back(b); }
-        }
+        const int flagged_rows = vwgpu_zone_flagged_rows(tf.data(), z.zh, &rows);
         if (!rows.empty() && flagged_rows * 2 < z.zh) {             // (most of the image flagged: the whole raster in one go is cheaper)
           ctx->last_path = VWGPU_PATH_EXACT_ORDER;
           return vwgpu_launch_bm_exact(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, &z, 1, d_out, nullptr, rows.data(), (int)rows.size() / 2);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -260,7 +261,24 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
                           int edge_m = 0, int edge_k = 0, int edge_lo = 0, int edge_hi = 0,      // certified passes: edge_m > 0 turns the "cannot matter" certificate on (bm_zones.hip, ZEdge)
                           ptrdiff_t as = 0, ptrdiff_t bs = 0,                                      // row strides of A / B in floats (0: the widths)
                           const vwgpu_zone_group* grp = nullptr,                                   // several image pairs in one launch sequence; d_any then has n_img words
-                          int* d_tflag = nullptr);                                                 // single-zone certified calls: one int per 32 x 32 tile of the zone (zeroed by the caller), set for tiles with an unproven pixel
+                          int* d_tflag = nullptr);                                                 // certified passes without d_need: one int per 32-row band of every zone (vwgpu_zone_row_flags of them, zeroed by the caller; zone i's begin where the bands of zones 0 .. i-1 end), set for bands with an unproven pixel
+inline size_t vwgpu_zone_row_flags(const vwgpu_zone_task* zones, int n) {
+  size_t r = 0;
+  for (int i = 0; i < n; ++i) r += (size_t)(zones[i].zh + 31) / 32;
+  return r;
+}
+// The flagged bands of one zone as row ranges {begin, end}, ... for vwgpu_launch_bm_exact; returns the number of flagged rows.
+inline int vwgpu_zone_flagged_rows(const int* bands, int zh, std::vector<int>* rows) {
+  int flagged = 0;
+  rows->clear();
+  for (int ty = 0; ty * 32 < zh; ++ty) {
+    if (!bands[ty]) continue;
+    const int a = ty * 32, b = std::min(zh, a + 32);
+    flagged += b - a;
+    if (!rows->empty() && rows->back() == a) rows->back() = b; else { rows->push_back(a); rows->push_back(b); }
+  }
+  return flagged;
+}
 // The part of every zone's R->L image that its L/R check (vwgpu_launch_zone_lr, same tasks) will read, from the finished L->R result:
 // a rectangle per zone (d_need, 8 ints per zone) and a flag per 16 x 16 cell (d_cells; vwgpu_zone_need_cells numbers the cells into the
 // tasks' `ay` slot and returns their count).  d_zflag (optional): L->R zones still to be matched again ask for the whole image.
