@@ -460,7 +460,7 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
     if (COST == VWGPU_CROSS_CORRELATION && c < tw && y0 + m < th)
       lprec[m] = pa.p[(size_t)(z.ay + oy + y0 + m - pa.y0) * pa.w + (z.ax + ox + c - pa.x0)];
   }
-  bool fnan[4] = {false, false, false, false};                    // EDGE: the FIRST candidate of the search has a NaN cost (then it is the reference's winner)
+  CT s0[4] = {0, 0, 0, 0};                                        // EDGE: the cost of the search's FIRST candidate (a NaN there is the reference's winner: `fnan` below)
   CT bnf[4];                                                      // EDGE: the best cost among the candidates that are not far (ZEdge)
   int elo = 0, ehi = 0;
   if (EDGE) { elo = C.zc[it.zone].edge_lo; ehi = C.zc[it.zone].edge_hi; }
@@ -671,7 +671,9 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
                 s *= rp;
               }
               const bool cb = COST == VWGPU_CROSS_CORRELATION ? (s > best[m]) : (s < best[m]);
-              if (EDGE && di == 0) fnan[m] = !(s == s);           // (workgroup-uniform test: the first disparity of the search)
+              // (a select under the workgroup-uniform test "first disparity of the search": ONE instruction per evaluation — `if (di == 0)
+              // fnan = !(s == s)` compiled to five: compare, two flag materialisations, and, compare)
+              if (EDGE) s0[m] = di == 0 ? s : s0[m];
               if (EDGE) {
                 const CT snf = nfar ? s : kBestInit;
                 bnf[m] = COST == VWGPU_CROSS_CORRELATION ? zmax_raw(bnf[m], snf) : zmin_raw(bnf[m], snf);
@@ -734,6 +736,9 @@ __device__ __forceinline__ bool zmatch_item(const ZLaunch& G, const ZItem& it, c
 #pragma unroll
     for (int m = 0; m < 4; ++m) { best[m] = (CT)bestA[m]; worst[m] = (CT)worstA[m]; }
   }
+  bool fnan[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) fnan[m] = EDGE && !(s0[m] == s0[m]);
   if (it.slot >= 0) {                                           // one of several runs of this tile: leave the records to zones_merge_kernel
     const size_t base = (size_t)it.slot * (ZT * ZT);
     if (c < tw) {
