@@ -177,6 +177,25 @@ def test_single_level_exact_ties_fall_back_to_the_reference_order(ctx, oracle, c
     assert np.array_equal(got, want), int((got != want).any(-1).sum())
 
 
+def test_single_level_one_disparity_and_a_nan_cost_in_the_reference(ctx, oracle):
+    """Case 3889 of `tools/fuzz_round5.py 10000 800 7373` (round 5, found after the certificate had passed 26 000 others): NCC, 1 x 7 window, ONE
+    disparity, data of 12 decades.  One pixel's running box sum of squares cancels to <= 0 in the reference — its precision is infinite or
+    negative, the one cost a NaN, `best == worst` false: the pixel stays VALID (Correlation.cc:121-133) — while the tile sums of the certified
+    pass are fine and "one disparity => invalid" was returned without asking whether the reference's cost is a number."""
+    import fuzz_cases
+    case = next(c for c in fuzz_cases.bm_float_cases(3890, 7374) if c["it"] == 3889)
+    assert case["cost"] == 2 and case["kernel"] == (1, 7) and case["search"] == (1, 1)
+    want = oracle.calc_disparity(2, case["left"], case["right"], (1, 7), (1, 1))
+    assert (want[..., 2] != 0).sum() == 1, "the reference keeps exactly one pixel valid here"
+    for f32 in (1, 0):
+        ctx.set_option(core.OPT_CERT_F32, f32)
+        try:
+            got = stereo.calc_disparity(2, case["left"], case["right"], vwa.bounding_box(case["left"]), (1, 1), (1, 7), ctx=ctx)
+        finally:
+            ctx.set_option(core.OPT_CERT_F32, 1)
+        assert np.array_equal(got, want), (f32, int((got != want).any(-1).sum()))
+
+
 def test_single_level_order_free_float_raster(ctx, oracle):
     """Order-free float data (here: quarter-integers) takes the tile-parallel kernels without a certificate — any order returns the bits."""
     rng = np.random.default_rng(7200)

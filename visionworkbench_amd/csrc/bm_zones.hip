@@ -254,8 +254,8 @@ __device__ __forceinline__ bool ztile_geometry(const vwgpu_zone_task& z, int zon
 
 // "can this pixel's result be proven equal to the reference's?"  best / second / rpmax: what the chain has seen over ALL D disparities of
 // the pixel (second = the best cost among the disparities other than the winner; equal costs => second == best).  A certified pixel with
-// D >= 2 is valid (best > second >= worst in the reference's arithmetic too), so the chain keeps no `worst`; D == 1 is invalid by
-// definition (best == worst in any arithmetic).
+// D >= 2 is valid (best > second >= worst in the reference's arithmetic too), so the chain keeps no `worst`; D == 1 is invalid
+// (best == worst) provided the reference's one cost is not a NaN — see the NCC branch.
 // T32 (the fp32 tier): the window sums were formed in float32 — the SAME float cost elements as the reference's (CostFunctions.h:72-141
 // forms them in float), summed in another order AND another precision.  Two bounds on |float32 sum - exact sum|, u = 2^-24:
 //   absolute  zc.eps32 = 2 (2 K + 24) kx ky u E   (E bounds an element, K = max(kx, ky)): the sliding form of zwindow_sums subtracts, so an
@@ -268,13 +268,18 @@ __device__ __forceinline__ bool ztile_geometry(const vwgpu_zone_task& z, int zon
 template <int COST, bool T32 = false, bool REL32 = false>
 __device__ __forceinline__ bool zcertified(const ZCert& zc, int D, bool bad, double best, double second, double lprec, double rpmax) {
   if (bad) return false;                                     // a non-finite cost: the reference's chain is order dependent there
-  if (D == 1) return true;
+  if (D == 1 && COST != VWGPU_CROSS_CORRELATION) return true;   // (finite pixels: a finite cost, best == worst)
   double eps;
   if (COST == VWGPU_CROSS_CORRELATION) {
     // cost = S_lr * sqrt((1 / S_ll) * (1 / S_rr)), every S off by at most its eps, 1/x and sqrt propagated to first order with a factor 2.
     // |cost| <= 1 for every disparity (Cauchy-Schwarz: the three sums run over the same window positions), up to the roundings.
     const double dl = 2.0 * zc.eps_ll * lprec, dr = 2.0 * zc.eps_rr * rpmax;
     if (!(lprec > 0.0) || !(rpmax > 0.0) || !(dl <= 0x1p-10) || !(dr <= 0x1p-10)) return false;
+    // D == 1 is "invalid" only if the reference's one cost is a NUMBER (best == worst; a NaN compares unequal and the pixel stays valid,
+    // Correlation.cc:121-133).  Its running box sums of squares can cancel to zero or below on data of many decades — 1 / S infinite or
+    // negative, the cost NaN — where the tile sums here are fine: the two tests above say the reference's S_ll and S_rr lie within 2^-11 of
+    // these (positive, finite precisions), so its cost is finite too.  (Found by the round-5 campaign: 12-decade data, 1 x 7 window, one disparity.)
+    if (D == 1) return true;
     const double cmax = fmax(1.0 + 0x1p-20, fmax(fabs(best), fabs(second)));
     double s32 = 0.0;                                        // the fp32 tier's own error, in cost units
     if (T32) {
