@@ -76,6 +76,63 @@ def pyramid_cases(n, seed, prefilters=(0,), costs=(0, 0, 1), float_scene=0.0):
                    filt=filt, levels=levels, bbox=bbox, pf=pf, pfw=pfw, is_float=is_float)
 
 
+def pyramid_corner_cases(n, seed):
+    """pyramid_correlate on the kinds of imagery the random textures of pyramid_cases do not contain: blocks of exact zeros in both images
+    (nodata without a mask: all-zero windows, infinite NCC precisions), saturated blocks (constant 255: every disparity ties), smooth ramps (low
+    texture: near-ties everywhere), several decades of dynamic range, negative values — all costs, all prefilters."""
+    rng = np.random.default_rng([seed, 0xC1])
+    for it in range(n):
+        H, W = int(rng.integers(70, 260)), int(rng.integers(100, 380))
+        kind = int(rng.integers(0, 6))
+        tex = rng.random((H, W))
+        if kind == 0:
+            left = np.floor(tex * 256)
+        elif kind == 1:
+            left = tex * 0.37 * 256 + rng.random((H, W))
+        elif kind == 2:
+            yy, xx = np.mgrid[0:H, 0:W]
+            left = 40.0 + 0.31 * xx + 0.17 * yy + tex * float(rng.choice([0.0, 0.5, 4.0]))          # a ramp with little or no texture
+        elif kind == 3:
+            left = tex * 10.0 ** (rng.random((H, W)) * float(rng.choice([3.0, 6.0])))                # decades
+        elif kind == 4:
+            left = (tex - 0.5) * 500.0
+        else:
+            left = np.floor(tex * 4.0) * 64.0                                                       # four grey levels
+        left = left.astype(np.float32)
+        for _ in range(int(rng.integers(0, 4))):                                                     # nodata / saturation blocks
+            y0, x0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+            left[y0:y0 + int(rng.integers(4, 60)), x0:x0 + int(rng.integers(4, 90))] = np.float32(rng.choice([0.0, 0.0, 255.0]))
+        right = np.empty_like(left)
+        band = int(rng.integers(20, 90))
+        for y0 in range(0, H, band):
+            right[y0:y0 + band] = np.roll(left[y0:y0 + band], int(rng.integers(-6, 7)), axis=1)
+        if rng.random() < 0.3:
+            right = right + (rng.random((H, W)).astype(np.float32) - np.float32(0.5)) * np.float32(rng.choice([0.01, 1.0]))
+            right = right.astype(np.float32)
+        mx, my = int(rng.integers(1, 10)), int(rng.integers(0, 3))
+        search = (-mx, -my, mx + int(rng.integers(0, 3)), my + 1)
+        k = int(rng.choice([3, 5, 7, 9, 11]))
+        ky = int(rng.choice([k, k, 5]))
+        cost = int(rng.integers(0, 3))
+        thr = float(rng.choice([-1, 1, 2]))
+        filt = int(rng.choice([0, 3, 5]))
+        levels = int(rng.integers(0, 5))
+        lm = rm = None
+        if rng.random() < 0.3:
+            lm = np.full(left.shape, 255, np.uint8); rm = np.full(right.shape, 255, np.uint8)
+            y0, x0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+            lm[y0:y0 + 30, x0:x0 + 50] = 0
+            rm[:, -int(rng.integers(1, 40)):] = 0
+        bbox = None
+        if rng.random() < 0.5:
+            bw, bh = int(rng.integers(24, min(200, W))), int(rng.integers(24, min(160, H)))
+            bbox = (int(rng.integers(0, W - bw + 1)), int(rng.integers(0, H - bh + 1)), bw, bh)
+        pf = int(rng.integers(0, 3))
+        pfw = 0.0 if pf == 0 else float(rng.choice([1.4, 2.0, 3.0]))
+        yield dict(it=it, left=left, right=right, lm=lm, rm=rm, search=search, kernel=(k, ky), cost=cost, thr=thr,
+                   filt=filt, levels=levels, bbox=bbox, pf=pf, pfw=pfw, is_float=kind not in (0, 5), kind=kind)
+
+
 def sgm_cases(n, seed):
     """calc_disparity_sgm: random sizes, 1-D / 2-D searches, kernels, cost types, masks, previous-level disparities,
     memory limits, sub-pixel modes."""
@@ -186,6 +243,49 @@ def bm_float_cases(n, seed):
             v = np.float32(rng.choice([0.0, 3.3, 100.25]))
             left[y0:y0 + 25, x0:x0 + 45] = v
             right[y0:y0 + 27, x0:x0 + 60 + sx] = v
+        yield dict(it=it, cost=cost, kernel=(kx, ky), search=(sx, sy), left=left, right=right, kind=kind)
+
+
+def bm_float_corner_cases(n, seed):
+    """The corners of calc_disparity on float rasters that the campaign of round 5 found thinly covered (its one mismatch in 26 000 cases was a
+    1 x 7 window with ONE disparity on 12-decade data): one to a few disparities, windows with a side of 1, data whose running box sums cancel
+    (many decades, both signs), squares that underflow to zero in float32, blocks of exact zeros (infinite NCC precisions: NaN costs), constant
+    images (every cost ties), tiny rasters."""
+    rng = np.random.default_rng([seed, 0xC0])
+    sides = [1, 3, 5, 7, 9, 11, 13]
+    for it in range(n):
+        cost = int(rng.integers(0, 3))
+        kx = int(rng.choice(sides))
+        ky = kx if rng.random() < 0.5 else int(rng.choice(sides))
+        sx = int(rng.choice([1, 1, 2, 3, 4, 8, 17]))
+        sy = int(rng.choice([1, 1, 1, 2, 3]))
+        w = int(rng.integers(kx + 1, 130))
+        h = int(rng.integers(ky + 1, 90))
+        kind = int(rng.integers(0, 7))
+        shape = (h + sy - 1, w + sx - 1)
+        base = rng.random(shape)
+        if kind == 0:
+            right = base * 10.0 ** (rng.random(shape) * 12.0 - 3.0)                        # 12 decades, positive
+        elif kind == 1:
+            right = (base - 0.5) * 10.0 ** (rng.random(shape) * 12.0 - 4.0)                # 12 decades, both signs
+        elif kind == 2:
+            right = base * 1e-21 * 10.0 ** (rng.random(shape) * 4.0)                       # squares underflow (denormal or zero) in float32
+        elif kind == 3:
+            right = np.full(shape, float(rng.choice([0.0, 1.5, -7.25, 1e-3])))             # a constant image
+        elif kind == 4:
+            right = base * 100.0
+            for _ in range(int(rng.integers(1, 4))):                                       # blocks of exact zeros
+                y0, x0 = int(rng.integers(0, shape[0])), int(rng.integers(0, shape[1]))
+                right[y0:y0 + int(rng.integers(1, 30)), x0:x0 + int(rng.integers(1, 60))] = 0.0
+        elif kind == 5:
+            right = np.where(rng.random(shape) < 0.9, 0.0, base * 10.0 ** (rng.random(shape) * 8.0))      # sparse: mostly zero, a few large values
+        else:
+            right = np.floor(base * 4.0) * 10.0 ** rng.integers(-6, 9)                     # few distinct levels: many exact ties
+        right = right.astype(np.float32)
+        d = (int(rng.integers(0, sx)), int(rng.integers(0, sy)))
+        left = right[d[1]:d[1] + h, d[0]:d[0] + w].copy()
+        if rng.random() < 0.5:
+            left *= np.float32(1.0 + (rng.random() - 0.5) * rng.choice([0.0, 1e-6, 1e-2]))
         yield dict(it=it, cost=cost, kernel=(kx, ky), search=(sx, sy), left=left, right=right, kind=kind)
 
 

@@ -146,6 +146,40 @@ def test_fuzz_single_level_float_identical_to_oracle(ctx, oracle, n, seed):
     assert paths.get(core.PATH_CERTIFIED, 0) >= n // 5 and paths.get(core.PATH_EXACT_ORDER, 0) >= 3, paths      # both outcomes of the certificate occur
 
 
+@pytest.mark.parametrize("n,seed", [(70, 521)])
+def test_fuzz_pyramid_corner_scenes_identical_to_oracle(ctx, oracle, n, seed):
+    """pyramid_correlate on nodata / saturation blocks, ramps, decades of range, negative values, four-level images
+    (fuzz_cases.pyramid_corner_cases): all costs and prefilters."""
+    bad = []
+    for c in fuzz_cases.pyramid_corner_cases(n, seed):
+        s = c["search"]
+        g = stereo.pyramid_correlate(c["left"], c["right"], c["lm"], c["rm"], c["pf"], c["pfw"], BBox2i.from_corners(s[:2], s[2:]), c["kernel"], c["cost"],
+                                     0, 0.0, c["thr"], 0, c["filt"], c["levels"], bbox=None if c["bbox"] is None else BBox2i(*c["bbox"]), ctx=ctx)
+        o = oracle.pyramid_correlate(c["left"], c["right"], c["lm"], c["rm"], c["pf"], c["pfw"], s, c["kernel"], c["cost"], 0, 0.0, c["thr"], c["filt"],
+                                     c["levels"], bbox=c["bbox"])
+        if not np.array_equal(g, o):
+            bad.append((c["it"], c["kind"], c["cost"], c["pf"], int((g != o).any(-1).sum())))
+    assert not bad, "pyramid_corner_cases(seed=%d): %s" % (seed, bad)
+
+
+@pytest.mark.parametrize("n,seed", [(250, 511)])
+def test_fuzz_single_level_float_corner_cases_identical_to_oracle(ctx, oracle, n, seed):
+    """The thinly covered corners (fuzz_cases.bm_float_corner_cases): one to a few disparities, windows with a side of 1, box sums that cancel,
+    squares that underflow, blocks of zeros (NaN costs), constant images — through the default dispatch, fp32 tier on and off."""
+    bad = []
+    for f32 in (1, 0):
+        ctx.set_option(core.OPT_CERT_F32, f32)
+        try:
+            for c in fuzz_cases.bm_float_corner_cases(n, seed + f32):
+                got = stereo.calc_disparity(c["cost"], c["left"], c["right"], vwa.bounding_box(c["left"]), c["search"], c["kernel"], ctx=ctx)
+                want = oracle.calc_disparity(c["cost"], c["left"], c["right"], c["kernel"], c["search"])
+                if not np.array_equal(got, want):
+                    bad.append((f32, c["it"], c["cost"], c["kernel"], c["search"], c["left"].shape, c["kind"], ctx.last_path(), int((got != want).any(-1).sum())))
+        finally:
+            ctx.set_option(core.OPT_CERT_F32, 1)
+    assert not bad, "bm_float_corner_cases(seed=%d): %s" % (seed, bad)
+
+
 @pytest.mark.parametrize("n,seed", [(30, 601)])
 def test_fuzz_batch_identical_to_oracle(ctx, oracle, n, seed):
     """pyramid_correlate_batch on random scenes cut into random tile grids: every tile against the oracle's tile."""

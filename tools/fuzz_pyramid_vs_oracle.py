@@ -1,6 +1,6 @@
 """Randomised cross-check of pyramid_correlate (GPU, host entry) against the CPU oracle.  The bounded, seeded version runs
 under pytest -m gpu (tests/test_fuzz_gpu.py); this is the long-running aid for the GPU box.
-usage: python tools/fuzz_pyramid_vs_oracle.py [cases] [seed] [float_scene_probability] [prefilters, e.g. 0,1,2]"""
+usage: python tools/fuzz_pyramid_vs_oracle.py [cases] [seed] [float_scene_probability | corner] [prefilters, e.g. 0,1,2]"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -12,10 +12,11 @@ from visionworkbench_amd.core import BBox2i
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-FLOATP = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+CORNER = len(sys.argv) > 3 and sys.argv[3] == "corner"
+FLOATP = float(sys.argv[3]) if len(sys.argv) > 3 and not CORNER else 0.0
 PF = tuple(int(v) for v in sys.argv[4].split(",")) if len(sys.argv) > 4 else (0,)
 bad = 0
-for c in fuzz_cases.pyramid_cases(N, SEED, prefilters=PF, float_scene=FLOATP):
+for c in (fuzz_cases.pyramid_corner_cases(N, SEED) if CORNER else fuzz_cases.pyramid_cases(N, SEED, prefilters=PF, float_scene=FLOATP)):
     s = c["search"]
     try:
         g = stereo.pyramid_correlate(c["left"], c["right"], c["lm"], c["rm"], c["pf"], c["pfw"], BBox2i.from_corners(s[:2], s[2:]), c["kernel"],

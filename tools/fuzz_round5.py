@@ -31,8 +31,15 @@ for tier in (1, 0):
         want = oracle.calc_disparity(c["cost"], c["left"], c["right"], c["kernel"], c["search"])
         if not np.array_equal(got, want):
             bad.append(("single", tier, c["it"], int((got != want).any(-1).sum())))
+    for c in fuzz_cases.bm_float_corner_cases((n1 if tier else n1 // 4) // 2, seed + tier):
+        got = stereo.calc_disparity(c["cost"], c["left"], c["right"], vwa.bounding_box(c["left"]), c["search"], c["kernel"], ctx=ctx)
+        p = names.get(ctx.last_path())
+        paths[(tier, p)] = paths.get((tier, p), 0) + 1
+        want = oracle.calc_disparity(c["cost"], c["left"], c["right"], c["kernel"], c["search"])
+        if not np.array_equal(got, want):
+            bad.append(("corner", tier, c["it"], c["cost"], c["kernel"], c["search"], c["kind"], int((got != want).any(-1).sum())))
 ctx.set_option(core.OPT_CERT_F32, 1)
-print("single-level float rasters: %d + %d cases (fp32 tier on / off), %d mismatches, paths %s, %.0f s" % (n1, n1 // 4, len(bad), paths, time.time() - t0), flush=True)
+print("single-level float rasters: %d + %d cases (fp32 tier on / off) + half as many corner cases each, %d mismatches, paths %s, %.0f s" % (n1, n1 // 4, len(bad), paths, time.time() - t0), flush=True)
 t0 = time.time()
 tiles = 0
 for c in fuzz_cases.batch_cases(n2, seed + 7):
