@@ -235,6 +235,31 @@ def test_tier_and_tile_options_return_the_same_image(ctx, oracle, f32, tile16):
         ctx.set_option(core.OPT_ZONE_TILE16, 2)
 
 
+@pytest.mark.parametrize("sxc", [1, 5, 64, 4096])
+def test_zone_sxc_option_returns_the_same_image(ctx, oracle, sxc):
+    """VWGPU_OPT_ZONE_SXC (horizontal disparities per staged right patch): 1 and 5 cut every search row into several patches, 64 and
+    4096 go beyond the default 16 (the LDS budget caps them) — the lanes of a tile without a pixel then read the precision image's first row
+    at offsets up to the zone's search width (nd <= z.sx <= pb.w).  LoG + NCC pyramid tile with its 16 x 16 leaf zones (partly filled tiles on
+    every level), a float SSD pyramid and a single-level float NCC raster with a 70-wide search."""
+    ctx.set_option(core.OPT_ZONE_SXC, sxc)
+    try:
+        left, right, scale, trans, search = scenes.pyramid_scene("u8")
+        for cost, kernel, pf in ((2, (11, 11), 2), (1, (7, 7), 0)):
+            l, r = left, right
+            if pf == 0:
+                l = (left * np.float32(0.37) + np.float32(0.11)).astype(np.float32); r = (right * np.float32(0.37) + np.float32(0.07)).astype(np.float32)
+            pfw = float(np.float32(1.4)) if pf else 0.0
+            got = stereo.pyramid_correlate(l, r, None, None, pf, pfw, BBox2i.from_corners(search[:2], search[2:]), kernel, cost, 0, 0.0, 2, 0, 5, 5, ctx=ctx)
+            want = oracle.pyramid_correlate(l, r, None, None, pf, pfw, search, kernel, cost, 0, 0.0, 2, 5, 5)
+            assert np.array_equal(got, want), (cost, int((got != want).any(-1).sum()))
+        rng = np.random.default_rng(4343)
+        fl, fr = _float_scene(rng, 90, 150, 70, 2, decades=2.0)
+        got = stereo.calc_disparity(2, fl, fr, vwa.bounding_box(fl), (70, 2), (9, 9), ctx=ctx)
+        assert np.array_equal(got, oracle.calc_disparity(2, fl, fr, (9, 9), (70, 2)))
+    finally:
+        ctx.set_option(core.OPT_ZONE_SXC, 0)
+
+
 @pytest.mark.parametrize("cost,kernel,search", [(0, (7, 7), (21, 1)), (1, (5, 5), (9, 3)), (2, (11, 11), (33, 2))])
 def test_single_level_partial_redo_of_flagged_tile_rows(ctx, oracle, cost, kernel, search):
     """A few unprovable pixels in a large float raster: only the tile rows that hold them are redone in the reference's order — the column
