@@ -79,7 +79,8 @@ def pyramid_cases(n, seed, prefilters=(0,), costs=(0, 0, 1), float_scene=0.0):
 def pyramid_corner_cases(n, seed):
     """pyramid_correlate on the kinds of imagery the random textures of pyramid_cases do not contain: blocks of exact zeros in both images
     (nodata without a mask: all-zero windows, infinite NCC precisions), saturated blocks (constant 255: every disparity ties), smooth ramps (low
-    texture: near-ties everywhere), several decades of dynamic range, negative values — all costs, all prefilters."""
+    texture: near-ties everywhere), several decades of dynamic range, negative values — all costs, all prefilters, windows up to 15, the blob
+    filter (c["blob"]: the oracle takes it through set_blob_filter_area)."""
     rng = np.random.default_rng([seed, 0xC1])
     for it in range(n):
         H, W = int(rng.integers(70, 260)), int(rng.integers(100, 380))
@@ -111,12 +112,13 @@ def pyramid_corner_cases(n, seed):
             right = right.astype(np.float32)
         mx, my = int(rng.integers(1, 10)), int(rng.integers(0, 3))
         search = (-mx, -my, mx + int(rng.integers(0, 3)), my + 1)
-        k = int(rng.choice([3, 5, 7, 9, 11]))
+        k = int(rng.choice([3, 5, 7, 9, 11, 13, 15]))
         ky = int(rng.choice([k, k, 5]))
         cost = int(rng.integers(0, 3))
         thr = float(rng.choice([-1, 1, 2]))
         filt = int(rng.choice([0, 3, 5]))
         levels = int(rng.integers(0, 5))
+        blob = int(rng.choice([0, 0, 12, 80]))                                                      # blob_filter_area (CorrelationView.cc:242-271)
         lm = rm = None
         if rng.random() < 0.3:
             lm = np.full(left.shape, 255, np.uint8); rm = np.full(right.shape, 255, np.uint8)
@@ -130,7 +132,7 @@ def pyramid_corner_cases(n, seed):
         pf = int(rng.integers(0, 3))
         pfw = 0.0 if pf == 0 else float(rng.choice([1.4, 2.0, 3.0]))
         yield dict(it=it, left=left, right=right, lm=lm, rm=rm, search=search, kernel=(k, ky), cost=cost, thr=thr,
-                   filt=filt, levels=levels, bbox=bbox, pf=pf, pfw=pfw, is_float=kind not in (0, 5), kind=kind)
+                   filt=filt, levels=levels, bbox=bbox, pf=pf, pfw=pfw, is_float=kind not in (0, 5), kind=kind, blob=blob)
 
 
 def sgm_cases(n, seed):

@@ -154,9 +154,14 @@ def test_fuzz_pyramid_corner_scenes_identical_to_oracle(ctx, oracle, n, seed):
     for c in fuzz_cases.pyramid_corner_cases(n, seed):
         s = c["search"]
         g = stereo.pyramid_correlate(c["left"], c["right"], c["lm"], c["rm"], c["pf"], c["pfw"], BBox2i.from_corners(s[:2], s[2:]), c["kernel"], c["cost"],
-                                     0, 0.0, c["thr"], 0, c["filt"], c["levels"], bbox=None if c["bbox"] is None else BBox2i(*c["bbox"]), ctx=ctx)
-        o = oracle.pyramid_correlate(c["left"], c["right"], c["lm"], c["rm"], c["pf"], c["pfw"], s, c["kernel"], c["cost"], 0, 0.0, c["thr"], c["filt"],
-                                     c["levels"], bbox=c["bbox"])
+                                     0, 0.0, c["thr"], 0, c["filt"], c["levels"], bbox=None if c["bbox"] is None else BBox2i(*c["bbox"]),
+                                     blob_filter_area=c["blob"], ctx=ctx)
+        oracle.set_blob_filter_area(c["blob"])
+        try:
+            o = oracle.pyramid_correlate(c["left"], c["right"], c["lm"], c["rm"], c["pf"], c["pfw"], s, c["kernel"], c["cost"], 0, 0.0, c["thr"], c["filt"],
+                                         c["levels"], bbox=c["bbox"])
+        finally:
+            oracle.set_blob_filter_area(0)
         if not np.array_equal(g, o):
             bad.append((c["it"], c["kind"], c["cost"], c["pf"], int((g != o).any(-1).sum())))
     assert not bad, "pyramid_corner_cases(seed=%d): %s" % (seed, bad)

@@ -18,9 +18,10 @@ PF = tuple(int(v) for v in sys.argv[4].split(",")) if len(sys.argv) > 4 else (0,
 bad = 0
 for c in (fuzz_cases.pyramid_corner_cases(N, SEED) if CORNER else fuzz_cases.pyramid_cases(N, SEED, prefilters=PF, float_scene=FLOATP)):
     s = c["search"]
+    oracle.set_blob_filter_area(c.get("blob", 0))
     try:
         g = stereo.pyramid_correlate(c["left"], c["right"], c["lm"], c["rm"], c["pf"], c["pfw"], BBox2i.from_corners(s[:2], s[2:]), c["kernel"],
-                                     c["cost"], 0, 0.0, c["thr"], 0, c["filt"], c["levels"], bbox=None if c["bbox"] is None else BBox2i(*c["bbox"]))
+                                     c["cost"], 0, 0.0, c["thr"], 0, c["filt"], c["levels"], bbox=None if c["bbox"] is None else BBox2i(*c["bbox"]), blob_filter_area=c.get("blob", 0))
         o = oracle.pyramid_correlate(c["left"], c["right"], c["lm"], c["rm"], c["pf"], c["pfw"], s, c["kernel"], c["cost"], 0, 0.0, c["thr"],
                                      c["filt"], c["levels"], bbox=c["bbox"])
     except Exception as e:  # noqa: BLE001
