@@ -1,6 +1,7 @@
 SEED=${SEED:-40404}
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-L=gpurun_out/fuzz_campaign_r04k_sgm.txt; : > $L
+TAG=${TAG:-r04k}
+L=gpurun_out/fuzz_campaign_${TAG}_sgm.txt; : > $L
 run() { t0=$(date +%s); echo "\$ $*" >> $L; timeout 600 "$@" 2>&1 | grep -E "cases|MISMATCH|ERROR|Traceback" | tail -5 >> $L; echo "  ($(( $(date +%s) - t0 )) s)" >> $L; }
 run python tools/fuzz_sgm_vs_oracle.py 4000 $SEED
 run python tools/fuzz_sgm_vs_oracle.py 4000 $SEED mgm
