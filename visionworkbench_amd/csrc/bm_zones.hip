@@ -1202,7 +1202,21 @@ int vwgpu_launch_bm_zones(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
   // (a level that cannot fill the GPU with 16-disparity runs — the coarse levels of a tile: one zone of a few dozen tiles — is cut down to
   // 4-disparity runs: its launch is as long as its longest item)
   const double min_run = std::min(16.0, std::max(4.0, total / (1024.0 * resident)));
-  const double cap = std::max(min_run * 32 * 32, total / (3.0 * resident));
+  double cap = std::max(min_run * 32 * 32, total / (3.0 * resident));
+  // A level whose WHOLE tiles already are a round of the resident workgroups, none much longer than the mean — level 1 of a tile group: four
+  // tiles' 512 x 512 zones x 60 disparities = 1024 equal items — is not cut: its runs would leave 44 bytes of records per pixel and run,
+  // a merge launch, and the cut tiles stay out of the fp32 tier.
+  {
+    long long ntiles = 0;
+    double longest = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const vwgpu_zone_task& z = zones[i];
+      if (z.zw <= 0 || z.zh <= 0 || z.sx <= 0 || z.sy <= 0) continue;
+      ntiles += (long long)((z.zw + 31) / 32) * ((z.zh + 31) / 32);
+      longest = std::max(longest, (double)std::min(32, z.zw) * std::min(32, z.zh) * z.sx * z.sy);
+    }
+    if (ntiles >= resident && longest * (double)ntiles <= 1.5 * total) cap = std::max(cap, longest);
+  }
   for (int i = 0; i < n; ++i) {
     const vwgpu_zone_task& z = zones[i];
     if (z.zw <= 0 || z.zh <= 0 || z.sx <= 0 || z.sy <= 0) continue;
