@@ -145,6 +145,9 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *       (default: eight passes over the u16 sums, bandwidth bound), 1 = two concurrent fused raster sweeps of four directions each
  *       (a fifth of the HBM traffic, the same sums; slower on MI355X because a sweep is W + 2 H dependent pixel steps), 2 .. 15 = the
  *       sweeps with that many rows per workgroup (tuning).
+ *   VWGPU_OPT_SGM_PATH_MODE    the one-direction-per-launch schedule (tuning / measurements; same sums in every mode): bits 0-3 = scan lines
+ *       per workgroup (0 = default: 4 neighbouring lines for the six directions that cross the rows, 1 for the two along them; 1, 2, 4, 8),
+ *       bit 4 = read the census costs from a materialised u8 volume (the round-2 schedule) instead of forming them from the census rasters.
  *   VWGPU_OPT_EXACT_SPLIT      pass 2 of the exact-order matchers: 0 = chosen by the width of a zone (the recurrence alone + a parallel
  *       selection for zones of 1024 pixels and more (whole rasters), the tiled form — row sums transposed through LDS — for narrower
  *       ones), 1 = always the split form, 2 = always the fused form (selection across the disparity lanes inside the chain), 3 = always
@@ -159,7 +162,8 @@ typedef enum vwgpu_option {
   VWGPU_OPT_DEFER_EXACTNESS = 1, VWGPU_OPT_DEVICE_COUNT = 2, VWGPU_OPT_SAD_GROUPS = 3, VWGPU_OPT_EXACT_SCRATCH_MB = 4,
   VWGPU_OPT_TRACE = 5, VWGPU_OPT_SGM_SWEEP = 6, /* 7: removed in ABI 2 */ VWGPU_OPT_MGM_SWEEP = 8, VWGPU_OPT_EXACT_SPLIT = 9,
   /* 10: removed in ABI 2 */ VWGPU_OPT_HOST_RING_KB = 11, VWGPU_OPT_HOST_RING_WRAPS = 12, VWGPU_OPT_CERTIFY = 13,
-  VWGPU_OPT_CERT_PERMILLE = 14, VWGPU_OPT_ZONE_SXC = 15, VWGPU_OPT_CERT_F32 = 16, VWGPU_OPT_CERT_F64_PERMILLE = 17, VWGPU_OPT_ZONE_TILE16 = 18
+  VWGPU_OPT_CERT_PERMILLE = 14, VWGPU_OPT_ZONE_SXC = 15, VWGPU_OPT_CERT_F32 = 16, VWGPU_OPT_CERT_F64_PERMILLE = 17, VWGPU_OPT_ZONE_TILE16 = 18,
+  VWGPU_OPT_SGM_PATH_MODE = 19
 } vwgpu_option;
 int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value);
 int vwgpu_get_option(const vwgpu_ctx* ctx, int option, int* value);

@@ -7,5 +7,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o pmc_$c -- python tools/time_sgm.py 2048 2054 128 > /tmp/pmc_$c.log 2>&1
   db=$(find /tmp/pmc_$c -name "*.db" | head -1)
   python tools/rocprof_summary.py "$db" gpurun_out/sgm_traffic_$c.md > /dev/null 2>&1
-  grep -E "path_uniform_reg_kernel.*$c|cost_row_kernel.*$c|wta_uniform_kernel.*$c" gpurun_out/sgm_traffic_$c.md
+  grep -E "path_ring_kernel.*$c|path_uniform_reg_kernel.*$c|cost_row_kernel.*$c|wta_uniform_kernel.*$c" gpurun_out/sgm_traffic_$c.md
 done

@@ -11,6 +11,8 @@ MGM = len(sys.argv) > 4 and sys.argv[4] == "mgm"
 L, R, _ = synth.stereo_pair(W, H, SX + 1, 1)
 Lg, Rg = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
 ctx = core.default_context(0)
+import os
+if os.environ.get("SGM_PATH_MODE"): ctx.set_option(19, int(os.environ["SGM_PATH_MODE"]))      # VWGPU_OPT_SGM_PATH_MODE
 run = lambda: stereo.calc_disparity_sgm(3, Lg, Rg, BBox2i(0, 0, W, H), (SX, 0), (7, 7), use_mgm=MGM, with_subpixel=True, memory_limit_mb=200000)
 run(); torch.cuda.synchronize()
 t0 = time.perf_counter(); out = run(); torch.cuda.synchronize(); wall = time.perf_counter() - t0

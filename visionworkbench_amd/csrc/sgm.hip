@@ -1189,25 +1189,39 @@ enum { ACC_ATOMIC = 1, ACC_STORE = 2, ACC_NONE = 3, ACC_RMW = 4, ACC_RMW_WTA = 5
 #ifndef VWGPU_PATH_KC
 #define VWGPU_PATH_KC 8
 #endif
-template <int EPT, int ACC, int KC>
-__global__ void __launch_bounds__(64)
+// CEN (round 6): the Hamming costs of a step are formed from the two census rasters (one scalar left word, the lane's 2 EPT right
+// words: xor + v_bcnt) instead of being read from the u8 volume, which then is neither written nor read: 136 of the 680 bytes a
+// read-modify-write step moves at D = 129.  The right words of neighbouring lines overlap almost completely, so with the lines of
+// a workgroup adjacent they are L1 / L2 hits.  The raw words are fetched a chunk ahead into ONE register set and folded into cost
+// pairs before the next chunk's are requested.
+struct CenArgs {
+  const uint64_t* lcen; const uint64_t* rcen;      // at output pixel (0, 0), disparity 0
+  int lcw, rcw;
+};
+struct __attribute__((aligned(8))) CenPair { uint64_t a, b; };
+// WPB lines (wavefronts) per workgroup: the lines of a workgroup are neighbours, so the 128-byte lines that two neighbouring
+// pixels' vectors share (a 272-byte vector straddles three) are fetched by ONE compute unit / XCD instead of two.
+template <int EPT, int ACC, int KC, bool CEN, int WPB>
+__global__ void __launch_bounds__(64 * WPB)
 path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
-                        const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2,
+                        const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2, CenArgs CA,
                         int32_t* __restrict__ disp = nullptr, uint8_t* __restrict__ todo = nullptr, int* __restrict__ any_todo = nullptr) {
   constexpr bool RMW = (ACC == ACC_RMW || ACC == ACC_RMW_WTA);
-  constexpr int NW = CostWords<EPT>::N;
+  constexpr int NW = CEN ? EPT : CostWords<EPT>::N;
   const int num_disp = g.num_dx;                                                     // num_dy == 1
   const int npairs = (num_disp + 1) / 2;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 63;
+  const int gline = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WPB + (int)(threadIdx.x >> 6));
+  if (gline >= D.line0[D.n]) return;                                                 // (the last workgroup of a launch)
   // the tables are indexed dynamically (they land in scratch): readfirstlane tells the compiler the values are wave-uniform
   int dirq = 0;
-  while (dirq + 1 < D.n && (int)blockIdx.x >= D.line0[dirq + 1]) ++dirq;
+  while (dirq + 1 < D.n && gline >= D.line0[dirq + 1]) ++dirq;
   dirq = __builtin_amdgcn_readfirstlane(dirq);
   const int dc = __builtin_amdgcn_readfirstlane(D.dc[dirq]), dr = __builtin_amdgcn_readfirstlane(D.dr[dirq]);
   const int ww = g.ocols, wh = g.orows;
   int c0, r0;
   {
-    const int line = (int)blockIdx.x - __builtin_amdgcn_readfirstlane(D.line0[dirq]);
+    const int line = gline - __builtin_amdgcn_readfirstlane(D.line0[dirq]);
     const int nf = __builtin_amdgcn_readfirstlane(D.n_first[dirq]);
     if (line < nf) {
       if (__builtin_amdgcn_readfirstlane(D.row_border[dirq])) { c0 = line; r0 = dr > 0 ? 0 : wh - 1; }
@@ -1246,6 +1260,12 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
   const unsigned loff_c = in ? (unsigned)(tid * EPT * 2) : 0u, loff_a = in ? (unsigned)(tid * EPT) : 0u;
   const uint8_t* cfetch = cost + pbase * stride;                    // cost vector of the next step to fetch
   const long long cstep = delta * stride;
+  // CEN: the census words of the next step to fetch — the left one through a scalar pointer, the lane's right ones at its disparities
+  const uint64_t* lcfetch = CA.lcen + ((long long)r0 * CA.lcw + c0);
+  const long long lcstep = (long long)dr * CA.lcw + dc;
+  const uint64_t* rcfetch = CA.rcen + ((long long)r0 * CA.rcw + c0);
+  const long long rcstep = (long long)dr * CA.rcw + dc;
+  const unsigned loff_r = in ? (unsigned)(tid * EPT * 2) : 0u;      // in words
   const unsigned* afetch = reinterpret_cast<const unsigned*>(accum) + pbase * q32;
   const long long astep = delta * q32;
   unsigned* astore = reinterpret_cast<unsigned*>(accum) + pbase * q32 + loff_a;      // stores are masked by `in`
@@ -1285,7 +1305,9 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
       us2 m = __builtin_elementwise_min(__builtin_elementwise_min(as_us2(al[e]), as_us2(al[e + 1])), ctr);
       us2 v = __builtin_elementwise_add_sat(m, p1p1);
       v = __builtin_elementwise_min(v, __builtin_elementwise_min(ctr, dJ));
-      v = __builtin_elementwise_add_sat(v, as_us2(cost_pair<EPT>(w, e)));
+      unsigned cpair;
+      if constexpr (CEN) cpair = w[e]; else cpair = cost_pair<EPT>(w, e);
+      v = __builtin_elementwise_add_sat(v, as_us2(cpair));
       v = __builtin_elementwise_sub_sat(v, mp);
       r[e] = as_u32(v) | dead[e];
       mn2 = e == 0 ? as_us2(r[e]) : __builtin_elementwise_min(mn2, as_us2(r[e]));
@@ -1344,10 +1366,31 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
     const unsigned mnu = as_u32(mn2);
     min_prior = wave_min_u32_fused(min(mnu & 0xffffu, mnu >> 16));
   };
+  CenPair raw[CEN ? KC : 1][EPT];
+  uint64_t lraw[CEN ? KC : 1];
+  auto fetch_raw = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < (CEN ? KC : 0); ++k) {
+      const CenPair* rp = reinterpret_cast<const CenPair*>(rcfetch + loff_r);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) raw[k][e] = rp[e];
+      lraw[k] = *lcfetch;
+      rcfetch += rcstep;                                             // like the volumes: up to 2 KC steps past the line (guard zones)
+      lcfetch += lcstep;
+    }
+  };
+  auto convert = [&](unsigned (&buf)[KC][NW]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < (CEN ? KC : 0); ++k) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e)
+        buf[k][e] = (unsigned)__popcll(raw[k][e].a ^ lraw[k]) | ((unsigned)__popcll(raw[k][e].b ^ lraw[k]) << 16);
+    }
+  };
   auto fetch = [&](unsigned (&buf)[KC][NW], unsigned (&abuf)[KC][EPT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
-      load_cost_words<EPT>(cfetch + loff_c, true, buf[k]);
+      if constexpr (!CEN) load_cost_words<EPT>(cfetch + loff_c, true, buf[k]);
       if constexpr (RMW) {
         const unsigned* a = afetch + loff_a;
         if constexpr (EPT == 2) { const uint2 v = *reinterpret_cast<const uint2*>(a); abuf[k][0] = v.x; abuf[k][1] = v.y; }
@@ -1373,18 +1416,301 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
 
   unsigned ca[KC][NW], cb[KC][NW], aa[KC][EPT], ab[KC][EPT];
   const int nfull = len / KC;
-  fetch(ca, aa);
+  // CEN: the phases are pinned with scheduling barriers — left alone, the scheduler renames the buffers and hoists the next loads above
+  // the steps (three register sets of each: 256 VGPRs + 64 AGPRs, one wave per SIMD).
+#define VWGPU_SB() do { if constexpr (CEN) __builtin_amdgcn_sched_barrier(0); } while (0)
+  if constexpr (CEN) { fetch_raw(); fetch(ca, aa); convert(ca); VWGPU_SB(); fetch_raw(); }
+  else fetch(ca, aa);
   int ch = 0;
   for (; ch + 2 <= nfull; ch += 2) {                                // full chunks: no per-step test
+    VWGPU_SB();
     fetch(cb, ab);
+    VWGPU_SB();
     steps(ca, aa, ch * KC, std::false_type());
+    VWGPU_SB();
+    if constexpr (CEN) { convert(cb); VWGPU_SB(); fetch_raw(); }
     fetch(ca, aa);
+    VWGPU_SB();
     steps(cb, ab, (ch + 1) * KC, std::false_type());
+    VWGPU_SB();
+    if constexpr (CEN) { convert(ca); VWGPU_SB(); fetch_raw(); }
   }
   if (ch * KC < len) {                                              // the last one or two chunks
     fetch(cb, ab);
     steps(ca, aa, ch * KC, std::true_type());
+    if constexpr (CEN) convert(cb);
     steps(cb, ab, (ch + 1) * KC, std::true_type());
+  }
+#undef VWGPU_SB
+  if constexpr (ACC == ACC_RMW_WTA) {
+    if (flagged && tid == 0) atomicOr(any_todo, 1);
+  }
+}
+
+
+// ---- round 6: the same recurrence fed through an LDS ring (path_ring_kernel) ---------------------------------------------------
+// What bounds path_uniform_reg_kernel is not the HBM rate but the bytes it keeps in flight: a wavefront prefetches two chunks of 8
+// steps into registers (6.5 KB; 162 VGPRs, three waves per SIMD at most), a vertical or horizontal pass has 2048 lines = two waves per
+// SIMD, and 13 MB in flight at a loaded-memory latency of 2-3 us is the 5 TB/s the counters show.  Here the prefetch costs no register:
+// every wave owns a ring of RC chunks of 6 steps in LDS, filled by LDS-DMA (`global_load_lds_dwordx4`: per-lane global address, the
+// destination is wave-linear), and the step reads its 8 + 4 bytes per lane back with ds_read.  One DMA instruction moves three
+// accumulator vectors (3 x S/8 lanes x 16 B; S = vector stride, <= 160) or six cost vectors (6 x ceil(S/16) lanes).  Completion is
+// tracked with counted `s_waitcnt vmcnt(N)`: VMEM operations of a wave complete in issue order, and between the DMAs of chunk c and
+// the moment chunk c is needed the wave has issued exactly (RC - 1) x (NG DMAs + 6 stores) further operations (more only in the WTA
+// direction, whose per-pixel output stores are extra — a larger count errs on the safe side).  No ordinary global load sits in the
+// loop (the compiler would wait vmcnt(0) for it): the grey values of the next 60 steps arrive through a byte-wide DMA as well, and the
+// LDS reads are inline asm the compiler cannot see, fenced by hand.  Steps past the end of a line are clamped to its last pixel
+// (L2 hits), so every chunk issues the same number of operations and no guard zone is needed.
+#ifdef VWGPU_RING_DBG
+__constant__ int ring_dbg;     // tools build only (timing experiments, wrong results): 1 no sum stores, 2 no accumulator DMA, 4 no cost DMA, 8 no wave minimum
+#define RING_DBG(bit) (dbgv & (bit))
+#else
+#define RING_DBG(bit) false
+#endif
+template <int EPT, int ACC, int RC, int WPB>
+__global__ void __launch_bounds__(64 * WPB)
+path_ring_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
+                 const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2,
+                 int32_t* __restrict__ disp, uint8_t* __restrict__ todo, int* __restrict__ any_todo) {
+  constexpr bool RMW = (ACC == ACC_RMW || ACC == ACC_RMW_WTA);
+  constexpr int NG = RMW ? 3 : 1;                                  // DMA instructions per chunk
+  constexpr int CH = 6;                                            // steps per chunk
+  constexpr int BLK = 60;                                          // steps per penalty block (a multiple of CH)
+  typedef __attribute__((address_space(3))) uint8_t lds_u8;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  extern __shared__ __attribute__((aligned(16))) uint8_t ring_raw[];
+#ifdef VWGPU_RING_DBG
+  const int dbgv = __builtin_amdgcn_readfirstlane(ring_dbg);
+#endif
+  const int num_disp = g.num_dx;
+  const int npairs = (num_disp + 1) / 2;
+  const int tid = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int gline = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WPB + wv);
+  if (gline >= D.line0[D.n]) return;
+  int dirq = 0;
+  while (dirq + 1 < D.n && gline >= D.line0[dirq + 1]) ++dirq;
+  dirq = __builtin_amdgcn_readfirstlane(dirq);
+  const int dc = __builtin_amdgcn_readfirstlane(D.dc[dirq]), dr = __builtin_amdgcn_readfirstlane(D.dr[dirq]);
+  const int ww = g.ocols, wh = g.orows;
+  int c0, r0;
+  {
+    const int line = gline - __builtin_amdgcn_readfirstlane(D.line0[dirq]);
+    const int nf = __builtin_amdgcn_readfirstlane(D.n_first[dirq]);
+    if (line < nf) {
+      if (__builtin_amdgcn_readfirstlane(D.row_border[dirq])) { c0 = line; r0 = dr > 0 ? 0 : wh - 1; }
+      else { r0 = line; c0 = dc > 0 ? 0 : ww - 1; }
+    } else {
+      int i = line - nf;
+      if (D.rev_second && (dc > 0) == (dr > 0)) i = wh - 2 - i;
+      r0 = i + __builtin_amdgcn_readfirstlane(D.second_skip[dirq]);
+      c0 = dc > 0 ? 0 : ww - 1;
+    }
+  }
+  const int len_c = dc > 0 ? ww - c0 : (dc < 0 ? c0 + 1 : 0x7fffffff);
+  const int len_r = dr > 0 ? wh - r0 : (dr < 0 ? r0 + 1 : 0x7fffffff);
+  const int len = min(len_c, len_r);
+  const int S = stride, q32 = S / 2;
+  const int nA = S >> 3, nC = (S + 15) >> 4, CS = nC * 16;         // lanes per accumulator / cost vector of a DMA, LDS pitch of a cost vector
+  const int CHB = 2 * CH * S + CH * CS;                             // bytes per chunk: 6 accumulator vectors, then 6 cost vectors
+  const int WB = RC * CHB + 256;                                    // + the grey values of a penalty block (the dword around each byte)
+  lds_u8* const wring = (lds_u8*)ring_raw + wv * WB;
+  const unsigned wbase = (unsigned)(uintptr_t)wring;
+  const unsigned gbase = wbase + (unsigned)(RC * CHB);
+
+  unsigned dead[EPT], r[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int j = tid * EPT + e;
+    dead[e] = j >= npairs ? 0xffffffffu : ((2 * j + 1 >= num_disp) ? 0xffff0000u : 0u);
+    r[e] = dead[e];
+  }
+  const bool in = tid * EPT + EPT <= q32;
+  bool live0[EPT], live1[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) { live0[e] = 2 * (tid * EPT + e) < num_disp; live1[e] = 2 * (tid * EPT + e) + 1 < num_disp; }
+  bool flagged = false;
+  int last_val = 0;
+  unsigned min_prior = 0;
+  const long long delta = (long long)dr * g.ocols + dc;
+  const long long pbase = (long long)r0 * g.ocols + c0;
+  long long pcur = pbase;
+  const unsigned loff_c = in ? (unsigned)(tid * EPT * 2) : 0u, loff_a = in ? (unsigned)(tid * EPT * 4) : 0u;     // bytes
+  unsigned* astore = reinterpret_cast<unsigned*>(accum) + pbase * q32 + (in ? tid * EPT : 0);
+  const long long astore_step = delta * q32;
+  const us2 p1p1 = as_us2(p1 | (p1 << 16));
+  const uint8_t* lp = left + (size_t)(r0 + min_row) * lw + (c0 + min_col);
+  const int lstep = dr * lw + dc;
+
+  // producer side: per-lane source addresses of the three DMA shapes
+  const int ja = min(tid / nA, 2), ia = tid - ja * nA;              // accumulator DMA: lane -> (step of the triple, 16-byte piece)
+  const int jc = min(tid / nC, CH - 1), ic = tid - jc * nC;         // cost DMA: lane -> (step of the chunk, 16-byte piece)
+  const bool a_on = tid < 3 * nA, c_on = tid < CH * nC;
+  const uint8_t* const abase = reinterpret_cast<const uint8_t*>(accum) + pbase * (2 * S) + ia * 16;
+  const uint8_t* const cbase = cost + pbase * S + ic * 16;
+  const int astepB = (int)(delta * 2 * S), cstepB = (int)(delta * S);      // |delta| <= ocols + 1, S <= 160: fits
+  const int last = len - 1;
+  auto issue_chunk = [&](int c) __attribute__((always_inline)) {      // chunk c -> ring slot c % RC
+    lds_u8* slot = wring + (c % RC) * CHB;
+    const int s0 = c * CH;
+    if constexpr (RMW) {
+      if (a_on && !RING_DBG(2)) {
+        const uint8_t* p0 = abase + (long long)min(s0 + ja, last) * astepB;
+        __builtin_amdgcn_global_load_lds((gptr_t)p0, slot, 16, 0, 0);
+        const uint8_t* p1_ = abase + (long long)min(s0 + 3 + ja, last) * astepB;
+        __builtin_amdgcn_global_load_lds((gptr_t)p1_, slot + 6 * S, 16, 0, 0);
+      }
+    }
+    if (c_on && !RING_DBG(4)) {
+      const uint8_t* pc = cbase + (long long)min(s0 + jc, last) * cstepB;
+      __builtin_amdgcn_global_load_lds((gptr_t)pc, slot + 2 * CH * S, 16, 0, 0);
+    }
+  };
+  auto issue_grey = [&](int b) __attribute__((always_inline)) {       // grey values of steps 60 b .. 60 b + 63: the aligned dword around each
+    const uint8_t* pg = lp + (long long)min(b * BLK + tid, last) * lstep;
+    __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<uintptr_t>(pg) & ~(uintptr_t)3), wring + RC * CHB, 4, 0, 0);
+  };
+
+  unsigned penv = 0;
+  auto refresh = [&](int b) __attribute__((always_inline)) {          // penalties of steps 60 b .. 60 b + 59 (the block's DMA completed long ago)
+    unsigned pvu;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pvu) : "v"(gbase + (unsigned)(tid * 4)) : "memory");
+    const unsigned bsel = (unsigned)(reinterpret_cast<uintptr_t>(lp + (long long)min(b * BLK + tid, last) * lstep) & 3u);
+    issue_grey(b + 1);                                               // (the read above has completed: the one block can be refilled)
+    const int pv = (int)((pvu >> (8 * bsel)) & 0xffu);
+    const int prev = (int)wave_shr1((unsigned)pv, (unsigned)last_val);
+    int grad = pv - prev; grad = grad < 0 ? -grad : grad;
+    unsigned v = p2 / (unsigned)max(grad, 1);
+    if (v < p1) v = p1;
+    penv = v & 0xffffu;
+    last_val = __builtin_amdgcn_readlane(pv, min(BLK - 1, last - b * BLK));
+  };
+  unsigned pm = 0xffffffffu, pn = 0xffffffffu;
+  auto step = [&](unsigned cw, const unsigned (&aw)[EPT], int k) __attribute__((always_inline)) {      // k: step within the penalty block
+    const unsigned pen = (unsigned)__builtin_amdgcn_readlane((int)penv, k);
+    const unsigned dj = (min_prior + pen) & 0xffffu;
+    const us2 dJ = as_us2(dj | (dj << 16)), mp = as_us2(min_prior | (min_prior << 16));
+    wave_shr1_keep(pm, r[EPT - 1]);
+    wave_shl1_keep(pn, r[0]);
+    unsigned al[EPT + 1];
+    al[0] = __builtin_amdgcn_alignbit(r[0], pm, 16);
+#pragma unroll
+    for (int e = 1; e < EPT; ++e) al[e] = __builtin_amdgcn_alignbit(r[e], r[e - 1], 16);
+    al[EPT] = __builtin_amdgcn_alignbit(pn, r[EPT - 1], 16);
+    us2 mn2 = as_us2(0xffffffffu);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const us2 ctr = as_us2(r[e]);
+      us2 m = __builtin_elementwise_min(__builtin_elementwise_min(as_us2(al[e]), as_us2(al[e + 1])), ctr);
+      us2 v = __builtin_elementwise_add_sat(m, p1p1);
+      v = __builtin_elementwise_min(v, __builtin_elementwise_min(ctr, dJ));
+      const unsigned cpair = __builtin_amdgcn_perm(0u, cw, (e & 1) ? 0x0c030c02u : 0x0c010c00u);      // (c_2j, c_2j+1) as two u16
+      v = __builtin_elementwise_add_sat(v, as_us2(cpair));
+      v = __builtin_elementwise_sub_sat(v, mp);
+      r[e] = as_u32(v) | dead[e];
+      mn2 = e == 0 ? as_us2(r[e]) : __builtin_elementwise_min(mn2, as_us2(r[e]));
+    }
+    if constexpr (ACC != ACC_NONE) {
+      unsigned o[EPT];
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) o[e] = RMW ? as_u32(as_us2(aw[e]) + as_us2(r[e])) : r[e];
+      if constexpr (ACC == ACC_RMW_WTA) {
+        unsigned kk = 0xffffffffu;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const unsigned j2 = (unsigned)(tid * EPT + e) * 2u;
+          const unsigned k0 = live0[e] ? ((o[e] << 16) | j2) : 0xffffffffu, k1 = live1[e] ? ((o[e] & 0xffff0000u) | (j2 + 1u)) : 0xffffffffu;
+          kk = min(kk, min(k0, k1));
+        }
+        const unsigned key = wave_min_u32_fused(kk), mv = key >> 16;
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+          cnt += __popcll(__ballot(live0[e] && (o[e] & 0xffffu) == mv)) + __popcll(__ballot(live1[e] && (o[e] >> 16) == mv));
+        if (tid == 0) {
+          if (cnt > 1) { todo[pcur] = 1; }
+          else {
+            todo[pcur] = 0;
+            int32_t* w3 = disp + pcur * 3;
+            w3[0] = (int)(key & 0xffffu) + g.min_dx; w3[1] = g.min_dy; w3[2] = 0x7fffffff;
+          }
+        }
+        flagged |= cnt > 1;
+        pcur += delta;
+      }
+      if (in && !RING_DBG(1)) {
+        if constexpr (EPT == 2) *reinterpret_cast<uint2*>(astore) = make_uint2(o[0], o[1]);
+        else astore[0] = o[0];
+      }
+    }
+    astore += astore_step;
+    const unsigned mnu = as_u32(mn2);
+    if (!RING_DBG(8)) min_prior = wave_min_u32_fused(min(mnu & 0xffffu, mnu >> 16));
+  };
+  // one chunk: its 6 steps' bytes from the ring slot (all reads requested together, waited for step by step), then the steps
+  auto run_chunk = [&](int c, int kblk, int nsteps) __attribute__((always_inline)) {
+    const unsigned sb = wbase + (unsigned)((c % RC) * CHB);
+    unsigned cw[CH];
+    typedef typename std::conditional<EPT == 2, unsigned long long, unsigned>::type acc_t;
+    acc_t a64[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      if constexpr (RMW) {
+        const unsigned aa = sb + (unsigned)(k * 2 * S) + loff_a;
+        if constexpr (EPT == 2) asm volatile("ds_read_b64 %0, %1" : "=v"(a64[k]) : "v"(aa) : "memory");
+        else asm volatile("ds_read_b32 %0, %1" : "=v"(a64[k]) : "v"(aa) : "memory");
+      } else a64[k] = 0;
+      const unsigned ca = sb + (unsigned)(2 * CH * S + k * CS) + loff_c;
+      if constexpr (EPT == 2) asm volatile("ds_read_b32 %0, %1" : "=v"(cw[k]) : "v"(ca) : "memory");
+      else asm volatile("ds_read_u16 %0, %1" : "=v"(cw[k]) : "v"(ca) : "memory");
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      // LDS operations of a wave complete in order: the reads of steps k + 1 .. 5 may still be under way
+      if constexpr (RMW) {
+        switch (k) {
+          case 0: asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(cw[0]), "+v"(a64[0]) :: "memory"); break;
+          case 1: asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(cw[1]), "+v"(a64[1]) :: "memory"); break;
+          case 2: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(cw[2]), "+v"(a64[2]) :: "memory"); break;
+          case 3: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cw[3]), "+v"(a64[3]) :: "memory"); break;
+          case 4: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(cw[4]), "+v"(a64[4]) :: "memory"); break;
+          default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cw[5]), "+v"(a64[5]) :: "memory"); break;
+        }
+      } else if (k == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cw[0]), "+v"(cw[1]), "+v"(cw[2]), "+v"(cw[3]), "+v"(cw[4]), "+v"(cw[5]) :: "memory");
+      }
+      unsigned aw[EPT];
+      if constexpr (EPT == 2) { aw[0] = (unsigned)a64[k]; aw[1] = (unsigned)(a64[k] >> 32); } else aw[0] = (unsigned)a64[k];
+      if (k < nsteps) step(cw[k], aw, kblk + k);
+    }
+  };
+
+  // prologue: the first penalty block, then RC chunks in flight
+  issue_grey(0);
+#pragma unroll
+  for (int c = 0; c < RC; ++c) issue_chunk(c);
+  const int nfull = len / CH;
+  int c = 0, kblk = 0, blk = 0;
+  // the first RC - 1 chunks: fewer stores lie between a chunk's DMAs and its use than in the steady state — wait as if there were none
+  for (; c < min(nfull, RC - 1); ++c) {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RC - 1) * NG) : "memory");
+    if (kblk == 0) refresh(blk);
+    run_chunk(c, kblk, CH);
+    issue_chunk(c + RC);
+    kblk += CH;
+  }
+  for (; c < nfull; ++c) {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RC - 1) * (NG + (ACC == ACC_NONE ? 0 : CH)) > 63 ? 63 : (RC - 1) * (NG + (ACC == ACC_NONE ? 0 : CH))) : "memory");
+    if (kblk == BLK) { kblk = 0; ++blk; }
+    if (kblk == 0) refresh(blk);
+    run_chunk(c, kblk, CH);
+    issue_chunk(c + RC);
+    kblk += CH;
+  }
+  if (c * CH < len) {                                               // the last, partial chunk
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (kblk == BLK) { kblk = 0; ++blk; }
+    if (kblk == 0) refresh(blk);
+    run_chunk(c, kblk, len - c * CH);
   }
   if constexpr (ACC == ACC_RMW_WTA) {
     if (flagged && tid == 0) atomicOr(any_todo, 1);
@@ -2507,15 +2833,18 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
 
   // fixed-size part of the arena
   const int lcw = lw - 2 * hk, lch = lh - 2 * hk, rcw = rw - 2 * hk, rch = rh - 2 * hk;
-  const size_t fixed = (size_t)lw * lh + (size_t)rw * rh + 8 * ((size_t)lcw * lch + (size_t)rcw * rch) + npix * (16 + 8 + 1) +
+  // (guard zones around the census rasters: the register-resident path kernel requests census words up to 2 KC steps past a line's end)
+  const size_t cen_guard = (size_t)2 * VWGPU_PATH_KC * ((size_t)std::max(lcw, rcw) + 1) + 64;
+  const size_t fixed = (size_t)lw * lh + (size_t)rw * rh + 8 * ((size_t)lcw * lch + (size_t)rcw * rch + 3 * cen_guard) + npix * (16 + 8 + 1) +
                        (size_t)g.orows * (8 + 8 + 8) + (1 << 16);
   int rc = vwgpu_arena_reserve(ctx, &ctx->sgm, fixed);
   if (rc) return rc;
   Bump A{static_cast<char*>(ctx->sgm.base), ctx->sgm.cap};
   uint8_t* l8 = A.take<uint8_t>((size_t)lw * lh);
   uint8_t* r8 = A.take<uint8_t>((size_t)rw * rh);
-  uint64_t* lc = A.take<uint64_t>((size_t)lcw * lch);
-  uint64_t* rcen = A.take<uint64_t>((size_t)rcw * rch);
+  A.take<uint64_t>(cen_guard);
+  uint64_t* lc = A.take<uint64_t>((size_t)lcw * lch + cen_guard);
+  uint64_t* rcen = A.take<uint64_t>((size_t)rcw * rch + cen_guard);
   B4* bounds = A.take<B4>(npix);
   unsigned long long* starts = A.take<unsigned long long>(npix);
   uint8_t* full_search = A.take<uint8_t>(npix);
@@ -2639,7 +2968,12 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   const bool wta_in_paths = dir_paths && num_disp <= 256;
   bool wta_done = false;
   if (!dir_paths && !P->use_mgm) VWGPU_HIP(ctx, hipMemsetAsync(accum, 0, (size_t)main_buf * 2, st));      // (MGM: mgm_sum_kernel stores)
-  if (block_cost) {
+  // Census costs on that schedule are formed inside the path kernel from the census rasters (CEN): no u8 volume at all
+  const int cen_oc = min_col - hk, cen_or = min_row - hk;
+  const bool cen_paths = dir_paths && !block_cost && num_disp <= 256 && (ctx->sgm_path_mode & 16) && cen_oc >= 0 && cen_or >= 0 &&
+                         cen_oc + g.ocols <= lcw && cen_or + g.orows <= std::min(lch, rch) && cen_oc + g.ocols - 1 + (int)num_disp <= rcw;
+  if (cen_paths) {
+  } else if (block_cost) {
     // fill_costs_block (SGM.cc:1711-1738).  Exact n / count for every n the sums can reach: multiply-high by 2^32 / count + 1.
     vwgpu_prof_scope ps(ctx, "sgm_cost");
     const unsigned count = (unsigned)(kernel * kernel), magic = (unsigned)((1ull << 32) / count + 1);
@@ -2851,14 +3185,48 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
         if (nlines <= 0) continue;
         // the last direction takes the winners on the way (every pixel lies on exactly one of its lines)
         const int acc = q == 0 ? ACC_STORE : ((q == 7 && wta_in_paths) ? ACC_RMW_WTA : ACC_RMW);
-#define VWGPU_PATH_DIR1(E, A) hipLaunchKernelGGL((path_uniform_reg_kernel<E, A, VWGPU_PATH_KC>), dim3(nlines), dim3(64), 0, st, g, S, ustride, l8, lw, \
-                                 min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2, out_disp, full_search, wta_flag)
+        // lines per workgroup: neighbouring lines of the six directions that cross the rows share 128-byte lines of both volumes
+        int wpb = ctx->sgm_path_mode & 15;
+        if (wpb == 0) wpb = d.dr != 0 ? 4 : 1;
+        wpb = wpb >= 8 ? 8 : wpb >= 4 ? 4 : wpb >= 2 ? 2 : 1;
+        // round 6: the same recurrence fed through an LDS ring (path_ring_kernel) — vector strides up to 160 bytes
+        if (!(ctx->sgm_path_mode & 32) && !cen_paths && ustride <= 160) {
+#ifdef VWGPU_RING_DBG
+          { const int dv = getenv("VWGPU_RING_DBG") ? atoi(getenv("VWGPU_RING_DBG")) : 0; VWGPU_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(ring_dbg), &dv, sizeof dv, 0, hipMemcpyHostToDevice, st)); }
+#endif
+          const int rsel = (ctx->sgm_path_mode >> 6) & 3;
+          const int chb = 12 * ustride + 6 * 16 * ((ustride + 15) / 16);
+#define VWGPU_RING3(E, A, RCC) do { const size_t rl = (size_t)4 * ((size_t)RCC * chb + 256); \
+          VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(path_ring_kernel<E, A, RCC, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl)); \
+          hipLaunchKernelGGL((path_ring_kernel<E, A, RCC, 4>), dim3((nlines + 3) / 4), dim3(256), rl, st, g, S, ustride, l8, lw, min_col, min_row, cost, accum, \
+                             (unsigned)p1, (unsigned)p2, out_disp, full_search, wta_flag); } while (0)
+#define VWGPU_RING2(E, A) do { if (rsel == 1) VWGPU_RING3(E, A, 6); else if (rsel == 2) VWGPU_RING3(E, A, 8); else if (rsel == 3) VWGPU_RING3(E, A, 3); else VWGPU_RING3(E, A, 4); } while (0)
+#define VWGPU_RING(E) do { if (acc == ACC_STORE) VWGPU_RING2(E, ACC_STORE); else if (acc == ACC_RMW_WTA) VWGPU_RING2(E, ACC_RMW_WTA); else VWGPU_RING2(E, ACC_RMW); } while (0)
+          if (pe == 1) VWGPU_RING(1); else VWGPU_RING(2);
+#undef VWGPU_RING
+#undef VWGPU_RING2
+#undef VWGPU_RING3
+          if (acc == ACC_RMW_WTA) wta_done = true;
+          continue;
+        }
+        CenArgs CA;
+        CA.lcen = lc + (size_t)cen_or * lcw + cen_oc; CA.rcen = rcen + (size_t)cen_or * rcw + cen_oc; CA.lcw = lcw; CA.rcw = rcw;
+#define VWGPU_PATH_DIR3(E, A, C, WP) hipLaunchKernelGGL((path_uniform_reg_kernel<E, A, VWGPU_PATH_KC, C, WP>), dim3((nlines + WP - 1) / WP), dim3(64 * WP), 0, st, \
+                                 g, S, ustride, l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2, CA, out_disp, full_search, wta_flag)
+#define VWGPU_PATH_DIR2(E, A, C) do { if (wpb == 8) VWGPU_PATH_DIR3(E, A, C, 8); else if (wpb == 4) VWGPU_PATH_DIR3(E, A, C, 4); \
+                                      else if (wpb == 2) VWGPU_PATH_DIR3(E, A, C, 2); else VWGPU_PATH_DIR3(E, A, C, 1); } while (0)
+#define VWGPU_PATH_DIR1(E, A) do { if (cen_paths) VWGPU_PATH_DIR2(E, A, true); else VWGPU_PATH_DIR2(E, A, false); } while (0)
 #define VWGPU_PATH_DIR(E) do { if (acc == ACC_STORE) VWGPU_PATH_DIR1(E, ACC_STORE); else if (acc == ACC_RMW_WTA) VWGPU_PATH_DIR1(E, ACC_RMW_WTA); \
                                else VWGPU_PATH_DIR1(E, ACC_RMW); } while (0)
-        switch (pe) { case 1: VWGPU_PATH_DIR(1); break; case 2: VWGPU_PATH_DIR(2); break; default: VWGPU_PATH_DIR(4); break; }
+#define VWGPU_PATH_DIR_VOL(E) do { if (acc == ACC_STORE) VWGPU_PATH_DIR2(E, ACC_STORE, false); else if (acc == ACC_RMW_WTA) VWGPU_PATH_DIR2(E, ACC_RMW_WTA, false); \
+                                   else VWGPU_PATH_DIR2(E, ACC_RMW, false); } while (0)
+        switch (pe) { case 1: VWGPU_PATH_DIR(1); break; case 2: VWGPU_PATH_DIR(2); break; default: VWGPU_PATH_DIR_VOL(4); break; }   // (cen_paths: D <= 256, pe <= 2)
+#undef VWGPU_PATH_DIR_VOL
         if (acc == ACC_RMW_WTA) wta_done = true;
 #undef VWGPU_PATH_DIR
 #undef VWGPU_PATH_DIR1
+#undef VWGPU_PATH_DIR2
+#undef VWGPU_PATH_DIR3
       }
     } else
     for (int first = 0; first < 8; first += together ? 8 : 1) {

@@ -55,6 +55,7 @@ struct vwgpu_ctx {
   unsigned sgm_epoch = 0;
   int sgm_sweep = 0;     // VWGPU_OPT_SGM_SWEEP
   int mgm_sweep = 0;     // VWGPU_OPT_MGM_SWEEP
+  int sgm_path_mode = 0; // VWGPU_OPT_SGM_PATH_MODE
   vwgpu_arena xvol;      // exact-order path: column-sum volumes, band state, per-zone NCC precision images (bm_exact.hip)
   vwgpu_arena xtab;      // exact-order path: zone / work-item tables of one call
   vwgpu_arena xcarry;    // exact-order path: compare-chain state per pixel between the disparity groups of a zone with > 512 disparities
