@@ -182,6 +182,33 @@ def test_fused_sweeps_identical_to_oracle(vw, oracle, sweep, k, sx, w, h, cost):
     assert np.abs(gs - os_).max() < 1e-5
 
 
+# ---- the one-direction-per-launch schedule in all its forms (VWGPU_OPT_SGM_PATH_MODE): path_ring_kernel (LDS ring, the default),
+# path_uniform_reg_kernel (round 2), lines per workgroup, XCD clusters, census costs formed in the path kernel -------------------------
+
+@pytest.mark.parametrize("mode", [0, 192, 8, 512 + 8, 1024, 2048, 2048 + 512, 32, 32 + 1, 32 + 8, 32 + 16, 32 + 16 + 2])
+@pytest.mark.parametrize("k,sx,w,h,cost", [(7, 128, 300, 40, CENSUS), (5, 16, 64, 20, CENSUS), (3, 60, 500, 90, TERNARY), (9, 130, 257, 70, CENSUS),
+                                           (7, 127, 100, 300, TERNARY), (7, 8, 41, 25, CENSUS), (5, 159, 64, 47, CENSUS), (5, 200, 90, 33, CENSUS),
+                                           (7, 128, 12, 9, CENSUS), (7, 40, 3000, 9, CENSUS)])
+def test_path_modes_identical_to_oracle(vw, oracle, mode, k, sx, w, h, cost):
+    """Lines shorter than a chunk of the ring, widths that leave workgroups partly empty, 129 disparities (the 33rd lane), more than 160
+    bytes of stride (falls back to the register kernel), the winner-take-all inside the last direction: the same disparities every time."""
+    from visionworkbench_amd import core
+    ctx = core.default_context(0)
+    rng = np.random.default_rng(11 * k + sx + mode)
+    left = np.floor(rng.random((h, w)) * 256).astype(np.float32)
+    right = np.floor(rng.random((h, w + sx)) * 256).astype(np.float32)
+    right[:, sx // 3:sx // 3 + w] = left
+    left[h // 2:, : w // 2] = 90.0                                  # a flat patch: ties for the smoothing kernel
+    ctx.set_option(core.OPT_SGM_PATH_MODE, mode)
+    try:
+        gi, gs = vw.calc_disparity_sgm(cost, left, right, _box(w, h), (sx, 0), (k, k), with_subpixel=True, ctx=ctx)
+    finally:
+        ctx.set_option(core.OPT_SGM_PATH_MODE, 0)
+    oi, os_ = oracle.calc_disparity_sgm(cost, left, right, (sx, 0), k)
+    assert np.array_equal(gi, oi), int((gi != oi).any(-1).sum())
+    assert np.abs(gs - os_).max() < 1e-5
+
+
 def test_fused_sweeps_flat_image_and_user_penalties(vw, oracle):
     """Ties everywhere (the packed winner-take-all hands the pixel to the smoothing kernel, which must find the SUM of the two sweeps'
     volumes), and penalties large enough for the u16 sums to wrap."""

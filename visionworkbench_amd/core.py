@@ -42,7 +42,7 @@ CROSS_CORRELATION = CostFunctionType.CROSS_CORRELATION
 PATH_NONE, PATH_GENERIC_F64, PATH_SAD_U8, PATH_DOT_U8, PATH_EXACT_ORDER, PATH_SAD_U16, PATH_DOT_U16, PATH_REFUSED, PATH_CERTIFIED = 0, 1, 2, 3, 4, 5, 6, 7, 8
 OPT_DEFER_EXACTNESS, OPT_DEVICE_COUNT, OPT_SAD_GROUPS, OPT_EXACT_SCRATCH_MB, OPT_TRACE, OPT_SGM_SWEEP = 1, 2, 3, 4, 5, 6
 OPT_MGM_SWEEP, OPT_EXACT_SPLIT, OPT_HOST_RING_KB, OPT_HOST_RING_WRAPS, OPT_CERTIFY, OPT_CERT_PERMILLE, OPT_ZONE_SXC = 8, 9, 11, 12, 13, 14, 15      # vwgpu_option
-OPT_CERT_F32, OPT_CERT_F64_PERMILLE, OPT_ZONE_TILE16 = 16, 17, 18
+OPT_CERT_F32, OPT_CERT_F64_PERMILLE, OPT_ZONE_TILE16, OPT_SGM_PATH_MODE = 16, 17, 18, 19
 VALID_I32 = 0x7FFFFFFF
 
 

@@ -348,20 +348,23 @@ __global__ void cost_uniform16_kernel(const uint64_t* __restrict__ lc, int lcw, 
 // words of the right image they can reach in LDS once (6 KB at most) and every lane walks its pixel's disparities through
 // conflict-free 8-byte LDS reads (lane c reads word c + d).  The thread-per-16-disparities kernel above asked the L1 for 9-18
 // cache lines per wave load and ran at 0.7 TB/s (0.88 ms for the 606 MB of a 2048^2 x 129 volume).
+// Round 6: the 256 vectors of a workgroup are one contiguous run of the volume (256 x stride bytes), but a lane storing 8 bytes of ITS
+// vector put 64 addresses `stride` apart into every store instruction (1.9 GB of write requests for a 0.57 GB volume, 0.45 ms at
+// 2048^2 x 129).  The costs now go to a tile in LDS first and leave it as consecutive 16-byte pieces: every store instruction of a
+// wavefront writes 1 KiB of consecutive bytes.
 __global__ void __launch_bounds__(256)
 cost_row_kernel(const uint64_t* __restrict__ lc, int lcw, const uint64_t* __restrict__ rc, int rcw, int ocols, int num_disp, int stride,
                 int off_c, int off_r, uint8_t* __restrict__ cost) {
-  extern __shared__ uint64_t words[];
+  extern __shared__ uint64_t words[];                    // 256 + num_disp - 1 census words, then the tile of 256 x stride cost bytes
   const int tid = threadIdx.x, c0 = blockIdx.x * 256, r = blockIdx.y;
   const int br = r + off_r, bc0 = c0 + off_c;
+  const int nwords = (256 + num_disp - 1 + 1) & ~1;      // the tile starts 16-byte aligned
+  uint2* const tile = reinterpret_cast<uint2*>(words + nwords);
   const uint64_t* rrow = rc + (size_t)br * rcw;
   for (int i = tid; i < 256 + num_disp - 1; i += 256) words[i] = rrow[min(bc0 + i, rcw - 1)];
-  const int c = c0 + tid;
   const uint64_t lv = lc[(size_t)br * lcw + min(bc0 + tid, lcw - 1)];
   __syncthreads();
-  if (c >= ocols) return;
-  const int q = stride / 8;                              // stride % 8 == 0: 8 disparities per 8-byte store
-  uint2* o = reinterpret_cast<uint2*>(cost + ((size_t)r * ocols + c) * stride);
+  const int q = stride / 8;                              // stride % 8 == 0: 8 disparities per 8-byte piece
   for (int w = 0; w < q; ++w) {
     unsigned v[2] = {0u, 0u};
 #pragma unroll
@@ -371,7 +374,21 @@ cost_row_kernel(const uint64_t* __restrict__ lc, int lcw, const uint64_t* __rest
       const unsigned cst = i < num_disp ? (unsigned)__popcll(lv ^ rv) : 0u;      // dead slots of the stride are zero
       v[e >> 2] |= cst << (8 * (e & 3));
     }
-    o[w] = make_uint2(v[0], v[1]);
+    tile[tid * q + w] = make_uint2(v[0], v[1]);
+  }
+  __syncthreads();
+  const int npx = min(256, ocols - c0);                  // pixels of this workgroup inside the row
+  const int n16 = npx * stride / 16, rem8 = (npx * stride) & 8;      // 16-byte pieces (+ one 8-byte piece when npx * stride % 16 == 8)
+  uint8_t* const o = cost + ((size_t)r * ocols + c0) * stride;       // 8-byte aligned; 16-byte aligned when the pixel index is even
+  const bool a16 = (reinterpret_cast<uintptr_t>(o) & 15) == 0;
+  if (a16) {
+    const uint4* t4 = reinterpret_cast<const uint4*>(tile);
+    uint4* o4 = reinterpret_cast<uint4*>(o);
+    for (int i = tid; i < n16; i += 256) o4[i] = t4[i];
+    if (rem8 && tid == 0) reinterpret_cast<uint2*>(o)[2 * n16] = tile[2 * n16];
+  } else {                                               // (odd first pixel and stride % 16 == 8)
+    uint2* o2 = reinterpret_cast<uint2*>(o);
+    for (int i = tid; i < npx * q; i += 256) o2[i] = tile[i];
   }
 }
 
@@ -1467,13 +1484,21 @@ __constant__ int ring_dbg;     // tools build only (timing experiments, wrong re
 #else
 #define RING_DBG(bit) false
 #endif
-template <int EPT, int ACC, int RC, int WPB>
+// CEN: no cost volume.  The wave forms the Hamming costs of a chunk itself, right before the chunk's steps: lane l holds the right census
+// words of disparities 2 l and 2 l + 1 (one 16-byte load per step, requested two chunks ahead into registers; the words of neighbouring
+// lines overlap, so these are L1 / L2 hits), the left word and the right word of disparity 128 arrive through the scalar cache; xor +
+// v_bcnt, two cost bytes per lane written to the chunk's cost area in LDS, from where the step reads its four bytes as before (LDS
+// operations of a wave complete in order).  That is 9 vector instructions per step on ALL 64 lanes instead of 19 on the 33 the recurrence
+// uses, 136 of the 680 bytes a step moved, and no cost_row_kernel launch (0.45 ms and 0.6 GB written at 2048^2 x 129).  Up to 129 disparities.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int EPT, int ACC, int RC, int WPB, bool CEN>
 __global__ void __launch_bounds__(64 * WPB)
 path_ring_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
                  const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2,
-                 int32_t* __restrict__ disp, uint8_t* __restrict__ todo, int* __restrict__ any_todo) {
+                 int32_t* __restrict__ disp, uint8_t* __restrict__ todo, int* __restrict__ any_todo, int cluster, CenArgs CA) {
   constexpr bool RMW = (ACC == ACC_RMW || ACC == ACC_RMW_WTA);
-  constexpr int NG = RMW ? 3 : 1;                                  // DMA instructions per chunk
+  constexpr int NGA = RMW ? 2 : 0;                                 // accumulator DMA instructions per chunk
+  constexpr int NG = NGA + (CEN ? 0 : 1);                          // DMA instructions per chunk
   constexpr int CH = 6;                                            // steps per chunk
   constexpr int BLK = 60;                                          // steps per penalty block (a multiple of CH)
   typedef __attribute__((address_space(3))) uint8_t lds_u8;
@@ -1485,7 +1510,14 @@ path_ring_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restrict__ le
   const int num_disp = g.num_dx;
   const int npairs = (num_disp + 1) / 2;
   const int tid = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int gline = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WPB + wv);
+  // Workgroups go round the eight XCDs (each with an L2 of its own): `cluster` consecutive groups of lines are given to ONE XCD, so the
+  // 128-byte lines that the last vector of a group shares with the first of the next are fetched once as well.
+  int grp = (int)blockIdx.x;
+  {
+    const int span = 8 * cluster, whole = ((int)gridDim.x / span) * span;
+    if (cluster > 1 && grp < whole) { const int xcd = grp & 7, slot = grp >> 3; grp = (slot / cluster) * span + xcd * cluster + slot % cluster; }
+  }
+  const int gline = __builtin_amdgcn_readfirstlane(grp * WPB + wv);
   if (gline >= D.line0[D.n]) return;
   int dirq = 0;
   while (dirq + 1 < D.n && gline >= D.line0[dirq + 1]) ++dirq;
@@ -1511,11 +1543,16 @@ path_ring_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restrict__ le
   const int len = min(len_c, len_r);
   const int S = stride, q32 = S / 2;
   const int nA = S >> 3, nC = (S + 15) >> 4, CS = nC * 16;         // lanes per accumulator / cost vector of a DMA, LDS pitch of a cost vector
-  const int CHB = 2 * CH * S + CH * CS;                             // bytes per chunk: 6 accumulator vectors, then 6 cost vectors
-  const int WB = RC * CHB + 256;                                    // + the grey values of a penalty block (the dword around each byte)
+  // LDS of a wave: RC ring slots (6 accumulator vectors; without CEN the 6 cost vectors of the chunk behind them), CEN: ONE cost area
+  // (the wave writes it right before the chunk's steps), then 256 B of grey values (the dword around each byte), a 16-byte dump slot and,
+  // CEN, two sets of 6 left + 6 disparity-128 census words (16 bytes apart: the DMA moves 16 bytes per lane)
+  const int ACB = 2 * CH * S, CCB = CH * CS;
+  const int CHB = ACB + (CEN ? 0 : CCB);
+  const int TB = RC * CHB + (CEN ? CCB : 0);
+  const int WB = TB + 256 + (CEN ? 16 + 384 : 0);                     // (without CEN, 129 disparities, RC = 4: 10240 B — four workgroups of four waves per CU)
   lds_u8* const wring = (lds_u8*)ring_raw + wv * WB;
   const unsigned wbase = (unsigned)(uintptr_t)wring;
-  const unsigned gbase = wbase + (unsigned)(RC * CHB);
+  const unsigned gbase = wbase + (unsigned)TB;
 
   unsigned dead[EPT], r[EPT];
 #pragma unroll
@@ -1525,9 +1562,12 @@ path_ring_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restrict__ le
     r[e] = dead[e];
   }
   const bool in = tid * EPT + EPT <= q32;
-  bool live0[EPT], live1[EPT];
+  unsigned ork0[EPT], ork1[EPT];                        // ACC_RMW_WTA: the index of each half that is a disparity of the search, all ones otherwise
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) { live0[e] = 2 * (tid * EPT + e) < num_disp; live1[e] = 2 * (tid * EPT + e) + 1 < num_disp; }
+  for (int e = 0; e < EPT; ++e) {
+    const unsigned j2 = (unsigned)(tid * EPT + e) * 2u;
+    ork0[e] = (int)j2 < num_disp ? j2 : 0xffffffffu; ork1[e] = (int)j2 + 1 < num_disp ? j2 + 1u : 0xffffffffu;
+  }
   bool flagged = false;
   int last_val = 0;
   unsigned min_prior = 0;
@@ -1560,16 +1600,73 @@ path_ring_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restrict__ le
         __builtin_amdgcn_global_load_lds((gptr_t)p1_, slot + 6 * S, 16, 0, 0);
       }
     }
-    if (c_on && !RING_DBG(4)) {
-      const uint8_t* pc = cbase + (long long)min(s0 + jc, last) * cstepB;
-      __builtin_amdgcn_global_load_lds((gptr_t)pc, slot + 2 * CH * S, 16, 0, 0);
+    if constexpr (!CEN) {
+      if (c_on && !RING_DBG(4)) {
+        const uint8_t* pc = cbase + (long long)min(s0 + jc, last) * cstepB;
+        __builtin_amdgcn_global_load_lds((gptr_t)pc, slot + ACB, 16, 0, 0);
+      }
+    }
+  };
+  // CEN: census words of a chunk -> registers (two chunks in flight; the uniform words -> LDS), costs of a chunk -> the cost area
+  u32x4 cen[2][CEN ? CH : 1];
+  const uint8_t* const rbase = reinterpret_cast<const uint8_t*>(CA.rcen + ((long long)r0 * CA.rcw + c0)) + tid * 16;
+  const int rstepW = dr * CA.rcw + dc, lstepW = dr * CA.lcw + dc;
+  // uniform words: lanes 0..5 the left word of step k = lane, lanes 6..11 the right word at disparity 128 of step k = lane - 6
+  const int ju = tid < CH ? tid : min(tid - CH, CH - 1);
+  const uint64_t* const ubase = tid < CH ? CA.lcen + ((long long)r0 * CA.lcw + c0) : CA.rcen + ((long long)r0 * CA.rcw + c0) + 128;
+  const int ustepW = tid < CH ? lstepW : rstepW;
+  const unsigned dump = gbase + 256u, ubase_lds = gbase + 272u;
+  const unsigned cw_lane = 2 * tid < S ? (unsigned)(2 * tid) : 0xffffffffu;      // the lane's two cost bytes in a cost vector (or the dump slot)
+  auto load_census = [&](int c, int b) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < (CEN ? CH : 0); ++k) {
+      const int sk = __builtin_amdgcn_readfirstlane(min(c * CH + k, last));
+      const uint8_t* pr = rbase + (long long)sk * rstepW * 8;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cen[b][k]) : "v"(pr) : "memory");
+    }
+    if constexpr (CEN) {
+      if (tid < 2 * CH) {
+        const uint64_t* pu = ubase + (long long)min(c * CH + ju, last) * ustepW;
+        __builtin_amdgcn_global_load_lds((gptr_t)pu, wring + TB + 272 + b * 192, 16, 0, 0);
+      }
+    }
+  };
+  auto produce_costs = [&](int c, int b) __attribute__((always_inline)) {
+    const unsigned cb = wbase + (unsigned)(RC * CHB);
+    // the uniform words: LDS -> (the same 12 registers twice) -> scalar registers
+    unsigned long long lw_[CEN ? CH : 1], xw_[CEN ? CH : 1];
+    {
+      unsigned long long t[CEN ? CH : 1];
+#pragma unroll
+      for (int k = 0; k < (CEN ? CH : 0); ++k) asm volatile("ds_read_b64 %0, %1" : "=v"(t[k]) : "v"(ubase_lds + (unsigned)(b * 192 + k * 16)) : "memory");
+      if constexpr (CEN) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]) :: "memory");
+#pragma unroll
+      for (int k = 0; k < (CEN ? CH : 0); ++k)
+        lw_[k] = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)t[k]) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(t[k] >> 32)) << 32);
+#pragma unroll
+      for (int k = 0; k < (CEN ? CH : 0); ++k) asm volatile("ds_read_b64 %0, %1" : "=v"(t[k]) : "v"(ubase_lds + (unsigned)(b * 192 + 96 + k * 16)) : "memory");
+      if constexpr (CEN) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]) :: "memory");
+#pragma unroll
+      for (int k = 0; k < (CEN ? CH : 0); ++k)
+        xw_[k] = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)t[k]) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(t[k] >> 32)) << 32);
+    }
+#pragma unroll
+    for (int k = 0; k < (CEN ? CH : 0); ++k) {
+      const unsigned llo = (unsigned)lw_[k], lhi = (unsigned)(lw_[k] >> 32);
+      const unsigned c0_ = __builtin_popcount(cen[b][k].x ^ llo) + __builtin_popcount(cen[b][k].y ^ lhi);
+      const unsigned c1_ = __builtin_popcount(cen[b][k].z ^ llo) + __builtin_popcount(cen[b][k].w ^ lhi);
+      const unsigned pk = c0_ | (c1_ << 8);
+      const unsigned cx = (unsigned)__builtin_popcountll(xw_[k] ^ lw_[k]);
+      const unsigned a2 = cw_lane == 0xffffffffu ? dump : cb + (unsigned)(k * CS) + cw_lane;
+      const unsigned a1 = 128 < S ? cb + (unsigned)(k * CS) + 128u : dump + 8u;
+      asm volatile("ds_write_b16 %0, %1" :: "v"(a2), "v"(pk) : "memory");
+      asm volatile("ds_write_b8 %0, %1" :: "v"(a1), "v"(cx) : "memory");
     }
   };
   auto issue_grey = [&](int b) __attribute__((always_inline)) {       // grey values of steps 60 b .. 60 b + 63: the aligned dword around each
     const uint8_t* pg = lp + (long long)min(b * BLK + tid, last) * lstep;
-    __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<uintptr_t>(pg) & ~(uintptr_t)3), wring + RC * CHB, 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<uintptr_t>(pg) & ~(uintptr_t)3), wring + TB, 4, 0, 0);
   };
-
   unsigned penv = 0;
   auto refresh = [&](int b) __attribute__((always_inline)) {          // penalties of steps 60 b .. 60 b + 59 (the block's DMA completed long ago)
     unsigned pvu;
@@ -1614,18 +1711,17 @@ path_ring_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restrict__ le
 #pragma unroll
       for (int e = 0; e < EPT; ++e) o[e] = RMW ? as_u32(as_us2(aw[e]) + as_us2(r[e])) : r[e];
       if constexpr (ACC == ACC_RMW_WTA) {
+        // keys (value << 16 | index); a half that is no disparity of the search has all ones OR-ed in (a per-lane constant: no select)
         unsigned kk = 0xffffffffu;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-          const unsigned j2 = (unsigned)(tid * EPT + e) * 2u;
-          const unsigned k0 = live0[e] ? ((o[e] << 16) | j2) : 0xffffffffu, k1 = live1[e] ? ((o[e] & 0xffff0000u) | (j2 + 1u)) : 0xffffffffu;
-          kk = min(kk, min(k0, k1));
-        }
+        for (int e = 0; e < EPT; ++e) kk = min(kk, min((o[e] << 16) | ork0[e], (o[e] & 0xffff0000u) | ork1[e]));
         const unsigned key = wave_min_u32_fused(kk), mv = key >> 16;
+        // Ties: the count may include a padding half that happens to hold the minimum's value (the sums of the padding are arbitrary) —
+        // that sends a pixel with a unique minimum to wta_kernel, which finds the same minimum.
         int cnt = 0;
 #pragma unroll
         for (int e = 0; e < EPT; ++e)
-          cnt += __popcll(__ballot(live0[e] && (o[e] & 0xffffu) == mv)) + __popcll(__ballot(live1[e] && (o[e] >> 16) == mv));
+          cnt += __popcll(__ballot((o[e] & 0xffffu) == mv)) + __popcll(__ballot((o[e] >> 16) == mv));
         if (tid == 0) {
           if (cnt > 1) { todo[pcur] = 1; }
           else {
@@ -1659,7 +1755,7 @@ path_ring_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restrict__ le
         if constexpr (EPT == 2) asm volatile("ds_read_b64 %0, %1" : "=v"(a64[k]) : "v"(aa) : "memory");
         else asm volatile("ds_read_b32 %0, %1" : "=v"(a64[k]) : "v"(aa) : "memory");
       } else a64[k] = 0;
-      const unsigned ca = sb + (unsigned)(2 * CH * S + k * CS) + loff_c;
+      const unsigned ca = (CEN ? wbase + (unsigned)(RC * CHB) : sb + (unsigned)ACB) + (unsigned)(k * CS) + loff_c;
       if constexpr (EPT == 2) asm volatile("ds_read_b32 %0, %1" : "=v"(cw[k]) : "v"(ca) : "memory");
       else asm volatile("ds_read_u16 %0, %1" : "=v"(cw[k]) : "v"(ca) : "memory");
     }
@@ -1684,33 +1780,62 @@ path_ring_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restrict__ le
     }
   };
 
-  // prologue: the first penalty block, then RC chunks in flight
+  // prologue: the first penalty block, (CEN: the census words of two chunks,) then RC chunks in flight
   issue_grey(0);
+  if constexpr (CEN) { load_census(0, 0); load_census(1, 1); }
 #pragma unroll
   for (int c = 0; c < RC; ++c) issue_chunk(c);
   const int nfull = len / CH;
   int c = 0, kblk = 0, blk = 0;
-  // the first RC - 1 chunks: fewer stores lie between a chunk's DMAs and its use than in the steady state — wait as if there were none
-  for (; c < min(nfull, RC - 1); ++c) {
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RC - 1) * NG) : "memory");
-    if (kblk == 0) refresh(blk);
-    run_chunk(c, kblk, CH);
-    issue_chunk(c + RC);
-    kblk += CH;
-  }
-  for (; c < nfull; ++c) {
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RC - 1) * (NG + (ACC == ACC_NONE ? 0 : CH)) > 63 ? 63 : (RC - 1) * (NG + (ACC == ACC_NONE ? 0 : CH))) : "memory");
+  // Operations a wave issues per chunk in the steady state, in this order: (CEN: 6 census loads of chunk c + 2,) 6 stores, NG DMAs of chunk
+  // c + RC.  Chunk c needs its DMAs (issued RC chunks ago) and, CEN, its census words (issued two chunks ago, BEFORE that chunk's stores):
+  // everything but the operations younger than those may still be under way.
+  constexpr int STORES = ACC == ACC_NONE ? 0 : CH;
+  constexpr int N_STEADY = CEN ? CH + 1 + 2 * (STORES + NG) : (RC - 1) * (NG + STORES);  // CEN: stores + DMAs of c - 2, census (6 + 1) + stores + DMAs of c - 1
+  constexpr int N_EARLY = CEN ? 0 : (RC - 1) * NG;                   // the first chunks: fewer stores lie in between — wait as if there were none
+  constexpr int C_EARLY = CEN ? RC : RC - 1;
+  static_assert(RC >= 3, "the census words of chunk c are requested after the DMAs of chunk c");
+  // one chunk; B = its census register set (compile time: the sets must stay registers), MODE = 0 one of the first chunks, 1 steady state,
+  // 2 the last, partial chunk
+  auto chunk = [&](auto Bc, auto MODEc, int nsteps) __attribute__((always_inline)) {
+    constexpr int B = decltype(Bc)::value;
+    constexpr int MODE = decltype(MODEc)::value;
+    constexpr int N = MODE == 2 ? 0 : MODE == 0 ? N_EARLY : (N_STEADY > 63 ? 63 : N_STEADY);
+    if constexpr (CEN) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(cen[B][0]), "+v"(cen[B][1]), "+v"(cen[B][2]), "+v"(cen[B][3]), "+v"(cen[B][4]), "+v"(cen[B][5]) : "n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
     if (kblk == BLK) { kblk = 0; ++blk; }
     if (kblk == 0) refresh(blk);
-    run_chunk(c, kblk, CH);
-    issue_chunk(c + RC);
+    if constexpr (CEN) {
+      produce_costs(c, B);
+      if constexpr (MODE != 2) load_census(c + 2, B);
+    }
+    run_chunk(c, kblk, nsteps);
+    if constexpr (MODE != 2) issue_chunk(c + RC);
     kblk += CH;
+    ++c;
+  };
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  typedef std::integral_constant<int, 2> I2;
+  if constexpr (CEN) {
+    const int ce = min(nfull & ~1, (C_EARLY + 1) & ~1);
+    while (c < ce) { chunk(I0(), I0(), CH); chunk(I1(), I0(), CH); }
+    while (c + 2 <= nfull) { chunk(I0(), I1(), CH); chunk(I1(), I1(), CH); }
+    if (c < nfull) {
+      chunk(I0(), I0(), CH);
+      if (c * CH < len) chunk(I1(), I2(), len - c * CH);
+    } else if (c * CH < len) chunk(I0(), I2(), len - c * CH);
+  } else {
+    const int ce = min(nfull, C_EARLY);
+    while (c < ce) chunk(I0(), I0(), CH);
+    while (c < nfull) chunk(I0(), I1(), CH);
+    if (c * CH < len) chunk(I0(), I2(), len - c * CH);
   }
-  if (c * CH < len) {                                               // the last, partial chunk
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (kblk == BLK) { kblk = 0; ++blk; }
-    if (kblk == 0) refresh(blk);
-    run_chunk(c, kblk, len - c * CH);
+  if constexpr (CEN) {
+    // The census words requested last are never used, and a register the compiler takes for dead is free for anything else — while its load
+    // is still under way.  Every register set stays allocated until the loads have landed:
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(cen[0][0]), "v"(cen[0][1]), "v"(cen[0][2]), "v"(cen[0][3]), "v"(cen[0][4]), "v"(cen[0][5]),
+                 "v"(cen[1][0]), "v"(cen[1][1]), "v"(cen[1][2]), "v"(cen[1][3]), "v"(cen[1][4]), "v"(cen[1][5]) : "memory");
   }
   if constexpr (ACC == ACC_RMW_WTA) {
     if (flagged && tid == 0) atomicOr(any_todo, 1);
@@ -2970,9 +3095,12 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   if (!dir_paths && !P->use_mgm) VWGPU_HIP(ctx, hipMemsetAsync(accum, 0, (size_t)main_buf * 2, st));      // (MGM: mgm_sum_kernel stores)
   // Census costs on that schedule are formed inside the path kernel from the census rasters (CEN): no u8 volume at all
   const int cen_oc = min_col - hk, cen_or = min_row - hk;
-  const bool cen_paths = dir_paths && !block_cost && num_disp <= 256 && (ctx->sgm_path_mode & 16) && cen_oc >= 0 && cen_or >= 0 &&
-                         cen_oc + g.ocols <= lcw && cen_or + g.orows <= std::min(lch, rch) && cen_oc + g.ocols - 1 + (int)num_disp <= rcw;
-  if (cen_paths) {
+  const bool cen_ok = dir_paths && !block_cost && cen_oc >= 0 && cen_or >= 0 && cen_oc + g.ocols <= lcw && cen_or + g.orows <= std::min(lch, rch) &&
+                      cen_oc + g.ocols - 1 + (int)num_disp <= rcw;
+  const bool ring_paths = dir_paths && !(ctx->sgm_path_mode & 32) && ustride <= 160;            // path_ring_kernel
+  const bool ring_cen = ring_paths && cen_ok && num_disp <= 129 && (ctx->sgm_path_mode & 2048);   // ... forming the census costs itself (opt-in: measured slower)
+  const bool cen_paths = !ring_paths && cen_ok && num_disp <= 256 && (ctx->sgm_path_mode & 16);   // path_uniform_reg_kernel<.., CEN> (measured: register bound)
+  if (cen_paths || ring_cen) {
   } else if (block_cost) {
     // fill_costs_block (SGM.cc:1711-1738).  Exact n / count for every n the sums can reach: multiply-high by 2^32 / count + 1.
     vwgpu_prof_scope ps(ctx, "sgm_cost");
@@ -2999,7 +3127,9 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     if (uniform)
     {
       if (g.num_dy == 1) {
-        hipLaunchKernelGGL(cost_row_kernel, dim3((g.ocols + 255) / 256, g.orows), dim3(256), (size_t)(256 + num_disp) * 8, st, lc, lcw, rcen, rcw,
+        const size_t crl = (size_t)(256 + num_disp + 1) * 8 + (size_t)256 * ustride;      // <= 6 KB + 128 KB (512 disparities)
+        VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(cost_row_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)crl));
+        hipLaunchKernelGGL(cost_row_kernel, dim3((g.ocols + 255) / 256, g.orows), dim3(256), crl, st, lc, lcw, rcen, rcw,
                            g.ocols, (int)num_disp, ustride, min_col - hk, min_row - hk, cost);
       } else {
         const int qd = ustride / 16;                        // 16-disparity groups per pixel (2-D searches: stride % 16 == 0, 1 .. 32 groups)
@@ -3189,28 +3319,33 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
         int wpb = ctx->sgm_path_mode & 15;
         if (wpb == 0) wpb = d.dr != 0 ? 4 : 1;
         wpb = wpb >= 8 ? 8 : wpb >= 4 ? 4 : wpb >= 2 ? 2 : 1;
+        CenArgs CA;
+        CA.lcen = lc + (size_t)cen_or * lcw + cen_oc; CA.rcen = rcen + (size_t)cen_or * rcw + cen_oc; CA.lcw = lcw; CA.rcw = rcw;
         // round 6: the same recurrence fed through an LDS ring (path_ring_kernel) — vector strides up to 160 bytes
-        if (!(ctx->sgm_path_mode & 32) && !cen_paths && ustride <= 160) {
+        if (ring_paths) {
 #ifdef VWGPU_RING_DBG
           { const int dv = getenv("VWGPU_RING_DBG") ? atoi(getenv("VWGPU_RING_DBG")) : 0; VWGPU_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(ring_dbg), &dv, sizeof dv, 0, hipMemcpyHostToDevice, st)); }
 #endif
           const int rsel = (ctx->sgm_path_mode >> 6) & 3;
-          const int chb = 12 * ustride + 6 * 16 * ((ustride + 15) / 16);
-#define VWGPU_RING3(E, A, RCC) do { const size_t rl = (size_t)4 * ((size_t)RCC * chb + 256); \
-          VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(path_ring_kernel<E, A, RCC, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl)); \
-          hipLaunchKernelGGL((path_ring_kernel<E, A, RCC, 4>), dim3((nlines + 3) / 4), dim3(256), rl, st, g, S, ustride, l8, lw, min_col, min_row, cost, accum, \
-                             (unsigned)p1, (unsigned)p2, out_disp, full_search, wta_flag); } while (0)
-#define VWGPU_RING2(E, A) do { if (rsel == 1) VWGPU_RING3(E, A, 6); else if (rsel == 2) VWGPU_RING3(E, A, 8); else if (rsel == 3) VWGPU_RING3(E, A, 3); else VWGPU_RING3(E, A, 4); } while (0)
+          const int rwpb = (ctx->sgm_path_mode & 15) >= 8 ? 8 : 4, cluster = 1 << ((ctx->sgm_path_mode >> 8) & 7);
+#define VWGPU_RING5(E, A, RCC, WP, C) do { const size_t acb = (size_t)12 * ustride, ccb = (size_t)6 * 16 * ((ustride + 15) / 16); \
+          const size_t rl = (size_t)WP * (C ? RCC * acb + ccb + 272 + 384 : RCC * (acb + ccb) + 256); \
+          VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(path_ring_kernel<E, A, RCC, WP, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl)); \
+          hipLaunchKernelGGL((path_ring_kernel<E, A, RCC, WP, C>), dim3((nlines + WP - 1) / WP), dim3(64 * WP), rl, st, g, S, ustride, l8, lw, min_col, min_row, cost, accum, \
+                             (unsigned)p1, (unsigned)p2, out_disp, full_search, wta_flag, cluster, CA); } while (0)
+#define VWGPU_RING4(E, A, RCC, WP) do { if (ring_cen) VWGPU_RING5(E, A, RCC, WP, true); else VWGPU_RING5(E, A, RCC, WP, false); } while (0)
+#define VWGPU_RING3(E, A, RCC) do { if (rwpb == 8) VWGPU_RING4(E, A, RCC, 8); else VWGPU_RING4(E, A, RCC, 4); } while (0)
+#define VWGPU_RING2(E, A) do { if (rsel == 3 || rwpb == 8) VWGPU_RING3(E, A, 3); else VWGPU_RING3(E, A, 4); } while (0)
 #define VWGPU_RING(E) do { if (acc == ACC_STORE) VWGPU_RING2(E, ACC_STORE); else if (acc == ACC_RMW_WTA) VWGPU_RING2(E, ACC_RMW_WTA); else VWGPU_RING2(E, ACC_RMW); } while (0)
           if (pe == 1) VWGPU_RING(1); else VWGPU_RING(2);
 #undef VWGPU_RING
 #undef VWGPU_RING2
 #undef VWGPU_RING3
+#undef VWGPU_RING4
+#undef VWGPU_RING5
           if (acc == ACC_RMW_WTA) wta_done = true;
           continue;
         }
-        CenArgs CA;
-        CA.lcen = lc + (size_t)cen_or * lcw + cen_oc; CA.rcen = rcen + (size_t)cen_or * rcw + cen_oc; CA.lcw = lcw; CA.rcw = rcw;
 #define VWGPU_PATH_DIR3(E, A, C, WP) hipLaunchKernelGGL((path_uniform_reg_kernel<E, A, VWGPU_PATH_KC, C, WP>), dim3((nlines + WP - 1) / WP), dim3(64 * WP), 0, st, \
                                  g, S, ustride, l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2, CA, out_disp, full_search, wta_flag)
 #define VWGPU_PATH_DIR2(E, A, C) do { if (wpb == 8) VWGPU_PATH_DIR3(E, A, C, 8); else if (wpb == 4) VWGPU_PATH_DIR3(E, A, C, 4); \

@@ -248,7 +248,7 @@ int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value) {
   if (option == VWGPU_OPT_ZONE_SXC && value >= 0 && value <= 4096) { ctx->zone_sxc = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_SGM_SWEEP && value >= 0 && value <= 15) { ctx->sgm_sweep = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_MGM_SWEEP && value >= 0 && value <= 15) { ctx->mgm_sweep = value; return VWGPU_OK; }
-  if (option == VWGPU_OPT_SGM_PATH_MODE && value >= 0 && value <= 255) { ctx->sgm_path_mode = value; return VWGPU_OK; }
+  if (option == VWGPU_OPT_SGM_PATH_MODE && value >= 0 && value <= 4095) { ctx->sgm_path_mode = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_EXACT_SPLIT && value >= 0 && value <= 3) { ctx->exact_split = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_HOST_RING_KB && value >= 16 && value <= (1 << 20)) {
     if (value != ctx->host_ring_kb && ctx->host_ring) {            // pending copies read the old ring
