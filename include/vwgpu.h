@@ -122,7 +122,8 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *   The remaining options never change a result (they choose between kernels / schedules that return identical bits, and are
  *   what tests and tools use to reach every variant); values outside the stated range are rejected with VWGPU_ERR_ARGUMENT:
  *   VWGPU_OPT_SAD_GROUPS       packed-u8 SAD matcher flavour: 0 = chosen by the launcher's cost model (default), 1 = one wave
- *       group per tile, 2 = two wave groups per tile.
+ *       group per tile, 2 = two wave groups per tile, 3 = four wave groups on 512-column tiles of 16 rows (sizes without that flavour
+ *       keep the launcher's choice).  Same results in every flavour.
  *   VWGPU_OPT_EXACT_SCRATCH_MB scratch budget of the exact-order path in MiB (16 .. 65536, default 4096): column-sum volumes
  *       beyond it are swept in row bands / zone groups / disparity groups.
  *   VWGPU_OPT_TRACE            bit 0: host-side timeline of a pyramid tile on stderr, bit 1: the zone shapes of a level, bit 2: certification

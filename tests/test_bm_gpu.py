@@ -35,11 +35,12 @@ def _default_options(ctx):
     ctx.set_option(core.OPT_EXACT_SCRATCH_MB, 4096)
 
 
-@pytest.fixture(params=["auto", "one-group"])
+@pytest.fixture(params=["auto", "one-group", "two-groups", "narrow-four-groups"])
 def sad_variant(request, ctx):
-    """Small images run the packed-u8 matcher with two wave groups per tile (the launcher's choice for grids that do not
-    fill the chip); OPT_SAD_GROUPS = 1 pins the one-group kernel the full-size case uses, so both see every case."""
-    ctx.set_option(core.OPT_SAD_GROUPS, 1 if request.param == "one-group" else 0)
+    """Small images run the packed-u8 matcher with several wave groups per tile (the launcher's choice for grids that do not
+    fill the chip: two groups on 1024-column tiles or, round 6, four groups on 512-column tiles of 16 rows); OPT_SAD_GROUPS pins the
+    one-group kernel the full-size case uses and either split flavour, so all of them see every case."""
+    ctx.set_option(core.OPT_SAD_GROUPS, {"auto": 0, "one-group": 1, "two-groups": 2, "narrow-four-groups": 3}[request.param])
     yield request.param
     ctx.set_option(core.OPT_SAD_GROUPS, 0)
 
@@ -324,14 +325,14 @@ def test_full_size_config2_sampled_parity(ctx, oracle):
     assert (got[..., 0] == t).mean() > 0.9
 
 
-@pytest.mark.parametrize("rows,variant", [(1028, None), (517, None), (1028, "0"), (2051, "1")])
+@pytest.mark.parametrize("rows,variant", [(1028, None), (517, None), (1028, "0"), (2051, "1"), (517, "2"), (1028, "2"), (261, "2")])
 def test_row_strip_sizes_sampled_parity(ctx, oracle, monkeypatch, rows, variant):
     """The strips a 4096^2 pair is cut into on 4 and 8 GPUs (and the tile-height / wave-group variants the launcher picks
     for them: 16-row two-group tiles for 1/4, 8-row two-group tiles for 1/8; OPT_SAD_GROUPS pins the other flavour): full-width
     strip on the GPU, the oracle on sampled padded crops, bit for bit."""
     import torch
     from visionworkbench_amd import stereo
-    ctx.set_option(core.OPT_SAD_GROUPS, {None: 0, "0": 1, "1": 2}[variant])
+    ctx.set_option(core.OPT_SAD_GROUPS, {None: 0, "0": 1, "1": 2, "2": 3}[variant])
     W = 4096
     left, right, _ = synth.stereo_pair(W, rows, 129, 1)
     lt, rt = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()

@@ -1,5 +1,1 @@
-SGM_PATH_MODE=0 TAG=r06_default timeout 250 bash tools/pmc_sgm_dirs.sh > /dev/null
-SGM_PATH_MODE=33 TAG=r06_round5 timeout 250 bash tools/pmc_sgm_dirs.sh > /dev/null
-SGM_PATH_MODE=0 timeout 100 python tools/time_sgm.py 2048 2054 128 > gpurun_out/time_sgm_r06.txt 2>&1
-SGM_PATH_MODE=33 timeout 100 python tools/time_sgm.py 2048 2054 128 > gpurun_out/time_sgm_r06_round5.txt 2>&1
-cat gpurun_out/time_sgm_r06.txt
+timeout 1500 python -m pytest tests/test_bm_gpu.py tests/test_fuzz_gpu.py -m gpu -x -q > gpurun_out/t_bm.txt 2>&1; grep -E "passed|failed|error|Error" gpurun_out/t_bm.txt | tail -5

@@ -29,6 +29,7 @@ def run(W, H, SX, ctx, lib, save=None):
     assert lib.vwgpu_debug_set_sad_stamps(null) == 0
     box = vwa.bounding_box(left)
     ctx.set_option(core.OPT_DEFER_EXACTNESS, 1)
+    if os.environ.get("SAD_GROUPS"): ctx.set_option(core.OPT_SAD_GROUPS, int(os.environ["SAD_GROUPS"]))
     for _ in range(30):
         stereo.calc_disparity(0, lt, rt, box, (SX, 1), (7, 7), ctx=ctx)
     torch.cuda.synchronize()

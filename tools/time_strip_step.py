@@ -1,6 +1,6 @@
 """ms per bench step of rank 0's row strip when config 2 is split N ways (what `bench.py --gpus N` times per rank), on one GPU.
 usage: python tools/time_strip_step.py [N...]"""
-import sys, time
+import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 import visionworkbench_amd as vwa
@@ -14,6 +14,7 @@ for N in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     (la, lb), (ra, rb) = partition.strip_inputs(0, N, H, 7, 1)
     l = torch.from_numpy(left[la:lb]).cuda(); r = torch.from_numpy(right[ra:rb]).cuda()
     ctx = vwa.Context(0); ctx.set_option(core.OPT_DEFER_EXACTNESS, 1)
+    if os.environ.get("SAD_GROUPS"): ctx.set_option(core.OPT_SAD_GROUPS, int(os.environ["SAD_GROUPS"]))
     region = vwa.BBox2i(0, 0, W, r1 - r0 + 6)
     step = lambda: stereo.calc_disparity(0, l, r, region, SEARCH, KERNEL, ctx=ctx)
     for _ in range(300): step()
@@ -28,5 +29,8 @@ for N in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     rec = ctx.profile_read(1 << 10); ctx.profile_enable(False)
     agg = {}
     for n, ms in rec: agg.setdefault(n, []).append(ms)
+    if os.environ.get("SAD_GROUPS"):
+        got = step().cpu().numpy(); ctx.set_option(core.OPT_SAD_GROUPS, 0); ref = step().cpu().numpy()
+        print("   SAD_GROUPS=%s result %s the default flavour's" % (os.environ["SAD_GROUPS"], "identical to" if np.array_equal(got, ref) else "DIFFERENT from"))
     print("N=%d strip rows %d: %.1f us/step; kernels (us, HIP events): %s" % (N, r1 - r0, dt / K * 1e6, {k: round(float(np.mean(v)) * 1e3, 1) for k, v in agg.items()}))
     ctx.close()

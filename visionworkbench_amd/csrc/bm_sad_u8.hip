@@ -102,11 +102,15 @@ __device__ __forceinline__ void key_sub(u32& key, u32 a, u32 b) {
                  : "+v"(key) : "v"(a), "v"(b));
 }
 
-template <int KX, int KY, int TY>
+// WV: wavefronts side by side (0 = 4 for kernels up to 8 columns, 2 for wider ones).  Round 6: WV = 2 with two wave groups is the
+// 512-column tile for small grids — a row strip of an 8-GPU run is one tile per CU either way, and what a CU then pays is its tile's
+// halo: 22 input rows for 16 output rows on 512 columns instead of 14 for 8 on 1024 (tools/sad_timeline.py: staging 9.0 -> 7.x us,
+// the four byte phases 53 -> 4x us per tile).
+template <int KX, int KY, int TY, int WV = 0>
 struct Cfg {
   static constexpr int NW = (KX + 3) / 4;          // qsads per row
   static constexpr int EW = NW <= 2 ? 2 : 4;       // dwords per LDS entry
-  static constexpr int WAVES = NW <= 2 ? 4 : 2;    // waves side by side
+  static constexpr int WAVES = WV ? WV : (NW <= 2 ? 4 : 2);    // waves side by side
   static constexpr int THREADS = WAVES * 64;
   static constexpr int TWB = WAVES * 256;          // output columns per workgroup
   static constexpr int NR = TY + KY - 1;           // input rows per tile
@@ -132,14 +136,17 @@ __device__ __forceinline__ void divmod_small(int idx, int d, float inv, int& quo
 //        counter (the arbiter favours the older wave, so a fixed split would leave one group waiting), and the partial
 //        keys are merged through LDS at the end of the tile — a key minimum is order independent.  (The validity sweep
 //        is not split: group 0 walks its items alone, group 1 only helps to build the word groups.)
-template <int KX, int KY, int TY, bool SPLIT>
-__global__ void __launch_bounds__((SPLIT ? 2 : 1) * (KX <= 8 ? 256 : 128), (SPLIT ? 1 : (TY <= 8 && KX <= 8 ? 3 : 2)))
+// GR = number of wave groups on the tile (1, 2, 4); SPLIT = GR > 1.  GR = 4 (round 6) exists for the 512-column tile: two wave columns x
+// four groups = the same eight wavefronts per CU as the two-group 1024-column tile.
+template <int KX, int KY, int TY, int GR, int WV = 0>
+__global__ void __launch_bounds__((GR * (Cfg<KX, KY, TY, WV>::THREADS)), (GR > 1 ? 1 : (TY <= 8 && KX <= 8 ? 3 : 2)))
 bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
                  const float* __restrict__ R, ptrdiff_t rs, int rcw, int rch,
                  int sx, int sy, int ne, int32_t* __restrict__ out, ptrdiff_t os, int ow, int oh,
                  int* __restrict__ flag_set, int* __restrict__ flag_clear,
                  int gxt, int ntiles) {
-  typedef Cfg<KX, KY, TY> C;
+  typedef Cfg<KX, KY, TY, WV> C;
+  constexpr bool SPLIT = GR > 1;
   constexpr int NW = C::NW, EW = C::EW, NR = C::NR;
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   u32* ent = lds;                                   // [NR][ne][EW]   word groups of the current byte phase
@@ -148,7 +155,7 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   u32* item_ctr = base + (size_t)NR * bpitch;       // SPLIT: one work item counter per wave pair
 
   constexpr int PT = C::THREADS;                    // threads that map to pixels
-  constexpr int NT = SPLIT ? 2 * PT : PT;           // threads of the workgroup
+  constexpr int NT = GR * PT;                       // threads of the workgroup
   const int tid = threadIdx.x;
   const int grp = SPLIT ? __builtin_amdgcn_readfirstlane(tid / PT) : 0;    // wave-uniform
   const int ltid = SPLIT ? tid % PT : tid;
@@ -405,33 +412,44 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   if (bad_acc != 0u) atomicOr(flag_set, 1);
   // ---- SPLIT: merge the two wave groups.  Group 0 finishes rows [0,TY/2), group 1 rows [TY/2,TY): each hands the
   // other its partial keys of the other's rows (and its equality bits) through the entry array, free by now.
-  auto row_mine = [&](int y) __attribute__((always_inline)) -> bool { return !SPLIT || ((y >= TY / 2) == (grp == 1)); };
+  // Group g finishes rows [g TY / GR, (g + 1) TY / GR): round d hands group d the partial keys of ITS rows from every other group (and
+  // everybody's equality bits) through the entry array, free by now.
+  constexpr int RG = TY / GR;                       // rows a group finishes
+  static_assert(TY % GR == 0, "rows per group");
+  auto row_mine = [&](int y) __attribute__((always_inline)) -> bool { return !SPLIT || (y / RG == grp); };
   if (SPLIT) {
-    u32* xk = ent;                                  // [TY/2][4][PT] keys, then [PT] equality words
-    u32* xe = ent + (TY / 2) * 4 * PT;
+    u32* xk = ent;                                  // [GR - 1][RG][4][PT] keys, then [GR][PT] equality words
+    u32* xe = ent + (size_t)(GR - 1) * RG * 4 * PT;
+    u32 eq_all = eq_rows;
 #pragma unroll
-    for (int round = 0; round < 2; ++round) {       // round 0: group 1 -> group 0 (upper rows), round 1: the reverse
-      const int src = 1 - round, ybase = round * (TY / 2);
+    for (int d = 0; d < GR; ++d) {                  // round d: everybody -> group d
       __syncthreads();                              // steps done / previous round read
-      if (grp == src) {
+      if (grp != d) {
+        const int slot = grp < d ? grp : grp - 1;
 #pragma unroll
-        for (int y = 0; y < TY / 2; ++y)
+        for (int y = 0; y < RG; ++y)
 #pragma unroll
-          for (int s2 = 0; s2 < 4; ++s2) xk[(y * 4 + s2) * PT + ltid] = K[ybase + y][s2];
-        xe[ltid] = eq_rows;
+          for (int s2 = 0; s2 < 4; ++s2) xk[((slot * RG + y) * 4 + s2) * PT + ltid] = K[d * RG + y][s2];
       }
+      if (d == 0) xe[grp * PT + ltid] = eq_rows;
       __syncthreads();
-      if (grp != src) {
+      if (grp == d) {
 #pragma unroll
-        for (int y = 0; y < TY / 2; ++y)
+        for (int slot = 0; slot < GR - 1; ++slot)
 #pragma unroll
-          for (int s2 = 0; s2 < 4; ++s2) {
-            const u32 o = xk[(y * 4 + s2) * PT + ltid];
-            K[ybase + y][s2] = o < K[ybase + y][s2] ? o : K[ybase + y][s2];
-          }
-        eq_rows &= xe[ltid];                        // round 1 hands the AND of both back, so both groups agree
+          for (int y = 0; y < RG; ++y)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+              const u32 o = xk[((slot * RG + y) * 4 + s2) * PT + ltid];
+              K[d * RG + y][s2] = o < K[d * RG + y][s2] ? o : K[d * RG + y][s2];
+            }
+      }
+      if (d == 0) {
+#pragma unroll
+        for (int g2 = 0; g2 < GR; ++g2) eq_all &= xe[g2 * PT + ltid];      // (xe lies behind the key slots: not overwritten by later rounds)
       }
     }
+    eq_rows = eq_all;                               // every group agrees
   }
   // ---- validity: only rows in which some pixel's probed costs were all equal can hold an invalid pixel -----------
   u32 cand = eq_checks < NPROBE ? (1u << TY) - 1u : eq_rows;   // small search range: nothing is known -> every row
@@ -521,16 +539,17 @@ typedef void (*KernelFn)(const float*, ptrdiff_t, int, int, const float*, ptrdif
 struct Launch {
   int kx, ky, ty;
   int threads, twb, nr, ew, nw;
+  int split_groups;          // wave groups of split_fn
   KernelFn fn;
   KernelFn split_fn;         // the two-wave-group matcher for small grids (nullptr: not instantiated for this size)
 };
 
-template <int KX, int KY, int TY, bool WITH_SPLIT = false>
+template <int KX, int KY, int TY, bool WITH_SPLIT = false, int WV = 0>
 constexpr Launch make_launch() {
-  typedef Cfg<KX, KY, TY> C;
-  return Launch{KX, KY, TY, C::THREADS, C::TWB, C::NR, C::EW, C::NW,
-                bm_sad_u8_kernel<KX, KY, TY, false>,
-                WITH_SPLIT ? bm_sad_u8_kernel<KX, KY, TY, WITH_SPLIT> : nullptr};
+  typedef Cfg<KX, KY, TY, WV> C;
+  return Launch{KX, KY, TY, C::THREADS, C::TWB, C::NR, C::EW, C::NW, WV ? 4 : 2,
+                WV ? nullptr : bm_sad_u8_kernel<KX, KY, TY, 1, WV>,              // (the narrow tile exists as the four-group matcher only)
+                WITH_SPLIT ? bm_sad_u8_kernel<KX, KY, TY, (WV ? 4 : 2), WV> : nullptr};
 }
 
 // Instantiated kernel sizes.  Others fall back to the generic path.
@@ -540,7 +559,7 @@ constexpr Launch make_launch() {
 // small images / multi-GPU strips use 8-row tiles when 16-row tiles would leave fewer than 2 workgroups per CU
 // (tools/time_strips.py: 1/4 strip 137 -> 128 us, 1/8 strip 128 -> 84 us; 4-row tiles never win — 10/4 halo rows).
 const Launch kLaunch[] = {
-    make_launch<3, 3, 16>(), make_launch<5, 5, 16>(), make_launch<7, 7, 16, true>(), make_launch<7, 7, 8, true>(),
+    make_launch<3, 3, 16>(), make_launch<5, 5, 16>(), make_launch<7, 7, 16, true>(), make_launch<7, 7, 8, true>(), make_launch<7, 7, 16, true, 2>(),
     make_launch<7, 5, 16>(), make_launch<9, 9, 12>(), make_launch<11, 11, 8>(),
 };
 
@@ -558,22 +577,31 @@ const Launch* find_launch(int kx, int ky) {
 //                        per SIMD reaches ~2/3 of the issue rate);  two groups: rows * 0.55 * n (8 waves on one tile)
 //   rounds   sequential staging / output phases: ceil(n / resident) for one group, n for two; ~4.5 row-units each
 // 4096^2: 16-row tiles, one group (4 per CU).  1/4 strip: 16-row tiles, two groups (exactly one per CU; 8-row tiles would
-// put a third tile on a few CUs).  1/8 strip: 8-row tiles, two groups.
+// put a third tile on a few CUs).  1/8 strip: 512-column tiles of 16 rows, four groups (round 6; 8-row tiles with two groups before).
 const Launch* pick_launch(int kx, int ky, int ow, int oh, int num_cu, int groups, bool* split) {
   const Launch* best = nullptr;
   double best_cost = 0.0;
   *split = false;
+  if (groups == 3) {                                 // sizes without the narrow flavour keep the launcher's choice
+    bool has = false;
+    for (const Launch& l : kLaunch) has |= l.kx == kx && l.ky == ky && l.split_fn && !l.fn;
+    if (!has) groups = 0;
+  }
   for (const Launch& l : kLaunch) {
     if (l.kx != kx || l.ky != ky) continue;
     const long long wgs = (long long)((ow + l.twb - 1) / l.twb) * ((oh + l.ty - 1) / l.ty);
     const double n = (double)((wgs + num_cu - 1) / num_cu);
     const int resident = (l.ty <= 8 && l.kx <= 8) ? 3 : 2;
+    const bool narrow = l.twb * 2 <= 4 * 256 && l.split_fn && !l.fn;         // the 512-column two-group tile
+    const double wfrac = narrow ? 0.5 : 1.0;
     for (int sp = 0; sp < 2; ++sp) {
       if (sp && !l.split_fn) continue;
-      if (groups && l.split_fn && (groups == 2) != (sp == 1)) continue;       // VWGPU_OPT_SAD_GROUPS pins the flavour (same results)
-      const double steps = sp ? l.nr * 0.55 * n : (n < 2.0 ? l.nr * 0.74 : l.nr * 0.5 * n);
+      if (!sp && !l.fn) continue;
+      if (groups == 3 && !narrow) continue;                                    // VWGPU_OPT_SAD_GROUPS pins the flavour (same results)
+      if (groups && groups != 3 && (narrow || (l.split_fn && (groups == 2) != (sp == 1)))) continue;
+      const double steps = (sp ? l.nr * 0.55 * n : (n < 2.0 ? l.nr * 0.74 : l.nr * 0.5 * n)) * wfrac;
       const double rounds = sp ? n : (double)(((long long)n + resident - 1) / resident);
-      const double cost = steps + 4.5 * rounds;
+      const double cost = steps + (narrow ? 5.7 : 4.5) * rounds;               // (four groups: four merge rounds; tools/time_strip_step.py: 59.7 vs 61.7 us for a 1/8 strip)
       if (!best || cost < best_cost) { best = &l; best_cost = cost; *split = sp != 0; }
     }
   }
@@ -630,7 +658,7 @@ int vwgpu_launch_bm_sad_u8(vwgpu_ctx* ctx,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   {
     vwgpu_prof_scope ps(ctx, "bm_sad_u8");
-    hipLaunchKernelGGL(main_fn, dim3(grid1), dim3(split ? 2 * l->threads : l->threads), shmem, ctx->stream,
+    hipLaunchKernelGGL(main_fn, dim3(grid1), dim3(split ? l->split_groups * l->threads : l->threads), shmem, ctx->stream,
                        left, ls, lw, lh, right, rs, rcw, rch, sx, sy, ne, out, os, ow, oh,
                        flag_set, flag_clear, gx, gx * gy);
   }

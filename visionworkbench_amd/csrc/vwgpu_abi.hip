@@ -239,7 +239,7 @@ int vwgpu_set_option(vwgpu_ctx* ctx, int option, int value) {
   if (!ctx) return VWGPU_ERR_ARGUMENT;
   if (option == VWGPU_OPT_DEFER_EXACTNESS) { ctx->defer_exact = value != 0; return VWGPU_OK; }
   // the options below select between variants that return identical results; out-of-range values are refused
-  if (option == VWGPU_OPT_SAD_GROUPS && value >= 0 && value <= 2) { ctx->sad_groups = value; return VWGPU_OK; }
+  if (option == VWGPU_OPT_SAD_GROUPS && value >= 0 && value <= 3) { ctx->sad_groups = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_EXACT_SCRATCH_MB && value >= 16 && value <= 65536) { ctx->exact_scratch_mb = value; return VWGPU_OK; }
   if (option == VWGPU_OPT_TRACE && value >= 0 && value <= 7) { ctx->trace = value; ctx->cert_px[0] = ctx->cert_px[1] = ctx->cert_px[2] = 0; return VWGPU_OK; }
   if (option == VWGPU_OPT_CERTIFY && (value == 0 || value == 1)) { ctx->certify = value; return VWGPU_OK; }
