@@ -34,7 +34,9 @@ extern "C" {
  *     (VWGPU_OPT_EXACT_LDS) and 10 (VWGPU_OPT_CORR_MFMA) are gone with the two slower kernel variants they selected.
  * 3 (round 5): vwgpu_pyramid_correlate_batch[_dev] (tile groups); vwgpu_last_path() may answer VWGPU_PATH_CERTIFIED (single-level calls on
  *     float rasters proven equal to the reference's summation order); options VWGPU_OPT_CERT_F32, _CERT_F64_PERMILLE, _ZONE_TILE16.  No struct
- *     of version 2 changed: a version-2 host keeps working against this library, a version-3 host needs it for the batch entry.
+ *     of version 2 changed, but observable behaviour did (VWGPU_PATH_CERTIFIED where a version-2 host saw VWGPU_PATH_EXACT_ORDER), and hosts
+ *     compare versions for EQUALITY: a host built against version 2 refuses this library and is rebuilt against this header.
+ *     Round 6 added option values only (VWGPU_OPT_SGM_PATH_MODE, VWGPU_OPT_SAD_GROUPS = 3): same version.
  * A host checks vwgpu_abi_version() == VWGPU_ABI_VERSION once after loading the library (vw::engine does, vw/Engine.h). */
 #define VWGPU_ABI_VERSION 3
 
@@ -141,6 +143,8 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *   VWGPU_OPT_CERT_F32         1 (default): the certified pass is two tiers in one launch — float32 window sums and compare chain first,
  *       proven against the reference's order AND their own float32 roundings; a 32 x 32 tile with a pixel that tier cannot prove runs again
  *       in float64, and only what float64 cannot prove goes to the exact-order kernels.  0: float64 only (the round-4 schedule).  Same results.
+ *   VWGPU_OPT_ZONE_TILE16      zone matcher tiles for 16 x 16 leaf zones: 0 (default) = 32 x 32 workgroup tiles for every zone, 1 = one-wavefront
+ *       16 x 16 tiles for zones of at most 16 x 16 pixels, 2 = those tiles for every zone (measurements).  Same results.
  *   VWGPU_OPT_CERT_F64_PERMILLE (read only) per mille of the counted pixels that lay in tiles the fp32 tier passed on to float64; -1 = none.
  *   VWGPU_OPT_SGM_SWEEP        SGM path aggregation of full-range one-row searches (<= 256 disparities): 0 = one direction per launch
  *       (default: eight passes over the u16 sums, bandwidth bound), 1 = two concurrent fused raster sweeps of four directions each

@@ -103,6 +103,17 @@ def test_batch_group_sizes_and_host_entry(ctx):
         stereo.pyramid_correlate_batch(left, right, None, None, 0, 0.0, BBox2i.from_corners((-8, -1), (9, 2)), (6, 7), 0, boxes, ctx=ctx)
 
 
+def test_host_entry_stages_per_run_of_tiles(ctx):
+    """Host pointers, tiles far apart (round 6): the sources are staged per run of equal tiles, a run whose union window is much
+    larger than its tiles' own windows goes tile by tile — the results are those of the single-tile entry either way."""
+    left, right = _scene(91, H=900, W=1500)
+    far = [BBox2i(10, 10, 96, 96), BBox2i(1300, 700, 96, 96), BBox2i(20, 780, 96, 96)]                 # one run, scattered: tile by tile
+    near = [BBox2i(600 + 96 * i, 300, 96, 96) for i in range(4)]                                        # one run, adjacent: one window
+    mixed = far[:1] + near + [BBox2i(1200, 40, 120, 80), BBox2i(1320, 40, 120, 80)] + far[1:]          # three runs
+    for boxes in (far, near, mixed):
+        _check(ctx, left, right, None, None, 0, 0.0, (-8, -1, 9, 2), (7, 7), 0, boxes, device=False, max_pyramid_levels=2)
+
+
 def test_batch_at_benchmark_size(ctx, oracle):
     """Four 1024^2 tiles of the bench pair (interior, borders, corner) with the `correlate` defaults in one group: identical to the oracle."""
     import concurrent.futures

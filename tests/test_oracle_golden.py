@@ -162,17 +162,120 @@ def test_synthetic_pair_truth(oracle):
 # ---- image filters on the path (pyramid, prefilters) ------------------------------------------------------------
 
 def test_gaussian_kernel_golden(oracle):
-    """src/vw/Image/tests/TestFilter.cxx:45-74 (GaussianKernel)."""
+    """src/vw/Image/tests/TestFilter.cxx:45-74 (GaussianKernel), each tap at the tolerance the reference's own EXPECT_NEAR asks."""
     k = oracle.generate_gaussian_kernel(1.0, 5, np.float64)
     assert len(k) == 5
-    np.testing.assert_allclose(k, [0.06135958087, 0.2447702197, 0.3877403988, 0.2447702197, 0.06135958087], atol=1e-7)
+    for got, want, tol in zip(k, [0.06135958087, 0.2447702197, 0.3877403988, 0.2447702197, 0.06135958087], [1e-8, 1e-7, 1e-7, 1e-7, 1e-8]):
+        assert abs(got - want) <= tol
     k = oracle.generate_gaussian_kernel(1.0, 4, np.float64)
-    np.testing.assert_allclose(k, [0.1423836140, 0.3576163860, 0.3576163860, 0.1423836140], atol=1e-7)
+    assert len(k) == 4
+    for got, want in zip(k, [0.1423836140, 0.3576163860, 0.3576163860, 0.1423836140]):
+        assert abs(got - want) <= 1e-7
     k = oracle.generate_gaussian_kernel(1.5, 0, np.float64)
     assert len(k) == 9
-    np.testing.assert_allclose(k, [0.008488347404, 0.03807782601, 0.1111650246, 0.2113567063, 0.2618241916,
-                                   0.2113567063, 0.1111650246, 0.03807782601, 0.008488347404], atol=1e-7)
+    for got, want, tol in zip(k, [0.008488347404, 0.03807782601, 0.1111650246, 0.2113567063, 0.2618241916, 0.2113567063, 0.1111650246,
+                                  0.03807782601, 0.008488347404], [1e-9, 1e-8, 1e-7, 1e-7, 1e-7, 1e-7, 1e-7, 1e-8, 1e-9]):
+        assert abs(got - want) <= tol
     assert len(oracle.generate_gaussian_kernel(0, 0, np.float64)) == 0
+
+
+# ---- independent evidence for rows the reference's tests do not pin (VERDICT r5, "unpinned oracle rows") ------------------------------
+# A second formulation written from the mathematics, not from the reference's text: scipy box filters in float64 (exact on small integer
+# imagery), argmin / argmax with first-wins ties, exact rational comparison for NCC.  The oracle must agree with it.
+
+def _window_sums(img, ky, kx):
+    """Sum over every full ky x kx window, float64 (exact for integer data of this size)."""
+    from scipy.ndimage import uniform_filter
+    s = uniform_filter(img.astype(np.float64), size=(ky, kx), mode="constant") * (ky * kx)
+    return np.rint(s[ky // 2: img.shape[0] - ky // 2, kx // 2: img.shape[1] - kx // 2])
+
+
+def _independent_winners(cost, left, right, kernel, search):
+    kx, ky = kernel
+    sx, sy = search
+    h, w = left.shape
+    l = left.astype(np.int64)
+    vols = []
+    for dy in range(sy):
+        for dx in range(sx):
+            r = right[dy:dy + h, dx:dx + w].astype(np.int64)
+            e = np.abs(l - r) if cost == 0 else (l - r) ** 2 if cost == 1 else l * r
+            vols.append(_window_sums(e, ky, kx))
+    vol = np.stack(vols)                                   # [disparity index (dy outer, dx inner), y, x]
+    return vol
+
+
+@pytest.mark.parametrize("cost", [0, 1])
+@pytest.mark.parametrize("kernel,search", [((5, 5), (9, 3)), ((7, 3), (16, 1)), ((3, 9), (5, 4))])
+def test_sad_ssd_winners_against_an_independent_formulation(oracle, cost, kernel, search):
+    """AbsoluteCost / SquaredCost through calc_disparity: the winner is the FIRST minimum in (dy outer, dx inner) order, a pixel is invalid
+    exactly when all its costs are equal (Correlation.cc:91-133 reduces to that for costs that are numbers)."""
+    rng = np.random.default_rng(100 * cost + kernel[0] + search[0])
+    h, w = 40, 52
+    left = rng.integers(0, 256, (h, w)).astype(np.float32)
+    right = rng.integers(0, 256, (h + search[1] - 1, w + search[0] - 1)).astype(np.float32)
+    dy0, dx0 = min(2, search[1] - 1), min(3, search[0] - 1)
+    right[dy0:dy0 + h, dx0:dx0 + w][8:, 10:] = left[8:, 10:]       # a true shift over most of the image
+    left[:6, :20] = 17.0; right[:12, :40] = 17.0           # a flat corner: every cost equal -> invalid
+    vol = _independent_winners(cost, left, right, kernel, search)
+    idx = vol.argmin(axis=0)                               # first minimum
+    want_dx, want_dy = idx % search[0], idx // search[0]
+    want_valid = ~(vol == vol[0]).all(axis=0)
+    got = oracle.calc_disparity(cost, left, right, kernel, search)
+    assert np.array_equal(got[..., 0], want_dx) and np.array_equal(got[..., 1], want_dy)
+    assert np.array_equal(got[..., 2] != 0, want_valid)
+    assert (~want_valid).sum() > 0
+
+
+@pytest.mark.parametrize("kernel,search", [((5, 5), (9, 3)), ((11, 11), (17, 1))])
+def test_ncc_winners_against_exact_rational_arithmetic(oracle, kernel, search):
+    """NCCCost (CostFunctions.h:207-236): the winner maximises S_lr / sqrt(S_ll S_rr).  With integer imagery the three sums are exact integers,
+    so two candidates compare exactly as S_lr_a^2 S_rr_b vs S_lr_b^2 S_rr_a in Python integers; wherever the exact best leads the exact
+    runner-up by more than a relative 1e-12 the oracle's float64 pipeline (1 / S, *, sqrt, *) must name the same first maximum."""
+    rng = np.random.default_rng(7 + kernel[0])
+    h, w = 36, 44
+    kx, ky = kernel
+    sx, sy = search
+    left = rng.integers(1, 256, (h, w)).astype(np.float32)
+    right = rng.integers(1, 256, (h + sy - 1, w + sx - 1)).astype(np.float32)
+    dy0 = 1 if sy > 1 else 0
+    right[dy0:dy0 + h, 4:4 + w][6:, 5:] = left[6:, 5:]
+    slr = _independent_winners(2, left, right, kernel, search)
+    srr_full = _window_sums(right.astype(np.int64) ** 2, ky, kx)
+    oh, ow = slr.shape[1:]
+    got = oracle.calc_disparity(2, left, right, kernel, search)
+    checked = 0
+    for y in range(oh):
+        for x in range(ow):
+            best, bi, second = None, -1, None
+            for i in range(sx * sy):
+                dy, dx = divmod(i, sx)
+                a, b = int(slr[i, y, x]), int(srr_full[y + dy, x + dx])          # value = a / sqrt(b) (S_ll is common to all candidates), a > 0
+                if best is None or a * a * best[1] > best[0] * best[0] * b:       # strictly greater: first maximum wins
+                    if best is not None: second = best if second is None or best[0] ** 2 * second[1] > second[0] ** 2 * best[1] else second
+                    best, bi = (a, b), i
+                elif second is None or a * a * second[1] > second[0] ** 2 * b:
+                    second = (a, b)
+            va, vb = best[0] / np.sqrt(best[1]), second[0] / np.sqrt(second[1])
+            if va - vb > 1e-12 * va:
+                checked += 1
+                assert (int(got[y, x, 0]), int(got[y, x, 1])) == (bi % sx, bi // sx), (y, x)
+                assert got[y, x, 2] != 0
+    assert checked > 0.99 * oh * ow
+
+
+def test_pyramid_level_against_scipy(oracle):
+    """subsample(separable_convolution_filter(img, k, k), 2) (CorrelationView.cc:38-63): scipy's correlate1d in float64 with the nearest-pixel
+    edge, every second pixel — the oracle's float accumulation agrees to float32 rounding."""
+    from scipy.ndimage import correlate1d
+    rng = np.random.default_rng(5)
+    img = (rng.random((37, 50)) * 200).astype(np.float32)
+    k = np.asarray(oracle.pyramid_smoothing_kernel(), np.float64)
+    assert len(k) == 5 and abs(k.sum() - 1.0) < 1e-6 and np.allclose(k, k[::-1])
+    ref = correlate1d(correlate1d(img.astype(np.float64), k, axis=1, mode="nearest"), k, axis=0, mode="nearest")[::2, ::2]
+    lvl = oracle.separable_convolution(img, k.astype(np.float32), k.astype(np.float32), subsample=2)
+    assert lvl.shape == ref.shape == (19, 25)
+    np.testing.assert_allclose(lvl, ref, rtol=2e-6, atol=1e-4)
 
 
 def _src22():

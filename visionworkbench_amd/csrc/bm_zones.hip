@@ -835,7 +835,7 @@ bm_zones_kernel(ZLaunch G, const vwgpu_zone_task* __restrict__ zones, const ZIte
     if (threadIdx.x == 0) {
       if (any) {
         G.C.zflag[it.zone] = 1; if (G.C.any) G.C.any[z.img] = 1;
-        if (G.C.tflag) G.C.tflag[G.C.zc[it.zone].trow + (it.txy >> 16)] = 1;
+        if (G.C.tflag) G.C.tflag[G.C.zc[it.zone].trow + (int)((unsigned)it.txy >> 16)] = 1;      // (ty in the upper half: up to 65535 tile rows)
       }
       if (G.C.stats) {
         atomicAdd(&G.C.stats[any ? 1 : 0], (unsigned long long)(geom.tw * geom.th));

@@ -1993,15 +1993,22 @@ int vwgpu_pyramid_correlate_batch_dev(vwgpu_ctx* ctx, const float* d_left, int l
   VWGPU_HIP(ctx, hipSetDevice(ctx->device));
   // groups: runs of consecutive tiles of equal size, at most VWGPU_MAX_GROUP each; what a group cannot take (SGM / MGM, lr_disp_diff, blob
   // filter, time budget, a forced kernel family) and lone tiles go through the single-tile entry — same results either way
-  int t0 = 0;
+  int t0 = 0, cap = VWGPU_MAX_GROUP;                   // cap: halved when a group's arena does not fit the device
   while (t0 < n_tiles) {
     int t1 = t0 + 1;
-    while (t1 < n_tiles && t1 - t0 < VWGPU_MAX_GROUP && bw[t1] == bw[t0] && bh[t1] == bh[t0]) ++t1;
+    while (t1 < n_tiles && t1 - t0 < cap && bw[t1] == bw[t0] && bh[t1] == bh[t0]) ++t1;
     const int m = t1 - t0;
-    if (vwgpu_pyramid_group_eligible(ctx, P, m, bw + t0, bh + t0)) {
+    if (m > 1 && vwgpu_pyramid_group_eligible(ctx, P, m, bw + t0, bh + t0)) {
       ptrdiff_t oss[VWGPU_MAX_GROUP];
       for (int t = 0; t < m; ++t) oss[t] = (os && os[t0 + t]) ? os[t0 + t] : bw[t0 + t];
       int rc = vwgpu_pyramid_group_impl(ctx, d_left, lw, lh, ls, d_right, rw, rh, rs, d_lmask, lms, d_rmask, rms, P, m, bx + t0, by + t0, bw[t0], bh[t0], d_outs + t0, oss);
+      if (rc == VWGPU_ERR_NOMEM) {
+        // n slices + the group's tables did not fit where the single-tile entry's arena would: the batch entry must never be less robust
+        // than a loop over the single-tile entry.  Nothing of the group has been written (the reservation comes first): smaller groups.
+        ctx->err.clear();
+        cap = m / 2;
+        continue;
+      }
       if (rc) return rc;
     } else {
       for (int t = t0; t < t1; ++t) {
@@ -2018,33 +2025,11 @@ int vwgpu_pyramid_correlate_batch_dev(vwgpu_ctx* ctx, const float* d_left, int l
   return VWGPU_OK;
 }
 
-int vwgpu_pyramid_correlate_batch(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t ls,
-                                  const float* right, int rw, int rh, ptrdiff_t rs,
-                                  const uint8_t* lmask, ptrdiff_t lms, const uint8_t* rmask, ptrdiff_t rms,
-                                  const vwgpu_pyramid_params* P, int n_tiles, const int* bx, const int* by, const int* bw, const int* bh,
-                                  float* const* outs, const ptrdiff_t* os) {
-  if (!ctx) return VWGPU_ERR_ARGUMENT;
-  ctx->err.clear();
-  if (n_tiles < 0 || (n_tiles > 0 && (!bx || !by || !bw || !bh || !outs))) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate_batch: null tile table");
-  if (n_tiles == 0) return VWGPU_OK;
-  // an lr_disp_diff image is staged per tile by the single-tile entry (concurrent tiles must not write back each other's pixels)
-  if (P && P->lr_disp_diff) {
-    for (int t = 0; t < n_tiles; ++t) {
-      int rc = vwgpu_pyramid_correlate(ctx, left, lw, lh, ls, right, rw, rh, rs, lmask, lms, rmask, rms, P, bx[t], by[t], bw[t], bh[t], outs[t], os ? os[t] : 0);
-      if (rc) return rc;
-    }
-    return VWGPU_OK;
-  }
-  for (int t = 0; t < n_tiles; ++t) {
-    int rc = check_pyramid_args(ctx, left, lw, lh, right, rw, rh, P, bw[t], bh[t], outs[t]);
-    if (rc) return rc;
-  }
-  if (ls == 0) ls = lw;
-  if (rs == 0) rs = rw;
-  if (lms == 0) lms = lw;
-  if (rms == 0) rms = rw;
-  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
-  // the window of the sources the tiles can touch (see vwgpu_pyramid_correlate): the union over the tiles, one origin for both images and masks
+// One run of tiles of the host batch entry: ONE staged window (the union of what the run's tiles can touch), one device batch call.
+static int pyramid_batch_host_run(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t ls, const float* right, int rw, int rh, ptrdiff_t rs,
+                                  const uint8_t* lmask, ptrdiff_t lms, const uint8_t* rmask, ptrdiff_t rms, const vwgpu_pyramid_params* P, int n_tiles,
+                                  const int* bx, const int* by, const int* bw, const int* bh, float* const* outs, const ptrdiff_t* os) {
+  // the window of the sources the tiles can touch (see vwgpu_pyramid_correlate): the union over the run's tiles, one origin for both images and masks
   const int upb = 1 << std::max(0, std::min(P->max_pyramid_levels, 12));
   const int sdx = P->search_max_x - P->search_min_x, sdy = P->search_max_y - P->search_min_y;
   const long long padx = (long long)(P->kernel_x / 2) * upb + 2LL * std::max(sdx, 0) + 8;
@@ -2091,6 +2076,64 @@ int vwgpu_pyramid_correlate_batch(vwgpu_ctx* ctx, const float* left, int lw, int
     VWGPU_HIP(ctx, hipMemcpy2DAsync(outs[t], (size_t)o * 12, d_outs[t], (size_t)bw[t] * 12, (size_t)bw[t] * 12, bh[t], hipMemcpyDeviceToHost, ctx->stream));
   }
   VWGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VWGPU_OK;
+}
+
+int vwgpu_pyramid_correlate_batch(vwgpu_ctx* ctx, const float* left, int lw, int lh, ptrdiff_t ls,
+                                  const float* right, int rw, int rh, ptrdiff_t rs,
+                                  const uint8_t* lmask, ptrdiff_t lms, const uint8_t* rmask, ptrdiff_t rms,
+                                  const vwgpu_pyramid_params* P, int n_tiles, const int* bx, const int* by, const int* bw, const int* bh,
+                                  float* const* outs, const ptrdiff_t* os) {
+  if (!ctx) return VWGPU_ERR_ARGUMENT;
+  ctx->err.clear();
+  if (n_tiles < 0 || (n_tiles > 0 && (!bx || !by || !bw || !bh || !outs))) return vwgpu_fail(ctx, VWGPU_ERR_ARGUMENT, "pyramid_correlate_batch: null tile table");
+  if (n_tiles == 0) return VWGPU_OK;
+  // an lr_disp_diff image is staged per tile by the single-tile entry (concurrent tiles must not write back each other's pixels)
+  if (P && P->lr_disp_diff) {
+    for (int t = 0; t < n_tiles; ++t) {
+      int rc = vwgpu_pyramid_correlate(ctx, left, lw, lh, ls, right, rw, rh, rs, lmask, lms, rmask, rms, P, bx[t], by[t], bw[t], bh[t], outs[t], os ? os[t] : 0);
+      if (rc) return rc;
+    }
+    return VWGPU_OK;
+  }
+  for (int t = 0; t < n_tiles; ++t) {
+    int rc = check_pyramid_args(ctx, left, lw, lh, right, rw, rh, P, bw[t], bh[t], outs[t]);
+    if (rc) return rc;
+  }
+  if (ls == 0) ls = lw;
+  if (rs == 0) rs = rw;
+  if (lms == 0) lms = lw;
+  if (rms == 0) rms = rw;
+  VWGPU_HIP(ctx, hipSetDevice(ctx->device));
+  // Staged per RUN of tiles (consecutive tiles of equal size, at most VWGPU_MAX_GROUP: what one device group takes), not per call: tiles
+  // scattered over a large pair would otherwise upload nearly the whole pair.  A run whose union window is more than three
+  // times the windows of its tiles taken one by one (tiles far apart inside the run) goes through the single-tile entry.
+  const int upb_ = 1 << std::max(0, std::min(P->max_pyramid_levels, 12));
+  const long long padx_ = (long long)(P->kernel_x / 2) * upb_ + 2LL * std::max(P->search_max_x - P->search_min_x, 0) + 8 + std::max(P->search_max_x, 0) - std::min(P->search_min_x, 0);
+  const long long pady_ = (long long)(P->kernel_y / 2) * upb_ + 2LL * std::max(P->search_max_y - P->search_min_y, 0) + 8 + std::max(P->search_max_y, 0) - std::min(P->search_min_y, 0);
+  int t0 = 0;
+  while (t0 < n_tiles) {
+    int t1 = t0 + 1;
+    while (t1 < n_tiles && t1 - t0 < VWGPU_MAX_GROUP && bw[t1] == bw[t0] && bh[t1] == bh[t0]) ++t1;
+    long long ux0 = LLONG_MAX, uy0 = LLONG_MAX, ux1 = LLONG_MIN, uy1 = LLONG_MIN;
+    double each = 0.0;
+    for (int t = t0; t < t1; ++t) {
+      ux0 = std::min<long long>(ux0, bx[t]); uy0 = std::min<long long>(uy0, by[t]);
+      ux1 = std::max<long long>(ux1, (long long)bx[t] + bw[t]); uy1 = std::max<long long>(uy1, (long long)by[t] + bh[t]);
+      each += (double)(bw[t] + 2 * padx_) * (double)(bh[t] + 2 * pady_);
+    }
+    const double uni = (double)(ux1 - ux0 + 2 * padx_) * (double)(uy1 - uy0 + 2 * pady_);
+    if (t1 - t0 > 1 && uni <= 3.0 * each) {
+      int rc = pyramid_batch_host_run(ctx, left, lw, lh, ls, right, rw, rh, rs, lmask, lms, rmask, rms, P, t1 - t0, bx + t0, by + t0, bw + t0, bh + t0, outs + t0, os ? os + t0 : nullptr);
+      if (rc) return rc;
+    } else {
+      for (int t = t0; t < t1; ++t) {
+        int rc = vwgpu_pyramid_correlate(ctx, left, lw, lh, ls, right, rw, rh, rs, lmask, lms, rmask, rms, P, bx[t], by[t], bw[t], bh[t], outs[t], os ? os[t] : 0);
+        if (rc) return rc;
+      }
+    }
+    t0 = t1;
+  }
   return VWGPU_OK;
 }
 
