@@ -392,6 +392,21 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right, with
                 "pcie_GBs_pinned": round(moved / (res_e2e["pinned"]["ms_per_call"] * 1e-3) / 1e9, 1),
                 "note": "never `value`: the device-resident column is the headline (inputs in HBM when the clock starts)"})
     del pl_, pr_, po_
+    # (2c) the headline with DEFAULT options: no VWGPU_OPT_DEFER_EXACTNESS — every call waits for the input-class flags of its launch (one host
+    # round trip) before it returns; inputs device resident
+    dctx = vwa.Context(lt.device.index)
+    dcall = lambda: stereo.calc_disparity(0, lt, rt, vwa.bounding_box(left), (129, 1), (7, 7), ctx=dctx)
+    for _ in range(5): dcall()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20): dcall()
+    torch.cuda.synchronize()
+    dms = (time.perf_counter() - t0) / 20 * 1e3
+    dpath = dctx.last_path()
+    dctx.close()
+    out.append({"name": "headline with DEFAULT options (no VWGPU_OPT_DEFER_EXACTNESS): device-resident calc_disparity, 4096^2, 7x7 SAD, search 129x1",
+                "wall_ms_per_call": round(dms, 4), "Mpix_per_s": round((W - 6) * (H - 6) / (dms * 1e-3) / 1e6, 1), "path": int(dpath),
+                "note": "matcher + the host round trip for the input-class flags of this launch; the deferred mode of the headline queues calls back to back"})
     # (3) SGM building block of config 4: 2048^2, census 7x7, 129 disparities, 8 paths, LC-blend sub-pixel
     n = 2048
     ls, rs_ = lt[:n, :n].contiguous(), rt[:n, :n + 128].contiguous()
@@ -1074,6 +1089,27 @@ def main():
                                                  ["--workload", "config5", "--no-cpu-baseline"], c5, ckeys, timeout=1500))
             except Exception as e:  # noqa: BLE001
                 res["extra"] = [{"name": "extra points failed", "error": "%s: %s" % (type(e).__name__, str(e)[:300])}]
+            # Every point once more in a dozen short entries: inside `config` (the part of the line the driver's record keeps whole) and as the
+            # LAST key of the line (the part its 2000-character tail keeps).  [Mpix/s, fraction of the HBM roofline, checked against the oracle]
+            pts = {}
+            short = [("search 33x1", "sad_pm16"), ("config 3a: ", "c3a_ncc11"), ("config 3a on 12-bit", "c3a_ncc11_12bit"), ("config 3b", "c3b_parabola"),
+                     ("config 2 on a FLOAT", "c2_float"), ("config 3a on a FLOAT", "c3a_float"), ("END TO END", "c2_end_to_end"), ("DEFAULT options", "c2_default_opts"),
+                     ("SGM 2048^2", "sgm_2048_block"), ("MGM (use_mgm)", "mgm_1024"), ("tile loop, 4096^2 in 16 tiles of 1024^2, SAD", "loop_sad"),
+                     ("tile loop, 4096^2 in 16 tiles of 1024^2, LoG", "loop_log_ncc"), ("configs[3] on one GPU", "config4_full"), ("configs[4] on one GPU", "config5_full")]
+            for e in res["extra"]:
+                key = next((k for pat, k in short if pat in e.get("name", "")), None)
+                if key is None or "error" in e: continue
+                v = e.get("Mpix_per_s", e.get("value"))
+                fr = e.get("roofline_frac", (e.get("roofline") or {}).get("frac"))
+                chk = e.get("tiles_identical_to_oracle", e.get("identical_to_oracle"))
+                if key == "config5_full":
+                    tv = (e.get("config") or {}).get("tiles_vs_oracle") or {}
+                    chk = "%s / %s bm, %s / %s sgm" % (tv.get("bm_identical"), tv.get("bm_checked"), tv.get("sgm_identical"), tv.get("sgm_checked"))
+                    pts["config5_full_sgm"] = [round(((e.get("config") or {}).get("sgm") or {}).get("Mpix_per_s", 0.0), 1), None, None]
+                pts[key] = [None if v is None else round(float(v), 1), None if fr is None else round(float(fr), 4), chk]
+                if key == "c2_end_to_end": pts[key] = [(e.get("pinned") or {}).get("Mpix_per_s"), None, None]
+            res["config"]["points"] = pts
+            res["points"] = pts
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -758,8 +758,11 @@ mgm_front_kernel(SgmGeom g, MgmDirs D, int front, const uint8_t* __restrict__ le
   // separated by s_waitcnt alone (wave_lds_sync) — no workgroup barrier, and a wave may return early.
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), wpw = (int)blockDim.x >> 6;
   // the two predecessors' vectors over the whole search range, BAD_VAL elsewhere (evaluate_path's full_prior_buffer, SGM.cc:1013-1150)
-  uint16_t* fp_a = sm + (size_t)wave * 2 * num_disp;
-  uint16_t* fp_b = fp_a + num_disp;
+  // Round 6: ONE 32-bit cell per disparity — low half = predecessor A's value, high half = predecessor B's — so that the nine reads of an
+  // evaluation serve both predecessors and the minima are packed 16-bit instructions (18 u16 reads and two scalar chains before).
+  unsigned* fp = reinterpret_cast<unsigned*>(sm) + (size_t)wave * num_disp;
+  uint16_t* fp_a = reinterpret_cast<uint16_t*>(fp);              // cell i of A at fp_a[2 i], of B at fp_a[2 i + 1]
+  uint16_t* fp_b = fp_a + 1;
   const int lane = threadIdx.x & 63, q = blockIdx.y, W = g.ocols, H = g.orows;
   int c, r;
   if (!mgm_front_pixel(D, q, front, (int)blockIdx.x * wpw + wave, W, H, c, r)) return;
@@ -790,7 +793,7 @@ mgm_front_kernel(SgmGeom g, MgmDirs D, int front, const uint8_t* __restrict__ le
   const uint16_t* prb = vol + stb;
   const unsigned a0 = lane < na ? pra[lane] : BAD, a1 = lane + 64 < na ? pra[lane + 64] : BAD;
   const unsigned b0 = lane < nb ? prb[lane] : BAD, b1 = lane + 64 < nb ? prb[lane + 64] : BAD;
-  for (int i = lane; i < num_disp; i += 64) { fp_a[i] = (uint16_t)BAD; fp_b[i] = (uint16_t)BAD; }
+  for (int i = lane; i < num_disp; i += 64) fp[i] = BAD | (BAD << 16);
   grad = grad < 0 ? -grad : grad;
   unsigned p2_mod = p2;
   if (grad > 0) p2_mod /= (unsigned)grad;
@@ -804,13 +807,15 @@ mgm_front_kernel(SgmGeom g, MgmDirs D, int front, const uint8_t* __restrict__ le
       divmod_f(i, wp, inv_wp, qy, qx);
       const unsigned v = i < 64 ? v0 : i < 128 ? v1 : (unsigned)prior[i];
       mn = min(mn, v);
-      fp[(bp.y0 + qy - g.min_dy) * g.num_dx + (bp.x0 + qx - g.min_dx)] = (uint16_t)v;
+      fp[2 * ((bp.y0 + qy - g.min_dy) * g.num_dx + (bp.x0 + qx - g.min_dx))] = (uint16_t)v;
     }
     return wave_min_u32(mn);
   };
   const unsigned min_a = scatter(fp_a, ba, wa, na, pra, a0, a1), min_b = scatter(fp_b, bb, wb, nb, prb, b0, b1);
   const unsigned dj_a = (min_a + p2_mod) & 0xffffu, dj_b = (min_b + p2_mod) & 0xffffu;
   const float inv_wd = __builtin_amdgcn_rcpf((float)wd);
+  const unsigned p1c = min(p1, 65535u);                          // (adds16 saturates: a larger penalty is 65535)
+  const us2 p1p1 = as_us2(p1c | (p1c << 16)), dJ2 = as_us2(dj_a | (dj_b << 16)), mp2 = as_us2((min_a & 0xffffu) | (min_b << 16));
   wave_lds_sync();
   for (int i = lane; i < nd; i += 64) {
     int qy, qx;
@@ -820,17 +825,18 @@ mgm_front_kernel(SgmGeom g, MgmDirs D, int front, const uint8_t* __restrict__ le
     const int xl = dx - 1 < g.min_dx ? xo : xo - 1, xm = dx + 1 > g.max_dx ? xo : xo + 1;
     const int yl = (dy - 1 < g.min_dy ? yo : yo - 1) * g.num_dx, ym = (dy + 1 > g.max_dy ? yo : yo + 1) * g.num_dx, yc = yo * g.num_dx;
     const unsigned lc = i < 64 ? c0 : i < 128 ? c1 : (unsigned)cost[st + i];
-    auto eval = [&](const uint16_t* fp, unsigned min_prior, unsigned dJ) __attribute__((always_inline)) {
-      unsigned m = fp[yl + xo];
-      m = min(m, (unsigned)fp[yc + xl]); m = min(m, (unsigned)fp[yc + xm]); m = min(m, (unsigned)fp[ym + xo]);
-      m = min(m, (unsigned)fp[yl + xl]); m = min(m, (unsigned)fp[yl + xm]);
-      m = min(m, (unsigned)fp[ym + xl]); m = min(m, (unsigned)fp[ym + xm]);
-      unsigned res = adds16(m, p1);
-      res = min(res, min((unsigned)fp[yc + xo], dJ));
-      res = adds16(res, lc);
-      return subs16(res, min_prior);
-    };
-    vol[st + i] = (uint16_t)((eval(fp_a, min_a, dj_a) + eval(fp_b, min_b, dj_b)) >> 1);      // "(a + b) / 2" in int (SGMAssist.h:945-946)
+    // both predecessors at once: packed saturating u16 arithmetic = adds16 / subs16 per half
+    us2 m = as_us2(fp[yl + xo]);
+    m = __builtin_elementwise_min(m, as_us2(fp[yc + xl])); m = __builtin_elementwise_min(m, as_us2(fp[yc + xm]));
+    m = __builtin_elementwise_min(m, as_us2(fp[ym + xo])); m = __builtin_elementwise_min(m, as_us2(fp[yl + xl]));
+    m = __builtin_elementwise_min(m, as_us2(fp[yl + xm])); m = __builtin_elementwise_min(m, as_us2(fp[ym + xl]));
+    m = __builtin_elementwise_min(m, as_us2(fp[ym + xm]));
+    us2 res = __builtin_elementwise_add_sat(m, p1p1);
+    res = __builtin_elementwise_min(res, __builtin_elementwise_min(as_us2(fp[yc + xo]), dJ2));
+    res = __builtin_elementwise_add_sat(res, as_us2(lc | (lc << 16)));
+    res = __builtin_elementwise_sub_sat(res, mp2);
+    const unsigned rr = as_u32(res);
+    vol[st + i] = (uint16_t)(((rr & 0xffffu) + (rr >> 16)) >> 1);      // "(a + b) / 2" in int (SGMAssist.h:945-946)
   }
 }
 
