@@ -144,6 +144,23 @@ def test_ties_and_flat_regions(ctx, oracle, sad_variant):
                                   oracle.calc_disparity(cost, left, right, kernel, search))
 
 
+@pytest.mark.parametrize("sx", [2, 4, 8, 13])
+def test_flat_images_with_a_narrow_search(ctx, oracle, sad_variant, sx):
+    """Round-6 campaign (seed 6161): a constant image with a search of 2 .. 8 disparities.  The validity sweep reads the RIGHT base tile after
+    the wave-group merge and the epilogue have borrowed the entry array; on the 512-column four-group tile a narrow search made that array
+    smaller than what they borrow, and the pixels came out valid.  Wide enough for several tiles, a textured stripe for contrast."""
+    rng = np.random.RandomState(17 + sx)
+    left = np.full((70, 1300), 90.0, np.float32)
+    right = np.full((70, 1300 + sx - 1), 90.0, np.float32)
+    left[30:45, 500:900] = rng.randint(0, 256, (15, 400)).astype(np.float32)
+    right[30:45, 500 + sx // 2:900 + sx // 2] = left[30:45, 500:900]
+    want = oracle.calc_disparity(ABS, left, right, (7, 7), (sx, 1))
+    assert (want[..., 2] == 0).mean() > 0.5 and (want[..., 2] != 0).any()
+    got, path = _gpu(ctx, ABS, left, right, (7, 7), (sx, 1))
+    assert path == core.PATH_SAD_U8
+    assert np.array_equal(got, want), int((got != want).any(-1).sum())
+
+
 def test_search_volume_one_all_invalid(ctx, oracle):
     left, right, _ = synth.stereo_pair(80, 30, 1, 1)
     for cost in (ABS, SQ, NCC):

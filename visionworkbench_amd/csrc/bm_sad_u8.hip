@@ -127,6 +127,14 @@ __device__ __forceinline__ void divmod_small(int idx, int d, float inv, int& quo
   quo = qq; rem = rr;
 }
 
+// dwords of the entry array: the word groups of a byte phase, or what borrows the array after the sweep (see the kernel)
+__host__ __device__ constexpr size_t ent_words(int nr, int ne, int ew, int gr, int ty, int pt) {
+  const size_t ent = (size_t)nr * ne * ew;
+  const size_t merge = gr > 1 ? (size_t)(gr - 1) * (ty / gr) * 4 * pt + (size_t)gr * pt : 0;
+  const size_t ob = (size_t)gr * (pt / 64) * 768;
+  return ent > merge ? (ent > ob ? ent : ob) : (merge > ob ? merge : ob);
+}
+
 // One launch: the matcher sweep (keys + equality probe), the epilogue, and — only in workgroups where some pixel may be
 // invalid — the validity sweep: packed best / worst costs recomputed, pixels with best == worst invalidated
 // (Correlation.cc:121-133).
@@ -151,7 +159,11 @@ bm_sad_u8_kernel(const float* __restrict__ L, ptrdiff_t ls, int lw, int lh,
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   u32* ent = lds;                                   // [NR][ne][EW]   word groups of the current byte phase
   const int bpitch = ne + NW + 1;                   // dwords per row of the RIGHT u8 base tile
-  u32* base = lds + (size_t)NR * ne * EW;           // [NR][bpitch]
+  // The entry array is borrowed twice after the sweep: by the merge of the wave groups ((GR - 1) x TY / GR x 4 x PT keys + GR x PT equality
+  // words) and by the epilogue's per-wave transposition buffers (768 dwords each).  With a narrow search both can exceed NR x ne x EW — and
+  // the RIGHT base tile behind it is still needed by the validity sweep (found by the round-6 campaign: constant images, search 2 .. 8 on the
+  // 512-column four-group tile).  ent_words() is the size both sides use.
+  u32* base = lds + ent_words(NR, ne, EW, GR, TY, C::THREADS);           // [NR][bpitch]
   u32* item_ctr = base + (size_t)NR * bpitch;       // SPLIT: one work item counter per wave pair
 
   constexpr int PT = C::THREADS;                    // threads that map to pixels
@@ -612,9 +624,9 @@ constexpr size_t kMaxLds = 80 * 1024;   // two workgroups per CU
 
 int entries_per_row(const Launch& l, int sx) { return l.twb / 4 + ((sx + 2) >> 2) + 1; }
 
-size_t lds_bytes(const Launch& l, int sx) {
+size_t lds_bytes(const Launch& l, int sx, int groups) {
   const int ne = entries_per_row(l, sx);
-  const size_t ent = (size_t)l.nr * ne * l.ew;
+  const size_t ent = ent_words(l.nr, ne, l.ew, groups, l.ty, l.threads);
   const size_t left = (size_t)l.nr * (l.twb / 4 + l.nw + 1);        // borrowed from the entry array
   const size_t base = (size_t)l.nr * (ne + l.nw + 1);
   return ((ent > left ? ent : left) + base) * sizeof(u32);
@@ -627,7 +639,7 @@ bool vwgpu_bm_sad_u8_supported(int cost_type, int kx, int ky, int sx, int sy) {
   const Launch* l = find_launch(kx, ky);
   if (!l) return false;
   if ((long long)sx * sy > 65535) return false;
-  return lds_bytes(*l, sx) <= kMaxLds;
+  return lds_bytes(*l, sx, l->split_fn ? l->split_groups : 1) <= kMaxLds;
 }
 
 int vwgpu_launch_bm_sad_u8(vwgpu_ctx* ctx,
@@ -650,7 +662,7 @@ int vwgpu_launch_bm_sad_u8(vwgpu_ctx* ctx,
   int rc = vwgpu_next_flags(ctx, 0, &flag_set, &flag_clear, nullptr);
   if (rc) return rc;
   *d_fallback_flag = flag_set;
-  const size_t shmem = lds_bytes(*l, sx) + (split ? 64 : 0);   // + the item counters of the split variant
+  const size_t shmem = lds_bytes(*l, sx, split ? l->split_groups : 1) + (split ? 64 : 0);   // + the item counters of the split variant
   const KernelFn main_fn = split ? l->split_fn : l->fn;
   const unsigned grid1 = (unsigned)((gx * gy + 7) / 8 * 8);   // one tile per workgroup, see the XCD note in the kernel
   if (shmem > 64 * 1024)
