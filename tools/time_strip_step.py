@@ -23,6 +23,24 @@ for N in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     t0 = time.perf_counter()
     for _ in range(K): step()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    F = int(os.environ.get("INFLIGHT", "1"))
+    if F > 1:
+        # F independent steps in flight: F engine contexts on F streams, steps handed out round-robin (the reference keeps several tiles in
+        # flight per device as well, one thread per tile: ImageIO.h:228-251) — the staging burst of one step overlaps the sweep of another
+        cs = [vwa.Context(0) for _ in range(F)]
+        ss = [torch.cuda.Stream() for _ in range(F)]
+        for c_ in cs: c_.set_option(core.OPT_DEFER_EXACTNESS, 1)
+        def stepf(i):
+            with torch.cuda.stream(ss[i % F]):
+                return stereo.calc_disparity(0, l, r, region, SEARCH, KERNEL, ctx=cs[i % F])
+        for i in range(100): stepf(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K): o_ = stepf(i)
+        torch.cuda.synchronize(); dtf = time.perf_counter() - t0
+        same = np.array_equal(o_.cpu().numpy(), step().cpu().numpy())
+        print("   %d steps in flight: %.1f us/step (%s the serial result)" % (F, dtf / K * 1e6, "identical to" if same else "DIFFERENT from"))
+        for c_ in cs: c_.close()
     ctx.profile_enable(True); ctx.profile_reset()
     for _ in range(20): step()
     torch.cuda.synchronize()
