@@ -1,18 +1,18 @@
 #!/usr/bin/env python3
 """Where the time of one packed-u8 SAD launch goes, workgroup by workgroup (GPU box; needs `make -C visionworkbench_amd/csrc stamps`).
 
-Every workgroup of the instrumented matcher (tools/build/libvwgpu_stamps.so, -DVWGPU_TILE_STAMPS) leaves wall-clock stamps (100 MHz) at
+Every workgroup of the instrumented matcher (tools/libexp/libvwgpu_stamps.so, -DVWGPU_TILE_STAMPS) leaves wall-clock stamps (100 MHz) at
 its start, after staging, after each byte phase and after its epilogue, the shader clock at start and end, and the XCC / SE / CU it ran
 on.  This script prints the launch as a schedule: dispatch ramp, rounds per CU, gaps between a CU's consecutive workgroups, the phase
 durations, the average shader clock, and how the wall time of the launch divides into them.
-usage: VWGPU_LIBRARY=tools/build/libvwgpu_stamps.so python tools/sad_timeline.py [W H SX]..."""
+usage: VWGPU_LIBRARY=tools/libexp/libvwgpu_stamps.so python tools/sad_timeline.py [W H SX]..."""
 import ctypes
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("VWGPU_LIBRARY", os.path.join(ROOT, "tools", "build", "libvwgpu_stamps.so"))
+os.environ.setdefault("VWGPU_LIBRARY", os.path.join(ROOT, "tools", "libexp", "libvwgpu_stamps.so"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
