@@ -1,3 +1,4 @@
+# needs: make -C visionworkbench_amd/csrc ringdbg
 # per-direction durations of the ring kernel under the knock-out build (tools/libexp/libvwgpu_ringdbg.so).  GPU box only.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
