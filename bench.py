@@ -79,11 +79,26 @@ class HaloFetcher:
             return
         err = ""
         uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        puid = torch.zeros(128, dtype=torch.uint8, device=dev)
         if rank == 0:
             try:
                 uid = torch.tensor(list(partition.EngineComm.unique_id()), dtype=torch.uint8, device=dev)
+                puid = torch.tensor(list(partition.EngineComm.unique_id()), dtype=torch.uint8, device=dev)
             except Exception as e:  # noqa: BLE001
                 err = "unique id: %s" % (str(e)[:80],)
+        # first contact in child processes (see halo_probe): a crash or a hang of the engine path ends a child, not this rank
+        if self.agree(not err) and os.environ.get("VWGPU_BENCH_HALO_PROBE", "1") != "0":
+            dist.broadcast(puid, 0)
+            try:
+                import subprocess
+                spec = "%s:%d:%d:%d" % (bytes(puid.cpu().numpy().tobytes()).hex(), rank, world, dev.index)
+                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--halo-probe", spec], capture_output=True, text=True, timeout=120)
+                if pr.returncode != 0:
+                    err = "probe child exited %d: %s" % (pr.returncode, (pr.stderr or "")[-80:].replace("\n", " "))
+            except Exception as e:  # noqa: BLE001  (incl. the timeout: a hung exchange)
+                err = "probe: %s" % (str(e)[:80],)
+            if not self.agree(not err) and not err:
+                err = "probe failed on another rank"
         if self.agree(not err):
             dist.broadcast(uid, 0)
             try:
@@ -872,7 +887,36 @@ def sub_workload(name, extra_args, env_extra, keys, timeout=900):
     return out
 
 
+def halo_probe(spec):
+    """`bench.py --halo-probe UIDHEX:RANK:WORLD:DEVICE` — one rank of a throw-away communicator: the engine's own RCCL exchange (csrc/halo.hip, RCCL
+    behind dlopen) has met more than one rank on no machine yet, and a crash or a hang inside it must not cost the run its JSON line.  So the
+    ranks of `bench.py --gpus N` first let CHILD processes do one small halo fetch through the engine path (each child = this function, under a
+    timeout); only if every child comes back clean does the parent open its own engine communicator, otherwise the torch.distributed mirror
+    serves the halo.  Exit code 0 = the fetched window is the rows the plan promises."""
+    uid_hex, rank, world, device = spec.split(":")
+    rank, world, device = int(rank), int(world), int(device)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import visionworkbench_amd as vwa
+    from visionworkbench_amd import partition
+    torch.cuda.set_device(device)
+    ctx = vwa.Context(device)
+    comm = partition.EngineComm(ctx, bytes.fromhex(uid_hex), rank, world)
+    rows, above, below = 16 * world, 3, 5
+    full = torch.arange(rows * 24, dtype=torch.float32, device="cuda").reshape(rows, 24)
+    a, b = partition.row_strip(rank, world, rows)
+    win, first = comm.fetch_strip_window(full[a:b].contiguous(), rows, above, below)
+    torch.cuda.synchronize()
+    _, _, na, nb = partition.halo_plan(rank, world, rows, above, below)
+    ok = first == na and torch.equal(win, full[na:nb])
+    comm.close()
+    ctx.close()
+    sys.exit(0 if ok else 4)
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--halo-probe":
+        return halo_probe(sys.argv[2])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)     # 0.36 ms each: long enough to amortise the ~1.3 ms of barrier + first-launch latency
