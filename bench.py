@@ -434,12 +434,12 @@ def extra_points(ctx, torch, stereo, core, vwa, synth, lt, rt, left, right, with
     def fstep(i):
         with torch.cuda.stream(fstr[i & 1]):
             return stereo.calc_disparity(0, lt, rt, vwa.bounding_box(left), (129, 1), (7, 7), ctx=fctx[i & 1])
-    for i in range(10): fstep(i)
+    for i in range(40): fstep(i)                                   # (the allocator's per-stream pools and the clocks settle)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(40): fo = fstep(i)
+    for i in range(200): fo = fstep(i)
     torch.cuda.synchronize()
-    fms = (time.perf_counter() - t0) / 40 * 1e3
+    fms = (time.perf_counter() - t0) / 200 * 1e3
     fsame = bool(torch.equal(fo, dcall_ref)) if dcall_ref is not None else None
     for c_ in fctx: c_.close()
     out.append({"name": "headline, TWO steps in flight (two contexts on two streams): 4096^2, 7x7 SAD, search 129x1",
