@@ -150,9 +150,11 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *       (default: eight passes over the u16 sums, bandwidth bound), 1 = two concurrent fused raster sweeps of four directions each
  *       (a fifth of the HBM traffic, the same sums; slower on MI355X because a sweep is W + 2 H dependent pixel steps), 2 .. 15 = the
  *       sweeps with that many rows per workgroup (tuning).
- *   VWGPU_OPT_SGM_PATH_MODE    the one-direction-per-launch schedule (tuning / measurements; same sums in every mode): bits 0-3 = scan lines
- *       per workgroup (0 = default: 4 neighbouring lines for the six directions that cross the rows, 1 for the two along them; 1, 2, 4, 8),
- *       bit 4 = read the census costs from a materialised u8 volume (the round-2 schedule) instead of forming them from the census rasters.
+ *   VWGPU_OPT_SGM_PATH_MODE    the one-direction-per-launch schedule of full-range one-row searches (tuning / measurements; the same sums in every
+ *       mode): bits 0-3 = scan lines per workgroup (0 = default: 4 neighbouring lines; 8 = eight lines with a ring of three chunks; the register
+ *       kernel: < 4 = one line), bit 5 = the round-2 kernel that prefetches into registers (path_uniform_reg_kernel) instead of the LDS ring
+ *       (path_ring_kernel, vector strides up to 160 bytes), bits 8-10 = log2 of the consecutive workgroups given to one XCD, bit 11 = the ring
+ *       kernel forms the census costs itself from the census rasters (up to 129 disparities; no u8 cost volume; measured slower).
  *   VWGPU_OPT_EXACT_SPLIT      pass 2 of the exact-order matchers: 0 = chosen by the width of a zone (the recurrence alone + a parallel
  *       selection for zones of 1024 pixels and more (whole rasters), the tiled form — row sums transposed through LDS — for narrower
  *       ones), 1 = always the split form, 2 = always the fused form (selection across the disparity lanes inside the chain), 3 = always

@@ -183,9 +183,9 @@ def test_fused_sweeps_identical_to_oracle(vw, oracle, sweep, k, sx, w, h, cost):
 
 
 # ---- the one-direction-per-launch schedule in all its forms (VWGPU_OPT_SGM_PATH_MODE): path_ring_kernel (LDS ring, the default),
-# path_uniform_reg_kernel (round 2), lines per workgroup, XCD clusters, census costs formed in the path kernel -------------------------
+# path_uniform_reg_kernel (round 2), lines per workgroup, XCD clusters, census costs formed in the ring kernel -------------------------
 
-@pytest.mark.parametrize("mode", [0, 192, 8, 512 + 8, 1024, 2048, 2048 + 512, 32, 32 + 1, 32 + 8, 32 + 16, 32 + 16 + 2])
+@pytest.mark.parametrize("mode", [0, 8, 512 + 8, 1024, 2048, 2048 + 512, 2048 + 8, 32, 32 + 1, 32 + 8])
 @pytest.mark.parametrize("k,sx,w,h,cost", [(7, 128, 300, 40, CENSUS), (5, 16, 64, 20, CENSUS), (3, 60, 500, 90, TERNARY), (9, 130, 257, 70, CENSUS),
                                            (7, 127, 100, 300, TERNARY), (7, 8, 41, 25, CENSUS), (5, 159, 64, 47, CENSUS), (5, 200, 90, 33, CENSUS),
                                            (7, 128, 12, 9, CENSUS), (7, 40, 3000, 9, CENSUS)])

@@ -8,7 +8,7 @@ import oracle
 from visionworkbench_amd import stereo, synth, core
 from visionworkbench_amd.core import BBox2i
 OPT = 19
-modes = [int(a) for a in sys.argv[1:]] or [2048, 0, 512, 192, 8, 32]
+modes = [int(a) for a in sys.argv[1:]] or [32 + 1, 32, 0, 8, 512, 2048]
 ctx = core.default_context(0)
 # correctness: 2 small scenes x every mode
 for (W, H, SX) in ((200, 90, 40), (131, 77, 128)):

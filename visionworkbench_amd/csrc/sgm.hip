@@ -1212,25 +1212,22 @@ enum { ACC_ATOMIC = 1, ACC_STORE = 2, ACC_NONE = 3, ACC_RMW = 4, ACC_RMW_WTA = 5
 #ifndef VWGPU_PATH_KC
 #define VWGPU_PATH_KC 8
 #endif
-// CEN (round 6): the Hamming costs of a step are formed from the two census rasters (one scalar left word, the lane's 2 EPT right
-// words: xor + v_bcnt) instead of being read from the u8 volume, which then is neither written nor read: 136 of the 680 bytes a
-// read-modify-write step moves at D = 129.  The right words of neighbouring lines overlap almost completely, so with the lines of
-// a workgroup adjacent they are L1 / L2 hits.  The raw words are fetched a chunk ahead into ONE register set and folded into cost
-// pairs before the next chunk's are requested.
+// CenArgs: the two census rasters at output pixel (0, 0), disparity 0 (path_ring_kernel<.., CEN> forms the Hamming costs itself).
 struct CenArgs {
-  const uint64_t* lcen; const uint64_t* rcen;      // at output pixel (0, 0), disparity 0
+  const uint64_t* lcen; const uint64_t* rcen;
   int lcw, rcw;
 };
-struct __attribute__((aligned(8))) CenPair { uint64_t a, b; };
 // WPB lines (wavefronts) per workgroup: the lines of a workgroup are neighbours, so the 128-byte lines that two neighbouring
 // pixels' vectors share (a 272-byte vector straddles three) are fetched by ONE compute unit / XCD instead of two.
-template <int EPT, int ACC, int KC, bool CEN, int WPB>
+// (Round 6 also built this kernel with the census costs formed in registers — 32 bytes of census words per lane and step, fetched a
+// chunk ahead: 320 registers, one wave per SIMD, 9.6 ms against 5.4 — and removed it; profiles/r06_sgm_traffic.md.)
+template <int EPT, int ACC, int KC, int WPB>
 __global__ void __launch_bounds__(64 * WPB)
 path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
-                        const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2, CenArgs CA,
+                        const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2,
                         int32_t* __restrict__ disp = nullptr, uint8_t* __restrict__ todo = nullptr, int* __restrict__ any_todo = nullptr) {
   constexpr bool RMW = (ACC == ACC_RMW || ACC == ACC_RMW_WTA);
-  constexpr int NW = CEN ? EPT : CostWords<EPT>::N;
+  constexpr int NW = CostWords<EPT>::N;
   const int num_disp = g.num_dx;                                                     // num_dy == 1
   const int npairs = (num_disp + 1) / 2;
   const int tid = threadIdx.x & 63;
@@ -1283,12 +1280,6 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
   const unsigned loff_c = in ? (unsigned)(tid * EPT * 2) : 0u, loff_a = in ? (unsigned)(tid * EPT) : 0u;
   const uint8_t* cfetch = cost + pbase * stride;                    // cost vector of the next step to fetch
   const long long cstep = delta * stride;
-  // CEN: the census words of the next step to fetch — the left one through a scalar pointer, the lane's right ones at its disparities
-  const uint64_t* lcfetch = CA.lcen + ((long long)r0 * CA.lcw + c0);
-  const long long lcstep = (long long)dr * CA.lcw + dc;
-  const uint64_t* rcfetch = CA.rcen + ((long long)r0 * CA.rcw + c0);
-  const long long rcstep = (long long)dr * CA.rcw + dc;
-  const unsigned loff_r = in ? (unsigned)(tid * EPT * 2) : 0u;      // in words
   const unsigned* afetch = reinterpret_cast<const unsigned*>(accum) + pbase * q32;
   const long long astep = delta * q32;
   unsigned* astore = reinterpret_cast<unsigned*>(accum) + pbase * q32 + loff_a;      // stores are masked by `in`
@@ -1328,9 +1319,7 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
       us2 m = __builtin_elementwise_min(__builtin_elementwise_min(as_us2(al[e]), as_us2(al[e + 1])), ctr);
       us2 v = __builtin_elementwise_add_sat(m, p1p1);
       v = __builtin_elementwise_min(v, __builtin_elementwise_min(ctr, dJ));
-      unsigned cpair;
-      if constexpr (CEN) cpair = w[e]; else cpair = cost_pair<EPT>(w, e);
-      v = __builtin_elementwise_add_sat(v, as_us2(cpair));
+      v = __builtin_elementwise_add_sat(v, as_us2(cost_pair<EPT>(w, e)));
       v = __builtin_elementwise_sub_sat(v, mp);
       r[e] = as_u32(v) | dead[e];
       mn2 = e == 0 ? as_us2(r[e]) : __builtin_elementwise_min(mn2, as_us2(r[e]));
@@ -1389,31 +1378,10 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
     const unsigned mnu = as_u32(mn2);
     min_prior = wave_min_u32_fused(min(mnu & 0xffffu, mnu >> 16));
   };
-  CenPair raw[CEN ? KC : 1][EPT];
-  uint64_t lraw[CEN ? KC : 1];
-  auto fetch_raw = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int k = 0; k < (CEN ? KC : 0); ++k) {
-      const CenPair* rp = reinterpret_cast<const CenPair*>(rcfetch + loff_r);
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) raw[k][e] = rp[e];
-      lraw[k] = *lcfetch;
-      rcfetch += rcstep;                                             // like the volumes: up to 2 KC steps past the line (guard zones)
-      lcfetch += lcstep;
-    }
-  };
-  auto convert = [&](unsigned (&buf)[KC][NW]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int k = 0; k < (CEN ? KC : 0); ++k) {
-#pragma unroll
-      for (int e = 0; e < EPT; ++e)
-        buf[k][e] = (unsigned)__popcll(raw[k][e].a ^ lraw[k]) | ((unsigned)__popcll(raw[k][e].b ^ lraw[k]) << 16);
-    }
-  };
   auto fetch = [&](unsigned (&buf)[KC][NW], unsigned (&abuf)[KC][EPT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
-      if constexpr (!CEN) load_cost_words<EPT>(cfetch + loff_c, true, buf[k]);
+      load_cost_words<EPT>(cfetch + loff_c, true, buf[k]);
       if constexpr (RMW) {
         const unsigned* a = afetch + loff_a;
         if constexpr (EPT == 2) { const uint2 v = *reinterpret_cast<const uint2*>(a); abuf[k][0] = v.x; abuf[k][1] = v.y; }
@@ -1439,32 +1407,19 @@ path_uniform_reg_kernel(SgmGeom g, DirSet D, int stride, const uint8_t* __restri
 
   unsigned ca[KC][NW], cb[KC][NW], aa[KC][EPT], ab[KC][EPT];
   const int nfull = len / KC;
-  // CEN: the phases are pinned with scheduling barriers — left alone, the scheduler renames the buffers and hoists the next loads above
-  // the steps (three register sets of each: 256 VGPRs + 64 AGPRs, one wave per SIMD).
-#define VWGPU_SB() do { if constexpr (CEN) __builtin_amdgcn_sched_barrier(0); } while (0)
-  if constexpr (CEN) { fetch_raw(); fetch(ca, aa); convert(ca); VWGPU_SB(); fetch_raw(); }
-  else fetch(ca, aa);
+  fetch(ca, aa);
   int ch = 0;
   for (; ch + 2 <= nfull; ch += 2) {                                // full chunks: no per-step test
-    VWGPU_SB();
     fetch(cb, ab);
-    VWGPU_SB();
     steps(ca, aa, ch * KC, std::false_type());
-    VWGPU_SB();
-    if constexpr (CEN) { convert(cb); VWGPU_SB(); fetch_raw(); }
     fetch(ca, aa);
-    VWGPU_SB();
     steps(cb, ab, (ch + 1) * KC, std::false_type());
-    VWGPU_SB();
-    if constexpr (CEN) { convert(ca); VWGPU_SB(); fetch_raw(); }
   }
   if (ch * KC < len) {                                              // the last one or two chunks
     fetch(cb, ab);
     steps(ca, aa, ch * KC, std::true_type());
-    if constexpr (CEN) convert(cb);
     steps(cb, ab, (ch + 1) * KC, std::true_type());
   }
-#undef VWGPU_SB
   if constexpr (ACC == ACC_RMW_WTA) {
     if (flagged && tid == 0) atomicOr(any_todo, 1);
   }
@@ -3104,9 +3059,8 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   const bool cen_ok = dir_paths && !block_cost && cen_oc >= 0 && cen_or >= 0 && cen_oc + g.ocols <= lcw && cen_or + g.orows <= std::min(lch, rch) &&
                       cen_oc + g.ocols - 1 + (int)num_disp <= rcw;
   const bool ring_paths = dir_paths && !(ctx->sgm_path_mode & 32) && ustride <= 160;            // path_ring_kernel
-  const bool ring_cen = ring_paths && cen_ok && num_disp <= 129 && (ctx->sgm_path_mode & 2048);   // ... forming the census costs itself (opt-in: measured slower)
-  const bool cen_paths = !ring_paths && cen_ok && num_disp <= 256 && (ctx->sgm_path_mode & 16);   // path_uniform_reg_kernel<.., CEN> (measured: register bound)
-  if (cen_paths || ring_cen) {
+  const bool ring_cen = ring_paths && cen_ok && num_disp <= 129 && (ctx->sgm_path_mode & 2048) && (ctx->sgm_path_mode & 15) < 8;   // ... forming the census costs itself (opt-in: measured slower)
+  if (ring_cen) {
   } else if (block_cost) {
     // fill_costs_block (SGM.cc:1711-1738).  Exact n / count for every n the sums can reach: multiply-high by 2^32 / count + 1.
     vwgpu_prof_scope ps(ctx, "sgm_cost");
@@ -3324,7 +3278,6 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
         // lines per workgroup: neighbouring lines of the six directions that cross the rows share 128-byte lines of both volumes
         int wpb = ctx->sgm_path_mode & 15;
         if (wpb == 0) wpb = d.dr != 0 ? 4 : 1;
-        wpb = wpb >= 8 ? 8 : wpb >= 4 ? 4 : wpb >= 2 ? 2 : 1;
         CenArgs CA;
         CA.lcen = lc + (size_t)cen_or * lcw + cen_oc; CA.rcen = rcen + (size_t)cen_or * rcw + cen_oc; CA.lcw = lcw; CA.rcw = rcw;
         // round 6: the same recurrence fed through an LDS ring (path_ring_kernel) — vector strides up to 160 bytes
@@ -3332,40 +3285,29 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
 #ifdef VWGPU_RING_DBG
           { const int dv = getenv("VWGPU_RING_DBG") ? atoi(getenv("VWGPU_RING_DBG")) : 0; VWGPU_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(ring_dbg), &dv, sizeof dv, 0, hipMemcpyHostToDevice, st)); }
 #endif
-          const int rsel = (ctx->sgm_path_mode >> 6) & 3;
           const int rwpb = (ctx->sgm_path_mode & 15) >= 8 ? 8 : 4, cluster = 1 << ((ctx->sgm_path_mode >> 8) & 7);
 #define VWGPU_RING5(E, A, RCC, WP, C) do { const size_t acb = (size_t)12 * ustride, ccb = (size_t)6 * 16 * ((ustride + 15) / 16); \
           const size_t rl = (size_t)WP * (C ? RCC * acb + ccb + 272 + 384 : RCC * (acb + ccb) + 256); \
           VWGPU_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(path_ring_kernel<E, A, RCC, WP, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl)); \
           hipLaunchKernelGGL((path_ring_kernel<E, A, RCC, WP, C>), dim3((nlines + WP - 1) / WP), dim3(64 * WP), rl, st, g, S, ustride, l8, lw, min_col, min_row, cost, accum, \
                              (unsigned)p1, (unsigned)p2, out_disp, full_search, wta_flag, cluster, CA); } while (0)
-#define VWGPU_RING4(E, A, RCC, WP) do { if (ring_cen) VWGPU_RING5(E, A, RCC, WP, true); else VWGPU_RING5(E, A, RCC, WP, false); } while (0)
-#define VWGPU_RING3(E, A, RCC) do { if (rwpb == 8) VWGPU_RING4(E, A, RCC, 8); else VWGPU_RING4(E, A, RCC, 4); } while (0)
-#define VWGPU_RING2(E, A) do { if (rsel == 3 || rwpb == 8) VWGPU_RING3(E, A, 3); else VWGPU_RING3(E, A, 4); } while (0)
+#define VWGPU_RING2(E, A) do { if (rwpb == 8) VWGPU_RING5(E, A, 3, 8, false); else if (ring_cen) VWGPU_RING5(E, A, 4, 4, true); else VWGPU_RING5(E, A, 4, 4, false); } while (0)
 #define VWGPU_RING(E) do { if (acc == ACC_STORE) VWGPU_RING2(E, ACC_STORE); else if (acc == ACC_RMW_WTA) VWGPU_RING2(E, ACC_RMW_WTA); else VWGPU_RING2(E, ACC_RMW); } while (0)
           if (pe == 1) VWGPU_RING(1); else VWGPU_RING(2);
 #undef VWGPU_RING
 #undef VWGPU_RING2
-#undef VWGPU_RING3
-#undef VWGPU_RING4
 #undef VWGPU_RING5
           if (acc == ACC_RMW_WTA) wta_done = true;
           continue;
         }
-#define VWGPU_PATH_DIR3(E, A, C, WP) hipLaunchKernelGGL((path_uniform_reg_kernel<E, A, VWGPU_PATH_KC, C, WP>), dim3((nlines + WP - 1) / WP), dim3(64 * WP), 0, st, \
-                                 g, S, ustride, l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2, CA, out_disp, full_search, wta_flag)
-#define VWGPU_PATH_DIR2(E, A, C) do { if (wpb == 8) VWGPU_PATH_DIR3(E, A, C, 8); else if (wpb == 4) VWGPU_PATH_DIR3(E, A, C, 4); \
-                                      else if (wpb == 2) VWGPU_PATH_DIR3(E, A, C, 2); else VWGPU_PATH_DIR3(E, A, C, 1); } while (0)
-#define VWGPU_PATH_DIR1(E, A) do { if (cen_paths) VWGPU_PATH_DIR2(E, A, true); else VWGPU_PATH_DIR2(E, A, false); } while (0)
-#define VWGPU_PATH_DIR(E) do { if (acc == ACC_STORE) VWGPU_PATH_DIR1(E, ACC_STORE); else if (acc == ACC_RMW_WTA) VWGPU_PATH_DIR1(E, ACC_RMW_WTA); \
-                               else VWGPU_PATH_DIR1(E, ACC_RMW); } while (0)
-#define VWGPU_PATH_DIR_VOL(E) do { if (acc == ACC_STORE) VWGPU_PATH_DIR2(E, ACC_STORE, false); else if (acc == ACC_RMW_WTA) VWGPU_PATH_DIR2(E, ACC_RMW_WTA, false); \
-                                   else VWGPU_PATH_DIR2(E, ACC_RMW, false); } while (0)
-        switch (pe) { case 1: VWGPU_PATH_DIR(1); break; case 2: VWGPU_PATH_DIR(2); break; default: VWGPU_PATH_DIR_VOL(4); break; }   // (cen_paths: D <= 256, pe <= 2)
-#undef VWGPU_PATH_DIR_VOL
+#define VWGPU_PATH_DIR3(E, A, WP) hipLaunchKernelGGL((path_uniform_reg_kernel<E, A, VWGPU_PATH_KC, WP>), dim3((nlines + WP - 1) / WP), dim3(64 * WP), 0, st, \
+                                 g, S, ustride, l8, lw, min_col, min_row, cost, accum, (unsigned)p1, (unsigned)p2, out_disp, full_search, wta_flag)
+#define VWGPU_PATH_DIR2(E, A) do { if (wpb >= 4) VWGPU_PATH_DIR3(E, A, 4); else VWGPU_PATH_DIR3(E, A, 1); } while (0)
+#define VWGPU_PATH_DIR(E) do { if (acc == ACC_STORE) VWGPU_PATH_DIR2(E, ACC_STORE); else if (acc == ACC_RMW_WTA) VWGPU_PATH_DIR2(E, ACC_RMW_WTA); \
+                               else VWGPU_PATH_DIR2(E, ACC_RMW); } while (0)
+        switch (pe) { case 1: VWGPU_PATH_DIR(1); break; case 2: VWGPU_PATH_DIR(2); break; default: VWGPU_PATH_DIR(4); break; }
         if (acc == ACC_RMW_WTA) wta_done = true;
 #undef VWGPU_PATH_DIR
-#undef VWGPU_PATH_DIR1
 #undef VWGPU_PATH_DIR2
 #undef VWGPU_PATH_DIR3
       }
