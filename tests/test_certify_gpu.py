@@ -271,10 +271,15 @@ def test_single_level_partial_redo_of_flagged_tile_rows(ctx, oracle, cost, kerne
     def flat(y0, y1, x0, x1):
         left[y0:y1, x0:x1] = np.float32(2.7)
         right[y0:y1 + search[1] - 1, x0:x1 + search[0] + 30] = np.float32(2.7)
-    for bands in ([(200, 230)], [(0, 25)], [(H - 30, H)], [(40, 70), (300, 340)], [(0, H)]):
+    # (round 6: the redo also stops at the last flagged tile COLUMN — patches at the left edge, in the middle, at the right edge, and two bands
+    # whose patches end at different columns)
+    for bands in ([(200, 230)], [(0, 25)], [(H - 30, H)], [(40, 70), (300, 340)], [(0, H)], [(120, 150, 0, 40)], [(120, 150, W - 90, W)],
+                  [(60, 80, 10, 50), (260, 290, 300, 420)]):
         l0, r0 = left.copy(), right.copy()
-        for (a, b) in bands:
-            flat(a, b, 100, 260)
+        for bd in bands:
+            a, b = bd[0], bd[1]
+            x0, x1 = (bd[2], bd[3]) if len(bd) == 4 else (100, 260)
+            flat(a, b, x0, x1)
         want = oracle.calc_disparity(cost, left, right, kernel, search)
         got = stereo.calc_disparity(cost, left, right, vwa.bounding_box(left), search, kernel, ctx=ctx)
         assert np.array_equal(got, want), (bands, ctx.last_path(), int((got != want).any(-1).sum()))

@@ -208,7 +208,7 @@ struct ZPart { double* best; double* worst; int* idx; double* second; double* rp
 struct ZCert { double eps_s, eps_ll, eps_rr, eps32; int edge_lo, edge_hi, trow, pad1; };      // eps32: bound on |float32 tile sum - exact sum| of the fp32 tier, see vwgpu_launch_bm_zones
 struct ZCertArgs { const ZCert* zc; int* zflag; unsigned long long* stats; int* any; const int* need; const unsigned char* cells;
                    int edge_m, edge_k;        // zc == nullptr: no certification; any[image]: "some zone was flagged"; edge_* (the bounds: per zone, in ZCert): see ZEdge
-                   int* tflag; };             // tflag != nullptr: the 32-row bands of a zone that hold an unproven pixel, tflag[ZCert::trow + tile y] = 1 (see vwgpu_zone_row_flags)
+                   int* tflag; };             // tflag != nullptr: the 32-row bands of a zone that hold an unproven pixel, tflag[ZCert::trow + tile y] = 1 + the last such tile's column (see vwgpu_zone_row_flags)
 // The "cannot matter" certificate (EDGE kernels; edge_m > 0).  A candidate (pixel, disparity) whose partner lies edge_m or more columns
 // outside the other image — partner column = origin of its window in the other image - edge_k, outside [edge_lo, edge_hi] — is FAR
 // (edge_m > 0 switches the certificate on; the caller folds the margin into the two bounds).  Far windows are clamped copies of the border column: whole runs of them have bit-identical data, their costs tie exactly
@@ -835,7 +835,7 @@ bm_zones_kernel(ZLaunch G, const vwgpu_zone_task* __restrict__ zones, const ZIte
     if (threadIdx.x == 0) {
       if (any) {
         G.C.zflag[it.zone] = 1; if (G.C.any) G.C.any[z.img] = 1;
-        if (G.C.tflag) G.C.tflag[G.C.zc[it.zone].trow + (int)((unsigned)it.txy >> 16)] = 1;      // (ty in the upper half: up to 65535 tile rows)
+        if (G.C.tflag) atomicMax(&G.C.tflag[G.C.zc[it.zone].trow + (int)((unsigned)it.txy >> 16)], (int)(it.txy & 0xffff) + 1);      // (ty in the upper half: up to 65535 tile rows; the value: 1 + the band's last flagged tile column)
       }
       if (G.C.stats) {
         atomicAdd(&G.C.stats[any ? 1 : 0], (unsigned long long)(geom.tw * geom.th));
@@ -946,7 +946,7 @@ zones_merge_kernel(const vwgpu_zone_task* __restrict__ zones, const ZMergeItem* 
     if (t == 0) {
       if (any) {
         C.zflag[it.zone] = 1; if (C.any) C.any[z.img] = 1;
-        if (C.tflag) C.tflag[C.zc[it.zone].trow + (it.txy >> 16)] = 1;
+        if (C.tflag) atomicMax(&C.tflag[C.zc[it.zone].trow + (int)((unsigned)it.txy >> 16)], (int)(it.txy & 0xffff) + 1);
       }
       if (C.stats) { atomicAdd(&C.stats[any ? 1 : 0], (unsigned long long)(tw * th)); }
     }

@@ -468,7 +468,14 @@ static int calc_disparity_classified(vwgpu_ctx* ctx, int cost_type, const float*
         const int flagged_rows = vwgpu_zone_flagged_rows(tf.data(), z.zh, &rows);
         if (!rows.empty() && flagged_rows * 2 < z.zh) {             // (most of the image flagged: the whole raster in one go is cheaper)
           ctx->last_path = VWGPU_PATH_EXACT_ORDER;
-          return vwgpu_launch_bm_exact(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, &z, 1, d_out, nullptr, rows.data(), (int)rows.size() / 2);
+          // ... and only for the columns up to the last flagged tile (round 6): the reference's row chains run from column 0 rightwards, a sum at
+          // column x has seen columns <= x + kx - 1 only, so the narrower raster [0, wneed) reproduces them bit for bit (a band's flag holds 1 + its
+          // last flagged tile column; tiles are at most 32 pixels wide).  The columns right of it keep their certified values.
+          int tmax = 0;
+          for (int v : tf) tmax = std::max(tmax, v);
+          vwgpu_zone_task z2 = z;
+          z2.zw = (int)std::min<long long>(z.zw, (long long)tmax * 32);
+          return vwgpu_launch_bm_exact(ctx, cost_type, d_left, lw, lh, ls, d_right, rw, rh, rs, kx, ky, &z2, 1, d_out, nullptr, rows.data(), (int)rows.size() / 2);
         }
       }
     }
