@@ -952,7 +952,9 @@ void add_zone(Tables& t, XZone z, int kx, int rows, bool box) {
 // split_from: zones at least this wide take the split pass 2 (rowsum + select items), narrower ones the fused kernel (row items);
 // box tables pass INT_MAX (their pass 2 is bmx_box_row_kernel over the row items).
 // (zones that take the tiled form get the offsets of their group records here: the table is uploaded afterwards)
-void build_items(Tables& t, int kx, int y_begin, int y_end, int split_from = INT_MAX, int tiled_from = INT_MAX, int tiled_to = INT_MAX) {
+// cols_only: a segment whose rows nobody reads (partial redo): the column chains advance through it, no row / tile / selection / merge item is
+// built or uploaded (thousands of rows of tables for launches that return before using them)
+void build_items(Tables& t, int kx, int y_begin, int y_end, int split_from = INT_MAX, int tiled_from = INT_MAX, int tiled_to = INT_MAX, bool cols_only = false) {
   t.col_items.clear();
   t.row_items.clear();
   t.sel_items.clear();
@@ -971,7 +973,7 @@ void build_items(Tables& t, int kx, int y_begin, int y_end, int split_from = INT
       for (int c = 0; c < z.nchunk; ++c)
         for (int x0 = 0; x0 < cw; x0 += cpw) t.col_items.push_back(make_int4((int)i, x0, c, 0));
     }
-    const int y1 = std::min(y_end, z.zh);
+    const int y1 = cols_only ? std::max(y_begin, 0) : std::min(y_end, z.zh);      // (cols_only: the row loops below are empty)
     if (z.tiled) {
       const int ngrp = (z.dn + TL_X - 1) / TL_X, yb = std::max(y_begin, 0);
       for (int y0 = yb; y0 < y1; y0 += TL_R)
@@ -1312,7 +1314,7 @@ static int run_group(vwgpu_ctx* ctx, int cost_type, const float* A, int aw, int 
   for (const Seg& sg : segs) {
     const int yb = sg.yb, ye = sg.ye;
     const bool col_only = sg.col_only;
-    if (band != INT_MAX) build_items(match, kx, yb, ye, split_from, tiled_from, tiled_to);
+    if (band != INT_MAX) build_items(match, kx, yb, ye, split_from, tiled_from, tiled_to, col_only);
     if ((rc = upload(ctx, match, cur, end, &d))) return rc;
     switch (cost_type) {
       case VWGPU_CROSS_CORRELATION:
@@ -1372,7 +1374,12 @@ int vwgpu_launch_bm_exact(vwgpu_ctx* ctx, int cost_type, const float* A, int aw,
     bytes += need;
   }
   if (group.empty()) return VWGPU_OK;
-  return run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, group.data(), (int)group.size(), out, nullptr, gates_of(), rows, nranges);
+  int rcg = run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, group.data(), (int)group.size(), out, nullptr, gates_of(), rows, nranges);
+  if (rcg == VWGPU_ERR_LOGIC && rows && nranges > 0) {            // the partial path ran out of table space: the whole raster in the reference's order
+    ctx->err.clear();
+    rcg = run_group(ctx, cost_type, A, aw, ah, as, B, bw, bh, bs, kx, ky, group.data(), (int)group.size(), out, nullptr, gates_of(), nullptr, 0);
+  }
+  return rcg;
 }
 
 // fast_box_sum<double>(image, kernel) (Algorithms.h:41-43) in the reference's order.  d_out: (w-kx+1) x (h-ky+1) doubles, dense.
