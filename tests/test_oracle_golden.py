@@ -264,6 +264,106 @@ def test_ncc_winners_against_exact_rational_arithmetic(oracle, kernel, search):
     assert checked > 0.99 * oh * ow
 
 
+@pytest.mark.parametrize("k,sx", [(5, 12), (7, 20), (3, 6)])
+def test_sgm_integer_disparities_against_a_numpy_formulation(oracle, k, sx):
+    """SemiGlobalMatcher on full boxes (SGM.cc:2462-2612, :1013-1150, CensusTransform.h), written again from the textbook recurrence
+    L_r(p, d) = C(p, d) + min(L_r(p - r, d), L_r(p - r, d +- 1) + P1, min_k L_r(p - r, k) + P2') - min_k L_r(p - r, k), P2' = max(P1, P2 / |dI|),
+    the first pixel of a line taking its plain costs, the eight directions summed in u16, census bits = (neighbour > centre): wherever the sum
+    has a UNIQUE minimum (ties go through the reference's smoothing loop, which this formulation leaves out) the oracle must name it."""
+    rng = np.random.default_rng(50 + k)
+    H, W = 26, 34
+    left = rng.integers(0, 256, (H, W)).astype(np.float32)
+    right = rng.integers(0, 256, (H, W + sx)).astype(np.float32)
+    right[:, sx // 2:sx // 2 + W][4:, 6:] = left[4:, 6:]
+    left[0, 0], left[0, 1], right[0, 0], right[0, 1] = 0, 255, 0, 255          # full range: the u8 conversion is the identity
+    hk = k // 2
+    oh, ow = H - 2 * hk, W - 2 * hk
+    Li, Ri = left.astype(np.int64), right.astype(np.int64)
+
+    def census(img):
+        h, w = img.shape
+        c = img[hk:h - hk, hk:w - hk]
+        bits = [img[hk + j:h - hk + j, hk + i:w - hk + i] > c for j in range(-hk, hk + 1) for i in range(-hk, hk + 1) if (i, j) != (0, 0)]
+        return np.stack(bits, -1)
+    cl, cr = census(Li), census(Ri)                           # (oh, ow, n) and (oh, ow + sx, n)
+    D = sx + 1
+    C = np.stack([(cl != cr[:, d:d + ow]).sum(-1) for d in range(D)], -1).astype(np.int64)      # (oh, ow, D)
+    p1 = {3: 3, 5: 15, 7: 30}[k]
+    p2 = {3: 70, 5: 750, 7: 1500}[k]
+    grey = Li[hk:hk + oh, hk:hk + ow]
+    S = np.zeros((oh, ow, D), np.int64)
+    for dc, dr in [(0, 1), (0, -1), (1, 0), (-1, 0), (1, 1), (-1, 1), (1, -1), (-1, -1)]:
+        starts = set()
+        for c in range(ow):
+            for r in range(oh):
+                if not (0 <= c - dc < ow and 0 <= r - dr < oh):
+                    starts.add((c, r))
+        for (c, r) in starts:
+            prev = None
+            while 0 <= c < ow and 0 <= r < oh:
+                if prev is None:
+                    cur = C[r, c].copy()
+                else:
+                    g = abs(int(grey[r, c]) - int(grey[r - dr, c - dc]))
+                    pen = max(p1, p2 // g if g > 0 else p2)
+                    mp = prev.min()
+                    lo = np.concatenate(([prev[0]], prev[:-1])); hi = np.concatenate((prev[1:], [prev[-1]]))
+                    cur = C[r, c] + np.minimum(np.minimum(prev, np.minimum(lo, hi) + p1), mp + pen) - mp
+                S[r, c] += cur
+                prev = cur
+                c += dc; r += dr
+    assert S.max() < 65536
+    best = S.argmin(-1)
+    unique = (S == S.min(-1, keepdims=True)).sum(-1) == 1
+    oi, _ = oracle.calc_disparity_sgm(3, left, right, (sx, 0), k)
+    assert oi.shape == (oh, ow, 3)
+    assert unique.mean() > 0.9
+    assert np.array_equal(oi[..., 0][unique], best[unique])
+    assert (oi[..., 1][unique] == 0).all() and (oi[..., 2][unique] != 0).all()
+
+
+def test_parabola_offsets_against_a_least_squares_fit(oracle):
+    """ParabolaSubpixelView (ParabolaSubpixelView.cc:31-274, .h:83-88) from the mathematics: nine windowed SADs around the integer disparity, a
+    least-squares quadric z = a x^2 + b y^2 + c xy + d x + e y + f through them (numpy.linalg.lstsq instead of the reference's tabulated
+    pseudo-inverse), its stationary point as the offset, kept when shorter than 5 pixels.  Interior pixels (no edge extension), no prefilter."""
+    rng = np.random.default_rng(77)
+    h, w, kx, ky = 28, 36, 5, 7
+    hx, hy = kx // 2, ky // 2
+    left = (rng.random((h, w)) * 200).astype(np.float32)
+    right = (rng.random((h + 6, w + 8)) * 200).astype(np.float32)
+    disp = np.zeros((h, w, 3), np.float32)
+    disp[..., 0] = rng.integers(1, 5, (h, w)); disp[..., 1] = rng.integers(1, 3, (h, w)); disp[..., 2] = 1.0
+    for y in range(h):                                      # a smooth right image around the true match: the quadric has a minimum nearby
+        for x in range(w):
+            right[y + int(disp[y, x, 1]), x + int(disp[y, x, 0])] = left[y, x] * 0.9 + 5.0
+    disp[3, 4, 2] = 0.0
+    got = oracle.parabola_subpixel(disp, left, right, 0, 0.0, (kx, ky))
+    gx, gy = np.meshgrid([-1.0, 0.0, 1.0], [-1.0, 0.0, 1.0])
+    Amat = np.stack([gx.ravel() ** 2, gy.ravel() ** 2, (gx * gy).ravel(), gx.ravel(), gy.ravel(), np.ones(9)], 1)
+    checked = 0
+    for y in range(hy + 1, h - hy - 1):
+        for x in range(hx + 1, w - hx - 1):
+            if disp[y, x, 2] == 0:
+                assert (got[y, x] == 0).all()
+                continue
+            Dx, Dy = int(disp[y, x, 0]), int(disp[y, x, 1])
+            lwin = left[y - hy:y + hy + 1, x - hx:x + hx + 1].astype(np.float64)
+            z = np.empty(9)
+            for ddy in (-1, 0, 1):
+                for ddx in (-1, 0, 1):
+                    ry, rx = y + Dy + ddy, x + Dx + ddx
+                    z[(ddy + 1) * 3 + ddx + 1] = np.abs(lwin - right[ry - hy:ry + hy + 1, rx - hx:rx + hx + 1]).sum()
+            a, b, c, d, e, _ = np.linalg.lstsq(Amat, z, rcond=None)[0]
+            den = 4 * a * b - c * c
+            ox, oy = (c * e - 2 * b * d) / den, (c * d - 2 * a * e) / den
+            want = (Dx + ox, Dy + oy) if np.hypot(ox, oy) < 5.0 else (Dx, Dy)
+            if abs(np.hypot(ox, oy) - 5.0) < 1e-3: continue      # on the acceptance threshold: float32 may fall either way
+            assert abs(got[y, x, 0] - want[0]) < 2e-3 * max(1.0, abs(ox)) and abs(got[y, x, 1] - want[1]) < 2e-3 * max(1.0, abs(oy)), (y, x, got[y, x], want)
+            assert got[y, x, 2] != 0
+            checked += 1
+    assert checked > 400
+
+
 def test_pyramid_level_against_scipy(oracle):
     """subsample(separable_convolution_filter(img, k, k), 2) (CorrelationView.cc:38-63): scipy's correlate1d in float64 with the nearest-pixel
     edge, every second pixel — the oracle's float accumulation agrees to float32 rounding."""
