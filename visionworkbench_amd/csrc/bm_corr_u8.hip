@@ -306,21 +306,35 @@ ncc_full_kernel(const float* __restrict__ L, ptrdiff_t ls, const float* __restri
   }
   const int lane = threadIdx.x & 63;
   const u32 nwaves = gridDim.x * 4u;
+  // Round 6: the ky rows of the right image a pixel's windows can reach (kx + sx - 1 values each) and its left window go to a wave-private LDS
+  // area once, as integers; the 129 x 121 products then read LDS (the left value of a product is one address for the whole wave: a broadcast)
+  // instead of asking the L1 for every operand again (130 -> 6x us for the ~2 % of the bench pair's pixels that are queued).
+  extern __shared__ u32 full_lds[];
+  const int rwid = kx + sx - 1;
+  u32* const Rw = full_lds + (size_t)(threadIdx.x >> 6) * ((size_t)ky * rwid + (size_t)ky * kx);
+  u32* const Lw = Rw + (size_t)ky * rwid;
   for (u32 e = blockIdx.x * 4u + (threadIdx.x >> 6); e < total; e += nwaves) {
     const u32 p = full_list[e];
     const int y = (int)(p / (u32)ow), x = (int)(p - (u32)y * (u32)ow);
     const double pl = 1.0 / (double)a2img[p];
     double best = 0.0, worst = 0.0;
     int bd = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the previous pixel's reads are done (a wave's LDS operations complete in order)
+    for (int j = 0; j < ky; ++j) {
+      const float* rp = R + (ptrdiff_t)(y + j) * rs + x;
+      for (int c = lane; c < rwid; c += 64) Rw[j * rwid + c] = (u32)rp[c];
+      if (lane < kx) Lw[j * kx + lane] = (u32)L[(ptrdiff_t)(y + j) * ls + x + lane];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int d0 = 0; d0 < sx; d0 += 64) {
       const int d = d0 + lane;
       const bool act = d < sx;
       u32 S = 0;
       if (act)
         for (int j = 0; j < ky; ++j) {
-          const float* lp = L + (ptrdiff_t)(y + j) * ls + x;
-          const float* rp = R + (ptrdiff_t)(y + j) * rs + x + d;
-          for (int i = 0; i < kx; ++i) S += (u32)lp[i] * (u32)rp[i];
+          const u32* lp = Lw + j * kx;
+          const u32* rp = Rw + j * rwid + d;
+          for (int i = 0; i < kx; ++i) S += lp[i] * rp[i];
         }
       double v = act ? (double)S * sqrt(pl * (1.0 / (double)b2img[(size_t)y * b2w + x + d])) : -1.0;   // scores are >= 0
       double w = act ? v : INFINITY;
@@ -430,7 +444,8 @@ int vwgpu_launch_ncc_full(vwgpu_ctx* ctx, const float* left, ptrdiff_t ls, const
                           const uint32_t* a2, const uint32_t* b2, int b2w, int32_t* out, ptrdiff_t os, int ow, int* flag,
                           const uint32_t* full_list, const uint32_t* full_count, uint32_t cap) {
   vwgpu_prof_scope ps(ctx, "ncc_full");
-  hipLaunchKernelGGL(ncc_full_kernel, dim3(2048), dim3(256), 0, ctx->stream, left, ls, right, rs, kx, ky, sx, a2, b2, b2w,
+  const size_t full_lds = (size_t)4 * ((size_t)ky * (kx + sx - 1) + (size_t)ky * kx) * sizeof(uint32_t);      // kx, ky <= 11 (64 lanes cover a window row), sx <= 256: <= 49 KB
+  hipLaunchKernelGGL(ncc_full_kernel, dim3(2048), dim3(256), full_lds, ctx->stream, left, ls, right, rs, kx, ky, sx, a2, b2, b2w,
                      out, os, ow, flag, full_list, full_count, cap);
   VWGPU_HIP(ctx, hipGetLastError());
   return VWGPU_OK;
