@@ -6,10 +6,13 @@
 //   constrain_disp_bound_image      SGM.cc:502-672               constrain_kernel (full-search pixels adopt the box of their neighbours)
 //   calc_main_buf_size              SGM.cc:677-731               row_count_kernel + host prefix over rows + row_scan_kernel (ragged starts)
 //   compute_disparity_costs         SGM.cc:1740-1893, :40-75     cost_kernel: popcount(left_census ^ right_census) inside each pixel's bounds
-//   accum_sgm_multithread           SGM.cc:2462-2612             one wavefront per scan line: path_uniform_reg_kernel (one search row, every
-//                                                                pixel the full range: path vector in registers, one direction per launch,
-//                                                                plain read-modify-write of the sums), path_uniform_kernel / path_inplace_kernel
-//                                                                / path_kernel (2-D or ragged boxes, all directions in one launch, atomics)
+//   accum_sgm_multithread           SGM.cc:2462-2612             one wavefront per scan line, path vector in registers, one direction per launch,
+//                                                                plain read-modify-write of the sums: path_ring_kernel (round 6: one search row,
+//                                                                every pixel the full range, strides <= 160 B; costs and sums prefetched by
+//                                                                LDS-DMA into a ring per wave, four neighbouring lines per workgroup),
+//                                                                path_uniform_reg_kernel (round 2: prefetch in registers; wider vectors),
+//                                                                path_uniform_kernel / path_inplace_kernel / path_kernel (2-D or ragged boxes,
+//                                                                all directions in one launch, atomics)
 //   evaluate_path (SSE semantics)   SGM.cc:936-984, 1013-1150    saturating u16 add/sub, 8-neighbour 2-D disparity adjacency with
 //                                                                repetition at the global range border, BAD_VAL outside the prior's box
 //   select_best_disparity           SGM.cc:1159-1284             wta_kernel: (value << 16 | index) min = first minimum; tie smoothing loop
@@ -19,7 +22,8 @@
 // into two ragged arrays: cost (u8) and accumulated cost (u16) — the reference's m_cost_buffer / m_accum_buffer
 // (SGM.cc:733-751).  Algorithmic bytes ("materialised volume" model): 20 + 11 D bytes per pixel
 // (D = disparities per pixel): cost written once (D) and read by 8 paths, accum read-modify-written per path — 23 GB for
-// 2048^2 x 129, which is what bounds the uniform path today (5.5 ms = 4.2 TB/s; the recurrence alone runs in 2.9 ms).
+// 2048^2 x 129: the seven read-modify-write passes run at 4.5-4.9 TB/s of mixed traffic, the first and the last pass at the issue rate of the
+// recurrence (round 6: 5.05 ms; the recurrence alone 3.9 ms; profiles/r06_sgm_traffic.md).
 #include <algorithm>
 #include <cmath>
 #include <vector>
