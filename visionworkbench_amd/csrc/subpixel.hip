@@ -193,10 +193,10 @@ parabola_kernel(const float* __restrict__ disp, int w, int h, ptrdiff_t dstride_
     // The rasters are bytes here (f32_to_u8_raster_kernel, pitches lrw / rrw in bytes): nw + 1 aligned dwords and one
     // v_alignbyte per dword give the packed bytes starting at any x — 9 loads and 7 ALU ops per row pair of the window instead of
     // 24 float loads and 24 conversions (the float form ran into the L1: 21 GB through it for a 4096^2 image).
-    auto pack_row = [&](const uint8_t* p, int n, unsigned* w, int nw) __attribute__((always_inline)) {
-      (void)n;
-      const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);
-      const unsigned* a = reinterpret_cast<const unsigned*>(p - sh);
+    // (the pitches are multiples of 4 — vwgpu_parabola_u8_pitch — so the byte phase of a window is the same in every row: the aligned dword
+    // pointer and the shift are formed ONCE per image and the rows are a pitch apart; round 6: the per-row (address & 3, subtract) pair was
+    // a seventh of the kernel's instructions)
+    auto pack_row = [&](const unsigned* a, unsigned sh, unsigned* w, int nw) __attribute__((always_inline)) {
       unsigned raw[NB + 1];
 #pragma unroll
       for (int j = 0; j <= nw; ++j) raw[j] = a[j];
@@ -205,16 +205,21 @@ parabola_kernel(const float* __restrict__ disp, int w, int h, ptrdiff_t dstride_
     };
     const uint8_t* lbase8 = reinterpret_cast<const uint8_t*>(lras) + (ptrdiff_t)y * lrw + x;
     const uint8_t* rras8 = reinterpret_cast<const uint8_t*>(rras);
+    const unsigned lsh = (unsigned)(reinterpret_cast<uintptr_t>(lbase8) & 3u);
+    const unsigned* const lrow32 = reinterpret_cast<const unsigned*>(lbase8 - lsh);
+    const int lpd = lrw >> 2, rpd = rrw >> 2;
     unsigned la[NW], lb[NW], lc[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) { la[j] = 0u; lb[j] = 0u; }
-    pack_row(lbase8, K, lc, NW);
+    pack_row(lrow32, lsh, lc, NW);
     lc[NW - 1] &= LAST;
-    const uint8_t* rrow = rras8 + (ptrdiff_t)(y + Dy - 1 - range_miny) * rrw + (x + Dx - 1 - range_minx);
+    const uint8_t* rrow8 = rras8 + (ptrdiff_t)(y + Dy - 1 - range_miny) * rrw + (x + Dx - 1 - range_minx);
+    const unsigned rsh = (unsigned)(reinterpret_cast<uintptr_t>(rrow8) & 3u);
+    const unsigned* rrow = reinterpret_cast<const unsigned*>(rrow8 - rsh);
     const int kyy = KY > 0 ? KY : ky;
     auto row_step = [&](int q) __attribute__((always_inline)) {
       unsigned rb[NB];
-      pack_row(rrow, K + 2, rb, NB);
+      pack_row(rrow, rsh, rb, NB);
       unsigned rs[3][NW];                                  // the window bytes at x shift b = 0, 1, 2
 #pragma unroll
       for (int b = 0; b < 3; ++b)
@@ -244,10 +249,10 @@ parabola_kernel(const float* __restrict__ disp, int w, int h, ptrdiff_t dstride_
 #pragma unroll
       for (int j = 0; j < NW; ++j) { la[j] = lb[j]; lb[j] = lc[j]; }
       if (q + 2 < kyy) {
-        pack_row(lbase8 + (ptrdiff_t)(q + 2) * lrw, K, lc, NW);
+        pack_row(lrow32 + (ptrdiff_t)(q + 2) * lpd, lsh, lc, NW);
         lc[NW - 1] &= LAST;
       }
-      rrow += rrw;
+      rrow += rpd;
     };
     if constexpr (KY > 0) {
 #pragma unroll
