@@ -155,6 +155,8 @@ const char* vwgpu_last_error(const vwgpu_ctx* ctx);
  *       kernel: < 4 = one line), bit 5 = the round-2 kernel that prefetches into registers (path_uniform_reg_kernel) instead of the LDS ring
  *       (path_ring_kernel, vector strides up to 160 bytes), bits 8-10 = log2 of the consecutive workgroups given to one XCD, bit 11 = the ring
  *       kernel forms the census costs itself from the census rasters (up to 129 disparities; no u8 cost volume; measured slower).
+ *       Ragged boxes (a previous level's disparities given): bit 4 / bit 7 = four / two scan lines per wavefront whatever the level's boxes
+ *       (path_multi_kernel; default: chosen per level from the share of small boxes), bit 6 = always one line per wavefront.
  *   VWGPU_OPT_EXACT_SPLIT      pass 2 of the exact-order matchers: 0 = chosen by the width of a zone (the recurrence alone + a parallel
  *       selection for zones of 1024 pixels and more (whole rasters), the tiled form — row sums transposed through LDS — for narrower
  *       ones), 1 = always the split form, 2 = always the fused form (selection across the disparity lanes inside the chain), 3 = always

@@ -431,6 +431,38 @@ def test_user_penalties_incl_u16_wrap(vw, oracle, p1, p2):
     assert np.array_equal(gi, oi) and np.abs(gs - os_).max() < 1e-5
 
 
+@pytest.mark.parametrize("mode", [16, 128, 64, 0])
+@pytest.mark.parametrize("p1,p2,sx,sy,w,h,bad", [(0, 0, 40, 2, 150, 97, 0.03), (0, 0, 127, 2, 90, 140, 0.2), (1, 65000, 24, 1, 77, 50, 0.05),
+                                                  (0, 0, 30, 0, 200, 33, 0.0), (0, 0, 70, 3, 64, 64, 0.5)])
+def test_several_lines_per_wavefront_on_ragged_boxes(vw, oracle, mode, p1, p2, sx, sy, w, h, bad):
+    """Ragged boxes from a previous level through path_multi_kernel (SGM_PATH_MODE bit 4: four lines per wavefront, bit 7: two, bit 6: the
+    one-line kernel, 0: chosen by the level): boxes of up to 16 / 32 cells in a group's own lanes, pixels without a trusted coarser disparity
+    (whole range: more cells than a wavefront has lanes) on all lanes, patches of them, lines of unequal length in one wavefront, a number of
+    lines that does not fill the last wavefront, penalties that separate the directions (plain u16 sums instead of atomics)."""
+    from visionworkbench_amd import core
+    ctx = core.default_context(0)
+    k = 5
+    rng = np.random.default_rng(sx * 7 + sy + w)
+    shift = sx // 2
+    base = rng.integers(0, 256, (h + sy + 8, w + sx + 8)).astype(np.float32)
+    left = np.ascontiguousarray(base[4:4 + h, 4 + shift:4 + shift + w])
+    right = np.ascontiguousarray(base[4:4 + h + sy, 4:4 + w + sx])
+    oh, ow = h - k + 1, w - k + 1
+    prev = np.zeros(((oh + 1) // 2, (ow + 1) // 2, 3), np.int32)
+    prev[..., 0] = shift // 2 + rng.integers(-1, 2, prev.shape[:2]); prev[..., 1] = rng.integers(0, sy // 2 + 1, prev.shape[:2])
+    prev[..., 2] = np.where(rng.random(prev.shape[:2]) < bad, 0, np.iinfo(np.int32).max)
+    prev[prev.shape[0] // 3:prev.shape[0] // 3 + 9, 5:25, 2] = 0                 # a patch of untrusted pixels
+    ctx.set_option(core.OPT_SGM_PATH_MODE, mode)
+    try:
+        gi, gs = vw.calc_disparity_sgm(CENSUS, left, right, _box(w, h), (sx, sy), (k, k), subpixel_mode=5, with_subpixel=True, p1=p1, p2=p2,
+                                       prev_disparity=prev, ctx=ctx)
+    finally:
+        ctx.set_option(core.OPT_SGM_PATH_MODE, 0)
+    oi, os_ = oracle.calc_disparity_sgm(CENSUS, left, right, (sx, sy), k, subpixel=5, p1=p1, p2=p2, prev_disparity=prev)
+    assert np.array_equal(gi, oi), int((gi != oi).any(-1).sum())
+    assert np.abs(gs - os_).max() < 1e-5
+
+
 @pytest.mark.parametrize("sx,sy,k,w,h", [(4, 0, 7, 40, 30), (8, 0, 7, 60, 48), (3, 1, 5, 20, 16), (16, 0, 7, 100, 80)])
 def test_uniform_path_detected_from_the_boxes(vw, oracle, sx, sy, k, w, h):
     """All-valid masks (the top level of every pyramid): the boxes come out full everywhere and the uniform kernel runs;

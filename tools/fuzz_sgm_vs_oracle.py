@@ -10,6 +10,11 @@ import oracle
 from visionworkbench_amd import stereo
 from visionworkbench_amd.core import BBox2i
 
+import os
+if os.environ.get("SGM_PATH_MODE"):      # VWGPU_OPT_SGM_PATH_MODE of the default context (e.g. 16 / 128: four / two lines per wavefront on ragged boxes)
+    from visionworkbench_amd import core
+    core.default_context(0).set_option(core.OPT_SGM_PATH_MODE, int(os.environ["SGM_PATH_MODE"]))
+
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 MGM = len(sys.argv) > 3 and sys.argv[3] == "mgm"

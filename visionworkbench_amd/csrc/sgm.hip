@@ -12,7 +12,8 @@
 //                                                                LDS-DMA into a ring per wave, four neighbouring lines per workgroup),
 //                                                                path_uniform_reg_kernel (round 2: prefetch in registers; wider vectors),
 //                                                                path_uniform_kernel / path_inplace_kernel / path_kernel (2-D or ragged boxes,
-//                                                                all directions in one launch, atomics)
+//                                                                all directions in one launch, atomics), path_multi_kernel (round 6: ragged
+//                                                                boxes of a large level, two or four scan lines per wavefront)
 //   evaluate_path (SSE semantics)   SGM.cc:936-984, 1013-1150    saturating u16 add/sub, 8-neighbour 2-D disparity adjacency with
 //                                                                repetition at the global range border, BAD_VAL outside the prior's box
 //   select_best_disparity           SGM.cc:1159-1284             wta_kernel: (value << 16 | index) min = first minimum; tie smoothing loop
@@ -236,15 +237,25 @@ constrain_kernel(SgmGeom g, const uint8_t* __restrict__ full_search, B4* __restr
 
 // ---- ragged starts ----------------------------------------------------------------------------------------------------
 
+// rowsum[r] = cells of row r; rowsum[gridDim.x + r] = its pixels with boxes of at most 16 cells (low word) and of at most 32 (high word);
+// rowsum[2 gridDim.x + r] = the cells of the former: what the lines-per-wavefront of the ragged path kernel is chosen by
 __global__ void row_count_kernel(const B4* __restrict__ bounds, int ocols, unsigned long long* __restrict__ rowsum) {
   const int r = blockIdx.x;
-  unsigned long long s = 0;
-  for (int c = threadIdx.x; c < ocols; c += blockDim.x) s += (unsigned long long)b4_count(bounds[(size_t)r * ocols + c]);
-  __shared__ unsigned long long sh[256];
-  sh[threadIdx.x] = s;
+  unsigned long long s = 0, small = 0, cells16 = 0;
+  for (int c = threadIdx.x; c < ocols; c += blockDim.x) {
+    const int n = b4_count(bounds[(size_t)r * ocols + c]);
+    s += (unsigned long long)n;
+    small += (n <= 16 ? 1ull : 0ull) + (n <= 32 ? 1ull << 32 : 0ull);
+    cells16 += n <= 16 ? (unsigned long long)n : 0ull;
+  }
+  __shared__ unsigned long long sh[256], shm[256], shc[256];
+  sh[threadIdx.x] = s; shm[threadIdx.x] = small; shc[threadIdx.x] = cells16;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
-  if (threadIdx.x == 0) rowsum[r] = sh[0];
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { sh[threadIdx.x] += sh[threadIdx.x + o]; shm[threadIdx.x] += shm[threadIdx.x + o]; shc[threadIdx.x] += shc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { rowsum[r] = sh[0]; rowsum[gridDim.x + r] = shm[0]; rowsum[2 * gridDim.x + r] = shc[0]; }
 }
 
 __global__ void row_scan_kernel(const B4* __restrict__ bounds, int ocols, const unsigned long long* __restrict__ rowoff,
@@ -1015,6 +1026,237 @@ path_inplace_kernel(SgmGeom g, DirSet D,
     lds_barrier();
     bp = b; last_val = cur;
     b = uni(b_n); st = uni64(st_n); cur = __builtin_amdgcn_readfirstlane(cur_n); cv0 = cn0; cv1 = cn1;
+  }
+}
+
+// Minimum over each group of SUB = 16 or 32 consecutive lanes, returned to every lane of the group.
+template <int SUB>
+__device__ __forceinline__ unsigned sub_min_u32_fused(unsigned v, int lane) {
+  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1"
+               : "+v"(v));
+  if constexpr (SUB == 32) {
+    asm volatile("v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1" : "+v"(v));
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)v, 31), hi = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+    return lane >= 32 ? hi : lo;
+  }
+  return v;
+}
+
+// The ragged recurrence of path_inplace_kernel with 64 / SUB scan lines per wavefront, SUB = 16 or 32 lanes each (round 6).  The boxes of a
+// pyramid level descend from the coarser level's disparities +- a margin: at level 0 of a 1024^2 tile with a 129 x 3 search 92 % of the
+// pixels have 15 cells, at the levels above 5-12 — a quarter of a wavefront's lanes, and the kernel is bound by the vector instructions of
+// a step.  A group of SUB lanes owns a line: what was wave-uniform (records of the pixel, vector start, grey step, minimum of the previous
+// vector) is per lane and equal within the group, the full-range buffer exists once per group, the minimum is a group reduction, and a
+// step ends when every group has finished its pixel.  A box of more than SUB cells (pixels without a trusted coarser disparity search the
+// whole range: 1.5 % of the pixels, a quarter of the cells) is served by ALL lanes of the wavefront, one such line after the other, with
+// the line's records broadcast and the new values staged in a vector of their own.
+// Same arithmetic per line as path_inplace_kernel (evaluate_path, SGMAssist.h:705-819; accum_sgm_multithread, SGM.cc:2488-2610).
+template <int SUB>
+__global__ void __launch_bounds__(64)
+path_multi_kernel(SgmGeom g, DirSet D, int lines, int spread,
+                  const uint8_t* __restrict__ left, int lw, int min_col, int min_row,
+                  const B4* __restrict__ bounds, const unsigned long long* __restrict__ starts,
+                  const uint8_t* __restrict__ cost, uint16_t* __restrict__ accum, unsigned p1, unsigned p2) {
+  constexpr int NSUB = 64 / SUB;
+  extern __shared__ uint16_t sm[];
+  const int num_disp = g.num_dx * g.num_dy;
+  const int fpn = (num_disp + 1) & ~1;
+  const int lane = threadIdx.x, hl = lane & (SUB - 1), sub = lane / SUB;
+  uint16_t* full_prior = sm + sub * fpn;            // num_disp per group
+  uint16_t* p2tab = sm + NSUB * fpn;                // 256: max(P1, P2 / |grey step|), the adaptive P2 of SGM.cc:813-818
+  uint16_t* stage = p2tab + 256;                    // num_disp: the new vector of a large box
+  // A wavefront's lines are `spread` lines apart: pixels without a trusted coarser disparity come in patches, a line inside one is slow for
+  // as long as it stays there, and neighbouring lines are slow TOGETHER — a wavefront that owns one of them at a time falls less far behind
+  // the others than one that owns four (the launch ends with its slowest wavefront).
+  const int line = ((int)blockIdx.x / spread) * (NSUB * spread) + (int)blockIdx.x % spread + sub * spread;
+  int c, r, dc, dr;
+  line_start(D, g, line < lines ? line : 0, dc, dr, c, r);
+  const unsigned BAD = (255u + p2) & 0xffffu;
+  for (int i = lane; i < NSUB * fpn; i += 64) sm[i] = (uint16_t)BAD;
+  for (int q = lane; q < 256; q += 64) {
+    unsigned v = p2;
+    if (q > 0) v /= (unsigned)q;
+    if (v < p1) v = p1;
+    p2tab[q] = (uint16_t)v;
+  }
+  lds_barrier();
+  const long long delta = (long long)dr * g.ocols + dc;         // pixel index step along the line
+  const long long ldelta = (long long)dr * lw + dc;
+  int len = 0;                                                  // steps of the line inside the image
+  if (line < lines && c >= 0 && r >= 0 && c < g.ocols && r < g.orows) {
+    const int len_c = dc > 0 ? g.ocols - c : (dc < 0 ? c + 1 : 0x7fffffff);
+    const int len_r = dr > 0 ? g.orows - r : (dr < 0 ? r + 1 : 0x7fffffff);
+    len = min(len_c, len_r);
+  }
+  auto group_max = [&](int v) __attribute__((always_inline)) {  // the largest of the groups' (group-uniform) values, wave-uniform
+    int m = max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 32));
+    if (NSUB == 4) m = max(m, max(__builtin_amdgcn_readlane(v, 16), __builtin_amdgcn_readlane(v, 48)));
+    return m;
+  };
+  // (a group without a line reads the records of pixel 0 and never writes)
+  long long p = len > 0 ? (long long)r * g.ocols + c : 0;
+  long long lp = len > 0 ? (long long)(r + min_row) * lw + (c + min_col) : (long long)min_row * lw + min_col;
+  const int maxlen = group_max(len);
+  // The records (box, vector start, grey value) are requested TWO pixels ahead and the cost bytes one: a step of four short lines is over
+  // before a memory round trip is, and the sums' atomics of the step before sit in the same in-order queue as the loads.
+  B4 b = bounds[p];
+  unsigned long long st = starts[p];
+  int cur = left[lp];
+  if (1 < len) { p += delta; lp += ldelta; }
+  B4 b_n = bounds[p];
+  unsigned long long st_n = starts[p];
+  int cur_n = left[lp];
+  unsigned cv0 = cost[st + max(min(hl, b4_count(b) - 1), 0)];     // cost[st + hl] of the current pixel (prefetched, clamped)
+  // cost bytes of the large boxes of the coming step: chunk k of group s's vector, element 64 k + lane
+  constexpr int KC = 8;
+  unsigned cbig[NSUB][KC];
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+    for (int k = 0; k < KC; ++k) cbig[s][k] = 0;
+  auto request_big = [&](const B4& bb, unsigned long long stt, bool on_line) __attribute__((always_inline)) {
+    const int ndl = on_line ? b4_count(bb) : 0;
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(ndl > SUB);
+    if (mask == 0) return;
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+      if (!((mask >> (s * SUB)) & 1ull)) continue;               // wave-uniform
+      const int l0 = s * SUB;
+      const int nd_s = __builtin_amdgcn_readlane(ndl, l0);
+      const unsigned long long st_s = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)stt, l0) |
+                                      ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(stt >> 32), l0) << 32);
+#pragma unroll
+      for (int k = 0; k < KC; ++k)
+        if (64 * k < nd_s) cbig[s][k] = cost[st_s + (unsigned)min(64 * k + lane, nd_s - 1)];
+    }
+  };
+  request_big(b, st, len > 0);
+  int last_val = -1;
+  unsigned min_prior = 0;
+  B4 bp{0, 0, -1, -1};
+  // value of the box's element i from the previous vector, and its cell in the full-range buffer: value | cell << 16
+  auto eval = [&](int i, unsigned cb, const B4& bb, int wd, float inv_wd, const uint16_t* fp, bool has_prior, unsigned dJ, unsigned minp)
+      __attribute__((always_inline)) -> unsigned {
+    int qy, qx;
+    divmod_f(i, wd, inv_wd, qy, qx);
+    const int dx = bb.x0 + qx, dy = bb.y0 + qy;
+    const int xo = dx - g.min_dx, yo = dy - g.min_dy;
+    unsigned v = cb;
+    if (has_prior) {
+      const int xl = dx - 1 < g.min_dx ? xo : xo - 1, xm = dx + 1 > g.max_dx ? xo : xo + 1;
+      const int yl = (dy - 1 < g.min_dy ? yo : yo - 1) * g.num_dx, ym = (dy + 1 > g.max_dy ? yo : yo + 1) * g.num_dx, yc = yo * g.num_dx;
+      unsigned m = fp[yl + xo];
+      m = min(m, (unsigned)fp[yc + xl]); m = min(m, (unsigned)fp[yc + xm]); m = min(m, (unsigned)fp[ym + xo]);
+      m = min(m, (unsigned)fp[yl + xl]); m = min(m, (unsigned)fp[yl + xm]);
+      m = min(m, (unsigned)fp[ym + xl]); m = min(m, (unsigned)fp[ym + xm]);
+      v = adds16(m, p1);
+      v = min(v, min((unsigned)fp[yc + xo], dJ));
+      v = adds16(v, cb);
+      v = subs16(v, minp);
+    }
+    return v | ((unsigned)(yo * g.num_dx + xo) << 16);
+  };
+  // an element goes to its cell and to the sums.  One 32-bit atomic per pair of u16 elements (see path_inplace_kernel); `edge`: the last lane
+  // of those that share the vector — it never takes its right neighbour's value; `first`: the first of them always adds its own element.
+  auto commit = [&](unsigned rcv, unsigned long long e, uint16_t* fp, unsigned& mn, bool first, bool edge) __attribute__((always_inline)) {
+    const unsigned cell = rcv >> 16, val = rcv & 0xffffu;
+    const bool on = cell != 0xffffu;
+    if (on) {
+      fp[cell] = (uint16_t)val;
+      mn = min(mn, val);
+    }
+    const unsigned mine = on ? val : 0u;
+    const unsigned next = wave_shl1(mine, 0u);
+    const bool low = (e & 1ull) == 0;
+    if (D.n == 1) {                                     // one direction per launch: plain u16 sums (see accum_add_u16)
+      if (on) accum[e] = (uint16_t)(accum[e] + mine);
+    } else if (on && (low || first)) {
+      const unsigned v = low ? (mine | (edge ? 0u : next << 16)) : (mine << 16);
+      atomicAdd(reinterpret_cast<unsigned*>(accum) + (e >> 1), v);
+    }
+  };
+  for (int step = 0; step < maxlen; ++step) {
+    const bool act = step < len;
+    const int wd = b.x1 - b.x0 + 1, nd = act ? wd * (b.y1 - b.y0 + 1) : 0;
+    const bool big = nd > SUB;
+    const unsigned long long bigmask = __builtin_amdgcn_ballot_w64(big);
+    // the records of the pixel after the next one; no load under a condition (path_inplace_kernel)
+    if (step + 2 < len) { p += delta; lp += ldelta; }
+    const B4 b_nn = bounds[p];
+    const unsigned long long st_nn = starts[p];
+    const int cur_nn = left[lp];
+    const float inv_wd = __builtin_amdgcn_rcpf((float)max(wd, 1));
+    int grad = cur - last_val; grad = grad < 0 ? -grad : grad;
+    const unsigned dJ = (min_prior + (unsigned)p2tab[last_val >= 0 ? grad : 0]) & 0xffffu;
+    // ---- the lines whose box fits the group: reads of the previous vector, barrier, the new vector
+    unsigned rc = 0xffffffffu;
+    if (hl < nd && !big) rc = eval(hl, cv0, b, wd, inv_wd, full_prior, last_val >= 0, dJ, min_prior);
+    const unsigned cn0 = cost[st_n + max(min(hl, b4_count(b_n) - 1), 0)];      // the next pixel's first cost bytes
+    lds_barrier();
+    unsigned mn = BAD;                            // (the minimum of an empty vector is BAD_VAL, SGMAssist.h)
+    commit(rc, st + (unsigned)hl, full_prior, mn, hl == 0, hl == SUB - 1);
+    unsigned new_min = sub_min_u32_fused<SUB>(mn, lane);
+    // ---- the lines with a large box, one after the other, on all 64 lanes
+    if (bigmask != 0) {
+#pragma unroll
+      for (int s = 0; s < NSUB; ++s) {
+        if (!((bigmask >> (s * SUB)) & 1ull)) continue;          // wave-uniform
+        const int l0 = s * SUB;
+        const B4 bs{__builtin_amdgcn_readlane(b.x0, l0), __builtin_amdgcn_readlane(b.y0, l0), __builtin_amdgcn_readlane(b.x1, l0), __builtin_amdgcn_readlane(b.y1, l0)};
+        const unsigned long long st_s = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)st, l0) |
+                                        ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(st >> 32), l0) << 32);
+        const int wd_s = bs.x1 - bs.x0 + 1, nd_s = wd_s * (bs.y1 - bs.y0 + 1);
+        const float inv_s = __builtin_amdgcn_rcpf((float)wd_s);
+        const bool prior_s = __builtin_amdgcn_readlane(last_val, l0) >= 0;
+        const unsigned dJ_s = (unsigned)__builtin_amdgcn_readlane((int)dJ, l0), minp_s = (unsigned)__builtin_amdgcn_readlane((int)min_prior, l0);
+        uint16_t* fp_s = sm + s * fpn;
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+          if (64 * k < nd_s && 64 * k + lane < nd_s) stage[64 * k + lane] = (uint16_t)eval(64 * k + lane, cbig[s][k], bs, wd_s, inv_s, fp_s, prior_s, dJ_s, minp_s);
+        for (int i = 64 * KC + lane; i < nd_s; i += 64) stage[i] = (uint16_t)eval(i, (unsigned)cost[st_s + (unsigned)i], bs, wd_s, inv_s, fp_s, prior_s, dJ_s, minp_s);
+        lds_barrier();
+        unsigned mn_s = BAD;
+        for (int i0 = 0; i0 < nd_s; i0 += 64) {                  // (every lane takes part in every trip: the neighbour exchange of commit)
+          const int i = i0 + lane;
+          unsigned rcv = 0xffffffffu;
+          if (i < nd_s) {
+            int qy, qx;
+            divmod_f(i, wd_s, inv_s, qy, qx);
+            rcv = (unsigned)stage[i] | ((unsigned)((bs.y0 + qy - g.min_dy) * g.num_dx + (bs.x0 + qx - g.min_dx)) << 16);
+          }
+          commit(rcv, st_s + (unsigned)i, fp_s, mn_s, lane == 0, lane == 63);
+        }
+        mn_s = wave_min_u32_fused(mn_s);
+        if (sub == s) new_min = mn_s;
+        lds_barrier();                                          // `stage` is free again
+      }
+    }
+    request_big(b_n, st_n, step + 1 < len);                     // (their registers are free now)
+    // cells only the previous box covered go back to BAD_VAL
+    const bool shrunk = act && last_val >= 0 && (bp.x0 < b.x0 || bp.x1 > b.x1 || bp.y0 < b.y0 || bp.y1 > b.y1);
+    if (__builtin_amdgcn_ballot_w64(shrunk) != 0) {
+      const int wp = bp.x1 - bp.x0 + 1, np = shrunk ? wp * (bp.y1 - bp.y0 + 1) : 0;
+      const int npmax = group_max(np);
+      const float inv_wp = __builtin_amdgcn_rcpf((float)max(wp, 1));
+      for (int i = hl; i < npmax; i += SUB) {
+        if (i < np) {
+          int qy, qx;
+          divmod_f(i, wp, inv_wp, qy, qx);
+          const int dx = bp.x0 + qx, dy = bp.y0 + qy;
+          if (dx < b.x0 || dx > b.x1 || dy < b.y0 || dy > b.y1)
+            full_prior[(dy - g.min_dy) * g.num_dx + (dx - g.min_dx)] = (uint16_t)BAD;
+        }
+      }
+    }
+    min_prior = new_min;
+    lds_barrier();
+    if (act) { bp = b; last_val = cur; }
+    b = b_n; st = st_n; cur = cur_n; cv0 = cn0;
+    b_n = b_nn; st_n = st_nn; cur_n = cur_nn;
   }
 }
 
@@ -2926,7 +3168,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   // (guard zones around the census rasters: the register-resident path kernel requests census words up to 2 KC steps past a line's end)
   const size_t cen_guard = (size_t)2 * VWGPU_PATH_KC * ((size_t)std::max(lcw, rcw) + 1) + 64;
   const size_t fixed = (size_t)lw * lh + (size_t)rw * rh + 8 * ((size_t)lcw * lch + (size_t)rcw * rch + 3 * cen_guard) + npix * (16 + 8 + 1) +
-                       (size_t)g.orows * (8 + 8 + 8) + (1 << 16);
+                       (size_t)g.orows * (24 + 8 + 8) + (1 << 16);
   int rc = vwgpu_arena_reserve(ctx, &ctx->sgm, fixed);
   if (rc) return rc;
   Bump A{static_cast<char*>(ctx->sgm.base), ctx->sgm.cap};
@@ -2938,7 +3180,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
   B4* bounds = A.take<B4>(npix);
   unsigned long long* starts = A.take<unsigned long long>(npix);
   uint8_t* full_search = A.take<uint8_t>(npix);
-  unsigned long long* rowsum = A.take<unsigned long long>(g.orows);
+  unsigned long long* rowsum = A.take<unsigned long long>((size_t)3 * g.orows);      // sums, then the rows' counts of small boxes and their cells
   unsigned long long* rowoff = A.take<unsigned long long>(g.orows);
   int2* rowext = A.take<int2>(g.orows);
   unsigned* mm = A.take<unsigned>(8);
@@ -2973,8 +3215,8 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     hipLaunchKernelGGL(bounds_kernel, dim3((g.ocols + 255) / 256, g.orows), dim3(256), 0, st, g, lmask, rmask, ext, rowext, prev, pw, ph, bounds, full_search);
   }
   // memory-cap loop over the conservation levels (SGM.cc:468-491) + ragged starts
-  std::vector<unsigned long long> h_rows(g.orows);
-  unsigned long long main_buf = 0, n_total = 0;
+  std::vector<unsigned long long> h_rows((size_t)3 * g.orows);
+  unsigned long long main_buf = 0, n_total = 0, small16 = 0, small32 = 0, cells16 = 0;
   bool ok = false;
   const int threads = P->num_threads > 0 ? P->num_threads : 1;
   for (int level = 0; level <= 3; ++level) {
@@ -2984,10 +3226,14 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       hipLaunchKernelGGL(constrain_kernel, dim3((g.ocols + 255) / 256, g.orows), dim3(256), 0, st, g, full_search, bounds, range, level);
     }
     hipLaunchKernelGGL(row_count_kernel, dim3(g.orows), dim3(256), 0, st, bounds, g.ocols, rowsum);
-    VWGPU_HIP(ctx, hipMemcpyAsync(h_rows.data(), rowsum, (size_t)g.orows * 8, hipMemcpyDeviceToHost, st));
+    VWGPU_HIP(ctx, hipMemcpyAsync(h_rows.data(), rowsum, (size_t)g.orows * 24, hipMemcpyDeviceToHost, st));
     VWGPU_HIP(ctx, hipStreamSynchronize(st));
     unsigned long long n = 0;
-    for (int r = 0; r < g.orows; ++r) { const unsigned long long v = h_rows[r]; h_rows[r] = n; n += v; }
+    small16 = small32 = cells16 = 0;
+    for (int r = 0; r < g.orows; ++r) {
+      const unsigned long long v = h_rows[r], sm_ = h_rows[(size_t)g.orows + r];
+      h_rows[r] = n; n += v; small16 += sm_ & 0xffffffffull; small32 += sm_ >> 32; cells16 += h_rows[(size_t)2 * g.orows + r];
+    }
     n_total = n;
     if (n < 6) n = 6;
     main_buf = n;
@@ -3342,6 +3588,21 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
       } else {
 #define VWGPU_PATH_IP(RR) hipLaunchKernelGGL(path_inplace_kernel<RR>, dim3(lines), dim3(64), ((size_t)num_disp + 2 + 256) * sizeof(uint16_t), st, g, D, l8, lw, \
                                              min_col, min_row, bounds, starts, cost, accum, (unsigned)p1, (unsigned)p2)
+        // Several lines per wavefront (path_multi_kernel) on the large levels whose boxes nearly all fit a quarter or a half of one.  Four
+        // lines when the large boxes hold little of the volume as well (a line inside a patch of them occupies the whole wavefront);
+        // small levels keep one line per wavefront — they are short of wavefronts as it is.  SGM_PATH_MODE: bit 6 off, bit 4 / bit 7 force
+        // four / two lines.
+        constexpr int spread = 64;
+#define VWGPU_PATH_MULTI(SUBL) hipLaunchKernelGGL(path_multi_kernel<SUBL>, dim3((unsigned)(((size_t)lines + (size_t)(64 / SUBL) * spread - 1) / ((size_t)(64 / SUBL) * spread) * spread)), dim3(64), \
+                                                  ((size_t)(64 / SUBL + 1) * ((num_disp + 1) & ~1) + 256) * sizeof(uint16_t), st, \
+                                                  g, D, lines, spread, l8, lw, min_col, min_row, bounds, starts, cost, accum, (unsigned)p1, (unsigned)p2)
+        const int pm = ctx->sgm_path_mode;
+        const bool multi_ok = num_disp < 65535 && !(pm & 64);
+        const bool large = lines >= 8192;
+        if (multi_ok && ((pm & 16) || (!(pm & 128) && large && small16 * 5 >= npix * 4 && (n_total - cells16) * 100 <= n_total * 15))) VWGPU_PATH_MULTI(16);
+        else if (multi_ok && ((pm & 128) || (large && small32 * 5 >= npix * 4))) VWGPU_PATH_MULTI(32);
+        else
+#undef VWGPU_PATH_MULTI
         if (num_disp <= 64) VWGPU_PATH_IP(1);
         else if (num_disp <= 128) VWGPU_PATH_IP(2);
         else if (num_disp <= 256) VWGPU_PATH_IP(4);
