@@ -3597,7 +3597,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
                                                   ((size_t)(64 / SUBL + 1) * ((num_disp + 1) & ~1) + 256) * sizeof(uint16_t), st, \
                                                   g, D, lines, spread, l8, lw, min_col, min_row, bounds, starts, cost, accum, (unsigned)p1, (unsigned)p2)
         const int pm = ctx->sgm_path_mode;
-        const bool multi_ok = num_disp < 65535 && !(pm & 64);
+        const bool multi_ok = num_disp <= 4096 && !(pm & 64);           // (five full-range vectors of u16 in LDS; the cell index shares a register with the value)
         const bool large = lines >= 8192;
         if (multi_ok && ((pm & 16) || (!(pm & 128) && large && small16 * 5 >= npix * 4 && (n_total - cells16) * 100 <= n_total * 15))) VWGPU_PATH_MULTI(16);
         else if (multi_ok && ((pm & 128) || (large && small32 * 5 >= npix * 4))) VWGPU_PATH_MULTI(32);
