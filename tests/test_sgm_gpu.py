@@ -463,6 +463,28 @@ def test_several_lines_per_wavefront_on_ragged_boxes(vw, oracle, mode, p1, p2, s
     assert np.abs(gs - os_).max() < 1e-5
 
 
+@pytest.mark.parametrize("bad,patch", [(0.001, False), (0.01, True), (0.3, False)])
+def test_ragged_level_large_enough_for_the_chosen_form(vw, oracle, bad, patch):
+    """A level of 8 192 scan lines and more, default options: the library picks four, two or one scan line per wavefront from the level's
+    own boxes (clean coarser disparities: four; patches of untrusted pixels: two; many untrusted pixels: one) — the same image each time."""
+    k, sx, sy, w, h = 5, 64, 2, 724, 704
+    rng = np.random.default_rng(int(bad * 1000) + patch)
+    shift = 30
+    base = rng.integers(0, 256, (h + sy + 8, w + sx + 8)).astype(np.float32)
+    left = np.ascontiguousarray(base[4:4 + h, 4 + shift:4 + shift + w])
+    right = np.ascontiguousarray(base[4:4 + h + sy, 4:4 + w + sx])
+    oh, ow = h - k + 1, w - k + 1
+    prev = np.zeros(((oh + 1) // 2, (ow + 1) // 2, 3), np.int32)
+    prev[..., 0] = shift // 2 + rng.integers(0, 2, prev.shape[:2]); prev[..., 1] = rng.integers(0, 2, prev.shape[:2])
+    prev[..., 2] = np.where(rng.random(prev.shape[:2]) < bad, 0, np.iinfo(np.int32).max)
+    if patch:
+        prev[40:90, 100:140, 2] = 0; prev[200:215, 10:300, 2] = 0
+    gi, gs = vw.calc_disparity_sgm(CENSUS, left, right, _box(w, h), (sx, sy), (k, k), subpixel_mode=5, with_subpixel=True, prev_disparity=prev)
+    oi, os_ = oracle.calc_disparity_sgm(CENSUS, left, right, (sx, sy), k, subpixel=5, prev_disparity=prev)
+    assert np.array_equal(gi, oi), int((gi != oi).any(-1).sum())
+    assert np.abs(gs - os_).max() < 1e-5
+
+
 @pytest.mark.parametrize("sx,sy,k,w,h", [(4, 0, 7, 40, 30), (8, 0, 7, 60, 48), (3, 1, 5, 20, 16), (16, 0, 7, 100, 80)])
 def test_uniform_path_detected_from_the_boxes(vw, oracle, sx, sy, k, w, h):
     """All-valid masks (the top level of every pyramid): the boxes come out full everywhere and the uniform kernel runs;
