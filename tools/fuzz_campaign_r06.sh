@@ -5,7 +5,7 @@ SEED=${SEED:-6161}
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 L=gpurun_out/fuzz_campaign_r06.txt; : > $L
 echo "# SEED=$SEED bash tools/fuzz_campaign_r06.sh" >> $L
-run() { t0=$(date +%s); echo "\$ $*" >> $L; timeout 900 "$@" 2>&1 | grep -E "cases|mismatch|MISMATCH|ERROR|Traceback" | tail -5 >> $L; echo "  ($(( $(date +%s) - t0 )) s)" >> $L; }
+run() { t0=$(date +%s); echo "\$ ${SGM_PATH_MODE:+SGM_PATH_MODE=$SGM_PATH_MODE }$*" >> $L; timeout 900 "$@" 2>&1 | grep -E "cases|mismatch|MISMATCH|ERROR|Traceback" | tail -5 >> $L; echo "  ($(( $(date +%s) - t0 )) s)" >> $L; }
 run python tools/fuzz_pyramid_vs_oracle.py 5000 $SEED 0.6 0,1,2
 run python tools/fuzz_pyramid_vs_oracle.py 3000 $SEED corner
 run python tools/fuzz_borders.py 400 $SEED
@@ -19,4 +19,9 @@ run python tools/fuzz_sgm_vs_oracle.py 4000 $SEED mgm
 run python tools/fuzz_pyramid_sgm_vs_oracle.py 1500 $SEED 1
 run python tools/fuzz_pyramid_sgm_vs_oracle.py 1000 $SEED 2
 run python tools/fuzz_pyramid_sgm_vs_oracle.py 1000 $SEED 3
+# ragged boxes with four / two scan lines per wavefront forced (the levels of these small scenes would take one)
+SGM_PATH_MODE=16 run python tools/fuzz_sgm_vs_oracle.py 3000 $SEED
+SGM_PATH_MODE=128 run python tools/fuzz_sgm_vs_oracle.py 3000 $SEED
+SGM_PATH_MODE=16 run python tools/fuzz_pyramid_sgm_vs_oracle.py 800 $SEED 1
+SGM_PATH_MODE=128 run python tools/fuzz_pyramid_sgm_vs_oracle.py 800 $SEED 1
 cat $L
