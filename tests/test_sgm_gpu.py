@@ -465,7 +465,7 @@ def test_several_lines_per_wavefront_on_ragged_boxes(vw, oracle, mode, p1, p2, s
 
 @pytest.mark.parametrize("bad,patch", [(0.001, False), (0.01, True), (0.3, False)])
 def test_ragged_level_large_enough_for_the_chosen_form(vw, oracle, bad, patch):
-    """A level of 8 192 scan lines and more, default options: the library picks four, two or one scan line per wavefront from the level's
+    """A level of 6 000 scan lines and more, default options: the library picks four, two or one scan line per wavefront from the level's
     own boxes (clean coarser disparities: four; patches of untrusted pixels: two; many untrusted pixels: one) — the same image each time."""
     k, sx, sy, w, h = 5, 64, 2, 724, 704
     rng = np.random.default_rng(int(bad * 1000) + patch)

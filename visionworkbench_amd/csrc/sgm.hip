@@ -3590,7 +3590,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
                                              min_col, min_row, bounds, starts, cost, accum, (unsigned)p1, (unsigned)p2)
         // Several lines per wavefront (path_multi_kernel) on the large levels whose boxes nearly all fit a quarter or a half of one.  Four
         // lines when the large boxes hold little of the volume as well (a line inside a patch of them occupies the whole wavefront);
-        // small levels keep one line per wavefront — they are short of wavefronts as it is.  SGM_PATH_MODE: bit 6 off, bit 4 / bit 7 force
+        // levels of fewer than 6 000 lines keep one line per wavefront.  SGM_PATH_MODE: bit 6 off, bit 4 / bit 7 force
         // four / two lines.
         constexpr int spread = 64;
 #define VWGPU_PATH_MULTI(SUBL) hipLaunchKernelGGL(path_multi_kernel<SUBL>, dim3((unsigned)(((size_t)lines + (size_t)(64 / SUBL) * spread - 1) / ((size_t)(64 / SUBL) * spread) * spread)), dim3(64), \
@@ -3598,7 +3598,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
                                                   g, D, lines, spread, l8, lw, min_col, min_row, bounds, starts, cost, accum, (unsigned)p1, (unsigned)p2)
         const int pm = ctx->sgm_path_mode;
         const bool multi_ok = num_disp <= 4096 && !(pm & 64);           // (five full-range vectors of u16 in LDS; the cell index shares a register with the value)
-        const bool large = lines >= 8192;
+        const bool large = lines >= 6000;                               // (a 512^2 level; below, the launch is short of wavefronts either way: no gain measured)
         if (multi_ok && ((pm & 16) || (!(pm & 128) && large && small16 * 5 >= npix * 4 && (n_total - cells16) * 100 <= n_total * 15))) VWGPU_PATH_MULTI(16);
         else if (multi_ok && ((pm & 128) || (large && small32 * 5 >= npix * 4))) VWGPU_PATH_MULTI(32);
         else
