@@ -188,16 +188,18 @@ __global__ void bounds_kernel(SgmGeom g, const uint8_t* lmask, const uint8_t* rm
   full_search[idx] = fs;
 }
 
-// A wave owns 64 consecutive pixels of a row and visits its full-search pixels one after the other, all lanes scanning that pixel's
-// (2 range + 1)^2 neighbourhood together (one lane per pixel walked the window alone: 441 or 2601 dependent 17-byte loads with
-// a few lanes of the wave active).
+// A wave owns CONSTRAIN_CPW consecutive pixels of a row and visits its full-search pixels one after the other, all lanes scanning that
+// pixel's (2 range + 1)^2 neighbourhood together (one lane per pixel walked the window alone: 441 or 2601 dependent 17-byte loads with
+// a few lanes of the wave active).  ONE pixel per wave (round 6; 64 before): full-search pixels come in patches, a wave inside one
+// visited 64 of them in a row — 450 dependent window trips — while most waves had none: 0.15-0.19 ms per 1024^2 level; with 8 / 2 / 1
+// pixels per wave the ten launches of a pyramid tile take 0.69 / 0.53 / 0.46 ms (0.89 before) — a wave without such a pixel is one load.
+constexpr int CONSTRAIN_CPW = 1;
 __global__ void __launch_bounds__(256)
 constrain_kernel(SgmGeom g, const uint8_t* __restrict__ full_search, B4* __restrict__ bounds, int range, int conserve) {
   const int lane = threadIdx.x & 63;
-  const int c_mine = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-  const bool mine = c_mine < g.ocols && full_search[(size_t)r * g.ocols + c_mine] != 0;
+  const int c_base = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * CONSTRAIN_CPW, c_mine = c_base + lane, r = blockIdx.y;
+  const bool mine = lane < CONSTRAIN_CPW && c_mine < g.ocols && full_search[(size_t)r * g.ocols + c_mine] != 0;
   unsigned long long todo = __ballot(mine);
-  const int c_base = c_mine - lane;
   const int r0 = max(r - range, 0), r1 = min(r + range, g.orows - 1);
   while (todo) {                                       // wave-uniform
     const int j = __ffsll((long long)todo) - 1;
@@ -212,8 +214,9 @@ constrain_kernel(SgmGeom g, const uint8_t* __restrict__ full_search, B4* __restr
       int rem = i - q * ww;
       if (rem < 0) { rem += ww; --q; } else if (rem >= ww) { rem -= ww; ++q; }
       const size_t idx = (size_t)(r0 + q) * g.ocols + (c0 + rem);
-      if (full_search[idx]) continue;
+      const uint8_t fs = full_search[idx];                // (both requested before either is looked at)
       const B4 v = bounds[idx];
+      if (fs) continue;
       if (v.x0 == 0 && v.y0 == 0 && v.x1 == -1 && v.y1 == -1) continue;
       x0 = min(x0, min(v.x0, v.x1)); x1 = max(x1, max(v.x0, v.x1));       // grow(min corner); grow(max corner)
       y0 = min(y0, min(v.y0, v.y1)); y1 = max(y1, max(v.y0, v.y1));
@@ -3223,7 +3226,7 @@ int vwgpu_sgm_impl(vwgpu_ctx* ctx, const vwgpu_sgm_params* P, const float* left,
     if (prev) {
       const int range = level == 0 ? 10 : level == 1 ? 25 : level == 2 ? 3 : 0;
       vwgpu_prof_scope ps(ctx, "sgm_constrain");
-      hipLaunchKernelGGL(constrain_kernel, dim3((g.ocols + 255) / 256, g.orows), dim3(256), 0, st, g, full_search, bounds, range, level);
+      hipLaunchKernelGGL(constrain_kernel, dim3((g.ocols + 4 * CONSTRAIN_CPW - 1) / (4 * CONSTRAIN_CPW), g.orows), dim3(256), 0, st, g, full_search, bounds, range, level);
     }
     hipLaunchKernelGGL(row_count_kernel, dim3(g.orows), dim3(256), 0, st, bounds, g.ocols, rowsum);
     VWGPU_HIP(ctx, hipMemcpyAsync(h_rows.data(), rowsum, (size_t)g.orows * 24, hipMemcpyDeviceToHost, st));
