@@ -172,16 +172,23 @@ def threaded_tiles(fn, jobs, threads, budget_s):
         while True:
             with lock:
                 i = state["next"]
-                if i >= len(jobs) or (i >= threads and time.perf_counter() - t0 > budget_s):
+                if i >= len(jobs) or "error" in state or (i >= threads and time.perf_counter() - t0 > budget_s):
                     return
                 state["next"] = i + 1
-            fn(jobs[i])
+            try:
+                fn(jobs[i])
+            except BaseException as e:                             # a worker's exception must not vanish with its thread
+                with lock:
+                    state.setdefault("error", e)
+                return
             with lock:
                 state["done"] += 1
 
     th = [threading.Thread(target=work) for _ in range(threads)]
     [x.start() for x in th]
     [x.join() for x in th]
+    if "error" in state:
+        raise state["error"]
     return state["done"], time.perf_counter() - t0
 
 
@@ -676,6 +683,7 @@ def check_config5_tiles(synth, keep, bm_xy, sgm_xy, modes, W, H, D, TILE, LEVELS
 
     threaded_tiles(fn, work, max(1, min(os.cpu_count() or 1, len(work))), 1e9)
     out["tiles"].sort()
+    assert out["bm_checked"] == len(bm_xy) and out["sgm_checked"] == len(sgm_xy), out      # every sampled tile was compared
     return out
 
 

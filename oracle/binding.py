@@ -1,5 +1,6 @@
 """ctypes binding of oracle/libvw_oracle.so (see vw_oracle.h). TEST INFRASTRUCTURE ONLY."""
 import ctypes
+import threading
 import os
 import subprocess
 
@@ -7,6 +8,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIB_LOCK = threading.Lock()
 
 ABSOLUTE_DIFFERENCE, SQUARED_DIFFERENCE, CROSS_CORRELATION = 0, 1, 2
 VALID = np.iinfo(np.int32).max
@@ -34,60 +36,71 @@ def build(force=False):
 
 
 def lib():
+    """The oracle's shared library with its prototypes.  Thread safe: callers run the oracle on pools of host threads (bench.py's checkers and
+    CPU baselines), and a second thread must not see the handle before every prototype is declared (an undeclared double argument raises
+    ctypes.ArgumentError — which a worker thread dies of silently)."""
     global _LIB
-    if _LIB is None:
-        _LIB = ctypes.CDLL(build())
-        P, I, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
-        _LIB.vwo_fast_box_sum_f32.argtypes = [P, I, I, I, I, P]
-        _LIB.vwo_fast_box_sum_f64.argtypes = [P, I, I, I, I, P]
-        _LIB.vwo_cost_image.argtypes = [I, P, P, I, I, P]
-        _LIB.vwo_calc_disparity.argtypes = [I, P, I, I, L, P, I, I, L, I, I, I, I, P]
-        _LIB.vwo_calc_disparity_tiled.argtypes = [I, P, I, I, P, I, I, I, I, I, I, P, I, I, I, P]
-        _LIB.vwo_cross_corr_consistency_check.argtypes = [P, I, I, P, I, I, ctypes.c_float]
-        D, F = ctypes.c_double, ctypes.c_float
-        _LIB.vwo_generate_gaussian_kernel_f32.argtypes = [D, I, P, I]
-        _LIB.vwo_generate_gaussian_kernel_f64.argtypes = [D, I, P, I]
-        _LIB.vwo_separable_convolution_f32.argtypes = [P, I, I, P, I, I, P, I, I, I, I, P]
-        _LIB.vwo_separable_convolution_f64.argtypes = [P, I, I, P, I, I, P, I, I, I, I, P]
-        _LIB.vwo_convolution_2d_f32.argtypes = [P, I, I, P, I, I, I, I, I, P]
-        _LIB.vwo_convolution_2d_f64.argtypes = [P, I, I, P, I, I, I, I, I, P]
-        _LIB.vwo_subsample_mask_by_two.argtypes = [P, I, I, P]
-        _LIB.vwo_prefilter_image.argtypes = [P, I, I, I, F, P]
-        _LIB.vwo_subdivide_regions.argtypes = [P, I, I, I, I, P, I]
-        _LIB.vwo_prefilter_region.argtypes = [P, I, I, I, F, I, I, I, I, P]
-        _LIB.vwo_parabola_subpixel.argtypes = [P, I, I, P, P, I, I, I, F, I, I, P]
-        _LIB.vwo_pyramid_correlate.argtypes = [P, I, I, P, I, I, P, P, I, F, I, I, I, I, I, I, I, I, D, F, I, I, I, I, I, I, P]
-        _LIB.vwo_disparity_filter.argtypes = [P, I, I, I, I, D, D, I]
-        _LIB.vwo_disparity_mask.argtypes = [P, I, I, P, P, I, I]
-        Z = ctypes.c_size_t
-        _LIB.vwo_blob_sizes.argtypes = [P, I, I, P]
-        _LIB.vwo_disparity_blob_filter.argtypes = [P, I, I, I]
-        _LIB.vwo_set_blob_filter_area.argtypes = [I]
-        _LIB.vwo_set_blob_filter_area.restype = None
-        _LIB.vwo_set_sgm_algorithm.argtypes = [I]
-        _LIB.vwo_set_sgm_algorithm.restype = None
-        _LIB.vwo_cross_corr_consistency_check_diff.argtypes = [P, I, I, P, I, I, F, P, I, I, I, I]
-        _LIB.vwo_set_lr_disp_diff.argtypes = [P, I, I, I, I]
-        _LIB.vwo_set_lr_disp_diff.restype = None
-        _LIB.vwo_u8_convert.argtypes = [P, I, I, P]
-        _LIB.vwo_census_transform.argtypes = [P, I, I, I, I, I, P]
-        _LIB.vwo_hamming_distance.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
-        _LIB.vwo_sgm_create.argtypes = [I, I, I, I, I, I, I, I, I, I, Z, I, I, I, I]
-        _LIB.vwo_sgm_create.restype = P
-        _LIB.vwo_sgm_destroy.argtypes = [P]
-        _LIB.vwo_sgm_destroy.restype = None
-        _LIB.vwo_sgm_run.argtypes = [P, P, I, I, P, I, I, P, I, I, P, I, I, P, I, I, P, I]
-        _LIB.vwo_sgm_output_size.argtypes = [P, P, P]
-        _LIB.vwo_sgm_subpixel.argtypes = [P, P, P]
-        _LIB.vwo_sgm_buffer_size.argtypes = [P]
-        _LIB.vwo_sgm_buffer_size.restype = Z
-        _LIB.vwo_sgm_read.argtypes = [P, P, P, P, P]
-        _LIB.vwo_sgm_p1p2.argtypes = [P, P, P]
-        _LIB.vwo_pyramid_correlate_sgm.argtypes = [P, I, I, P, I, I, P, P, I, I, I, I, I, I, F, I, I, I, I, I, I, Z, I, I, I, I, I, P]
-        _LIB.vwo_calc_disparity_sgm.argtypes = [I, P, I, I, P, I, I, I, I, I, I, I, I, Z, I, P, I, I, P, I, I, P, I, I, P, P, P, P]
-        _LIB.vwo_calc_disparity_sgm_p.argtypes = [I, P, I, I, P, I, I, I, I, I, I, I, I, Z, I, P, I, I, P, I, I, P, I, I, I, I, P, P, P, P]
-        _LIB.vwo_calc_disparity_sgm_x.argtypes = [I, I, P, I, I, P, I, I, I, I, I, I, I, I, Z, I, P, I, I, P, I, I, P, I, I, I, I, P, P, P, P]
+    if _LIB is not None:
+        return _LIB
+    with _LIB_LOCK:
+        if _LIB is None:
+            _LIB = _load()
     return _LIB
+
+
+def _load():
+    so = ctypes.CDLL(build())
+    P, I, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    so.vwo_fast_box_sum_f32.argtypes = [P, I, I, I, I, P]
+    so.vwo_fast_box_sum_f64.argtypes = [P, I, I, I, I, P]
+    so.vwo_cost_image.argtypes = [I, P, P, I, I, P]
+    so.vwo_calc_disparity.argtypes = [I, P, I, I, L, P, I, I, L, I, I, I, I, P]
+    so.vwo_calc_disparity_tiled.argtypes = [I, P, I, I, P, I, I, I, I, I, I, P, I, I, I, P]
+    so.vwo_cross_corr_consistency_check.argtypes = [P, I, I, P, I, I, ctypes.c_float]
+    D, F = ctypes.c_double, ctypes.c_float
+    so.vwo_generate_gaussian_kernel_f32.argtypes = [D, I, P, I]
+    so.vwo_generate_gaussian_kernel_f64.argtypes = [D, I, P, I]
+    so.vwo_separable_convolution_f32.argtypes = [P, I, I, P, I, I, P, I, I, I, I, P]
+    so.vwo_separable_convolution_f64.argtypes = [P, I, I, P, I, I, P, I, I, I, I, P]
+    so.vwo_convolution_2d_f32.argtypes = [P, I, I, P, I, I, I, I, I, P]
+    so.vwo_convolution_2d_f64.argtypes = [P, I, I, P, I, I, I, I, I, P]
+    so.vwo_subsample_mask_by_two.argtypes = [P, I, I, P]
+    so.vwo_prefilter_image.argtypes = [P, I, I, I, F, P]
+    so.vwo_subdivide_regions.argtypes = [P, I, I, I, I, P, I]
+    so.vwo_prefilter_region.argtypes = [P, I, I, I, F, I, I, I, I, P]
+    so.vwo_parabola_subpixel.argtypes = [P, I, I, P, P, I, I, I, F, I, I, P]
+    so.vwo_pyramid_correlate.argtypes = [P, I, I, P, I, I, P, P, I, F, I, I, I, I, I, I, I, I, D, F, I, I, I, I, I, I, P]
+    so.vwo_disparity_filter.argtypes = [P, I, I, I, I, D, D, I]
+    so.vwo_disparity_mask.argtypes = [P, I, I, P, P, I, I]
+    Z = ctypes.c_size_t
+    so.vwo_blob_sizes.argtypes = [P, I, I, P]
+    so.vwo_disparity_blob_filter.argtypes = [P, I, I, I]
+    so.vwo_set_blob_filter_area.argtypes = [I]
+    so.vwo_set_blob_filter_area.restype = None
+    so.vwo_set_sgm_algorithm.argtypes = [I]
+    so.vwo_set_sgm_algorithm.restype = None
+    so.vwo_cross_corr_consistency_check_diff.argtypes = [P, I, I, P, I, I, F, P, I, I, I, I]
+    so.vwo_set_lr_disp_diff.argtypes = [P, I, I, I, I]
+    so.vwo_set_lr_disp_diff.restype = None
+    so.vwo_u8_convert.argtypes = [P, I, I, P]
+    so.vwo_census_transform.argtypes = [P, I, I, I, I, I, P]
+    so.vwo_hamming_distance.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
+    so.vwo_sgm_create.argtypes = [I, I, I, I, I, I, I, I, I, I, Z, I, I, I, I]
+    so.vwo_sgm_create.restype = P
+    so.vwo_sgm_destroy.argtypes = [P]
+    so.vwo_sgm_destroy.restype = None
+    so.vwo_sgm_run.argtypes = [P, P, I, I, P, I, I, P, I, I, P, I, I, P, I, I, P, I]
+    so.vwo_sgm_output_size.argtypes = [P, P, P]
+    so.vwo_sgm_subpixel.argtypes = [P, P, P]
+    so.vwo_sgm_buffer_size.argtypes = [P]
+    so.vwo_sgm_buffer_size.restype = Z
+    so.vwo_sgm_read.argtypes = [P, P, P, P, P]
+    so.vwo_sgm_p1p2.argtypes = [P, P, P]
+    so.vwo_pyramid_correlate_sgm.argtypes = [P, I, I, P, I, I, P, P, I, I, I, I, I, I, F, I, I, I, I, I, I, Z, I, I, I, I, I, P]
+    so.vwo_calc_disparity_sgm.argtypes = [I, P, I, I, P, I, I, I, I, I, I, I, I, Z, I, P, I, I, P, I, I, P, I, I, P, P, P, P]
+    so.vwo_calc_disparity_sgm_p.argtypes = [I, P, I, I, P, I, I, I, I, I, I, I, I, Z, I, P, I, I, P, I, I, P, I, I, I, I, P, P, P, P]
+    so.vwo_calc_disparity_sgm_x.argtypes = [I, I, P, I, I, P, I, I, I, I, I, I, I, I, Z, I, P, I, I, P, I, I, P, I, I, I, I, P, P, P, P]
+    return so
 
 
 def _p(a):
